@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric ("million edges processed/sec + total match count") on MI355X.
+
+A "step" = one pass of the hot path (one mining kernel over every task edge of the graph, plus the
+RCCL all-reduce of the 64-bit count when --gpus > 1), inputs resident in HBM before the timed region.
+
+Default workload (N=1) = BASELINE.json configs[1]: triangle counting on LiveJournal. The real
+LiveJournal files are not in the image, so the default graph is the stand-in
+SURVEY.md section 8d names: R-MAT scale 22, edge factor 10, seed 42 (|V| = 4.19 M, ~LiveJournal's
+|E|); pass --graph <prefix> to run the real graph.meta.txt/vertex.bin/edge.bin instead.
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+         --master-port 29500 bench.py --gpus 8 --steps 20 --warmup 3
+
+Multi-GPU: one process per GPU; every rank holds the full CSR (it regenerates / reloads it, no
+broadcast needed), owns the task chunks c = rank (mod world) [Scheduler::round_robin policy,
+src/common/scheduler.cc:34-85] and the per-rank counts are summed by ONE all-reduce per step
+(torch.distributed backend "nccl" = RCCL over xGMI). Per-GPU work shrinks as N grows: scaling =
+"strong" (the graph, hence total work, is fixed).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (default scale, edge factor, oriented?, description)
+    "tc": (22, 10, True, "triangle counting, LiveJournal stand-in"),
+    "diamond": (22, 10, False, "sgl diamond, LiveJournal stand-in"),
+    "clique4": (22, 28, True, "4-clique, com-Orkut stand-in"),
+    "motif3": (24, 16, False, "3-motif, R-MAT scale 24"),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="tc", choices=sorted(WORKLOADS))
+    ap.add_argument("--scale", type=int, default=0)
+    ap.add_argument("--ef", type=int, default=0)
+    ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--graph", default="", help="prefix of graph.meta.txt/.vertex.bin/.edge.bin (real dataset)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the bounded oracle sample")
+    ap.add_argument("--tune", default="", help="comma separated gm_launch.tune[] override")
+    ap.add_argument("--policy", type=int, default=0, help="0 = chunked round robin, 1 = contiguous ranges")
+    return ap.parse_args()
+
+
+def alg_bytes(workload, rp, ci):
+    """SURVEY.md 8(d) ALGORITHMIC bytes of one launch over the whole graph (numpy, exact)."""
+    import numpy as np
+
+    deg = np.diff(rp).astype(np.int64)
+    sq = int((deg * deg).sum())          # sum_e d(src)
+    dv = int(deg[ci].sum())              # sum_e d(dst)
+    ne = int(ci.size)
+    if workload in ("tc",):
+        return 4 * (sq + dv) + 40 * ne
+    if workload == "diamond":            # edges v1 < v0 only: by symmetry exactly half of sum_e (d(v0)+d(v1))
+        return 4 * (sq + dv) // 2 + 40 * (ne // 2)
+    if workload == "motif3":             # one difference per directed edge + one intersect per v1 < v0 edge
+        return 4 * (sq + dv) + 4 * (sq + dv) // 2 + 40 * ne
+    return None                          # clique4 needs |S1| per edge: taken from the oracle in tests, not here
+
+
+def main():
+    a = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path to measure)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from graphminer_amd import Graph, _lib
+    from graphminer_amd._lib import gm_launch, gm_stats
+    from graphminer_amd.rmat import rmat_csr_device
+
+    lib = _lib.load()
+    scale0, ef0, oriented, desc = WORKLOADS[a.workload]
+    scale, ef = a.scale or scale0, a.ef or ef0
+
+    # ---- input: CSR resident in HBM -------------------------------------------------------------
+    t_in = time.perf_counter()
+    if a.graph:
+        sym = Graph(a.graph).to_device(local_rank)
+        gname = f"file:{a.graph}"
+    else:
+        sym, _rp, _ci = rmat_csr_device(scale, ef, a.seed, local_rank)
+        gname = f"rmat_s{scale}_ef{ef}_seed{a.seed}"
+    g = sym.orient() if oriented else sym
+    torch.cuda.synchronize()
+    t_in = time.perf_counter() - t_in
+
+    counts = torch.zeros(4, dtype=torch.int64, device=dev)
+    la = gm_launch()
+    la.stream = torch.cuda.current_stream().cuda_stream or None
+    la.rank, la.world, la.policy = rank, world, a.policy
+    la.d_counts = counts.data_ptr()
+    if a.tune:
+        for i, t in enumerate(a.tune.split(",")):
+            la.tune[i] = int(t)
+    st = gm_stats()
+
+    def step():
+        if a.workload == "tc":
+            rc = lib.gm_tc(g.handle, C.byref(la), None, C.byref(st))
+        elif a.workload == "diamond":
+            rc = lib.gm_sgl(g.handle, b"diamond", C.byref(la), None, C.byref(st))
+        elif a.workload == "clique4":
+            rc = lib.gm_clique(g.handle, 4, C.byref(la), None, C.byref(st))
+        else:
+            rc = lib.gm_motif(g.handle, 3, C.byref(la), None, 2, C.byref(st))
+        _lib.check(rc, "bench step")
+        if world > 1:
+            dist.all_reduce(counts)  # ONE RCCL all-reduce of the 64-bit counts
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    result = [int(x) for x in counts.cpu().tolist()]
+    kms = g.kernel_times_ms(min(a.steps, 64))
+    k_avg_ms = sum(kms) / max(len(kms), 1)
+
+    # "edges processed" = the reference's nnz (src/triangle/gpu_base.cu:69): |E+| (tc, clique),
+    # ne/2 (diamond), ne (motif)
+    tasks_total = g.E() // 2 if a.workload == "diamond" else g.E()
+    ms_per_step = 1e3 * elapsed / a.steps
+    value = tasks_total / (elapsed / a.steps) / 1e6
+
+    out = {
+        "metric": "million edges processed/sec + total match count",
+        "value": round(value, 3),
+        "unit": "Medges/s",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "int32 ids / int64 offsets / uint64 counts",
+        "data": "synthetic R-MAT (0.57,0.19,0.19,0.05), SplitMix64 counter stream" if not a.graph else "file",
+        "config": {"workload": f"{a.workload}: {desc}", "graph": gname, "nv": g.V(), "ne_sym": sym.E(), "tasks": tasks_total,
+                   "max_degree": g.get_max_degree(), "parallelism": f"task-chunk round-robin x{world}, replicated CSR",
+                   "input_build_s": round(t_in, 2)},
+        "count": result[:2] if a.workload == "motif3" else result[0],
+        "matches_per_sec": round((result[1] if a.workload == "motif3" else result[0]) / (elapsed / a.steps), 1),
+        "kernel_ms_avg": round(k_avg_ms, 4),
+    }
+
+    if rank == 0:
+        host = g.download()
+        ab = alg_bytes(a.workload, host.row_ptr, host.col_idx)
+        if ab is not None:
+            per_launch = ab / world  # each rank's kernel covers ~1/world of the chunks
+            ach = per_launch / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms > 0 else 0.0
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):  # PMC-measured HBM bytes per launch (rocprofv3 --pmc), keyed by graph+workload
+                traffic = json.load(open(tpath)).get(f"{a.workload}:{gname}:n{world}")
+            out["roofline"] = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                               "algorithmic_bytes_per_launch": int(per_launch), "kernel": f"mine_kernel<{a.workload}>"}
+        if world == 1 and not a.no_cpu_baseline and a.workload == "tc":
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle as O  # the CPU oracle, timed as the OpenMP baseline ("port"): never the product path
+
+            od = O.OGraph(host.row_ptr, host.col_idx)
+            cal = 256
+            t1 = time.perf_counter()
+            O.tc_sample(od, cal, 1)
+            tcal = time.perf_counter() - t1
+            stride = max(1, int(tcal * cal / max(a.cpu_seconds, 1e-3)))
+            t1 = time.perf_counter()
+            cnt, tasks = O.tc_sample(od, stride, 0)
+            tcpu = time.perf_counter() - t1
+            out["cpu_baseline"] = {"value": round(tasks / tcpu / 1e6, 3), "unit": "Medges/s", "cores": O.num_threads(),
+                                   "kind": "port", "seconds": round(tcpu, 2),
+                                   "sample": f"oracle gmo_tc_sample: vertices u = 0 mod {stride} of the same DAG "
+                                             f"({tasks} of {g.E()} task edges), OpenMP schedule(dynamic,1)",
+                                   "host_cpus": os.cpu_count()}
+            if stride == 1:
+                out["cpu_baseline"]["count_matches_gpu"] = bool(cnt == result[0])
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

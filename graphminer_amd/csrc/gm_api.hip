@@ -1,0 +1,673 @@
+// gm_api.hip -- the C ABI (include/graphminer_amd.h) over the HIP kernels.
+//
+// Host-side counterparts in the reference:
+//   GraphGPU::init / init_edgelist          include/graph_gpu.h:69-194
+//   launch sizing                            src/triangle/gpu_base.cu:36-45, src/clique/gpu_base.cu:28-50
+//   Scheduler::round_robin                   src/common/scheduler.cc:34-85
+//   Graph::orientation                       src/common/graph.cc:233-279
+// None of that code is reused: tasks are described by a compact chunk table (16 B per ~256 edges)
+// instead of per-GPU COO copies, and the multi-GPU split is index arithmetic on chunk ids.
+#include "../../include/graphminer_amd.h"
+#include "gm_mine.h"
+#include "gm_setops.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <list>
+#include <mutex>
+#include <string>
+#include <vector>
+
+using namespace gm;
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static int hip_fail(hipError_t e, const char *what, const char *file, int line) {
+  char buf[512];
+  snprintf(buf, sizeof buf, "%s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+  g_last_error = buf;
+  return (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver) ? GM_ERR_NO_DEVICE
+                                                                                                  : GM_ERR_HIP;
+}
+#define HIP_TRY(call)                                              \
+  do {                                                             \
+    hipError_t _e = (call);                                        \
+    if (_e != hipSuccess) return hip_fail(_e, #call, __FILE__, __LINE__); \
+  } while (0)
+
+extern "C" const char *gm_strerror(int s) {
+  switch (s) {
+    case GM_OK: return "ok";
+    case GM_ERR_INVALID: return "invalid argument";
+    case GM_ERR_NO_DEVICE: return "no HIP device (this library has no CPU fallback)";
+    case GM_ERR_HIP: return "HIP runtime error";
+    case GM_ERR_TOO_LARGE: return "graph exceeds the 32-bit task index of this build";
+    case GM_ERR_UNSUPPORTED: return "Not implemented";
+    case GM_ERR_IO: return "I/O error";
+    case GM_ERR_FORMAT: return "bad graph format";
+    default: return "unknown status";
+  }
+}
+extern "C" const char *gm_last_error(void) { return g_last_error.c_str(); }
+extern "C" int gm_version(void) { return 100; }
+
+extern "C" int gm_device_count(int *n) {
+  if (!n) return GM_ERR_INVALID;
+  *n = 0;
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) return hip_fail(e, "hipGetDeviceCount", __FILE__, __LINE__);
+  *n = c;
+  return c > 0 ? GM_OK : GM_ERR_NO_DEVICE;
+}
+
+// ------------------------------------------------------------------------------------------------
+// graph handle
+// ------------------------------------------------------------------------------------------------
+struct ChunkTable {
+  int target;       // T: CSR entries per chunk
+  bool allow_split; // rows longer than the staging capacity may be cut across chunks
+  int bit_words;    // clique: LDS bit-matrix budget the chunks were built for (0 = unconstrained)
+  ChunkRec *d = nullptr;
+  size_t n = 0;
+  unsigned long long max_bit_words = 0;  // largest nel*stride over chunks that exceed bit_words
+  std::vector<unsigned long long> edge_prefix;  // edges owned by chunks [0,i)
+};
+
+struct gm_graph {
+  int device = 0;
+  int nv = 0;
+  long long ne = 0;
+  int max_deg = 0;
+  int *d_rp = nullptr;   // int32 offsets, owned
+  int *d_col = nullptr;  // col_idx
+  bool own_col = true;
+  std::vector<int> h_rp;  // host copy of the offsets (chunk building, download)
+  std::list<ChunkTable> tables;  // list: handed-out pointers stay valid
+  unsigned long long *d_counters = nullptr;  // [4] + queue word, 64 B
+  unsigned *d_scratch = nullptr;
+  size_t scratch_bytes = 0;
+  static constexpr int kEvRing = 64;  // HIP-event pairs of the most recent launches
+  hipEvent_t ev[kEvRing][2] = {};
+  unsigned long long ev_launches = 0;
+  int cu_count = 256;
+  std::mutex mu;
+};
+
+static void free_tables(gm_graph *g) {
+  for (auto &t : g->tables)
+    if (t.d) (void)hipFree(t.d);
+  g->tables.clear();
+}
+
+extern "C" void gm_graph_free(gm_graph *g) {
+  if (!g) return;
+  (void)hipSetDevice(g->device);
+  free_tables(g);
+  if (g->d_rp) (void)hipFree(g->d_rp);
+  if (g->own_col && g->d_col) (void)hipFree(g->d_col);
+  if (g->d_counters) (void)hipFree(g->d_counters);
+  if (g->d_scratch) (void)hipFree(g->d_scratch);
+  for (auto &pr : g->ev)
+    for (auto &e : pr)
+      if (e) (void)hipEventDestroy(e);
+  delete g;
+}
+
+static int finish_handle(gm_graph *g) {
+  HIP_TRY(hipMalloc(&g->d_counters, 64));
+  HIP_TRY(hipMemset(g->d_counters, 0, 64));
+  for (auto &pr : g->ev)
+    for (auto &e : pr) HIP_TRY(hipEventCreate(&e));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, g->device));
+  g->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  int md = 0;
+  for (int v = 0; v < g->nv; ++v) md = std::max(md, g->h_rp[v + 1] - g->h_rp[v]);
+  g->max_deg = md;
+  return GM_OK;
+}
+
+static int check_sizes(long long nv, long long ne) {
+  if (nv < 0 || ne < 0) return GM_ERR_INVALID;
+  if (nv >= 0x7ffffffeLL || ne >= 0x7fffffffLL) return GM_ERR_TOO_LARGE;
+  return GM_OK;
+}
+
+static int convert_offsets(const int64_t *rp64, int nv, long long ne, std::vector<int> &out) {
+  out.resize((size_t)nv + 1);
+  if (rp64[0] != 0 || rp64[nv] != ne) return GM_ERR_FORMAT;
+  for (int v = 0; v <= nv; ++v) {
+    if (v > 0 && rp64[v] < rp64[v - 1]) return GM_ERR_FORMAT;
+    if (v > 0 && rp64[v] - rp64[v - 1] >= (1 << 24)) return GM_ERR_TOO_LARGE;  // per-row limit of the flattened scan
+    out[v] = (int)rp64[v];
+  }
+  return GM_OK;
+}
+
+extern "C" int gm_graph_upload(const gm_csr *h, int device, gm_graph **out) {
+  if (!h || !out || !h->row_ptr || (h->ne > 0 && !h->col_idx)) return GM_ERR_INVALID;
+  *out = nullptr;
+  int rc = check_sizes(h->nv, h->ne);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(device));
+  gm_graph *g = new gm_graph();
+  g->device = device;
+  g->nv = h->nv;
+  g->ne = h->ne;
+  rc = convert_offsets(h->row_ptr, h->nv, h->ne, g->h_rp);
+  if (rc) { delete g; return rc; }
+  auto fail = [&](int code) { gm_graph_free(g); return code; };
+  hipError_t e;
+  if ((e = hipMalloc(&g->d_rp, sizeof(int) * ((size_t)g->nv + 1))) != hipSuccess) return fail(hip_fail(e, "hipMalloc(rp)", __FILE__, __LINE__));
+  if ((e = hipMalloc(&g->d_col, sizeof(int) * (size_t)std::max<long long>(g->ne, 1))) != hipSuccess) return fail(hip_fail(e, "hipMalloc(col)", __FILE__, __LINE__));
+  if ((e = hipMemcpy(g->d_rp, g->h_rp.data(), sizeof(int) * ((size_t)g->nv + 1), hipMemcpyHostToDevice)) != hipSuccess) return fail(hip_fail(e, "hipMemcpy(rp)", __FILE__, __LINE__));
+  if (g->ne > 0 && (e = hipMemcpy(g->d_col, h->col_idx, sizeof(int) * (size_t)g->ne, hipMemcpyHostToDevice)) != hipSuccess) return fail(hip_fail(e, "hipMemcpy(col)", __FILE__, __LINE__));
+  rc = finish_handle(g);
+  if (rc) return fail(rc);
+  *out = g;
+  return GM_OK;
+}
+
+extern "C" int gm_graph_from_device(int32_t nv, int64_t ne, const int64_t *d_row_ptr, const int32_t *d_col_idx, int device,
+                                    gm_graph **out) {
+  if (!out || !d_row_ptr || (ne > 0 && !d_col_idx)) return GM_ERR_INVALID;
+  *out = nullptr;
+  int rc = check_sizes(nv, ne);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(device));
+  std::vector<int64_t> rp64((size_t)nv + 1);
+  HIP_TRY(hipMemcpy(rp64.data(), d_row_ptr, sizeof(int64_t) * ((size_t)nv + 1), hipMemcpyDeviceToHost));
+  gm_graph *g = new gm_graph();
+  g->device = device;
+  g->nv = nv;
+  g->ne = ne;
+  g->own_col = false;
+  g->d_col = const_cast<int *>(d_col_idx);
+  rc = convert_offsets(rp64.data(), nv, ne, g->h_rp);
+  if (rc) { delete g; return rc; }
+  auto fail = [&](int code) { gm_graph_free(g); return code; };
+  hipError_t e;
+  if ((e = hipMalloc(&g->d_rp, sizeof(int) * ((size_t)nv + 1))) != hipSuccess) return fail(hip_fail(e, "hipMalloc(rp)", __FILE__, __LINE__));
+  if ((e = hipMemcpy(g->d_rp, g->h_rp.data(), sizeof(int) * ((size_t)nv + 1), hipMemcpyHostToDevice)) != hipSuccess) return fail(hip_fail(e, "hipMemcpy(rp)", __FILE__, __LINE__));
+  rc = finish_handle(g);
+  if (rc) return fail(rc);
+  *out = g;
+  return GM_OK;
+}
+
+extern "C" int gm_graph_meta(const gm_graph *g, gm_csr *m) {
+  if (!g || !m) return GM_ERR_INVALID;
+  m->nv = g->nv;
+  m->ne = g->ne;
+  m->max_deg = g->max_deg;
+  m->row_ptr = nullptr;
+  m->col_idx = nullptr;
+  return GM_OK;
+}
+
+extern "C" int gm_graph_download(const gm_graph *g, int64_t *row_ptr, int32_t *col_idx) {
+  if (!g) return GM_ERR_INVALID;
+  if (row_ptr)
+    for (int v = 0; v <= g->nv; ++v) row_ptr[v] = g->h_rp[v];
+  if (col_idx && g->ne > 0) {
+    HIP_TRY(hipSetDevice(g->device));
+    HIP_TRY(hipMemcpy(col_idx, g->d_col, sizeof(int) * (size_t)g->ne, hipMemcpyDeviceToHost));
+  }
+  return GM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// orientation on the GPU (Graph::orientation, src/common/graph.cc:233-279)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool dag_keep(int ds, int s, int dd, int d) { return dd > ds || (dd == ds && d > s); }
+
+// one wave per row: count (pass 0) or compact (pass 1) the kept neighbours, order preserved
+__global__ __launch_bounds__(256) void orient_kernel(int nv, const int *__restrict__ rp, const int *__restrict__ col,
+                                                     int *__restrict__ new_deg, const int *__restrict__ new_rp,
+                                                     int *__restrict__ new_col, int pass) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (int s = wave; s < nv; s += nwaves) {
+    const int b = rp[s], ds = rp[s + 1] - b;
+    int n = 0;
+    const int ob = pass ? new_rp[s] : 0;
+    for (int base = 0; base < ds; base += 64) {
+      const int i = base + lane;
+      bool keep = false;
+      int d = 0;
+      if (i < ds) {
+        d = col[b + i];
+        keep = dag_keep(ds, s, rp[d + 1] - rp[d], d);
+      }
+      const unsigned long long m = __ballot(keep);
+      if (pass && keep) new_col[ob + n + rank_below(m)] = d;
+      n += __popcll(m);
+    }
+    if (!pass && lane == 0) new_deg[s] = n;
+  }
+}
+
+extern "C" int gm_graph_orient(const gm_graph *sym, gm_graph **out) {
+  if (!sym || !out) return GM_ERR_INVALID;
+  *out = nullptr;
+  HIP_TRY(hipSetDevice(sym->device));
+  const int nv = sym->nv;
+  int *d_deg = nullptr;
+  HIP_TRY(hipMalloc(&d_deg, sizeof(int) * (size_t)std::max(nv, 1)));
+  const int blocks = std::max(1, std::min((nv + 3) / 4, sym->cu_count * 8));
+  hipLaunchKernelGGL(orient_kernel, dim3(blocks), dim3(256), 0, 0, nv, sym->d_rp, sym->d_col, d_deg, (const int *)nullptr,
+                     (int *)nullptr, 0);
+  std::vector<int> deg((size_t)std::max(nv, 1));
+  hipError_t e = hipMemcpy(deg.data(), d_deg, sizeof(int) * (size_t)nv, hipMemcpyDeviceToHost);
+  (void)hipFree(d_deg);
+  if (e != hipSuccess) return hip_fail(e, "hipMemcpy(deg)", __FILE__, __LINE__);
+  gm_graph *g = new gm_graph();
+  g->device = sym->device;
+  g->nv = nv;
+  g->h_rp.resize((size_t)nv + 1);
+  long long acc = 0;
+  for (int v = 0; v < nv; ++v) {  // parallel_prefix_sum, include/scan.h:5-35
+    g->h_rp[v] = (int)acc;
+    acc += deg[v];
+  }
+  g->h_rp[nv] = (int)acc;
+  g->ne = acc;
+  auto fail = [&](int code) { gm_graph_free(g); return code; };
+  if ((e = hipMalloc(&g->d_rp, sizeof(int) * ((size_t)nv + 1))) != hipSuccess) return fail(hip_fail(e, "hipMalloc", __FILE__, __LINE__));
+  if ((e = hipMalloc(&g->d_col, sizeof(int) * (size_t)std::max<long long>(acc, 1))) != hipSuccess) return fail(hip_fail(e, "hipMalloc", __FILE__, __LINE__));
+  if ((e = hipMemcpy(g->d_rp, g->h_rp.data(), sizeof(int) * ((size_t)nv + 1), hipMemcpyHostToDevice)) != hipSuccess) return fail(hip_fail(e, "hipMemcpy", __FILE__, __LINE__));
+  hipLaunchKernelGGL(orient_kernel, dim3(blocks), dim3(256), 0, 0, nv, sym->d_rp, sym->d_col, (int *)nullptr, g->d_rp, g->d_col, 1);
+  if ((e = hipDeviceSynchronize()) != hipSuccess) return fail(hip_fail(e, "orient_kernel", __FILE__, __LINE__));
+  int rc = finish_handle(g);
+  if (rc) return fail(rc);
+  *out = g;
+  return GM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// task chunk tables
+// ------------------------------------------------------------------------------------------------
+static void build_chunks(const std::vector<int> &rp, int nv, int target, bool allow_split, int bit_words,
+                         std::vector<ChunkRec> &out, unsigned long long &max_bit_words) {
+  out.clear();
+  max_bit_words = 0;
+  int u = 0;
+  auto deg = [&](int v) { return rp[v + 1] - rp[v]; };
+  while (u < nv) {
+    const int d = deg(u);
+    if (d == 0) { ++u; continue; }
+    if (d > kStageCap) {
+      if (allow_split) {
+        for (int s = rp[u]; s < rp[u + 1]; s += target) out.push_back({u, u + 1, s, std::min(s + target, rp[u + 1])});
+      } else {
+        out.push_back({u, u + 1, rp[u], rp[u + 1]});
+        if (bit_words) max_bit_words = std::max(max_bit_words, (unsigned long long)d * (unsigned long long)((d + 31) / 32));
+      }
+      ++u;
+      continue;
+    }
+    const int start = u;
+    int edges = 0, maxd = 0;
+    while (u < nv && (u - start) < kMaxChunkVerts) {
+      const int du = deg(u);
+      if (du > kStageCap) break;
+      if (edges > 0 && edges + du > kStageCap) break;
+      if (bit_words && edges > 0) {
+        const int nm = std::max(maxd, du);
+        if ((long long)(edges + du) * ((nm + 31) / 32) > bit_words) break;
+      }
+      edges += du;
+      maxd = std::max(maxd, du);
+      ++u;
+      if (edges >= target) break;
+    }
+    if (edges > 0) {
+      out.push_back({start, u, rp[start], rp[u]});
+      if (bit_words) {
+        const unsigned long long w = (unsigned long long)edges * (unsigned long long)((maxd + 31) / 32);
+        if (w > (unsigned long long)bit_words) max_bit_words = std::max(max_bit_words, w);
+      }
+    }
+  }
+}
+
+static int get_table(gm_graph *g, int target, bool allow_split, int bit_words, ChunkTable **out) {
+  std::lock_guard<std::mutex> lk(g->mu);
+  for (auto &t : g->tables)
+    if (t.target == target && t.allow_split == allow_split && t.bit_words == bit_words) { *out = &t; return GM_OK; }
+  std::vector<ChunkRec> recs;
+  ChunkTable t;
+  t.target = target;
+  t.allow_split = allow_split;
+  t.bit_words = bit_words;
+  build_chunks(g->h_rp, g->nv, target, allow_split, bit_words, recs, t.max_bit_words);
+  t.n = recs.size();
+  t.edge_prefix.resize(t.n + 1);
+  t.edge_prefix[0] = 0;
+  for (size_t i = 0; i < t.n; ++i) t.edge_prefix[i + 1] = t.edge_prefix[i] + (unsigned long long)(recs[i].e_end - recs[i].e_begin);
+  HIP_TRY(hipMalloc(&t.d, sizeof(ChunkRec) * std::max<size_t>(t.n, 1)));
+  if (t.n) HIP_TRY(hipMemcpy(t.d, recs.data(), sizeof(ChunkRec) * t.n, hipMemcpyHostToDevice));
+  g->tables.push_back(std::move(t));
+  *out = &g->tables.back();
+  return GM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// solvers
+// ------------------------------------------------------------------------------------------------
+__global__ void finalize_kernel(int pat, const unsigned long long *__restrict__ c, unsigned long long *__restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (pat == PAT_MOTIF3) {
+    out[0] = c[2] - c[0];  // wedges = sum_e idx(e) - sum_e |A' ^ B|   (automine_base.h:13)
+    out[1] = c[1];         // triangles                                  (automine_base.h:18)
+  } else {
+    out[0] = c[0];
+  }
+}
+
+static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uint64_t *h_out, int nout, gm_stats *st) {
+  if (!cg) return GM_ERR_INVALID;
+  gm_graph *g = const_cast<gm_graph *>(cg);
+  gm_launch dflt;
+  memset(&dflt, 0, sizeof dflt);
+  if (!la) la = &dflt;
+  const int world = la->world > 1 ? la->world : 1;
+  const int rank = la->rank;
+  if (rank < 0 || rank >= world) return GM_ERR_INVALID;
+  if (!h_out && !la->d_counts) return GM_ERR_INVALID;
+  HIP_TRY(hipSetDevice(g->device));
+  hipStream_t stream = (hipStream_t)la->stream;
+
+  // tune[0] = chunk target override, tune[1] = grab, tune[2] = cost_x_step, tune[3] = cost_y_step,
+  // tune[4] = blocks per CU override, tune[5] = force "search in HBM" (no LDS staging) when 1
+  int target = la->chunk > 0 ? la->chunk : 256;
+  if (la->tune[0] > 0) target = la->tune[0];
+  target = std::max(64, std::min(target, kStageCap));
+  const bool clique = pat == PAT_CLIQUE4;
+  ChunkTable *tab = nullptr;
+  int rc = get_table(g, target, !clique, clique ? kBitWords : 0, &tab);
+  if (rc) return rc;
+
+  MineParams p;
+  memset(&p, 0, sizeof p);
+  p.g.nv = g->nv;
+  p.g.ne = (int)g->ne;
+  p.g.rp = g->d_rp;
+  p.g.col = g->d_col;
+  p.chunks = tab->d;
+  const long long n = (long long)tab->n;
+  unsigned long long my_edges = 0;
+  if (la->policy == GM_PART_RANGE) {
+    const long long lo = n * rank / world, hi = n * (rank + 1) / world;
+    p.first = (int)lo;
+    p.step = 1;
+    p.count = (int)(hi - lo);
+    my_edges = tab->edge_prefix[hi] - tab->edge_prefix[lo];
+  } else {
+    p.first = rank;
+    p.step = world;
+    p.count = (int)((n - rank + world - 1) / world);
+    if (p.count < 0) p.count = 0;
+    if (world == 1) my_edges = tab->edge_prefix[n];
+    else for (long long c = rank; c < n; c += world) my_edges += tab->edge_prefix[c + 1] - tab->edge_prefix[c];
+  }
+  p.grab = la->tune[1] > 0 ? la->tune[1] : 4;
+  p.cost_x_step = la->tune[2] > 0 ? la->tune[2] : 1;
+  p.cost_y_step = la->tune[3] > 0 ? la->tune[3] : 6;
+  p.k = k;
+  p.flags = (la->tune[5] == 1) ? 1 : 0;
+  p.counters = g->d_counters;
+  p.queue = reinterpret_cast<unsigned *>(g->d_counters + 4);
+
+  const size_t lds = mine_lds_bytes(pat);
+  int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds));
+  if (la->tune[4] > 0) per_cu = la->tune[4];
+  long long want = ((long long)p.count + (long long)p.grab * kWavesPerBlock - 1) / ((long long)p.grab * kWavesPerBlock);
+  int grid = (int)std::max<long long>(1, std::min<long long>(want, (long long)g->cu_count * per_cu));
+
+  if (clique && tab->max_bit_words > 0) {
+    const size_t need = (size_t)tab->max_bit_words * sizeof(unsigned) * (size_t)grid * kWavesPerBlock;
+    if (need > g->scratch_bytes) {
+      if (g->d_scratch) (void)hipFree(g->d_scratch);
+      g->d_scratch = nullptr;
+      g->scratch_bytes = 0;
+      HIP_TRY(hipMalloc(&g->d_scratch, need));
+      g->scratch_bytes = need;
+    }
+    p.scratch = g->d_scratch;
+    p.scratch_words = tab->max_bit_words;
+  }
+
+  HIP_TRY(hipMemsetAsync(g->d_counters, 0, 64, stream));
+  hipEvent_t *evp = g->ev[g->ev_launches % gm_graph::kEvRing];
+  g->ev_launches++;
+  HIP_TRY(hipEventRecord(evp[0], stream));
+  if (p.count > 0) HIP_TRY(launch_mine(pat, p, grid, stream));
+  HIP_TRY(hipEventRecord(evp[1], stream));
+
+  if (st) {
+    st->kernel_ms = 0.0;
+    st->tasks = (pat == PAT_DIAMOND) ? my_edges / 2 : my_edges;
+    st->chunks = (uint64_t)p.count;
+    st->grid = (uint32_t)grid;
+    st->block = kWavesPerBlock * GM_WAVE;
+  }
+  if (la->d_counts) {
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, stream, (int)pat, g->d_counters, (unsigned long long *)la->d_counts);
+    HIP_TRY(hipGetLastError());
+    if (!h_out) return GM_OK;  // asynchronous: caller owns the synchronisation
+  }
+  unsigned long long c[4];
+  HIP_TRY(hipMemcpyAsync(c, g->d_counters, sizeof c, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  if (st) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, evp[0], evp[1]));
+    st->kernel_ms = ms;
+  }
+  if (pat == PAT_MOTIF3) {
+    if (nout > 0) h_out[0] = c[2] - c[0];
+    if (nout > 1) h_out[1] = c[1];
+  } else {
+    h_out[0] = c[0];
+  }
+  return GM_OK;
+}
+
+extern "C" int gm_kernel_times(const gm_graph *g, int n, double *ms_out, int *n_out) {
+  if (!g || !ms_out || !n_out || n < 0) return GM_ERR_INVALID;
+  const unsigned long long have = std::min<unsigned long long>(g->ev_launches, gm_graph::kEvRing);
+  const int m = (int)std::min<unsigned long long>((unsigned long long)n, have);
+  HIP_TRY(hipSetDevice(g->device));
+  for (int i = 0; i < m; ++i) {  // oldest of the last m launches first
+    const unsigned long long idx = (g->ev_launches - (unsigned long long)m + (unsigned long long)i) % gm_graph::kEvRing;
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, g->ev[idx][0], g->ev[idx][1]));
+    ms_out[i] = ms;
+  }
+  *n_out = m;
+  return GM_OK;
+}
+
+extern "C" int gm_tc(const gm_graph *dag, const gm_launch *la, uint64_t *total, gm_stats *st) {
+  return run_pattern(PAT_TC, dag, la, 3, total, 1, st);
+}
+
+extern "C" int gm_sgl(const gm_graph *sym, const char *pattern, const gm_launch *la, uint64_t *total, gm_stats *st) {
+  if (!pattern) return GM_ERR_INVALID;
+  if (strcmp(pattern, "diamond") == 0) return run_pattern(PAT_DIAMOND, sym, la, 4, total, 1, st);
+  if (total) *total = 0;  // "Not implemented", total_num = 0 (src/sgl/omp_base.cc:51-53)
+  return GM_ERR_UNSUPPORTED;
+}
+
+extern "C" int gm_clique(const gm_graph *dag, int k, const gm_launch *la, uint64_t *total, gm_stats *st) {
+  if (k == 3) return run_pattern(PAT_TC, dag, la, 3, total, 1, st);
+  if (k == 4) return run_pattern(PAT_CLIQUE4, dag, la, 4, total, 1, st);
+  if (total) *total = 0;
+  return (k < 3 || k > 8) ? GM_ERR_INVALID : GM_ERR_UNSUPPORTED;
+}
+
+extern "C" int gm_motif(const gm_graph *sym, int k, const gm_launch *la, uint64_t *counts, int ncounts, gm_stats *st) {
+  if (k != 3) return (k == 4) ? GM_ERR_UNSUPPORTED : GM_ERR_INVALID;
+  if (ncounts < 2) return GM_ERR_INVALID;
+  return run_pattern(PAT_MOTIF3, sym, la, 3, counts, ncounts, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// set-op batch (one wave per pair)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void setop_kernel(int op, long long npairs, const int *__restrict__ vals,
+                                                    const long long *__restrict__ ab, const long long *__restrict__ ae,
+                                                    const long long *__restrict__ bb, const long long *__restrict__ be,
+                                                    const int *__restrict__ upper, const int *__restrict__ skip,
+                                                    unsigned *__restrict__ out_num, int *__restrict__ out_vals) {
+  const int lane = threadIdx.x & 63;
+  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+  for (long long i = wave; i < npairs; i += nwaves) {
+    const int *A = vals + ab[i];
+    const int *B = vals + bb[i];
+    const int a = (int)(ae[i] - ab[i]), b = (int)(be[i] - bb[i]);
+    const int up = upper ? upper[i] : 0x7fffffff;
+    const int sk = skip ? skip[i] : -1;
+    int *O = out_vals ? out_vals + ab[i] : nullptr;
+    unsigned r = 0;
+    switch (op) {
+      case GM_OP_INTERSECT_NUM: r = (unsigned)wave_sum((int)wave_intersect_num(A, a, B, b)); break;
+      case GM_OP_INTERSECT_NUM_UPPER: r = (unsigned)wave_sum((int)wave_intersect_num_upper(A, a, B, b, up)); break;
+      case GM_OP_INTERSECT_SET: r = (unsigned)wave_intersect_set(A, a, B, b, O); break;
+      case GM_OP_INTERSECT_SET_UPPER: r = (unsigned)wave_intersect_set_upper(A, a, B, b, up, O); break;
+      case GM_OP_DIFFERENCE_NUM: r = (unsigned)wave_sum((int)wave_difference_num(A, a, B, b, sk)); break;
+      case GM_OP_DIFFERENCE_NUM_UPPER: r = (unsigned)wave_sum((int)wave_difference_num_upper(A, a, B, b, sk, up)); break;
+      case GM_OP_DIFFERENCE_SET: r = (unsigned)wave_difference_set(A, a, B, b, sk, O); break;
+      case GM_OP_DIFFERENCE_SET_UPPER: r = (unsigned)wave_difference_set_upper(A, a, B, b, sk, up, O); break;
+      default: break;
+    }
+    if (lane == 0) out_num[i] = r;
+  }
+}
+
+extern "C" int gm_setop_batch(int op, int64_t npairs, const int32_t *d_values, const int64_t *d_a_begin, const int64_t *d_a_end,
+                              const int64_t *d_b_begin, const int64_t *d_b_end, const int32_t *d_upper, const int32_t *d_skip,
+                              uint32_t *d_out_num, int32_t *d_out_values, void *stream) {
+  if (op < 0 || op > GM_OP_DIFFERENCE_SET_UPPER || npairs < 0) return GM_ERR_INVALID;
+  if (npairs == 0) return GM_OK;
+  if (!d_values || !d_a_begin || !d_a_end || !d_b_begin || !d_b_end || !d_out_num) return GM_ERR_INVALID;
+  const bool is_set = (op == GM_OP_INTERSECT_SET || op == GM_OP_INTERSECT_SET_UPPER || op == GM_OP_DIFFERENCE_SET ||
+                       op == GM_OP_DIFFERENCE_SET_UPPER);
+  if (is_set && !d_out_values) return GM_ERR_INVALID;
+  const long long blocks = std::min<long long>((npairs + 3) / 4, 8192);
+  hipLaunchKernelGGL(setop_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, op, (long long)npairs, d_values,
+                     (const long long *)d_a_begin, (const long long *)d_a_end, (const long long *)d_b_begin,
+                     (const long long *)d_b_end, d_upper, d_skip, d_out_num, d_out_values);
+  HIP_TRY(hipGetLastError());
+  return GM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// R-MAT key generator (tooling)
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ unsigned long long gm_mix64(unsigned long long z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void rmat_kernel(int scale, long long n_edges, unsigned long long seed,
+                                                   unsigned long long *__restrict__ keys) {
+  const unsigned TA = 2448131358u;  // floor(0.57 * 2^32)
+  const unsigned TB = 3264175144u;  // TA + floor(0.19 * 2^32)
+  const unsigned TC = 4080218930u;  // TB + floor(0.19 * 2^32)
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_edges; i += stride) {
+    const unsigned long long h = gm_mix64(seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1));
+    unsigned long long s = 0, d = 0;
+    for (int l = 0; l < scale; ++l) {
+      const unsigned r = (unsigned)(gm_mix64(h + 0xD1B54A32D192ED03ull * (unsigned long long)(l + 1)) >> 32);
+      const unsigned q = (r < TA) ? 0u : (r < TB) ? 1u : (r < TC) ? 2u : 3u;
+      s = (s << 1) | (q >> 1);
+      d = (d << 1) | (q & 1u);
+    }
+    if (s == d) {
+      keys[2 * i] = ~0ull;
+      keys[2 * i + 1] = ~0ull;
+    } else {
+      keys[2 * i] = (s << 32) | d;
+      keys[2 * i + 1] = (d << 32) | s;
+    }
+  }
+}
+
+extern "C" int gm_rmat_keys(int scale, int64_t n_edges, uint64_t seed, uint64_t *d_keys, void *stream) {
+  if (scale < 1 || scale > 30 || n_edges < 0 || !d_keys) return GM_ERR_INVALID;
+  if (n_edges == 0) return GM_OK;
+  const long long blocks = std::min<long long>((n_edges + 255) / 256, 65536);
+  hipLaunchKernelGGL(rmat_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, scale, (long long)n_edges,
+                     (unsigned long long)seed, (unsigned long long *)d_keys);
+  HIP_TRY(hipGetLastError());
+  return GM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// wave-primitive self test
+// ------------------------------------------------------------------------------------------------
+__global__ void selftest_kernel(int *out) {
+  __shared__ int lds[64];
+  const int lane = threadIdx.x;
+  const int x = (lane * 7 + 3) % 11;
+  out[lane] = wave_incl_scan_add(x);
+  const int y = (lane % 9 == 0) ? lane + 1 : 0;
+  out[64 + lane] = wave_incl_scan_max(y);
+  const unsigned long long m = __ballot((lane % 3) == 1);
+  out[128 + lane] = rank_below(m);
+  out[192 + lane] = lane_id();
+  lds[lane] = lane * 3;  // ascending
+  wave_sync();
+  int pos;
+  const bool f = contains(&lds[0], 64, lane * 2, &pos);
+  out[256 + lane] = f ? pos : -1;
+  out[320 + lane] = lower_bound(&lds[0], 64, lane * 2);
+  out[384 + lane] = (int)wave_sum_u64((unsigned long long)lane + (1ull << 33));  // low word of 64*2^33 + 2016
+  out[448 + lane] = (int)(wave_sum_u64((unsigned long long)lane + (1ull << 33)) >> 32);
+}
+
+extern "C" int gm_selftest(int device, int *n_fail) {
+  if (n_fail) *n_fail = -1;
+  HIP_TRY(hipSetDevice(device));
+  int *d = nullptr;
+  HIP_TRY(hipMalloc(&d, sizeof(int) * 512));
+  hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, 0, d);
+  int h[512];
+  hipError_t e = hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) return hip_fail(e, "selftest", __FILE__, __LINE__);
+  int bad = 0, acc = 0, mx = 0, rk = 0;
+  for (int l = 0; l < 64; ++l) {
+    acc += (l * 7 + 3) % 11;
+    bad += h[l] != acc;
+    const int y = (l % 9 == 0) ? l + 1 : 0;
+    mx = std::max(mx, y);
+    bad += h[64 + l] != mx;
+    bad += h[128 + l] != rk;
+    rk += (l % 3) == 1;
+    bad += h[192 + l] != l;
+    const int key = l * 2;
+    const int expect_pos = (key % 3 == 0 && key / 3 < 64) ? key / 3 : -1;
+    bad += h[256 + l] != expect_pos;
+    int lb = 0;
+    while (lb < 64 && lb * 3 < key) ++lb;
+    bad += h[320 + l] != lb;
+    const unsigned long long tot = 64ull * (1ull << 33) + 2016ull;
+    bad += h[384 + l] != (int)(unsigned)tot;
+    bad += h[448 + l] != (int)(tot >> 32);
+  }
+  if (n_fail) *n_fail = bad;
+  if (bad) { g_last_error = "wave primitive self test mismatch"; return GM_ERR_HIP; }
+  return GM_OK;
+}

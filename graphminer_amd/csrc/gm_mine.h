@@ -1,0 +1,51 @@
+// gm_mine.h -- shared declarations between the host API (gm_api.hip / gm_graph.hip) and the
+// mining kernels (gm_mine.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gm {
+
+// ---- compile-time geometry of one worker wave ------------------------------------------------
+constexpr int kWavesPerBlock = 4;         // 256-thread workgroups, the 4 waves work independently
+constexpr int kStageCap = 1024;           // adjacency entries one wave stages in LDS (4 KB)
+constexpr int kMaxChunkVerts = 256;       // rows per task chunk (local row_ptr slice in LDS)
+constexpr int kMarkWindow = 1024;         // flattened positions resolved per owner-mark window
+constexpr int kBitWords = 2048;           // clique: LDS words for the per-chunk adjacency bit-matrix (8 KB)
+
+// Task chunk = a contiguous vertex range [u_begin,u_end) and the CSR entries [e_begin,e_end) it owns.
+// Normal chunks own whole rows (e_begin == rp[u_begin], e_end == rp[u_end]); a row longer than the
+// staging capacity is cut into SPLIT chunks (u_end == u_begin+1, [e_begin,e_end) inside the row).
+struct ChunkRec {
+  int u_begin, u_end, e_begin, e_end;
+};
+
+struct GraphView {
+  int nv;
+  int ne;
+  const int *rp;   // int32 row offsets (nv+1), internal copy of row_ptr
+  const int *col;  // col_idx
+};
+
+enum Pattern : int { PAT_TC = 0, PAT_DIAMOND = 1, PAT_MOTIF3 = 2, PAT_CLIQUE4 = 3 };
+
+struct MineParams {
+  GraphView g;
+  const ChunkRec *chunks;
+  int first, step, count;        // this rank owns chunk ids first + i*step, i in [0,count)
+  int grab;                      // chunks taken per dequeue
+  unsigned *queue;               // dequeue head (zeroed before launch)
+  unsigned long long *counters;  // [4] accumulators (zeroed before launch)
+  unsigned *scratch;             // clique: global bit-matrix arena, scratch_words per wave
+  unsigned long long scratch_words;
+  int cost_x_step;  // direction heuristic, see choose_dir()
+  int cost_y_step;
+  int k;
+  int flags;  // bit 0: never stage adjacency in LDS (A/B switch: every search goes to HBM/L2)
+};
+
+// host-side launchers (gm_mine.hip)
+hipError_t launch_mine(Pattern pat, const MineParams &p, int grid_blocks, hipStream_t stream);
+size_t mine_lds_bytes(Pattern pat);
+
+}  // namespace gm

@@ -1,0 +1,101 @@
+"""Deterministic R-MAT graph generator (tooling).
+
+The reference ships no generator (its converter lives in another repo, README.md:104), so this
+module DEFINES the synthetic fixtures: edge i of ``edge_factor * 2**scale`` draws one quadrant
+per bit level with probabilities (a,b,c,d) = (0.57, 0.19, 0.19, 0.05) from a counter-based
+SplitMix64 hash of (seed, i, level); then self-loops are dropped, the edge set is symmetrised,
+rows are sorted and de-duplicated, max_degree = longest row.
+
+Two implementations of the SAME stream:
+  * ``rmat_csr_numpy``  -- host, vectorised numpy (tests, small scales);
+  * ``rmat_csr_device`` -- the HIP kernel ``gm_rmat_keys`` + torch sort/unique (bench, full scale).
+tests/test_rmat.py checks they produce identical CSR arrays.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .graph import DeviceGraph, Graph
+
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+_G1 = np.uint64(0x9E3779B97F4A7C15)
+_G2 = np.uint64(0xD1B54A32D192ED03)
+TA = 2448131358  # floor(0.57 * 2^32)
+TB = 3264175144  # TA + floor(0.19 * 2^32)
+TC = 4080218930  # TB + floor(0.19 * 2^32)
+
+
+def _mix64(z: np.ndarray) -> np.ndarray:
+    z = (z ^ (z >> np.uint64(30))) * _M1
+    z = (z ^ (z >> np.uint64(27))) * _M2
+    return z ^ (z >> np.uint64(31))
+
+
+def rmat_edges_numpy(scale: int, edge_factor: int, seed: int = 42):
+    """(src, dst) uint64 arrays of the raw generated pairs (self-loops included)."""
+    n = (1 << scale) * edge_factor
+    with np.errstate(over="ignore"):
+        i = np.arange(1, n + 1, dtype=np.uint64)
+        h = _mix64(np.uint64(seed) + _G1 * i)
+        s = np.zeros(n, dtype=np.uint64)
+        d = np.zeros(n, dtype=np.uint64)
+        for l in range(scale):
+            r = _mix64(h + _G2 * np.uint64(l + 1)) >> np.uint64(32)
+            q = (r >= TA).astype(np.uint64) + (r >= TB).astype(np.uint64) + (r >= TC).astype(np.uint64)
+            s = (s << np.uint64(1)) | (q >> np.uint64(1))
+            d = (d << np.uint64(1)) | (q & np.uint64(1))
+    return s, d
+
+
+def csr_from_pairs(nv: int, s: np.ndarray, d: np.ndarray) -> Graph:
+    """Drop self-loops, symmetrise, sort + dedupe rows."""
+    keep = s != d
+    s, d = s[keep].astype(np.uint64), d[keep].astype(np.uint64)
+    keys = np.concatenate([(s << np.uint64(32)) | d, (d << np.uint64(32)) | s])
+    keys = np.unique(keys)
+    src = (keys >> np.uint64(32)).astype(np.int64)
+    col = (keys & np.uint64(0xFFFFFFFF)).astype(np.int32)
+    row_ptr = np.zeros(nv + 1, dtype=np.int64)
+    np.cumsum(np.bincount(src, minlength=nv), out=row_ptr[1:])
+    return Graph(row_ptr=row_ptr, col_idx=col, name=f"rmat")
+
+
+def rmat_csr_numpy(scale: int, edge_factor: int, seed: int = 42) -> Graph:
+    s, d = rmat_edges_numpy(scale, edge_factor, seed)
+    g = csr_from_pairs(1 << scale, s, d)
+    g.name = f"rmat{scale}_ef{edge_factor}_s{seed}"
+    return g
+
+
+def rmat_csr_device(scale: int, edge_factor: int, seed: int = 42, device: int = 0):
+    """Generate on the GPU. Returns (DeviceGraph, row_ptr_tensor, col_idx_tensor); the tensors
+    own the memory the handle borrows (kept alive by the handle too)."""
+    import ctypes as C
+
+    import torch
+
+    from . import _lib
+
+    lib = _lib.load()
+    nv = 1 << scale
+    n = nv * edge_factor
+    dev = torch.device("cuda", device)
+    with torch.cuda.device(dev):
+        keys = torch.empty(2 * n, dtype=torch.int64, device=dev)
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(lib.gm_rmat_keys(scale, n, C.c_uint64(seed), keys.data_ptr(), stream), "gm_rmat_keys")
+        # sort as UNSIGNED 64-bit: sentinel 0xFFFF.. (self-loop) is -1 as int64 and sorts first; keys are < 2^62
+        keys = torch.unique(keys)  # sorted ascending (signed): [-1?, k0, k1, ...]
+        if keys.numel() and int(keys[0].item()) == -1:
+            keys = keys[1:]
+        src = keys >> 32
+        col = (keys & 0xFFFFFFFF).to(torch.int32).contiguous()
+        deg = torch.bincount(src, minlength=nv)
+        row_ptr = torch.zeros(nv + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(deg, 0, out=row_ptr[1:])
+        del keys, src, deg
+        torch.cuda.synchronize(dev)
+    g = DeviceGraph.from_device_ptrs(nv, int(col.numel()), row_ptr.data_ptr(), col.data_ptr(), device,
+                                     keepalive=(row_ptr, col))
+    return g, row_ptr, col

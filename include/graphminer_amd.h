@@ -1,0 +1,170 @@
+/*
+ * graphminer_amd.h -- C ABI of the MI355X-native subgraph-matching hot path.
+ *
+ * One shared object (graphminer_amd/libgraphminer_amd.so), plain pointers and sizes,
+ * no C++/torch types. It is the drop-in boundary for GraphMiner's link-time solver
+ * seam: each reference solver
+ *     void TCSolver    (Graph&, uint64_t& total, int n_gpu, int chunk)            src/triangle/main.cc:5
+ *     void SglSolver   (Graph&, Pattern&, uint64_t& total, int n_dev, int chunk)  src/sgl/main.cc:7
+ *     void CliqueSolver(Graph&, int k, uint64_t& total, int, int)                 src/clique/main.cc:6
+ *     void MotifSolver (Graph&, int k, std::vector<uint64_t>&, int, int)          src/motif/main.cc:7
+ * becomes a ~10 line shim over gm_tc / gm_sgl / gm_clique / gm_motif (see INTEGRATION.md
+ * and graphminer_amd/host/solvers.cc, which is exactly that shim).
+ *
+ * Conventions
+ *   - every entry point returns a gm_status (0 = ok); nothing calls exit().
+ *   - host pointers are borrowed for the duration of the call only.
+ *   - device buffers are owned by the opaque gm_graph handle.
+ *   - outputs are WRITTEN, not accumulated (the reference multi-GPU solvers '+=' into
+ *     a caller-zeroed total, src/triangle/multigpu.cu:84; the shim does that '+=').
+ *   - vertex ids int32, CSR offsets int64, counts uint64 (include/common.h:36-40).
+ *   - there is NO CPU fallback: without a HIP device every compute call fails with
+ *     GM_ERR_NO_DEVICE.
+ */
+#ifndef GRAPHMINER_AMD_H
+#define GRAPHMINER_AMD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum gm_status {
+  GM_OK = 0,
+  GM_ERR_INVALID = 1,      /* bad argument (null pointer, k out of range, ...) */
+  GM_ERR_NO_DEVICE = 2,    /* no HIP device / HIP runtime error before launch */
+  GM_ERR_HIP = 3,          /* HIP runtime error (see gm_last_error) */
+  GM_ERR_TOO_LARGE = 4,    /* ne >= 2^31 or nv >= 2^31-1: outside this build's 32-bit task index */
+  GM_ERR_UNSUPPORTED = 5,  /* pattern / k not implemented ("Not implemented", src/sgl/omp_base.cc:51) */
+  GM_ERR_IO = 6,           /* file could not be opened / short read (custom_alloc.h:38-41) */
+  GM_ERR_FORMAT = 7        /* meta.txt violates the loader asserts (src/common/graph.cc:30-34) */
+} gm_status;
+
+const char *gm_strerror(int status);
+/* thread-local text of the last failing HIP call made through this library */
+const char *gm_last_error(void);
+int gm_version(void);
+
+/* Exactly what Graph::V()/E()/get_max_degree()/out_rowptr()/out_colidx() expose
+ * (include/graph.h:63-64,73,83-84). Host pointers. */
+typedef struct gm_csr {
+  int32_t nv;
+  int64_t ne;
+  int32_t max_deg;
+  const int64_t *row_ptr; /* nv+1 */
+  const int32_t *col_idx; /* ne, rows strictly ascending */
+} gm_csr;
+
+/* Device-resident CSR (+ task-chunk tables). Replaces GraphGPU, include/graph_gpu.h:6-211. */
+typedef struct gm_graph gm_graph;
+
+int gm_device_count(int *n);
+
+/* GraphGPU::init (include/graph_gpu.h:69-122): H->D copy of row_ptr / col_idx on `device`. */
+int gm_graph_upload(const gm_csr *host, int device, gm_graph **out);
+/* Adopt CSR arrays that already live in HBM (e.g. built on the GPU); the arrays are BORROWED
+ * and must outlive the handle. d_row_ptr is int64[nv+1], d_col_idx int32[ne]. */
+int gm_graph_from_device(int32_t nv, int64_t ne, const int64_t *d_row_ptr, const int32_t *d_col_idx,
+                         int device, gm_graph **out);
+/* Graph::orientation (src/common/graph.cc:233-279) on the GPU: keep s->d iff
+ * deg[d] > deg[s] || (deg[d] == deg[s] && d > s). Returns a new handle. */
+int gm_graph_orient(const gm_graph *sym, gm_graph **dag);
+/* nv / ne / max_deg of a handle (pointers in *meta are left NULL). */
+int gm_graph_meta(const gm_graph *g, gm_csr *meta);
+/* D->H copy (row_ptr: nv+1 int64, col_idx: ne int32); either pointer may be NULL. */
+int gm_graph_download(const gm_graph *g, int64_t *row_ptr, int32_t *col_idx);
+void gm_graph_free(gm_graph *g);
+
+/* Scheduler policy for the multi-GPU task split (include/scheduler.h, src/common/scheduler.cc). */
+enum {
+  GM_PART_ROUND_ROBIN = 0, /* Scheduler::round_robin, scheduler.cc:34-85: chunk c -> rank c mod world */
+  GM_PART_RANGE = 1        /* even contiguous split (EVEN_SPLIT, src/clique/multigpu.cu:42-44) */
+};
+
+typedef struct gm_launch {
+  void *stream;       /* hipStream_t; NULL = the null stream */
+  int32_t rank;       /* this process' share of the task chunks: rank in [0, world) */
+  int32_t world;      /* 0 or 1 = single GPU */
+  int32_t policy;     /* GM_PART_* */
+  int32_t chunk;      /* tasks (edges) per scheduling chunk; 0 = library default. Reference default 1024
+                         (src/triangle/main.cc:16) */
+  uint64_t *d_counts; /* optional DEVICE buffer (>= ncounts uint64). When set the result is left on the
+                         device, no host sync is done (use it to feed an RCCL all-reduce). */
+  int32_t tune[8];    /* kernel tuning knobs, all 0 = defaults */
+} gm_launch;
+
+typedef struct gm_stats {
+  double kernel_ms;  /* HIP-event time of the mining kernel(s) on the launch stream (0 when d_counts is set
+                        and the call did not synchronise) */
+  uint64_t tasks;    /* "edges processed" as the reference's TEPS line defines nnz (src/triangle/gpu_base.cu:69) */
+  uint64_t chunks;   /* task chunks owned by this rank */
+  uint32_t grid;     /* workgroups launched */
+  uint32_t block;    /* threads per workgroup */
+} gm_stats;
+
+/* HIP-event durations (ms) of the mining kernels of the most recent launches on this handle, oldest
+ * first; at most 64 are remembered. The caller must have synchronised the launch stream(s).
+ * This is how an asynchronous (d_counts) caller reads the kernel time the reference prints as
+ * "runtime [gpu_base]" (src/triangle/gpu_base.cu:53-68). */
+int gm_kernel_times(const gm_graph *g, int n, double *ms_out, int *n_out);
+
+/* ---- solvers ------------------------------------------------------------------------------ */
+/* launch may be NULL (single GPU, null stream, defaults). stats may be NULL. */
+
+/* TCSolver: total = sum_{(u,v) in DAG} |N+(u) ^ N+(v)|  (src/triangle/omp_base.cc:15-21,
+ * src/triangle/gpu_kernels/bs_warp_edge.cuh:2-18). `dag` must be an ORIENTED graph. */
+int gm_tc(const gm_graph *dag, const gm_launch *launch, uint64_t *total, gm_stats *stats);
+
+/* SglSolver: edge-induced subgraph listing on the SYMMETRIC graph, pattern by NAME
+ * (include/pattern.hh:62-78). Implemented: "diamond" (src/sgl/cpu_kernels/diamond.h:1-14,
+ * src/sgl/gpu_kernels/diamond_count.cuh:3-21). Others -> GM_ERR_UNSUPPORTED, *total = 0. */
+int gm_sgl(const gm_graph *sym, const char *pattern, const gm_launch *launch, uint64_t *total, gm_stats *stats);
+
+/* CliqueSolver on the DAG, 3 <= k <= 8 (src/clique/cpu_kernels/automine_omp.h:67-83,138-157;
+ * src/clique/gpu_kernels/clique4_warp_edge.cuh:3-31 ... clique8). */
+int gm_clique(const gm_graph *dag, int k, const gm_launch *launch, uint64_t *total, gm_stats *stats);
+
+/* MotifSolver on the SYMMETRIC graph. k = 3: counts[0] = wedges, counts[1] = triangles
+ * (the CPU order, src/motif/cpu_kernels/automine_base.h:13,18; NOT the swapped order of
+ * src/motif/gpu_kernels/motif3_edge_warp.cuh:19-22). ncounts must be
+ * num_possible_patterns[k] (include/pattern.hh:4-15): 2 for k = 3. */
+int gm_motif(const gm_graph *sym, int k, const gm_launch *launch, uint64_t *counts, int ncounts, gm_stats *stats);
+
+/* ---- set-operation primitives (batch form) -------------------------------------------------- */
+/* The wave64 equivalents of include/set_intersect.cuh / set_difference.cuh, exposed so the
+ * per-primitive parity tests can drive them directly. One wave per pair of ascending int32 lists.
+ * All pointers are DEVICE pointers. */
+enum {
+  GM_OP_INTERSECT_NUM = 0,       /* |A ^ B|                                  set_intersect.cuh:352  */
+  GM_OP_INTERSECT_NUM_UPPER = 1, /* |{x in A ^ B : x < upper_i}|              set_intersect.cuh:392  */
+  GM_OP_INTERSECT_SET = 2,       /* A ^ B -> out (ascending)                  set_intersect.cuh:73   */
+  GM_OP_DIFFERENCE_NUM = 3,      /* |{x in A : x not in B}|                   set_difference.cuh:20  */
+  GM_OP_DIFFERENCE_NUM_UPPER = 4,/* |{x in A : x < upper_i, x not in B}|      set_difference.cuh:62  */
+  GM_OP_DIFFERENCE_SET = 5,      /* A \ B -> out (ascending)                  set_difference.cuh:112 */
+  GM_OP_INTERSECT_SET_UPPER = 6, /* {x in A ^ B : x < upper_i} -> out         set_intersect.cuh:152  */
+  GM_OP_DIFFERENCE_SET_UPPER = 7 /* {x in A \ B : x < upper_i} -> out         set_difference.cuh:171 */
+};
+/* Pair i is A_i = values[a_begin[i] .. a_end[i]), B_i = values[b_begin[i] .. b_end[i]).
+ * out_num: npairs uint32 (count, or size of the materialised set). For *_SET ops the result of pair
+ * i is written at out_values[a_begin[i] ..) (capacity |A_i|; may be NULL for count-only ops).
+ * d_upper may be NULL for ops without a bound. d_skip (may be NULL) is the CPU-oracle "other.vid"
+ * exclusion of the difference ops (src/common/VertexSet.cc:29,37): elements equal to skip[i] are dropped. */
+int gm_setop_batch(int op, int64_t npairs, const int32_t *d_values, const int64_t *d_a_begin, const int64_t *d_a_end,
+                   const int64_t *d_b_begin, const int64_t *d_b_end, const int32_t *d_upper, const int32_t *d_skip,
+                   uint32_t *d_out_num, int32_t *d_out_values, void *stream);
+
+/* ---- tooling ------------------------------------------------------------------------------- */
+/* Deterministic R-MAT edge generator: edge i of 2^scale*edge_factor,
+ * quadrant probabilities (0.57, 0.19, 0.19, 0.05), SplitMix64 counter hash of (seed, i, level).
+ * Writes 2 keys per edge (src<<32|dst and dst<<32|src) to DEVICE buffer d_keys[2*n_edges];
+ * self-loops are written as the sentinel 0xFFFFFFFFFFFFFFFF. */
+int gm_rmat_keys(int scale, int64_t n_edges, uint64_t seed, uint64_t *d_keys, void *stream);
+
+/* wave-primitive self test (DPP scans, ballot rank, LDS search); returns GM_OK when the device
+ * results equal the host expectation. *n_fail receives the number of mismatching lanes. */
+int gm_selftest(int device, int *n_fail);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

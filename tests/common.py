@@ -1,0 +1,42 @@
+"""Shared helpers for the test-suite."""
+from __future__ import annotations
+
+import hashlib
+import json
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+with open(os.path.join(ROOT, "tests", "golden", "golden.json")) as f:
+    GOLDEN = json.load(f)
+
+GRAPH_NAMES = [k for k in GOLDEN if not k.startswith("_")]
+
+
+def load_graph(name):
+    """Return a graphminer_amd.Graph for a golden entry (fixture file or regenerated R-MAT)."""
+    from graphminer_amd.graph import Graph
+    from graphminer_amd.rmat import rmat_csr_numpy
+
+    e = GOLDEN[name]
+    if e["kind"] == "fixture":
+        return Graph(os.path.join(ROOT, "tests", "fixtures", name, "graph"))
+    return rmat_csr_numpy(e["scale"], e["edge_factor"], e["seed"])
+
+
+def csr_sha(g):
+    h = hashlib.sha256()
+    h.update(np.asarray(g.row_ptr).astype("<i8").tobytes())
+    h.update(np.asarray(g.col_idx).astype("<i4").tobytes())
+    return h.hexdigest()
+
+
+def random_graph(nv, ne_target, seed):
+    """Small random symmetric simple graph (numpy)."""
+    from graphminer_amd.rmat import csr_from_pairs
+
+    rng = np.random.default_rng(seed)
+    s = rng.integers(0, nv, ne_target).astype(np.uint64)
+    d = rng.integers(0, nv, ne_target).astype(np.uint64)
+    return csr_from_pairs(nv, s, d)

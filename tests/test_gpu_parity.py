@@ -1,0 +1,227 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle, the golden vectors of
+the real reference, and size-independent properties. Run on the MI355X box: pytest -m gpu."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+import oracle as O
+from common import GOLDEN, GRAPH_NAMES, load_graph, random_graph
+from graphminer_amd import CliqueSolver, DeviceGraph, Graph, MotifSolver, SglSolver, TCSolver, _lib
+from graphminer_amd.rmat import csr_from_pairs, rmat_csr_numpy
+
+pytestmark = pytest.mark.gpu
+
+
+def _complete_graph(n):
+    s, d = np.triu_indices(n, 1)
+    return csr_from_pairs(n, s.astype(np.uint64), d.astype(np.uint64))
+
+
+def _star_plus(n_leaves, extra_seed=3):
+    """hub 0 joined to everything (row >> staging capacity) + a sparse random graph among the leaves"""
+    rng = np.random.default_rng(extra_seed)
+    s = np.concatenate([np.zeros(n_leaves, dtype=np.uint64), rng.integers(1, n_leaves + 1, 4 * n_leaves).astype(np.uint64)])
+    d = np.concatenate([np.arange(1, n_leaves + 1, dtype=np.uint64), rng.integers(1, n_leaves + 1, 4 * n_leaves).astype(np.uint64)])
+    return csr_from_pairs(n_leaves + 1, s, d)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import torch
+
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    lib = _lib.load()
+    nfail = C.c_int(0)
+    rc = lib.gm_selftest(0, C.byref(nfail))
+    assert rc == 0 and nfail.value == 0, f"wave primitive self test failed: {nfail.value} lanes"
+    return 0
+
+
+@pytest.fixture(scope="module", params=GRAPH_NAMES)
+def gg(request, dev):
+    name = request.param
+    g = load_graph(name)
+    sym = g.to_device(dev)
+    dag = sym.orient()
+    yield name, g, sym, dag
+    sym.free()
+    dag.free()
+
+
+def test_selftest(dev):
+    assert dev == 0
+
+
+def test_orientation_bit_exact(gg):
+    name, g, sym, dag = gg
+    want = O.orient(O.OGraph(g.row_ptr, g.col_idx))
+    got = dag.download()
+    assert np.array_equal(got.row_ptr, want.row_ptr)
+    assert np.array_equal(got.col_idx, want.col_idx)
+    assert (dag.E(), dag.get_max_degree()) == (GOLDEN[name]["dag_ne"], GOLDEN[name]["dag_max_degree"])
+
+
+def test_tc_matches_reference(gg):
+    name, _, _, dag = gg
+    total, st = TCSolver(dag, return_stats=True)
+    assert total == GOLDEN[name]["tc"]
+    assert st.tasks == dag.E()  # "edges processed" = |E+| (src/triangle/gpu_base.cu:69)
+    assert CliqueSolver(dag, 3) == GOLDEN[name]["tc"]
+
+
+@pytest.mark.parametrize("tune", [
+    [64, 1, 0, 0, 0, 0], [256, 4, 0, 0, 0, 1], [1024, 2, 0, 0, 0, 0], [128, 8, 1, 1, 0, 0], [256, 4, 1, 30, 2, 0],
+    [256, 4, 8, 1, 0, 0],
+])
+def test_tc_invariant_under_tuning(gg, tune):
+    name, _, sym, dag = gg
+    assert TCSolver(dag, tune=tune) == GOLDEN[name]["tc"]
+    assert MotifSolver(sym, 3, tune=tune) == GOLDEN[name]["motif3"]
+
+
+def test_diamond_matches_reference(gg):
+    name, _, sym, _ = gg
+    total, st = SglSolver(sym, "diamond", return_stats=True)
+    assert total == GOLDEN[name]["diamond"]
+    assert st.tasks == sym.E() // 2
+    assert SglSolver(sym, "diamond", tune=[128, 2, 0, 0, 0, 1]) == GOLDEN[name]["diamond"]
+
+
+def test_clique4_matches_reference(gg):
+    name, _, _, dag = gg
+    assert CliqueSolver(dag, 4) == GOLDEN[name]["clique4"]
+    assert CliqueSolver(dag, 4, tune=[64, 1, 1, 1, 0, 0]) == GOLDEN[name]["clique4"]
+    assert CliqueSolver(dag, 4, tune=[512, 4, 0, 0, 0, 1]) == GOLDEN[name]["clique4"]
+
+
+def test_motif3_matches_reference(gg):
+    name, _, sym, _ = gg
+    assert MotifSolver(sym, 3) == GOLDEN[name]["motif3"]  # [wedges, triangles]: CPU order
+
+
+@pytest.mark.parametrize("world,policy", [(2, 0), (3, 0), (8, 0), (2, 1), (5, 1)])
+def test_task_partition_sums_to_the_whole(gg, world, policy):
+    name, _, sym, dag = gg
+    e = GOLDEN[name]
+    tc = dia = k4 = 0
+    m3 = [0, 0]
+    tasks = 0
+    for r in range(world):
+        t, st = TCSolver(dag, rank=r, world=world, policy=policy, return_stats=True)
+        tc += t
+        tasks += st.tasks
+        dia += SglSolver(sym, "diamond", rank=r, world=world, policy=policy)
+        k4 += CliqueSolver(dag, 4, rank=r, world=world, policy=policy)
+        m = MotifSolver(sym, 3, rank=r, world=world, policy=policy)
+        m3 = [m3[0] + m[0], m3[1] + m[1]]
+    assert (tc, dia, k4, m3) == (e["tc"], e["diamond"], e["clique4"], e["motif3"])
+    assert tasks == dag.E()
+
+
+def test_unsupported_and_invalid_arguments(gg):
+    _, _, sym, dag = gg
+    assert SglSolver(sym, "foo") == 0  # "Not implemented", total_num = 0 (src/sgl/omp_base.cc:51-53)
+    with pytest.raises(_lib.GraphMinerError):
+        CliqueSolver(dag, 2)
+    with pytest.raises(_lib.GraphMinerError):
+        TCSolver(dag, rank=3, world=2)
+
+
+# ---- edge cases ----------------------------------------------------------------------------------
+def test_empty_and_tiny_graphs(dev):
+    g = Graph(row_ptr=[0, 0, 0, 0], col_idx=[]).to_device(dev)
+    d = g.orient()
+    assert TCSolver(d) == 0 and SglSolver(g, "diamond") == 0 and CliqueSolver(d, 4) == 0 and MotifSolver(g, 3) == [0, 0]
+    # a single edge, a path, a triangle
+    for rp, ci, want in [([0, 1, 2], [1, 0], (0, 0, 0, [0, 0])),
+                         ([0, 1, 3, 4], [1, 0, 2, 1], (0, 0, 0, [1, 0])),
+                         ([0, 2, 4, 6], [1, 2, 0, 2, 0, 1], (1, 0, 0, [0, 1]))]:
+        s = Graph(row_ptr=rp, col_idx=ci).to_device(dev)
+        o = s.orient()
+        assert (TCSolver(o), SglSolver(s, "diamond"), CliqueSolver(o, 4), MotifSolver(s, 3)) == want
+
+
+@pytest.mark.parametrize("n", [5, 64, 65, 130])
+def test_complete_graph_closed_forms(dev, n):
+    g = _complete_graph(n)
+    s = g.to_device(dev)
+    d = s.orient()
+    assert TCSolver(d) == math.comb(n, 3)
+    assert CliqueSolver(d, 4) == math.comb(n, 4)
+    assert SglSolver(s, "diamond") == math.comb(n, 2) * math.comb(n - 2, 2)
+    assert MotifSolver(s, 3) == [0, math.comb(n, 3)]
+
+
+def test_rows_longer_than_the_lds_staging_capacity(dev):
+    """K_1100: every symmetric row (1099) exceeds the 1024-entry stage -> split chunks, HBM search;
+    DAG rows up to 1099 -> clique bit-matrix in the global scratch arena."""
+    n = 1100
+    s = _complete_graph(n).to_device(dev)
+    d = s.orient()
+    assert d.get_max_degree() == n - 1
+    assert TCSolver(d) == math.comb(n, 3)
+    assert MotifSolver(s, 3) == [0, math.comb(n, 3)]
+    assert SglSolver(s, "diamond") == math.comb(n, 2) * math.comb(n - 2, 2)
+    assert CliqueSolver(d, 4) == math.comb(n, 4)
+
+
+def test_hub_graph_against_oracle(dev):
+    g = _star_plus(5000)
+    osym = O.OGraph(g.row_ptr, g.col_idx)
+    odag = O.orient(osym)
+    s = g.to_device(dev)
+    d = s.orient()
+    assert TCSolver(d) == O.tc(odag)
+    assert MotifSolver(s, 3) == O.motif3(osym)
+    assert SglSolver(s, "diamond") == O.diamond(osym)
+    assert CliqueSolver(d, 4) == O.clique(odag, 4)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_graphs_against_oracle(dev, seed):
+    g = random_graph(2000 * seed, 30000 * seed, seed)
+    osym = O.OGraph(g.row_ptr, g.col_idx)
+    odag = O.orient(osym)
+    s = g.to_device(dev)
+    d = s.orient()
+    assert TCSolver(d) == O.tc(odag)
+    assert SglSolver(s, "diamond") == O.diamond(osym)
+    assert CliqueSolver(d, 4) == O.clique(odag, 4)
+    assert MotifSolver(s, 3) == O.motif3(osym)
+
+
+# ---- full-size, size-independent properties -------------------------------------------------------
+def test_large_rmat_properties(dev):
+    """R-MAT scale 18 (ef 16): kernels must agree with each other, with the wedge closed form
+    sum_v C(d,2) - 3T (src/motif/cpu_kernels/automine_formula.h:2-19), with the oracle's TC, and be
+    invariant under partitioning / staging."""
+    from graphminer_amd.rmat import rmat_csr_device
+
+    s, rp, ci = rmat_csr_device(18, 16, 42, dev)
+    d = s.orient()
+    t = TCSolver(d)
+    wedges, tri = MotifSolver(s, 3)
+    assert tri == t == CliqueSolver(d, 3)
+    deg = (rp[1:] - rp[:-1]).cpu().numpy().astype(object)
+    assert wedges == int(sum(x * (x - 1) // 2 for x in deg)) - 3 * t
+    assert sum(TCSolver(d, rank=r, world=4) for r in range(4)) == t
+    assert TCSolver(d, tune=[256, 4, 0, 0, 0, 1]) == t
+    host = s.download()
+    assert O.tc(O.orient(O.OGraph(host.row_ptr, host.col_idx))) == t
+    dia = SglSolver(s, "diamond")
+    assert sum(SglSolver(s, "diamond", rank=r, world=3, policy=1) for r in range(3)) == dia
+    k4 = CliqueSolver(d, 4)
+    assert sum(CliqueSolver(d, 4, rank=r, world=2) for r in range(2)) == k4
+
+
+def test_rmat_device_generator_equals_numpy(dev):
+    from graphminer_amd.rmat import rmat_csr_device
+
+    for scale, ef, seed in [(10, 16, 42), (12, 8, 7)]:
+        s, rp, ci = rmat_csr_device(scale, ef, seed, dev)
+        g = rmat_csr_numpy(scale, ef, seed)
+        assert np.array_equal(rp.cpu().numpy(), g.row_ptr)
+        assert np.array_equal(ci.cpu().numpy(), g.col_idx)
+        assert TCSolver(s.orient()) == GOLDEN[g.name]["tc"]

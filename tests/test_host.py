@@ -1,0 +1,100 @@
+"""CPU-side tests of the host logic and of the C-ABI surface (no compute calls: no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from common import GOLDEN, csr_sha, load_graph
+from graphminer_amd import _lib
+from graphminer_amd.graph import Graph, GraphFormatError
+from graphminer_amd.rmat import rmat_csr_numpy
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "graphminer_amd.h")).read()
+    declared = set(re.findall(r"\b(gm_[a-z0-9_]+)\s*\(", header))
+    declared -= {"gm_status"}
+    bound = {s[0] for s in _lib.SYMBOLS}
+    assert declared == bound, (declared - bound, bound - declared)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.gm_version() >= 100
+    assert lib.gm_strerror(_lib.GM_ERR_UNSUPPORTED) == b"Not implemented"
+
+
+def test_no_device_is_an_error_not_a_fallback():
+    """On a box without a GPU every compute entry point must fail loudly."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    lib = _lib.load()
+    n = C.c_int(-1)
+    assert lib.gm_device_count(C.byref(n)) != _lib.GM_OK and n.value == 0
+    g = load_graph("citeseer")
+    with pytest.raises(_lib.GraphMinerError):
+        g.to_device(0)
+
+
+def test_argument_validation_without_device():
+    lib = _lib.load()
+    h = C.c_void_p()
+    assert lib.gm_graph_upload(None, 0, C.byref(h)) == _lib.GM_ERR_INVALID
+    tot = C.c_uint64(7)
+    assert lib.gm_tc(None, None, C.byref(tot), None) == _lib.GM_ERR_INVALID
+    assert lib.gm_setop_batch(99, 1, None, None, None, None, None, None, None, None, None, None) == _lib.GM_ERR_INVALID
+    assert lib.gm_rmat_keys(0, 10, 1, None, None) == _lib.GM_ERR_INVALID
+
+
+def test_loader_reads_fixture_and_matches_reference_meta():
+    g = Graph(os.path.join(ROOT, "tests", "fixtures", "citeseer", "graph"))
+    assert (g.V(), g.E(), g.get_max_degree()) == (3312, 9072, 99)
+    assert g.name == "citeseer"
+    assert g.print_meta_data() == "|V|: 3312, |E|: 9072, Max Degree: 99"
+    # rows strictly ascending, symmetric, no self loops
+    for v in (0, 17, 3311):
+        r = g.N(v)
+        assert np.all(np.diff(r) > 0) and v not in r
+        for u in r:
+            assert v in g.N(int(u))
+
+
+def test_loader_error_behaviour(tmp_path):
+    with pytest.raises(FileNotFoundError):
+        Graph(str(tmp_path / "nope" / "graph"))
+    g = rmat_csr_numpy(6, 4, 1)
+    p = str(tmp_path / "g" / "graph")
+    g.save(p)
+    assert csr_sha(Graph(p)) == csr_sha(g)
+    meta = open(p + ".meta.txt").read().split()
+    meta[2] = "8"  # sizeof(vidType) != 4 -> graph.cc:30 assert
+    open(p + ".meta.txt", "w").write("\n".join(meta))
+    with pytest.raises(GraphFormatError):
+        Graph(p)
+    meta[2], meta[6] = "4", str(g.V())  # max_degree < nv violated -> graph.cc:34
+    open(p + ".meta.txt", "w").write("\n".join(meta))
+    with pytest.raises(GraphFormatError):
+        Graph(p)
+
+
+def test_rmat_is_deterministic_and_pinned():
+    for name, e in GOLDEN.items():
+        if name.startswith("_") or e["kind"] != "rmat" or e["scale"] > 12:
+            continue
+        g = rmat_csr_numpy(e["scale"], e["edge_factor"], e["seed"])
+        assert csr_sha(g) == e["csr_sha256"], name
+        assert g.max_degree == e["max_degree"]
+    a, b = rmat_csr_numpy(8, 4, 1), rmat_csr_numpy(8, 4, 2)
+    assert csr_sha(a) != csr_sha(b)
+
+
+def test_empty_and_ragged_host_graphs():
+    g = Graph(row_ptr=[0, 0, 0], col_idx=[])
+    assert (g.V(), g.E(), g.max_degree) == (2, 0, 0)
+    with pytest.raises(GraphFormatError):
+        Graph(row_ptr=[0, 2, 1], col_idx=[1])
