@@ -417,7 +417,7 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
     if (world == 1) my_edges = tab->edge_prefix[n];
     else for (long long c = rank; c < n; c += world) my_edges += tab->edge_prefix[c + 1] - tab->edge_prefix[c];
   }
-  p.grab = la->tune[1] > 0 ? la->tune[1] : 4;
+  p.grab = la->tune[1] > 0 ? la->tune[1] : 2;
   p.cost_x_step = la->tune[2] > 0 ? la->tune[2] : 1;
   p.cost_y_step = la->tune[3] > 0 ? la->tune[3] : 6;
   p.k = k;
@@ -428,11 +428,11 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
   const size_t lds = mine_lds_bytes(pat);
   int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds));
   if (la->tune[4] > 0) per_cu = la->tune[4];
-  long long want = ((long long)p.count + (long long)p.grab * kWavesPerBlock - 1) / ((long long)p.grab * kWavesPerBlock);
+  long long want = ((long long)p.count + (long long)p.grab - 1) / (long long)p.grab;
   int grid = (int)std::max<long long>(1, std::min<long long>(want, (long long)g->cu_count * per_cu));
 
   if (clique && tab->max_bit_words > 0) {
-    const size_t need = (size_t)tab->max_bit_words * sizeof(unsigned) * (size_t)grid * kWavesPerBlock;
+    const size_t need = (size_t)tab->max_bit_words * sizeof(unsigned) * (size_t)grid;  // one arena slot per workgroup
     if (need > g->scratch_bytes) {
       if (g->d_scratch) (void)hipFree(g->d_scratch);
       g->d_scratch = nullptr;

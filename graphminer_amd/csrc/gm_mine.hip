@@ -27,14 +27,22 @@
 
 namespace gm {
 
-template <int PAT>
+// per-wave scratch of the flattened passes
 struct alignas(16) WaveLds {
-  int4 desc[GM_WAVE];                     // per-edge descriptors of the current pass
-  int stage[kStageCap];                   // staged adjacency slice col[e_begin .. e_end)
-  int rpl[kMaxChunkVerts + 8];            // row offsets of the chunk's vertices (absolute)
-  unsigned char marks[kMarkWindow];       // owner marks of the flattened positions
-  unsigned cnt[GM_WAVE];                  // per-edge match counts (diamond)
+  int4 desc[GM_WAVE];                // per-edge descriptors of the current pass
+  unsigned char marks[kMarkWindow];  // owner marks of the flattened positions
+  unsigned cnt[GM_WAVE];             // per-edge match counts (diamond)
+};
+
+// per-workgroup state of the current task chunk, shared by the 4 waves
+template <int PAT>
+struct alignas(16) BlockLds {
+  int stage[kStageCap];         // staged adjacency slice col[e_begin .. e_end)
+  int rpl[kMaxChunkVerts + 8];  // row offsets of the chunk's vertices (absolute)
   unsigned bits[PAT == PAT_CLIQUE4 ? kBitWords : 4];
+  int next_batch;               // dynamic batch counter of the chunk
+  unsigned queue_pos;           // broadcast slot of the chunk dequeue
+  WaveLds w[kWavesPerBlock];
 };
 
 struct Acc {
@@ -49,57 +57,89 @@ __device__ __forceinline__ int bitlen(int x) { return 32 - __clz(x); }
 //   s_base     search list: index into L.stage (SLDS) or col[] (!SLDS)
 //   s_len_flag search-list length | flag << 30
 // act(found, owner_lane, key_index, pos_in_search_list, flag)
-template <bool SLDS, int PAT, class Act>
-__device__ __forceinline__ void flat_pass(WaveLds<PAT> &L, const int *__restrict__ col, const int lane, const int llen,
+//
+// Latency hiding: kTiles tiles (64 positions each) are resolved together, so kTiles independent
+// key loads and kTiles independent bisection chains are in flight per wave. The bisection is the
+// branch-free "binary lifting" form with a wave-uniform trip count (bit length of the longest
+// search list of the pass): no exec-mask juggling, only v_cmp/v_cndmask and one load per step.
+constexpr int kTiles = 4;
+
+template <bool SLDS, class Act>
+__device__ __forceinline__ void flat_pass(WaveLds &L, const int *__restrict__ stage, const int *__restrict__ col, const int lane, const int llen,
                                           const int key_base, const int s_base, const int s_len_flag, Act act) {
   const int incl = wave_incl_scan_add(llen);
   const int total = readlane(incl, GM_WAVE - 1);
   if (total == 0) return;  // wave-uniform
   const int off = incl - llen;
+  const int steps = bitlen(wave_max_nonneg(llen > 0 ? (s_len_flag & 0x3fffffff) : 0));
   L.desc[lane] = make_int4(key_base, off, s_base, s_len_flag);
   unsigned *m32 = reinterpret_cast<unsigned *>(L.marks);
   int carry = 0;
   for (int wb = 0; wb < total; wb += kMarkWindow) {
     const int wn = min(kMarkWindow, total - wb);
-    const int nwords = ((wn + 63) >> 6) << 4;
+    const int nwords = ((wn + GM_WAVE * kTiles - 1) / (GM_WAVE * kTiles)) * (GM_WAVE * kTiles / 4);
     for (int i = lane; i < nwords; i += GM_WAVE) m32[i] = 0u;
     wave_sync();
     if (llen > 0 && off >= wb && off < wb + kMarkWindow) L.marks[off - wb] = (unsigned char)(lane + 1);
     wave_sync();
-    for (int t = 0; t < wn; t += GM_WAVE) {
-      int own = (int)L.marks[t + lane];
-      own = max(wave_incl_scan_max(own), carry);
-      carry = readlane(own, GM_WAVE - 1);
-      const int p = wb + t + lane;
-      if (p < total) {
-        const int4 d = L.desc[own - 1];
-        const int kidx = p - d.y;
-        const int key = col[d.x + kidx];
-        const int slen = d.w & 0x3fffffff;
-        int pos;
-        bool f;
-        if (SLDS) f = contains(&L.stage[d.z], slen, key, &pos);
-        else f = contains(col + d.z, slen, key, &pos);
-        act(f, own - 1, kidx, pos, d.w >> 30);
+    for (int t = 0; t < wn; t += GM_WAVE * kTiles) {
+      int own[kTiles], key[kTiles], kidx[kTiles], sb[kTiles], sl[kTiles], fl[kTiles], lo[kTiles];
+      bool in[kTiles];
+#pragma unroll
+      for (int q = 0; q < kTiles; ++q) own[q] = (int)L.marks[t + q * GM_WAVE + lane];
+#pragma unroll
+      for (int q = 0; q < kTiles; ++q) {
+        own[q] = max(wave_incl_scan_max(own[q]), carry);
+        carry = readlane(own[q], GM_WAVE - 1);
+      }
+#pragma unroll
+      for (int q = 0; q < kTiles; ++q) {
+        const int p = wb + t + q * GM_WAVE + lane;
+        in[q] = p < total;
+        const int4 d = L.desc[in[q] ? own[q] - 1 : 0];
+        kidx[q] = p - d.y;
+        sb[q] = in[q] ? d.z : 0;
+        sl[q] = in[q] ? (d.w & 0x3fffffff) : 0;
+        fl[q] = d.w >> 30;
+        key[q] = in[q] ? col[d.x + kidx[q]] : 0;
+        lo[q] = 0;
+      }
+      // lower_bound by binary lifting: lo = #elements < key
+      for (int s = steps - 1; s >= 0; --s) {
+#pragma unroll
+        for (int q = 0; q < kTiles; ++q) {
+          const int mid = lo[q] + (1 << s);
+          const int idx = sb[q] + max(min(mid, sl[q]) - 1, 0);
+          const int x = SLDS ? stage[idx] : col[idx];
+          lo[q] = (mid <= sl[q] && x < key[q]) ? mid : lo[q];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < kTiles; ++q) {
+        const int idx = sb[q] + max(min(lo[q], sl[q] - 1), 0);
+        const int x = SLDS ? stage[idx] : col[idx];
+        const bool f = in[q] && lo[q] < sl[q] && x == key[q];
+        act(f, own[q] - 1, kidx[q], lo[q], fl[q]);
       }
     }
     wave_sync();
   }
 }
 
-template <int PAT, bool BLDS>
-__device__ __forceinline__ unsigned long long clique4_count(WaveLds<PAT> &L, const unsigned *__restrict__ bits, const int lane,
-                                                            const int eb, const int nel, const int nvl, const int stride) {
-  // sum_i sum_{j in M[i]} popc(M[i] & M[j])  ==  sum_{(v0,v1)} sum_{v2 in S1} |S1 ^ N+(v2)|
+// sum_i sum_{j in M[i]} popc(M[i] & M[j])  ==  sum_{(v0,v1)} sum_{v2 in S1} |S1 ^ N+(v2)|
+// (the second DFS level of clique4_warp_edge.cuh:22-27 on the LDS / scratch bit-matrix)
+__device__ __forceinline__ unsigned long long clique4_count(const int *__restrict__ rpl, const unsigned *__restrict__ bits,
+                                                            const int tid, const int nthreads, const int eb, const int nel,
+                                                            const int nvl, const int stride) {
   unsigned long long c = 0;
-  for (int le = lane; le < nel; le += GM_WAVE) {
+  for (int le = tid; le < nel; le += nthreads) {
     const int e = eb + le;
     int lo = 0, hi = nvl - 1;
     while (lo < hi) {
       int mid = (lo + hi + 1) >> 1;
-      if (L.rpl[mid] <= e) lo = mid; else hi = mid - 1;
+      if (rpl[mid] <= e) lo = mid; else hi = mid - 1;
     }
-    const int row0 = L.rpl[lo] - eb;  // local index of edge (u, A[0])
+    const int row0 = rpl[lo] - eb;  // local index of edge (u, A[0])
     const unsigned *Mi = bits + (size_t)le * stride;
     for (int w = 0; w < stride; ++w) {
       unsigned x = Mi[w];
@@ -115,19 +155,23 @@ __device__ __forceinline__ unsigned long long clique4_count(WaveLds<PAT> &L, con
 }
 
 template <int PAT>
-__device__ __forceinline__ void process_chunk(const MineParams &p, WaveLds<PAT> &L, const ChunkRec r, const int lane,
-                                              const int wave_slot, Acc &acc) {
+__device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT> &B, const ChunkRec r, const int lane,
+                                              const int wave, Acc &acc) {
   const int *__restrict__ rp = p.g.rp;
   const int *__restrict__ col = p.g.col;
+  WaveLds &L = B.w[wave];
+  const int tid = threadIdx.x, nthreads = kWavesPerBlock * GM_WAVE;
   const int ub = r.u_begin, nvl = r.u_end - r.u_begin;
   const int eb = r.e_begin, nel = r.e_end - r.e_begin;
 
-  for (int i = lane; i <= nvl; i += GM_WAVE) L.rpl[i] = rp[ub + i];
-  wave_sync();
-  const bool whole_rows = (eb == L.rpl[0]) && (r.e_end == L.rpl[nvl]);
+  // ---- workgroup: stage the chunk (coalesced row_ptr / col_idx loads) -----------------------------
+  for (int i = tid; i <= nvl; i += nthreads) B.rpl[i] = rp[ub + i];
+  if (tid == 0) B.next_batch = 0;
+  __syncthreads();
+  const bool whole_rows = (eb == B.rpl[0]) && (r.e_end == B.rpl[nvl]);
   const bool staged = whole_rows && (nel <= kStageCap) && !(p.flags & 1);
   if (staged)
-    for (int i = lane; i < nel; i += GM_WAVE) L.stage[i] = col[eb + i];
+    for (int i = tid; i < nel; i += nthreads) B.stage[i] = col[eb + i];
 
   // clique: adjacency bit-matrix of the chunk, one row of `stride` words per edge
   int stride = 0;
@@ -135,34 +179,40 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, WaveLds<PAT> 
   unsigned *gbits = nullptr;
   if (PAT == PAT_CLIQUE4) {
     int m = 0;
-    for (int i = lane; i < nvl; i += GM_WAVE) m = max(m, L.rpl[i + 1] - L.rpl[i]);
+    for (int i = lane; i < nvl; i += GM_WAVE) m = max(m, B.rpl[i + 1] - B.rpl[i]);
     stride = (wave_max_nonneg(m) + 31) >> 5;
     const long long words = (long long)nel * stride;
     bits_lds = words <= kBitWords;
     if (bits_lds) {
-      for (int i = lane; i < (int)words; i += GM_WAVE) L.bits[i] = 0u;
+      for (int i = tid; i < (int)words; i += nthreads) B.bits[i] = 0u;
     } else {
-      gbits = p.scratch + (size_t)wave_slot * p.scratch_words;
-      for (long long i = lane; i < words; i += GM_WAVE) gbits[i] = 0u;
+      gbits = p.scratch + (size_t)blockIdx.x * p.scratch_words;
+      for (long long i = tid; i < words; i += nthreads) gbits[i] = 0u;
     }
   }
-  wave_sync();
+  __syncthreads();
 
-  for (int le0 = 0; le0 < nel; le0 += GM_WAVE) {
+  // ---- waves: take batches of 64 edges dynamically ------------------------------------------------
+  for (;;) {
+    int bi = 0;
+    if (lane == 0) bi = atomicAdd(&B.next_batch, 1);
+    bi = readfirst(bi);
+    const int le0 = bi * GM_WAVE;
+    if (le0 >= nel) break;
     const int le = le0 + lane;
     const bool valid = le < nel;
     const int e = eb + le;
     int v = 0, u = 0, ru = 0, a = 0, rv = 0, b = 0, idx = 0;
     if (valid) {
-      if (staged) v = L.stage[le];
+      if (staged) v = B.stage[le];
       else v = col[e];
       int lo = 0, hi = nvl - 1;  // owner row: largest i with rpl[i] <= e
       while (lo < hi) {
         int mid = (lo + hi + 1) >> 1;
-        if (L.rpl[mid] <= e) lo = mid; else hi = mid - 1;
+        if (B.rpl[mid] <= e) lo = mid; else hi = mid - 1;
       }
-      ru = L.rpl[lo];
-      a = L.rpl[lo + 1] - ru;
+      ru = B.rpl[lo];
+      a = B.rpl[lo + 1] - ru;
       u = ub + lo;
       idx = e - ru;
       rv = rp[v];
@@ -208,7 +258,7 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, WaveLds<PAT> 
       } else if (PAT == PAT_CLIQUE4) {
         const int cbit = is_x ? pos : kidx;  // position of the common neighbour inside N+(u)
         const size_t word = (size_t)(le0 + owner) * stride + (cbit >> 5);
-        if (bits_lds) atomicOr(&L.bits[word], 1u << (cbit & 31));
+        if (bits_lds) atomicOr(&B.bits[word], 1u << (cbit & 31));
         else atomicOr(&gbits[word], 1u << (cbit & 31));
       }
     };
@@ -218,15 +268,15 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, WaveLds<PAT> 
       const int llen = dirx ? b : 0;
       const int s_len_flag = al | (flag << 30);
       auto actx = [&](bool f, int owner, int kidx, int pos, int fl) { on_found(f, owner, kidx, pos, fl, true); };
-      if (staged) flat_pass<true, PAT>(L, col, lane, llen, rv, ru - eb, s_len_flag, actx);
-      else flat_pass<false, PAT>(L, col, lane, llen, rv, ru, s_len_flag, actx);
+      if (staged) flat_pass<true>(L, B.stage, col, lane, llen, rv, ru - eb, s_len_flag, actx);
+      else flat_pass<false>(L, B.stage, col, lane, llen, rv, ru, s_len_flag, actx);
     }
     // pass Y
     {
       const int llen = diry ? al : 0;
       const int s_len_flag = b | (flag << 30);
       auto acty = [&](bool f, int owner, int kidx, int pos, int fl) { on_found(f, owner, kidx, pos, fl, false); };
-      flat_pass<false, PAT>(L, col, lane, llen, ru, rv, s_len_flag, acty);
+      flat_pass<false>(L, B.stage, col, lane, llen, ru, rv, s_len_flag, acty);
     }
 
     if (PAT == PAT_DIAMOND) {
@@ -237,32 +287,34 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, WaveLds<PAT> 
     }
   }
 
+  __syncthreads();  // every batch of the chunk is done (LDS is reused by the next chunk)
   if (PAT == PAT_CLIQUE4) {
-    wave_sync();
-    if (!bits_lds) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");  // own atomics -> own loads through L2
-    if (bits_lds) acc.c0 += clique4_count<PAT, true>(L, L.bits, lane, eb, nel, nvl, stride);
-    else acc.c0 += clique4_count<PAT, false>(L, gbits, lane, eb, nel, nvl, stride);
-    wave_sync();
+    if (bits_lds) {
+      acc.c0 += clique4_count(B.rpl, B.bits, tid, nthreads, eb, nel, nvl, stride);
+    } else {
+      __threadfence();  // the scratch matrix was built with device atomics by all 4 waves
+      __syncthreads();
+      acc.c0 += clique4_count(B.rpl, gbits, tid, nthreads, eb, nel, nvl, stride);
+    }
+    __syncthreads();
   }
 }
 
 template <int PAT>
 __global__ __launch_bounds__(kWavesPerBlock *GM_WAVE) void mine_kernel(const MineParams p) {
-  __shared__ WaveLds<PAT> lds[kWavesPerBlock];
+  __shared__ BlockLds<PAT> B;
   const int lane = threadIdx.x & (GM_WAVE - 1);
   const int wave = threadIdx.x >> 6;
-  const int wave_slot = blockIdx.x * kWavesPerBlock + wave;
-  WaveLds<PAT> &L = lds[wave];
   Acc acc;
   for (;;) {
-    unsigned q = 0;
-    if (lane == 0) q = atomicAdd(p.queue, (unsigned)p.grab);
-    q = (unsigned)readfirst((int)q);
+    if (threadIdx.x == 0) B.queue_pos = atomicAdd(p.queue, (unsigned)p.grab);
+    __syncthreads();
+    const unsigned q = B.queue_pos;
     if (q >= (unsigned)p.count) break;
     const unsigned qe = min(q + (unsigned)p.grab, (unsigned)p.count);
     for (unsigned i = q; i < qe; ++i) {
       const ChunkRec r = p.chunks[(size_t)p.first + (size_t)i * (size_t)p.step];
-      process_chunk<PAT>(p, L, r, lane, wave_slot, acc);
+      process_chunk<PAT>(p, B, r, lane, wave, acc);  // ends with a workgroup barrier
     }
   }
   const unsigned long long s0 = wave_sum_u64(acc.c0);
@@ -277,8 +329,8 @@ __global__ __launch_bounds__(kWavesPerBlock *GM_WAVE) void mine_kernel(const Min
 
 size_t mine_lds_bytes(Pattern pat) {
   switch (pat) {
-    case PAT_CLIQUE4: return sizeof(WaveLds<PAT_CLIQUE4>) * kWavesPerBlock;
-    default: return sizeof(WaveLds<PAT_TC>) * kWavesPerBlock;
+    case PAT_CLIQUE4: return sizeof(BlockLds<PAT_CLIQUE4>);
+    default: return sizeof(BlockLds<PAT_TC>);
   }
 }
 
