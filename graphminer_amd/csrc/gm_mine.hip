@@ -104,21 +104,35 @@ __device__ __forceinline__ void flat_pass(WaveLds &L, const int *__restrict__ st
         key[q] = in[q] ? col[d.x + kidx[q]] : 0;
         lo[q] = 0;
       }
-      // lower_bound by binary lifting: lo = #elements < key
+      // lower_bound by binary lifting: lo = #elements < key.  Written with non-short-circuit '&' and
+      // always-executed loads on purpose: with '&&' the compiler sinks each load under its range
+      // test and serialises the kTiles chains behind s_waitcnt vmcnt(0).
       for (int s = steps - 1; s >= 0; --s) {
+        int x[kTiles], mid[kTiles];
 #pragma unroll
         for (int q = 0; q < kTiles; ++q) {
-          const int mid = lo[q] + (1 << s);
-          const int idx = sb[q] + max(min(mid, sl[q]) - 1, 0);
-          const int x = SLDS ? stage[idx] : col[idx];
-          lo[q] = (mid <= sl[q] && x < key[q]) ? mid : lo[q];
+          mid[q] = lo[q] + (1 << s);
+          if (SLDS) {
+            x[q] = stage[sb[q] + mid[q] - 1];  // may read past the list (never past LDS): masked below
+          } else {
+            x[q] = col[sb[q] + max(min(mid[q], sl[q]) - 1, 0)];
+          }
         }
+#pragma unroll
+        for (int q = 0; q < kTiles; ++q) {
+          const bool take = (mid[q] <= sl[q]) & (x[q] < key[q]);
+          lo[q] = take ? mid[q] : lo[q];
+        }
+      }
+      int xf[kTiles];
+#pragma unroll
+      for (int q = 0; q < kTiles; ++q) {
+        if (SLDS) xf[q] = stage[sb[q] + lo[q]];
+        else xf[q] = col[sb[q] + max(min(lo[q], sl[q] - 1), 0)];
       }
 #pragma unroll
       for (int q = 0; q < kTiles; ++q) {
-        const int idx = sb[q] + max(min(lo[q], sl[q] - 1), 0);
-        const int x = SLDS ? stage[idx] : col[idx];
-        const bool f = in[q] && lo[q] < sl[q] && x == key[q];
+        const bool f = in[q] & (lo[q] < sl[q]) & (xf[q] == key[q]);
         act(f, own[q] - 1, kidx[q], lo[q], fl[q]);
       }
     }
