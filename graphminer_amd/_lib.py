@@ -73,6 +73,9 @@ SYMBOLS = [
     ("gm_graph_meta", C.c_int, [_P, C.POINTER(gm_csr)]),
     ("gm_graph_download", C.c_int, [_P, _P, _P]),
     ("gm_graph_free", None, [_P]),
+    ("gm_partition", C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                               C.POINTER(C.c_int64)]),
+    ("gm_chunk_table", C.c_int, [C.c_int32, _P, C.c_int32, C.c_int32, _P, C.c_int64, C.POINTER(C.c_int64)]),
     ("gm_kernel_times", C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     ("gm_tc", C.c_int, [_P, C.POINTER(gm_launch), C.POINTER(C.c_uint64), C.POINTER(gm_stats)]),
     ("gm_sgl", C.c_int, [_P, C.c_char_p, C.POINTER(gm_launch), C.POINTER(C.c_uint64), C.POINTER(gm_stats)]),

@@ -68,6 +68,8 @@ extern "C" int gm_device_count(int *n) {
 // ------------------------------------------------------------------------------------------------
 // graph handle
 // ------------------------------------------------------------------------------------------------
+constexpr int kDefaultChunk = 512;  // task edges per chunk when the caller does not say
+
 struct ChunkTable {
   int target;       // T: CSR entries per chunk
   bool allow_split; // rows longer than the staging capacity may be cut across chunks
@@ -358,6 +360,48 @@ static int get_table(gm_graph *g, int target, bool allow_split, int bit_words, C
   return GM_OK;
 }
 
+// Scheduler policy as index arithmetic on chunk ids (replaces the per-GPU COO copies of
+// Scheduler::round_robin, src/common/scheduler.cc:34-85, and EVEN_SPLIT, src/clique/multigpu.cu:42-44).
+extern "C" int gm_partition(int64_t n_chunks, int32_t rank, int32_t world, int32_t policy, int64_t *first, int64_t *step,
+                            int64_t *count) {
+  if (!first || !step || !count || n_chunks < 0) return GM_ERR_INVALID;
+  if (world < 1) world = 1;
+  if (rank < 0 || rank >= world) return GM_ERR_INVALID;
+  if (policy == GM_PART_RANGE) {
+    const long long lo = n_chunks * rank / world, hi = n_chunks * (rank + 1) / world;
+    *first = lo;
+    *step = 1;
+    *count = hi - lo;
+  } else {
+    *first = rank;
+    *step = world;
+    *count = n_chunks > rank ? (n_chunks - rank + world - 1) / world : 0;
+  }
+  return GM_OK;
+}
+
+// Host-only view of the task-chunk table (no device needed): used by the CPU-side multi-process tests.
+extern "C" int gm_chunk_table(int32_t nv, const int64_t *row_ptr, int32_t chunk, int32_t for_clique, int32_t *recs,
+                              int64_t cap, int64_t *n_out) {
+  if (!row_ptr || !n_out || nv < 0 || (cap > 0 && !recs)) return GM_ERR_INVALID;
+  std::vector<int> rp;
+  int rc = convert_offsets(row_ptr, nv, row_ptr[nv], rp);
+  if (rc) return rc;
+  int target = chunk > 0 ? chunk : kDefaultChunk;
+  target = std::max(64, std::min(target, kStageCap));
+  std::vector<ChunkRec> out;
+  unsigned long long mb = 0;
+  build_chunks(rp, nv, target, !for_clique, for_clique ? kBitWords : 0, out, mb);
+  *n_out = (int64_t)out.size();
+  for (int64_t i = 0; i < (int64_t)out.size() && i < cap; ++i) {
+    recs[4 * i + 0] = out[i].u_begin;
+    recs[4 * i + 1] = out[i].u_end;
+    recs[4 * i + 2] = out[i].e_begin;
+    recs[4 * i + 3] = out[i].e_end;
+  }
+  return GM_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // solvers
 // ------------------------------------------------------------------------------------------------
@@ -386,7 +430,7 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
 
   // tune[0] = chunk target override, tune[1] = grab, tune[2] = cost_x_step, tune[3] = cost_y_step,
   // tune[4] = blocks per CU override, tune[5] = force "search in HBM" (no LDS staging) when 1
-  int target = la->chunk > 0 ? la->chunk : 256;
+  int target = la->chunk > 0 ? la->chunk : kDefaultChunk;
   if (la->tune[0] > 0) target = la->tune[0];
   target = std::max(64, std::min(target, kStageCap));
   const bool clique = pat == PAT_CLIQUE4;
@@ -403,23 +447,18 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
   p.chunks = tab->d;
   const long long n = (long long)tab->n;
   unsigned long long my_edges = 0;
-  if (la->policy == GM_PART_RANGE) {
-    const long long lo = n * rank / world, hi = n * (rank + 1) / world;
-    p.first = (int)lo;
-    p.step = 1;
-    p.count = (int)(hi - lo);
-    my_edges = tab->edge_prefix[hi] - tab->edge_prefix[lo];
-  } else {
-    p.first = rank;
-    p.step = world;
-    p.count = (int)((n - rank + world - 1) / world);
-    if (p.count < 0) p.count = 0;
-    if (world == 1) my_edges = tab->edge_prefix[n];
-    else for (long long c = rank; c < n; c += world) my_edges += tab->edge_prefix[c + 1] - tab->edge_prefix[c];
+  {
+    long long first = 0, step = 1, count = 0;
+    gm_partition((int64_t)n, rank, world, la->policy, (int64_t *)&first, (int64_t *)&step, (int64_t *)&count);
+    p.first = (int)first;
+    p.step = (int)step;
+    p.count = (int)count;
+    if (step == 1) my_edges = tab->edge_prefix[first + count] - tab->edge_prefix[first];
+    else for (long long c = first; c < n; c += step) my_edges += tab->edge_prefix[c + 1] - tab->edge_prefix[c];
   }
-  p.grab = la->tune[1] > 0 ? la->tune[1] : 2;
-  p.cost_x_step = la->tune[2] > 0 ? la->tune[2] : 1;
-  p.cost_y_step = la->tune[3] > 0 ? la->tune[3] : 6;
+  p.grab = la->tune[1] > 0 ? la->tune[1] : 1;
+  p.cost_x_step = la->tune[2] > 0 ? la->tune[2] : 2;
+  p.cost_y_step = la->tune[3] > 0 ? la->tune[3] : 4;
   p.k = k;
   p.flags = (la->tune[5] == 1) ? 1 : 0;
   p.counters = g->d_counters;

@@ -1,0 +1,66 @@
+"""Multi-GPU glue: one process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI on the
+GPU box, "gloo" in CPU tests) for the ONE collective the path has -- the all-reduce of the 64-bit
+match counts (replaces the host-side sum of src/clique/multigpu.cu:134 and
+MPI_Allreduce of src/triangle/dist_cpu.cpp:56). The CSR is replicated; tasks are split by chunk id.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+
+
+def init_from_env(backend: str | None = None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract).
+    Returns (rank, world, local_rank)."""
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+def allreduce_counts(counts, device=None):
+    """Sum per-rank uint64 counts over all ranks. `counts`: list of ints or an int64 tensor (returned
+    as given type). Counts are < 2^63 for every graph this build accepts, so int64 transport is exact."""
+    import torch
+    import torch.distributed as dist
+
+    if isinstance(counts, torch.Tensor):
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(counts)
+        return counts
+    t = torch.tensor([int(c) for c in counts], dtype=torch.int64, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t)
+    return [int(x) for x in t.cpu().tolist()]
+
+
+def partition(n_chunks: int, rank: int, world: int, policy: int = _lib.GM_PART_ROUND_ROBIN):
+    """Chunk ids owned by `rank`: the library's own index arithmetic (gm_partition)."""
+    f, s, c = C.c_int64(), C.c_int64(), C.c_int64()
+    _lib.check(_lib.load().gm_partition(n_chunks, rank, world, policy, C.byref(f), C.byref(s), C.byref(c)), "gm_partition")
+    return range(f.value, f.value + s.value * c.value, s.value)
+
+
+def chunk_table(row_ptr, chunk: int = 0, for_clique: bool = False) -> np.ndarray:
+    """The solvers' task-chunk table for a CSR as an (n,4) int32 array {u_begin,u_end,e_begin,e_end}."""
+    rp = np.ascontiguousarray(row_ptr, dtype=np.int64)
+    lib = _lib.load()
+    n = C.c_int64()
+    _lib.check(lib.gm_chunk_table(rp.size - 1, rp.ctypes.data, chunk, int(for_clique), None, 0, C.byref(n)), "gm_chunk_table")
+    recs = np.zeros((max(n.value, 1), 4), dtype=np.int32)
+    _lib.check(lib.gm_chunk_table(rp.size - 1, rp.ctypes.data, chunk, int(for_clique), recs.ctypes.data, n.value, C.byref(n)),
+               "gm_chunk_table")
+    return recs[: n.value]

@@ -1,0 +1,248 @@
+// solvers.cc -- the four link-time solver entry points of the reference, as thin shims over the C ABI.
+//
+//   TCSolver      src/triangle/gpu_base.cu:25-72, multi-GPU src/triangle/multigpu_base.cu:25-105
+//   SglSolver     src/sgl/gpu_base.cu:21-103
+//   CliqueSolver  src/clique/gpu_base.cu:14-80,  multi-GPU src/clique/multigpu.cu:20-139
+//   MotifSolver   src/motif/gpu_base.cu:21-110
+//
+// Single GPU: upload (GraphGPU::init), one gm_* call, print the reference's runtime / throughput lines.
+// Multi GPU (n_gpu > 1), one process, n devices:
+//   * the CSR goes over PCIe ONCE (to GPU 0) and is replicated with ncclBroadcast over xGMI, instead of
+//     the reference's n host->device copies (src/clique/multigpu.cu:57-66);
+//   * the task split is index arithmetic on chunk ids inside the library (rank i owns chunks i mod n,
+//     Scheduler::round_robin policy, src/common/scheduler.cc:34-85) -- no per-GPU COO copies;
+//   * the per-GPU 64-bit counts are combined by ONE ncclAllReduce(ncclUint64, ncclSum) instead of the
+//     host-side `total += h_counts[i]` (src/clique/multigpu.cu:134) / MPI_Allreduce (src/triangle/dist_cpu.cpp:56).
+#include "graph.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <vector>
+
+namespace {
+
+#define HIP_OK(call)                                                                                   \
+  do {                                                                                                 \
+    hipError_t e_ = (call);                                                                            \
+    if (e_ != hipSuccess) {                                                                            \
+      std::fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__);      \
+      std::exit(EXIT_FAILURE);                                                                         \
+    }                                                                                                  \
+  } while (0)
+#define NCCL_OK(call)                                                                                  \
+  do {                                                                                                 \
+    ncclResult_t r_ = (call);                                                                          \
+    if (r_ != ncclSuccess) {                                                                           \
+      std::fprintf(stderr, "RCCL error %s at %s:%d\n", ncclGetErrorString(r_), __FILE__, __LINE__);    \
+      std::exit(EXIT_FAILURE);                                                                         \
+    }                                                                                                  \
+  } while (0)
+
+struct Job {
+  enum Kind { TC, SGL, CLIQUE, MOTIF } kind;
+  int k = 0;
+  const char *pattern = nullptr;
+  int ncounts = 1;
+  const char *name = "gpu_base";
+};
+
+int call(const Job &j, gm_graph *g, const gm_launch *la, uint64_t *out, gm_stats *st) {
+  switch (j.kind) {
+    case Job::TC: return gm_tc(g, la, out, st);
+    case Job::SGL: return gm_sgl(g, j.pattern, la, out, st);
+    case Job::CLIQUE: return gm_clique(g, j.k, la, out, st);
+    case Job::MOTIF: return gm_motif(g, j.k, la, out, j.ncounts, st);
+  }
+  return GM_ERR_INVALID;
+}
+
+// returns false when the pattern / k is not implemented (caller prints the reference's message)
+bool run_single(Graph &g, const Job &j, int chunk, uint64_t *out) {
+  gm_csr h = g.csr();
+  gm_graph *dg = nullptr;
+  int rc = gm_graph_upload(&h, 0, &dg);
+  if (rc) gm_die(rc, "gm_graph_upload");
+  gm_launch la;
+  std::memset(&la, 0, sizeof la);
+  la.chunk = chunk == 1024 ? 0 : chunk;  // 1024 is the reference's CLI default: keep the library default then
+  gm_stats st;
+  std::memset(&st, 0, sizeof st);
+  rc = call(j, dg, &la, out, &st);  // first call builds the task-chunk table ("Time on generating the edgelist")
+  if (rc == GM_ERR_UNSUPPORTED) { gm_graph_free(dg); return false; }
+  if (rc) gm_die(rc, "mining kernel");
+  rc = call(j, dg, &la, out, &st);  // timed call: kernel only, like the reference's Timer (gpu_base.cu:53-65)
+  if (rc) gm_die(rc, "mining kernel");
+  std::cout << "HIP " << j.name << " (" << st.grid << " workgroups, " << st.block << " threads/workgroup)\n";
+  const double sec = st.kernel_ms * 1e-3;
+  std::cout << "runtime [" << j.name << "] = " << sec << " sec\n";
+  std::cout << "throughput = " << double(st.tasks) / sec / 1e9 << " billion Traversed Edges Per Second (TEPS)\n";
+  gm_graph_free(dg);
+  return true;
+}
+
+bool run_multi(Graph &g, const Job &j, int n, int chunk, uint64_t *out) {
+  std::vector<int> devs(n);
+  for (int i = 0; i < n; ++i) devs[i] = i;
+  std::vector<ncclComm_t> comms(n);
+  NCCL_OK(ncclCommInitAll(comms.data(), n, devs.data()));
+  const size_t nv = size_t(g.V()), ne = size_t(g.E());
+  std::vector<int64_t *> d_rp(n);
+  std::vector<int32_t *> d_ci(n);
+  std::vector<uint64_t *> d_cnt(n);
+  std::vector<hipStream_t> streams(n);
+  Timer tb;
+  tb.Start();
+  for (int i = 0; i < n; ++i) {
+    HIP_OK(hipSetDevice(i));
+    HIP_OK(hipStreamCreate(&streams[i]));
+    HIP_OK(hipMalloc(&d_rp[i], sizeof(int64_t) * (nv + 1)));
+    HIP_OK(hipMalloc(&d_ci[i], sizeof(int32_t) * (ne ? ne : 1)));
+    HIP_OK(hipMalloc(&d_cnt[i], sizeof(uint64_t) * 8));
+  }
+  HIP_OK(hipSetDevice(0));
+  HIP_OK(hipMemcpyAsync(d_rp[0], g.out_rowptr(), sizeof(int64_t) * (nv + 1), hipMemcpyHostToDevice, streams[0]));
+  HIP_OK(hipMemcpyAsync(d_ci[0], g.out_colidx(), sizeof(int32_t) * ne, hipMemcpyHostToDevice, streams[0]));
+  NCCL_OK(ncclGroupStart());
+  for (int i = 0; i < n; ++i) {
+    NCCL_OK(ncclBroadcast(d_rp[i], d_rp[i], nv + 1, ncclInt64, 0, comms[i], streams[i]));
+    NCCL_OK(ncclBroadcast(d_ci[i], d_ci[i], ne, ncclInt32, 0, comms[i], streams[i]));
+  }
+  NCCL_OK(ncclGroupEnd());
+  std::vector<gm_graph *> dg(n, nullptr);
+  for (int i = 0; i < n; ++i) {
+    HIP_OK(hipSetDevice(i));
+    HIP_OK(hipStreamSynchronize(streams[i]));
+    int rc = gm_graph_from_device(int32_t(nv), int64_t(ne), d_rp[i], d_ci[i], i, &dg[i]);
+    if (rc) gm_die(rc, "gm_graph_from_device");
+  }
+  tb.Stop();
+  std::cout << "Time on replicating the CSR to " << n << " GPUs (1 PCIe copy + RCCL broadcast over xGMI): " << tb.Seconds()
+            << " sec\n";
+
+  auto launch_all = [&](bool &unsupported) {
+    for (int i = 0; i < n; ++i) {
+      gm_launch la;
+      std::memset(&la, 0, sizeof la);
+      la.stream = streams[i];
+      la.rank = i;
+      la.world = n;
+      la.policy = GM_PART_ROUND_ROBIN;
+      la.chunk = chunk == 1024 ? 0 : chunk;
+      la.d_counts = d_cnt[i];
+      int rc = call(j, dg[i], &la, nullptr, nullptr);  // asynchronous: kernels of all GPUs overlap
+      if (rc == GM_ERR_UNSUPPORTED) { unsupported = true; return; }
+      if (rc) gm_die(rc, "mining kernel");
+    }
+    NCCL_OK(ncclGroupStart());
+    for (int i = 0; i < n; ++i)
+      NCCL_OK(ncclAllReduce(d_cnt[i], d_cnt[i], size_t(j.ncounts), ncclUint64, ncclSum, comms[i], streams[i]));
+    NCCL_OK(ncclGroupEnd());
+    for (int i = 0; i < n; ++i) {
+      HIP_OK(hipSetDevice(i));
+      HIP_OK(hipStreamSynchronize(streams[i]));
+    }
+  };
+  bool unsupported = false;
+  launch_all(unsupported);  // warm-up: builds the chunk tables
+  if (!unsupported) {
+    Timer t;
+    t.Start();
+    launch_all(unsupported);
+    t.Stop();
+    for (int i = 0; i < n; ++i) {
+      double ms = 0;
+      int got = 0;
+      gm_kernel_times(dg[i], 1, &ms, &got);
+      std::cout << "runtime[gpu" << i << "] = " << ms * 1e-3 << " sec\n";  // src/clique/multigpu.cu:136-137
+    }
+    std::cout << "runtime [" << j.name << "] = " << t.Seconds() << " sec\n";
+    HIP_OK(hipSetDevice(0));
+    HIP_OK(hipMemcpy(out, d_cnt[0], sizeof(uint64_t) * size_t(j.ncounts), hipMemcpyDeviceToHost));
+  }
+  for (int i = 0; i < n; ++i) {
+    HIP_OK(hipSetDevice(i));
+    gm_graph_free(dg[i]);
+    HIP_OK(hipFree(d_rp[i]));
+    HIP_OK(hipFree(d_ci[i]));
+    HIP_OK(hipFree(d_cnt[i]));
+    HIP_OK(hipStreamDestroy(streams[i]));
+    ncclCommDestroy(comms[i]);
+  }
+  return !unsupported;
+}
+
+bool run(Graph &g, Job j, int n_gpu, int chunk, uint64_t *out) {
+  int ndev = 0;
+  int rc = gm_device_count(&ndev);
+  if (rc) gm_die(rc, "gm_device_count");
+  if (n_gpu > ndev) {
+    std::cout << "requested " << n_gpu << " GPUs, " << ndev << " available\n";
+    n_gpu = ndev;
+  }
+  // GM_FORCE_RCCL_PATH=1 drives the multi-GPU code (broadcast + all-reduce) even with one device,
+  // so the RCCL path is exercised on a single-GPU test box.
+  if (n_gpu <= 1 && !std::getenv("GM_FORCE_RCCL_PATH")) return run_single(g, j, chunk, out);
+  if (n_gpu < 1) n_gpu = 1;
+  j.name = "multigpu";
+  return run_multi(g, j, n_gpu, chunk, out);
+}
+
+}  // namespace
+
+void TCSolver(Graph &g, uint64_t &total, int n_gpu, int chunk_size) {
+  Job j;
+  j.kind = Job::TC;
+  uint64_t out[8] = {0};
+  run(g, j, n_gpu, chunk_size, out);
+  total += out[0];  // multi-GPU solvers '+=' into the caller-zeroed total (src/triangle/multigpu.cu:84)
+}
+
+void SglSolver(Graph &g, Pattern &p, uint64_t &total, int n_devices, int chunk_size) {
+  Job j;
+  j.kind = Job::SGL;
+  j.pattern = p.get_name().c_str();
+  uint64_t out[8] = {0};
+  if (!run(g, j, n_devices, chunk_size, out)) {
+    std::cout << "Not implemented\n";  // src/sgl/omp_base.cc:51-53: total stays 0
+    return;
+  }
+  total += out[0];
+}
+
+void CliqueSolver(Graph &g, int k, uint64_t &total, int n_gpu, int chunk_size) {
+  if (k < 3 || k > 8) {
+    std::cout << "Not implemented yet\n";  // src/clique/cpu_kernels/automine_omp.h:179-182
+    std::exit(0);
+  }
+  Job j;
+  j.kind = Job::CLIQUE;
+  j.k = k;
+  uint64_t out[8] = {0};
+  if (!run(g, j, n_gpu, chunk_size, out)) {
+    std::cout << "Not supported right now\n";  // src/clique/gpu_base.cu:70
+    return;
+  }
+  total += out[0];
+}
+
+void MotifSolver(Graph &g, int k, std::vector<uint64_t> &accum, int n_gpu, int chunk_size) {
+  Job j;
+  j.kind = Job::MOTIF;
+  j.k = k;
+  j.ncounts = int(accum.size());
+  if (k != 3) {
+    std::cout << "Not supported right now\n";  // src/motif/gpu_base.cu:101
+    return;
+  }
+  uint64_t out[8] = {0};
+  if (!run(g, j, n_gpu, chunk_size, out)) {
+    std::cout << "Not supported right now\n";
+    return;
+  }
+  for (size_t i = 0; i < accum.size() && i < 8; ++i) accum[i] += out[i];
+}

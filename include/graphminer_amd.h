@@ -102,6 +102,16 @@ typedef struct gm_stats {
   uint32_t block;    /* threads per workgroup */
 } gm_stats;
 
+/* The multi-GPU task split as index arithmetic: rank owns chunk ids first + i*step, i in [0,count).
+ * Host-only (no device needed). */
+int gm_partition(int64_t n_chunks, int32_t rank, int32_t world, int32_t policy, int64_t *first, int64_t *step,
+                 int64_t *count);
+/* Host-only view of the task-chunk table the solvers build for a CSR: recs receives up to `cap` records
+ * {u_begin, u_end, e_begin, e_end} (4 x int32 each); *n_out = number of chunks. for_clique = 1 gives the
+ * table of gm_clique (whole rows only). */
+int gm_chunk_table(int32_t nv, const int64_t *row_ptr, int32_t chunk, int32_t for_clique, int32_t *recs, int64_t cap,
+                   int64_t *n_out);
+
 /* HIP-event durations (ms) of the mining kernels of the most recent launches on this handle, oldest
  * first; at most 64 are remembered. The caller must have synchronised the launch stream(s).
  * This is how an asynchronous (d_counts) caller reads the kernel time the reference prints as

@@ -1,0 +1,60 @@
+"""The C++ command-line surface (tc_/sgl_/clique_|kcl_/motif_ binaries) on the GPU: argv order and the
+final result lines must be byte-identical to the reference mains."""
+import os
+import subprocess
+
+import pytest
+
+from common import GOLDEN, ROOT
+
+pytestmark = pytest.mark.gpu
+BIN = os.path.join(ROOT, "graphminer_amd", "bin")
+
+
+def run(exe, *args, env=None):
+    p = os.path.join(BIN, exe)
+    assert os.path.exists(p), f"{p} not built (make -C graphminer_amd)"
+    e = dict(os.environ, **(env or {}))
+    r = subprocess.run([p, *map(str, args)], capture_output=True, text=True, env=e, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return r.stdout.strip().splitlines()
+
+
+@pytest.mark.parametrize("name", ["citeseer", "cora"])
+def test_cli_result_lines(name):
+    e = GOLDEN[name]
+    prefix = os.path.join(ROOT, "tests", "fixtures", name, "graph")
+    out = run("tc_gpu_base", prefix)
+    assert out[0] == "Triangle Counting: we assume the neighbor lists are sorted."
+    assert f"|V|: {e['nv']}, |E|: {e['dag_ne']}, Max Degree: {e['dag_max_degree']}" in out  # post-orientation meta
+    assert out[-1] == f"total_num_triangles = {e['tc']}"
+    out = run("sgl_gpu_base", prefix, "diamond")
+    assert "Pattern: diamond" in out and out[-1] == f"total_num = {e['diamond']}"
+    out = run("sgl_gpu_base", prefix, "foo")
+    assert out[-2:] == ["Not implemented", "total_num = 0"]  # src/sgl/omp_base.cc:51-53
+    out = run("clique_gpu_base", prefix, 4)
+    assert out[-1] == f"num_4-cliques = {e['clique4']}"
+    out = run("kcl_gpu_base", prefix, 4)
+    assert f"total_num_cliques = {e['clique4']}" in out  # Pangolin spelling
+    out = run("motif_gpu_base", prefix, 3)
+    assert out[-2:] == [f"pattern 0: {e['motif3'][0]}", f"pattern 1: {e['motif3'][1]}"]
+    assert "num_patterns: 2" in out
+
+
+def test_cli_usage_exits_1():
+    r = subprocess.run([os.path.join(BIN, "tc_gpu_base")], capture_output=True, text=True)
+    assert r.returncode == 1 and r.stdout.startswith("Usage:")
+
+
+def test_rccl_path_on_one_gpu():
+    """broadcast + ncclAllReduce(uint64, sum) code path, forced with a single device"""
+    e = GOLDEN["citeseer"]
+    prefix = os.path.join(ROOT, "tests", "fixtures", "citeseer", "graph")
+    env = {"GM_FORCE_RCCL_PATH": "1"}
+    assert run("tc_multigpu", prefix, 1, env=env)[-1] == f"total_num_triangles = {e['tc']}"
+    assert run("clique_multigpu", prefix, 4, 1, env=env)[-1] == f"num_4-cliques = {e['clique4']}"
+    out = run("motif_multigpu", prefix, 3, 1, env=env)
+    assert out[-2:] == [f"pattern 0: {e['motif3'][0]}", f"pattern 1: {e['motif3'][1]}"]
+    assert run("sgl_multigpu", prefix, "diamond", 1, env=env)[-1] == f"total_num = {e['diamond']}"
+    # asking for more GPUs than present clamps (the reference would fail in cudaSetDevice)
+    assert run("tc_multigpu", prefix, 8)[-1] == f"total_num_triangles = {e['tc']}"
