@@ -457,10 +457,14 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
     else for (long long c = first; c < n; c += step) my_edges += tab->edge_prefix[c + 1] - tab->edge_prefix[c];
   }
   p.grab = la->tune[1] > 0 ? la->tune[1] : 1;
-  p.cost_x_step = la->tune[2] > 0 ? la->tune[2] : 2;
-  p.cost_y_step = la->tune[3] > 0 ? la->tune[3] : 4;
+  // direction rule: X if b*(xb + xs*lg a) <= a*(yb + ys*lg b); tune[2] = xs+1, tune[3] = ys+1, tune[7] = xb*16 + yb
+  p.cost_x_step = la->tune[2] > 0 ? la->tune[2] - 1 : 1;
+  p.cost_y_step = la->tune[3] > 0 ? la->tune[3] - 1 : 4;
+  p.cost_x_base = la->tune[7] > 0 ? (la->tune[7] >> 4) : 2;
+  p.cost_y_base = la->tune[7] > 0 ? (la->tune[7] & 15) : 2;
   p.k = k;
   p.flags = (la->tune[5] == 1) ? 1 : 0;
+  p.flags |= (la->tune[6] & 63) << 1;  // debug/ablation: bit1 skip clique phase 2, bit2 skip bit-matrix writes (counts wrong)
   p.counters = g->d_counters;
   p.queue = reinterpret_cast<unsigned *>(g->d_counters + 4);
 

@@ -10,7 +10,11 @@ namespace gm {
 constexpr int kWavesPerBlock = 4;         // 256-thread workgroups, the 4 waves work independently
 constexpr int kStageCap = 1024;           // adjacency entries one wave stages in LDS (4 KB)
 constexpr int kMaxChunkVerts = 256;       // rows per task chunk (local row_ptr slice in LDS)
-constexpr int kMarkWindow = 1024;         // flattened positions resolved per owner-mark window
+constexpr int kMarkWindow = 512;          // flattened positions resolved per owner-mark window
+constexpr int kFilterLog2 = 14;           // hashed membership filter: 2^14 bits (2 KB) per workgroup
+constexpr int kFilterBits = 1 << kFilterLog2;
+constexpr int kFilterWords = kFilterBits / 32;
+constexpr int kQueueCap = 320;            // candidate queue entries per wave (63 left over + 4 tiles)
 constexpr int kBitWords = 2048;           // clique: LDS words for the per-chunk adjacency bit-matrix (8 KB)
 
 // Task chunk = a contiguous vertex range [u_begin,u_end) and the CSR entries [e_begin,e_end) it owns.
@@ -40,8 +44,10 @@ struct MineParams {
   unsigned long long scratch_words;
   int cost_x_step;  // direction heuristic, see choose_dir()
   int cost_y_step;
+  int cost_x_base;
+  int cost_y_base;
   int k;
-  int flags;  // bit 0: never stage adjacency in LDS (A/B switch: every search goes to HBM/L2)
+  int flags;  // bit 0: never stage adjacency in LDS; bit 3: no hashed filter in front of the LDS bisection (A/B switches)
 };
 
 // host-side launchers (gm_mine.hip)

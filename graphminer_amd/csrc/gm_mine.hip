@@ -32,6 +32,8 @@ struct alignas(16) WaveLds {
   int4 desc[GM_WAVE];                // per-edge descriptors of the current pass
   unsigned char marks[kMarkWindow];  // owner marks of the flattened positions
   unsigned cnt[GM_WAVE];             // per-edge match counts (diamond)
+  int qkey[kQueueCap];               // candidate queue of the filtered pass: keys that passed the bit filter
+  unsigned char qown[kQueueCap];     // ... and the batch lane (edge) they belong to
 };
 
 // per-workgroup state of the current task chunk, shared by the 4 waves
@@ -40,6 +42,8 @@ struct alignas(16) BlockLds {
   int stage[kStageCap];         // staged adjacency slice col[e_begin .. e_end)
   int rpl[kMaxChunkVerts + 8];  // row offsets of the chunk's vertices (absolute)
   unsigned bits[PAT == PAT_CLIQUE4 ? kBitWords : 4];
+  unsigned fbits[kFilterWords];        // hashed membership filter over (row, neighbour) pairs of the staged slice
+  unsigned char lrow[kStageCap];       // local row of every staged entry
   int next_batch;               // dynamic batch counter of the chunk
   unsigned queue_pos;           // broadcast slot of the chunk dequeue
   WaveLds w[kWavesPerBlock];
@@ -50,6 +54,13 @@ struct Acc {
 };
 
 __device__ __forceinline__ int bitlen(int x) { return 32 - __clz(x); }
+
+// Filter hash of (neighbour id, row salt) -> bit index. 24-bit multiplicative hash (v_mul_u32_u24 is full rate).
+__device__ __forceinline__ unsigned filter_hash(int x, unsigned salt) {
+  const unsigned xl = ((unsigned)x ^ ((unsigned)x >> 24)) & 0xffffffu;
+  return ((__umul24(xl, 0x9E3779u) >> (32 - kFilterLog2)) ^ salt) & (unsigned)(kFilterBits - 1);
+}
+__device__ __forceinline__ unsigned filter_salt(int local_row) { return ((unsigned)local_row * 0x2545u) & (unsigned)(kFilterBits - 1); }
 
 // One flattened pass over the 64 edges of a batch.
 //   llen       lookup-list length of this lane's edge (0 = edge not in this pass)
@@ -140,6 +151,177 @@ __device__ __forceinline__ void flat_pass(WaveLds &L, const int *__restrict__ st
   }
 }
 
+// Exact bisection of up to kTiles*64 queued candidates (key, edge) against the LDS-staged rows.
+template <class Act>
+__device__ __forceinline__ void drain_candidates(WaveLds &L, const int *__restrict__ stage, const int lane, const int n,
+                                                 const int steps, Act act) {
+  int own[kTiles], key[kTiles], sb[kTiles], sl[kTiles], fl[kTiles], lo[kTiles];
+  bool in[kTiles];
+#pragma unroll
+  for (int q = 0; q < kTiles; ++q) {
+    const int slot = q * GM_WAVE + lane;
+    in[q] = slot < n;
+    key[q] = in[q] ? L.qkey[slot] : 0;
+    own[q] = in[q] ? (int)L.qown[slot] : 0;
+  }
+#pragma unroll
+  for (int q = 0; q < kTiles; ++q) {
+    const int4 d = L.desc[own[q]];
+    sb[q] = d.z & 0xffff;
+    sl[q] = in[q] ? (d.w & 0x3fffffff) : 0;
+    fl[q] = d.w >> 30;
+    lo[q] = 0;
+  }
+  for (int s = steps - 1; s >= 0; --s) {
+    int x[kTiles], mid[kTiles];
+#pragma unroll
+    for (int q = 0; q < kTiles; ++q) {
+      mid[q] = lo[q] + (1 << s);
+      x[q] = stage[sb[q] + mid[q] - 1];
+    }
+#pragma unroll
+    for (int q = 0; q < kTiles; ++q) {
+      const bool take = (mid[q] <= sl[q]) & (x[q] < key[q]);
+      lo[q] = take ? mid[q] : lo[q];
+    }
+  }
+  int xf[kTiles];
+#pragma unroll
+  for (int q = 0; q < kTiles; ++q) xf[q] = stage[sb[q] + lo[q]];
+#pragma unroll
+  for (int q = 0; q < kTiles; ++q) {
+    const bool f = in[q] & (lo[q] < sl[q]) & (xf[q] == key[q]);
+    act(f, own[q], 0, lo[q], fl[q]);
+  }
+}
+
+// Pass X on a staged chunk with the hashed bit filter in front of the bisection. ~90 % of the streamed keys are
+// not in the row they are tested against: they cost one hash + one ds_read_b32 here. The survivors are
+// compacted (ballot + v_mbcnt) into a per-wave LDS queue and bisected 64..256 at a time with all lanes busy.
+//   s_base carries the row's filter salt in bits 16..29.
+// Two regimes share the queue:
+//   * LONG lookup lists (>= kLongList keys) are streamed one edge at a time with a wave-uniform descriptor
+//     (scalar base address, scalar salt): no owner marks, no scans -- this is where skewed graphs spend their time;
+//   * the remaining short lists of the batch are flattened (owner marks + DPP max-scan), with a fast path for
+//     tiles that contain no list boundary.
+constexpr int kLongList = 192;
+
+template <class Act>
+__device__ __forceinline__ void flat_pass_filtered(WaveLds &L, const int *__restrict__ stage, const unsigned *__restrict__ fbits,
+                                                   const int *__restrict__ col, const int lane, const int llen_all,
+                                                   const int key_base, const int s_base_salt, const int s_len_flag, const int dbg, Act act) {
+  if (wave_max_nonneg(llen_all) == 0) return;  // wave-uniform
+  const int steps = bitlen(wave_max_nonneg(llen_all > 0 ? (s_len_flag & 0x3fffffff) : 0));
+  const bool is_long = llen_all >= kLongList;
+  const int llen = is_long ? 0 : llen_all;
+  const int incl = wave_incl_scan_add(llen);
+  const int total = readlane(incl, GM_WAVE - 1);
+  const int off = incl - llen;
+  L.desc[lane] = make_int4(key_base, off, s_base_salt, s_len_flag);
+  int qcount = 0;  // wave-uniform number of queued candidates
+
+  auto enqueue = [&](const bool cand, const int key, const int owner) {
+    const unsigned long long m = __ballot(cand);
+    if (cand) {
+      const int slot = qcount + rank_below(m);
+      L.qkey[slot] = key;
+      L.qown[slot] = (unsigned char)owner;
+    }
+    qcount += __popcll(m);
+  };
+  auto drain_full_tiles = [&]() {
+    if (qcount >= GM_WAVE) {  // wave-uniform
+      wave_sync();
+      const int n = qcount & ~(GM_WAVE - 1);
+      if (!(dbg & 16)) drain_candidates(L, stage, lane, n, steps, act);
+      const int rest = qcount - n;  // < 64: move to the front
+      int k = 0;
+      unsigned char o = 0;
+      if (lane < rest) { k = L.qkey[n + lane]; o = L.qown[n + lane]; }
+      wave_sync();
+      if (lane < rest) { L.qkey[lane] = k; L.qown[lane] = o; }
+      qcount = rest;
+    }
+  };
+
+  // ---- long lists: one edge at a time, wave-uniform descriptor -----------------------------------------
+  unsigned long long lm = __ballot(is_long);
+  while (lm) {
+    const int src = __ffsll((long long)lm) - 1;
+    lm &= lm - 1;
+    const int base = readlane(key_base, src);
+    const int n = readlane(llen_all, src);
+    const unsigned salt = (unsigned)readlane(s_base_salt, src) >> 16;
+    const int *__restrict__ kp = col + base;
+    for (int t = 0; t < n; t += GM_WAVE * kTiles) {
+      int key[kTiles];
+      unsigned h[kTiles], fw[kTiles];
+      bool in[kTiles];
+#pragma unroll
+      for (int q = 0; q < kTiles; ++q) {
+        const int p = t + q * GM_WAVE + lane;
+        in[q] = p < n;
+        key[q] = in[q] ? kp[p] : 0;
+      }
+#pragma unroll
+      for (int q = 0; q < kTiles; ++q) {
+        h[q] = filter_hash(key[q], salt);
+        fw[q] = fbits[h[q] >> 5];
+      }
+#pragma unroll
+      for (int q = 0; q < kTiles; ++q) enqueue(in[q] & (((fw[q] >> (h[q] & 31u)) & 1u) != 0u), key[q], src);
+      drain_full_tiles();
+    }
+  }
+
+  // ---- short lists: flattened ---------------------------------------------------------------------------
+  unsigned *m32 = reinterpret_cast<unsigned *>(L.marks);
+  int carry = 0;
+  for (int wb = 0; wb < total; wb += kMarkWindow) {
+    const int wn = min(kMarkWindow, total - wb);
+    const int nwords = ((wn + GM_WAVE * kTiles - 1) / (GM_WAVE * kTiles)) * (GM_WAVE * kTiles / 4);
+    for (int i = lane; i < nwords; i += GM_WAVE) m32[i] = 0u;
+    wave_sync();
+    if (llen > 0 && off >= wb && off < wb + kMarkWindow) L.marks[off - wb] = (unsigned char)(lane + 1);
+    wave_sync();
+    for (int t = 0; t < wn; t += GM_WAVE * kTiles) {
+      int own[kTiles], key[kTiles];
+      unsigned h[kTiles], fw[kTiles];
+      bool in[kTiles];
+#pragma unroll
+      for (int q = 0; q < kTiles; ++q) own[q] = (int)L.marks[t + q * GM_WAVE + lane];
+#pragma unroll
+      for (int q = 0; q < kTiles; ++q) {
+        if (__ballot(own[q] != 0) == 0ull) {
+          own[q] = carry;  // no list starts inside this tile: every position belongs to the running owner
+        } else {
+          own[q] = max(wave_incl_scan_max(own[q]), carry);
+          carry = readlane(own[q], GM_WAVE - 1);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < kTiles; ++q) {
+        const int p = wb + t + q * GM_WAVE + lane;
+        in[q] = p < total;
+        const int4 d = L.desc[in[q] ? own[q] - 1 : 0];
+        key[q] = (in[q] && !(dbg & 64)) ? col[d.x + (p - d.y)] : (d.x + p);
+        h[q] = filter_hash(key[q], (unsigned)d.z >> 16);
+      }
+#pragma unroll
+      for (int q = 0; q < kTiles; ++q) fw[q] = (dbg & 32) ? 0u : fbits[h[q] >> 5];
+#pragma unroll
+      for (int q = 0; q < kTiles; ++q) enqueue(in[q] & (((fw[q] >> (h[q] & 31u)) & 1u) != 0u), key[q], own[q] - 1);
+      drain_full_tiles();
+    }
+    wave_sync();
+  }
+  if (qcount > 0) {
+    wave_sync();
+    drain_candidates(L, stage, lane, qcount, steps, act);
+  }
+  wave_sync();
+}
+
 // sum_i sum_{j in M[i]} popc(M[i] & M[j])  ==  sum_{(v0,v1)} sum_{v2 in S1} |S1 ^ N+(v2)|
 // (the second DFS level of clique4_warp_edge.cuh:22-27 on the LDS / scratch bit-matrix)
 __device__ __forceinline__ unsigned long long clique4_count(const int *__restrict__ rpl, const unsigned *__restrict__ bits,
@@ -184,8 +366,12 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
   __syncthreads();
   const bool whole_rows = (eb == B.rpl[0]) && (r.e_end == B.rpl[nvl]);
   const bool staged = whole_rows && (nel <= kStageCap) && !(p.flags & 1);
-  if (staged)
+  const bool use_filter = staged && !(p.flags & 8);
+  if (staged) {
+    if (use_filter)
+      for (int i = tid; i < kFilterWords; i += nthreads) B.fbits[i] = 0u;
     for (int i = tid; i < nel; i += nthreads) B.stage[i] = col[eb + i];
+  }
 
   // clique: adjacency bit-matrix of the chunk, one row of `stride` words per edge
   int stride = 0;
@@ -205,6 +391,22 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
     }
   }
   __syncthreads();
+  if (staged) {  // local row of every staged entry (+ its filter bit)
+    for (int i = tid; i < nel; i += nthreads) {
+      const int e = eb + i;
+      int lo = 0, hi = nvl - 1;  // owner row: largest r with rpl[r] <= e
+      while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (B.rpl[mid] <= e) lo = mid; else hi = mid - 1;
+      }
+      B.lrow[i] = (unsigned char)lo;
+      if (use_filter) {
+        const unsigned h = filter_hash(B.stage[i], filter_salt(lo));
+        atomicOr(&B.fbits[h >> 5], 1u << (h & 31u));
+      }
+    }
+    __syncthreads();
+  }
 
   // ---- waves: take batches of 64 edges dynamically ------------------------------------------------
   for (;;) {
@@ -216,15 +418,21 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
     const int le = le0 + lane;
     const bool valid = le < nel;
     const int e = eb + le;
-    int v = 0, u = 0, ru = 0, a = 0, rv = 0, b = 0, idx = 0;
+    int v = 0, u = 0, ru = 0, a = 0, rv = 0, b = 0, idx = 0, lrow_of_lane = 0;
     if (valid) {
-      if (staged) v = B.stage[le];
-      else v = col[e];
-      int lo = 0, hi = nvl - 1;  // owner row: largest i with rpl[i] <= e
-      while (lo < hi) {
-        int mid = (lo + hi + 1) >> 1;
-        if (B.rpl[mid] <= e) lo = mid; else hi = mid - 1;
+      int lo = 0;
+      if (staged) {
+        v = B.stage[le];
+        lo = (int)B.lrow[le];
+      } else {
+        v = col[e];
+        int hi = nvl - 1;  // owner row: largest i with rpl[i] <= e
+        while (lo < hi) {
+          int mid = (lo + hi + 1) >> 1;
+          if (B.rpl[mid] <= e) lo = mid; else hi = mid - 1;
+        }
       }
+      lrow_of_lane = lo;
       ru = B.rpl[lo];
       a = B.rpl[lo + 1] - ru;
       u = ub + lo;
@@ -247,8 +455,8 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
     bool dirx = false;
     if (act) {
       if (staged) {
-        const float cx = (float)b * (float)(2 + p.cost_x_step * bitlen(al));
-        const float cy = (float)al * (float)(2 + p.cost_y_step * bitlen(b));
+        const float cx = (float)b * (float)(p.cost_x_base + p.cost_x_step * bitlen(al));
+        const float cy = (float)al * (float)(p.cost_y_base + p.cost_y_step * bitlen(b));
         dirx = cx <= cy;
       } else {
         dirx = b <= al;
@@ -270,8 +478,9 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
         acc.c0 += 1;               // |A' ^ B| summed over all directed edges
         acc.c1 += (unsigned)fl;    // ... over edges with v1 < v0  (triangles)
       } else if (PAT == PAT_CLIQUE4) {
+        if (p.flags & 4) { acc.c1 += 1; return; }
         const int cbit = is_x ? pos : kidx;  // position of the common neighbour inside N+(u)
-        const size_t word = (size_t)(le0 + owner) * stride + (cbit >> 5);
+        const int word = (le0 + owner) * stride + (cbit >> 5);
         if (bits_lds) atomicOr(&B.bits[word], 1u << (cbit & 31));
         else atomicOr(&gbits[word], 1u << (cbit & 31));
       }
@@ -282,7 +491,10 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
       const int llen = dirx ? b : 0;
       const int s_len_flag = al | (flag << 30);
       auto actx = [&](bool f, int owner, int kidx, int pos, int fl) { on_found(f, owner, kidx, pos, fl, true); };
-      if (staged) flat_pass<true>(L, B.stage, col, lane, llen, rv, ru - eb, s_len_flag, actx);
+      if (use_filter)
+        flat_pass_filtered(L, B.stage, B.fbits, col, lane, llen, rv, (ru - eb) | (int)(filter_salt(lrow_of_lane) << 16),
+                           s_len_flag, p.flags, actx);
+      else if (staged) flat_pass<true>(L, B.stage, col, lane, llen, rv, ru - eb, s_len_flag, actx);
       else flat_pass<false>(L, B.stage, col, lane, llen, rv, ru, s_len_flag, actx);
     }
     // pass Y
@@ -302,7 +514,7 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
   }
 
   __syncthreads();  // every batch of the chunk is done (LDS is reused by the next chunk)
-  if (PAT == PAT_CLIQUE4) {
+  if (PAT == PAT_CLIQUE4 && !(p.flags & 2)) {
     if (bits_lds) {
       acc.c0 += clique4_count(B.rpl, B.bits, tid, nthreads, eb, nel, nvl, stride);
     } else {
@@ -315,7 +527,7 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
 }
 
 template <int PAT>
-__global__ __launch_bounds__(kWavesPerBlock *GM_WAVE) void mine_kernel(const MineParams p) {
+__global__ __launch_bounds__(kWavesPerBlock *GM_WAVE, PAT == PAT_CLIQUE4 ? 5 : 8) void mine_kernel(const MineParams p) {
   __shared__ BlockLds<PAT> B;
   const int lane = threadIdx.x & (GM_WAVE - 1);
   const int wave = threadIdx.x >> 6;

@@ -9,20 +9,20 @@ from graphminer_amd.rmat import rmat_csr_device
 ap = argparse.ArgumentParser()
 ap.add_argument("--scale", type=int, default=22); ap.add_argument("--ef", type=int, default=10)
 ap.add_argument("--workload", default="tc"); ap.add_argument("--reps", type=int, default=3)
-ap.add_argument("--T", default="256"); ap.add_argument("--grab", default="2"); ap.add_argument("--cx", default="1")
-ap.add_argument("--cy", default="6"); ap.add_argument("--bpc", default="0"); ap.add_argument("--nostage", default="0")
+ap.add_argument("--T", default="512"); ap.add_argument("--grab", default="1"); ap.add_argument("--cx", default="0")
+ap.add_argument("--cy", default="0"); ap.add_argument("--bpc", default="0"); ap.add_argument("--nostage", default="0"); ap.add_argument("--dbg", default="0"); ap.add_argument("--base", default="0")
 a = ap.parse_args()
 sym, rp, ci = rmat_csr_device(a.scale, a.ef, 42, 0)
 g = sym.orient() if a.workload in ("tc", "clique4") else sym
 fn = {"tc": lambda **k: TCSolver(g, **k), "diamond": lambda **k: SglSolver(g, "diamond", **k),
       "clique4": lambda **k: CliqueSolver(g, 4, **k), "motif3": lambda **k: MotifSolver(g, 3, **k)}[a.workload]
 L = lambda s: [int(x) for x in s.split(",")]
-base = None
-for T, gr, cx, cy, bpc, ns in itertools.product(L(a.T), L(a.grab), L(a.cx), L(a.cy), L(a.bpc), L(a.nostage)):
-    tune = [T, gr, cx, cy, bpc, ns]
+ref_count = None
+for T, gr, cx, cy, bpc, ns, dbg, base in itertools.product(L(a.T), L(a.grab), L(a.cx), L(a.cy), L(a.bpc), L(a.nostage), L(a.dbg), L(a.base)):
+    tune = [T, gr, cx, cy, bpc, ns, dbg, base]
     ms = []
     for _ in range(a.reps):
         r, st = fn(tune=tune, return_stats=True)
         ms.append(st.kernel_ms)
-    if base is None: base = r
-    print(f"tune={tune} kernel_ms min={min(ms):.3f} med={sorted(ms)[len(ms)//2]:.3f} count_ok={r == base} grid={st.grid}", flush=True)
+    if ref_count is None: ref_count = r
+    print(f"maxdeg={g.get_max_degree()} ne={g.E()} tune={tune} kernel_ms min={min(ms):.3f} med={sorted(ms)[len(ms)//2]:.3f} count_ok={r == ref_count} grid={st.grid}", flush=True)
