@@ -350,6 +350,36 @@ __device__ __forceinline__ unsigned long long clique4_count(const int *__restric
   return c;
 }
 
+// Same sum for a matrix that lives in the global scratch arena (one big vertex, rows 0..nel-1, row0 = 0):
+// one wave per row i, lane w holds word w of M_i, the set bits j of M_i are walked with scalar code and the
+// rows M_j are fetched with coalesced loads, four independent loads in flight.
+__device__ __forceinline__ unsigned long long clique4_count_wide(const unsigned *__restrict__ bits, const int lane, const int wave,
+                                                                 const int nel, const int stride) {
+  // requires stride <= 64 (rows up to 2048 columns): lane w holds word w of M_i
+  unsigned long long c = 0;
+  for (int i = wave; i < nel; i += kWavesPerBlock) {
+    const unsigned mi = (lane < stride) ? bits[(size_t)i * stride + lane] : 0u;
+    for (int w = 0; w < stride; ++w) {
+      unsigned x = (unsigned)readlane((int)mi, w);  // wave-uniform: the set bits of word w select rows j
+      while (x) {
+        int j[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int bit = x ? (__ffs((int)x) - 1) : 0;
+          j[k] = x ? (w * 32 + bit) : -1;
+          x = x ? (x & (x - 1)) : 0u;
+        }
+        unsigned m[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m[k] = (j[k] >= 0 && lane < stride) ? bits[(size_t)j[k] * stride + lane] : 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) c += (unsigned)__popc(mi & m[k]);
+      }
+    }
+  }
+  return c;
+}
+
 template <int PAT>
 __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT> &B, const ChunkRec r, const int lane,
                                               const int wave, Acc &acc) {
@@ -375,7 +405,8 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
 
   // clique: adjacency bit-matrix of the chunk, one row of `stride` words per edge
   int stride = 0;
-  bool bits_lds = true;
+  bool bits_lds = true, grouped = false;
+  int grp_rows = nel > 0 ? nel : 1;
   unsigned *gbits = nullptr;
   if (PAT == PAT_CLIQUE4) {
     int m = 0;
@@ -386,8 +417,17 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
     if (bits_lds) {
       for (int i = tid; i < (int)words; i += nthreads) B.bits[i] = 0u;
     } else {
+      // a big vertex: its matrix lives in the scratch arena, but it is BUILT in LDS, kGroup rows at a time,
+      // and flushed with plain coalesced stores (no device atomics). Only rows wider than the LDS budget
+      // (stride > kBitWords/64) fall back to atomics on the arena.
       gbits = p.scratch + (size_t)blockIdx.x * p.scratch_words;
-      for (long long i = tid; i < words; i += nthreads) gbits[i] = 0u;
+      const int r = (kBitWords / stride) & ~(GM_WAVE - 1);
+      if (r >= GM_WAVE) {
+        grouped = true;
+        grp_rows = r;
+      } else {
+        for (long long i = tid; i < words; i += nthreads) gbits[i] = 0u;
+      }
     }
   }
   __syncthreads();
@@ -409,12 +449,19 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
   }
 
   // ---- waves: take batches of 64 edges dynamically ------------------------------------------------
+  for (int g0 = 0; g0 < nel; g0 += grp_rows) {  // one trip unless a big clique vertex is built in row groups
+  const int gend = min(nel, g0 + grp_rows);
+  if (PAT == PAT_CLIQUE4 && grouped) {
+    for (int i = tid; i < (gend - g0) * stride; i += nthreads) B.bits[i] = 0u;
+    if (tid == 0) B.next_batch = g0 / GM_WAVE;
+    __syncthreads();
+  }
   for (;;) {
     int bi = 0;
     if (lane == 0) bi = atomicAdd(&B.next_batch, 1);
     bi = readfirst(bi);
     const int le0 = bi * GM_WAVE;
-    if (le0 >= nel) break;
+    if (le0 >= gend) break;
     const int le = le0 + lane;
     const bool valid = le < nel;
     const int e = eb + le;
@@ -482,6 +529,7 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
         const int cbit = is_x ? pos : kidx;  // position of the common neighbour inside N+(u)
         const int word = (le0 + owner) * stride + (cbit >> 5);
         if (bits_lds) atomicOr(&B.bits[word], 1u << (cbit & 31));
+        else if (grouped) atomicOr(&B.bits[word - g0 * stride], 1u << (cbit & 31));
         else atomicOr(&gbits[word], 1u << (cbit & 31));
       }
     };
@@ -512,15 +560,22 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
       wave_sync();
     }
   }
+  if (PAT == PAT_CLIQUE4 && grouped) {  // flush the finished rows of this group to the arena
+    __syncthreads();
+    for (int i = tid; i < (gend - g0) * stride; i += nthreads) gbits[(size_t)g0 * stride + i] = B.bits[i];
+    __syncthreads();
+  }
+  }  // row groups
 
   __syncthreads();  // every batch of the chunk is done (LDS is reused by the next chunk)
   if (PAT == PAT_CLIQUE4 && !(p.flags & 2)) {
     if (bits_lds) {
       acc.c0 += clique4_count(B.rpl, B.bits, tid, nthreads, eb, nel, nvl, stride);
     } else {
-      __threadfence();  // the scratch matrix was built with device atomics by all 4 waves
+      __threadfence();  // the scratch matrix was written by all 4 waves (plain stores or device atomics)
       __syncthreads();
-      acc.c0 += clique4_count(B.rpl, gbits, tid, nthreads, eb, nel, nvl, stride);
+      if (nvl == 1 && stride <= GM_WAVE) acc.c0 += clique4_count_wide(gbits, lane, wave, nel, stride);
+      else acc.c0 += clique4_count(B.rpl, gbits, tid, nthreads, eb, nel, nvl, stride);
     }
     __syncthreads();
   }
