@@ -87,9 +87,11 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path to measure)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("GM_BENCH_FORCE_DIST") == "1"  # the latter: exercise RCCL with one rank
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from graphminer_amd import Graph, _lib
     from graphminer_amd._lib import gm_launch, gm_stats
@@ -131,12 +133,12 @@ def main():
         else:
             rc = lib.gm_motif(g.handle, 3, C.byref(la), None, 2, C.byref(st))
         _lib.check(rc, "bench step")
-        if world > 1:
+        if use_dist:
             dist.all_reduce(counts)  # ONE RCCL all-reduce of the 64-bit counts
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -148,7 +150,7 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -217,7 +219,7 @@ def main():
             if stride == 1:
                 out["cpu_baseline"]["count_matches_gpu"] = bool(cnt == result[0])
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

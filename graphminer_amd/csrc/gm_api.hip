@@ -433,7 +433,7 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
   int target = la->chunk > 0 ? la->chunk : kDefaultChunk;
   if (la->tune[0] > 0) target = la->tune[0];
   target = std::max(64, std::min(target, kStageCap));
-  const bool clique = pat == PAT_CLIQUE4;
+  const bool clique = pat == PAT_CLIQUE4 || pat == PAT_CLIQUEK;
   ChunkTable *tab = nullptr;
   int rc = get_table(g, target, !clique, clique ? kBitWords : 0, &tab);
   if (rc) return rc;
@@ -551,9 +551,15 @@ extern "C" int gm_sgl(const gm_graph *sym, const char *pattern, const gm_launch 
 
 extern "C" int gm_clique(const gm_graph *dag, int k, const gm_launch *la, uint64_t *total, gm_stats *st) {
   if (k == 3) return run_pattern(PAT_TC, dag, la, 3, total, 1, st);
-  if (k == 4) return run_pattern(PAT_CLIQUE4, dag, la, 4, total, 1, st);
-  if (total) *total = 0;
-  return (k < 3 || k > 8) ? GM_ERR_INVALID : GM_ERR_UNSUPPORTED;
+  if (k < 3 || k > 8) {
+    if (total) *total = 0;
+    return GM_ERR_INVALID;
+  }
+  if (k > 4 && dag && dag->max_deg > 2048) {  // deeper levels need the whole row in one 64-lane sweep
+    if (total) *total = 0;
+    return GM_ERR_UNSUPPORTED;
+  }
+  return run_pattern(k == 4 ? PAT_CLIQUE4 : PAT_CLIQUEK, dag, la, k, total, 1, st);
 }
 
 extern "C" int gm_motif(const gm_graph *sym, int k, const gm_launch *la, uint64_t *counts, int ncounts, gm_stats *st) {

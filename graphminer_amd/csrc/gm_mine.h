@@ -31,7 +31,7 @@ struct GraphView {
   const int *col;  // col_idx
 };
 
-enum Pattern : int { PAT_TC = 0, PAT_DIAMOND = 1, PAT_MOTIF3 = 2, PAT_CLIQUE4 = 3 };
+enum Pattern : int { PAT_TC = 0, PAT_DIAMOND = 1, PAT_MOTIF3 = 2, PAT_CLIQUE4 = 3, PAT_CLIQUEK = 4 /* k = 5..8 */ };
 
 struct MineParams {
   GraphView g;

@@ -27,6 +27,8 @@
 
 namespace gm {
 
+#define GM_IS_CLIQUE(P) ((P) == PAT_CLIQUE4 || (P) == PAT_CLIQUEK)
+
 // per-wave scratch of the flattened passes
 struct alignas(16) WaveLds {
   int4 desc[GM_WAVE];                // per-edge descriptors of the current pass
@@ -41,7 +43,7 @@ template <int PAT>
 struct alignas(16) BlockLds {
   int stage[kStageCap];         // staged adjacency slice col[e_begin .. e_end)
   int rpl[kMaxChunkVerts + 8];  // row offsets of the chunk's vertices (absolute)
-  unsigned bits[PAT == PAT_CLIQUE4 ? kBitWords : 4];
+  unsigned bits[GM_IS_CLIQUE(PAT) ? kBitWords : 4];
   unsigned fbits[kFilterWords];        // hashed membership filter over (row, neighbour) pairs of the staged slice
   unsigned char lrow[kStageCap];       // local row of every staged entry
   int next_batch;               // dynamic batch counter of the chunk
@@ -380,6 +382,98 @@ __device__ __forceinline__ unsigned long long clique4_count_wide(const unsigned 
   return c;
 }
 
+// ---- k-clique, k >= 5: deeper DFS levels on the same bit-matrix ----------------------------------------
+// C_1(S) = |S|,  C_m(S) = sum_{j in S} C_{m-1}(S & M_j);  k-cliques through edge i = C_{k-2}(M_i)
+// (the nested intersect levels of clique5..8_warp_edge.cuh / automine_5clique, automine_omp.h:138-157).
+constexpr int kSmallWords = 8;  // LDS-resident matrices have rows of <= 256 columns
+
+template <int M>
+struct CliqueSmall {  // one lane per row, the candidate set lives in 8 registers
+  static __device__ __forceinline__ unsigned long long run(const unsigned (&S)[kSmallWords], const unsigned *__restrict__ bits,
+                                                           const int row0, const int stride) {
+    unsigned long long c = 0;
+#pragma unroll
+    for (int w = 0; w < kSmallWords; ++w) {
+      unsigned x = S[w];
+      while (x) {
+        const int bit = __ffs((int)x) - 1;
+        x &= x - 1;
+        const unsigned *Mj = bits + (size_t)(row0 + w * 32 + bit) * stride;
+        unsigned T[kSmallWords];
+#pragma unroll
+        for (int w2 = 0; w2 < kSmallWords; ++w2) T[w2] = (w2 < stride) ? (S[w2] & Mj[w2]) : 0u;
+        c += CliqueSmall<M - 1>::run(T, bits, row0, stride);
+      }
+    }
+    return c;
+  }
+};
+template <>
+struct CliqueSmall<1> {
+  static __device__ __forceinline__ unsigned long long run(const unsigned (&S)[kSmallWords], const unsigned *, int, int) {
+    unsigned c = 0;
+#pragma unroll
+    for (int w = 0; w < kSmallWords; ++w) c += (unsigned)__popc(S[w]);
+    return c;
+  }
+};
+
+template <int M>
+__device__ __forceinline__ unsigned long long cliquek_count_small(const int *__restrict__ rpl, const unsigned *__restrict__ bits,
+                                                                  const int tid, const int nthreads, const int eb, const int nel,
+                                                                  const int nvl, const int stride) {
+  unsigned long long c = 0;
+  for (int le = tid; le < nel; le += nthreads) {
+    const int e = eb + le;
+    int lo = 0, hi = nvl - 1;
+    while (lo < hi) {
+      int mid = (lo + hi + 1) >> 1;
+      if (rpl[mid] <= e) lo = mid; else hi = mid - 1;
+    }
+    const int row0 = rpl[lo] - eb;
+    unsigned S[kSmallWords];
+#pragma unroll
+    for (int w = 0; w < kSmallWords; ++w) S[w] = (w < stride) ? bits[(size_t)le * stride + w] : 0u;
+    c += CliqueSmall<M>::run(S, bits, row0, stride);
+  }
+  return c;
+}
+
+template <int M>
+struct CliqueWide {  // one wave per row, lane w holds word w of the candidate set (stride <= 64)
+  static __device__ __forceinline__ unsigned long long run(const unsigned S, const unsigned *__restrict__ bits, const int lane,
+                                                           const int stride) {
+    unsigned long long c = 0;
+    for (int w = 0; w < stride; ++w) {
+      unsigned x = (unsigned)readlane((int)S, w);  // wave-uniform
+      while (x) {
+        const int bit = __ffs((int)x) - 1;
+        x &= x - 1;
+        const unsigned mj = (lane < stride) ? bits[(size_t)(w * 32 + bit) * stride + lane] : 0u;
+        c += CliqueWide<M - 1>::run(S & mj, bits, lane, stride);
+      }
+    }
+    return c;
+  }
+};
+template <>
+struct CliqueWide<1> {
+  static __device__ __forceinline__ unsigned long long run(const unsigned S, const unsigned *, int, int) {
+    return (unsigned long long)__popc(S);  // per-lane partial; summed over the wave at kernel end
+  }
+};
+
+template <int M>
+__device__ __forceinline__ unsigned long long cliquek_count_wide(const unsigned *__restrict__ bits, const int lane, const int wave,
+                                                                 const int nel, const int stride) {
+  unsigned long long c = 0;
+  for (int i = wave; i < nel; i += kWavesPerBlock) {
+    const unsigned mi = (lane < stride) ? bits[(size_t)i * stride + lane] : 0u;
+    c += CliqueWide<M>::run(mi, bits, lane, stride);
+  }
+  return c;
+}
+
 template <int PAT>
 __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT> &B, const ChunkRec r, const int lane,
                                               const int wave, Acc &acc) {
@@ -408,7 +502,7 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
   bool bits_lds = true, grouped = false;
   int grp_rows = nel > 0 ? nel : 1;
   unsigned *gbits = nullptr;
-  if (PAT == PAT_CLIQUE4) {
+  if (GM_IS_CLIQUE(PAT)) {
     int m = 0;
     for (int i = lane; i < nvl; i += GM_WAVE) m = max(m, B.rpl[i + 1] - B.rpl[i]);
     stride = (wave_max_nonneg(m) + 31) >> 5;
@@ -451,7 +545,7 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
   // ---- waves: take batches of 64 edges dynamically ------------------------------------------------
   for (int g0 = 0; g0 < nel; g0 += grp_rows) {  // one trip unless a big clique vertex is built in row groups
   const int gend = min(nel, g0 + grp_rows);
-  if (PAT == PAT_CLIQUE4 && grouped) {
+  if (GM_IS_CLIQUE(PAT) && grouped) {
     for (int i = tid; i < (gend - g0) * stride; i += nthreads) B.bits[i] = 0u;
     if (tid == 0) B.next_batch = g0 / GM_WAVE;
     __syncthreads();
@@ -524,7 +618,7 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
       } else if (PAT == PAT_MOTIF3) {
         acc.c0 += 1;               // |A' ^ B| summed over all directed edges
         acc.c1 += (unsigned)fl;    // ... over edges with v1 < v0  (triangles)
-      } else if (PAT == PAT_CLIQUE4) {
+      } else if (GM_IS_CLIQUE(PAT)) {
         if (p.flags & 4) { acc.c1 += 1; return; }
         const int cbit = is_x ? pos : kidx;  // position of the common neighbour inside N+(u)
         const int word = (le0 + owner) * stride + (cbit >> 5);
@@ -560,7 +654,7 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
       wave_sync();
     }
   }
-  if (PAT == PAT_CLIQUE4 && grouped) {  // flush the finished rows of this group to the arena
+  if (GM_IS_CLIQUE(PAT) && grouped) {  // flush the finished rows of this group to the arena
     __syncthreads();
     for (int i = tid; i < (gend - g0) * stride; i += nthreads) gbits[(size_t)g0 * stride + i] = B.bits[i];
     __syncthreads();
@@ -568,21 +662,38 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
   }  // row groups
 
   __syncthreads();  // every batch of the chunk is done (LDS is reused by the next chunk)
-  if (PAT == PAT_CLIQUE4 && !(p.flags & 2)) {
-    if (bits_lds) {
-      acc.c0 += clique4_count(B.rpl, B.bits, tid, nthreads, eb, nel, nvl, stride);
-    } else {
+  if (GM_IS_CLIQUE(PAT) && !(p.flags & 2)) {
+    const bool wide = !bits_lds && nvl == 1 && stride <= GM_WAVE;
+    if (!bits_lds) {
       __threadfence();  // the scratch matrix was written by all 4 waves (plain stores or device atomics)
       __syncthreads();
-      if (nvl == 1 && stride <= GM_WAVE) acc.c0 += clique4_count_wide(gbits, lane, wave, nel, stride);
-      else acc.c0 += clique4_count(B.rpl, gbits, tid, nthreads, eb, nel, nvl, stride);
+    }
+    const unsigned *M = bits_lds ? B.bits : gbits;
+    switch (PAT == PAT_CLIQUE4 ? 4 : p.k) {
+      case 4:
+        if (wide) acc.c0 += clique4_count_wide(M, lane, wave, nel, stride);
+        else acc.c0 += clique4_count(B.rpl, M, tid, nthreads, eb, nel, nvl, stride);
+        break;
+#define GM_CLIQUE_CASE(K)                                                                                   \
+      case K:                                                                                                \
+        if (PAT != PAT_CLIQUEK) break;                                                                       \
+        if (wide) acc.c0 += cliquek_count_wide<K - 2>(M, lane, wave, nel, stride);                          \
+        else if (bits_lds) acc.c0 += cliquek_count_small<K - 2>(B.rpl, M, tid, nthreads, eb, nel, nvl, stride); \
+        else acc.c1 += 1; /* row wider than 2048 columns: not supported for k >= 5 (reported by the host) */ \
+        break;
+      GM_CLIQUE_CASE(5)
+      GM_CLIQUE_CASE(6)
+      GM_CLIQUE_CASE(7)
+      GM_CLIQUE_CASE(8)
+#undef GM_CLIQUE_CASE
+      default: break;
     }
     __syncthreads();
   }
 }
 
 template <int PAT>
-__global__ __launch_bounds__(kWavesPerBlock *GM_WAVE, PAT == PAT_CLIQUE4 ? 5 : 8) void mine_kernel(const MineParams p) {
+__global__ __launch_bounds__(kWavesPerBlock *GM_WAVE, PAT == PAT_CLIQUEK ? 4 : (PAT == PAT_CLIQUE4 ? 5 : 8)) void mine_kernel(const MineParams p) {
   __shared__ BlockLds<PAT> B;
   const int lane = threadIdx.x & (GM_WAVE - 1);
   const int wave = threadIdx.x >> 6;
@@ -610,7 +721,8 @@ __global__ __launch_bounds__(kWavesPerBlock *GM_WAVE, PAT == PAT_CLIQUE4 ? 5 : 8
 
 size_t mine_lds_bytes(Pattern pat) {
   switch (pat) {
-    case PAT_CLIQUE4: return sizeof(BlockLds<PAT_CLIQUE4>);
+    case PAT_CLIQUE4:
+    case PAT_CLIQUEK: return sizeof(BlockLds<PAT_CLIQUE4>);
     default: return sizeof(BlockLds<PAT_TC>);
   }
 }
@@ -622,6 +734,7 @@ hipError_t launch_mine(Pattern pat, const MineParams &p, int grid_blocks, hipStr
     case PAT_DIAMOND: hipLaunchKernelGGL(mine_kernel<PAT_DIAMOND>, grid, block, 0, stream, p); break;
     case PAT_MOTIF3: hipLaunchKernelGGL(mine_kernel<PAT_MOTIF3>, grid, block, 0, stream, p); break;
     case PAT_CLIQUE4: hipLaunchKernelGGL(mine_kernel<PAT_CLIQUE4>, grid, block, 0, stream, p); break;
+    case PAT_CLIQUEK: hipLaunchKernelGGL(mine_kernel<PAT_CLIQUEK>, grid, block, 0, stream, p); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -96,6 +96,19 @@ def test_clique4_matches_reference(gg):
     assert CliqueSolver(dag, 4, tune=[512, 4, 0, 0, 0, 1]) == GOLDEN[name]["clique4"]
 
 
+@pytest.mark.parametrize("k", [5, 6, 7])
+def test_clique_k_matches_reference(gg, k):
+    """k = 5 (automine_5clique, automine_omp.h:138-157) and k = 6, 7 (goldens from clique_omp_recursive) on the
+    same bit-matrix: C_1(S)=|S|, C_m(S)=sum_{j in S} C_{m-1}(S & M_j)."""
+    name, _, _, dag = gg
+    e = GOLDEN[name]
+    if f"clique{k}" not in e:
+        pytest.skip("no golden for this k")
+    assert CliqueSolver(dag, k) == e[f"clique{k}"]
+    assert CliqueSolver(dag, k, tune=[64, 1, 0, 0, 0, 1]) == e[f"clique{k}"]
+    assert sum(CliqueSolver(dag, k, rank=r, world=3) for r in range(3)) == e[f"clique{k}"]
+
+
 def test_motif3_matches_reference(gg):
     name, _, sym, _ = gg
     assert MotifSolver(sym, 3) == GOLDEN[name]["motif3"]  # [wedges, triangles]: CPU order
@@ -150,6 +163,8 @@ def test_complete_graph_closed_forms(dev, n):
     d = s.orient()
     assert TCSolver(d) == math.comb(n, 3)
     assert CliqueSolver(d, 4) == math.comb(n, 4)
+    for k in ((5, 6, 7, 8) if n <= 65 else (5, 6)):
+        assert CliqueSolver(d, k) == math.comb(n, k)
     assert SglSolver(s, "diamond") == math.comb(n, 2) * math.comb(n - 2, 2)
     assert MotifSolver(s, 3) == [0, math.comb(n, 3)]
 
@@ -165,6 +180,13 @@ def test_rows_longer_than_the_lds_staging_capacity(dev):
     assert MotifSolver(s, 3) == [0, math.comb(n, 3)]
     assert SglSolver(s, "diamond") == math.comb(n, 2) * math.comb(n - 2, 2)
     assert CliqueSolver(d, 4) == math.comb(n, 4)
+
+
+def test_big_rows_deeper_cliques(dev):
+    """K_300: DAG rows up to 299 > 256 columns -> scratch-resident matrix, wave-per-row recursion"""
+    n = 300
+    d = _complete_graph(n).to_device(dev).orient()
+    assert CliqueSolver(d, 5) == math.comb(n, 5)
 
 
 def test_hub_graph_against_oracle(dev):
@@ -189,6 +211,7 @@ def test_random_graphs_against_oracle(dev, seed):
     assert TCSolver(d) == O.tc(odag)
     assert SglSolver(s, "diamond") == O.diamond(osym)
     assert CliqueSolver(d, 4) == O.clique(odag, 4)
+    assert CliqueSolver(d, 5) == O.clique(odag, 5)
     assert MotifSolver(s, 3) == O.motif3(osym)
 
 
