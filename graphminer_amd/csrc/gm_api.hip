@@ -664,6 +664,25 @@ extern "C" int gm_rmat_keys(int scale, int64_t n_edges, uint64_t seed, uint64_t 
 }
 
 // ------------------------------------------------------------------------------------------------
+// PMC calibration stream: every lane reads one dword per iteration (the access width of the mining kernels'
+// key loads); n*4 bytes are read exactly once, so FETCH_SIZE / (4n) gives the counter's scale for this width.
+__global__ __launch_bounds__(256) void calib_stream_kernel(const int *__restrict__ buf, long long n, unsigned long long *out) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  unsigned long long acc = 0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) acc += (unsigned)buf[i];
+  acc = wave_sum_u64(acc);
+  if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+}
+
+extern "C" int gm_calib_stream(const int32_t *d_buf, int64_t n, uint64_t *d_out, void *stream) {
+  if (!d_buf || !d_out || n < 0) return GM_ERR_INVALID;
+  hipLaunchKernelGGL(calib_stream_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, d_buf, (long long)n,
+                     (unsigned long long *)d_out);
+  HIP_TRY(hipGetLastError());
+  return GM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // wave-primitive self test
 // ------------------------------------------------------------------------------------------------
 __global__ void selftest_kernel(int *out) {

@@ -170,6 +170,11 @@ int gm_setop_batch(int op, int64_t npairs, const int32_t *d_values, const int64_
  * self-loops are written as the sentinel 0xFFFFFFFFFFFFFFFF. */
 int gm_rmat_keys(int scale, int64_t n_edges, uint64_t seed, uint64_t *d_keys, void *stream);
 
+/* PMC calibration (tooling): one pass of dword-per-lane coalesced loads over d_buf[0..n), sum -> *d_out.
+ * Exactly 4n bytes are read once; run under `rocprofv3 --pmc FETCH_SIZE` to get the counter scale for the
+ * access width the mining kernels use (MI355X_MICROARCH.md: FETCH_SIZE is calibrated only for 16 B/lane). */
+int gm_calib_stream(const int32_t *d_buf, int64_t n, uint64_t *d_out, void *stream);
+
 /* wave-primitive self test (DPP scans, ballot rank, LDS search); returns GM_OK when the device
  * results equal the host expectation. *n_fail receives the number of mismatching lanes. */
 int gm_selftest(int device, int *n_fail);
