@@ -35,6 +35,7 @@ WORKLOADS = {
     "diamond": (22, 10, False, "sgl diamond, LiveJournal stand-in"),
     "clique4": (22, 28, True, "4-clique, com-Orkut stand-in"),
     "motif3": (24, 16, False, "3-motif, R-MAT scale 24"),
+    "motif3f": (24, 16, False, "3-motif, formula variant (motif_gpu_formula), R-MAT scale 24"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -130,6 +131,8 @@ def main():
             rc = lib.gm_sgl(g.handle, b"diamond", C.byref(la), None, C.byref(st))
         elif a.workload == "clique4":
             rc = lib.gm_clique(g.handle, 4, C.byref(la), None, C.byref(st))
+        elif a.workload == "motif3f":
+            rc = lib.gm_motif_formula(g.handle, 3, C.byref(la), None, 2, C.byref(st))
         else:
             rc = lib.gm_motif(g.handle, 3, C.byref(la), None, 2, C.byref(st))
         _lib.check(rc, "bench step")
@@ -180,8 +183,8 @@ def main():
         "config": {"workload": f"{a.workload}: {desc}", "graph": gname, "nv": g.V(), "ne_sym": sym.E(), "tasks": tasks_total,
                    "max_degree": g.get_max_degree(), "parallelism": f"task-chunk round-robin x{world}, replicated CSR",
                    "input_build_s": round(t_in, 2)},
-        "count": result[:2] if a.workload == "motif3" else result[0],
-        "matches_per_sec": round((result[1] if a.workload == "motif3" else result[0]) / (elapsed / a.steps), 1),
+        "count": result[:2] if a.workload.startswith("motif3") else result[0],
+        "matches_per_sec": round((result[1] if a.workload.startswith("motif3") else result[0]) / (elapsed / a.steps), 1),
         "kernel_ms_avg": round(k_avg_ms, 4),
     }
 

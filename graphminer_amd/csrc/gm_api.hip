@@ -97,6 +97,10 @@ struct gm_graph {
   hipEvent_t ev[kEvRing][2] = {};
   unsigned long long ev_launches = 0;
   int cu_count = 256;
+  gm_graph *dag_cache = nullptr;          // oriented copy, built on demand by gm_motif_formula
+  const gm_graph *ring_alias = nullptr;   // handle whose event ring holds this handle's most recent launch
+  unsigned long long sum_c2 = 0;          // sum_v C(d(v),2)
+  bool sum_c2_valid = false;
   std::mutex mu;
 };
 
@@ -108,6 +112,8 @@ static void free_tables(gm_graph *g) {
 
 extern "C" void gm_graph_free(gm_graph *g) {
   if (!g) return;
+  if (g->dag_cache) gm_graph_free(g->dag_cache);
+  g->dag_cache = nullptr;
   (void)hipSetDevice(g->device);
   free_tables(g);
   if (g->d_rp) (void)hipFree(g->d_rp);
@@ -405,17 +411,25 @@ extern "C" int gm_chunk_table(int32_t nv, const int64_t *row_ptr, int32_t chunk,
 // ------------------------------------------------------------------------------------------------
 // solvers
 // ------------------------------------------------------------------------------------------------
-__global__ void finalize_kernel(int pat, const unsigned long long *__restrict__ c, unsigned long long *__restrict__ out) {
+enum FinMode : int { FIN_COPY = 0, FIN_MOTIF3 = 1, FIN_MOTIF3_FORMULA = 2 };
+
+__global__ void finalize_kernel(int mode, unsigned long long base, const unsigned long long *__restrict__ c,
+                                unsigned long long *__restrict__ out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  if (pat == PAT_MOTIF3) {
+  if (mode == FIN_MOTIF3) {
     out[0] = c[2] - c[0];  // wedges = sum_e idx(e) - sum_e |A' ^ B|   (automine_base.h:13)
     out[1] = c[1];         // triangles                                  (automine_base.h:18)
+  } else if (mode == FIN_MOTIF3_FORMULA) {
+    out[0] = base - 3ull * c[0];  // wedges = sum_v C(d,2) - 3T  (src/motif/omp_formula.cc:39-40); base only on rank 0
+    out[1] = c[0];
   } else {
     out[0] = c[0];
   }
 }
 
-static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uint64_t *h_out, int nout, gm_stats *st) {
+static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uint64_t *h_out, int nout, gm_stats *st,
+                       int fin_mode = -1, unsigned long long fin_base = 0) {
+  if (fin_mode < 0) fin_mode = (pat == PAT_MOTIF3) ? FIN_MOTIF3 : FIN_COPY;
   if (!cg) return GM_ERR_INVALID;
   gm_graph *g = const_cast<gm_graph *>(cg);
   gm_launch dflt;
@@ -488,6 +502,7 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
   }
 
   HIP_TRY(hipMemsetAsync(g->d_counters, 0, 64, stream));
+  g->ring_alias = nullptr;
   hipEvent_t *evp = g->ev[g->ev_launches % gm_graph::kEvRing];
   g->ev_launches++;
   HIP_TRY(hipEventRecord(evp[0], stream));
@@ -502,7 +517,8 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
     st->block = kWavesPerBlock * GM_WAVE;
   }
   if (la->d_counts) {
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, stream, (int)pat, g->d_counters, (unsigned long long *)la->d_counts);
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, stream, fin_mode, fin_base, g->d_counters,
+                       (unsigned long long *)la->d_counts);
     HIP_TRY(hipGetLastError());
     if (!h_out) return GM_OK;  // asynchronous: caller owns the synchronisation
   }
@@ -514,9 +530,12 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
     HIP_TRY(hipEventElapsedTime(&ms, evp[0], evp[1]));
     st->kernel_ms = ms;
   }
-  if (pat == PAT_MOTIF3) {
+  if (fin_mode == FIN_MOTIF3) {
     if (nout > 0) h_out[0] = c[2] - c[0];
     if (nout > 1) h_out[1] = c[1];
+  } else if (fin_mode == FIN_MOTIF3_FORMULA) {
+    if (nout > 0) h_out[0] = fin_base - 3ull * c[0];
+    if (nout > 1) h_out[1] = c[0];
   } else {
     h_out[0] = c[0];
   }
@@ -525,6 +544,7 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
 
 extern "C" int gm_kernel_times(const gm_graph *g, int n, double *ms_out, int *n_out) {
   if (!g || !ms_out || !n_out || n < 0) return GM_ERR_INVALID;
+  if (g->ring_alias) g = g->ring_alias;
   const unsigned long long have = std::min<unsigned long long>(g->ev_launches, gm_graph::kEvRing);
   const int m = (int)std::min<unsigned long long>((unsigned long long)n, have);
   HIP_TRY(hipSetDevice(g->device));
@@ -566,6 +586,37 @@ extern "C" int gm_motif(const gm_graph *sym, int k, const gm_launch *la, uint64_
   if (k != 3) return (k == 4) ? GM_ERR_UNSUPPORTED : GM_ERR_INVALID;
   if (ncounts < 2) return GM_ERR_INVALID;
   return run_pattern(PAT_MOTIF3, sym, la, 3, counts, ncounts, st);
+}
+
+// motif_omp_formula / motif_gpu_formula (src/motif/omp_formula.cc:39-46, cpu_kernels/automine_formula.h:2-19):
+// enumerate only the triangles, derive the wedges: wedges = sum_v C(d(v),2) - 3*T. Here the triangles come from the
+// TC kernel on the oriented graph (built once per handle and cached), so the hub rows of the symmetric graph are
+// never intersected. Counts are identical to gm_motif; with world > 1 the sum_v C(d,2) term is contributed by rank 0
+// and the per-rank partial wedge count is only meaningful after the all-reduce (mod 2^64 arithmetic).
+extern "C" int gm_motif_formula(const gm_graph *sym, int k, const gm_launch *la, uint64_t *counts, int ncounts, gm_stats *st) {
+  if (!sym) return GM_ERR_INVALID;
+  if (k != 3) return (k == 4) ? GM_ERR_UNSUPPORTED : GM_ERR_INVALID;
+  if (ncounts < 2) return GM_ERR_INVALID;
+  gm_graph *g = const_cast<gm_graph *>(sym);
+  if (!g->dag_cache) {
+    gm_graph *dag = nullptr;
+    int rc = gm_graph_orient(sym, &dag);
+    if (rc) return rc;
+    g->dag_cache = dag;
+  }
+  if (!g->sum_c2_valid) {
+    unsigned long long s2 = 0;
+    for (int v = 0; v < g->nv; ++v) {
+      const unsigned long long d = (unsigned long long)(g->h_rp[v + 1] - g->h_rp[v]);
+      s2 += d * (d - 1) / 2;
+    }
+    g->sum_c2 = s2;
+    g->sum_c2_valid = true;
+  }
+  const int rank = la ? la->rank : 0;
+  const int rc = run_pattern(PAT_TC, g->dag_cache, la, 3, counts, ncounts, st, FIN_MOTIF3_FORMULA, rank == 0 ? g->sum_c2 : 0ull);
+  g->ring_alias = g->dag_cache;
+  return rc;
 }
 
 // ------------------------------------------------------------------------------------------------

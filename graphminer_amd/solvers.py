@@ -77,12 +77,16 @@ def CliqueSolver(g: DeviceGraph, k: int, *, rank=0, world=1, chunk=0, return_sta
     return (int(total.value), _stats(st)) if return_stats else int(total.value)
 
 
-def MotifSolver(g: DeviceGraph, k: int, *, rank=0, world=1, chunk=0, return_stats=False, **kw):
-    """k-motif counts on the SYMMETRIC graph; k=3 -> [wedges, triangles] (CPU order)."""
+def MotifSolver(g: DeviceGraph, k: int, *, rank=0, world=1, chunk=0, return_stats=False, formula=False, **kw):
+    """k-motif counts on the SYMMETRIC graph; k=3 -> [wedges, triangles] (CPU order).
+
+    formula=True is the reference's motif_omp_formula / motif_gpu_formula variant (enumerate triangles only,
+    derive the wedges); with world > 1 its per-rank wedge value is a partial modulo 2**64 -- sum the ranks."""
     lib = _lib.load()
     n = num_possible_patterns[k] if 0 <= k < len(num_possible_patterns) else 0
     la, st = _launch(rank, world, chunk, **kw), gm_stats()
     out = (C.c_uint64 * max(n, 1))()
-    _lib.check(lib.gm_motif(g.handle, k, C.byref(la), out, n, C.byref(st)), "gm_motif")
+    fn = lib.gm_motif_formula if formula else lib.gm_motif
+    _lib.check(fn(g.handle, k, C.byref(la), out, n, C.byref(st)), "gm_motif")
     res = [int(out[i]) for i in range(n)]
     return (res, _stats(st)) if return_stats else res

@@ -140,6 +140,11 @@ int gm_clique(const gm_graph *dag, int k, const gm_launch *launch, uint64_t *tot
  * num_possible_patterns[k] (include/pattern.hh:4-15): 2 for k = 3. */
 int gm_motif(const gm_graph *sym, int k, const gm_launch *launch, uint64_t *counts, int ncounts, gm_stats *stats);
 
+/* motif_omp_formula / motif_gpu_formula (src/motif/omp_formula.cc:39-46, src/motif/gpu_formula.cu:86-92): same
+ * counts as gm_motif(k = 3), obtained by enumerating only the triangles (TC kernel on the oriented graph, built once
+ * per handle) and deriving wedges = sum_v C(d(v),2) - 3T. */
+int gm_motif_formula(const gm_graph *sym, int k, const gm_launch *launch, uint64_t *counts, int ncounts, gm_stats *stats);
+
 /* ---- set-operation primitives (batch form) -------------------------------------------------- */
 /* The wave64 equivalents of include/set_intersect.cuh / set_difference.cuh, exposed so the
  * per-primitive parity tests can drive them directly. One wave per pair of ascending int32 lists.

@@ -112,6 +112,10 @@ def test_clique_k_matches_reference(gg, k):
 def test_motif3_matches_reference(gg):
     name, _, sym, _ = gg
     assert MotifSolver(sym, 3) == GOLDEN[name]["motif3"]  # [wedges, triangles]: CPU order
+    # motif_omp_formula variant (src/motif/omp_formula.cc:39-40): identical counts, also when partitioned
+    assert MotifSolver(sym, 3, formula=True) == GOLDEN[name]["motif3"]
+    parts = [MotifSolver(sym, 3, formula=True, rank=r, world=3) for r in range(3)]
+    assert [sum(p[0] for p in parts) % 2**64, sum(p[1] for p in parts)] == GOLDEN[name]["motif3"]
 
 
 @pytest.mark.parametrize("world,policy", [(2, 0), (3, 0), (8, 0), (2, 1), (5, 1)])
