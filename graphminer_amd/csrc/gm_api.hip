@@ -76,6 +76,10 @@ struct ChunkTable {
   int bit_words;    // clique: LDS bit-matrix budget the chunks were built for (0 = unconstrained)
   ChunkRec *d = nullptr;
   size_t n = 0;
+  int *d_slot = nullptr;                 // per chunk: hub bitmap slot or -1
+  unsigned *d_bitmaps = nullptr;         // n_bitmaps x bitmap_words
+  size_t n_bitmaps = 0;
+  unsigned long long bitmap_words = 0;
   unsigned long long max_bit_words = 0;  // largest nel*stride over chunks that exceed bit_words
   std::vector<unsigned long long> edge_prefix;  // edges owned by chunks [0,i)
 };
@@ -105,8 +109,11 @@ struct gm_graph {
 };
 
 static void free_tables(gm_graph *g) {
-  for (auto &t : g->tables)
+  for (auto &t : g->tables) {
     if (t.d) (void)hipFree(t.d);
+    if (t.d_slot) (void)hipFree(t.d_slot);
+    if (t.d_bitmaps) (void)hipFree(t.d_bitmaps);
+  }
   g->tables.clear();
 }
 
@@ -345,6 +352,18 @@ static void build_chunks(const std::vector<int> &rp, int nv, int target, bool al
   }
 }
 
+// one workgroup per hub row: set bit x for every neighbour x of the row
+__global__ __launch_bounds__(256) void bitmap_build_kernel(const int *__restrict__ rp, const int *__restrict__ col,
+                                                           const int *__restrict__ rows, unsigned *__restrict__ bitmaps,
+                                                           unsigned long long words) {
+  const int u = rows[blockIdx.x];
+  unsigned *bm = bitmaps + (size_t)blockIdx.x * words;
+  for (int i = rp[u] + threadIdx.x; i < rp[u + 1]; i += blockDim.x) {
+    const unsigned x = (unsigned)col[i];
+    atomicOr(&bm[x >> 5], 1u << (x & 31u));
+  }
+}
+
 static int get_table(gm_graph *g, int target, bool allow_split, int bit_words, ChunkTable **out) {
   std::lock_guard<std::mutex> lk(g->mu);
   for (auto &t : g->tables)
@@ -361,6 +380,47 @@ static int get_table(gm_graph *g, int target, bool allow_split, int bit_words, C
   for (size_t i = 0; i < t.n; ++i) t.edge_prefix[i + 1] = t.edge_prefix[i] + (unsigned long long)(recs[i].e_end - recs[i].e_begin);
   HIP_TRY(hipMalloc(&t.d, sizeof(ChunkRec) * std::max<size_t>(t.n, 1)));
   if (t.n) HIP_TRY(hipMemcpy(t.d, recs.data(), sizeof(ChunkRec) * t.n, hipMemcpyHostToDevice));
+  if (allow_split) {
+    // Hub rows (longer than the LDS stage, cut into SPLIT chunks) get a dense bitmap over the vertex ids, the
+    // longest rows first, within a memory budget: one probe then replaces a ~17-step bisection in HBM.
+    const unsigned long long words = ((unsigned long long)g->nv + 31ull) / 32ull;
+    const unsigned long long budget_bytes = 8ull << 30;
+    std::vector<std::pair<int, int>> big;  // (degree, vertex)
+    for (int v = 0; v < g->nv; ++v) {
+      const int d = g->h_rp[v + 1] - g->h_rp[v];
+      if (d > kStageCap) big.push_back({d, v});
+    }
+    std::sort(big.begin(), big.end(), [](const std::pair<int, int> &x, const std::pair<int, int> &y) { return x.first > y.first; });
+    const size_t nb = words ? std::min<size_t>(big.size(), (size_t)(budget_bytes / (words * 4ull))) : 0;
+    if (nb > 0) {
+      std::vector<int> slot_of_row;  // sparse map through a sorted vector
+      std::vector<std::pair<int, int>> row_slot(nb);
+      std::vector<int> rows(nb);
+      for (size_t i = 0; i < nb; ++i) { row_slot[i] = {big[i].second, (int)i}; rows[i] = big[i].second; }
+      std::sort(row_slot.begin(), row_slot.end());
+      std::vector<int> slots(t.n, -1);
+      for (size_t c = 0; c < t.n; ++c) {
+        const ChunkRec &r = recs[c];
+        if (r.u_end == r.u_begin + 1 && (g->h_rp[r.u_begin + 1] - g->h_rp[r.u_begin]) > kStageCap) {
+          auto it = std::lower_bound(row_slot.begin(), row_slot.end(), std::make_pair(r.u_begin, -1));
+          if (it != row_slot.end() && it->first == r.u_begin) slots[c] = it->second;
+        }
+      }
+      HIP_TRY(hipMalloc(&t.d_slot, sizeof(int) * t.n));
+      HIP_TRY(hipMemcpy(t.d_slot, slots.data(), sizeof(int) * t.n, hipMemcpyHostToDevice));
+      HIP_TRY(hipMalloc(&t.d_bitmaps, (size_t)nb * (size_t)words * 4));
+      HIP_TRY(hipMemset(t.d_bitmaps, 0, (size_t)nb * (size_t)words * 4));
+      int *d_rows = nullptr;
+      HIP_TRY(hipMalloc(&d_rows, sizeof(int) * nb));
+      HIP_TRY(hipMemcpy(d_rows, rows.data(), sizeof(int) * nb, hipMemcpyHostToDevice));
+      hipLaunchKernelGGL(bitmap_build_kernel, dim3((unsigned)nb), dim3(256), 0, 0, g->d_rp, g->d_col, d_rows, t.d_bitmaps, words);
+      hipError_t e = hipDeviceSynchronize();
+      (void)hipFree(d_rows);
+      if (e != hipSuccess) return hip_fail(e, "bitmap_build_kernel", __FILE__, __LINE__);
+      t.n_bitmaps = nb;
+      t.bitmap_words = words;
+    }
+  }
   g->tables.push_back(std::move(t));
   *out = &g->tables.back();
   return GM_OK;
@@ -459,6 +519,9 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
   p.g.rp = g->d_rp;
   p.g.col = g->d_col;
   p.chunks = tab->d;
+  p.chunk_slot = tab->d_slot;
+  p.bitmaps = tab->d_bitmaps;
+  p.bitmap_words = tab->bitmap_words;
   const long long n = (long long)tab->n;
   unsigned long long my_edges = 0;
   {
@@ -478,7 +541,7 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
   p.cost_y_base = la->tune[7] > 0 ? (la->tune[7] & 15) : 2;
   p.k = k;
   p.flags = (la->tune[5] == 1) ? 1 : 0;
-  p.flags |= (la->tune[6] & 63) << 1;  // debug/ablation: bit1 skip clique phase 2, bit2 skip bit-matrix writes (counts wrong)
+  p.flags |= (la->tune[6] & 1023) << 1;  // debug/ablation: bit1 skip clique phase 2, bit2 skip bit-matrix writes (counts wrong)
   p.counters = g->d_counters;
   p.queue = reinterpret_cast<unsigned *>(g->d_counters + 4);
 

@@ -36,6 +36,9 @@ enum Pattern : int { PAT_TC = 0, PAT_DIAMOND = 1, PAT_MOTIF3 = 2, PAT_CLIQUE4 = 
 struct MineParams {
   GraphView g;
   const ChunkRec *chunks;
+  const int *chunk_slot;         // per chunk: bitmap slot of its hub row, or -1 (may be nullptr)
+  const unsigned *bitmaps;       // dense vertex-id bitmaps of the longest rows, bitmap_words each
+  unsigned long long bitmap_words;
   int first, step, count;        // this rank owns chunk ids first + i*step, i in [0,count)
   int grab;                      // chunks taken per dequeue
   unsigned *queue;               // dequeue head (zeroed before launch)
@@ -47,7 +50,7 @@ struct MineParams {
   int cost_x_base;
   int cost_y_base;
   int k;
-  int flags;  // bit 0: never stage adjacency in LDS; bit 3: no hashed filter in front of the LDS bisection (A/B switches)
+  int flags;  // bit 0: never stage adjacency in LDS; bit 3: no hashed filter in front of the LDS bisection; bit 9: ignore hub bitmaps (A/B switches)
 };
 
 // host-side launchers (gm_mine.hip)

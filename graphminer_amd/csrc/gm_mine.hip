@@ -77,9 +77,18 @@ __device__ __forceinline__ unsigned filter_salt(int local_row) { return ((unsign
 // search list of the pass): no exec-mask juggling, only v_cmp/v_cndmask and one load per step.
 constexpr int kTiles = 4;
 
-template <bool SLDS, class Act>
-__device__ __forceinline__ void flat_pass(WaveLds &L, const int *__restrict__ stage, const int *__restrict__ col, const int lane, const int llen,
+// MODE: how membership of a key in the search list is decided
+//   SEARCH_HBM   bisect the sorted list in global memory (col[s_base ..))
+//   SEARCH_LDS   bisect the LDS-staged copy (stage[s_base ..))
+//   SEARCH_BITMAP one probe of the row's dense bitmap over vertex ids (hub rows of SPLIT chunks); s_base then
+//                 carries the exclusive upper bound of the admissible keys (prefix bound of 3-motif, else INT_MAX)
+enum : int { SEARCH_HBM = 0, SEARCH_LDS = 1, SEARCH_BITMAP = 2 };
+
+template <int MODE, class Act>
+__device__ __forceinline__ void flat_pass(WaveLds &L, const int *__restrict__ stage, const int *__restrict__ col,
+                                          const unsigned *__restrict__ bm, const int lane, const int llen,
                                           const int key_base, const int s_base, const int s_len_flag, Act act) {
+  constexpr bool SLDS = (MODE == SEARCH_LDS);
   const int incl = wave_incl_scan_add(llen);
   const int total = readlane(incl, GM_WAVE - 1);
   if (total == 0) return;  // wave-uniform
@@ -117,6 +126,17 @@ __device__ __forceinline__ void flat_pass(WaveLds &L, const int *__restrict__ st
         key[q] = in[q] ? col[d.x + kidx[q]] : 0;
         lo[q] = 0;
       }
+      if (MODE == SEARCH_BITMAP) {
+        unsigned wv[kTiles];
+#pragma unroll
+        for (int q = 0; q < kTiles; ++q) wv[q] = bm[(unsigned)key[q] >> 5];
+#pragma unroll
+        for (int q = 0; q < kTiles; ++q) {
+          const bool f = in[q] & (((wv[q] >> ((unsigned)key[q] & 31u)) & 1u) != 0u) & (key[q] < sb[q]);
+          act(f, own[q] - 1, kidx[q], 0, fl[q], key[q]);
+        }
+        continue;
+      }
       // lower_bound by binary lifting: lo = #elements < key.  Written with non-short-circuit '&' and
       // always-executed loads on purpose: with '&&' the compiler sinks each load under its range
       // test and serialises the kTiles chains behind s_waitcnt vmcnt(0).
@@ -146,7 +166,7 @@ __device__ __forceinline__ void flat_pass(WaveLds &L, const int *__restrict__ st
 #pragma unroll
       for (int q = 0; q < kTiles; ++q) {
         const bool f = in[q] & (lo[q] < sl[q]) & (xf[q] == key[q]);
-        act(f, own[q] - 1, kidx[q], lo[q], fl[q]);
+        act(f, own[q] - 1, kidx[q], lo[q], fl[q], key[q]);
       }
     }
     wave_sync();
@@ -193,7 +213,7 @@ __device__ __forceinline__ void drain_candidates(WaveLds &L, const int *__restri
 #pragma unroll
   for (int q = 0; q < kTiles; ++q) {
     const bool f = in[q] & (lo[q] < sl[q]) & (xf[q] == key[q]);
-    act(f, own[q], 0, lo[q], fl[q]);
+    act(f, own[q], 0, lo[q], fl[q], key[q]);
   }
 }
 
@@ -475,8 +495,11 @@ __device__ __forceinline__ unsigned long long cliquek_count_wide(const unsigned 
 }
 
 template <int PAT>
-__device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT> &B, const ChunkRec r, const int lane,
-                                              const int wave, Acc &acc) {
+__device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT> &B, const ChunkRec r, const int slot,
+                                              const int lane, const int wave, Acc &acc) {
+  // dense bitmap of the hub row this SPLIT chunk belongs to (nullptr: none was built for it)
+  const unsigned *__restrict__ bm = (!GM_IS_CLIQUE(PAT) && slot >= 0 && !(p.flags & 512))
+                                        ? p.bitmaps + (size_t)slot * p.bitmap_words : nullptr;
   const int *__restrict__ rp = p.g.rp;
   const int *__restrict__ col = p.g.col;
   WaveLds &L = B.w[wave];
@@ -489,6 +512,8 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
   if (tid == 0) B.next_batch = 0;
   __syncthreads();
   const bool whole_rows = (eb == B.rpl[0]) && (r.e_end == B.rpl[nvl]);
+  if ((p.flags & 128) && !whole_rows) { __syncthreads(); return; }  // ablation: skip SPLIT chunks (counts wrong)
+  if ((p.flags & 256) && whole_rows) { __syncthreads(); return; }   // ablation: only SPLIT chunks
   const bool staged = whole_rows && (nel <= kStageCap) && !(p.flags & 1);
   const bool use_filter = staged && !(p.flags & 8);
   if (staged) {
@@ -587,9 +612,17 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
     int flag = 0;
     if (PAT == PAT_DIAMOND) act = valid && (v < u);  // symmetry break, diamond.h:5
     if (PAT == PAT_MOTIF3) {
-      al = idx;              // {w in N(v0) : w < v1} is exactly the idx entries before v1
-      flag = (v < u) ? 1 : 0;
-      if (valid) acc.c2 += (unsigned long long)idx;
+      // One bounded intersection per UNDIRECTED edge {u,v}, v < u, serves both directed edges of automine_3motif:
+      //   I(u,v) = |{w in N(u)^N(v) : w < v}|  and  I(v,u) = |{w in N(u)^N(v) : w < u}|.
+      // A' = {w in N(u) : w < u} (bounded(), VertexSet.h:240); every common w < u counts for I(v,u), and for
+      // I(u,v) and the triangle count when additionally w < v.  sum idx over ALL directed edges is kept per lane.
+      if (valid) acc.c2 += (unsigned long long)idx;  // |{w in N(v0): w < v1}| = position of v1 in its row
+      act = valid && (v < u);
+      if (act) {
+        if (staged) al = lower_bound(&B.stage[ru - eb], a, u);
+        else al = lower_bound(col + ru, a, u);
+      }
+      L.cnt[lane] = (unsigned)v;  // read back by the match handler (rare)
     }
     act = act && al > 0 && b > 0;
     // direction: X streams B = N(v) and bisects A; Y takes keys from A and bisects B in HBM
@@ -599,6 +632,8 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
         const float cx = (float)b * (float)(p.cost_x_base + p.cost_x_step * bitlen(al));
         const float cy = (float)al * (float)(p.cost_y_base + p.cost_y_step * bitlen(b));
         dirx = cx <= cy;
+      } else if (bm) {
+        dirx = (p.flags & 1024) ? ((float)b <= (float)al * (float)(2 + bitlen(b))) : (b <= al);  // bitmap probe vs lg(b) HBM probes
       } else {
         dirx = b <= al;
       }
@@ -609,15 +644,16 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
       wave_sync();
     }
 
-    auto on_found = [&](bool f, int owner, int kidx, int pos, int fl, bool is_x) {
+    auto on_found = [&](bool f, int owner, int kidx, int pos, int fl, int key, bool is_x) {
       if (!f) return;
       if (PAT == PAT_TC) {
         acc.c0 += 1;
       } else if (PAT == PAT_DIAMOND) {
         atomicAdd(&L.cnt[owner], 1u);
       } else if (PAT == PAT_MOTIF3) {
-        acc.c0 += 1;               // |A' ^ B| summed over all directed edges
-        acc.c1 += (unsigned)fl;    // ... over edges with v1 < v0  (triangles)
+        const unsigned below_v = (key < (int)L.cnt[owner]) ? 1u : 0u;
+        acc.c0 += 1u + below_v;    // I(v,u) + I(u,v) contributions of this common neighbour
+        acc.c1 += below_v;         // triangle u > v > w, counted once (automine_base.h:18)
       } else if (GM_IS_CLIQUE(PAT)) {
         if (p.flags & 4) { acc.c1 += 1; return; }
         const int cbit = is_x ? pos : kidx;  // position of the common neighbour inside N+(u)
@@ -632,19 +668,20 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
     {
       const int llen = dirx ? b : 0;
       const int s_len_flag = al | (flag << 30);
-      auto actx = [&](bool f, int owner, int kidx, int pos, int fl) { on_found(f, owner, kidx, pos, fl, true); };
+      auto actx = [&](bool f, int owner, int kidx, int pos, int fl, int key) { on_found(f, owner, kidx, pos, fl, key, true); };
       if (use_filter)
         flat_pass_filtered(L, B.stage, B.fbits, col, lane, llen, rv, (ru - eb) | (int)(filter_salt(lrow_of_lane) << 16),
                            s_len_flag, p.flags, actx);
-      else if (staged) flat_pass<true>(L, B.stage, col, lane, llen, rv, ru - eb, s_len_flag, actx);
-      else flat_pass<false>(L, B.stage, col, lane, llen, rv, ru, s_len_flag, actx);
+      else if (staged) flat_pass<SEARCH_LDS>(L, B.stage, col, bm, lane, llen, rv, ru - eb, s_len_flag, actx);
+      else if (bm) flat_pass<SEARCH_BITMAP>(L, B.stage, col, bm, lane, llen, rv, (PAT == PAT_MOTIF3) ? u : 0x7fffffff, s_len_flag, actx);
+      else flat_pass<SEARCH_HBM>(L, B.stage, col, bm, lane, llen, rv, ru, s_len_flag, actx);
     }
     // pass Y
     {
       const int llen = diry ? al : 0;
       const int s_len_flag = b | (flag << 30);
-      auto acty = [&](bool f, int owner, int kidx, int pos, int fl) { on_found(f, owner, kidx, pos, fl, false); };
-      flat_pass<false>(L, B.stage, col, lane, llen, ru, rv, s_len_flag, acty);
+      auto acty = [&](bool f, int owner, int kidx, int pos, int fl, int key) { on_found(f, owner, kidx, pos, fl, key, false); };
+      flat_pass<SEARCH_HBM>(L, B.stage, col, bm, lane, llen, ru, rv, s_len_flag, acty);
     }
 
     if (PAT == PAT_DIAMOND) {
@@ -705,8 +742,10 @@ __global__ __launch_bounds__(kWavesPerBlock *GM_WAVE, PAT == PAT_CLIQUEK ? 4 : (
     if (q >= (unsigned)p.count) break;
     const unsigned qe = min(q + (unsigned)p.grab, (unsigned)p.count);
     for (unsigned i = q; i < qe; ++i) {
-      const ChunkRec r = p.chunks[(size_t)p.first + (size_t)i * (size_t)p.step];
-      process_chunk<PAT>(p, B, r, lane, wave, acc);  // ends with a workgroup barrier
+      const size_t cid = (size_t)p.first + (size_t)i * (size_t)p.step;
+      const ChunkRec r = p.chunks[cid];
+      const int slot = p.chunk_slot ? p.chunk_slot[cid] : -1;
+      process_chunk<PAT>(p, B, r, slot, lane, wave, acc);  // ends with a workgroup barrier
     }
   }
   const unsigned long long s0 = wave_sum_u64(acc.c0);

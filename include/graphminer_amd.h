@@ -137,7 +137,9 @@ int gm_clique(const gm_graph *dag, int k, const gm_launch *launch, uint64_t *tot
 /* MotifSolver on the SYMMETRIC graph. k = 3: counts[0] = wedges, counts[1] = triangles
  * (the CPU order, src/motif/cpu_kernels/automine_base.h:13,18; NOT the swapped order of
  * src/motif/gpu_kernels/motif3_edge_warp.cuh:19-22). ncounts must be
- * num_possible_patterns[k] (include/pattern.hh:4-15): 2 for k = 3. */
+ * num_possible_patterns[k] (include/pattern.hh:4-15): 2 for k = 3.
+ * With world > 1 a rank's wedge value is a partial modulo 2^64 (one intersection per undirected edge serves both
+ * directed edges, which may belong to different ranks); the uint64 sum over ranks is the exact count. */
 int gm_motif(const gm_graph *sym, int k, const gm_launch *launch, uint64_t *counts, int ncounts, gm_stats *stats);
 
 /* motif_omp_formula / motif_gpu_formula (src/motif/omp_formula.cc:39-46, src/motif/gpu_formula.cu:86-92): same

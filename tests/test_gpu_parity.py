@@ -132,7 +132,7 @@ def test_task_partition_sums_to_the_whole(gg, world, policy):
         dia += SglSolver(sym, "diamond", rank=r, world=world, policy=policy)
         k4 += CliqueSolver(dag, 4, rank=r, world=world, policy=policy)
         m = MotifSolver(sym, 3, rank=r, world=world, policy=policy)
-        m3 = [m3[0] + m[0], m3[1] + m[1]]
+        m3 = [(m3[0] + m[0]) % 2**64, m3[1] + m[1]]  # per-rank wedge partials are modulo 2^64 (like the uint64 all-reduce)
     assert (tc, dia, k4, m3) == (e["tc"], e["diamond"], e["clique4"], e["motif3"])
     assert tasks == dag.E()
 
