@@ -241,30 +241,74 @@ extern "C" int gm_graph_download(const gm_graph *g, int64_t *row_ptr, int32_t *c
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool dag_keep(int ds, int s, int dd, int d) { return dd > ds || (dd == ds && d > s); }
 
-// one wave per row: count (pass 0) or compact (pass 1) the kept neighbours, order preserved
-__global__ __launch_bounds__(256) void orient_kernel(int nv, const int *__restrict__ rp, const int *__restrict__ col,
-                                                     int *__restrict__ new_deg, const int *__restrict__ new_rp,
-                                                     int *__restrict__ new_col, int pass) {
+// Orientation kernels: count (pass 0) or compact (pass 1) the kept neighbours, order preserved (ballot + popcount
+// ranks). Short rows (<= kOrientShort entries) take 8 lanes each, 8 rows per wave. Longer rows are cut into
+// SEGMENTS of kOrientSeg entries (table built on the host from the row offsets) so that a 100k-entry hub row is
+// spread over ~100 waves instead of serialising one.
+constexpr int kOrientShort = 64;
+constexpr int kOrientSeg = 1024;
+
+struct OrientSeg {
+  int row, begin, end, out;  // CSR entry range [begin,end) of `row`; out = output offset of the segment (pass 1)
+};
+
+__global__ __launch_bounds__(256) void orient_short_kernel(int nv, const int *__restrict__ rp, const int *__restrict__ col,
+                                                           int *__restrict__ new_deg, const int *__restrict__ new_rp,
+                                                           int *__restrict__ new_col, int pass) {
+  constexpr int G = 8, RPW = 64 / G;
   const int lane = threadIdx.x & 63;
+  const int grp = lane / G, gl = lane % G;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
-  for (int s = wave; s < nv; s += nwaves) {
-    const int b = rp[s], ds = rp[s + 1] - b;
+  for (int s0 = wave * RPW; s0 < nv; s0 += nwaves * RPW) {
+    const int s = s0 + grp;
+    int b = 0, ds = 0;
+    if (s < nv) { b = rp[s]; ds = rp[s + 1] - b; }
+    const int full = ds;
+    if (ds > kOrientShort) ds = 0;  // long rows belong to the segment kernel
+    const int maxds = wave_max_nonneg(ds);
     int n = 0;
-    const int ob = pass ? new_rp[s] : 0;
-    for (int base = 0; base < ds; base += 64) {
-      const int i = base + lane;
+    const int ob = (pass && ds > 0) ? new_rp[s] : 0;
+    for (int base = 0; base < maxds; base += G) {
+      const int i = base + gl;
       bool keep = false;
       int d = 0;
       if (i < ds) {
         d = col[b + i];
-        keep = dag_keep(ds, s, rp[d + 1] - rp[d], d);
+        keep = dag_keep(full, s, rp[d + 1] - rp[d], d);
       }
-      const unsigned long long m = __ballot(keep);
-      if (pass && keep) new_col[ob + n + rank_below(m)] = d;
+      const unsigned long long m = (__ballot(keep) >> (grp * G)) & 0xffull;
+      if (pass && keep) new_col[ob + n + __popcll(m & ((1ull << gl) - 1ull))] = d;
       n += __popcll(m);
     }
-    if (!pass && lane == 0) new_deg[s] = n;
+    if (!pass && gl == 0 && s < nv && full <= kOrientShort) new_deg[s] = n;
+  }
+}
+
+// one wave per segment
+__global__ __launch_bounds__(256) void orient_seg_kernel(int nseg, const OrientSeg *__restrict__ segs, const int *__restrict__ rp,
+                                                         const int *__restrict__ col, int *__restrict__ seg_count,
+                                                         int *__restrict__ new_col, int pass) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (int sg = wave; sg < nseg; sg += nwaves) {
+    const OrientSeg q = segs[sg];
+    const int ds = rp[q.row + 1] - rp[q.row];
+    int n = 0;
+    for (int base = q.begin; base < q.end; base += 64) {
+      const int i = base + lane;
+      bool keep = false;
+      int d = 0;
+      if (i < q.end) {
+        d = col[i];
+        keep = dag_keep(ds, q.row, rp[d + 1] - rp[d], d);
+      }
+      const unsigned long long m = __ballot(keep);
+      if (pass && keep) new_col[q.out + n + rank_below(m)] = d;
+      n += __popcll(m);
+    }
+    if (!pass && lane == 0) seg_count[sg] = n;
   }
 }
 
@@ -273,15 +317,34 @@ extern "C" int gm_graph_orient(const gm_graph *sym, gm_graph **out) {
   *out = nullptr;
   HIP_TRY(hipSetDevice(sym->device));
   const int nv = sym->nv;
-  int *d_deg = nullptr;
+  // segment table of the long rows
+  std::vector<OrientSeg> segs;
+  for (int v = 0; v < nv; ++v) {
+    const int b = sym->h_rp[v], e = sym->h_rp[v + 1];
+    if (e - b > kOrientShort)
+      for (int s = b; s < e; s += kOrientSeg) segs.push_back({v, s, std::min(s + kOrientSeg, e), 0});
+  }
+  const int nseg = (int)segs.size();
+  int *d_deg = nullptr, *d_segcnt = nullptr;
+  OrientSeg *d_segs = nullptr;
   HIP_TRY(hipMalloc(&d_deg, sizeof(int) * (size_t)std::max(nv, 1)));
-  const int blocks = std::max(1, std::min((nv + 3) / 4, sym->cu_count * 8));
-  hipLaunchKernelGGL(orient_kernel, dim3(blocks), dim3(256), 0, 0, nv, sym->d_rp, sym->d_col, d_deg, (const int *)nullptr,
+  HIP_TRY(hipMemset(d_deg, 0, sizeof(int) * (size_t)std::max(nv, 1)));
+  HIP_TRY(hipMalloc(&d_segcnt, sizeof(int) * (size_t)std::max(nseg, 1)));
+  HIP_TRY(hipMalloc(&d_segs, sizeof(OrientSeg) * (size_t)std::max(nseg, 1)));
+  if (nseg) HIP_TRY(hipMemcpy(d_segs, segs.data(), sizeof(OrientSeg) * (size_t)nseg, hipMemcpyHostToDevice));
+  const int bs = std::max(1, std::min((nv + 31) / 32, sym->cu_count * 8));
+  const int bl = std::max(1, std::min((nseg + 3) / 4, sym->cu_count * 8));
+  hipLaunchKernelGGL(orient_short_kernel, dim3(bs), dim3(256), 0, 0, nv, sym->d_rp, sym->d_col, d_deg, (const int *)nullptr,
                      (int *)nullptr, 0);
-  std::vector<int> deg((size_t)std::max(nv, 1));
+  if (nseg)
+    hipLaunchKernelGGL(orient_seg_kernel, dim3(bl), dim3(256), 0, 0, nseg, d_segs, sym->d_rp, sym->d_col, d_segcnt, (int *)nullptr, 0);
+  std::vector<int> deg((size_t)std::max(nv, 1)), segcnt((size_t)std::max(nseg, 1));
   hipError_t e = hipMemcpy(deg.data(), d_deg, sizeof(int) * (size_t)nv, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && nseg) e = hipMemcpy(segcnt.data(), d_segcnt, sizeof(int) * (size_t)nseg, hipMemcpyDeviceToHost);
   (void)hipFree(d_deg);
-  if (e != hipSuccess) return hip_fail(e, "hipMemcpy(deg)", __FILE__, __LINE__);
+  (void)hipFree(d_segcnt);
+  if (e != hipSuccess) { (void)hipFree(d_segs); return hip_fail(e, "hipMemcpy(deg)", __FILE__, __LINE__); }
+  for (int i = 0; i < nseg; ++i) deg[segs[i].row] += segcnt[i];
   gm_graph *g = new gm_graph();
   g->device = sym->device;
   g->nv = nv;
@@ -293,14 +356,23 @@ extern "C" int gm_graph_orient(const gm_graph *sym, gm_graph **out) {
   }
   g->h_rp[nv] = (int)acc;
   g->ne = acc;
-  auto fail = [&](int code) { gm_graph_free(g); return code; };
+  for (int i = 0, run = 0; i < nseg; ++i) {  // output offset of every segment inside its row
+    if (i == 0 || segs[i].row != segs[i - 1].row) run = 0;
+    segs[i].out = g->h_rp[segs[i].row] + run;
+    run += segcnt[i];
+  }
+  auto fail = [&](int code) { (void)hipFree(d_segs); gm_graph_free(g); return code; };
+  if (nseg && (e = hipMemcpy(d_segs, segs.data(), sizeof(OrientSeg) * (size_t)nseg, hipMemcpyHostToDevice)) != hipSuccess) return fail(hip_fail(e, "hipMemcpy", __FILE__, __LINE__));
   if ((e = hipMalloc(&g->d_rp, sizeof(int) * ((size_t)nv + 1))) != hipSuccess) return fail(hip_fail(e, "hipMalloc", __FILE__, __LINE__));
   if ((e = hipMalloc(&g->d_col, sizeof(int) * (size_t)std::max<long long>(acc, 1))) != hipSuccess) return fail(hip_fail(e, "hipMalloc", __FILE__, __LINE__));
   if ((e = hipMemcpy(g->d_rp, g->h_rp.data(), sizeof(int) * ((size_t)nv + 1), hipMemcpyHostToDevice)) != hipSuccess) return fail(hip_fail(e, "hipMemcpy", __FILE__, __LINE__));
-  hipLaunchKernelGGL(orient_kernel, dim3(blocks), dim3(256), 0, 0, nv, sym->d_rp, sym->d_col, (int *)nullptr, g->d_rp, g->d_col, 1);
-  if ((e = hipDeviceSynchronize()) != hipSuccess) return fail(hip_fail(e, "orient_kernel", __FILE__, __LINE__));
+  hipLaunchKernelGGL(orient_short_kernel, dim3(bs), dim3(256), 0, 0, nv, sym->d_rp, sym->d_col, (int *)nullptr, g->d_rp, g->d_col, 1);
+  if (nseg)
+    hipLaunchKernelGGL(orient_seg_kernel, dim3(bl), dim3(256), 0, 0, nseg, d_segs, sym->d_rp, sym->d_col, (int *)nullptr, g->d_col, 1);
+  if ((e = hipDeviceSynchronize()) != hipSuccess) return fail(hip_fail(e, "orient kernels", __FILE__, __LINE__));
+  (void)hipFree(d_segs);
   int rc = finish_handle(g);
-  if (rc) return fail(rc);
+  if (rc) { gm_graph_free(g); return rc; }
   *out = g;
   return GM_OK;
 }
