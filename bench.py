@@ -35,6 +35,10 @@ WORKLOADS = {
     "diamond": (22, 10, False, "sgl diamond, LiveJournal stand-in"),
     "clique4": (22, 28, True, "4-clique, com-Orkut stand-in"),
     "motif3": (24, 16, False, "3-motif, R-MAT scale 24"),
+    "rectangle": (16, 16, False, "sgl rectangle (4-cycle), R-MAT scale 16"),
+    "house": (12, 8, False, "sgl house, R-MAT scale 12"),
+    "pentagon": (12, 8, False, "sgl pentagon, R-MAT scale 12"),
+    "clique5": (20, 16, True, "5-clique, R-MAT scale 20"),
     "motif3f": (24, 16, False, "3-motif, formula variant (motif_gpu_formula), R-MAT scale 24"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
@@ -129,8 +133,10 @@ def main():
             rc = lib.gm_tc(g.handle, C.byref(la), None, C.byref(st))
         elif a.workload == "diamond":
             rc = lib.gm_sgl(g.handle, b"diamond", C.byref(la), None, C.byref(st))
-        elif a.workload == "clique4":
-            rc = lib.gm_clique(g.handle, 4, C.byref(la), None, C.byref(st))
+        elif a.workload in ("rectangle", "house", "pentagon"):
+            rc = lib.gm_sgl(g.handle, a.workload.encode(), C.byref(la), None, C.byref(st))
+        elif a.workload in ("clique4", "clique5"):
+            rc = lib.gm_clique(g.handle, int(a.workload[-1]), C.byref(la), None, C.byref(st))
         elif a.workload == "motif3f":
             rc = lib.gm_motif_formula(g.handle, 3, C.byref(la), None, 2, C.byref(st))
         else:
@@ -163,7 +169,7 @@ def main():
 
     # "edges processed" = the reference's nnz (src/triangle/gpu_base.cu:69): |E+| (tc, clique),
     # ne/2 (diamond), ne (motif)
-    tasks_total = g.E() // 2 if a.workload == "diamond" else g.E()
+    tasks_total = g.E() // 2 if a.workload in ("diamond", "rectangle", "house", "pentagon") else g.E()
     ms_per_step = 1e3 * elapsed / a.steps
     value = tasks_total / (elapsed / a.steps) / 1e6
 

@@ -697,9 +697,84 @@ extern "C" int gm_tc(const gm_graph *dag, const gm_launch *la, uint64_t *total, 
   return run_pattern(PAT_TC, dag, la, 3, total, 1, st);
 }
 
+// rectangle / house / pentagon: one wave per symmetry-broken edge (gm_sgl.hip)
+static int run_sgl_nested(int pat, const gm_graph *cg, const gm_launch *la, uint64_t *h_out, gm_stats *st) {
+  if (!cg) return GM_ERR_INVALID;
+  gm_graph *g = const_cast<gm_graph *>(cg);
+  gm_launch dflt;
+  memset(&dflt, 0, sizeof dflt);
+  if (!la) la = &dflt;
+  const int world = la->world > 1 ? la->world : 1;
+  if (la->rank < 0 || la->rank >= world) return GM_ERR_INVALID;
+  if (!h_out && !la->d_counts) return GM_ERR_INVALID;
+  HIP_TRY(hipSetDevice(g->device));
+  hipStream_t stream = (hipStream_t)la->stream;
+  SglParams p;
+  memset(&p, 0, sizeof p);
+  p.g.nv = g->nv;
+  p.g.ne = (int)g->ne;
+  p.g.rp = g->d_rp;
+  p.g.col = g->d_col;
+  p.chunk = la->chunk > 0 ? la->chunk : 64;
+  const long long nchunks = (g->ne + p.chunk - 1) / p.chunk;
+  int64_t first = 0, step = 1, count = 0;
+  gm_partition(nchunks, la->rank, world, la->policy, &first, &step, &count);
+  p.first = first;
+  p.step = step;
+  p.count = count;
+  p.counters = g->d_counters;
+  p.queue = reinterpret_cast<unsigned *>(g->d_counters + 4);
+  p.max_deg = std::max(g->max_deg, 1);
+  const int grid = (int)std::max<long long>(1, std::min<long long>((count + 3) / 4, (long long)g->cu_count * 8));
+  if (pat == SGL_HOUSE) {
+    const size_t need = (size_t)grid * 4 * (size_t)p.max_deg * sizeof(int);
+    if (need > g->scratch_bytes) {
+      if (g->d_scratch) (void)hipFree(g->d_scratch);
+      g->d_scratch = nullptr;
+      g->scratch_bytes = 0;
+      HIP_TRY(hipMalloc(&g->d_scratch, need));
+      g->scratch_bytes = need;
+    }
+    p.scratch = reinterpret_cast<int *>(g->d_scratch);
+  }
+  HIP_TRY(hipMemsetAsync(g->d_counters, 0, 64, stream));
+  g->ring_alias = nullptr;
+  hipEvent_t *evp = g->ev[g->ev_launches % gm_graph::kEvRing];
+  g->ev_launches++;
+  HIP_TRY(hipEventRecord(evp[0], stream));
+  if (count > 0) HIP_TRY(launch_sgl_nested(pat, p, grid, stream));
+  HIP_TRY(hipEventRecord(evp[1], stream));
+  if (st) {
+    st->kernel_ms = 0.0;
+    st->tasks = (uint64_t)(g->ne / 2 / world);
+    st->chunks = (uint64_t)count;
+    st->grid = (uint32_t)grid;
+    st->block = 256;
+  }
+  if (la->d_counts) {
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, stream, (int)FIN_COPY, 0ull, g->d_counters,
+                       (unsigned long long *)la->d_counts);
+    HIP_TRY(hipGetLastError());
+    if (!h_out) return GM_OK;
+  }
+  unsigned long long c[4];
+  HIP_TRY(hipMemcpyAsync(c, g->d_counters, sizeof c, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  if (st) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, evp[0], evp[1]));
+    st->kernel_ms = ms;
+  }
+  h_out[0] = c[0];
+  return GM_OK;
+}
+
 extern "C" int gm_sgl(const gm_graph *sym, const char *pattern, const gm_launch *la, uint64_t *total, gm_stats *st) {
   if (!pattern) return GM_ERR_INVALID;
   if (strcmp(pattern, "diamond") == 0) return run_pattern(PAT_DIAMOND, sym, la, 4, total, 1, st);
+  if (strcmp(pattern, "rectangle") == 0) return run_sgl_nested(SGL_RECTANGLE, sym, la, total, st);
+  if (strcmp(pattern, "house") == 0) return run_sgl_nested(SGL_HOUSE, sym, la, total, st);
+  if (strcmp(pattern, "pentagon") == 0) return run_sgl_nested(SGL_PENTAGON, sym, la, total, st);
   if (total) *total = 0;  // "Not implemented", total_num = 0 (src/sgl/omp_base.cc:51-53)
   return GM_ERR_UNSUPPORTED;
 }

@@ -53,6 +53,20 @@ struct MineParams {
   int flags;  // bit 0: never stage adjacency in LDS; bit 3: no hashed filter in front of the LDS bisection; bit 9: ignore hub bitmaps (A/B switches)
 };
 
+// nested SgL patterns (gm_sgl.hip)
+enum SglPattern : int { SGL_RECTANGLE = 0, SGL_HOUSE = 1, SGL_PENTAGON = 2 };
+
+struct SglParams {
+  GraphView g;
+  long long first, step, count;  // this rank owns entry-chunk ids first + i*step, i in [0,count)
+  int chunk;                     // CSR entries per task chunk
+  unsigned *queue;
+  unsigned long long *counters;
+  int *scratch;                  // house: max_deg ints per wave
+  int max_deg;
+};
+hipError_t launch_sgl_nested(int pat, const SglParams &p, int grid_blocks, hipStream_t stream);
+
 // host-side launchers (gm_mine.hip)
 hipError_t launch_mine(Pattern pat, const MineParams &p, int grid_blocks, hipStream_t stream);
 size_t mine_lds_bytes(Pattern pat);

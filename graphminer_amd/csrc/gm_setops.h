@@ -69,6 +69,30 @@ __device__ __forceinline__ unsigned wave_intersect_num_upper(const int *A, int a
   return wave_intersect_num(A, a, B, b);
 }
 
+// |{x in A ^ B : x != ex, x != ey}| per-lane partial (intersect_num with two excluded ancestors,
+// include/set_intersect.cuh:471 / VertexSet::intersect_ns_except, include/VertexSet.h:178-188)
+__device__ __forceinline__ unsigned wave_intersect_num_except2(const int *A, int a, const int *B, int b, int ex, int ey) {
+  const int lane = lane_id();
+  const int *L = A, *S = B;
+  int nl = a, ns = b;
+  if (b < a) { L = B; S = A; nl = b; ns = a; }
+  unsigned cnt = 0;
+  for (int i = lane; i < nl; i += GM_WAVE) {
+    int pos;
+    const int key = L[i];
+    cnt += (contains(S, ns, key, &pos) && key != ex && key != ey) ? 1u : 0u;
+  }
+  return cnt;
+}
+
+// |{x in A ^ B : x < upper, x != ex}| per-lane partial (intersect_num(..., upper, ancestor), set_intersect.cuh:436 /
+// VertexSet::intersect_ns_bound_except, include/VertexSet.h:152-164)
+__device__ __forceinline__ unsigned wave_intersect_num_upper_except(const int *A, int a, const int *B, int b, int upper, int ex) {
+  a = lower_bound(A, a, upper);
+  b = lower_bound(B, b, upper);
+  return wave_intersect_num_except2(A, a, B, b, ex, ex);
+}
+
 // A ^ B -> out (ascending, capacity min(a,b)); returns the size in every lane
 __device__ __forceinline__ int wave_intersect_set(const int *A, int a, const int *B, int b, int *out) {
   const int lane = lane_id();

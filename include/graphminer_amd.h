@@ -127,7 +127,8 @@ int gm_tc(const gm_graph *dag, const gm_launch *launch, uint64_t *total, gm_stat
 
 /* SglSolver: edge-induced subgraph listing on the SYMMETRIC graph, pattern by NAME
  * (include/pattern.hh:62-78). Implemented: "diamond" (src/sgl/cpu_kernels/diamond.h:1-14,
- * src/sgl/gpu_kernels/diamond_count.cuh:3-21). Others -> GM_ERR_UNSUPPORTED, *total = 0. */
+ * src/sgl/gpu_kernels/diamond_count.cuh:3-21), "rectangle" (rectangle.h:1-11), "house" (house.h:1-16),
+ * "pentagon" (pentagon.h:2-17). Others -> GM_ERR_UNSUPPORTED, *total = 0. */
 int gm_sgl(const gm_graph *sym, const char *pattern, const gm_launch *launch, uint64_t *total, gm_stats *stats);
 
 /* CliqueSolver on the DAG, 3 <= k <= 8 (src/clique/cpu_kernels/automine_omp.h:67-83,138-157;

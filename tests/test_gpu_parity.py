@@ -89,6 +89,19 @@ def test_diamond_matches_reference(gg):
     assert SglSolver(sym, "diamond", tune=[128, 2, 0, 0, 0, 1]) == GOLDEN[name]["diamond"]
 
 
+@pytest.mark.parametrize("pattern", ["rectangle", "house", "pentagon"])
+def test_sgl_nested_patterns_match_reference(gg, pattern):
+    """rectangle.h / house.h / pentagon.h loop nests on the wave64 primitives; goldens from sgl_omp_base"""
+    name, _, sym, _ = gg
+    e = GOLDEN[name]
+    if pattern not in e:
+        pytest.skip("no golden (pattern too slow for the reference binary at this size)")
+    total, st = SglSolver(sym, pattern, return_stats=True)
+    assert total == e[pattern]
+    assert sum(SglSolver(sym, pattern, rank=r, world=3, chunk=32) for r in range(3)) == e[pattern]
+    assert sum(SglSolver(sym, pattern, rank=r, world=2, policy=1) for r in range(2)) == e[pattern]
+
+
 def test_clique4_matches_reference(gg):
     name, _, _, dag = gg
     assert CliqueSolver(dag, 4) == GOLDEN[name]["clique4"]
