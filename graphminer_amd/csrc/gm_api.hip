@@ -543,7 +543,7 @@ extern "C" int gm_chunk_table(int32_t nv, const int64_t *row_ptr, int32_t chunk,
 // ------------------------------------------------------------------------------------------------
 // solvers
 // ------------------------------------------------------------------------------------------------
-enum FinMode : int { FIN_COPY = 0, FIN_MOTIF3 = 1, FIN_MOTIF3_FORMULA = 2 };
+enum FinMode : int { FIN_COPY = 0, FIN_MOTIF3 = 1, FIN_MOTIF3_FORMULA = 2, FIN_RAW4 = 3 };
 
 __global__ void finalize_kernel(int mode, unsigned long long base, const unsigned long long *__restrict__ c,
                                 unsigned long long *__restrict__ out) {
@@ -554,6 +554,8 @@ __global__ void finalize_kernel(int mode, unsigned long long base, const unsigne
   } else if (mode == FIN_MOTIF3_FORMULA) {
     out[0] = base - 3ull * c[0];  // wedges = sum_v C(d,2) - 3T  (src/motif/omp_formula.cc:39-40); base only on rank 0
     out[1] = c[0];
+  } else if (mode == FIN_RAW4) {
+    out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
   } else {
     out[0] = c[0];
   }
@@ -646,7 +648,7 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
 
   if (st) {
     st->kernel_ms = 0.0;
-    st->tasks = (pat == PAT_DIAMOND) ? my_edges / 2 : my_edges;
+    st->tasks = (pat == PAT_DIAMOND || pat == PAT_MOTIF4E) ? my_edges / 2 : my_edges;
     st->chunks = (uint64_t)p.count;
     st->grid = (uint32_t)grid;
     st->block = kWavesPerBlock * GM_WAVE;
@@ -671,6 +673,8 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
   } else if (fin_mode == FIN_MOTIF3_FORMULA) {
     if (nout > 0) h_out[0] = fin_base - 3ull * c[0];
     if (nout > 1) h_out[1] = c[0];
+  } else if (fin_mode == FIN_RAW4) {
+    for (int i = 0; i < 4 && i < nout; ++i) h_out[i] = c[i];
   } else {
     h_out[0] = c[0];
   }
@@ -792,8 +796,64 @@ extern "C" int gm_clique(const gm_graph *dag, int k, const gm_launch *la, uint64
   return run_pattern(k == 4 ? PAT_CLIQUE4 : PAT_CLIQUEK, dag, la, k, total, 1, st);
 }
 
+// 4-motif, formula form (src/motif/cpu_kernels/automine_formula.h:21-56 + src/motif/omp_formula.cc:41-45):
+// raw[0..3] = the per-edge sums counter[0], counter[1], counter[2], counter[4] (PAT_MOTIF4E, one |N(v0)^N(v1)| per
+// undirected edge), raw[4] = edge-induced 4-cycles (rectangle kernel), raw[5] = 4-cliques (clique kernel on the cached
+// DAG). Every raw value is a plain sum over tasks, so per-rank partials add up; gm_motif4_finish turns the summed raw
+// values into the six vertex-induced counts.
+extern "C" int gm_motif4_partial(const gm_graph *sym, const gm_launch *la, uint64_t raw[6], gm_stats *st) {
+  if (!sym || !raw) return GM_ERR_INVALID;
+  gm_graph *g = const_cast<gm_graph *>(sym);
+  gm_launch l2;
+  memset(&l2, 0, sizeof l2);
+  if (la) l2 = *la;
+  l2.d_counts = nullptr;  // synchronous: the three kernels are combined on the host
+  if (!g->dag_cache) {
+    gm_graph *dag = nullptr;
+    int rc = gm_graph_orient(sym, &dag);
+    if (rc) return rc;
+    g->dag_cache = dag;
+  }
+  gm_stats s1, s2, s3;
+  memset(&s1, 0, sizeof s1); memset(&s2, 0, sizeof s2); memset(&s3, 0, sizeof s3);
+  int rc = run_pattern(PAT_MOTIF4E, sym, &l2, 4, raw, 4, &s1, FIN_RAW4, 0);
+  if (rc) return rc;
+  rc = run_sgl_nested(SGL_RECTANGLE, sym, &l2, &raw[4], &s2);
+  if (rc) return rc;
+  rc = run_pattern(PAT_CLIQUE4, g->dag_cache, &l2, 4, &raw[5], 1, &s3);
+  if (rc) return rc;
+  if (st) {
+    *st = s1;
+    st->kernel_ms = s1.kernel_ms + s2.kernel_ms + s3.kernel_ms;
+  }
+  return GM_OK;
+}
+
+extern "C" int gm_motif4_finish(const uint64_t raw[6], uint64_t counts[6]) {
+  if (!raw || !counts) return GM_ERR_INVALID;
+  const uint64_t k4 = raw[5];
+  const uint64_t diamond = raw[3] / 2 - 6 * k4;            // total[4] = total[4]/2 - 6*total[5]
+  const uint64_t tailed = raw[2] / 2 - 2 * diamond;        // total[2] = total[2]/2 - 2*total[4]
+  const uint64_t cycle4 = raw[4] - diamond - 3 * k4;       // vertex-induced 4-cycles from the edge-induced count
+  const uint64_t path4 = raw[1] - 4 * cycle4;              // total[1] = total[1] - 4*total[3]
+  const uint64_t star3 = raw[0] / 6 - tailed / 3;          // total[0] = total[0]/6 - total[2]/3
+  counts[0] = star3; counts[1] = path4; counts[2] = tailed; counts[3] = cycle4; counts[4] = diamond; counts[5] = k4;
+  return GM_OK;
+}
+
 extern "C" int gm_motif(const gm_graph *sym, int k, const gm_launch *la, uint64_t *counts, int ncounts, gm_stats *st) {
-  if (k != 3) return (k == 4) ? GM_ERR_UNSUPPORTED : GM_ERR_INVALID;
+  if (k == 4) {
+    if (ncounts < 6 || !counts) return GM_ERR_INVALID;
+    if (la && la->world > 1) return GM_ERR_UNSUPPORTED;  // multi-GPU: gm_motif4_partial + all-reduce + gm_motif4_finish
+    uint64_t raw[6];
+    int rc = gm_motif4_partial(sym, la, raw, st);
+    if (rc) return rc;
+    rc = gm_motif4_finish(raw, counts);
+    if (rc) return rc;
+    if (la && la->d_counts) HIP_TRY(hipMemcpy(la->d_counts, counts, sizeof(uint64_t) * 6, hipMemcpyHostToDevice));
+    return GM_OK;
+  }
+  if (k != 3) return GM_ERR_INVALID;
   if (ncounts < 2) return GM_ERR_INVALID;
   return run_pattern(PAT_MOTIF3, sym, la, 3, counts, ncounts, st);
 }

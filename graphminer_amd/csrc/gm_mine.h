@@ -31,7 +31,8 @@ struct GraphView {
   const int *col;  // col_idx
 };
 
-enum Pattern : int { PAT_TC = 0, PAT_DIAMOND = 1, PAT_MOTIF3 = 2, PAT_CLIQUE4 = 3, PAT_CLIQUEK = 4 /* k = 5..8 */ };
+enum Pattern : int { PAT_TC = 0, PAT_DIAMOND = 1, PAT_MOTIF3 = 2, PAT_CLIQUE4 = 3, PAT_CLIQUEK = 4 /* k = 5..8 */,
+                     PAT_MOTIF4E = 5 /* per-edge sums of the 4-motif formula */ };
 
 struct MineParams {
   GraphView g;

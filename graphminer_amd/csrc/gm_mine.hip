@@ -28,6 +28,7 @@
 namespace gm {
 
 #define GM_IS_CLIQUE(P) ((P) == PAT_CLIQUE4 || (P) == PAT_CLIQUEK)
+#define GM_IS_PEREDGE(P) ((P) == PAT_DIAMOND || (P) == PAT_MOTIF4E)  // need |N(v0) ^ N(v1)| per task edge
 
 // per-wave scratch of the flattened passes
 struct alignas(16) WaveLds {
@@ -52,7 +53,7 @@ struct alignas(16) BlockLds {
 };
 
 struct Acc {
-  unsigned long long c0 = 0, c1 = 0, c2 = 0;
+  unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
 };
 
 __device__ __forceinline__ int bitlen(int x) { return 32 - __clz(x); }
@@ -610,7 +611,7 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
     bool act = valid;
     int al = a;       // effective length of A = N(u) (a prefix of the row)
     int flag = 0;
-    if (PAT == PAT_DIAMOND) act = valid && (v < u);  // symmetry break, diamond.h:5
+    if (GM_IS_PEREDGE(PAT)) act = valid && (v < u);  // symmetry break, diamond.h:5 / automine_formula.h:27
     if (PAT == PAT_MOTIF3) {
       // One bounded intersection per UNDIRECTED edge {u,v}, v < u, serves both directed edges of automine_3motif:
       //   I(u,v) = |{w in N(u)^N(v) : w < v}|  and  I(v,u) = |{w in N(u)^N(v) : w < u}|.
@@ -639,7 +640,7 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
       }
     }
     const bool diry = act && !dirx;
-    if (PAT == PAT_DIAMOND) {
+    if (GM_IS_PEREDGE(PAT)) {
       L.cnt[lane] = 0u;
       wave_sync();
     }
@@ -648,7 +649,7 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
       if (!f) return;
       if (PAT == PAT_TC) {
         acc.c0 += 1;
-      } else if (PAT == PAT_DIAMOND) {
+      } else if (GM_IS_PEREDGE(PAT)) {
         atomicAdd(&L.cnt[owner], 1u);
       } else if (PAT == PAT_MOTIF3) {
         const unsigned below_v = (key < (int)L.cnt[owner]) ? 1u : 0u;
@@ -688,6 +689,19 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
       wave_sync();
       const unsigned long long n = L.cnt[lane];
       acc.c0 += n * (n - 1) / 2;  // C(n,2), 64-bit (diamond_count.cuh:15-17)
+      wave_sync();
+    }
+    if (PAT == PAT_MOTIF4E) {
+      // per-edge sums of the formula-based 4-motif (src/motif/cpu_kernels/automine_formula.h:30-39)
+      wave_sync();
+      if (valid && v < u) {
+        const unsigned long long tri = L.cnt[lane];
+        const unsigned long long su = (unsigned long long)a - tri - 1ull, sv = (unsigned long long)b - tri - 1ull;
+        acc.c0 += su * (su - 1ull) + sv * (sv - 1ull);  // counter[0]
+        acc.c1 += su * sv;                              // counter[1]
+        acc.c2 += tri * (su + sv);                      // counter[2]
+        acc.c3 += tri * (tri - 1ull);                   // counter[4]
+      }
       wave_sync();
     }
   }
@@ -751,10 +765,12 @@ __global__ __launch_bounds__(kWavesPerBlock *GM_WAVE, PAT == PAT_CLIQUEK ? 4 : (
   const unsigned long long s0 = wave_sum_u64(acc.c0);
   const unsigned long long s1 = wave_sum_u64(acc.c1);
   const unsigned long long s2 = wave_sum_u64(acc.c2);
+  const unsigned long long s3 = wave_sum_u64(acc.c3);
   if (lane == 0) {
     if (s0) atomicAdd(&p.counters[0], s0);
     if (s1) atomicAdd(&p.counters[1], s1);
     if (s2) atomicAdd(&p.counters[2], s2);
+    if (s3) atomicAdd(&p.counters[3], s3);
   }
 }
 
@@ -771,6 +787,7 @@ hipError_t launch_mine(Pattern pat, const MineParams &p, int grid_blocks, hipStr
   switch (pat) {
     case PAT_TC: hipLaunchKernelGGL(mine_kernel<PAT_TC>, grid, block, 0, stream, p); break;
     case PAT_DIAMOND: hipLaunchKernelGGL(mine_kernel<PAT_DIAMOND>, grid, block, 0, stream, p); break;
+    case PAT_MOTIF4E: hipLaunchKernelGGL(mine_kernel<PAT_MOTIF4E>, grid, block, 0, stream, p); break;
     case PAT_MOTIF3: hipLaunchKernelGGL(mine_kernel<PAT_MOTIF3>, grid, block, 0, stream, p); break;
     case PAT_CLIQUE4: hipLaunchKernelGGL(mine_kernel<PAT_CLIQUE4>, grid, block, 0, stream, p); break;
     case PAT_CLIQUEK: hipLaunchKernelGGL(mine_kernel<PAT_CLIQUEK>, grid, block, 0, stream, p); break;

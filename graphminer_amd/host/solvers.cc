@@ -235,9 +235,13 @@ void MotifSolver(Graph &g, int k, std::vector<uint64_t> &accum, int n_gpu, int c
   j.kind = Job::MOTIF;
   j.k = k;
   j.ncounts = int(accum.size());
-  if (k != 3) {
+  if (k != 3 && k != 4) {
     std::cout << "Not supported right now\n";  // src/motif/gpu_base.cu:101
     return;
+  }
+  if (k == 4 && n_gpu > 1) {
+    std::cout << "4-motif: running on one GPU (multi-GPU needs gm_motif4_partial + all-reduce + gm_motif4_finish)\n";
+    n_gpu = 1;
   }
   uint64_t out[8] = {0};
   if (!run(g, j, n_gpu, chunk_size, out)) {

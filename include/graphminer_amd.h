@@ -138,10 +138,17 @@ int gm_clique(const gm_graph *dag, int k, const gm_launch *launch, uint64_t *tot
 /* MotifSolver on the SYMMETRIC graph. k = 3: counts[0] = wedges, counts[1] = triangles
  * (the CPU order, src/motif/cpu_kernels/automine_base.h:13,18; NOT the swapped order of
  * src/motif/gpu_kernels/motif3_edge_warp.cuh:19-22). ncounts must be
- * num_possible_patterns[k] (include/pattern.hh:4-15): 2 for k = 3.
+ * num_possible_patterns[k] (include/pattern.hh:4-15): 2 for k = 3, 6 for k = 4 (see gm_motif4_partial).
  * With world > 1 a rank's wedge value is a partial modulo 2^64 (one intersection per undirected edge serves both
  * directed edges, which may belong to different ranks); the uint64 sum over ranks is the exact count. */
 int gm_motif(const gm_graph *sym, int k, const gm_launch *launch, uint64_t *counts, int ncounts, gm_stats *stats);
+
+/* 4-motif in the reference's formula form (src/motif/cpu_kernels/automine_formula.h:21-56, host fix-up
+ * src/motif/omp_formula.cc:41-45). gm_motif(k = 4, ncounts = 6) returns [3-star, 4-path, tailed-triangle, 4-cycle,
+ * diamond, 4-clique] (vertex-induced, the order of src/motif/README.md:50-60) on one GPU. Multi-GPU: every rank calls
+ * gm_motif4_partial (raw[6] are plain sums over its tasks), the ranks all-reduce raw, then gm_motif4_finish. */
+int gm_motif4_partial(const gm_graph *sym, const gm_launch *launch, uint64_t raw[6], gm_stats *stats);
+int gm_motif4_finish(const uint64_t raw[6], uint64_t counts[6]);
 
 /* motif_omp_formula / motif_gpu_formula (src/motif/omp_formula.cc:39-46, src/motif/gpu_formula.cu:86-92): same
  * counts as gm_motif(k = 3), obtained by enumerating only the triangles (TC kernel on the oriented graph, built once

@@ -41,6 +41,8 @@ def test_cli_result_lines(name):
     out = run("motif_gpu_base", prefix, 3)
     assert out[-2:] == [f"pattern 0: {e['motif3'][0]}", f"pattern 1: {e['motif3'][1]}"]
     assert "num_patterns: 2" in out
+    out = run("motif_gpu_base", prefix, 4)
+    assert out[-6:] == [f"pattern {i}: {c}" for i, c in enumerate(e["motif4"])] and "num_patterns: 6" in out
 
 
 def test_cli_usage_exits_1():

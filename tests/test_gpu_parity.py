@@ -131,6 +131,30 @@ def test_motif3_matches_reference(gg):
     assert [sum(p[0] for p in parts) % 2**64, sum(p[1] for p in parts)] == GOLDEN[name]["motif3"]
 
 
+def test_motif4_matches_reference(gg):
+    """formula-based 4-motif (automine_formula.h:21-56 + omp_formula.cc:41-45) = [3-star, 4-path, tailed-triangle,
+    4-cycle, diamond, 4-clique]; goldens from motif_omp_base (== motif_omp_formula)"""
+    import ctypes as C
+
+    name, _, sym, _ = gg
+    e = GOLDEN[name]
+    if "motif4" not in e:
+        pytest.skip("no golden")
+    assert MotifSolver(sym, 4) == e["motif4"]
+    # multi-rank: raw partial sums add up, then one finish
+    lib = _lib.load()
+    tot = [0] * 6
+    for r in range(3):
+        la = _lib.gm_launch()
+        la.rank, la.world = r, 3
+        raw = (C.c_uint64 * 6)()
+        assert lib.gm_motif4_partial(sym.handle, C.byref(la), raw, None) == 0
+        tot = [a + int(b) for a, b in zip(tot, raw)]
+    out = (C.c_uint64 * 6)()
+    assert lib.gm_motif4_finish((C.c_uint64 * 6)(*tot), out) == 0
+    assert [int(x) for x in out] == e["motif4"]
+
+
 @pytest.mark.parametrize("world,policy", [(2, 0), (3, 0), (8, 0), (2, 1), (5, 1)])
 def test_task_partition_sums_to_the_whole(gg, world, policy):
     name, _, sym, dag = gg
