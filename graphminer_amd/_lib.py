@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgraphminer_amd.so")
+LIB_PATH = os.environ.get("GM_LIB_PATH") or os.path.join(_HERE, "libgraphminer_amd.so")  # GM_LIB_PATH: A/B builds
 
 
 class GraphMinerBuildError(RuntimeError):

@@ -68,7 +68,7 @@ extern "C" int gm_device_count(int *n) {
 // ------------------------------------------------------------------------------------------------
 // graph handle
 // ------------------------------------------------------------------------------------------------
-constexpr int kDefaultChunk = 512;  // task edges per chunk when the caller does not say
+constexpr int kDefaultChunk = 1024;  // task edges per chunk when the caller does not say
 
 struct ChunkTable {
   int target;       // T: CSR entries per chunk
@@ -578,7 +578,11 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
 
   // tune[0] = chunk target override, tune[1] = grab, tune[2] = cost_x_step, tune[3] = cost_y_step,
   // tune[4] = blocks per CU override, tune[5] = force "search in HBM" (no LDS staging) when 1
-  int target = la->chunk > 0 ? la->chunk : kDefaultChunk;
+  // default chunk size: as large as the LDS stage allows (fewer dequeues, better staging reuse) while every rank still
+  // gets >= ~6 chunks per resident workgroup for the dynamic dequeue to balance (matters for strong scaling at N = 8)
+  int target = kDefaultChunk;
+  while (target > 128 && g->ne / ((long long)world * target) < 2LL * g->cu_count * 7) target >>= 1;
+  if (la->chunk > 0) target = la->chunk;
   if (la->tune[0] > 0) target = la->tune[0];
   target = std::max(64, std::min(target, kStageCap));
   const bool clique = pat == PAT_CLIQUE4 || pat == PAT_CLIQUEK;
@@ -610,7 +614,7 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
   p.grab = la->tune[1] > 0 ? la->tune[1] : 1;
   // direction rule: X if b*(xb + xs*lg a) <= a*(yb + ys*lg b); tune[2] = xs+1, tune[3] = ys+1, tune[7] = xb*16 + yb
   p.cost_x_step = la->tune[2] > 0 ? la->tune[2] - 1 : 1;
-  p.cost_y_step = la->tune[3] > 0 ? la->tune[3] - 1 : 4;
+  p.cost_y_step = la->tune[3] > 0 ? la->tune[3] - 1 : 6;
   p.cost_x_base = la->tune[7] > 0 ? (la->tune[7] >> 4) : 2;
   p.cost_y_base = la->tune[7] > 0 ? (la->tune[7] & 15) : 2;
   p.k = k;

@@ -11,10 +11,17 @@ constexpr int kWavesPerBlock = 4;         // 256-thread workgroups, the 4 waves 
 constexpr int kStageCap = 1024;           // adjacency entries one wave stages in LDS (4 KB)
 constexpr int kMaxChunkVerts = 256;       // rows per task chunk (local row_ptr slice in LDS)
 constexpr int kMarkWindow = 512;          // flattened positions resolved per owner-mark window
-constexpr int kFilterLog2 = 14;           // hashed membership filter: 2^14 bits (2 KB) per workgroup
+#ifndef GM_TILES
+#define GM_TILES 2  // 64-wide tiles resolved together per wave (ILP); swept on MI355X: 2 beats 4 once the filter is in
+#endif
+#define GM_TILES_DEFAULT GM_TILES
+#ifndef GM_FILTER_LOG2
+#define GM_FILTER_LOG2 15
+#endif
+constexpr int kFilterLog2 = GM_FILTER_LOG2;           // hashed membership filter: 2^14 bits (2 KB) per workgroup
 constexpr int kFilterBits = 1 << kFilterLog2;
 constexpr int kFilterWords = kFilterBits / 32;
-constexpr int kQueueCap = 320;            // candidate queue entries per wave (63 left over + 4 tiles)
+constexpr int kQueueCap = 64 * (GM_TILES_DEFAULT + 1);  // candidate queue entries per wave (63 left over + kTiles tiles)
 constexpr int kBitWords = 2048;           // clique: LDS words for the per-chunk adjacency bit-matrix (8 KB)
 
 // Task chunk = a contiguous vertex range [u_begin,u_end) and the CSR entries [e_begin,e_end) it owns.

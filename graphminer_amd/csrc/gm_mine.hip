@@ -76,7 +76,8 @@ __device__ __forceinline__ unsigned filter_salt(int local_row) { return ((unsign
 // key loads and kTiles independent bisection chains are in flight per wave. The bisection is the
 // branch-free "binary lifting" form with a wave-uniform trip count (bit length of the longest
 // search list of the pass): no exec-mask juggling, only v_cmp/v_cndmask and one load per step.
-constexpr int kTiles = 4;
+constexpr int kTiles = GM_TILES;  // filtered LDS pass (X): tiles resolved together per wave
+constexpr int kTilesG = 4;        // passes that bisect / probe in HBM (Y, SPLIT chunks): more loads in flight pay off
 
 // MODE: how membership of a key in the search list is decided
 //   SEARCH_HBM   bisect the sorted list in global memory (col[s_base ..))
@@ -100,23 +101,23 @@ __device__ __forceinline__ void flat_pass(WaveLds &L, const int *__restrict__ st
   int carry = 0;
   for (int wb = 0; wb < total; wb += kMarkWindow) {
     const int wn = min(kMarkWindow, total - wb);
-    const int nwords = ((wn + GM_WAVE * kTiles - 1) / (GM_WAVE * kTiles)) * (GM_WAVE * kTiles / 4);
+    const int nwords = ((wn + GM_WAVE * kTilesG - 1) / (GM_WAVE * kTilesG)) * (GM_WAVE * kTilesG / 4);
     for (int i = lane; i < nwords; i += GM_WAVE) m32[i] = 0u;
     wave_sync();
     if (llen > 0 && off >= wb && off < wb + kMarkWindow) L.marks[off - wb] = (unsigned char)(lane + 1);
     wave_sync();
-    for (int t = 0; t < wn; t += GM_WAVE * kTiles) {
-      int own[kTiles], key[kTiles], kidx[kTiles], sb[kTiles], sl[kTiles], fl[kTiles], lo[kTiles];
-      bool in[kTiles];
+    for (int t = 0; t < wn; t += GM_WAVE * kTilesG) {
+      int own[kTilesG], key[kTilesG], kidx[kTilesG], sb[kTilesG], sl[kTilesG], fl[kTilesG], lo[kTilesG];
+      bool in[kTilesG];
 #pragma unroll
-      for (int q = 0; q < kTiles; ++q) own[q] = (int)L.marks[t + q * GM_WAVE + lane];
+      for (int q = 0; q < kTilesG; ++q) own[q] = (int)L.marks[t + q * GM_WAVE + lane];
 #pragma unroll
-      for (int q = 0; q < kTiles; ++q) {
+      for (int q = 0; q < kTilesG; ++q) {
         own[q] = max(wave_incl_scan_max(own[q]), carry);
         carry = readlane(own[q], GM_WAVE - 1);
       }
 #pragma unroll
-      for (int q = 0; q < kTiles; ++q) {
+      for (int q = 0; q < kTilesG; ++q) {
         const int p = wb + t + q * GM_WAVE + lane;
         in[q] = p < total;
         const int4 d = L.desc[in[q] ? own[q] - 1 : 0];
@@ -128,11 +129,11 @@ __device__ __forceinline__ void flat_pass(WaveLds &L, const int *__restrict__ st
         lo[q] = 0;
       }
       if (MODE == SEARCH_BITMAP) {
-        unsigned wv[kTiles];
+        unsigned wv[kTilesG];
 #pragma unroll
-        for (int q = 0; q < kTiles; ++q) wv[q] = bm[(unsigned)key[q] >> 5];
+        for (int q = 0; q < kTilesG; ++q) wv[q] = bm[(unsigned)key[q] >> 5];
 #pragma unroll
-        for (int q = 0; q < kTiles; ++q) {
+        for (int q = 0; q < kTilesG; ++q) {
           const bool f = in[q] & (((wv[q] >> ((unsigned)key[q] & 31u)) & 1u) != 0u) & (key[q] < sb[q]);
           act(f, own[q] - 1, kidx[q], 0, fl[q], key[q]);
         }
@@ -140,11 +141,11 @@ __device__ __forceinline__ void flat_pass(WaveLds &L, const int *__restrict__ st
       }
       // lower_bound by binary lifting: lo = #elements < key.  Written with non-short-circuit '&' and
       // always-executed loads on purpose: with '&&' the compiler sinks each load under its range
-      // test and serialises the kTiles chains behind s_waitcnt vmcnt(0).
+      // test and serialises the kTilesG chains behind s_waitcnt vmcnt(0).
       for (int s = steps - 1; s >= 0; --s) {
-        int x[kTiles], mid[kTiles];
+        int x[kTilesG], mid[kTilesG];
 #pragma unroll
-        for (int q = 0; q < kTiles; ++q) {
+        for (int q = 0; q < kTilesG; ++q) {
           mid[q] = lo[q] + (1 << s);
           if (SLDS) {
             x[q] = stage[sb[q] + mid[q] - 1];  // may read past the list (never past LDS): masked below
@@ -153,19 +154,19 @@ __device__ __forceinline__ void flat_pass(WaveLds &L, const int *__restrict__ st
           }
         }
 #pragma unroll
-        for (int q = 0; q < kTiles; ++q) {
+        for (int q = 0; q < kTilesG; ++q) {
           const bool take = (mid[q] <= sl[q]) & (x[q] < key[q]);
           lo[q] = take ? mid[q] : lo[q];
         }
       }
-      int xf[kTiles];
+      int xf[kTilesG];
 #pragma unroll
-      for (int q = 0; q < kTiles; ++q) {
+      for (int q = 0; q < kTilesG; ++q) {
         if (SLDS) xf[q] = stage[sb[q] + lo[q]];
         else xf[q] = col[sb[q] + max(min(lo[q], sl[q] - 1), 0)];
       }
 #pragma unroll
-      for (int q = 0; q < kTiles; ++q) {
+      for (int q = 0; q < kTilesG; ++q) {
         const bool f = in[q] & (lo[q] < sl[q]) & (xf[q] == key[q]);
         act(f, own[q] - 1, kidx[q], lo[q], fl[q], key[q]);
       }
@@ -227,7 +228,10 @@ __device__ __forceinline__ void drain_candidates(WaveLds &L, const int *__restri
 //     (scalar base address, scalar salt): no owner marks, no scans -- this is where skewed graphs spend their time;
 //   * the remaining short lists of the batch are flattened (owner marks + DPP max-scan), with a fast path for
 //     tiles that contain no list boundary.
-constexpr int kLongList = 192;
+#ifndef GM_LONG_LIST
+#define GM_LONG_LIST 192
+#endif
+constexpr int kLongList = GM_LONG_LIST;
 
 template <class Act>
 __device__ __forceinline__ void flat_pass_filtered(WaveLds &L, const int *__restrict__ stage, const unsigned *__restrict__ fbits,
@@ -276,15 +280,27 @@ __device__ __forceinline__ void flat_pass_filtered(WaveLds &L, const int *__rest
     const int n = readlane(llen_all, src);
     const unsigned salt = (unsigned)readlane(s_base_salt, src) >> 16;
     const int *__restrict__ kp = col + base;
+    // software pipeline: the keys of the NEXT 4 tiles are requested before the current 4 are hashed / filtered /
+    // queued, so 8 coalesced key loads (2 KB) per wave are in flight instead of 4
+    int nxt[kTiles];
+#pragma unroll
+    for (int q = 0; q < kTiles; ++q) {
+      const int p = q * GM_WAVE + lane;
+      nxt[q] = (p < n) ? kp[p] : 0;
+    }
     for (int t = 0; t < n; t += GM_WAVE * kTiles) {
       int key[kTiles];
       unsigned h[kTiles], fw[kTiles];
       bool in[kTiles];
 #pragma unroll
       for (int q = 0; q < kTiles; ++q) {
-        const int p = t + q * GM_WAVE + lane;
-        in[q] = p < n;
-        key[q] = in[q] ? kp[p] : 0;
+        key[q] = nxt[q];
+        in[q] = (t + q * GM_WAVE + lane) < n;
+      }
+#pragma unroll
+      for (int q = 0; q < kTiles; ++q) {
+        const int p = t + GM_WAVE * kTiles + q * GM_WAVE + lane;
+        nxt[q] = (p < n) ? kp[p] : 0;
       }
 #pragma unroll
       for (int q = 0; q < kTiles; ++q) {
