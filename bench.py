@@ -184,7 +184,7 @@ def main():
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "int32 ids / int64 offsets / uint64 counts",
+        "dtype": "int32 (vertex ids, offsets; uint64 counts)",
         "data": "synthetic R-MAT (0.57,0.19,0.19,0.05), SplitMix64 counter stream" if not a.graph else "file",
         "config": {"workload": f"{a.workload}: {desc}", "graph": gname, "nv": g.V(), "ne_sym": sym.E(), "tasks": tasks_total,
                    "max_degree": g.get_max_degree(), "parallelism": f"task-chunk round-robin x{world}, replicated CSR",
@@ -206,7 +206,7 @@ def main():
                 traffic = json.load(open(tpath)).get(f"{a.workload}:{gname}:n{world}")
             out["roofline"] = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-                               "algorithmic_bytes_per_launch": int(per_launch), "kernel": f"mine_kernel<{a.workload}>"}
+                               "algorithmic_bytes_per_launch": int(per_launch), "kernel": "gm::mine_kernel<PAT> (PAT = " + a.workload + ")"}
         if world == 1 and not a.no_cpu_baseline and a.workload == "tc":
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle as O  # the CPU oracle, timed as the OpenMP baseline ("port"): never the product path
