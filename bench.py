@@ -229,6 +229,7 @@ def main():
                 out["cpu_baseline"]["count_matches_gpu"] = bool(cnt == result[0])
         print(json.dumps(out), flush=True)
     if use_dist:
+        dist.barrier()  # rank 0 finishes its host-side reporting before any rank tears the communicator down
         dist.destroy_process_group()
 
 
