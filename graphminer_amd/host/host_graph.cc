@@ -1,5 +1,5 @@
-// graph.cc -- loader + meta printing + GPU orientation for the C++ host side (see graph.h).
-#include "graph.h"
+// host_graph.cc -- loader + meta printing + GPU orientation for the C++ host side (see host_graph.h).
+#include "host_graph.h"
 
 #include <cstdio>
 #include <cstdlib>

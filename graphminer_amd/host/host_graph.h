@@ -1,4 +1,4 @@
-// graph.h -- C++ host side: the Graph / Pattern surface the reference's mains and solvers use.
+// host_graph.h -- C++ host side: the Graph / Pattern surface the reference's mains and solvers use.
 //
 // Mirrors (names, argument meaning, printed lines, error behaviour) of
 //   class Graph    include/graph.h:49-148, src/common/graph.cc:4-124,645-665

@@ -13,7 +13,7 @@
 //     Scheduler::round_robin policy, src/common/scheduler.cc:34-85) -- no per-GPU COO copies;
 //   * the per-GPU 64-bit counts are combined by ONE ncclAllReduce(ncclUint64, ncclSum) instead of the
 //     host-side `total += h_counts[i]` (src/clique/multigpu.cu:134) / MPI_Allreduce (src/triangle/dist_cpu.cpp:56).
-#include "graph.h"
+#include "host_graph.h"
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>

@@ -9,7 +9,7 @@
  *     void CliqueSolver(Graph&, int k, uint64_t& total, int, int)                 src/clique/main.cc:6
  *     void MotifSolver (Graph&, int k, std::vector<uint64_t>&, int, int)          src/motif/main.cc:7
  * becomes a ~10 line shim over gm_tc / gm_sgl / gm_clique / gm_motif (see INTEGRATION.md
- * and graphminer_amd/host/solvers.cc, which is exactly that shim).
+ * and graphminer_amd/host/solvers.cc and integration/hip_solvers.cc, which are exactly that shim).
  *
  * Conventions
  *   - every entry point returns a gm_status (0 = ok); nothing calls exit().
