@@ -197,6 +197,10 @@ def main():
     if rank == 0:
         host = g.download()
         ab = alg_bytes(a.workload, host.row_ptr, host.col_idx)
+        if a.workload == "clique4":  # level 1 = the TC formula, level 2 from the statistics kernel
+            l2 = C.c_uint64(0)
+            _lib.check(lib.gm_clique4_level2_bytes(g.handle, C.byref(l2)), "gm_clique4_level2_bytes")
+            ab = alg_bytes("tc", host.row_ptr, host.col_idx) + int(l2.value)
         if ab is not None:
             per_launch = ab / world  # each rank's kernel covers ~1/world of the chunks
             ach = per_launch / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms > 0 else 0.0

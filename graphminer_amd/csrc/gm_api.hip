@@ -893,6 +893,19 @@ extern "C" int gm_motif_formula(const gm_graph *sym, int k, const gm_launch *la,
   return rc;
 }
 
+// Tooling: the level-2 part of SURVEY.md 8(d)'s ALGORITHMIC bytes of one 4-clique launch,
+//   sum_e [ 8|S1| + sum_{v2 in S1} (4(|S1| + d+(v2)) + 16) ]  =  24*sum|S1| + 4*sum|S1|^2 + 4*sum_{matches} d+(v2),
+// from three sums the mining kernel itself produces (PAT_DAGSTATS). The level-1 part 4*sum_e(d+(v0)+d+(v1)) + 40|E+|
+// is the TC formula (computed by the caller from the CSR arrays).
+extern "C" int gm_clique4_level2_bytes(const gm_graph *dag, uint64_t *bytes) {
+  if (!dag || !bytes) return GM_ERR_INVALID;
+  uint64_t raw[4] = {0, 0, 0, 0};  // raw[0] = sum n^2, raw[1] = sum_{matches} d+(v2), raw[2] = sum n
+  const int rc = run_pattern(PAT_DAGSTATS, dag, nullptr, 4, raw, 4, nullptr, FIN_RAW4, 0);
+  if (rc) return rc;
+  *bytes = 24ull * raw[2] + 4ull * raw[0] + 4ull * raw[1];
+  return GM_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // set-op batch (one wave per pair)
 // ------------------------------------------------------------------------------------------------

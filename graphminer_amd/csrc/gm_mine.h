@@ -39,7 +39,8 @@ struct GraphView {
 };
 
 enum Pattern : int { PAT_TC = 0, PAT_DIAMOND = 1, PAT_MOTIF3 = 2, PAT_CLIQUE4 = 3, PAT_CLIQUEK = 4 /* k = 5..8 */,
-                     PAT_MOTIF4E = 5 /* per-edge sums of the 4-motif formula */ };
+                     PAT_MOTIF4E = 5 /* per-edge sums of the 4-motif formula */,
+                     PAT_DAGSTATS = 6 /* tooling: sum n, sum n^2, sum_{matches} d+(w) for the 4-clique algorithmic bytes */ };
 
 struct MineParams {
   GraphView g;

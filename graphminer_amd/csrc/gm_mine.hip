@@ -28,7 +28,7 @@
 namespace gm {
 
 #define GM_IS_CLIQUE(P) ((P) == PAT_CLIQUE4 || (P) == PAT_CLIQUEK)
-#define GM_IS_PEREDGE(P) ((P) == PAT_DIAMOND || (P) == PAT_MOTIF4E)  // need |N(v0) ^ N(v1)| per task edge
+#define GM_IS_PEREDGE(P) ((P) == PAT_DIAMOND || (P) == PAT_MOTIF4E || (P) == PAT_DAGSTATS)  // need |N(v0) ^ N(v1)| per task edge
 
 // per-wave scratch of the flattened passes
 struct alignas(16) WaveLds {
@@ -627,7 +627,7 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
     bool act = valid;
     int al = a;       // effective length of A = N(u) (a prefix of the row)
     int flag = 0;
-    if (GM_IS_PEREDGE(PAT)) act = valid && (v < u);  // symmetry break, diamond.h:5 / automine_formula.h:27
+    if (PAT == PAT_DIAMOND || PAT == PAT_MOTIF4E) act = valid && (v < u);  // symmetry break, diamond.h:5 / automine_formula.h:27
     if (PAT == PAT_MOTIF3) {
       // One bounded intersection per UNDIRECTED edge {u,v}, v < u, serves both directed edges of automine_3motif:
       //   I(u,v) = |{w in N(u)^N(v) : w < v}|  and  I(v,u) = |{w in N(u)^N(v) : w < u}|.
@@ -667,6 +667,7 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
         acc.c0 += 1;
       } else if (GM_IS_PEREDGE(PAT)) {
         atomicAdd(&L.cnt[owner], 1u);
+        if (PAT == PAT_DAGSTATS) acc.c1 += (unsigned long long)(rp[key + 1] - rp[key]);  // d+(v2) of the common neighbour
       } else if (PAT == PAT_MOTIF3) {
         const unsigned below_v = (key < (int)L.cnt[owner]) ? 1u : 0u;
         acc.c0 += 1u + below_v;    // I(v,u) + I(u,v) contributions of this common neighbour
@@ -705,6 +706,13 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
       wave_sync();
       const unsigned long long n = L.cnt[lane];
       acc.c0 += n * (n - 1) / 2;  // C(n,2), 64-bit (diamond_count.cuh:15-17)
+      wave_sync();
+    }
+    if (PAT == PAT_DAGSTATS) {
+      wave_sync();
+      const unsigned long long n = valid ? L.cnt[lane] : 0ull;
+      acc.c0 += n * n;
+      acc.c2 += n;
       wave_sync();
     }
     if (PAT == PAT_MOTIF4E) {
@@ -804,6 +812,7 @@ hipError_t launch_mine(Pattern pat, const MineParams &p, int grid_blocks, hipStr
     case PAT_TC: hipLaunchKernelGGL(mine_kernel<PAT_TC>, grid, block, 0, stream, p); break;
     case PAT_DIAMOND: hipLaunchKernelGGL(mine_kernel<PAT_DIAMOND>, grid, block, 0, stream, p); break;
     case PAT_MOTIF4E: hipLaunchKernelGGL(mine_kernel<PAT_MOTIF4E>, grid, block, 0, stream, p); break;
+    case PAT_DAGSTATS: hipLaunchKernelGGL(mine_kernel<PAT_DAGSTATS>, grid, block, 0, stream, p); break;
     case PAT_MOTIF3: hipLaunchKernelGGL(mine_kernel<PAT_MOTIF3>, grid, block, 0, stream, p); break;
     case PAT_CLIQUE4: hipLaunchKernelGGL(mine_kernel<PAT_CLIQUE4>, grid, block, 0, stream, p); break;
     case PAT_CLIQUEK: hipLaunchKernelGGL(mine_kernel<PAT_CLIQUEK>, grid, block, 0, stream, p); break;

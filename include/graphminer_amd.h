@@ -185,6 +185,11 @@ int gm_setop_batch(int op, int64_t npairs, const int32_t *d_values, const int64_
  * self-loops are written as the sentinel 0xFFFFFFFFFFFFFFFF. */
 int gm_rmat_keys(int scale, int64_t n_edges, uint64_t seed, uint64_t *d_keys, void *stream);
 
+/* Tooling: level-2 part of the ALGORITHMIC bytes of one 4-clique launch on `dag`:
+ * sum_e [8|S1| + sum_{v2 in S1}(4(|S1| + d+(v2)) + 16)]; the level-1 part is the TC formula. Runs one statistics
+ * kernel (per-edge |S1| and the out-degrees of the matched vertices). */
+int gm_clique4_level2_bytes(const gm_graph *dag, uint64_t *bytes);
+
 /* PMC calibration (tooling): one pass of dword-per-lane coalesced loads over d_buf[0..n), sum -> *d_out.
  * Exactly 4n bytes are read once; run under `rocprofv3 --pmc FETCH_SIZE` to get the counter scale for the
  * access width the mining kernels use (MI355X_MICROARCH.md: FETCH_SIZE is calibrated only for 16 B/lane). */

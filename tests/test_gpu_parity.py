@@ -122,6 +122,17 @@ def test_clique_k_matches_reference(gg, k):
     assert sum(CliqueSolver(dag, k, rank=r, world=3) for r in range(3)) == e[f"clique{k}"]
 
 
+def test_algorithmic_bytes_clique4(gg):
+    """SURVEY 8(d) 4-clique bytes: TC formula (level 1) + gm_clique4_level2_bytes == the oracle's one-pass value"""
+    import ctypes as C
+
+    name, g, _, dag = gg
+    odag = O.orient(O.OGraph(g.row_ptr, g.col_idx))
+    l2 = C.c_uint64(0)
+    assert _lib.load().gm_clique4_level2_bytes(dag.handle, C.byref(l2)) == 0
+    assert O.alg_bytes("tc", odag) + int(l2.value) == O.alg_bytes("clique4", odag)
+
+
 def test_motif3_matches_reference(gg):
     name, _, sym, _ = gg
     assert MotifSolver(sym, 3) == GOLDEN[name]["motif3"]  # [wedges, triangles]: CPU order
