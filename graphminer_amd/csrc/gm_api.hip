@@ -102,7 +102,10 @@ struct gm_graph {
   unsigned long long ev_launches = 0;
   int cu_count = 256;
   gm_graph *dag_cache = nullptr;          // oriented copy, built on demand by gm_motif_formula
-  const gm_graph *ring_alias = nullptr;   // handle whose event ring holds this handle's most recent launch
+  const gm_graph *ring_alias = nullptr;
+  int *d_idx0 = nullptr;                  // rectangle: #neighbours below v, and the wedge-block prefix
+  unsigned long long *d_wblock_prefix = nullptr;
+  unsigned long long n_wblocks = 0;   // handle whose event ring holds this handle's most recent launch
   unsigned long long sum_c2 = 0;          // sum_v C(d(v),2)
   bool sum_c2_valid = false;
   std::mutex mu;
@@ -127,6 +130,8 @@ extern "C" void gm_graph_free(gm_graph *g) {
   if (g->own_col && g->d_col) (void)hipFree(g->d_col);
   if (g->d_counters) (void)hipFree(g->d_counters);
   if (g->d_scratch) (void)hipFree(g->d_scratch);
+  if (g->d_idx0) (void)hipFree(g->d_idx0);
+  if (g->d_wblock_prefix) (void)hipFree(g->d_wblock_prefix);
   for (auto &pr : g->ev)
     for (auto &e : pr)
       if (e) (void)hipEventDestroy(e);
@@ -705,6 +710,88 @@ extern "C" int gm_tc(const gm_graph *dag, const gm_launch *la, uint64_t *total, 
   return run_pattern(PAT_TC, dag, la, 3, total, 1, st);
 }
 
+// rectangle, flattened over wedges (rect_flat_kernel in gm_mine.hip)
+static int run_rect_flat(const gm_graph *cg, const gm_launch *la, uint64_t *h_out, gm_stats *st) {
+  if (!cg) return GM_ERR_INVALID;
+  gm_graph *g = const_cast<gm_graph *>(cg);
+  gm_launch dflt;
+  memset(&dflt, 0, sizeof dflt);
+  if (!la) la = &dflt;
+  const int world = la->world > 1 ? la->world : 1;
+  if (la->rank < 0 || la->rank >= world) return GM_ERR_INVALID;
+  if (!h_out && !la->d_counts) return GM_ERR_INVALID;
+  HIP_TRY(hipSetDevice(g->device));
+  hipStream_t stream = (hipStream_t)la->stream;
+  GraphView gv;
+  gv.nv = g->nv;
+  gv.ne = (int)g->ne;
+  gv.rp = g->d_rp;
+  gv.col = g->d_col;
+  if (!g->d_wblock_prefix) {  // once per graph: idx0[v] on the device, wedge-block prefix on the host
+    HIP_TRY(hipMalloc(&g->d_idx0, sizeof(int) * (size_t)std::max(g->nv, 1)));
+    HIP_TRY(launch_idx0(gv, g->d_idx0, 0));
+    std::vector<int> idx0((size_t)std::max(g->nv, 1));
+    HIP_TRY(hipMemcpy(idx0.data(), g->d_idx0, sizeof(int) * (size_t)g->nv, hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> pre((size_t)g->nv + 1);
+    unsigned long long acc = 0;
+    for (int v = 0; v < g->nv; ++v) {
+      pre[v] = acc;
+      const unsigned long long n = (unsigned long long)idx0[v];
+      acc += (n * (n - (n ? 1ull : 0ull)) / 2ull + 63ull) / 64ull;
+    }
+    pre[g->nv] = acc;
+    g->n_wblocks = acc;
+    HIP_TRY(hipMalloc(&g->d_wblock_prefix, sizeof(unsigned long long) * ((size_t)g->nv + 1)));
+    HIP_TRY(hipMemcpy(g->d_wblock_prefix, pre.data(), sizeof(unsigned long long) * ((size_t)g->nv + 1), hipMemcpyHostToDevice));
+  }
+  RectParams p;
+  memset(&p, 0, sizeof p);
+  p.g = gv;
+  p.idx0 = g->d_idx0;
+  p.block_prefix = g->d_wblock_prefix;
+  p.nblocks = g->n_wblocks;
+  p.group = la->chunk > 0 ? la->chunk : 16;
+  const long long ngroups = (long long)((p.nblocks + (unsigned long long)p.group - 1) / (unsigned long long)p.group);
+  int64_t first = 0, step = 1, count = 0;
+  gm_partition(ngroups, la->rank, world, la->policy, &first, &step, &count);
+  p.first = (unsigned long long)first;
+  p.step = (unsigned long long)step;
+  p.count = (unsigned long long)count;
+  p.counters = g->d_counters;
+  p.queue = g->d_counters + 4;
+  const int grid = (int)std::max<long long>(1, std::min<long long>((count + 3) / 4, (long long)g->cu_count * 8));
+  HIP_TRY(hipMemsetAsync(g->d_counters, 0, 64, stream));
+  g->ring_alias = nullptr;
+  hipEvent_t *evp = g->ev[g->ev_launches % gm_graph::kEvRing];
+  g->ev_launches++;
+  HIP_TRY(hipEventRecord(evp[0], stream));
+  if (count > 0) HIP_TRY(launch_rect_flat(p, grid, stream));
+  HIP_TRY(hipEventRecord(evp[1], stream));
+  if (st) {
+    st->kernel_ms = 0.0;
+    st->tasks = (uint64_t)(g->ne / 2 / world);
+    st->chunks = (uint64_t)count;
+    st->grid = (uint32_t)grid;
+    st->block = 256;
+  }
+  if (la->d_counts) {
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, stream, (int)FIN_COPY, 0ull, g->d_counters,
+                       (unsigned long long *)la->d_counts);
+    HIP_TRY(hipGetLastError());
+    if (!h_out) return GM_OK;
+  }
+  unsigned long long c[4];
+  HIP_TRY(hipMemcpyAsync(c, g->d_counters, sizeof c, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  if (st) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, evp[0], evp[1]));
+    st->kernel_ms = ms;
+  }
+  h_out[0] = c[0];
+  return GM_OK;
+}
+
 // rectangle / house / pentagon: one wave per symmetry-broken edge (gm_sgl.hip)
 static int run_sgl_nested(int pat, const gm_graph *cg, const gm_launch *la, uint64_t *h_out, gm_stats *st) {
   if (!cg) return GM_ERR_INVALID;
@@ -780,7 +867,8 @@ static int run_sgl_nested(int pat, const gm_graph *cg, const gm_launch *la, uint
 extern "C" int gm_sgl(const gm_graph *sym, const char *pattern, const gm_launch *la, uint64_t *total, gm_stats *st) {
   if (!pattern) return GM_ERR_INVALID;
   if (strcmp(pattern, "diamond") == 0) return run_pattern(PAT_DIAMOND, sym, la, 4, total, 1, st);
-  if (strcmp(pattern, "rectangle") == 0) return run_sgl_nested(SGL_RECTANGLE, sym, la, total, st);
+  if (strcmp(pattern, "rectangle") == 0)  // tune[6] & 1024: the first, wave-per-edge version (A/B)
+    return (la && (la->tune[6] & 1024)) ? run_sgl_nested(SGL_RECTANGLE, sym, la, total, st) : run_rect_flat(sym, la, total, st);
   if (strcmp(pattern, "house") == 0) return run_sgl_nested(SGL_HOUSE, sym, la, total, st);
   if (strcmp(pattern, "pentagon") == 0) return run_sgl_nested(SGL_PENTAGON, sym, la, total, st);
   if (total) *total = 0;  // "Not implemented", total_num = 0 (src/sgl/omp_base.cc:51-53)
@@ -822,7 +910,7 @@ extern "C" int gm_motif4_partial(const gm_graph *sym, const gm_launch *la, uint6
   memset(&s1, 0, sizeof s1); memset(&s2, 0, sizeof s2); memset(&s3, 0, sizeof s3);
   int rc = run_pattern(PAT_MOTIF4E, sym, &l2, 4, raw, 4, &s1, FIN_RAW4, 0);
   if (rc) return rc;
-  rc = run_sgl_nested(SGL_RECTANGLE, sym, &l2, &raw[4], &s2);
+  rc = run_rect_flat(sym, &l2, &raw[4], &s2);
   if (rc) return rc;
   rc = run_pattern(PAT_CLIQUE4, g->dag_cache, &l2, 4, &raw[5], 1, &s3);
   if (rc) return rc;

@@ -76,6 +76,20 @@ struct SglParams {
 };
 hipError_t launch_sgl_nested(int pat, const SglParams &p, int grid_blocks, hipStream_t stream);
 
+// flattened rectangle (gm_mine.hip): tasks are WEDGES (v1, v0, v2), v2 < v1 < v0, 64 per wave
+struct RectParams {
+  GraphView g;
+  const int *idx0;                         // idx0[v] = number of neighbours of v that are < v
+  const unsigned long long *block_prefix;  // prefix sum over v of ceil(C(idx0[v],2) / 64)
+  unsigned long long first, step, count;   // this rank owns wedge-block groups first + i*step, i in [0,count)
+  unsigned long long nblocks;              // total wedge blocks
+  int group;                               // wedge blocks per dequeue
+  unsigned long long *queue;               // 64-bit dequeue head
+  unsigned long long *counters;
+};
+hipError_t launch_rect_flat(const RectParams &p, int grid_blocks, hipStream_t stream);
+hipError_t launch_idx0(const GraphView &g, int *idx0, hipStream_t stream);
+
 // host-side launchers (gm_mine.hip)
 hipError_t launch_mine(Pattern pat, const MineParams &p, int grid_blocks, hipStream_t stream);
 size_t mine_lds_bytes(Pattern pat);

@@ -798,6 +798,79 @@ __global__ __launch_bounds__(kWavesPerBlock *GM_WAVE, PAT == PAT_CLIQUEK ? 4 : (
   }
 }
 
+// ---- rectangle (4-cycle), flattened ------------------------------------------------------------------------
+// src/sgl/cpu_kernels/rectangle.h:1-11:  for v0, v1 in N(v0) (v1 < v0), v2 in N(v0) (v2 < v1):
+//                                            count += |{w in N(v1) ^ N(v2) : w < v0}|
+// The task space is the set of WEDGES (v1, v0, v2). A wave takes 64 wedges of one centre v0 (wedge id t ->
+// (i, j), j < i < idx0[v0], by inverting the triangular number), trims both neighbour lists to keys < v0 and runs
+// ONE flattened pass: the shorter trimmed list is the lookup list, the longer one is bisected in HBM/L2.
+__global__ __launch_bounds__(256) void idx0_kernel(GraphView g, int *__restrict__ idx0) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < g.nv) idx0[v] = lower_bound(g.col + g.rp[v], g.rp[v + 1] - g.rp[v], v);
+}
+
+__global__ __launch_bounds__(256) void rect_flat_kernel(const RectParams p) {
+  __shared__ WaveLds W[kWavesPerBlock];
+  const int *__restrict__ rp = p.g.rp;
+  const int *__restrict__ col = p.g.col;
+  const int lane = threadIdx.x & 63;
+  WaveLds &L = W[threadIdx.x >> 6];
+  unsigned long long cnt = 0;
+  for (;;) {
+    unsigned long long q = 0;
+    if (lane == 0) q = atomicAdd(p.queue, 1ull);
+    q = ((unsigned long long)(unsigned)readfirst((int)(q >> 32)) << 32) | (unsigned)readfirst((int)q);
+    if (q >= p.count) break;
+    const unsigned long long gid = p.first + q * p.step;
+    const unsigned long long b0 = gid * (unsigned long long)p.group;
+    const unsigned long long b1 = min(p.nblocks, b0 + (unsigned long long)p.group);
+    // centre of the first block: largest v with block_prefix[v] <= b0 (wave-uniform bisection)
+    int lo = 0, hi = p.g.nv - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (p.block_prefix[mid] <= b0) lo = mid; else hi = mid - 1;
+    }
+    int v0 = lo;
+    for (unsigned long long blk = b0; blk < b1; ++blk) {
+      while (p.block_prefix[v0 + 1] <= blk) ++v0;
+      const int n0 = p.idx0[v0];
+      const unsigned long long nw = (unsigned long long)n0 * (unsigned long long)(n0 - 1) / 2ull;  // wedges of v0
+      const unsigned long long t = (blk - p.block_prefix[v0]) * 64ull + (unsigned long long)lane;
+      const bool valid = t < nw;
+      int llen = 0, key_base = 0, s_base = 0, s_len = 0;
+      if (valid) {
+        // t = i(i-1)/2 + j, 0 <= j < i  ->  i = floor((1 + sqrt(1 + 8t)) / 2), fixed up against rounding
+        long long i = (long long)((1.0 + sqrt(1.0 + 8.0 * (double)t)) * 0.5);
+        while (i * (i - 1) / 2 > (long long)t) --i;
+        while ((i + 1) * i / 2 <= (long long)t) ++i;
+        const long long j = (long long)t - i * (i - 1) / 2;
+        const int *A0 = col + rp[v0];
+        const int v1 = A0[i], v2 = A0[j];
+        const int r1 = rp[v1], r2 = rp[v2];
+        const int d1 = lower_bound(col + r1, rp[v1 + 1] - r1, v0);  // keys >= v0 can never count (rectangle.h:8)
+        const int d2 = lower_bound(col + r2, rp[v2 + 1] - r2, v0);
+        if (d1 <= d2) { llen = d1; key_base = r1; s_base = r2; s_len = d2; }
+        else { llen = d2; key_base = r2; s_base = r1; s_len = d1; }
+        if (s_len == 0) llen = 0;
+      }
+      auto act = [&](bool f, int, int, int, int, int) { cnt += f ? 1u : 0u; };
+      flat_pass<SEARCH_HBM>(L, nullptr, col, nullptr, lane, llen, key_base, s_base, s_len, act);
+    }
+  }
+  const unsigned long long s0 = wave_sum_u64(cnt);
+  if (lane == 0 && s0) atomicAdd(&p.counters[0], s0);
+}
+
+hipError_t launch_idx0(const GraphView &g, int *idx0, hipStream_t stream) {
+  hipLaunchKernelGGL(idx0_kernel, dim3((unsigned)((g.nv + 255) / 256)), dim3(256), 0, stream, g, idx0);
+  return hipGetLastError();
+}
+
+hipError_t launch_rect_flat(const RectParams &p, int grid_blocks, hipStream_t stream) {
+  hipLaunchKernelGGL(rect_flat_kernel, dim3((unsigned)grid_blocks), dim3(256), 0, stream, p);
+  return hipGetLastError();
+}
+
 size_t mine_lds_bytes(Pattern pat) {
   switch (pat) {
     case PAT_CLIQUE4:
