@@ -98,3 +98,31 @@ def test_empty_and_ragged_host_graphs():
     assert (g.V(), g.E(), g.max_degree) == (2, 0, 0)
     with pytest.raises(GraphFormatError):
         Graph(row_ptr=[0, 2, 1], col_idx=[1])
+
+
+def test_size_limits_are_reported_not_wrapped():
+    """maximum sizes: this build indexes tasks with int32; larger graphs must be refused, never truncated"""
+    lib = _lib.load()
+    dummy = np.zeros(4, dtype=np.int64)
+    h = C.c_void_p()
+    big = _lib.gm_csr(10, 2**31, 5, dummy.ctypes.data, dummy.ctypes.data)
+    assert lib.gm_graph_upload(C.byref(big), 0, C.byref(h)) == _lib.GM_ERR_TOO_LARGE
+    neg = _lib.gm_csr(-1, 0, 0, dummy.ctypes.data, dummy.ctypes.data)
+    assert lib.gm_graph_upload(C.byref(neg), 0, C.byref(h)) == _lib.GM_ERR_INVALID
+    assert lib.gm_strerror(_lib.GM_ERR_TOO_LARGE).startswith(b"graph exceeds")
+
+
+def test_partition_and_chunk_table_host_api():
+    from graphminer_amd import dist
+
+    g = load_graph("cora")
+    t = dist.chunk_table(g.row_ptr)
+    assert t[:, 3].max() == g.E() and (t[:, 1] > t[:, 0]).all()
+    f, s_, c = C.c_int64(), C.c_int64(), C.c_int64()
+    lib = _lib.load()
+    assert lib.gm_partition(10, 3, 3, 0, C.byref(f), C.byref(s_), C.byref(c)) == _lib.GM_ERR_INVALID  # rank >= world
+    assert lib.gm_partition(10, 2, 3, 0, C.byref(f), C.byref(s_), C.byref(c)) == 0 and (f.value, s_.value, c.value) == (2, 3, 3)
+    raw = (C.c_uint64 * 6)(1381580, 123529, 54600, 7460, 6059, 255)  # citeseer raw sums (4-motif formula)
+    out = (C.c_uint64 * 6)()
+    assert lib.gm_motif4_finish(raw, out) == 0
+    assert [int(x) for x in out] == GOLDEN["citeseer"]["motif4"]
