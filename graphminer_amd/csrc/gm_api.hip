@@ -624,7 +624,7 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
   p.cost_y_base = la->tune[7] > 0 ? (la->tune[7] & 15) : 2;
   p.k = k;
   p.flags = (la->tune[5] == 1) ? 1 : 0;
-  p.flags |= (la->tune[6] & 1023) << 1;  // debug/ablation: bit1 skip clique phase 2, bit2 skip bit-matrix writes (counts wrong)
+  p.flags |= (la->tune[6] & 0xffff) << 1;  // debug/ablation: bit1 skip clique phase 2, bit2 skip bit-matrix writes (counts wrong)
   p.counters = g->d_counters;
   p.queue = reinterpret_cast<unsigned *>(g->d_counters + 4);
 

@@ -392,27 +392,55 @@ __device__ __forceinline__ unsigned long long clique4_count(const int *__restric
 // Same sum for a matrix that lives in the global scratch arena (one big vertex, rows 0..nel-1, row0 = 0):
 // one wave per row i, lane w holds word w of M_i, the set bits j of M_i are walked with scalar code and the
 // rows M_j are fetched with coalesced loads, four independent loads in flight.
-__device__ __forceinline__ unsigned long long clique4_count_wide(const unsigned *__restrict__ bits, const int lane, const int wave,
-                                                                 const int nel, const int stride) {
-  // requires stride <= 64 (rows up to 2048 columns): lane w holds word w of M_i
+__device__ __forceinline__ unsigned long long clique4_count_wide(WaveLds &L, const unsigned *__restrict__ bits, const int lane,
+                                                                 const int wave, const int nel, const int stride) {
+  // requires stride <= 64 (rows up to 2048 columns).
+  // Per row i: the set-bit positions of M_i are expanded into a per-wave LDS list (popcount + DPP scan give each lane its
+  // slot), then the rows M_j are fetched G at a time by 64/G-lane groups with 16 independent loads in flight per lane --
+  // the matrix of a big vertex lives in the scratch arena (L2 / Infinity Cache), so memory-level parallelism is what counts.
+  unsigned short *plist = reinterpret_cast<unsigned short *>(&L);  // the flat-pass scratch is idle during this phase
+  constexpr int kCap = (int)(sizeof(WaveLds) / sizeof(unsigned short));
+  const int P2 = stride <= 8 ? 8 : stride <= 16 ? 16 : stride <= 32 ? 32 : 64;
+  const int G = 64 / P2, gid = lane / P2, wq = lane % P2;
+  const bool actw = wq < stride;
   unsigned long long c = 0;
   for (int i = wave; i < nel; i += kWavesPerBlock) {
     const unsigned mi = (lane < stride) ? bits[(size_t)i * stride + lane] : 0u;
-    for (int w = 0; w < stride; ++w) {
-      unsigned x = (unsigned)readlane((int)mi, w);  // wave-uniform: the set bits of word w select rows j
+    const int cw = __popc(mi);
+    const int incl = wave_incl_scan_add(cw);
+    const int total = readlane(incl, GM_WAVE - 1);
+    if (total == 0) continue;
+    if (total <= kCap) {
+      unsigned x = mi;
+      int k = incl - cw;
       while (x) {
-        int j[4];
+        plist[k++] = (unsigned short)(lane * 32 + (__ffs((int)x) - 1));
+        x &= x - 1;
+      }
+      wave_sync();
+      const unsigned mrep = actw ? bits[(size_t)i * stride + wq] : 0u;
+      constexpr int kInFlight = 16;
+      for (int p = 0; p < total; p += kInFlight * G) {
+        unsigned m[kInFlight];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int bit = x ? (__ffs((int)x) - 1) : 0;
-          j[k] = x ? (w * 32 + bit) : -1;
-          x = x ? (x & (x - 1)) : 0u;
+        for (int u = 0; u < kInFlight; ++u) {
+          const int idx = p + u * G + gid;
+          const int j = (idx < total) ? (int)plist[idx] : -1;
+          m[u] = (j >= 0 && actw) ? bits[(size_t)j * stride + wq] : 0u;
         }
-        unsigned m[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) m[k] = (j[k] >= 0 && lane < stride) ? bits[(size_t)j[k] * stride + lane] : 0u;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) c += (unsigned)__popc(mi & m[k]);
+        for (int u = 0; u < kInFlight; ++u) c += (unsigned)__popc(mrep & m[u]);
+      }
+      wave_sync();
+    } else {  // more set bits than the list holds: walk them with scalar code
+      for (int w = 0; w < stride; ++w) {
+        unsigned x = (unsigned)readlane((int)mi, w);
+        while (x) {
+          const int bit = __ffs((int)x) - 1;
+          x &= x - 1;
+          const unsigned mj = (lane < stride) ? bits[(size_t)(w * 32 + bit) * stride + lane] : 0u;
+          c += (unsigned)__popc(mi & mj);
+        }
       }
     }
   }
@@ -592,14 +620,22 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
     if (tid == 0) B.next_batch = g0 / GM_WAVE;
     __syncthreads();
   }
+  // A big clique vertex is built in row groups that may hold a single batch: then all 4 waves work on EVERY batch of
+  // the group, each owning the edges with (lane & 3) == wave, instead of one wave working while three idle.
+  const bool split4 = GM_IS_CLIQUE(PAT) && grouped;
+  int my_bi = g0 / GM_WAVE;
   for (;;) {
     int bi = 0;
-    if (lane == 0) bi = atomicAdd(&B.next_batch, 1);
-    bi = readfirst(bi);
+    if (split4) {
+      bi = my_bi++;
+    } else {
+      if (lane == 0) bi = atomicAdd(&B.next_batch, 1);
+      bi = readfirst(bi);
+    }
     const int le0 = bi * GM_WAVE;
     if (le0 >= gend) break;
     const int le = le0 + lane;
-    const bool valid = le < nel;
+    const bool valid = (le < nel) && (!split4 || (lane & 3) == wave);
     const int e = eb + le;
     int v = 0, u = 0, ru = 0, a = 0, rv = 0, b = 0, idx = 0, lrow_of_lane = 0;
     if (valid) {
@@ -739,6 +775,7 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
   __syncthreads();  // every batch of the chunk is done (LDS is reused by the next chunk)
   if (GM_IS_CLIQUE(PAT) && !(p.flags & 2)) {
     const bool wide = !bits_lds && nvl == 1 && stride <= GM_WAVE;
+    if (((p.flags & 4096) && bits_lds) || ((p.flags & 8192) && !bits_lds)) { __syncthreads(); return; }  // ablation
     if (!bits_lds) {
       __threadfence();  // the scratch matrix was written by all 4 waves (plain stores or device atomics)
       __syncthreads();
@@ -746,7 +783,7 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
     const unsigned *M = bits_lds ? B.bits : gbits;
     switch (PAT == PAT_CLIQUE4 ? 4 : p.k) {
       case 4:
-        if (wide) acc.c0 += clique4_count_wide(M, lane, wave, nel, stride);
+        if (wide) acc.c0 += clique4_count_wide(L, M, lane, wave, nel, stride);
         else acc.c0 += clique4_count(B.rpl, M, tid, nthreads, eb, nel, nvl, stride);
         break;
 #define GM_CLIQUE_CASE(K)                                                                                   \
