@@ -1,24 +1,24 @@
-// gm_mine.h -- shared declarations between the host API (gm_api.hip / gm_graph.hip) and the
-// mining kernels (gm_mine.hip).
+// gm_mine.h -- shared declarations between the host API (gm_api.hip) and the mining kernels
+// (gm_mine.hip, gm_sgl.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace gm {
 
-// ---- compile-time geometry of one worker wave ------------------------------------------------
-constexpr int kWavesPerBlock = 4;         // 256-thread workgroups, the 4 waves work independently
-constexpr int kStageCap = 1024;           // adjacency entries one wave stages in LDS (4 KB)
+// ---- compile-time geometry of one workgroup ---------------------------------------------------
+constexpr int kWavesPerBlock = 4;         // 256-thread workgroups: the 4 waves share a chunk's LDS stage, take batches independently
+constexpr int kStageCap = 1024;           // adjacency entries a workgroup stages in LDS per chunk (4 KB)
 constexpr int kMaxChunkVerts = 256;       // rows per task chunk (local row_ptr slice in LDS)
 constexpr int kMarkWindow = 512;          // flattened positions resolved per owner-mark window
 #ifndef GM_TILES
-#define GM_TILES 2  // 64-wide tiles resolved together per wave (ILP); swept on MI355X: 2 beats 4 once the filter is in
+#define GM_TILES 2  // 64-wide tiles resolved together per wave in the FILTERED pass; swept on MI355X (2 beats 4 there)
 #endif
 #define GM_TILES_DEFAULT GM_TILES
 #ifndef GM_FILTER_LOG2
 #define GM_FILTER_LOG2 15
 #endif
-constexpr int kFilterLog2 = GM_FILTER_LOG2;           // hashed membership filter: 2^14 bits (2 KB) per workgroup
+constexpr int kFilterLog2 = GM_FILTER_LOG2;           // hashed membership filter: 2^15 bits (4 KB) per workgroup (2^14 and 2^16 measured slower)
 constexpr int kFilterBits = 1 << kFilterLog2;
 constexpr int kFilterWords = kFilterBits / 32;
 constexpr int kQueueCap = 64 * (GM_TILES_DEFAULT + 1);  // candidate queue entries per wave (63 left over + kTiles tiles)
@@ -52,9 +52,9 @@ struct MineParams {
   int grab;                      // chunks taken per dequeue
   unsigned *queue;               // dequeue head (zeroed before launch)
   unsigned long long *counters;  // [4] accumulators (zeroed before launch)
-  unsigned *scratch;             // clique: global bit-matrix arena, scratch_words per wave
+  unsigned *scratch;             // clique: global bit-matrix arena, scratch_words per workgroup
   unsigned long long scratch_words;
-  int cost_x_step;  // direction heuristic, see choose_dir()
+  int cost_x_step;  // direction rule: X if b*(xb + xs*lg a) <= a*(yb + ys*lg b)
   int cost_y_step;
   int cost_x_base;
   int cost_y_base;

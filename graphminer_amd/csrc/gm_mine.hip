@@ -8,20 +8,22 @@
 // and the CPU loops they mirror (src/triangle/omp_base.cc:15-21, src/sgl/cpu_kernels/diamond.h,
 // src/clique/cpu_kernels/automine_omp.h:67-83, src/motif/cpu_kernels/automine_base.h:2-22).
 //
-// MI355X design (see DESIGN.md):
-//  * worker = one wave64. A worker dequeues TASK CHUNKS (a contiguous vertex range owning ~T CSR
-//    entries), loads the chunk's row offsets and adjacency slice into LDS with coalesced loads
-//    ("adjacency slices staged in LDS"), then walks the chunk 64 edges (u,v) at a time.
-//  * the reference gives each edge a whole 32-lane warp, so on LiveJournal (mean oriented list
-//    length 8.8) most lanes idle. Here the 64 edges of a batch are FLATTENED: the lookup lists of
-//    all 64 edges form one virtual array, lane p handles element p. The element->edge map is an
-//    owner-mark array in LDS resolved by a DPP max-scan, so every lane of every tile does one
-//    binary search regardless of how skewed the list lengths are.
-//  * per edge the cheaper direction is chosen: (X) stream N(v) with coalesced loads and bisect
-//    the LDS-resident N(u), or (Y) take the keys from N(u) and bisect N(v) in global memory.
+// MI355X design (see DESIGN.md section 4.1):
+//  * workgroup = 4 waves. Workgroups dequeue TASK CHUNKS (a contiguous vertex range owning up to 1024 CSR
+//    entries), stage the chunk's row offsets and adjacency slice in LDS with coalesced loads ("adjacency
+//    slices staged in LDS") together with a hashed membership bit filter; the waves then take batches of
+//    64 task edges (u,v) from an LDS counter.
+//  * the reference gives each edge a whole 32-lane warp, so on LiveJournal (mean oriented list length 8.8)
+//    most lanes idle. Here the lookup lists of the 64 edges of a batch are FLATTENED into one virtual
+//    array, lane p handles element p; the element->edge map is an owner-mark array in LDS resolved by a
+//    DPP max-scan. Long lists (>= 192 keys) are streamed with a wave-uniform descriptor instead.
+//  * per edge the cheaper direction is chosen: (X) stream N(v) with coalesced loads and test the keys against
+//    the LDS-resident N(u) (bit filter -> ballot compaction -> branch-free bisection of the survivors), or
+//    (Y) take the keys from N(u) and bisect N(v) in HBM/L2. Hub rows longer than the stage (SPLIT chunks of
+//    symmetric graphs) are probed through a dense vertex-id bitmap.
 //  * counts stay in 64-bit per-lane registers; one global atomic per wave per counter at the end.
-//  * 4-clique keeps the candidate sets as an LDS bit-matrix over N+(u) (row = edge (u,v1), bit j =
-//    N+(u)[j] in N+(v1)); the second DFS level is popcount(row_i & row_j) without touching HBM.
+//  * k-clique keeps the candidate sets as an LDS bit-matrix over N+(u) (row = edge (u,v1), bit j =
+//    N+(u)[j] in N+(v1)); deeper DFS levels are popcounts of row ANDs without touching HBM.
 #include "gm_mine.h"
 #include "gm_setops.h"
 

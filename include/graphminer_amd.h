@@ -90,7 +90,10 @@ typedef struct gm_launch {
                          (src/triangle/main.cc:16) */
   uint64_t *d_counts; /* optional DEVICE buffer (>= ncounts uint64). When set the result is left on the
                          device, no host sync is done (use it to feed an RCCL all-reduce). */
-  int32_t tune[8];    /* kernel tuning knobs, all 0 = defaults */
+  int32_t tune[8];    /* kernel tuning / ablation knobs, all 0 = defaults: [0] task edges per chunk, [1] chunks per
+                         dequeue, [2] xs+1 and [3] ys+1 of the direction rule b*(xb+xs*lg a) <= a*(yb+ys*lg b),
+                         [4] workgroups per CU, [5] 1 = never stage adjacency in LDS, [6] ablation bit mask
+                         (gm_api.hip), [7] xb*16+yb. Results never depend on them (tests/test_gpu_parity.py). */
 } gm_launch;
 
 typedef struct gm_stats {
