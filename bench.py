@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--ef", type=int, default=0)
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--graph", default="", help="prefix of graph.meta.txt/.vertex.bin/.edge.bin (real dataset)")
+    ap.add_argument("--uniform", default="", help="NV,M: uniform random graph instead of R-MAT (LiveJournal-size flat-degree stand-in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the bounded oracle sample")
     ap.add_argument("--tune", default="", help="comma separated gm_launch.tune[] override")
@@ -111,6 +112,12 @@ def main():
     if a.graph:
         sym = Graph(a.graph).to_device(local_rank)
         gname = f"file:{a.graph}"
+    elif a.uniform:
+        from graphminer_amd.rmat import uniform_csr_device
+
+        unv, um = (int(x) for x in a.uniform.split(","))
+        sym, _rp, _ci = uniform_csr_device(unv, um, a.seed, local_rank)
+        gname = f"uniform_nv{unv}_m{um}_seed{a.seed}"
     else:
         sym, _rp, _ci = rmat_csr_device(scale, ef, a.seed, local_rank)
         gname = f"rmat_s{scale}_ef{ef}_seed{a.seed}"
@@ -185,7 +192,8 @@ def main():
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": "int32 (vertex ids, offsets; uint64 counts)",
-        "data": "synthetic R-MAT (0.57,0.19,0.19,0.05), SplitMix64 counter stream" if not a.graph else "file",
+        "data": "file" if a.graph else ("synthetic uniform random graph (torch RNG)" if a.uniform else
+                                        "synthetic R-MAT (0.57,0.19,0.19,0.05), SplitMix64 counter stream"),
         "config": {"workload": f"{a.workload}: {desc}", "graph": gname, "nv": g.V(), "ne_sym": sym.E(), "tasks": tasks_total,
                    "max_degree": g.get_max_degree(), "parallelism": f"task-chunk round-robin x{world}, replicated CSR",
                    "input_build_s": round(t_in, 2)},

@@ -99,3 +99,29 @@ def rmat_csr_device(scale: int, edge_factor: int, seed: int = 42, device: int = 
     g = DeviceGraph.from_device_ptrs(nv, int(col.numel()), row_ptr.data_ptr(), col.data_ptr(), device,
                                      keepalive=(row_ptr, col))
     return g, row_ptr, col
+
+
+def uniform_csr_device(nv: int, m: int, seed: int = 1, device: int = 0):
+    """Erdos-Renyi-like graph on the GPU (torch RNG): m random pairs, self-loops dropped, symmetrised, deduplicated.
+    A second synthetic stand-in with LiveJournal's SIZE but a flat degree profile (mean oriented list ~9): the
+    short-list regime, where R-MAT (hub-dominated) is the long-list regime. Not bit-reproducible across torch
+    versions -- used for measurements only, never for goldens."""
+    import torch
+
+    dev = torch.device("cuda", device)
+    with torch.cuda.device(dev):
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(seed)
+        s = torch.randint(0, nv, (m,), device=dev, generator=gen)
+        d = torch.randint(0, nv, (m,), device=dev, generator=gen)
+        keep = s != d
+        s, d = s[keep], d[keep]
+        keys = torch.unique(torch.cat([(s << 32) | d, (d << 32) | s]))
+        src = keys >> 32
+        col = (keys & 0xFFFFFFFF).to(torch.int32).contiguous()
+        row_ptr = torch.zeros(nv + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(torch.bincount(src, minlength=nv), 0, out=row_ptr[1:])
+        del keys, src, s, d
+        torch.cuda.synchronize(dev)
+    g = DeviceGraph.from_device_ptrs(nv, int(col.numel()), row_ptr.data_ptr(), col.data_ptr(), device, keepalive=(row_ptr, col))
+    return g, row_ptr, col
