@@ -82,6 +82,7 @@ struct ChunkTable {
   unsigned long long bitmap_words = 0;
   unsigned long long max_bit_words = 0;  // largest nel*stride over chunks that exceed bit_words
   std::vector<unsigned long long> edge_prefix;  // edges owned by chunks [0,i)
+  std::vector<int> first_vertex;                // u_begin of every chunk (ascending; SPLIT chunks repeat it)
 };
 
 struct gm_graph {
@@ -452,6 +453,8 @@ static int get_table(gm_graph *g, int target, bool allow_split, int bit_words, C
   t.bit_words = bit_words;
   build_chunks(g->h_rp, g->nv, target, allow_split, bit_words, recs, t.max_bit_words);
   t.n = recs.size();
+  t.first_vertex.resize(t.n);
+  for (size_t i = 0; i < t.n; ++i) t.first_vertex[i] = recs[i].u_begin;
   t.edge_prefix.resize(t.n + 1);
   t.edge_prefix[0] = 0;
   for (size_t i = 0; i < t.n; ++i) t.edge_prefix[i + 1] = t.edge_prefix[i] + (unsigned long long)(recs[i].e_end - recs[i].e_begin);
@@ -510,7 +513,7 @@ extern "C" int gm_partition(int64_t n_chunks, int32_t rank, int32_t world, int32
   if (!first || !step || !count || n_chunks < 0) return GM_ERR_INVALID;
   if (world < 1) world = 1;
   if (rank < 0 || rank >= world) return GM_ERR_INVALID;
-  if (policy == GM_PART_RANGE) {
+  if (policy == GM_PART_RANGE || policy == GM_PART_VERTEX) {
     const long long lo = n_chunks * rank / world, hi = n_chunks * (rank + 1) / world;
     *first = lo;
     *step = 1;
@@ -609,7 +612,21 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
   unsigned long long my_edges = 0;
   {
     long long first = 0, step = 1, count = 0;
-    gm_partition((int64_t)n, rank, world, la->policy, (int64_t *)&first, (int64_t *)&step, (int64_t *)&count);
+    if (la->policy == GM_PART_VERTEX) {  // contiguous chunk range whose first vertex lies in this rank's vertex range
+      const long long vlo = (long long)g->nv * rank / world, vhi = (long long)g->nv * (rank + 1) / world;
+      auto first_chunk_at = [&](long long v) {
+        long long lo = 0, hi = n;
+        while (lo < hi) {
+          const long long mid = (lo + hi) / 2;
+          if (tab->first_vertex[(size_t)mid] < v) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+      };
+      first = first_chunk_at(vlo);
+      count = first_chunk_at(vhi) - first;
+    } else {
+      gm_partition((int64_t)n, rank, world, la->policy, (int64_t *)&first, (int64_t *)&step, (int64_t *)&count);
+    }
     p.first = (int)first;
     p.step = (int)step;
     p.count = (int)count;

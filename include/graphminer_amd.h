@@ -78,7 +78,10 @@ void gm_graph_free(gm_graph *g);
 /* Scheduler policy for the multi-GPU task split (include/scheduler.h, src/common/scheduler.cc). */
 enum {
   GM_PART_ROUND_ROBIN = 0, /* Scheduler::round_robin, scheduler.cc:34-85: chunk c -> rank c mod world */
-  GM_PART_RANGE = 1        /* even contiguous split (EVEN_SPLIT, src/clique/multigpu.cu:42-44) */
+  GM_PART_RANGE = 1,       /* even contiguous split of the task chunks (EVEN_SPLIT, src/clique/multigpu.cu:42-44) */
+  GM_PART_VERTEX = 2       /* vertex-balanced: rank r owns the tasks of vertices [nv*r/world, nv*(r+1)/world)
+                              (1-D vertex ranges of src/common/graph_partition.cc:82-132, without the halo copies:
+                              the CSR is replicated); solvers only, gm_partition treats it like GM_PART_RANGE */
 };
 
 typedef struct gm_launch {

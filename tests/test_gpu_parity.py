@@ -166,7 +166,7 @@ def test_motif4_matches_reference(gg):
     assert [int(x) for x in out] == e["motif4"]
 
 
-@pytest.mark.parametrize("world,policy", [(2, 0), (3, 0), (8, 0), (2, 1), (5, 1)])
+@pytest.mark.parametrize("world,policy", [(2, 0), (3, 0), (8, 0), (2, 1), (5, 1), (2, 2), (7, 2)])
 def test_task_partition_sums_to_the_whole(gg, world, policy):
     name, _, sym, dag = gg
     e = GOLDEN[name]
