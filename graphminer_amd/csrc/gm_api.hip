@@ -569,25 +569,94 @@ __global__ void finalize_kernel(int mode, unsigned long long base, const unsigne
   }
 }
 
+// ---- common launch prologue / epilogue of every mining entry point -----------------------------------------------
+struct LaunchCtx {
+  gm_graph *g = nullptr;
+  gm_launch la;          // caller's launch descriptor, or the all-zero default
+  int world = 1, rank = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t *evp = nullptr;  // event pair of this launch (ring slot)
+};
+
+// validates the arguments, selects the device, zeroes the 64-byte counter block on the launch stream
+static int begin_launch(const gm_graph *cg, const gm_launch *la, const uint64_t *h_out, LaunchCtx &c) {
+  if (!cg) return GM_ERR_INVALID;
+  c.g = const_cast<gm_graph *>(cg);
+  memset(&c.la, 0, sizeof c.la);
+  if (la) c.la = *la;
+  c.world = c.la.world > 1 ? c.la.world : 1;
+  c.rank = c.la.rank;
+  if (c.rank < 0 || c.rank >= c.world) return GM_ERR_INVALID;
+  if (!h_out && !c.la.d_counts) return GM_ERR_INVALID;
+  HIP_TRY(hipSetDevice(c.g->device));
+  c.stream = (hipStream_t)c.la.stream;
+  HIP_TRY(hipMemsetAsync(c.g->d_counters, 0, 64, c.stream));
+  return GM_OK;
+}
+
+static int start_timer(LaunchCtx &c) {
+  c.g->ring_alias = nullptr;
+  c.evp = c.g->ev[c.g->ev_launches % gm_graph::kEvRing];
+  c.g->ev_launches++;
+  HIP_TRY(hipEventRecord(c.evp[0], c.stream));
+  return GM_OK;
+}
+
+// stops the timer, publishes the counters: to d_counts (device, asynchronous) and / or to h_out (synchronises)
+static int end_launch(LaunchCtx &c, int fin_mode, unsigned long long fin_base, uint64_t *h_out, int nout, gm_stats *st) {
+  HIP_TRY(hipEventRecord(c.evp[1], c.stream));
+  if (c.la.d_counts) {
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, c.stream, fin_mode, fin_base, c.g->d_counters,
+                       (unsigned long long *)c.la.d_counts);
+    HIP_TRY(hipGetLastError());
+    if (!h_out) return GM_OK;  // asynchronous: the caller owns the synchronisation
+  }
+  unsigned long long v[4];
+  HIP_TRY(hipMemcpyAsync(v, c.g->d_counters, sizeof v, hipMemcpyDeviceToHost, c.stream));
+  HIP_TRY(hipStreamSynchronize(c.stream));
+  if (st) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, c.evp[0], c.evp[1]));
+    st->kernel_ms = ms;
+  }
+  if (fin_mode == FIN_MOTIF3) {
+    if (nout > 0) h_out[0] = v[2] - v[0];
+    if (nout > 1) h_out[1] = v[1];
+  } else if (fin_mode == FIN_MOTIF3_FORMULA) {
+    if (nout > 0) h_out[0] = fin_base - 3ull * v[0];
+    if (nout > 1) h_out[1] = v[0];
+  } else if (fin_mode == FIN_RAW4) {
+    for (int i = 0; i < 4 && i < nout; ++i) h_out[i] = v[i];
+  } else {
+    h_out[0] = v[0];
+  }
+  return GM_OK;
+}
+
+static void fill_stats(gm_stats *st, uint64_t tasks, uint64_t chunks, int grid, int block) {
+  if (!st) return;
+  st->kernel_ms = 0.0;
+  st->tasks = tasks;
+  st->chunks = chunks;
+  st->grid = (uint32_t)grid;
+  st->block = (uint32_t)block;
+}
+
 static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uint64_t *h_out, int nout, gm_stats *st,
                        int fin_mode = -1, unsigned long long fin_base = 0) {
   if (fin_mode < 0) fin_mode = (pat == PAT_MOTIF3) ? FIN_MOTIF3 : FIN_COPY;
-  if (!cg) return GM_ERR_INVALID;
-  gm_graph *g = const_cast<gm_graph *>(cg);
-  gm_launch dflt;
-  memset(&dflt, 0, sizeof dflt);
-  if (!la) la = &dflt;
-  const int world = la->world > 1 ? la->world : 1;
-  const int rank = la->rank;
-  if (rank < 0 || rank >= world) return GM_ERR_INVALID;
-  if (!h_out && !la->d_counts) return GM_ERR_INVALID;
-  HIP_TRY(hipSetDevice(g->device));
-  hipStream_t stream = (hipStream_t)la->stream;
+  LaunchCtx ctx;
+  int rc0 = begin_launch(cg, la, h_out, ctx);
+  if (rc0) return rc0;
+  gm_graph *g = ctx.g;
+  la = &ctx.la;
+  const int world = ctx.world, rank = ctx.rank;
+  hipStream_t stream = ctx.stream;
 
   // tune[0] = chunk target override, tune[1] = grab, tune[2] = cost_x_step, tune[3] = cost_y_step,
   // tune[4] = blocks per CU override, tune[5] = force "search in HBM" (no LDS staging) when 1
   // default chunk size: as large as the LDS stage allows (fewer dequeues, better staging reuse) while every rank still
-  // gets >= ~6 chunks per resident workgroup for the dynamic dequeue to balance (matters for strong scaling at N = 8)
+  // gets >= ~2 chunks per resident workgroup for the dynamic dequeue to balance (matters for strong scaling at N = 8)
   int target = kDefaultChunk;
   while (target > 128 && g->ne / ((long long)world * target) < 2LL * g->cu_count * 7) target >>= 1;
   if (la->chunk > 0) target = la->chunk;
@@ -664,47 +733,12 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
     p.scratch_words = tab->max_bit_words;
   }
 
-  HIP_TRY(hipMemsetAsync(g->d_counters, 0, 64, stream));
-  g->ring_alias = nullptr;
-  hipEvent_t *evp = g->ev[g->ev_launches % gm_graph::kEvRing];
-  g->ev_launches++;
-  HIP_TRY(hipEventRecord(evp[0], stream));
+  rc = start_timer(ctx);
+  if (rc) return rc;
   if (p.count > 0) HIP_TRY(launch_mine(pat, p, grid, stream));
-  HIP_TRY(hipEventRecord(evp[1], stream));
-
-  if (st) {
-    st->kernel_ms = 0.0;
-    st->tasks = (pat == PAT_DIAMOND || pat == PAT_MOTIF4E) ? my_edges / 2 : my_edges;
-    st->chunks = (uint64_t)p.count;
-    st->grid = (uint32_t)grid;
-    st->block = kWavesPerBlock * GM_WAVE;
-  }
-  if (la->d_counts) {
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, stream, fin_mode, fin_base, g->d_counters,
-                       (unsigned long long *)la->d_counts);
-    HIP_TRY(hipGetLastError());
-    if (!h_out) return GM_OK;  // asynchronous: caller owns the synchronisation
-  }
-  unsigned long long c[4];
-  HIP_TRY(hipMemcpyAsync(c, g->d_counters, sizeof c, hipMemcpyDeviceToHost, stream));
-  HIP_TRY(hipStreamSynchronize(stream));
-  if (st) {
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, evp[0], evp[1]));
-    st->kernel_ms = ms;
-  }
-  if (fin_mode == FIN_MOTIF3) {
-    if (nout > 0) h_out[0] = c[2] - c[0];
-    if (nout > 1) h_out[1] = c[1];
-  } else if (fin_mode == FIN_MOTIF3_FORMULA) {
-    if (nout > 0) h_out[0] = fin_base - 3ull * c[0];
-    if (nout > 1) h_out[1] = c[0];
-  } else if (fin_mode == FIN_RAW4) {
-    for (int i = 0; i < 4 && i < nout; ++i) h_out[i] = c[i];
-  } else {
-    h_out[0] = c[0];
-  }
-  return GM_OK;
+  fill_stats(st, (pat == PAT_DIAMOND || pat == PAT_MOTIF4E) ? my_edges / 2 : my_edges, (uint64_t)p.count, grid,
+             kWavesPerBlock * GM_WAVE);
+  return end_launch(ctx, fin_mode, fin_base, h_out, nout, st);
 }
 
 extern "C" int gm_kernel_times(const gm_graph *g, int n, double *ms_out, int *n_out) {
@@ -728,17 +762,12 @@ extern "C" int gm_tc(const gm_graph *dag, const gm_launch *la, uint64_t *total, 
 }
 
 // rectangle, flattened over wedges (rect_flat_kernel in gm_mine.hip)
-static int run_rect_flat(const gm_graph *cg, const gm_launch *la, uint64_t *h_out, gm_stats *st) {
-  if (!cg) return GM_ERR_INVALID;
-  gm_graph *g = const_cast<gm_graph *>(cg);
-  gm_launch dflt;
-  memset(&dflt, 0, sizeof dflt);
-  if (!la) la = &dflt;
-  const int world = la->world > 1 ? la->world : 1;
-  if (la->rank < 0 || la->rank >= world) return GM_ERR_INVALID;
-  if (!h_out && !la->d_counts) return GM_ERR_INVALID;
-  HIP_TRY(hipSetDevice(g->device));
-  hipStream_t stream = (hipStream_t)la->stream;
+static int run_rect_flat(const gm_graph *cg, const gm_launch *la_in, uint64_t *h_out, gm_stats *st) {
+  LaunchCtx ctx;
+  int rc = begin_launch(cg, la_in, h_out, ctx);
+  if (rc) return rc;
+  gm_graph *g = ctx.g;
+  const gm_launch *la = &ctx.la;
   GraphView gv;
   gv.nv = g->nv;
   gv.ne = (int)g->ne;
@@ -770,57 +799,27 @@ static int run_rect_flat(const gm_graph *cg, const gm_launch *la, uint64_t *h_ou
   p.group = la->chunk > 0 ? la->chunk : 16;
   const long long ngroups = (long long)((p.nblocks + (unsigned long long)p.group - 1) / (unsigned long long)p.group);
   int64_t first = 0, step = 1, count = 0;
-  gm_partition(ngroups, la->rank, world, la->policy, &first, &step, &count);
+  gm_partition(ngroups, ctx.rank, ctx.world, la->policy, &first, &step, &count);
   p.first = (unsigned long long)first;
   p.step = (unsigned long long)step;
   p.count = (unsigned long long)count;
   p.counters = g->d_counters;
   p.queue = g->d_counters + 4;
   const int grid = (int)std::max<long long>(1, std::min<long long>((count + 3) / 4, (long long)g->cu_count * 8));
-  HIP_TRY(hipMemsetAsync(g->d_counters, 0, 64, stream));
-  g->ring_alias = nullptr;
-  hipEvent_t *evp = g->ev[g->ev_launches % gm_graph::kEvRing];
-  g->ev_launches++;
-  HIP_TRY(hipEventRecord(evp[0], stream));
-  if (count > 0) HIP_TRY(launch_rect_flat(p, grid, stream));
-  HIP_TRY(hipEventRecord(evp[1], stream));
-  if (st) {
-    st->kernel_ms = 0.0;
-    st->tasks = (uint64_t)(g->ne / 2 / world);
-    st->chunks = (uint64_t)count;
-    st->grid = (uint32_t)grid;
-    st->block = 256;
-  }
-  if (la->d_counts) {
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, stream, (int)FIN_COPY, 0ull, g->d_counters,
-                       (unsigned long long *)la->d_counts);
-    HIP_TRY(hipGetLastError());
-    if (!h_out) return GM_OK;
-  }
-  unsigned long long c[4];
-  HIP_TRY(hipMemcpyAsync(c, g->d_counters, sizeof c, hipMemcpyDeviceToHost, stream));
-  HIP_TRY(hipStreamSynchronize(stream));
-  if (st) {
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, evp[0], evp[1]));
-    st->kernel_ms = ms;
-  }
-  h_out[0] = c[0];
-  return GM_OK;
+  rc = start_timer(ctx);
+  if (rc) return rc;
+  if (count > 0) HIP_TRY(launch_rect_flat(p, grid, ctx.stream));
+  fill_stats(st, (uint64_t)(g->ne / 2 / ctx.world), (uint64_t)count, grid, 256);
+  return end_launch(ctx, FIN_COPY, 0, h_out, 1, st);
 }
 
 // rectangle / house / pentagon: one wave per symmetry-broken edge (gm_sgl.hip)
-static int run_sgl_nested(int pat, const gm_graph *cg, const gm_launch *la, uint64_t *h_out, gm_stats *st) {
-  if (!cg) return GM_ERR_INVALID;
-  gm_graph *g = const_cast<gm_graph *>(cg);
-  gm_launch dflt;
-  memset(&dflt, 0, sizeof dflt);
-  if (!la) la = &dflt;
-  const int world = la->world > 1 ? la->world : 1;
-  if (la->rank < 0 || la->rank >= world) return GM_ERR_INVALID;
-  if (!h_out && !la->d_counts) return GM_ERR_INVALID;
-  HIP_TRY(hipSetDevice(g->device));
-  hipStream_t stream = (hipStream_t)la->stream;
+static int run_sgl_nested(int pat, const gm_graph *cg, const gm_launch *la_in, uint64_t *h_out, gm_stats *st) {
+  LaunchCtx ctx;
+  int rc = begin_launch(cg, la_in, h_out, ctx);
+  if (rc) return rc;
+  gm_graph *g = ctx.g;
+  const gm_launch *la = &ctx.la;
   SglParams p;
   memset(&p, 0, sizeof p);
   p.g.nv = g->nv;
@@ -830,7 +829,7 @@ static int run_sgl_nested(int pat, const gm_graph *cg, const gm_launch *la, uint
   p.chunk = la->chunk > 0 ? la->chunk : 64;
   const long long nchunks = (g->ne + p.chunk - 1) / p.chunk;
   int64_t first = 0, step = 1, count = 0;
-  gm_partition(nchunks, la->rank, world, la->policy, &first, &step, &count);
+  gm_partition(nchunks, ctx.rank, ctx.world, la->policy, &first, &step, &count);
   p.first = first;
   p.step = step;
   p.count = count;
@@ -849,36 +848,11 @@ static int run_sgl_nested(int pat, const gm_graph *cg, const gm_launch *la, uint
     }
     p.scratch = reinterpret_cast<int *>(g->d_scratch);
   }
-  HIP_TRY(hipMemsetAsync(g->d_counters, 0, 64, stream));
-  g->ring_alias = nullptr;
-  hipEvent_t *evp = g->ev[g->ev_launches % gm_graph::kEvRing];
-  g->ev_launches++;
-  HIP_TRY(hipEventRecord(evp[0], stream));
-  if (count > 0) HIP_TRY(launch_sgl_nested(pat, p, grid, stream));
-  HIP_TRY(hipEventRecord(evp[1], stream));
-  if (st) {
-    st->kernel_ms = 0.0;
-    st->tasks = (uint64_t)(g->ne / 2 / world);
-    st->chunks = (uint64_t)count;
-    st->grid = (uint32_t)grid;
-    st->block = 256;
-  }
-  if (la->d_counts) {
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, stream, (int)FIN_COPY, 0ull, g->d_counters,
-                       (unsigned long long *)la->d_counts);
-    HIP_TRY(hipGetLastError());
-    if (!h_out) return GM_OK;
-  }
-  unsigned long long c[4];
-  HIP_TRY(hipMemcpyAsync(c, g->d_counters, sizeof c, hipMemcpyDeviceToHost, stream));
-  HIP_TRY(hipStreamSynchronize(stream));
-  if (st) {
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, evp[0], evp[1]));
-    st->kernel_ms = ms;
-  }
-  h_out[0] = c[0];
-  return GM_OK;
+  rc = start_timer(ctx);
+  if (rc) return rc;
+  if (count > 0) HIP_TRY(launch_sgl_nested(pat, p, grid, ctx.stream));
+  fill_stats(st, (uint64_t)(g->ne / 2 / ctx.world), (uint64_t)count, grid, 256);
+  return end_launch(ctx, FIN_COPY, 0, h_out, 1, st);
 }
 
 extern "C" int gm_sgl(const gm_graph *sym, const char *pattern, const gm_launch *la, uint64_t *total, gm_stats *st) {
