@@ -762,7 +762,7 @@ extern "C" int gm_tc(const gm_graph *dag, const gm_launch *la, uint64_t *total, 
 }
 
 // rectangle, flattened over wedges (rect_flat_kernel in gm_mine.hip)
-static int run_rect_flat(const gm_graph *cg, const gm_launch *la_in, uint64_t *h_out, gm_stats *st) {
+static int run_rect_flat(const gm_graph *cg, const gm_launch *la_in, uint64_t *h_out, gm_stats *st, bool pentagon = false) {
   LaunchCtx ctx;
   int rc = begin_launch(cg, la_in, h_out, ctx);
   if (rc) return rc;
@@ -796,7 +796,7 @@ static int run_rect_flat(const gm_graph *cg, const gm_launch *la_in, uint64_t *h
   p.idx0 = g->d_idx0;
   p.block_prefix = g->d_wblock_prefix;
   p.nblocks = g->n_wblocks;
-  p.group = la->chunk > 0 ? la->chunk : 16;
+  p.group = la->chunk > 0 ? la->chunk : (pentagon ? 2 : 16);
   const long long ngroups = (long long)((p.nblocks + (unsigned long long)p.group - 1) / (unsigned long long)p.group);
   int64_t first = 0, step = 1, count = 0;
   gm_partition(ngroups, ctx.rank, ctx.world, la->policy, &first, &step, &count);
@@ -808,7 +808,7 @@ static int run_rect_flat(const gm_graph *cg, const gm_launch *la_in, uint64_t *h
   const int grid = (int)std::max<long long>(1, std::min<long long>((count + 3) / 4, (long long)g->cu_count * 8));
   rc = start_timer(ctx);
   if (rc) return rc;
-  if (count > 0) HIP_TRY(launch_rect_flat(p, grid, ctx.stream));
+  if (count > 0) HIP_TRY(launch_rect_flat(p, pentagon, grid, ctx.stream));
   fill_stats(st, (uint64_t)(g->ne / 2 / ctx.world), (uint64_t)count, grid, 256);
   return end_launch(ctx, FIN_COPY, 0, h_out, 1, st);
 }
@@ -861,7 +861,8 @@ extern "C" int gm_sgl(const gm_graph *sym, const char *pattern, const gm_launch 
   if (strcmp(pattern, "rectangle") == 0)  // tune[6] & 1024: the first, wave-per-edge version (A/B)
     return (la && (la->tune[6] & 1024)) ? run_sgl_nested(SGL_RECTANGLE, sym, la, total, st) : run_rect_flat(sym, la, total, st);
   if (strcmp(pattern, "house") == 0) return run_sgl_nested(SGL_HOUSE, sym, la, total, st);
-  if (strcmp(pattern, "pentagon") == 0) return run_sgl_nested(SGL_PENTAGON, sym, la, total, st);
+  if (strcmp(pattern, "pentagon") == 0)
+    return (la && (la->tune[6] & 1024)) ? run_sgl_nested(SGL_PENTAGON, sym, la, total, st) : run_rect_flat(sym, la, total, st, true);
   if (total) *total = 0;  // "Not implemented", total_num = 0 (src/sgl/omp_base.cc:51-53)
   return GM_ERR_UNSUPPORTED;
 }

@@ -76,7 +76,7 @@ struct SglParams {
 };
 hipError_t launch_sgl_nested(int pat, const SglParams &p, int grid_blocks, hipStream_t stream);
 
-// flattened rectangle (gm_mine.hip): tasks are WEDGES (v1, v0, v2), v2 < v1 < v0, 64 per wave
+// flattened rectangle / pentagon (gm_mine.hip): tasks are WEDGES (v1, v0, v2), v2 < v1 < v0, 64 per wave
 struct RectParams {
   GraphView g;
   const int *idx0;                         // idx0[v] = number of neighbours of v that are < v
@@ -87,7 +87,7 @@ struct RectParams {
   unsigned long long *queue;               // 64-bit dequeue head
   unsigned long long *counters;
 };
-hipError_t launch_rect_flat(const RectParams &p, int grid_blocks, hipStream_t stream);
+hipError_t launch_rect_flat(const RectParams &p, bool pentagon, int grid_blocks, hipStream_t stream);
 hipError_t launch_idx0(const GraphView &g, int *idx0, hipStream_t stream);
 
 // host-side launchers (gm_mine.hip)

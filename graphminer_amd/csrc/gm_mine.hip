@@ -848,6 +848,10 @@ __global__ __launch_bounds__(256) void idx0_kernel(GraphView g, int *__restrict_
   if (v < g.nv) idx0[v] = lower_bound(g.col + g.rp[v], g.rp[v + 1] - g.rp[v], v);
 }
 
+// PENT = false: rectangle (one intersection per wedge).  PENT = true: pentagon, src/sgl/cpu_kernels/pentagon.h:2-17 --
+// the same wedges (v1, v0, v2); every lane then walks v3 in N(v2) (v3 < v0, v3 != v1) and round r intersects
+// N(v1) with the r-th v3 of all 64 wedges in ONE flattened pass, counting common w < v0, w != v2.
+template <bool PENT>
 __global__ __launch_bounds__(256) void rect_flat_kernel(const RectParams p) {
   __shared__ WaveLds W[kWavesPerBlock];
   const int *__restrict__ rp = p.g.rp;
@@ -876,7 +880,7 @@ __global__ __launch_bounds__(256) void rect_flat_kernel(const RectParams p) {
       const unsigned long long nw = (unsigned long long)n0 * (unsigned long long)(n0 - 1) / 2ull;  // wedges of v0
       const unsigned long long t = (blk - p.block_prefix[v0]) * 64ull + (unsigned long long)lane;
       const bool valid = t < nw;
-      int llen = 0, key_base = 0, s_base = 0, s_len = 0;
+      int v1 = 0, v2 = 0, r1 = 0, d1 = 0, r2 = 0, d2 = 0;
       if (valid) {
         // t = i(i-1)/2 + j, 0 <= j < i  ->  i = floor((1 + sqrt(1 + 8t)) / 2), fixed up against rounding
         long long i = (long long)((1.0 + sqrt(1.0 + 8.0 * (double)t)) * 0.5);
@@ -884,16 +888,43 @@ __global__ __launch_bounds__(256) void rect_flat_kernel(const RectParams p) {
         while ((i + 1) * i / 2 <= (long long)t) ++i;
         const long long j = (long long)t - i * (i - 1) / 2;
         const int *A0 = col + rp[v0];
-        const int v1 = A0[i], v2 = A0[j];
-        const int r1 = rp[v1], r2 = rp[v2];
-        const int d1 = lower_bound(col + r1, rp[v1 + 1] - r1, v0);  // keys >= v0 can never count (rectangle.h:8)
-        const int d2 = lower_bound(col + r2, rp[v2 + 1] - r2, v0);
-        if (d1 <= d2) { llen = d1; key_base = r1; s_base = r2; s_len = d2; }
-        else { llen = d2; key_base = r2; s_base = r1; s_len = d1; }
-        if (s_len == 0) llen = 0;
+        v1 = A0[i];
+        v2 = A0[j];
+        r1 = rp[v1];
+        r2 = rp[v2];
+        d1 = lower_bound(col + r1, rp[v1 + 1] - r1, v0);  // keys >= v0 can never count (rectangle.h:8, pentagon.h:12)
+        d2 = lower_bound(col + r2, rp[v2 + 1] - r2, v0);
       }
-      auto act = [&](bool f, int, int, int, int, int) { cnt += f ? 1u : 0u; };
-      flat_pass<SEARCH_HBM>(L, nullptr, col, nullptr, lane, llen, key_base, s_base, s_len, act);
+      if (!PENT) {
+        int llen = 0, key_base = 0, s_base = 0, s_len = 0;
+        if (valid) {
+          if (d1 <= d2) { llen = d1; key_base = r1; s_base = r2; s_len = d2; }
+          else { llen = d2; key_base = r2; s_base = r1; s_len = d1; }
+          if (s_len == 0) llen = 0;
+        }
+        auto act = [&](bool f, int, int, int, int, int) { cnt += f ? 1u : 0u; };
+        flat_pass<SEARCH_HBM>(L, nullptr, col, nullptr, lane, llen, key_base, s_base, s_len, act);
+      } else {
+        L.cnt[lane] = (unsigned)v2;  // the excluded ancestor of this wedge (intersection_num_bound_except(..., v0, v2))
+        wave_sync();
+        const int rounds = wave_max_nonneg(valid ? d2 : 0);  // v3 candidates: the d2 entries of N(v2) below v0
+        for (int r = 0; r < rounds; ++r) {
+          int llen = 0, key_base = 0, s_base = 0, s_len = 0;
+          if (valid && r < d2 && d1 > 0) {
+            const int v3 = col[r2 + r];
+            if (v3 != v1) {
+              const int r3 = rp[v3];
+              const int d3 = lower_bound(col + r3, rp[v3 + 1] - r3, v0);
+              if (d1 <= d3) { llen = d1; key_base = r1; s_base = r3; s_len = d3; }
+              else { llen = d3; key_base = r3; s_base = r1; s_len = d1; }
+              if (s_len == 0) llen = 0;
+            }
+          }
+          auto act = [&](bool f, int owner, int, int, int, int key) { cnt += (f && key != (int)L.cnt[owner]) ? 1u : 0u; };
+          flat_pass<SEARCH_HBM>(L, nullptr, col, nullptr, lane, llen, key_base, s_base, s_len, act);
+        }
+        wave_sync();
+      }
     }
   }
   const unsigned long long s0 = wave_sum_u64(cnt);
@@ -905,8 +936,9 @@ hipError_t launch_idx0(const GraphView &g, int *idx0, hipStream_t stream) {
   return hipGetLastError();
 }
 
-hipError_t launch_rect_flat(const RectParams &p, int grid_blocks, hipStream_t stream) {
-  hipLaunchKernelGGL(rect_flat_kernel, dim3((unsigned)grid_blocks), dim3(256), 0, stream, p);
+hipError_t launch_rect_flat(const RectParams &p, bool pentagon, int grid_blocks, hipStream_t stream) {
+  if (pentagon) hipLaunchKernelGGL(rect_flat_kernel<true>, dim3((unsigned)grid_blocks), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL(rect_flat_kernel<false>, dim3((unsigned)grid_blocks), dim3(256), 0, stream, p);
   return hipGetLastError();
 }
 
