@@ -106,7 +106,9 @@ struct gm_graph {
   const gm_graph *ring_alias = nullptr;
   int *d_idx0 = nullptr;                  // rectangle: #neighbours below v, and the wedge-block prefix
   unsigned long long *d_wblock_prefix = nullptr;
-  unsigned long long n_wblocks = 0;   // handle whose event ring holds this handle's most recent launch
+  unsigned long long n_wblocks = 0;
+  unsigned long long *d_house_prefix = nullptr;  // house: per-entry task-block prefix
+  unsigned long long n_house_blocks = 0;   // handle whose event ring holds this handle's most recent launch
   unsigned long long sum_c2 = 0;          // sum_v C(d(v),2)
   bool sum_c2_valid = false;
   std::mutex mu;
@@ -133,6 +135,7 @@ extern "C" void gm_graph_free(gm_graph *g) {
   if (g->d_scratch) (void)hipFree(g->d_scratch);
   if (g->d_idx0) (void)hipFree(g->d_idx0);
   if (g->d_wblock_prefix) (void)hipFree(g->d_wblock_prefix);
+  if (g->d_house_prefix) (void)hipFree(g->d_house_prefix);
   for (auto &pr : g->ev)
     for (auto &e : pr)
       if (e) (void)hipEventDestroy(e);
@@ -813,6 +816,57 @@ static int run_rect_flat(const gm_graph *cg, const gm_launch *la_in, uint64_t *h
   return end_launch(ctx, FIN_COPY, 0, h_out, 1, st);
 }
 
+// house, flattened over (v0, v1, v3) tasks (house_flat_kernel in gm_mine.hip)
+static int run_house_flat(const gm_graph *cg, const gm_launch *la_in, uint64_t *h_out, gm_stats *st) {
+  LaunchCtx ctx;
+  int rc = begin_launch(cg, la_in, h_out, ctx);
+  if (rc) return rc;
+  gm_graph *g = ctx.g;
+  const gm_launch *la = &ctx.la;
+  GraphView gv;
+  gv.nv = g->nv;
+  gv.ne = (int)g->ne;
+  gv.rp = g->d_rp;
+  gv.col = g->d_col;
+  if (!g->d_house_prefix) {  // once per graph: blocks per entry on the device, prefix on the host
+    const size_t ne = (size_t)g->ne;
+    unsigned *d_nblk = nullptr;
+    HIP_TRY(hipMalloc(&d_nblk, sizeof(unsigned) * std::max<size_t>(ne, 1)));
+    if (ne) HIP_TRY(launch_house_blocks(gv, d_nblk, 0));
+    std::vector<unsigned> nblk(std::max<size_t>(ne, 1));
+    hipError_t e = hipMemcpy(nblk.data(), d_nblk, sizeof(unsigned) * ne, hipMemcpyDeviceToHost);
+    (void)hipFree(d_nblk);
+    if (e != hipSuccess) return hip_fail(e, "hipMemcpy(nblk)", __FILE__, __LINE__);
+    std::vector<unsigned long long> pre(ne + 1);
+    unsigned long long acc = 0;
+    for (size_t i = 0; i < ne; ++i) { pre[i] = acc; acc += nblk[i]; }
+    pre[ne] = acc;
+    g->n_house_blocks = acc;
+    HIP_TRY(hipMalloc(&g->d_house_prefix, sizeof(unsigned long long) * (ne + 1)));
+    HIP_TRY(hipMemcpy(g->d_house_prefix, pre.data(), sizeof(unsigned long long) * (ne + 1), hipMemcpyHostToDevice));
+  }
+  HouseParams p;
+  memset(&p, 0, sizeof p);
+  p.g = gv;
+  p.entry_prefix = g->d_house_prefix;
+  p.nblocks = g->n_house_blocks;
+  p.group = la->chunk > 0 ? la->chunk : 8;
+  const long long ngroups = (long long)((p.nblocks + (unsigned long long)p.group - 1) / (unsigned long long)p.group);
+  int64_t first = 0, step = 1, count = 0;
+  gm_partition(ngroups, ctx.rank, ctx.world, la->policy, &first, &step, &count);
+  p.first = (unsigned long long)first;
+  p.step = (unsigned long long)step;
+  p.count = (unsigned long long)count;
+  p.counters = g->d_counters;
+  p.queue = g->d_counters + 4;
+  const int grid = (int)std::max<long long>(1, std::min<long long>((count + 3) / 4, (long long)g->cu_count * 8));
+  rc = start_timer(ctx);
+  if (rc) return rc;
+  if (count > 0 && g->ne > 0) HIP_TRY(launch_house_flat(p, grid, ctx.stream));
+  fill_stats(st, (uint64_t)(g->ne / 2 / ctx.world), (uint64_t)count, grid, 256);
+  return end_launch(ctx, FIN_COPY, 0, h_out, 1, st);
+}
+
 // rectangle / house / pentagon: one wave per symmetry-broken edge (gm_sgl.hip)
 static int run_sgl_nested(int pat, const gm_graph *cg, const gm_launch *la_in, uint64_t *h_out, gm_stats *st) {
   LaunchCtx ctx;
@@ -860,7 +914,8 @@ extern "C" int gm_sgl(const gm_graph *sym, const char *pattern, const gm_launch 
   if (strcmp(pattern, "diamond") == 0) return run_pattern(PAT_DIAMOND, sym, la, 4, total, 1, st);
   if (strcmp(pattern, "rectangle") == 0)  // tune[6] & 1024: the first, wave-per-edge version (A/B)
     return (la && (la->tune[6] & 1024)) ? run_sgl_nested(SGL_RECTANGLE, sym, la, total, st) : run_rect_flat(sym, la, total, st);
-  if (strcmp(pattern, "house") == 0) return run_sgl_nested(SGL_HOUSE, sym, la, total, st);
+  if (strcmp(pattern, "house") == 0)
+    return (la && (la->tune[6] & 1024)) ? run_sgl_nested(SGL_HOUSE, sym, la, total, st) : run_house_flat(sym, la, total, st);
   if (strcmp(pattern, "pentagon") == 0)
     return (la && (la->tune[6] & 1024)) ? run_sgl_nested(SGL_PENTAGON, sym, la, total, st) : run_rect_flat(sym, la, total, st, true);
   if (total) *total = 0;  // "Not implemented", total_num = 0 (src/sgl/omp_base.cc:51-53)

@@ -90,6 +90,19 @@ struct RectParams {
 hipError_t launch_rect_flat(const RectParams &p, bool pentagon, int grid_blocks, hipStream_t stream);
 hipError_t launch_idx0(const GraphView &g, int *idx0, hipStream_t stream);
 
+// flattened house (gm_mine.hip): tasks are (v0, v1, v3) with v1 < v0 in N(v0), v3 in N(v1) \ {v0}, 64 v3 per wave
+struct HouseParams {
+  GraphView g;
+  const unsigned long long *entry_prefix;  // prefix over CSR entries e of ceil(d(col[e]) / 64) if col[e] < row(e), else 0
+  unsigned long long first, step, count;   // this rank owns block groups first + i*step, i in [0,count)
+  unsigned long long nblocks;
+  int group;
+  unsigned long long *queue;
+  unsigned long long *counters;
+};
+hipError_t launch_house_flat(const HouseParams &p, int grid_blocks, hipStream_t stream);
+hipError_t launch_house_blocks(const GraphView &g, unsigned *nblk, hipStream_t stream);
+
 // host-side launchers (gm_mine.hip)
 hipError_t launch_mine(Pattern pat, const MineParams &p, int grid_blocks, hipStream_t stream);
 size_t mine_lds_bytes(Pattern pat);

@@ -931,6 +931,105 @@ __global__ __launch_bounds__(256) void rect_flat_kernel(const RectParams p) {
   if (lane == 0 && s0) atomicAdd(&p.counters[0], s0);
 }
 
+// ---- house, flattened ----------------------------------------------------------------------------------------
+// src/sgl/cpu_kernels/house.h:1-16:  for v0, v1 in N(v0) (v1 < v0), S = N(v0) ^ N(v1), v2 in S, v3 in N(v1) \ {v0, v2}:
+//                                        count += |N(v0) ^ N(v3) \ {v1, v2}|
+// Summing over v2 first (v1 is always common to N(v0) and N(v3); v2 in S is common iff v2 in N(v3)):
+//   house(v0,v1) = sum_{v3 in N(v1), v3 != v0} [ (|S| - [v3 in S]) * (|N(v0) ^ N(v3)| - 1) - |S ^ N(v3)| ]
+// (checked against the reference's goldens). Tasks = (v0, v1, v3): a wave takes one entry (v0 -> v1) and 64 of its v3;
+// |S| is one cooperative intersection per wave, the 64 intersections N(v0) ^ N(v3) run as ONE flattened pass whose
+// match handler also tests the matched key against N(v1) (that is |S ^ N(v3)|).
+__global__ __launch_bounds__(256) void house_blocks_kernel(GraphView g, unsigned *__restrict__ nblk) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= g.ne) return;
+  int lo = 0, hi = g.nv - 1;  // row of entry e
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (g.rp[mid] <= e) lo = mid; else hi = mid - 1;
+  }
+  const int v1 = g.col[e];
+  nblk[e] = (v1 < lo) ? (unsigned)((g.rp[v1 + 1] - g.rp[v1] + 63) / 64) : 0u;
+}
+
+__global__ __launch_bounds__(256) void house_flat_kernel(const HouseParams p) {
+  __shared__ WaveLds W[kWavesPerBlock];
+  const int *__restrict__ rp = p.g.rp;
+  const int *__restrict__ col = p.g.col;
+  const int lane = threadIdx.x & 63;
+  WaveLds &L = W[threadIdx.x >> 6];
+  unsigned long long cnt = 0;
+  for (;;) {
+    unsigned long long q = 0;
+    if (lane == 0) q = atomicAdd(p.queue, 1ull);
+    q = ((unsigned long long)(unsigned)readfirst((int)(q >> 32)) << 32) | (unsigned)readfirst((int)q);
+    if (q >= p.count) break;
+    const unsigned long long gid = p.first + q * p.step;
+    const unsigned long long b0 = gid * (unsigned long long)p.group;
+    const unsigned long long b1 = min(p.nblocks, b0 + (unsigned long long)p.group);
+    int elo = 0, ehi = p.g.ne - 1;  // entry of the first block: largest e with entry_prefix[e] <= b0
+    while (elo < ehi) {
+      const int mid = (int)(((long long)elo + ehi + 1) >> 1);
+      if (p.entry_prefix[mid] <= b0) elo = mid; else ehi = mid - 1;
+    }
+    int e = elo;
+    int vlo = 0, vhi = p.g.nv - 1;  // row of that entry
+    while (vlo < vhi) {
+      const int mid = (vlo + vhi + 1) >> 1;
+      if (rp[mid] <= e) vlo = mid; else vhi = mid - 1;
+    }
+    int v0 = vlo;
+    for (unsigned long long blk = b0; blk < b1; ++blk) {
+      while (p.entry_prefix[e + 1] <= blk) ++e;
+      while (rp[v0 + 1] <= e) ++v0;
+      const int v1 = col[e];
+      const int r0 = rp[v0], d0 = rp[v0 + 1] - r0;
+      const int r1 = rp[v1], d1 = rp[v1 + 1] - r1;
+      const long long sn = (long long)wave_sum((int)wave_intersect_num(col + r0, d0, col + r1, d1));  // |S|
+      const int k = (int)(blk - p.entry_prefix[e]) * 64 + lane;
+      bool valid = k < d1;
+      int v3 = valid ? col[r1 + k] : 0;
+      valid = valid && v3 != v0;
+      int llen = 0, key_base = 0, s_base = 0, s_len = 0;
+      long long in_s = 0;
+      if (valid) {
+        int pos;
+        in_s = contains(col + r0, d0, v3, &pos) ? 1 : 0;  // v3 in N(v1) already, so v3 in S  <=>  v3 in N(v0)
+        const int r3 = rp[v3], d3 = rp[v3 + 1] - r3;
+        if (d0 <= d3) { llen = d0; key_base = r0; s_base = r3; s_len = d3; }
+        else { llen = d3; key_base = r3; s_base = r0; s_len = d0; }
+      }
+      L.cnt[lane] = 0u;   // |N(v0) ^ N(v3)| of this lane's task
+      L.qkey[lane] = 0;   // |S ^ N(v3)|
+      wave_sync();
+      auto act = [&](bool f, int owner, int, int, int, int key) {
+        if (!f) return;
+        atomicAdd(&L.cnt[owner], 1u);
+        int pos;
+        if (contains(col + r1, d1, key, &pos)) atomicAdd(&L.qkey[owner], 1);
+      };
+      flat_pass<SEARCH_HBM>(L, nullptr, col, nullptr, lane, llen, key_base, s_base, s_len, act);
+      wave_sync();
+      if (valid) {
+        const long long ca = (long long)L.cnt[lane], cs = (long long)L.qkey[lane];
+        cnt += (unsigned long long)((sn - in_s) * (ca - 1) - cs);
+      }
+      wave_sync();
+    }
+  }
+  const unsigned long long s0 = wave_sum_u64(cnt);
+  if (lane == 0 && s0) atomicAdd(&p.counters[0], s0);
+}
+
+hipError_t launch_house_blocks(const GraphView &g, unsigned *nblk, hipStream_t stream) {
+  hipLaunchKernelGGL(house_blocks_kernel, dim3((unsigned)((g.ne + 255) / 256)), dim3(256), 0, stream, g, nblk);
+  return hipGetLastError();
+}
+
+hipError_t launch_house_flat(const HouseParams &p, int grid_blocks, hipStream_t stream) {
+  hipLaunchKernelGGL(house_flat_kernel, dim3((unsigned)grid_blocks), dim3(256), 0, stream, p);
+  return hipGetLastError();
+}
+
 hipError_t launch_idx0(const GraphView &g, int *idx0, hipStream_t stream) {
   hipLaunchKernelGGL(idx0_kernel, dim3((unsigned)((g.nv + 255) / 256)), dim3(256), 0, stream, g, idx0);
   return hipGetLastError();
