@@ -851,6 +851,7 @@ static int run_house_flat(const gm_graph *cg, const gm_launch *la_in, uint64_t *
   p.entry_prefix = g->d_house_prefix;
   p.nblocks = g->n_house_blocks;
   p.group = la->chunk > 0 ? la->chunk : 8;
+  p.no_bits = (la->tune[6] & 2048) ? 1 : 0;
   const long long ngroups = (long long)((p.nblocks + (unsigned long long)p.group - 1) / (unsigned long long)p.group);
   int64_t first = 0, step = 1, count = 0;
   gm_partition(ngroups, ctx.rank, ctx.world, la->policy, &first, &step, &count);

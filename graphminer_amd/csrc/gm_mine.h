@@ -97,6 +97,7 @@ struct HouseParams {
   unsigned long long first, step, count;   // this rank owns block groups first + i*step, i in [0,count)
   unsigned long long nblocks;
   int group;
+  int no_bits;  // test hook: always take the long-row path (S membership by bisection in N(v1))
   unsigned long long *queue;
   unsigned long long *counters;
 };

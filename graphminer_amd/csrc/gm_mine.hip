@@ -951,12 +951,16 @@ __global__ __launch_bounds__(256) void house_blocks_kernel(GraphView g, unsigned
   nblk[e] = (v1 < lo) ? (unsigned)((g.rp[v1 + 1] - g.rp[v1] + 63) / 64) : 0u;
 }
 
+constexpr int kHouseBitWords = 512;  // per-wave LDS bitmap over the positions of N(v0): which of them are in S
+
 __global__ __launch_bounds__(256) void house_flat_kernel(const HouseParams p) {
   __shared__ WaveLds W[kWavesPerBlock];
+  __shared__ unsigned SB[kWavesPerBlock][kHouseBitWords];
   const int *__restrict__ rp = p.g.rp;
   const int *__restrict__ col = p.g.col;
   const int lane = threadIdx.x & 63;
   WaveLds &L = W[threadIdx.x >> 6];
+  unsigned *sbits = SB[threadIdx.x >> 6];
   unsigned long long cnt = 0;
   for (;;) {
     unsigned long long q = 0;
@@ -978,13 +982,43 @@ __global__ __launch_bounds__(256) void house_flat_kernel(const HouseParams p) {
       if (rp[mid] <= e) vlo = mid; else vhi = mid - 1;
     }
     int v0 = vlo;
+    int cached_e = -1;
+    long long sn = 0;
+    bool use_bits = false;
     for (unsigned long long blk = b0; blk < b1; ++blk) {
       while (p.entry_prefix[e + 1] <= blk) ++e;
       while (rp[v0 + 1] <= e) ++v0;
       const int v1 = col[e];
       const int r0 = rp[v0], d0 = rp[v0 + 1] - r0;
       const int r1 = rp[v1], d1 = rp[v1 + 1] - r1;
-      const long long sn = (long long)wave_sum((int)wave_intersect_num(col + r0, d0, col + r1, d1));  // |S|
+      if (e != cached_e) {  // S = N(v0) ^ N(v1): its size, and (rows up to 16 K entries) its members as bits over N(v0)
+        cached_e = e;
+        use_bits = (d0 <= kHouseBitWords * 32) & !p.no_bits;
+        if (use_bits) {
+          for (int i = lane; i < (d0 + 31) / 32; i += GM_WAVE) sbits[i] = 0u;
+          wave_sync();
+        }
+        unsigned c = 0;
+        if (d0 <= d1) {
+          for (int i = lane; i < d0; i += GM_WAVE) {
+            int pos;
+            if (contains(col + r1, d1, col[r0 + i], &pos)) {
+              ++c;
+              if (use_bits) atomicOr(&sbits[i >> 5], 1u << (i & 31));
+            }
+          }
+        } else {
+          for (int i = lane; i < d1; i += GM_WAVE) {
+            int pos;
+            if (contains(col + r0, d0, col[r1 + i], &pos)) {
+              ++c;
+              if (use_bits) atomicOr(&sbits[pos >> 5], 1u << (pos & 31));
+            }
+          }
+        }
+        sn = (long long)wave_sum((int)c);
+        wave_sync();
+      }
       const int k = (int)(blk - p.entry_prefix[e]) * 64 + lane;
       bool valid = k < d1;
       int v3 = valid ? col[r1 + k] : 0;
@@ -995,17 +1029,24 @@ __global__ __launch_bounds__(256) void house_flat_kernel(const HouseParams p) {
         int pos;
         in_s = contains(col + r0, d0, v3, &pos) ? 1 : 0;  // v3 in N(v1) already, so v3 in S  <=>  v3 in N(v0)
         const int r3 = rp[v3], d3 = rp[v3 + 1] - r3;
-        if (d0 <= d3) { llen = d0; key_base = r0; s_base = r3; s_len = d3; }
-        else { llen = d3; key_base = r3; s_base = r0; s_len = d0; }
+        if (d0 <= d3) { llen = d0; key_base = r0; s_base = r3; s_len = d3; }             // keys from N(v0): flag 0
+        else { llen = d3; key_base = r3; s_base = r0; s_len = d0 | (1 << 30); }          // keys from N(v3): flag 1
       }
       L.cnt[lane] = 0u;   // |N(v0) ^ N(v3)| of this lane's task
       L.qkey[lane] = 0;   // |S ^ N(v3)|
       wave_sync();
-      auto act = [&](bool f, int owner, int, int, int, int key) {
+      auto act = [&](bool f, int owner, int kidx, int pos, int flag, int key) {
         if (!f) return;
         atomicAdd(&L.cnt[owner], 1u);
-        int pos;
-        if (contains(col + r1, d1, key, &pos)) atomicAdd(&L.qkey[owner], 1);
+        bool ins;
+        if (use_bits) {
+          const int p0 = flag ? pos : kidx;  // position of the matched key inside N(v0)
+          ins = (sbits[p0 >> 5] >> (p0 & 31)) & 1u;
+        } else {
+          int pp;
+          ins = contains(col + r1, d1, key, &pp);
+        }
+        if (ins) atomicAdd(&L.qkey[owner], 1);
       };
       flat_pass<SEARCH_HBM>(L, nullptr, col, nullptr, lane, llen, key_base, s_base, s_len, act);
       wave_sync();

@@ -173,6 +173,13 @@ class DeviceGraph:
             _lib.load().gm_graph_free(self._h)
             self._h = C.c_void_p()
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.free()
+        return False
+
     def __del__(self):
         try:
             self.free()

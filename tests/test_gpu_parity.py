@@ -100,6 +100,26 @@ def test_sgl_nested_patterns_match_reference(gg, pattern):
     assert total == e[pattern]
     assert sum(SglSolver(sym, pattern, rank=r, world=3, chunk=32) for r in range(3)) == e[pattern]
     assert sum(SglSolver(sym, pattern, rank=r, world=2, policy=1) for r in range(2)) == e[pattern]
+    if pattern == "house":  # the other two implementations: rows too long for the LDS S-bitmap; one wave per edge
+        assert SglSolver(sym, pattern, tune=[0, 0, 0, 0, 0, 0, 2048]) == e[pattern]
+        assert SglSolver(sym, pattern, tune=[0, 0, 0, 0, 0, 0, 1024]) == e[pattern]
+
+
+def test_house_hub_row_longer_than_lds_bitmap():
+    """a hub with 17,000 neighbours (> the 16,384-bit LDS S-bitmap) plus a sparse random graph: the flattened kernel's
+    long-row path against the wave-per-edge loop nest (house.h order) on the same graph"""
+    rng = np.random.default_rng(5)
+    n = 17001
+    hub = n - 1  # highest id: every hub edge is a symmetry-broken (v0 = hub, v1) task
+    s = np.concatenate([np.full(n - 1, hub), rng.integers(0, n - 1, 40000)]).astype(np.uint64)
+    d = np.concatenate([np.arange(n - 1), rng.integers(0, n - 1, 40000)]).astype(np.uint64)
+    g = csr_from_pairs(n, s, d)
+    assert int(np.diff(g.row_ptr).max()) > 16384
+    with DeviceGraph.upload(g) as sym:
+        flat = SglSolver(sym, "house")
+        assert flat == SglSolver(sym, "house", tune=[0, 0, 0, 0, 0, 0, 1024])
+        assert flat == SglSolver(sym, "house", tune=[0, 0, 0, 0, 0, 0, 2048])
+        assert flat == sum(SglSolver(sym, "house", rank=r, world=3) for r in range(3))
 
 
 def test_clique4_matches_reference(gg):
