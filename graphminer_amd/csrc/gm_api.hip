@@ -832,11 +832,11 @@ static int run_house_flat(const gm_graph *cg, const gm_launch *la_in, uint64_t *
     const size_t ne = (size_t)g->ne;
     unsigned *d_nblk = nullptr;
     HIP_TRY(hipMalloc(&d_nblk, sizeof(unsigned) * std::max<size_t>(ne, 1)));
-    if (ne) HIP_TRY(launch_house_blocks(gv, d_nblk, 0));
     std::vector<unsigned> nblk(std::max<size_t>(ne, 1));
-    hipError_t e = hipMemcpy(nblk.data(), d_nblk, sizeof(unsigned) * ne, hipMemcpyDeviceToHost);
+    hipError_t e = ne ? launch_house_blocks(gv, d_nblk, 0) : hipSuccess;
+    if (e == hipSuccess) e = hipMemcpy(nblk.data(), d_nblk, sizeof(unsigned) * ne, hipMemcpyDeviceToHost);
     (void)hipFree(d_nblk);
-    if (e != hipSuccess) return hip_fail(e, "hipMemcpy(nblk)", __FILE__, __LINE__);
+    if (e != hipSuccess) return hip_fail(e, "house block table", __FILE__, __LINE__);
     std::vector<unsigned long long> pre(ne + 1);
     unsigned long long acc = 0;
     for (size_t i = 0; i < ne; ++i) { pre[i] = acc; acc += nblk[i]; }

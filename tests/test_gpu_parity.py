@@ -285,6 +285,11 @@ def test_random_graphs_against_oracle(dev, seed):
     assert CliqueSolver(d, 4) == O.clique(odag, 4)
     assert CliqueSolver(d, 5) == O.clique(odag, 5)
     assert MotifSolver(s, 3) == O.motif3(osym)
+    if seed == 1:  # the flattened wedge kernels and the 4-motif formula path, against the restated loop nests
+        assert SglSolver(s, "rectangle") == O.rectangle(osym)
+        assert SglSolver(s, "house") == O.house(osym)
+        assert SglSolver(s, "pentagon") == O.pentagon(osym)
+        assert MotifSolver(s, 4) == O.motif4(osym)
 
 
 # ---- full-size, size-independent properties -------------------------------------------------------
