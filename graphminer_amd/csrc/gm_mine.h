@@ -27,8 +27,11 @@ constexpr int kBitWords = 2048;           // clique: LDS words for the per-chunk
 // Task chunk = a contiguous vertex range [u_begin,u_end) and the CSR entries [e_begin,e_end) it owns.
 // Normal chunks own whole rows (e_begin == rp[u_begin], e_end == rp[u_end]); a row longer than the
 // staging capacity is cut into SPLIT chunks (u_end == u_begin+1, [e_begin,e_end) inside the row).
+// A chunk whose estimated work is far above the mean is additionally cut into PARTS: every part stages the whole chunk but
+// takes only the 64-edge batches b with b % nparts == part, so that several workgroups share one heavy chunk.
 struct ChunkRec {
   int u_begin, u_end, e_begin, e_end;
+  int part, nparts;  // nparts >= 1
 };
 
 struct GraphView {
@@ -46,6 +49,7 @@ struct MineParams {
   GraphView g;
   const ChunkRec *chunks;
   const int *chunk_slot;         // per chunk: bitmap slot of its hub row, or -1 (may be nullptr)
+  const int *order;              // dequeue position -> chunk id (nullptr = identity)
   const unsigned *bitmaps;       // dense vertex-id bitmaps of the longest rows, bitmap_words each
   unsigned long long bitmap_words;
   int first, step, count;        // this rank owns chunk ids first + i*step, i in [0,count)

@@ -632,7 +632,7 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
       bi = my_bi++;
     } else {
       if (lane == 0) bi = atomicAdd(&B.next_batch, 1);
-      bi = readfirst(bi);
+      bi = readfirst(bi) * r.nparts + r.part;  // this part's batches (nparts == 1: all of them)
     }
     const int le0 = bi * GM_WAVE;
     if (le0 >= gend) break;
@@ -819,7 +819,8 @@ __global__ __launch_bounds__(kWavesPerBlock *GM_WAVE, PAT == PAT_CLIQUEK ? 4 : (
     if (q >= (unsigned)p.count) break;
     const unsigned qe = min(q + (unsigned)p.grab, (unsigned)p.count);
     for (unsigned i = q; i < qe; ++i) {
-      const size_t cid = (size_t)p.first + (size_t)i * (size_t)p.step;
+      const size_t pos = (size_t)p.first + (size_t)i * (size_t)p.step;
+      const size_t cid = p.order ? (size_t)p.order[pos] : pos;
       const ChunkRec r = p.chunks[cid];
       const int slot = p.chunk_slot ? p.chunk_slot[cid] : -1;
       process_chunk<PAT>(p, B, r, slot, lane, wave, acc);  // ends with a workgroup barrier

@@ -77,7 +77,8 @@ void gm_graph_free(gm_graph *g);
 
 /* Scheduler policy for the multi-GPU task split (include/scheduler.h, src/common/scheduler.cc). */
 enum {
-  GM_PART_ROUND_ROBIN = 0, /* Scheduler::round_robin, scheduler.cc:34-85: chunk c -> rank c mod world */
+  GM_PART_ROUND_ROBIN = 0, /* Scheduler::round_robin, scheduler.cc:34-85: the j-th chunk of the dequeue order -> rank
+                              j mod world (order = estimated work, heaviest first, when world > 1) */
   GM_PART_RANGE = 1,       /* even contiguous split of the task chunks (EVEN_SPLIT, src/clique/multigpu.cu:42-44) */
   GM_PART_VERTEX = 2       /* vertex-balanced: rank r owns the tasks of vertices [nv*r/world, nv*(r+1)/world)
                               (1-D vertex ranges of src/common/graph_partition.cc:82-132, without the halo copies:
@@ -95,8 +96,8 @@ typedef struct gm_launch {
                          device, no host sync is done (use it to feed an RCCL all-reduce). */
   int32_t tune[8];    /* kernel tuning / ablation knobs, all 0 = defaults: [0] task edges per chunk, [1] chunks per
                          dequeue, [2] xs+1 and [3] ys+1 of the direction rule b*(xb+xs*lg a) <= a*(yb+ys*lg b),
-                         [4] workgroups per CU, [5] 1 = never stage adjacency in LDS, [6] ablation bit mask
-                         (gm_api.hip), [7] xb*16+yb. Results never depend on them (tests/test_gpu_parity.py). */
+                         [4] workgroups per CU, [5] 1 = never stage adjacency in LDS, [6] ablation / test bit mask
+                         (gm_api.hip; 0x1000 cut chunks into parts eagerly, 0x4000 plain chunk-id dequeue order), [7] xb*16+yb. Results never depend on them (tests/test_gpu_parity.py). */
 } gm_launch;
 
 typedef struct gm_stats {

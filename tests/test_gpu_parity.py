@@ -73,12 +73,26 @@ def test_tc_matches_reference(gg):
 
 @pytest.mark.parametrize("tune", [
     [64, 1, 0, 0, 0, 0], [256, 4, 0, 0, 0, 1], [1024, 2, 0, 0, 0, 0], [128, 8, 1, 1, 0, 0], [256, 4, 1, 30, 2, 0],
+    [0, 0, 0, 0, 0, 0, 0x1000], [0, 0, 0, 0, 0, 0, 0x4000], [0, 0, 0, 0, 0, 0, 0x3000],
     [256, 4, 8, 1, 0, 0],
 ])
 def test_tc_invariant_under_tuning(gg, tune):
     name, _, sym, dag = gg
     assert TCSolver(dag, tune=tune) == GOLDEN[name]["tc"]
     assert MotifSolver(sym, 3, tune=tune) == GOLDEN[name]["motif3"]
+
+
+def test_heavy_chunks_cut_into_parts(gg):
+    """tune[6] & 0x1000 cuts every chunk above 4096 estimated entries into parts (several workgroups share one chunk's
+    64-edge batches): counts and the per-rank task totals must not change"""
+    name, _, sym, dag = gg
+    parts = [0, 0, 0, 0, 0, 0, 0x1000]
+    assert SglSolver(sym, "diamond", tune=parts) == GOLDEN[name]["diamond"]
+    assert MotifSolver(sym, 4, tune=parts) == GOLDEN[name].get("motif4", MotifSolver(sym, 4))
+    for policy in (0, 1, 2):
+        res = [TCSolver(dag, rank=r, world=3, policy=policy, tune=parts, return_stats=True) for r in range(3)]
+        assert sum(c for c, _ in res) == GOLDEN[name]["tc"]
+        assert sum(st.tasks for _, st in res) == dag.E()
 
 
 def test_diamond_matches_reference(gg):
