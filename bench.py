@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--graph", default="", help="prefix of graph.meta.txt/.vertex.bin/.edge.bin (real dataset)")
     ap.add_argument("--uniform", default="", help="NV,M: uniform random graph instead of R-MAT (LiveJournal-size flat-degree stand-in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ref-baseline", action="store_true", help="skip the timed run of oracle/_ref/tc_omp_base")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the bounded oracle sample")
     ap.add_argument("--tune", default="", help="comma separated gm_launch.tune[] override")
     ap.add_argument("--policy", type=int, default=0, help="0 = chunked round robin, 1 = contiguous ranges")
@@ -239,10 +240,50 @@ def main():
                                    "host_cpus": os.cpu_count()}
             if stride == 1:
                 out["cpu_baseline"]["count_matches_gpu"] = bool(cnt == result[0])
+            ref = None if a.no_ref_baseline else reference_tc_baseline(sym, g.E(), O.num_threads(), result[0])
+            if ref is not None:  # the reference's own tc_omp_base binary (oracle/_ref, prebuilt) on the same graph
+                ref["port"] = {k: out["cpu_baseline"][k] for k in ("value", "seconds", "sample")}
+                out["cpu_baseline"] = ref
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()  # rank 0 finishes its host-side reporting before any rank tears the communicator down
         dist.destroy_process_group()
+
+
+def reference_tc_baseline(sym, tasks, threads, gpu_count):
+    """Time the REFERENCE's tc_omp_base (built by oracle/ref/Makefile into oracle/_ref/, test infrastructure) on the same
+    graph: write the symmetric CSR in the three-file format, run the binary, read its own `runtime [omp_base]` line
+    (Timer around the parallel loop only, src/triangle/omp_base.cc:12-24). None when the binary is not there or fails."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = os.path.join(ROOT, "oracle", "_ref", "tc_omp_base")
+    if not os.path.exists(exe):
+        return None
+    tmp = tempfile.mkdtemp(prefix="gm_ref_", dir="/tmp")
+    try:
+        sym.download().save(os.path.join(tmp, "graph"))
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="spread")
+        best, count = None, None
+        for _ in range(2):
+            r = subprocess.run([exe, os.path.join(tmp, "graph")], capture_output=True, text=True, env=env, timeout=300)
+            m = re.search(r"runtime \[omp_base\] = ([0-9.eE+-]+) sec", r.stdout)
+            c = re.search(r"total_num_triangles = (\d+)", r.stdout)
+            if r.returncode != 0 or not m or not c:
+                return None
+            t = float(m.group(1))
+            best, count = (t if best is None else min(best, t)), int(c.group(1))
+        return {"value": round(tasks / best / 1e6, 3), "unit": "Medges/s", "cores": threads, "kind": "reference",
+                "seconds": round(best, 3), "count_matches_gpu": bool(count == gpu_count),
+                "sample": "tc_omp_base (reference binary, g++ -O3 -fopenmp, its own orientation + Timer) on the whole graph, "
+                          "best of 2 runs", "host_cpus": os.cpu_count()}
+    except Exception as e:  # the baseline is a report, never a reason to lose the bench line
+        print(f"[bench] reference baseline skipped: {e}", file=sys.stderr)
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 if __name__ == "__main__":
