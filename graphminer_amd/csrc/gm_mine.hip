@@ -722,7 +722,7 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
 
     // pass X
     {
-      const int llen = dirx ? b : 0;
+      const int llen = (dirx && !(p.flags & 2048)) ? b : 0;  // (2048: ablation, skip pass X)
       const int s_len_flag = al | (flag << 30);
       auto actx = [&](bool f, int owner, int kidx, int pos, int fl, int key) { on_found(f, owner, kidx, pos, fl, key, true); };
       if (use_filter)
@@ -734,7 +734,7 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
     }
     // pass Y
     {
-      const int llen = diry ? al : 0;
+      const int llen = (diry && !(p.flags & 0x10000)) ? al : 0;  // (0x10000: ablation, skip pass Y)
       const int s_len_flag = b | (flag << 30);
       auto acty = [&](bool f, int owner, int kidx, int pos, int fl, int key) { on_found(f, owner, kidx, pos, fl, key, false); };
       flat_pass<SEARCH_HBM>(L, B.stage, col, bm, lane, llen, ru, rv, s_len_flag, acty);
