@@ -114,6 +114,10 @@ struct gm_graph {
   int *d_idx0 = nullptr;                  // rectangle: #neighbours below v, and the wedge-block prefix
   unsigned long long *d_wblock_prefix = nullptr;
   unsigned long long n_wblocks = 0;
+  int4 *d_rect_tasks = nullptr;          // rectangle by wedge accumulation: task list, counter maps
+  unsigned long long n_rect_tasks = 0;
+  unsigned *d_rect_acc = nullptr;
+  size_t rect_acc_bytes = 0;
   unsigned long long *d_house_prefix = nullptr;  // house: per-entry task-block prefix
   unsigned long long n_house_blocks = 0;   // handle whose event ring holds this handle's most recent launch
   unsigned long long sum_c2 = 0;          // sum_v C(d(v),2)
@@ -144,6 +148,8 @@ extern "C" void gm_graph_free(gm_graph *g) {
   if (g->d_idx0) (void)hipFree(g->d_idx0);
   if (g->d_wblock_prefix) (void)hipFree(g->d_wblock_prefix);
   if (g->d_house_prefix) (void)hipFree(g->d_house_prefix);
+  if (g->d_rect_tasks) (void)hipFree(g->d_rect_tasks);
+  if (g->d_rect_acc) (void)hipFree(g->d_rect_acc);
   for (auto &pr : g->ev)
     for (auto &e : pr)
       if (e) (void)hipEventDestroy(e);
@@ -866,6 +872,13 @@ extern "C" int gm_tc(const gm_graph *dag, const gm_launch *la, uint64_t *total, 
 }
 
 // rectangle, flattened over wedges (rect_flat_kernel in gm_mine.hip)
+static int ensure_idx0(gm_graph *g, const GraphView &gv) {
+  if (g->d_idx0) return GM_OK;
+  HIP_TRY(hipMalloc(&g->d_idx0, sizeof(int) * (size_t)std::max(g->nv, 1)));
+  HIP_TRY(launch_idx0(gv, g->d_idx0, 0));
+  return GM_OK;
+}
+
 static int run_rect_flat(const gm_graph *cg, const gm_launch *la_in, uint64_t *h_out, gm_stats *st, bool pentagon = false) {
   LaunchCtx ctx;
   int rc = begin_launch(cg, la_in, h_out, ctx);
@@ -878,8 +891,8 @@ static int run_rect_flat(const gm_graph *cg, const gm_launch *la_in, uint64_t *h
   gv.rp = g->d_rp;
   gv.col = g->d_col;
   if (!g->d_wblock_prefix) {  // once per graph: idx0[v] on the device, wedge-block prefix on the host
-    HIP_TRY(hipMalloc(&g->d_idx0, sizeof(int) * (size_t)std::max(g->nv, 1)));
-    HIP_TRY(launch_idx0(gv, g->d_idx0, 0));
+    rc = ensure_idx0(g, gv);
+    if (rc) return rc;
     std::vector<int> idx0((size_t)std::max(g->nv, 1));
     HIP_TRY(hipMemcpy(idx0.data(), g->d_idx0, sizeof(int) * (size_t)g->nv, hipMemcpyDeviceToHost));
     std::vector<unsigned long long> pre((size_t)g->nv + 1);
@@ -914,6 +927,85 @@ static int run_rect_flat(const gm_graph *cg, const gm_launch *la_in, uint64_t *h
   if (rc) return rc;
   if (count > 0) HIP_TRY(launch_rect_flat(p, pentagon, grid, ctx.stream));
   fill_stats(st, (uint64_t)(g->ne / 2 / ctx.world), (uint64_t)count, grid, 256);
+  return end_launch(ctx, FIN_COPY, 0, h_out, 1, st);
+}
+
+// rectangle by wedge accumulation (rect_acc_kernel in gm_mine.hip)
+static int run_rect_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h_out, gm_stats *st) {
+  LaunchCtx ctx;
+  int rc = begin_launch(cg, la_in, h_out, ctx);
+  if (rc) return rc;
+  gm_graph *g = ctx.g;
+  const gm_launch *la = &ctx.la;
+  GraphView gv;
+  gv.nv = g->nv;
+  gv.ne = (int)g->ne;
+  gv.rp = g->d_rp;
+  gv.col = g->d_col;
+  rc = ensure_idx0(g, gv);
+  if (rc) return rc;
+  if (!g->d_rect_tasks) {  // once per graph: 2-path estimate per centre (device), task list (host): heavy first, then light by 4
+    const size_t nv = (size_t)g->nv;
+    unsigned long long *d_work = nullptr;
+    HIP_TRY(hipMalloc(&d_work, sizeof(unsigned long long) * std::max<size_t>(nv, 1)));
+    std::vector<unsigned long long> work(std::max<size_t>(nv, 1));
+    hipError_t e = nv ? launch_rect_work(gv, g->d_idx0, d_work, 0) : hipSuccess;
+    if (e == hipSuccess) e = hipMemcpy(work.data(), d_work, sizeof(unsigned long long) * nv, hipMemcpyDeviceToHost);
+    (void)hipFree(d_work);
+    if (e != hipSuccess) return hip_fail(e, "rect_work_kernel", __FILE__, __LINE__);
+    std::vector<int> vs;
+    vs.reserve(nv);
+    for (size_t v = 0; v < nv; ++v)
+      if (work[v] > 0) vs.push_back((int)v);
+    std::stable_sort(vs.begin(), vs.end(), [&](int a, int b) { return work[(size_t)a] > work[(size_t)b]; });
+    const unsigned long long heavy = 1ull << 15;  // 2-paths above which a centre gets a whole workgroup
+    std::vector<int4> tasks;
+    size_t i = 0;
+    for (; i < vs.size() && work[(size_t)vs[i]] >= heavy; ++i) tasks.push_back(make_int4(vs[i], -2, -2, -2));
+    for (; i < vs.size(); i += 4) {
+      int4 t = make_int4(-1, -1, -1, -1);
+      t.x = vs[i];
+      if (i + 1 < vs.size()) t.y = vs[i + 1];
+      if (i + 2 < vs.size()) t.z = vs[i + 2];
+      if (i + 3 < vs.size()) t.w = vs[i + 3];
+      tasks.push_back(t);
+    }
+    g->n_rect_tasks = tasks.size();
+    HIP_TRY(hipMalloc(&g->d_rect_tasks, sizeof(int4) * std::max<size_t>(tasks.size(), 1)));
+    if (!tasks.empty()) HIP_TRY(hipMemcpy(g->d_rect_tasks, tasks.data(), sizeof(int4) * tasks.size(), hipMemcpyHostToDevice));
+  }
+  RectAccParams p;
+  memset(&p, 0, sizeof p);
+  p.g = gv;
+  p.idx0 = g->d_idx0;
+  p.tasks = g->d_rect_tasks;
+  int64_t first = 0, step = 1, count = 0;
+  gm_partition((int64_t)g->n_rect_tasks, ctx.rank, ctx.world, la->policy, &first, &step, &count);
+  p.first = (unsigned long long)first;
+  p.step = (unsigned long long)step;
+  p.count = (unsigned long long)count;
+  p.counters = g->d_counters;
+  p.queue = g->d_counters + 4;
+  // one counter map (nv words) per wave, within a memory budget
+  p.acc_stride = ((unsigned long long)g->nv + 63ull) & ~63ull;
+  const unsigned long long per_wg = p.acc_stride * 4ull * kWavesPerBlock;
+  const unsigned long long budget = 32ull << 30;
+  long long grid = std::min<long long>((long long)g->cu_count * 8, (long long)std::max<unsigned long long>(1, budget / std::max<unsigned long long>(per_wg, 1)));
+  grid = std::max<long long>(1, std::min<long long>(grid, count));
+  const size_t need = (size_t)per_wg * (size_t)grid;
+  if (need > g->rect_acc_bytes) {
+    if (g->d_rect_acc) (void)hipFree(g->d_rect_acc);
+    g->d_rect_acc = nullptr;
+    g->rect_acc_bytes = 0;
+    HIP_TRY(hipMalloc(&g->d_rect_acc, need));
+    HIP_TRY(hipMemset(g->d_rect_acc, 0, need));  // every launch leaves the maps zeroed again
+    g->rect_acc_bytes = need;
+  }
+  p.acc = g->d_rect_acc;
+  rc = start_timer(ctx);
+  if (rc) return rc;
+  if (count > 0) HIP_TRY(launch_rect_acc(p, (int)grid, ctx.stream));
+  fill_stats(st, (uint64_t)(g->ne / 2 / ctx.world), (uint64_t)count, (int)grid, 256);
   return end_launch(ctx, FIN_COPY, 0, h_out, 1, st);
 }
 
@@ -1014,8 +1106,11 @@ static int run_sgl_nested(int pat, const gm_graph *cg, const gm_launch *la_in, u
 extern "C" int gm_sgl(const gm_graph *sym, const char *pattern, const gm_launch *la, uint64_t *total, gm_stats *st) {
   if (!pattern) return GM_ERR_INVALID;
   if (strcmp(pattern, "diamond") == 0) return run_pattern(PAT_DIAMOND, sym, la, 4, total, 1, st);
-  if (strcmp(pattern, "rectangle") == 0)  // tune[6] & 1024: the first, wave-per-edge version (A/B)
-    return (la && (la->tune[6] & 1024)) ? run_sgl_nested(SGL_RECTANGLE, sym, la, total, st) : run_rect_flat(sym, la, total, st);
+  if (strcmp(pattern, "rectangle") == 0) {  // tune[6] & 1024: wave-per-edge loop nest; & 2048: wedges + flat intersections (A/B, tests)
+    if (la && (la->tune[6] & 1024)) return run_sgl_nested(SGL_RECTANGLE, sym, la, total, st);
+    if (la && (la->tune[6] & 2048)) return run_rect_flat(sym, la, total, st);
+    return run_rect_acc(sym, la, total, st);
+  }
   if (strcmp(pattern, "house") == 0)
     return (la && (la->tune[6] & 1024)) ? run_sgl_nested(SGL_HOUSE, sym, la, total, st) : run_house_flat(sym, la, total, st);
   if (strcmp(pattern, "pentagon") == 0)
@@ -1059,7 +1154,7 @@ extern "C" int gm_motif4_partial(const gm_graph *sym, const gm_launch *la, uint6
   memset(&s1, 0, sizeof s1); memset(&s2, 0, sizeof s2); memset(&s3, 0, sizeof s3);
   int rc = run_pattern(PAT_MOTIF4E, sym, &l2, 4, raw, 4, &s1, FIN_RAW4, 0);
   if (rc) return rc;
-  rc = run_rect_flat(sym, &l2, &raw[4], &s2);
+  rc = (l2.tune[6] & 2048) ? run_rect_flat(sym, &l2, &raw[4], &s2) : run_rect_acc(sym, &l2, &raw[4], &s2);
   if (rc) return rc;
   rc = run_pattern(PAT_CLIQUE4, g->dag_cache, &l2, 4, &raw[5], 1, &s3);
   if (rc) return rc;

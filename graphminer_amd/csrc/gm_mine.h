@@ -94,6 +94,21 @@ struct RectParams {
 hipError_t launch_rect_flat(const RectParams &p, bool pentagon, int grid_blocks, hipStream_t stream);
 hipError_t launch_idx0(const GraphView &g, int *idx0, hipStream_t stream);
 
+// rectangle by wedge accumulation (gm_mine.hip): per centre v0 a vertex-indexed counter map (the reference's "c-map"
+// idea, src/clique/omp_recursive.cc:59) replaces the per-wedge intersections
+struct RectAccParams {
+  GraphView g;
+  const int *idx0;
+  const int4 *tasks;                      // {v0, -2, -2, -2}: heavy centre, all 4 waves; else up to 4 light centres (-1 = none)
+  unsigned long long first, step, count;  // this rank owns tasks first + i*step
+  unsigned *acc;                          // one zeroed counter map per wave: grid * 4 * acc_stride
+  unsigned long long acc_stride;
+  unsigned long long *queue;
+  unsigned long long *counters;
+};
+hipError_t launch_rect_acc(const RectAccParams &p, int grid_blocks, hipStream_t stream);
+hipError_t launch_rect_work(const GraphView &g, const int *idx0, unsigned long long *work, hipStream_t stream);
+
 // flattened house (gm_mine.hip): tasks are (v0, v1, v3) with v1 < v0 in N(v0), v3 in N(v1) \ {v0}, 64 v3 per wave
 struct HouseParams {
   GraphView g;

@@ -86,7 +86,8 @@ constexpr int kTilesG = 4;        // passes that bisect / probe in HBM (Y, SPLIT
 //   SEARCH_LDS   bisect the LDS-staged copy (stage[s_base ..))
 //   SEARCH_BITMAP one probe of the row's dense bitmap over vertex ids (hub rows of SPLIT chunks); s_base then
 //                 carries the exclusive upper bound of the admissible keys (prefix bound of 3-motif, else INT_MAX)
-enum : int { SEARCH_HBM = 0, SEARCH_LDS = 1, SEARCH_BITMAP = 2 };
+//   SEARCH_NONE  no search: act(in_range, owner, key_index, 0, flag, key) for every key of every lookup list
+enum : int { SEARCH_HBM = 0, SEARCH_LDS = 1, SEARCH_BITMAP = 2, SEARCH_NONE = 3 };
 
 template <int MODE, class Act>
 __device__ __forceinline__ void flat_pass(WaveLds &L, const int *__restrict__ stage, const int *__restrict__ col,
@@ -129,6 +130,11 @@ __device__ __forceinline__ void flat_pass(WaveLds &L, const int *__restrict__ st
         fl[q] = d.w >> 30;
         key[q] = in[q] ? col[d.x + kidx[q]] : 0;
         lo[q] = 0;
+      }
+      if (MODE == SEARCH_NONE) {
+#pragma unroll
+        for (int q = 0; q < kTilesG; ++q) act(in[q], own[q] - 1, kidx[q], 0, fl[q], key[q]);
+        continue;
       }
       if (MODE == SEARCH_BITMAP) {
         unsigned wv[kTilesG];
@@ -930,6 +936,105 @@ __global__ __launch_bounds__(256) void rect_flat_kernel(const RectParams p) {
   }
   const unsigned long long s0 = wave_sum_u64(cnt);
   if (lane == 0 && s0) atomicAdd(&p.counters[0], s0);
+}
+
+// ---- rectangle by wedge accumulation ---------------------------------------------------------------------------
+// rectangle.h:1-11 counts, for the largest vertex v0 of a 4-cycle, sum_{v2 < v1 in N(v0), both < v0} |{w in N(v1) ^ N(v2) : w < v0}|
+//   = sum_{w < v0} C(c(w), 2),   c(w) = |{x in N(v0) ^ N(w) : x < v0}|
+// so one walk over the 2-paths v0 - x - w (x, w < v0) with a vertex-indexed counter map is enough: every increment adds the
+// counter's OLD value (0 + 1 + ... + (c-1) = C(c,2)); a second walk over the same 2-paths clears the map. No intersections.
+// A wave owns a map; light centres go one per wave, heavy centres (many 2-paths) use all 4 waves on wave 0's map.
+__global__ __launch_bounds__(256) void rect_work_kernel(GraphView g, const int *__restrict__ idx0, unsigned long long *__restrict__ work) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= g.nv) return;
+  unsigned long long w = 0;
+  const int r0 = g.rp[v];
+  for (int i = 0; i < idx0[v]; ++i) {
+    const int x = g.col[r0 + i];
+    w += (unsigned long long)(g.rp[x + 1] - g.rp[x]) + 1ull;  // >= |{w in N(x) : w < v}| + 1
+  }
+  work[v] = w;
+}
+
+__global__ __launch_bounds__(256) void rect_acc_kernel(const RectAccParams p) {
+  __shared__ WaveLds W[kWavesPerBlock];
+  __shared__ int4 s_task;
+  __shared__ int s_next;
+  const int *__restrict__ rp = p.g.rp;
+  const int *__restrict__ col = p.g.col;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  WaveLds &L = W[wave];
+  unsigned *acc_own = p.acc + ((size_t)blockIdx.x * kWavesPerBlock + wave) * p.acc_stride;
+  unsigned *acc_wg = p.acc + ((size_t)blockIdx.x * kWavesPerBlock) * p.acc_stride;
+  unsigned long long cnt = 0;
+  for (;;) {
+    if (threadIdx.x == 0) {
+      const unsigned long long q = atomicAdd(p.queue, 1ull);
+      s_task = (q < p.count) ? p.tasks[p.first + q * p.step] : make_int4(-3, -3, -3, -3);
+      s_next = 0;
+    }
+    __syncthreads();
+    const int4 t = s_task;
+    if (t.x == -3) break;
+    const bool heavy = t.y == -2;
+    const int v0 = heavy ? t.x : (wave == 0 ? t.x : wave == 1 ? t.y : wave == 2 ? t.z : t.w);
+    unsigned *acc = heavy ? acc_wg : acc_own;
+    for (int phase = 0; phase < 2; ++phase) {
+      if (v0 >= 0) {
+        const int r0 = rp[v0], n0 = p.idx0[v0];
+        int mine = 0;
+        for (;;) {
+          int bi = 0;
+          if (heavy) {
+            if (lane == 0) bi = atomicAdd(&s_next, 1);
+            bi = readfirst(bi);
+          } else {
+            bi = mine++;
+          }
+          if (bi * GM_WAVE >= n0) break;
+          const int i = bi * GM_WAVE + lane;
+          int llen = 0, kb = 0;
+          if (i < n0) {
+            const int x = col[r0 + i];
+            kb = rp[x];
+            llen = lower_bound(col + kb, rp[x + 1] - kb, v0);  // {w in N(x) : w < v0}
+          }
+          if (phase == 0) {
+            auto inc = [&](bool f, int, int, int, int, int key) {
+              if (f) cnt += (unsigned long long)__hip_atomic_fetch_add(&acc[key], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            };
+            flat_pass<SEARCH_NONE>(L, nullptr, col, nullptr, lane, llen, kb, 0, 0, inc);
+          } else {
+            auto clr = [&](bool f, int, int, int, int, int key) {
+              if (f) acc[key] = 0u;
+            };
+            flat_pass<SEARCH_NONE>(L, nullptr, col, nullptr, lane, llen, kb, 0, 0, clr);
+          }
+        }
+      }
+      if (heavy) {  // (t is uniform over the workgroup)
+        __syncthreads();
+        if (threadIdx.x == 0) s_next = 0;
+        __threadfence_block();
+        __syncthreads();
+      } else {
+        __threadfence_block();
+      }
+    }
+    __syncthreads();
+  }
+  const unsigned long long s0 = wave_sum_u64(cnt);
+  if (lane == 0 && s0) atomicAdd(&p.counters[0], s0);
+}
+
+hipError_t launch_rect_work(const GraphView &g, const int *idx0, unsigned long long *work, hipStream_t stream) {
+  hipLaunchKernelGGL(rect_work_kernel, dim3((unsigned)((g.nv + 255) / 256)), dim3(256), 0, stream, g, idx0, work);
+  return hipGetLastError();
+}
+
+hipError_t launch_rect_acc(const RectAccParams &p, int grid_blocks, hipStream_t stream) {
+  hipLaunchKernelGGL(rect_acc_kernel, dim3((unsigned)grid_blocks), dim3(256), 0, stream, p);
+  return hipGetLastError();
 }
 
 // ---- house, flattened ----------------------------------------------------------------------------------------
