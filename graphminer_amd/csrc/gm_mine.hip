@@ -128,14 +128,13 @@ __device__ __forceinline__ void flat_pass(WaveLds &L, const int *__restrict__ st
         sb[q] = in[q] ? d.z : 0;
         sl[q] = in[q] ? (d.w & 0x3fffffff) : 0;
         fl[q] = d.w >> 30;
-        key[q] = in[q] ? col[d.x + kidx[q]] : 0;
+        key[q] = col[in[q] ? d.x + kidx[q] : 0];  // unconditional load (select on the index): keeps vmcnt countable
         lo[q] = 0;
       }
-      if (MODE == SEARCH_NONE) {
-#pragma unroll
-        for (int q = 0; q < kTilesG; ++q) act(in[q], own[q] - 1, kidx[q], 0, fl[q], key[q]);
+      if constexpr (MODE == SEARCH_NONE) {
+        act(in, key);  // the whole tile group at once: act(const bool in[kTilesG], const int key[kTilesG])
         continue;
-      }
+      } else {
       if (MODE == SEARCH_BITMAP) {
         unsigned wv[kTilesG];
 #pragma unroll
@@ -178,6 +177,7 @@ __device__ __forceinline__ void flat_pass(WaveLds &L, const int *__restrict__ st
         const bool f = in[q] & (lo[q] < sl[q]) & (xf[q] == key[q]);
         act(f, own[q] - 1, kidx[q], lo[q], fl[q], key[q]);
       }
+      }  // MODE != SEARCH_NONE
     }
     wave_sync();
   }
@@ -290,12 +290,12 @@ __device__ __forceinline__ void flat_pass_filtered(WaveLds &L, const int *__rest
     const int *__restrict__ kp = col + base;
     // software pipeline: the keys of the NEXT 4 tiles are requested before the current 4 are hashed / filtered /
     // queued, so 8 coalesced key loads (2 KB) per wave are in flight instead of 4
+    // (loads are UNCONDITIONAL with a clamped index: a predicated load sits in its own exec-masked block, and the
+    // compiler then cannot count how many younger loads are in flight and waits with vmcnt(0) -- which would also
+    // wait for the prefetch it has just issued)
     int nxt[kTiles];
 #pragma unroll
-    for (int q = 0; q < kTiles; ++q) {
-      const int p = q * GM_WAVE + lane;
-      nxt[q] = (p < n) ? kp[p] : 0;
-    }
+    for (int q = 0; q < kTiles; ++q) nxt[q] = kp[min(q * GM_WAVE + lane, n - 1)];
     for (int t = 0; t < n; t += GM_WAVE * kTiles) {
       int key[kTiles];
       unsigned h[kTiles], fw[kTiles];
@@ -306,10 +306,7 @@ __device__ __forceinline__ void flat_pass_filtered(WaveLds &L, const int *__rest
         in[q] = (t + q * GM_WAVE + lane) < n;
       }
 #pragma unroll
-      for (int q = 0; q < kTiles; ++q) {
-        const int p = t + GM_WAVE * kTiles + q * GM_WAVE + lane;
-        nxt[q] = (p < n) ? kp[p] : 0;
-      }
+      for (int q = 0; q < kTiles; ++q) nxt[q] = kp[min(t + GM_WAVE * kTiles + q * GM_WAVE + lane, n - 1)];
 #pragma unroll
       for (int q = 0; q < kTiles; ++q) {
         h[q] = filter_hash(key[q], salt);
@@ -351,7 +348,7 @@ __device__ __forceinline__ void flat_pass_filtered(WaveLds &L, const int *__rest
         const int p = wb + t + q * GM_WAVE + lane;
         in[q] = p < total;
         const int4 d = L.desc[in[q] ? own[q] - 1 : 0];
-        key[q] = (in[q] && !(dbg & 64)) ? col[d.x + (p - d.y)] : (d.x + p);
+        key[q] = col[in[q] ? d.x + (p - d.y) : 0];  // unconditional load (select on the index)
         h[q] = filter_hash(key[q], (unsigned)d.z >> 16);
       }
 #pragma unroll
@@ -1000,13 +997,19 @@ __global__ __launch_bounds__(256) void rect_acc_kernel(const RectAccParams p) {
             llen = lower_bound(col + kb, rp[x + 1] - kb, v0);  // {w in N(x) : w < v0}
           }
           if (phase == 0) {
-            auto inc = [&](bool f, int, int, int, int, int key) {
-              if (f) cnt += (unsigned long long)__hip_atomic_fetch_add(&acc[key], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // (measured: issuing the four returning atomics of a tile group back to back is ~5 % SLOWER than one at a
+            // time -- the map updates are bound by the L2 atomic units, not by latency)
+            auto inc = [&](const bool *in, const int *key) {
+#pragma unroll
+              for (int q = 0; q < kTilesG; ++q)
+                if (in[q]) cnt += (unsigned long long)__hip_atomic_fetch_add(&acc[key[q]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             };
             flat_pass<SEARCH_NONE>(L, nullptr, col, nullptr, lane, llen, kb, 0, 0, inc);
           } else {
-            auto clr = [&](bool f, int, int, int, int, int key) {
-              if (f) acc[key] = 0u;
+            auto clr = [&](const bool *in, const int *key) {
+#pragma unroll
+              for (int q = 0; q < kTilesG; ++q)
+                if (in[q]) acc[key[q]] = 0u;
             };
             flat_pass<SEARCH_NONE>(L, nullptr, col, nullptr, lane, llen, kb, 0, 0, clr);
           }
