@@ -184,17 +184,21 @@ __device__ __forceinline__ void flat_pass(WaveLds &L, const int *__restrict__ st
 }
 
 // Exact bisection of up to kTiles*64 queued candidates (key, edge) against the LDS-staged rows.
+// Queue slots >= own_from belong to edge cur_owner (the long list being streamed: its owner is wave-uniform and is
+// not written per candidate); slots below carry their owner in L.qown.
 template <class Act>
 __device__ __forceinline__ void drain_candidates(WaveLds &L, const int *__restrict__ stage, const int lane, const int n,
-                                                 const int steps, Act act) {
+                                                 const int steps, const int own_from, const int cur_owner, Act act) {
   int own[kTiles], key[kTiles], sb[kTiles], sl[kTiles], fl[kTiles], lo[kTiles];
   bool in[kTiles];
 #pragma unroll
   for (int q = 0; q < kTiles; ++q) {
-    const int slot = q * GM_WAVE + lane;
+    const int slot = q * GM_WAVE + lane;  // < kQueueCap: the reads below are always in bounds
     in[q] = slot < n;
-    key[q] = in[q] ? L.qkey[slot] : 0;
-    own[q] = in[q] ? (int)L.qown[slot] : 0;
+    key[q] = L.qkey[slot];
+    own[q] = (int)L.qown[slot];
+    own[q] = (slot >= own_from) ? cur_owner : own[q];
+    own[q] = in[q] ? own[q] : 0;
   }
 #pragma unroll
   for (int q = 0; q < kTiles; ++q) {
@@ -264,18 +268,28 @@ __device__ __forceinline__ void flat_pass_filtered(WaveLds &L, const int *__rest
     }
     qcount += __popcll(m);
   };
+  int own_from = kQueueCap, cur_owner = 0;  // wave-uniform: slots >= own_from belong to the long list being streamed
+  auto enqueue_long = [&](const bool cand, const int key) {
+    const unsigned long long m = __ballot(cand);
+    if (cand) L.qkey[qcount + rank_below(m)] = key;
+    qcount += __popcll(m);
+  };
   auto drain_full_tiles = [&]() {
     if (qcount >= GM_WAVE) {  // wave-uniform
       wave_sync();
       const int n = qcount & ~(GM_WAVE - 1);
-      if (!(dbg & 16)) drain_candidates(L, stage, lane, n, steps, act);
-      const int rest = qcount - n;  // < 64: move to the front
+      if (!(dbg & 16)) drain_candidates(L, stage, lane, n, steps, own_from, cur_owner, act);
+      const int rest = qcount - n;  // < 64: move to the front, owners written out
       int k = 0;
       unsigned char o = 0;
-      if (lane < rest) { k = L.qkey[n + lane]; o = L.qown[n + lane]; }
+      if (lane < rest) {
+        k = L.qkey[n + lane];
+        o = (n + lane >= own_from) ? (unsigned char)cur_owner : L.qown[n + lane];
+      }
       wave_sync();
       if (lane < rest) { L.qkey[lane] = k; L.qown[lane] = o; }
       qcount = rest;
+      own_from = (own_from < kQueueCap) ? rest : kQueueCap;
     }
   };
 
@@ -288,6 +302,8 @@ __device__ __forceinline__ void flat_pass_filtered(WaveLds &L, const int *__rest
     const int n = readlane(llen_all, src);
     const unsigned salt = (unsigned)readlane(s_base_salt, src) >> 16;
     const int *__restrict__ kp = col + base;
+    own_from = qcount;  // (< 64 queued candidates of earlier lists keep their written owners)
+    cur_owner = src;
     // Software pipeline: the keys of the NEXT tile group are requested before the current group is hashed / filtered /
     // queued. (A deeper pipeline was measured and does not pay: 1 group ahead 11.16 ms, 2: 11.22, 3: 11.31, 4: 11.50.)
     // Loads are UNCONDITIONAL: a predicated load sits in its own exec-masked block, the compiler then cannot count how
@@ -302,7 +318,7 @@ __device__ __forceinline__ void flat_pass_filtered(WaveLds &L, const int *__rest
         fw[q] = fbits[h[q] >> 5];
       }
 #pragma unroll
-      for (int q = 0; q < kTiles; ++q) enqueue(in[q] & (((fw[q] >> (h[q] & 31u)) & 1u) != 0u), key[q], src);
+      for (int q = 0; q < kTiles; ++q) enqueue_long(in[q] & (((fw[q] >> (h[q] & 31u)) & 1u) != 0u), key[q]);
       drain_full_tiles();
     };
     constexpr int G = GM_WAVE * kTiles;
@@ -335,6 +351,9 @@ __device__ __forceinline__ void flat_pass_filtered(WaveLds &L, const int *__rest
       for (int q = 0; q < kTiles; ++q) nxt[q] = kp[min(t + G + q * GM_WAVE + lane, n - 1)];
       process(key, in);
     }
+    // the list is done: write the owner of what is still queued (< 64 entries), later candidates carry their own
+    if (own_from + lane < qcount) L.qown[own_from + lane] = (unsigned char)src;
+    own_from = kQueueCap;
   }
 
   // ---- short lists: flattened ---------------------------------------------------------------------------
@@ -380,7 +399,7 @@ __device__ __forceinline__ void flat_pass_filtered(WaveLds &L, const int *__rest
   }
   if (qcount > 0) {
     wave_sync();
-    drain_candidates(L, stage, lane, qcount, steps, act);
+    drain_candidates(L, stage, lane, qcount, steps, kQueueCap, 0, act);
   }
   wave_sync();
 }
