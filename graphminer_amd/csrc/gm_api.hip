@@ -69,6 +69,20 @@ extern "C" int gm_device_count(int *n) {
 // graph handle
 // ------------------------------------------------------------------------------------------------
 // estimated work (adjacency entries touched) above which a chunk is cut into parts
+// Rows longer than kBitmapMinDeg get a dense vertex-id bitmap, longest first, within kBitmapBudget bytes: SPLIT chunks
+// probe their own row's, pass Y probes the searched row's (one load instead of ~lg d dependent ones). A probe is a random
+// 64 B line, so it only beats a bisection whose upper levels sit in cache when the row is long. Measured (diamond ms on
+// R-MAT-20 / -22 / -24, 3-motif on R-MAT-24): min degree 1024: - / 117 / - / 1037;  2048: 25.8 / 94.8 / - / 1068;
+// 4096: 30.6 / 94.5 / 1539 / 1057;  8192: 30.8 / 89.6 / 1528 / 1073;  16384: 44.7 / 89.8 / 1528 / 1072;
+// 2048 within 256 MB (Infinity-Cache sized): 25.7 / 87.1 / 2275 / 1373;  no pass-Y bitmaps at all: - / 124 / - / 1473.
+#ifndef GM_BITMAP_MIN_DEG
+#define GM_BITMAP_MIN_DEG 2048
+#endif
+#ifndef GM_BITMAP_BUDGET_MB
+#define GM_BITMAP_BUDGET_MB 8192
+#endif
+constexpr int kBitmapMinDeg = GM_BITMAP_MIN_DEG;
+constexpr unsigned long long kBitmapBudget = (unsigned long long)GM_BITMAP_BUDGET_MB << 20;
 constexpr unsigned long long kPartCostCap = 8ull << 20;  // R-MAT-22 diamond: hub-row chunks reach 10^8; staged chunks stay whole
 constexpr int kDefaultChunk = 1024;  // task edges per chunk when the caller does not say
 
@@ -80,6 +94,7 @@ struct ChunkTable {
   ChunkRec *d = nullptr;
   size_t n = 0;
   int *d_slot = nullptr;                 // per chunk: hub bitmap slot or -1
+  int *d_row_slot = nullptr;             // per vertex: bitmap slot or -1
   // dequeue orders of the round-robin policy: [0] chunks well above the mean cost first (heaviest first), the rest in vertex
   // order (single rank); [1] all chunks by estimated cost, descending (rank r of n owns every n-th entry)
   int *d_order[2] = {nullptr, nullptr};
@@ -129,6 +144,7 @@ static void free_tables(gm_graph *g) {
   for (auto &t : g->tables) {
     if (t.d) (void)hipFree(t.d);
     if (t.d_slot) (void)hipFree(t.d_slot);
+    if (t.d_row_slot) (void)hipFree(t.d_row_slot);
     for (int i = 0; i < 2; ++i) if (t.d_order[i]) (void)hipFree(t.d_order[i]);
     if (t.d_bitmaps) (void)hipFree(t.d_bitmaps);
   }
@@ -560,11 +576,11 @@ static int get_table(gm_graph *g, int target, bool allow_split, int bit_words, u
     // Hub rows (longer than the LDS stage, cut into SPLIT chunks) get a dense bitmap over the vertex ids, the
     // longest rows first, within a memory budget: one probe then replaces a ~17-step bisection in HBM.
     const unsigned long long words = ((unsigned long long)g->nv + 31ull) / 32ull;
-    const unsigned long long budget_bytes = 8ull << 30;
+    const unsigned long long budget_bytes = kBitmapBudget;
     std::vector<std::pair<int, int>> big;  // (degree, vertex)
     for (int v = 0; v < g->nv; ++v) {
       const int d = g->h_rp[v + 1] - g->h_rp[v];
-      if (d > kStageCap) big.push_back({d, v});
+      if (d > kBitmapMinDeg) big.push_back({d, v});
     }
     std::sort(big.begin(), big.end(), [](const std::pair<int, int> &x, const std::pair<int, int> &y) { return x.first > y.first; });
     const size_t nb = words ? std::min<size_t>(big.size(), (size_t)(budget_bytes / (words * 4ull))) : 0;
@@ -584,6 +600,12 @@ static int get_table(gm_graph *g, int target, bool allow_split, int bit_words, u
       }
       HIP_TRY(hipMalloc(&t.d_slot, sizeof(int) * t.n));
       HIP_TRY(hipMemcpy(t.d_slot, slots.data(), sizeof(int) * t.n, hipMemcpyHostToDevice));
+      {
+        std::vector<int> by_vertex((size_t)g->nv, -1);
+        for (size_t i = 0; i < nb; ++i) by_vertex[(size_t)rows[i]] = (int)i;
+        HIP_TRY(hipMalloc(&t.d_row_slot, sizeof(int) * (size_t)g->nv));
+        HIP_TRY(hipMemcpy(t.d_row_slot, by_vertex.data(), sizeof(int) * (size_t)g->nv, hipMemcpyHostToDevice));
+      }
       HIP_TRY(hipMalloc(&t.d_bitmaps, (size_t)nb * (size_t)words * 4));
       HIP_TRY(hipMemset(t.d_bitmaps, 0, (size_t)nb * (size_t)words * 4));
       int *d_rows = nullptr;
@@ -777,6 +799,7 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
   p.chunk_slot = tab->d_slot;
   p.bitmaps = tab->d_bitmaps;
   p.bitmap_words = tab->bitmap_words;
+  p.row_slot = tab->d_row_slot;
   const long long n = (long long)tab->n;
   unsigned long long my_edges = 0;
   {
@@ -816,8 +839,9 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
   // direction rule: X if b*(xb + xs*lg a) <= a*(yb + ys*lg b); tune[2] = xs+1, tune[3] = ys+1, tune[7] = xb*16 + yb
   p.cost_x_step = la->tune[2] > 0 ? la->tune[2] - 1 : 1;
   p.cost_y_step = la->tune[3] > 0 ? la->tune[3] - 1 : 6;
-  p.cost_x_base = la->tune[7] > 0 ? (la->tune[7] >> 4) : 2;
-  p.cost_y_base = la->tune[7] > 0 ? (la->tune[7] & 15) : 2;
+  p.cost_x_base = (la->tune[7] & 255) > 0 ? ((la->tune[7] >> 4) & 15) : 2;
+  p.cost_y_base = (la->tune[7] & 255) > 0 ? (la->tune[7] & 15) : 2;
+  p.cost_y_bitmap = la->tune[7] >> 8;  // 0 = price pass Y as a bisection even when row v has a bitmap
   p.k = k;
   p.flags = (la->tune[5] == 1) ? 1 : 0;
   p.flags |= (la->tune[6] & 0xffff) << 1;  // debug/ablation: bit1 skip clique phase 2, bit2 skip bit-matrix writes (counts wrong)

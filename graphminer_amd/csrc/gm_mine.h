@@ -52,6 +52,7 @@ struct MineParams {
   const int *order;              // dequeue position -> chunk id (nullptr = identity)
   const unsigned *bitmaps;       // dense vertex-id bitmaps of the longest rows, bitmap_words each
   unsigned long long bitmap_words;
+  const int *row_slot;           // per vertex: its bitmap slot or -1 (nullptr when the table has no bitmaps)
   int first, step, count;        // this rank owns chunk ids first + i*step, i in [0,count)
   int grab;                      // chunks taken per dequeue
   unsigned *queue;               // dequeue head (zeroed before launch)
@@ -62,6 +63,7 @@ struct MineParams {
   int cost_y_step;
   int cost_x_base;
   int cost_y_base;
+  int cost_y_bitmap;  // pass Y cost per key when row v has a dense bitmap (one random probe)
   int k;
   int flags;  // bit 0: never stage adjacency in LDS; bit 3: no hashed filter in front of the LDS bisection; bit 9: ignore hub bitmaps (A/B switches)
 };

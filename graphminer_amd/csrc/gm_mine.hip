@@ -86,13 +86,16 @@ constexpr int kTilesG = 4;        // passes that bisect / probe in HBM (Y, SPLIT
 //   SEARCH_LDS   bisect the LDS-staged copy (stage[s_base ..))
 //   SEARCH_BITMAP one probe of the row's dense bitmap over vertex ids (hub rows of SPLIT chunks); s_base then
 //                 carries the exclusive upper bound of the admissible keys (prefix bound of 3-motif, else INT_MAX)
+//   SEARCH_BITMAP_ROW one probe of the dense bitmap of the SEARCHED row, which differs per edge: the slot travels in the
+//                 length field of the descriptor, bm = base of all bitmaps, bm_words = words per bitmap
 //   SEARCH_NONE  no search: act(in_range, owner, key_index, 0, flag, key) for every key of every lookup list
-enum : int { SEARCH_HBM = 0, SEARCH_LDS = 1, SEARCH_BITMAP = 2, SEARCH_NONE = 3 };
+enum : int { SEARCH_HBM = 0, SEARCH_LDS = 1, SEARCH_BITMAP = 2, SEARCH_NONE = 3, SEARCH_BITMAP_ROW = 4 };
 
 template <int MODE, class Act>
 __device__ __forceinline__ void flat_pass(WaveLds &L, const int *__restrict__ stage, const int *__restrict__ col,
                                           const unsigned *__restrict__ bm, const int lane, const int llen,
-                                          const int key_base, const int s_base, const int s_len_flag, Act act) {
+                                          const int key_base, const int s_base, const int s_len_flag, Act act,
+                                          const unsigned long long bm_words = 0) {
   constexpr bool SLDS = (MODE == SEARCH_LDS);
   const int incl = wave_incl_scan_add(llen);
   const int total = readlane(incl, GM_WAVE - 1);
@@ -135,10 +138,12 @@ __device__ __forceinline__ void flat_pass(WaveLds &L, const int *__restrict__ st
         act(in, key);  // the whole tile group at once: act(const bool in[kTilesG], const int key[kTilesG])
         continue;
       } else {
-      if (MODE == SEARCH_BITMAP) {
+      if (MODE == SEARCH_BITMAP || MODE == SEARCH_BITMAP_ROW) {
         unsigned wv[kTilesG];
 #pragma unroll
-        for (int q = 0; q < kTilesG; ++q) wv[q] = bm[(unsigned)key[q] >> 5];
+        for (int q = 0; q < kTilesG; ++q)
+          wv[q] = (MODE == SEARCH_BITMAP) ? bm[(unsigned)key[q] >> 5]
+                                          : bm[(size_t)sl[q] * (size_t)bm_words + ((unsigned)key[q] >> 5)];
 #pragma unroll
         for (int q = 0; q < kTilesG; ++q) {
           const bool f = in[q] & (((wv[q] >> ((unsigned)key[q] & 31u)) & 1u) != 0u) & (key[q] < sb[q]);
@@ -723,10 +728,15 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
     act = act && al > 0 && b > 0;
     // direction: X streams B = N(v) and bisects A; Y takes keys from A and bisects B in HBM
     bool dirx = false;
+    int vslot = -1;  // dense bitmap of row v, if it has one: pass Y then probes it instead of bisecting N(v)
+    if (!GM_IS_CLIQUE(PAT) && p.row_slot != nullptr && act && !(p.flags & 512)) vslot = p.row_slot[v];
     if (act) {
       if (staged) {
         const float cx = (float)b * (float)(p.cost_x_base + p.cost_x_step * bitlen(al));
-        const float cy = (float)al * (float)(p.cost_y_base + p.cost_y_step * bitlen(b));
+        // (a bitmap probe is a random 64 B line from a multi-GB region: measured, pricing it below the bisection makes the
+        // rule pick Y far too often -- TC 10.9 -> 38 ms at 4 per key; by default the rule ignores the bitmap)
+        const float cy = (float)al * ((vslot >= 0 && p.cost_y_bitmap > 0) ? (float)p.cost_y_bitmap
+                                                                           : (float)(p.cost_y_base + p.cost_y_step * bitlen(b)));
         dirx = cx <= cy;
       } else if (bm) {
         dirx = (p.flags & 1024) ? ((float)b <= (float)al * (float)(2 + bitlen(b))) : (b <= al);  // bitmap probe vs lg(b) HBM probes
@@ -773,12 +783,15 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
       else if (bm) flat_pass<SEARCH_BITMAP>(L, B.stage, col, bm, lane, llen, rv, (PAT == PAT_MOTIF3) ? u : 0x7fffffff, s_len_flag, actx);
       else flat_pass<SEARCH_HBM>(L, B.stage, col, bm, lane, llen, rv, ru, s_len_flag, actx);
     }
-    // pass Y
+    // pass Y: keys from A bisect B = N(v) in HBM -- or, when v is a hub row with a dense bitmap, probe that (one load
+    // instead of ~lg b dependent ones; on symmetric R-MAT graphs most Y keys go against hub rows)
     {
-      const int llen = (diry && !(p.flags & 0x10000)) ? al : 0;  // (0x10000: ablation, skip pass Y)
-      const int s_len_flag = b | (flag << 30);
       auto acty = [&](bool f, int owner, int kidx, int pos, int fl, int key) { on_found(f, owner, kidx, pos, fl, key, false); };
-      flat_pass<SEARCH_HBM>(L, B.stage, col, bm, lane, llen, ru, rv, s_len_flag, acty);
+      const bool y_on = diry && !(p.flags & 0x10000);  // (0x10000: ablation, skip pass Y)
+      flat_pass<SEARCH_HBM>(L, B.stage, col, bm, lane, (y_on && vslot < 0) ? al : 0, ru, rv, b | (flag << 30), acty);
+      if (!GM_IS_CLIQUE(PAT) && p.row_slot != nullptr)
+        flat_pass<SEARCH_BITMAP_ROW>(L, B.stage, col, p.bitmaps, lane, (y_on && vslot >= 0) ? al : 0, ru, 0x7fffffff,
+                                     max(vslot, 0) | (flag << 30), acty, p.bitmap_words);
     }
 
     if (PAT == PAT_DIAMOND) {
