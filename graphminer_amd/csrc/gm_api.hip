@@ -91,6 +91,7 @@ struct ChunkTable {
   bool allow_split; // rows longer than the staging capacity may be cut across chunks
   int bit_words;    // clique: LDS bit-matrix budget the chunks were built for (0 = unconstrained)
   unsigned long long part_cap = 0;  // estimated work above which a chunk is cut into parts
+  int stage_cap = 0;                // rows longer than this are SPLIT rows
   ChunkRec *d = nullptr;
   size_t n = 0;
   int *d_slot = nullptr;                 // per chunk: hub bitmap slot or -1
@@ -419,7 +420,7 @@ extern "C" int gm_graph_orient(const gm_graph *sym, gm_graph **out) {
 // ------------------------------------------------------------------------------------------------
 // task chunk tables
 // ------------------------------------------------------------------------------------------------
-static void build_chunks(const std::vector<int> &rp, int nv, int target, bool allow_split, int bit_words,
+static void build_chunks(const std::vector<int> &rp, int nv, int target, bool allow_split, int bit_words, int stage_cap,
                          std::vector<ChunkRec> &out, unsigned long long &max_bit_words) {
   out.clear();
   max_bit_words = 0;
@@ -428,7 +429,7 @@ static void build_chunks(const std::vector<int> &rp, int nv, int target, bool al
   while (u < nv) {
     const int d = deg(u);
     if (d == 0) { ++u; continue; }
-    if (d > kStageCap) {
+    if (d > stage_cap) {
       if (allow_split) {
         for (int s = rp[u]; s < rp[u + 1]; s += target) out.push_back({u, u + 1, s, std::min(s + target, rp[u + 1]), 0, 1});
       } else {
@@ -442,8 +443,8 @@ static void build_chunks(const std::vector<int> &rp, int nv, int target, bool al
     int edges = 0, maxd = 0;
     while (u < nv && (u - start) < kMaxChunkVerts) {
       const int du = deg(u);
-      if (du > kStageCap) break;
-      if (edges > 0 && edges + du > kStageCap) break;
+      if (du > stage_cap) break;
+      if (edges > 0 && edges + du > stage_cap) break;
       if (bit_words && edges > 0) {
         const int nm = std::max(maxd, du);
         if ((long long)(edges + du) * ((nm + 31) / 32) > bit_words) break;
@@ -492,17 +493,19 @@ __global__ __launch_bounds__(256) void chunk_cost_kernel(const int *__restrict__
   if ((threadIdx.x & 63) == 0 && c) atomicAdd(&cost[blockIdx.x], c);
 }
 
-static int get_table(gm_graph *g, int target, bool allow_split, int bit_words, unsigned long long part_cap, ChunkTable **out) {
+static int get_table(gm_graph *g, int target, bool allow_split, int bit_words, unsigned long long part_cap, int stage_cap,
+                     ChunkTable **out) {
   std::lock_guard<std::mutex> lk(g->mu);
   for (auto &t : g->tables)
-    if (t.target == target && t.allow_split == allow_split && t.bit_words == bit_words && t.part_cap == part_cap) { *out = &t; return GM_OK; }
+    if (t.target == target && t.allow_split == allow_split && t.bit_words == bit_words && t.part_cap == part_cap && t.stage_cap == stage_cap) { *out = &t; return GM_OK; }
   std::vector<ChunkRec> recs;
   ChunkTable t;
   t.target = target;
   t.allow_split = allow_split;
   t.bit_words = bit_words;
   t.part_cap = part_cap;
-  build_chunks(g->h_rp, g->nv, target, allow_split, bit_words, recs, t.max_bit_words);
+  t.stage_cap = stage_cap;
+  build_chunks(g->h_rp, g->nv, target, allow_split, bit_words, stage_cap, recs, t.max_bit_words);
   // estimated work per chunk (device), then: cut the heavy ones into parts, and fix the dequeue orders
   std::vector<unsigned long long> cost(recs.size());
   if (!recs.empty()) {
@@ -593,7 +596,7 @@ static int get_table(gm_graph *g, int target, bool allow_split, int bit_words, u
       std::vector<int> slots(t.n, -1);
       for (size_t c = 0; c < t.n; ++c) {
         const ChunkRec &r = recs[c];
-        if (r.u_end == r.u_begin + 1 && (g->h_rp[r.u_begin + 1] - g->h_rp[r.u_begin]) > kStageCap) {
+        if (r.u_end == r.u_begin + 1 && (g->h_rp[r.u_begin + 1] - g->h_rp[r.u_begin]) > stage_cap) {
           auto it = std::lower_bound(row_slot.begin(), row_slot.end(), std::make_pair(r.u_begin, -1));
           if (it != row_slot.end() && it->first == r.u_begin) slots[c] = it->second;
         }
@@ -655,7 +658,7 @@ extern "C" int gm_chunk_table(int32_t nv, const int64_t *row_ptr, int32_t chunk,
   target = std::max(64, std::min(target, kStageCap));
   std::vector<ChunkRec> out;
   unsigned long long mb = 0;
-  build_chunks(rp, nv, target, !for_clique, for_clique ? kBitWords : 0, out, mb);
+  build_chunks(rp, nv, target, !for_clique, for_clique ? kBitWords : 0, kStageCap, out, mb);
   *n_out = (int64_t)out.size();
   for (int64_t i = 0; i < (int64_t)out.size() && i < cap; ++i) {
     recs[4 * i + 0] = out[i].u_begin;
@@ -786,7 +789,7 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
   // (measured, R-MAT: cutting helps the per-edge patterns on symmetric graphs -- diamond 128 -> 125 ms, 21.7 -> 19.5 ms on an
   // 1/8 share; the bounded intersections of 3-motif make the estimate too pessimistic there and cutting costs 4 %)
   const unsigned long long part_cap = (la->tune[6] & 0x1000) ? 4096ull : (pat == PAT_MOTIF3 ? ~0ull : kPartCostCap);
-  int rc = get_table(g, target, !clique, clique ? kBitWords : 0, part_cap, &tab);
+  int rc = get_table(g, target, !clique, clique ? kBitWords : 0, part_cap, stage_cap_of(pat), &tab);
   if (rc) return rc;
 
   MineParams p;

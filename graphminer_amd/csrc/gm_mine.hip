@@ -44,11 +44,11 @@ struct alignas(16) WaveLds {
 // per-workgroup state of the current task chunk, shared by the 4 waves
 template <int PAT>
 struct alignas(16) BlockLds {
-  int stage[kStageCap];         // staged adjacency slice col[e_begin .. e_end)
+  int stage[stage_cap_of(PAT)];  // staged adjacency slice col[e_begin .. e_end)
   int rpl[kMaxChunkVerts + 8];  // row offsets of the chunk's vertices (absolute)
   unsigned bits[GM_IS_CLIQUE(PAT) ? kBitWords : 4];
   unsigned fbits[kFilterWords];        // hashed membership filter over (row, neighbour) pairs of the staged slice
-  unsigned char lrow[kStageCap];       // local row of every staged entry
+  unsigned char lrow[stage_cap_of(PAT)];  // local row of every staged entry
   int next_batch;               // dynamic batch counter of the chunk
   unsigned queue_pos;           // broadcast slot of the chunk dequeue
   WaveLds w[kWavesPerBlock];
@@ -607,7 +607,7 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
   const bool whole_rows = (eb == B.rpl[0]) && (r.e_end == B.rpl[nvl]);
   if ((p.flags & 128) && !whole_rows) { __syncthreads(); return; }  // ablation: skip SPLIT chunks (counts wrong)
   if ((p.flags & 256) && whole_rows) { __syncthreads(); return; }   // ablation: only SPLIT chunks
-  const bool staged = whole_rows && (nel <= kStageCap) && !(p.flags & 1);
+  const bool staged = whole_rows && (nel <= stage_cap_of(PAT)) && !(p.flags & 1);
   const bool use_filter = staged && !(p.flags & 8);
   if (staged) {
     if (use_filter)
@@ -1246,6 +1246,9 @@ size_t mine_lds_bytes(Pattern pat) {
   switch (pat) {
     case PAT_CLIQUE4:
     case PAT_CLIQUEK: return sizeof(BlockLds<PAT_CLIQUE4>);
+    case PAT_DIAMOND:
+    case PAT_MOTIF3:
+    case PAT_MOTIF4E: return sizeof(BlockLds<PAT_DIAMOND>);
     default: return sizeof(BlockLds<PAT_TC>);
   }
 }
