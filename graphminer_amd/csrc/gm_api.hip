@@ -83,7 +83,8 @@ extern "C" int gm_device_count(int *n) {
 #endif
 constexpr int kBitmapMinDeg = GM_BITMAP_MIN_DEG;
 constexpr unsigned long long kBitmapBudget = (unsigned long long)GM_BITMAP_BUDGET_MB << 20;
-constexpr unsigned long long kPartCostCap = 8ull << 20;  // R-MAT-22 diamond: hub-row chunks reach 10^8; staged chunks stay whole
+constexpr unsigned long long kPartCostCap = 8ull << 20;     // DAG patterns: staged chunks stay whole
+constexpr unsigned long long kPartCostCapSym = 1ull << 20;  // symmetric-graph patterns (measured on R-MAT-20/22/24: 1 M best for diamond, 2 M for 3-motif)
 constexpr int kDefaultChunk = 1024;  // task edges per chunk when the caller does not say
 
 struct ChunkTable {
@@ -92,6 +93,7 @@ struct ChunkTable {
   int bit_words;    // clique: LDS bit-matrix budget the chunks were built for (0 = unconstrained)
   unsigned long long part_cap = 0;  // estimated work above which a chunk is cut into parts
   int stage_cap = 0;                // rows longer than this are SPLIT rows
+  std::vector<unsigned long long> cost;  // estimated work per chunk (after cutting)
   ChunkRec *d = nullptr;
   size_t n = 0;
   int *d_slot = nullptr;                 // per chunk: hub bitmap slot or -1
@@ -476,21 +478,44 @@ __global__ __launch_bounds__(256) void bitmap_build_kernel(const int *__restrict
   }
 }
 
-// one workgroup per chunk: estimated work = sum over its task edges (u, v) of d(u) + d(v)
+// one workgroup per chunk: estimated work = keys touched. DAG patterns: sum over the task edges (u, v) of d(u) + d(v);
+// symmetric-graph patterns (owner_rule): only the edges whose longer row is u are tasks here, and each streams the
+// shorter list, d(v) keys (process_chunk's ownership rule).
 __global__ __launch_bounds__(256) void chunk_cost_kernel(const int *__restrict__ rp, const int *__restrict__ col,
-                                                         const ChunkRec *__restrict__ chunks, unsigned long long *__restrict__ cost) {
+                                                         const ChunkRec *__restrict__ chunks, unsigned long long *__restrict__ cost,
+                                                         int owner_rule, int stage_cap) {
   const ChunkRec r = chunks[blockIdx.x];
   unsigned long long c = 0;
-  for (int e = r.e_begin + (int)threadIdx.x; e < r.e_end; e += 256) {
-    const int v = col[e];
-    c += (unsigned long long)(rp[v + 1] - rp[v]);
-  }
-  for (int u = r.u_begin + (int)threadIdx.x; u < r.u_end; u += 256) {
-    const int lo = max(rp[u], r.e_begin), hi = min(rp[u + 1], r.e_end);
-    c += (unsigned long long)max(hi - lo, 0) * (unsigned long long)(rp[u + 1] - rp[u]);
+  if (owner_rule) {
+    // a key streamed by a SPLIT chunk is a random probe of the hub row's bitmap in HBM, a key of a staged chunk an LDS filter probe
+    const unsigned long long w = (r.u_end == r.u_begin + 1 && (r.e_begin != rp[r.u_begin] || r.e_end != rp[r.u_end])) ? (unsigned long long)kProbeCost : 1ull;
+    for (int u = r.u_begin; u < r.u_end; ++u) {  // (a SPLIT chunk has one row; a staged chunk few long or many short ones)
+      const int a = rp[u + 1] - rp[u];
+      const int lo = max(rp[u], r.e_begin), hi = min(rp[u + 1], r.e_end);
+      for (int e = lo + (int)threadIdx.x; e < hi; e += 256) {
+        const int v = col[e];
+        const int b = rp[v + 1] - rp[v];
+        if (sym_hosts(a, b, u, v, stage_cap)) c += ((unsigned long long)b + 8ull) * w;  // (X streams N(v) whichever is longer)
+      }
+    }
+  } else {
+    for (int e = r.e_begin + (int)threadIdx.x; e < r.e_end; e += 256) {
+      const int v = col[e];
+      c += (unsigned long long)(rp[v + 1] - rp[v]);
+    }
+    for (int u = r.u_begin + (int)threadIdx.x; u < r.u_end; u += 256) {
+      const int lo = max(rp[u], r.e_begin), hi = min(rp[u + 1], r.e_end);
+      c += (unsigned long long)max(hi - lo, 0) * (unsigned long long)(rp[u + 1] - rp[u]);
+    }
   }
   c = gm::wave_sum_u64(c);
   if ((threadIdx.x & 63) == 0 && c) atomicAdd(&cost[blockIdx.x], c);
+}
+
+// edges per batch of a chunk (process_chunk: kSplitBatch in the SPLIT chunks of the symmetric-graph patterns)
+static int batch_edges(const ChunkRec &r, const std::vector<int> &rp, int stage_cap) {
+  const bool whole = r.e_begin == rp[(size_t)r.u_begin] && r.e_end == rp[(size_t)r.u_end];
+  return (stage_cap == kStageCapWide && !whole) ? kSplitBatch : GM_WAVE;
 }
 
 static int get_table(gm_graph *g, int target, bool allow_split, int bit_words, unsigned long long part_cap, int stage_cap,
@@ -516,7 +541,8 @@ static int get_table(gm_graph *g, int target, bool allow_split, int bit_words, u
     if (e == hipSuccess) e = hipMemcpy(d_tmp, recs.data(), sizeof(ChunkRec) * recs.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(d_cost, 0, sizeof(unsigned long long) * recs.size());
     if (e == hipSuccess) {
-      hipLaunchKernelGGL(chunk_cost_kernel, dim3((unsigned)recs.size()), dim3(256), 0, 0, g->d_rp, g->d_col, d_tmp, d_cost);
+      hipLaunchKernelGGL(chunk_cost_kernel, dim3((unsigned)recs.size()), dim3(256), 0, 0, g->d_rp, g->d_col, d_tmp, d_cost,
+                         stage_cap == kStageCapWide ? 1 : 0, stage_cap);
       e = hipMemcpy(cost.data(), d_cost, sizeof(unsigned long long) * recs.size(), hipMemcpyDeviceToHost);
     }
     if (d_tmp) (void)hipFree(d_tmp);
@@ -530,7 +556,8 @@ static int get_table(gm_graph *g, int target, bool allow_split, int bit_words, u
     cut.reserve(recs.size());
     cut_cost.reserve(recs.size());
     for (size_t i = 0; i < recs.size(); ++i) {
-      const int batches = (recs[i].e_end - recs[i].e_begin + GM_WAVE - 1) / GM_WAVE;
+      const int bsz = batch_edges(recs[i], g->h_rp, stage_cap);
+      const int batches = (recs[i].e_end - recs[i].e_begin + bsz - 1) / bsz;
       const int np = (int)std::max<unsigned long long>(1, std::min<unsigned long long>((unsigned long long)batches, (cost[i] + cap - 1) / cap));
       for (int q = 0; q < np; ++q) {
         ChunkRec r = recs[i];
@@ -543,6 +570,7 @@ static int get_table(gm_graph *g, int target, bool allow_split, int bit_words, u
     recs.swap(cut);
     cost.swap(cut_cost);
   }
+  t.cost = cost;
   t.n = recs.size();
   t.first_vertex.resize(t.n);
   for (size_t i = 0; i < t.n; ++i) t.first_vertex[i] = recs[i].u_begin;
@@ -551,7 +579,8 @@ static int get_table(gm_graph *g, int target, bool allow_split, int bit_words, u
   for (size_t i = 0; i < t.n; ++i) {  // task edges of a part = the entries of its batches
     const int nel = recs[i].e_end - recs[i].e_begin, np = recs[i].nparts;
     unsigned long long mine = 0;
-    for (int b = recs[i].part; b * GM_WAVE < nel; b += np) mine += (unsigned long long)std::min(GM_WAVE, nel - b * GM_WAVE);
+    const int bsz = batch_edges(recs[i], g->h_rp, stage_cap);
+    for (int b = recs[i].part; b * bsz < nel; b += np) mine += (unsigned long long)std::min(bsz, nel - b * bsz);
     t.edge_prefix[i + 1] = t.edge_prefix[i] + mine;
   }
   HIP_TRY(hipMalloc(&t.d, sizeof(ChunkRec) * std::max<size_t>(t.n, 1)));
@@ -786,9 +815,9 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
   const bool clique = pat == PAT_CLIQUE4 || pat == PAT_CLIQUEK;
   ChunkTable *tab = nullptr;
   // tune[6] & 0x1000 (tests): cut every chunk above 4096 estimated entries into parts
-  // (measured, R-MAT: cutting helps the per-edge patterns on symmetric graphs -- diamond 128 -> 125 ms, 21.7 -> 19.5 ms on an
-  // 1/8 share; the bounded intersections of 3-motif make the estimate too pessimistic there and cutting costs 4 %)
-  const unsigned long long part_cap = (la->tune[6] & 0x1000) ? 4096ull : (pat == PAT_MOTIF3 ? ~0ull : kPartCostCap);
+  // chunk costs are estimated keys (DAG patterns: d(u) + d(v) per edge; symmetric patterns: streamed keys, bitmap probes
+  // weighted kProbeCost); parts bound the longest task of a launch
+  const unsigned long long part_cap = (la->tune[6] & 0x1000) ? 4096ull : (stage_cap_of(pat) == kStageCapWide ? kPartCostCapSym : kPartCostCap);
   int rc = get_table(g, target, !clique, clique ? kBitWords : 0, part_cap, stage_cap_of(pat), &tab);
   if (rc) return rc;
 
@@ -870,9 +899,52 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
     p.scratch_words = tab->max_bit_words;
   }
 
+#ifdef GM_DEBUG_CHUNKS
+  unsigned long long *d_ticks = nullptr;
+  HIP_TRY(hipMalloc(&d_ticks, sizeof(unsigned long long) * std::max<size_t>(tab->n, 1)));
+  HIP_TRY(hipMemset(d_ticks, 0, sizeof(unsigned long long) * std::max<size_t>(tab->n, 1)));
+  p.chunk_ticks = d_ticks;
+#endif
   rc = start_timer(ctx);
   if (rc) return rc;
   if (p.count > 0) HIP_TRY(launch_mine(pat, p, grid, stream));
+#ifdef GM_DEBUG_CHUNKS
+  {
+    HIP_TRY(hipStreamSynchronize(stream));
+    std::vector<unsigned long long> ticks(tab->n);
+    HIP_TRY(hipMemcpy(ticks.data(), d_ticks, sizeof(unsigned long long) * tab->n, hipMemcpyDeviceToHost));
+    (void)hipFree(d_ticks);
+    std::vector<ChunkRec> recs(tab->n);
+    HIP_TRY(hipMemcpy(recs.data(), tab->d, sizeof(ChunkRec) * tab->n, hipMemcpyDeviceToHost));
+    std::vector<size_t> idx(tab->n);
+    for (size_t i = 0; i < tab->n; ++i) idx[i] = i;
+    std::sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return ticks[a] > ticks[b]; });
+    unsigned long long tot = 0;
+    for (auto t : ticks) tot += t;
+    if (const char *dump = getenv("GM_CHUNK_DUMP")) {
+      FILE *f = fopen(dump, "w");
+      if (f) {
+        fprintf(f, "pos,cid,rows,entries,rowlen,whole,part,nparts,cost,us\n");
+        for (size_t pos = 0; pos < tab->n; ++pos) {
+          const size_t cid = p.order ? (size_t)(p.order == tab->d_order[0] ? tab->order[0][pos] : tab->order[1][pos]) : pos;
+          const ChunkRec &r = recs[cid];
+          const bool whole = r.e_begin == g->h_rp[r.u_begin] && r.e_end == g->h_rp[r.u_end];
+          fprintf(f, "%zu,%zu,%d,%d,%d,%d,%d,%d,%llu,%.1f\n", pos, cid, r.u_end - r.u_begin, r.e_end - r.e_begin,
+                  g->h_rp[r.u_begin + 1] - g->h_rp[r.u_begin], (int)whole, r.part, r.nparts, tab->cost[cid], ticks[pos] / 100.0);
+        }
+        fclose(f);
+      }
+    }
+    fprintf(stderr, "[chunks] n=%zu total ticks %llu (100 MHz): mean %.1f us\n", tab->n, tot, tot / 100.0 / std::max<size_t>(tab->n, 1));
+    for (size_t k = 0; k < std::min<size_t>(12, tab->n); ++k) {
+      const size_t pos = idx[k];
+      const size_t cid = p.order ? (size_t)(p.order == tab->d_order[0] ? tab->order[0][pos] : tab->order[1][pos]) : pos;
+      const ChunkRec &r = recs[cid];
+      fprintf(stderr, "[chunks] #%zu pos %zu: %.1f us  rows [%d,%d) entries [%d,%d) n=%d part %d/%d rowlen %d\n", k, pos, ticks[pos] / 100.0,
+              r.u_begin, r.u_end, r.e_begin, r.e_end, r.e_end - r.e_begin, r.part, r.nparts, g->h_rp[r.u_begin + 1] - g->h_rp[r.u_begin]);
+    }
+  }
+#endif
   fill_stats(st, (pat == PAT_DIAMOND || pat == PAT_MOTIF4E) ? my_edges / 2 : my_edges, (uint64_t)p.count, grid,
              kWavesPerBlock * GM_WAVE);
   return end_launch(ctx, fin_mode, fin_base, h_out, nout, st);

@@ -30,6 +30,10 @@ constexpr int kBitWords = 2048;           // clique: LDS words for the per-chunk
 // staging capacity is cut into SPLIT chunks (u_end == u_begin+1, [e_begin,e_end) inside the row).
 // A chunk whose estimated work is far above the mean is additionally cut into PARTS: every part stages the whole chunk but
 // takes only the 64-edge batches b with b % nparts == part, so that several workgroups share one heavy chunk.
+// Batches are 64 task edges, except in SPLIT chunks of the symmetric-graph patterns: there every edge streams a whole list
+// against a hub row and 64 hub-hub edges are milliseconds of work for one wave, so the batch is kSplitBatch edges (the
+// flattened pass still fills all 64 lanes with keys).
+constexpr int kSplitBatch = 16;
 struct ChunkRec {
   int u_begin, u_end, e_begin, e_end;
   int part, nparts;  // nparts >= 1
@@ -49,6 +53,20 @@ enum Pattern : int { PAT_TC = 0, PAT_DIAMOND = 1, PAT_MOTIF3 = 2, PAT_CLIQUE4 = 
 // Symmetric-graph patterns stage up to 4096 entries: on skewed graphs thousands of rows have 1-4 K neighbours; with a
 // 1024-entry stage they are SPLIT rows whose keys are bisected in HBM, otherwise ordinary staged chunks behind
 // the LDS filter. Measured (diamond R-MAT-22 / 3-motif R-MAT-24, ms): 1024: 94.4 / 1056, 2048: 82.5 / 1021, 4096: 77.4 / 920, 8192: 104.9 / 1111.
+// Which endpoint of an undirected edge {u, v} hosts its task in the symmetric-graph patterns (a = d(u), b = d(v)); asked
+// from u's side: true = u's row hosts. Any rule that picks exactly one endpoint gives the same counts. Normally the LONGER
+// row hosts (it is staged or bitmapped, the shorter list is streamed: min(a, b) keys). Exception: a row too long for the
+// LDS stage is probed through its HBM bitmap, ~kProbeCost times dearer per key than the LDS filter (measured: ~5.2 ns vs
+// ~1.25 ns per key and workgroup, R-MAT-22 diamond chunk timings), so against a partner that fits the stage and is less than kProbeCost times shorter the
+// SHORTER row hosts and the long list is streamed through the filter.
+constexpr int kProbeCost = 4;
+__host__ __device__ inline bool sym_hosts(int a, int b, int u, int v, int stage_cap) {
+  const bool u_longer = (a > b) || (a == b && u > v);
+  const int dl = u_longer ? a : b, ds = u_longer ? b : a;
+  const bool shorter_hosts = dl > stage_cap && ds <= stage_cap && (long long)dl < (long long)kProbeCost * ds;
+  return u_longer != shorter_hosts;
+}
+
 constexpr int stage_cap_of(int pat) { return (pat == PAT_DIAMOND || pat == PAT_MOTIF3 || pat == PAT_MOTIF4E) ? kStageCapWide : kStageCap; }
 
 struct MineParams {
@@ -56,6 +74,7 @@ struct MineParams {
   const ChunkRec *chunks;
   const int *chunk_slot;         // per chunk: bitmap slot of its hub row, or -1 (may be nullptr)
   const int *order;              // dequeue position -> chunk id (nullptr = identity)
+  unsigned long long *chunk_ticks;  // diagnostics (-DGM_DEBUG_CHUNKS builds): per dequeue position, wall_clock64 ticks spent
   const unsigned *bitmaps;       // dense vertex-id bitmaps of the longest rows, bitmap_words each
   unsigned long long bitmap_words;
   const int *row_slot;           // per vertex: its bitmap slot or -1 (nullptr when the table has no bitmaps)

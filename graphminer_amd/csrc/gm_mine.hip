@@ -671,6 +671,7 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
   // A big clique vertex is built in row groups that may hold a single batch: then all 4 waves work on EVERY batch of
   // the group, each owning the edges with (lane & 3) == wave, instead of one wave working while three idle.
   const bool split4 = GM_IS_CLIQUE(PAT) && grouped;
+  const int bsz = (stage_cap_of(PAT) == kStageCapWide && !whole_rows) ? kSplitBatch : GM_WAVE;  // edges per batch
   int my_bi = g0 / GM_WAVE;
   for (;;) {
     int bi = 0;
@@ -680,10 +681,10 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
       if (lane == 0) bi = atomicAdd(&B.next_batch, 1);
       bi = readfirst(bi) * r.nparts + r.part;  // this part's batches (nparts == 1: all of them)
     }
-    const int le0 = bi * GM_WAVE;
+    const int le0 = bi * bsz;
     if (le0 >= gend) break;
     const int le = le0 + lane;
-    const bool valid = (le < nel) && (!split4 || (lane & 3) == wave);
+    const bool valid = (le < nel) && (lane < bsz) && (!split4 || (lane & 3) == wave);
     const int e = eb + le;
     int v = 0, u = 0, ru = 0, a = 0, rv = 0, b = 0, idx = 0, lrow_of_lane = 0;
     if (valid) {
@@ -711,19 +712,25 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
     bool act = valid;
     int al = a;       // effective length of A = N(u) (a prefix of the row)
     int flag = 0;
-    if (PAT == PAT_DIAMOND || PAT == PAT_MOTIF4E) act = valid && (v < u);  // symmetry break, diamond.h:5 / automine_formula.h:27
+    // The symmetric-graph patterns need every UNDIRECTED edge once (the reference takes v1 < v0, diamond.h:5 /
+    // automine_formula.h:27 / automine_base.h:18); which endpoint's row hosts the task does not change any count, so the
+    // endpoint with the LONGER row normally does (sym_hosts, gm_mine.h): its row is the staged / bitmapped side and the
+    // SHORTER list is the one that is streamed -- and pass Y (bisection in HBM) all but disappears.
+    const bool owns = sym_hosts(a, b, u, v, stage_cap_of(PAT));
+    const int hi = max(u, v), lo = min(u, v);
+    if (PAT == PAT_DIAMOND || PAT == PAT_MOTIF4E) act = valid && owns;
     if (PAT == PAT_MOTIF3) {
-      // One bounded intersection per UNDIRECTED edge {u,v}, v < u, serves both directed edges of automine_3motif:
-      //   I(u,v) = |{w in N(u)^N(v) : w < v}|  and  I(v,u) = |{w in N(u)^N(v) : w < u}|.
-      // A' = {w in N(u) : w < u} (bounded(), VertexSet.h:240); every common w < u counts for I(v,u), and for
-      // I(u,v) and the triangle count when additionally w < v.  sum idx over ALL directed edges is kept per lane.
+      // One bounded intersection per UNDIRECTED edge {lo, hi} serves both directed edges of automine_3motif:
+      //   I(hi,lo) = |{w in N(hi)^N(lo) : w < lo}|  and  I(lo,hi) = |{w in N(hi)^N(lo) : w < hi}|.
+      // A' = {w in N(u) : w < hi} (bounded(), VertexSet.h:240); every common w < hi counts for I(lo,hi), and for
+      // I(hi,lo) and the triangle count when additionally w < lo.  sum idx over ALL directed edges is kept per lane.
       if (valid) acc.c2 += (unsigned long long)idx;  // |{w in N(v0): w < v1}| = position of v1 in its row
-      act = valid && (v < u);
+      act = valid && owns;
       if (act) {
-        if (staged) al = lower_bound(&B.stage[ru - eb], a, u);
-        else al = lower_bound(col + ru, a, u);
+        if (staged) al = lower_bound(&B.stage[ru - eb], a, hi);
+        else al = lower_bound(col + ru, a, hi);
       }
-      L.cnt[lane] = (unsigned)v;  // read back by the match handler (rare)
+      L.cnt[lane] = (unsigned)lo;  // read back by the match handler (rare)
     }
     act = act && al > 0 && b > 0;
     // direction: X streams B = N(v) and bisects A; Y takes keys from A and bisects B in HBM
@@ -780,7 +787,7 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
         flat_pass_filtered(L, B.stage, B.fbits, col, lane, llen, rv, (ru - eb) | (int)(filter_salt(lrow_of_lane) << 16),
                            s_len_flag, p.flags, actx);
       else if (staged) flat_pass<SEARCH_LDS>(L, B.stage, col, bm, lane, llen, rv, ru - eb, s_len_flag, actx);
-      else if (bm) flat_pass<SEARCH_BITMAP>(L, B.stage, col, bm, lane, llen, rv, (PAT == PAT_MOTIF3) ? u : 0x7fffffff, s_len_flag, actx);
+      else if (bm) flat_pass<SEARCH_BITMAP>(L, B.stage, col, bm, lane, llen, rv, (PAT == PAT_MOTIF3) ? hi : 0x7fffffff, s_len_flag, actx);
       else flat_pass<SEARCH_HBM>(L, B.stage, col, bm, lane, llen, rv, ru, s_len_flag, actx);
     }
     // pass Y: keys from A bisect B = N(v) in HBM -- or, when v is a hub row with a dense bitmap, probe that (one load
@@ -810,7 +817,7 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
     if (PAT == PAT_MOTIF4E) {
       // per-edge sums of the formula-based 4-motif (src/motif/cpu_kernels/automine_formula.h:30-39)
       wave_sync();
-      if (valid && v < u) {
+      if (valid && owns) {
         const unsigned long long tri = L.cnt[lane];
         const unsigned long long su = (unsigned long long)a - tri - 1ull, sv = (unsigned long long)b - tri - 1ull;
         acc.c0 += su * (su - 1ull) + sv * (sv - 1ull);  // counter[0]
@@ -877,7 +884,13 @@ __global__ __launch_bounds__(kWavesPerBlock *GM_WAVE, PAT == PAT_CLIQUEK ? 4 : (
       const size_t cid = p.order ? (size_t)p.order[pos] : pos;
       const ChunkRec r = p.chunks[cid];
       const int slot = p.chunk_slot ? p.chunk_slot[cid] : -1;
+#ifdef GM_DEBUG_CHUNKS
+      const unsigned long long t0 = wall_clock64();
+#endif
       process_chunk<PAT>(p, B, r, slot, lane, wave, acc);  // ends with a workgroup barrier
+#ifdef GM_DEBUG_CHUNKS
+      if (p.chunk_ticks && threadIdx.x == 0) p.chunk_ticks[pos] = wall_clock64() - t0;
+#endif
     }
   }
   const unsigned long long s0 = wave_sum_u64(acc.c0);
