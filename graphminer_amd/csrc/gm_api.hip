@@ -11,6 +11,8 @@
 #include "gm_mine.h"
 #include "gm_setops.h"
 
+#include <hipcub/hipcub.hpp>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -128,6 +130,7 @@ struct gm_graph {
   unsigned long long ev_launches = 0;
   int cu_count = 256;
   gm_graph *dag_cache = nullptr;          // oriented copy, built on demand by gm_motif_formula
+  gm_graph *relabel_cache[2] = {nullptr, nullptr};  // copies renumbered by degree (ascending / descending), see get_relabeled
   const gm_graph *ring_alias = nullptr;
   int *d_idx0 = nullptr;                  // rectangle: #neighbours below v, and the wedge-block prefix
   unsigned long long *d_wblock_prefix = nullptr;
@@ -158,6 +161,10 @@ extern "C" void gm_graph_free(gm_graph *g) {
   if (!g) return;
   if (g->dag_cache) gm_graph_free(g->dag_cache);
   g->dag_cache = nullptr;
+  for (auto &r : g->relabel_cache) {
+    if (r) gm_graph_free(r);
+    r = nullptr;
+  }
   (void)hipSetDevice(g->device);
   free_tables(g);
   if (g->d_rp) (void)hipFree(g->d_rp);
@@ -416,6 +423,97 @@ extern "C" int gm_graph_orient(const gm_graph *sym, gm_graph **out) {
   int rc = finish_handle(g);
   if (rc) { gm_graph_free(g); return rc; }
   *out = g;
+  return GM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Degree renumbering. A pattern count does not depend on the vertex numbering, but the work of the SgL kernels does: they
+// anchor a match at its largest vertex id and walk smaller ids. With ids ascending in degree the 2-path walks of rectangle and the
+// (v0, v1 < v0, v3) tasks of house go through low-degree vertices (R-MAT-16: 522 M -> 128 M 2-paths, 898 M -> 163 M tasks); with
+// ids descending in degree the wedges (v0; v2 < v1 < v0) of pentagon avoid the hubs (99 M -> 33 M). The copy is built once
+// per handle: counting sort of the vertices by degree on the host, one 64-bit key (new row, new neighbour) per CSR entry and
+// a device radix sort (hipCUB) -- the rows come out ascending.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void relabel_keys_kernel(int nv, long long ne, const int *__restrict__ rp, const int *__restrict__ col,
+                                                           const int *__restrict__ newid, unsigned long long *__restrict__ keys) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= ne) return;
+  int lo = 0, hi = nv - 1;  // row of entry e
+  while (lo < hi) {
+    const int mid = (int)(((long long)lo + hi + 1) >> 1);
+    if (rp[mid] <= e) lo = mid; else hi = mid - 1;
+  }
+  keys[e] = ((unsigned long long)(unsigned)newid[lo] << 32) | (unsigned long long)(unsigned)newid[col[e]];
+}
+
+__global__ __launch_bounds__(256) void relabel_cols_kernel(long long ne, const unsigned long long *__restrict__ keys, int *__restrict__ col) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < ne) col[e] = (int)(unsigned)(keys[e] & 0xffffffffull);
+}
+
+static int get_relabeled(gm_graph *g, int descending, gm_graph **out) {
+  {
+    std::lock_guard<std::mutex> lk(g->mu);
+    if (g->relabel_cache[descending]) { *out = g->relabel_cache[descending]; return GM_OK; }
+  }
+  HIP_TRY(hipSetDevice(g->device));
+  const int nv = g->nv;
+  const long long ne = g->ne;
+  // counting sort by degree (ties: ascending id)
+  std::vector<int> newid((size_t)std::max(nv, 1));
+  {
+    std::vector<long long> bucket((size_t)g->max_deg + 2, 0);
+    for (int v = 0; v < nv; ++v) bucket[(size_t)(g->h_rp[v + 1] - g->h_rp[v]) + 1]++;
+    for (size_t d = 1; d < bucket.size(); ++d) bucket[d] += bucket[d - 1];
+    for (int v = 0; v < nv; ++v) {
+      const long long pos = bucket[(size_t)(g->h_rp[v + 1] - g->h_rp[v])]++;
+      newid[(size_t)v] = descending ? (int)((long long)nv - 1 - pos) : (int)pos;
+    }
+  }
+  gm_graph *r = new gm_graph();
+  r->device = g->device;
+  r->nv = nv;
+  r->ne = ne;
+  r->h_rp.assign((size_t)nv + 1, 0);
+  for (int v = 0; v < nv; ++v) r->h_rp[(size_t)newid[(size_t)v] + 1] = g->h_rp[v + 1] - g->h_rp[v];
+  for (int v = 0; v < nv; ++v) r->h_rp[(size_t)v + 1] += r->h_rp[(size_t)v];
+  int *d_newid = nullptr;
+  unsigned long long *d_keys = nullptr, *d_sorted = nullptr;
+  void *d_tmp = nullptr;
+  auto cleanup = [&]() {
+    if (d_newid) (void)hipFree(d_newid);
+    if (d_keys) (void)hipFree(d_keys);
+    if (d_sorted) (void)hipFree(d_sorted);
+    if (d_tmp) (void)hipFree(d_tmp);
+  };
+  auto fail = [&](hipError_t e, const char *what) { cleanup(); gm_graph_free(r); return hip_fail(e, what, __FILE__, __LINE__); };
+  hipError_t e;
+  const size_t n1 = (size_t)std::max<long long>(ne, 1);
+  if ((e = hipMalloc(&d_newid, sizeof(int) * (size_t)std::max(nv, 1))) != hipSuccess) return fail(e, "hipMalloc(newid)");
+  if ((e = hipMemcpy(d_newid, newid.data(), sizeof(int) * (size_t)nv, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(newid)");
+  if ((e = hipMalloc(&d_keys, sizeof(unsigned long long) * n1)) != hipSuccess) return fail(e, "hipMalloc(keys)");
+  if ((e = hipMalloc(&d_sorted, sizeof(unsigned long long) * n1)) != hipSuccess) return fail(e, "hipMalloc(sorted)");
+  if ((e = hipMalloc(&r->d_rp, sizeof(int) * ((size_t)nv + 1))) != hipSuccess) return fail(e, "hipMalloc(rp)");
+  if ((e = hipMalloc(&r->d_col, sizeof(int) * n1)) != hipSuccess) return fail(e, "hipMalloc(col)");
+  if ((e = hipMemcpy(r->d_rp, r->h_rp.data(), sizeof(int) * ((size_t)nv + 1), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(rp)");
+  if (ne > 0) {
+    const unsigned blocks = (unsigned)((ne + 255) / 256);
+    hipLaunchKernelGGL(relabel_keys_kernel, dim3(blocks), dim3(256), 0, 0, nv, ne, g->d_rp, g->d_col, d_newid, d_keys);
+    int bits = 1;
+    while (bits < 32 && (1ll << bits) < (long long)nv) ++bits;
+    size_t tmp_bytes = 0;
+    if ((e = hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, d_keys, d_sorted, (int)ne, 0, 32 + bits)) != hipSuccess) return fail(e, "SortKeys(size)");
+    if ((e = hipMalloc(&d_tmp, std::max<size_t>(tmp_bytes, 16))) != hipSuccess) return fail(e, "hipMalloc(sort temp)");
+    if ((e = hipcub::DeviceRadixSort::SortKeys(d_tmp, tmp_bytes, d_keys, d_sorted, (int)ne, 0, 32 + bits)) != hipSuccess) return fail(e, "SortKeys");
+    hipLaunchKernelGGL(relabel_cols_kernel, dim3(blocks), dim3(256), 0, 0, ne, d_sorted, r->d_col);
+    if ((e = hipDeviceSynchronize()) != hipSuccess) return fail(e, "relabel kernels");
+  }
+  cleanup();
+  int rc = finish_handle(r);
+  if (rc) { gm_graph_free(r); return rc; }
+  std::lock_guard<std::mutex> lk(g->mu);
+  g->relabel_cache[descending] = r;
+  *out = r;
   return GM_OK;
 }
 
@@ -1205,15 +1303,31 @@ static int run_sgl_nested(int pat, const gm_graph *cg, const gm_launch *la_in, u
 extern "C" int gm_sgl(const gm_graph *sym, const char *pattern, const gm_launch *la, uint64_t *total, gm_stats *st) {
   if (!pattern) return GM_ERR_INVALID;
   if (strcmp(pattern, "diamond") == 0) return run_pattern(PAT_DIAMOND, sym, la, 4, total, 1, st);
-  if (strcmp(pattern, "rectangle") == 0) {  // tune[6] & 1024: wave-per-edge loop nest; & 2048: wedges + flat intersections (A/B, tests)
-    if (la && (la->tune[6] & 1024)) return run_sgl_nested(SGL_RECTANGLE, sym, la, total, st);
-    if (la && (la->tune[6] & 2048)) return run_rect_flat(sym, la, total, st);
-    return run_rect_acc(sym, la, total, st);
+  // rectangle / house / pentagon run on a copy of the graph renumbered by degree (get_relabeled; tune[6] & 512: on the
+  // graph as given). tune[6] & 1024: the wave-per-edge loop nests; & 2048: rectangle as wedges + flat intersections,
+  // house without the LDS S-bitmap (A/B, tests).
+  const bool is_rect = strcmp(pattern, "rectangle") == 0, is_house = strcmp(pattern, "house") == 0, is_pent = strcmp(pattern, "pentagon") == 0;
+  if (is_rect || is_house || is_pent) {
+    if (!sym) return GM_ERR_INVALID;
+    const int t6 = la ? la->tune[6] : 0;
+    gm_graph *self = const_cast<gm_graph *>(sym);
+    const gm_graph *run_on = sym;
+    const bool wedge_form = is_pent || (is_rect && (t6 & 2048));  // anchored wedges: hubs first; 2-path / (v0,v1,v3) forms: hubs last
+    if (!(t6 & 512) && !(t6 & 1024)) {
+      gm_graph *r = nullptr;
+      int rc = get_relabeled(self, wedge_form ? 1 : 0, &r);
+      if (rc) return rc;
+      run_on = r;
+    }
+    int rc;
+    if (t6 & 1024) rc = run_sgl_nested(is_rect ? SGL_RECTANGLE : is_house ? SGL_HOUSE : SGL_PENTAGON, run_on, la, total, st);
+    else if (is_house) rc = run_house_flat(run_on, la, total, st);
+    else if (is_pent) rc = run_rect_flat(run_on, la, total, st, true);
+    else if (t6 & 2048) rc = run_rect_flat(run_on, la, total, st);
+    else rc = run_rect_acc(run_on, la, total, st);
+    self->ring_alias = (run_on != sym) ? const_cast<gm_graph *>(run_on) : nullptr;
+    return rc;
   }
-  if (strcmp(pattern, "house") == 0)
-    return (la && (la->tune[6] & 1024)) ? run_sgl_nested(SGL_HOUSE, sym, la, total, st) : run_house_flat(sym, la, total, st);
-  if (strcmp(pattern, "pentagon") == 0)
-    return (la && (la->tune[6] & 1024)) ? run_sgl_nested(SGL_PENTAGON, sym, la, total, st) : run_rect_flat(sym, la, total, st, true);
   if (total) *total = 0;  // "Not implemented", total_num = 0 (src/sgl/omp_base.cc:51-53)
   return GM_ERR_UNSUPPORTED;
 }
@@ -1253,7 +1367,16 @@ extern "C" int gm_motif4_partial(const gm_graph *sym, const gm_launch *la, uint6
   memset(&s1, 0, sizeof s1); memset(&s2, 0, sizeof s2); memset(&s3, 0, sizeof s3);
   int rc = run_pattern(PAT_MOTIF4E, sym, &l2, 4, raw, 4, &s1, FIN_RAW4, 0);
   if (rc) return rc;
-  rc = (l2.tune[6] & 2048) ? run_rect_flat(sym, &l2, &raw[4], &s2) : run_rect_acc(sym, &l2, &raw[4], &s2);
+  {
+    const gm_graph *rect_on = sym;
+    if (!(l2.tune[6] & 512)) {
+      gm_graph *r = nullptr;
+      rc = get_relabeled(g, (l2.tune[6] & 2048) ? 1 : 0, &r);
+      if (rc) return rc;
+      rect_on = r;
+    }
+    rc = (l2.tune[6] & 2048) ? run_rect_flat(rect_on, &l2, &raw[4], &s2) : run_rect_acc(rect_on, &l2, &raw[4], &s2);
+  }
   if (rc) return rc;
   rc = run_pattern(PAT_CLIQUE4, g->dag_cache, &l2, 4, &raw[5], 1, &s3);
   if (rc) return rc;

@@ -114,6 +114,7 @@ def test_sgl_nested_patterns_match_reference(gg, pattern):
     assert total == e[pattern]
     assert sum(SglSolver(sym, pattern, rank=r, world=3, chunk=32) for r in range(3)) == e[pattern]
     assert sum(SglSolver(sym, pattern, rank=r, world=2, policy=1) for r in range(2)) == e[pattern]
+    assert SglSolver(sym, pattern, tune=[0, 0, 0, 0, 0, 0, 512]) == e[pattern]  # on the graph as numbered (no degree renumbering)
     if pattern == "rectangle":  # the other two implementations: wedges + flattened intersections; one wave per edge
         assert SglSolver(sym, pattern, tune=[0, 0, 0, 0, 0, 0, 2048]) == e[pattern]
         assert SglSolver(sym, pattern, tune=[0, 0, 0, 0, 0, 0, 1024]) == e[pattern]
