@@ -94,10 +94,18 @@ typedef struct gm_launch {
                          (src/triangle/main.cc:16) */
   uint64_t *d_counts; /* optional DEVICE buffer (>= ncounts uint64). When set the result is left on the
                          device, no host sync is done (use it to feed an RCCL all-reduce). */
-  int32_t tune[8];    /* kernel tuning / ablation knobs, all 0 = defaults: [0] task edges per chunk, [1] chunks per
-                         dequeue, [2] xs+1 and [3] ys+1 of the direction rule b*(xb+xs*lg a) <= a*(yb+ys*lg b),
-                         [4] workgroups per CU, [5] 1 = never stage adjacency in LDS, [6] ablation / test bit mask
-                         (gm_api.hip; 0x1000 cut chunks into parts eagerly, 0x4000 plain chunk-id dequeue order), [7] xb*16+yb. Results never depend on them (tests/test_gpu_parity.py). */
+  int32_t tune[8];    /* kernel tuning / ablation knobs, all 0 = defaults. Counts never depend on them
+                         (tests/test_gpu_parity.py) unless a bit is marked "ablation" (work is skipped, counts wrong).
+                         [0] task edges per chunk, [1] chunks per dequeue, [2] xs+1 and [3] ys+1 of the direction rule
+                         b*(xb+xs*lg a) <= a*(yb+ys*lg b), [4] workgroups per CU, [5] 1 = never stage adjacency in LDS,
+                         [7] bits 0..7 xb*16+yb, bits 8.. price of a pass-Y key against a bitmapped row (0 = as a bisection).
+                         [6] bit mask. Alternative implementations (same counts): 0x100 mining kernels ignore the hub bitmaps,
+                         0x200 SgL on the graph as numbered (no degree renumbering), 0x400 SgL wave-per-edge loop nests,
+                         0x800 rectangle as wedges + flat intersections / house without the LDS S-bitmap, 0x1000 cut
+                         chunks into parts eagerly, 0x2000 swap the two dequeue orders, 0x4000 plain chunk-id order.
+                         Ablation (mining kernels): 0x1 skip clique phase 2, 0x2 skip bit-matrix writes, 0x4 no filter,
+                         0x8 / 0x10 / 0x20 filtered-pass stages, 0x40 skip SPLIT chunks, 0x80 only SPLIT chunks,
+                         0x400 skip pass X, 0x8000 skip pass Y (gm_api.hip / gm_mine.hip). */
 } gm_launch;
 
 typedef struct gm_stats {
