@@ -693,9 +693,13 @@ static int get_table(gm_graph *g, int target, bool allow_split, int bit_words, u
       std::vector<int> &o = t.order[m];
       o.resize(t.n);
       for (size_t i = 0; i < t.n; ++i) o[i] = (int)i;
+      // order 0 of the symmetric-graph tables keeps chunk-id order INSIDE the heavy class as well: the heavy chunks are the
+      // SPLIT chunks of the hub rows, and consecutive chunks of one row probe the same bitmap -- run together they keep it
+      // in L2 (R-MAT-22 diamond: by cost 47.8 ms, by id 39.5 ms)
+      const bool classes_only = (m == 0) && (stage_cap == kStageCapWide);
       std::stable_sort(o.begin(), o.end(), [&](int a, int b) {
         unsigned long long ca = cost[(size_t)a], cb = cost[(size_t)b];
-        if (m == 0) { ca = ca >= heavy ? ca : 0ull; cb = cb >= heavy ? cb : 0ull; }
+        if (m == 0) { ca = ca >= heavy ? (classes_only ? 1ull : ca) : 0ull; cb = cb >= heavy ? (classes_only ? 1ull : cb) : 0ull; }
         return ca > cb;
       });
       HIP_TRY(hipMalloc(&t.d_order[m], sizeof(int) * t.n));
@@ -955,7 +959,8 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
     // dequeue order (tune[6] & 0x4000: plain chunk-id order; & 0x2000: swap the two orders -- ablation only)
     // measured on R-MAT (one rank): k >= 5 cliques want the full order (796 -> 589 ms), 4-clique none (its big vertices
     // contend for the scratch arena when they all start together: 270 vs 278 ms), the rest the heavy-first order
-    const int which = ((world > 1 || pat == PAT_CLIQUEK) ? 1 : 0) ^ ((la->tune[6] & 0x2000) ? 1 : 0);
+    const bool sym_pat = stage_cap_of(pat) == kStageCapWide;  // these keep the locality-preserving order at every world size
+    const int which = (((world > 1 && !sym_pat) || pat == PAT_CLIQUEK) ? 1 : 0) ^ ((la->tune[6] & 0x2000) ? 1 : 0);
     const bool lpt = la->policy == GM_PART_ROUND_ROBIN && tab->d_order[which] && !(la->tune[6] & 0x4000) &&
                      !(pat == PAT_CLIQUE4 && world == 1 && !(la->tune[6] & 0x2000));
     p.order = lpt ? tab->d_order[which] : nullptr;
