@@ -55,11 +55,16 @@ enum Pattern : int { PAT_TC = 0, PAT_DIAMOND = 1, PAT_MOTIF3 = 2, PAT_CLIQUE4 = 
 // the LDS filter. Measured (diamond R-MAT-22 / 3-motif R-MAT-24, ms): 1024: 94.4 / 1056, 2048: 82.5 / 1021, 4096: 77.4 / 920, 8192: 104.9 / 1111.
 // Which endpoint of an undirected edge {u, v} hosts its task in the symmetric-graph patterns (a = d(u), b = d(v)); asked
 // from u's side: true = u's row hosts. Any rule that picks exactly one endpoint gives the same counts. Normally the LONGER
-// row hosts (it is staged or bitmapped, the shorter list is streamed: min(a, b) keys). Exception: a row too long for the
-// LDS stage is probed through its HBM bitmap, ~kProbeCost times dearer per key than the LDS filter (measured: ~5.2 ns vs
-// ~1.25 ns per key and workgroup, R-MAT-22 diamond chunk timings), so against a partner that fits the stage and is less than kProbeCost times shorter the
-// SHORTER row hosts and the long list is streamed through the filter.
-constexpr int kProbeCost = 4;
+// row hosts (it is staged or bitmapped, the shorter list is streamed: min(a, b) keys). kProbeCost > 1 adds an exception for
+// hosts too long for the LDS stage, whose keys are verified against a bitmap in HBM: against a partner that fits the stage and
+// is less than kProbeCost times shorter, the SHORTER row hosts and streams the long list through its filter. It was needed
+// (4) while every streamed key of a SPLIT chunk was an HBM probe (5.2 ns vs 1.25 ns per key and workgroup); since SPLIT chunks
+// pre-filter in LDS the two paths cost the same and 1 (no exception) measures best: diamond R-MAT-22 27.9 / 28.6 / 31.8 / 36.4 ms
+// for 1 / 2 / 3 / 4.
+#ifndef GM_PROBE_COST
+#define GM_PROBE_COST 1
+#endif
+constexpr int kProbeCost = GM_PROBE_COST;
 __host__ __device__ inline bool sym_hosts(int a, int b, int u, int v, int stage_cap) {
   const bool u_longer = (a > b) || (a == b && u > v);
   const int dl = u_longer ? a : b, ds = u_longer ? b : a;

@@ -61,10 +61,15 @@ struct Acc {
 __device__ __forceinline__ int bitlen(int x) { return 32 - __clz(x); }
 
 // Filter hash of (neighbour id, row salt) -> bit index. 24-bit multiplicative hash (v_mul_u32_u24 is full rate).
+template <int FL2 = kFilterLog2>
 __device__ __forceinline__ unsigned filter_hash(int x, unsigned salt) {
   const unsigned xl = ((unsigned)x ^ ((unsigned)x >> 24)) & 0xffffffu;
-  return ((__umul24(xl, 0x9E3779u) >> (32 - kFilterLog2)) ^ salt) & (unsigned)(kFilterBits - 1);
+  return ((__umul24(xl, 0x9E3779u) >> (32 - FL2)) ^ salt) & (unsigned)((1u << FL2) - 1u);
 }
+// SPLIT chunks of the symmetric-graph patterns: the 16 KB stage is idle (the row does not fit), so it holds a 2^17-bit
+// hashed filter of the WHOLE hub row; only the keys that pass it are verified against the row's dense bitmap in HBM.
+constexpr int kSplitFilterLog2 = 17;
+constexpr int kSplitFilterMaxRow = 1 << 16;  // longer rows: the filter would pass > 40 % -- probe the bitmap directly
 __device__ __forceinline__ unsigned filter_salt(int local_row) { return ((unsigned)local_row * 0x2545u) & (unsigned)(kFilterBits - 1); }
 
 // One flattened pass over the 64 edges of a batch.
@@ -191,9 +196,12 @@ __device__ __forceinline__ void flat_pass(WaveLds &L, const int *__restrict__ st
 // Exact bisection of up to kTiles*64 queued candidates (key, edge) against the LDS-staged rows.
 // Queue slots >= own_from belong to edge cur_owner (the long list being streamed: its owner is wave-uniform and is
 // not written per candidate); slots below carry their owner in L.qown.
-template <class Act>
+// BM: the candidates are verified with one probe of the dense bitmap `bm` of the (single) searched row instead of a
+// bisection of the LDS stage (SPLIT chunks; positions are not reported, act gets pos = 0).
+template <bool BM, class Act>
 __device__ __forceinline__ void drain_candidates(WaveLds &L, const int *__restrict__ stage, const int lane, const int n,
-                                                 const int steps, const int own_from, const int cur_owner, Act act) {
+                                                 const int steps, const int own_from, const int cur_owner, Act act,
+                                                 const unsigned *__restrict__ bm = nullptr) {
   int own[kTiles], key[kTiles], sb[kTiles], sl[kTiles], fl[kTiles], lo[kTiles];
   bool in[kTiles];
 #pragma unroll
@@ -204,6 +212,17 @@ __device__ __forceinline__ void drain_candidates(WaveLds &L, const int *__restri
     own[q] = (int)L.qown[slot];
     own[q] = (slot >= own_from) ? cur_owner : own[q];
     own[q] = in[q] ? own[q] : 0;
+  }
+  if constexpr (BM) {
+    unsigned wv[kTiles];
+#pragma unroll
+    for (int q = 0; q < kTiles; ++q) wv[q] = bm[(unsigned)(in[q] ? key[q] : 0) >> 5];  // unconditional loads
+#pragma unroll
+    for (int q = 0; q < kTiles; ++q) {
+      const bool f = in[q] & (((wv[q] >> ((unsigned)key[q] & 31u)) & 1u) != 0u);
+      act(f, own[q], 0, 0, L.desc[own[q]].w >> 30, key[q]);
+    }
+    return;
   }
 #pragma unroll
   for (int q = 0; q < kTiles; ++q) {
@@ -250,10 +269,11 @@ __device__ __forceinline__ void drain_candidates(WaveLds &L, const int *__restri
 #endif
 constexpr int kLongList = GM_LONG_LIST;
 
-template <class Act>
+template <int FL2 = kFilterLog2, bool BM = false, class Act>
 __device__ __forceinline__ void flat_pass_filtered(WaveLds &L, const int *__restrict__ stage, const unsigned *__restrict__ fbits,
                                                    const int *__restrict__ col, const int lane, const int llen_all,
-                                                   const int key_base, const int s_base_salt, const int s_len_flag, const int dbg, Act act) {
+                                                   const int key_base, const int s_base_salt, const int s_len_flag, const int dbg, Act act,
+                                                   const unsigned *__restrict__ bm = nullptr) {
   if (wave_max_nonneg(llen_all) == 0) return;  // wave-uniform
   const int steps = bitlen(wave_max_nonneg(llen_all > 0 ? (s_len_flag & 0x3fffffff) : 0));
   const bool is_long = llen_all >= kLongList;
@@ -283,7 +303,7 @@ __device__ __forceinline__ void flat_pass_filtered(WaveLds &L, const int *__rest
     if (qcount >= GM_WAVE) {  // wave-uniform
       wave_sync();
       const int n = qcount & ~(GM_WAVE - 1);
-      if (!(dbg & 16)) drain_candidates(L, stage, lane, n, steps, own_from, cur_owner, act);
+      if (!(dbg & 16)) drain_candidates<BM>(L, stage, lane, n, steps, own_from, cur_owner, act, bm);
       const int rest = qcount - n;  // < 64: move to the front, owners written out
       int k = 0;
       unsigned char o = 0;
@@ -319,7 +339,7 @@ __device__ __forceinline__ void flat_pass_filtered(WaveLds &L, const int *__rest
       unsigned h[kTiles], fw[kTiles];
 #pragma unroll
       for (int q = 0; q < kTiles; ++q) {
-        h[q] = filter_hash(key[q], salt);
+        h[q] = filter_hash<FL2>(key[q], salt);
         fw[q] = fbits[h[q] >> 5];
       }
 #pragma unroll
@@ -392,7 +412,7 @@ __device__ __forceinline__ void flat_pass_filtered(WaveLds &L, const int *__rest
         in[q] = p < total;
         const int4 d = L.desc[in[q] ? own[q] - 1 : 0];
         key[q] = col[in[q] ? d.x + (p - d.y) : 0];  // unconditional load (select on the index)
-        h[q] = filter_hash(key[q], (unsigned)d.z >> 16);
+        h[q] = filter_hash<FL2>(key[q], (unsigned)d.z >> 16);
       }
 #pragma unroll
       for (int q = 0; q < kTiles; ++q) fw[q] = (dbg & 32) ? 0u : fbits[h[q] >> 5];
@@ -404,7 +424,7 @@ __device__ __forceinline__ void flat_pass_filtered(WaveLds &L, const int *__rest
   }
   if (qcount > 0) {
     wave_sync();
-    drain_candidates(L, stage, lane, qcount, steps, kQueueCap, 0, act);
+    drain_candidates<BM>(L, stage, lane, qcount, steps, kQueueCap, 0, act, bm);
   }
   wave_sync();
 }
@@ -614,6 +634,16 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
       for (int i = tid; i < kFilterWords; i += nthreads) B.fbits[i] = 0u;
     for (int i = tid; i < nel; i += nthreads) B.stage[i] = col[eb + i];
   }
+  // SPLIT chunk of a bitmapped hub row (symmetric-graph patterns): the idle stage becomes a 2^17-bit hashed filter of the
+  // whole row, so that ~90 % of the streamed keys are rejected in LDS and only the rest probe the bitmap in HBM
+  bool split_filter = false;
+  unsigned *sfbits = reinterpret_cast<unsigned *>(B.stage);
+  if constexpr (stage_cap_of(PAT) == kStageCapWide) {
+    static_assert(sizeof(B.stage) * 8 >= (1u << kSplitFilterLog2), "stage too small for the SPLIT-row filter");
+    split_filter = !whole_rows && bm != nullptr && !(p.flags & 8) && (B.rpl[1] - B.rpl[0]) <= kSplitFilterMaxRow;
+    if (split_filter)
+      for (int i = tid; i < (1 << kSplitFilterLog2) / 32; i += nthreads) sfbits[i] = 0u;
+  }
 
   // clique: adjacency bit-matrix of the chunk, one row of `stride` words per edge
   int stride = 0;
@@ -643,6 +673,13 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
     }
   }
   __syncthreads();
+  if (split_filter) {
+    for (int i = B.rpl[0] + tid; i < B.rpl[1]; i += nthreads) {
+      const unsigned h = filter_hash<kSplitFilterLog2>(col[i], 0u);
+      atomicOr(&sfbits[h >> 5], 1u << (h & 31u));
+    }
+    __syncthreads();
+  }
   if (staged) {  // local row of every staged entry (+ its filter bit)
     for (int i = tid; i < nel; i += nthreads) {
       const int e = eb + i;
@@ -780,13 +817,16 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
 
     // pass X
     {
-      const int llen = (dirx && !(p.flags & 2048)) ? b : 0;  // (2048: ablation, skip pass X)
+      int llen = (dirx && !(p.flags & 2048)) ? b : 0;  // (2048: ablation, skip pass X)
+      if (PAT == PAT_MOTIF3 && split_filter && llen > 0) llen = lower_bound(col + rv, b, hi);  // only keys < hi can count
       const int s_len_flag = al | (flag << 30);
       auto actx = [&](bool f, int owner, int kidx, int pos, int fl, int key) { on_found(f, owner, kidx, pos, fl, key, true); };
       if (use_filter)
         flat_pass_filtered(L, B.stage, B.fbits, col, lane, llen, rv, (ru - eb) | (int)(filter_salt(lrow_of_lane) << 16),
                            s_len_flag, p.flags, actx);
       else if (staged) flat_pass<SEARCH_LDS>(L, B.stage, col, bm, lane, llen, rv, ru - eb, s_len_flag, actx);
+      else if (bm && split_filter)
+        flat_pass_filtered<kSplitFilterLog2, true>(L, nullptr, sfbits, col, lane, llen, rv, 0, s_len_flag, p.flags, actx, bm);
       else if (bm) flat_pass<SEARCH_BITMAP>(L, B.stage, col, bm, lane, llen, rv, (PAT == PAT_MOTIF3) ? hi : 0x7fffffff, s_len_flag, actx);
       else flat_pass<SEARCH_HBM>(L, B.stage, col, bm, lane, llen, rv, ru, s_len_flag, actx);
     }
