@@ -86,7 +86,10 @@ extern "C" int gm_device_count(int *n) {
 constexpr int kBitmapMinDeg = GM_BITMAP_MIN_DEG;
 constexpr unsigned long long kBitmapBudget = (unsigned long long)GM_BITMAP_BUDGET_MB << 20;
 constexpr unsigned long long kPartCostCap = 8ull << 20;     // DAG patterns: staged chunks stay whole
-constexpr unsigned long long kPartCostCapSym = 1ull << 20;  // symmetric-graph patterns (measured on R-MAT-20/22/24: 1 M best for diamond, 2 M for 3-motif)
+#ifndef GM_PART_CAP_SYM
+#define GM_PART_CAP_SYM (2ull << 20)
+#endif
+constexpr unsigned long long kPartCostCapSym = GM_PART_CAP_SYM;  // symmetric-graph patterns (measured on R-MAT-20/22/24: 1 M best for diamond, 2 M for 3-motif)
 constexpr int kDefaultChunk = 1024;  // task edges per chunk when the caller does not say
 
 struct ChunkTable {

@@ -33,7 +33,10 @@ constexpr int kBitWords = 2048;           // clique: LDS words for the per-chunk
 // Batches are 64 task edges, except in SPLIT chunks of the symmetric-graph patterns: there every edge streams a whole list
 // against a hub row and 64 hub-hub edges are milliseconds of work for one wave, so the batch is kSplitBatch edges (the
 // flattened pass still fills all 64 lanes with keys).
-constexpr int kSplitBatch = 16;
+#ifndef GM_SPLIT_BATCH
+#define GM_SPLIT_BATCH 16
+#endif
+constexpr int kSplitBatch = GM_SPLIT_BATCH;
 struct ChunkRec {
   int u_begin, u_end, e_begin, e_end;
   int part, nparts;  // nparts >= 1
