@@ -9,7 +9,10 @@ namespace gm {
 // ---- compile-time geometry of one workgroup ---------------------------------------------------
 constexpr int kWavesPerBlock = 4;         // 256-thread workgroups: the 4 waves share a chunk's LDS stage, take batches independently
 constexpr int kStageCap = 1024;           // adjacency entries a workgroup stages in LDS per chunk (4 KB)
-constexpr int kStageCapWide = 4096;       // ... for the patterns that run on SYMMETRIC graphs (see stage_cap_of)
+#ifndef GM_STAGE_WIDE
+#define GM_STAGE_WIDE 3072
+#endif
+constexpr int kStageCapWide = GM_STAGE_WIDE;       // ... for the patterns that run on SYMMETRIC graphs (see stage_cap_of)
 constexpr int kMaxChunkVerts = 256;       // rows per task chunk (local row_ptr slice in LDS)
 constexpr int kMarkWindow = 512;          // flattened positions resolved per owner-mark window
 #ifndef GM_TILES
@@ -53,9 +56,11 @@ enum Pattern : int { PAT_TC = 0, PAT_DIAMOND = 1, PAT_MOTIF3 = 2, PAT_CLIQUE4 = 
                      PAT_MOTIF4E = 5 /* per-edge sums of the 4-motif formula */,
                      PAT_DAGSTATS = 6 /* tooling: sum n, sum n^2, sum_{matches} d+(w) for the 4-clique algorithmic bytes */ };
 
-// Symmetric-graph patterns stage up to 4096 entries: on skewed graphs thousands of rows have 1-4 K neighbours; with a
+// Symmetric-graph patterns stage up to 3072 entries: on skewed graphs thousands of rows have 1-3 K neighbours; with a
 // 1024-entry stage they are SPLIT rows whose keys are bisected in HBM, otherwise ordinary staged chunks behind
-// the LDS filter. Measured (diamond R-MAT-22 / 3-motif R-MAT-24, ms): 1024: 94.4 / 1056, 2048: 82.5 / 1021, 4096: 77.4 / 920, 8192: 104.9 / 1111.
+// the LDS filter. Measured (diamond R-MAT-22 / 3-motif R-MAT-24, ms) before SPLIT chunks pre-filtered in LDS: 1024: 94.4 / 1056,
+// 2048: 82.5 / 1021, 4096: 77.4 / 920, 8192: 104.9 / 1111; after (diamond R-MAT-22 / 3-motif R-MAT-24 / diamond R-MAT-20): 2048: 28.2 / 748 /
+// 10.1, 3072 (31.5 KB of LDS, 5 workgroups per CU): 28.2 / 625 / 10.2, 4096 (36 KB, 4 per CU): 27.9 / 706 / 13.8.
 // Which endpoint of an undirected edge {u, v} hosts its task in the symmetric-graph patterns (a = d(u), b = d(v)); asked
 // from u's side: true = u's row hosts. Any rule that picks exactly one endpoint gives the same counts. Normally the LONGER
 // row hosts (it is staged or bitmapped, the shorter list is streamed: min(a, b) keys). kProbeCost > 1 adds an exception for

@@ -66,10 +66,13 @@ __device__ __forceinline__ unsigned filter_hash(int x, unsigned salt) {
   const unsigned xl = ((unsigned)x ^ ((unsigned)x >> 24)) & 0xffffffu;
   return ((__umul24(xl, 0x9E3779u) >> (32 - FL2)) ^ salt) & (unsigned)((1u << FL2) - 1u);
 }
-// SPLIT chunks of the symmetric-graph patterns: the 16 KB stage is idle (the row does not fit), so it holds a 2^17-bit
+// SPLIT chunks of the symmetric-graph patterns: the 12 KB stage is idle (the row does not fit), so 8 KB of it hold a 2^16-bit
 // hashed filter of the WHOLE hub row; only the keys that pass it are verified against the row's dense bitmap in HBM.
-constexpr int kSplitFilterLog2 = 17;
-constexpr int kSplitFilterMaxRow = 1 << 16;  // longer rows: the filter would pass > 40 % -- probe the bitmap directly
+#ifndef GM_SPLIT_FL2
+#define GM_SPLIT_FL2 16
+#endif
+constexpr int kSplitFilterLog2 = GM_SPLIT_FL2;
+constexpr int kSplitFilterMaxRow = 1 << 16;  // longer rows: the filter would pass > 60 % -- probe the bitmap directly
 __device__ __forceinline__ unsigned filter_salt(int local_row) { return ((unsigned)local_row * 0x2545u) & (unsigned)(kFilterBits - 1); }
 
 // One flattened pass over the 64 edges of a batch.
@@ -634,7 +637,7 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
       for (int i = tid; i < kFilterWords; i += nthreads) B.fbits[i] = 0u;
     for (int i = tid; i < nel; i += nthreads) B.stage[i] = col[eb + i];
   }
-  // SPLIT chunk of a bitmapped hub row (symmetric-graph patterns): the idle stage becomes a 2^17-bit hashed filter of the
+  // SPLIT chunk of a bitmapped hub row (symmetric-graph patterns): the idle stage becomes a 2^16-bit hashed filter of the
   // whole row, so that ~90 % of the streamed keys are rejected in LDS and only the rest probe the bitmap in HBM
   bool split_filter = false;
   unsigned *sfbits = reinterpret_cast<unsigned *>(B.stage);
@@ -773,7 +776,10 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
     // direction: X streams B = N(v) and bisects A; Y takes keys from A and bisects B in HBM
     bool dirx = false;
     int vslot = -1;  // dense bitmap of row v, if it has one: pass Y then probes it instead of bisecting N(v)
-    if (!GM_IS_CLIQUE(PAT) && p.row_slot != nullptr && act && !(p.flags & 512)) vslot = p.row_slot[v];
+    // (only the symmetric-graph instantiations carry this path: DAG rows rarely reach the bitmap threshold, and TC would pay
+    // for it with 3 VGPRs = one wave per SIMD)
+    constexpr bool kRowBitmaps = stage_cap_of(PAT) == kStageCapWide;
+    if (kRowBitmaps && p.row_slot != nullptr && act && !(p.flags & 512)) vslot = p.row_slot[v];
     if (act) {
       if (staged) {
         const float cx = (float)b * (float)(p.cost_x_base + p.cost_x_step * bitlen(al));
@@ -836,7 +842,7 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
       auto acty = [&](bool f, int owner, int kidx, int pos, int fl, int key) { on_found(f, owner, kidx, pos, fl, key, false); };
       const bool y_on = diry && !(p.flags & 0x10000);  // (0x10000: ablation, skip pass Y)
       flat_pass<SEARCH_HBM>(L, B.stage, col, bm, lane, (y_on && vslot < 0) ? al : 0, ru, rv, b | (flag << 30), acty);
-      if (!GM_IS_CLIQUE(PAT) && p.row_slot != nullptr)
+      if (kRowBitmaps && p.row_slot != nullptr)
         flat_pass<SEARCH_BITMAP_ROW>(L, B.stage, col, p.bitmaps, lane, (y_on && vslot >= 0) ? al : 0, ru, 0x7fffffff,
                                      max(vslot, 0) | (flag << 30), acty, p.bitmap_words);
     }
