@@ -922,7 +922,10 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
   // tune[6] & 0x1000 (tests): cut every chunk above 4096 estimated entries into parts
   // chunk costs are estimated keys (DAG patterns: d(u) + d(v) per edge; symmetric patterns: streamed keys, bitmap probes
   // weighted kProbeCost); parts bound the longest task of a launch
-  const unsigned long long part_cap = (la->tune[6] & 0x1000) ? 4096ull : (stage_cap_of(pat) == kStageCapWide ? kPartCostCapSym : kPartCostCap);
+  const unsigned long long part_cap = (la->tune[6] & 0x1000) ? 4096ull : (stage_cap_of(pat) != kStageCapWide ? kPartCostCap
+       // a rank's share is 1/world of the launch: so is the tolerable tail (3-motif's bounded lists make its estimates
+       // pessimistic already: measured, 1/8 share 84.8 ms unscaled vs 91.2 ms scaled; diamond 5.2 vs 4.2 ms)
+       : (pat == PAT_MOTIF3 ? kPartCostCapSym : std::max<unsigned long long>(kPartCostCapSym / (unsigned long long)world, 256ull << 10)));
   int rc = get_table(g, target, !clique, clique ? kBitWords : 0, part_cap, stage_cap_of(pat), &tab);
   if (rc) return rc;
 
