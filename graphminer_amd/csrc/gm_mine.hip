@@ -772,6 +772,7 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
       }
       L.cnt[lane] = (unsigned)lo;  // read back by the match handler (rare)
     }
+    if (PAT == PAT_MOTIF3 && act && b >= 128) b = lower_bound(col + rv, b, hi);  // only the keys < hi of N(v) can count: trim B too
     act = act && al > 0 && b > 0;
     // direction: X streams B = N(v) and bisects A; Y takes keys from A and bisects B in HBM
     bool dirx = false;
@@ -824,7 +825,7 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
     // pass X
     {
       int llen = (dirx && !(p.flags & 2048)) ? b : 0;  // (2048: ablation, skip pass X)
-      if (PAT == PAT_MOTIF3 && split_filter && llen > 0) llen = lower_bound(col + rv, b, hi);  // only keys < hi can count
+      if (PAT == PAT_MOTIF3 && split_filter && llen > 0 && b < 128) llen = lower_bound(col + rv, b, hi);  // (the filtered pass has no key bound)
       const int s_len_flag = al | (flag << 30);
       auto actx = [&](bool f, int owner, int kidx, int pos, int fl, int key) { on_found(f, owner, kidx, pos, fl, key, true); };
       if (use_filter)
