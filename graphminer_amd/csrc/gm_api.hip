@@ -1031,7 +1031,9 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
     unsigned long long tot = 0;
     for (auto t : ticks) tot += t;
     if (const char *dump = getenv("GM_CHUNK_DUMP")) {
-      FILE *f = fopen(dump, "w");
+      static int dump_no = 0;
+      const std::string name = std::string(dump) + "." + std::to_string(dump_no++) + ".pat" + std::to_string((int)pat);
+      FILE *f = fopen(name.c_str(), "w");
       if (f) {
         fprintf(f, "pos,cid,rows,entries,rowlen,whole,part,nparts,cost,us\n");
         for (size_t pos = 0; pos < tab->n; ++pos) {

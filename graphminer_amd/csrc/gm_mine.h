@@ -80,7 +80,13 @@ __host__ __device__ inline bool sym_hosts(int a, int b, int u, int v, int stage_
   return u_longer != shorter_hosts;
 }
 
-constexpr int stage_cap_of(int pat) { return (pat == PAT_DIAMOND || pat == PAT_MOTIF3 || pat == PAT_MOTIF4E) ? kStageCapWide : kStageCap; }
+// k-clique keeps the 1024-entry stage: rows above it are whole-row chunks searched in HBM, but staging them (1536 entries
+// still leave 5 workgroups per CU) measured SLOWER, 257 -> 282 ms on R-MAT-22 ef 28 -- their time is the d x d/32 bit-matrix.
+constexpr int kStageCapClique = 1024;
+constexpr int stage_cap_of(int pat) {
+  return (pat == PAT_DIAMOND || pat == PAT_MOTIF3 || pat == PAT_MOTIF4E) ? kStageCapWide
+         : (pat == PAT_CLIQUE4 || pat == PAT_CLIQUEK) ? kStageCapClique : kStageCap;
+}
 
 struct MineParams {
   GraphView g;
