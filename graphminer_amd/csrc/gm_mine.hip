@@ -651,6 +651,7 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
   // clique: adjacency bit-matrix of the chunk, one row of `stride` words per edge
   int stride = 0;
   bool bits_lds = true, grouped = false;
+  int clique_batch = GM_WAVE;  // edges per batch while a big vertex is built in row groups
   int grp_rows = nel > 0 ? nel : 1;
   unsigned *gbits = nullptr;
   if (GM_IS_CLIQUE(PAT)) {
@@ -666,11 +667,15 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
       // and flushed with plain coalesced stores (no device atomics). Only rows wider than the LDS budget
       // (stride > kBitWords/64) fall back to atomics on the arena.
       gbits = p.scratch + (size_t)blockIdx.x * p.scratch_words;
-      const int r = (kBitWords / stride) & ~(GM_WAVE - 1);
-      if (r >= GM_WAVE) {
+      // (rows of 1025..2048 columns, stride 33..64: 64 rows no longer fit the 2048-word budget -- their groups are 32 rows
+      // and their batches 32 edges, which keeps them off the device-atomic path)
+      clique_batch = (stride > 32) ? 32 : GM_WAVE;
+      const int r = (kBitWords / stride) & ~(clique_batch - 1);
+      if (r >= clique_batch) {
         grouped = true;
         grp_rows = r;
       } else {
+        clique_batch = GM_WAVE;
         for (long long i = tid; i < words; i += nthreads) gbits[i] = 0u;
       }
     }
@@ -705,14 +710,14 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
   const int gend = min(nel, g0 + grp_rows);
   if (GM_IS_CLIQUE(PAT) && grouped) {
     for (int i = tid; i < (gend - g0) * stride; i += nthreads) B.bits[i] = 0u;
-    if (tid == 0) B.next_batch = g0 / GM_WAVE;
+    if (tid == 0) B.next_batch = g0 / clique_batch;
     __syncthreads();
   }
   // A big clique vertex is built in row groups that may hold a single batch: then all 4 waves work on EVERY batch of
   // the group, each owning the edges with (lane & 3) == wave, instead of one wave working while three idle.
   const bool split4 = GM_IS_CLIQUE(PAT) && grouped;
-  const int bsz = (stage_cap_of(PAT) == kStageCapWide && !whole_rows) ? kSplitBatch : GM_WAVE;  // edges per batch
-  int my_bi = g0 / GM_WAVE;
+  const int bsz = (stage_cap_of(PAT) == kStageCapWide && !whole_rows) ? kSplitBatch : (split4 ? clique_batch : GM_WAVE);  // edges per batch
+  int my_bi = g0 / bsz;
   for (;;) {
     int bi = 0;
     if (split4) {
