@@ -895,17 +895,19 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
       __threadfence();  // the scratch matrix was written by all 4 waves (plain stores or device atomics)
       __syncthreads();
     }
-    const unsigned *M = bits_lds ? B.bits : gbits;
+    // (the matrix pointer is passed with its address space visible -- B.bits = LDS, gbits = global: through a common
+    // generic pointer every load became a FLAT load)
     switch (PAT == PAT_CLIQUE4 ? 4 : p.k) {
       case 4:
-        if (wide) acc.c0 += clique4_count_wide(L, M, lane, wave, nel, stride);
-        else acc.c0 += clique4_count(B.rpl, M, tid, nthreads, eb, nel, nvl, stride);
+        if (wide) acc.c0 += clique4_count_wide(L, gbits, lane, wave, nel, stride);
+        else if (bits_lds) acc.c0 += clique4_count(B.rpl, B.bits, tid, nthreads, eb, nel, nvl, stride);
+        else acc.c0 += clique4_count(B.rpl, gbits, tid, nthreads, eb, nel, nvl, stride);
         break;
 #define GM_CLIQUE_CASE(K)                                                                                   \
       case K:                                                                                                \
         if (PAT != PAT_CLIQUEK) break;                                                                       \
-        if (wide) acc.c0 += cliquek_count_wide<K - 2>(M, lane, wave, nel, stride);                          \
-        else if (bits_lds) acc.c0 += cliquek_count_small<K - 2>(B.rpl, M, tid, nthreads, eb, nel, nvl, stride); \
+        if (wide) acc.c0 += cliquek_count_wide<K - 2>(gbits, lane, wave, nel, stride);                      \
+        else if (bits_lds) acc.c0 += cliquek_count_small<K - 2>(B.rpl, B.bits, tid, nthreads, eb, nel, nvl, stride); \
         else acc.c1 += 1; /* row wider than 2048 columns: not supported for k >= 5 (reported by the host) */ \
         break;
       GM_CLIQUE_CASE(5)
