@@ -963,12 +963,13 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
     p.step = (int)step;
     p.count = (int)count;
     // dequeue order (tune[6] & 0x4000: plain chunk-id order; & 0x2000: swap the two orders -- ablation only)
-    // measured on R-MAT (one rank): k >= 5 cliques want the full order (796 -> 589 ms), 4-clique none (its big vertices
-    // contend for the scratch arena when they all start together: 270 vs 278 ms), the rest the heavy-first order
-    const bool sym_pat = stage_cap_of(pat) == kStageCapWide;  // these keep the locality-preserving order at every world size
-    const int which = (((world > 1 && !sym_pat) || pat == PAT_CLIQUEK) ? 1 : 0) ^ ((la->tune[6] & 0x2000) ? 1 : 0);
-    const bool lpt = la->policy == GM_PART_ROUND_ROBIN && tab->d_order[which] && !(la->tune[6] & 0x4000) &&
-                     !(pat == PAT_CLIQUE4 && world == 1 && !(la->tune[6] & 0x2000));
+    // measured on R-MAT (one rank): the cliques want the full cost order (4-clique 220.6 -> 208.6 ms, 5-clique 796 -> 589 ms),
+    // the symmetric-graph patterns the locality-preserving heavy-first order at every world size, TC heavy-first for one
+    // rank and the full order for shares
+    const bool sym_pat = stage_cap_of(pat) == kStageCapWide;
+    const bool clique_pat = pat == PAT_CLIQUE4 || pat == PAT_CLIQUEK;
+    const int which = (((world > 1 && !sym_pat) || clique_pat) ? 1 : 0) ^ ((la->tune[6] & 0x2000) ? 1 : 0);
+    const bool lpt = la->policy == GM_PART_ROUND_ROBIN && tab->d_order[which] && !(la->tune[6] & 0x4000);
     p.order = lpt ? tab->d_order[which] : nullptr;
     if (step == 1) my_edges = tab->edge_prefix[first + count] - tab->edge_prefix[first];  // (any order: the same set)
     else for (long long j = first; j < n; j += step) {
