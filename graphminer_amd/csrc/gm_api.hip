@@ -534,9 +534,9 @@ static void build_chunks(const std::vector<int> &rp, int nv, int target, bool al
     if (d == 0) { ++u; continue; }
     if (d > stage_cap) {
       if (allow_split) {
-        for (int s = rp[u]; s < rp[u + 1]; s += target) out.push_back({u, u + 1, s, std::min(s + target, rp[u + 1]), 0, 1});
+        for (int s = rp[u]; s < rp[u + 1]; s += target) out.push_back({u, u + 1, s, std::min(s + target, rp[u + 1]), 0, 1, GM_WAVE, 0});
       } else {
-        out.push_back({u, u + 1, rp[u], rp[u + 1], 0, 1});
+        out.push_back({u, u + 1, rp[u], rp[u + 1], 0, 1, GM_WAVE, 0});
         if (bit_words) max_bit_words = std::max(max_bit_words, (unsigned long long)d * (unsigned long long)((d + 31) / 32));
       }
       ++u;
@@ -558,7 +558,7 @@ static void build_chunks(const std::vector<int> &rp, int nv, int target, bool al
       if (edges >= target) break;
     }
     if (edges > 0) {
-      out.push_back({start, u, rp[start], rp[u], 0, 1});
+      out.push_back({start, u, rp[start], rp[u], 0, 1, GM_WAVE, 0});
       if (bit_words) {
         const unsigned long long w = (unsigned long long)edges * (unsigned long long)((maxd + 31) / 32);
         if (w > (unsigned long long)bit_words) max_bit_words = std::max(max_bit_words, w);
@@ -613,10 +613,12 @@ __global__ __launch_bounds__(256) void chunk_cost_kernel(const int *__restrict__
   if ((threadIdx.x & 63) == 0 && c) atomicAdd(&cost[blockIdx.x], c);
 }
 
-// edges per batch of a chunk (process_chunk: kSplitBatch in the SPLIT chunks of the symmetric-graph patterns)
-static int batch_edges(const ChunkRec &r, const std::vector<int> &rp, int stage_cap) {
+// edges per batch of a chunk: 64, or kSplitBatch in the SPLIT chunks of the symmetric-graph patterns whose task edges stream
+// long lists (estimated keys per entry >= kSplitBatchMinKeys)
+static int batch_edges(const ChunkRec &r, const std::vector<int> &rp, int stage_cap, unsigned long long cost) {
   const bool whole = r.e_begin == rp[(size_t)r.u_begin] && r.e_end == rp[(size_t)r.u_end];
-  return (stage_cap == kStageCapWide && !whole) ? kSplitBatch : GM_WAVE;
+  const unsigned long long nel = (unsigned long long)std::max(r.e_end - r.e_begin, 1);
+  return (stage_cap == kStageCapWide && !whole && cost / nel >= (unsigned long long)kSplitBatchMinKeys) ? kSplitBatch : GM_WAVE;
 }
 
 static int get_table(gm_graph *g, int target, bool allow_split, int bit_words, unsigned long long part_cap, int stage_cap,
@@ -657,13 +659,14 @@ static int get_table(gm_graph *g, int target, bool allow_split, int bit_words, u
     cut.reserve(recs.size());
     cut_cost.reserve(recs.size());
     for (size_t i = 0; i < recs.size(); ++i) {
-      const int bsz = batch_edges(recs[i], g->h_rp, stage_cap);
+      const int bsz = batch_edges(recs[i], g->h_rp, stage_cap, cost[i]);
       const int batches = (recs[i].e_end - recs[i].e_begin + bsz - 1) / bsz;
       const int np = (int)std::max<unsigned long long>(1, std::min<unsigned long long>((unsigned long long)batches, (cost[i] + cap - 1) / cap));
       for (int q = 0; q < np; ++q) {
         ChunkRec r = recs[i];
         r.part = q;
         r.nparts = np;
+        r.batch = bsz;
         cut.push_back(r);
         cut_cost.push_back(cost[i] / (unsigned long long)np);
       }
@@ -680,7 +683,7 @@ static int get_table(gm_graph *g, int target, bool allow_split, int bit_words, u
   for (size_t i = 0; i < t.n; ++i) {  // task edges of a part = the entries of its batches
     const int nel = recs[i].e_end - recs[i].e_begin, np = recs[i].nparts;
     unsigned long long mine = 0;
-    const int bsz = batch_edges(recs[i], g->h_rp, stage_cap);
+    const int bsz = recs[i].batch;
     for (int b = recs[i].part; b * bsz < nel; b += np) mine += (unsigned long long)std::min(bsz, nel - b * bsz);
     t.edge_prefix[i + 1] = t.edge_prefix[i] + mine;
   }

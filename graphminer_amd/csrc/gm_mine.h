@@ -35,7 +35,10 @@ constexpr int kBitWords = 2048;           // clique: LDS words for the per-chunk
 // takes only the 64-edge batches b with b % nparts == part, so that several workgroups share one heavy chunk.
 // Batches are 64 task edges, except in SPLIT chunks of the symmetric-graph patterns: there every edge streams a whole list
 // against a hub row and 64 hub-hub edges are milliseconds of work for one wave, so the batch is kSplitBatch edges (the
-// flattened pass still fills all 64 lanes with keys).
+// flattened pass still fills all 64 lanes with keys). SPLIT chunks whose partner lists are short keep 64-edge batches: there the
+// per-batch setup (a dozen dependent loads per edge) would dominate -- chunk timings, R-MAT-24 3-motif: rows of ~7 K entries
+// spent 4.5 ns per streamed key with 16-edge batches against 1.2 ns for the rows of 17..46 K entries.
+constexpr int kSplitBatchMinKeys = 2048;  // mean streamed keys per task edge from which a SPLIT chunk takes the small batches
 #ifndef GM_SPLIT_BATCH
 #define GM_SPLIT_BATCH 16
 #endif
@@ -43,6 +46,7 @@ constexpr int kSplitBatch = GM_SPLIT_BATCH;
 struct ChunkRec {
   int u_begin, u_end, e_begin, e_end;
   int part, nparts;  // nparts >= 1
+  int batch, pad_;   // task edges per batch (64; kSplitBatch in SPLIT chunks whose edges stream long lists)
 };
 
 struct GraphView {

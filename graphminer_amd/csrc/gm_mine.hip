@@ -763,7 +763,7 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
   // A big clique vertex is built in row groups that may hold a single batch: then all 4 waves work on EVERY batch of
   // the group, each owning the edges with (lane & 3) == wave, instead of one wave working while three idle.
   const bool split4 = GM_IS_CLIQUE(PAT) && grouped;
-  const int bsz = (stage_cap_of(PAT) == kStageCapWide && !whole_rows) ? kSplitBatch : (split4 ? clique_batch : GM_WAVE);  // edges per batch
+  const int bsz = split4 ? clique_batch : r.batch;  // edges per batch (host: 64, or kSplitBatch in heavy SPLIT chunks)
   int my_bi = g0 / bsz;
   for (;;) {
     int bi = 0;
@@ -820,7 +820,9 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
       act = valid && owns;
       if (act) {
         if (staged) al = lower_bound(&B.stage[ru - eb], a, hi);
-        else al = lower_bound(col + ru, a, hi);
+        else if (bm == nullptr) al = lower_bound(col + ru, a, hi);
+        // (SPLIT chunk with a bitmap: the row itself is never searched, the bound is applied to the streamed keys -- saves a
+        // 13-step bisection of the hub row in HBM per edge)
       }
       L.cnt[lane] = (unsigned)lo;  // read back by the match handler (rare)
     }
