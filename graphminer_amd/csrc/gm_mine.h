@@ -77,10 +77,21 @@ enum Pattern : int { PAT_TC = 0, PAT_DIAMOND = 1, PAT_MOTIF3 = 2, PAT_CLIQUE4 = 
 #define GM_PROBE_COST 1
 #endif
 constexpr int kProbeCost = GM_PROBE_COST;
+#ifndef GM_MID_PROBE_COST
+#define GM_MID_PROBE_COST 1
+#endif
+constexpr int kMidProbeCost = GM_MID_PROBE_COST;
+constexpr int kMidRowMax = 16384;
 __host__ __device__ inline bool sym_hosts(int a, int b, int u, int v, int stage_cap) {
   const bool u_longer = (a > b) || (a == b && u > v);
   const int dl = u_longer ? a : b, ds = u_longer ? b : a;
-  const bool shorter_hosts = dl > stage_cap && ds <= stage_cap && (long long)dl < (long long)kProbeCost * ds;
+  // kProbeCost applies to every long row; kMidProbeCost only to the rows just above the stage (<= kMidRowMax entries): each of
+  // them has its own multi-MB bitmap that only a handful of chunks ever touch, so their probes are cold HBM accesses
+  // (chunk timings, R-MAT-24 3-motif: 4.5 ns per key for rows of ~7 K entries, 1.1 ns for rows of 17..46 K, 1.4 ns staged).
+  // Measured (diamond R-MAT-22 / 3-motif R-MAT-24 / diamond R-MAT-20, ms): 1: 28.1 / 460 / 10.3, 2: 28.3 / 460 / 10.3, 3: 28.2 / 454 / 11.6,
+  // 4: 30.7 / 421 / 12.3 -- no setting wins on all three, the default stays 1 (off).
+  const int k = (dl <= kMidRowMax) ? kMidProbeCost : kProbeCost;
+  const bool shorter_hosts = dl > stage_cap && ds <= stage_cap && (long long)dl < (long long)k * ds;
   return u_longer != shorter_hosts;
 }
 
