@@ -142,6 +142,12 @@ struct gm_graph {
   unsigned long long n_rect_tasks = 0;
   unsigned *d_rect_acc = nullptr;
   size_t rect_acc_bytes = 0;
+  unsigned *d_house_t = nullptr;         // house by wedge accumulation: per-entry tables, task list, 64-bit maps
+  unsigned *d_house_tlt = nullptr;
+  int4 *d_house_tasks = nullptr;
+  unsigned long long n_house_tasks = 0;
+  unsigned long long *d_house_acc = nullptr;
+  size_t house_acc_bytes = 0;
   unsigned long long *d_house_prefix = nullptr;  // house: per-entry task-block prefix
   unsigned long long n_house_blocks = 0;   // handle whose event ring holds this handle's most recent launch
   unsigned long long sum_c2 = 0;          // sum_v C(d(v),2)
@@ -177,6 +183,10 @@ extern "C" void gm_graph_free(gm_graph *g) {
   if (g->d_idx0) (void)hipFree(g->d_idx0);
   if (g->d_wblock_prefix) (void)hipFree(g->d_wblock_prefix);
   if (g->d_house_prefix) (void)hipFree(g->d_house_prefix);
+  if (g->d_house_t) (void)hipFree(g->d_house_t);
+  if (g->d_house_tlt) (void)hipFree(g->d_house_tlt);
+  if (g->d_house_tasks) (void)hipFree(g->d_house_tasks);
+  if (g->d_house_acc) (void)hipFree(g->d_house_acc);
   if (g->d_rect_tasks) (void)hipFree(g->d_rect_tasks);
   if (g->d_rect_acc) (void)hipFree(g->d_rect_acc);
   for (auto &pr : g->ev)
@@ -1223,6 +1233,92 @@ static int run_rect_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h_
   return end_launch(ctx, FIN_COPY, 0, h_out, 1, st);
 }
 
+// house by wedge accumulation (edge_tab_kernel + house_acc_kernel in gm_mine.hip)
+static int run_house_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h_out, gm_stats *st) {
+  LaunchCtx ctx;
+  int rc = begin_launch(cg, la_in, h_out, ctx);
+  if (rc) return rc;
+  gm_graph *g = ctx.g;
+  const gm_launch *la = &ctx.la;
+  GraphView gv;
+  gv.nv = g->nv;
+  gv.ne = (int)g->ne;
+  gv.rp = g->d_rp;
+  gv.col = g->d_col;
+  const size_t ne1 = (size_t)std::max<long long>(g->ne, 1);
+  if (!g->d_house_tasks) {  // once per graph (every rank builds the whole tables: they are inputs of every centre)
+    HIP_TRY(hipMalloc(&g->d_house_t, sizeof(unsigned) * ne1));
+    HIP_TRY(hipMalloc(&g->d_house_tlt, sizeof(unsigned) * ne1));
+    HIP_TRY(hipMemset(g->d_counters, 0, 64));
+    if (g->ne > 0) {
+      HIP_TRY(launch_edge_tab(gv, g->d_house_t, g->d_house_tlt, g->d_counters + 4, g->cu_count * 8, 0));
+      HIP_TRY(hipDeviceSynchronize());
+      HIP_TRY(hipMemset(g->d_counters, 0, 64));  // (the table kernel used the dequeue head)
+    }
+    const size_t nv = (size_t)g->nv;
+    unsigned long long *d_work = nullptr;
+    HIP_TRY(hipMalloc(&d_work, sizeof(unsigned long long) * std::max<size_t>(nv, 1)));
+    std::vector<unsigned long long> work(std::max<size_t>(nv, 1));
+    hipError_t e = nv ? launch_house_work(gv, d_work, 0) : hipSuccess;
+    if (e == hipSuccess) e = hipMemcpy(work.data(), d_work, sizeof(unsigned long long) * nv, hipMemcpyDeviceToHost);
+    (void)hipFree(d_work);
+    if (e != hipSuccess) return hip_fail(e, "house_work_kernel", __FILE__, __LINE__);
+    std::vector<int> vs;
+    vs.reserve(nv);
+    for (size_t v = 0; v < nv; ++v)
+      if (work[v] > 0) vs.push_back((int)v);
+    std::stable_sort(vs.begin(), vs.end(), [&](int a, int b) { return work[(size_t)a] > work[(size_t)b]; });
+    const unsigned long long heavy = 1ull << 15;
+    std::vector<int4> tasks;
+    size_t i = 0;
+    for (; i < vs.size() && work[(size_t)vs[i]] >= heavy; ++i) tasks.push_back(make_int4(vs[i], -2, -2, -2));
+    for (; i < vs.size(); i += 4) {
+      int4 t4 = make_int4(-1, -1, -1, -1);
+      t4.x = vs[i];
+      if (i + 1 < vs.size()) t4.y = vs[i + 1];
+      if (i + 2 < vs.size()) t4.z = vs[i + 2];
+      if (i + 3 < vs.size()) t4.w = vs[i + 3];
+      tasks.push_back(t4);
+    }
+    g->n_house_tasks = tasks.size();
+    HIP_TRY(hipMalloc(&g->d_house_tasks, sizeof(int4) * std::max<size_t>(tasks.size(), 1)));
+    if (!tasks.empty()) HIP_TRY(hipMemcpy(g->d_house_tasks, tasks.data(), sizeof(int4) * tasks.size(), hipMemcpyHostToDevice));
+  }
+  HouseAccParams p;
+  memset(&p, 0, sizeof p);
+  p.g = gv;
+  p.t = g->d_house_t;
+  p.tlt = g->d_house_tlt;
+  p.tasks = g->d_house_tasks;
+  int64_t first = 0, step = 1, count = 0;
+  gm_partition((int64_t)g->n_house_tasks, ctx.rank, ctx.world, la->policy, &first, &step, &count);
+  p.first = (unsigned long long)first;
+  p.step = (unsigned long long)step;
+  p.count = (unsigned long long)count;
+  p.counters = g->d_counters;
+  p.queue = g->d_counters + 4;
+  p.acc_stride = ((unsigned long long)g->nv + 63ull) & ~63ull;
+  const unsigned long long per_wg = p.acc_stride * 8ull * kWavesPerBlock;
+  const unsigned long long budget = 32ull << 30;
+  long long grid = std::min<long long>((long long)g->cu_count * 8, (long long)std::max<unsigned long long>(1, budget / std::max<unsigned long long>(per_wg, 1)));
+  grid = std::max<long long>(1, std::min<long long>(grid, count));
+  const size_t need = (size_t)per_wg * (size_t)grid;
+  if (need > g->house_acc_bytes) {
+    if (g->d_house_acc) (void)hipFree(g->d_house_acc);
+    g->d_house_acc = nullptr;
+    g->house_acc_bytes = 0;
+    HIP_TRY(hipMalloc(&g->d_house_acc, need));
+    HIP_TRY(hipMemset(g->d_house_acc, 0, need));  // every launch leaves the maps zeroed again
+    g->house_acc_bytes = need;
+  }
+  p.acc = g->d_house_acc;
+  rc = start_timer(ctx);
+  if (rc) return rc;
+  if (count > 0) HIP_TRY(launch_house_acc(p, (int)grid, ctx.stream));
+  fill_stats(st, (uint64_t)(g->ne / 2 / ctx.world), (uint64_t)count, (int)grid, 256);
+  return end_launch(ctx, FIN_COPY, 0, h_out, 1, st);
+}
+
 // house, flattened over (v0, v1, v3) tasks (house_flat_kernel in gm_mine.hip)
 static int run_house_flat(const gm_graph *cg, const gm_launch *la_in, uint64_t *h_out, gm_stats *st) {
   LaunchCtx ctx;
@@ -1258,7 +1354,7 @@ static int run_house_flat(const gm_graph *cg, const gm_launch *la_in, uint64_t *
   p.entry_prefix = g->d_house_prefix;
   p.nblocks = g->n_house_blocks;
   p.group = la->chunk > 0 ? la->chunk : 8;
-  p.no_bits = (la->tune[6] & 2048) ? 1 : 0;
+  p.no_bits = (la->tune[6] & 0x8000) ? 1 : 0;
   const long long ngroups = (long long)((p.nblocks + (unsigned long long)p.group - 1) / (unsigned long long)p.group);
   int64_t first = 0, step = 1, count = 0;
   gm_partition(ngroups, ctx.rank, ctx.world, la->policy, &first, &step, &count);
@@ -1330,7 +1426,11 @@ extern "C" int gm_sgl(const gm_graph *sym, const char *pattern, const gm_launch 
     gm_graph *self = const_cast<gm_graph *>(sym);
     const gm_graph *run_on = sym;
     const bool wedge_form = is_pent || (is_rect && (t6 & 2048));  // anchored wedges: hubs first; 2-path / (v0,v1,v3) forms: hubs last
-    if (!(t6 & 512) && !(t6 & 1024)) {
+    // house: by wedge accumulation (default; its 2-path count does not depend on the numbering, so no renumbered copy), or
+    // the flattened (v0, v1, v3) form (0x800; 0x8000: without the LDS S-bitmap). The packed map holds 24-bit counts and
+    // 40-bit weighted sums: rows of 2^20 entries or more take the flattened form.
+    const bool house_acc = is_house && !(t6 & (1024 | 2048 | 0x8000)) && sym->max_deg < (1 << 20);
+    if (!(t6 & 512) && !(t6 & 1024) && !house_acc) {
       gm_graph *r = nullptr;
       int rc = get_relabeled(self, wedge_form ? 1 : 0, &r);
       if (rc) return rc;
@@ -1338,6 +1438,7 @@ extern "C" int gm_sgl(const gm_graph *sym, const char *pattern, const gm_launch 
     }
     int rc;
     if (t6 & 1024) rc = run_sgl_nested(is_rect ? SGL_RECTANGLE : is_house ? SGL_HOUSE : SGL_PENTAGON, run_on, la, total, st);
+    else if (house_acc) rc = run_house_acc(run_on, la, total, st);
     else if (is_house) rc = run_house_flat(run_on, la, total, st);
     else if (is_pent) rc = run_rect_flat(run_on, la, total, st, true);
     else if (t6 & 2048) rc = run_rect_flat(run_on, la, total, st);

@@ -170,6 +170,23 @@ struct RectAccParams {
 hipError_t launch_rect_acc(const RectAccParams &p, int grid_blocks, hipStream_t stream);
 hipError_t launch_rect_work(const GraphView &g, const int *idx0, unsigned long long *work, hipStream_t stream);
 
+// house by wedge accumulation (gm_mine.hip): per-entry triangle tables + one 2-path walk per centre with a 64-bit
+// (weighted sum | count) map; same task list layout as RectAccParams
+struct HouseAccParams {
+  GraphView g;
+  const unsigned *t;    // per CSR entry (v0 -> v1): |N(v0) ^ N(v1)|
+  const unsigned *tlt;  // per CSR entry (v0 -> v1): |{x in N(v0) ^ N(v1) : x < v0}|
+  const int4 *tasks;
+  unsigned long long first, step, count;
+  unsigned long long *acc;  // one zeroed 64-bit map per wave: grid * 4 * acc_stride
+  unsigned long long acc_stride;
+  unsigned long long *queue;
+  unsigned long long *counters;
+};
+hipError_t launch_edge_tab(const GraphView &g, unsigned *t, unsigned *tlt, unsigned long long *queue, int grid_blocks, hipStream_t stream);
+hipError_t launch_house_acc(const HouseAccParams &p, int grid_blocks, hipStream_t stream);
+hipError_t launch_house_work(const GraphView &g, unsigned long long *work, hipStream_t stream);
+
 // flattened house (gm_mine.hip): tasks are (v0, v1, v3) with v1 < v0 in N(v0), v3 in N(v1) \ {v0}, 64 v3 per wave
 struct HouseParams {
   GraphView g;

@@ -143,7 +143,7 @@ __device__ __forceinline__ void flat_pass(WaveLds &L, const int *__restrict__ st
         lo[q] = 0;
       }
       if constexpr (MODE == SEARCH_NONE) {
-        act(in, key);  // the whole tile group at once: act(const bool in[kTilesG], const int key[kTilesG])
+        act(in, key, own);  // the whole tile group at once: act(const bool in[], const int key[], const int own[] /* lane + 1 */)
         continue;
       } else {
       if (MODE == SEARCH_BITMAP || MODE == SEARCH_BITMAP_ROW) {
@@ -1167,14 +1167,14 @@ __global__ __launch_bounds__(256) void rect_acc_kernel(const RectAccParams p) {
           if (phase == 0) {
             // (measured: issuing the four returning atomics of a tile group back to back is ~5 % SLOWER than one at a
             // time -- the map updates are bound by the L2 atomic units, not by latency)
-            auto inc = [&](const bool *in, const int *key) {
+            auto inc = [&](const bool *in, const int *key, const int *) {
 #pragma unroll
               for (int q = 0; q < kTilesG; ++q)
                 if (in[q]) cnt += (unsigned long long)__hip_atomic_fetch_add(&acc[key[q]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             };
             flat_pass<SEARCH_NONE>(L, nullptr, col, nullptr, lane, llen, kb, 0, 0, inc);
           } else {
-            auto clr = [&](const bool *in, const int *key) {
+            auto clr = [&](const bool *in, const int *key, const int *) {
 #pragma unroll
               for (int q = 0; q < kTilesG; ++q)
                 if (in[q]) acc[key[q]] = 0u;
@@ -1205,6 +1205,208 @@ hipError_t launch_rect_work(const GraphView &g, const int *idx0, unsigned long l
 
 hipError_t launch_rect_acc(const RectAccParams &p, int grid_blocks, hipStream_t stream) {
   hipLaunchKernelGGL(rect_acc_kernel, dim3((unsigned)grid_blocks), dim3(256), 0, stream, p);
+  return hipGetLastError();
+}
+
+// ---- house by wedge accumulation ---------------------------------------------------------------------------------
+// Summing house.h:1-16 over v2 AND exchanging the sums over v1 and v3 (t(a,b) = |N(a) ^ N(b)|, S = N(v0) ^ N(v1)):
+//   house = A - B - C - D
+//   A = sum_{v0} sum_{v3 != v0} c(v0,v3) * w(v0,v3),   c = |N(v0) ^ N(v3)|,  w = sum_{v1 in N(v0)^N(v3), v1 < v0} t(v0,v1)
+//   B = sum_{(v0,v1), v1 < v0} t(v0,v1) * (d(v1) - 1)
+//   C = sum_{entries (v0 -> v3)} (t(v0,v3) - 1) * |{v1 in N(v0)^N(v3) : v1 < v0}|
+//   D = sum_{(v0,v1), v1 < v0} sum_{w in S} (t(v1,w) - 1)
+// (checked against the reference's goldens). A is ONE walk over the 2-paths v0 - v1 - v3 with a vertex-indexed 64-bit map
+// (count in the low 24 bits, weighted sum above): a returning atomic add of (delta << 24 | 1), delta = [v1 < v0] t(v0,v1),
+// yields the old (c, w) and the pair products telescope to c * w. B, C, D need the per-entry tables t and
+// tlt(v0 -> v1) = |{x in S : x < v0}| (edge_tab_kernel) and one more intersection per edge (D). No per-wedge intersections.
+__global__ __launch_bounds__(256) void edge_tab_kernel(GraphView g, unsigned *__restrict__ t, unsigned *__restrict__ tlt,
+                                                       unsigned long long *__restrict__ queue) {
+  __shared__ WaveLds W[kWavesPerBlock];
+  __shared__ int AUX[kWavesPerBlock][GM_WAVE];
+  const int *__restrict__ rp = g.rp;
+  const int *__restrict__ col = g.col;
+  const int lane = threadIdx.x & 63;
+  WaveLds &L = W[threadIdx.x >> 6];
+  int *v0s = AUX[threadIdx.x >> 6];
+  const unsigned long long nblk = ((unsigned long long)g.ne + 63ull) / 64ull;
+  for (;;) {
+    unsigned long long q = 0;
+    if (lane == 0) q = atomicAdd(queue, 1ull);
+    q = ((unsigned long long)(unsigned)readfirst((int)(q >> 32)) << 32) | (unsigned)readfirst((int)q);
+    if (q >= nblk) break;
+    const long long e = (long long)q * 64 + lane;
+    bool valid = e < (long long)g.ne;
+    int v0 = 0, v1 = 0;
+    if (valid) {
+      int lo = 0, hi = g.nv - 1;  // row of entry e
+      while (lo < hi) {
+        const int mid = (int)(((long long)lo + hi + 1) >> 1);
+        if (rp[mid] <= e) lo = mid; else hi = mid - 1;
+      }
+      v0 = lo;
+      v1 = col[e];
+      valid = v1 < v0;  // every undirected edge once; both directed entries are written below
+    }
+    int llen = 0, kb = 0, sb = 0, sl = 0;
+    if (valid) {
+      const int r0 = rp[v0], d0 = rp[v0 + 1] - r0, r1 = rp[v1], d1 = rp[v1 + 1] - r1;
+      if (d0 <= d1) { llen = d0; kb = r0; sb = r1; sl = d1; } else { llen = d1; kb = r1; sb = r0; sl = d0; }
+    }
+    L.cnt[lane] = 0u;
+    L.qkey[lane] = 0;             // common neighbours below v0
+    L.qkey[GM_WAVE + lane] = 0;   // ... below v1
+    L.qkey[2 * GM_WAVE + lane] = v1;
+    v0s[lane] = v0;
+    wave_sync();
+    auto act = [&](bool f, int owner, int, int, int, int key) {
+      if (!f) return;
+      atomicAdd(&L.cnt[owner], 1u);
+      if (key < v0s[owner]) atomicAdd(&L.qkey[owner], 1);
+      if (key < L.qkey[2 * GM_WAVE + owner]) atomicAdd(&L.qkey[GM_WAVE + owner], 1);
+    };
+    flat_pass<SEARCH_HBM>(L, nullptr, col, nullptr, lane, llen, kb, sb, sl, act);
+    wave_sync();
+    if (valid) {
+      const unsigned c = L.cnt[lane];
+      const long long e10 = (long long)rp[v1] + lower_bound(col + rp[v1], rp[v1 + 1] - rp[v1], v0);
+      t[e] = c;
+      tlt[e] = (unsigned)L.qkey[lane];
+      t[e10] = c;
+      tlt[e10] = (unsigned)L.qkey[GM_WAVE + lane];
+    }
+    wave_sync();
+  }
+}
+
+__global__ __launch_bounds__(256) void house_work_kernel(GraphView g, unsigned long long *__restrict__ work) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= g.nv) return;
+  unsigned long long w = 0;
+  for (int i = g.rp[v]; i < g.rp[v + 1]; ++i) {
+    const int x = g.col[i];
+    w += (unsigned long long)(g.rp[x + 1] - g.rp[x]) + 1ull;
+  }
+  work[v] = w;
+}
+
+__global__ __launch_bounds__(256) void house_acc_kernel(const HouseAccParams p) {
+  __shared__ WaveLds W[kWavesPerBlock];
+  __shared__ int AUX[kWavesPerBlock][GM_WAVE];
+  __shared__ int4 s_task;
+  __shared__ int s_next;
+  const int *__restrict__ rp = p.g.rp;
+  const int *__restrict__ col = p.g.col;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  WaveLds &L = W[wave];
+  int *aux = AUX[wave];
+  unsigned long long *acc_own = p.acc + ((size_t)blockIdx.x * kWavesPerBlock + wave) * p.acc_stride;
+  unsigned long long *acc_wg = p.acc + ((size_t)blockIdx.x * kWavesPerBlock) * p.acc_stride;
+  unsigned long long res = 0;  // A - B - C - D of this lane, modulo 2^64 (per centre the total is a count, >= 0)
+  for (;;) {
+    if (threadIdx.x == 0) {
+      const unsigned long long q = atomicAdd(p.queue, 1ull);
+      s_task = (q < p.count) ? p.tasks[p.first + q * p.step] : make_int4(-3, -3, -3, -3);
+      s_next = 0;
+    }
+    __syncthreads();
+    const int4 tk = s_task;
+    if (tk.x == -3) break;
+    const bool heavy = tk.y == -2;
+    const int v0 = heavy ? tk.x : (wave == 0 ? tk.x : wave == 1 ? tk.y : wave == 2 ? tk.z : tk.w);
+    unsigned long long *acc = heavy ? acc_wg : acc_own;
+    // phases: 0 = B, C, D (tables + one intersection per edge v1 < v0); 1 = the 2-path walk (A); 2 = clear the map
+    for (int phase = 0; phase < 3; ++phase) {
+      if (v0 >= 0) {
+        const int r0 = rp[v0], d0 = rp[v0 + 1] - r0;
+        int mine = 0;
+        for (;;) {
+          int bi = 0;
+          if (heavy) {
+            if (lane == 0) bi = atomicAdd(&s_next, 1);
+            bi = readfirst(bi);
+          } else {
+            bi = mine++;
+          }
+          if (bi * GM_WAVE >= d0) break;
+          const int i = bi * GM_WAVE + lane;
+          const bool valid = i < d0;
+          const int v1 = valid ? col[r0 + i] : 0;
+          const int r1 = rp[v1], d1 = rp[v1 + 1] - r1;
+          const unsigned te = valid ? p.t[r0 + i] : 0u;
+          if (phase == 0) {
+            const bool sb = valid && v1 < v0;
+            if (valid) res -= (unsigned long long)p.tlt[r0 + i] * (unsigned long long)(te - 1u + (te == 0u ? 1u : 0u));  // C (t = 0 => tlt = 0)
+            if (sb) res -= (unsigned long long)te * (unsigned long long)(d1 - 1);                                         // B
+            if (sb) res += (unsigned long long)te;                                                                        // the "- 1" of D
+            int llen = 0, kb = 0, sbase = 0, sl = 0;
+            if (sb && te > 0u) {
+              if (d1 <= d0) { llen = d1; kb = r1; sbase = r0; sl = d0 | (1 << 30); }  // keys from N(v1): flag 1, kidx = position in N(v1)
+              else { llen = d0; kb = r0; sbase = r1; sl = d1; }                       // keys from N(v0): pos = position in N(v1)
+            }
+            aux[lane] = r1;
+            wave_sync();
+            unsigned long long dsum = 0;
+            auto act = [&](bool f, int owner, int kidx, int pos, int flag, int) {
+              if (f) dsum += (unsigned long long)p.t[aux[owner] + (flag ? kidx : pos)];  // t(v1, w)
+            };
+            flat_pass<SEARCH_HBM>(L, nullptr, col, nullptr, lane, llen, kb, sbase, sl, act);
+            res -= dsum;  // D
+            wave_sync();
+          } else {
+            L.cnt[lane] = (valid && v1 < v0) ? te : 0u;  // delta of this entry's 2-paths
+            wave_sync();
+            const int llen = valid ? d1 : 0;
+            if (phase == 1) {
+              auto inc = [&](const bool *in, const int *key, const int *own) {
+#pragma unroll
+                for (int q = 0; q < kTilesG; ++q)
+                  if (in[q] && key[q] != v0) {
+                    const unsigned long long delta = (unsigned long long)L.cnt[own[q] - 1];
+                    const unsigned long long old = __hip_atomic_fetch_add(&acc[key[q]], (delta << 24) | 1ull, __ATOMIC_RELAXED,
+                                                                          __HIP_MEMORY_SCOPE_WORKGROUP);
+                    res += delta * (old & 0xffffffull) + (old >> 24) + delta;  // A
+                  }
+              };
+              flat_pass<SEARCH_NONE>(L, nullptr, col, nullptr, lane, llen, r1, 0, 0, inc);
+            } else {
+              auto clr = [&](const bool *in, const int *key, const int *) {
+#pragma unroll
+                for (int q = 0; q < kTilesG; ++q)
+                  if (in[q]) acc[key[q]] = 0ull;
+              };
+              flat_pass<SEARCH_NONE>(L, nullptr, col, nullptr, lane, llen, r1, 0, 0, clr);
+            }
+            wave_sync();
+          }
+        }
+      }
+      if (heavy) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_next = 0;
+        __threadfence_block();
+        __syncthreads();
+      } else {
+        __threadfence_block();
+      }
+    }
+    __syncthreads();
+  }
+  const unsigned long long s0 = wave_sum_u64(res);
+  if (lane == 0 && s0) atomicAdd(&p.counters[0], s0);
+}
+
+hipError_t launch_edge_tab(const GraphView &g, unsigned *t, unsigned *tlt, unsigned long long *queue, int grid_blocks, hipStream_t stream) {
+  hipLaunchKernelGGL(edge_tab_kernel, dim3((unsigned)grid_blocks), dim3(256), 0, stream, g, t, tlt, queue);
+  return hipGetLastError();
+}
+
+hipError_t launch_house_work(const GraphView &g, unsigned long long *work, hipStream_t stream) {
+  hipLaunchKernelGGL(house_work_kernel, dim3((unsigned)((g.nv + 255) / 256)), dim3(256), 0, stream, g, work);
+  return hipGetLastError();
+}
+
+hipError_t launch_house_acc(const HouseAccParams &p, int grid_blocks, hipStream_t stream) {
+  hipLaunchKernelGGL(house_acc_kernel, dim3((unsigned)grid_blocks), dim3(256), 0, stream, p);
   return hipGetLastError();
 }
 

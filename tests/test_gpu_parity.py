@@ -119,9 +119,12 @@ def test_sgl_nested_patterns_match_reference(gg, pattern):
         assert SglSolver(sym, pattern, tune=[0, 0, 0, 0, 0, 0, 2048]) == e[pattern]
         assert SglSolver(sym, pattern, tune=[0, 0, 0, 0, 0, 0, 1024]) == e[pattern]
         assert SglSolver(sym, pattern) == e[pattern]  # (the counter maps are left zeroed by every launch)
-    if pattern == "house":  # the other two implementations: rows too long for the LDS S-bitmap; one wave per edge
-        assert SglSolver(sym, pattern, tune=[0, 0, 0, 0, 0, 0, 2048]) == e[pattern]
+    if pattern == "house":  # the other implementations: flattened (v0,v1,v3) form with / without the LDS S-bitmap; one wave per edge
+        assert SglSolver(sym, pattern, tune=[0, 0, 0, 0, 0, 0, 0x800]) == e[pattern]
+        assert SglSolver(sym, pattern, tune=[0, 0, 0, 0, 0, 0, 0x8000]) == e[pattern]
+        assert SglSolver(sym, pattern, tune=[0, 0, 0, 0, 0, 0, 0x800 | 0x200]) == e[pattern]
         assert SglSolver(sym, pattern, tune=[0, 0, 0, 0, 0, 0, 1024]) == e[pattern]
+        assert SglSolver(sym, pattern) == e[pattern]  # (the maps are left zeroed by every launch)
 
 
 def test_house_hub_row_longer_than_lds_bitmap():
@@ -137,7 +140,8 @@ def test_house_hub_row_longer_than_lds_bitmap():
     with DeviceGraph.upload(g) as sym:
         flat = SglSolver(sym, "house")
         assert flat == SglSolver(sym, "house", tune=[0, 0, 0, 0, 0, 0, 1024])
-        assert flat == SglSolver(sym, "house", tune=[0, 0, 0, 0, 0, 0, 2048])
+        assert flat == SglSolver(sym, "house", tune=[0, 0, 0, 0, 0, 0, 0x800])
+        assert flat == SglSolver(sym, "house", tune=[0, 0, 0, 0, 0, 0, 0x8000])
         assert flat == sum(SglSolver(sym, "house", rank=r, world=3) for r in range(3))
 
 
