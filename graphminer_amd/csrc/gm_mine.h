@@ -26,7 +26,11 @@ constexpr int kFilterLog2 = GM_FILTER_LOG2;           // hashed membership filte
 constexpr int kFilterBits = 1 << kFilterLog2;
 constexpr int kFilterWords = kFilterBits / 32;
 constexpr int kQueueCap = 64 * (GM_TILES_DEFAULT + 1);  // candidate queue entries per wave (63 left over + kTiles tiles)
-constexpr int kBitWords = 2048;           // clique: LDS words for the per-chunk adjacency bit-matrix (8 KB)
+#ifndef GM_BIT_WORDS
+#define GM_BIT_WORDS 2048
+#endif
+constexpr int kBitWords = GM_BIT_WORDS;  // clique: LDS words for the per-chunk adjacency bit-matrix (8 KB)
+static_assert(GM_BIT_WORDS >= 2048 && GM_BIT_WORDS % 64 == 0, "rows of up to 2048 columns (stride 64) need 32 of them in one LDS group / tile");
 
 // Task chunk = a contiguous vertex range [u_begin,u_end) and the CSR entries [e_begin,e_end) it owns.
 // Normal chunks own whole rows (e_begin == rp[u_begin], e_end == rp[u_end]); a row longer than the
