@@ -87,6 +87,7 @@ __device__ __forceinline__ unsigned filter_salt(int local_row) { return ((unsign
 // branch-free "binary lifting" form with a wave-uniform trip count (bit length of the longest
 // search list of the pass): no exec-mask juggling, only v_cmp/v_cndmask and one load per step.
 constexpr int kTiles = GM_TILES;  // filtered LDS pass (X): tiles resolved together per wave
+static_assert(GM_TILES == 2 || GM_TILES == 4, "the mark window / queue arithmetic assumes a power-of-two tile group (3 miscounts)");
 constexpr int kTilesG = 4;        // passes that bisect / probe in HBM (Y, SPLIT chunks): more loads in flight pay off
 
 // MODE: how membership of a key in the search list is decided
