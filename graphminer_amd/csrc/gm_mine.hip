@@ -72,6 +72,8 @@ __device__ __forceinline__ unsigned filter_hash(int x, unsigned salt) {
 #define GM_SPLIT_FL2 16
 #endif
 constexpr int kSplitFilterLog2 = GM_SPLIT_FL2;
+// (a second, independent 2^15-bit filter in the stage's last 4 KB was measured: diamond R-MAT-22 28.2 -> 26.2 ms, 3-motif 460 -> 449 ms,
+// but diamond R-MAT-20 10.3 -> 11.3 ms -- not kept)
 constexpr int kSplitFilterMaxRow = 1 << 16;  // longer rows: the filter would pass > 60 % -- probe the bitmap directly
 __device__ __forceinline__ unsigned filter_salt(int local_row) { return ((unsigned)local_row * 0x2545u) & (unsigned)(kFilterBits - 1); }
 
