@@ -37,7 +37,7 @@ WORKLOADS = {
     "motif3": (24, 16, False, "3-motif, R-MAT scale 24"),
     "rectangle": (16, 16, False, "sgl rectangle (4-cycle), R-MAT scale 16"),
     "house": (16, 16, False, "sgl house, R-MAT scale 16"),
-    "pentagon": (14, 8, False, "sgl pentagon, R-MAT scale 14"),
+    "pentagon": (16, 16, False, "sgl pentagon, R-MAT scale 16"),
     "clique5": (20, 16, True, "5-clique, R-MAT scale 20"),
     "motif3f": (24, 16, False, "3-motif, formula variant (motif_gpu_formula), R-MAT scale 24"),
 }

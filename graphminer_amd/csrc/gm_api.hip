@@ -148,6 +148,8 @@ struct gm_graph {
   unsigned long long n_house_tasks = 0;
   unsigned long long *d_house_acc = nullptr;
   size_t house_acc_bytes = 0;
+  int *d_pent_touched = nullptr;         // pentagon by wedge accumulation: touched-vertex lists (same shape as d_rect_acc)
+  size_t pent_touched_bytes = 0;
   unsigned long long *d_house_prefix = nullptr;  // house: per-entry task-block prefix
   unsigned long long n_house_blocks = 0;   // handle whose event ring holds this handle's most recent launch
   unsigned long long sum_c2 = 0;          // sum_v C(d(v),2)
@@ -183,6 +185,7 @@ extern "C" void gm_graph_free(gm_graph *g) {
   if (g->d_idx0) (void)hipFree(g->d_idx0);
   if (g->d_wblock_prefix) (void)hipFree(g->d_wblock_prefix);
   if (g->d_house_prefix) (void)hipFree(g->d_house_prefix);
+  if (g->d_pent_touched) (void)hipFree(g->d_pent_touched);
   if (g->d_house_t) (void)hipFree(g->d_house_t);
   if (g->d_house_tlt) (void)hipFree(g->d_house_tlt);
   if (g->d_house_tasks) (void)hipFree(g->d_house_tasks);
@@ -819,7 +822,7 @@ extern "C" int gm_chunk_table(int32_t nv, const int64_t *row_ptr, int32_t chunk,
 // ------------------------------------------------------------------------------------------------
 // solvers
 // ------------------------------------------------------------------------------------------------
-enum FinMode : int { FIN_COPY = 0, FIN_MOTIF3 = 1, FIN_MOTIF3_FORMULA = 2, FIN_RAW4 = 3 };
+enum FinMode : int { FIN_COPY = 0, FIN_MOTIF3 = 1, FIN_MOTIF3_FORMULA = 2, FIN_RAW4 = 3, FIN_HALF_SIGNED = 4 };
 
 __global__ void finalize_kernel(int mode, unsigned long long base, const unsigned long long *__restrict__ c,
                                 unsigned long long *__restrict__ out) {
@@ -832,6 +835,8 @@ __global__ void finalize_kernel(int mode, unsigned long long base, const unsigne
     out[1] = c[0];
   } else if (mode == FIN_RAW4) {
     out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+  } else if (mode == FIN_HALF_SIGNED) {
+    out[0] = (unsigned long long)((long long)c[0] >> 1);  // an even two's-complement sum (pent_acc_kernel): rank partials add up mod 2^64
   } else {
     out[0] = c[0];
   }
@@ -895,6 +900,8 @@ static int end_launch(LaunchCtx &c, int fin_mode, unsigned long long fin_base, u
     if (nout > 1) h_out[1] = v[0];
   } else if (fin_mode == FIN_RAW4) {
     for (int i = 0; i < 4 && i < nout; ++i) h_out[i] = v[i];
+  } else if (fin_mode == FIN_HALF_SIGNED) {
+    h_out[0] = (uint64_t)((long long)v[0] >> 1);
   } else {
     h_out[0] = v[0];
   }
@@ -1154,8 +1161,10 @@ static int run_rect_flat(const gm_graph *cg, const gm_launch *la_in, uint64_t *h
   return end_launch(ctx, FIN_COPY, 0, h_out, 1, st);
 }
 
-// rectangle by wedge accumulation (rect_acc_kernel in gm_mine.hip)
-static int run_rect_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h_out, gm_stats *st) {
+static int ensure_edge_tables(gm_graph *g, const GraphView &gv);
+
+// rectangle (rect_acc_kernel) and pentagon (pent_acc_kernel) by wedge accumulation: same centres, same counter maps
+static int run_rect_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h_out, gm_stats *st, bool pentagon = false) {
   LaunchCtx ctx;
   int rc = begin_launch(cg, la_in, h_out, ctx);
   if (rc) return rc;
@@ -1226,11 +1235,58 @@ static int run_rect_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h_
     g->rect_acc_bytes = need;
   }
   p.acc = g->d_rect_acc;
+  if (pentagon) {
+    rc = ensure_edge_tables(g, gv);
+    if (rc) return rc;
+    if (need > g->pent_touched_bytes) {  // (same shape as the maps: one int list of up to nv entries per wave)
+      if (g->d_pent_touched) (void)hipFree(g->d_pent_touched);
+      g->d_pent_touched = nullptr;
+      g->pent_touched_bytes = 0;
+      HIP_TRY(hipMalloc(&g->d_pent_touched, need));
+      g->pent_touched_bytes = need;
+    }
+    PentAccParams q;
+    memset(&q, 0, sizeof q);
+    q.g = gv;
+    q.idx0 = g->d_idx0;
+    q.tlt = g->d_house_tlt;
+    q.tasks = p.tasks;
+    q.first = p.first;
+    q.step = p.step;
+    q.count = p.count;
+    q.acc = p.acc;
+    q.touched = g->d_pent_touched;
+    q.acc_stride = p.acc_stride;
+    q.queue = p.queue;
+    q.counters = p.counters;
+    rc = start_timer(ctx);
+    if (rc) return rc;
+    if (count > 0) HIP_TRY(launch_pent_acc(q, (int)grid, ctx.stream));
+    fill_stats(st, (uint64_t)(g->ne / 2 / ctx.world), (uint64_t)count, (int)grid, 256);
+    return end_launch(ctx, FIN_HALF_SIGNED, 0, h_out, 1, st);
+  }
   rc = start_timer(ctx);
   if (rc) return rc;
   if (count > 0) HIP_TRY(launch_rect_acc(p, (int)grid, ctx.stream));
   fill_stats(st, (uint64_t)(g->ne / 2 / ctx.world), (uint64_t)count, (int)grid, 256);
   return end_launch(ctx, FIN_COPY, 0, h_out, 1, st);
+}
+
+// per-entry triangle tables t / tlt (edge_tab_kernel), once per graph; every rank builds the whole tables: they are inputs of
+// every centre of the house / pentagon map kernels
+static int ensure_edge_tables(gm_graph *g, const GraphView &gv) {
+  if (g->d_house_t && g->d_house_tlt) return GM_OK;
+  const size_t ne1 = (size_t)std::max<long long>(g->ne, 1);
+  HIP_TRY(hipMalloc(&g->d_house_t, sizeof(unsigned) * ne1));
+  HIP_TRY(hipMalloc(&g->d_house_tlt, sizeof(unsigned) * ne1));
+  if (g->ne > 0) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemset(g->d_counters, 0, 64));
+    HIP_TRY(launch_edge_tab(gv, g->d_house_t, g->d_house_tlt, g->d_counters + 4, g->cu_count * 8, 0));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemset(g->d_counters, 0, 64));  // (the table kernel used the dequeue head)
+  }
+  return GM_OK;
 }
 
 // house by wedge accumulation (edge_tab_kernel + house_acc_kernel in gm_mine.hip)
@@ -1245,16 +1301,9 @@ static int run_house_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h
   gv.ne = (int)g->ne;
   gv.rp = g->d_rp;
   gv.col = g->d_col;
-  const size_t ne1 = (size_t)std::max<long long>(g->ne, 1);
-  if (!g->d_house_tasks) {  // once per graph (every rank builds the whole tables: they are inputs of every centre)
-    HIP_TRY(hipMalloc(&g->d_house_t, sizeof(unsigned) * ne1));
-    HIP_TRY(hipMalloc(&g->d_house_tlt, sizeof(unsigned) * ne1));
-    HIP_TRY(hipMemset(g->d_counters, 0, 64));
-    if (g->ne > 0) {
-      HIP_TRY(launch_edge_tab(gv, g->d_house_t, g->d_house_tlt, g->d_counters + 4, g->cu_count * 8, 0));
-      HIP_TRY(hipDeviceSynchronize());
-      HIP_TRY(hipMemset(g->d_counters, 0, 64));  // (the table kernel used the dequeue head)
-    }
+  rc = ensure_edge_tables(g, gv);
+  if (rc) return rc;
+  if (!g->d_house_tasks) {  // once per graph
     const size_t nv = (size_t)g->nv;
     unsigned long long *d_work = nullptr;
     HIP_TRY(hipMalloc(&d_work, sizeof(unsigned long long) * std::max<size_t>(nv, 1)));
@@ -1425,7 +1474,7 @@ extern "C" int gm_sgl(const gm_graph *sym, const char *pattern, const gm_launch 
     const int t6 = la ? la->tune[6] : 0;
     gm_graph *self = const_cast<gm_graph *>(sym);
     const gm_graph *run_on = sym;
-    const bool wedge_form = is_pent || (is_rect && (t6 & 2048));  // anchored wedges: hubs first; 2-path / (v0,v1,v3) forms: hubs last
+    const bool wedge_form = (is_pent || is_rect) && (t6 & 2048);  // anchored wedges: hubs first; 2-path / (v0,v1,v3) forms: hubs last
     // house: by wedge accumulation (default; its 2-path count does not depend on the numbering, so no renumbered copy), or
     // the flattened (v0, v1, v3) form (0x800; 0x8000: without the LDS S-bitmap). The packed map holds 24-bit counts and
     // 40-bit weighted sums: rows of 2^20 entries or more take the flattened form.
@@ -1440,7 +1489,8 @@ extern "C" int gm_sgl(const gm_graph *sym, const char *pattern, const gm_launch 
     if (t6 & 1024) rc = run_sgl_nested(is_rect ? SGL_RECTANGLE : is_house ? SGL_HOUSE : SGL_PENTAGON, run_on, la, total, st);
     else if (house_acc) rc = run_house_acc(run_on, la, total, st);
     else if (is_house) rc = run_house_flat(run_on, la, total, st);
-    else if (is_pent) rc = run_rect_flat(run_on, la, total, st, true);
+    else if (is_pent && (t6 & 2048)) rc = run_rect_flat(run_on, la, total, st, true);
+    else if (is_pent) rc = run_rect_acc(run_on, la, total, st, true);
     else if (t6 & 2048) rc = run_rect_flat(run_on, la, total, st);
     else rc = run_rect_acc(run_on, la, total, st);
     self->ring_alias = (run_on != sym) ? const_cast<gm_graph *>(run_on) : nullptr;

@@ -191,6 +191,21 @@ hipError_t launch_edge_tab(const GraphView &g, unsigned *t, unsigned *tlt, unsig
 hipError_t launch_house_acc(const HouseAccParams &p, int grid_blocks, hipStream_t stream);
 hipError_t launch_house_work(const GraphView &g, unsigned long long *work, hipStream_t stream);
 
+// pentagon by wedge accumulation (gm_mine.hip): the rectangle counter map + a walk over the touched vertices
+struct PentAccParams {
+  GraphView g;
+  const int *idx0;
+  const unsigned *tlt;  // per CSR entry (v0 -> v1): |{x in N(v0) ^ N(v1) : x < v0}|
+  const int4 *tasks;
+  unsigned long long first, step, count;
+  unsigned *acc;   // one zeroed counter map per wave: grid * 4 * acc_stride
+  int *touched;    // one list per wave (same stride): the vertices whose counter is non-zero
+  unsigned long long acc_stride;
+  unsigned long long *queue;
+  unsigned long long *counters;
+};
+hipError_t launch_pent_acc(const PentAccParams &p, int grid_blocks, hipStream_t stream);
+
 // flattened house (gm_mine.hip): tasks are (v0, v1, v3) with v1 < v0 in N(v0), v3 in N(v1) \ {v0}, 64 v3 per wave
 struct HouseParams {
   GraphView g;

@@ -1413,6 +1413,143 @@ hipError_t launch_house_acc(const HouseAccParams &p, int grid_blocks, hipStream_
   return hipGetLastError();
 }
 
+// ---- pentagon by wedge accumulation --------------------------------------------------------------------------------
+// pentagon.h:2-17 counts every 5-cycle once, at its largest vertex v0. With M = {b in N(v0) : b < v0} and the rectangle
+// kernel's map cm[x] = |N(x) ^ M| (x < v0), the closed walks v0 - a - x - y - b - v0 (a, b in M; x ~ y; x, y < v0) number
+//   W(v0) = sum_{x < v0} cm[x] * sum_{y in N(x), y < v0} cm[y];
+// a 5-cycle is two of them, the rest repeat a vertex (a = b: a triangle under v0; a = y or x = b: an edge inside M):
+//   2 pentagon = sum_{v0} [ W - 2 N2 + N23 ] - N1,    N2 = sum_{a in M} |{x in N(a) : x < v0}| * |N(a) ^ M|,   N23 = sum_{a in M} |N(a) ^ M|,
+//   N1 = 2 sum_{edges x < y} [ tlo (above(x,y) + d(y) - idx0(y)) + tmid above(x,y) ],   above(x,y) = |{z in N(x) : z > y}|,
+// with tlo / tmid = common neighbours of x, y below x / between them (both from the tlt table: tlt(x->y) and tlt(y->x) - tlt(x->y)),
+// |N(a) ^ M| = tlt(v0->a). (Checked against the reference's goldens.) Per centre: one 2-path walk that fills the map and
+// lists the touched vertices, one walk over the rows of the touched vertices, a row of table arithmetic, one clearing pass --
+// no intersections at all. The N1 terms are grouped by the row of the edge's larger endpoint, so a centre's contribution is an
+// even, possibly negative integer: the 64-bit sum is kept in two's complement and halved (arithmetically) at the end.
+__global__ __launch_bounds__(256) void pent_acc_kernel(const PentAccParams p) {
+  __shared__ WaveLds W[kWavesPerBlock];
+  __shared__ int4 s_task;
+  __shared__ int s_next, s_ntouched;
+  __shared__ int s_wtouched[kWavesPerBlock];
+  const int *__restrict__ rp = p.g.rp;
+  const int *__restrict__ col = p.g.col;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  WaveLds &L = W[wave];
+  const size_t slot_own = (size_t)blockIdx.x * kWavesPerBlock + wave, slot_wg = (size_t)blockIdx.x * kWavesPerBlock;
+  long long res = 0;
+  for (;;) {
+    if (threadIdx.x == 0) {
+      const unsigned long long q = atomicAdd(p.queue, 1ull);
+      s_task = (q < p.count) ? p.tasks[p.first + q * p.step] : make_int4(-3, -3, -3, -3);
+      s_next = 0;
+      s_ntouched = 0;
+    }
+    if (lane == 0) s_wtouched[wave] = 0;
+    __syncthreads();
+    const int4 tk = s_task;
+    if (tk.x == -3) break;
+    const bool heavy = tk.y == -2;
+    const int v0 = heavy ? tk.x : (wave == 0 ? tk.x : wave == 1 ? tk.y : wave == 2 ? tk.z : tk.w);
+    unsigned *acc = p.acc + (heavy ? slot_wg : slot_own) * p.acc_stride;
+    int *touched = p.touched + (heavy ? slot_wg : slot_own) * p.acc_stride;
+    int *ntouched = heavy ? &s_ntouched : &s_wtouched[wave];
+    // phases: 0 = fill the map over the 2-paths v0 - b - x and list the touched x; 1 = W over the touched rows and the
+    // table terms of the entries (v0 -> a), a < v0; 2 = clear the map
+    for (int phase = 0; phase < 3; ++phase) {
+      if (v0 >= 0) {
+        const int r0 = rp[v0], n0 = p.idx0[v0], d0 = rp[v0 + 1] - r0;
+        const int nt = (phase == 0) ? 0 : *ntouched;          // (written in phase 0, barrier / fence in between)
+        const int nitems = (phase == 0) ? n0 : nt;            // entries b in M  /  touched vertices
+        int mine = 0;
+        for (;;) {
+          int bi = 0;
+          if (heavy) {
+            if (lane == 0) bi = atomicAdd(&s_next, 1);
+            bi = readfirst(bi);
+          } else {
+            bi = mine++;
+          }
+          if (bi * GM_WAVE >= nitems) break;
+          const int i = bi * GM_WAVE + lane;
+          const bool valid = i < nitems;
+          if (phase == 0) {
+            int llen = 0, kb = 0;
+            if (valid) {
+              const int b = col[r0 + i];
+              kb = rp[b];
+              llen = lower_bound(col + kb, rp[b + 1] - kb, v0);
+            }
+            auto inc = [&](const bool *in, const int *key, const int *) {
+#pragma unroll
+              for (int q = 0; q < kTilesG; ++q) {
+                bool first = false;
+                if (in[q]) first = __hip_atomic_fetch_add(&acc[key[q]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u;
+                const unsigned long long m = __ballot(first);
+                if (m) {  // wave-uniform: append the newly touched vertices
+                  int base = 0;
+                  if (lane == 0) base = atomicAdd(ntouched, __popcll(m));
+                  base = readfirst(base);
+                  if (first) touched[base + rank_below(m)] = key[q];
+                }
+              }
+            };
+            flat_pass<SEARCH_NONE>(L, nullptr, col, nullptr, lane, llen, kb, 0, 0, inc);
+          } else {
+            const int x = valid ? touched[i] : 0;
+            if (phase == 1) {
+              const int rx = rp[x];
+              const int llen = valid ? lower_bound(col + rx, rp[x + 1] - rx, v0) : 0;
+              L.cnt[lane] = valid ? __hip_atomic_load(&acc[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;  // cm[x] (not through L1)
+              wave_sync();
+              auto walk = [&](const bool *in, const int *key, const int *own) {
+#pragma unroll
+                for (int q = 0; q < kTilesG; ++q)
+                  if (in[q]) {
+                    const unsigned cy = __hip_atomic_load(&acc[key[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    res += (long long)((unsigned long long)L.cnt[own[q] - 1] * (unsigned long long)cy);  // W
+                  }
+              };
+              flat_pass<SEARCH_NONE>(L, nullptr, col, nullptr, lane, llen, rx, 0, 0, walk);
+              wave_sync();
+            } else if (valid) {
+              acc[x] = 0u;
+            }
+          }
+        }
+        if (phase == 1) {  // table terms of the entries (v0 -> a), a < v0 (lanes / waves stride them; no flat pass needed)
+          const int wstep = heavy ? kWavesPerBlock * GM_WAVE : GM_WAVE, wfirst = heavy ? (int)threadIdx.x : lane;
+          for (int i = wfirst; i < n0; i += wstep) {
+            const int e = r0 + i, a = col[e];
+            const int ra = rp[a], da = rp[a + 1] - ra;
+            const int pos = lower_bound(col + ra, da, v0);  // = |{x in N(a) : x < v0}|, and the entry (a -> v0) is ra + pos
+            const long long tl = (long long)p.tlt[e];       // common neighbours below v0 = |N(a) ^ M| = tlo + tmid
+            const long long tlo = (long long)p.tlt[ra + pos];
+            const long long above = (long long)(da - pos - 1);
+            res += tl - 2ll * (long long)pos * tl;                                                   // N23 - 2 N2
+            res -= 2ll * (tlo * (above + (long long)(d0 - n0)) + (tl - tlo) * above);             // N1, row v0
+          }
+        }
+      }
+      if (heavy) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_next = 0;
+        __threadfence_block();
+        __syncthreads();
+      } else {
+        __threadfence_block();
+        wave_sync();
+      }
+    }
+    __syncthreads();
+  }
+  const unsigned long long s0 = wave_sum_u64((unsigned long long)res);
+  if (lane == 0 && s0) atomicAdd(&p.counters[0], s0);
+}
+
+hipError_t launch_pent_acc(const PentAccParams &p, int grid_blocks, hipStream_t stream) {
+  hipLaunchKernelGGL(pent_acc_kernel, dim3((unsigned)grid_blocks), dim3(256), 0, stream, p);
+  return hipGetLastError();
+}
+
 // ---- house, flattened ----------------------------------------------------------------------------------------
 // src/sgl/cpu_kernels/house.h:1-16:  for v0, v1 in N(v0) (v1 < v0), S = N(v0) ^ N(v1), v2 in S, v3 in N(v1) \ {v0, v2}:
 //                                        count += |N(v0) ^ N(v3) \ {v1, v2}|

@@ -101,7 +101,7 @@ typedef struct gm_launch {
                          [7] bits 0..7 xb*16+yb, bits 8.. price of a pass-Y key against a bitmapped row (0 = as a bisection).
                          [6] bit mask. Alternative implementations (same counts): 0x100 mining kernels ignore the hub bitmaps,
                          0x200 SgL on the graph as numbered (no degree renumbering), 0x400 SgL wave-per-edge loop nests,
-                         0x800 rectangle as wedges + flat intersections / house flattened over (v0,v1,v3), 0x1000 cut
+                         0x800 rectangle / pentagon as wedges + flat intersections, house flattened over (v0,v1,v3), 0x1000 cut
                          chunks into parts eagerly, 0x2000 swap the two dequeue orders, 0x4000 plain chunk-id order.
                          Ablation (mining kernels): 0x1 skip clique phase 2, 0x2 skip bit-matrix writes, 0x4 no filter,
                          0x8 / 0x10 / 0x20 filtered-pass stages, 0x40 skip SPLIT chunks, 0x80 only SPLIT chunks,
