@@ -365,6 +365,24 @@ def test_hub_paths_against_oracle_rmat16(dev):
     assert MotifSolver(s, 4) == [503764659200, 122696041276, 48153202316, 1160147308, 3513532002, 292680292]
 
 
+@pytest.mark.parametrize("pattern", ["rectangle", "house", "pentagon"])
+def test_sgl_map_kernels_match_flat_kernels_rmat14(dev, pattern):
+    """R-MAT-14 (ef 16, max degree 3.6 K: heavy centres use all four waves on one map): the wedge-accumulation kernels against
+    the flattened-intersection kernels (independent implementations), as numbered and on the renumbered copies, and across
+    rank shares"""
+    g = rmat_csr_numpy(14, 16, 42)
+    s = g.to_device(dev)
+    want = SglSolver(s, pattern, tune=[0, 0, 0, 0, 0, 0, 0x800])
+    if pattern == "rectangle":
+        assert want == GOLDEN[g.name]["rectangle"]
+    assert SglSolver(s, pattern) == want
+    assert SglSolver(s, pattern, tune=[0, 0, 0, 0, 0, 0, 0x200]) == want
+    assert SglSolver(s, pattern, tune=[0, 0, 0, 0, 0, 0, 0x800 | 0x200]) == want
+    assert sum(SglSolver(s, pattern, rank=r, world=8) for r in range(8)) % 2**64 == want
+    assert sum(SglSolver(s, pattern, rank=r, world=3, policy=1) for r in range(3)) % 2**64 == want
+    assert SglSolver(s, pattern) == want
+
+
 def test_rmat_device_generator_equals_numpy(dev):
     from graphminer_amd.rmat import rmat_csr_device
 
