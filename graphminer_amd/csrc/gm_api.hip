@@ -1235,16 +1235,17 @@ static int run_rect_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h_
     g->rect_acc_bytes = need;
   }
   p.acc = g->d_rect_acc;
+  if (need > g->pent_touched_bytes) {  // touched-vertex lists: same shape as the maps (one int list of up to nv entries per wave)
+    if (g->d_pent_touched) (void)hipFree(g->d_pent_touched);
+    g->d_pent_touched = nullptr;
+    g->pent_touched_bytes = 0;
+    HIP_TRY(hipMalloc(&g->d_pent_touched, need));
+    g->pent_touched_bytes = need;
+  }
+  p.touched = g->d_pent_touched;
   if (pentagon) {
     rc = ensure_edge_tables(g, gv);
     if (rc) return rc;
-    if (need > g->pent_touched_bytes) {  // (same shape as the maps: one int list of up to nv entries per wave)
-      if (g->d_pent_touched) (void)hipFree(g->d_pent_touched);
-      g->d_pent_touched = nullptr;
-      g->pent_touched_bytes = 0;
-      HIP_TRY(hipMalloc(&g->d_pent_touched, need));
-      g->pent_touched_bytes = need;
-    }
     PentAccParams q;
     memset(&q, 0, sizeof q);
     q.g = gv;

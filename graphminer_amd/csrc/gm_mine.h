@@ -167,6 +167,7 @@ struct RectAccParams {
   const int4 *tasks;                      // {v0, -2, -2, -2}: heavy centre, all 4 waves; else up to 4 light centres (-1 = none)
   unsigned long long first, step, count;  // this rank owns tasks first + i*step
   unsigned *acc;                          // one zeroed counter map per wave: grid * 4 * acc_stride
+  int *touched;                           // one list per wave (same stride): the vertices whose counter is non-zero
   unsigned long long acc_stride;
   unsigned long long *queue;
   unsigned long long *counters;

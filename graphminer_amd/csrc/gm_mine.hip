@@ -1127,29 +1127,36 @@ __global__ __launch_bounds__(256) void rect_work_kernel(GraphView g, const int *
 __global__ __launch_bounds__(256) void rect_acc_kernel(const RectAccParams p) {
   __shared__ WaveLds W[kWavesPerBlock];
   __shared__ int4 s_task;
-  __shared__ int s_next;
+  __shared__ int s_next, s_ntouched;
+  __shared__ int s_wtouched[kWavesPerBlock];
   const int *__restrict__ rp = p.g.rp;
   const int *__restrict__ col = p.g.col;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   WaveLds &L = W[wave];
-  unsigned *acc_own = p.acc + ((size_t)blockIdx.x * kWavesPerBlock + wave) * p.acc_stride;
-  unsigned *acc_wg = p.acc + ((size_t)blockIdx.x * kWavesPerBlock) * p.acc_stride;
+  const size_t slot_own = (size_t)blockIdx.x * kWavesPerBlock + wave, slot_wg = (size_t)blockIdx.x * kWavesPerBlock;
   unsigned long long cnt = 0;
   for (;;) {
     if (threadIdx.x == 0) {
       const unsigned long long q = atomicAdd(p.queue, 1ull);
       s_task = (q < p.count) ? p.tasks[p.first + q * p.step] : make_int4(-3, -3, -3, -3);
       s_next = 0;
+      s_ntouched = 0;
     }
+    if (lane == 0) s_wtouched[wave] = 0;
     __syncthreads();
     const int4 t = s_task;
     if (t.x == -3) break;
     const bool heavy = t.y == -2;
     const int v0 = heavy ? t.x : (wave == 0 ? t.x : wave == 1 ? t.y : wave == 2 ? t.z : t.w);
-    unsigned *acc = heavy ? acc_wg : acc_own;
+    unsigned *acc = p.acc + (heavy ? slot_wg : slot_own) * p.acc_stride;
+    int *touched = p.touched + (heavy ? slot_wg : slot_own) * p.acc_stride;
+    int *ntouched = heavy ? &s_ntouched : &s_wtouched[wave];
+    // phase 0: the 2-path walk (every increment adds the counter's old value; a vertex whose old value is 0 is listed);
+    // phase 1: the listed counters are cleared (one store per touched vertex instead of a second walk over the 2-paths)
     for (int phase = 0; phase < 2; ++phase) {
       if (v0 >= 0) {
-        const int r0 = rp[v0], n0 = p.idx0[v0];
+        const int r0 = rp[v0];
+        const int nitems = (phase == 0) ? p.idx0[v0] : *ntouched;
         int mine = 0;
         for (;;) {
           int bi = 0;
@@ -1159,30 +1166,38 @@ __global__ __launch_bounds__(256) void rect_acc_kernel(const RectAccParams p) {
           } else {
             bi = mine++;
           }
-          if (bi * GM_WAVE >= n0) break;
+          if (bi * GM_WAVE >= nitems) break;
           const int i = bi * GM_WAVE + lane;
-          int llen = 0, kb = 0;
-          if (i < n0) {
-            const int x = col[r0 + i];
-            kb = rp[x];
-            llen = lower_bound(col + kb, rp[x + 1] - kb, v0);  // {w in N(x) : w < v0}
-          }
           if (phase == 0) {
+            int llen = 0, kb = 0;
+            if (i < nitems) {
+              const int x = col[r0 + i];
+              kb = rp[x];
+              llen = lower_bound(col + kb, rp[x + 1] - kb, v0);  // {w in N(x) : w < v0}
+            }
             // (measured: issuing the four returning atomics of a tile group back to back is ~5 % SLOWER than one at a
             // time -- the map updates are bound by the L2 atomic units, not by latency)
             auto inc = [&](const bool *in, const int *key, const int *) {
 #pragma unroll
-              for (int q = 0; q < kTilesG; ++q)
-                if (in[q]) cnt += (unsigned long long)__hip_atomic_fetch_add(&acc[key[q]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              for (int q = 0; q < kTilesG; ++q) {
+                bool first = false;
+                if (in[q]) {
+                  const unsigned old = __hip_atomic_fetch_add(&acc[key[q]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                  cnt += (unsigned long long)old;
+                  first = old == 0u;
+                }
+                const unsigned long long m = __ballot(first);
+                if (m) {  // wave-uniform
+                  int base = 0;
+                  if (lane == 0) base = atomicAdd(ntouched, __popcll(m));
+                  base = readfirst(base);
+                  if (first) touched[base + rank_below(m)] = key[q];
+                }
+              }
             };
             flat_pass<SEARCH_NONE>(L, nullptr, col, nullptr, lane, llen, kb, 0, 0, inc);
-          } else {
-            auto clr = [&](const bool *in, const int *key, const int *) {
-#pragma unroll
-              for (int q = 0; q < kTilesG; ++q)
-                if (in[q]) acc[key[q]] = 0u;
-            };
-            flat_pass<SEARCH_NONE>(L, nullptr, col, nullptr, lane, llen, kb, 0, 0, clr);
+          } else if (i < nitems) {
+            acc[touched[i]] = 0u;
           }
         }
       }
@@ -1193,6 +1208,7 @@ __global__ __launch_bounds__(256) void rect_acc_kernel(const RectAccParams p) {
         __syncthreads();
       } else {
         __threadfence_block();
+        wave_sync();
       }
     }
     __syncthreads();
