@@ -148,6 +148,7 @@ struct gm_graph {
   unsigned long long n_house_tasks = 0;
   unsigned long long *d_house_acc = nullptr;
   size_t house_acc_bytes = 0;
+  int *d_house_touched = nullptr;
   int *d_pent_touched = nullptr;         // pentagon by wedge accumulation: touched-vertex lists (same shape as d_rect_acc)
   size_t pent_touched_bytes = 0;
   unsigned long long *d_house_prefix = nullptr;  // house: per-entry task-block prefix
@@ -190,6 +191,7 @@ extern "C" void gm_graph_free(gm_graph *g) {
   if (g->d_house_tlt) (void)hipFree(g->d_house_tlt);
   if (g->d_house_tasks) (void)hipFree(g->d_house_tasks);
   if (g->d_house_acc) (void)hipFree(g->d_house_acc);
+  if (g->d_house_touched) (void)hipFree(g->d_house_touched);
   if (g->d_rect_tasks) (void)hipFree(g->d_rect_tasks);
   if (g->d_rect_acc) (void)hipFree(g->d_rect_acc);
   for (auto &pr : g->ev)
@@ -1359,9 +1361,13 @@ static int run_house_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h
     g->house_acc_bytes = 0;
     HIP_TRY(hipMalloc(&g->d_house_acc, need));
     HIP_TRY(hipMemset(g->d_house_acc, 0, need));  // every launch leaves the maps zeroed again
+    if (g->d_house_touched) (void)hipFree(g->d_house_touched);
+    g->d_house_touched = nullptr;
+    HIP_TRY(hipMalloc(&g->d_house_touched, need / 2));  // one int list per map
     g->house_acc_bytes = need;
   }
   p.acc = g->d_house_acc;
+  p.touched = g->d_house_touched;
   rc = start_timer(ctx);
   if (rc) return rc;
   if (count > 0) HIP_TRY(launch_house_acc(p, (int)grid, ctx.stream));

@@ -184,6 +184,7 @@ struct HouseAccParams {
   const int4 *tasks;
   unsigned long long first, step, count;
   unsigned long long *acc;  // one zeroed 64-bit map per wave: grid * 4 * acc_stride
+  int *touched;             // one list per wave (same stride): the vertices whose map entry is non-zero
   unsigned long long acc_stride;
   unsigned long long *queue;
   unsigned long long *counters;

@@ -1312,7 +1312,8 @@ __global__ __launch_bounds__(256) void house_acc_kernel(const HouseAccParams p) 
   __shared__ WaveLds W[kWavesPerBlock];
   __shared__ int AUX[kWavesPerBlock][GM_WAVE];
   __shared__ int4 s_task;
-  __shared__ int s_next;
+  __shared__ int s_next, s_ntouched;
+  __shared__ int s_wtouched[kWavesPerBlock];
   const int *__restrict__ rp = p.g.rp;
   const int *__restrict__ col = p.g.col;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1326,14 +1327,19 @@ __global__ __launch_bounds__(256) void house_acc_kernel(const HouseAccParams p) 
       const unsigned long long q = atomicAdd(p.queue, 1ull);
       s_task = (q < p.count) ? p.tasks[p.first + q * p.step] : make_int4(-3, -3, -3, -3);
       s_next = 0;
+      s_ntouched = 0;
     }
+    if (lane == 0) s_wtouched[wave] = 0;
     __syncthreads();
     const int4 tk = s_task;
     if (tk.x == -3) break;
     const bool heavy = tk.y == -2;
     const int v0 = heavy ? tk.x : (wave == 0 ? tk.x : wave == 1 ? tk.y : wave == 2 ? tk.z : tk.w);
     unsigned long long *acc = heavy ? acc_wg : acc_own;
-    // phases: 0 = B, C, D (tables + one intersection per edge v1 < v0); 1 = the 2-path walk (A); 2 = clear the map
+    int *touched = p.touched + ((size_t)blockIdx.x * kWavesPerBlock + (heavy ? 0 : wave)) * p.acc_stride;
+    int *ntouched = heavy ? &s_ntouched : &s_wtouched[wave];
+    // phases: 0 = B, C, D (tables + one intersection per edge v1 < v0); 1 = the 2-path walk (A), listing the touched
+    // vertices; 2 = clear the listed map entries
     for (int phase = 0; phase < 3; ++phase) {
       if (v0 >= 0) {
         const int r0 = rp[v0], d0 = rp[v0 + 1] - r0;
@@ -1346,8 +1352,13 @@ __global__ __launch_bounds__(256) void house_acc_kernel(const HouseAccParams p) 
           } else {
             bi = mine++;
           }
-          if (bi * GM_WAVE >= d0) break;
+          const int nitems = (phase == 2) ? *ntouched : d0;
+          if (bi * GM_WAVE >= nitems) break;
           const int i = bi * GM_WAVE + lane;
+          if (phase == 2) {
+            if (i < nitems) acc[touched[i]] = 0ull;
+            continue;
+          }
           const bool valid = i < d0;
           const int v1 = valid ? col[r0 + i] : 0;
           const int r1 = rp[v1], d1 = rp[v1 + 1] - r1;
@@ -1378,22 +1389,25 @@ __global__ __launch_bounds__(256) void house_acc_kernel(const HouseAccParams p) 
             if (phase == 1) {
               auto inc = [&](const bool *in, const int *key, const int *own) {
 #pragma unroll
-                for (int q = 0; q < kTilesG; ++q)
+                for (int q = 0; q < kTilesG; ++q) {
+                  bool first = false;
                   if (in[q] && key[q] != v0) {
                     const unsigned long long delta = (unsigned long long)L.cnt[own[q] - 1];
                     const unsigned long long old = __hip_atomic_fetch_add(&acc[key[q]], (delta << 24) | 1ull, __ATOMIC_RELAXED,
                                                                           __HIP_MEMORY_SCOPE_WORKGROUP);
                     res += delta * (old & 0xffffffull) + (old >> 24) + delta;  // A
+                    first = old == 0ull;
                   }
+                  const unsigned long long m = __ballot(first);
+                  if (m) {  // wave-uniform: list the newly touched vertices
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(ntouched, __popcll(m));
+                    base = readfirst(base);
+                    if (first) touched[base + rank_below(m)] = key[q];
+                  }
+                }
               };
               flat_pass<SEARCH_NONE>(L, nullptr, col, nullptr, lane, llen, r1, 0, 0, inc);
-            } else {
-              auto clr = [&](const bool *in, const int *key, const int *) {
-#pragma unroll
-                for (int q = 0; q < kTilesG; ++q)
-                  if (in[q]) acc[key[q]] = 0ull;
-              };
-              flat_pass<SEARCH_NONE>(L, nullptr, col, nullptr, lane, llen, r1, 0, 0, clr);
             }
             wave_sync();
           }
@@ -1406,6 +1420,7 @@ __global__ __launch_bounds__(256) void house_acc_kernel(const HouseAccParams p) 
         __syncthreads();
       } else {
         __threadfence_block();
+        wave_sync();
       }
     }
     __syncthreads();
