@@ -629,14 +629,31 @@ template <int M>
 struct CliqueWide {  // one wave per row, lane w holds word w of the candidate set (stride <= 64)
   static __device__ __forceinline__ unsigned long long run(const unsigned S, const unsigned *__restrict__ bits, const int lane,
                                                            const int stride) {
+    // the rows M_j of up to four set bits are requested together (unconditional loads; lanes >= stride hold 0 in S, so
+    // whatever they read is masked by the AND): one dependent arena round trip per four sub-trees instead of per sub-tree --
+    // chunk timings: 94 % of the 5-clique time was this walk, one load at a time
     unsigned long long c = 0;
+    const int lw = min(lane, stride - 1);
     for (int w = 0; w < stride; ++w) {
       unsigned x = (unsigned)readlane((int)S, w);  // wave-uniform
       while (x) {
-        const int bit = __ffs((int)x) - 1;
-        x &= x - 1;
-        const unsigned mj = (lane < stride) ? bits[(size_t)(w * 32 + bit) * stride + lane] : 0u;
-        c += CliqueWide<M - 1>::run(S & mj, bits, lane, stride);
+        int j[4];
+        int n = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          j[u] = w * 32;
+          if (x) {
+            j[u] += __ffs((int)x) - 1;
+            x &= x - 1;
+            n = u + 1;
+          }
+        }
+        unsigned mj[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) mj[u] = bits[(size_t)j[u] * stride + lw];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (u < n) c += CliqueWide<M - 1>::run(S & mj[u], bits, lane, stride);
       }
     }
     return c;
