@@ -1019,7 +1019,9 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
   int grid = (int)std::max<long long>(1, std::min<long long>(want, (long long)g->cu_count * per_cu));
 
   if (clique && tab->max_bit_words > 0) {
-    const size_t need = (size_t)tab->max_bit_words * sizeof(unsigned) * (size_t)grid;  // one arena slot per workgroup
+    // one arena slot per workgroup; k >= 5 doubles it (second half: compacted sub-matrices, cliquek_count_sub)
+    const unsigned long long slot_words = (pat == PAT_CLIQUEK) ? 2ull * tab->max_bit_words + 4096ull : tab->max_bit_words;  // (+ margin: compacted rows are padded to 64 columns)
+    const size_t need = (size_t)slot_words * sizeof(unsigned) * (size_t)grid;
     if (need > g->scratch_bytes) {
       if (g->d_scratch) (void)hipFree(g->d_scratch);
       g->d_scratch = nullptr;
@@ -1028,7 +1030,7 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
       g->scratch_bytes = need;
     }
     p.scratch = g->d_scratch;
-    p.scratch_words = tab->max_bit_words;
+    p.scratch_words = slot_words;
   }
 
 #ifdef GM_DEBUG_CHUNKS

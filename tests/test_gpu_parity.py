@@ -283,10 +283,26 @@ def test_rows_longer_than_the_lds_staging_capacity(dev):
 
 
 def test_big_rows_deeper_cliques(dev):
-    """K_300: DAG rows up to 299 > 256 columns -> scratch-resident matrix, wave-per-row recursion"""
+    """K_300 / K_600: DAG rows beyond 256 columns -> scratch-resident matrix; k = 5 compacts the induced sub-matrices (LDS up
+    to 256 set bits, a second arena slot beyond), k = 6 keeps the per-sub-tree walk for the wide rows"""
     n = 300
     d = _complete_graph(n).to_device(dev).orient()
     assert CliqueSolver(d, 5) == math.comb(n, 5)
+    assert CliqueSolver(d, 5, tune=[0, 0, 0, 0, 0, 0, 0x20]) == math.comb(n, 5)  # the per-sub-tree walk everywhere (A/B)
+    d = _complete_graph(270).to_device(dev).orient()
+    assert CliqueSolver(d, 6) == math.comb(270, 6)
+    d = _complete_graph(600).to_device(dev).orient()
+    assert CliqueSolver(d, 5) == math.comb(600, 5)
+
+
+def test_deeper_cliques_sub_matrix_path_rmat14(dev):
+    """R-MAT-14 (ef 16) DAG: induced-sub-matrix path against the per-sub-tree walk, k = 5 and 6"""
+    d = rmat_csr_numpy(14, 16, 42).to_device(dev).orient()
+    for k in (5, 6):
+        want = CliqueSolver(d, k, tune=[0, 0, 0, 0, 0, 0, 0x20])
+        assert CliqueSolver(d, k) == want
+        assert sum(CliqueSolver(d, k, rank=r, world=4) for r in range(4)) == want
+    assert CliqueSolver(d, 5) == O.clique(O.orient(O.OGraph(*(lambda g: (g.row_ptr, g.col_idx))(rmat_csr_numpy(14, 16, 42)))), 5)
 
 
 def test_hub_graph_against_oracle(dev):
