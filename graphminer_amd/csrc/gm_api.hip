@@ -1020,7 +1020,9 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
 
   if (clique && tab->max_bit_words > 0) {
     // one arena slot per workgroup; k >= 5 doubles it (second half: compacted sub-matrices, cliquek_count_sub)
-    const unsigned long long slot_words = (pat == PAT_CLIQUEK) ? 2ull * tab->max_bit_words + 4096ull : tab->max_bit_words;  // (+ margin: compacted rows are padded to 64 columns)
+    // k >= 5: k - 2 slots of max_bit_words + 4096 words (the vertex's matrix + one compacted sub-matrix per deeper level; the
+    // margin covers the padding of compacted rows to 64 columns)
+    const unsigned long long slot_words = (pat == PAT_CLIQUEK) ? (unsigned long long)(k - 2) * (tab->max_bit_words + 4096ull) : tab->max_bit_words;
     const size_t need = (size_t)slot_words * sizeof(unsigned) * (size_t)grid;
     if (need > g->scratch_bytes) {
       if (g->d_scratch) (void)hipFree(g->d_scratch);

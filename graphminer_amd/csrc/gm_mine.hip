@@ -671,13 +671,14 @@ struct CliqueWide<1> {
 // columns of M_i, re-indexed by position: a gather of the row's bits + one ballot per 64 columns) and the remaining
 // k - 3 levels run on it like on any LDS-resident matrix (one thread per row, the candidate set in 8 registers). The arena is
 // read |M_i| rows per row i instead of once per visited sub-tree (chunk timings: that walk was 94 % of the 5-clique time,
-// bound by 17 G row fetches of 128 B). Rows with more than 256 set bits: for k = 5 the compacted matrix goes to a second arena
-// slot and its pair count is the 4-clique tile walk; for k >= 6 they keep the per-sub-tree walk.
+// bound by 17 G row fetches of 128 B). Rows with more than 256 set bits: the compacted matrix goes to the next arena slot and is
+// processed one level down the same way (k = 5: what is left is a pair count, the 4-clique tile walk).
 template <int M>
 __device__ __forceinline__ unsigned long long cliquek_count_sub(unsigned *__restrict__ sub, int *__restrict__ lds_scratch,
                                                                 unsigned short *__restrict__ plist, const unsigned *__restrict__ gbits,
-                                                                unsigned *__restrict__ sub_arena, const int tid, const int lane,
-                                                                const int wave, const int nel, const int stride) {
+                                                                unsigned *__restrict__ sub_arena, const size_t arena_step,
+                                                                const int tid, const int lane, const int wave, const int nel,
+                                                                const int stride) {
   static_assert(kBitWords >= 256 * kSmallWords, "the sub-matrix of 256 rows must fit the bit-matrix LDS");
   unsigned *rowbuf = reinterpret_cast<unsigned *>(lds_scratch) + wave * GM_WAVE;  // 64 words per wave
   unsigned long long c = 0;
@@ -688,10 +689,6 @@ __device__ __forceinline__ unsigned long long cliquek_count_sub(unsigned *__rest
     const int m = readlane(incl, GM_WAVE - 1);
     if (m == 0) continue;
     const bool in_lds = m <= 256;
-    if (!in_lds && (M != 3 || sub_arena == nullptr)) {  // k >= 6 with a wide row: one wave walks the sub-trees in the arena
-      if ((i & (kWavesPerBlock - 1)) == wave) c += CliqueWide<M>::run(mi, gbits, lane, stride);
-      continue;
-    }
     __syncthreads();  // the previous row's sub-matrix / position list is no longer read
     if (wave == 0) {
       unsigned x = mi;
@@ -734,9 +731,14 @@ __device__ __forceinline__ unsigned long long cliquek_count_sub(unsigned *__rest
         for (int w = 0; w < kSmallWords; ++w) S[w] = sub[p * kSmallWords + w];
         c += CliqueSmall<M - 1>::run(S, sub, 0, kSmallWords);
       }
-    } else {  // k = 5: what is left is the pair count of the compacted matrix -- the 4-clique tile walk (begins with a barrier)
+    } else {
       __threadfence();
-      c += clique4_count_tiled(sub, sub_arena, tid, lane, wave, m, words);
+      if constexpr (M == 3) {  // what is left is the pair count of the compacted matrix: the 4-clique tile walk (begins with a barrier)
+        c += clique4_count_tiled(sub, sub_arena, tid, lane, wave, m, words);
+      } else {  // one level down on the compacted matrix, with the next arena slot for ITS wide rows
+        __syncthreads();
+        c += cliquek_count_sub<M - 1>(sub, lds_scratch, plist, sub_arena, sub_arena + arena_step, arena_step, tid, lane, wave, m, words);
+      }
     }
   }
   __syncthreads();
@@ -1055,7 +1057,8 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
         if (PAT != PAT_CLIQUEK) break;                                                                       \
         if (wide && !(p.flags & 64))                                                                          \
           acc.c0 += cliquek_count_sub<K - 2>(B.bits, B.stage, reinterpret_cast<unsigned short *>(B.fbits), gbits,       \
-                                             gbits + (p.scratch_words - 4096) / 2, tid, lane, wave, nel, stride);               \
+                                             gbits + p.scratch_words / (K - 3 + 1), p.scratch_words / (K - 3 + 1), tid, lane,   \
+                                             wave, nel, stride);                                                          \
         else if (wide) acc.c0 += cliquek_count_wide<K - 2>(gbits, lane, wave, nel, stride);                      \
         else if (bits_lds) acc.c0 += cliquek_count_small<K - 2>(B.rpl, B.bits, tid, nthreads, eb, nel, nvl, stride); \
         else acc.c1 += 1; /* row wider than 2048 columns: not supported for k >= 5 (reported by the host) */ \
