@@ -24,12 +24,12 @@ from graphminer_amd.graph import Graph  # noqa: E402
 from graphminer_amd.rmat import rmat_csr_numpy  # noqa: E402
 
 REF = os.path.join(ROOT, "oracle", "_ref")
-RMATS = [  # (scale, edge_factor, seed, heavy patterns too?)
+RMATS = [  # (scale, edge_factor, seed, heavy patterns too? -- True, False, or "sgl": only house / pentagon of the heavy ones)
     (6, 4, 1, True),
     (8, 8, 42, True),
     (10, 16, 42, True),
-    (12, 8, 7, False),
-    (14, 16, 42, False),
+    (12, 8, 7, "sgl"),
+    (14, 16, 42, "sgl"),
 ]
 
 
@@ -48,7 +48,8 @@ def last_int(out, pat):
 def counts_for(prefix, heavy=True):
     r = {}
     r["tc"] = last_int(run("tc_omp_base", prefix), r"total_num_triangles = (\d+)")
-    pats = ["diamond", "rectangle"] + (["house", "pentagon"] if heavy else [])
+    pats = ["diamond", "rectangle"] + (["house", "pentagon"] if heavy else [])  # (heavy == "sgl" is truthy)
+    heavy = heavy is True
     for p in pats:
         r[p] = last_int(run("sgl_omp_base", prefix, p), r"total_num = (\d+)")
     for k in (4, 5):
