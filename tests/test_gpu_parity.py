@@ -128,7 +128,8 @@ def test_sgl_nested_patterns_match_reference(gg, pattern):
         assert SglSolver(sym, pattern, tune=[0, 0, 0, 0, 0, 0, 0x800]) == e[pattern]
         assert SglSolver(sym, pattern, tune=[0, 0, 0, 0, 0, 0, 0x8000]) == e[pattern]
         assert SglSolver(sym, pattern, tune=[0, 0, 0, 0, 0, 0, 0x800 | 0x200]) == e[pattern]
-        assert SglSolver(sym, pattern, tune=[0, 0, 0, 0, 0, 0, 1024]) == e[pattern]
+        if e["ne"] < 100000:  # (the wave-per-edge loop nest needs minutes on R-MAT-14)
+            assert SglSolver(sym, pattern, tune=[0, 0, 0, 0, 0, 0, 1024]) == e[pattern]
         assert SglSolver(sym, pattern) == e[pattern]  # (the maps are left zeroed by every launch)
 
 
@@ -389,8 +390,8 @@ def test_sgl_map_kernels_match_flat_kernels_rmat14(dev, pattern):
     g = rmat_csr_numpy(14, 16, 42)
     s = g.to_device(dev)
     want = SglSolver(s, pattern, tune=[0, 0, 0, 0, 0, 0, 0x800])
-    if pattern == "rectangle":
-        assert want == GOLDEN[g.name]["rectangle"]
+    if pattern in GOLDEN[g.name]:  # from the reference's sgl_omp_base (house: 25 min on 8 threads)
+        assert want == GOLDEN[g.name][pattern]
     assert SglSolver(s, pattern) == want
     assert SglSolver(s, pattern, tune=[0, 0, 0, 0, 0, 0, 0x200]) == want
     assert SglSolver(s, pattern, tune=[0, 0, 0, 0, 0, 0, 0x800 | 0x200]) == want
