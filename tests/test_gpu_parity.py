@@ -117,7 +117,8 @@ def test_sgl_nested_patterns_match_reference(gg, pattern):
     assert sum(SglSolver(sym, pattern, rank=r, world=2, policy=1) for r in range(2)) % 2**64 == e[pattern]
     if pattern == "pentagon":  # the other implementations: wedges + per-round flat intersections (on the descending copy / as numbered)
         assert SglSolver(sym, pattern, tune=[0, 0, 0, 0, 0, 0, 0x800]) == e[pattern]
-        assert SglSolver(sym, pattern, tune=[0, 0, 0, 0, 0, 0, 0x800 | 0x200]) == e[pattern]
+        if e["ne"] < 100000:  # (the wedge form as numbered needs many seconds on R-MAT-14)
+            assert SglSolver(sym, pattern, tune=[0, 0, 0, 0, 0, 0, 0x800 | 0x200]) == e[pattern]
         assert SglSolver(sym, pattern) == e[pattern]
     assert SglSolver(sym, pattern, tune=[0, 0, 0, 0, 0, 0, 512]) == e[pattern]  # on the graph as numbered (no degree renumbering)
     if pattern == "rectangle":  # the other two implementations: wedges + flattened intersections; one wave per edge
