@@ -1529,13 +1529,16 @@ extern "C" int gm_clique(const gm_graph *dag, int k, const gm_launch *la, uint64
 // undirected edge), raw[4] = edge-induced 4-cycles (rectangle kernel), raw[5] = 4-cliques (clique kernel on the cached
 // DAG). Every raw value is a plain sum over tasks, so per-rank partials add up; gm_motif4_finish turns the summed raw
 // values into the six vertex-induced counts.
+// With la->d_counts set the six raw sums are left in that DEVICE buffer (raw[0..3] by the per-edge kernel, raw[4] by the
+// rectangle kernel, raw[5] by the clique kernel, all ordered on la->stream) and nothing synchronises unless `raw` is given
+// too -- this is what feeds the RCCL all-reduce of motif_multigpu.
 extern "C" int gm_motif4_partial(const gm_graph *sym, const gm_launch *la, uint64_t raw[6], gm_stats *st) {
-  if (!sym || !raw) return GM_ERR_INVALID;
+  if (!sym || (!raw && !(la && la->d_counts))) return GM_ERR_INVALID;
   gm_graph *g = const_cast<gm_graph *>(sym);
   gm_launch l2;
   memset(&l2, 0, sizeof l2);
   if (la) l2 = *la;
-  l2.d_counts = nullptr;  // synchronous: the three kernels are combined on the host
+  uint64_t *d_out = l2.d_counts;
   if (!g->dag_cache) {
     gm_graph *dag = nullptr;
     int rc = gm_graph_orient(sym, &dag);
@@ -1544,6 +1547,7 @@ extern "C" int gm_motif4_partial(const gm_graph *sym, const gm_launch *la, uint6
   }
   gm_stats s1, s2, s3;
   memset(&s1, 0, sizeof s1); memset(&s2, 0, sizeof s2); memset(&s3, 0, sizeof s3);
+  l2.d_counts = d_out;
   int rc = run_pattern(PAT_MOTIF4E, sym, &l2, 4, raw, 4, &s1, FIN_RAW4, 0);
   if (rc) return rc;
   {
@@ -1554,10 +1558,13 @@ extern "C" int gm_motif4_partial(const gm_graph *sym, const gm_launch *la, uint6
       if (rc) return rc;
       rect_on = r;
     }
-    rc = (l2.tune[6] & 2048) ? run_rect_flat(rect_on, &l2, &raw[4], &s2) : run_rect_acc(rect_on, &l2, &raw[4], &s2);
+    l2.d_counts = d_out ? d_out + 4 : nullptr;
+    rc = (l2.tune[6] & 2048) ? run_rect_flat(rect_on, &l2, raw ? &raw[4] : nullptr, &s2)
+                             : run_rect_acc(rect_on, &l2, raw ? &raw[4] : nullptr, &s2);
   }
   if (rc) return rc;
-  rc = run_pattern(PAT_CLIQUE4, g->dag_cache, &l2, 4, &raw[5], 1, &s3);
+  l2.d_counts = d_out ? d_out + 5 : nullptr;
+  rc = run_pattern(PAT_CLIQUE4, g->dag_cache, &l2, 4, raw ? &raw[5] : nullptr, 1, &s3);
   if (rc) return rc;
   if (st) {
     *st = s1;
@@ -1566,29 +1573,47 @@ extern "C" int gm_motif4_partial(const gm_graph *sym, const gm_launch *la, uint6
   return GM_OK;
 }
 
+// raw sums -> the six vertex-induced counts (host fix-up of src/motif/omp_formula.cc:41-45, same arithmetic on both sides)
+__host__ __device__ static inline void motif4_finish_math(const unsigned long long *raw, unsigned long long *counts) {
+  const unsigned long long k4 = raw[5];
+  const unsigned long long diamond = raw[3] / 2 - 6 * k4;            // total[4] = total[4]/2 - 6*total[5]
+  const unsigned long long tailed = raw[2] / 2 - 2 * diamond;        // total[2] = total[2]/2 - 2*total[4]
+  const unsigned long long cycle4 = raw[4] - diamond - 3 * k4;       // vertex-induced 4-cycles from the edge-induced count
+  const unsigned long long path4 = raw[1] - 4 * cycle4;              // total[1] = total[1] - 4*total[3]
+  const unsigned long long star3 = raw[0] / 6 - tailed / 3;          // total[0] = total[0]/6 - total[2]/3
+  counts[0] = star3; counts[1] = path4; counts[2] = tailed; counts[3] = cycle4; counts[4] = diamond; counts[5] = k4;
+}
+
+__global__ void motif4_finish_kernel(unsigned long long *__restrict__ c) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  unsigned long long raw[6], out[6];
+  for (int i = 0; i < 6; ++i) raw[i] = c[i];
+  motif4_finish_math(raw, out);
+  for (int i = 0; i < 6; ++i) c[i] = out[i];
+}
+
 extern "C" int gm_motif4_finish(const uint64_t raw[6], uint64_t counts[6]) {
   if (!raw || !counts) return GM_ERR_INVALID;
-  const uint64_t k4 = raw[5];
-  const uint64_t diamond = raw[3] / 2 - 6 * k4;            // total[4] = total[4]/2 - 6*total[5]
-  const uint64_t tailed = raw[2] / 2 - 2 * diamond;        // total[2] = total[2]/2 - 2*total[4]
-  const uint64_t cycle4 = raw[4] - diamond - 3 * k4;       // vertex-induced 4-cycles from the edge-induced count
-  const uint64_t path4 = raw[1] - 4 * cycle4;              // total[1] = total[1] - 4*total[3]
-  const uint64_t star3 = raw[0] / 6 - tailed / 3;          // total[0] = total[0]/6 - total[2]/3
-  counts[0] = star3; counts[1] = path4; counts[2] = tailed; counts[3] = cycle4; counts[4] = diamond; counts[5] = k4;
+  unsigned long long r[6], c[6];
+  for (int i = 0; i < 6; ++i) r[i] = raw[i];
+  motif4_finish_math(r, c);
+  for (int i = 0; i < 6; ++i) counts[i] = c[i];
   return GM_OK;
 }
 
 extern "C" int gm_motif(const gm_graph *sym, int k, const gm_launch *la, uint64_t *counts, int ncounts, gm_stats *st) {
   if (k == 4) {
-    if (ncounts < 6 || !counts) return GM_ERR_INVALID;
+    const bool async = la && la->d_counts;  // the asynchronous contract of every solver: counts may be NULL then
+    if (ncounts < 6 || (!counts && !async)) return GM_ERR_INVALID;
     if (la && la->world > 1) return GM_ERR_UNSUPPORTED;  // multi-GPU: gm_motif4_partial + all-reduce + gm_motif4_finish
     uint64_t raw[6];
-    int rc = gm_motif4_partial(sym, la, raw, st);
+    int rc = gm_motif4_partial(sym, la, counts ? raw : nullptr, st);
     if (rc) return rc;
-    rc = gm_motif4_finish(raw, counts);
-    if (rc) return rc;
-    if (la && la->d_counts) HIP_TRY(hipMemcpy(la->d_counts, counts, sizeof(uint64_t) * 6, hipMemcpyHostToDevice));
-    return GM_OK;
+    if (async) {  // finish in place on the device, ordered on the launch stream
+      hipLaunchKernelGGL(motif4_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)la->stream, (unsigned long long *)la->d_counts);
+      HIP_TRY(hipGetLastError());
+    }
+    return counts ? gm_motif4_finish(raw, counts) : GM_OK;
   }
   if (k != 3) return GM_ERR_INVALID;
   if (ncounts < 2) return GM_ERR_INVALID;

@@ -31,9 +31,17 @@ def init_from_env(backend: str | None = None):
     return rank, world, local_rank
 
 
+_M64 = (1 << 64) - 1
+
+
 def allreduce_counts(counts, device=None):
-    """Sum per-rank uint64 counts over all ranks. `counts`: list of ints or an int64 tensor (returned
-    as given type). Counts are < 2^63 for every graph this build accepts, so int64 transport is exact."""
+    """Sum per-rank uint64 counts over all ranks, modulo 2**64. `counts`: list of ints (returned as a list of
+    ints in [0, 2**64)) or an int64 tensor (reduced in place and returned as given).
+
+    Per-rank partials are only defined modulo 2**64 and routinely exceed 2**63: the 3-motif wedge partial
+    (c[2] - c[0]), gm_motif_formula on ranks != 0 (0 - 3T) and the signed pentagon partial. torch has no uint64
+    all-reduce, so the values travel as their two's-complement int64 image -- int64 addition wraps exactly like
+    uint64 addition -- and are mapped back to [0, 2**64) afterwards."""
     import torch
     import torch.distributed as dist
 
@@ -41,10 +49,11 @@ def allreduce_counts(counts, device=None):
         if dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(counts)
         return counts
-    t = torch.tensor([int(c) for c in counts], dtype=torch.int64, device=device)
+    vals = [int(c) & _M64 for c in counts]
+    t = torch.tensor([v - (1 << 64) if v >= (1 << 63) else v for v in vals], dtype=torch.int64, device=device)
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t)
-    return [int(x) for x in t.cpu().tolist()]
+    return [int(x) & _M64 for x in t.cpu().tolist()]
 
 
 def partition(n_chunks: int, rank: int, world: int, policy: int = _lib.GM_PART_ROUND_ROBIN):

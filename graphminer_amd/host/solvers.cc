@@ -56,7 +56,12 @@ int call(const Job &j, gm_graph *g, const gm_launch *la, uint64_t *out, gm_stats
     case Job::TC: return gm_tc(g, la, out, st);
     case Job::SGL: return gm_sgl(g, j.pattern, la, out, st);
     case Job::CLIQUE: return gm_clique(g, j.k, la, out, st);
-    case Job::MOTIF: return gm_motif(g, j.k, la, out, j.ncounts, st);
+    case Job::MOTIF:
+      // 4-motif on several GPUs: every rank leaves its six RAW sums on the device (gm_motif4_partial), the all-reduce adds
+      // them, run_multi applies gm_motif4_finish to the reduced sums (src/motif/omp_formula.cc:41-45)
+      // (also with one device under GM_FORCE_RCCL_PATH, so that a one-GPU test box exercises this path)
+      if (j.k == 4 && la && la->d_counts && !out) return gm_motif4_partial(g, la, out, st);
+      return gm_motif(g, j.k, la, out, j.ncounts, st);
   }
   return GM_ERR_INVALID;
 }
@@ -163,6 +168,12 @@ bool run_multi(Graph &g, const Job &j, int n, int chunk, uint64_t *out) {
     std::cout << "runtime [" << j.name << "] = " << t.Seconds() << " sec\n";
     HIP_OK(hipSetDevice(0));
     HIP_OK(hipMemcpy(out, d_cnt[0], sizeof(uint64_t) * size_t(j.ncounts), hipMemcpyDeviceToHost));
+    if (j.kind == Job::MOTIF && j.k == 4) {  // reduced raw sums -> the six vertex-induced counts
+      uint64_t raw[6];
+      std::memcpy(raw, out, sizeof raw);
+      int rc = gm_motif4_finish(raw, out);
+      if (rc) gm_die(rc, "gm_motif4_finish");
+    }
   }
   for (int i = 0; i < n; ++i) {
     HIP_OK(hipSetDevice(i));
@@ -238,10 +249,6 @@ void MotifSolver(Graph &g, int k, std::vector<uint64_t> &accum, int n_gpu, int c
   if (k != 3 && k != 4) {
     std::cout << "Not supported right now\n";  // src/motif/gpu_base.cu:101
     return;
-  }
-  if (k == 4 && n_gpu > 1) {
-    std::cout << "4-motif: running on one GPU (multi-GPU needs gm_motif4_partial + all-reduce + gm_motif4_finish)\n";
-    n_gpu = 1;
   }
   uint64_t out[8] = {0};
   if (!run(g, j, n_gpu, chunk_size, out)) {

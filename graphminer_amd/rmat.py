@@ -9,7 +9,7 @@ rows are sorted and de-duplicated, max_degree = longest row.
 Two implementations of the SAME stream:
   * ``rmat_csr_numpy``  -- host, vectorised numpy (tests, small scales);
   * ``rmat_csr_device`` -- the HIP kernel ``gm_rmat_keys`` + torch sort/unique (bench, full scale).
-tests/test_rmat.py checks they produce identical CSR arrays.
+tests/test_gpu_parity.py::test_rmat_device_generator_equals_numpy checks they produce identical CSR arrays.
 """
 from __future__ import annotations
 

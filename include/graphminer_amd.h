@@ -161,7 +161,10 @@ int gm_motif(const gm_graph *sym, int k, const gm_launch *launch, uint64_t *coun
 /* 4-motif in the reference's formula form (src/motif/cpu_kernels/automine_formula.h:21-56, host fix-up
  * src/motif/omp_formula.cc:41-45). gm_motif(k = 4, ncounts = 6) returns [3-star, 4-path, tailed-triangle, 4-cycle,
  * diamond, 4-clique] (vertex-induced, the order of src/motif/README.md:50-60) on one GPU. Multi-GPU: every rank calls
- * gm_motif4_partial (raw[6] are plain sums over its tasks), the ranks all-reduce raw, then gm_motif4_finish. */
+ * gm_motif4_partial (raw[6] are plain sums over its tasks), the ranks all-reduce raw, then gm_motif4_finish.
+ * Asynchronous form: with launch->d_counts set, gm_motif4_partial leaves raw[0..5] in that device buffer without
+ * synchronising (raw may then be NULL) -- all-reduce it in place, copy it back, call gm_motif4_finish. gm_motif(k = 4)
+ * accepts counts == NULL with d_counts set like every other solver (the fix-up then runs on the device). */
 int gm_motif4_partial(const gm_graph *sym, const gm_launch *launch, uint64_t raw[6], gm_stats *stats);
 int gm_motif4_finish(const uint64_t raw[6], uint64_t counts[6]);
 

@@ -5,8 +5,12 @@ Run in the build container (where /root/reference exists and oracle/ref/Makefile
 oracle/_ref/):   python tests/golden/make_golden.py
 
 For every graph it runs tc_omp_base, sgl_omp_base {diamond,rectangle,house,pentagon},
-clique_omp_base k=4,5 (+ clique_omp_recursive k=6,7 for the k>=6 goldens), motif_omp_base k=3,4
-and stores the printed counts. Graphs: the two data fixtures (tests/fixtures/{citeseer,cora}) and
+clique_omp_base k=4,5 (+ clique_omp_recursive k=6,7,8 for the k>=6 goldens), motif_omp_base k=3,4
+and stores the printed counts. EXTRA lists graphs that only get selected (affordable) entries, e.g. the 4-motif
+vector of R-MAT-16 from motif_omp_formula.
+
+    python tests/golden/make_golden.py            regenerate everything (hours: house / pentagon of R-MAT-14)
+    python tests/golden/make_golden.py --update   keep what golden.json already holds, run only what is missing Graphs: the two data fixtures (tests/fixtures/{citeseer,cora}) and
 seeded R-MAT graphs produced by graphminer_amd.rmat (only their parameters + a SHA-256 of the
 CSR arrays are stored; the graphs are regenerated deterministically by the tests).
 """
@@ -45,7 +49,42 @@ def last_int(out, pat):
     return int(m[-1])
 
 
-def counts_for(prefix, heavy=True):
+class Lazy(dict):
+    """dict that only evaluates (runs the reference binary) for keys golden.json does not hold yet (--update)"""
+
+    def __init__(self, have):
+        super().__init__(have or {})
+
+    def put(self, key, fn):
+        if key not in self:
+            self[key] = fn()
+            print("   ran", key, "->", self[key], flush=True)
+
+
+def extra_counts_for(prefix, what, have=None):
+    """selected entries only (EXTRA graphs): `what` = list of keys"""
+    r = Lazy(have)
+    for key in what:
+        if key == "motif4":  # motif_omp_formula: the reference's formula-based 4-motif (src/motif/omp_formula.cc)
+            r.put(key, lambda: [int(x) for x in re.findall(r"pattern \d+: (\d+)", run("motif_omp_formula", prefix, 4))])
+        elif key == "motif3":
+            r.put(key, lambda: [int(x) for x in re.findall(r"pattern \d+: (\d+)", run("motif_omp_base", prefix, 3))])
+        elif key == "tc":
+            r.put(key, lambda: last_int(run("tc_omp_base", prefix), r"total_num_triangles = (\d+)"))
+        elif key == "diamond":
+            r.put(key, lambda: last_int(run("sgl_omp_base", prefix, "diamond"), r"total_num = (\d+)"))
+        elif key.startswith("clique"):
+            k = int(key[6:])
+            exe = "clique_omp_base" if k <= 5 else "clique_omp_recursive"
+            r.put(key, lambda: last_int(run(exe, prefix, k), rf"num_{k}-cliques = (\d+)"))
+        else:
+            raise KeyError(key)
+    return dict(r)
+
+
+def counts_for(prefix, heavy=True, have=None):
+    if have is not None:
+        return counts_for_update(prefix, heavy, have)
     r = {}
     r["tc"] = last_int(run("tc_omp_base", prefix), r"total_num_triangles = (\d+)")
     pats = ["diamond", "rectangle"] + (["house", "pentagon"] if heavy else [])  # (heavy == "sgl" is truthy)
@@ -55,8 +94,8 @@ def counts_for(prefix, heavy=True):
     for k in (4, 5):
         r[f"clique{k}"] = last_int(run("clique_omp_base", prefix, k), rf"num_{k}-cliques = (\d+)")
     r["kcl4"] = last_int(run("kcl_omp_base", prefix, 4), r"total_num_cliques = (\d+)")
-    if heavy:
-        for k in (6, 7):
+    if True:  # (heavy or not: the recursive solver is quick at every k)
+        for k in (6, 7, 8):
             r[f"clique{k}"] = last_int(run("clique_omp_recursive", prefix, k), rf"num_{k}-cliques = (\d+)")
     out = run("motif_omp_base", prefix, 3)
     r["motif3"] = [int(x) for x in re.findall(r"pattern \d+: (\d+)", out)]
@@ -70,6 +109,14 @@ def counts_for(prefix, heavy=True):
     return r
 
 
+def counts_for_update(prefix, heavy, have):
+    """--update: only the entries golden.json lacks (today: clique8 of the `heavy is True` graphs)"""
+    r = Lazy(have)
+    for k in (6, 7, 8):
+        r.put(f"clique{k}", lambda: last_int(run("clique_omp_recursive", prefix, k), rf"num_{k}-cliques = (\d+)"))
+    return dict(r)
+
+
 def csr_sha(g: Graph):
     h = hashlib.sha256()
     h.update(g.row_ptr.astype("<i8").tobytes())
@@ -77,13 +124,22 @@ def csr_sha(g: Graph):
     return h.hexdigest()
 
 
+EXTRA = [  # (scale, edge_factor, seed, entries): graphs too big for the full set
+    (16, 16, 42, ["tc", "motif3", "motif4"]),
+]
+
+
 def main():
+    update = "--update" in sys.argv
+    path = os.path.join(ROOT, "tests", "golden", "golden.json")
+    old = json.load(open(path)) if update else {}
     gold = {}
     for name in ("citeseer", "cora"):
         prefix = os.path.join(ROOT, "tests", "fixtures", name, "graph")
         g = Graph(prefix)
+        have = old.get(name) if update else None
         gold[name] = {"kind": "fixture", "nv": g.V(), "ne": g.E(), "max_degree": g.max_degree, "csr_sha256": csr_sha(g),
-                      **counts_for(prefix)}
+                      **counts_for(prefix, True, have)}
         print(name, gold[name])
     with tempfile.TemporaryDirectory() as td:
         for scale, ef, seed, heavy in RMATS:
@@ -92,8 +148,20 @@ def main():
             os.makedirs(d)
             prefix = os.path.join(d, "graph")
             g.save(prefix)
+            have = old.get(g.name) if update else None
             gold[g.name] = {"kind": "rmat", "scale": scale, "edge_factor": ef, "seed": seed, "nv": g.V(), "ne": g.E(),
-                            "max_degree": g.max_degree, "csr_sha256": csr_sha(g), **counts_for(prefix, heavy)}
+                            "max_degree": g.max_degree, "csr_sha256": csr_sha(g), **counts_for(prefix, heavy, have)}
+            print(g.name, gold[g.name])
+        for scale, ef, seed, what in EXTRA:
+            g = rmat_csr_numpy(scale, ef, seed)
+            d = os.path.join(td, g.name)
+            os.makedirs(d)
+            prefix = os.path.join(d, "graph")
+            g.save(prefix)
+            have = old.get(g.name) if update else None
+            gold[g.name] = {"kind": "rmat", "partial": True, "scale": scale, "edge_factor": ef, "seed": seed, "nv": g.V(),
+                            "ne": g.E(), "max_degree": g.max_degree, "csr_sha256": csr_sha(g),
+                            **extra_counts_for(prefix, what, have)}
             print(g.name, gold[g.name])
     # README known answers for the full-size graphs (no data here; kept for when real files are supplied)
     gold["_readme_known_answers"] = {
@@ -101,7 +169,7 @@ def main():
         "com-orkut": {"tc": 627584181, "diamond": 67098889426, "motif3": [43742714028, 627584181], "clique4": 3221946137,
                       "clique5": 15766607860},
     }
-    with open(os.path.join(ROOT, "tests", "golden", "golden.json"), "w") as f:
+    with open(path, "w") as f:
         json.dump(gold, f, indent=1, sort_keys=True)
         f.write("\n")
 

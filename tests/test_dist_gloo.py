@@ -103,3 +103,48 @@ def test_chunk_table_is_a_partition_of_the_edges():
                 if clique:
                     assert eb == g.row_ptr[ub] and ee == g.row_ptr[ue]  # whole rows only
             assert np.all(covered == 1)
+
+
+def _wrap_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+    from graphminer_amd import dist
+
+    dist.init_from_env("gloo")
+    # the shapes the kernels really hand over: rank 0 of gm_motif_formula holds sum C(d,2) - 3T0, every other rank 0 - 3Tr
+    # (a value just below 2**64); the pentagon partial is a signed even number; plus a plain count
+    wedges_base, t = 10**15, [123456789, 987654321, 55555]
+    partial_w = ((wedges_base if rank == 0 else 0) - 3 * t[rank]) % 2**64
+    partial_p = (-2 * (rank + 1) if rank else 2 * 10**12) % 2**64
+    out = dist.allreduce_counts([partial_w, t[rank], partial_p, 2**64 - 1])
+    q.put((rank, [partial_w, partial_p], out))
+    import torch.distributed as td
+    td.destroy_process_group()
+
+
+def test_allreduce_counts_is_exact_modulo_2_64():
+    """Per-rank partials are defined modulo 2**64 and exceed 2**63: they travel as two's complement."""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_wrap_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    t = [123456789, 987654321, 55555]
+    want = [10**15 - 3 * sum(t), sum(t), 2 * 10**12 - 2 * 2 - 2 * 3, (3 * (2**64 - 1)) % 2**64]
+    assert any(pw >= 2**63 for _, (pw, _), _ in res)  # the case that used to raise "Overflow when unpacking long long"
+    for _, _, out in res:
+        assert out == want
+
+
+def test_allreduce_counts_single_process_keeps_uint64_range():
+    sys.path.insert(0, ROOT)
+    from graphminer_amd import dist
+
+    assert dist.allreduce_counts([2**64 - 5, 0, 2**63, 7]) == [2**64 - 5, 0, 2**63, 7]

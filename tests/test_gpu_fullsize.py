@@ -1,0 +1,96 @@
+"""Full-size parity inside `pytest -m gpu` (VERDICT r1, item 5 iv/v): the BASELINE stand-in workloads one size below the
+bench sizes, GPU count == CPU oracle (OpenMP on every host core of the GPU box) on the same generated graph, plus the
+size-independent identities between the kernels; and the README known answers when the real datasets are supplied.
+
+The sizes are chosen so that the oracle finishes in about a minute each on the 128-thread host (it is the loop nest of the
+reference: seconds on the GPU, minutes on the CPU). GM_SKIP_FULLSIZE=1 skips this file."""
+import os
+import time
+
+import pytest
+
+import oracle as O
+from common import GOLDEN
+from graphminer_amd import CliqueSolver, Graph, MotifSolver, SglSolver, TCSolver
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("GM_SKIP_FULLSIZE") == "1", reason="GM_SKIP_FULLSIZE=1")]
+
+
+@pytest.fixture(scope="module")
+def rmat_dev():
+    import torch
+
+    assert torch.cuda.is_available()
+    from graphminer_amd.rmat import rmat_csr_device
+
+    cache = {}
+
+    def get(scale, ef):
+        if (scale, ef) not in cache:
+            cache.clear()  # one graph resident at a time
+            sym, rp, ci = rmat_csr_device(scale, ef, 42, 0)
+            host = sym.download()
+            cache[(scale, ef)] = (sym, O.OGraph(host.row_ptr, host.col_idx), (rp, ci))
+        return cache[(scale, ef)][:2]
+
+    return get
+
+
+@pytest.mark.timeout(900)
+def test_diamond_rmat20_equals_oracle(rmat_dev):
+    sym, osym = rmat_dev(20, 16)
+    t = time.perf_counter()
+    want = O.diamond(osym)
+    print(f"oracle diamond R-MAT-20 ef16: {time.perf_counter() - t:.1f} s on {O.num_threads()} threads")
+    got, st = SglSolver(sym, "diamond", return_stats=True)
+    assert got == want
+    assert st.tasks == osym.ne // 2
+    assert sum(SglSolver(sym, "diamond", rank=r, world=8) for r in range(8)) == want
+
+
+@pytest.mark.timeout(900)
+def test_clique4_rmat20_equals_oracle(rmat_dev):
+    sym, osym = rmat_dev(20, 16)
+    dag, odag = sym.orient(), O.orient(osym)
+    t = time.perf_counter()
+    want = O.clique(odag, 4)
+    print(f"oracle 4-clique R-MAT-20 ef16: {time.perf_counter() - t:.1f} s on {O.num_threads()} threads")
+    got, st = CliqueSolver(dag, 4, return_stats=True)
+    assert got == want
+    assert st.tasks == odag.ne
+    assert sum(CliqueSolver(dag, 4, rank=r, world=8) for r in range(8)) == want
+    # cross-kernel identity: the triangles of the same DAG three ways
+    assert TCSolver(dag) == CliqueSolver(dag, 3) == O.tc(odag)
+
+
+@pytest.mark.timeout(1200)
+def test_motif3_rmat22_equals_oracle(rmat_dev):
+    sym, osym = rmat_dev(22, 16)
+    t = time.perf_counter()
+    want = O.motif3(osym)
+    print(f"oracle 3-motif R-MAT-22 ef16: {time.perf_counter() - t:.1f} s on {O.num_threads()} threads")
+    got, st = MotifSolver(sym, 3, return_stats=True)
+    assert got == want
+    assert st.tasks == osym.ne
+    assert MotifSolver(sym, 3, formula=True) == want
+    parts = [MotifSolver(sym, 3, rank=r, world=8) for r in range(8)]
+    assert [sum(p[i] for p in parts) % 2**64 for i in range(2)] == want
+
+
+@pytest.mark.parametrize("name", ["livej", "com-orkut"])
+def test_readme_known_answers_on_real_datasets(name):
+    """golden.json::_readme_known_answers (src/triangle/README.md:58-59, src/sgl/README.md:58, src/clique/README.md:59,
+    src/motif/README.md:59-60) when GM_DATA_DIR/<name>/graph.{meta.txt,vertex.bin,edge.bin} are supplied."""
+    root = os.environ.get("GM_DATA_DIR", "")
+    prefix = os.path.join(root, name, "graph")
+    if not root or not os.path.exists(prefix + ".meta.txt"):
+        pytest.skip("real dataset not supplied (set GM_DATA_DIR)")
+    known = GOLDEN["_readme_known_answers"][name]
+    sym = Graph(prefix).to_device(0)
+    dag = sym.orient()
+    assert TCSolver(dag) == known["tc"]
+    assert SglSolver(sym, "diamond") == known["diamond"]
+    assert MotifSolver(sym, 3) == known["motif3"]
+    assert CliqueSolver(dag, 4) == known["clique4"]
+    if "clique5" in known:
+        assert CliqueSolver(dag, 5) == known["clique5"]

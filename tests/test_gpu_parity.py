@@ -144,8 +144,10 @@ def test_house_hub_row_longer_than_lds_bitmap():
     d = np.concatenate([np.arange(n - 1), rng.integers(0, n - 1, 40000)]).astype(np.uint64)
     g = csr_from_pairs(n, s, d)
     assert int(np.diff(g.row_ptr).max()) > 16384
+    want = O.house(O.OGraph(g.row_ptr, g.col_idx))  # the restated loop nest of house.h:1-16 (seconds: one hub row)
     with DeviceGraph.upload(g) as sym:
         flat = SglSolver(sym, "house")
+        assert flat == want
         assert flat == SglSolver(sym, "house", tune=[0, 0, 0, 0, 0, 0, 1024])
         assert flat == SglSolver(sym, "house", tune=[0, 0, 0, 0, 0, 0, 0x800])
         assert flat == SglSolver(sym, "house", tune=[0, 0, 0, 0, 0, 0, 0x8000])
@@ -159,9 +161,9 @@ def test_clique4_matches_reference(gg):
     assert CliqueSolver(dag, 4, tune=[512, 4, 0, 0, 0, 1]) == GOLDEN[name]["clique4"]
 
 
-@pytest.mark.parametrize("k", [5, 6, 7])
+@pytest.mark.parametrize("k", [5, 6, 7, 8])
 def test_clique_k_matches_reference(gg, k):
-    """k = 5 (automine_5clique, automine_omp.h:138-157) and k = 6, 7 (goldens from clique_omp_recursive) on the
+    """k = 5 (automine_5clique, automine_omp.h:138-157) and k = 6, 7, 8 (goldens from clique_omp_recursive) on the
     same bit-matrix: C_1(S)=|S|, C_m(S)=sum_{j in S} C_{m-1}(S & M_j)."""
     name, _, _, dag = gg
     e = GOLDEN[name]
@@ -299,12 +301,16 @@ def test_big_rows_deeper_cliques(dev):
 
 def test_deeper_cliques_sub_matrix_path_rmat14(dev):
     """R-MAT-14 (ef 16) DAG: induced-sub-matrix path against the per-sub-tree walk, k = 5 and 6"""
-    d = rmat_csr_numpy(14, 16, 42).to_device(dev).orient()
+    g = rmat_csr_numpy(14, 16, 42)
+    d = g.to_device(dev).orient()
+    odag = O.orient(O.OGraph(g.row_ptr, g.col_idx))
     for k in (5, 6):
-        want = CliqueSolver(d, k, tune=[0, 0, 0, 0, 0, 0, 0x20])
+        want = GOLDEN[g.name][f"clique{k}"]  # clique_omp_base (k = 5) / clique_omp_recursive (k = 6) of the reference
+        assert O.clique(odag, k) == want     # ... and the oracle's DFS on the same DAG
         assert CliqueSolver(d, k) == want
+        assert CliqueSolver(d, k, tune=[0, 0, 0, 0, 0, 0, 0x20]) == want
         assert sum(CliqueSolver(d, k, rank=r, world=4) for r in range(4)) == want
-    assert CliqueSolver(d, 5) == O.clique(O.orient(O.OGraph(*(lambda g: (g.row_ptr, g.col_idx))(rmat_csr_numpy(14, 16, 42)))), 5)
+    assert CliqueSolver(d, 7) == GOLDEN[g.name]["clique7"]
 
 
 def test_hub_graph_against_oracle(dev):
@@ -379,8 +385,11 @@ def test_hub_paths_against_oracle_rmat16(dev):
     assert sum(SglSolver(s, "diamond", rank=r, world=8) for r in range(8)) == want_d
     parts = [MotifSolver(s, 3, rank=r, world=3, policy=2) for r in range(3)]
     assert [sum(p[i] for p in parts) % 2**64 for i in range(2)] == want_m3
-    # 4-motif of this graph (the oracle needs ~6 min on 8 cores for it; checked once against the GPU result)
-    assert MotifSolver(s, 4) == [503764659200, 122696041276, 48153202316, 1160147308, 3513532002, 292680292]
+    # golden.json: tc / motif3 / motif4 of this graph from the reference's tc_omp_base, motif_omp_base, motif_omp_formula
+    e = GOLDEN[g.name]
+    assert e["csr_sha256"] == __import__("common").csr_sha(g)
+    assert want_m3 == e["motif3"] and TCSolver(s.orient()) == e["tc"]
+    assert MotifSolver(s, 4) == e["motif4"]
 
 
 @pytest.mark.parametrize("pattern", ["rectangle", "house", "pentagon"])
