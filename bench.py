@@ -1,29 +1,42 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE.json's metric ("million edges processed/sec + total match count") on MI355X.
 
-A "step" = one pass of the hot path (one mining kernel over every task edge of the graph, plus the
-RCCL all-reduce of the 64-bit count when --gpus > 1), inputs resident in HBM before the timed region.
+A "step" = one pass of the hot path (the mining kernel(s) of one workload over every task edge of the graph, plus the
+RCCL all-reduce of the 64-bit counts when --gpus > 1), inputs resident in HBM before the timed region.
 
-Default workload (N=1) = BASELINE.json configs[1]: triangle counting on LiveJournal. The real
-LiveJournal files are not in the image, so the default graph is the stand-in
-SURVEY.md section 8d names: R-MAT scale 22, edge factor 10, seed 42 (|V| = 4.19 M, ~LiveJournal's
-|E|); pass --graph <prefix> to run the real graph.meta.txt/vertex.bin/edge.bin instead.
+Default run = ALL FIVE BASELINE.json configs on one JSON line:
+  * the top-level keys (`value`, `ms_per_step`, `roofline`, `cpu_baseline`, ...) are the HEADLINE: configs[1], triangle
+    counting on LiveJournal. The real LiveJournal / Orkut files are not in the image, so the graphs
+    are the stand-ins SURVEY.md section 8d names: R-MAT scale 22 ef 10 (TC, diamond), scale 22 ef 28 (4-clique),
+    scale 24 ef 16 (3-motif), seed 42; `--data-dir D` runs D/livej/graph.* and D/com-orkut/graph.* instead and checks the
+    README known answers;
+  * `configs` holds one record per BASELINE config (1: the CPU plumbing case on citeseer, 2: TC, 3: diamond, 4: 4-clique,
+    5: 3-motif R-MAT-24 -- the largest single-GPU configuration), each with its count, count check, algorithmic and
+    counter-traffic bandwidth, the compulsory floor, and a CPU baseline timed on this box's host cores.
 
   python bench.py --gpus 1 --steps 20 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
          --master-port 29500 bench.py --gpus 8 --steps 20 --warmup 3
+  python bench.py --workload diamond --scale 20 --ef 16          # one workload (development / profiling)
 
-Multi-GPU: one process per GPU; every rank holds the full CSR (it regenerates / reloads it, no
-broadcast needed), owns the task chunks c = rank (mod world) [Scheduler::round_robin policy,
-src/common/scheduler.cc:34-85] and the per-rank counts are summed by ONE all-reduce per step
-(torch.distributed backend "nccl" = RCCL over xGMI). Per-GPU work shrinks as N grows: scaling =
-"strong" (the graph, hence total work, is fixed).
+Multi-GPU: one process per GPU; every rank holds the full CSR (it regenerates / reloads it, no broadcast needed), owns
+the task chunks c = rank (mod world) of the cost-ordered dequeue list [Scheduler::round_robin policy,
+src/common/scheduler.cc:34-85] and the per-rank counts are summed by ONE all-reduce per step (torch.distributed backend
+"nccl" = RCCL over xGMI). Per-GPU work shrinks as N grows: scaling = "strong" (the graph, hence total work, is fixed).
+
+Timing follows src/triangle/gpu_base.cu:53-71 (timer around the kernel loop only, TEPS = nnz / t) with the reference's
+averaging (OSDI-experiments-guide.md:39-41: mean of the runs): W untimed steps, then K steps between barriers, max over ranks.
 """
 import argparse
 import ctypes as C
+import glob
 import json
 import os
+import re
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -41,7 +54,27 @@ WORKLOADS = {
     "clique5": (20, 16, True, "5-clique, R-MAT scale 20"),
     "motif3f": (24, 16, False, "3-motif, formula variant (motif_gpu_formula), R-MAT scale 24"),
 }
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# BASELINE.json configs[1..4] (configs[0] = the CPU plumbing case, handled by config1_record)
+BASELINE_CONFIGS = [
+    (2, "tc", "triangle counting on LiveJournal, 1xMI355X, count bit-exact vs tc_omp_base", "livej"),
+    (3, "diamond", "sgl diamond pattern on LiveJournal, 1xMI355X (2-level set-intersect DFS)", "livej"),
+    (4, "clique4", "4-clique (k-CL k=4) on Orkut, edge-partitioned across 8xMI355X with RCCL count all-reduce", "com-orkut"),
+    (5, "motif3", "3-motif counting on a synthetic RMAT scale-24 graph, 1->8 GPU scaling + HBM BW fraction", None),
+]
+# rocprofv3 kernel names that make up one launch of a workload (everything between the library's two timing events)
+KERNELS = {
+    "tc": ["mine_kernel<0>"],
+    "diamond": ["mine_kernel<1>", "mine_wide_kernel<1>"],
+    "motif3": ["mine_kernel<2>", "mine_wide_kernel<2>"],
+    "clique4": ["mine_kernel<3>", "clique_wide_kernel"],
+    "clique5": ["mine_kernel<4>"],
+    "motif3f": ["mine_kernel<0>"],
+    "rectangle": ["rect_acc_kernel"],
+    "house": ["house_acc_kernel"],
+    "pentagon": ["pent_acc_kernel"],
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (~6.3 TB/s achievable by a stream)
+M64 = (1 << 64) - 1
 
 
 def parse():
@@ -49,241 +82,648 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="tc", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="", choices=[""] + sorted(WORKLOADS), help="run ONE workload instead of the five BASELINE configs")
+    ap.add_argument("--configs", default="all", help="'all' or a comma list out of tc,diamond,clique4,motif3 (default run)")
     ap.add_argument("--scale", type=int, default=0)
     ap.add_argument("--ef", type=int, default=0)
     ap.add_argument("--seed", type=int, default=42)
-    ap.add_argument("--graph", default="", help="prefix of graph.meta.txt/.vertex.bin/.edge.bin (real dataset)")
+    ap.add_argument("--graph", default="", help="prefix of graph.meta.txt/.vertex.bin/.edge.bin (real dataset), one-workload mode")
+    ap.add_argument("--data-dir", default=os.environ.get("GM_DATA_DIR", ""), help="directory with livej/graph.* and com-orkut/graph.* (real datasets)")
     ap.add_argument("--uniform", default="", help="NV,M: uniform random graph instead of R-MAT (LiveJournal-size flat-degree stand-in)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-ref-baseline", action="store_true", help="skip the timed run of oracle/_ref/tc_omp_base")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the bounded oracle sample")
+    ap.add_argument("--no-ref-baseline", action="store_true", help="skip the timed runs of the oracle/_ref reference binaries")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of each bounded oracle sample")
+    ap.add_argument("--traffic", default="auto", choices=["auto", "off", "file"],
+                    help="HBM-side bytes per launch: auto = re-run the workloads under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                         "(two extra passes, N = 1 only), file = profiles/traffic.json, off = null")
+    ap.add_argument("--traffic-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--tune", default="", help="comma separated gm_launch.tune[] override")
     ap.add_argument("--policy", type=int, default=0, help="0 = chunked round robin, 1 = contiguous ranges")
     return ap.parse_args()
 
 
-def alg_bytes(workload, rp, ci):
-    """SURVEY.md 8(d) ALGORITHMIC bytes of one launch over the whole graph (numpy, exact)."""
-    import numpy as np
+# ---------------------------------------------------------------------------------------------------------------
+# graphs
+# ---------------------------------------------------------------------------------------------------------------
+class BenchGraph:
+    """symmetric CSR resident in HBM (+ torch views of its arrays) and, on demand, its oriented copy"""
 
-    deg = np.diff(rp).astype(np.int64)
-    sq = int((deg * deg).sum())          # sum_e d(src)
-    dv = int(deg[ci].sum())              # sum_e d(dst)
-    ne = int(ci.size)
-    if workload in ("tc",):
-        return 4 * (sq + dv) + 40 * ne
-    if workload == "diamond":            # edges v1 < v0 only: by symmetry exactly half of sum_e (d(v0)+d(v1))
-        return 4 * (sq + dv) // 2 + 40 * (ne // 2)
-    if workload == "motif3":             # one difference per directed edge + one intersect per v1 < v0 edge
-        return 4 * (sq + dv) + 4 * (sq + dv) // 2 + 40 * ne
-    return None                          # clique4 needs |S1| per edge: taken from the oracle in tests, not here
+    def __init__(self, sym, rp, ci, name, build_s):
+        self.sym, self.rp, self.ci, self.name, self.build_s = sym, rp, ci, name, build_s
+        self._dag = None
+
+    def dag(self):
+        if self._dag is None:
+            self._dag = self.sym.orient()
+        return self._dag
+
+    def free(self):
+        if self._dag is not None:
+            self._dag.free()
+        self.sym.free()
+        self.rp = self.ci = None
+
+
+def build_graph(a, local_rank, scale, ef, graph_prefix=""):
+    import torch
+
+    from graphminer_amd import DeviceGraph, Graph
+    from graphminer_amd.rmat import rmat_csr_device, uniform_csr_device
+
+    t = time.perf_counter()
+    if graph_prefix:
+        h = Graph(graph_prefix)
+        dev = torch.device("cuda", local_rank)
+        rp = torch.from_numpy(h.row_ptr).to(dev)
+        ci = torch.from_numpy(h.col_idx).to(dev)
+        sym = DeviceGraph.from_device_ptrs(h.V(), h.E(), rp.data_ptr(), ci.data_ptr(), local_rank, keepalive=(rp, ci))
+        name = f"file:{graph_prefix}"
+    elif a.uniform:
+        unv, um = (int(x) for x in a.uniform.split(","))
+        sym, rp, ci = uniform_csr_device(unv, um, a.seed, local_rank)
+        name = f"uniform_nv{unv}_m{um}_seed{a.seed}"
+    else:
+        sym, rp, ci = rmat_csr_device(scale, ef, a.seed, local_rank)
+        name = f"rmat_s{scale}_ef{ef}_seed{a.seed}"
+    torch.cuda.synchronize()
+    return BenchGraph(sym, rp, ci, name, time.perf_counter() - t)
+
+
+def alg_bytes_device(workload, bg, lib, g):
+    """SURVEY.md 8(d) ALGORITHMIC bytes of one launch over the whole graph, exact, computed on the GPU with torch
+    (tests/test_gpu_bench.py checks it against the oracle's gmo_alg_bytes_* on small graphs).
+    Returns (bytes or None, compulsory floor 8(nv+1)+4ne of the CSR the workload runs on)."""
+    import torch
+
+    from graphminer_amd import _lib
+
+    rp, ci = bg.rp, bg.ci
+    nv = rp.numel() - 1
+    deg = rp[1:] - rp[:-1]
+    if workload in ("tc", "clique4", "clique5", "motif3f"):
+        # oriented degrees from the symmetric arrays: keep (s -> d) iff deg[d] > deg[s] or (== and d > s)  (graph.cc:246-247)
+        src = torch.repeat_interleave(torch.arange(nv, device=rp.device), deg)
+        dst = ci.long()
+        keep = (deg[dst] > deg[src]) | ((deg[dst] == deg[src]) & (dst > src))
+        s2, d2 = src[keep], dst[keep]
+        del src, dst, keep
+        dplus = torch.bincount(s2, minlength=nv)
+        ne = int(s2.numel())
+        sq = int((dplus * dplus).sum().item())
+        dv = int(dplus[d2].sum().item())
+        del s2, d2, dplus
+        floor = 8 * (nv + 1) + 4 * ne
+        if workload == "clique5":
+            return None, floor
+        ab = 4 * (sq + dv) + 40 * ne  # TC (motif3f = the TC kernel on the DAG)
+        if workload == "clique4":  # level 1 = the TC formula, level 2 from the statistics kernel
+            l2 = C.c_uint64(0)
+            _lib.check(lib.gm_clique4_level2_bytes(g.handle, C.byref(l2)), "gm_clique4_level2_bytes")
+            ab += int(l2.value)
+        return ab, floor
+    ne = int(ci.numel())
+    floor = 8 * (nv + 1) + 4 * ne
+    sq = int((deg * deg).sum().item())  # sum_e d(src)
+    dv = int(deg[ci.long()].sum().item())  # sum_e d(dst)
+    if workload == "diamond":  # edges v1 < v0 only: by symmetry exactly half of sum_e (d(v0)+d(v1))
+        return 4 * (sq + dv) // 2 + 40 * (ne // 2), floor
+    if workload == "motif3":  # one difference per directed edge + one intersect per v1 < v0 edge
+        return 4 * (sq + dv) + 4 * (sq + dv) // 2 + 40 * ne, floor
+    return None, floor
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# one workload: W warm-up steps, K timed steps
+# ---------------------------------------------------------------------------------------------------------------
+class Runner:
+    def __init__(self, a):
+        import torch
+        import torch.distributed as dist
+
+        self.a, self.torch, self.dist = a, torch, dist
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != a.gpus:
+            raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={self.world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+        assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path to measure)"
+        torch.cuda.set_device(self.local_rank)
+        self.dev = torch.device("cuda", self.local_rank)
+        self.use_dist = self.world > 1 or os.environ.get("GM_BENCH_FORCE_DIST") == "1"  # the latter: exercise RCCL with one rank
+        if self.use_dist:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
+        from graphminer_amd import _lib
+
+        self._lib = _lib
+        self.lib = _lib.load()
+        self.counts = torch.zeros(8, dtype=torch.int64, device=self.dev)
+
+    def fence(self):
+        self.torch.cuda.synchronize()
+        if self.use_dist:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def close(self):
+        if self.use_dist:
+            self.dist.barrier()  # rank 0 finishes its host-side reporting before any rank tears the communicator down
+            self.dist.destroy_process_group()
+
+    def run(self, workload, bg, steps, warmup):
+        """Returns a dict with the timing and the counts of `workload` on graph `bg`."""
+        from graphminer_amd._lib import gm_launch, gm_stats
+
+        a, lib, torch = self.a, self.lib, self.torch
+        oriented = WORKLOADS[workload][2]
+        g = bg.dag() if oriented else bg.sym
+        la = gm_launch()
+        la.stream = torch.cuda.current_stream().cuda_stream or None
+        la.rank, la.world, la.policy = self.rank, self.world, a.policy
+        la.d_counts = self.counts.data_ptr()
+        if a.tune:
+            for i, t in enumerate(a.tune.split(",")):
+                la.tune[i] = int(t)
+        st = gm_stats()
+
+        def step():
+            if workload == "tc":
+                rc = lib.gm_tc(g.handle, C.byref(la), None, C.byref(st))
+            elif workload in ("diamond", "rectangle", "house", "pentagon"):
+                rc = lib.gm_sgl(g.handle, workload.encode(), C.byref(la), None, C.byref(st))
+            elif workload in ("clique4", "clique5"):
+                rc = lib.gm_clique(g.handle, int(workload[-1]), C.byref(la), None, C.byref(st))
+            elif workload == "motif3f":
+                rc = lib.gm_motif_formula(g.handle, 3, C.byref(la), None, 2, C.byref(st))
+            else:
+                rc = lib.gm_motif(g.handle, 3, C.byref(la), None, 2, C.byref(st))
+            self._lib.check(rc, "bench step")
+            if self.use_dist:
+                self.dist.all_reduce(self.counts)  # ONE RCCL all-reduce of the 64-bit counts (int64 add wraps like uint64)
+
+        # first call: builds the per-graph task tables ("Time on generating the edgelist" of the reference) -- timed apart
+        self.fence()
+        t0 = time.perf_counter()
+        step()
+        self.fence()
+        first_call_s = time.perf_counter() - t0
+        for _ in range(max(warmup - 1, 0)):
+            step()
+        self.fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        self.fence()
+        elapsed = time.perf_counter() - t0
+        if self.use_dist:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=self.dev)
+            self.dist.all_reduce(tmax, op=self.dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        result = [int(x) & M64 for x in self.counts.cpu().tolist()]
+        kms = g.kernel_times_ms(min(steps, 64))
+        k_avg = sum(kms) / max(len(kms), 1)
+        per_gpu = [k_avg]
+        if self.use_dist:  # per-GPU kernel time, as the reference prints runtime[gpu i] (src/clique/multigpu.cu:136-137)
+            tk = torch.zeros(self.world, dtype=torch.float64, device=self.dev)
+            tk[self.rank] = k_avg
+            self.dist.all_reduce(tk)
+            per_gpu = [float(x) for x in tk.cpu().tolist()]
+        sym_e = bg.sym.E()
+        # "edges processed" = the reference's nnz (src/triangle/gpu_base.cu:69): |E+| (tc, clique), ne/2 (diamond), ne (motif)
+        tasks = g.E() // 2 if workload in ("diamond", "rectangle", "house", "pentagon") else g.E()
+        setup = g.setup_times_ms()  # (the DAG handle carries the orientation time of the graph it was made from)
+        return {
+            "workload": workload, "g": g, "tasks": tasks, "elapsed": elapsed, "steps": steps,
+            "ms_per_step": 1e3 * elapsed / steps, "count": result[:2] if workload.startswith("motif3") else result[0],
+            "kernel_ms_avg": k_avg, "per_gpu_kernel_ms": per_gpu, "first_call_ms": 1e3 * first_call_s, "setup_ms": setup,
+            "nv": g.V(), "ne_sym": sym_e, "max_degree": g.get_max_degree(), "stats": {"grid": int(st.grid), "block": int(st.block)},
+        }
+
+    def stream_ceiling(self):
+        """Measured dword-stream read bandwidth (gm_calib_stream over 4 GiB >> the 256 MiB Infinity Cache), GB/s."""
+        torch = self.torch
+        n = 1 << 30
+        buf = torch.ones(n, dtype=torch.int32, device=self.dev)
+        out = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        s = torch.cuda.current_stream().cuda_stream or None
+        best = 0.0
+        for i in range(4):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self._lib.check(self.lib.gm_calib_stream(buf.data_ptr(), n, out.data_ptr(), s), "gm_calib_stream")
+            e1.record()
+            torch.cuda.synchronize()
+            if i:
+                best = max(best, 4.0 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+        del buf
+        return best
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# HBM-side traffic: the same workloads under rocprofv3 --pmc (separate passes for FETCH_SIZE and WRITE_SIZE)
+# ---------------------------------------------------------------------------------------------------------------
+def traffic_worker(a):
+    """Child of measure_traffic(): runs every requested workload (1 warm-up + `steps` launches), prints the launch counts."""
+    r = Runner(a)
+    todo = [w for w in (a.configs.split(",") if a.configs != "all" else ["tc", "diamond", "clique4", "motif3"])]
+    graphs, launches = {}, {}
+    for w in todo:
+        scale, ef = (a.scale or WORKLOADS[w][0]), (a.ef or WORKLOADS[w][1])
+        prefix = dataset_prefix(a, w)
+        key = prefix or (scale, ef)
+        if key not in graphs:
+            for bg in graphs.values():
+                bg.free()
+            graphs.clear()
+            graphs[key] = build_graph(a, r.local_rank, scale, ef, prefix)
+        r.run(w, graphs[key], a.steps, 1)
+        launches[w] = a.steps + 1
+    print("TRAFFIC_WORKER " + json.dumps(launches), flush=True)
+    r.close()
+
+
+def dataset_prefix(a, workload):
+    """real dataset for a BASELINE config when --data-dir holds it, else '' (synthetic stand-in)"""
+    if a.graph:
+        return a.graph
+    if not a.data_dir:
+        return ""
+    name = {"tc": "livej", "diamond": "livej", "clique4": "com-orkut"}.get(workload)
+    p = os.path.join(a.data_dir, name, "graph") if name else ""
+    return p if p and os.path.exists(p + ".meta.txt") else ""
+
+
+def measure_traffic(a, workloads):
+    """{workload: {"fetch_bytes", "write_bytes", "launches", "kernels": {...}}} per launch, or (None, reason)."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    out = {w: {"kernels": {}} for w in workloads}
+    tmp = tempfile.mkdtemp(prefix="gm_traffic_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+                   sys.executable, os.path.abspath(__file__), "--traffic-worker", "--configs", ",".join(workloads), "--steps", "2",
+                   "--traffic", "off", "--no-cpu-baseline", "--seed", str(a.seed)]
+            for flag, val in (("--scale", a.scale), ("--ef", a.ef)):
+                if val:
+                    cmd += [flag, str(val)]
+            for flag, val in (("--graph", a.graph), ("--data-dir", a.data_dir), ("--uniform", a.uniform), ("--tune", a.tune)):
+                if val:
+                    cmd += [flag, val]
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "GM_BENCH_FORCE_DIST"):
+                env.pop(k, None)
+            r = subprocess.run(cmd, capture_output=True, text=True, cwd="/tmp", env=env, timeout=900)
+            m = re.search(r"TRAFFIC_WORKER (\{.*\})", r.stdout)
+            if r.returncode != 0 or not m:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {(r.stderr or r.stdout)[-300:]}"
+            launches = json.loads(m.group(1))
+            import csv
+
+            sums = {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") == counter:
+                        k = row.get("Kernel_Name", "")
+                        sums[k] = sums.get(k, 0.0) + float(row.get("Counter_Value", 0))
+            if not sums:
+                return None, f"no {counter} rows in the rocprofv3 output"
+            for w in workloads:
+                tot = 0.0
+                for kname, v in sums.items():
+                    if any(p in kname for p in KERNELS.get(w, [])):
+                        tot += v
+                        out[w]["kernels"][kname[:60]] = out[w]["kernels"].get(kname[:60], {})
+                        out[w]["kernels"][kname[:60]][counter] = v / launches[w]
+                # counter unit: KB. gfx950: FETCH_SIZE reports exactly 1/2 of the bytes of a coalesced stream (MI355X_MICROARCH.md,
+                # re-checked for the dword-per-lane width these kernels use: profiles/r01/traffic_fetch_write_summary.txt) -> x2;
+                # WRITE_SIZE is uncalibrated (x1)
+                scale = 2048.0 if counter == "FETCH_SIZE" else 1024.0
+                out[w]["fetch_bytes" if counter == "FETCH_SIZE" else "write_bytes"] = tot * scale / launches[w]
+                out[w]["launches"] = launches[w]
+        return out, "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of the same workloads in this run; FETCH x2 (gfx950 calibration), KB units"
+    except Exception as e:  # a report, never a reason to lose the bench line
+        return None, f"traffic measurement failed: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CPU baselines (rank 0, N = 1 only): the reference's binaries (oracle/_ref) and / or the oracle, on this box's host cores
+# ---------------------------------------------------------------------------------------------------------------
+def median(xs):
+    s = sorted(xs)
+    return s[len(s) // 2] if len(s) % 2 else 0.5 * (s[len(s) // 2 - 1] + s[len(s) // 2])
+
+
+def run_reference(exe_name, args, pattern_time, pattern_count, threads, runs, timeout=600):
+    exe = os.path.join(ROOT, "oracle", "_ref", exe_name)
+    if not os.path.exists(exe):
+        return None
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="spread")
+    times, count = [], None
+    for _ in range(runs):
+        r = subprocess.run([exe, *args], capture_output=True, text=True, env=env, timeout=timeout)
+        m = re.search(pattern_time, r.stdout)
+        c = re.findall(pattern_count, r.stdout)
+        if r.returncode != 0 or not m or not c:
+            return None
+        times.append(float(m.group(1)))
+        count = [int(x) for x in c]
+    return {"seconds": median(times), "all_seconds": [round(t, 3) for t in times], "count": count}
+
+
+def cpu_baselines(a, recs, graphs):
+    """cpu_baseline object per workload. TC: the REFERENCE's tc_omp_base on the whole graph, median of 3 (its own Timer line,
+    src/triangle/omp_base.cc:12-24); diamond: the reference's sgl_omp_base, one run (tens of seconds); 4-clique / 3-motif:
+    the oracle on a bounded, degree-representative sample (vertices v0 = 0 mod stride, ~a.cpu_seconds of CPU work)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle as O  # the CPU oracle, timed as the OpenMP baseline ("port"): never the product path
+
+    threads = O.num_threads()
+    out = {}
+    saved = {}  # graph name -> (tmpdir, prefix) of the three-file copy the reference binaries read
+    host = {}
+
+    def host_graph(bg):
+        if bg.name not in host:
+            h = bg.sym.download()
+            host[bg.name] = (h, O.OGraph(h.row_ptr, h.col_idx))
+        return host[bg.name]
+
+    def saved_prefix(bg):
+        if bg.name not in saved:
+            tmp = tempfile.mkdtemp(prefix="gm_ref_", dir="/tmp")
+            host_graph(bg)[0].save(os.path.join(tmp, "graph"))
+            saved[bg.name] = tmp
+        return os.path.join(saved[bg.name], "graph")
+
+    def sample(fn_sample, tasks_total, what):
+        """calibrate a stride on a thin sample, then time one sample of ~cpu_seconds"""
+        cal = 1024
+        t = time.perf_counter()
+        fn_sample(cal)
+        tcal = time.perf_counter() - t
+        stride = max(1, int(tcal * cal / max(a.cpu_seconds, 1e-3)))
+        t = time.perf_counter()
+        cnt, tasks = fn_sample(stride)
+        dt = time.perf_counter() - t
+        return {"value": round(tasks / dt / 1e6, 3), "unit": "Medges/s", "cores": threads, "kind": "port", "seconds": round(dt, 2),
+                "sample": f"oracle {what}: vertices v0 = 0 mod {stride} of the same graph ({tasks} of {tasks_total} task edges), "
+                          f"OpenMP schedule(dynamic,1), OMP_PROC_BIND unset", "host_cpus": os.cpu_count(),
+                "sample_count": cnt, "stride": stride}
+
+    try:
+        for rec in recs:
+            w, bg = rec["workload"], graphs[rec["workload"]]
+            try:
+                if w == "tc":
+                    h, osym = host_graph(bg)
+                    odag = O.orient(osym)
+                    port = sample(lambda s: O.tc_sample(odag, s, 0), rec["tasks"], "gmo_tc_sample")
+                    if port["stride"] == 1:
+                        port["count_matches_gpu"] = bool(port["sample_count"] == rec["count"])
+                    base = port
+                    ref = None if a.no_ref_baseline else run_reference(
+                        "tc_omp_base", [saved_prefix(bg)], r"runtime \[omp_base\] = ([0-9.eE+-]+) sec", r"total_num_triangles = (\d+)", threads, 3)
+                    if ref:
+                        base = {"value": round(rec["tasks"] / ref["seconds"] / 1e6, 3), "unit": "Medges/s", "cores": threads,
+                                "kind": "reference", "seconds": round(ref["seconds"], 3), "runs_seconds": ref["all_seconds"],
+                                "count_matches_gpu": bool(ref["count"][-1] == rec["count"]), "cpu_count": ref["count"][-1],
+                                "sample": "tc_omp_base (reference binary, g++ -O3 -fopenmp, its own orientation + Timer) on the whole "
+                                          "graph, median of 3 runs, OMP_PROC_BIND=spread", "host_cpus": os.cpu_count(),
+                                "port": {k: port[k] for k in ("value", "seconds", "sample")}}
+                    out[w] = base
+                elif w == "diamond":
+                    h, osym = host_graph(bg)
+                    port = sample(lambda s: O.diamond_sample(osym, s, 0), rec["tasks"], "gmo_diamond_sample")
+                    base = port
+                    est_full = port["seconds"] * port["stride"]
+                    if not a.no_ref_baseline and est_full < 150:
+                        ref = run_reference("sgl_omp_base", [saved_prefix(bg), "diamond"], r"runtime \[omp_base\] = ([0-9.eE+-]+) sec",
+                                            r"total_num = (\d+)", threads, 1)
+                        if ref:
+                            base = {"value": round(rec["tasks"] / ref["seconds"] / 1e6, 3), "unit": "Medges/s", "cores": threads,
+                                    "kind": "reference", "seconds": round(ref["seconds"], 3),
+                                    "count_matches_gpu": bool(ref["count"][-1] == rec["count"]), "cpu_count": ref["count"][-1],
+                                    "sample": "sgl_omp_base diamond (reference binary, its own Timer) on the whole graph, ONE run "
+                                              "(tens of seconds; the reference's methodology is the mean of 3), OMP_PROC_BIND=spread",
+                                    "host_cpus": os.cpu_count(), "port": {k: port[k] for k in ("value", "seconds", "sample")}}
+                    out[w] = base
+                elif w == "clique4":
+                    h, osym = host_graph(bg)
+                    odag = O.orient(osym)
+                    out[w] = sample(lambda s: O.clique_sample(odag, 4, s, 0), rec["tasks"], "gmo_clique_sample(k=4)")
+                elif w == "motif3":
+                    h, osym = host_graph(bg)
+
+                    def ms(s):
+                        c, t = O.motif3_sample(osym, s, 0)
+                        return c, t
+                    out[w] = sample(ms, rec["tasks"], "gmo_motif3_sample")
+            except Exception as e:
+                print(f"[bench] cpu baseline of {w} skipped: {e}", file=sys.stderr)
+            if w in ("clique4", "motif3"):
+                host.pop(bg.name, None)  # (gigabytes of host copies: drop them as soon as the sample is timed)
+    finally:
+        for tmp in saved.values():
+            shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
+def config1_record(a):
+    """BASELINE configs[0]: `tc_omp_base inputs/citeseer/graph` -- the CPU plumbing case (loader + orientation + OMP solver),
+    run as the reference binary and as the oracle's CLI; plus the same graph through the HIP path."""
+    prefix = os.path.join(ROOT, "tests", "fixtures", "citeseer", "graph")
+    rec = {"id": 1, "config": "tc_omp_base on inputs/citeseer/graph (triangle count, CPU-only plumbing)", "graph": "citeseer",
+           "expected": 1166}
+    for kind, exe in (("reference", os.path.join(ROOT, "oracle", "_ref", "tc_omp_base")), ("port", os.path.join(ROOT, "oracle", "bin", "tc_omp_base"))):
+        if os.path.exists(exe):
+            r = subprocess.run([exe, prefix], capture_output=True, text=True, timeout=120)
+            m = re.search(r"total_num_triangles = (\d+)", r.stdout)
+            rec[f"{kind}_count"] = int(m.group(1)) if m else None
+    try:
+        from graphminer_amd import Graph, TCSolver
+
+        with Graph(prefix).to_device(int(os.environ.get("LOCAL_RANK", "0"))) as sym:
+            dag = sym.orient()
+            rec["gpu_count"] = TCSolver(dag)
+            dag.free()
+    except Exception as e:
+        rec["gpu_count"] = f"error: {e}"
+    rec["count_matches_cpu"] = all(rec.get(k, 1166) == 1166 for k in ("reference_count", "port_count", "gpu_count"))
+    return rec
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def finish_record(rec, a, world, ab, floor, traffic, traffic_src, cpu, known, stream_gbs):
+    """the JSON sub-record of one workload"""
+    t = rec["kernel_ms_avg"] * 1e-3
+    step_t = rec["elapsed"] / rec["steps"]
+    out = {
+        "workload": rec["workload"], "graph": rec["graph"], "nv": rec["nv"], "ne_sym": rec["ne_sym"], "tasks": rec["tasks"],
+        "max_degree": rec["max_degree"], "steps": rec["steps"], "ms_per_step": round(rec["ms_per_step"], 4),
+        "kernel_ms_avg": round(rec["kernel_ms_avg"], 4), "value": round(rec["tasks"] / step_t / 1e6, 3), "unit": "Medges/s",
+        "count": rec["count"], "matches_per_sec": round((rec["count"][1] if isinstance(rec["count"], list) else rec["count"]) / step_t, 1),
+        "first_call_ms": round(rec["first_call_ms"], 2), "setup_ms": rec["setup_ms"],
+        "per_gpu_kernel_ms": {"max": round(max(rec["per_gpu_kernel_ms"]), 4), "mean": round(sum(rec["per_gpu_kernel_ms"]) / len(rec["per_gpu_kernel_ms"]), 4),
+                              "all": [round(x, 4) for x in rec["per_gpu_kernel_ms"]]},
+        "grid": rec["stats"],
+    }
+    roof = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": "+".join(KERNELS.get(rec["workload"], ["?"])),
+            "compulsory_floor_bytes": floor, "stream_ceiling_GBs": round(stream_gbs, 1) if stream_gbs else None}
+    alg_gbs = None
+    if ab is not None and t > 0:
+        per_launch = ab / world  # each rank's kernel covers ~1/world of the task chunks
+        alg_gbs = per_launch / t / 1e9
+        roof.update({"algorithmic_bytes_per_launch": int(per_launch), "algorithmic_GBs": round(alg_gbs, 2),
+                     "algorithmic_frac": round(alg_gbs / HBM_PEAK_GBS, 5)})
+    tr_gbs = None
+    if traffic:
+        tb = traffic.get("fetch_bytes", 0.0) + traffic.get("write_bytes", 0.0)
+        tr_gbs = tb / t / 1e9 if t > 0 else None
+        roof.update({"traffic": int(tb), "traffic_fetch_bytes": int(traffic.get("fetch_bytes", 0)), "traffic_write_bytes": int(traffic.get("write_bytes", 0)),
+                     "traffic_GBs": round(tr_gbs, 2) if tr_gbs else None, "traffic_frac": round(tr_gbs / HBM_PEAK_GBS, 5) if tr_gbs else None,
+                     "traffic_source": traffic_src, "traffic_kernels": traffic.get("kernels")})
+    else:
+        roof.update({"traffic": None, "traffic_source": traffic_src})
+    # `achieved` / `frac`: the algorithmic figure while it is a roofline (<= 1 of the peak). Where the section-8(d) formula
+    # exceeds the peak -- it charges the reference's loop nest: a hub row is re-charged for each of its edges while the kernel
+    # stages it once, and 3-motif runs one intersection per undirected edge instead of difference + intersection per directed
+    # edge -- the counter traffic is the honest numerator.
+    if alg_gbs is not None and alg_gbs <= HBM_PEAK_GBS:
+        roof.update({"achieved": round(alg_gbs, 2), "frac": round(alg_gbs / HBM_PEAK_GBS, 5), "frac_basis": "algorithmic bytes (SURVEY 8d) / kernel time / 8 TB/s"})
+    elif tr_gbs is not None:
+        roof.update({"achieved": round(tr_gbs, 2), "frac": round(tr_gbs / HBM_PEAK_GBS, 5),
+                     "frac_basis": "counter traffic (FETCH x2 + WRITE) / kernel time / 8 TB/s -- the algorithmic formula exceeds the peak here"
+                                   + (f" (algorithmic_frac {alg_gbs / HBM_PEAK_GBS:.2f})" if alg_gbs else "")})
+    else:
+        roof.update({"achieved": round(alg_gbs, 2) if alg_gbs else None, "frac": None,
+                     "frac_basis": "no counter traffic available and the algorithmic formula exceeds the peak: not a roofline"})
+    if stream_gbs and roof.get("achieved"):
+        roof["frac_of_stream_ceiling"] = round(roof["achieved"] / stream_gbs, 5)
+    out["roofline"] = roof
+    if cpu:
+        out["cpu_baseline"] = cpu
+    # count check: against the CPU count of this run when one exists, else against the recorded full-size oracle answers
+    chk = {}
+    if cpu and "count_matches_gpu" in cpu:
+        chk = {"count_matches_cpu": cpu["count_matches_gpu"], "cpu_count_source": f"this run: {cpu['kind']} ({cpu['sample'][:40]}...)"}
+    elif known is not None:
+        chk = {"count_matches_cpu": bool(known["count"] == rec["count"]), "cpu_count_source": known["source"]}
+    else:
+        chk = {"count_matches_cpu": None, "cpu_count_source": "no full CPU count for this graph (sampled baseline only)"}
+    out.update(chk)
+    return out
+
+
+def known_answer(a, workload, graph_name):
+    """recorded CPU answers: README values for the real datasets, full-size oracle runs for the default stand-ins"""
+    try:
+        if graph_name.startswith("file:"):
+            gold = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))["_readme_known_answers"]
+            for ds, e in gold.items():
+                if f"/{ds}/" in graph_name and workload in e:
+                    return {"count": e[workload], "source": f"README known answer of {ds} (tests/golden/golden.json::_readme_known_answers)"}
+            return None
+        full = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize.json")))
+        e = full.get(f"{workload}:{graph_name}")
+        return {"count": e["count"], "source": e["source"]} if e else None
+    except Exception:
+        return None
 
 
 def main():
     a = parse()
-    import numpy as np
-    import torch
-    import torch.distributed as dist
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
-    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path to measure)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    use_dist = world > 1 or os.environ.get("GM_BENCH_FORCE_DIST") == "1"  # the latter: exercise RCCL with one rank
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
-    from graphminer_amd import Graph, _lib
-    from graphminer_amd._lib import gm_launch, gm_stats
-    from graphminer_amd.rmat import rmat_csr_device
-
-    lib = _lib.load()
-    scale0, ef0, oriented, desc = WORKLOADS[a.workload]
-    scale, ef = a.scale or scale0, a.ef or ef0
-
-    # ---- input: CSR resident in HBM -------------------------------------------------------------
-    t_in = time.perf_counter()
-    if a.graph:
-        sym = Graph(a.graph).to_device(local_rank)
-        gname = f"file:{a.graph}"
-    elif a.uniform:
-        from graphminer_amd.rmat import uniform_csr_device
-
-        unv, um = (int(x) for x in a.uniform.split(","))
-        sym, _rp, _ci = uniform_csr_device(unv, um, a.seed, local_rank)
-        gname = f"uniform_nv{unv}_m{um}_seed{a.seed}"
+    if a.traffic_worker:
+        return traffic_worker(a)
+    r = Runner(a)
+    world, rank = r.world, r.rank
+    single = bool(a.workload or a.graph or a.uniform)
+    if single:
+        todo = [(0, a.workload or "tc", WORKLOADS[a.workload or "tc"][3], None)]
     else:
-        sym, _rp, _ci = rmat_csr_device(scale, ef, a.seed, local_rank)
-        gname = f"rmat_s{scale}_ef{ef}_seed{a.seed}"
-    g = sym.orient() if oriented else sym
-    torch.cuda.synchronize()
-    t_in = time.perf_counter() - t_in
+        sel = ["tc", "diamond", "clique4", "motif3"] if a.configs == "all" else a.configs.split(",")
+        todo = [c for c in BASELINE_CONFIGS if c[1] in sel]
+        if not any(c[1] == "tc" for c in todo):
+            todo.insert(0, BASELINE_CONFIGS[0])  # the headline is always measured
 
-    counts = torch.zeros(4, dtype=torch.int64, device=dev)
-    la = gm_launch()
-    la.stream = torch.cuda.current_stream().cuda_stream or None
-    la.rank, la.world, la.policy = rank, world, a.policy
-    la.d_counts = counts.data_ptr()
-    if a.tune:
-        for i, t in enumerate(a.tune.split(",")):
-            la.tune[i] = int(t)
-    st = gm_stats()
+    t_start = time.perf_counter()
+    graphs, recs, bytes_of = {}, [], {}
+    keep = {}
+    for cid, w, desc, _ds in todo:
+        scale, ef = (a.scale or WORKLOADS[w][0]), (a.ef or WORKLOADS[w][1])
+        prefix = dataset_prefix(a, w)
+        key = prefix or (scale, ef)
+        if key not in keep:
+            keep[key] = build_graph(a, r.local_rank, scale, ef, prefix)
+        bg = keep[key]
+        graphs[w] = bg
+        rec = r.run(w, bg, a.steps, a.warmup)
+        rec.update({"id": cid, "config": desc, "graph": bg.name, "input_build_s": bg.build_s})
+        if rank == 0:
+            bytes_of[w] = alg_bytes_device(w, bg, r.lib, rec["g"])
+        recs.append(rec)
 
-    def step():
-        if a.workload == "tc":
-            rc = lib.gm_tc(g.handle, C.byref(la), None, C.byref(st))
-        elif a.workload == "diamond":
-            rc = lib.gm_sgl(g.handle, b"diamond", C.byref(la), None, C.byref(st))
-        elif a.workload in ("rectangle", "house", "pentagon"):
-            rc = lib.gm_sgl(g.handle, a.workload.encode(), C.byref(la), None, C.byref(st))
-        elif a.workload in ("clique4", "clique5"):
-            rc = lib.gm_clique(g.handle, int(a.workload[-1]), C.byref(la), None, C.byref(st))
-        elif a.workload == "motif3f":
-            rc = lib.gm_motif_formula(g.handle, 3, C.byref(la), None, 2, C.byref(st))
-        else:
-            rc = lib.gm_motif(g.handle, 3, C.byref(la), None, 2, C.byref(st))
-        _lib.check(rc, "bench step")
-        if use_dist:
-            dist.all_reduce(counts)  # ONE RCCL all-reduce of the 64-bit counts
-
-    def fence():
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(a.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    result = [int(x) for x in counts.cpu().tolist()]
-    kms = g.kernel_times_ms(min(a.steps, 64))
-    k_avg_ms = sum(kms) / max(len(kms), 1)
-
-    # "edges processed" = the reference's nnz (src/triangle/gpu_base.cu:69): |E+| (tc, clique),
-    # ne/2 (diamond), ne (motif)
-    tasks_total = g.E() // 2 if a.workload in ("diamond", "rectangle", "house", "pentagon") else g.E()
-    ms_per_step = 1e3 * elapsed / a.steps
-    value = tasks_total / (elapsed / a.steps) / 1e6
-
-    out = {
-        "metric": "million edges processed/sec + total match count",
-        "value": round(value, 3),
-        "unit": "Medges/s",
-        "n_gpus": world,
-        "steps": a.steps,
-        "warmup": a.warmup,
-        "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True,
-        "scaling": "strong",
-        "vs_baseline": None,
-        "dtype": "int32 (vertex ids, offsets; uint64 counts)",
-        "data": "file" if a.graph else ("synthetic uniform random graph (torch RNG)" if a.uniform else
-                                        "synthetic R-MAT (0.57,0.19,0.19,0.05), SplitMix64 counter stream"),
-        "config": {"workload": f"{a.workload}: {desc}", "graph": gname, "nv": g.V(), "ne_sym": sym.E(), "tasks": tasks_total,
-                   "max_degree": g.get_max_degree(), "parallelism": f"task-chunk round-robin x{world}, replicated CSR",
-                   "input_build_s": round(t_in, 2)},
-        "count": result[:2] if a.workload.startswith("motif3") else result[0],
-        "matches_per_sec": round((result[1] if a.workload.startswith("motif3") else result[0]) / (elapsed / a.steps), 1),
-        "kernel_ms_avg": round(k_avg_ms, 4),
-    }
-
+    out = None
     if rank == 0:
-        host = g.download()
-        ab = alg_bytes(a.workload, host.row_ptr, host.col_idx)
-        if a.workload == "clique4":  # level 1 = the TC formula, level 2 from the statistics kernel
-            l2 = C.c_uint64(0)
-            _lib.check(lib.gm_clique4_level2_bytes(g.handle, C.byref(l2)), "gm_clique4_level2_bytes")
-            ab = alg_bytes("tc", host.row_ptr, host.col_idx) + int(l2.value)
-        if ab is not None:
-            per_launch = ab / world  # each rank's kernel covers ~1/world of the chunks
-            ach = per_launch / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms > 0 else 0.0
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath):  # PMC-measured HBM bytes per launch (rocprofv3 --pmc), keyed by graph+workload
-                traffic = json.load(open(tpath)).get(f"{a.workload}:{gname}:n{world}")
-            out["roofline"] = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-                               "algorithmic_bytes_per_launch": int(per_launch), "kernel": "gm::mine_kernel<PAT> (PAT = " + a.workload + ")"}
-        if world == 1 and not a.no_cpu_baseline and a.workload == "tc":
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            import oracle as O  # the CPU oracle, timed as the OpenMP baseline ("port"): never the product path
-
-            od = O.OGraph(host.row_ptr, host.col_idx)
-            cal = 256
-            t1 = time.perf_counter()
-            O.tc_sample(od, cal, 1)
-            tcal = time.perf_counter() - t1
-            stride = max(1, int(tcal * cal / max(a.cpu_seconds, 1e-3)))
-            t1 = time.perf_counter()
-            cnt, tasks = O.tc_sample(od, stride, 0)
-            tcpu = time.perf_counter() - t1
-            out["cpu_baseline"] = {"value": round(tasks / tcpu / 1e6, 3), "unit": "Medges/s", "cores": O.num_threads(),
-                                   "kind": "port", "seconds": round(tcpu, 2),
-                                   "sample": f"oracle gmo_tc_sample: vertices u = 0 mod {stride} of the same DAG "
-                                             f"({tasks} of {g.E()} task edges), OpenMP schedule(dynamic,1)",
-                                   "host_cpus": os.cpu_count()}
-            if stride == 1:
-                out["cpu_baseline"]["count_matches_gpu"] = bool(cnt == result[0])
-            ref = None if a.no_ref_baseline else reference_tc_baseline(sym, g.E(), O.num_threads(), result[0])
-            if ref is not None:  # the reference's own tc_omp_base binary (oracle/_ref, prebuilt) on the same graph
-                ref["port"] = {k: out["cpu_baseline"][k] for k in ("value", "seconds", "sample")}
-                out["cpu_baseline"] = ref
+        stream_gbs = r.stream_ceiling()
+        # ---- HBM-side traffic ------------------------------------------------------------------------------------
+        traffic, traffic_src = {}, "off"
+        if a.traffic == "auto" and world == 1 and not r.use_dist:
+            got, traffic_src = measure_traffic(a, [x["workload"] for x in recs])
+            traffic = got or {}
+        if (a.traffic == "file" or (a.traffic == "auto" and not traffic)) and os.path.exists(os.path.join(ROOT, "profiles", "traffic.json")):
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            for x in recs:
+                v = tj.get(f"{x['workload']}:{x['graph']}:n{world}")
+                if v:
+                    traffic[x["workload"]] = {"fetch_bytes": float(v), "write_bytes": 0.0}
+            traffic_src = (traffic_src + "; fallback: " if a.traffic == "auto" else "") + "profiles/traffic.json (static, recorded " + str(tj.get("_recorded", "r01")) + ")"
+        # ---- CPU baselines ---------------------------------------------------------------------------------------
+        cpu = {}
+        if world == 1 and not a.no_cpu_baseline:
+            cpu = cpu_baselines(a, [x for x in recs if x["workload"] in ("tc", "diamond", "clique4", "motif3")], graphs)
+        subs = []
+        for x in recs:
+            ab, floor = bytes_of[x["workload"]]
+            sub = finish_record(x, a, world, ab, floor, traffic.get(x["workload"]), traffic_src, cpu.get(x["workload"]),
+                                known_answer(a, x["workload"], x["graph"]), stream_gbs)
+            sub = {"id": x["id"], "config": x["config"], **sub, "input_build_s": round(x["input_build_s"], 2)}
+            if x["workload"] == "motif3" and isinstance(x["count"], list):
+                # size-independent identity, checked in the run: wedges = sum_v C(d,2) - 3T  (automine_formula.h:2-19)
+                bg = graphs["motif3"]
+                deg = (bg.rp[1:] - bg.rp[:-1])
+                c2 = int((deg * (deg - 1) // 2).sum().item())
+                sub["identity_wedges_eq_sumC2_minus_3T"] = bool(x["count"][0] == c2 - 3 * x["count"][1])
+            subs.append(sub)
+        head = subs[0]
+        out = {
+            "metric": "million edges processed/sec + total match count",
+            "value": head["value"], "unit": "Medges/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "int32 (vertex ids, offsets; uint64 counts)",
+            "data": "file" if head["graph"].startswith("file:") else ("synthetic uniform random graph (torch RNG)" if a.uniform else
+                                                                     "synthetic R-MAT (0.57,0.19,0.19,0.05), SplitMix64 counter stream"),
+            "config": {"workload": f"{head['workload']}: {WORKLOADS[head['workload']][3]}", "graph": head["graph"], "nv": head["nv"],
+                       "ne_sym": head["ne_sym"], "tasks": head["tasks"], "max_degree": head["max_degree"],
+                       "parallelism": f"task-chunk round-robin x{world}, replicated CSR", "input_build_s": head["input_build_s"]},
+            "count": head["count"], "matches_per_sec": head["matches_per_sec"], "kernel_ms_avg": head["kernel_ms_avg"],
+            "per_gpu_kernel_ms": head["per_gpu_kernel_ms"], "setup_ms": head["setup_ms"], "first_call_ms": head["first_call_ms"],
+            "roofline": head["roofline"],
+        }
+        if "cpu_baseline" in head:
+            out["cpu_baseline"] = head["cpu_baseline"]
+        out["count_matches_cpu"] = head.get("count_matches_cpu")
+        if not single:
+            out["configs"] = [config1_record(a)] + subs
+            out["all_counts_match_cpu"] = all(s.get("count_matches_cpu") is True for s in out["configs"])
+        out["bench_wall_s"] = round(time.perf_counter() - t_start, 1)
         print(json.dumps(out), flush=True)
-    if use_dist:
-        dist.barrier()  # rank 0 finishes its host-side reporting before any rank tears the communicator down
-        dist.destroy_process_group()
-
-
-def reference_tc_baseline(sym, tasks, threads, gpu_count):
-    """Time the REFERENCE's tc_omp_base (built by oracle/ref/Makefile into oracle/_ref/, test infrastructure) on the same
-    graph: write the symmetric CSR in the three-file format, run the binary, read its own `runtime [omp_base]` line
-    (Timer around the parallel loop only, src/triangle/omp_base.cc:12-24). None when the binary is not there or fails."""
-    import re
-    import shutil
-    import subprocess
-    import tempfile
-
-    exe = os.path.join(ROOT, "oracle", "_ref", "tc_omp_base")
-    if not os.path.exists(exe):
-        return None
-    tmp = tempfile.mkdtemp(prefix="gm_ref_", dir="/tmp")
-    try:
-        sym.download().save(os.path.join(tmp, "graph"))
-        env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="spread")
-        best, count = None, None
-        for _ in range(2):
-            r = subprocess.run([exe, os.path.join(tmp, "graph")], capture_output=True, text=True, env=env, timeout=300)
-            m = re.search(r"runtime \[omp_base\] = ([0-9.eE+-]+) sec", r.stdout)
-            c = re.search(r"total_num_triangles = (\d+)", r.stdout)
-            if r.returncode != 0 or not m or not c:
-                return None
-            t = float(m.group(1))
-            best, count = (t if best is None else min(best, t)), int(c.group(1))
-        return {"value": round(tasks / best / 1e6, 3), "unit": "Medges/s", "cores": threads, "kind": "reference",
-                "seconds": round(best, 3), "count_matches_gpu": bool(count == gpu_count),
-                "sample": "tc_omp_base (reference binary, g++ -O3 -fopenmp, its own orientation + Timer) on the whole graph, "
-                          "best of 2 runs", "host_cpus": os.cpu_count()}
-    except Exception as e:  # the baseline is a report, never a reason to lose the bench line
-        print(f"[bench] reference baseline skipped: {e}", file=sys.stderr)
-        return None
-    finally:
-        shutil.rmtree(tmp, ignore_errors=True)
+    r.close()
 
 
 if __name__ == "__main__":

@@ -55,6 +55,11 @@ class gm_stats(C.Structure):
     ]
 
 
+class gm_setup_times(C.Structure):
+    _fields_ = [("orient_ms", C.c_double), ("table_ms", C.c_double), ("bitmap_ms", C.c_double), ("relabel_ms", C.c_double),
+                ("other_ms", C.c_double)]
+
+
 GM_OK, GM_ERR_INVALID, GM_ERR_NO_DEVICE, GM_ERR_HIP, GM_ERR_TOO_LARGE, GM_ERR_UNSUPPORTED, GM_ERR_IO, GM_ERR_FORMAT = range(8)
 GM_PART_ROUND_ROBIN, GM_PART_RANGE, GM_PART_VERTEX = 0, 1, 2
 (GM_OP_INTERSECT_NUM, GM_OP_INTERSECT_NUM_UPPER, GM_OP_INTERSECT_SET, GM_OP_DIFFERENCE_NUM,
@@ -76,6 +81,7 @@ SYMBOLS = [
     ("gm_partition", C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                C.POINTER(C.c_int64)]),
     ("gm_chunk_table", C.c_int, [C.c_int32, _P, C.c_int32, C.c_int32, _P, C.c_int64, C.POINTER(C.c_int64)]),
+    ("gm_graph_setup_times", C.c_int, [_P, C.POINTER(gm_setup_times)]),
     ("gm_kernel_times", C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     ("gm_tc", C.c_int, [_P, C.POINTER(gm_launch), C.POINTER(C.c_uint64), C.POINTER(gm_stats)]),
     ("gm_sgl", C.c_int, [_P, C.c_char_p, C.POINTER(gm_launch), C.POINTER(C.c_uint64), C.POINTER(gm_stats)]),

@@ -14,6 +14,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <list>
@@ -155,8 +156,40 @@ struct gm_graph {
   unsigned long long n_house_blocks = 0;   // handle whose event ring holds this handle's most recent launch
   unsigned long long sum_c2 = 0;          // sum_v C(d(v),2)
   bool sum_c2_valid = false;
+  gm_setup_times setup = {0, 0, 0, 0, 0};  // accumulated pre-processing time of this handle (gm_graph_setup_times)
   std::mutex mu;
 };
+
+// wall-clock stopwatch for the setup accounting (host clock: the steps mix host work, copies and synchronised kernels)
+struct SetupTimer {
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
+// scope guard: the enclosed once-per-graph pattern setup (device work included) is charged to setup.other_ms
+struct OtherSetupScope {
+  gm_graph *g;
+  SetupTimer t;
+  explicit OtherSetupScope(gm_graph *g_) : g(g_) {}
+  ~OtherSetupScope() {
+    (void)hipDeviceSynchronize();
+    g->setup.other_ms += t.ms();
+  }
+};
+
+extern "C" int gm_graph_setup_times(const gm_graph *g, gm_setup_times *out) {
+  if (!g || !out) return GM_ERR_INVALID;
+  *out = g->setup;
+  // cached derived handles report through their owner
+  for (const gm_graph *r : {g->dag_cache, g->relabel_cache[0], g->relabel_cache[1]})
+    if (r) {
+      out->orient_ms += r->setup.orient_ms;
+      out->table_ms += r->setup.table_ms;
+      out->bitmap_ms += r->setup.bitmap_ms;
+      out->other_ms += r->setup.other_ms;
+    }
+  return GM_OK;
+}
 
 static void free_tables(gm_graph *g) {
   for (auto &t : g->tables) {
@@ -383,6 +416,7 @@ extern "C" int gm_graph_orient(const gm_graph *sym, gm_graph **out) {
   if (!sym || !out) return GM_ERR_INVALID;
   *out = nullptr;
   HIP_TRY(hipSetDevice(sym->device));
+  SetupTimer timer;
   const int nv = sym->nv;
   // segment table of the long rows
   std::vector<OrientSeg> segs;
@@ -440,6 +474,7 @@ extern "C" int gm_graph_orient(const gm_graph *sym, gm_graph **out) {
   (void)hipFree(d_segs);
   int rc = finish_handle(g);
   if (rc) { gm_graph_free(g); return rc; }
+  g->setup.orient_ms = timer.ms();
   *out = g;
   return GM_OK;
 }
@@ -475,6 +510,7 @@ static int get_relabeled(gm_graph *g, int descending, gm_graph **out) {
     if (g->relabel_cache[descending]) { *out = g->relabel_cache[descending]; return GM_OK; }
   }
   HIP_TRY(hipSetDevice(g->device));
+  SetupTimer timer;
   const int nv = g->nv;
   const long long ne = g->ne;
   // counting sort by degree (ties: ascending id)
@@ -531,6 +567,7 @@ static int get_relabeled(gm_graph *g, int descending, gm_graph **out) {
   if (rc) { gm_graph_free(r); return rc; }
   std::lock_guard<std::mutex> lk(g->mu);
   g->relabel_cache[descending] = r;
+  g->setup.relabel_ms += timer.ms();
   *out = r;
   return GM_OK;
 }
@@ -641,6 +678,8 @@ static int get_table(gm_graph *g, int target, bool allow_split, int bit_words, u
   std::lock_guard<std::mutex> lk(g->mu);
   for (auto &t : g->tables)
     if (t.target == target && t.allow_split == allow_split && t.bit_words == bit_words && t.part_cap == part_cap && t.stage_cap == stage_cap) { *out = &t; return GM_OK; }
+  SetupTimer timer;
+  double bitmap_ms = 0;
   std::vector<ChunkRec> recs;
   ChunkTable t;
   t.target = target;
@@ -728,6 +767,7 @@ static int get_table(gm_graph *g, int target, bool allow_split, int bit_words, u
     }
   }
   if (allow_split) {
+    SetupTimer bm_timer;
     // Hub rows (longer than the LDS stage, cut into SPLIT chunks) get a dense bitmap over the vertex ids, the
     // longest rows first, within a memory budget: one probe then replaces a ~17-step bisection in HBM.
     const unsigned long long words = ((unsigned long long)g->nv + 31ull) / 32ull;
@@ -773,7 +813,11 @@ static int get_table(gm_graph *g, int target, bool allow_split, int bit_words, u
       t.n_bitmaps = nb;
       t.bitmap_words = words;
     }
+    bitmap_ms = bm_timer.ms();
   }
+  HIP_TRY(hipDeviceSynchronize());
+  g->setup.bitmap_ms += bitmap_ms;
+  g->setup.table_ms += timer.ms() - bitmap_ms;
   g->tables.push_back(std::move(t));
   *out = &g->tables.back();
   return GM_OK;
@@ -1111,6 +1155,7 @@ extern "C" int gm_tc(const gm_graph *dag, const gm_launch *la, uint64_t *total, 
 // rectangle, flattened over wedges (rect_flat_kernel in gm_mine.hip)
 static int ensure_idx0(gm_graph *g, const GraphView &gv) {
   if (g->d_idx0) return GM_OK;
+  OtherSetupScope scope(g);
   HIP_TRY(hipMalloc(&g->d_idx0, sizeof(int) * (size_t)std::max(g->nv, 1)));
   HIP_TRY(launch_idx0(gv, g->d_idx0, 0));
   return GM_OK;
@@ -1128,6 +1173,7 @@ static int run_rect_flat(const gm_graph *cg, const gm_launch *la_in, uint64_t *h
   gv.rp = g->d_rp;
   gv.col = g->d_col;
   if (!g->d_wblock_prefix) {  // once per graph: idx0[v] on the device, wedge-block prefix on the host
+    OtherSetupScope scope(g);
     rc = ensure_idx0(g, gv);
     if (rc) return rc;
     std::vector<int> idx0((size_t)std::max(g->nv, 1));
@@ -1184,6 +1230,7 @@ static int run_rect_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h_
   rc = ensure_idx0(g, gv);
   if (rc) return rc;
   if (!g->d_rect_tasks) {  // once per graph: 2-path estimate per centre (device), task list (host): heavy first, then light by 4
+    OtherSetupScope scope(g);
     const size_t nv = (size_t)g->nv;
     unsigned long long *d_work = nullptr;
     HIP_TRY(hipMalloc(&d_work, sizeof(unsigned long long) * std::max<size_t>(nv, 1)));
@@ -1283,6 +1330,7 @@ static int run_rect_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h_
 // every centre of the house / pentagon map kernels
 static int ensure_edge_tables(gm_graph *g, const GraphView &gv) {
   if (g->d_house_t && g->d_house_tlt) return GM_OK;
+  OtherSetupScope scope(g);
   const size_t ne1 = (size_t)std::max<long long>(g->ne, 1);
   HIP_TRY(hipMalloc(&g->d_house_t, sizeof(unsigned) * ne1));
   HIP_TRY(hipMalloc(&g->d_house_tlt, sizeof(unsigned) * ne1));
@@ -1311,6 +1359,7 @@ static int run_house_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h
   rc = ensure_edge_tables(g, gv);
   if (rc) return rc;
   if (!g->d_house_tasks) {  // once per graph
+    OtherSetupScope scope(g);
     const size_t nv = (size_t)g->nv;
     unsigned long long *d_work = nullptr;
     HIP_TRY(hipMalloc(&d_work, sizeof(unsigned long long) * std::max<size_t>(nv, 1)));
@@ -1392,6 +1441,7 @@ static int run_house_flat(const gm_graph *cg, const gm_launch *la_in, uint64_t *
   gv.rp = g->d_rp;
   gv.col = g->d_col;
   if (!g->d_house_prefix) {  // once per graph: blocks per entry on the device, prefix on the host
+    OtherSetupScope scope(g);
     const size_t ne = (size_t)g->ne;
     unsigned *d_nblk = nullptr;
     HIP_TRY(hipMalloc(&d_nblk, sizeof(unsigned) * std::max<size_t>(ne, 1)));

@@ -168,6 +168,15 @@ class DeviceGraph:
         _lib.check(_lib.load().gm_kernel_times(self.handle, n, buf, C.byref(got)), "gm_kernel_times")
         return [float(buf[i]) for i in range(got.value)]
 
+    def setup_times_ms(self) -> dict:
+        """Accumulated pre-processing time of this handle (gm_graph_setup_times): orientation, task tables, hub
+        bitmaps, renumbered copies, per-pattern tables -- the steps the reference leaves untimed."""
+        from ._lib import gm_setup_times
+
+        t = gm_setup_times()
+        _lib.check(_lib.load().gm_graph_setup_times(self.handle, C.byref(t)), "gm_graph_setup_times")
+        return {k: round(float(getattr(t, k)), 3) for k, _ in gm_setup_times._fields_}
+
     def free(self):
         if self._h:
             _lib.load().gm_graph_free(self._h)

@@ -127,6 +127,21 @@ int gm_partition(int64_t n_chunks, int32_t rank, int32_t world, int32_t policy, 
 int gm_chunk_table(int32_t nv, const int64_t *row_ptr, int32_t chunk, int32_t for_clique, int32_t *recs, int64_t cap,
                    int64_t *n_out);
 
+/* Pre-processing ("setup") accounting. The reference leaves these steps untimed ("Time on generating the DAG",
+ * "Time on generating the edgelist", src/common/graph.cc:233-279,297-326); here every handle accumulates the wall-clock
+ * milliseconds (host clock around device work + host work, synchronised) it has spent in them, so that a caller can report
+ * them beside the kernel time:
+ *   orient_ms   gm_graph_orient that produced this handle (recorded on the DAG handle)
+ *   table_ms    task-chunk tables: chunk records, cost estimate, parts, dequeue orders (all tables built so far)
+ *   bitmap_ms   hub-row bitmaps (symmetric-graph patterns)
+ *   relabel_ms  renumbered copies (SgL patterns, clique topological numbering), including their own setup
+ *   other_ms    per-pattern tables (idx0, 2-path estimates, per-entry triangle tables, task lists)
+ * Cached structures cost nothing on later calls. */
+typedef struct gm_setup_times {
+  double orient_ms, table_ms, bitmap_ms, relabel_ms, other_ms;
+} gm_setup_times;
+int gm_graph_setup_times(const gm_graph *g, gm_setup_times *out);
+
 /* HIP-event durations (ms) of the mining kernels of the most recent launches on this handle, oldest
  * first; at most 64 are remembered. The caller must have synchronised the launch stream(s).
  * This is how an asynchronous (d_counts) caller reads the kernel time the reference prints as

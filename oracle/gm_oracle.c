@@ -340,32 +340,46 @@ uint64_t gmo_tc_sample(const gmo_graph *g, gmo_vid stride, gmo_vid offset, uint6
   return counter;
 }
 
-uint64_t gmo_diamond_range(const gmo_graph *g, gmo_vid vb, gmo_vid ve) {
-  /* src/sgl/cpu_kernels/diamond.h:1-14 (pair enumeration kept literal: it IS the CPU baseline's cost) */
+static uint64_t diamond_vertex(const gmo_graph *g, gmo_vid v0, gmo_vid *buf, uint64_t *tasks) {
+  /* one iteration of the v0 loop of src/sgl/cpu_kernels/diamond.h:1-14 (pair enumeration kept literal: it IS the CPU
+   * baseline's cost); *tasks += symmetry-broken edges (v0, v1 < v0) */
   uint64_t counter = 0;
-#pragma omp parallel reduction(+ : counter)
+  const gmo_vid *y0 = row_of(g, v0);
+  gmo_vid d0 = deg_of(g, v0);
+  for (gmo_vid i = 0; i < d0; i++) {
+    gmo_vid v1 = y0[i];
+    if (v1 >= v0) break;
+    *tasks += 1;
+    gmo_vid n = gmo_intersect_set(y0, d0, row_of(g, v1), deg_of(g, v1), buf);
+    for (gmo_vid p = 0; p < n; p++) {
+      gmo_vid v2 = buf[p];
+      for (gmo_vid q = 0; q < n; q++) {
+        if (buf[q] >= v2) break;
+        counter += 1;
+      }
+    }
+  }
+  return counter;
+}
+
+/* vertices v0 = begin + i * stride < end: stride 1 = the contiguous range, stride > 1 = a degree-representative sample */
+static uint64_t diamond_strided(const gmo_graph *g, gmo_vid vb, gmo_vid ve, gmo_vid stride, uint64_t *tasks) {
+  uint64_t counter = 0, t = 0;
+  if (stride < 1) stride = 1;
+  gmo_vid n = ve > vb ? (ve - vb + stride - 1) / stride : 0;
+#pragma omp parallel reduction(+ : counter, t)
   {
     gmo_vid *buf = (gmo_vid *)malloc(sizeof(gmo_vid) * (size_t)(g->max_degree > 0 ? g->max_degree : 1));
 #pragma omp for schedule(dynamic, 1)
-    for (gmo_vid v0 = vb; v0 < ve; v0++) {
-      const gmo_vid *y0 = row_of(g, v0);
-      gmo_vid d0 = deg_of(g, v0);
-      for (gmo_vid i = 0; i < d0; i++) {
-        gmo_vid v1 = y0[i];
-        if (v1 >= v0) break;
-        gmo_vid n = gmo_intersect_set(y0, d0, row_of(g, v1), deg_of(g, v1), buf);
-        for (gmo_vid p = 0; p < n; p++) {
-          gmo_vid v2 = buf[p];
-          for (gmo_vid q = 0; q < n; q++) {
-            if (buf[q] >= v2) break;
-            counter += 1;
-          }
-        }
-      }
-    }
+    for (gmo_vid i = 0; i < n; i++) counter += diamond_vertex(g, vb + i * stride, buf, &t);
     free(buf);
   }
+  if (tasks) *tasks = t;
   return counter;
+}
+uint64_t gmo_diamond_range(const gmo_graph *g, gmo_vid vb, gmo_vid ve) { return diamond_strided(g, vb, ve, 1, NULL); }
+uint64_t gmo_diamond_sample(const gmo_graph *g, gmo_vid stride, gmo_vid offset, uint64_t *tasks) {
+  return diamond_strided(g, offset, g->nv, stride, tasks);
 }
 uint64_t gmo_diamond(const gmo_graph *g) { return gmo_diamond_range(g, 0, g->nv); }
 
@@ -465,15 +479,8 @@ static uint64_t clique_dfs(const gmo_graph *g, const gmo_vid *S, gmo_vid s, int 
   return c;
 }
 
-uint64_t gmo_clique_range(const gmo_graph *g, int k, gmo_vid vb, gmo_vid ve) {
-  uint64_t counter = 0;
-  if (k < 3 || k > 8) return 0;
-  gmo_vid md = g->max_degree > 0 ? g->max_degree : 1;
-#pragma omp parallel reduction(+ : counter)
-  {
-    gmo_vid *buf = (gmo_vid *)malloc(sizeof(gmo_vid) * (size_t)md * 8);
-#pragma omp for schedule(dynamic, 1)
-    for (gmo_vid v0 = vb; v0 < ve; v0++) {
+static uint64_t clique_vertex(const gmo_graph *g, int k, gmo_vid v0, gmo_vid *buf, gmo_vid md) {
+      /* one iteration of the v0 loop of the automine k-clique solvers */
       const gmo_vid *y0 = row_of(g, v0);
       gmo_vid d0 = deg_of(g, v0);
       uint64_t local = 0;
@@ -503,22 +510,47 @@ uint64_t gmo_clique_range(const gmo_graph *g, int k, gmo_vid vb, gmo_vid ve) {
         /* same loop nest, one more intersection level per extra vertex */
         local += clique_dfs(g, y0, d0, k - 1, buf, md);
       }
-      counter += local;
+      return local;
+}
+
+static uint64_t clique_strided(const gmo_graph *g, int k, gmo_vid vb, gmo_vid ve, gmo_vid stride, uint64_t *tasks) {
+  uint64_t counter = 0, t = 0;
+  if (k < 3 || k > 8) return 0;
+  if (stride < 1) stride = 1;
+  gmo_vid md = g->max_degree > 0 ? g->max_degree : 1;
+  gmo_vid n = ve > vb ? (ve - vb + stride - 1) / stride : 0;
+#pragma omp parallel reduction(+ : counter, t)
+  {
+    gmo_vid *buf = (gmo_vid *)malloc(sizeof(gmo_vid) * (size_t)md * 8);
+#pragma omp for schedule(dynamic, 1)
+    for (gmo_vid i = 0; i < n; i++) {
+      gmo_vid v0 = vb + i * stride;
+      t += (uint64_t)deg_of(g, v0);
+      counter += clique_vertex(g, k, v0, buf, md);
     }
     free(buf);
   }
+  if (tasks) *tasks = t;
   return counter;
+}
+uint64_t gmo_clique_range(const gmo_graph *g, int k, gmo_vid vb, gmo_vid ve) { return clique_strided(g, k, vb, ve, 1, NULL); }
+uint64_t gmo_clique_sample(const gmo_graph *g, int k, gmo_vid stride, gmo_vid offset, uint64_t *tasks) {
+  return clique_strided(g, k, offset, g->nv, stride, tasks);
 }
 uint64_t gmo_clique(const gmo_graph *g, int k) { return gmo_clique_range(g, k, 0, g->nv); }
 
-void gmo_motif3_range(const gmo_graph *g, gmo_vid vb, gmo_vid ve, uint64_t out[2]) {
+static void motif3_strided(const gmo_graph *g, gmo_vid vb, gmo_vid ve, gmo_vid stride, uint64_t out[2], uint64_t *tasks) {
   /* automine_3motif, src/motif/cpu_kernels/automine_base.h:2-22; out[0]=wedges, out[1]=triangles */
-  uint64_t c0 = 0, c1 = 0;
-#pragma omp parallel for schedule(dynamic, 1) reduction(+ : c0, c1)
-  for (gmo_vid v0 = vb; v0 < ve; v0++) {
+  uint64_t c0 = 0, c1 = 0, t = 0;
+  if (stride < 1) stride = 1;
+  gmo_vid n = ve > vb ? (ve - vb + stride - 1) / stride : 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : c0, c1, t)
+  for (gmo_vid k = 0; k < n; k++) {
+    gmo_vid v0 = vb + k * stride;
     const gmo_vid *y0 = row_of(g, v0);
     gmo_vid d0 = deg_of(g, v0);
     gmo_vid f0 = gmo_bounded(y0, d0, v0);
+    t += (uint64_t)d0; /* every directed edge is a task (src/motif/gpu_base.cu:34,47) */
     for (gmo_vid i = 0; i < d0; i++) {
       gmo_vid v1 = y0[i];
       c0 += gmo_difference_num_upper(y0, d0, row_of(g, v1), deg_of(g, v1), v1, v1);
@@ -530,6 +562,11 @@ void gmo_motif3_range(const gmo_graph *g, gmo_vid vb, gmo_vid ve, uint64_t out[2
   }
   out[0] = c0;
   out[1] = c1;
+  if (tasks) *tasks = t;
+}
+void gmo_motif3_range(const gmo_graph *g, gmo_vid vb, gmo_vid ve, uint64_t out[2]) { motif3_strided(g, vb, ve, 1, out, NULL); }
+void gmo_motif3_sample(const gmo_graph *g, gmo_vid stride, gmo_vid offset, uint64_t out[2], uint64_t *tasks) {
+  motif3_strided(g, offset, g->nv, stride, out, tasks);
 }
 void gmo_motif3(const gmo_graph *g, uint64_t out[2]) { gmo_motif3_range(g, 0, g->nv, out); }
 

@@ -69,6 +69,11 @@ uint64_t gmo_tc_range(const gmo_graph *dag, gmo_vid v_begin, gmo_vid v_end);
 uint64_t gmo_tc_sample(const gmo_graph *dag, gmo_vid stride, gmo_vid offset, uint64_t *tasks);
 uint64_t gmo_diamond(const gmo_graph *sym);
 uint64_t gmo_diamond_range(const gmo_graph *sym, gmo_vid v_begin, gmo_vid v_end);
+/* strided samples like gmo_tc_sample (vertices v0 = offset mod stride); *tasks = the tasks of the sampled vertices as the
+ * reference counts them (diamond: edges v1 < v0; clique: DAG edges; motif: directed edges) */
+uint64_t gmo_diamond_sample(const gmo_graph *sym, gmo_vid stride, gmo_vid offset, uint64_t *tasks);
+uint64_t gmo_clique_sample(const gmo_graph *dag, int k, gmo_vid stride, gmo_vid offset, uint64_t *tasks);
+void gmo_motif3_sample(const gmo_graph *sym, gmo_vid stride, gmo_vid offset, uint64_t out[2], uint64_t *tasks);
 uint64_t gmo_rectangle(const gmo_graph *sym);
 uint64_t gmo_house(const gmo_graph *sym);
 uint64_t gmo_pentagon(const gmo_graph *sym);

@@ -41,6 +41,12 @@ def lib():
             getattr(L, name).argtypes = [G, C.c_int32, C.c_int32]
         L.gmo_tc_sample.restype = C.c_uint64
         L.gmo_tc_sample.argtypes = [G, C.c_int32, C.c_int32, C.POINTER(C.c_uint64)]
+        L.gmo_diamond_sample.restype = C.c_uint64
+        L.gmo_diamond_sample.argtypes = [G, C.c_int32, C.c_int32, C.POINTER(C.c_uint64)]
+        L.gmo_clique_sample.restype = C.c_uint64
+        L.gmo_clique_sample.argtypes = [G, C.c_int, C.c_int32, C.c_int32, C.POINTER(C.c_uint64)]
+        L.gmo_motif3_sample.restype = None
+        L.gmo_motif3_sample.argtypes = [G, C.c_int32, C.c_int32, P, C.POINTER(C.c_uint64)]
         L.gmo_clique.restype = C.c_uint64
         L.gmo_clique.argtypes = [G, C.c_int]
         L.gmo_clique_range.restype = C.c_uint64
@@ -120,6 +126,25 @@ def tc_sample(dag, stride, offset=0):
     t = C.c_uint64(0)
     c = int(lib().gmo_tc_sample(dag.ref(), stride, offset, C.byref(t)))
     return c, int(t.value)
+
+
+def diamond_sample(sym, stride, offset=0):
+    t = C.c_uint64(0)
+    c = int(lib().gmo_diamond_sample(sym.ref(), stride, offset, C.byref(t)))
+    return c, int(t.value)
+
+
+def clique_sample(dag, k, stride, offset=0):
+    t = C.c_uint64(0)
+    c = int(lib().gmo_clique_sample(dag.ref(), k, stride, offset, C.byref(t)))
+    return c, int(t.value)
+
+
+def motif3_sample(sym, stride, offset=0):
+    t = C.c_uint64(0)
+    out = (C.c_uint64 * 2)()
+    lib().gmo_motif3_sample(sym.ref(), stride, offset, out, C.byref(t))
+    return [int(out[0]), int(out[1])], int(t.value)
 
 
 def alg_bytes(kind, g):
