@@ -90,9 +90,10 @@ def parse():
     ap.add_argument("--graph", default="", help="prefix of graph.meta.txt/.vertex.bin/.edge.bin (real dataset), one-workload mode")
     ap.add_argument("--data-dir", default=os.environ.get("GM_DATA_DIR", ""), help="directory with livej/graph.* and com-orkut/graph.* (real datasets)")
     ap.add_argument("--uniform", default="", help="NV,M: uniform random graph instead of R-MAT (LiveJournal-size flat-degree stand-in)")
+    ap.add_argument("--powerlaw", default="", help="NV,M,MAXDEG: Chung-Lu power-law graph (LiveJournal: 4847571,43000000,20000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ref-baseline", action="store_true", help="skip the timed runs of the oracle/_ref reference binaries")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of each bounded oracle sample")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the oracle's (secondary) TC sample")
     ap.add_argument("--traffic", default="auto", choices=["auto", "off", "file"],
                     help="HBM-side bytes per launch: auto = re-run the workloads under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                          "(two extra passes, N = 1 only), file = profiles/traffic.json, off = null")
@@ -128,7 +129,7 @@ def build_graph(a, local_rank, scale, ef, graph_prefix=""):
     import torch
 
     from graphminer_amd import DeviceGraph, Graph
-    from graphminer_amd.rmat import rmat_csr_device, uniform_csr_device
+    from graphminer_amd.rmat import powerlaw_csr_device, rmat_csr_device, uniform_csr_device
 
     t = time.perf_counter()
     if graph_prefix:
@@ -138,6 +139,10 @@ def build_graph(a, local_rank, scale, ef, graph_prefix=""):
         ci = torch.from_numpy(h.col_idx).to(dev)
         sym = DeviceGraph.from_device_ptrs(h.V(), h.E(), rp.data_ptr(), ci.data_ptr(), local_rank, keepalive=(rp, ci))
         name = f"file:{graph_prefix}"
+    elif a.powerlaw:
+        pnv, pm, pmax = (int(x) for x in a.powerlaw.split(","))
+        sym, rp, ci = powerlaw_csr_device(pnv, pm, pmax, 2.5, a.seed, local_rank)
+        name = f"powerlaw_nv{pnv}_m{pm}_max{pmax}_seed{a.seed}"
     elif a.uniform:
         unv, um = (int(x) for x in a.uniform.split(","))
         sym, rp, ci = uniform_csr_device(unv, um, a.seed, local_rank)
@@ -301,7 +306,7 @@ class Runner:
         }
 
     def stream_ceiling(self):
-        """Measured dword-stream read bandwidth (gm_calib_stream over 4 GiB >> the 256 MiB Infinity Cache), GB/s."""
+        """Measured stream read bandwidth (gm_stream_ceiling: 16 B per lane over 4 GiB >> the 256 MiB Infinity Cache), GB/s."""
         torch = self.torch
         n = 1 << 30
         buf = torch.ones(n, dtype=torch.int32, device=self.dev)
@@ -311,7 +316,7 @@ class Runner:
         for i in range(4):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            self._lib.check(self.lib.gm_calib_stream(buf.data_ptr(), n, out.data_ptr(), s), "gm_calib_stream")
+            self._lib.check(self.lib.gm_stream_ceiling(buf.data_ptr(), n, out.data_ptr(), s), "gm_stream_ceiling")
             e1.record()
             torch.cuda.synchronize()
             if i:
@@ -370,7 +375,7 @@ def measure_traffic(a, workloads):
             for flag, val in (("--scale", a.scale), ("--ef", a.ef)):
                 if val:
                     cmd += [flag, str(val)]
-            for flag, val in (("--graph", a.graph), ("--data-dir", a.data_dir), ("--uniform", a.uniform), ("--tune", a.tune)):
+            for flag, val in (("--graph", a.graph), ("--data-dir", a.data_dir), ("--uniform", a.uniform), ("--powerlaw", a.powerlaw), ("--tune", a.tune)):
                 if val:
                     cmd += [flag, val]
             env = dict(os.environ, TMPDIR="/tmp")
@@ -436,100 +441,101 @@ def run_reference(exe_name, args, pattern_time, pattern_count, threads, runs, ti
     return {"seconds": median(times), "all_seconds": [round(t, 3) for t in times], "count": count}
 
 
-def cpu_baselines(a, recs, graphs):
-    """cpu_baseline object per workload. TC: the REFERENCE's tc_omp_base on the whole graph, median of 3 (its own Timer line,
-    src/triangle/omp_base.cc:12-24); diamond: the reference's sgl_omp_base, one run (tens of seconds); 4-clique / 3-motif:
-    the oracle on a bounded, degree-representative sample (vertices v0 = 0 mod stride, ~a.cpu_seconds of CPU work)."""
+# reduced scale (same generator, same seed and edge factor) on which the reference binary of a slow workload finishes in
+# 10-40 s on the host: its whole-graph run there is the bounded CPU sample of that workload
+REDUCED_SCALE = {"clique4": 20, "motif3": 21}
+
+
+def cpu_baselines(a, r, recs, graphs):
+    """cpu_baseline object per workload, all from the REFERENCE's own binaries (oracle/_ref, their own Timer line = the
+    solver loop only, src/triangle/omp_base.cc:12-24), OMP_NUM_THREADS = the oracle's thread count, OMP_PROC_BIND=spread:
+      tc       tc_omp_base on the whole graph, median of 3 runs (+ the oracle restatement as `port`);
+      diamond  sgl_omp_base on the whole graph, one run (tens of seconds);
+      clique4 / motif3   minutes at full size (recorded: tests/golden/fullsize.json), so the bounded sample is the WHOLE graph of
+               the same generator at a reduced scale (REDUCED_SCALE), one run; the GPU runs that graph too and the counts
+               are compared. A vertex-strided sample of the full graph was tried and rejected: the loop is vertex-parallel, so
+               a sample that contains a hub row measures that row's serial time, not the machine's throughput."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle as O  # the CPU oracle, timed as the OpenMP baseline ("port"): never the product path
 
     threads = O.num_threads()
     out = {}
-    saved = {}  # graph name -> (tmpdir, prefix) of the three-file copy the reference binaries read
-    host = {}
+    tmpdirs = []
 
-    def host_graph(bg):
-        if bg.name not in host:
-            h = bg.sym.download()
-            host[bg.name] = (h, O.OGraph(h.row_ptr, h.col_idx))
-        return host[bg.name]
+    def save(bg):
+        tmp = tempfile.mkdtemp(prefix="gm_ref_", dir="/tmp")
+        tmpdirs.append(tmp)
+        h = bg.sym.download()
+        h.save(os.path.join(tmp, "graph"))
+        return os.path.join(tmp, "graph"), h
 
-    def saved_prefix(bg):
-        if bg.name not in saved:
-            tmp = tempfile.mkdtemp(prefix="gm_ref_", dir="/tmp")
-            host_graph(bg)[0].save(os.path.join(tmp, "graph"))
-            saved[bg.name] = tmp
-        return os.path.join(saved[bg.name], "graph")
-
-    def sample(fn_sample, tasks_total, what):
-        """calibrate a stride on a thin sample, then time one sample of ~cpu_seconds"""
-        cal = 1024
-        t = time.perf_counter()
-        fn_sample(cal)
-        tcal = time.perf_counter() - t
-        stride = max(1, int(tcal * cal / max(a.cpu_seconds, 1e-3)))
-        t = time.perf_counter()
-        cnt, tasks = fn_sample(stride)
-        dt = time.perf_counter() - t
-        return {"value": round(tasks / dt / 1e6, 3), "unit": "Medges/s", "cores": threads, "kind": "port", "seconds": round(dt, 2),
-                "sample": f"oracle {what}: vertices v0 = 0 mod {stride} of the same graph ({tasks} of {tasks_total} task edges), "
-                          f"OpenMP schedule(dynamic,1), OMP_PROC_BIND unset", "host_cpus": os.cpu_count(),
-                "sample_count": cnt, "stride": stride}
+    def ref_record(exe, args, tasks, count_pat, gpu_count, runs, what, nvals=1):
+        ref = run_reference(exe, args, r"runtime(?: \[omp_base\])? = ([0-9.eE+-]+)", count_pat, threads, runs, timeout=900)
+        if not ref:
+            return None
+        cnt = ref["count"][-nvals:] if nvals > 1 else ref["count"][-1]
+        return {"value": round(tasks / ref["seconds"] / 1e6, 3), "unit": "Medges/s", "cores": threads, "kind": "reference",
+                "seconds": round(ref["seconds"], 3), "runs_seconds": ref["all_seconds"], "count_matches_gpu": bool(cnt == gpu_count),
+                "cpu_count": cnt, "sample": what, "host_cpus": os.cpu_count()}
 
     try:
+        prefixes = {}
         for rec in recs:
             w, bg = rec["workload"], graphs[rec["workload"]]
             try:
+                if w in ("tc", "diamond"):
+                    if bg.name not in prefixes:
+                        prefixes[bg.name] = save(bg)
+                    prefix, h = prefixes[bg.name]
                 if w == "tc":
-                    h, osym = host_graph(bg)
-                    odag = O.orient(osym)
-                    port = sample(lambda s: O.tc_sample(odag, s, 0), rec["tasks"], "gmo_tc_sample")
-                    if port["stride"] == 1:
-                        port["count_matches_gpu"] = bool(port["sample_count"] == rec["count"])
-                    base = port
-                    ref = None if a.no_ref_baseline else run_reference(
-                        "tc_omp_base", [saved_prefix(bg)], r"runtime \[omp_base\] = ([0-9.eE+-]+) sec", r"total_num_triangles = (\d+)", threads, 3)
+                    odag = O.orient(O.OGraph(h.row_ptr, h.col_idx))
+                    cal = 256
+                    t = time.perf_counter()
+                    O.tc_sample(odag, cal, 1)
+                    stride = max(1, int((time.perf_counter() - t) * cal / max(a.cpu_seconds, 1e-3)))
+                    t = time.perf_counter()
+                    cnt, tasks = O.tc_sample(odag, stride, 0)
+                    dt = time.perf_counter() - t
+                    port = {"value": round(tasks / dt / 1e6, 3), "unit": "Medges/s", "cores": threads, "kind": "port", "seconds": round(dt, 2),
+                            "sample": f"oracle gmo_tc_sample: vertices u = 0 mod {stride} of the same DAG ({tasks} of {rec['tasks']} task "
+                                      f"edges), OpenMP schedule(dynamic,1)", "host_cpus": os.cpu_count()}
+                    if stride == 1:
+                        port["count_matches_gpu"] = bool(cnt == rec["count"])
+                    ref = None if a.no_ref_baseline else ref_record(
+                        "tc_omp_base", [prefix], rec["tasks"], r"total_num_triangles = (\d+)", rec["count"], 3,
+                        "tc_omp_base (reference binary, g++ -O3 -fopenmp, its own orientation + Timer) on the whole graph, median of 3 runs")
                     if ref:
-                        base = {"value": round(rec["tasks"] / ref["seconds"] / 1e6, 3), "unit": "Medges/s", "cores": threads,
-                                "kind": "reference", "seconds": round(ref["seconds"], 3), "runs_seconds": ref["all_seconds"],
-                                "count_matches_gpu": bool(ref["count"][-1] == rec["count"]), "cpu_count": ref["count"][-1],
-                                "sample": "tc_omp_base (reference binary, g++ -O3 -fopenmp, its own orientation + Timer) on the whole "
-                                          "graph, median of 3 runs, OMP_PROC_BIND=spread", "host_cpus": os.cpu_count(),
-                                "port": {k: port[k] for k in ("value", "seconds", "sample")}}
-                    out[w] = base
-                elif w == "diamond":
-                    h, osym = host_graph(bg)
-                    port = sample(lambda s: O.diamond_sample(osym, s, 0), rec["tasks"], "gmo_diamond_sample")
-                    base = port
-                    est_full = port["seconds"] * port["stride"]
-                    if not a.no_ref_baseline and est_full < 150:
-                        ref = run_reference("sgl_omp_base", [saved_prefix(bg), "diamond"], r"runtime \[omp_base\] = ([0-9.eE+-]+) sec",
-                                            r"total_num = (\d+)", threads, 1)
-                        if ref:
-                            base = {"value": round(rec["tasks"] / ref["seconds"] / 1e6, 3), "unit": "Medges/s", "cores": threads,
-                                    "kind": "reference", "seconds": round(ref["seconds"], 3),
-                                    "count_matches_gpu": bool(ref["count"][-1] == rec["count"]), "cpu_count": ref["count"][-1],
-                                    "sample": "sgl_omp_base diamond (reference binary, its own Timer) on the whole graph, ONE run "
-                                              "(tens of seconds; the reference's methodology is the mean of 3), OMP_PROC_BIND=spread",
-                                    "host_cpus": os.cpu_count(), "port": {k: port[k] for k in ("value", "seconds", "sample")}}
-                    out[w] = base
-                elif w == "clique4":
-                    h, osym = host_graph(bg)
-                    odag = O.orient(osym)
-                    out[w] = sample(lambda s: O.clique_sample(odag, 4, s, 0), rec["tasks"], "gmo_clique_sample(k=4)")
-                elif w == "motif3":
-                    h, osym = host_graph(bg)
-
-                    def ms(s):
-                        c, t = O.motif3_sample(osym, s, 0)
-                        return c, t
-                    out[w] = sample(ms, rec["tasks"], "gmo_motif3_sample")
+                        ref["port"] = {k: port[k] for k in ("value", "seconds", "sample")}
+                    out[w] = ref or port
+                elif w == "diamond" and not a.no_ref_baseline:
+                    out[w] = ref_record("sgl_omp_base", [prefix, "diamond"], rec["tasks"], r"total_num = (\d+)", rec["count"], 1,
+                                        "sgl_omp_base diamond (reference binary, its own Timer) on the whole graph, ONE run (tens of "
+                                        "seconds; the reference's methodology is the mean of 3)")
+                elif w in ("clique4", "motif3") and not a.no_ref_baseline and bg.name.startswith("rmat"):
+                    scale = min(REDUCED_SCALE[w], a.scale or WORKLOADS[w][0])
+                    ef = a.ef or WORKLOADS[w][1]
+                    small = build_graph(a, r.local_rank, scale, ef)
+                    try:
+                        gpu = r.run(w, small, 1, 1)  # the HIP path on the reduced graph: count for the comparison
+                        sp, _h = save(small)
+                        del _h
+                        if w == "clique4":
+                            rr = ref_record("clique_omp_base", [sp, "4"], gpu["tasks"], r"num_4-cliques = (\d+)", gpu["count"], 1, "")
+                        else:
+                            rr = ref_record("motif_omp_base", [sp, "3"], gpu["tasks"], r"pattern \d+: (\d+)", gpu["count"], 1, "", nvals=2)
+                        if rr:
+                            rr["sample"] = (f"{'clique_omp_base 4' if w == 'clique4' else 'motif_omp_base 3'} (reference binary, its own Timer) on the "
+                                            f"WHOLE graph of the same generator at reduced scale: {small.name} ({gpu['tasks']} task edges instead "
+                                            f"of {rec['tasks']}), ONE run; GPU on that graph: {gpu['kernel_ms_avg']:.3f} ms")
+                            rr["gpu_ms_on_sample_graph"] = round(gpu["kernel_ms_avg"], 4)
+                            rr["count_matches_gpu_on"] = small.name
+                            out[w] = rr
+                    finally:
+                        small.free()
             except Exception as e:
                 print(f"[bench] cpu baseline of {w} skipped: {e}", file=sys.stderr)
-            if w in ("clique4", "motif3"):
-                host.pop(bg.name, None)  # (gigabytes of host copies: drop them as soon as the sample is timed)
     finally:
-        for tmp in saved.values():
+        for tmp in tmpdirs:
             shutil.rmtree(tmp, ignore_errors=True)
     return out
 
@@ -610,8 +616,11 @@ def finish_record(rec, a, world, ab, floor, traffic, traffic_src, cpu, known, st
         out["cpu_baseline"] = cpu
     # count check: against the CPU count of this run when one exists, else against the recorded full-size oracle answers
     chk = {}
-    if cpu and "count_matches_gpu" in cpu:
-        chk = {"count_matches_cpu": cpu["count_matches_gpu"], "cpu_count_source": f"this run: {cpu['kind']} ({cpu['sample'][:40]}...)"}
+    if cpu and "count_matches_gpu" in cpu and "count_matches_gpu_on" not in cpu:
+        chk = {"count_matches_cpu": cpu["count_matches_gpu"], "cpu_count_source": f"this run: {cpu['kind']} ({cpu['sample'][:60]}...)"}
+    elif known is not None and cpu and "count_matches_gpu_on" in cpu:  # full size: recorded answer; reduced scale: this run
+        chk = {"count_matches_cpu": bool(known["count"] == rec["count"]) and bool(cpu["count_matches_gpu"]),
+               "cpu_count_source": known["source"] + f"; and this run's reference binary on {cpu['count_matches_gpu_on']}"}
     elif known is not None:
         chk = {"count_matches_cpu": bool(known["count"] == rec["count"]), "cpu_count_source": known["source"]}
     else:
@@ -642,7 +651,7 @@ def main():
         return traffic_worker(a)
     r = Runner(a)
     world, rank = r.world, r.rank
-    single = bool(a.workload or a.graph or a.uniform)
+    single = bool(a.workload or a.graph or a.uniform or a.powerlaw)
     if single:
         todo = [(0, a.workload or "tc", WORKLOADS[a.workload or "tc"][3], None)]
     else:
@@ -686,7 +695,7 @@ def main():
         # ---- CPU baselines ---------------------------------------------------------------------------------------
         cpu = {}
         if world == 1 and not a.no_cpu_baseline:
-            cpu = cpu_baselines(a, [x for x in recs if x["workload"] in ("tc", "diamond", "clique4", "motif3")], graphs)
+            cpu = cpu_baselines(a, r, [x for x in recs if x["workload"] in ("tc", "diamond", "clique4", "motif3")], graphs)
         subs = []
         for x in recs:
             ab, floor = bytes_of[x["workload"]]
@@ -707,6 +716,7 @@ def main():
             "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "int32 (vertex ids, offsets; uint64 counts)",
             "data": "file" if head["graph"].startswith("file:") else ("synthetic uniform random graph (torch RNG)" if a.uniform else
+                                                                     "synthetic Chung-Lu power-law graph (torch RNG)" if a.powerlaw else
                                                                      "synthetic R-MAT (0.57,0.19,0.19,0.05), SplitMix64 counter stream"),
             "config": {"workload": f"{head['workload']}: {WORKLOADS[head['workload']][3]}", "graph": head["graph"], "nv": head["nv"],
                        "ne_sym": head["ne_sym"], "tasks": head["tasks"], "max_degree": head["max_degree"],

@@ -94,6 +94,7 @@ SYMBOLS = [
     ("gm_rmat_keys", C.c_int, [C.c_int, C.c_int64, C.c_uint64, _P, _P]),
     ("gm_clique4_level2_bytes", C.c_int, [_P, C.POINTER(C.c_uint64)]),
     ("gm_calib_stream", C.c_int, [_P, C.c_int64, _P, _P]),
+    ("gm_stream_ceiling", C.c_int, [_P, C.c_int64, _P, _P]),
     ("gm_selftest", C.c_int, [C.c_int, C.POINTER(C.c_int)]),
 ]
 

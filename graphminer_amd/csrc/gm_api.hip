@@ -124,6 +124,7 @@ struct gm_graph {
   int *d_rp = nullptr;   // int32 offsets, owned
   int *d_col = nullptr;  // col_idx
   bool own_col = true;
+  int2 *d_edesc = nullptr;  // per CSR entry: {rp[col[e]], degree(col[e])}, built on first use (ensure_edesc)
   std::vector<int> h_rp;  // host copy of the offsets (chunk building, download)
   std::list<ChunkTable> tables;  // list: handed-out pointers stay valid
   unsigned long long *d_counters = nullptr;  // [4] + queue word, 64 B
@@ -214,6 +215,7 @@ extern "C" void gm_graph_free(gm_graph *g) {
   free_tables(g);
   if (g->d_rp) (void)hipFree(g->d_rp);
   if (g->own_col && g->d_col) (void)hipFree(g->d_col);
+  if (g->d_edesc) (void)hipFree(g->d_edesc);
   if (g->d_counters) (void)hipFree(g->d_counters);
   if (g->d_scratch) (void)hipFree(g->d_scratch);
   if (g->d_idx0) (void)hipFree(g->d_idx0);
@@ -823,6 +825,33 @@ static int get_table(gm_graph *g, int target, bool allow_split, int bit_words, u
   return GM_OK;
 }
 
+// Edge descriptors (GraphView::edesc): one gather pass over the CSR, once per graph -- the device-side counterpart of
+// Graph::init_edgelist (src/common/graph.cc:297-326), which builds the reference's COO task list serially on the host.
+__global__ __launch_bounds__(256) void edesc_kernel(long long ne, const int *__restrict__ rp, const int *__restrict__ col, int2 *__restrict__ out) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += stride) {
+    const int v = col[e];
+    const int r = rp[v];
+    out[e] = make_int2(r, rp[v + 1] - r);
+  }
+}
+
+static int ensure_edesc(gm_graph *g) {
+  if (g->d_edesc || g->ne == 0) return GM_OK;
+  std::lock_guard<std::mutex> lk(g->mu);
+  if (g->d_edesc) return GM_OK;
+  SetupTimer timer;
+  int2 *d = nullptr;
+  HIP_TRY(hipMalloc(&d, sizeof(int2) * (size_t)g->ne));
+  const long long blocks = std::min<long long>((g->ne + 255) / 256, (long long)g->cu_count * 32);
+  hipLaunchKernelGGL(edesc_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, g->ne, g->d_rp, g->d_col, d);
+  hipError_t e = hipDeviceSynchronize();
+  if (e != hipSuccess) { (void)hipFree(d); return hip_fail(e, "edesc_kernel", __FILE__, __LINE__); }
+  g->d_edesc = d;
+  g->setup.table_ms += timer.ms();
+  return GM_OK;
+}
+
 // Scheduler policy as index arithmetic on chunk ids (replaces the per-GPU COO copies of
 // Scheduler::round_robin, src/common/scheduler.cc:34-85, and EVEN_SPLIT, src/clique/multigpu.cu:42-44).
 extern "C" int gm_partition(int64_t n_chunks, int32_t rank, int32_t world, int32_t policy, int64_t *first, int64_t *step,
@@ -1001,6 +1030,11 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
   p.g.ne = (int)g->ne;
   p.g.rp = g->d_rp;
   p.g.col = g->d_col;
+  if (!(la->tune[6] & 0x10000)) {  // (0x10000: A/B switch, gather rp[v] instead of reading the edge descriptors)
+    rc = ensure_edesc(g);
+    if (rc) return rc;
+    p.g.edesc = g->d_edesc;
+  }
   p.chunks = tab->d;
   p.chunk_slot = tab->d_slot;
   p.bitmaps = tab->d_bitmaps;
@@ -1824,6 +1858,34 @@ extern "C" int gm_calib_stream(const int32_t *d_buf, int64_t n, uint64_t *d_out,
   if (!d_buf || !d_out || n < 0) return GM_ERR_INVALID;
   hipLaunchKernelGGL(calib_stream_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, d_buf, (long long)n,
                      (unsigned long long *)d_out);
+  HIP_TRY(hipGetLastError());
+  return GM_OK;
+}
+
+// Stream ceiling: the fastest plain read this library can issue (16 B per lane, grid-stride, 8 workgroups per CU), used by
+// bench.py as the MEASURED HBM ceiling next to the 8 TB/s spec (SURVEY.md 8d "Bounding roofline").
+typedef int gm_v4i __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void stream_ceiling_kernel(const gm_v4i *__restrict__ buf, long long n4, unsigned long long *out) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  gm_v4i acc = {0, 0, 0, 0};
+  for (; i + 3 * stride < n4; i += 4 * stride) {  // four independent 16-byte loads in flight per lane
+    const gm_v4i a = __builtin_nontemporal_load(buf + i), b = __builtin_nontemporal_load(buf + i + stride);
+    const gm_v4i c = __builtin_nontemporal_load(buf + i + 2 * stride), d = __builtin_nontemporal_load(buf + i + 3 * stride);
+    acc ^= a ^ b ^ c ^ d;
+  }
+  for (; i < n4; i += stride) acc ^= buf[i];
+  const unsigned long long s = wave_sum_u64((unsigned long long)(unsigned)(acc.x ^ acc.y ^ acc.z ^ acc.w));
+  if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
+}
+
+extern "C" int gm_stream_ceiling(const int32_t *d_buf, int64_t n, uint64_t *d_out, void *stream) {
+  if (!d_buf || !d_out || n < 0 || ((uintptr_t)d_buf & 15)) return GM_ERR_INVALID;
+  int dev = 0, cus = 256;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+  hipLaunchKernelGGL(stream_ceiling_kernel, dim3((unsigned)(cus * 8)), dim3(256), 0, (hipStream_t)stream, (const gm_v4i *)d_buf,
+                     (long long)(n / 4), (unsigned long long *)d_out);
   HIP_TRY(hipGetLastError());
   return GM_OK;
 }

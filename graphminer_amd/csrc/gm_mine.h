@@ -58,6 +58,12 @@ struct GraphView {
   int ne;
   const int *rp;   // int32 row offsets (nv+1), internal copy of row_ptr
   const int *col;  // col_idx
+  // Edge descriptors, one per CSR entry e: {rp[col[e]], d(col[e])} -- where the neighbour list of the entry's destination
+  // starts and how long it is. A lane reads the descriptor of ITS task edge with a coalesced 8-byte load instead of
+  // gathering rp[v], rp[v+1] from a random 64-byte line: in the short-list regime (LiveJournal: mean list 9) that gather
+  // was half of the lines a task edge touches. Takes the place of the reference's COO src/dst lists (8 B per task,
+  // include/graph_gpu.h:29-30); nullptr = gather from rp.
+  const int2 *edesc = nullptr;
 };
 
 enum Pattern : int { PAT_TC = 0, PAT_DIAMOND = 1, PAT_MOTIF3 = 2, PAT_CLIQUE4 = 3, PAT_CLIQUEK = 4 /* k = 5..8 */,

@@ -764,6 +764,12 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
                                         ? p.bitmaps + (size_t)slot * p.bitmap_words : nullptr;
   const int *__restrict__ rp = p.g.rp;
   const int *__restrict__ col = p.g.col;
+#ifndef GM_EDESC
+#define GM_EDESC 1
+#endif
+  // (compile-time: with both the descriptor and the rp-gather path alive TC needs 74 VGPRs = 6 waves per SIMD instead of 7;
+  // GM_EDESC=0 builds the gather version for A/B runs -- the host passes edesc whenever the graph has entries)
+  const int2 *__restrict__ edesc = GM_EDESC ? p.g.edesc : nullptr;
   WaveLds &L = B.w[wave];
   const int tid = threadIdx.x, nthreads = kWavesPerBlock * GM_WAVE;
   const int ub = r.u_begin, nvl = r.u_end - r.u_begin;
@@ -864,7 +870,7 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
   const bool split4 = GM_IS_CLIQUE(PAT) && grouped;
   const int bsz = split4 ? clique_batch : r.batch;  // edges per batch (host: 64, or kSplitBatch in heavy SPLIT chunks)
   int my_bi = g0 / bsz;
-  for (;;) {
+  auto grab_batch = [&]() {
     int bi = 0;
     if (split4) {
       bi = my_bi++;
@@ -872,8 +878,35 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
       if (lane == 0) bi = atomicAdd(&B.next_batch, 1);
       bi = readfirst(bi) * r.nparts + r.part;  // this part's batches (nparts == 1: all of them)
     }
+    return bi;
+  };
+  // GM_DESC_PREFETCH=1 requests the edge descriptors of the NEXT batch before the current batch is processed (the wave takes
+  // its next batch index early). Measured on MI355X (profiles/r02/ab_edesc.log), TC ms, descriptors without / with the
+  // prefetch: uniform LiveJournal-size 0.885 / 0.887, power-law 1.977 / 1.978, R-MAT-22 10.27 / 10.34 -- the coalesced
+  // descriptor load is not what a batch waits for, so the default is 0 (3 VGPRs fewer).
+  auto load_desc = [&](const int bi) {
+    const int e = eb + bi * bsz + lane;  // (ne < 2^31)
+    return edesc[min(e, p.g.ne - 1)];    // unconditional load, clamped index (invalid lanes are masked later)
+  };
+#ifndef GM_DESC_PREFETCH
+#define GM_DESC_PREFETCH 0
+#endif
+  // (the prefetch holds 3 more VGPRs across the passes; GM_DESC_PREFETCH=0 loads the descriptors at the top of their own batch)
+  constexpr bool kPrefetch = GM_DESC_PREFETCH != 0 && GM_EDESC != 0;
+  int next_bi = grab_batch();
+  int2 next_desc = make_int2(0, 0);
+  if (kPrefetch && GM_EDESC && next_bi * bsz < gend) next_desc = load_desc(next_bi);
+  for (;;) {
+    const int bi = next_bi;
+    int2 desc = next_desc;
     const int le0 = bi * bsz;
     if (le0 >= gend) break;
+    if (kPrefetch) {
+      next_bi = grab_batch();
+      if (GM_EDESC && next_bi * bsz < gend) next_desc = load_desc(next_bi);  // wave-uniform condition
+    } else if (GM_EDESC) {
+      desc = load_desc(bi);
+    }
     const int le = le0 + lane;
     const bool valid = (le < nel) && (lane < bsz) && (!split4 || (lane & 3) == wave);
     const int e = eb + le;
@@ -896,8 +929,13 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
       a = B.rpl[lo + 1] - ru;
       u = ub + lo;
       idx = e - ru;
-      rv = rp[v];
-      b = rp[v + 1] - rv;
+      if (GM_EDESC) {  // (requested one batch ago, coalesced: lane le read entry eb + le)
+        rv = desc.x;
+        b = desc.y;
+      } else {
+        rv = rp[v];
+        b = rp[v + 1] - rv;
+      }
     }
     // pattern-specific task filter / bounds
     bool act = valid;
@@ -1027,6 +1065,7 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
       }
       wave_sync();
     }
+    if (!kPrefetch) next_bi = grab_batch();
   }
   if (GM_IS_CLIQUE(PAT) && grouped) {  // flush the finished rows of this group to the arena
     __syncthreads();
@@ -1075,7 +1114,13 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT>
 }
 
 template <int PAT>
-__global__ __launch_bounds__(kWavesPerBlock *GM_WAVE, PAT == PAT_CLIQUEK ? 4 : (PAT == PAT_CLIQUE4 ? 5 : 8)) void mine_kernel(const MineParams p) {
+#ifndef GM_TC_WAVES
+#define GM_TC_WAVES 7
+#endif
+// (second launch bound = workgroups per CU the register allocator aims for: TC's LDS allows 7, asking for 8 made the allocator
+// give up at 74 VGPRs = 6 waves per SIMD once the edge descriptors were added; asking for 7 makes it fit the 72 of 7 waves)
+// The symmetric-graph patterns (31.5 KB of LDS: 5 workgroups per CU) get 5 for the same reason: 96 VGPRs, not 97.
+__global__ __launch_bounds__(kWavesPerBlock *GM_WAVE, PAT == PAT_CLIQUEK ? 4 : (PAT == PAT_TC ? GM_TC_WAVES : 5)) void mine_kernel(const MineParams p) {
   __shared__ BlockLds<PAT> B;
   const int lane = threadIdx.x & (GM_WAVE - 1);
   const int wave = threadIdx.x >> 6;

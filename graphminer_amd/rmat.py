@@ -125,3 +125,50 @@ def uniform_csr_device(nv: int, m: int, seed: int = 1, device: int = 0):
         torch.cuda.synchronize(dev)
     g = DeviceGraph.from_device_ptrs(nv, int(col.numel()), row_ptr.data_ptr(), col.data_ptr(), device, keepalive=(row_ptr, col))
     return g, row_ptr, col
+
+
+def powerlaw_csr_device(nv: int, m: int, max_deg: int = 20000, gamma: float = 2.5, seed: int = 1, device: int = 0):
+    """Chung-Lu power-law graph on the GPU (torch RNG): m endpoint pairs drawn from weights w_i ~ (i + i0)^(-1/(gamma-1)),
+    i0 chosen so that the heaviest vertex expects `max_deg` neighbours; ids randomly permuted (hubs are not clustered at low
+    ids, unlike R-MAT); self-loops dropped, symmetrised, de-duplicated. With nv = 4,847,571, m = 43,000,000,
+    max_deg = 20,000 it has LiveJournal's published |V|, |E| and maximum degree (src/triangle/README.md:58): the third
+    stand-in for BASELINE configs 2 / 3, between the flat uniform graph and the hub-dominated R-MAT. Measurements only
+    (not bit-reproducible across torch versions), never goldens."""
+    import torch
+
+    alpha = 1.0 / (gamma - 1.0)
+    one = 1.0 - alpha
+
+    def d0(i0):  # expected degree of the heaviest vertex
+        w = ((nv + i0) ** one - i0 ** one) / one
+        return 2.0 * m * (i0 ** -alpha) / w
+
+    lo, hi = 1e-6, float(nv)
+    for _ in range(200):  # d0 decreases in i0
+        mid = (lo * hi) ** 0.5
+        lo, hi = (mid, hi) if d0(mid) > max_deg else (lo, mid)
+    i0 = hi
+    dev = torch.device("cuda", device)
+    with torch.cuda.device(dev):
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(seed)
+        a_, b_ = i0 ** one, (nv + i0) ** one
+
+        def draw():
+            u = torch.rand(m, device=dev, dtype=torch.float64, generator=gen)
+            x = (u * (b_ - a_) + a_) ** (1.0 / one) - i0
+            return x.floor().clamp_(0, nv - 1).to(torch.int64)
+
+        perm = torch.randperm(nv, device=dev, generator=gen)
+        s, d = perm[draw()], perm[draw()]
+        keep = s != d
+        s, d = s[keep], d[keep]
+        keys = torch.unique(torch.cat([(s << 32) | d, (d << 32) | s]))
+        src = keys >> 32
+        col = (keys & 0xFFFFFFFF).to(torch.int32).contiguous()
+        row_ptr = torch.zeros(nv + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(torch.bincount(src, minlength=nv), 0, out=row_ptr[1:])
+        del keys, src, s, d, perm
+        torch.cuda.synchronize(dev)
+    g = DeviceGraph.from_device_ptrs(nv, int(col.numel()), row_ptr.data_ptr(), col.data_ptr(), device, keepalive=(row_ptr, col))
+    return g, row_ptr, col

@@ -228,6 +228,11 @@ int gm_clique4_level2_bytes(const gm_graph *dag, uint64_t *bytes);
  * access width the mining kernels use (MI355X_MICROARCH.md: FETCH_SIZE is calibrated only for 16 B/lane). */
 int gm_calib_stream(const int32_t *d_buf, int64_t n, uint64_t *d_out, void *stream);
 
+/* Measured stream ceiling (tooling): one pass of 16-byte-per-lane loads over d_buf[0..n) (n int32 words, 16-byte aligned),
+ * xor-sum -> *d_out. Time it with events: bytes / t is the read bandwidth a plain stream reaches on this part (the MEASURED
+ * ceiling bench.py prints beside the 8 TB/s spec). */
+int gm_stream_ceiling(const int32_t *d_buf, int64_t n, uint64_t *d_out, void *stream);
+
 /* wave-primitive self test (DPP scans, ballot rank, LDS search); returns GM_OK when the device
  * results equal the host expectation. *n_fail receives the number of mismatching lanes. */
 int gm_selftest(int device, int *n_fail);
