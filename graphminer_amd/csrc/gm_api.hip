@@ -99,6 +99,7 @@ struct ChunkTable {
   int bit_words;    // clique: LDS bit-matrix budget the chunks were built for (0 = unconstrained)
   unsigned long long part_cap = 0;  // estimated work above which a chunk is cut into parts
   int stage_cap = 0;                // rows longer than this are SPLIT rows
+  bool skip_wide = false;           // clique: the wide vertices are left to the big-LDS kernel
   std::vector<unsigned long long> cost;  // estimated work per chunk (after cutting)
   ChunkRec *d = nullptr;
   size_t n = 0;
@@ -114,6 +115,23 @@ struct ChunkTable {
   unsigned long long max_bit_words = 0;  // largest nel*stride over chunks that exceed bit_words
   std::vector<unsigned long long> edge_prefix;  // edges owned by chunks [0,i)
   std::vector<int> first_vertex;                // u_begin of every chunk (ascending; SPLIT chunks repeat it)
+};
+
+struct WidePlan {
+  int rank = 0, world = 1, policy = 0;
+  std::vector<int> verts;  // this rank's wide vertices; slot = index here (heaviest first)
+  struct Round {
+    size_t chunk_begin = 0, chunk_end = 0;  // row-group chunks of the round (phase 1)
+    size_t cls_begin[4] = {0, 0, 0, 0};     // slots of the round per count class S / L / X, in d_cls_slots (phase 2)
+    unsigned long long words = 0;           // arena words of the round
+  };
+  std::vector<Round> rounds;
+  unsigned long long edges = 0;    // task edges of these vertices
+  size_t n_chunks = 0;
+  int *d_verts = nullptr;
+  unsigned long long *d_base = nullptr;  // slot -> word offset inside its round's arena
+  ChunkRec *d_chunks = nullptr;
+  int *d_cls_slots = nullptr;
 };
 
 struct gm_graph {
@@ -157,6 +175,14 @@ struct gm_graph {
   unsigned long long n_house_blocks = 0;   // handle whose event ring holds this handle's most recent launch
   unsigned long long sum_c2 = 0;          // sum_v C(d(v),2)
   bool sum_c2_valid = false;
+  // k-clique: the wide DAG vertices (clique_is_wide), longest rows first, and the per-(rank, world, policy) plans of their two
+  // phases (row-group chunks of phase 1, count classes of phase 2, matrix offsets, arena rounds)
+  std::vector<int> h_wide;
+  bool wide_valid = false;
+  std::list<struct WidePlan> wide_plans;
+  unsigned *d_wide_mat = nullptr;      // matrix arena (largest round so far)
+  size_t wide_mat_bytes = 0;
+  unsigned *d_wide_queue = nullptr;    // dequeue words of the wide launches of one call (zeroed per call)
   gm_setup_times setup = {0, 0, 0, 0, 0};  // accumulated pre-processing time of this handle (gm_graph_setup_times)
   std::mutex mu;
 };
@@ -216,6 +242,14 @@ extern "C" void gm_graph_free(gm_graph *g) {
   if (g->d_rp) (void)hipFree(g->d_rp);
   if (g->own_col && g->d_col) (void)hipFree(g->d_col);
   if (g->d_edesc) (void)hipFree(g->d_edesc);
+  for (auto &pl : g->wide_plans) {
+    if (pl.d_verts) (void)hipFree(pl.d_verts);
+    if (pl.d_base) (void)hipFree(pl.d_base);
+    if (pl.d_chunks) (void)hipFree(pl.d_chunks);
+    if (pl.d_cls_slots) (void)hipFree(pl.d_cls_slots);
+  }
+  if (g->d_wide_mat) (void)hipFree(g->d_wide_mat);
+  if (g->d_wide_queue) (void)hipFree(g->d_wide_queue);
   if (g->d_counters) (void)hipFree(g->d_counters);
   if (g->d_scratch) (void)hipFree(g->d_scratch);
   if (g->d_idx0) (void)hipFree(g->d_idx0);
@@ -578,7 +612,7 @@ static int get_relabeled(gm_graph *g, int descending, gm_graph **out) {
 // task chunk tables
 // ------------------------------------------------------------------------------------------------
 static void build_chunks(const std::vector<int> &rp, int nv, int target, bool allow_split, int bit_words, int stage_cap,
-                         std::vector<ChunkRec> &out, unsigned long long &max_bit_words) {
+                         std::vector<ChunkRec> &out, unsigned long long &max_bit_words, bool skip_wide = false) {
   out.clear();
   max_bit_words = 0;
   int u = 0;
@@ -586,6 +620,7 @@ static void build_chunks(const std::vector<int> &rp, int nv, int target, bool al
   while (u < nv) {
     const int d = deg(u);
     if (d == 0) { ++u; continue; }
+    if (skip_wide && clique_is_wide(d)) { ++u; continue; }  // two-phase path: row groups + clique_count_kernel
     if (d > stage_cap) {
       if (allow_split) {
         for (int s = rp[u]; s < rp[u + 1]; s += target) out.push_back({u, u + 1, s, std::min(s + target, rp[u + 1]), 0, 1, GM_WAVE, 0});
@@ -601,6 +636,7 @@ static void build_chunks(const std::vector<int> &rp, int nv, int target, bool al
     while (u < nv && (u - start) < kMaxChunkVerts) {
       const int du = deg(u);
       if (du > stage_cap) break;
+      if (skip_wide && clique_is_wide(du)) break;
       if (edges > 0 && edges + du > stage_cap) break;
       if (bit_words && edges > 0) {
         const int nm = std::max(maxd, du);
@@ -676,10 +712,10 @@ static int batch_edges(const ChunkRec &r, const std::vector<int> &rp, int stage_
 }
 
 static int get_table(gm_graph *g, int target, bool allow_split, int bit_words, unsigned long long part_cap, int stage_cap,
-                     ChunkTable **out) {
+                     ChunkTable **out, bool skip_wide = false) {
   std::lock_guard<std::mutex> lk(g->mu);
   for (auto &t : g->tables)
-    if (t.target == target && t.allow_split == allow_split && t.bit_words == bit_words && t.part_cap == part_cap && t.stage_cap == stage_cap) { *out = &t; return GM_OK; }
+    if (t.target == target && t.allow_split == allow_split && t.bit_words == bit_words && t.part_cap == part_cap && t.stage_cap == stage_cap && t.skip_wide == skip_wide) { *out = &t; return GM_OK; }
   SetupTimer timer;
   double bitmap_ms = 0;
   std::vector<ChunkRec> recs;
@@ -689,7 +725,8 @@ static int get_table(gm_graph *g, int target, bool allow_split, int bit_words, u
   t.bit_words = bit_words;
   t.part_cap = part_cap;
   t.stage_cap = stage_cap;
-  build_chunks(g->h_rp, g->nv, target, allow_split, bit_words, stage_cap, recs, t.max_bit_words);
+  t.skip_wide = skip_wide;
+  build_chunks(g->h_rp, g->nv, target, allow_split, bit_words, stage_cap, recs, t.max_bit_words, skip_wide);
   // estimated work per chunk (device), then: cut the heavy ones into parts, and fix the dequeue orders
   std::vector<unsigned long long> cost(recs.size());
   if (!recs.empty()) {
@@ -848,6 +885,93 @@ static int ensure_edesc(gm_graph *g) {
   hipError_t e = hipDeviceSynchronize();
   if (e != hipSuccess) { (void)hipFree(d); return hip_fail(e, "edesc_kernel", __FILE__, __LINE__); }
   g->d_edesc = d;
+  g->setup.table_ms += timer.ms();
+  return GM_OK;
+}
+
+// k-clique, wide vertices (see gm_mine.h): the plan of one rank's share -- which wide vertices it owns (every world-th of
+// the list sorted by row length, or a contiguous range), where each one's matrix sits in the arena, the row-group chunks of
+// phase 1 and the slots per count class of phase 2. The arena is bounded (GM_WIDE_ARENA_MB, default 16 GiB): a share whose
+// matrices need more is processed in several ROUNDS that reuse it.
+#ifndef GM_WIDE_ARENA_MB
+#define GM_WIDE_ARENA_MB 16384
+#endif
+static int get_wide_plan(gm_graph *g, int rank, int world, int policy, WidePlan **out) {
+  std::lock_guard<std::mutex> lk(g->mu);
+  SetupTimer timer;
+  if (!g->wide_valid) {
+    for (int v = 0; v < g->nv; ++v)
+      if (clique_is_wide(g->h_rp[v + 1] - g->h_rp[v])) g->h_wide.push_back(v);
+    std::stable_sort(g->h_wide.begin(), g->h_wide.end(), [&](int a, int b) { return g->h_rp[a + 1] - g->h_rp[a] > g->h_rp[b + 1] - g->h_rp[b]; });
+    g->wide_valid = true;
+  }
+  for (auto &pl : g->wide_plans)
+    if (pl.rank == rank && pl.world == world && pl.policy == policy) { *out = &pl; return GM_OK; }
+  WidePlan pl;
+  pl.rank = rank; pl.world = world; pl.policy = policy;
+  int64_t first = 0, step = 1, count = 0;
+  gm_partition((int64_t)g->h_wide.size(), rank, world, policy, &first, &step, &count);
+  for (int64_t i = 0; i < count; ++i) pl.verts.push_back(g->h_wide[(size_t)(first + i * step)]);
+  unsigned long long arena_mb = GM_WIDE_ARENA_MB;
+  if (const char *e = getenv("GM_WIDE_ARENA_MB")) arena_mb = std::max(1ll, atoll(e));  // (tests: force several rounds)
+  const unsigned long long budget_words = (arena_mb << 20) / 4ull;
+  std::vector<unsigned long long> base(pl.verts.size());
+  std::vector<ChunkRec> chunks;
+  std::vector<int> cls_slots;
+  size_t s0 = 0;
+  while (s0 < pl.verts.size()) {
+    WidePlan::Round rd;
+    rd.chunk_begin = chunks.size();
+    size_t s1 = s0;
+    unsigned long long words = 0;
+    std::vector<int> by_cls[3];
+    for (; s1 < pl.verts.size(); ++s1) {
+      const int u = pl.verts[s1], d = g->h_rp[u + 1] - g->h_rp[u], stride = (d + 31) / 32;
+      const unsigned long long w = (unsigned long long)d * (unsigned long long)stride;
+      if (s1 > s0 && words + w > budget_words) break;
+      base[s1] = words;
+      words += w;
+      pl.edges += (unsigned long long)d;
+      const int R = clique_group_rows(d);
+      for (int g0 = 0; g0 < d; g0 += R)
+        chunks.push_back({u, u + 1, g->h_rp[u] + g0, g->h_rp[u] + std::min(g0 + R, d), 0, 1, 8, (int)s1 + 1});
+      by_cls[clique_count_class(d)].push_back((int)s1);
+    }
+    rd.chunk_end = chunks.size();
+    rd.words = words;
+    for (int c = 0; c < 3; ++c) {
+      rd.cls_begin[c] = cls_slots.size();
+      cls_slots.insert(cls_slots.end(), by_cls[c].begin(), by_cls[c].end());
+    }
+    rd.cls_begin[3] = cls_slots.size();
+    pl.rounds.push_back(rd);
+    s0 = s1;
+  }
+  pl.n_chunks = chunks.size();
+  if (!pl.verts.empty()) {
+    HIP_TRY(hipSetDevice(g->device));
+    HIP_TRY(hipMalloc(&pl.d_verts, sizeof(int) * pl.verts.size()));
+    HIP_TRY(hipMemcpy(pl.d_verts, pl.verts.data(), sizeof(int) * pl.verts.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&pl.d_base, sizeof(unsigned long long) * base.size()));
+    HIP_TRY(hipMemcpy(pl.d_base, base.data(), sizeof(unsigned long long) * base.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&pl.d_chunks, sizeof(ChunkRec) * chunks.size()));
+    HIP_TRY(hipMemcpy(pl.d_chunks, chunks.data(), sizeof(ChunkRec) * chunks.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&pl.d_cls_slots, sizeof(int) * cls_slots.size()));
+    HIP_TRY(hipMemcpy(pl.d_cls_slots, cls_slots.data(), sizeof(int) * cls_slots.size(), hipMemcpyHostToDevice));
+    unsigned long long need_words = 0;
+    for (auto &rd : pl.rounds) need_words = std::max(need_words, rd.words);
+    const size_t need = (size_t)need_words * 4;
+    if (need > g->wide_mat_bytes) {
+      if (g->d_wide_mat) (void)hipFree(g->d_wide_mat);
+      g->d_wide_mat = nullptr;
+      g->wide_mat_bytes = 0;
+      HIP_TRY(hipMalloc(&g->d_wide_mat, need));
+      g->wide_mat_bytes = need;
+    }
+    if (!g->d_wide_queue) HIP_TRY(hipMalloc(&g->d_wide_queue, 65536));
+  }
+  g->wide_plans.push_back(std::move(pl));
+  *out = &g->wide_plans.back();
   g->setup.table_ms += timer.ms();
   return GM_OK;
 }
@@ -1021,8 +1145,16 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
        // a rank's share is 1/world of the launch: so is the tolerable tail (3-motif's bounded lists make its estimates
        // pessimistic already: measured, 1/8 share 84.8 ms unscaled vs 91.2 ms scaled; diamond 5.2 vs 4.2 ms)
        : (pat == PAT_MOTIF3 ? kPartCostCapSym : std::max<unsigned long long>(kPartCostCapSym / (unsigned long long)world, 256ull << 10)));
-  int rc = get_table(g, target, !clique, clique ? kBitWords : 0, part_cap, stage_cap_of(pat), &tab);
+  // 4-clique: vertices whose matrix exceeds the 8 KB budget but fits a big-LDS workgroup go to gm_wide.hip
+  // (tune[6] & 0x40000: A/B switch, everything stays in the mining kernel with its arena path)
+  const bool use_wide = pat == PAT_CLIQUE4 && !(la->tune[6] & 0x40000);
+  int rc = get_table(g, target, !clique, clique ? kBitWords : 0, part_cap, stage_cap_of(pat), &tab, use_wide);
   if (rc) return rc;
+  WidePlan *plan = nullptr;
+  if (use_wide) {
+    rc = get_wide_plan(g, rank, world, la->policy == GM_PART_VERTEX ? GM_PART_RANGE : la->policy, &plan);
+    if (rc) return rc;
+  }
 
   MineParams p;
   memset(&p, 0, sizeof p);
@@ -1030,11 +1162,9 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
   p.g.ne = (int)g->ne;
   p.g.rp = g->d_rp;
   p.g.col = g->d_col;
-  if (!(la->tune[6] & 0x10000)) {  // (0x10000: A/B switch, gather rp[v] instead of reading the edge descriptors)
-    rc = ensure_edesc(g);
-    if (rc) return rc;
-    p.g.edesc = g->d_edesc;
-  }
+  rc = ensure_edesc(g);  // (the kernels read them unconditionally; -DGM_EDESC=0 builds gather rp[v] instead, for A/B runs)
+  if (rc) return rc;
+  p.g.edesc = g->d_edesc;
   p.chunks = tab->d;
   p.chunk_slot = tab->d_slot;
   p.bitmaps = tab->d_bitmaps;
@@ -1121,6 +1251,64 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
 #endif
   rc = start_timer(ctx);
   if (rc) return rc;
+  if (use_wide && plan && !plan->verts.empty()) {
+    // wide vertices first (the heaviest work of the launch): per round, phase 1 = the mining kernel over the row-group
+    // chunks, phase 2 = the big-LDS count kernels per class; then the mining kernel over everything else
+    my_edges += plan->edges;
+    HIP_TRY(hipMemsetAsync(g->d_wide_queue, 0, 65536, stream));
+    const bool prof = getenv("GM_WIDE_PROFILE") != nullptr;
+    unsigned long long *d_prof = nullptr;
+    if (prof) {
+      HIP_TRY(hipMalloc(&d_prof, 4 * 32));
+      HIP_TRY(hipMemset(d_prof, 0, 4 * 32));
+    }
+    int qword = 0;
+    for (const auto &rd : plan->rounds) {
+      if (qword + 4 > 16384) return GM_ERR_TOO_LARGE;  // (more than 4096 arena rounds)
+      CliqueBuildParams pw;
+      memset(&pw, 0, sizeof pw);
+      pw.g = p.g;
+      pw.chunks = plan->d_chunks + rd.chunk_begin;
+      pw.count = (int)(rd.chunk_end - rd.chunk_begin);
+      pw.queue = g->d_wide_queue + qword++;
+      pw.mat = g->d_wide_mat;
+      pw.base = plan->d_base;
+      pw.cost_x_step = p.cost_x_step; pw.cost_y_step = p.cost_y_step; pw.cost_x_base = p.cost_x_base; pw.cost_y_base = p.cost_y_base;
+      pw.flags = p.flags;
+      const int per_cu_b = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / clique_build_lds_bytes()));
+      const int wgrid = (int)std::max<long long>(1, std::min<long long>(pw.count, (long long)g->cu_count * per_cu_b));
+      if (pw.count > 0) HIP_TRY(launch_clique_build(pw, wgrid, stream));
+      for (int cls = 2; cls >= 0; --cls) {  // X and L (one workgroup per CU) before S
+        CliqueCountParams c;
+        memset(&c, 0, sizeof c);
+        c.rp = g->d_rp;
+        c.verts = plan->d_verts;
+        c.base = plan->d_base;
+        c.mat = g->d_wide_mat;
+        c.slots = plan->d_cls_slots + rd.cls_begin[cls];
+        c.count = (int)(rd.cls_begin[cls + 1] - rd.cls_begin[cls]);
+        c.queue = g->d_wide_queue + qword++;
+        c.counters = g->d_counters;
+        c.profile = prof ? d_prof + 4 * cls : nullptr;
+        if (c.count == 0) continue;
+        const int per_cu_c = (int)std::max<size_t>(1, std::min<size_t>((160 * 1024) / clique_count_lds_bytes(cls), (size_t)(2048 / clique_count_threads(cls))));
+        const int cgrid = (int)std::max<long long>(1, std::min<long long>(c.count, (long long)g->cu_count * per_cu_c));
+        HIP_TRY(launch_clique_count(cls, c, cgrid, stream));
+      }
+    }
+    if (prof) {
+      unsigned long long h[12];
+      HIP_TRY(hipStreamSynchronize(stream));
+      HIP_TRY(hipMemcpy(h, d_prof, sizeof h, hipMemcpyDeviceToHost));
+      (void)hipFree(d_prof);
+      for (int cls = 0; cls < 3; ++cls)
+        if (h[4 * cls + 3])
+          fprintf(stderr, "[wide] count class %c: %llu workgroups; per workgroup ms: load %.2f count %.2f\n", "SLX"[cls], h[4 * cls + 3],
+                  h[4 * cls] / (double)h[4 * cls + 3] / 1e5, h[4 * cls + 1] / (double)h[4 * cls + 3] / 1e5);
+      fprintf(stderr, "[wide] %zu vertices, %zu row-group chunks, %zu round(s), arena %.1f MB\n", plan->verts.size(), plan->n_chunks,
+              plan->rounds.size(), g->wide_mat_bytes / 1048576.0);
+    }
+  }
   if (p.count > 0) HIP_TRY(launch_mine(pat, p, grid, stream));
 #ifdef GM_DEBUG_CHUNKS
   {

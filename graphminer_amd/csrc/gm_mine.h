@@ -50,7 +50,8 @@ constexpr int kSplitBatch = GM_SPLIT_BATCH;
 struct ChunkRec {
   int u_begin, u_end, e_begin, e_end;
   int part, nparts;  // nparts >= 1
-  int batch, pad_;   // task edges per batch (64; kSplitBatch in SPLIT chunks whose edges stream long lists)
+  int batch, pad_;   // task edges per batch (64; kSplitBatch in SPLIT chunks whose edges stream long lists); pad_ > 0: k-clique row
+                     // group of the wide slot pad_ - 1 (see "k-clique, wide vertices" below)
 };
 
 struct GraphView {
@@ -227,6 +228,70 @@ struct HouseParams {
 };
 hipError_t launch_house_flat(const HouseParams &p, int grid_blocks, hipStream_t stream);
 hipError_t launch_house_blocks(const GraphView &g, unsigned *nblk, hipStream_t stream);
+
+// ---- k-clique, wide vertices: two phases -----------------------------------------------------------------------------------
+// A DAG vertex u whose d x d adjacency bit-matrix over N+(u) exceeds the mining kernel's 8 KB LDS budget (d+ > 256) is WIDE.
+//  phase 1 (gm_wide.hip, clique_build_kernel): its task edges are cut into ROW GROUPS of 32 rows; a row group is an
+//          independent task chunk (any workgroup takes it; a lean 22 KB workgroup, 7 per CU), built in LDS by the flattened
+//          passes of gm_flat.h and flushed with coalesced stores to the vertex's slot of a MATRIX ARENA in HBM
+//          (sum d * ceil(d/32) words over the wide vertices: 4.4 GB for the com-Orkut stand-in -- HBM capacity is what
+//          MI355X has plenty of);
+//  phase 2 (gm_wide.hip, clique_count_kernel): one big-LDS workgroup per wide vertex copies the finished matrix into LDS
+//          (up to 128 KB) and counts sum_i sum_{j in M_i} popc(M_i & M_j) there.
+// Round 1 kept one arena slot per workgroup, so a wide vertex was built AND counted by a single workgroup (88 % of the
+// kernel time sat in those vertices, 382 GB of arena re-reads per launch).
+constexpr int kWideMaxDeg = 2048;   // wider DAG rows stay on the mining kernel's per-workgroup arena path
+__host__ __device__ inline bool clique_is_wide(int d) {
+  return (long long)d * ((d + 31) / 32) > kBitWords && d <= kWideMaxDeg;
+}
+constexpr int kBuildBitWords = 1024;  // LDS words of one row group: 32 rows x 32 words, 16 rows x 64 words
+__host__ __device__ inline int clique_group_rows(int d) { return ((d + 31) / 32) <= 32 ? 32 : 16; }  // rows * stride <= kBuildBitWords
+struct CliqueBuildParams {
+  GraphView g;
+  const ChunkRec *chunks;         // row groups: {u, u + 1, first entry, last entry + 1, 0, 1, batch, slot + 1}
+  int count;
+  unsigned *queue;                // dequeue head (zeroed before launch; its own word)
+  unsigned *mat;                  // matrix arena
+  const unsigned long long *base; // slot -> word offset of the vertex's matrix
+  int cost_x_step, cost_y_step, cost_x_base, cost_y_base;  // direction rule of the mining kernel
+  int flags;
+};
+hipError_t launch_clique_build(const CliqueBuildParams &p, int grid_blocks, hipStream_t stream);
+size_t clique_build_lds_bytes();
+// padded row stride of the LDS copy: a multiple of 4 words whose quarter is odd, so that the 16-byte row reads of 16 lanes
+// (16 different rows, same word offset) fall into 16 different bank groups
+__host__ __device__ inline int clique_padded_stride(int w) {
+  int p = (w + 3) & ~3;
+  if (((p >> 2) & 1) == 0) p += 4;
+  return p;
+}
+// count classes (LDS budget of the copy, in words): S = 4 waves / 32 KB (3 workgroups per CU), L = 16 waves / 112 KB (one per CU),
+// X = rows wider than L's budget: counted in COLUMN BLOCKS of the matrix
+#ifndef GM_COUNT_WAVES_L
+#define GM_COUNT_WAVES_L 16
+#endif
+constexpr int kCountWavesS = 4, kCountWordsS = 8192;
+constexpr int kCountWavesL = GM_COUNT_WAVES_L, kCountWordsL = 28672;
+constexpr int kCountWavesX = GM_COUNT_WAVES_L;
+struct CliqueCountParams {
+  const int *rp;
+  const int *verts;                 // slot -> vertex (this rank's wide vertices of the round)
+  const unsigned long long *base;   // slot -> word offset of the vertex's matrix in `mat`
+  const unsigned *mat;              // matrix arena
+  const int *slots;                 // the slots of this launch (one count class), heaviest first
+  int count;
+  unsigned *queue;                  // dequeue head (zeroed before launch; its own word)
+  unsigned long long *counters;     // [0] += 4-cliques
+  unsigned long long *profile;      // GM_WIDE_PROFILE: [0] load ticks, [1] count ticks, [3] workgroups (100 MHz, thread 0)
+};
+hipError_t launch_clique_count(int cls, const CliqueCountParams &p, int grid_blocks, hipStream_t stream);
+size_t clique_count_lds_bytes(int cls);
+int clique_count_threads(int cls);
+// class of a wide vertex: 0 = S, 1 = L (whole padded matrix in LDS), 2 = X (column blocks, runs on the L instantiation)
+__host__ __device__ inline int clique_count_class(int d) {
+  const long long words = (long long)d * clique_padded_stride((d + 31) / 32);
+  return words <= kCountWordsS ? 0 : (words <= kCountWordsL ? 1 : 2);
+}
 
 // host-side launchers (gm_mine.hip)
 hipError_t launch_mine(Pattern pat, const MineParams &p, int grid_blocks, hipStream_t stream);

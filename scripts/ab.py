@@ -20,6 +20,9 @@ for case in cases:
                 res[f"{label}/{v}"] = {"error": (r.stderr or r.stdout)[-400:]}
                 print(label, v, "ERROR", (r.stderr or r.stdout)[-300:], flush=True)
                 continue
+            for l in r.stderr.splitlines():
+                if l.startswith("["):
+                    print("    ", l[:200], flush=True)
             d = json.loads(line[0])
             res[f"{label}/{v}"] = {"kernel_ms": d["kernel_ms_avg"], "ms_per_step": d["ms_per_step"], "count": d["count"],
                                    "frac": d["roofline"].get("algorithmic_frac"), "setup": d["setup_ms"], "first_call_ms": d["first_call_ms"]}
