@@ -63,12 +63,12 @@ BASELINE_CONFIGS = [
 ]
 # rocprofv3 kernel names that make up one launch of a workload (everything between the library's two timing events)
 KERNELS = {
-    "tc": ["mine_kernel<0>"],
-    "diamond": ["mine_kernel<1>", "mine_wide_kernel<1>"],
-    "motif3": ["mine_kernel<2>", "mine_wide_kernel<2>"],
-    "clique4": ["mine_kernel<3>", "clique_wide_kernel"],
-    "clique5": ["mine_kernel<4>"],
-    "motif3f": ["mine_kernel<0>"],
+    "tc": ["mine_kernel<0,"],
+    "diamond": ["mine_kernel<1,"],           # class 0 and the big-LDS classes <1, 1>, <1, 2>
+    "motif3": ["mine_kernel<2,"],
+    "clique4": ["mine_kernel<3,", "clique_build_kernel", "clique_count_kernel"],
+    "clique5": ["mine_kernel<4,"],
+    "motif3f": ["mine_kernel<0,"],
     "rectangle": ["rect_acc_kernel"],
     "house": ["house_acc_kernel"],
     "pentagon": ["pent_acc_kernel"],
@@ -407,6 +407,8 @@ def measure_traffic(a, workloads):
                 # re-checked for the dword-per-lane width these kernels use: profiles/r01/traffic_fetch_write_summary.txt) -> x2;
                 # WRITE_SIZE is uncalibrated (x1)
                 scale = 2048.0 if counter == "FETCH_SIZE" else 1024.0
+                if counter == "FETCH_SIZE" and tot <= 0:
+                    return None, f"no FETCH_SIZE rows matched the kernels of {w} ({KERNELS.get(w)}): " + ", ".join(sorted(k[:40] for k in sums)[:6])
                 out[w]["fetch_bytes" if counter == "FETCH_SIZE" else "write_bytes"] = tot * scale / launches[w]
                 out[w]["launches"] = launches[w]
         return out, "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of the same workloads in this run; FETCH x2 (gfx950 calibration), KB units"
@@ -579,7 +581,7 @@ def finish_record(rec, a, world, ab, floor, traffic, traffic_src, cpu, known, st
                               "all": [round(x, 4) for x in rec["per_gpu_kernel_ms"]]},
         "grid": rec["stats"],
     }
-    roof = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": "+".join(KERNELS.get(rec["workload"], ["?"])),
+    roof = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": " + ".join(k.rstrip(",") + (">" if k.endswith(",") else "") for k in KERNELS.get(rec["workload"], ["?"])),
             "compulsory_floor_bytes": floor, "stream_ceiling_GBs": round(stream_gbs, 1) if stream_gbs else None}
     alg_gbs = None
     if ab is not None and t > 0:

@@ -93,13 +93,29 @@ constexpr unsigned long long kPartCostCap = 8ull << 20;     // DAG patterns: sta
 constexpr unsigned long long kPartCostCapSym = GM_PART_CAP_SYM;  // symmetric-graph patterns (measured on R-MAT-20/22/24: 1 M best for diamond, 2 M for 3-motif)
 constexpr int kDefaultChunk = 1024;  // task edges per chunk when the caller does not say
 
+// Which rows a chunk table covers. The k-clique table leaves the wide vertices to the two-phase path; the tables of the
+// symmetric-graph patterns come in three: the general one skips the rows of the big-LDS classes, each class table keeps only
+// its own window of row lengths.
+struct RowFilter {
+  bool skip_clique_wide = false;
+  int skip_lo = 0, skip_hi = 0;                // rows with skip_lo < d <= skip_hi are left out (0, 0 = none)
+  int only_lo = -1, only_hi = 0x7fffffff;      // rows with only_lo < d <= only_hi are kept
+  bool skips(int d) const {
+    return (skip_clique_wide && clique_is_wide(d)) || (d > skip_lo && d <= skip_hi) || !(d > only_lo && d <= only_hi);
+  }
+  bool operator==(const RowFilter &o) const {
+    return skip_clique_wide == o.skip_clique_wide && skip_lo == o.skip_lo && skip_hi == o.skip_hi && only_lo == o.only_lo && only_hi == o.only_hi;
+  }
+};
+
 struct ChunkTable {
   int target;       // T: CSR entries per chunk
   bool allow_split; // rows longer than the staging capacity may be cut across chunks
   int bit_words;    // clique: LDS bit-matrix budget the chunks were built for (0 = unconstrained)
   unsigned long long part_cap = 0;  // estimated work above which a chunk is cut into parts
   int stage_cap = 0;                // rows longer than this are SPLIT rows
-  bool skip_wide = false;           // clique: the wide vertices are left to the big-LDS kernel
+  RowFilter rf;                     // the rows the table covers
+  int bitmap_min_deg = 0;           // rows longer than this got dense bitmaps (allow_split tables)
   std::vector<unsigned long long> cost;  // estimated work per chunk (after cutting)
   ChunkRec *d = nullptr;
   size_t n = 0;
@@ -183,6 +199,8 @@ struct gm_graph {
   unsigned *d_wide_mat = nullptr;      // matrix arena (largest round so far)
   size_t wide_mat_bytes = 0;
   unsigned *d_wide_queue = nullptr;    // dequeue words of the wide launches of one call (zeroed per call)
+  hipStream_t aux_stream[2] = {nullptr, nullptr};  // the big-LDS class kernels run beside the general one (run_pattern)
+  hipEvent_t aux_done[2] = {nullptr, nullptr};
   gm_setup_times setup = {0, 0, 0, 0, 0};  // accumulated pre-processing time of this handle (gm_graph_setup_times)
   std::mutex mu;
 };
@@ -250,6 +268,8 @@ extern "C" void gm_graph_free(gm_graph *g) {
   }
   if (g->d_wide_mat) (void)hipFree(g->d_wide_mat);
   if (g->d_wide_queue) (void)hipFree(g->d_wide_queue);
+  for (auto &st_ : g->aux_stream) if (st_) (void)hipStreamDestroy(st_);
+  for (auto &ev_ : g->aux_done) if (ev_) (void)hipEventDestroy(ev_);
   if (g->d_counters) (void)hipFree(g->d_counters);
   if (g->d_scratch) (void)hipFree(g->d_scratch);
   if (g->d_idx0) (void)hipFree(g->d_idx0);
@@ -612,7 +632,7 @@ static int get_relabeled(gm_graph *g, int descending, gm_graph **out) {
 // task chunk tables
 // ------------------------------------------------------------------------------------------------
 static void build_chunks(const std::vector<int> &rp, int nv, int target, bool allow_split, int bit_words, int stage_cap,
-                         std::vector<ChunkRec> &out, unsigned long long &max_bit_words, bool skip_wide = false) {
+                         std::vector<ChunkRec> &out, unsigned long long &max_bit_words, const RowFilter &rf = RowFilter()) {
   out.clear();
   max_bit_words = 0;
   int u = 0;
@@ -620,7 +640,7 @@ static void build_chunks(const std::vector<int> &rp, int nv, int target, bool al
   while (u < nv) {
     const int d = deg(u);
     if (d == 0) { ++u; continue; }
-    if (skip_wide && clique_is_wide(d)) { ++u; continue; }  // two-phase path: row groups + clique_count_kernel
+    if (rf.skips(d)) { ++u; continue; }
     if (d > stage_cap) {
       if (allow_split) {
         for (int s = rp[u]; s < rp[u + 1]; s += target) out.push_back({u, u + 1, s, std::min(s + target, rp[u + 1]), 0, 1, GM_WAVE, 0});
@@ -636,7 +656,7 @@ static void build_chunks(const std::vector<int> &rp, int nv, int target, bool al
     while (u < nv && (u - start) < kMaxChunkVerts) {
       const int du = deg(u);
       if (du > stage_cap) break;
-      if (skip_wide && clique_is_wide(du)) break;
+      if (rf.skips(du)) break;
       if (edges > 0 && edges + du > stage_cap) break;
       if (bit_words && edges > 0) {
         const int nm = std::max(maxd, du);
@@ -708,16 +728,20 @@ __global__ __launch_bounds__(256) void chunk_cost_kernel(const int *__restrict__
 static int batch_edges(const ChunkRec &r, const std::vector<int> &rp, int stage_cap, unsigned long long cost) {
   const bool whole = r.e_begin == rp[(size_t)r.u_begin] && r.e_end == rp[(size_t)r.u_end];
   const unsigned long long nel = (unsigned long long)std::max(r.e_end - r.e_begin, 1);
-  return (stage_cap == kStageCapWide && !whole && cost / nel >= (unsigned long long)kSplitBatchMinKeys) ? kSplitBatch : GM_WAVE;
+  // (the one-row chunks of the big-LDS classes are in the same situation as SPLIT chunks: every task edge streams a long list)
+  const bool long_lists = cost / nel >= (unsigned long long)kSplitBatchMinKeys;
+  return ((stage_cap == kStageCapWide && !whole && long_lists) || (stage_cap > kStageCapWide && long_lists)) ? kSplitBatch : GM_WAVE;
 }
 
 static int get_table(gm_graph *g, int target, bool allow_split, int bit_words, unsigned long long part_cap, int stage_cap,
-                     ChunkTable **out, bool skip_wide = false) {
+                     ChunkTable **out, const RowFilter &rf = RowFilter(), int bitmap_min_deg = kBitmapMinDeg) {
   std::lock_guard<std::mutex> lk(g->mu);
   for (auto &t : g->tables)
-    if (t.target == target && t.allow_split == allow_split && t.bit_words == bit_words && t.part_cap == part_cap && t.stage_cap == stage_cap && t.skip_wide == skip_wide) { *out = &t; return GM_OK; }
+    if (t.target == target && t.allow_split == allow_split && t.bit_words == bit_words && t.part_cap == part_cap && t.stage_cap == stage_cap &&
+        t.rf == rf && t.bitmap_min_deg == bitmap_min_deg) { *out = &t; return GM_OK; }
   SetupTimer timer;
   double bitmap_ms = 0;
+  const bool sym_table = stage_cap >= kStageCapWide;  // a table of the symmetric-graph patterns (general, mid or big class)
   std::vector<ChunkRec> recs;
   ChunkTable t;
   t.target = target;
@@ -725,8 +749,9 @@ static int get_table(gm_graph *g, int target, bool allow_split, int bit_words, u
   t.bit_words = bit_words;
   t.part_cap = part_cap;
   t.stage_cap = stage_cap;
-  t.skip_wide = skip_wide;
-  build_chunks(g->h_rp, g->nv, target, allow_split, bit_words, stage_cap, recs, t.max_bit_words, skip_wide);
+  t.rf = rf;
+  t.bitmap_min_deg = bitmap_min_deg;
+  build_chunks(g->h_rp, g->nv, target, allow_split, bit_words, stage_cap, recs, t.max_bit_words, rf);
   // estimated work per chunk (device), then: cut the heavy ones into parts, and fix the dequeue orders
   std::vector<unsigned long long> cost(recs.size());
   if (!recs.empty()) {
@@ -738,14 +763,14 @@ static int get_table(gm_graph *g, int target, bool allow_split, int bit_words, u
     if (e == hipSuccess) e = hipMemset(d_cost, 0, sizeof(unsigned long long) * recs.size());
     if (e == hipSuccess) {
       hipLaunchKernelGGL(chunk_cost_kernel, dim3((unsigned)recs.size()), dim3(256), 0, 0, g->d_rp, g->d_col, d_tmp, d_cost,
-                         stage_cap == kStageCapWide ? 1 : 0, stage_cap);
+                         sym_table ? 1 : 0, kStageCapWide);
       e = hipMemcpy(cost.data(), d_cost, sizeof(unsigned long long) * recs.size(), hipMemcpyDeviceToHost);
     }
     if (d_tmp) (void)hipFree(d_tmp);
     if (d_cost) (void)hipFree(d_cost);
     if (e != hipSuccess) return hip_fail(e, "chunk_cost_kernel", __FILE__, __LINE__);
   }
-  if (allow_split) {  // (clique chunks are never cut: their second phase needs the whole bit-matrix)
+  if (allow_split || sym_table) {  // (clique chunks are never cut: their second phase needs the whole bit-matrix)
     const unsigned long long cap = std::max<unsigned long long>(part_cap, 1);
     std::vector<ChunkRec> cut;
     std::vector<unsigned long long> cut_cost;
@@ -754,7 +779,10 @@ static int get_table(gm_graph *g, int target, bool allow_split, int bit_words, u
     for (size_t i = 0; i < recs.size(); ++i) {
       const int bsz = batch_edges(recs[i], g->h_rp, stage_cap, cost[i]);
       const int batches = (recs[i].e_end - recs[i].e_begin + bsz - 1) / bsz;
-      const int np = (int)std::max<unsigned long long>(1, std::min<unsigned long long>((unsigned long long)batches, (cost[i] + cap - 1) / cap));
+      // a part must keep every wave of its workgroup busy for several batches: the 16-wave class takes batches of 4 edges
+      // (its rows' partners are thousands of keys long) and parts of >= 64 batches, the 4-wave classes parts of >= 16
+      const int min_batches = stage_cap == kStageCapBig ? 64 : (stage_cap == kStageCapMid ? 16 : 1);
+      const int np = (int)std::max<unsigned long long>(1, std::min<unsigned long long>((unsigned long long)std::max(batches / min_batches, 1), (cost[i] + cap - 1) / cap));
       for (int q = 0; q < np; ++q) {
         ChunkRec r = recs[i];
         r.part = q;
@@ -795,7 +823,7 @@ static int get_table(gm_graph *g, int target, bool allow_split, int bit_words, u
       // order 0 of the symmetric-graph tables keeps chunk-id order INSIDE the heavy class as well: the heavy chunks are the
       // SPLIT chunks of the hub rows, and consecutive chunks of one row probe the same bitmap -- run together they keep it
       // in L2 (R-MAT-22 diamond: by cost 47.8 ms, by id 39.5 ms)
-      const bool classes_only = (m == 0) && (stage_cap == kStageCapWide);
+      const bool classes_only = (m == 0) && sym_table;
       std::stable_sort(o.begin(), o.end(), [&](int a, int b) {
         unsigned long long ca = cost[(size_t)a], cb = cost[(size_t)b];
         if (m == 0) { ca = ca >= heavy ? (classes_only ? 1ull : ca) : 0ull; cb = cb >= heavy ? (classes_only ? 1ull : cb) : 0ull; }
@@ -814,7 +842,7 @@ static int get_table(gm_graph *g, int target, bool allow_split, int bit_words, u
     std::vector<std::pair<int, int>> big;  // (degree, vertex)
     for (int v = 0; v < g->nv; ++v) {
       const int d = g->h_rp[v + 1] - g->h_rp[v];
-      if (d > kBitmapMinDeg) big.push_back({d, v});
+      if (d > bitmap_min_deg && !rf.skips(d)) big.push_back({d, v});
     }
     std::sort(big.begin(), big.end(), [](const std::pair<int, int> &x, const std::pair<int, int> &y) { return x.first > y.first; });
     const size_t nb = words ? std::min<size_t>(big.size(), (size_t)(budget_bytes / (words * 4ull))) : 0;
@@ -855,6 +883,12 @@ static int get_table(gm_graph *g, int target, bool allow_split, int bit_words, u
     bitmap_ms = bm_timer.ms();
   }
   HIP_TRY(hipDeviceSynchronize());
+  if (getenv("GM_TABLE_INFO")) {  // diagnostics
+    unsigned long long tc = 0, mx = 0;
+    for (auto c : t.cost) { tc += c; mx = std::max(mx, c); }
+    fprintf(stderr, "[table] stage_cap %d rows (%d,%d] skip (%d,%d]: %zu chunks, est. keys %.3e (max chunk %.3e), %zu bitmaps, edges %llu\n", stage_cap,
+            rf.only_lo, rf.only_hi, rf.skip_lo, rf.skip_hi, t.n, (double)tc, (double)mx, t.n_bitmaps, t.edge_prefix.empty() ? 0ull : t.edge_prefix.back());
+  }
   g->setup.bitmap_ms += bitmap_ms;
   g->setup.table_ms += timer.ms() - bitmap_ms;
   g->tables.push_back(std::move(t));
@@ -1145,11 +1179,38 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
        // a rank's share is 1/world of the launch: so is the tolerable tail (3-motif's bounded lists make its estimates
        // pessimistic already: measured, 1/8 share 84.8 ms unscaled vs 91.2 ms scaled; diamond 5.2 vs 4.2 ms)
        : (pat == PAT_MOTIF3 ? kPartCostCapSym : std::max<unsigned long long>(kPartCostCapSym / (unsigned long long)world, 256ull << 10)));
-  // 4-clique: vertices whose matrix exceeds the 8 KB budget but fits a big-LDS workgroup go to gm_wide.hip
+  // 4-clique: vertices whose matrix exceeds the 8 KB budget go through the two-phase path (gm_mine.h)
   // (tune[6] & 0x40000: A/B switch, everything stays in the mining kernel with its arena path)
   const bool use_wide = pat == PAT_CLIQUE4 && !(la->tune[6] & 0x40000);
-  int rc = get_table(g, target, !clique, clique ? kBitWords : 0, part_cap, stage_cap_of(pat), &tab, use_wide);
+  // symmetric-graph patterns: the rows just above the LDS stage go to the big-LDS workgroup classes (gm_chunk.h MineCfg)
+  // (tune[6] & 0x80000: A/B switch, they stay SPLIT rows with dense bitmaps)
+  const bool sym_pat = stage_cap_of(pat) == kStageCapWide;
+  // They pay where the dense bitmaps of the SPLIT path are cold: a bitmap has nv bits, and up to 512 KB (nv <= 2^22) the bitmaps
+  // of the rows being worked on stay in L2 -- measured, diamond R-MAT-22 28 ms (SPLIT + bitmaps) vs 47 ms (classes), R-MAT-20
+  // 10.4 vs 20.8; at nv = 2^24 (2 MB per bitmap) 819 vs 636 ms, 3-motif 458 vs 370 ms. tune[6] & 0x100000 forces them on.
+  const bool use_classes = sym_pat && !(la->tune[6] & 0x80000) && !(la->tune[5] == 1) &&
+                           ((la->tune[6] & 0x100000) || g->nv > (1 << 22));
+  RowFilter rf;
+  rf.skip_clique_wide = use_wide;
+  if (use_classes) { rf.skip_lo = kStageCapWide; rf.skip_hi = kStageCapBig; }
+  int rc = get_table(g, target, !clique, clique ? kBitWords : 0, part_cap, stage_cap_of(pat), &tab, rf, use_classes ? kStageCapBig : kBitmapMinDeg);
   if (rc) return rc;
+  ChunkTable *tab_cls[3] = {tab, nullptr, nullptr};
+  if (use_classes) {
+    RowFilter r1, r2;
+    r1.only_lo = kStageCapWide; r1.only_hi = kStageCapMid;
+    r2.only_lo = kStageCapMid; r2.only_hi = kStageCapBig;
+    // Parts of the one-row chunks: coarse. Measured on MI355X (profiles/r02/ab_sym_classes.log, diamond / 3-motif R-MAT-24, ms):
+    // whole rows (largest chunk 6e7 estimated keys) 636 / 370; parts of 512 K keys 1277 / 765 (16-wave workgroups with ~10
+    // batches per part); 512 K keys with >= 64 batches per part and 4-edge batches 743 / 462 -- every batch pays a few
+    // dependent global round trips (descriptors, the bounded prefix of 3-motif) before it streams, so small batches and
+    // small parts lose more than the shorter tail wins. Parts of 8 M keys only trim the few heaviest rows.
+    const unsigned long long cls_cap = (la->tune[6] & 0x1000) ? 4096ull : std::max<unsigned long long>(part_cap, 8ull << 20);
+    rc = get_table(g, target, false, 0, cls_cap, kStageCapMid, &tab_cls[1], r1, 0x7fffffff);
+    if (rc) return rc;
+    rc = get_table(g, target, false, 0, cls_cap, kStageCapBig, &tab_cls[2], r2, 0x7fffffff);
+    if (rc) return rc;
+  }
   WidePlan *plan = nullptr;
   if (use_wide) {
     rc = get_wide_plan(g, rank, world, la->policy == GM_PART_VERTEX ? GM_PART_RANGE : la->policy, &plan);
@@ -1165,14 +1226,15 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
   rc = ensure_edesc(g);  // (the kernels read them unconditionally; -DGM_EDESC=0 builds gather rp[v] instead, for A/B runs)
   if (rc) return rc;
   p.g.edesc = g->d_edesc;
-  p.chunks = tab->d;
-  p.chunk_slot = tab->d_slot;
-  p.bitmaps = tab->d_bitmaps;
-  p.bitmap_words = tab->bitmap_words;
-  p.row_slot = tab->d_row_slot;
-  const long long n = (long long)tab->n;
   unsigned long long my_edges = 0;
-  {
+  // this rank's share of a table: chunk ids first + i*step of the dequeue order (or a contiguous / vertex range)
+  auto take_share = [&](ChunkTable *tb, MineParams &q) {
+    q.chunks = tb->d;
+    q.chunk_slot = tb->d_slot;
+    q.bitmaps = tb->d_bitmaps;
+    q.bitmap_words = tb->bitmap_words;
+    q.row_slot = tb->d_row_slot;
+    const long long n = (long long)tb->n;
     long long first = 0, step = 1, count = 0;
     if (la->policy == GM_PART_VERTEX) {  // contiguous chunk range whose first vertex lies in this rank's vertex range
       const long long vlo = (long long)g->nv * rank / world, vhi = (long long)g->nv * (rank + 1) / world;
@@ -1180,7 +1242,7 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
         long long lo = 0, hi = n;
         while (lo < hi) {
           const long long mid = (lo + hi) / 2;
-          if (tab->first_vertex[(size_t)mid] < v) lo = mid + 1; else hi = mid;
+          if (tb->first_vertex[(size_t)mid] < v) lo = mid + 1; else hi = mid;
         }
         return lo;
       };
@@ -1189,24 +1251,24 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
     } else {
       gm_partition((int64_t)n, rank, world, la->policy, (int64_t *)&first, (int64_t *)&step, (int64_t *)&count);
     }
-    p.first = (int)first;
-    p.step = (int)step;
-    p.count = (int)count;
+    q.first = (int)first;
+    q.step = (int)step;
+    q.count = (int)count;
     // dequeue order (tune[6] & 0x4000: plain chunk-id order; & 0x2000: swap the two orders -- ablation only)
     // measured on R-MAT (one rank): the cliques want the full cost order (4-clique 220.6 -> 208.6 ms, 5-clique 796 -> 589 ms),
     // the symmetric-graph patterns the locality-preserving heavy-first order at every world size, TC heavy-first for one
     // rank and the full order for shares
-    const bool sym_pat = stage_cap_of(pat) == kStageCapWide;
     const bool clique_pat = pat == PAT_CLIQUE4 || pat == PAT_CLIQUEK;
     const int which = (((world > 1 && !sym_pat) || clique_pat) ? 1 : 0) ^ ((la->tune[6] & 0x2000) ? 1 : 0);
-    const bool lpt = la->policy == GM_PART_ROUND_ROBIN && tab->d_order[which] && !(la->tune[6] & 0x4000);
-    p.order = lpt ? tab->d_order[which] : nullptr;
-    if (step == 1) my_edges = tab->edge_prefix[first + count] - tab->edge_prefix[first];  // (any order: the same set)
+    const bool lpt = la->policy == GM_PART_ROUND_ROBIN && tb->d_order[which] && !(la->tune[6] & 0x4000);
+    q.order = lpt ? tb->d_order[which] : nullptr;
+    if (step == 1) my_edges += tb->edge_prefix[first + count] - tb->edge_prefix[first];  // (any order: the same set)
     else for (long long j = first; j < n; j += step) {
-      const size_t c = lpt ? (size_t)tab->order[which][(size_t)j] : (size_t)j;
-      my_edges += tab->edge_prefix[c + 1] - tab->edge_prefix[c];
+      const size_t c = lpt ? (size_t)tb->order[which][(size_t)j] : (size_t)j;
+      my_edges += tb->edge_prefix[c + 1] - tb->edge_prefix[c];
     }
-  }
+  };
+  take_share(tab, p);
   p.grab = la->tune[1] > 0 ? la->tune[1] : 1;
   // direction rule: X if b*(xb + xs*lg a) <= a*(yb + ys*lg b); tune[2] = xs+1, tune[3] = ys+1, tune[7] = xb*16 + yb
   p.cost_x_step = la->tune[2] > 0 ? la->tune[2] - 1 : 1;
@@ -1309,6 +1371,37 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
               plan->rounds.size(), g->wide_mat_bytes / 1048576.0);
     }
   }
+  uint64_t chunks_total = (uint64_t)p.count;
+  bool joined[2] = {false, false};
+  if (use_classes) {
+    // The class kernels run on their own streams BESIDE the general kernel: class 2 (one 160 KB workgroup per CU) is launched
+    // first and takes the CUs; as its persistent workgroups run out of chunks they leave, and the workgroups of class 1 and of
+    // the general kernel move in -- the tails overlap instead of adding up (on one stream every kernel boundary waited for
+    // the slowest workgroup of the kernel before it).
+    for (int cls = 2; cls >= 1; --cls) {
+      MineParams q = p;
+      take_share(tab_cls[cls], q);
+      q.queue = reinterpret_cast<unsigned *>(g->d_counters + 4) + cls;  // its own dequeue word inside the zeroed 64-byte block
+      if (q.count == 0) continue;
+      chunks_total += (uint64_t)q.count;
+      const int per_cu_w = (int)std::max<size_t>(1, (160 * 1024) / mine_wide_lds_bytes(cls));
+      const int wgrid = (int)std::max<long long>(1, std::min<long long>(q.count, (long long)g->cu_count * per_cu_w));
+      hipStream_t ws = stream;
+      if (getenv("GM_CLASSES_STREAMS")) {  // (measured: side streams 743 / 462 ms vs one stream 699 / 426 ms -- off by default)
+        if (!g->aux_stream[cls - 1]) {
+          HIP_TRY(hipStreamCreateWithFlags(&g->aux_stream[cls - 1], hipStreamNonBlocking));
+          HIP_TRY(hipEventCreateWithFlags(&g->aux_done[cls - 1], hipEventDisableTiming));
+        }
+        ws = g->aux_stream[cls - 1];
+        HIP_TRY(hipStreamWaitEvent(ws, ctx.evp[0], 0));  // after the counters were zeroed and the timer started
+      }
+      HIP_TRY(launch_mine_wide(pat, cls, q, wgrid, ws));
+      if (ws != stream) {
+        HIP_TRY(hipEventRecord(g->aux_done[cls - 1], ws));
+        joined[cls - 1] = true;
+      }
+    }
+  }
   if (p.count > 0) HIP_TRY(launch_mine(pat, p, grid, stream));
 #ifdef GM_DEBUG_CHUNKS
   {
@@ -1349,7 +1442,9 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
     }
   }
 #endif
-  fill_stats(st, (pat == PAT_DIAMOND || pat == PAT_MOTIF4E) ? my_edges / 2 : my_edges, (uint64_t)p.count, grid,
+  for (int i = 0; i < 2; ++i)
+    if (joined[i]) HIP_TRY(hipStreamWaitEvent(stream, g->aux_done[i], 0));  // the launch ends when all three kernels have
+  fill_stats(st, (pat == PAT_DIAMOND || pat == PAT_MOTIF4E) ? my_edges / 2 : my_edges, chunks_total, grid,
              kWavesPerBlock * GM_WAVE);
   return end_launch(ctx, fin_mode, fin_base, h_out, nout, st);
 }

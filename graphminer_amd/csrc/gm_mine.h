@@ -13,6 +13,12 @@ constexpr int kStageCap = 1024;           // adjacency entries a workgroup stage
 #define GM_STAGE_WIDE 3072
 #endif
 constexpr int kStageCapWide = GM_STAGE_WIDE;       // ... for the patterns that run on SYMMETRIC graphs (see stage_cap_of)
+// big-LDS workgroup classes of the symmetric-graph patterns (MineCfg in gm_chunk.h): rows of kStageCapWide+1 .. kStageCapMid
+// entries are staged whole by class 1, rows up to kStageCapBig by class 2; longer rows stay SPLIT rows with dense bitmaps.
+// (8191, not 8192: the branch-free bisection reads up to 2^bitlen(row) - 2 entries past the row start, which must stay inside
+// the workgroup's LDS)
+constexpr int kStageCapMid = 8191;
+constexpr int kStageCapBig = 24576;
 constexpr int kMaxChunkVerts = 256;       // rows per task chunk (local row_ptr slice in LDS)
 constexpr int kMarkWindow = 512;          // flattened positions resolved per owner-mark window
 #ifndef GM_TILES
@@ -296,5 +302,9 @@ __host__ __device__ inline int clique_count_class(int d) {
 // host-side launchers (gm_mine.hip)
 hipError_t launch_mine(Pattern pat, const MineParams &p, int grid_blocks, hipStream_t stream);
 size_t mine_lds_bytes(Pattern pat);
+// the big-LDS classes (gm_mine_wide.hip): cls = 1 (mid rows) or 2 (big rows); DIAMOND, MOTIF3, MOTIF4E only
+hipError_t launch_mine_wide(Pattern pat, int cls, const MineParams &p, int grid_blocks, hipStream_t stream);
+size_t mine_wide_lds_bytes(int cls);
+int mine_wide_threads(int cls);
 
 }  // namespace gm

@@ -1,0 +1,14 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+export TMPDIR=/tmp
+O=gpurun_out/r2i; mkdir -p $O
+timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "diamond or motif or hub or random_graphs or large_rmat or rows_longer" 2>&1 | tail -4 | tee $O/pytest_sym.log
+OLD='--tune;0,0,0,0,0,0,524288'
+python scripts/ab.py $O/ab_sym.json default \
+  'diamond_rmat22:--workload;diamond;--steps;10;--warmup;2' "diamond_rmat22_old:--workload;diamond;--steps;10;--warmup;2;$OLD" \
+  'diamond_rmat20:--workload;diamond;--scale;20;--ef;16;--steps;10;--warmup;2' \
+  'diamond_rmat24:--workload;diamond;--scale;24;--ef;16;--steps;3;--warmup;1' \
+  'motif3_rmat24:--workload;motif3;--steps;3;--warmup;1' \
+  'motif3_rmat22:--workload;motif3;--scale;22;--ef;16;--steps;5;--warmup;1' \
+  'diamond_powerlaw:--workload;diamond;--powerlaw;4847571,43000000,20000;--steps;10;--warmup;2' 2>&1 | tee $O/ab_sym.log
+echo "== one stream"; GM_CLASSES_ONE_STREAM=1 python scripts/ab.py $O/ab_sym1.json default 'diamond_rmat24:--workload;diamond;--scale;24;--ef;16;--steps;3;--warmup;1' 'motif3_rmat24:--workload;motif3;--steps;3;--warmup;1' 2>&1 | tee -a $O/ab_sym.log

@@ -46,6 +46,8 @@ def test_diamond_rmat20_equals_oracle(rmat_dev):
     assert got == want
     assert st.tasks == osym.ne // 2
     assert sum(SglSolver(sym, "diamond", rank=r, world=8) for r in range(8)) == want
+    # the big-LDS workgroup classes (rows of 3073..24576 entries staged whole; default from nv > 2^22), forced on
+    assert SglSolver(sym, "diamond", tune=[0, 0, 0, 0, 0, 0, 0x100000]) == want
 
 
 @pytest.mark.timeout(900)
@@ -73,6 +75,7 @@ def test_motif3_rmat22_equals_oracle(rmat_dev):
     assert got == want
     assert st.tasks == osym.ne
     assert MotifSolver(sym, 3, formula=True) == want
+    assert MotifSolver(sym, 3, tune=[0, 0, 0, 0, 0, 0, 0x100000]) == want  # with the big-LDS workgroup classes
     parts = [MotifSolver(sym, 3, rank=r, world=8) for r in range(8)]
     assert [sum(p[i] for p in parts) % 2**64 for i in range(2)] == want
 
