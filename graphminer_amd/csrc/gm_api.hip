@@ -69,6 +69,41 @@ extern "C" int gm_device_count(int *n) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// device-side setup helpers: scans / sorts / selections of the pre-processing run on the GPU (rocPRIM through hipCUB for the
+// primitives, hand-written kernels around them) -- no host loop over the vertices anywhere in the default paths
+// ------------------------------------------------------------------------------------------------
+template <class T>
+struct DevBuf {  // RAII device array
+  T *p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t count) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = count;
+    return hipMalloc(&p, sizeof(T) * std::max<size_t>(count, 1));
+  }
+  T *release() { T *q = p; p = nullptr; n = 0; return q; }
+};
+
+struct ScanTemp {  // temp storage of the hipCUB calls, grown on demand
+  DevBuf<char> buf;
+  hipError_t reserve(size_t bytes) { return bytes <= buf.n ? hipSuccess : buf.alloc(bytes); }
+};
+
+template <class TI, class TO>
+static hipError_t dev_exclusive_sum(ScanTemp &tmp, const TI *d_in, TO *d_out, size_t n, hipStream_t stream = 0) {
+  size_t bytes = 0;
+  hipError_t e = hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, d_in, d_out, (int)n, stream);
+  if (e != hipSuccess) return e;
+  if ((e = tmp.reserve(bytes)) != hipSuccess) return e;
+  return hipcub::DeviceScan::ExclusiveSum(tmp.buf.p, bytes, d_in, d_out, (int)n, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
 // graph handle
 // ------------------------------------------------------------------------------------------------
 // estimated work (adjacency entries touched) above which a chunk is cut into parts
@@ -100,7 +135,7 @@ struct RowFilter {
   bool skip_clique_wide = false;
   int skip_lo = 0, skip_hi = 0;                // rows with skip_lo < d <= skip_hi are left out (0, 0 = none)
   int only_lo = -1, only_hi = 0x7fffffff;      // rows with only_lo < d <= only_hi are kept
-  bool skips(int d) const {
+  __host__ __device__ bool skips(int d) const {
     return (skip_clique_wide && clique_is_wide(d)) || (d > skip_lo && d <= skip_hi) || !(d > only_lo && d <= only_hi);
   }
   bool operator==(const RowFilter &o) const {
@@ -159,7 +194,7 @@ struct gm_graph {
   int *d_col = nullptr;  // col_idx
   bool own_col = true;
   int2 *d_edesc = nullptr;  // per CSR entry: {rp[col[e]], degree(col[e])}, built on first use (ensure_edesc)
-  std::vector<int> h_rp;  // host copy of the offsets (chunk building, download)
+  std::vector<int> h_rp;  // host copy of the offsets, fetched on first use (host_rp): download, k-clique tables, SgL renumbering
   std::list<ChunkTable> tables;  // list: handed-out pointers stay valid
   unsigned long long *d_counters = nullptr;  // [4] + queue word, 64 B
   unsigned *d_scratch = nullptr;
@@ -193,7 +228,8 @@ struct gm_graph {
   bool sum_c2_valid = false;
   // k-clique: the wide DAG vertices (clique_is_wide), longest rows first, and the per-(rank, world, policy) plans of their two
   // phases (row-group chunks of phase 1, count classes of phase 2, matrix offsets, arena rounds)
-  std::vector<int> h_wide;
+  int *d_wide_sorted = nullptr;
+  size_t n_wide = 0;
   bool wide_valid = false;
   std::list<struct WidePlan> wide_plans;
   unsigned *d_wide_mat = nullptr;      // matrix arena (largest round so far)
@@ -267,6 +303,7 @@ extern "C" void gm_graph_free(gm_graph *g) {
     if (pl.d_cls_slots) (void)hipFree(pl.d_cls_slots);
   }
   if (g->d_wide_mat) (void)hipFree(g->d_wide_mat);
+  if (g->d_wide_sorted) (void)hipFree(g->d_wide_sorted);
   if (g->d_wide_queue) (void)hipFree(g->d_wide_queue);
   for (auto &st_ : g->aux_stream) if (st_) (void)hipStreamDestroy(st_);
   for (auto &ev_ : g->aux_done) if (ev_) (void)hipEventDestroy(ev_);
@@ -297,9 +334,59 @@ static int finish_handle(gm_graph *g) {
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, g->device));
   g->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  int md = 0;
-  for (int v = 0; v < g->nv; ++v) md = std::max(md, g->h_rp[v + 1] - g->h_rp[v]);
-  g->max_deg = md;
+  return GM_OK;  // (max_deg: set by the caller from the device-side pass that produced the offsets)
+}
+
+// host copy of the 32-bit offsets, fetched from the device on first use
+static int host_rp(gm_graph *g, const std::vector<int> **out) {
+  if (g->h_rp.size() != (size_t)g->nv + 1) {
+    g->h_rp.resize((size_t)g->nv + 1);
+    HIP_TRY(hipSetDevice(g->device));
+    HIP_TRY(hipMemcpy(g->h_rp.data(), g->d_rp, sizeof(int) * ((size_t)g->nv + 1), hipMemcpyDeviceToHost));
+  }
+  if (out) *out = &g->h_rp;
+  return GM_OK;
+}
+
+// int64 offsets of the ABI -> the internal int32 copy, validated on the device: err bit 0 = not an offset array (first != 0,
+// last != ne, or decreasing), bit 1 = a row of 2^24 entries or more; info[1] = longest row
+__global__ __launch_bounds__(256) void convert_offsets_kernel(const long long *__restrict__ rp64, int nv, long long ne, int *__restrict__ rp32,
+                                                              int *__restrict__ info) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  int err = 0, md = 0;
+  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v <= nv; v += stride) {
+    const long long x = rp64[v];
+    rp32[v] = (int)x;
+    if (v == 0 && x != 0) err |= 1;
+    if (v == nv && x != ne) err |= 1;
+    if (v > 0) {
+      const long long d = x - rp64[v - 1];
+      if (d < 0) err |= 1;
+      else if (d >= (1 << 24)) err |= 2;  // per-row limit of the flattened scan
+      else md = max(md, (int)d);
+    }
+  }
+  md = gm::wave_max_nonneg(md);
+  err = gm::wave_max_nonneg(err & 1) | (gm::wave_max_nonneg((err >> 1) & 1) << 1);
+  if ((threadIdx.x & 63) == 0) {
+    if (md) atomicMax(&info[1], md);
+    if (err & 3) atomicOr(&info[0], err & 3);
+  }
+}
+
+// d_rp64: DEVICE array of nv + 1 int64 offsets. Allocates and fills g->d_rp, sets g->max_deg.
+static int adopt_offsets(gm_graph *g, const int64_t *d_rp64) {
+  HIP_TRY(hipMalloc(&g->d_rp, sizeof(int) * ((size_t)g->nv + 1)));
+  DevBuf<int> info;
+  HIP_TRY(info.alloc(2));
+  HIP_TRY(hipMemset(info.p, 0, 8));
+  const long long blocks = std::min<long long>(((long long)g->nv + 256) / 256, 4096);
+  hipLaunchKernelGGL(convert_offsets_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, (const long long *)d_rp64, g->nv, g->ne, g->d_rp, info.p);
+  int h[2] = {0, 0};
+  HIP_TRY(hipMemcpy(h, info.p, 8, hipMemcpyDeviceToHost));
+  if (h[0] & 1) return GM_ERR_FORMAT;
+  if (h[0] & 2) return GM_ERR_TOO_LARGE;
+  g->max_deg = h[1];
   return GM_OK;
 }
 
@@ -330,13 +417,17 @@ extern "C" int gm_graph_upload(const gm_csr *h, int device, gm_graph **out) {
   g->device = device;
   g->nv = h->nv;
   g->ne = h->ne;
-  rc = convert_offsets(h->row_ptr, h->nv, h->ne, g->h_rp);
-  if (rc) { delete g; return rc; }
   auto fail = [&](int code) { gm_graph_free(g); return code; };
+  {  // the int64 offsets go up as they are and are narrowed / validated on the device (adopt_offsets)
+    DevBuf<int64_t> rp64;
+    hipError_t e;
+    if ((e = rp64.alloc((size_t)g->nv + 1)) != hipSuccess) return fail(hip_fail(e, "hipMalloc(rp64)", __FILE__, __LINE__));
+    if ((e = hipMemcpy(rp64.p, h->row_ptr, sizeof(int64_t) * ((size_t)g->nv + 1), hipMemcpyHostToDevice)) != hipSuccess) return fail(hip_fail(e, "hipMemcpy(rp)", __FILE__, __LINE__));
+    rc = adopt_offsets(g, rp64.p);
+    if (rc) return fail(rc);
+  }
   hipError_t e;
-  if ((e = hipMalloc(&g->d_rp, sizeof(int) * ((size_t)g->nv + 1))) != hipSuccess) return fail(hip_fail(e, "hipMalloc(rp)", __FILE__, __LINE__));
   if ((e = hipMalloc(&g->d_col, sizeof(int) * (size_t)std::max<long long>(g->ne, 1))) != hipSuccess) return fail(hip_fail(e, "hipMalloc(col)", __FILE__, __LINE__));
-  if ((e = hipMemcpy(g->d_rp, g->h_rp.data(), sizeof(int) * ((size_t)g->nv + 1), hipMemcpyHostToDevice)) != hipSuccess) return fail(hip_fail(e, "hipMemcpy(rp)", __FILE__, __LINE__));
   if (g->ne > 0 && (e = hipMemcpy(g->d_col, h->col_idx, sizeof(int) * (size_t)g->ne, hipMemcpyHostToDevice)) != hipSuccess) return fail(hip_fail(e, "hipMemcpy(col)", __FILE__, __LINE__));
   rc = finish_handle(g);
   if (rc) return fail(rc);
@@ -351,20 +442,15 @@ extern "C" int gm_graph_from_device(int32_t nv, int64_t ne, const int64_t *d_row
   int rc = check_sizes(nv, ne);
   if (rc) return rc;
   HIP_TRY(hipSetDevice(device));
-  std::vector<int64_t> rp64((size_t)nv + 1);
-  HIP_TRY(hipMemcpy(rp64.data(), d_row_ptr, sizeof(int64_t) * ((size_t)nv + 1), hipMemcpyDeviceToHost));
   gm_graph *g = new gm_graph();
   g->device = device;
   g->nv = nv;
   g->ne = ne;
   g->own_col = false;
   g->d_col = const_cast<int *>(d_col_idx);
-  rc = convert_offsets(rp64.data(), nv, ne, g->h_rp);
-  if (rc) { delete g; return rc; }
   auto fail = [&](int code) { gm_graph_free(g); return code; };
-  hipError_t e;
-  if ((e = hipMalloc(&g->d_rp, sizeof(int) * ((size_t)nv + 1))) != hipSuccess) return fail(hip_fail(e, "hipMalloc(rp)", __FILE__, __LINE__));
-  if ((e = hipMemcpy(g->d_rp, g->h_rp.data(), sizeof(int) * ((size_t)nv + 1), hipMemcpyHostToDevice)) != hipSuccess) return fail(hip_fail(e, "hipMemcpy(rp)", __FILE__, __LINE__));
+  rc = adopt_offsets(g, d_row_ptr);
+  if (rc) return fail(rc);
   rc = finish_handle(g);
   if (rc) return fail(rc);
   *out = g;
@@ -383,8 +469,12 @@ extern "C" int gm_graph_meta(const gm_graph *g, gm_csr *m) {
 
 extern "C" int gm_graph_download(const gm_graph *g, int64_t *row_ptr, int32_t *col_idx) {
   if (!g) return GM_ERR_INVALID;
-  if (row_ptr)
-    for (int v = 0; v <= g->nv; ++v) row_ptr[v] = g->h_rp[v];
+  if (row_ptr) {
+    const std::vector<int> *rp = nullptr;
+    int rc = host_rp(const_cast<gm_graph *>(g), &rp);
+    if (rc) return rc;
+    for (int v = 0; v <= g->nv; ++v) row_ptr[v] = (*rp)[(size_t)v];
+  }
   if (col_idx && g->ne > 0) {
     HIP_TRY(hipSetDevice(g->device));
     HIP_TRY(hipMemcpy(col_idx, g->d_col, sizeof(int) * (size_t)g->ne, hipMemcpyDeviceToHost));
@@ -441,9 +531,9 @@ __global__ __launch_bounds__(256) void orient_short_kernel(int nv, const int *__
   }
 }
 
-// one wave per segment
+// one wave per segment; pass 0 adds the segment's count to its row's new degree (and keeps it per segment for the offsets)
 __global__ __launch_bounds__(256) void orient_seg_kernel(int nseg, const OrientSeg *__restrict__ segs, const int *__restrict__ rp,
-                                                         const int *__restrict__ col, int *__restrict__ seg_count,
+                                                         const int *__restrict__ col, int *__restrict__ seg_count, int *__restrict__ new_deg,
                                                          int *__restrict__ new_col, int pass) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -464,8 +554,52 @@ __global__ __launch_bounds__(256) void orient_seg_kernel(int nseg, const OrientS
       if (pass && keep) new_col[q.out + n + rank_below(m)] = d;
       n += __popcll(m);
     }
-    if (!pass && lane == 0) seg_count[sg] = n;
+    if (!pass && lane == 0) {
+      seg_count[sg] = n;
+      if (n) atomicAdd(&new_deg[q.row], n);
+    }
   }
+}
+
+// segment table of the long rows, built on the device: seg_first[v] = exclusive scan of ceil(d/kOrientSeg) over the long rows
+__global__ __launch_bounds__(256) void orient_segcount_kernel(int nv, const int *__restrict__ rp, int *__restrict__ nseg_of) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v > nv) return;
+  int n = 0;
+  if (v < nv) {
+    const int d = rp[v + 1] - rp[v];
+    n = d > kOrientShort ? (d + kOrientSeg - 1) / kOrientSeg : 0;
+  }
+  nseg_of[v] = n;  // (nseg_of[nv] = 0: the scan's last element is the total)
+}
+__global__ __launch_bounds__(256) void orient_segfill_kernel(int nv, const int *__restrict__ rp, const int *__restrict__ seg_first,
+                                                             OrientSeg *__restrict__ segs) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nv) return;
+  const int b = rp[v], e = rp[v + 1];
+  if (e - b <= kOrientShort) return;
+  int k = seg_first[v];
+  for (int s0 = b; s0 < e; s0 += kOrientSeg) segs[k++] = {v, s0, min(s0 + kOrientSeg, e), 0};
+}
+// output offset of every segment: the row's new offset + the kept entries of the row's earlier segments (one thread per long row)
+__global__ __launch_bounds__(256) void orient_segout_kernel(int nv, const int *__restrict__ rp, const int *__restrict__ seg_first,
+                                                            const int *__restrict__ seg_count, const int *__restrict__ new_rp,
+                                                            OrientSeg *__restrict__ segs) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nv) return;
+  if (rp[v + 1] - rp[v] <= kOrientShort) return;
+  int run = new_rp[v];
+  for (int k = seg_first[v]; k < seg_first[v + 1]; ++k) {
+    segs[k].out = run;
+    run += seg_count[k];
+  }
+}
+__global__ __launch_bounds__(256) void max_degree_kernel(int nv, const int *__restrict__ rp, int *__restrict__ out) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  int md = 0;
+  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += stride) md = max(md, rp[v + 1] - rp[v]);
+  md = gm::wave_max_nonneg(md);
+  if ((threadIdx.x & 63) == 0 && md) atomicMax(out, md);
 }
 
 extern "C" int gm_graph_orient(const gm_graph *sym, gm_graph **out) {
@@ -474,60 +608,52 @@ extern "C" int gm_graph_orient(const gm_graph *sym, gm_graph **out) {
   HIP_TRY(hipSetDevice(sym->device));
   SetupTimer timer;
   const int nv = sym->nv;
-  // segment table of the long rows
-  std::vector<OrientSeg> segs;
-  for (int v = 0; v < nv; ++v) {
-    const int b = sym->h_rp[v], e = sym->h_rp[v + 1];
-    if (e - b > kOrientShort)
-      for (int s = b; s < e; s += kOrientSeg) segs.push_back({v, s, std::min(s + kOrientSeg, e), 0});
-  }
-  const int nseg = (int)segs.size();
-  int *d_deg = nullptr, *d_segcnt = nullptr;
-  OrientSeg *d_segs = nullptr;
-  HIP_TRY(hipMalloc(&d_deg, sizeof(int) * (size_t)std::max(nv, 1)));
-  HIP_TRY(hipMemset(d_deg, 0, sizeof(int) * (size_t)std::max(nv, 1)));
-  HIP_TRY(hipMalloc(&d_segcnt, sizeof(int) * (size_t)std::max(nseg, 1)));
-  HIP_TRY(hipMalloc(&d_segs, sizeof(OrientSeg) * (size_t)std::max(nseg, 1)));
-  if (nseg) HIP_TRY(hipMemcpy(d_segs, segs.data(), sizeof(OrientSeg) * (size_t)nseg, hipMemcpyHostToDevice));
+  const unsigned vb = (unsigned)((nv + 256) / 256);  // blocks covering v = 0 .. nv
+  ScanTemp tmp;
+  // segment table of the long rows (device): counts -> exclusive scan -> fill
+  DevBuf<int> nseg_of, seg_first, deg, segcnt;
+  DevBuf<OrientSeg> segs;
+  HIP_TRY(nseg_of.alloc((size_t)nv + 1));
+  HIP_TRY(seg_first.alloc((size_t)nv + 1));
+  hipLaunchKernelGGL(orient_segcount_kernel, dim3(vb), dim3(256), 0, 0, nv, sym->d_rp, nseg_of.p);
+  HIP_TRY(dev_exclusive_sum(tmp, nseg_of.p, seg_first.p, (size_t)nv + 1));
+  int nseg = 0;
+  HIP_TRY(hipMemcpy(&nseg, seg_first.p + nv, sizeof(int), hipMemcpyDeviceToHost));
+  HIP_TRY(segs.alloc((size_t)nseg));
+  HIP_TRY(segcnt.alloc((size_t)nseg));
+  if (nseg) hipLaunchKernelGGL(orient_segfill_kernel, dim3(vb), dim3(256), 0, 0, nv, sym->d_rp, seg_first.p, segs.p);
+  // pass 0: new degrees (short rows write, segments of long rows add)
+  HIP_TRY(deg.alloc((size_t)nv + 1));
+  HIP_TRY(hipMemsetAsync(deg.p, 0, sizeof(int) * ((size_t)nv + 1), 0));
   const int bs = std::max(1, std::min((nv + 31) / 32, sym->cu_count * 8));
   const int bl = std::max(1, std::min((nseg + 3) / 4, sym->cu_count * 8));
-  hipLaunchKernelGGL(orient_short_kernel, dim3(bs), dim3(256), 0, 0, nv, sym->d_rp, sym->d_col, d_deg, (const int *)nullptr,
-                     (int *)nullptr, 0);
+  hipLaunchKernelGGL(orient_short_kernel, dim3(bs), dim3(256), 0, 0, nv, sym->d_rp, sym->d_col, deg.p, (const int *)nullptr, (int *)nullptr, 0);
   if (nseg)
-    hipLaunchKernelGGL(orient_seg_kernel, dim3(bl), dim3(256), 0, 0, nseg, d_segs, sym->d_rp, sym->d_col, d_segcnt, (int *)nullptr, 0);
-  std::vector<int> deg((size_t)std::max(nv, 1)), segcnt((size_t)std::max(nseg, 1));
-  hipError_t e = hipMemcpy(deg.data(), d_deg, sizeof(int) * (size_t)nv, hipMemcpyDeviceToHost);
-  if (e == hipSuccess && nseg) e = hipMemcpy(segcnt.data(), d_segcnt, sizeof(int) * (size_t)nseg, hipMemcpyDeviceToHost);
-  (void)hipFree(d_deg);
-  (void)hipFree(d_segcnt);
-  if (e != hipSuccess) { (void)hipFree(d_segs); return hip_fail(e, "hipMemcpy(deg)", __FILE__, __LINE__); }
-  for (int i = 0; i < nseg; ++i) deg[segs[i].row] += segcnt[i];
+    hipLaunchKernelGGL(orient_seg_kernel, dim3(bl), dim3(256), 0, 0, nseg, segs.p, sym->d_rp, sym->d_col, segcnt.p, deg.p, (int *)nullptr, 0);
+  // new offsets = exclusive scan of the new degrees (parallel_prefix_sum, include/scan.h:5-35)
   gm_graph *g = new gm_graph();
   g->device = sym->device;
   g->nv = nv;
-  g->h_rp.resize((size_t)nv + 1);
-  long long acc = 0;
-  for (int v = 0; v < nv; ++v) {  // parallel_prefix_sum, include/scan.h:5-35
-    g->h_rp[v] = (int)acc;
-    acc += deg[v];
-  }
-  g->h_rp[nv] = (int)acc;
-  g->ne = acc;
-  for (int i = 0, run = 0; i < nseg; ++i) {  // output offset of every segment inside its row
-    if (i == 0 || segs[i].row != segs[i - 1].row) run = 0;
-    segs[i].out = g->h_rp[segs[i].row] + run;
-    run += segcnt[i];
-  }
-  auto fail = [&](int code) { (void)hipFree(d_segs); gm_graph_free(g); return code; };
-  if (nseg && (e = hipMemcpy(d_segs, segs.data(), sizeof(OrientSeg) * (size_t)nseg, hipMemcpyHostToDevice)) != hipSuccess) return fail(hip_fail(e, "hipMemcpy", __FILE__, __LINE__));
+  auto fail = [&](int code) { gm_graph_free(g); return code; };
+  hipError_t e;
   if ((e = hipMalloc(&g->d_rp, sizeof(int) * ((size_t)nv + 1))) != hipSuccess) return fail(hip_fail(e, "hipMalloc", __FILE__, __LINE__));
-  if ((e = hipMalloc(&g->d_col, sizeof(int) * (size_t)std::max<long long>(acc, 1))) != hipSuccess) return fail(hip_fail(e, "hipMalloc", __FILE__, __LINE__));
-  if ((e = hipMemcpy(g->d_rp, g->h_rp.data(), sizeof(int) * ((size_t)nv + 1), hipMemcpyHostToDevice)) != hipSuccess) return fail(hip_fail(e, "hipMemcpy", __FILE__, __LINE__));
+  if ((e = dev_exclusive_sum(tmp, deg.p, g->d_rp, (size_t)nv + 1)) != hipSuccess) return fail(hip_fail(e, "ExclusiveSum", __FILE__, __LINE__));
+  DevBuf<int> md;
+  if ((e = md.alloc(1)) != hipSuccess) return fail(hip_fail(e, "hipMalloc", __FILE__, __LINE__));
+  (void)hipMemsetAsync(md.p, 0, sizeof(int), 0);
+  hipLaunchKernelGGL(max_degree_kernel, dim3((unsigned)std::min<long long>(((long long)nv + 255) / 256, 2048)), dim3(256), 0, 0, nv, g->d_rp, md.p);
+  int ne_new = 0, max_deg = 0;
+  if ((e = hipMemcpy(&ne_new, g->d_rp + nv, sizeof(int), hipMemcpyDeviceToHost)) != hipSuccess) return fail(hip_fail(e, "hipMemcpy", __FILE__, __LINE__));
+  if ((e = hipMemcpy(&max_deg, md.p, sizeof(int), hipMemcpyDeviceToHost)) != hipSuccess) return fail(hip_fail(e, "hipMemcpy", __FILE__, __LINE__));
+  g->ne = ne_new;
+  g->max_deg = max_deg;
+  if ((e = hipMalloc(&g->d_col, sizeof(int) * (size_t)std::max(ne_new, 1))) != hipSuccess) return fail(hip_fail(e, "hipMalloc", __FILE__, __LINE__));
+  // pass 1: compact
+  if (nseg) hipLaunchKernelGGL(orient_segout_kernel, dim3(vb), dim3(256), 0, 0, nv, sym->d_rp, seg_first.p, segcnt.p, g->d_rp, segs.p);
   hipLaunchKernelGGL(orient_short_kernel, dim3(bs), dim3(256), 0, 0, nv, sym->d_rp, sym->d_col, (int *)nullptr, g->d_rp, g->d_col, 1);
   if (nseg)
-    hipLaunchKernelGGL(orient_seg_kernel, dim3(bl), dim3(256), 0, 0, nseg, d_segs, sym->d_rp, sym->d_col, (int *)nullptr, g->d_col, 1);
+    hipLaunchKernelGGL(orient_seg_kernel, dim3(bl), dim3(256), 0, 0, nseg, segs.p, sym->d_rp, sym->d_col, (int *)nullptr, (int *)nullptr, g->d_col, 1);
   if ((e = hipDeviceSynchronize()) != hipSuccess) return fail(hip_fail(e, "orient kernels", __FILE__, __LINE__));
-  (void)hipFree(d_segs);
   int rc = finish_handle(g);
   if (rc) { gm_graph_free(g); return rc; }
   g->setup.orient_ms = timer.ms();
@@ -567,6 +693,10 @@ static int get_relabeled(gm_graph *g, int descending, gm_graph **out) {
   }
   HIP_TRY(hipSetDevice(g->device));
   SetupTimer timer;
+  {
+    int rc = host_rp(g, nullptr);
+    if (rc) return rc;
+  }
   const int nv = g->nv;
   const long long ne = g->ne;
   // counting sort by degree (ties: ascending id)
@@ -621,6 +751,7 @@ static int get_relabeled(gm_graph *g, int descending, gm_graph **out) {
   cleanup();
   int rc = finish_handle(r);
   if (rc) { gm_graph_free(r); return rc; }
+  r->max_deg = g->max_deg;  // (a permutation of the same rows)
   std::lock_guard<std::mutex> lk(g->mu);
   g->relabel_cache[descending] = r;
   g->setup.relabel_ms += timer.ms();
@@ -631,50 +762,70 @@ static int get_relabeled(gm_graph *g, int descending, gm_graph **out) {
 // ------------------------------------------------------------------------------------------------
 // task chunk tables
 // ------------------------------------------------------------------------------------------------
-static void build_chunks(const std::vector<int> &rp, int nv, int target, bool allow_split, int bit_words, int stage_cap,
-                         std::vector<ChunkRec> &out, unsigned long long &max_bit_words, const RowFilter &rf = RowFilter()) {
-  out.clear();
-  max_bit_words = 0;
-  int u = 0;
-  auto deg = [&](int v) { return rp[v + 1] - rp[v]; };
-  while (u < nv) {
-    const int d = deg(u);
+// The greedy chunk walk over the vertices [v0, v1): a contiguous run of whole rows is closed when it reaches `target` entries,
+// would exceed the LDS stage (or, k-clique, the bit-matrix budget), spans kMaxChunkVerts rows, or meets a row that is left out /
+// too long for the stage; rows longer than the stage are SPLIT into `target`-entry chunks (allow_split) or chunks of their
+// own. Runs on the host (gm_chunk_table, GM_HOST_TABLES) and, one thread per block of kTableBlock vertices, on the device:
+// the walk restarts at every block boundary, so a table is the same whichever side built it.
+constexpr int kTableBlock = 2048;
+struct ChunkWalk {
+  int target, allow_split, bit_words, stage_cap;
+  RowFilter rf;
+};
+template <class Emit>
+__host__ __device__ inline unsigned long long walk_chunks(const ChunkWalk &w, const int *rp, int v0, int v1, Emit emit) {
+  unsigned long long max_bit_words = 0;
+  int u = v0;
+  while (u < v1) {
+    const int d = rp[u + 1] - rp[u];
     if (d == 0) { ++u; continue; }
-    if (rf.skips(d)) { ++u; continue; }
-    if (d > stage_cap) {
-      if (allow_split) {
-        for (int s = rp[u]; s < rp[u + 1]; s += target) out.push_back({u, u + 1, s, std::min(s + target, rp[u + 1]), 0, 1, GM_WAVE, 0});
+    if (w.rf.skips(d)) { ++u; continue; }
+    if (d > w.stage_cap) {
+      if (w.allow_split) {
+        for (int s0 = rp[u]; s0 < rp[u + 1]; s0 += w.target) emit(ChunkRec{u, u + 1, s0, min(s0 + w.target, rp[u + 1]), 0, 1, GM_WAVE, 0});
       } else {
-        out.push_back({u, u + 1, rp[u], rp[u + 1], 0, 1, GM_WAVE, 0});
-        if (bit_words) max_bit_words = std::max(max_bit_words, (unsigned long long)d * (unsigned long long)((d + 31) / 32));
+        emit(ChunkRec{u, u + 1, rp[u], rp[u + 1], 0, 1, GM_WAVE, 0});
+        if (w.bit_words) max_bit_words = max(max_bit_words, (unsigned long long)d * (unsigned long long)((d + 31) / 32));
       }
       ++u;
       continue;
     }
     const int start = u;
     int edges = 0, maxd = 0;
-    while (u < nv && (u - start) < kMaxChunkVerts) {
-      const int du = deg(u);
-      if (du > stage_cap) break;
-      if (rf.skips(du)) break;
-      if (edges > 0 && edges + du > stage_cap) break;
-      if (bit_words && edges > 0) {
-        const int nm = std::max(maxd, du);
-        if ((long long)(edges + du) * ((nm + 31) / 32) > bit_words) break;
+    while (u < v1 && (u - start) < kMaxChunkVerts) {
+      const int du = rp[u + 1] - rp[u];
+      if (du > w.stage_cap) break;
+      if (w.rf.skips(du) && du > 0) break;
+      if (edges > 0 && edges + du > w.stage_cap) break;
+      if (w.bit_words && edges > 0) {
+        const int nm = max(maxd, du);
+        if ((long long)(edges + du) * ((nm + 31) / 32) > w.bit_words) break;
       }
       edges += du;
-      maxd = std::max(maxd, du);
+      maxd = max(maxd, du);
       ++u;
-      if (edges >= target) break;
+      if (edges >= w.target) break;
     }
     if (edges > 0) {
-      out.push_back({start, u, rp[start], rp[u], 0, 1, GM_WAVE, 0});
-      if (bit_words) {
-        const unsigned long long w = (unsigned long long)edges * (unsigned long long)((maxd + 31) / 32);
-        if (w > (unsigned long long)bit_words) max_bit_words = std::max(max_bit_words, w);
+      emit(ChunkRec{start, u, rp[start], rp[u], 0, 1, GM_WAVE, 0});
+      if (w.bit_words) {
+        const unsigned long long bw = (unsigned long long)edges * (unsigned long long)((maxd + 31) / 32);
+        if (bw > (unsigned long long)w.bit_words) max_bit_words = max(max_bit_words, bw);
       }
+    } else if (u == start) {
+      ++u;  // (cannot happen: the row at `start` fits the stage and is not filtered)
     }
   }
+  return max_bit_words;
+}
+
+static void build_chunks(const std::vector<int> &rp, int nv, int target, bool allow_split, int bit_words, int stage_cap,
+                         std::vector<ChunkRec> &out, unsigned long long &max_bit_words, const RowFilter &rf = RowFilter()) {
+  out.clear();
+  max_bit_words = 0;
+  ChunkWalk w{target, allow_split ? 1 : 0, bit_words, stage_cap, rf};
+  for (int v0 = 0; v0 < nv; v0 += kTableBlock)
+    max_bit_words = std::max(max_bit_words, walk_chunks(w, rp.data(), v0, std::min(v0 + kTableBlock, nv), [&](const ChunkRec &r) { out.push_back(r); }));
 }
 
 // one workgroup per hub row: set bit x for every neighbour x of the row
@@ -733,6 +884,271 @@ static int batch_edges(const ChunkRec &r, const std::vector<int> &rp, int stage_
   return ((stage_cap == kStageCapWide && !whole && long_lists) || (stage_cap > kStageCapWide && long_lists)) ? kSplitBatch : GM_WAVE;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Task-chunk table, built on the device. The reference builds its COO task list with a serial host loop
+// (Graph::init_edgelist, src/common/graph.cc:297-326) and round 1 of this library walked the vertices on the host too
+// (~100 ms per table at nv = 2^24, three tables for a symmetric-graph pattern). Here:
+//   greedy walk, one thread per block of kTableBlock vertices (count -> exclusive scan -> emit)  ->  cost kernel  ->
+//   parts (scan + expand)  ->  dequeue orders (stable radix sorts)  ->  hub-row bitmaps (select + scatter)
+// What stays on the host is O(chunks) or O(hub rows): the per-chunk edge prefix, the dequeue orders' host copies.
+// (A fully parallel chunk definition -- short rows grouped by floor(prefix / G) -- was tried first: its groups cannot fill
+// the stage as tightly as the greedy walk, the chunks of a flat graph shrank from ~1024 to ~683 entries and TC on the
+// LiveJournal-size flat graph went from 0.873 to 1.145 ms; profiles/r02/ab_setup_device_tables.log.)
+// ------------------------------------------------------------------------------------------------
+// pass 0: chunks per vertex block (+ the k-clique arena requirement); pass 1: the records, at the block's offset.
+// A workgroup (one wave) owns kWalkPerWG blocks: all 64 lanes copy the blocks' offsets into LDS with coalesced loads (128 KB of
+// the CU's 160 KB), then lanes 0 .. kWalkPerWG-1 each walk one block out of LDS -- the walk is a serial chain of dependent
+// reads, ~30 cycles per vertex from LDS against a memory round trip per cache line from HBM (one thread per block straight
+// from memory: 132 ms for the three 3-motif tables of R-MAT-24; this form: see profiles/r02/ab_setup_device_tables.log).
+constexpr int kWalkPerWG = 16;
+__global__ __launch_bounds__(64) void tab_walk_kernel(ChunkWalk w, int nv, const int *__restrict__ rp, int nblocks, int *__restrict__ count,
+                                                      unsigned long long *__restrict__ max_bw, const int *__restrict__ offset, ChunkRec *__restrict__ recs) {
+  __shared__ int rpl[kWalkPerWG][kTableBlock + 1];  // (row stride 2049 words: the walkers' lanes fall into different banks)
+  const int b0 = blockIdx.x * kWalkPerWG;
+  for (int k = 0; k < kWalkPerWG; ++k) {
+    const int v0 = (b0 + k) * kTableBlock;
+    if (v0 >= nv) break;
+    const int n = min(kTableBlock, nv - v0) + 1;
+    for (int i = threadIdx.x; i < n; i += 64) rpl[k][i] = rp[v0 + i];
+  }
+  __syncthreads();
+  const int k = threadIdx.x, b = b0 + k;
+  if (k >= kWalkPerWG || b > nblocks) return;
+  if (b == nblocks) { if (!recs) count[b] = 0; return; }
+  const int v0 = b * kTableBlock, v1 = min(v0 + kTableBlock, nv);
+  const int *lrp = &rpl[k][0] - v0;  // indexed by the absolute vertex id
+  if (!recs) {
+    int n = 0;
+    const unsigned long long bw = walk_chunks(w, lrp, v0, v1, [&](const ChunkRec &) { ++n; });
+    count[b] = n;
+    if (bw) atomicMax(max_bw, bw);
+  } else {
+    int o = offset[b];
+    walk_chunks(w, lrp, v0, v1, [&](const ChunkRec &r) { recs[o++] = r; });
+  }
+}
+struct TableDevParams {
+  int nv;
+  RowFilter rf;
+};
+__device__ __forceinline__ bool rf_skips(const RowFilter &rf, int d) { return rf.skips(d); }
+// parts and batch sizes per chunk (batch_edges + the part rule of the host path)
+__global__ __launch_bounds__(256) void tab_parts_kernel(int n0, const ChunkRec *__restrict__ recs, const int *__restrict__ rp,
+                                                        const unsigned long long *__restrict__ cost, int stage_cap, unsigned long long cap,
+                                                        int cut, int *__restrict__ np_out, int *__restrict__ bsz_out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > n0) return;
+  if (c == n0) { np_out[c] = 0; return; }
+  const ChunkRec r = recs[c];
+  const bool whole = r.e_begin == rp[r.u_begin] && r.e_end == rp[r.u_end];
+  const unsigned long long nel = (unsigned long long)max(r.e_end - r.e_begin, 1);
+  const bool long_lists = cost[c] / nel >= (unsigned long long)kSplitBatchMinKeys;
+  const int bsz = ((stage_cap == kStageCapWide && !whole && long_lists) || (stage_cap > kStageCapWide && long_lists)) ? kSplitBatch : GM_WAVE;
+  int np = 1;
+  if (cut) {
+    const int batches = (r.e_end - r.e_begin + bsz - 1) / bsz;
+    const int min_batches = stage_cap == kStageCapBig ? 64 : (stage_cap == kStageCapMid ? 16 : 1);
+    const unsigned long long want = (cost[c] + cap - 1) / cap;
+    np = (int)max(1ull, min((unsigned long long)max(batches / min_batches, 1), want));
+  }
+  np_out[c] = np;
+  bsz_out[c] = bsz;
+}
+__global__ __launch_bounds__(256) void tab_expand_kernel(int n0, const ChunkRec *__restrict__ recs, const unsigned long long *__restrict__ cost,
+                                                         const int *__restrict__ np_in, const int *__restrict__ bsz_in, const int *__restrict__ off,
+                                                         ChunkRec *__restrict__ out, unsigned long long *__restrict__ cost_out,
+                                                         int *__restrict__ edges_out, int *__restrict__ first_vertex) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n0) return;
+  ChunkRec r = recs[c];
+  const int np = np_in[c], bsz = bsz_in[c], nel = r.e_end - r.e_begin;
+  r.nparts = np;
+  r.batch = bsz;
+  for (int qd = 0; qd < np; ++qd) {
+    r.part = qd;
+    int mine = 0;  // task edges of a part = the entries of its batches
+    for (int b = qd; b * bsz < nel; b += np) mine += min(bsz, nel - b * bsz);
+    const int o = off[c] + qd;
+    out[o] = r;
+    cost_out[o] = cost[c] / (unsigned long long)np;
+    edges_out[o] = mine;
+    first_vertex[o] = r.u_begin;
+  }
+}
+__global__ __launch_bounds__(256) void tab_orderkeys_kernel(int n, const unsigned long long *__restrict__ cost, unsigned long long heavy, int classes_only,
+                                                            unsigned long long *__restrict__ key0, unsigned long long *__restrict__ key1, int *__restrict__ iota) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  const unsigned long long x = cost[c];
+  key0[c] = x >= heavy ? (classes_only ? 1ull : x) : 0ull;
+  key1[c] = x;
+  iota[c] = c;
+}
+__global__ __launch_bounds__(256) void tab_hubflag_kernel(TableDevParams q, int bitmap_min_deg, const int *__restrict__ rp, int *__restrict__ flag, int *__restrict__ iota) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= q.nv) return;
+  const int d = rp[v + 1] - rp[v];
+  flag[v] = (d > bitmap_min_deg && !rf_skips(q.rf, d)) ? 1 : 0;
+  iota[v] = v;
+}
+__global__ __launch_bounds__(256) void tab_rowslot_kernel(int nb, const int *__restrict__ rows, int *__restrict__ row_slot) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nb) row_slot[rows[i]] = i;
+}
+__global__ __launch_bounds__(256) void tab_chunkslot_kernel(int n, const ChunkRec *__restrict__ recs, const int *__restrict__ rp, int stage_cap,
+                                                            const int *__restrict__ row_slot, int *__restrict__ slots) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  const ChunkRec r = recs[c];
+  slots[c] = (r.u_end == r.u_begin + 1 && rp[r.u_begin + 1] - rp[r.u_begin] > stage_cap) ? row_slot[r.u_begin] : -1;
+}
+__global__ __launch_bounds__(256) void gather_deg_kernel(int m, const int *__restrict__ verts, const int *__restrict__ rp, int *__restrict__ deg) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) deg[i] = rp[verts[i] + 1] - rp[verts[i]];
+}
+
+static int build_table_device(gm_graph *g, ChunkTable &t, bool sym_table, double &bitmap_ms) {
+  const int nv = g->nv;
+  TableDevParams q;
+  q.nv = nv;
+  q.rf = t.rf;
+  ScanTemp tmp;
+  auto blocks = [](long long n) { return dim3((unsigned)std::max<long long>(1, (n + 255) / 256)); };
+  // the greedy walk, one thread per block of kTableBlock vertices: count, scan, emit
+  ChunkWalk w{t.target, t.allow_split ? 1 : 0, t.bit_words, t.stage_cap, t.rf};
+  const int nblk = (nv + kTableBlock - 1) / kTableBlock;
+  DevBuf<int> bcount, boff;
+  DevBuf<unsigned long long> maxbw;
+  HIP_TRY(bcount.alloc((size_t)nblk + 1));
+  HIP_TRY(boff.alloc((size_t)nblk + 1));
+  HIP_TRY(maxbw.alloc(1));
+  HIP_TRY(hipMemsetAsync(maxbw.p, 0, 8, 0));
+  const dim3 wgrid((unsigned)((nblk + 1 + kWalkPerWG - 1) / kWalkPerWG));
+  hipLaunchKernelGGL(tab_walk_kernel, wgrid, dim3(64), 0, 0, w, nv, g->d_rp, nblk, bcount.p, maxbw.p, (const int *)nullptr, (ChunkRec *)nullptr);
+  HIP_TRY(dev_exclusive_sum(tmp, bcount.p, boff.p, (size_t)nblk + 1));
+  int n0 = 0;
+  HIP_TRY(hipMemcpy(&n0, boff.p + nblk, sizeof(int), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(&t.max_bit_words, maxbw.p, 8, hipMemcpyDeviceToHost));
+  t.n = 0;
+  HIP_TRY(hipMalloc(&t.d, sizeof(ChunkRec)));  // (placeholder, replaced below when the table has chunks)
+  if (n0 == 0) {
+    t.edge_prefix.assign(1, 0ull);
+    return GM_OK;
+  }
+  DevBuf<ChunkRec> recs0;
+  HIP_TRY(recs0.alloc((size_t)n0));
+  hipLaunchKernelGGL(tab_walk_kernel, wgrid, dim3(64), 0, 0, w, nv, g->d_rp, nblk, bcount.p, maxbw.p, (const int *)boff.p, recs0.p);
+  // estimated work per chunk, parts
+  DevBuf<unsigned long long> cost0;
+  HIP_TRY(cost0.alloc((size_t)n0));
+  HIP_TRY(hipMemsetAsync(cost0.p, 0, sizeof(unsigned long long) * (size_t)n0, 0));
+  hipLaunchKernelGGL(chunk_cost_kernel, dim3((unsigned)n0), dim3(256), 0, 0, g->d_rp, g->d_col, recs0.p, cost0.p, sym_table ? 1 : 0, kStageCapWide);
+  DevBuf<int> np, bsz, off;
+  HIP_TRY(np.alloc((size_t)n0 + 1));
+  HIP_TRY(bsz.alloc((size_t)n0 + 1));
+  HIP_TRY(off.alloc((size_t)n0 + 1));
+  hipLaunchKernelGGL(tab_parts_kernel, blocks(n0 + 1), dim3(256), 0, 0, n0, recs0.p, g->d_rp, cost0.p, t.stage_cap,
+                     std::max<unsigned long long>(t.part_cap, 1), (t.allow_split || sym_table) ? 1 : 0, np.p, bsz.p);
+  HIP_TRY(dev_exclusive_sum(tmp, np.p, off.p, (size_t)n0 + 1));
+  int n = 0;
+  HIP_TRY(hipMemcpy(&n, off.p + n0, sizeof(int), hipMemcpyDeviceToHost));
+  (void)hipFree(t.d);
+  t.d = nullptr;
+  HIP_TRY(hipMalloc(&t.d, sizeof(ChunkRec) * (size_t)n));
+  DevBuf<unsigned long long> cost;
+  DevBuf<int> edges, firstv;
+  HIP_TRY(cost.alloc((size_t)n));
+  HIP_TRY(edges.alloc((size_t)n));
+  HIP_TRY(firstv.alloc((size_t)n));
+  hipLaunchKernelGGL(tab_expand_kernel, blocks(n0), dim3(256), 0, 0, n0, recs0.p, cost0.p, np.p, bsz.p, off.p, t.d, cost.p, edges.p, firstv.p);
+  t.n = (size_t)n;
+  // host views of the per-chunk scalars (O(chunks), not O(vertices)): edges -> prefix, first vertex, cost
+  {
+    std::vector<int> h_edges((size_t)n);
+    t.first_vertex.resize((size_t)n);
+    t.cost.resize((size_t)n);
+    HIP_TRY(hipMemcpy(h_edges.data(), edges.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(t.first_vertex.data(), firstv.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(t.cost.data(), cost.p, sizeof(unsigned long long) * (size_t)n, hipMemcpyDeviceToHost));
+    t.edge_prefix.resize((size_t)n + 1);
+    t.edge_prefix[0] = 0;
+    for (size_t i = 0; i < (size_t)n; ++i) t.edge_prefix[i + 1] = t.edge_prefix[i] + (unsigned long long)h_edges[i];
+  }
+  // dequeue orders: stable descending radix sorts of (key, chunk id)
+  {
+    unsigned long long total_cost = 0;
+    for (auto c : t.cost) total_cost += c;
+    const unsigned long long heavy = 2ull * (total_cost / (unsigned long long)n) + 1ull;
+    DevBuf<unsigned long long> key0, key1, keyo;
+    DevBuf<int> iota;
+    HIP_TRY(key0.alloc((size_t)n));
+    HIP_TRY(key1.alloc((size_t)n));
+    HIP_TRY(keyo.alloc((size_t)n));
+    HIP_TRY(iota.alloc((size_t)n));
+    hipLaunchKernelGGL(tab_orderkeys_kernel, blocks(n), dim3(256), 0, 0, n, cost.p, heavy, sym_table ? 1 : 0, key0.p, key1.p, iota.p);
+    for (int m = 0; m < 2; ++m) {
+      HIP_TRY(hipMalloc(&t.d_order[m], sizeof(int) * (size_t)n));
+      size_t bytes = 0;
+      const unsigned long long *keys = m == 0 ? key0.p : key1.p;
+      HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, bytes, keys, keyo.p, iota.p, t.d_order[m], n));
+      HIP_TRY(tmp.reserve(bytes));
+      HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(tmp.buf.p, bytes, keys, keyo.p, iota.p, t.d_order[m], n));
+      t.order[m].resize((size_t)n);
+      HIP_TRY(hipMemcpy(t.order[m].data(), t.d_order[m], sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+    }
+  }
+  if (t.allow_split) {
+    SetupTimer bm_timer;
+    // Hub rows (longer than the LDS stage, cut into SPLIT chunks) get a dense bitmap over the vertex ids, the longest rows
+    // first, within a memory budget: one probe then replaces a ~17-step bisection in HBM.
+    const unsigned long long words = ((unsigned long long)nv + 31ull) / 32ull;
+    DevBuf<int> flag, iota, sel, nsel;
+    HIP_TRY(flag.alloc((size_t)nv));
+    HIP_TRY(iota.alloc((size_t)nv));
+    HIP_TRY(sel.alloc((size_t)nv));
+    HIP_TRY(nsel.alloc(1));
+    hipLaunchKernelGGL(tab_hubflag_kernel, blocks(nv), dim3(256), 0, 0, q, t.bitmap_min_deg, g->d_rp, flag.p, iota.p);
+    size_t bytes = 0;
+    HIP_TRY(hipcub::DeviceSelect::Flagged(nullptr, bytes, iota.p, flag.p, sel.p, nsel.p, nv));
+    HIP_TRY(tmp.reserve(bytes));
+    HIP_TRY(hipcub::DeviceSelect::Flagged(tmp.buf.p, bytes, iota.p, flag.p, sel.p, nsel.p, nv));
+    int m = 0;
+    HIP_TRY(hipMemcpy(&m, nsel.p, sizeof(int), hipMemcpyDeviceToHost));
+    const size_t nb_max = words ? (size_t)(kBitmapBudget / (words * 4ull)) : 0;
+    if (m > 0 && nb_max > 0) {
+      DevBuf<int> degs;
+      HIP_TRY(degs.alloc((size_t)m));
+      hipLaunchKernelGGL(gather_deg_kernel, blocks(m), dim3(256), 0, 0, m, sel.p, g->d_rp, degs.p);
+      std::vector<int> hv((size_t)m), hd((size_t)m);
+      HIP_TRY(hipMemcpy(hv.data(), sel.p, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(hd.data(), degs.p, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost));
+      std::vector<int> idx((size_t)m);  // (hub rows only: thousands at most)
+      for (int i = 0; i < m; ++i) idx[(size_t)i] = i;
+      std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return hd[(size_t)a] > hd[(size_t)b]; });
+      const size_t nb = std::min<size_t>((size_t)m, nb_max);
+      std::vector<int> rows(nb);
+      for (size_t i = 0; i < nb; ++i) rows[i] = hv[(size_t)idx[i]];
+      DevBuf<int> d_rows;
+      HIP_TRY(d_rows.alloc(nb));
+      HIP_TRY(hipMemcpy(d_rows.p, rows.data(), sizeof(int) * nb, hipMemcpyHostToDevice));
+      HIP_TRY(hipMalloc(&t.d_row_slot, sizeof(int) * (size_t)nv));
+      HIP_TRY(hipMemsetAsync(t.d_row_slot, 0xff, sizeof(int) * (size_t)nv, 0));  // -1
+      hipLaunchKernelGGL(tab_rowslot_kernel, blocks((long long)nb), dim3(256), 0, 0, (int)nb, d_rows.p, t.d_row_slot);
+      HIP_TRY(hipMalloc(&t.d_slot, sizeof(int) * (size_t)n));
+      hipLaunchKernelGGL(tab_chunkslot_kernel, blocks(n), dim3(256), 0, 0, n, t.d, g->d_rp, t.stage_cap, t.d_row_slot, t.d_slot);
+      HIP_TRY(hipMalloc(&t.d_bitmaps, (size_t)nb * (size_t)words * 4));
+      HIP_TRY(hipMemsetAsync(t.d_bitmaps, 0, (size_t)nb * (size_t)words * 4, 0));
+      hipLaunchKernelGGL(bitmap_build_kernel, dim3((unsigned)nb), dim3(256), 0, 0, g->d_rp, g->d_col, d_rows.p, t.d_bitmaps, words);
+      HIP_TRY(hipDeviceSynchronize());
+      t.n_bitmaps = nb;
+      t.bitmap_words = words;
+    }
+    bitmap_ms = bm_timer.ms();
+  }
+  HIP_TRY(hipDeviceSynchronize());
+  return GM_OK;
+}
+
 static int get_table(gm_graph *g, int target, bool allow_split, int bit_words, unsigned long long part_cap, int stage_cap,
                      ChunkTable **out, const RowFilter &rf = RowFilter(), int bitmap_min_deg = kBitmapMinDeg) {
   std::lock_guard<std::mutex> lk(g->mu);
@@ -751,6 +1167,26 @@ static int get_table(gm_graph *g, int target, bool allow_split, int bit_words, u
   t.stage_cap = stage_cap;
   t.rf = rf;
   t.bitmap_min_deg = bitmap_min_deg;
+  if (!getenv("GM_HOST_TABLES")) {  // (GM_HOST_TABLES: the same walk in a host loop over the vertices, kept for A/B)
+    HIP_TRY(hipSetDevice(g->device));
+    int rc = build_table_device(g, t, sym_table, bitmap_ms);
+    if (rc) return rc;
+    if (getenv("GM_TABLE_INFO")) {
+      unsigned long long tc = 0, mx = 0;
+      for (auto c : t.cost) { tc += c; mx = std::max(mx, c); }
+      fprintf(stderr, "[table/device] stage_cap %d rows (%d,%d] skip (%d,%d]: %zu chunks, est. keys %.3e (max chunk %.3e), %zu bitmaps, edges %llu, %.2f ms\n",
+              stage_cap, rf.only_lo, rf.only_hi, rf.skip_lo, rf.skip_hi, t.n, (double)tc, (double)mx, t.n_bitmaps, t.edge_prefix.back(), timer.ms());
+    }
+    g->setup.bitmap_ms += bitmap_ms;
+    g->setup.table_ms += timer.ms() - bitmap_ms;
+    g->tables.push_back(std::move(t));
+    *out = &g->tables.back();
+    return GM_OK;
+  }
+  {
+    int rc = host_rp(g, nullptr);
+    if (rc) return rc;
+  }
   build_chunks(g->h_rp, g->nv, target, allow_split, bit_words, stage_cap, recs, t.max_bit_words, rf);
   // estimated work per chunk (device), then: cut the heavy ones into parts, and fix the dequeue orders
   std::vector<unsigned long long> cost(recs.size());
@@ -930,13 +1366,65 @@ static int ensure_edesc(gm_graph *g) {
 #ifndef GM_WIDE_ARENA_MB
 #define GM_WIDE_ARENA_MB 16384
 #endif
+__global__ __launch_bounds__(256) void wide_flag_kernel(int nv, const int *__restrict__ rp, int *__restrict__ flag, int *__restrict__ iota) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nv) return;
+  flag[v] = clique_is_wide(rp[v + 1] - rp[v]) ? 1 : 0;
+  iota[v] = v;
+}
+// this rank's share of the sorted wide list: slot i = entry first + i * step
+__global__ __launch_bounds__(256) void wide_share_kernel(int count, long long first, long long step, const int *__restrict__ wide_sorted,
+                                                         const int *__restrict__ rp, int *__restrict__ verts, int *__restrict__ degs, int *__restrict__ ngroups) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > count) return;
+  if (i == count) { ngroups[i] = 0; return; }
+  const int u = wide_sorted[first + (long long)i * step];
+  const int d = rp[u + 1] - rp[u];
+  verts[i] = u;
+  degs[i] = d;
+  const int R = clique_group_rows(d);
+  ngroups[i] = (d + R - 1) / R;
+}
+__global__ __launch_bounds__(256) void wide_groups_kernel(int count, const int *__restrict__ verts, const int *__restrict__ rp, const int *__restrict__ goff,
+                                                          ChunkRec *__restrict__ chunks) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const int u = verts[i], b = rp[u], d = rp[u + 1] - b, R = clique_group_rows(d);
+  int o = goff[i];
+  for (int g0 = 0; g0 < d; g0 += R) chunks[o++] = {u, u + 1, b + g0, b + min(g0 + R, d), 0, 1, 8, i + 1};
+}
+
 static int get_wide_plan(gm_graph *g, int rank, int world, int policy, WidePlan **out) {
   std::lock_guard<std::mutex> lk(g->mu);
   SetupTimer timer;
-  if (!g->wide_valid) {
-    for (int v = 0; v < g->nv; ++v)
-      if (clique_is_wide(g->h_rp[v + 1] - g->h_rp[v])) g->h_wide.push_back(v);
-    std::stable_sort(g->h_wide.begin(), g->h_wide.end(), [&](int a, int b) { return g->h_rp[a + 1] - g->h_rp[a] > g->h_rp[b + 1] - g->h_rp[b]; });
+  HIP_TRY(hipSetDevice(g->device));
+  ScanTemp tmp;
+  auto blocks = [](long long n) { return dim3((unsigned)std::max<long long>(1, (n + 255) / 256)); };
+  if (!g->wide_valid) {  // once per graph: the wide vertices, longest rows first (select + stable radix sort by row length)
+    const int nv = g->nv;
+    DevBuf<int> flag, iota, sel, nsel, degs, keyo;
+    HIP_TRY(flag.alloc((size_t)nv));
+    HIP_TRY(iota.alloc((size_t)nv));
+    HIP_TRY(sel.alloc((size_t)nv));
+    HIP_TRY(nsel.alloc(1));
+    hipLaunchKernelGGL(wide_flag_kernel, blocks(nv), dim3(256), 0, 0, nv, g->d_rp, flag.p, iota.p);
+    size_t bytes = 0;
+    HIP_TRY(hipcub::DeviceSelect::Flagged(nullptr, bytes, iota.p, flag.p, sel.p, nsel.p, nv));
+    HIP_TRY(tmp.reserve(bytes));
+    HIP_TRY(hipcub::DeviceSelect::Flagged(tmp.buf.p, bytes, iota.p, flag.p, sel.p, nsel.p, nv));
+    int m = 0;
+    HIP_TRY(hipMemcpy(&m, nsel.p, sizeof(int), hipMemcpyDeviceToHost));
+    g->n_wide = (size_t)m;
+    if (m > 0) {
+      HIP_TRY(degs.alloc((size_t)m));
+      HIP_TRY(keyo.alloc((size_t)m));
+      hipLaunchKernelGGL(gather_deg_kernel, blocks(m), dim3(256), 0, 0, m, sel.p, g->d_rp, degs.p);
+      HIP_TRY(hipMalloc(&g->d_wide_sorted, sizeof(int) * (size_t)m));
+      bytes = 0;
+      HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, bytes, degs.p, keyo.p, sel.p, g->d_wide_sorted, m));
+      HIP_TRY(tmp.reserve(bytes));
+      HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(tmp.buf.p, bytes, degs.p, keyo.p, sel.p, g->d_wide_sorted, m));
+    }
     g->wide_valid = true;
   }
   for (auto &pl : g->wide_plans)
@@ -944,52 +1432,60 @@ static int get_wide_plan(gm_graph *g, int rank, int world, int policy, WidePlan 
   WidePlan pl;
   pl.rank = rank; pl.world = world; pl.policy = policy;
   int64_t first = 0, step = 1, count = 0;
-  gm_partition((int64_t)g->h_wide.size(), rank, world, policy, &first, &step, &count);
-  for (int64_t i = 0; i < count; ++i) pl.verts.push_back(g->h_wide[(size_t)(first + i * step)]);
-  unsigned long long arena_mb = GM_WIDE_ARENA_MB;
-  if (const char *e = getenv("GM_WIDE_ARENA_MB")) arena_mb = std::max(1ll, atoll(e));  // (tests: force several rounds)
-  const unsigned long long budget_words = (arena_mb << 20) / 4ull;
-  std::vector<unsigned long long> base(pl.verts.size());
-  std::vector<ChunkRec> chunks;
-  std::vector<int> cls_slots;
-  size_t s0 = 0;
-  while (s0 < pl.verts.size()) {
-    WidePlan::Round rd;
-    rd.chunk_begin = chunks.size();
-    size_t s1 = s0;
-    unsigned long long words = 0;
-    std::vector<int> by_cls[3];
-    for (; s1 < pl.verts.size(); ++s1) {
-      const int u = pl.verts[s1], d = g->h_rp[u + 1] - g->h_rp[u], stride = (d + 31) / 32;
-      const unsigned long long w = (unsigned long long)d * (unsigned long long)stride;
-      if (s1 > s0 && words + w > budget_words) break;
-      base[s1] = words;
-      words += w;
-      pl.edges += (unsigned long long)d;
-      const int R = clique_group_rows(d);
-      for (int g0 = 0; g0 < d; g0 += R)
-        chunks.push_back({u, u + 1, g->h_rp[u] + g0, g->h_rp[u] + std::min(g0 + R, d), 0, 1, 8, (int)s1 + 1});
-      by_cls[clique_count_class(d)].push_back((int)s1);
+  gm_partition((int64_t)g->n_wide, rank, world, policy, &first, &step, &count);
+  if (count > 0) {
+    DevBuf<int> degs, ngroups, goff;
+    HIP_TRY(hipMalloc(&pl.d_verts, sizeof(int) * (size_t)count));
+    HIP_TRY(degs.alloc((size_t)count));
+    HIP_TRY(ngroups.alloc((size_t)count + 1));
+    HIP_TRY(goff.alloc((size_t)count + 1));
+    hipLaunchKernelGGL(wide_share_kernel, blocks(count + 1), dim3(256), 0, 0, (int)count, (long long)first, (long long)step, g->d_wide_sorted, g->d_rp,
+                       pl.d_verts, degs.p, ngroups.p);
+    HIP_TRY(dev_exclusive_sum(tmp, ngroups.p, goff.p, (size_t)count + 1));
+    int nchunks = 0;
+    HIP_TRY(hipMemcpy(&nchunks, goff.p + count, sizeof(int), hipMemcpyDeviceToHost));
+    pl.n_chunks = (size_t)nchunks;
+    HIP_TRY(hipMalloc(&pl.d_chunks, sizeof(ChunkRec) * (size_t)std::max(nchunks, 1)));
+    hipLaunchKernelGGL(wide_groups_kernel, blocks(count), dim3(256), 0, 0, (int)count, pl.d_verts, g->d_rp, goff.p, pl.d_chunks);
+    // host part, O(wide vertices of this share): arena offsets, rounds within the arena budget, count classes
+    pl.verts.resize((size_t)count);
+    std::vector<int> hd((size_t)count), hgoff((size_t)count + 1);
+    HIP_TRY(hipMemcpy(pl.verts.data(), pl.d_verts, sizeof(int) * (size_t)count, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hd.data(), degs.p, sizeof(int) * (size_t)count, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hgoff.data(), goff.p, sizeof(int) * ((size_t)count + 1), hipMemcpyDeviceToHost));
+    unsigned long long arena_mb = GM_WIDE_ARENA_MB;
+    if (const char *e = getenv("GM_WIDE_ARENA_MB")) arena_mb = std::max(1ll, atoll(e));  // (tests: force several rounds)
+    const unsigned long long budget_words = (arena_mb << 20) / 4ull;
+    std::vector<unsigned long long> base((size_t)count);
+    std::vector<int> cls_slots;
+    size_t s0 = 0;
+    while (s0 < (size_t)count) {
+      WidePlan::Round rd;
+      rd.chunk_begin = (size_t)hgoff[s0];
+      size_t s1 = s0;
+      unsigned long long words = 0;
+      std::vector<int> by_cls[3];
+      for (; s1 < (size_t)count; ++s1) {
+        const int d = hd[s1];
+        const unsigned long long w = (unsigned long long)d * (unsigned long long)((d + 31) / 32);
+        if (s1 > s0 && words + w > budget_words) break;
+        base[s1] = words;
+        words += w;
+        pl.edges += (unsigned long long)d;
+        by_cls[clique_count_class(d)].push_back((int)s1);
+      }
+      rd.chunk_end = (size_t)hgoff[s1];
+      rd.words = words;
+      for (int c = 0; c < 3; ++c) {
+        rd.cls_begin[c] = cls_slots.size();
+        cls_slots.insert(cls_slots.end(), by_cls[c].begin(), by_cls[c].end());
+      }
+      rd.cls_begin[3] = cls_slots.size();
+      pl.rounds.push_back(rd);
+      s0 = s1;
     }
-    rd.chunk_end = chunks.size();
-    rd.words = words;
-    for (int c = 0; c < 3; ++c) {
-      rd.cls_begin[c] = cls_slots.size();
-      cls_slots.insert(cls_slots.end(), by_cls[c].begin(), by_cls[c].end());
-    }
-    rd.cls_begin[3] = cls_slots.size();
-    pl.rounds.push_back(rd);
-    s0 = s1;
-  }
-  pl.n_chunks = chunks.size();
-  if (!pl.verts.empty()) {
-    HIP_TRY(hipSetDevice(g->device));
-    HIP_TRY(hipMalloc(&pl.d_verts, sizeof(int) * pl.verts.size()));
-    HIP_TRY(hipMemcpy(pl.d_verts, pl.verts.data(), sizeof(int) * pl.verts.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc(&pl.d_base, sizeof(unsigned long long) * base.size()));
     HIP_TRY(hipMemcpy(pl.d_base, base.data(), sizeof(unsigned long long) * base.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc(&pl.d_chunks, sizeof(ChunkRec) * chunks.size()));
-    HIP_TRY(hipMemcpy(pl.d_chunks, chunks.data(), sizeof(ChunkRec) * chunks.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc(&pl.d_cls_slots, sizeof(int) * cls_slots.size()));
     HIP_TRY(hipMemcpy(pl.d_cls_slots, cls_slots.data(), sizeof(int) * cls_slots.size(), hipMemcpyHostToDevice));
     unsigned long long need_words = 0;
@@ -1003,6 +1499,7 @@ static int get_wide_plan(gm_graph *g, int rank, int world, int policy, WidePlan 
       g->wide_mat_bytes = need;
     }
     if (!g->d_wide_queue) HIP_TRY(hipMalloc(&g->d_wide_queue, 65536));
+    HIP_TRY(hipDeviceSynchronize());
   }
   g->wide_plans.push_back(std::move(pl));
   *out = &g->wide_plans.back();
@@ -1041,7 +1538,7 @@ extern "C" int gm_chunk_table(int32_t nv, const int64_t *row_ptr, int32_t chunk,
   target = std::max(64, std::min(target, kStageCap));
   std::vector<ChunkRec> out;
   unsigned long long mb = 0;
-  build_chunks(rp, nv, target, !for_clique, for_clique ? kBitWords : 0, kStageCap, out, mb);
+  build_chunks(rp, nv, target, !for_clique, for_clique ? kBitWords : 0, kStageCap, out, mb);  // (the walk the device runs: walk_chunks)
   *n_out = (int64_t)out.size();
   for (int64_t i = 0; i < (int64_t)out.size() && i < cap; ++i) {
     recs[4 * i + 0] = out[i].u_begin;
@@ -1992,6 +2489,17 @@ extern "C" int gm_motif(const gm_graph *sym, int k, const gm_launch *la, uint64_
 // TC kernel on the oriented graph (built once per handle and cached), so the hub rows of the symmetric graph are
 // never intersected. Counts are identical to gm_motif; with world > 1 the sum_v C(d,2) term is contributed by rank 0
 // and the per-rank partial wedge count is only meaningful after the all-reduce (mod 2^64 arithmetic).
+__global__ __launch_bounds__(256) void sum_c2_kernel(int nv, const int *__restrict__ rp, unsigned long long *__restrict__ out) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  unsigned long long s = 0;
+  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += stride) {
+    const unsigned long long d = (unsigned long long)(rp[v + 1] - rp[v]);
+    s += d * (d - 1) / 2;
+  }
+  s = gm::wave_sum_u64(s);
+  if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
+}
+
 extern "C" int gm_motif_formula(const gm_graph *sym, int k, const gm_launch *la, uint64_t *counts, int ncounts, gm_stats *st) {
   if (!sym) return GM_ERR_INVALID;
   if (k != 3) return (k == 4) ? GM_ERR_UNSUPPORTED : GM_ERR_INVALID;
@@ -2003,12 +2511,14 @@ extern "C" int gm_motif_formula(const gm_graph *sym, int k, const gm_launch *la,
     if (rc) return rc;
     g->dag_cache = dag;
   }
-  if (!g->sum_c2_valid) {
+  if (!g->sum_c2_valid) {  // sum_v C(d(v),2): one reduction kernel over the offsets
+    DevBuf<unsigned long long> acc;
+    HIP_TRY(hipSetDevice(g->device));
+    HIP_TRY(acc.alloc(1));
+    HIP_TRY(hipMemset(acc.p, 0, 8));
+    hipLaunchKernelGGL(sum_c2_kernel, dim3((unsigned)std::min<long long>(((long long)g->nv + 255) / 256, 2048)), dim3(256), 0, 0, g->nv, g->d_rp, acc.p);
     unsigned long long s2 = 0;
-    for (int v = 0; v < g->nv; ++v) {
-      const unsigned long long d = (unsigned long long)(g->h_rp[v + 1] - g->h_rp[v]);
-      s2 += d * (d - 1) / 2;
-    }
+    HIP_TRY(hipMemcpy(&s2, acc.p, 8, hipMemcpyDeviceToHost));
     g->sum_c2 = s2;
     g->sum_c2_valid = true;
   }
