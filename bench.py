@@ -92,6 +92,7 @@ def parse():
     ap.add_argument("--uniform", default="", help="NV,M: uniform random graph instead of R-MAT (LiveJournal-size flat-degree stand-in)")
     ap.add_argument("--powerlaw", default="", help="NV,M,MAXDEG: Chung-Lu power-law graph (LiveJournal: 4847571,43000000,20000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-standins", action="store_true", help="skip the extra LiveJournal-size stand-in graphs of the default run")
     ap.add_argument("--no-ref-baseline", action="store_true", help="skip the timed runs of the oracle/_ref reference binaries")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the oracle's (secondary) TC sample")
     ap.add_argument("--traffic", default="auto", choices=["auto", "off", "file"],
@@ -727,6 +728,26 @@ def main():
             "per_gpu_kernel_ms": head["per_gpu_kernel_ms"], "setup_ms": head["setup_ms"], "first_call_ms": head["first_call_ms"],
             "roofline": head["roofline"],
         }
+        if not single and world == 1 and not a.scale and not a.data_dir and not a.no_standins:
+            # Config 2 / 3 name LiveJournal, which is not in the image. Beside the R-MAT stand-in (hub-dominated: max degree
+            # 115 k) two more graphs with LiveJournal's |V| and |E| bracket its shape: a flat-degree one (mean oriented list 9,
+            # the short-list regime) and a Chung-Lu power-law one with LiveJournal's published maximum degree (20 k).
+            extra = []
+            for kind, spec in (("uniform", "4847571,43000000"), ("powerlaw", "4847571,43000000,20000")):
+                a2 = argparse.Namespace(**vars(a))
+                a2.uniform, a2.powerlaw = (spec, "") if kind == "uniform" else ("", spec)
+                bg2 = build_graph(a2, r.local_rank, 0, 0)
+                for w in ("tc", "diamond"):
+                    rec2 = r.run(w, bg2, a.steps, a.warmup)
+                    ab2, fl2 = alg_bytes_device(w, bg2, r.lib, rec2["g"])
+                    t2 = rec2["kernel_ms_avg"] * 1e-3
+                    extra.append({"workload": w, "graph": bg2.name, "nv": rec2["nv"], "tasks": rec2["tasks"], "max_degree": rec2["max_degree"],
+                                  "kernel_ms_avg": round(rec2["kernel_ms_avg"], 4), "value": round(rec2["tasks"] / (rec2["elapsed"] / rec2["steps"]) / 1e6, 3),
+                                  "unit": "Medges/s", "count": rec2["count"], "algorithmic_bytes_per_launch": ab2,
+                                  "algorithmic_frac": round(ab2 / t2 / 1e9 / HBM_PEAK_GBS, 5) if ab2 and t2 > 0 else None,
+                                  "compulsory_floor_bytes": fl2, "setup_ms": rec2["setup_ms"]})
+                bg2.free()
+            out["livejournal_standins"] = extra
         if "cpu_baseline" in head:
             out["cpu_baseline"] = head["cpu_baseline"]
         out["count_matches_cpu"] = head.get("count_matches_cpu")

@@ -75,6 +75,7 @@ SYMBOLS = [
     ("gm_graph_upload", C.c_int, [C.POINTER(gm_csr), C.c_int, C.POINTER(_P)]),
     ("gm_graph_from_device", C.c_int, [C.c_int32, C.c_int64, _P, _P, C.c_int, C.POINTER(_P)]),
     ("gm_graph_orient", C.c_int, [_P, C.POINTER(_P)]),
+    ("gm_graph_sort_neighbors", C.c_int, [_P]),
     ("gm_graph_meta", C.c_int, [_P, C.POINTER(gm_csr)]),
     ("gm_graph_download", C.c_int, [_P, _P, _P]),
     ("gm_graph_free", None, [_P]),
@@ -131,7 +132,7 @@ def check(status: int, where: str):
     if status != GM_OK:
         lib = load()
         detail = lib.gm_strerror(status).decode()
-        if status in (GM_ERR_HIP, GM_ERR_NO_DEVICE):
+        if status in (GM_ERR_HIP, GM_ERR_NO_DEVICE, GM_ERR_TOO_LARGE):
             last = lib.gm_last_error().decode()
             if last:
                 detail += "; " + last

@@ -72,10 +72,7 @@ int main(int argc, char **argv) {
   std::fflush(stdout);
   Graph g(c.graph, USE_DAG);
   g.print_meta_data();
-  if (!c.adj_sorted) {
-    std::printf("unsorted neighbor lists are not supported (sort_neighbors, src/common/graph.cc:138, is out of scope)\n");
-    return 1;
-  }
+  if (!c.adj_sorted) g.sort_neighbors();  // src/triangle/main.cc:22
   uint64_t total = 0;
   TCSolver(g, total, c.n_gpu, c.chunk);
   std::printf("total_num_triangles = %llu\n", (unsigned long long)total);

@@ -160,6 +160,7 @@ struct ChunkTable {
   // order (single rank); [1] all chunks by estimated cost, descending (rank r of n owns every n-th entry)
   int *d_order[2] = {nullptr, nullptr};
   std::vector<int> order[2];
+  bool own_bitmaps = true;               // false: d_bitmaps / d_row_slot belong to a BitmapSet of the graph (shared by its tables)
   unsigned *d_bitmaps = nullptr;         // n_bitmaps x bitmap_words
   size_t n_bitmaps = 0;
   unsigned long long bitmap_words = 0;
@@ -183,6 +184,18 @@ struct WidePlan {
   unsigned long long *d_base = nullptr;  // slot -> word offset inside its round's arena
   ChunkRec *d_chunks = nullptr;
   int *d_cls_slots = nullptr;
+};
+
+// Dense vertex-id bitmaps of the hub rows: a property of the graph (which rows: longer than min_deg and not left to a
+// big-LDS class), shared by every chunk table that needs them -- tables differ per world size / tuning, the bitmaps do not
+// (round 1 rebuilt up to 8 GB of them per table: ADVICE r1).
+struct BitmapSet {
+  int min_deg = 0;
+  RowFilter rf;
+  unsigned *d_bitmaps = nullptr;
+  int *d_row_slot = nullptr;
+  size_t n = 0;
+  unsigned long long words = 0;
 };
 
 struct gm_graph {
@@ -228,6 +241,7 @@ struct gm_graph {
   bool sum_c2_valid = false;
   // k-clique: the wide DAG vertices (clique_is_wide), longest rows first, and the per-(rank, world, policy) plans of their two
   // phases (row-group chunks of phase 1, count classes of phase 2, matrix offsets, arena rounds)
+  std::list<BitmapSet> bitmap_sets;
   int *d_wide_sorted = nullptr;
   size_t n_wide = 0;
   bool wide_valid = false;
@@ -276,9 +290,9 @@ static void free_tables(gm_graph *g) {
   for (auto &t : g->tables) {
     if (t.d) (void)hipFree(t.d);
     if (t.d_slot) (void)hipFree(t.d_slot);
-    if (t.d_row_slot) (void)hipFree(t.d_row_slot);
+    if (t.d_row_slot && t.own_bitmaps) (void)hipFree(t.d_row_slot);
     for (int i = 0; i < 2; ++i) if (t.d_order[i]) (void)hipFree(t.d_order[i]);
-    if (t.d_bitmaps) (void)hipFree(t.d_bitmaps);
+    if (t.d_bitmaps && t.own_bitmaps) (void)hipFree(t.d_bitmaps);
   }
   g->tables.clear();
 }
@@ -293,6 +307,10 @@ extern "C" void gm_graph_free(gm_graph *g) {
   }
   (void)hipSetDevice(g->device);
   free_tables(g);
+  for (auto &b : g->bitmap_sets) {
+    if (b.d_bitmaps) (void)hipFree(b.d_bitmaps);
+    if (b.d_row_slot) (void)hipFree(b.d_row_slot);
+  }
   if (g->d_rp) (void)hipFree(g->d_rp);
   if (g->own_col && g->d_col) (void)hipFree(g->d_col);
   if (g->d_edesc) (void)hipFree(g->d_edesc);
@@ -454,6 +472,27 @@ extern "C" int gm_graph_from_device(int32_t nv, int64_t ne, const int64_t *d_row
   rc = finish_handle(g);
   if (rc) return fail(rc);
   *out = g;
+  return GM_OK;
+}
+
+// Graph::sort_neighbors (src/common/graph.cc:138-146: std::sort per row under OpenMP) on the GPU: one segmented radix sort
+// of col_idx with the rows as segments. In place: a borrowed col_idx array (gm_graph_from_device) is overwritten too.
+extern "C" int gm_graph_sort_neighbors(gm_graph *g) {
+  if (!g) return GM_ERR_INVALID;
+  if (g->ne == 0) return GM_OK;
+  if (!g->tables.empty() || g->d_edesc || g->dag_cache || g->relabel_cache[0] || g->relabel_cache[1]) return GM_ERR_INVALID;  // before any solver ran
+  HIP_TRY(hipSetDevice(g->device));
+  DevBuf<int> sorted;
+  HIP_TRY(sorted.alloc((size_t)g->ne));
+  ScanTemp tmp;
+  size_t bytes = 0;
+  int bits = 1;
+  while (bits < 31 && (1ll << bits) < (long long)g->nv) ++bits;
+  HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, bytes, g->d_col, sorted.p, (int)g->ne, g->nv, g->d_rp, g->d_rp + 1, 0, bits));
+  HIP_TRY(tmp.reserve(bytes));
+  HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(tmp.buf.p, bytes, g->d_col, sorted.p, (int)g->ne, g->nv, g->d_rp, g->d_rp + 1, 0, bits));
+  HIP_TRY(hipMemcpy(g->d_col, sorted.p, sizeof(int) * (size_t)g->ne, hipMemcpyDeviceToDevice));
+  HIP_TRY(hipDeviceSynchronize());
   return GM_OK;
 }
 
@@ -1100,48 +1139,73 @@ static int build_table_device(gm_graph *g, ChunkTable &t, bool sym_table, double
   if (t.allow_split) {
     SetupTimer bm_timer;
     // Hub rows (longer than the LDS stage, cut into SPLIT chunks) get a dense bitmap over the vertex ids, the longest rows
-    // first, within a memory budget: one probe then replaces a ~17-step bisection in HBM.
-    const unsigned long long words = ((unsigned long long)nv + 31ull) / 32ull;
-    DevBuf<int> flag, iota, sel, nsel;
-    HIP_TRY(flag.alloc((size_t)nv));
-    HIP_TRY(iota.alloc((size_t)nv));
-    HIP_TRY(sel.alloc((size_t)nv));
-    HIP_TRY(nsel.alloc(1));
-    hipLaunchKernelGGL(tab_hubflag_kernel, blocks(nv), dim3(256), 0, 0, q, t.bitmap_min_deg, g->d_rp, flag.p, iota.p);
-    size_t bytes = 0;
-    HIP_TRY(hipcub::DeviceSelect::Flagged(nullptr, bytes, iota.p, flag.p, sel.p, nsel.p, nv));
-    HIP_TRY(tmp.reserve(bytes));
-    HIP_TRY(hipcub::DeviceSelect::Flagged(tmp.buf.p, bytes, iota.p, flag.p, sel.p, nsel.p, nv));
-    int m = 0;
-    HIP_TRY(hipMemcpy(&m, nsel.p, sizeof(int), hipMemcpyDeviceToHost));
-    const size_t nb_max = words ? (size_t)(kBitmapBudget / (words * 4ull)) : 0;
-    if (m > 0 && nb_max > 0) {
-      DevBuf<int> degs;
-      HIP_TRY(degs.alloc((size_t)m));
-      hipLaunchKernelGGL(gather_deg_kernel, blocks(m), dim3(256), 0, 0, m, sel.p, g->d_rp, degs.p);
-      std::vector<int> hv((size_t)m), hd((size_t)m);
-      HIP_TRY(hipMemcpy(hv.data(), sel.p, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost));
-      HIP_TRY(hipMemcpy(hd.data(), degs.p, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost));
-      std::vector<int> idx((size_t)m);  // (hub rows only: thousands at most)
-      for (int i = 0; i < m; ++i) idx[(size_t)i] = i;
-      std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return hd[(size_t)a] > hd[(size_t)b]; });
-      const size_t nb = std::min<size_t>((size_t)m, nb_max);
-      std::vector<int> rows(nb);
-      for (size_t i = 0; i < nb; ++i) rows[i] = hv[(size_t)idx[i]];
-      DevBuf<int> d_rows;
-      HIP_TRY(d_rows.alloc(nb));
-      HIP_TRY(hipMemcpy(d_rows.p, rows.data(), sizeof(int) * nb, hipMemcpyHostToDevice));
-      HIP_TRY(hipMalloc(&t.d_row_slot, sizeof(int) * (size_t)nv));
-      HIP_TRY(hipMemsetAsync(t.d_row_slot, 0xff, sizeof(int) * (size_t)nv, 0));  // -1
-      hipLaunchKernelGGL(tab_rowslot_kernel, blocks((long long)nb), dim3(256), 0, 0, (int)nb, d_rows.p, t.d_row_slot);
+    // first, within a memory budget (and a quarter of the free device memory): one probe then replaces a ~17-step bisection
+    // in HBM. The set is cached on the graph and shared by its tables.
+    BitmapSet *bs = nullptr;
+    for (auto &b : g->bitmap_sets)
+      if (b.min_deg == t.bitmap_min_deg && b.rf == t.rf) bs = &b;
+    if (!bs) {
+      BitmapSet nb_set;
+      nb_set.min_deg = t.bitmap_min_deg;
+      nb_set.rf = t.rf;
+      const unsigned long long words = ((unsigned long long)nv + 31ull) / 32ull;
+      DevBuf<int> flag, iota, sel, nsel;
+      HIP_TRY(flag.alloc((size_t)nv));
+      HIP_TRY(iota.alloc((size_t)nv));
+      HIP_TRY(sel.alloc((size_t)nv));
+      HIP_TRY(nsel.alloc(1));
+      hipLaunchKernelGGL(tab_hubflag_kernel, blocks(nv), dim3(256), 0, 0, q, t.bitmap_min_deg, g->d_rp, flag.p, iota.p);
+      size_t bytes = 0;
+      HIP_TRY(hipcub::DeviceSelect::Flagged(nullptr, bytes, iota.p, flag.p, sel.p, nsel.p, nv));
+      HIP_TRY(tmp.reserve(bytes));
+      HIP_TRY(hipcub::DeviceSelect::Flagged(tmp.buf.p, bytes, iota.p, flag.p, sel.p, nsel.p, nv));
+      int m = 0;
+      HIP_TRY(hipMemcpy(&m, nsel.p, sizeof(int), hipMemcpyDeviceToHost));
+      size_t free_b = 0, total_b = 0;
+      (void)hipMemGetInfo(&free_b, &total_b);
+      const unsigned long long budget = std::min<unsigned long long>(kBitmapBudget, free_b / 4);
+      const size_t nb_max = words ? (size_t)(budget / (words * 4ull)) : 0;
+      if (m > 0 && nb_max > 0) {
+        DevBuf<int> degs;
+        HIP_TRY(degs.alloc((size_t)m));
+        hipLaunchKernelGGL(gather_deg_kernel, blocks(m), dim3(256), 0, 0, m, sel.p, g->d_rp, degs.p);
+        std::vector<int> hv((size_t)m), hd((size_t)m);
+        HIP_TRY(hipMemcpy(hv.data(), sel.p, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(hd.data(), degs.p, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost));
+        std::vector<int> idx((size_t)m);  // (hub rows only: thousands at most)
+        for (int i = 0; i < m; ++i) idx[(size_t)i] = i;
+        std::stable_sort(idx.begin(), idx.end(), [&](int a_, int b_) { return hd[(size_t)a_] > hd[(size_t)b_]; });
+        const size_t nb = std::min<size_t>((size_t)m, nb_max);
+        std::vector<int> rows(nb);
+        for (size_t i = 0; i < nb; ++i) rows[i] = hv[(size_t)idx[i]];
+        DevBuf<int> d_rows;
+        DevBuf<int> row_slot;
+        DevBuf<unsigned> bitmaps;
+        HIP_TRY(d_rows.alloc(nb));
+        HIP_TRY(hipMemcpy(d_rows.p, rows.data(), sizeof(int) * nb, hipMemcpyHostToDevice));
+        HIP_TRY(row_slot.alloc((size_t)nv));
+        HIP_TRY(hipMemsetAsync(row_slot.p, 0xff, sizeof(int) * (size_t)nv, 0));  // -1
+        hipLaunchKernelGGL(tab_rowslot_kernel, blocks((long long)nb), dim3(256), 0, 0, (int)nb, d_rows.p, row_slot.p);
+        HIP_TRY(bitmaps.alloc((size_t)nb * (size_t)words));
+        HIP_TRY(hipMemsetAsync(bitmaps.p, 0, (size_t)nb * (size_t)words * 4, 0));
+        hipLaunchKernelGGL(bitmap_build_kernel, dim3((unsigned)nb), dim3(256), 0, 0, g->d_rp, g->d_col, d_rows.p, bitmaps.p, words);
+        HIP_TRY(hipDeviceSynchronize());  // (the set is published only after its kernels have succeeded)
+        nb_set.d_bitmaps = bitmaps.release();
+        nb_set.d_row_slot = row_slot.release();
+        nb_set.n = nb;
+        nb_set.words = words;
+      }
+      g->bitmap_sets.push_back(nb_set);
+      bs = &g->bitmap_sets.back();
+    }
+    if (bs->n > 0) {
+      t.own_bitmaps = false;
+      t.d_bitmaps = bs->d_bitmaps;
+      t.d_row_slot = bs->d_row_slot;
+      t.n_bitmaps = bs->n;
+      t.bitmap_words = bs->words;
       HIP_TRY(hipMalloc(&t.d_slot, sizeof(int) * (size_t)n));
       hipLaunchKernelGGL(tab_chunkslot_kernel, blocks(n), dim3(256), 0, 0, n, t.d, g->d_rp, t.stage_cap, t.d_row_slot, t.d_slot);
-      HIP_TRY(hipMalloc(&t.d_bitmaps, (size_t)nb * (size_t)words * 4));
-      HIP_TRY(hipMemsetAsync(t.d_bitmaps, 0, (size_t)nb * (size_t)words * 4, 0));
-      hipLaunchKernelGGL(bitmap_build_kernel, dim3((unsigned)nb), dim3(256), 0, 0, g->d_rp, g->d_col, d_rows.p, t.d_bitmaps, words);
-      HIP_TRY(hipDeviceSynchronize());
-      t.n_bitmaps = nb;
-      t.bitmap_words = words;
     }
     bitmap_ms = bm_timer.ms();
   }
@@ -1682,11 +1746,12 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
   // symmetric-graph patterns: the rows just above the LDS stage go to the big-LDS workgroup classes (gm_chunk.h MineCfg)
   // (tune[6] & 0x80000: A/B switch, they stay SPLIT rows with dense bitmaps)
   const bool sym_pat = stage_cap_of(pat) == kStageCapWide;
-  // They pay where the dense bitmaps of the SPLIT path are cold: a bitmap has nv bits, and up to 512 KB (nv <= 2^22) the bitmaps
+  // They pay where the dense bitmaps of the SPLIT path are cold: a bitmap has nv bits, and up to ~1 MB (nv <= 2^23) the bitmaps
   // of the rows being worked on stay in L2 -- measured, diamond R-MAT-22 28 ms (SPLIT + bitmaps) vs 47 ms (classes), R-MAT-20
-  // 10.4 vs 20.8; at nv = 2^24 (2 MB per bitmap) 819 vs 636 ms, 3-motif 458 vs 370 ms. tune[6] & 0x100000 forces them on.
+  // 10.4 vs 20.8, the LiveJournal-size power-law graph (nv 4.8 M, 600 KB bitmaps) 3.9 vs 8.0; at nv = 2^24 (2 MB per bitmap) 819 vs
+  // 636 ms, 3-motif 458 vs 370 ms. tune[6] & 0x100000 forces them on.
   const bool use_classes = sym_pat && !(la->tune[6] & 0x80000) && !(la->tune[5] == 1) &&
-                           ((la->tune[6] & 0x100000) || g->nv > (1 << 22));
+                           ((la->tune[6] & 0x100000) || g->nv > (1 << 23));
   RowFilter rf;
   rf.skip_clique_wide = use_wide;
   if (use_classes) { rf.skip_lo = kStageCapWide; rf.skip_hi = kStageCapBig; }
@@ -1776,6 +1841,7 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
   p.k = k;
   p.flags = (la->tune[5] == 1) ? 1 : 0;
   p.flags |= (la->tune[6] & 0xffff) << 1;  // debug/ablation: bit1 skip clique phase 2, bit2 skip bit-matrix writes (counts wrong)
+  if (la->tune[6] & 0x200000) p.flags |= 1 << 20;  // k >= 5: the any-width pair count instead of the tile walk (tests)
   p.counters = g->d_counters;
   p.queue = reinterpret_cast<unsigned *>(g->d_counters + 4);
 
@@ -2089,7 +2155,9 @@ static int run_rect_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h_
   // one counter map (nv words) per wave, within a memory budget
   p.acc_stride = ((unsigned long long)g->nv + 63ull) & ~63ull;
   const unsigned long long per_wg = p.acc_stride * 4ull * kWavesPerBlock;
-  const unsigned long long budget = 32ull << 30;
+  size_t free_b = 0, total_b = 0;
+  (void)hipMemGetInfo(&free_b, &total_b);
+  const unsigned long long budget = std::min<unsigned long long>(32ull << 30, (unsigned long long)free_b / 4 + (unsigned long long)g->rect_acc_bytes);  // (maps + touched lists)
   long long grid = std::min<long long>((long long)g->cu_count * 8, (long long)std::max<unsigned long long>(1, budget / std::max<unsigned long long>(per_wg, 1)));
   grid = std::max<long long>(1, std::min<long long>(grid, count));
   const size_t need = (size_t)per_wg * (size_t)grid;
@@ -2146,15 +2214,18 @@ static int ensure_edge_tables(gm_graph *g, const GraphView &gv) {
   if (g->d_house_t && g->d_house_tlt) return GM_OK;
   OtherSetupScope scope(g);
   const size_t ne1 = (size_t)std::max<long long>(g->ne, 1);
-  HIP_TRY(hipMalloc(&g->d_house_t, sizeof(unsigned) * ne1));
-  HIP_TRY(hipMalloc(&g->d_house_tlt, sizeof(unsigned) * ne1));
+  DevBuf<unsigned> t, tlt;
+  HIP_TRY(t.alloc(ne1));
+  HIP_TRY(tlt.alloc(ne1));
   if (g->ne > 0) {
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemset(g->d_counters, 0, 64));
-    HIP_TRY(launch_edge_tab(gv, g->d_house_t, g->d_house_tlt, g->d_counters + 4, g->cu_count * 8, 0));
+    HIP_TRY(launch_edge_tab(gv, t.p, tlt.p, g->d_counters + 4, g->cu_count * 8, 0));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemset(g->d_counters, 0, 64));  // (the table kernel used the dequeue head)
   }
+  g->d_house_t = t.release();  // (published only after the build kernel has succeeded; the buffers free themselves on the error paths)
+  g->d_house_tlt = tlt.release();
   return GM_OK;
 }
 
@@ -2218,7 +2289,9 @@ static int run_house_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h
   p.queue = g->d_counters + 4;
   p.acc_stride = ((unsigned long long)g->nv + 63ull) & ~63ull;
   const unsigned long long per_wg = p.acc_stride * 8ull * kWavesPerBlock;
-  const unsigned long long budget = 32ull << 30;
+  size_t free_b = 0, total_b = 0;
+  (void)hipMemGetInfo(&free_b, &total_b);
+  const unsigned long long budget = std::min<unsigned long long>(32ull << 30, (unsigned long long)free_b / 3 + (unsigned long long)g->house_acc_bytes);  // (maps + touched lists)
   long long grid = std::min<long long>((long long)g->cu_count * 8, (long long)std::max<unsigned long long>(1, budget / std::max<unsigned long long>(per_wg, 1)));
   grid = std::max<long long>(1, std::min<long long>(grid, count));
   const size_t need = (size_t)per_wg * (size_t)grid;
@@ -2381,9 +2454,10 @@ extern "C" int gm_clique(const gm_graph *dag, int k, const gm_launch *la, uint64
     if (total) *total = 0;
     return GM_ERR_INVALID;
   }
-  if (k > 4 && dag && dag->max_deg > 2048) {  // deeper levels need the whole row in one 64-lane sweep
+  if (k > 4 && dag && dag->max_deg > 4096) {  // deeper levels sweep a row with two words per lane (cliquek_count_sub)
     if (total) *total = 0;
-    return GM_ERR_UNSUPPORTED;
+    g_last_error = "gm_clique: k >= 5 needs max out-degree <= 4096 (this DAG: " + std::to_string(dag->max_deg) + ")";
+    return GM_ERR_TOO_LARGE;
   }
   return run_pattern(k == 4 ? PAT_CLIQUE4 : PAT_CLIQUEK, dag, la, k, total, 1, st);
 }

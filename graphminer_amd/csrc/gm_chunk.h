@@ -283,29 +283,66 @@ struct CliqueWide<1> {
 // read |M_i| rows per row i instead of once per visited sub-tree (chunk timings: that walk was 94 % of the 5-clique time,
 // bound by 17 G row fetches of 128 B). Rows with more than 256 set bits: the compacted matrix goes to the next arena slot and is
 // processed one level down the same way (k = 5: what is left is a pair count, the 4-clique tile walk).
+// pair count of a matrix in the arena whose rows are wider than the 64-lane sweep of the tile walk (> 2048 columns): one wave
+// per row i, lanes stride the words; the rows M_j of its set bits are fetched from the arena. Only the top rows of a DAG ever
+// get here (a vertex with more than 2048 common out-neighbours with one of its out-neighbours).
+__device__ __forceinline__ unsigned long long clique4_count_anywidth(const unsigned *__restrict__ gbits, const int lane, const int wave,
+                                                                     const int nel, const int stride) {
+  unsigned long long c = 0;
+  for (int i = wave; i < nel; i += kWavesPerBlock) {
+    const unsigned *Mi = gbits + (size_t)i * stride;
+    for (int w = 0; w < stride; ++w) {
+      unsigned x = Mi[w];  // (wave-uniform address: a broadcast load)
+      while (x) {
+        const int j = w * 32 + (__ffs((int)x) - 1);
+        x &= x - 1;
+        const unsigned *Mj = gbits + (size_t)j * stride;
+        unsigned part = 0;
+        for (int w2 = lane; w2 < stride; w2 += GM_WAVE) part += (unsigned)__popc(Mi[w2] & Mj[w2]);
+        c += part;
+      }
+    }
+  }
+  return c;
+}
+
+constexpr int kSubMaxStride = 128;  // cliquek_count_sub: rows of up to 4096 columns, two words per lane
 template <int M>
 __device__ __forceinline__ unsigned long long cliquek_count_sub(unsigned *__restrict__ sub, int *__restrict__ lds_scratch,
                                                                 unsigned short *__restrict__ plist, const unsigned *__restrict__ gbits,
                                                                 unsigned *__restrict__ sub_arena, const size_t arena_step,
                                                                 const int tid, const int lane, const int wave, const int nel,
-                                                                const int stride) {
+                                                                const int stride, const bool force_anywidth = false) {
   static_assert(kBitWords >= 256 * kSmallWords, "the sub-matrix of 256 rows must fit the bit-matrix LDS");
-  unsigned *rowbuf = reinterpret_cast<unsigned *>(lds_scratch) + wave * GM_WAVE;  // 64 words per wave
+  static_assert(sizeof(WaveLds) * kWavesPerBlock >= 2 * 32 * kSubMaxStride, "the position list (one entry per column) lives in the idle pass scratch");
+  static_assert(kStageCapClique >= kWavesPerBlock * kSubMaxStride, "one row buffer per wave in the idle stage");
+  constexpr int W = kSubMaxStride / GM_WAVE;  // words of a row per lane
+  unsigned *rowbuf = reinterpret_cast<unsigned *>(lds_scratch) + wave * kSubMaxStride;  // one row per wave (lds_scratch: 4 x 128 words)
   unsigned long long c = 0;
   for (int i = 0; i < nel; ++i) {
-    const unsigned mi = (lane < stride) ? gbits[(size_t)i * stride + lane] : 0u;  // (all four waves read the row: m is uniform)
-    const int cw = __popc(mi);
-    const int incl = wave_incl_scan_add(cw);
-    const int m = readlane(incl, GM_WAVE - 1);
+    unsigned mi[W];
+    int cw[W], off[W];
+    int m = 0;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {  // (all four waves read the row: m is uniform)
+      mi[w] = (w * GM_WAVE + lane < stride) ? gbits[(size_t)i * stride + w * GM_WAVE + lane] : 0u;
+      cw[w] = __popc(mi[w]);
+      const int incl = wave_incl_scan_add(cw[w]);
+      off[w] = m + incl - cw[w];  // positions stay ascending: the words 0..63 first, then 64..127
+      m += readlane(incl, GM_WAVE - 1);
+    }
     if (m == 0) continue;
     const bool in_lds = m <= 256;
     __syncthreads();  // the previous row's sub-matrix / position list is no longer read
     if (wave == 0) {
-      unsigned x = mi;
-      int k = incl - cw;
-      while (x) {
-        plist[k++] = (unsigned short)(lane * 32 + (__ffs((int)x) - 1));
-        x &= x - 1;
+#pragma unroll
+      for (int w = 0; w < W; ++w) {
+        unsigned x = mi[w];
+        int k = off[w];
+        while (x) {
+          plist[k++] = (unsigned short)((w * GM_WAVE + lane) * 32 + (__ffs((int)x) - 1));
+          x &= x - 1;
+        }
       }
     }
     __syncthreads();
@@ -315,7 +352,8 @@ __device__ __forceinline__ unsigned long long cliquek_count_sub(unsigned *__rest
     unsigned *dst = in_lds ? sub : sub_arena;
     for (int p = wave; p < m; p += kWavesPerBlock) {
       const int j = (int)plist[p];
-      rowbuf[lane] = (lane < stride) ? gbits[(size_t)j * stride + lane] : 0u;
+#pragma unroll
+      for (int w = 0; w < W; ++w) rowbuf[w * GM_WAVE + lane] = (w * GM_WAVE + lane < stride) ? gbits[(size_t)j * stride + w * GM_WAVE + lane] : 0u;
       wave_sync();
       for (int q0 = 0; q0 < m; q0 += GM_WAVE) {
         const int q = q0 + lane;
@@ -343,11 +381,16 @@ __device__ __forceinline__ unsigned long long cliquek_count_sub(unsigned *__rest
       }
     } else {
       __threadfence();
-      if constexpr (M == 3) {  // what is left is the pair count of the compacted matrix: the 4-clique tile walk (begins with a barrier)
-        c += clique4_count_tiled(sub, sub_arena, tid, lane, wave, m, words);
+      if constexpr (M == 3) {  // what is left is the pair count of the compacted matrix
+        if (words <= GM_WAVE && !force_anywidth) {
+          c += clique4_count_tiled(sub, sub_arena, tid, lane, wave, m, words);  // the 4-clique tile walk (begins with a barrier)
+        } else {
+          __syncthreads();
+          c += clique4_count_anywidth(sub_arena, lane, wave, m, words);  // (per-lane partials like the tile walk's)
+        }
       } else {  // one level down on the compacted matrix, with the next arena slot for ITS wide rows
         __syncthreads();
-        c += cliquek_count_sub<M - 1>(sub, lds_scratch, plist, sub_arena, sub_arena + arena_step, arena_step, tid, lane, wave, m, words);
+        c += cliquek_count_sub<M - 1>(sub, lds_scratch, plist, sub_arena, sub_arena + arena_step, arena_step, tid, lane, wave, m, words, force_anywidth);
       }
     }
   }
@@ -685,7 +728,8 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT,
 
   __syncthreads();  // every batch of the chunk is done (LDS is reused by the next chunk)
   if (GM_IS_CLIQUE(PAT) && !(p.flags & 2)) {
-    const bool wide = !bits_lds && nvl == 1 && stride <= GM_WAVE;
+    const bool wide = !bits_lds && nvl == 1 && stride <= GM_WAVE;        // one 64-lane sweep per row
+    const bool wide2 = !bits_lds && nvl == 1 && stride <= kSubMaxStride;  // k >= 5: the sub-matrix path takes two words per lane
     if (((p.flags & 4096) && bits_lds) || ((p.flags & 8192) && !bits_lds)) { __syncthreads(); return; }  // ablation
     if (!bits_lds) {
       __threadfence();  // the scratch matrix was written by all 4 waves (plain stores or device atomics)
@@ -703,13 +747,13 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT,
 #define GM_CLIQUE_CASE(K)                                                                                   \
       case K:                                                                                                \
         if (PAT != PAT_CLIQUEK) break;                                                                       \
-        if (wide && !(p.flags & 64))                                                                          \
-          acc.c0 += cliquek_count_sub<K - 2>(B.bits, B.stage, reinterpret_cast<unsigned short *>(B.fbits), gbits,       \
+        if (wide2 && !((p.flags & 64) && wide))                                                               \
+          acc.c0 += cliquek_count_sub<K - 2>(B.bits, B.stage, reinterpret_cast<unsigned short *>(&B.w[0]), gbits,       \
                                              gbits + p.scratch_words / (K - 3 + 1), p.scratch_words / (K - 3 + 1), tid, lane,   \
-                                             wave, nel, stride);                                                          \
+                                             wave, nel, stride, (p.flags & (1 << 20)) != 0);                               \
         else if (wide) acc.c0 += cliquek_count_wide<K - 2>(gbits, lane, wave, nel, stride);                      \
         else if (bits_lds) acc.c0 += cliquek_count_small<K - 2>(B.rpl, B.bits, tid, nthreads, eb, nel, nvl, stride); \
-        else acc.c1 += 1; /* row wider than 2048 columns: not supported for k >= 5 (reported by the host) */ \
+        else acc.c1 += 1; /* row wider than 4096 columns: not supported for k >= 5 (refused by the host) */  \
         break;
       GM_CLIQUE_CASE(5)
       GM_CLIQUE_CASE(6)

@@ -146,6 +146,11 @@ class DeviceGraph:
         _lib.check(_lib.load().gm_graph_orient(self._h, C.byref(h)), "gm_graph_orient")
         return DeviceGraph(h.value, self.device)
 
+    def sort_neighbors(self) -> "DeviceGraph":
+        """Graph::sort_neighbors (src/common/graph.cc:138-146) on the GPU, in place; returns self."""
+        _lib.check(_lib.load().gm_graph_sort_neighbors(self._h), "gm_graph_sort_neighbors")
+        return self
+
     def download(self) -> Graph:
         rp = np.empty(self.nv + 1, dtype=np.int64)
         ci = np.empty(self.ne, dtype=np.int32)

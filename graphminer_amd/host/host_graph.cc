@@ -72,6 +72,19 @@ VertexSetView Graph::N(vidType v) const {
   return VertexSetView{edges.data() + begin, vidType(end - begin), v};
 }
 
+void Graph::sort_neighbors() {
+  std::cout << "Sorting the neighbor lists (used for pattern mining)\n";  // graph.cc:139
+  gm_csr h = csr();
+  gm_graph *dg = nullptr;
+  int rc = gm_graph_upload(&h, 0, &dg);
+  if (rc) gm_die(rc, "gm_graph_upload");
+  rc = gm_graph_sort_neighbors(dg);
+  if (rc) gm_die(rc, "gm_graph_sort_neighbors");
+  rc = gm_graph_download(dg, nullptr, edges.data());
+  if (rc) gm_die(rc, "gm_graph_download");
+  gm_graph_free(dg);
+}
+
 void Graph::orientation() {
   std::cout << "Orientation enabled, using DAG\n";  // graph.cc:234
   Timer t;

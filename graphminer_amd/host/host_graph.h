@@ -63,6 +63,7 @@ class Graph {
   VertexSetView N(vidType v) const;  // src/common/graph.cc:172-182
   void print_meta_data() const;      // src/common/graph.cc:645-665
   void orientation();                // src/common/graph.cc:233-279 (runs on GPU 0)
+  void sort_neighbors();             // src/common/graph.cc:138-146 (segmented sort on GPU 0)
   gm_csr csr() const { return gm_csr{n_vertices, n_edges, max_degree, vertices.data(), edges.data()}; }
   const std::string &name() const { return name_; }
 

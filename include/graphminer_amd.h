@@ -69,6 +69,10 @@ int gm_graph_from_device(int32_t nv, int64_t ne, const int64_t *d_row_ptr, const
 /* Graph::orientation (src/common/graph.cc:233-279) on the GPU: keep s->d iff
  * deg[d] > deg[s] || (deg[d] == deg[s] && d > s). Returns a new handle. */
 int gm_graph_orient(const gm_graph *sym, gm_graph **dag);
+/* Graph::sort_neighbors (src/common/graph.cc:138-146), the `adj_sorted = 0` case of tc_* (src/triangle/main.cc:22): sorts
+ * every row ascending, in place on the device (one segmented radix sort). Every solver assumes sorted rows, so call it
+ * before the first solver / gm_graph_orient result is used; after a solver has run on the handle -> GM_ERR_INVALID. */
+int gm_graph_sort_neighbors(gm_graph *g);
 /* nv / ne / max_deg of a handle (pointers in *meta are left NULL). */
 int gm_graph_meta(const gm_graph *g, gm_csr *meta);
 /* D->H copy (row_ptr: nv+1 int64, col_idx: ne int32); either pointer may be NULL. */
@@ -162,7 +166,10 @@ int gm_tc(const gm_graph *dag, const gm_launch *launch, uint64_t *total, gm_stat
 int gm_sgl(const gm_graph *sym, const char *pattern, const gm_launch *launch, uint64_t *total, gm_stats *stats);
 
 /* CliqueSolver on the DAG, 3 <= k <= 8 (src/clique/cpu_kernels/automine_omp.h:67-83,138-157;
- * src/clique/gpu_kernels/clique4_warp_edge.cuh:3-31 ... clique8). */
+ * src/clique/gpu_kernels/clique4_warp_edge.cuh:3-31 ... clique8). k = 3, 4: any out-degree. k >= 5: the deeper levels run on
+ * adjacency bit-matrices swept with two words per lane, which takes DAG rows of up to 4096 entries (the degree-ordered DAG of
+ * com-Orkut has 535, of a scale-24 R-MAT graph 1744); a longer row -> GM_ERR_TOO_LARGE, *total = 0, gm_last_error names the
+ * degree -- the count is refused, never wrong. */
 int gm_clique(const gm_graph *dag, int k, const gm_launch *launch, uint64_t *total, gm_stats *stats);
 
 /* MotifSolver on the SYMMETRIC graph. k = 3: counts[0] = wedges, counts[1] = triangles

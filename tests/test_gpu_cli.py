@@ -45,6 +45,40 @@ def test_cli_result_lines(name):
     assert out[-6:] == [f"pattern {i}: {c}" for i, c in enumerate(e["motif4"])] and "num_patterns: 6" in out
 
 
+def test_cli_unsorted_neighbor_lists(tmp_path):
+    """tc_* <graph> 1 1024 0: adj_sorted = 0 -> Graph::sort_neighbors (src/triangle/main.cc:22), here a segmented sort on the GPU"""
+    import numpy as np
+
+    from common import load_graph
+
+    g = load_graph("citeseer")
+    rng = np.random.default_rng(1)
+    col = g.col_idx.copy()
+    for v in range(g.V()):
+        a, b = int(g.row_ptr[v]), int(g.row_ptr[v + 1])
+        col[a:b] = rng.permutation(col[a:b])
+    from graphminer_amd import Graph
+
+    Graph(row_ptr=g.row_ptr, col_idx=col).save(str(tmp_path / "graph"))
+    out = run("tc_gpu_base", str(tmp_path / "graph"), 1, 1024, 0)
+    assert "Sorting the neighbor lists (used for pattern mining)" in out
+    assert out[-1] == f"total_num_triangles = {GOLDEN['citeseer']['tc']}"
+
+
+def test_clique_k5_beyond_the_row_limit_fails_loudly(tmp_path):
+    """a DAG row beyond the k >= 5 limit must not print `num_5-cliques = 0` with exit code 0"""
+    import numpy as np
+
+    from graphminer_amd.rmat import csr_from_pairs
+
+    W = 4200
+    s = np.concatenate([np.zeros(W, dtype=np.uint64), np.repeat(np.arange(1, W + 1, dtype=np.uint64), W - 1)])
+    d = np.concatenate([np.arange(1, W + 1, dtype=np.uint64), np.arange(W + 1, W + 1 + W * (W - 1), dtype=np.uint64)])
+    csr_from_pairs(int(W + 1 + W * (W - 1)), s, d).save(str(tmp_path / "graph"))
+    r = subprocess.run([os.path.join(BIN, "clique_gpu_base"), str(tmp_path / "graph"), "5"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "num_5-cliques" not in r.stdout and "4096" in r.stderr
+
+
 def test_cli_usage_exits_1():
     r = subprocess.run([os.path.join(BIN, "tc_gpu_base")], capture_output=True, text=True)
     assert r.returncode == 1 and r.stdout.startswith("Usage:")

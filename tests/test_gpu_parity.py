@@ -295,10 +295,50 @@ def test_big_rows_deeper_cliques(dev):
     d = _complete_graph(n).to_device(dev).orient()
     assert CliqueSolver(d, 5) == math.comb(n, 5)
     assert CliqueSolver(d, 5, tune=[0, 0, 0, 0, 0, 0, 0x20]) == math.comb(n, 5)  # the per-sub-tree walk everywhere (A/B)
+    assert CliqueSolver(d, 5, tune=[0, 0, 0, 0, 0, 0, 0x200000]) == math.comb(n, 5)  # the any-width pair count (A/B)
     d = _complete_graph(270).to_device(dev).orient()
     assert CliqueSolver(d, 6) == math.comb(270, 6)
     d = _complete_graph(600).to_device(dev).orient()
     assert CliqueSolver(d, 5) == math.comb(600, 5)
+
+
+def test_deeper_cliques_on_a_row_wider_than_2048(dev):
+    """a DAG row of 2100 entries (two words per lane in cliquek_count_sub; round 1 refused k >= 5 beyond 2048). Vertex 0 has
+    2100 neighbours w_j, every w_j has 2099 private leaves (so deg(w_j) >= deg(0) and 0 -> w_j in the degree-ordered DAG) and
+    the w_j carry a random graph; every k-clique through 0 is a (k-1)-clique of that graph -- checked against the oracle"""
+    rng = np.random.default_rng(11)
+    W = 2100
+    s = [np.zeros(W, dtype=np.uint64)]
+    d = [np.arange(1, W + 1, dtype=np.uint64)]
+    leaf = W + 1
+    ws = np.repeat(np.arange(1, W + 1, dtype=np.uint64), W - 1)
+    s.append(ws)
+    d.append(np.arange(leaf, leaf + ws.size, dtype=np.uint64))
+    a, b = np.triu_indices(W, 1)
+    keep = rng.random(a.size) < 0.12
+    s.append((a[keep] + 1).astype(np.uint64))
+    d.append((b[keep] + 1).astype(np.uint64))
+    g = csr_from_pairs(int(leaf + ws.size), np.concatenate(s), np.concatenate(d))
+    odag = O.orient(O.OGraph(g.row_ptr, g.col_idx))
+    assert int(np.diff(odag.row_ptr).max()) == W and int(odag.row_ptr[1] - odag.row_ptr[0]) == W
+    dg = g.to_device(dev).orient()
+    for k in (4, 5, 6):
+        want = O.clique(odag, k)
+        assert want > 0
+        assert CliqueSolver(dg, k) == want
+        if k > 4:
+            assert CliqueSolver(dg, k, tune=[0, 0, 0, 0, 0, 0, 0x200000]) == want  # any-width pair count instead of the tile walk
+    # and the limit itself: a row of more than 4096 entries is refused with a status, not counted wrong
+    W2 = 4200
+    s2 = np.concatenate([np.zeros(W2, dtype=np.uint64), np.repeat(np.arange(1, W2 + 1, dtype=np.uint64), W2 - 1)])
+    d2 = np.concatenate([np.arange(1, W2 + 1, dtype=np.uint64), np.arange(W2 + 1, W2 + 1 + W2 * (W2 - 1), dtype=np.uint64)])
+    g2 = csr_from_pairs(int(W2 + 1 + W2 * (W2 - 1)), s2, d2)
+    d2g = g2.to_device(dev).orient()
+    assert d2g.get_max_degree() == W2
+    assert CliqueSolver(d2g, 4) == 0
+    with pytest.raises(_lib.GraphMinerError) as ei:
+        CliqueSolver(d2g, 5)
+    assert ei.value.status == _lib.GM_ERR_TOO_LARGE
 
 
 def test_deeper_cliques_sub_matrix_path_rmat14(dev):
@@ -451,6 +491,28 @@ def test_sgl_map_kernels_match_flat_kernels_rmat14(dev, pattern):
     assert sum(SglSolver(s, pattern, rank=r, world=8) for r in range(8)) % 2**64 == want
     assert sum(SglSolver(s, pattern, rank=r, world=3, policy=1) for r in range(3)) % 2**64 == want
     assert SglSolver(s, pattern) == want
+
+
+def test_sort_neighbors_on_the_device(dev):
+    """Graph::sort_neighbors (src/common/graph.cc:138-146; tc_* with adj_sorted = 0): rows shuffled on the host, sorted by
+    one segmented radix sort on the device, equal to the original CSR; the solvers then see the golden counts"""
+    g = load_graph("rmat12_ef8_s7")
+    rng = np.random.default_rng(3)
+    shuffled = g.col_idx.copy()
+    for v in range(g.V()):
+        a, b = int(g.row_ptr[v]), int(g.row_ptr[v + 1])
+        shuffled[a:b] = rng.permutation(shuffled[a:b])
+    assert not np.array_equal(shuffled, g.col_idx)
+    u = Graph(row_ptr=g.row_ptr.copy(), col_idx=shuffled)
+    with u.to_device(dev) as s:
+        s.sort_neighbors()
+        back = s.download()
+        assert np.array_equal(back.col_idx, g.col_idx) and np.array_equal(back.row_ptr, g.row_ptr)
+        d = s.orient()
+        assert TCSolver(d) == GOLDEN[g.name]["tc"]
+        assert MotifSolver(s, 3) == GOLDEN[g.name]["motif3"]
+        with pytest.raises(_lib.GraphMinerError):  # (after a solver has built its tables the rows must not move any more)
+            s.sort_neighbors()
 
 
 def test_rmat_device_generator_equals_numpy(dev):
