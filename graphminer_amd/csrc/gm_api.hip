@@ -1766,8 +1766,10 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
     // whole rows (largest chunk 6e7 estimated keys) 636 / 370; parts of 512 K keys 1277 / 765 (16-wave workgroups with ~10
     // batches per part); 512 K keys with >= 64 batches per part and 4-edge batches 743 / 462 -- every batch pays a few
     // dependent global round trips (descriptors, the bounded prefix of 3-motif) before it streams, so small batches and
-    // small parts lose more than the shorter tail wins. Parts of 8 M keys only trim the few heaviest rows.
-    const unsigned long long cls_cap = (la->tune[6] & 0x1000) ? 4096ull : std::max<unsigned long long>(part_cap, 8ull << 20);
+    // small parts lose more than the shorter tail wins (8 M keys 368 / 634, 32 M keys 363 / 627). Parts of 32 M keys only trim the
+    // few heaviest rows. Side streams for the class kernels: 396 / 667 (GM_CLASSES_STREAMS, off).
+    unsigned long long cls_cap = (la->tune[6] & 0x1000) ? 4096ull : std::max<unsigned long long>(part_cap, 32ull << 20);
+    if (const char *e = getenv("GM_CLS_CAP_MKEYS")) cls_cap = (unsigned long long)std::max(1, atoi(e)) << 20;  // (sweeps)
     rc = get_table(g, target, false, 0, cls_cap, kStageCapMid, &tab_cls[1], r1, 0x7fffffff);
     if (rc) return rc;
     rc = get_table(g, target, false, 0, cls_cap, kStageCapBig, &tab_cls[2], r2, 0x7fffffff);
