@@ -63,7 +63,7 @@ class gm_setup_times(C.Structure):
 GM_OK, GM_ERR_INVALID, GM_ERR_NO_DEVICE, GM_ERR_HIP, GM_ERR_TOO_LARGE, GM_ERR_UNSUPPORTED, GM_ERR_IO, GM_ERR_FORMAT = range(8)
 GM_PART_ROUND_ROBIN, GM_PART_RANGE, GM_PART_VERTEX = 0, 1, 2
 (GM_OP_INTERSECT_NUM, GM_OP_INTERSECT_NUM_UPPER, GM_OP_INTERSECT_SET, GM_OP_DIFFERENCE_NUM,
- GM_OP_DIFFERENCE_NUM_UPPER, GM_OP_DIFFERENCE_SET, GM_OP_INTERSECT_SET_UPPER, GM_OP_DIFFERENCE_SET_UPPER) = range(8)
+ GM_OP_DIFFERENCE_NUM_UPPER, GM_OP_DIFFERENCE_SET, GM_OP_INTERSECT_SET_UPPER, GM_OP_DIFFERENCE_SET_UPPER, GM_OP_COUNT_SMALLER) = range(9)
 
 # every symbol include/graphminer_amd.h declares: (name, restype, argtypes)
 _P = C.c_void_p

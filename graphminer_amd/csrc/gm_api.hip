@@ -132,11 +132,11 @@ constexpr int kDefaultChunk = 1024;  // task edges per chunk when the caller doe
 // symmetric-graph patterns come in three: the general one skips the rows of the big-LDS classes, each class table keeps only
 // its own window of row lengths.
 struct RowFilter {
-  bool skip_clique_wide = false;
+  int skip_clique_wide = 0;                    // > 0: leave out the vertices with clique_is_wide(d, this many matrix words)
   int skip_lo = 0, skip_hi = 0;                // rows with skip_lo < d <= skip_hi are left out (0, 0 = none)
   int only_lo = -1, only_hi = 0x7fffffff;      // rows with only_lo < d <= only_hi are kept
   __host__ __device__ bool skips(int d) const {
-    return (skip_clique_wide && clique_is_wide(d)) || (d > skip_lo && d <= skip_hi) || !(d > only_lo && d <= only_hi);
+    return (skip_clique_wide > 0 && clique_is_wide(d, skip_clique_wide)) || (d > skip_lo && d <= skip_hi) || !(d > only_lo && d <= only_hi);
   }
   bool operator==(const RowFilter &o) const {
     return skip_clique_wide == o.skip_clique_wide && skip_lo == o.skip_lo && skip_hi == o.skip_hi && only_lo == o.only_lo && only_hi == o.only_hi;
@@ -1427,13 +1427,16 @@ static int ensure_edesc(gm_graph *g) {
 // the list sorted by row length, or a contiguous range), where each one's matrix sits in the arena, the row-group chunks of
 // phase 1 and the slots per count class of phase 2. The arena is bounded (GM_WIDE_ARENA_MB, default 16 GiB): a share whose
 // matrices need more is processed in several ROUNDS that reuse it.
+#ifndef GM_WIDE_MIN_WORDS_DEFAULT
+#define GM_WIDE_MIN_WORDS_DEFAULT kBitWords
+#endif
 #ifndef GM_WIDE_ARENA_MB
 #define GM_WIDE_ARENA_MB 16384
 #endif
-__global__ __launch_bounds__(256) void wide_flag_kernel(int nv, const int *__restrict__ rp, int *__restrict__ flag, int *__restrict__ iota) {
+__global__ __launch_bounds__(256) void wide_flag_kernel(int nv, const int *__restrict__ rp, int min_words, int *__restrict__ flag, int *__restrict__ iota) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= nv) return;
-  flag[v] = clique_is_wide(rp[v + 1] - rp[v]) ? 1 : 0;
+  flag[v] = clique_is_wide(rp[v + 1] - rp[v], min_words) ? 1 : 0;
   iota[v] = v;
 }
 // this rank's share of the sorted wide list: slot i = entry first + i * step
@@ -1458,6 +1461,14 @@ __global__ __launch_bounds__(256) void wide_groups_kernel(int count, const int *
   for (int g0 = 0; g0 < d; g0 += R) chunks[o++] = {u, u + 1, b + g0, b + min(g0 + R, d), 0, 1, 8, i + 1};
 }
 
+static int clique_wide_min_words() {
+  static const int v = [] {
+    const char *e = getenv("GM_WIDE_MIN_WORDS");  // (sweeps; read once: tables and plans are cached per graph)
+    return e ? std::max(64, std::min(atoi(e), kBitWords)) : GM_WIDE_MIN_WORDS_DEFAULT;
+  }();
+  return v;
+}
+
 static int get_wide_plan(gm_graph *g, int rank, int world, int policy, WidePlan **out) {
   std::lock_guard<std::mutex> lk(g->mu);
   SetupTimer timer;
@@ -1471,7 +1482,7 @@ static int get_wide_plan(gm_graph *g, int rank, int world, int policy, WidePlan 
     HIP_TRY(iota.alloc((size_t)nv));
     HIP_TRY(sel.alloc((size_t)nv));
     HIP_TRY(nsel.alloc(1));
-    hipLaunchKernelGGL(wide_flag_kernel, blocks(nv), dim3(256), 0, 0, nv, g->d_rp, flag.p, iota.p);
+    hipLaunchKernelGGL(wide_flag_kernel, blocks(nv), dim3(256), 0, 0, nv, g->d_rp, clique_wide_min_words(), flag.p, iota.p);
     size_t bytes = 0;
     HIP_TRY(hipcub::DeviceSelect::Flagged(nullptr, bytes, iota.p, flag.p, sel.p, nsel.p, nv));
     HIP_TRY(tmp.reserve(bytes));
@@ -1753,7 +1764,7 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
   const bool use_classes = sym_pat && !(la->tune[6] & 0x80000) && !(la->tune[5] == 1) &&
                            ((la->tune[6] & 0x100000) || g->nv > (1 << 23));
   RowFilter rf;
-  rf.skip_clique_wide = use_wide;
+  rf.skip_clique_wide = use_wide ? clique_wide_min_words() : 0;
   if (use_classes) { rf.skip_lo = kStageCapWide; rf.skip_hi = kStageCapBig; }
   int rc = get_table(g, target, !clique, clique ? kBitWords : 0, part_cap, stage_cap_of(pat), &tab, rf, use_classes ? kStageCapBig : kBitmapMinDeg);
   if (rc) return rc;
@@ -2394,7 +2405,7 @@ static int run_sgl_nested(int pat, const gm_graph *cg, const gm_launch *la_in, u
   p.queue = reinterpret_cast<unsigned *>(g->d_counters + 4);
   p.max_deg = std::max(g->max_deg, 1);
   const int grid = (int)std::max<long long>(1, std::min<long long>((count + 3) / 4, (long long)g->cu_count * 8));
-  if (pat == SGL_HOUSE) {
+  if (pat == SGL_HOUSE || pat == SGL_DIAMOND) {  // per-wave list for the materialised S = N(v0) ^ N(v1)
     const size_t need = (size_t)grid * 4 * (size_t)p.max_deg * sizeof(int);
     if (need > g->scratch_bytes) {
       if (g->d_scratch) (void)hipFree(g->d_scratch);
@@ -2414,7 +2425,12 @@ static int run_sgl_nested(int pat, const gm_graph *cg, const gm_launch *la_in, u
 
 extern "C" int gm_sgl(const gm_graph *sym, const char *pattern, const gm_launch *la, uint64_t *total, gm_stats *st) {
   if (!pattern) return GM_ERR_INVALID;
-  if (strcmp(pattern, "diamond") == 0) return run_pattern(PAT_DIAMOND, sym, la, 4, total, 1, st);
+  if (strcmp(pattern, "diamond") == 0) {
+    // tune[6] & 1024: the LISTING (nested) form of the reference, src/sgl/gpu_kernels/diamond_nested.cuh:4-31 -- materialise
+    // S, count_smaller per member -- as a second implementation; the default counts C(|S|,2) per edge (diamond_count.cuh:15-17)
+    if (la && (la->tune[6] & 1024)) return run_sgl_nested(SGL_DIAMOND, sym, la, total, st);
+    return run_pattern(PAT_DIAMOND, sym, la, 4, total, 1, st);
+  }
   // rectangle / house / pentagon run on a copy of the graph renumbered by degree (get_relabeled; tune[6] & 512: on the
   // graph as given). tune[6] & 1024: the wave-per-edge loop nests; & 2048: rectangle as wedges + flat intersections,
   // house without the LDS S-bitmap (A/B, tests).
@@ -2645,6 +2661,7 @@ __global__ __launch_bounds__(256) void setop_kernel(int op, long long npairs, co
       case GM_OP_DIFFERENCE_NUM_UPPER: r = (unsigned)wave_sum((int)wave_difference_num_upper(A, a, B, b, sk, up)); break;
       case GM_OP_DIFFERENCE_SET: r = (unsigned)wave_difference_set(A, a, B, b, sk, O); break;
       case GM_OP_DIFFERENCE_SET_UPPER: r = (unsigned)wave_difference_set_upper(A, a, B, b, sk, up, O); break;
+      case GM_OP_COUNT_SMALLER: r = (unsigned)wave_sum((int)wave_count_smaller(up, A, a)); break;
       default: break;
     }
     if (lane == 0) out_num[i] = r;
@@ -2654,7 +2671,7 @@ __global__ __launch_bounds__(256) void setop_kernel(int op, long long npairs, co
 extern "C" int gm_setop_batch(int op, int64_t npairs, const int32_t *d_values, const int64_t *d_a_begin, const int64_t *d_a_end,
                               const int64_t *d_b_begin, const int64_t *d_b_end, const int32_t *d_upper, const int32_t *d_skip,
                               uint32_t *d_out_num, int32_t *d_out_values, void *stream) {
-  if (op < 0 || op > GM_OP_DIFFERENCE_SET_UPPER || npairs < 0) return GM_ERR_INVALID;
+  if (op < 0 || op > GM_OP_COUNT_SMALLER || npairs < 0) return GM_ERR_INVALID;
   if (npairs == 0) return GM_OK;
   if (!d_values || !d_a_begin || !d_a_end || !d_b_begin || !d_b_end || !d_out_num) return GM_ERR_INVALID;
   const bool is_set = (op == GM_OP_INTERSECT_SET || op == GM_OP_INTERSECT_SET_UPPER || op == GM_OP_DIFFERENCE_SET ||

@@ -145,7 +145,7 @@ struct MineParams {
 };
 
 // nested SgL patterns (gm_sgl.hip)
-enum SglPattern : int { SGL_RECTANGLE = 0, SGL_HOUSE = 1, SGL_PENTAGON = 2 };
+enum SglPattern : int { SGL_RECTANGLE = 0, SGL_HOUSE = 1, SGL_PENTAGON = 2, SGL_DIAMOND = 3 /* listing (nested) form */ };
 
 struct SglParams {
   GraphView g;
@@ -247,8 +247,10 @@ hipError_t launch_house_blocks(const GraphView &g, unsigned *nblk, hipStream_t s
 // Round 1 kept one arena slot per workgroup, so a wide vertex was built AND counted by a single workgroup (88 % of the
 // kernel time sat in those vertices, 382 GB of arena re-reads per launch).
 constexpr int kWideMaxDeg = 2048;   // wider DAG rows stay on the mining kernel's per-workgroup arena path
-__host__ __device__ inline bool clique_is_wide(int d) {
-  return (long long)d * ((d + 31) / 32) > kBitWords && d <= kWideMaxDeg;
+// min_words: the matrix size (words) from which a vertex takes the two-phase path; kBitWords = what no longer fits the mining
+// kernel's LDS matrix, smaller values hand more vertices to the lean build kernel + the class-S count (GM_WIDE_MIN_WORDS)
+__host__ __device__ inline bool clique_is_wide(int d, int min_words = kBitWords) {
+  return (long long)d * ((d + 31) / 32) > min_words && d <= kWideMaxDeg;
 }
 constexpr int kBuildBitWords = 1024;  // LDS words of one row group: 32 rows x 32 words, 16 rows x 64 words
 __host__ __device__ inline int clique_group_rows(int d) { return ((d + 31) / 32) <= 32 ? 32 : 16; }  // rows * stride <= kBuildBitWords

@@ -122,6 +122,16 @@ __device__ __forceinline__ int wave_intersect_set_upper(const int *A, int a, con
   return wave_intersect_set(A, a, B, b, out);
 }
 
+// count_smaller (include/operations.cuh:61-105): number of elements of the ascending list a[0..n) that are < bound, as a
+// per-lane partial (sum over the wave = the count): lanes stride the list -- the listing form of diamond walks S with it
+// (src/sgl/gpu_kernels/diamond_nested.cuh:23-27); lower_bound gives the same number with one lane.
+__device__ __forceinline__ unsigned wave_count_smaller(int bound, const int *a, int n) {
+  const int lane = lane_id();
+  unsigned c = 0;
+  for (int i = lane; i < n; i += GM_WAVE) c += (a[i] < bound) ? 1u : 0u;
+  return c;
+}
+
 // |{x in A : x not in B, x != skip}| per-lane partial. skip = -1 disables the exclusion.
 __device__ __forceinline__ unsigned wave_difference_num(const int *A, int a, const int *B, int b, int skip) {
   const int lane = lane_id();

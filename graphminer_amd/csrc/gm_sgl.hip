@@ -1,10 +1,13 @@
-// gm_sgl.hip -- nested SgL patterns (rectangle / house / pentagon) on the wave64 set-op primitives.
+// gm_sgl.hip -- nested SgL patterns (diamond listing form / rectangle / house / pentagon) on the wave64 set-op primitives.
 //
 // First correct MI355X versions of the "next" SgL rows. Loop nests and symmetry breaking
 // follow the CPU oracle semantics:
 //   rectangle  src/sgl/cpu_kernels/rectangle.h:1-11   (GPU shape: src/sgl/gpu_kernels/rectangle_nested.cuh:3)
 //   house      src/sgl/cpu_kernels/house.h:1-16        (house_edge_warp_nested.cuh:4)
 //   pentagon   src/sgl/cpu_kernels/pentagon.h:2-17     (pentagon_edge_warp_nested.cuh:3)
+//   diamond    src/sgl/cpu_kernels/diamond.h:1-14      (the LISTING form, diamond_nested.cuh:4-31: materialise
+//              S = N(v0) ^ N(v1), then for every v2 in S count the v3 in S below it -- count_smaller; the default
+//              diamond path counts C(|S|,2) per edge instead, diamond_count.cuh:15-17)
 // Task = one symmetry-broken edge (v0,v1), v1 < v0, taken by one wave (waves dequeue chunks of consecutive CSR
 // entries); the inner loops are wave-uniform and every set operation is a cooperative 64-lane primitive from
 // gm_setops.h (lanes stride the shorter list with coalesced loads, bisect the longer one). Unlike the flattened
@@ -49,7 +52,13 @@ __global__ __launch_bounds__(256) void sgl_nested_kernel(const SglParams p) {
       const int idx1 = (int)(e - r0);  // neighbours of v0 below v1 are A0[0 .. idx1)
       const int *B1 = col + rp[v1];
       const int b1 = rp[v1 + 1] - rp[v1];
-      if (PAT == SGL_RECTANGLE) {
+      if (PAT == SGL_DIAMOND) {
+        const int n = wave_intersect_set(A0, a0, B1, b1, S);
+        wave_sync();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+        for (int s = 0; s < n; ++s) cnt += wave_count_smaller(S[s], S, n);  // v2 = S[s], the v3 < v2 of S
+        wave_sync();
+      } else if (PAT == SGL_RECTANGLE) {
         for (int j = 0; j < idx1; ++j) {
           const int v2 = A0[j];
           cnt += wave_intersect_num_upper(B1, b1, col + rp[v2], rp[v2 + 1] - rp[v2], v0);
@@ -89,6 +98,7 @@ __global__ __launch_bounds__(256) void sgl_nested_kernel(const SglParams p) {
 hipError_t launch_sgl_nested(int pat, const SglParams &p, int grid_blocks, hipStream_t stream) {
   dim3 grid((unsigned)grid_blocks), block(256);
   switch (pat) {
+    case SGL_DIAMOND: hipLaunchKernelGGL(sgl_nested_kernel<SGL_DIAMOND>, grid, block, 0, stream, p); break;
     case SGL_RECTANGLE: hipLaunchKernelGGL(sgl_nested_kernel<SGL_RECTANGLE>, grid, block, 0, stream, p); break;
     case SGL_HOUSE: hipLaunchKernelGGL(sgl_nested_kernel<SGL_HOUSE>, grid, block, 0, stream, p); break;
     case SGL_PENTAGON: hipLaunchKernelGGL(sgl_nested_kernel<SGL_PENTAGON>, grid, block, 0, stream, p); break;

@@ -207,7 +207,8 @@ enum {
   GM_OP_DIFFERENCE_NUM_UPPER = 4,/* |{x in A : x < upper_i, x not in B}|      set_difference.cuh:62  */
   GM_OP_DIFFERENCE_SET = 5,      /* A \ B -> out (ascending)                  set_difference.cuh:112 */
   GM_OP_INTERSECT_SET_UPPER = 6, /* {x in A ^ B : x < upper_i} -> out         set_intersect.cuh:152  */
-  GM_OP_DIFFERENCE_SET_UPPER = 7 /* {x in A \ B : x < upper_i} -> out         set_difference.cuh:171 */
+  GM_OP_DIFFERENCE_SET_UPPER = 7,/* {x in A \ B : x < upper_i} -> out         set_difference.cuh:171 */
+  GM_OP_COUNT_SMALLER = 8        /* |{x in A : x < upper_i}| (B unused)       operations.cuh:61-105  */
 };
 /* Pair i is A_i = values[a_begin[i] .. a_end[i]), B_i = values[b_begin[i] .. b_end[i]).
  * out_num: npairs uint32 (count, or size of the materialised set). For *_SET ops the result of pair

@@ -95,6 +95,15 @@ def test_heavy_chunks_cut_into_parts(gg):
         assert sum(st.tasks for _, st in res) == dag.E()
 
 
+def test_diamond_listing_form_matches_reference(gg):
+    """the nested / listing form (diamond_nested.cuh: materialised S + count_smaller) against the goldens and the count form"""
+    name, _, sym, _ = gg
+    if GOLDEN[name]["ne"] > 100000:
+        pytest.skip("the wave-per-edge listing form is the parity version: small graphs only")
+    assert SglSolver(sym, "diamond", tune=[0, 0, 0, 0, 0, 0, 1024]) == GOLDEN[name]["diamond"]
+    assert sum(SglSolver(sym, "diamond", rank=r, world=3, tune=[0, 0, 0, 0, 0, 0, 1024]) for r in range(3)) == GOLDEN[name]["diamond"]
+
+
 def test_diamond_matches_reference(gg):
     name, _, sym, _ = gg
     total, st = SglSolver(sym, "diamond", return_stats=True)

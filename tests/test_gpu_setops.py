@@ -125,3 +125,12 @@ def test_difference(batch, bounded):
         assert num[i] == n and snum[i] == n, i
         s = batch["h_ab"][i]
         assert np.array_equal(vals[s:s + n], out[:n]), i
+
+
+def test_count_smaller(batch):
+    """count_smaller (include/operations.cuh:61-105; the listing form of diamond): |{x in A : x < bound}| = the oracle's
+    bounded() prefix length (include/VertexSet.h:240-255)"""
+    got, _ = _run(_lib.GM_OP_COUNT_SMALLER, batch, True, False, False)
+    L = O.lib()
+    for i, (a, b) in enumerate(batch["pairs"]):
+        assert got[i] == L.gmo_bounded(_p(a), a.size, batch["h_upper"][i]) == int(np.searchsorted(a, batch["h_upper"][i], side="left")), i
