@@ -705,6 +705,16 @@ def main():
             sub = finish_record(x, a, world, ab, floor, traffic.get(x["workload"]), traffic_src, cpu.get(x["workload"]),
                                 known_answer(a, x["workload"], x["graph"]), stream_gbs)
             sub = {"id": x["id"], "config": x["config"], **sub, "input_build_s": round(x["input_build_s"], 2)}
+            if x["workload"] == "motif3" and isinstance(x["count"], list) and not a.scale:
+                # the reference's OTHER 3-motif solver (motif_omp_formula / motif_gpu_formula, src/motif/omp_formula.cc:39-46):
+                # enumerate only the triangles (TC kernel on the oriented graph), derive the wedges -- same counts, reported beside
+                # the enumeration form that the config names
+                try:
+                    f = r.run("motif3f", graphs["motif3"], max(2, min(a.steps, 5)), 1)
+                    sub["formula_variant"] = {"kernel_ms_avg": round(f["kernel_ms_avg"], 4), "counts_equal": bool(f["count"] == x["count"]),
+                                              "note": "gm_motif_formula: TC on the cached DAG + sum_v C(d,2) - 3T"}
+                except Exception as e:  # a report, never a reason to lose the line
+                    sub["formula_variant"] = {"error": str(e)}
             if x["workload"] == "motif3" and isinstance(x["count"], list):
                 # size-independent identity, checked in the run: wedges = sum_v C(d,2) - 3T  (automine_formula.h:2-19)
                 bg = graphs["motif3"]

@@ -1453,12 +1453,12 @@ __global__ __launch_bounds__(256) void wide_share_kernel(int count, long long fi
   ngroups[i] = (d + R - 1) / R;
 }
 __global__ __launch_bounds__(256) void wide_groups_kernel(int count, const int *__restrict__ verts, const int *__restrict__ rp, const int *__restrict__ goff,
-                                                          ChunkRec *__restrict__ chunks) {
+                                                          int batch, ChunkRec *__restrict__ chunks) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
   const int u = verts[i], b = rp[u], d = rp[u + 1] - b, R = clique_group_rows(d);
   int o = goff[i];
-  for (int g0 = 0; g0 < d; g0 += R) chunks[o++] = {u, u + 1, b + g0, b + min(g0 + R, d), 0, 1, 8, i + 1};
+  for (int g0 = 0; g0 < d; g0 += R) chunks[o++] = {u, u + 1, b + g0, b + min(g0 + R, d), 0, 1, batch, i + 1};
 }
 
 static int clique_wide_min_words() {
@@ -1521,7 +1521,8 @@ static int get_wide_plan(gm_graph *g, int rank, int world, int policy, WidePlan 
     HIP_TRY(hipMemcpy(&nchunks, goff.p + count, sizeof(int), hipMemcpyDeviceToHost));
     pl.n_chunks = (size_t)nchunks;
     HIP_TRY(hipMalloc(&pl.d_chunks, sizeof(ChunkRec) * (size_t)std::max(nchunks, 1)));
-    hipLaunchKernelGGL(wide_groups_kernel, blocks(count), dim3(256), 0, 0, (int)count, pl.d_verts, g->d_rp, goff.p, pl.d_chunks);
+    const int build_batch = kBuildBatchRows;
+    hipLaunchKernelGGL(wide_groups_kernel, blocks(count), dim3(256), 0, 0, (int)count, pl.d_verts, g->d_rp, goff.p, build_batch, pl.d_chunks);
     // host part, O(wide vertices of this share): arena offsets, rounds within the arena budget, count classes
     pl.verts.resize((size_t)count);
     std::vector<int> hd((size_t)count), hgoff((size_t)count + 1);

@@ -237,9 +237,9 @@ hipError_t launch_house_blocks(const GraphView &g, unsigned *nblk, hipStream_t s
 
 // ---- k-clique, wide vertices: two phases -----------------------------------------------------------------------------------
 // A DAG vertex u whose d x d adjacency bit-matrix over N+(u) exceeds the mining kernel's 8 KB LDS budget (d+ > 256) is WIDE.
-//  phase 1 (gm_wide.hip, clique_build_kernel): its task edges are cut into ROW GROUPS of 32 rows; a row group is an
-//          independent task chunk (any workgroup takes it; a lean 22 KB workgroup, 7 per CU), built in LDS by the flattened
-//          passes of gm_flat.h and flushed with coalesced stores to the vertex's slot of a MATRIX ARENA in HBM
+//  phase 1 (gm_wide.hip, clique_build_kernel): its task edges are cut into ROW RANGES of 256 rows; a range is an independent
+//          task chunk (any workgroup takes it; a lean 22 KB workgroup, 7 per CU) whose waves build 4 rows at a time in LDS with
+//          the flattened passes of gm_flat.h and write them with coalesced stores to the vertex's slot of a MATRIX ARENA in HBM
 //          (sum d * ceil(d/32) words over the wide vertices: 4.4 GB for the com-Orkut stand-in -- HBM capacity is what
 //          MI355X has plenty of);
 //  phase 2 (gm_wide.hip, clique_count_kernel): one big-LDS workgroup per wide vertex copies the finished matrix into LDS
@@ -252,8 +252,9 @@ constexpr int kWideMaxDeg = 2048;   // wider DAG rows stay on the mining kernel'
 __host__ __device__ inline bool clique_is_wide(int d, int min_words = kBitWords) {
   return (long long)d * ((d + 31) / 32) > min_words && d <= kWideMaxDeg;
 }
-constexpr int kBuildBitWords = 1024;  // LDS words of one row group: 32 rows x 32 words, 16 rows x 64 words
-__host__ __device__ inline int clique_group_rows(int d) { return ((d + 31) / 32) <= 32 ? 32 : 16; }  // rows * stride <= kBuildBitWords
+constexpr int kBuildBatchRows = 4;        // task edges (rows) a wave builds at a time in its private LDS rows
+constexpr int kBuildRowsPerChunk = 256;   // rows of a wide vertex per phase-1 chunk (the workgroup stages N+(u) once per chunk)
+__host__ __device__ inline int clique_group_rows(int) { return kBuildRowsPerChunk; }
 struct CliqueBuildParams {
   GraphView g;
   const ChunkRec *chunks;         // row groups: {u, u + 1, first entry, last entry + 1, 0, 1, batch, slot + 1}
@@ -267,11 +268,17 @@ struct CliqueBuildParams {
 hipError_t launch_clique_build(const CliqueBuildParams &p, int grid_blocks, hipStream_t stream);
 size_t clique_build_lds_bytes();
 // padded row stride of the LDS copy: a multiple of 4 words whose quarter is odd, so that the 16-byte row reads of 16 lanes
-// (16 different rows, same word offset) fall into 16 different bank groups
+// (16 consecutive rows, same word offset) fall into 16 different bank groups
 __host__ __device__ inline int clique_padded_stride(int w) {
   int p = (w + 3) & ~3;
   if (((p >> 2) & 1) == 0) p += 4;
   return p;
+}
+// ... but the padding is dropped when only the unpadded copy fits the budget: a whole matrix with some bank conflicts beats
+// column blocks (class X) -- rows of 897..1000 entries (stride 29..32 -> 32 words instead of 36)
+__host__ __device__ inline int clique_copy_stride(int d, int w, int budget_words) {
+  const int p = clique_padded_stride(w), q = (w + 3) & ~3;
+  return ((long long)d * p <= budget_words || (long long)d * q > budget_words) ? p : q;
 }
 // count classes (LDS budget of the copy, in words): S = 4 waves / 32 KB (3 workgroups per CU), L = 16 waves / 112 KB (one per CU),
 // X = rows wider than L's budget: counted in COLUMN BLOCKS of the matrix
@@ -279,7 +286,7 @@ __host__ __device__ inline int clique_padded_stride(int w) {
 #define GM_COUNT_WAVES_L 16
 #endif
 constexpr int kCountWavesS = 4, kCountWordsS = 8192;
-constexpr int kCountWavesL = GM_COUNT_WAVES_L, kCountWordsL = 28672;
+constexpr int kCountWavesL = GM_COUNT_WAVES_L, kCountWordsL = 32000;  // 125 KB + 16 x 2 KB of position lists: 157 KB
 constexpr int kCountWavesX = GM_COUNT_WAVES_L;
 struct CliqueCountParams {
   const int *rp;
@@ -297,8 +304,9 @@ size_t clique_count_lds_bytes(int cls);
 int clique_count_threads(int cls);
 // class of a wide vertex: 0 = S, 1 = L (whole padded matrix in LDS), 2 = X (column blocks, runs on the L instantiation)
 __host__ __device__ inline int clique_count_class(int d) {
-  const long long words = (long long)d * clique_padded_stride((d + 31) / 32);
-  return words <= kCountWordsS ? 0 : (words <= kCountWordsL ? 1 : 2);
+  const int w = (d + 31) / 32;
+  if ((long long)d * clique_copy_stride(d, w, kCountWordsS) <= kCountWordsS) return 0;
+  return (long long)d * clique_copy_stride(d, w, kCountWordsL) <= kCountWordsL ? 1 : 2;
 }
 
 // host-side launchers (gm_mine.hip)

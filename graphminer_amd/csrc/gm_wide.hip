@@ -19,17 +19,21 @@
 
 namespace gm {
 
-// ---- phase 1: build the rows of one ROW GROUP of a wide vertex ---------------------------------------------------------------
-// The chunk is the task edges (u, A[t0 .. t0 + rows)), A = N+(u). The rows are built in LDS exactly like a staged chunk of the
-// mining kernel (pass X: stream N+(v) through the hashed filter of the staged row A, bisect the survivors in LDS; pass Y: keys
-// of A bisect N+(v) in HBM / L2) and flushed with coalesced stores into the vertex's matrix in the arena. Building is
-// latency-bound streaming -- occupancy is what counts -- so this workgroup is lean: 4 KB stage + 4 KB filter + 4 KB of rows +
-// 4 x 2.4 KB of pass scratch = 22 KB, seven workgroups (28 waves) per CU like TC; mine_kernel<PAT_CLIQUE4> (29.5 KB, 95 VGPRs)
-// runs five. Rows longer than the 1024-entry stage (d+ 1025..2048) are searched in HBM / L2.
+// ---- phase 1: build rows of a wide vertex ---------------------------------------------------------------------------------
+// The chunk is a ROW RANGE of a wide vertex: the task edges (u, A[t0 .. t0 + rows)), A = N+(u), rows <= kBuildRowsPerChunk.
+// The workgroup stages A and its hashed filter once; then every WAVE takes batches of kBuildBatchRows edges on its own, builds
+// their rows in its private 1 KB of LDS exactly like a staged chunk of the mining kernel (pass X: stream N+(v) through the
+// filter, bisect the survivors in LDS; pass Y: keys of A bisect N+(v) in HBM / L2) and writes the finished rows straight into
+// the vertex's matrix in the arena -- rows are independent, so there is no workgroup barrier between batches. (The first
+// version built 32-row groups with a barrier per group: the group waited for its slowest wave, and the batch size decided
+// the kernel: 32-edge batches 139 ms, 8: 69.6, 4: 64 -- profiles/r02/ab_clique4_build_batch.log.) Building is latency-bound
+// streaming -- occupancy is what counts -- so the workgroup is lean: 4 KB stage + 4 KB filter + 4 x 1 KB of rows + 4 x 2.4 KB of
+// pass scratch = 22 KB, seven workgroups (28 waves) per CU like TC; mine_kernel<PAT_CLIQUE4> (29.5 KB, 95 VGPRs) runs five.
+// Rows longer than the 1024-entry stage (d+ 1025..2048) are searched in HBM / L2.
 struct alignas(16) BuildLds {
   int stage[kStageCapClique];     // N+(u) (first member: the bisection may read past the row, never past LDS)
   unsigned fbits[kFilterWords];   // hashed membership filter of the row (salt 0)
-  unsigned bits[kBuildBitWords];  // the group's rows: rows x stride words
+  unsigned bits[kWavesPerBlock][kBuildBatchRows * (kWideMaxDeg / 32)];  // per wave: the rows of its current batch
   int next_batch;
   unsigned queue_pos;
   WaveLdsLean w[kWavesPerBlock];
@@ -43,6 +47,7 @@ __global__ __launch_bounds__(kWavesPerBlock *GM_WAVE, 7) void clique_build_kerne
   const int tid = threadIdx.x, lane = tid & (GM_WAVE - 1), wave = tid >> 6;
   constexpr int NT = kWavesPerBlock * GM_WAVE;
   WaveLdsLean &L = B.w[wave];
+  unsigned *wb = B.bits[wave];
   for (;;) {
     if (tid == 0) B.queue_pos = atomicAdd(p.queue, 1u);
     __syncthreads();
@@ -50,13 +55,12 @@ __global__ __launch_bounds__(kWavesPerBlock *GM_WAVE, 7) void clique_build_kerne
     if (q >= (unsigned)p.count) break;
     const ChunkRec r = p.chunks[q];
     const int u = r.u_begin, ru = rp[u], d = rp[u + 1] - ru, stride = (d + 31) >> 5;
-    const int t0 = r.e_begin - ru, rows = r.e_end - r.e_begin;  // rows * stride <= kBuildBitWords (host: clique_group_rows)
+    const int t0 = r.e_begin - ru, rows = r.e_end - r.e_begin;
     const bool staged = d <= kStageCapClique;
     if (staged) {
       for (int i = tid; i < d; i += NT) B.stage[i] = col[ru + i];
       for (int i = tid; i < kFilterWords; i += NT) B.fbits[i] = 0u;
     }
-    for (int i = tid; i < rows * stride; i += NT) B.bits[i] = 0u;
     if (tid == 0) B.next_batch = 0;
     __syncthreads();
     if (staged) {
@@ -66,15 +70,18 @@ __global__ __launch_bounds__(kWavesPerBlock *GM_WAVE, 7) void clique_build_kerne
       }
       __syncthreads();
     }
-    const int bsz = r.batch;  // small batches: every edge of a wide vertex streams a long list, 8 of them keep the 4 waves balanced
-    for (;;) {
+    unsigned *__restrict__ gm = p.mat + p.base[r.pad_ - 1] + (size_t)t0 * stride;  // the chunk's rows in the vertex's matrix
+    constexpr int bsz = kBuildBatchRows;
+    for (;;) {  // waves take batches on their own: no workgroup barrier until the chunk is done
       int bi = 0;
       if (lane == 0) bi = atomicAdd(&B.next_batch, 1);
       bi = readfirst(bi);
       const int l0 = bi * bsz;  // first local row of the batch
       if (l0 >= rows) break;
+      const int nr = min(bsz, rows - l0);
+      for (int i = lane; i < nr * stride; i += GM_WAVE) wb[i] = 0u;
       const int lr = l0 + lane;
-      const bool valid = (lane < bsz) && (lr < rows);
+      const bool valid = (lane < nr);
       int rv = 0, b = 0;
       if (valid) {
         if (edesc) {
@@ -98,19 +105,18 @@ __global__ __launch_bounds__(kWavesPerBlock *GM_WAVE, 7) void clique_build_kerne
           dirx = b <= d;
         }
       }
-      auto set_bit = [&](const int owner, const int cbit) {
-        atomicOr(&B.bits[(l0 + owner) * stride + (cbit >> 5)], 1u << (cbit & 31));
-      };
+      wave_sync();  // the row buffer is zeroed
+      auto set_bit = [&](const int owner, const int cbit) { atomicOr(&wb[owner * stride + (cbit >> 5)], 1u << (cbit & 31)); };
       auto actx = [&](bool f, int owner, int, int pos, int, int) { if (f) set_bit(owner, pos); };   // pos: position in N+(u)
       auto acty = [&](bool f, int owner, int kidx, int, int, int) { if (f) set_bit(owner, kidx); };  // kidx: index of the key in N+(u)
       if (staged) flat_pass_filtered(L, B.stage, B.fbits, col, lane, (act && dirx) ? b : 0, rv, 0, d, 0, actx);
       else flat_pass<SEARCH_HBM>(L, B.stage, col, nullptr, lane, (act && dirx) ? b : 0, rv, ru, d, actx);
       flat_pass<SEARCH_HBM>(L, B.stage, col, nullptr, lane, (act && !dirx) ? d : 0, ru, rv, b, acty);
+      wave_sync();
+      for (int i = lane; i < nr * stride; i += GM_WAVE) gm[(size_t)l0 * stride + i] = wb[i];  // finished rows: contiguous in the arena
+      wave_sync();
     }
-    __syncthreads();
-    unsigned *__restrict__ gm = p.mat + p.base[r.pad_ - 1] + (size_t)t0 * stride;
-    for (int i = tid; i < rows * stride; i += NT) gm[i] = B.bits[i];  // the finished rows: contiguous in the arena
-    __syncthreads();
+    __syncthreads();  // every wave is done with the stage / filter
   }
 }
 
@@ -242,10 +248,10 @@ __global__ __launch_bounds__(WAVES *GM_WAVE, 1) void clique_count_kernel(const C
     const unsigned *__restrict__ gm = p.mat + p.base[slot];
     // column blocks: the fewest equal blocks of cw words whose padded copy (d rows of ps words) fits the LDS budget and the
     // register budget of a row (one block for classes S / L). d <= kWideMaxDeg: a block of <= 8 words always fits.
-    int cw = stride, ps = clique_padded_stride(cw);
+    int cw = stride, ps = clique_copy_stride(d, cw, WORDS);
     for (int nb = 2; (long long)d * ps > WORDS || ps > 4 * kCountMaxQ; ++nb) {
       cw = (stride + nb - 1) / nb;
-      ps = clique_padded_stride(cw);
+      ps = clique_copy_stride(d, cw, WORDS);
     }
     const int nq = ps >> 2;
     for (int c0 = 0; c0 < stride; c0 += cw) {
@@ -267,11 +273,15 @@ __global__ __launch_bounds__(WAVES *GM_WAVE, 1) void clique_count_kernel(const C
       // (WHOLE instantiations -- classes S / L -- only ever see one block: clique_count_class and the loop above agree)
 #define GM_COUNT_CASE(NQ) \
   case NQ: tot += count_block<NQ, WHOLE>(S.bits, plist, &S.next_row, gm, d, stride, lane); break;
-      switch (nq) {  // (the padded stride has an odd quarter)
+      switch (nq) {
         GM_COUNT_CASE(1)
+        GM_COUNT_CASE(2)
         GM_COUNT_CASE(3)
+        GM_COUNT_CASE(4)
         GM_COUNT_CASE(5)
+        GM_COUNT_CASE(6)
         GM_COUNT_CASE(7)
+        GM_COUNT_CASE(8)
         default: tot += count_block<9, WHOLE>(S.bits, plist, &S.next_row, gm, d, stride, lane); break;
       }
 #undef GM_COUNT_CASE
