@@ -986,7 +986,7 @@ __global__ __launch_bounds__(256) void tab_parts_kernel(int n0, const ChunkRec *
   int np = 1;
   if (cut) {
     const int batches = (r.e_end - r.e_begin + bsz - 1) / bsz;
-    const int min_batches = stage_cap == kStageCapBig ? 64 : (stage_cap == kStageCapMid ? 16 : 1);
+    const int min_batches = stage_cap == kStageCapBig ? 64 : (stage_cap == kStageCapMid ? 32 : 1);
     const unsigned long long want = (cost[c] + cap - 1) / cap;
     np = (int)max(1ull, min((unsigned long long)max(batches / min_batches, 1), want));
   }
@@ -1281,7 +1281,7 @@ static int get_table(gm_graph *g, int target, bool allow_split, int bit_words, u
       const int batches = (recs[i].e_end - recs[i].e_begin + bsz - 1) / bsz;
       // a part must keep every wave of its workgroup busy for several batches: the 16-wave class takes batches of 4 edges
       // (its rows' partners are thousands of keys long) and parts of >= 64 batches, the 4-wave classes parts of >= 16
-      const int min_batches = stage_cap == kStageCapBig ? 64 : (stage_cap == kStageCapMid ? 16 : 1);
+      const int min_batches = stage_cap == kStageCapBig ? 64 : (stage_cap == kStageCapMid ? 32 : 1);
       const int np = (int)std::max<unsigned long long>(1, std::min<unsigned long long>((unsigned long long)std::max(batches / min_batches, 1), (cost[i] + cap - 1) / cap));
       for (int q = 0; q < np; ++q) {
         ChunkRec r = recs[i];

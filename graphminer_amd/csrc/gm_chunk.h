@@ -22,9 +22,13 @@ namespace gm {
 //   CLS 2 "big": rows of 8192..24576 entries, staged whole (96 KB) behind a 2^17-bit filter, 16 waves, one workgroup per CU.
 // Their chunks are whole single rows (cut into PARTS by estimated work), so they go through the ordinary staged path of
 // process_chunk: LDS filter -> candidate queue -> bisection in LDS, no bitmap, no HBM probe.
+// class 1 keeps two workgroups per CU: 8 waves each (63 KB) = 16 waves per CU for the 3-motif kernels (91 VGPRs); 12 waves
+// each (74 KB) = 24 per CU for diamond, whose 80 VGPRs allow six waves per SIMD.  (4 waves x three workgroups = 12 per CU was
+// 11 % slower on R-MAT-24; 10 waves -- not a multiple of the four SIMDs -- 12 % slower than 8: profiles/r02/ab_mid_waves.log.)
+constexpr __host__ __device__ int mid_waves_of(int pat) { return pat == PAT_DIAMOND ? 12 : 8; }
 template <int PAT, int CLS>
 struct MineCfg {
-  static constexpr int waves = CLS == 2 ? 16 : kWavesPerBlock;
+  static constexpr int waves = CLS == 2 ? 16 : (CLS == 1 ? mid_waves_of(PAT) : kWavesPerBlock);
   static constexpr int stage = CLS == 0 ? stage_cap_of(PAT) : CLS == 1 ? kStageCapMid : kStageCapBig;
   static constexpr int fl2 = CLS == 0 ? kFilterLog2 : CLS == 1 ? 16 : 17;
   static constexpr bool multi_row = CLS == 0;  // the wide classes stage ONE row: no per-entry local row table
@@ -773,7 +777,7 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT,
 // give up at 74 VGPRs = 6 waves per SIMD once the edge descriptors were added; asking for 7 makes it fit the 72 of 7 waves)
 // The symmetric-graph patterns (31.5 KB of LDS: 5 workgroups per CU) get 5 for the same reason: 96 VGPRs, not 97.
 template <int PAT, int CLS = 0>
-__global__ __launch_bounds__((MineCfg<PAT, CLS>::waves * GM_WAVE), (CLS == 2 ? 1 : CLS == 1 ? 3 : PAT == PAT_CLIQUEK ? 4 : (PAT == PAT_TC ? GM_TC_WAVES : 5)))
+__global__ __launch_bounds__((MineCfg<PAT, CLS>::waves * GM_WAVE), (CLS == 2 ? 1 : CLS == 1 ? 2 : PAT == PAT_CLIQUEK ? 4 : (PAT == PAT_TC ? GM_TC_WAVES : 5)))
 void mine_kernel(const MineParams p) {
   __shared__ BlockLds<PAT, CLS> B;
   const int lane = threadIdx.x & (GM_WAVE - 1);

@@ -315,6 +315,6 @@ size_t mine_lds_bytes(Pattern pat);
 // the big-LDS classes (gm_mine_wide.hip): cls = 1 (mid rows) or 2 (big rows); DIAMOND, MOTIF3, MOTIF4E only
 hipError_t launch_mine_wide(Pattern pat, int cls, const MineParams &p, int grid_blocks, hipStream_t stream);
 size_t mine_wide_lds_bytes(int cls);
-int mine_wide_threads(int cls);
+int mine_wide_threads(Pattern pat, int cls);
 
 }  // namespace gm

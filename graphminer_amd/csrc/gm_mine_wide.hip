@@ -8,14 +8,15 @@
 namespace gm {
 
 size_t mine_wide_lds_bytes(int cls) { return cls == 2 ? sizeof(BlockLds<PAT_DIAMOND, 2>) : sizeof(BlockLds<PAT_DIAMOND, 1>); }
-int mine_wide_threads(int cls) { return GM_WAVE * (cls == 2 ? MineCfg<PAT_DIAMOND, 2>::waves : MineCfg<PAT_DIAMOND, 1>::waves); }
+int mine_wide_threads(Pattern pat, int cls) { return GM_WAVE * (cls == 2 ? MineCfg<PAT_DIAMOND, 2>::waves : mid_waves_of(pat)); }
 
 hipError_t launch_mine_wide(Pattern pat, int cls, const MineParams &p, int grid_blocks, hipStream_t stream) {
   static_assert(sizeof(BlockLds<PAT_DIAMOND, 2>) <= 163840, "class 2 must fit the 160 KB of one CU");
-  static_assert(sizeof(BlockLds<PAT_DIAMOND, 1>) * 3 <= 163840, "three class-1 workgroups per CU");
-  const dim3 grid((unsigned)grid_blocks), block((unsigned)mine_wide_threads(cls));
+  static_assert(sizeof(BlockLds<PAT_DIAMOND, 1>) * 2 <= 163840, "two class-1 workgroups per CU");
+  const dim3 grid((unsigned)grid_blocks), block((unsigned)mine_wide_threads(pat, cls));
 #define GM_WIDE_CASE(P)                                                                          \
   case P:                                                                                        \
+    static_assert(MineCfg<P, 1>::waves == mid_waves_of(P), "launch width = the kernel's");         \
     if (cls == 2) hipLaunchKernelGGL((mine_kernel<P, 2>), grid, block, 0, stream, p);             \
     else hipLaunchKernelGGL((mine_kernel<P, 1>), grid, block, 0, stream, p);                      \
     break;
