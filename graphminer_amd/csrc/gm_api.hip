@@ -1766,13 +1766,15 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
                            ((la->tune[6] & 0x100000) || g->nv > (1 << 23));
   RowFilter rf;
   rf.skip_clique_wide = use_wide ? clique_wide_min_words() : 0;
-  if (use_classes) { rf.skip_lo = kStageCapWide; rf.skip_hi = kStageCapBig; }
+  int cls_lo = kStageCapWide;
+  if (const char *e = getenv("GM_CLS_LO")) cls_lo = std::max(64, atoi(e));  // (sweeps)
+  if (use_classes) { rf.skip_lo = cls_lo; rf.skip_hi = kStageCapBig; }
   int rc = get_table(g, target, !clique, clique ? kBitWords : 0, part_cap, stage_cap_of(pat), &tab, rf, use_classes ? kStageCapBig : kBitmapMinDeg);
   if (rc) return rc;
   ChunkTable *tab_cls[3] = {tab, nullptr, nullptr};
   if (use_classes) {
     RowFilter r1, r2;
-    r1.only_lo = kStageCapWide; r1.only_hi = kStageCapMid;
+    r1.only_lo = cls_lo; r1.only_hi = kStageCapMid;
     r2.only_lo = kStageCapMid; r2.only_hi = kStageCapBig;
     // Parts of the one-row chunks: coarse. Measured on MI355X (profiles/r02/ab_sym_classes.log, diamond / 3-motif R-MAT-24, ms):
     // whole rows (largest chunk 6e7 estimated keys) 636 / 370; parts of 512 K keys 1277 / 765 (16-wave workgroups with ~10
@@ -1855,6 +1857,7 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
   p.k = k;
   p.flags = (la->tune[5] == 1) ? 1 : 0;
   p.flags |= (la->tune[6] & 0xffff) << 1;  // debug/ablation: bit1 skip clique phase 2, bit2 skip bit-matrix writes (counts wrong)
+  if (la->tune[6] & 0x800000) p.flags |= 1 << 22;  // hashed-row classes: every lookup through the global-memory fallback (tests)
   if (la->tune[6] & 0x200000) p.flags |= 1 << 20;  // k >= 5: the any-width pair count instead of the tile walk (tests)
   p.counters = g->d_counters;
   p.queue = reinterpret_cast<unsigned *>(g->d_counters + 4);
@@ -1961,7 +1964,10 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
       q.queue = reinterpret_cast<unsigned *>(g->d_counters + 4) + cls;  // its own dequeue word inside the zeroed 64-byte block
       if (q.count == 0) continue;
       chunks_total += (uint64_t)q.count;
-      const int per_cu_w = (int)std::max<size_t>(1, (160 * 1024) / mine_wide_lds_bytes(cls));
+      // the row as a hashed set in LDS (gm_hrow.hip) unless the ids are too wide for its 14-bit remainders
+      // (tune[6] & 0x400000: A/B switch, the sorted LDS copy + bit filter + bisection of gm_mine_wide.hip)
+      const bool hrow = !(la->tune[6] & 0x400000) && p.g.edesc != nullptr && hrow_fits(g->nv, cls);
+      const int per_cu_w = hrow ? hrow_per_cu(cls) : (int)std::max<size_t>(1, (160 * 1024) / mine_wide_lds_bytes(cls));
       const int wgrid = (int)std::max<long long>(1, std::min<long long>(q.count, (long long)g->cu_count * per_cu_w));
       hipStream_t ws = stream;
       if (getenv("GM_CLASSES_STREAMS")) {  // (measured: side streams 743 / 462 ms vs one stream 699 / 426 ms -- off by default)
@@ -1972,7 +1978,8 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
         ws = g->aux_stream[cls - 1];
         HIP_TRY(hipStreamWaitEvent(ws, ctx.evp[0], 0));  // after the counters were zeroed and the timer started
       }
-      HIP_TRY(launch_mine_wide(pat, cls, q, wgrid, ws));
+      if (hrow) HIP_TRY(launch_hrow(pat, cls, q, wgrid, ws));
+      else HIP_TRY(launch_mine_wide(pat, cls, q, wgrid, ws));
       if (ws != stream) {
         HIP_TRY(hipEventRecord(g->aux_done[cls - 1], ws));
         joined[cls - 1] = true;

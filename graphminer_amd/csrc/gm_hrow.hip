@@ -1,0 +1,438 @@
+// gm_hrow.hip -- hashed-row workgroup classes of the symmetric-graph patterns (diamond, 3-motif, the per-edge sums of the
+// formula 4-motif): one row of 3073..24576 entries per chunk, kept in LDS as a HASH-PARTITIONED SET instead of a sorted copy.
+//
+// Why (profiles/r02/diamond_rmat24_pmc_summary.txt): on the hub rows of a skewed graph HALF of the streamed keys pass the bit
+// filter of the sorted-copy classes (true common neighbours + 17 % false positives), and each of them then pays a 13..15 step
+// bisection of the LDS copy -- 74 VALU instructions and 12 LDS instructions per 64 streamed keys, VALU 71 % and LDS 65 % busy
+// (62 % of the LDS cycles are bank conflicts of the bisection's random reads).  A membership test is all these patterns need
+// (sgl diamond: |N(u) ^ N(v)| per edge, src/sgl/cpu_kernels/diamond.h:5-12; 3-motif: bounded intersections,
+// src/motif/cpu_kernels/automine_base.h:8-24), so the row is stored as a set:
+//   * ids are mapped through a bijection of [0, 2^K), K = bits of nv:  h = (id * C_K) mod 2^K, C_K odd (Fibonacci constant of 2^K);
+//   * the top LB bits of h pick one of 2^LB buckets of eight 16-bit slots (one 16-byte LDS line), the low K - LB <= 14 bits
+//     are what is stored: bucket and remainder together ARE the id, the test is exact with 2 bytes per entry;
+//   * 2^LB ~ n/3 (8 slots for ~3 entries: on R-MAT rows 0.02 % of the entries do not fit); a bucket that overflowed is flagged
+//     and its surplus ids sit in a small list (<= 128 per row) that only the lanes missing in a flagged bucket scan;
+//   * lookup = one multiply, one ds_read_b128, a packed has-zero-halfword test: no queue, no compaction, no bisection.
+// A row that overflows the surplus list (adversarial ids) is looked up by bisection of the row in global memory -- slow, exact.
+// Every task edge streams the partner list (pass X); pass Y does not exist here (the longer row hosts, gm_mine.h sym_hosts).
+#include "gm_flat.h"
+
+namespace gm {
+
+constexpr int kHrowOvfCap = 128;
+constexpr int kHrowRemBits = 14;  // stored remainder bits (bit 14 = "empty" pattern 0x7fff, bit 15 of slot 7 = overflow flag)
+constexpr int kHrowTiles = 4;     // 64-key tiles in flight per wave
+
+template <int CLS>
+struct HrowCfg {
+  static constexpr int waves = CLS == 2 ? 16 : 8;
+  static constexpr int lbmax = CLS == 2 ? kHrowLbBig : kHrowLbMid;
+  static constexpr int per_cu = CLS == 2 ? 1 : 3;
+};
+
+struct alignas(16) HrowWave {
+  int delta[GM_WAVE];                // per batch lane: key_base - offset of its list among the flattened positions
+  unsigned cnt[GM_WAVE];             // per batch lane: match count (diamond / 4-motif) or its partner vertex (3-motif)
+  unsigned char marks[kMarkWindow];  // owner marks of the flattened positions
+};
+
+template <int CLS>
+struct alignas(16) HrowLds {
+  unsigned short table[(1 << HrowCfg<CLS>::lbmax) * 8];
+  HrowWave w[HrowCfg<CLS>::waves];  // (while the table is built: packed 16-bit fill counters of the buckets)
+  int ovf[kHrowOvfCap];
+  int n_ovf;
+  int next_batch;
+  unsigned queue_pos;
+  int pad_;
+};
+static_assert(kHrowOvfCap == 2 * GM_WAVE, "the surplus list is scanned two entries per lane");
+static_assert(sizeof(HrowWave) * HrowCfg<2>::waves >= (size_t)(2 << kHrowLbBig), "fill counters alias the wave scratch");
+static_assert(sizeof(HrowWave) * HrowCfg<1>::waves >= (size_t)(2 << kHrowLbMid), "fill counters alias the wave scratch");
+
+struct HrowView {  // wave-uniform
+  unsigned ck, kmask, rmask;
+  int sh;        // K - LB
+  int n_ovf;
+  bool fallback; // the set is not usable: bisect the row in global memory
+};
+
+template <bool K24>
+__device__ __forceinline__ unsigned hrow_hash(const HrowView &hv, int key) {
+  const unsigned h = K24 ? __umul24((unsigned)key, hv.ck) : (unsigned)key * hv.ck;
+  return h & hv.kmask;
+}
+
+// Which of the T keys of this lane are in the row?  (in[q] = the lane carries a key in tile q.)  The T hashes, the T 16-byte
+// reads and the T packed tests are issued together; the rare paths (a flagged bucket missed, the fallback) cost one
+// wave-uniform branch per tile group.
+template <bool K24, int T, class LdsT>
+__device__ __forceinline__ void hrow_member(const LdsT &B, const HrowView &hv, const int *__restrict__ row, const int n_row,
+                                            const int (&key)[T], const bool (&in)[T], bool (&f)[T]) {
+  if (hv.fallback) {  // wave-uniform
+#pragma unroll
+    for (int q = 0; q < T; ++q) {
+      f[q] = false;
+      if (in[q]) {
+        const int pos = lower_bound(row, n_row, key[q]);
+        f[q] = pos < n_row && row[pos] == key[q];
+      }
+    }
+    return;
+  }
+  uint4 w[T];
+  unsigned rr[T];
+#pragma unroll
+  for (int q = 0; q < T; ++q) {
+    const unsigned h = hrow_hash<K24>(hv, key[q]);
+    const unsigned rem = h & hv.rmask;
+    rr[q] = rem | (rem << 16);
+    w[q] = *reinterpret_cast<const uint4 *>(&B.table[(h >> hv.sh) << 3]);
+  }
+  bool need[T], any_need = false;
+#pragma unroll
+  for (int q = 0; q < T; ++q) {
+    const unsigned c = 0x00010001u;
+    const unsigned t0 = w[q].x ^ rr[q], t1 = w[q].y ^ rr[q], t2 = w[q].z ^ rr[q], t3 = (w[q].w & 0x7fffffffu) ^ rr[q];
+    // a halfword of t is zero <=> that slot holds rem: (t - 0x00010001) & ~t & 0x80008000 is non-zero iff some halfword is zero
+    const unsigned z = ((t0 - c) & ~t0) | ((t1 - c) & ~t1) | ((t2 - c) & ~t2) | ((t3 - c) & ~t3);
+    f[q] = in[q] & ((z & 0x80008000u) != 0u);
+    need[q] = in[q] & !f[q] & ((int)w[q].w < 0);  // missed in a bucket that overflowed: the surplus list decides
+    any_need |= need[q];
+  }
+  if (__ballot(any_need) != 0ull) {
+    // The surplus list (<= 128 ids, unused entries -1) is spread over the lanes, two entries each; every key that needs it
+    // (typically one or two lanes of a tile) is broadcast and compared by all lanes at once.
+    const int lane = lane_id();
+    const int o0 = B.ovf[lane], o1 = B.ovf[lane + GM_WAVE];
+#pragma unroll
+    for (int q = 0; q < T; ++q) {
+      unsigned long long nm = __ballot(need[q]);
+      while (nm) {
+        const int src = __ffsll((long long)nm) - 1;
+        nm &= nm - 1;
+        const int k = readlane(key[q], src);
+        const bool any = __ballot((o0 == k) | (o1 == k)) != 0ull;
+        f[q] |= (lane == src) & any;
+      }
+    }
+  }
+}
+
+template <bool K24, class LdsT>
+struct HashedRow {
+  const LdsT &B;
+  const HrowView &hv;
+  const int *__restrict__ row;
+  int n_row;
+  __device__ __forceinline__ void operator()(const int (&key)[kHrowTiles], const bool (&in)[kHrowTiles], bool (&f)[kHrowTiles]) const {
+    hrow_member<K24, kHrowTiles>(B, hv, row, n_row, key, in, f);
+  }
+};
+
+// One batch of task edges of the row: stream the partner lists against the set (member = the membership test of kHrowTiles keys).
+//   llen_all / key_base: this lane's partner list (0 = no task), vpart: its partner vertex
+// DIAMOND / MOTIF4E: per-edge match counts end up in L.cnt[lane] (+ n_long for the lists streamed one at a time)
+// MOTIF3: m_any = matches below max(u, v), m_low = matches below min(u, v), accumulated per lane
+template <int PAT, class Member>
+__device__ __forceinline__ void hrow_pass(HrowWave &L, const Member &member, const int *__restrict__ col, const int u, const int lane,
+                                          const int llen_all, const int key_base, const int vpart, unsigned &n_long, unsigned &m_any,
+                                          unsigned &m_low) {
+  constexpr bool kPerEdge = PAT != PAT_MOTIF3;
+  constexpr int T = kHrowTiles;
+  if (wave_max_nonneg(llen_all) == 0) return;  // wave-uniform
+  const bool is_long = llen_all >= kLongList;
+  const int llen = is_long ? 0 : llen_all;
+
+  // ---- long lists: one task edge at a time, wave-uniform base / bounds ------------------------------------------------
+  unsigned long long lm = __ballot(is_long);
+  while (lm) {
+    const int src = __ffsll((long long)lm) - 1;
+    lm &= lm - 1;
+    const int base = readlane(key_base, src);
+    const int n = readlane(llen_all, src);
+    const int vv = readlane(vpart, src);
+    const int hi = max(u, vv), lo = min(u, vv);
+    const int *__restrict__ kp = col + base;
+    unsigned cnt_s = 0;  // wave-uniform
+    auto process = [&](const int (&key)[T], const bool (&in)[T]) {
+      bool f[T];
+      member(key, in, f);
+#pragma unroll
+      for (int q = 0; q < T; ++q) {
+        if (kPerEdge) {
+          cnt_s += (unsigned)__popcll(__ballot(f[q]));
+        } else {
+          const bool fa = f[q] & (key[q] < hi), fl = fa & (key[q] < lo);
+          m_any += fa ? 1u : 0u;
+          m_low += fl ? 1u : 0u;
+        }
+      }
+    };
+    constexpr int G = GM_WAVE * T;
+    int nxt[T];
+#pragma unroll
+    for (int q = 0; q < T; ++q) nxt[q] = kp[min(q * GM_WAVE + lane, n - 1)];
+    int t = 0;
+    for (; t + 2 * G <= n; t += G) {  // full groups whose successor is full too: unconditional, unclamped loads
+      int key[T];
+      bool in[T];
+#pragma unroll
+      for (int q = 0; q < T; ++q) {
+        key[q] = nxt[q];
+        in[q] = true;
+      }
+      const int *__restrict__ kn = kp + (t + G);
+#pragma unroll
+      for (int q = 0; q < T; ++q) nxt[q] = kn[(unsigned)(q * GM_WAVE + lane)];
+      process(key, in);
+    }
+    for (; t < n; t += G) {
+      int key[T];
+      bool in[T];
+#pragma unroll
+      for (int q = 0; q < T; ++q) {
+        key[q] = nxt[q];
+        in[q] = (t + q * GM_WAVE + lane) < n;
+      }
+#pragma unroll
+      for (int q = 0; q < T; ++q) nxt[q] = kp[min(t + G + q * GM_WAVE + lane, n - 1)];
+      process(key, in);
+    }
+    if (kPerEdge) n_long += (lane == src) ? cnt_s : 0u;
+  }
+
+  // ---- short lists: flattened (owner marks + DPP max-scan; tiles without a list boundary skip the scan) ----------------
+  const int incl = wave_incl_scan_add(llen);
+  const int total = readlane(incl, GM_WAVE - 1);
+  if (total == 0) return;  // wave-uniform
+  const int off = incl - llen;
+  L.delta[lane] = key_base - off;
+  unsigned *m32 = reinterpret_cast<unsigned *>(L.marks);
+  int carry = 0;
+  for (int wb = 0; wb < total; wb += kMarkWindow) {
+    const int wn = min(kMarkWindow, total - wb);
+    const int nwords = ((wn + GM_WAVE * T - 1) / (GM_WAVE * T)) * (GM_WAVE * T / 4);
+    for (int i = lane; i < nwords; i += GM_WAVE) m32[i] = 0u;
+    wave_sync();
+    if (llen > 0 && off >= wb && off < wb + kMarkWindow) L.marks[off - wb] = (unsigned char)(lane + 1);
+    wave_sync();
+    for (int t = 0; t < wn; t += GM_WAVE * T) {
+      int own[T], key[T];
+      bool in[T], one_owner[T];
+#pragma unroll
+      for (int q = 0; q < T; ++q) own[q] = (int)L.marks[t + q * GM_WAVE + lane];
+#pragma unroll
+      for (int q = 0; q < T; ++q) {
+        one_owner[q] = __ballot(own[q] != 0) == 0ull;  // wave-uniform: no list starts inside this tile
+        if (one_owner[q]) {
+          own[q] = carry;
+        } else {
+          own[q] = max(wave_incl_scan_max(own[q]), carry);
+          carry = readlane(own[q], GM_WAVE - 1);
+        }
+      }
+      int dl[T];
+#pragma unroll
+      for (int q = 0; q < T; ++q) {
+        const int p = wb + t + q * GM_WAVE + lane;
+        in[q] = p < total;
+        own[q] = in[q] ? own[q] - 1 : 0;
+        dl[q] = L.delta[own[q]];  // unconditional LDS read
+      }
+#pragma unroll
+      for (int q = 0; q < T; ++q) key[q] = col[in[q] ? dl[q] + (wb + t + q * GM_WAVE + lane) : 0];  // unconditional load (select on the index)
+      bool f[T];
+      member(key, in, f);
+      if (kPerEdge) {
+#pragma unroll
+        for (int q = 0; q < T; ++q) {
+          // a tile of one owner adds its count once (64 atomics on one LDS word would serialise)
+          const unsigned c = (unsigned)__popcll(__ballot(f[q]));
+          const bool add = one_owner[q] ? (lane == 0 && c != 0u) : f[q];
+          if (add) atomicAdd(&L.cnt[own[q]], one_owner[q] ? c : 1u);
+        }
+      } else {
+        int vv[T];
+#pragma unroll
+        for (int q = 0; q < T; ++q) vv[q] = (int)L.cnt[own[q]];
+#pragma unroll
+        for (int q = 0; q < T; ++q) {
+          const bool fa = f[q] & (key[q] < max(u, vv[q])), fl = fa & (key[q] < min(u, vv[q]));
+          m_any += fa ? 1u : 0u;
+          m_low += fl ? 1u : 0u;
+        }
+      }
+    }
+    wave_sync();
+  }
+}
+
+template <int PAT, int CLS, bool K24>
+__device__ __forceinline__ void hrow_chunk(const MineParams &p, HrowLds<CLS> &B, const ChunkRec r, const int lane, const int wave,
+                                           Acc &acc) {
+  using Cfg = HrowCfg<CLS>;
+  const int *__restrict__ rp = p.g.rp;
+  const int *__restrict__ col = p.g.col;
+  const int2 *__restrict__ edesc = p.g.edesc;
+  const int tid = threadIdx.x, nthreads = Cfg::waves * GM_WAVE;
+  const int u = r.u_begin;
+  const int ru = rp[u], n_row = rp[u + 1] - ru;
+  const int eb = r.e_begin, nel = r.e_end - r.e_begin;
+
+  // ---- workgroup: build the set --------------------------------------------------------------------------------------
+  HrowView hv;
+  const int K = max(bitlen(p.g.nv - 1), 1);
+  const int LB = min(min(Cfg::lbmax, K), max(K - kHrowRemBits, bitlen((n_row - 1) / 3)));
+  hv.sh = K - LB;
+  hv.kmask = (K >= 32) ? 0xffffffffu : ((1u << K) - 1u);
+  hv.rmask = (1u << hv.sh) - 1u;
+  hv.ck = (unsigned)(0x9E3779B97F4A7C15ull >> (64 - K)) | 1u;
+  // (more than 14 remainder bits -- nv beyond what the host sends here -- or the test switch: every lookup bisects the row in global memory)
+  hv.fallback = (p.flags & (1 << 22)) != 0 || hv.sh > kHrowRemBits;
+  const int nb = 1 << LB;
+  unsigned *fill32 = reinterpret_cast<unsigned *>(&B.w[0]);
+  {
+    const uint4 empty = make_uint4(0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu);
+    uint4 *t4 = reinterpret_cast<uint4 *>(B.table);
+    for (int i = tid; i < nb; i += nthreads) t4[i] = empty;
+    for (int i = tid; i < (nb + 1) / 2; i += nthreads) fill32[i] = 0u;
+    if (tid < kHrowOvfCap) B.ovf[tid] = -1;
+    if (tid == 0) {
+      B.n_ovf = 0;
+      B.next_batch = 0;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < n_row; i += nthreads) {
+    const int key = col[ru + i];
+    const unsigned h = hrow_hash<K24>(hv, key);
+    const unsigned b = h >> hv.sh, rem = h & hv.rmask;
+    const unsigned shift = (b & 1u) * 16u;
+    const unsigned slot = (atomicAdd(&fill32[b >> 1], 1u << shift) >> shift) & 0xffffu;
+    if (slot < 8u) {
+      B.table[(b << 3) + slot] = (unsigned short)rem;
+    } else {
+      const int j = atomicAdd(&B.n_ovf, 1);
+      if (j < kHrowOvfCap) B.ovf[j] = key;
+    }
+  }
+  __syncthreads();
+  for (int b = tid; b < nb; b += nthreads) {
+    const unsigned c = (fill32[b >> 1] >> ((b & 1) * 16)) & 0xffffu;
+    if (c > 8u) B.table[(b << 3) + 7] |= (unsigned short)0x8000u;
+  }
+  __syncthreads();  // (also: the fill counters are dead, the waves may use their scratch)
+  hv.n_ovf = B.n_ovf;
+  if (hv.n_ovf > kHrowOvfCap) hv.fallback = true;
+
+  // ---- waves: batches of task edges ----------------------------------------------------------------------------------
+  HrowWave &L = B.w[wave];
+  const HashedRow<K24, HrowLds<CLS>> member{B, hv, col + ru, n_row};
+  const int bsz = r.batch;
+  for (;;) {
+    int bi = 0;
+    if (lane == 0) bi = atomicAdd(&B.next_batch, 1);
+    bi = readfirst(bi) * r.nparts + r.part;
+    const int le0 = bi * bsz;
+    if (le0 >= nel) break;
+    const int le = le0 + lane;
+    const bool valid = (le < nel) && (lane < bsz);
+    const int e = eb + le;
+    const int2 desc = edesc[min(e, p.g.ne - 1)];  // {rp[v], d(v)} of the entry's destination, coalesced
+    const int v = col[min(e, p.g.ne - 1)];
+    const int rv = desc.x;
+    int b = desc.y;
+    const bool owns = sym_hosts(n_row, b, u, v, stage_cap_of(PAT));
+    bool act = valid && owns && b > 0;
+    if (PAT == PAT_MOTIF3) {
+      // (see process_chunk, gm_chunk.h: one bounded intersection per undirected edge serves both directed edges of
+      // automine_3motif; the sum of the positions idx over ALL directed edges is kept per lane)
+      if (valid) acc.c2 += (unsigned long long)(e - ru);
+      if (act && b >= 128) b = lower_bound(col + rv, b, max(u, v));  // only the keys below max(u, v) can count
+      act = act && b > 0;
+    }
+    L.cnt[lane] = (PAT == PAT_MOTIF3) ? (unsigned)v : 0u;
+    wave_sync();
+    unsigned n_long = 0, m_any = 0, m_low = 0;
+    hrow_pass<PAT>(L, member, col, u, lane, act ? b : 0, rv, v, n_long, m_any, m_low);
+    wave_sync();
+    if (PAT == PAT_MOTIF3) {
+      acc.c0 += (unsigned long long)m_any + (unsigned long long)m_low;  // I(lo,hi) + I(hi,lo)
+      acc.c1 += (unsigned long long)m_low;                              // triangles u > v > w, once
+    } else {
+      const unsigned long long tri = (unsigned long long)L.cnt[lane] + (unsigned long long)n_long;
+      if (PAT == PAT_DIAMOND) {
+        acc.c0 += tri * (tri - 1ull) / 2ull;  // C(n,2) (diamond_count.cuh:15-17); tri = 0 for lanes without a task
+      } else if (valid && owns) {            // PAT_MOTIF4E: per-edge sums of the formula 4-motif (automine_formula.h:30-39)
+        const unsigned long long su = (unsigned long long)n_row - tri - 1ull, sv = (unsigned long long)desc.y - tri - 1ull;
+        acc.c0 += su * (su - 1ull) + sv * (sv - 1ull);
+        acc.c1 += su * sv;
+        acc.c2 += tri * (su + sv);
+        acc.c3 += tri * (tri - 1ull);
+      }
+    }
+    wave_sync();
+  }
+  __syncthreads();  // the table is rebuilt by the next chunk
+}
+
+template <int PAT, int CLS, bool K24>
+__global__ __launch_bounds__((HrowCfg<CLS>::waves * GM_WAVE), (HrowCfg<CLS>::waves * HrowCfg<CLS>::per_cu / 4))  // (HIP: second bound = waves per SIMD)
+void hrow_kernel(const MineParams p) {
+  __shared__ HrowLds<CLS> B;
+  const int lane = threadIdx.x & (GM_WAVE - 1);
+  const int wave = threadIdx.x >> 6;
+  Acc acc;
+  for (;;) {
+    if (threadIdx.x == 0) B.queue_pos = atomicAdd(p.queue, (unsigned)p.grab);
+    __syncthreads();
+    const unsigned q = B.queue_pos;
+    if (q >= (unsigned)p.count) break;
+    const unsigned qe = min(q + (unsigned)p.grab, (unsigned)p.count);
+    for (unsigned i = q; i < qe; ++i) {
+      const size_t pos = (size_t)p.first + (size_t)i * (size_t)p.step;
+      const size_t cid = p.order ? (size_t)p.order[pos] : pos;
+      hrow_chunk<PAT, CLS, K24>(p, B, p.chunks[cid], lane, wave, acc);  // ends with a workgroup barrier
+    }
+  }
+  const unsigned long long s0 = wave_sum_u64(acc.c0);
+  const unsigned long long s1 = wave_sum_u64(acc.c1);
+  const unsigned long long s2 = wave_sum_u64(acc.c2);
+  const unsigned long long s3 = wave_sum_u64(acc.c3);
+  if (lane == 0) {
+    if (s0) atomicAdd(&p.counters[0], s0);
+    if (s1) atomicAdd(&p.counters[1], s1);
+    if (s2) atomicAdd(&p.counters[2], s2);
+    if (s3) atomicAdd(&p.counters[3], s3);
+  }
+}
+
+size_t hrow_lds_bytes(int cls) { return cls == 2 ? sizeof(HrowLds<2>) : sizeof(HrowLds<1>); }
+int hrow_per_cu(int cls) { return cls == 2 ? HrowCfg<2>::per_cu : HrowCfg<1>::per_cu; }
+
+hipError_t launch_hrow(Pattern pat, int cls, const MineParams &p, int grid_blocks, hipStream_t stream) {
+  static_assert(sizeof(HrowLds<2>) <= 163840, "class 2 must fit the 160 KB of one CU");
+  static_assert(sizeof(HrowLds<1>) * HrowCfg<1>::per_cu <= 163840, "class-1 workgroups per CU");
+  if (p.g.edesc == nullptr) return hipErrorInvalidValue;
+  const dim3 grid((unsigned)grid_blocks);
+  // ids (and the constant) below 2^24: the hash is one v_mul_u32_u24 (full rate) instead of v_mul_lo_u32 (quarter rate)
+  const bool k24 = p.g.nv <= (1 << 24) && !(p.flags & (1 << 23));
+#define GM_HROW_CASE(P)                                                                                                   \
+  case P:                                                                                                                 \
+    if (cls == 2 && k24) hipLaunchKernelGGL((hrow_kernel<P, 2, true>), grid, dim3(HrowCfg<2>::waves * GM_WAVE), 0, stream, p);   \
+    else if (cls == 2) hipLaunchKernelGGL((hrow_kernel<P, 2, false>), grid, dim3(HrowCfg<2>::waves * GM_WAVE), 0, stream, p);    \
+    else if (k24) hipLaunchKernelGGL((hrow_kernel<P, 1, true>), grid, dim3(HrowCfg<1>::waves * GM_WAVE), 0, stream, p);          \
+    else hipLaunchKernelGGL((hrow_kernel<P, 1, false>), grid, dim3(HrowCfg<1>::waves * GM_WAVE), 0, stream, p);                  \
+    break;
+  switch (pat) {
+    GM_HROW_CASE(PAT_DIAMOND)
+    GM_HROW_CASE(PAT_MOTIF3)
+    GM_HROW_CASE(PAT_MOTIF4E)
+    default: return hipErrorInvalidValue;
+  }
+#undef GM_HROW_CASE
+  return hipGetLastError();
+}
+
+}  // namespace gm

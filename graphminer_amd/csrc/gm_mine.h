@@ -315,6 +315,18 @@ size_t mine_lds_bytes(Pattern pat);
 // the big-LDS classes (gm_mine_wide.hip): cls = 1 (mid rows) or 2 (big rows); DIAMOND, MOTIF3, MOTIF4E only
 hipError_t launch_mine_wide(Pattern pat, int cls, const MineParams &p, int grid_blocks, hipStream_t stream);
 size_t mine_wide_lds_bytes(int cls);
+// hashed-row classes (gm_hrow.hip): the row as a hash-partitioned set of 16-bit remainders, 2^LB buckets of eight slots
+constexpr int kHrowLbMid = 11;  // class 1 (rows of 3073..8191 entries): 32 KB
+constexpr int kHrowLbBig = 13;  // class 2 (rows of 8192..24576 entries): 128 KB
+hipError_t launch_hrow(Pattern pat, int cls, const MineParams &p, int grid_blocks, hipStream_t stream);
+size_t hrow_lds_bytes(int cls);
+int hrow_per_cu(int cls);
+// ids must split into bucket + 14-bit remainder: bits of nv <= LB_max + 14
+inline bool hrow_fits(int nv, int cls) {
+  int k = 0;
+  while (k < 31 && (1ll << k) < (long long)nv) ++k;
+  return k <= (cls == 2 ? kHrowLbBig : kHrowLbMid) + 14;
+}
 int mine_wide_threads(Pattern pat, int cls);
 
 }  // namespace gm

@@ -467,7 +467,10 @@ def test_hub_paths_against_oracle_rmat16(dev):
     assert MotifSolver(s, 3) == want_m3
     # (0x100000: WITH the big-LDS workgroup classes for rows of 3073..24576 entries, which a graph this small does not get by default)
     for tune in ([0, 0, 0, 0, 0, 0, 0x1000], [0, 0, 0, 0, 0, 0, 0x4000], [0, 0, 0, 0, 0, 0, 0x100], [0, 0, 0, 0, 0, 0, 0x4], [0, 0, 0, 0, 0, 1],
-                 [0, 0, 0, 0, 0, 0, 0x100000], [0, 0, 0, 0, 0, 0, 0x100000 | 0x1000], [0, 0, 0, 0, 0, 0, 0x100000 | 0x4000]):
+                 [0, 0, 0, 0, 0, 0, 0x100000], [0, 0, 0, 0, 0, 0, 0x100000 | 0x1000], [0, 0, 0, 0, 0, 0, 0x100000 | 0x4000],
+                 # (0x400000: the classes with the sorted LDS copy + bisection instead of the hashed set; 0x800000: the hashed-set
+                 # kernels with every lookup through their global-memory fallback)
+                 [0, 0, 0, 0, 0, 0, 0x100000 | 0x400000], [0, 0, 0, 0, 0, 0, 0x100000 | 0x400000 | 0x1000], [0, 0, 0, 0, 0, 0, 0x100000 | 0x800000]):
         assert SglSolver(s, "diamond", tune=tune) == want_d
         assert MotifSolver(s, 3, tune=tune) == want_m3
     assert sum(SglSolver(s, "diamond", rank=r, world=8) for r in range(8)) == want_d
@@ -475,6 +478,7 @@ def test_hub_paths_against_oracle_rmat16(dev):
     parts = [MotifSolver(s, 3, rank=r, world=4, tune=[0, 0, 0, 0, 0, 0, 0x100000]) for r in range(4)]
     assert [sum(p[i] for p in parts) % 2**64 for i in range(2)] == want_m3
     assert MotifSolver(s, 4, tune=[0, 0, 0, 0, 0, 0, 0x100000]) == GOLDEN[g.name]["motif4"]
+    assert MotifSolver(s, 4, tune=[0, 0, 0, 0, 0, 0, 0x100000 | 0x400000]) == GOLDEN[g.name]["motif4"]
     parts = [MotifSolver(s, 3, rank=r, world=3, policy=2) for r in range(3)]
     assert [sum(p[i] for p in parts) % 2**64 for i in range(2)] == want_m3
     # golden.json: tc / motif3 / motif4 of this graph from the reference's tc_omp_base, motif_omp_base, motif_omp_formula
