@@ -203,6 +203,7 @@ struct gm_graph {
   int nv = 0;
   long long ne = 0;
   int max_deg = 0;
+  long long cls_entries = -1;  // entries of the rows above the general kernel's LDS stage (long_row_entries), -1 = not counted yet
   int *d_rp = nullptr;   // int32 offsets, owned
   int *d_col = nullptr;  // col_idx
   bool own_col = true;
@@ -632,6 +633,17 @@ __global__ __launch_bounds__(256) void orient_segout_kernel(int nv, const int *_
     segs[k].out = run;
     run += seg_count[k];
   }
+}
+// entries of the rows longer than `thresh` (how much work the workgroup classes of the symmetric-graph patterns would get)
+__global__ __launch_bounds__(256) void long_row_entries_kernel(int nv, const int *__restrict__ rp, int thresh, unsigned long long *__restrict__ out) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  unsigned long long s = 0;
+  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += stride) {
+    const int d = rp[v + 1] - rp[v];
+    s += d > thresh ? (unsigned long long)d : 0ull;
+  }
+  s = gm::wave_sum_u64(s);
+  if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
 }
 __global__ __launch_bounds__(256) void max_degree_kernel(int nv, const int *__restrict__ rp, int *__restrict__ out) {
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -1723,6 +1735,22 @@ static void fill_stats(gm_stats *st, uint64_t tasks, uint64_t chunks, int grid, 
   st->block = (uint32_t)block;
 }
 
+// entries of the rows above the general kernel's LDS stage, counted once per graph
+static int long_row_entries(gm_graph *g) {
+  if (g->cls_entries >= 0) return GM_OK;
+  HIP_TRY(hipSetDevice(g->device));
+  DevBuf<unsigned long long> sum;
+  HIP_TRY(sum.alloc(1));
+  HIP_TRY(hipMemset(sum.p, 0, sizeof(unsigned long long)));
+  hipLaunchKernelGGL(long_row_entries_kernel, dim3((unsigned)std::max<long long>(1, std::min<long long>(((long long)g->nv + 255) / 256, 2048))), dim3(256), 0, 0,
+                     g->nv, g->d_rp, kStageCapWide, sum.p);
+  HIP_TRY(hipGetLastError());
+  unsigned long long h = 0;
+  HIP_TRY(hipMemcpy(&h, sum.p, sizeof h, hipMemcpyDeviceToHost));
+  g->cls_entries = (long long)h;
+  return GM_OK;
+}
+
 static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uint64_t *h_out, int nout, gm_stats *st,
                        int fin_mode = -1, unsigned long long fin_base = 0) {
   if (fin_mode < 0) fin_mode = (pat == PAT_MOTIF3) ? FIN_MOTIF3 : FIN_COPY;
@@ -1762,16 +1790,28 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
   // of the rows being worked on stay in L2 -- measured, diamond R-MAT-22 28 ms (SPLIT + bitmaps) vs 47 ms (classes), R-MAT-20
   // 10.4 vs 20.8, the LiveJournal-size power-law graph (nv 4.8 M, 600 KB bitmaps) 3.9 vs 8.0; at nv = 2^24 (2 MB per bitmap) 819 vs
   // 636 ms, 3-motif 458 vs 370 ms. tune[6] & 0x100000 forces them on.
-  const bool use_classes = sym_pat && !(la->tune[6] & 0x80000) && !(la->tune[5] == 1) &&
-                           ((la->tune[6] & 0x100000) || g->nv > (1 << 23));
+  bool use_classes = sym_pat && !(la->tune[6] & 0x80000) && !(la->tune[5] == 1);
+  if (use_classes && !(la->tune[6] & 0x100000)) {
+    // ... and where they get enough work to fill the chip with their own launches.  Measured with the hashed sets / id-range
+    // bitmaps (profiles/r02/ab_class_threshold.log; entries of the rows > 3072, general path vs classes, ms): diamond R-MAT-18
+    // 0.9 M 2.6 vs 4.1, power law 2.3 M 3.9 vs 5.0, R-MAT-20 7.0 M 10.4 vs 8.4, R-MAT-22 (ef 10) 14 M 27.9 vs 21.0, R-MAT-23 78 M
+    // 255 vs 107; 3-motif (bounded lists: less to stream) R-MAT-20 6.4 vs 7.3, R-MAT-22 (ef 10) 16.3 vs 17.5, R-MAT-24 138 M 458 vs 196.
+    int rc = long_row_entries(g);
+    if (rc) return rc;
+    const long long per_rank = g->cls_entries / std::max(world, 1);
+    use_classes = per_rank >= (pat == PAT_MOTIF3 ? (24ll << 20) : (4ll << 20));
+  }
   RowFilter rf;
   rf.skip_clique_wide = use_wide ? clique_wide_min_words() : 0;
   int cls_lo = kStageCapWide;
   if (const char *e = getenv("GM_CLS_LO")) cls_lo = std::max(64, atoi(e));  // (sweeps)
-  if (use_classes) { rf.skip_lo = cls_lo; rf.skip_hi = kStageCapBig; }
+  // giant rows (> kStageCapBig entries): LDS bitmaps over id ranges (range_kernel, gm_hrow.hip) instead of SPLIT chunks probing
+  // dense bitmaps in HBM (tune[6] & 0x1000000: A/B switch, they stay SPLIT chunks of the general kernel)
+  const bool use_range = use_classes && !(la->tune[6] & 0x1000000);
+  if (use_classes) { rf.skip_lo = cls_lo; rf.skip_hi = use_range ? 0x7fffffff : kStageCapBig; }
   int rc = get_table(g, target, !clique, clique ? kBitWords : 0, part_cap, stage_cap_of(pat), &tab, rf, use_classes ? kStageCapBig : kBitmapMinDeg);
   if (rc) return rc;
-  ChunkTable *tab_cls[3] = {tab, nullptr, nullptr};
+  ChunkTable *tab_cls[4] = {tab, nullptr, nullptr, nullptr};
   if (use_classes) {
     RowFilter r1, r2;
     r1.only_lo = cls_lo; r1.only_hi = kStageCapMid;
@@ -1788,6 +1828,12 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
     if (rc) return rc;
     rc = get_table(g, target, false, 0, cls_cap, kStageCapBig, &tab_cls[2], r2, 0x7fffffff);
     if (rc) return rc;
+    if (use_range) {  // pieces of kRangeEdges task edges, never cut into parts
+      RowFilter r3;
+      r3.only_lo = kStageCapBig;
+      rc = get_table(g, kRangeEdges, true, 0, ~0ull, kStageCapBig, &tab_cls[3], r3, 0x7fffffff);
+      if (rc) return rc;
+    }
   }
   WidePlan *plan = nullptr;
   if (use_wide) {
@@ -1958,7 +2004,8 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
     // first and takes the CUs; as its persistent workgroups run out of chunks they leave, and the workgroups of class 1 and of
     // the general kernel move in -- the tails overlap instead of adding up (on one stream every kernel boundary waited for
     // the slowest workgroup of the kernel before it).
-    for (int cls = 2; cls >= 1; --cls) {
+    for (int cls = 3; cls >= 1; --cls) {
+      if (!tab_cls[cls]) continue;
       MineParams q = p;
       take_share(tab_cls[cls], q);
       q.queue = reinterpret_cast<unsigned *>(g->d_counters + 4) + cls;  // its own dequeue word inside the zeroed 64-byte block
@@ -1966,6 +2013,23 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
       chunks_total += (uint64_t)q.count;
       // the row as a hashed set in LDS (gm_hrow.hip) unless the ids are too wide for its 14-bit remainders
       // (tune[6] & 0x400000: A/B switch, the sorted LDS copy + bit filter + bisection of gm_mine_wide.hip)
+      if (cls == 3) {
+        // per workgroup: where the id ranges cut the partner lists of its chunk, kRangeEdges ints per range (range_bounds)
+        const int rgrid = (int)std::max<long long>(1, std::min<long long>(q.count, (long long)g->cu_count));
+        const unsigned long long slot_words = (unsigned long long)kRangeEdges * (unsigned long long)(((long long)g->nv + (1ll << 20) - 1) >> 20);
+        const size_t need = (size_t)slot_words * sizeof(unsigned) * (size_t)rgrid;
+        if (need > g->scratch_bytes) {
+          if (g->d_scratch) (void)hipFree(g->d_scratch);
+          g->d_scratch = nullptr;
+          g->scratch_bytes = 0;
+          HIP_TRY(hipMalloc(&g->d_scratch, need));
+          g->scratch_bytes = need;
+        }
+        q.scratch = g->d_scratch;
+        q.scratch_words = slot_words;
+        HIP_TRY(launch_range(pat, q, rgrid, stream));
+        continue;
+      }
       const bool hrow = !(la->tune[6] & 0x400000) && p.g.edesc != nullptr && hrow_fits(g->nv, cls);
       const int per_cu_w = hrow ? hrow_per_cu(cls) : (int)std::max<size_t>(1, (160 * 1024) / mine_wide_lds_bytes(cls));
       const int wgrid = (int)std::max<long long>(1, std::min<long long>(q.count, (long long)g->cu_count * per_cu_w));

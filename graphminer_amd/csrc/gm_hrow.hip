@@ -17,6 +17,10 @@
 // Every task edge streams the partner list (pass X); pass Y does not exist here (the longer row hosts, gm_mine.h sym_hosts).
 #include "gm_flat.h"
 
+#ifndef GM_HROW_CMP16
+#define GM_HROW_CMP16 1  // eight SDWA 16-bit compares (8 VALU + 7 SALU) instead of the packed has-zero-halfword test (17 VALU): diamond R-MAT-24 304 -> 284 ms
+#endif
+
 namespace gm {
 
 constexpr int kHrowOvfCap = 128;
@@ -92,10 +96,18 @@ __device__ __forceinline__ void hrow_member(const LdsT &B, const HrowView &hv, c
   bool need[T], any_need = false;
 #pragma unroll
   for (int q = 0; q < T; ++q) {
+#if GM_HROW_CMP16
+    const unsigned short r16 = (unsigned short)rr[q];
+    const bool hit = ((unsigned short)w[q].x == r16) | ((unsigned short)(w[q].x >> 16) == r16) | ((unsigned short)w[q].y == r16) |
+                     ((unsigned short)(w[q].y >> 16) == r16) | ((unsigned short)w[q].z == r16) | ((unsigned short)(w[q].z >> 16) == r16) |
+                     ((unsigned short)w[q].w == r16) | ((unsigned short)((w[q].w >> 16) & 0x7fffu) == r16);
+    const unsigned z = hit ? 0x8000u : 0u;
+#else
     const unsigned c = 0x00010001u;
     const unsigned t0 = w[q].x ^ rr[q], t1 = w[q].y ^ rr[q], t2 = w[q].z ^ rr[q], t3 = (w[q].w & 0x7fffffffu) ^ rr[q];
     // a halfword of t is zero <=> that slot holds rem: (t - 0x00010001) & ~t & 0x80008000 is non-zero iff some halfword is zero
     const unsigned z = ((t0 - c) & ~t0) | ((t1 - c) & ~t1) | ((t2 - c) & ~t2) | ((t3 - c) & ~t3);
+#endif
     f[q] = in[q] & ((z & 0x80008000u) != 0u);
     need[q] = in[q] & !f[q] & ((int)w[q].w < 0);  // missed in a bucket that overflowed: the surplus list decides
     any_need |= need[q];
@@ -406,6 +418,221 @@ void hrow_kernel(const MineParams p) {
     if (s2) atomicAdd(&p.counters[2], s2);
     if (s3) atomicAdd(&p.counters[3], s3);
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Giant rows (more than kStageCapBig = 24576 entries; R-MAT-24: 301 rows of 49 K .. 407 K entries that host 16 % of the streamed
+// keys): no exact set of such a row fits LDS, and the dense bitmap over all vertex ids (2 MB at nv = 2^24) lives in HBM -- every
+// streamed key was one random 64-byte line through L2 (0.33e12 keys/s over the whole chip against 1.1e12 for the hashed classes).
+// Both the row and every partner list are SORTED, so the id space is cut into ranges of 2^20 ids: for one range the row is an
+// EXACT BITMAP of 128 KB in LDS (one ds_read_b32 + a shift per key), and the keys of a partner list that fall into the range are
+// one contiguous segment.  A chunk is <= 1024 task edges of the row; their per-edge match counts (diamond needs C(n,2) of the
+// TOTAL) stay in LDS while the
+// workgroup walks the ranges; where the ranges cut each list is found once per chunk (range_bounds).
+constexpr int kRangeLog2 = 20;
+constexpr int kRangeWords = 1 << (kRangeLog2 - 5);
+constexpr int kRangeWaves = 16;
+constexpr int kRangeBatch = 16;  // task edges per batch: 64 batches per range and chunk for the 16 waves to balance
+
+struct alignas(16) RangeLds {
+  unsigned bits[kRangeWords];
+  unsigned ecnt[kRangeEdges];  // per task edge: matches so far
+  HrowWave w[kRangeWaves];
+  int next_batch;
+  unsigned queue_pos;
+  int pad_[2];
+};
+
+struct RangeBits {
+  const unsigned *bits;
+  int r_lo;
+  __device__ __forceinline__ void operator()(const int (&key)[kHrowTiles], const bool (&in)[kHrowTiles], bool (&f)[kHrowTiles]) const {
+    unsigned w[kHrowTiles], sh[kHrowTiles];
+#pragma unroll
+    for (int q = 0; q < kHrowTiles; ++q) {
+      const unsigned idx = in[q] ? (unsigned)(key[q] - r_lo) : 0u;  // (a segment holds exactly the keys of its range)
+      sh[q] = idx & 31u;
+      w[q] = bits[idx >> 5];
+    }
+#pragma unroll
+    for (int q = 0; q < kHrowTiles; ++q) f[q] = in[q] & (((w[q] >> sh[q]) & 1u) != 0u);
+  }
+};
+
+// Where the ranges cut a partner list: bnd[rg * kRangeEdges + i] = number of keys of edge i's list below (rg + 1) << 20, for
+// all ranges at once -- kRangeGroup independent bisections run interleaved (their loads are in flight together), so a chunk
+// pays ~2 x 17 dependent round trips once instead of 12 per range and batch.  The boundaries live in the workgroup's slot of
+// the global scratch (written and re-read by the same CU: L2 hits, coalesced over the edges).
+constexpr int kRangeGroup = 8;
+__device__ __forceinline__ void range_bounds(const int *__restrict__ list, const int len, const int n_ranges, int *__restrict__ bnd,
+                                             const int i) {
+  const int steps = bitlen(wave_max_nonneg(len));  // wave-uniform trip count, branch-free binary lifting
+  for (int g0 = 0; g0 < n_ranges; g0 += kRangeGroup) {
+    int lo[kRangeGroup];
+#pragma unroll
+    for (int j = 0; j < kRangeGroup; ++j) lo[j] = 0;
+    for (int sbit = steps - 1; sbit >= 0; --sbit) {
+      int x[kRangeGroup];
+#pragma unroll
+      for (int j = 0; j < kRangeGroup; ++j) x[j] = list[max(min(lo[j] + (1 << sbit), len) - 1, 0)];  // unconditional, clamped
+#pragma unroll
+      for (int j = 0; j < kRangeGroup; ++j) {
+        const int mid = lo[j] + (1 << sbit);
+        const long long bound = (long long)(g0 + j + 1) << kRangeLog2;
+        const bool take = (mid <= len) & ((long long)x[j] < bound);
+        lo[j] = take ? mid : lo[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kRangeGroup; ++j)
+      if (g0 + j < n_ranges) bnd[(size_t)(g0 + j) * kRangeEdges + i] = lo[j];
+  }
+}
+
+template <int PAT>
+__device__ __forceinline__ void range_chunk(const MineParams &p, RangeLds &B, const ChunkRec r, const int lane, const int wave, Acc &acc) {
+  const int *__restrict__ rp = p.g.rp;
+  const int *__restrict__ col = p.g.col;
+  const int2 *__restrict__ edesc = p.g.edesc;
+  const int tid = threadIdx.x, nthreads = kRangeWaves * GM_WAVE;
+  static_assert(kRangeWaves * GM_WAVE == kRangeEdges, "one task edge per thread while the boundaries are found");
+  const int u = r.u_begin;
+  const int ru = rp[u], n_row = rp[u + 1] - ru;
+  const int *__restrict__ row = col + ru;
+  const int n_ranges = (int)(((long long)p.g.nv + (1ll << kRangeLog2) - 1) >> kRangeLog2);
+  int *__restrict__ bnd = reinterpret_cast<int *>(p.scratch) + (size_t)blockIdx.x * p.scratch_words;
+  HrowWave &L = B.w[wave];
+  for (int eb = r.e_begin; eb < r.e_end; eb += kRangeEdges) {  // (the host cuts the rows into chunks of kRangeEdges task edges)
+    const int cnt = min(kRangeEdges, r.e_end - eb);
+    {
+      const int i = tid;
+      const int e = eb + min(i, cnt - 1);
+      const int v = col[e];
+      const int2 d = edesc[e];
+      int len = 0;
+      if (i < cnt && sym_hosts(n_row, d.y, u, v, stage_cap_of(PAT))) {
+        len = d.y;
+        if (PAT == PAT_MOTIF3) len = lower_bound(col + d.x, d.y, max(u, v));  // only the keys below max(u, v) can count
+      }
+      if (PAT == PAT_MOTIF3 && i < cnt) acc.c2 += (unsigned long long)(e - ru);  // position of v in the row, ALL directed edges
+      B.ecnt[i] = 0u;
+      range_bounds(col + d.x, len, n_ranges, bnd, i);
+    }
+    int row_pos = 0;  // workgroup-uniform: every thread bisects the same addresses
+    for (int rg = 0; rg < n_ranges; ++rg) {
+      const int r_lo = rg << kRangeLog2;
+      const long long r_hi = (long long)r_lo + (1ll << kRangeLog2);
+      const int s = row_pos;
+      const int t = (r_hi > 0x7fffffffll) ? n_row : s + lower_bound(row + s, n_row - s, (int)r_hi);
+      row_pos = t;
+      if (t == s) continue;  // the row has nobody in this range (uniform over the workgroup)
+      __syncthreads();       // the waves are done with the previous bitmap (first trip: the boundaries are written)
+      {
+        uint4 *b4 = reinterpret_cast<uint4 *>(B.bits);
+        for (int i = tid; i < kRangeWords / 4; i += nthreads) b4[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (tid == 0) B.next_batch = 0;
+      }
+      __syncthreads();
+      for (int i = s + tid; i < t; i += nthreads) {
+        const unsigned idx = (unsigned)(row[i] - r_lo);
+        atomicOr(&B.bits[idx >> 5], 1u << (idx & 31u));
+      }
+      __syncthreads();
+      const RangeBits member{B.bits, r_lo};
+      const int *__restrict__ b_end = bnd + (size_t)rg * kRangeEdges;
+      const int *__restrict__ b_start = bnd + (size_t)max(rg - 1, 0) * kRangeEdges;
+      for (;;) {
+        int bi = 0;
+        if (lane == 0) bi = atomicAdd(&B.next_batch, 1);
+        const int le0 = readfirst(bi) * kRangeBatch;
+        if (le0 >= cnt) break;
+        const int le = min(le0 + lane, cnt - 1);
+        const bool valid = (lane < kRangeBatch) && (le0 + lane < cnt);
+        const int e = eb + le;
+        const int2 desc = edesc[e];
+        const int v = col[e];
+        const int end = b_end[le];
+        const int start = rg ? b_start[le] : 0;
+        L.cnt[lane] = (PAT == PAT_MOTIF3) ? (unsigned)v : 0u;
+        wave_sync();
+        unsigned n_long = 0, m_any = 0, m_low = 0;
+        hrow_pass<PAT>(L, member, col, u, lane, valid ? end - start : 0, desc.x + start, v, n_long, m_any, m_low);
+        wave_sync();
+        if (PAT == PAT_MOTIF3) {
+          acc.c0 += (unsigned long long)m_any + (unsigned long long)m_low;
+          acc.c1 += (unsigned long long)m_low;
+        } else if (valid) {
+          B.ecnt[le] += L.cnt[lane] + n_long;
+        }
+        wave_sync();
+      }
+    }
+    __syncthreads();
+    if (PAT != PAT_MOTIF3) {
+      for (int i = tid; i < cnt; i += nthreads) {
+        const unsigned long long tri = B.ecnt[i];
+        if (PAT == PAT_DIAMOND) {
+          acc.c0 += tri * (tri - 1ull) / 2ull;
+        } else {  // PAT_MOTIF4E
+          const int e = eb + i;
+          const int v = col[e];
+          const int2 d = edesc[e];
+          if (sym_hosts(n_row, d.y, u, v, stage_cap_of(PAT))) {
+            const unsigned long long su = (unsigned long long)n_row - tri - 1ull, sv = (unsigned long long)d.y - tri - 1ull;
+            acc.c0 += su * (su - 1ull) + sv * (sv - 1ull);
+            acc.c1 += su * sv;
+            acc.c2 += tri * (su + sv);
+            acc.c3 += tri * (tri - 1ull);
+          }
+        }
+      }
+    }
+    __syncthreads();  // the per-edge state and the boundaries are rewritten by the next chunk
+  }
+}
+
+template <int PAT>
+__global__ __launch_bounds__((kRangeWaves * GM_WAVE), 4)
+void range_kernel(const MineParams p) {
+  __shared__ RangeLds B;
+  const int lane = threadIdx.x & (GM_WAVE - 1);
+  const int wave = threadIdx.x >> 6;
+  Acc acc;
+  for (;;) {
+    if (threadIdx.x == 0) B.queue_pos = atomicAdd(p.queue, (unsigned)p.grab);
+    __syncthreads();
+    const unsigned q = B.queue_pos;
+    if (q >= (unsigned)p.count) break;
+    const unsigned qe = min(q + (unsigned)p.grab, (unsigned)p.count);
+    for (unsigned i = q; i < qe; ++i) {
+      const size_t pos = (size_t)p.first + (size_t)i * (size_t)p.step;
+      const size_t cid = p.order ? (size_t)p.order[pos] : pos;
+      range_chunk<PAT>(p, B, p.chunks[cid], lane, wave, acc);  // ends with a workgroup barrier
+    }
+  }
+  const unsigned long long s0 = wave_sum_u64(acc.c0);
+  const unsigned long long s1 = wave_sum_u64(acc.c1);
+  const unsigned long long s2 = wave_sum_u64(acc.c2);
+  const unsigned long long s3 = wave_sum_u64(acc.c3);
+  if (lane == 0) {
+    if (s0) atomicAdd(&p.counters[0], s0);
+    if (s1) atomicAdd(&p.counters[1], s1);
+    if (s2) atomicAdd(&p.counters[2], s2);
+    if (s3) atomicAdd(&p.counters[3], s3);
+  }
+}
+
+hipError_t launch_range(Pattern pat, const MineParams &p, int grid_blocks, hipStream_t stream) {
+  static_assert(sizeof(RangeLds) <= 163840, "the range kernel must fit the 160 KB of one CU");
+  if (p.g.edesc == nullptr || p.scratch == nullptr) return hipErrorInvalidValue;
+  const dim3 grid((unsigned)grid_blocks), block(kRangeWaves * GM_WAVE);
+  switch (pat) {
+    case PAT_DIAMOND: hipLaunchKernelGGL((range_kernel<PAT_DIAMOND>), grid, block, 0, stream, p); break;
+    case PAT_MOTIF3: hipLaunchKernelGGL((range_kernel<PAT_MOTIF3>), grid, block, 0, stream, p); break;
+    case PAT_MOTIF4E: hipLaunchKernelGGL((range_kernel<PAT_MOTIF4E>), grid, block, 0, stream, p); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
 }
 
 size_t hrow_lds_bytes(int cls) { return cls == 2 ? sizeof(HrowLds<2>) : sizeof(HrowLds<1>); }

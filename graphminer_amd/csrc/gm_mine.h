@@ -320,6 +320,9 @@ constexpr int kHrowLbMid = 11;  // class 1 (rows of 3073..8191 entries): 32 KB
 constexpr int kHrowLbBig = 13;  // class 2 (rows of 8192..24576 entries): 128 KB
 hipError_t launch_hrow(Pattern pat, int cls, const MineParams &p, int grid_blocks, hipStream_t stream);
 size_t hrow_lds_bytes(int cls);
+// giant rows (> kStageCapBig entries): LDS bitmaps over ranges of 2^20 ids, chunks of kRangeEdges task edges (gm_hrow.hip)
+constexpr int kRangeEdges = 1024;
+hipError_t launch_range(Pattern pat, const MineParams &p, int grid_blocks, hipStream_t stream);
 int hrow_per_cu(int cls);
 // ids must split into bucket + 14-bit remainder: bits of nv <= LB_max + 14
 inline bool hrow_fits(int nv, int cls) {

@@ -48,6 +48,15 @@ def test_diamond_rmat20_equals_oracle(rmat_dev):
     assert sum(SglSolver(sym, "diamond", rank=r, world=8) for r in range(8)) == want
     # the big-LDS workgroup classes (rows of 3073..24576 entries staged whole; default from nv > 2^22), forced on
     assert SglSolver(sym, "diamond", tune=[0, 0, 0, 0, 0, 0, 0x100000]) == want
+    # ... the same with the sorted-copy class kernels (0x400000) and with the giant rows (> 24576 entries; this graph has rows of
+    # 64 K) left to the SPLIT chunks + HBM bitmaps instead of the id-range LDS bitmaps (0x1000000)
+    assert SglSolver(sym, "diamond", tune=[0, 0, 0, 0, 0, 0, 0x100000 | 0x400000]) == want
+    assert SglSolver(sym, "diamond", tune=[0, 0, 0, 0, 0, 0, 0x100000 | 0x1000000]) == want
+    assert sum(SglSolver(sym, "diamond", rank=r, world=3, tune=[0, 0, 0, 0, 0, 0, 0x100000]) for r in range(3)) == want
+    # (the classes are the default here -- 7 M entries in rows above the LDS stage; 0x80000: everything through the general kernel)
+    assert SglSolver(sym, "diamond", tune=[0, 0, 0, 0, 0, 0, 0x80000]) == want
+    # formula 4-motif: the per-edge kernel through the general path and through the classes (independent kernels)
+    assert MotifSolver(sym, 4, tune=[0, 0, 0, 0, 0, 0, 0x100000]) == MotifSolver(sym, 4, tune=[0, 0, 0, 0, 0, 0, 0x80000])
 
 
 @pytest.mark.timeout(900)
@@ -75,7 +84,10 @@ def test_motif3_rmat22_equals_oracle(rmat_dev):
     assert got == want
     assert st.tasks == osym.ne
     assert MotifSolver(sym, 3, formula=True) == want
-    assert MotifSolver(sym, 3, tune=[0, 0, 0, 0, 0, 0, 0x100000]) == want  # with the big-LDS workgroup classes
+    assert MotifSolver(sym, 3, tune=[0, 0, 0, 0, 0, 0, 0x100000]) == want  # with the workgroup classes (hashed rows, id-range bitmaps: 4 ranges)
+    assert MotifSolver(sym, 3, tune=[0, 0, 0, 0, 0, 0, 0x100000 | 0x400000 | 0x1000000]) == want  # sorted-copy classes, SPLIT giants
+    assert MotifSolver(sym, 3, tune=[0, 0, 0, 0, 0, 0, 0x100000 | 0x800000]) == want  # hashed-row kernels on their fallback lookup
+    assert SglSolver(sym, "diamond", tune=[0, 0, 0, 0, 0, 0, 0x100000]) == SglSolver(sym, "diamond", tune=[0, 0, 0, 0, 0, 0, 0x80000])
     parts = [MotifSolver(sym, 3, rank=r, world=8) for r in range(8)]
     assert [sum(p[i] for p in parts) % 2**64 for i in range(2)] == want
 
