@@ -64,9 +64,9 @@ BASELINE_CONFIGS = [
 # rocprofv3 kernel names that make up one launch of a workload (everything between the library's two timing events)
 KERNELS = {
     "tc": ["mine_kernel<0,"],
-    # general kernel <P, 0> (+ the sorted-copy classes <P, 1>, <P, 2>), the hashed-row classes and the id-range kernel of the giant rows
-    "diamond": ["mine_kernel<1,", "hrow_kernel<1,", "range_kernel<1>"],
-    "motif3": ["mine_kernel<2,", "hrow_kernel<2,", "range_kernel<2>"],
+    # general kernel <P, 0> (+ the sorted-copy classes <P, 1>, <P, 2>), the hashed-row classes and the kernel of the giant rows
+    "diamond": ["mine_kernel<1,", "hrow_kernel<1,", "giant_kernel<1,"],
+    "motif3": ["mine_kernel<2,", "hrow_kernel<2,", "giant_kernel<2,"],
     "clique4": ["mine_kernel<3,", "clique_build_kernel", "clique_count_kernel"],
     "clique5": ["mine_kernel<4,"],
     "motif3f": ["mine_kernel<0,"],

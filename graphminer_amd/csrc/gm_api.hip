@@ -1803,9 +1803,13 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
   }
   RowFilter rf;
   rf.skip_clique_wide = use_wide ? clique_wide_min_words() : 0;
-  int cls_lo = kStageCapWide;
+  // Rows of 1025..3072 entries fit the general kernel's stage, but their partner lists (mean 600 keys on R-MAT-24) are cheaper
+  // against a hashed set than against the filter + bisection of a multi-row chunk: measured (profiles/r02/ab_hrow_class_lower_bound.log,
+  // ms, lower bound 3072 / 2048 / 1024 / 512 / 256) diamond R-MAT-24 262 / 240 / 239 / 238 / 237, R-MAT-22 21.1 / 21.0 / 17.5 / 17.6 / 17.5,
+  // 3-motif R-MAT-24 185 / 172 / 172 / 171 / 171.
+  int cls_lo = kClassRowMin;
   if (const char *e = getenv("GM_CLS_LO")) cls_lo = std::max(64, atoi(e));  // (sweeps)
-  // giant rows (> kStageCapBig entries): LDS bitmaps over id ranges (range_kernel, gm_hrow.hip) instead of SPLIT chunks probing
+  // giant rows (> kStageCapBig entries): hashed sets of row pieces (giant_kernel, gm_hrow.hip) instead of SPLIT chunks probing
   // dense bitmaps in HBM (tune[6] & 0x1000000: A/B switch, they stay SPLIT chunks of the general kernel)
   const bool use_range = use_classes && !(la->tune[6] & 0x1000000);
   if (use_classes) { rf.skip_lo = cls_lo; rf.skip_hi = use_range ? 0x7fffffff : kStageCapBig; }
@@ -1824,14 +1828,15 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
     // few heaviest rows. Side streams for the class kernels: 396 / 667 (GM_CLASSES_STREAMS, off).
     unsigned long long cls_cap = (la->tune[6] & 0x1000) ? 4096ull : std::max<unsigned long long>(part_cap, 32ull << 20);
     if (const char *e = getenv("GM_CLS_CAP_MKEYS")) cls_cap = (unsigned long long)std::max(1, atoi(e)) << 20;  // (sweeps)
-    rc = get_table(g, target, false, 0, cls_cap, kStageCapMid, &tab_cls[1], r1, 0x7fffffff);
+    // (target 1: every row is a chunk of its own -- the class kernels take one-row chunks -- also below the general kernel's chunk target)
+    rc = get_table(g, 1, false, 0, cls_cap, kStageCapMid, &tab_cls[1], r1, 0x7fffffff);
     if (rc) return rc;
-    rc = get_table(g, target, false, 0, cls_cap, kStageCapBig, &tab_cls[2], r2, 0x7fffffff);
+    rc = get_table(g, 1, false, 0, cls_cap, kStageCapBig, &tab_cls[2], r2, 0x7fffffff);
     if (rc) return rc;
-    if (use_range) {  // pieces of kRangeEdges task edges, never cut into parts
+    if (use_range) {  // pieces of kGiantEdges task edges, never cut into parts
       RowFilter r3;
       r3.only_lo = kStageCapBig;
-      rc = get_table(g, kRangeEdges, true, 0, ~0ull, kStageCapBig, &tab_cls[3], r3, 0x7fffffff);
+      rc = get_table(g, kGiantEdges, true, 0, ~0ull, kStageCapBig, &tab_cls[3], r3, 0x7fffffff);
       if (rc) return rc;
     }
   }
@@ -2014,9 +2019,9 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
       // the row as a hashed set in LDS (gm_hrow.hip) unless the ids are too wide for its 14-bit remainders
       // (tune[6] & 0x400000: A/B switch, the sorted LDS copy + bit filter + bisection of gm_mine_wide.hip)
       if (cls == 3) {
-        // per workgroup: where the id ranges cut the partner lists of its chunk, kRangeEdges ints per range (range_bounds)
+        // per workgroup: where the pieces of the row cut the partner lists of its chunk, kGiantEdges ints per piece (giant_bounds)
         const int rgrid = (int)std::max<long long>(1, std::min<long long>(q.count, (long long)g->cu_count));
-        const unsigned long long slot_words = (unsigned long long)kRangeEdges * (unsigned long long)(((long long)g->nv + (1ll << 20) - 1) >> 20);
+        const unsigned long long slot_words = giant_scratch_words(g->max_deg);
         const size_t need = (size_t)slot_words * sizeof(unsigned) * (size_t)rgrid;
         if (need > g->scratch_bytes) {
           if (g->d_scratch) (void)hipFree(g->d_scratch);
@@ -2027,7 +2032,7 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
         }
         q.scratch = g->d_scratch;
         q.scratch_words = slot_words;
-        HIP_TRY(launch_range(pat, q, rgrid, stream));
+        HIP_TRY(launch_giant(pat, q, rgrid, stream));
         continue;
       }
       const bool hrow = !(la->tune[6] & 0x400000) && p.g.edesc != nullptr && hrow_fits(g->nv, cls);

@@ -131,6 +131,52 @@ __device__ __forceinline__ void hrow_member(const LdsT &B, const HrowView &hv, c
   }
 }
 
+// Build the set of row[0..n) in B.table (all threads of the workgroup; B.w is scratch meanwhile).  Ends with a barrier.
+template <bool K24, class LdsT>
+__device__ __forceinline__ void hrow_build(LdsT &B, HrowView &hv, const int *__restrict__ row, const int n, const int lbmax, const int nv,
+                                           const int flags, const int tid, const int nthreads) {
+  const int K = max(bitlen(nv - 1), 1);
+  const int LB = min(min(lbmax, K), max(K - kHrowRemBits, bitlen((n - 1) / 3)));
+  hv.sh = K - LB;
+  hv.kmask = (K >= 32) ? 0xffffffffu : ((1u << K) - 1u);
+  hv.rmask = (1u << hv.sh) - 1u;
+  hv.ck = (unsigned)(0x9E3779B97F4A7C15ull >> (64 - K)) | 1u;
+  // (more than 14 remainder bits -- nv beyond what the host sends here -- or the test switch: every lookup bisects the row in global memory)
+  hv.fallback = (flags & (1 << 22)) != 0 || hv.sh > kHrowRemBits;
+  const int nb = 1 << LB;
+  unsigned *fill32 = reinterpret_cast<unsigned *>(&B.w[0]);
+  {
+    const uint4 empty = make_uint4(0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu);
+    uint4 *t4 = reinterpret_cast<uint4 *>(B.table);
+    for (int i = tid; i < nb; i += nthreads) t4[i] = empty;
+    for (int i = tid; i < (nb + 1) / 2; i += nthreads) fill32[i] = 0u;
+    if (tid < kHrowOvfCap) B.ovf[tid] = -1;
+    if (tid == 0) B.n_ovf = 0;
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += nthreads) {
+    const int key = row[i];
+    const unsigned h = hrow_hash<K24>(hv, key);
+    const unsigned b = h >> hv.sh, rem = h & hv.rmask;
+    const unsigned shift = (b & 1u) * 16u;
+    const unsigned slot = (atomicAdd(&fill32[b >> 1], 1u << shift) >> shift) & 0xffffu;
+    if (slot < 8u) {
+      B.table[(b << 3) + slot] = (unsigned short)rem;
+    } else {
+      const int j = atomicAdd(&B.n_ovf, 1);
+      if (j < kHrowOvfCap) B.ovf[j] = key;
+    }
+  }
+  __syncthreads();
+  for (int b = tid; b < nb; b += nthreads) {
+    const unsigned c = (fill32[b >> 1] >> ((b & 1) * 16)) & 0xffffu;
+    if (c > 8u) B.table[(b << 3) + 7] |= (unsigned short)0x8000u;
+  }
+  __syncthreads();  // (also: the fill counters are dead, the waves may use their scratch)
+  hv.n_ovf = B.n_ovf;
+  if (hv.n_ovf > kHrowOvfCap) hv.fallback = true;
+}
+
 template <bool K24, class LdsT>
 struct HashedRow {
   const LdsT &B;
@@ -292,51 +338,10 @@ __device__ __forceinline__ void hrow_chunk(const MineParams &p, HrowLds<CLS> &B,
   const int ru = rp[u], n_row = rp[u + 1] - ru;
   const int eb = r.e_begin, nel = r.e_end - r.e_begin;
 
-  // ---- workgroup: build the set --------------------------------------------------------------------------------------
   HrowView hv;
-  const int K = max(bitlen(p.g.nv - 1), 1);
-  const int LB = min(min(Cfg::lbmax, K), max(K - kHrowRemBits, bitlen((n_row - 1) / 3)));
-  hv.sh = K - LB;
-  hv.kmask = (K >= 32) ? 0xffffffffu : ((1u << K) - 1u);
-  hv.rmask = (1u << hv.sh) - 1u;
-  hv.ck = (unsigned)(0x9E3779B97F4A7C15ull >> (64 - K)) | 1u;
-  // (more than 14 remainder bits -- nv beyond what the host sends here -- or the test switch: every lookup bisects the row in global memory)
-  hv.fallback = (p.flags & (1 << 22)) != 0 || hv.sh > kHrowRemBits;
-  const int nb = 1 << LB;
-  unsigned *fill32 = reinterpret_cast<unsigned *>(&B.w[0]);
-  {
-    const uint4 empty = make_uint4(0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu);
-    uint4 *t4 = reinterpret_cast<uint4 *>(B.table);
-    for (int i = tid; i < nb; i += nthreads) t4[i] = empty;
-    for (int i = tid; i < (nb + 1) / 2; i += nthreads) fill32[i] = 0u;
-    if (tid < kHrowOvfCap) B.ovf[tid] = -1;
-    if (tid == 0) {
-      B.n_ovf = 0;
-      B.next_batch = 0;
-    }
-  }
+  hrow_build<K24>(B, hv, col + ru, n_row, Cfg::lbmax, p.g.nv, p.flags, tid, nthreads);  // ends with a workgroup barrier
+  if (tid == 0) B.next_batch = 0;
   __syncthreads();
-  for (int i = tid; i < n_row; i += nthreads) {
-    const int key = col[ru + i];
-    const unsigned h = hrow_hash<K24>(hv, key);
-    const unsigned b = h >> hv.sh, rem = h & hv.rmask;
-    const unsigned shift = (b & 1u) * 16u;
-    const unsigned slot = (atomicAdd(&fill32[b >> 1], 1u << shift) >> shift) & 0xffffu;
-    if (slot < 8u) {
-      B.table[(b << 3) + slot] = (unsigned short)rem;
-    } else {
-      const int j = atomicAdd(&B.n_ovf, 1);
-      if (j < kHrowOvfCap) B.ovf[j] = key;
-    }
-  }
-  __syncthreads();
-  for (int b = tid; b < nb; b += nthreads) {
-    const unsigned c = (fill32[b >> 1] >> ((b & 1) * 16)) & 0xffffu;
-    if (c > 8u) B.table[(b << 3) + 7] |= (unsigned short)0x8000u;
-  }
-  __syncthreads();  // (also: the fill counters are dead, the waves may use their scratch)
-  hv.n_ovf = B.n_ovf;
-  if (hv.n_ovf > kHrowOvfCap) hv.fallback = true;
 
   // ---- waves: batches of task edges ----------------------------------------------------------------------------------
   HrowWave &L = B.w[wave];
@@ -422,90 +427,79 @@ void hrow_kernel(const MineParams p) {
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // Giant rows (more than kStageCapBig = 24576 entries; R-MAT-24: 301 rows of 49 K .. 407 K entries that host 16 % of the streamed
-// keys): no exact set of such a row fits LDS, and the dense bitmap over all vertex ids (2 MB at nv = 2^24) lives in HBM -- every
-// streamed key was one random 64-byte line through L2 (0.33e12 keys/s over the whole chip against 1.1e12 for the hashed classes).
-// Both the row and every partner list are SORTED, so the id space is cut into ranges of 2^20 ids: for one range the row is an
-// EXACT BITMAP of 128 KB in LDS (one ds_read_b32 + a shift per key), and the keys of a partner list that fall into the range are
-// one contiguous segment.  A chunk is <= 1024 task edges of the row; their per-edge match counts (diamond needs C(n,2) of the
-// TOTAL) stay in LDS while the
-// workgroup walks the ranges; where the ranges cut each list is found once per chunk (range_bounds).
-constexpr int kRangeLog2 = 20;
-constexpr int kRangeWords = 1 << (kRangeLog2 - 5);
-constexpr int kRangeWaves = 16;
-constexpr int kRangeBatch = 16;  // task edges per batch: 64 batches per range and chunk for the 16 waves to balance
+// keys): no exact set of such a row fits LDS, and its dense bitmap over all vertex ids (2 MB at nv = 2^24) lives in HBM -- every
+// streamed key was one random 64-byte line through L2 (0.33e12 keys/s over the whole chip against 1.3e12 for the hashed classes).
+// Both the row and every partner list are SORTED: the row is cut into PIECES of <= kGiantPiece consecutive entries, each piece is
+// a hashed set like a class-2 row, and the keys of a partner list that can be in piece p -- those up to the piece's last id --
+// are one contiguous segment.  A chunk is <= kGiantEdges task edges of the row; their per-edge match counts (diamond needs
+// C(n,2) of the TOTAL) stay in LDS while the workgroup walks the pieces, and where the pieces cut each list is found once per
+// chunk (giant_bounds).
+// (First built with LDS bitmaps over id ranges of 2^20 ids, one ds_read_b32 per key: 14 ranges at nv = 2^24 cut the lists
+// into segments of ~160 keys, the flattening of which cost more than the cheaper test won -- 84 ms against 130 for the SPLIT
+// chunks and their HBM bitmaps on diamond R-MAT-24; pieces of 24576 entries are 3..17 per row and their segments are long lists.)
+constexpr int kGiantPiece = kStageCapBig;
+constexpr int kGiantWaves = 16;
+#ifndef GM_GIANT_BATCH
+#define GM_GIANT_BATCH 16
+#endif
+constexpr int kGiantBatch = GM_GIANT_BATCH;  // task edges per batch: >= 64 batches per piece and chunk for the 16 waves to balance
+constexpr int kGiantGroup = 8;   // boundaries found together (independent bisections, their loads in flight together)
 
-struct alignas(16) RangeLds {
-  unsigned bits[kRangeWords];
-  unsigned ecnt[kRangeEdges];  // per task edge: matches so far
-  HrowWave w[kRangeWaves];
+struct alignas(16) GiantLds {
+  unsigned short table[(1 << kHrowLbBig) * 8];
+  HrowWave w[kGiantWaves];
+  unsigned ecnt[kGiantEdges];  // per task edge: matches so far
+  int ovf[kHrowOvfCap];
+  int n_ovf;
   int next_batch;
   unsigned queue_pos;
-  int pad_[2];
+  int pad_;
 };
 
-struct RangeBits {
-  const unsigned *bits;
-  int r_lo;
-  __device__ __forceinline__ void operator()(const int (&key)[kHrowTiles], const bool (&in)[kHrowTiles], bool (&f)[kHrowTiles]) const {
-    unsigned w[kHrowTiles], sh[kHrowTiles];
-#pragma unroll
-    for (int q = 0; q < kHrowTiles; ++q) {
-      const unsigned idx = in[q] ? (unsigned)(key[q] - r_lo) : 0u;  // (a segment holds exactly the keys of its range)
-      sh[q] = idx & 31u;
-      w[q] = bits[idx >> 5];
-    }
-#pragma unroll
-    for (int q = 0; q < kHrowTiles; ++q) f[q] = in[q] & (((w[q] >> sh[q]) & 1u) != 0u);
-  }
-};
-
-// Where the ranges cut a partner list: bnd[rg * kRangeEdges + i] = number of keys of edge i's list below (rg + 1) << 20, for
-// all ranges at once -- kRangeGroup independent bisections run interleaved (their loads are in flight together), so a chunk
-// pays ~2 x 17 dependent round trips once instead of 12 per range and batch.  The boundaries live in the workgroup's slot of
-// the global scratch (written and re-read by the same CU: L2 hits, coalesced over the edges).
-constexpr int kRangeGroup = 8;
-__device__ __forceinline__ void range_bounds(const int *__restrict__ list, const int len, const int n_ranges, int *__restrict__ bnd,
-                                             const int i) {
+// bnd[pc * kGiantEdges + i] = number of keys of edge i's list that are <= the last id of piece pc
+__device__ __forceinline__ void giant_bounds(const int *__restrict__ list, const int len, const int *__restrict__ row, const int n_row,
+                                             const int n_pieces, int *__restrict__ bnd, const int i) {
   const int steps = bitlen(wave_max_nonneg(len));  // wave-uniform trip count, branch-free binary lifting
-  for (int g0 = 0; g0 < n_ranges; g0 += kRangeGroup) {
-    int lo[kRangeGroup];
+  for (int g0 = 0; g0 < n_pieces; g0 += kGiantGroup) {
+    int lo[kGiantGroup], last[kGiantGroup];
 #pragma unroll
-    for (int j = 0; j < kRangeGroup; ++j) lo[j] = 0;
+    for (int j = 0; j < kGiantGroup; ++j) {
+      lo[j] = 0;
+      last[j] = row[min((g0 + j + 1) * kGiantPiece, n_row) - 1];  // (wave-uniform address)
+    }
     for (int sbit = steps - 1; sbit >= 0; --sbit) {
-      int x[kRangeGroup];
+      int x[kGiantGroup];
 #pragma unroll
-      for (int j = 0; j < kRangeGroup; ++j) x[j] = list[max(min(lo[j] + (1 << sbit), len) - 1, 0)];  // unconditional, clamped
+      for (int j = 0; j < kGiantGroup; ++j) x[j] = list[max(min(lo[j] + (1 << sbit), len) - 1, 0)];  // unconditional, clamped
 #pragma unroll
-      for (int j = 0; j < kRangeGroup; ++j) {
+      for (int j = 0; j < kGiantGroup; ++j) {
         const int mid = lo[j] + (1 << sbit);
-        const long long bound = (long long)(g0 + j + 1) << kRangeLog2;
-        const bool take = (mid <= len) & ((long long)x[j] < bound);
+        const bool take = (mid <= len) & (x[j] <= last[j]);
         lo[j] = take ? mid : lo[j];
       }
     }
 #pragma unroll
-    for (int j = 0; j < kRangeGroup; ++j)
-      if (g0 + j < n_ranges) bnd[(size_t)(g0 + j) * kRangeEdges + i] = lo[j];
+    for (int j = 0; j < kGiantGroup; ++j)
+      if (g0 + j < n_pieces) bnd[(size_t)(g0 + j) * kGiantEdges + i] = lo[j];
   }
 }
 
-template <int PAT>
-__device__ __forceinline__ void range_chunk(const MineParams &p, RangeLds &B, const ChunkRec r, const int lane, const int wave, Acc &acc) {
+template <int PAT, bool K24>
+__device__ __forceinline__ void giant_chunk(const MineParams &p, GiantLds &B, const ChunkRec r, const int lane, const int wave, Acc &acc) {
   const int *__restrict__ rp = p.g.rp;
   const int *__restrict__ col = p.g.col;
   const int2 *__restrict__ edesc = p.g.edesc;
-  const int tid = threadIdx.x, nthreads = kRangeWaves * GM_WAVE;
-  static_assert(kRangeWaves * GM_WAVE == kRangeEdges, "one task edge per thread while the boundaries are found");
+  const int tid = threadIdx.x, nthreads = kGiantWaves * GM_WAVE;
   const int u = r.u_begin;
   const int ru = rp[u], n_row = rp[u + 1] - ru;
   const int *__restrict__ row = col + ru;
-  const int n_ranges = (int)(((long long)p.g.nv + (1ll << kRangeLog2) - 1) >> kRangeLog2);
+  const int n_pieces = (n_row + kGiantPiece - 1) / kGiantPiece;
   int *__restrict__ bnd = reinterpret_cast<int *>(p.scratch) + (size_t)blockIdx.x * p.scratch_words;
   HrowWave &L = B.w[wave];
-  for (int eb = r.e_begin; eb < r.e_end; eb += kRangeEdges) {  // (the host cuts the rows into chunks of kRangeEdges task edges)
-    const int cnt = min(kRangeEdges, r.e_end - eb);
-    {
-      const int i = tid;
+  for (int eb = r.e_begin; eb < r.e_end; eb += kGiantEdges) {  // (the host cuts the rows into chunks of kGiantEdges task edges)
+    const int cnt = min(kGiantEdges, r.e_end - eb);
+    for (int i0 = 0; i0 < kGiantEdges; i0 += nthreads) {  // (whole waves: giant_bounds takes a wave-uniform trip count)
+      const int i = i0 + tid;
       const int e = eb + min(i, cnt - 1);
       const int v = col[e];
       const int2 d = edesc[e];
@@ -516,43 +510,30 @@ __device__ __forceinline__ void range_chunk(const MineParams &p, RangeLds &B, co
       }
       if (PAT == PAT_MOTIF3 && i < cnt) acc.c2 += (unsigned long long)(e - ru);  // position of v in the row, ALL directed edges
       B.ecnt[i] = 0u;
-      range_bounds(col + d.x, len, n_ranges, bnd, i);
+      if (i0 < cnt) giant_bounds(col + d.x, len, row, n_row, n_pieces, bnd, i);  // (wave-uniform condition)
     }
-    int row_pos = 0;  // workgroup-uniform: every thread bisects the same addresses
-    for (int rg = 0; rg < n_ranges; ++rg) {
-      const int r_lo = rg << kRangeLog2;
-      const long long r_hi = (long long)r_lo + (1ll << kRangeLog2);
-      const int s = row_pos;
-      const int t = (r_hi > 0x7fffffffll) ? n_row : s + lower_bound(row + s, n_row - s, (int)r_hi);
-      row_pos = t;
-      if (t == s) continue;  // the row has nobody in this range (uniform over the workgroup)
-      __syncthreads();       // the waves are done with the previous bitmap (first trip: the boundaries are written)
-      {
-        uint4 *b4 = reinterpret_cast<uint4 *>(B.bits);
-        for (int i = tid; i < kRangeWords / 4; i += nthreads) b4[i] = make_uint4(0u, 0u, 0u, 0u);
-        if (tid == 0) B.next_batch = 0;
-      }
+    for (int pc = 0; pc < n_pieces; ++pc) {
+      const int s = pc * kGiantPiece, t = min(s + kGiantPiece, n_row);
+      __syncthreads();  // the waves are done with the previous set (first trip: the boundaries are written)
+      HrowView hv;
+      hrow_build<K24>(B, hv, row + s, t - s, kHrowLbBig, p.g.nv, p.flags, tid, nthreads);
+      if (tid == 0) B.next_batch = 0;
       __syncthreads();
-      for (int i = s + tid; i < t; i += nthreads) {
-        const unsigned idx = (unsigned)(row[i] - r_lo);
-        atomicOr(&B.bits[idx >> 5], 1u << (idx & 31u));
-      }
-      __syncthreads();
-      const RangeBits member{B.bits, r_lo};
-      const int *__restrict__ b_end = bnd + (size_t)rg * kRangeEdges;
-      const int *__restrict__ b_start = bnd + (size_t)max(rg - 1, 0) * kRangeEdges;
+      const HashedRow<K24, GiantLds> member{B, hv, row + s, t - s};
+      const int *__restrict__ b_end = bnd + (size_t)pc * kGiantEdges;
+      const int *__restrict__ b_start = bnd + (size_t)max(pc - 1, 0) * kGiantEdges;
       for (;;) {
         int bi = 0;
         if (lane == 0) bi = atomicAdd(&B.next_batch, 1);
-        const int le0 = readfirst(bi) * kRangeBatch;
+        const int le0 = readfirst(bi) * kGiantBatch;
         if (le0 >= cnt) break;
         const int le = min(le0 + lane, cnt - 1);
-        const bool valid = (lane < kRangeBatch) && (le0 + lane < cnt);
+        const bool valid = (lane < kGiantBatch) && (le0 + lane < cnt);
         const int e = eb + le;
         const int2 desc = edesc[e];
         const int v = col[e];
         const int end = b_end[le];
-        const int start = rg ? b_start[le] : 0;
+        const int start = pc ? b_start[le] : 0;
         L.cnt[lane] = (PAT == PAT_MOTIF3) ? (unsigned)v : 0u;
         wave_sync();
         unsigned n_long = 0, m_any = 0, m_low = 0;
@@ -591,10 +572,10 @@ __device__ __forceinline__ void range_chunk(const MineParams &p, RangeLds &B, co
   }
 }
 
-template <int PAT>
-__global__ __launch_bounds__((kRangeWaves * GM_WAVE), 4)
-void range_kernel(const MineParams p) {
-  __shared__ RangeLds B;
+template <int PAT, bool K24>
+__global__ __launch_bounds__((kGiantWaves * GM_WAVE), 4)
+void giant_kernel(const MineParams p) {
+  __shared__ GiantLds B;
   const int lane = threadIdx.x & (GM_WAVE - 1);
   const int wave = threadIdx.x >> 6;
   Acc acc;
@@ -607,7 +588,7 @@ void range_kernel(const MineParams p) {
     for (unsigned i = q; i < qe; ++i) {
       const size_t pos = (size_t)p.first + (size_t)i * (size_t)p.step;
       const size_t cid = p.order ? (size_t)p.order[pos] : pos;
-      range_chunk<PAT>(p, B, p.chunks[cid], lane, wave, acc);  // ends with a workgroup barrier
+      giant_chunk<PAT, K24>(p, B, p.chunks[cid], lane, wave, acc);  // ends with a workgroup barrier
     }
   }
   const unsigned long long s0 = wave_sum_u64(acc.c0);
@@ -622,16 +603,27 @@ void range_kernel(const MineParams p) {
   }
 }
 
-hipError_t launch_range(Pattern pat, const MineParams &p, int grid_blocks, hipStream_t stream) {
-  static_assert(sizeof(RangeLds) <= 163840, "the range kernel must fit the 160 KB of one CU");
+// scratch words per workgroup: one boundary per piece and task edge of a chunk
+unsigned long long giant_scratch_words(int max_deg) { return (unsigned long long)kGiantEdges * (unsigned long long)(max_deg / kGiantPiece + 1); }
+
+hipError_t launch_giant(Pattern pat, const MineParams &p, int grid_blocks, hipStream_t stream) {
+  static_assert(sizeof(GiantLds) <= 163840, "the giant-row kernel must fit the 160 KB of one CU");
+  static_assert(sizeof(HrowWave) * kGiantWaves >= (size_t)(2 << kHrowLbBig), "fill counters alias the wave scratch");
   if (p.g.edesc == nullptr || p.scratch == nullptr) return hipErrorInvalidValue;
-  const dim3 grid((unsigned)grid_blocks), block(kRangeWaves * GM_WAVE);
+  const dim3 grid((unsigned)grid_blocks), block(kGiantWaves * GM_WAVE);
+  const bool k24 = p.g.nv <= (1 << 24) && !(p.flags & (1 << 23));
+#define GM_GIANT_CASE(P)                                                                    \
+  case P:                                                                                   \
+    if (k24) hipLaunchKernelGGL((giant_kernel<P, true>), grid, block, 0, stream, p);          \
+    else hipLaunchKernelGGL((giant_kernel<P, false>), grid, block, 0, stream, p);             \
+    break;
   switch (pat) {
-    case PAT_DIAMOND: hipLaunchKernelGGL((range_kernel<PAT_DIAMOND>), grid, block, 0, stream, p); break;
-    case PAT_MOTIF3: hipLaunchKernelGGL((range_kernel<PAT_MOTIF3>), grid, block, 0, stream, p); break;
-    case PAT_MOTIF4E: hipLaunchKernelGGL((range_kernel<PAT_MOTIF4E>), grid, block, 0, stream, p); break;
+    GM_GIANT_CASE(PAT_DIAMOND)
+    GM_GIANT_CASE(PAT_MOTIF3)
+    GM_GIANT_CASE(PAT_MOTIF4E)
     default: return hipErrorInvalidValue;
   }
+#undef GM_GIANT_CASE
   return hipGetLastError();
 }
 

@@ -316,13 +316,15 @@ size_t mine_lds_bytes(Pattern pat);
 hipError_t launch_mine_wide(Pattern pat, int cls, const MineParams &p, int grid_blocks, hipStream_t stream);
 size_t mine_wide_lds_bytes(int cls);
 // hashed-row classes (gm_hrow.hip): the row as a hash-partitioned set of 16-bit remainders, 2^LB buckets of eight slots
+constexpr int kClassRowMin = 1024;  // rows longer than this leave the general kernel when the classes are on
 constexpr int kHrowLbMid = 11;  // class 1 (rows of 3073..8191 entries): 32 KB
 constexpr int kHrowLbBig = 13;  // class 2 (rows of 8192..24576 entries): 128 KB
 hipError_t launch_hrow(Pattern pat, int cls, const MineParams &p, int grid_blocks, hipStream_t stream);
 size_t hrow_lds_bytes(int cls);
-// giant rows (> kStageCapBig entries): LDS bitmaps over ranges of 2^20 ids, chunks of kRangeEdges task edges (gm_hrow.hip)
-constexpr int kRangeEdges = 1024;
-hipError_t launch_range(Pattern pat, const MineParams &p, int grid_blocks, hipStream_t stream);
+// giant rows (> kStageCapBig entries): pieces of kStageCapBig entries as hashed sets, chunks of kGiantEdges task edges (gm_hrow.hip)
+constexpr int kGiantEdges = 2048;
+hipError_t launch_giant(Pattern pat, const MineParams &p, int grid_blocks, hipStream_t stream);
+unsigned long long giant_scratch_words(int max_deg);
 int hrow_per_cu(int cls);
 // ids must split into bucket + 14-bit remainder: bits of nv <= LB_max + 14
 inline bool hrow_fits(int nv, int cls) {
