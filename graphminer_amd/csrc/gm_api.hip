@@ -1792,14 +1792,15 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
   // 636 ms, 3-motif 458 vs 370 ms. tune[6] & 0x100000 forces them on.
   bool use_classes = sym_pat && !(la->tune[6] & 0x80000) && !(la->tune[5] == 1);
   if (use_classes && !(la->tune[6] & 0x100000)) {
-    // ... and where they get enough work to fill the chip with their own launches.  Measured with the hashed sets / id-range
-    // bitmaps (profiles/r02/ab_class_threshold.log; entries of the rows > 3072, general path vs classes, ms): diamond R-MAT-18
-    // 0.9 M 2.6 vs 4.1, power law 2.3 M 3.9 vs 5.0, R-MAT-20 7.0 M 10.4 vs 8.4, R-MAT-22 (ef 10) 14 M 27.9 vs 21.0, R-MAT-23 78 M
-    // 255 vs 107; 3-motif (bounded lists: less to stream) R-MAT-20 6.4 vs 7.3, R-MAT-22 (ef 10) 16.3 vs 17.5, R-MAT-24 138 M 458 vs 196.
+    // ... and where they get enough work to fill the chip with their own launches.  Measured (profiles/r02/ab_class_threshold.log;
+    // M entries in rows > 3072: general path vs classes, ms): diamond R-MAT-18 0.9 M: 2.6 vs 3.2, R-MAT-20 (ef 10) 1.8 M: 5.3 vs 6.6,
+    // power law 2.3 M: 4.0 vs 4.6, R-MAT-20 (ef 16) 7.0 M: 10.4 vs 7.9, R-MAT-22 (ef 10) 14 M: 27.9 vs 17.5, R-MAT-23 78 M: 255 vs 107;
+    // 3-motif (bounded lists: less to stream) R-MAT-20 7.0 M: 6.4 vs 7.0, R-MAT-22 (ef 10) 14 M: 16.4 vs 15.2, R-MAT-22 (ef 16) 26 M:
+    // 37.6 vs 33.2, R-MAT-23 78 M: 129 vs 73, R-MAT-24 138 M: 458 vs 172.
     int rc = long_row_entries(g);
     if (rc) return rc;
     const long long per_rank = g->cls_entries / std::max(world, 1);
-    use_classes = per_rank >= (pat == PAT_MOTIF3 ? (24ll << 20) : (4ll << 20));
+    use_classes = per_rank >= (pat == PAT_MOTIF3 ? (10ll << 20) : (4ll << 20));
   }
   RowFilter rf;
   rf.skip_clique_wide = use_wide ? clique_wide_min_words() : 0;
