@@ -154,17 +154,25 @@ __device__ __forceinline__ void hrow_build(LdsT &B, HrowView &hv, const int *__r
     if (tid == 0) B.n_ovf = 0;
   }
   __syncthreads();
-  for (int i = tid; i < n; i += nthreads) {
-    const int key = row[i];
-    const unsigned h = hrow_hash<K24>(hv, key);
-    const unsigned b = h >> hv.sh, rem = h & hv.rmask;
-    const unsigned shift = (b & 1u) * 16u;
-    const unsigned slot = (atomicAdd(&fill32[b >> 1], 1u << shift) >> shift) & 0xffffu;
-    if (slot < 8u) {
-      B.table[(b << 3) + slot] = (unsigned short)rem;
-    } else {
-      const int j = atomicAdd(&B.n_ovf, 1);
-      if (j < kHrowOvfCap) B.ovf[j] = key;
+  constexpr int kU = 4;  // keys requested together per thread (one round trip for four instead of one each)
+  for (int i0 = tid; i0 < n; i0 += kU * nthreads) {
+    int key[kU];
+#pragma unroll
+    for (int j = 0; j < kU; ++j) key[j] = row[min(i0 + j * nthreads, n - 1)];
+#pragma unroll
+    for (int j = 0; j < kU; ++j) {
+      if (i0 + j * nthreads < n) {
+        const unsigned h = hrow_hash<K24>(hv, key[j]);
+        const unsigned b = h >> hv.sh, rem = h & hv.rmask;
+        const unsigned shift = (b & 1u) * 16u;
+        const unsigned slot = (atomicAdd(&fill32[b >> 1], 1u << shift) >> shift) & 0xffffu;
+        if (slot < 8u) {
+          B.table[(b << 3) + slot] = (unsigned short)rem;
+        } else {
+          const int jo = atomicAdd(&B.n_ovf, 1);
+          if (jo < kHrowOvfCap) B.ovf[jo] = key[j];
+        }
+      }
     }
   }
   __syncthreads();

@@ -322,7 +322,10 @@ constexpr int kHrowLbBig = 13;  // class 2 (rows of 8192..24576 entries): 128 KB
 hipError_t launch_hrow(Pattern pat, int cls, const MineParams &p, int grid_blocks, hipStream_t stream);
 size_t hrow_lds_bytes(int cls);
 // giant rows (> kStageCapBig entries): pieces of kStageCapBig entries as hashed sets, chunks of kGiantEdges task edges (gm_hrow.hip)
-constexpr int kGiantEdges = 2048;
+#ifndef GM_GIANT_EDGES
+#define GM_GIANT_EDGES 2048
+#endif
+constexpr int kGiantEdges = GM_GIANT_EDGES;
 hipError_t launch_giant(Pattern pat, const MineParams &p, int grid_blocks, hipStream_t stream);
 unsigned long long giant_scratch_words(int max_deg);
 int hrow_per_cu(int cls);
