@@ -1,5 +1,4 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 export TMPDIR=/tmp
-mkdir -p gpurun_out/r2s
-python scripts/ab.py gpurun_out/r2s/a.json default,ge1024,ge3072 'motif3_rmat24:--workload;motif3;--steps;3;--warmup;1' 'diamond_rmat24:--workload;diamond;--scale;24;--ef;16;--steps;3;--warmup;1' 2>&1 | cut -c1-110 | tee gpurun_out/r2s/giant_edges.log
+timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "adversarial or hub_paths or hub_graph or random_graphs" --durations=5 2>&1 | tail -12

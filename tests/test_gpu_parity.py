@@ -488,6 +488,63 @@ def test_hub_paths_against_oracle_rmat16(dev):
     assert MotifSolver(s, 4) == e["motif4"]
 
 
+def test_hashed_row_classes_on_adversarial_ids(dev):
+    """The hashed-set kernels (gm_hrow.hip) on rows built against their hash: ids = h * C^-1 mod 2^K land in chosen buckets.
+    Hub 1 (1500 entries): five buckets take 20 ids each -> 12 surplus ids per bucket in the surplus list; hub 2 (1300 entries in
+    21 buckets) and hub 3 (9000 entries, every bucket of its class-2 table twice over) overflow the list -> the global-memory
+    lookup; hub 4 (30000 entries) is a giant row of two pieces; hub 5 (5000 random ids) the ordinary case. Against the CPU
+    oracle, classes forced on (0x100000), and every variant of the class kernels."""
+    K = 16
+    nv = 1 << K
+    ck = ((0x9E3779B97F4A7C15 >> (64 - K)) | 1) & (nv - 1)
+    inv = pow(ck, -1, nv)
+    rng = np.random.default_rng(7)
+    hubs = [3, 40001, 17, 5, 60000]
+
+    def ids_of_hashes(h):
+        x = (np.asarray(h, dtype=np.uint64) * np.uint64(inv)) & np.uint64(nv - 1)
+        return x
+
+    # hub 1: n = 1500 -> LB = 9 (512 buckets of 2^7 hash values): 5 buckets x 20 + 1400 spread over the others
+    sh1 = K - 9
+    h1 = np.concatenate([np.arange(20, dtype=np.uint64) + (np.uint64(b) << np.uint64(sh1)) for b in (7, 100, 101, 300, 511)] +
+                        [(np.arange(512, dtype=np.uint64) << np.uint64(sh1)) + np.uint64(64 + j) for j in range(3)])[:1500]
+    # hub 2: n = 1300 -> LB = 9: 21 buckets, 62 ids each
+    h2 = np.concatenate([np.arange(62, dtype=np.uint64) + (np.uint64(b * 11) << np.uint64(sh1)) for b in range(21)])
+    # hub 3: n = 9000 -> class 2, LB = 12 (4096 buckets of 16 hash values): 563 buckets completely full
+    h3 = np.arange(9000, dtype=np.uint64) + np.uint64(4096)
+    s, d = [], []
+    for hub, hs in zip(hubs[:3], (h1, h2, h3)):
+        x = ids_of_hashes(hs)
+        s.append(np.full(x.size, hub, dtype=np.uint64)); d.append(x)
+    x4 = rng.choice(nv, 30000, replace=False).astype(np.uint64)
+    s.append(np.full(x4.size, hubs[3], dtype=np.uint64)); d.append(x4)
+    x5 = rng.choice(nv, 5000, replace=False).astype(np.uint64)
+    s.append(np.full(x5.size, hubs[4], dtype=np.uint64)); d.append(x5)
+    # background: partner lists of 5..60 keys, some of them long (vertices 100..131 get ~3000 neighbours each)
+    s.append(rng.integers(0, nv, 600000).astype(np.uint64)); d.append(rng.integers(0, nv, 600000).astype(np.uint64))
+    for v in range(100, 132):
+        y = rng.choice(nv, 3000, replace=False).astype(np.uint64)
+        s.append(np.full(y.size, v, dtype=np.uint64)); d.append(y)
+    g = csr_from_pairs(nv, np.concatenate(s), np.concatenate(d))
+    deg = np.diff(g.row_ptr)
+    assert deg[hubs[3]] > 24576 and 8191 < deg[hubs[2]] <= 24576 and 1024 < deg[hubs[0]] <= 8191
+    osym = O.OGraph(g.row_ptr, g.col_idx)
+    want_d, want_m3 = O.diamond(osym), O.motif3(osym)
+    sd = g.to_device(dev)
+    general = [0, 0, 0, 0, 0, 0, 0x80000]
+    assert SglSolver(sd, "diamond", tune=general) == want_d and MotifSolver(sd, 3, tune=general) == want_m3
+    want_m4 = MotifSolver(sd, 4, tune=general)
+    for flags in (0x100000, 0x100000 | 0x800000, 0x100000 | 0x400000, 0x100000 | 0x1000000, 0x100000 | 0x1000):
+        tune = [0, 0, 0, 0, 0, 0, flags]
+        assert SglSolver(sd, "diamond", tune=tune) == want_d, hex(flags)
+        assert MotifSolver(sd, 3, tune=tune) == want_m3, hex(flags)
+        assert MotifSolver(sd, 4, tune=tune) == want_m4, hex(flags)
+    assert sum(SglSolver(sd, "diamond", rank=r, world=3, tune=[0, 0, 0, 0, 0, 0, 0x100000]) for r in range(3)) == want_d
+    parts = [MotifSolver(sd, 3, rank=r, world=5, tune=[0, 0, 0, 0, 0, 0, 0x100000]) for r in range(5)]
+    assert [sum(p[i] for p in parts) % 2**64 for i in range(2)] == want_m3
+
+
 @pytest.mark.parametrize("pattern", ["rectangle", "house", "pentagon"])
 def test_sgl_map_kernels_match_flat_kernels_rmat14(dev, pattern):
     """R-MAT-14 (ef 16, max degree 3.6 K: heavy centres use all four waves on one map): the wedge-accumulation kernels against
