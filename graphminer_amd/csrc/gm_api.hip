@@ -1827,7 +1827,11 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
     // dependent global round trips (descriptors, the bounded prefix of 3-motif) before it streams, so small batches and
     // small parts lose more than the shorter tail wins (8 M keys 368 / 634, 32 M keys 363 / 627). Parts of 32 M keys only trim the
     // few heaviest rows. Side streams for the class kernels: 396 / 667 (GM_CLASSES_STREAMS, off).
-    unsigned long long cls_cap = (la->tune[6] & 0x1000) ? 4096ull : std::max<unsigned long long>(part_cap, 32ull << 20);
+    // (hashed sets: a part costs one table build, ~10 us. A rank's share is 1/world of the launch and so is the tolerable tail -- one-GPU
+    // simulation of 8 rank shares, parts of 32 M / 8 M / 2 M keys: 3-motif R-MAT-24 28.2 / 25.8 / 26.5 ms per rank, diamond R-MAT-22 8.3 / 6.4 / 5.4;
+    // on one GPU the same parts cost 171 / 173 / 181 and 17.5 / 18.3 / 18.4 ms: profiles/r02/ab_class_part_cap.log)
+    unsigned long long cls_cap = (la->tune[6] & 0x1000) ? 4096ull
+                                 : std::max<unsigned long long>(part_cap, std::max<unsigned long long>((32ull << 20) / (unsigned long long)std::max(world, 1), 2ull << 20));
     if (const char *e = getenv("GM_CLS_CAP_MKEYS")) cls_cap = (unsigned long long)std::max(1, atoi(e)) << 20;  // (sweeps)
     // (target 1: every row is a chunk of its own -- the class kernels take one-row chunks -- also below the general kernel's chunk target)
     rc = get_table(g, 1, false, 0, cls_cap, kStageCapMid, &tab_cls[1], r1, 0x7fffffff);
