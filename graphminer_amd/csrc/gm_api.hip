@@ -203,7 +203,6 @@ struct gm_graph {
   int nv = 0;
   long long ne = 0;
   int max_deg = 0;
-  long long cls_entries = -1;  // entries of the rows above the general kernel's LDS stage (long_row_entries), -1 = not counted yet
   int *d_rp = nullptr;   // int32 offsets, owned
   int *d_col = nullptr;  // col_idx
   bool own_col = true;
@@ -250,8 +249,8 @@ struct gm_graph {
   unsigned *d_wide_mat = nullptr;      // matrix arena (largest round so far)
   size_t wide_mat_bytes = 0;
   unsigned *d_wide_queue = nullptr;    // dequeue words of the wide launches of one call (zeroed per call)
-  hipStream_t aux_stream[2] = {nullptr, nullptr};  // the big-LDS class kernels run beside the general one (run_pattern)
-  hipEvent_t aux_done[2] = {nullptr, nullptr};
+  hipStream_t aux_stream[3] = {nullptr, nullptr, nullptr};  // class kernels that cannot fill the chip run beside the others (run_pattern)
+  hipEvent_t aux_done[3] = {nullptr, nullptr, nullptr};
   gm_setup_times setup = {0, 0, 0, 0, 0};  // accumulated pre-processing time of this handle (gm_graph_setup_times)
   std::mutex mu;
 };
@@ -633,17 +632,6 @@ __global__ __launch_bounds__(256) void orient_segout_kernel(int nv, const int *_
     segs[k].out = run;
     run += seg_count[k];
   }
-}
-// entries of the rows longer than `thresh` (how much work the workgroup classes of the symmetric-graph patterns would get)
-__global__ __launch_bounds__(256) void long_row_entries_kernel(int nv, const int *__restrict__ rp, int thresh, unsigned long long *__restrict__ out) {
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  unsigned long long s = 0;
-  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += stride) {
-    const int d = rp[v + 1] - rp[v];
-    s += d > thresh ? (unsigned long long)d : 0ull;
-  }
-  s = gm::wave_sum_u64(s);
-  if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
 }
 __global__ __launch_bounds__(256) void max_degree_kernel(int nv, const int *__restrict__ rp, int *__restrict__ out) {
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -1735,22 +1723,6 @@ static void fill_stats(gm_stats *st, uint64_t tasks, uint64_t chunks, int grid, 
   st->block = (uint32_t)block;
 }
 
-// entries of the rows above the general kernel's LDS stage, counted once per graph
-static int long_row_entries(gm_graph *g) {
-  if (g->cls_entries >= 0) return GM_OK;
-  HIP_TRY(hipSetDevice(g->device));
-  DevBuf<unsigned long long> sum;
-  HIP_TRY(sum.alloc(1));
-  HIP_TRY(hipMemset(sum.p, 0, sizeof(unsigned long long)));
-  hipLaunchKernelGGL(long_row_entries_kernel, dim3((unsigned)std::max<long long>(1, std::min<long long>(((long long)g->nv + 255) / 256, 2048))), dim3(256), 0, 0,
-                     g->nv, g->d_rp, kStageCapWide, sum.p);
-  HIP_TRY(hipGetLastError());
-  unsigned long long h = 0;
-  HIP_TRY(hipMemcpy(&h, sum.p, sizeof h, hipMemcpyDeviceToHost));
-  g->cls_entries = (long long)h;
-  return GM_OK;
-}
-
 static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uint64_t *h_out, int nout, gm_stats *st,
                        int fin_mode = -1, unsigned long long fin_base = 0) {
   if (fin_mode < 0) fin_mode = (pat == PAT_MOTIF3) ? FIN_MOTIF3 : FIN_COPY;
@@ -1786,22 +1758,14 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
   // symmetric-graph patterns: the rows just above the LDS stage go to the big-LDS workgroup classes (gm_chunk.h MineCfg)
   // (tune[6] & 0x80000: A/B switch, they stay SPLIT rows with dense bitmaps)
   const bool sym_pat = stage_cap_of(pat) == kStageCapWide;
-  // They pay where the dense bitmaps of the SPLIT path are cold: a bitmap has nv bits, and up to ~1 MB (nv <= 2^23) the bitmaps
-  // of the rows being worked on stay in L2 -- measured, diamond R-MAT-22 28 ms (SPLIT + bitmaps) vs 47 ms (classes), R-MAT-20
-  // 10.4 vs 20.8, the LiveJournal-size power-law graph (nv 4.8 M, 600 KB bitmaps) 3.9 vs 8.0; at nv = 2^24 (2 MB per bitmap) 819 vs
-  // 636 ms, 3-motif 458 vs 370 ms. tune[6] & 0x100000 forces them on.
+  // (tune[6] & 0x80000: A/B switch, every row through the general kernel -- SPLIT chunks and dense HBM bitmaps for the long ones)
   bool use_classes = sym_pat && !(la->tune[6] & 0x80000) && !(la->tune[5] == 1);
-  if (use_classes && !(la->tune[6] & 0x100000)) {
-    // ... and where they get enough work to fill the chip with their own launches.  Measured (profiles/r02/ab_class_threshold.log;
-    // M entries in rows > 3072: general path vs classes, ms): diamond R-MAT-18 0.9 M: 2.6 vs 3.2, R-MAT-20 (ef 10) 1.8 M: 5.3 vs 6.6,
-    // power law 2.3 M: 4.0 vs 4.6, R-MAT-20 (ef 16) 7.0 M: 10.4 vs 7.9, R-MAT-22 (ef 10) 14 M: 27.9 vs 17.5, R-MAT-23 78 M: 255 vs 107;
-    // 3-motif (bounded lists: less to stream) R-MAT-20 7.0 M: 6.4 vs 7.0, R-MAT-22 (ef 10) 14 M: 16.4 vs 15.2, R-MAT-22 (ef 16) 26 M:
-    // 37.6 vs 33.2, R-MAT-23 78 M: 129 vs 73, R-MAT-24 138 M: 458 vs 172.
-    int rc = long_row_entries(g);
-    if (rc) return rc;
-    const long long per_rank = g->cls_entries / std::max(world, 1);
-    use_classes = per_rank >= (pat == PAT_MOTIF3 ? (10ll << 20) : (4ll << 20));
-  }
+  // They are separate launches: one whose share of chunks cannot fill the chip runs on a side stream (below), and with that the
+  // classes win or tie wherever there are long rows (profiles/r02/ab_class_threshold.log, general path vs classes, ms: diamond R-MAT-16
+  // 1.68 vs 0.76, R-MAT-18 2.64 vs 2.03, power law 3.94 vs 3.68, R-MAT-22 27.9 vs 16.6, R-MAT-23 255 vs 107; 3-motif R-MAT-16 1.43 vs 0.75,
+  // R-MAT-20 6.4 vs 5.7, power law 4.07 vs 4.10, R-MAT-24 458 vs 172). A graph without such rows skips their (empty) tables.
+  // tune[6] & 0x100000 forces them on.
+  if (use_classes && !(la->tune[6] & 0x100000)) use_classes = g->max_deg > kClassRowMin;
   RowFilter rf;
   rf.skip_clique_wide = use_wide ? clique_wide_min_words() : 0;
   // Rows of 1025..3072 entries fit the general kernel's stage, but their partner lists (mean 600 keys on R-MAT-24) are cheaper
@@ -2008,12 +1972,31 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
     }
   }
   uint64_t chunks_total = (uint64_t)p.count;
-  bool joined[2] = {false, false};
+  bool joined[3] = {false, false, false};
   if (use_classes) {
-    // The class kernels run on their own streams BESIDE the general kernel: class 2 (one 160 KB workgroup per CU) is launched
-    // first and takes the CUs; as its persistent workgroups run out of chunks they leave, and the workgroups of class 1 and of
-    // the general kernel move in -- the tails overlap instead of adding up (on one stream every kernel boundary waited for
-    // the slowest workgroup of the kernel before it).
+    // A class kernel whose share of chunks cannot fill the chip on its own (small graphs, 1/8 shares) runs on a side stream, so
+    // that the kernels launched after it fill the idle CUs; one that can fill it stays on the launch's stream -- there every
+    // kernel has the chip to itself (side streams at R-MAT-24 size: diamond 667 vs 636 ms, the 148 KB workgroups of class 2 wait
+    // for whole CUs to drain). GM_CLASSES_STREAMS=0 / 1 forces one or the other.
+    const char *streams_env = getenv("GM_CLASSES_STREAMS");
+    auto side_stream = [&](int cls, long long count, long long full_grid, hipStream_t *ws) -> int {
+      *ws = stream;
+      const bool side = streams_env ? atoi(streams_env) != 0 : count < full_grid;
+      if (!side) return GM_OK;
+      if (!g->aux_stream[cls - 1]) {
+        HIP_TRY(hipStreamCreateWithFlags(&g->aux_stream[cls - 1], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&g->aux_done[cls - 1], hipEventDisableTiming));
+      }
+      *ws = g->aux_stream[cls - 1];
+      HIP_TRY(hipStreamWaitEvent(*ws, ctx.evp[0], 0));  // after the counters were zeroed and the timer started
+      return GM_OK;
+    };
+    auto side_done = [&](int cls, hipStream_t ws) -> int {
+      if (ws == stream) return GM_OK;
+      HIP_TRY(hipEventRecord(g->aux_done[cls - 1], ws));
+      joined[cls - 1] = true;
+      return GM_OK;
+    };
     for (int cls = 3; cls >= 1; --cls) {
       if (!tab_cls[cls]) continue;
       MineParams q = p;
@@ -2037,27 +2020,24 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
         }
         q.scratch = g->d_scratch;
         q.scratch_words = slot_words;
-        HIP_TRY(launch_giant(pat, q, rgrid, stream));
+        hipStream_t ws;
+        rc = side_stream(cls, q.count, g->cu_count, &ws);
+        if (rc) return rc;
+        HIP_TRY(launch_giant(pat, q, rgrid, ws));
+        rc = side_done(cls, ws);
+        if (rc) return rc;
         continue;
       }
       const bool hrow = !(la->tune[6] & 0x400000) && p.g.edesc != nullptr && hrow_fits(g->nv, cls);
       const int per_cu_w = hrow ? hrow_per_cu(cls) : (int)std::max<size_t>(1, (160 * 1024) / mine_wide_lds_bytes(cls));
       const int wgrid = (int)std::max<long long>(1, std::min<long long>(q.count, (long long)g->cu_count * per_cu_w));
-      hipStream_t ws = stream;
-      if (getenv("GM_CLASSES_STREAMS")) {  // (measured: side streams 743 / 462 ms vs one stream 699 / 426 ms -- off by default)
-        if (!g->aux_stream[cls - 1]) {
-          HIP_TRY(hipStreamCreateWithFlags(&g->aux_stream[cls - 1], hipStreamNonBlocking));
-          HIP_TRY(hipEventCreateWithFlags(&g->aux_done[cls - 1], hipEventDisableTiming));
-        }
-        ws = g->aux_stream[cls - 1];
-        HIP_TRY(hipStreamWaitEvent(ws, ctx.evp[0], 0));  // after the counters were zeroed and the timer started
-      }
+      hipStream_t ws;
+      rc = side_stream(cls, q.count, (long long)g->cu_count * per_cu_w, &ws);
+      if (rc) return rc;
       if (hrow) HIP_TRY(launch_hrow(pat, cls, q, wgrid, ws));
       else HIP_TRY(launch_mine_wide(pat, cls, q, wgrid, ws));
-      if (ws != stream) {
-        HIP_TRY(hipEventRecord(g->aux_done[cls - 1], ws));
-        joined[cls - 1] = true;
-      }
+      rc = side_done(cls, ws);
+      if (rc) return rc;
     }
   }
   if (p.count > 0) HIP_TRY(launch_mine(pat, p, grid, stream));
@@ -2100,7 +2080,7 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
     }
   }
 #endif
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 3; ++i)
     if (joined[i]) HIP_TRY(hipStreamWaitEvent(stream, g->aux_done[i], 0));  // the launch ends when all three kernels have
   fill_stats(st, (pat == PAT_DIAMOND || pat == PAT_MOTIF4E) ? my_edges / 2 : my_edges, chunks_total, grid,
              kWavesPerBlock * GM_WAVE);

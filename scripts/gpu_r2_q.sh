@@ -1,12 +1,8 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 export TMPDIR=/tmp
-mkdir -p gpurun_out/r2s
-{
-for cap in 32 8 2 1; do
-echo "== GM_CLS_CAP_MKEYS=$cap, classes forced"
-GM_CLS_CAP_MKEYS=$cap python scripts/sim_scale.py --workload diamond --scale 22 --ef 10 --reps 2 --tune 0,0,0,0,0,0,1048576,0 --worlds 1,2,8
-GM_CLS_CAP_MKEYS=$cap python scripts/sim_scale.py --workload motif3 --scale 24 --ef 16 --reps 2 --tune 0,0,0,0,0,0,1048576,0 --worlds 1,8
-GM_CLS_CAP_MKEYS=$cap python scripts/sim_scale.py --workload diamond --scale 20 --ef 16 --reps 2 --tune 0,0,0,0,0,0,1048576,0 --worlds 1
-done
-} 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r2s/cls_cap.log
+timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+python bench.py --configs diamond,motif3 --no-cpu-baseline --traffic off 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read())
+for c in d['configs'][1:]: print('default-mode', c['workload'], c['kernel_ms_avg'], c['setup_ms'], c['count_matches_cpu'])
+for s_ in d.get('livejournal_standins',[]): print(s_['workload'], s_['graph'][:20], s_['kernel_ms_avg'])"

@@ -294,6 +294,9 @@ def test_rows_longer_than_the_lds_staging_capacity(dev):
     assert TCSolver(d) == math.comb(n, 3)
     assert MotifSolver(s, 3) == [0, math.comb(n, 3)]
     assert SglSolver(s, "diamond") == math.comb(n, 2) * math.comb(n - 2, 2)
+    general = [0, 0, 0, 0, 0, 0, 0x80000]  # (rows > 1024 entries go to the hashed-row class by default; this is the general kernel)
+    assert MotifSolver(s, 3, tune=general) == [0, math.comb(n, 3)]
+    assert SglSolver(s, "diamond", tune=general) == math.comb(n, 2) * math.comb(n - 2, 2)
     assert CliqueSolver(d, 4) == math.comb(n, 4)
 
 
@@ -408,6 +411,9 @@ def test_hub_graph_against_oracle(dev):
     assert TCSolver(d) == O.tc(odag)
     assert MotifSolver(s, 3) == O.motif3(osym)
     assert SglSolver(s, "diamond") == O.diamond(osym)
+    general = [0, 0, 0, 0, 0, 0, 0x80000]  # (the hub row through the general kernel instead of the hashed-row class)
+    assert MotifSolver(s, 3, tune=general) == O.motif3(osym)
+    assert SglSolver(s, "diamond", tune=general) == O.diamond(osym)
     assert CliqueSolver(d, 4) == O.clique(odag, 4)
 
 
@@ -465,8 +471,11 @@ def test_hub_paths_against_oracle_rmat16(dev):
     want_d, want_m3 = O.diamond(osym), O.motif3(osym)
     assert SglSolver(s, "diamond") == want_d
     assert MotifSolver(s, 3) == want_m3
-    # (0x100000: WITH the big-LDS workgroup classes for rows of 3073..24576 entries, which a graph this small does not get by default)
+    # (default: the workgroup classes take the rows > 1024 entries; 0x80000: every row through the general kernel -- SPLIT chunks, dense
+    # bitmaps, the LDS pre-filter; 0x100000: the classes forced on, which is also the default here)
+    G = 0x80000
     for tune in ([0, 0, 0, 0, 0, 0, 0x1000], [0, 0, 0, 0, 0, 0, 0x4000], [0, 0, 0, 0, 0, 0, 0x100], [0, 0, 0, 0, 0, 0, 0x4], [0, 0, 0, 0, 0, 1],
+                 [0, 0, 0, 0, 0, 0, G], [0, 0, 0, 0, 0, 0, G | 0x1000], [0, 0, 0, 0, 0, 0, G | 0x4000], [0, 0, 0, 0, 0, 0, G | 0x100], [0, 0, 0, 0, 0, 0, G | 0x4],
                  [0, 0, 0, 0, 0, 0, 0x100000], [0, 0, 0, 0, 0, 0, 0x100000 | 0x1000], [0, 0, 0, 0, 0, 0, 0x100000 | 0x4000],
                  # (0x400000: the classes with the sorted LDS copy + bisection instead of the hashed set; 0x800000: the hashed-set
                  # kernels with every lookup through their global-memory fallback)
@@ -474,6 +483,10 @@ def test_hub_paths_against_oracle_rmat16(dev):
         assert SglSolver(s, "diamond", tune=tune) == want_d
         assert MotifSolver(s, 3, tune=tune) == want_m3
     assert sum(SglSolver(s, "diamond", rank=r, world=8) for r in range(8)) == want_d
+    assert sum(SglSolver(s, "diamond", rank=r, world=8, tune=[0, 0, 0, 0, 0, 0, G]) for r in range(8)) == want_d
+    parts = [MotifSolver(s, 3, rank=r, world=3, tune=[0, 0, 0, 0, 0, 0, G]) for r in range(3)]
+    assert [sum(p[i] for p in parts) % 2**64 for i in range(2)] == want_m3
+    assert MotifSolver(s, 4, tune=[0, 0, 0, 0, 0, 0, G]) == GOLDEN[g.name]["motif4"]
     assert sum(SglSolver(s, "diamond", rank=r, world=5, tune=[0, 0, 0, 0, 0, 0, 0x100000]) for r in range(5)) == want_d
     parts = [MotifSolver(s, 3, rank=r, world=4, tune=[0, 0, 0, 0, 0, 0, 0x100000]) for r in range(4)]
     assert [sum(p[i] for p in parts) % 2**64 for i in range(2)] == want_m3
