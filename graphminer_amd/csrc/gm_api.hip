@@ -1776,7 +1776,7 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
   if (const char *e = getenv("GM_CLS_LO")) cls_lo = std::max(64, atoi(e));  // (sweeps)
   // giant rows (> kStageCapBig entries): hashed sets of row pieces (giant_kernel, gm_hrow.hip) instead of SPLIT chunks probing
   // dense bitmaps in HBM (tune[6] & 0x1000000: A/B switch, they stay SPLIT chunks of the general kernel)
-  const bool use_range = use_classes && !(la->tune[6] & 0x1000000);
+  const bool use_range = use_classes && !(la->tune[6] & 0x1000000) && hrow_fits(g->nv, 2);  // (its pieces are class-2 sets: nv <= 2^27)
   if (use_classes) { rf.skip_lo = cls_lo; rf.skip_hi = use_range ? 0x7fffffff : kStageCapBig; }
   int rc = get_table(g, target, !clique, clique ? kBitWords : 0, part_cap, stage_cap_of(pat), &tab, rf, use_classes ? kStageCapBig : kBitmapMinDeg);
   if (rc) return rc;
