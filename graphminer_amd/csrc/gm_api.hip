@@ -1755,8 +1755,7 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
   // 4-clique: vertices whose matrix exceeds the 8 KB budget go through the two-phase path (gm_mine.h)
   // (tune[6] & 0x40000: A/B switch, everything stays in the mining kernel with its arena path)
   const bool use_wide = pat == PAT_CLIQUE4 && !(la->tune[6] & 0x40000);
-  // symmetric-graph patterns: the rows just above the LDS stage go to the big-LDS workgroup classes (gm_chunk.h MineCfg)
-  // (tune[6] & 0x80000: A/B switch, they stay SPLIT rows with dense bitmaps)
+  // symmetric-graph patterns: the rows of more than kClassRowMin entries go to the workgroup classes (gm_hrow.hip: hashed sets in LDS)
   const bool sym_pat = stage_cap_of(pat) == kStageCapWide;
   // (tune[6] & 0x80000: A/B switch, every row through the general kernel -- SPLIT chunks and dense HBM bitmaps for the long ones)
   bool use_classes = sym_pat && !(la->tune[6] & 0x80000) && !(la->tune[5] == 1);

@@ -13,8 +13,9 @@ constexpr int kStageCap = 1024;           // adjacency entries a workgroup stage
 #define GM_STAGE_WIDE 3072
 #endif
 constexpr int kStageCapWide = GM_STAGE_WIDE;       // ... for the patterns that run on SYMMETRIC graphs (see stage_cap_of)
-// big-LDS workgroup classes of the symmetric-graph patterns (MineCfg in gm_chunk.h): rows of kStageCapWide+1 .. kStageCapMid
-// entries are staged whole by class 1, rows up to kStageCapBig by class 2; longer rows stay SPLIT rows with dense bitmaps.
+// workgroup classes of the symmetric-graph patterns: rows of kClassRowMin+1 .. kStageCapMid entries are class 1, rows up to
+// kStageCapBig class 2 (hashed sets in LDS, gm_hrow.hip; sorted copies, MineCfg in gm_chunk.h, where the ids are too wide), longer
+// rows are cut into pieces of kStageCapBig entries (giant_kernel) -- or stay SPLIT rows with dense bitmaps on the general path.
 // (8191, not 8192: the branch-free bisection reads up to 2^bitlen(row) - 2 entries past the row start, which must stay inside
 // the workgroup's LDS)
 constexpr int kStageCapMid = 8191;

@@ -2,7 +2,8 @@
 // the per-edge sums of 4-motif): MineCfg<PAT, 1> stages a whole row of 3073..8191 entries in 32 KB, MineCfg<PAT, 2> a whole row
 // of up to 24576 entries in 96 KB of the CU's 160 KB LDS (gm_chunk.h). Same process_chunk, same flattened passes -- only the
 // LDS budget and the waves per workgroup differ, so that these rows are searched in LDS instead of through a dense bitmap in
-// HBM. (reference kernels being replaced: src/motif/gpu_kernels/motif3_edge_warp.cuh:2-23, src/sgl/gpu_kernels/diamond_count.cuh:3-21)
+// HBM. Since the hashed-row kernels (gm_hrow.hip) these sorted-copy classes are the fallback for id spaces too wide for their
+// 14-bit remainders (nv > 2^25 / 2^27) and the A/B baseline (tune[6] & 0x400000). (reference kernels being replaced: src/motif/gpu_kernels/motif3_edge_warp.cuh:2-23, src/sgl/gpu_kernels/diamond_count.cuh:3-21)
 #include "gm_chunk.h"
 
 namespace gm {

@@ -1,5 +1,5 @@
 // gm_wide.hip -- k-clique, phase 2 for WIDE vertices: the second DFS level counted from a big-LDS copy of the vertex's
-// adjacency bit-matrix (see "k-clique, wide vertices" in gm_mine.h; phase 1 = process_wide_group in gm_mine.hip).
+// adjacency bit-matrix (see "k-clique, wide vertices" in gm_mine.h; phase 1 = clique_build_kernel below).
 //
 // MI355X gives a CU 160 KB of LDS. The mining kernel spends 21-32 KB per workgroup so that 5-7 workgroups share a CU -- right
 // for the millions of short rows and for BUILDING the matrices (latency-bound streaming: occupancy is what counts), wrong for

@@ -46,7 +46,7 @@ def test_diamond_rmat20_equals_oracle(rmat_dev):
     assert got == want
     assert st.tasks == osym.ne // 2
     assert sum(SglSolver(sym, "diamond", rank=r, world=8) for r in range(8)) == want
-    # the big-LDS workgroup classes (rows of 3073..24576 entries staged whole; default from nv > 2^22), forced on
+    # the workgroup classes (rows > 1024 entries as hashed sets in LDS; the default wherever such rows exist), forced on
     assert SglSolver(sym, "diamond", tune=[0, 0, 0, 0, 0, 0, 0x100000]) == want
     # ... the same with the sorted-copy class kernels (0x400000) and with the giant rows (> 24576 entries; this graph has rows of
     # 64 K) left to the SPLIT chunks + HBM bitmaps instead of the id-range LDS bitmaps (0x1000000)
