@@ -10,21 +10,21 @@
 //   * ids are mapped through a bijection of [0, 2^K), K = bits of nv:  h = (id * C_K) mod 2^K, C_K odd (Fibonacci constant of 2^K);
 //   * the top LB bits of h pick one of 2^LB buckets of eight 16-bit slots (one 16-byte LDS line), the low K - LB <= 14 bits
 //     are what is stored: bucket and remainder together ARE the id, the test is exact with 2 bytes per entry;
-//   * 2^LB ~ n/3 (8 slots for ~3 entries: on R-MAT rows 0.02 % of the entries do not fit); a bucket that overflowed is flagged
-//     and its surplus ids sit in a small list (<= 128 per row) that only the lanes missing in a flagged bucket scan;
-//   * lookup = one multiply, one ds_read_b128, a packed has-zero-halfword test: no queue, no compaction, no bisection.
+//   * 2^LB ~ n/3 (8 slots for ~3 entries: on R-MAT rows 0.05-0.3 % of the entries do not fit); a bucket that overflowed carries a
+//     marker in its last slot and its surplus ids sit in a small list (<= 128 per row) that only the lanes missing in such a
+//     bucket consult;
+//   * lookup = one multiply, one ds_read_b128, eight SDWA 16-bit compares (8 VALU + 7 SALU; a packed has-zero-halfword test is
+//     17 VALU: diamond R-MAT-24 304 vs 284 ms): no queue, no compaction, no bisection.
 // A row that overflows the surplus list (adversarial ids) is looked up by bisection of the row in global memory -- slow, exact.
 // Every task edge streams the partner list (pass X); pass Y does not exist here (the longer row hosts, gm_mine.h sym_hosts).
 #include "gm_flat.h"
 
-#ifndef GM_HROW_CMP16
-#define GM_HROW_CMP16 1  // eight SDWA 16-bit compares (8 VALU + 7 SALU) instead of the packed has-zero-halfword test (17 VALU): diamond R-MAT-24 304 -> 284 ms
-#endif
 
 namespace gm {
 
 constexpr int kHrowOvfCap = 128;
-constexpr int kHrowRemBits = 14;  // stored remainder bits (bit 14 = "empty" pattern 0x7fff, bit 15 of slot 7 = overflow flag)
+constexpr int kHrowRemBits = 14;  // stored remainder bits: a slot below 0x4000 is an entry, 0x7fff = empty, 0xfffe in the last slot = the bucket overflowed
+constexpr unsigned short kHrowMarker = 0xfffe;
 constexpr int kHrowTiles = 4;     // 64-key tiles in flight per wave
 
 template <int CLS>
@@ -67,67 +67,65 @@ __device__ __forceinline__ unsigned hrow_hash(const HrowView &hv, int key) {
   return h & hv.kmask;
 }
 
-// Which of the T keys of this lane are in the row?  (in[q] = the lane carries a key in tile q.)  The T hashes, the T 16-byte
-// reads and the T packed tests are issued together; the rare paths (a flagged bucket missed, the fallback) cost one
-// wave-uniform branch per tile group.
+// Which of the T keys of this lane are in the row?  Everything is a 64-bit LANE MASK (the SGPR pair a v_cmp writes): inm[q] = lanes
+// that carry a key in tile q, hm[q] = lanes whose key was found in its bucket, nm[q] = lanes that missed in a bucket that
+// overflowed (its last slot holds the marker) -- for those the surplus list decides, in hrow_surplus.  The T hashes, the T
+// 16-byte reads and the T x 8 SDWA compares are issued together; their results are OR-ed on the scalar unit and never become
+// vector registers (as `bool`s they cost a v_cndmask / shift / or chain per tile).
 template <bool K24, int T, class LdsT>
-__device__ __forceinline__ void hrow_member(const LdsT &B, const HrowView &hv, const int *__restrict__ row, const int n_row,
-                                            const int (&key)[T], const bool (&in)[T], bool (&f)[T]) {
+__device__ __forceinline__ void hrow_probe(const LdsT &B, const HrowView &hv, const int *__restrict__ row, const int n_row,
+                                           const int (&key)[T], const unsigned long long (&inm)[T], unsigned long long (&hm)[T],
+                                           unsigned long long (&nm)[T]) {
   if (hv.fallback) {  // wave-uniform
 #pragma unroll
     for (int q = 0; q < T; ++q) {
-      f[q] = false;
-      if (in[q]) {
+      bool f = false;
+      if (__builtin_amdgcn_inverse_ballot_w64(inm[q])) {
         const int pos = lower_bound(row, n_row, key[q]);
-        f[q] = pos < n_row && row[pos] == key[q];
+        f = pos < n_row && row[pos] == key[q];
       }
+      hm[q] = __ballot(f);
+      nm[q] = 0ull;
     }
     return;
   }
   uint4 w[T];
-  unsigned rr[T];
+  unsigned short r16[T];
 #pragma unroll
   for (int q = 0; q < T; ++q) {
     const unsigned h = hrow_hash<K24>(hv, key[q]);
-    const unsigned rem = h & hv.rmask;
-    rr[q] = rem | (rem << 16);
+    r16[q] = (unsigned short)(h & hv.rmask);
     w[q] = *reinterpret_cast<const uint4 *>(&B.table[(h >> hv.sh) << 3]);
   }
-  bool need[T], any_need = false;
 #pragma unroll
   for (int q = 0; q < T; ++q) {
-#if GM_HROW_CMP16
-    const unsigned short r16 = (unsigned short)rr[q];
-    const bool hit = ((unsigned short)w[q].x == r16) | ((unsigned short)(w[q].x >> 16) == r16) | ((unsigned short)w[q].y == r16) |
-                     ((unsigned short)(w[q].y >> 16) == r16) | ((unsigned short)w[q].z == r16) | ((unsigned short)(w[q].z >> 16) == r16) |
-                     ((unsigned short)w[q].w == r16) | ((unsigned short)((w[q].w >> 16) & 0x7fffu) == r16);
-    const unsigned z = hit ? 0x8000u : 0u;
-#else
-    const unsigned c = 0x00010001u;
-    const unsigned t0 = w[q].x ^ rr[q], t1 = w[q].y ^ rr[q], t2 = w[q].z ^ rr[q], t3 = (w[q].w & 0x7fffffffu) ^ rr[q];
-    // a halfword of t is zero <=> that slot holds rem: (t - 0x00010001) & ~t & 0x80008000 is non-zero iff some halfword is zero
-    const unsigned z = ((t0 - c) & ~t0) | ((t1 - c) & ~t1) | ((t2 - c) & ~t2) | ((t3 - c) & ~t3);
-#endif
-    f[q] = in[q] & ((z & 0x80008000u) != 0u);
-    need[q] = in[q] & !f[q] & ((int)w[q].w < 0);  // missed in a bucket that overflowed: the surplus list decides
-    any_need |= need[q];
+    const unsigned long long m = __ballot((unsigned short)w[q].x == r16[q]) | __ballot((unsigned short)(w[q].x >> 16) == r16[q]) |
+                                 __ballot((unsigned short)w[q].y == r16[q]) | __ballot((unsigned short)(w[q].y >> 16) == r16[q]) |
+                                 __ballot((unsigned short)w[q].z == r16[q]) | __ballot((unsigned short)(w[q].z >> 16) == r16[q]) |
+                                 __ballot((unsigned short)w[q].w == r16[q]) | __ballot((unsigned short)(w[q].w >> 16) == r16[q]);
+    hm[q] = m & inm[q];
+    nm[q] = __ballot((unsigned short)(w[q].w >> 16) == kHrowMarker) & ~m & inm[q];
   }
-  if (__ballot(any_need) != 0ull) {
-    // The surplus list (<= 128 ids, unused entries -1) is spread over the lanes, two entries each; every key that needs it
-    // (typically one or two lanes of a tile) is broadcast and compared by all lanes at once.
-    const int lane = lane_id();
-    const int o0 = B.ovf[lane], o1 = B.ovf[lane + GM_WAVE];
+}
+
+// The surplus list (<= 128 ids, unused entries -1) is spread over the lanes, two entries each; every key that needs it
+// (typically one or two lanes of a tile) is broadcast and compared by all lanes at once.  act(q, xm): xm = lanes of tile q whose
+// key is in the list.
+template <int T, class LdsT, class Act>
+__device__ __forceinline__ void hrow_surplus(const LdsT &B, const int (&key)[T], const unsigned long long (&nm)[T], Act act) {
+  const int lane = lane_id();
+  const int o0 = B.ovf[lane], o1 = B.ovf[lane + GM_WAVE];
 #pragma unroll
-    for (int q = 0; q < T; ++q) {
-      unsigned long long nm = __ballot(need[q]);
-      while (nm) {
-        const int src = __ffsll((long long)nm) - 1;
-        nm &= nm - 1;
-        const int k = readlane(key[q], src);
-        const bool any = __ballot((o0 == k) | (o1 == k)) != 0ull;
-        f[q] |= (lane == src) & any;
-      }
+  for (int q = 0; q < T; ++q) {
+    unsigned long long rest = nm[q], xm = 0ull;
+    if (rest == 0ull) continue;
+    while (rest) {
+      const int src = __ffsll((long long)rest) - 1;
+      rest &= rest - 1;
+      const int k = readlane(key[q], src);
+      if (__ballot((o0 == k) | (o1 == k)) != 0ull) xm |= 1ull << src;
     }
+    act(q, xm);
   }
 }
 
@@ -176,9 +174,20 @@ __device__ __forceinline__ void hrow_build(LdsT &B, HrowView &hv, const int *__r
     }
   }
   __syncthreads();
+  // A bucket that got more than eight entries gives up its last slot for the marker; the entry that sat there joins the surplus
+  // list -- its id comes back from (bucket, remainder) through the inverse of the hash.
+  unsigned cinv = hv.ck;  // inverse of the odd constant mod 2^32 (Newton: 3 -> 6 -> 12 -> 24 -> 48 correct bits)
+#pragma unroll
+  for (int it = 0; it < 4; ++it) cinv *= 2u - hv.ck * cinv;
   for (int b = tid; b < nb; b += nthreads) {
     const unsigned c = (fill32[b >> 1] >> ((b & 1) * 16)) & 0xffffu;
-    if (c > 8u) B.table[(b << 3) + 7] |= (unsigned short)0x8000u;
+    if (c > 8u) {
+      const unsigned rem7 = B.table[(b << 3) + 7];
+      const int id7 = (int)(((((unsigned)b << hv.sh) | rem7) * cinv) & hv.kmask);
+      const int jo = atomicAdd(&B.n_ovf, 1);
+      if (jo < kHrowOvfCap) B.ovf[jo] = id7;
+      B.table[(b << 3) + 7] = kHrowMarker;
+    }
   }
   __syncthreads();  // (also: the fill counters are dead, the waves may use their scratch)
   hv.n_ovf = B.n_ovf;
@@ -191,19 +200,24 @@ struct HashedRow {
   const HrowView &hv;
   const int *__restrict__ row;
   int n_row;
-  __device__ __forceinline__ void operator()(const int (&key)[kHrowTiles], const bool (&in)[kHrowTiles], bool (&f)[kHrowTiles]) const {
-    hrow_member<K24, kHrowTiles>(B, hv, row, n_row, key, in, f);
+  __device__ __forceinline__ void probe(const int (&key)[kHrowTiles], const unsigned long long (&inm)[kHrowTiles],
+                                        unsigned long long (&hm)[kHrowTiles], unsigned long long (&nm)[kHrowTiles]) const {
+    hrow_probe<K24, kHrowTiles>(B, hv, row, n_row, key, inm, hm, nm);
+  }
+  template <class Act>
+  __device__ __forceinline__ void surplus(const int (&key)[kHrowTiles], const unsigned long long (&nm)[kHrowTiles], Act act) const {
+    hrow_surplus<kHrowTiles>(B, key, nm, act);
   }
 };
 
 // One batch of task edges of the row: stream the partner lists against the set (member = the membership test of kHrowTiles keys).
 //   llen_all / key_base: this lane's partner list (0 = no task), vpart: its partner vertex
 // DIAMOND / MOTIF4E: per-edge match counts end up in L.cnt[lane] (+ n_long for the lists streamed one at a time)
-// MOTIF3: m_any = matches below max(u, v), m_low = matches below min(u, v), accumulated per lane
+// MOTIF3: s_any = matches below max(u, v), s_low = matches below min(u, v) over the whole batch, wave-uniform
 template <int PAT, class Member>
 __device__ __forceinline__ void hrow_pass(HrowWave &L, const Member &member, const int *__restrict__ col, const int u, const int lane,
-                                          const int llen_all, const int key_base, const int vpart, unsigned &n_long, unsigned &m_any,
-                                          unsigned &m_low) {
+                                          const int llen_all, const int key_base, const int vpart, unsigned &n_long, unsigned &s_any,
+                                          unsigned &s_low) {
   constexpr bool kPerEdge = PAT != PAT_MOTIF3;
   constexpr int T = kHrowTiles;
   if (wave_max_nonneg(llen_all) == 0) return;  // wave-uniform
@@ -221,19 +235,24 @@ __device__ __forceinline__ void hrow_pass(HrowWave &L, const Member &member, con
     const int hi = max(u, vv), lo = min(u, vv);
     const int *__restrict__ kp = col + base;
     unsigned cnt_s = 0;  // wave-uniform
-    auto process = [&](const int (&key)[T], const bool (&in)[T]) {
-      bool f[T];
-      member(key, in, f);
-#pragma unroll
-      for (int q = 0; q < T; ++q) {
+    auto process = [&](const int (&key)[T], const unsigned long long (&inm)[T]) {
+      unsigned long long hm[T], nm[T];
+      member.probe(key, inm, hm, nm);
+      auto take = [&](const int q, const unsigned long long xm) {
         if (kPerEdge) {
-          cnt_s += (unsigned)__popcll(__ballot(f[q]));
+          cnt_s += (unsigned)__popcll(xm);
         } else {
-          const bool fa = f[q] & (key[q] < hi), fl = fa & (key[q] < lo);
-          m_any += fa ? 1u : 0u;
-          m_low += fl ? 1u : 0u;
+          const unsigned long long am = xm & __ballot(key[q] < hi);
+          s_any += (unsigned)__popcll(am);
+          s_low += (unsigned)__popcll(am & __ballot(key[q] < lo));
         }
-      }
+      };
+#pragma unroll
+      for (int q = 0; q < T; ++q) take(q, hm[q]);
+      unsigned long long any_need = 0ull;
+#pragma unroll
+      for (int q = 0; q < T; ++q) any_need |= nm[q];
+      if (any_need != 0ull) member.surplus(key, nm, take);  // rare
     };
     constexpr int G = GM_WAVE * T;
     int nxt[T];
@@ -242,28 +261,28 @@ __device__ __forceinline__ void hrow_pass(HrowWave &L, const Member &member, con
     int t = 0;
     for (; t + 2 * G <= n; t += G) {  // full groups whose successor is full too: unconditional, unclamped loads
       int key[T];
-      bool in[T];
+      unsigned long long inm[T];
 #pragma unroll
       for (int q = 0; q < T; ++q) {
         key[q] = nxt[q];
-        in[q] = true;
+        inm[q] = ~0ull;
       }
       const int *__restrict__ kn = kp + (t + G);
 #pragma unroll
       for (int q = 0; q < T; ++q) nxt[q] = kn[(unsigned)(q * GM_WAVE + lane)];
-      process(key, in);
+      process(key, inm);
     }
     for (; t < n; t += G) {
       int key[T];
-      bool in[T];
+      unsigned long long inm[T];
 #pragma unroll
       for (int q = 0; q < T; ++q) {
         key[q] = nxt[q];
-        in[q] = (t + q * GM_WAVE + lane) < n;
+        inm[q] = __ballot((t + q * GM_WAVE + lane) < n);
       }
 #pragma unroll
       for (int q = 0; q < T; ++q) nxt[q] = kp[min(t + G + q * GM_WAVE + lane, n - 1)];
-      process(key, in);
+      process(key, inm);
     }
     if (kPerEdge) n_long += (lane == src) ? cnt_s : 0u;
   }
@@ -285,7 +304,8 @@ __device__ __forceinline__ void hrow_pass(HrowWave &L, const Member &member, con
     wave_sync();
     for (int t = 0; t < wn; t += GM_WAVE * T) {
       int own[T], key[T];
-      bool in[T], one_owner[T];
+      bool one_owner[T];
+      unsigned long long inm[T];
 #pragma unroll
       for (int q = 0; q < T; ++q) own[q] = (int)L.marks[t + q * GM_WAVE + lane];
 #pragma unroll
@@ -301,34 +321,43 @@ __device__ __forceinline__ void hrow_pass(HrowWave &L, const Member &member, con
       int dl[T];
 #pragma unroll
       for (int q = 0; q < T; ++q) {
-        const int p = wb + t + q * GM_WAVE + lane;
-        in[q] = p < total;
-        own[q] = in[q] ? own[q] - 1 : 0;
+        const bool in = (wb + t + q * GM_WAVE + lane) < total;
+        inm[q] = __ballot(in);
+        own[q] = in ? own[q] - 1 : 0;
         dl[q] = L.delta[own[q]];  // unconditional LDS read
       }
 #pragma unroll
-      for (int q = 0; q < T; ++q) key[q] = col[in[q] ? dl[q] + (wb + t + q * GM_WAVE + lane) : 0];  // unconditional load (select on the index)
-      bool f[T];
-      member(key, in, f);
-      if (kPerEdge) {
-#pragma unroll
-        for (int q = 0; q < T; ++q) {
-          // a tile of one owner adds its count once (64 atomics on one LDS word would serialise)
-          const unsigned c = (unsigned)__popcll(__ballot(f[q]));
-          const bool add = one_owner[q] ? (lane == 0 && c != 0u) : f[q];
-          if (add) atomicAdd(&L.cnt[own[q]], one_owner[q] ? c : 1u);
-        }
-      } else {
-        int vv[T];
+      for (int q = 0; q < T; ++q) {
+        const bool in = (wb + t + q * GM_WAVE + lane) < total;
+        key[q] = col[in ? dl[q] + (wb + t + q * GM_WAVE + lane) : 0];  // unconditional load (select on the index)
+      }
+      unsigned long long hm[T], nm[T];
+      member.probe(key, inm, hm, nm);
+      int vv[T];
+      if (!kPerEdge) {
 #pragma unroll
         for (int q = 0; q < T; ++q) vv[q] = (int)L.cnt[own[q]];
-#pragma unroll
-        for (int q = 0; q < T; ++q) {
-          const bool fa = f[q] & (key[q] < max(u, vv[q])), fl = fa & (key[q] < min(u, vv[q]));
-          m_any += fa ? 1u : 0u;
-          m_low += fl ? 1u : 0u;
-        }
       }
+      auto take = [&](const int q, const unsigned long long xm) {
+        if (kPerEdge) {
+          if (one_owner[q]) {  // wave-uniform: a tile of one owner adds its count once (64 atomics on one LDS word would serialise)
+            const unsigned c = (unsigned)__popcll(xm);
+            if (lane == 0 && c != 0u) atomicAdd(&L.cnt[own[q]], c);
+          } else if (__builtin_amdgcn_inverse_ballot_w64(xm)) {
+            atomicAdd(&L.cnt[own[q]], 1u);
+          }
+        } else {
+          const unsigned long long am = xm & __ballot(key[q] < max(u, vv[q]));
+          s_any += (unsigned)__popcll(am);
+          s_low += (unsigned)__popcll(am & __ballot(key[q] < min(u, vv[q])));
+        }
+      };
+#pragma unroll
+      for (int q = 0; q < T; ++q) take(q, hm[q]);
+      unsigned long long any_need = 0ull;
+#pragma unroll
+      for (int q = 0; q < T; ++q) any_need |= nm[q];
+      if (any_need != 0ull) member.surplus(key, nm, take);  // rare
     }
     wave_sync();
   }
@@ -379,12 +408,14 @@ __device__ __forceinline__ void hrow_chunk(const MineParams &p, HrowLds<CLS> &B,
     }
     L.cnt[lane] = (PAT == PAT_MOTIF3) ? (unsigned)v : 0u;
     wave_sync();
-    unsigned n_long = 0, m_any = 0, m_low = 0;
-    hrow_pass<PAT>(L, member, col, u, lane, act ? b : 0, rv, v, n_long, m_any, m_low);
+    unsigned n_long = 0, s_any = 0, s_low = 0;
+    hrow_pass<PAT>(L, member, col, u, lane, act ? b : 0, rv, v, n_long, s_any, s_low);
     wave_sync();
     if (PAT == PAT_MOTIF3) {
-      acc.c0 += (unsigned long long)m_any + (unsigned long long)m_low;  // I(lo,hi) + I(hi,lo)
-      acc.c1 += (unsigned long long)m_low;                              // triangles u > v > w, once
+      if (lane == 0) {  // (wave-uniform sums of the batch)
+        acc.c0 += (unsigned long long)s_any + (unsigned long long)s_low;  // I(lo,hi) + I(hi,lo)
+        acc.c1 += (unsigned long long)s_low;                              // triangles u > v > w, once
+      }
     } else {
       const unsigned long long tri = (unsigned long long)L.cnt[lane] + (unsigned long long)n_long;
       if (PAT == PAT_DIAMOND) {
@@ -544,12 +575,14 @@ __device__ __forceinline__ void giant_chunk(const MineParams &p, GiantLds &B, co
         const int start = pc ? b_start[le] : 0;
         L.cnt[lane] = (PAT == PAT_MOTIF3) ? (unsigned)v : 0u;
         wave_sync();
-        unsigned n_long = 0, m_any = 0, m_low = 0;
-        hrow_pass<PAT>(L, member, col, u, lane, valid ? end - start : 0, desc.x + start, v, n_long, m_any, m_low);
+        unsigned n_long = 0, s_any = 0, s_low = 0;
+        hrow_pass<PAT>(L, member, col, u, lane, valid ? end - start : 0, desc.x + start, v, n_long, s_any, s_low);
         wave_sync();
         if (PAT == PAT_MOTIF3) {
-          acc.c0 += (unsigned long long)m_any + (unsigned long long)m_low;
-          acc.c1 += (unsigned long long)m_low;
+          if (lane == 0) {
+            acc.c0 += (unsigned long long)s_any + (unsigned long long)s_low;
+            acc.c1 += (unsigned long long)s_low;
+          }
         } else if (valid) {
           B.ecnt[le] += L.cnt[lane] + n_long;
         }
