@@ -2007,7 +2007,7 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
       // (tune[6] & 0x400000: A/B switch, the sorted LDS copy + bit filter + bisection of gm_mine_wide.hip)
       if (cls == 3) {
         // per workgroup: where the pieces of the row cut the partner lists of its chunk, kGiantEdges ints per piece (giant_bounds)
-        const int rgrid = (int)std::max<long long>(1, std::min<long long>(q.count, (long long)g->cu_count));
+        const int rgrid = (int)std::max<long long>(1, std::min<long long>(q.count, (long long)g->cu_count * giant_per_cu()));
         const unsigned long long slot_words = giant_scratch_words(g->max_deg);
         const size_t need = (size_t)slot_words * sizeof(unsigned) * (size_t)rgrid;
         if (need > g->scratch_bytes) {
@@ -2020,7 +2020,7 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
         q.scratch = g->d_scratch;
         q.scratch_words = slot_words;
         hipStream_t ws;
-        rc = side_stream(cls, q.count, g->cu_count, &ws);
+        rc = side_stream(cls, q.count, (long long)g->cu_count * giant_per_cu(), &ws);
         if (rc) return rc;
         HIP_TRY(launch_giant(pat, q, rgrid, ws));
         rc = side_done(cls, ws);

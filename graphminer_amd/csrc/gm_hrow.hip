@@ -476,8 +476,13 @@ void hrow_kernel(const MineParams p) {
 // (First built with LDS bitmaps over id ranges of 2^20 ids, one ds_read_b32 per key: 14 ranges at nv = 2^24 cut the lists
 // into segments of ~160 keys, the flattening of which cost more than the cheaper test won -- 84 ms against 130 for the SPLIT
 // chunks and their HBM bitmaps on diamond R-MAT-24; pieces of 24576 entries are 3..17 per row and their segments are long lists.)
-constexpr int kGiantPiece = kStageCapBig;
-constexpr int kGiantWaves = 16;
+#ifndef GM_GIANT_LB
+#define GM_GIANT_LB 13
+#endif
+constexpr int kGiantLb = GM_GIANT_LB;                 // buckets of a piece's set: 2^13 x 16 B = 128 KB (one workgroup per CU), 2^12: two per CU
+constexpr int kGiantPiece = 3 << kGiantLb;             // 24576 entries at 2^13: three per bucket of eight slots
+constexpr int kGiantWaves = kGiantLb >= 13 ? 16 : 8;
+constexpr int kGiantPerCu = kGiantLb >= 13 ? 1 : 2;
 #ifndef GM_GIANT_BATCH
 #define GM_GIANT_BATCH 16
 #endif
@@ -485,7 +490,7 @@ constexpr int kGiantBatch = GM_GIANT_BATCH;  // task edges per batch: >= 64 batc
 constexpr int kGiantGroup = 8;   // boundaries found together (independent bisections, their loads in flight together)
 
 struct alignas(16) GiantLds {
-  unsigned short table[(1 << kHrowLbBig) * 8];
+  unsigned short table[(1 << kGiantLb) * 8];
   HrowWave w[kGiantWaves];
   unsigned ecnt[kGiantEdges];  // per task edge: matches so far
   int ovf[kHrowOvfCap];
@@ -555,7 +560,7 @@ __device__ __forceinline__ void giant_chunk(const MineParams &p, GiantLds &B, co
       const int s = pc * kGiantPiece, t = min(s + kGiantPiece, n_row);
       __syncthreads();  // the waves are done with the previous set (first trip: the boundaries are written)
       HrowView hv;
-      hrow_build<K24>(B, hv, row + s, t - s, kHrowLbBig, p.g.nv, p.flags, tid, nthreads);
+      hrow_build<K24>(B, hv, row + s, t - s, kGiantLb, p.g.nv, p.flags, tid, nthreads);
       if (tid == 0) B.next_batch = 0;
       __syncthreads();
       const HashedRow<K24, GiantLds> member{B, hv, row + s, t - s};
@@ -614,7 +619,7 @@ __device__ __forceinline__ void giant_chunk(const MineParams &p, GiantLds &B, co
 }
 
 template <int PAT, bool K24>
-__global__ __launch_bounds__((kGiantWaves * GM_WAVE), 4)
+__global__ __launch_bounds__((kGiantWaves * GM_WAVE), (kGiantWaves * kGiantPerCu / 4))
 void giant_kernel(const MineParams p) {
   __shared__ GiantLds B;
   const int lane = threadIdx.x & (GM_WAVE - 1);
@@ -645,11 +650,13 @@ void giant_kernel(const MineParams p) {
 }
 
 // scratch words per workgroup: one boundary per piece and task edge of a chunk
+int giant_per_cu() { return kGiantPerCu; }
 unsigned long long giant_scratch_words(int max_deg) { return (unsigned long long)kGiantEdges * (unsigned long long)(max_deg / kGiantPiece + 1); }
 
 hipError_t launch_giant(Pattern pat, const MineParams &p, int grid_blocks, hipStream_t stream) {
   static_assert(sizeof(GiantLds) <= 163840, "the giant-row kernel must fit the 160 KB of one CU");
-  static_assert(sizeof(HrowWave) * kGiantWaves >= (size_t)(2 << kHrowLbBig), "fill counters alias the wave scratch");
+  static_assert(sizeof(HrowWave) * kGiantWaves >= (size_t)(2 << kGiantLb), "fill counters alias the wave scratch");
+  static_assert(sizeof(GiantLds) * kGiantPerCu <= 163840, "giant-row workgroups per CU");
   if (p.g.edesc == nullptr || p.scratch == nullptr) return hipErrorInvalidValue;
   const dim3 grid((unsigned)grid_blocks), block(kGiantWaves * GM_WAVE);
   const bool k24 = p.g.nv <= (1 << 24) && !(p.flags & (1 << 23));

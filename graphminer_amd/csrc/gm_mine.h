@@ -329,6 +329,7 @@ size_t hrow_lds_bytes(int cls);
 constexpr int kGiantEdges = GM_GIANT_EDGES;
 hipError_t launch_giant(Pattern pat, const MineParams &p, int grid_blocks, hipStream_t stream);
 unsigned long long giant_scratch_words(int max_deg);
+int giant_per_cu();
 int hrow_per_cu(int cls);
 // ids must split into bucket + 14-bit remainder: bits of nv <= LB_max + 14
 inline bool hrow_fits(int nv, int cls) {
