@@ -1876,6 +1876,7 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
   p.k = k;
   p.flags = (la->tune[5] == 1) ? 1 : 0;
   p.flags |= (la->tune[6] & 0xffff) << 1;  // debug/ablation: bit1 skip clique phase 2, bit2 skip bit-matrix writes (counts wrong)
+  if (la->tune[6] & 0x2000000) p.flags |= 1 << 23;  // hashed-row classes: the 32-bit multiply of id spaces beyond 2^24 (tests)
   if (la->tune[6] & 0x800000) p.flags |= 1 << 22;  // hashed-row classes: every lookup through the global-memory fallback (tests)
   if (la->tune[6] & 0x200000) p.flags |= 1 << 20;  // k >= 5: the any-width pair count instead of the tile walk (tests)
   p.counters = g->d_counters;

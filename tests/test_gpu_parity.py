@@ -479,7 +479,8 @@ def test_hub_paths_against_oracle_rmat16(dev):
                  [0, 0, 0, 0, 0, 0, 0x100000], [0, 0, 0, 0, 0, 0, 0x100000 | 0x1000], [0, 0, 0, 0, 0, 0, 0x100000 | 0x4000],
                  # (0x400000: the classes with the sorted LDS copy + bisection instead of the hashed set; 0x800000: the hashed-set
                  # kernels with every lookup through their global-memory fallback)
-                 [0, 0, 0, 0, 0, 0, 0x100000 | 0x400000], [0, 0, 0, 0, 0, 0, 0x100000 | 0x400000 | 0x1000], [0, 0, 0, 0, 0, 0, 0x100000 | 0x800000]):
+                 [0, 0, 0, 0, 0, 0, 0x100000 | 0x400000], [0, 0, 0, 0, 0, 0, 0x100000 | 0x400000 | 0x1000], [0, 0, 0, 0, 0, 0, 0x100000 | 0x800000],
+                 [0, 0, 0, 0, 0, 0, 0x100000 | 0x2000000]):  # (0x2000000: the hash with the 32-bit multiply of id spaces > 2^24)
         assert SglSolver(s, "diamond", tune=tune) == want_d
         assert MotifSolver(s, 3, tune=tune) == want_m3
     assert sum(SglSolver(s, "diamond", rank=r, world=8) for r in range(8)) == want_d
@@ -548,7 +549,8 @@ def test_hashed_row_classes_on_adversarial_ids(dev):
     general = [0, 0, 0, 0, 0, 0, 0x80000]
     assert SglSolver(sd, "diamond", tune=general) == want_d and MotifSolver(sd, 3, tune=general) == want_m3
     want_m4 = MotifSolver(sd, 4, tune=general)
-    for flags in (0x100000, 0x100000 | 0x800000, 0x100000 | 0x400000, 0x100000 | 0x1000000, 0x100000 | 0x1000):
+    # (0x2000000: the kernels instantiated for id spaces beyond 2^24 -- v_mul_lo_u32 instead of v_mul_u32_u24 in the hash)
+    for flags in (0x100000, 0x100000 | 0x800000, 0x100000 | 0x400000, 0x100000 | 0x1000000, 0x100000 | 0x1000, 0x100000 | 0x2000000):
         tune = [0, 0, 0, 0, 0, 0, flags]
         assert SglSolver(sd, "diamond", tune=tune) == want_d, hex(flags)
         assert MotifSolver(sd, 3, tune=tune) == want_m3, hex(flags)
