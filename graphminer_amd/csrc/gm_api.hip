@@ -1911,6 +1911,27 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
   HIP_TRY(hipMemset(d_ticks, 0, sizeof(unsigned long long) * std::max<size_t>(tab->n, 1)));
   p.chunk_ticks = d_ticks;
 #endif
+  if (use_classes) {
+    // everything the class launches may allocate or create, before the timer starts (a first call used to time hipMalloc and
+    // hipStreamCreate between its two events): side streams + their events, and the giant-row kernel's scratch -- per workgroup,
+    // where the pieces of the row cut the partner lists of its chunk, kGiantEdges ints per piece (giant_bounds)
+    for (int i = 0; i < 3; ++i) {
+      if (!g->aux_stream[i]) {
+        HIP_TRY(hipStreamCreateWithFlags(&g->aux_stream[i], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&g->aux_done[i], hipEventDisableTiming));
+      }
+    }
+    if (tab_cls[3] && tab_cls[3]->n > 0) {
+      const size_t need = (size_t)giant_scratch_words(g->max_deg) * sizeof(unsigned) * (size_t)g->cu_count * (size_t)giant_per_cu();
+      if (need > g->scratch_bytes) {
+        if (g->d_scratch) (void)hipFree(g->d_scratch);
+        g->d_scratch = nullptr;
+        g->scratch_bytes = 0;
+        HIP_TRY(hipMalloc(&g->d_scratch, need));
+        g->scratch_bytes = need;
+      }
+    }
+  }
   rc = start_timer(ctx);
   if (rc) return rc;
   if (use_wide && plan && !plan->verts.empty()) {
@@ -1983,10 +2004,6 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
       *ws = stream;
       const bool side = streams_env ? atoi(streams_env) != 0 : count < full_grid;
       if (!side) return GM_OK;
-      if (!g->aux_stream[cls - 1]) {
-        HIP_TRY(hipStreamCreateWithFlags(&g->aux_stream[cls - 1], hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&g->aux_done[cls - 1], hipEventDisableTiming));
-      }
       *ws = g->aux_stream[cls - 1];
       HIP_TRY(hipStreamWaitEvent(*ws, ctx.evp[0], 0));  // after the counters were zeroed and the timer started
       return GM_OK;
@@ -2007,17 +2024,8 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
       // the row as a hashed set in LDS (gm_hrow.hip) unless the ids are too wide for its 14-bit remainders
       // (tune[6] & 0x400000: A/B switch, the sorted LDS copy + bit filter + bisection of gm_mine_wide.hip)
       if (cls == 3) {
-        // per workgroup: where the pieces of the row cut the partner lists of its chunk, kGiantEdges ints per piece (giant_bounds)
         const int rgrid = (int)std::max<long long>(1, std::min<long long>(q.count, (long long)g->cu_count * giant_per_cu()));
-        const unsigned long long slot_words = giant_scratch_words(g->max_deg);
-        const size_t need = (size_t)slot_words * sizeof(unsigned) * (size_t)rgrid;
-        if (need > g->scratch_bytes) {
-          if (g->d_scratch) (void)hipFree(g->d_scratch);
-          g->d_scratch = nullptr;
-          g->scratch_bytes = 0;
-          HIP_TRY(hipMalloc(&g->d_scratch, need));
-          g->scratch_bytes = need;
-        }
+        const unsigned long long slot_words = giant_scratch_words(g->max_deg);  // (allocated before the timer started)
         q.scratch = g->d_scratch;
         q.scratch_words = slot_words;
         hipStream_t ws;
