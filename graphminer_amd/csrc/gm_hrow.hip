@@ -1,7 +1,8 @@
 // gm_hrow.hip -- hashed-row workgroup classes of the symmetric-graph patterns (diamond, 3-motif, the per-edge sums of the
-// formula 4-motif): one row of 3073..24576 entries per chunk, kept in LDS as a HASH-PARTITIONED SET instead of a sorted copy.
+// formula 4-motif): one row of 1025..24576 entries per chunk (longer rows: in pieces, giant_kernel below), kept in LDS as a
+// HASH-PARTITIONED SET instead of a sorted copy.
 //
-// Why (profiles/r02/diamond_rmat24_pmc_summary.txt): on the hub rows of a skewed graph HALF of the streamed keys pass the bit
+// Why (profiles/r02/diamond_rmat24_sorted_classes_pmc_summary.txt): on the hub rows of a skewed graph HALF of the streamed keys pass the bit
 // filter of the sorted-copy classes (true common neighbours + 17 % false positives), and each of them then pays a 13..15 step
 // bisection of the LDS copy -- 74 VALU instructions and 12 LDS instructions per 64 streamed keys, VALU 71 % and LDS 65 % busy
 // (62 % of the LDS cycles are bank conflicts of the bisection's random reads).  A membership test is all these patterns need
@@ -13,12 +14,12 @@
 //   * 2^LB ~ n/3 (8 slots for ~3 entries: on R-MAT rows 0.05-0.3 % of the entries do not fit); a bucket that overflowed carries a
 //     marker in its last slot and its surplus ids sit in a small list (<= 128 per row) that only the lanes missing in such a
 //     bucket consult;
-//   * lookup = one multiply, one ds_read_b128, eight SDWA 16-bit compares (8 VALU + 7 SALU; a packed has-zero-halfword test is
-//     17 VALU: diamond R-MAT-24 304 vs 284 ms): no queue, no compaction, no bisection.
+//   * lookup = one multiply, one ds_read_b128, eight SDWA 16-bit compares whose results stay lane masks in SGPRs (a packed
+//     has-zero-halfword test is 17 VALU: diamond R-MAT-24 304 vs 284 ms; the compares as `bool`s: 240 vs 231 ms): no queue, no
+//     compaction, no bisection -- 16 VALU per 64 keys in the long-list loop.
 // A row that overflows the surplus list (adversarial ids) is looked up by bisection of the row in global memory -- slow, exact.
 // Every task edge streams the partner list (pass X); pass Y does not exist here (the longer row hosts, gm_mine.h sym_hosts).
 #include "gm_flat.h"
-
 
 namespace gm {
 
