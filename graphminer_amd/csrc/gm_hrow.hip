@@ -233,7 +233,7 @@ __device__ __forceinline__ void hrow_pass(HrowWave &L, const Member &member, con
     const int base = readlane(key_base, src);
     const int n = readlane(llen_all, src);
     const int vv = readlane(vpart, src);
-    const int hi = max(u, vv), lo = min(u, vv);
+    const int lo = min(u, vv);
     const int *__restrict__ kp = col + base;
     unsigned cnt_s = 0;  // wave-uniform
     auto process = [&](const int (&key)[T], const unsigned long long (&inm)[T]) {
@@ -242,10 +242,9 @@ __device__ __forceinline__ void hrow_pass(HrowWave &L, const Member &member, con
       auto take = [&](const int q, const unsigned long long xm) {
         if (kPerEdge) {
           cnt_s += (unsigned)__popcll(xm);
-        } else {
-          const unsigned long long am = xm & __ballot(key[q] < hi);
-          s_any += (unsigned)__popcll(am);
-          s_low += (unsigned)__popcll(am & __ballot(key[q] < lo));
+        } else {  // (a long list arrives trimmed to the keys below hi = max(u, v): hrow_chunk / giant_chunk)
+          s_any += (unsigned)__popcll(xm);
+          s_low += (unsigned)__popcll(xm & __ballot(key[q] < lo));
         }
       };
 #pragma unroll
@@ -255,6 +254,7 @@ __device__ __forceinline__ void hrow_pass(HrowWave &L, const Member &member, con
       for (int q = 0; q < T; ++q) any_need |= nm[q];
       if (any_need != 0ull) member.surplus(key, nm, take);  // rare
     };
+    static_assert(kLongList >= 128, "the lists streamed one at a time must be the ones hrow_chunk trims below max(u, v)");
     constexpr int G = GM_WAVE * T;
     int nxt[T];
 #pragma unroll
