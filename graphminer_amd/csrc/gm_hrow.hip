@@ -57,7 +57,8 @@ static_assert(sizeof(HrowWave) * HrowCfg<1>::waves >= (size_t)(2 << kHrowLbMid),
 
 struct HrowView {  // wave-uniform
   unsigned ck, kmask, rmask;
-  int sh;        // K - LB
+  unsigned imask;  // byte offset of a bucket = (h >> (sh - 4)) & imask: the shift and the 16-byte scaling in one, bits above K fall off
+  int sh;        // K - LB (>= 4, else the fallback)
   int n_ovf;
   bool fallback; // the set is not usable: bisect the row in global memory
 };
@@ -94,9 +95,9 @@ __device__ __forceinline__ void hrow_probe(const LdsT &B, const HrowView &hv, co
   unsigned short r16[T];
 #pragma unroll
   for (int q = 0; q < T; ++q) {
-    const unsigned h = hrow_hash<K24>(hv, key[q]);
+    const unsigned h = K24 ? __umul24((unsigned)key[q], hv.ck) : (unsigned)key[q] * hv.ck;  // (no mod 2^K: both masks below cut it)
     r16[q] = (unsigned short)(h & hv.rmask);
-    w[q] = *reinterpret_cast<const uint4 *>(&B.table[(h >> hv.sh) << 3]);
+    w[q] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(B.table) + ((h >> (hv.sh - 4)) & hv.imask));
   }
 #pragma unroll
   for (int q = 0; q < T; ++q) {
@@ -135,13 +136,14 @@ template <bool K24, class LdsT>
 __device__ __forceinline__ void hrow_build(LdsT &B, HrowView &hv, const int *__restrict__ row, const int n, const int lbmax, const int nv,
                                            const int flags, const int tid, const int nthreads) {
   const int K = max(bitlen(nv - 1), 1);
-  const int LB = min(min(lbmax, K), max(K - kHrowRemBits, bitlen((n - 1) / 3)));
+  const int LB = max(min(min(lbmax, K - 4), max(K - kHrowRemBits, bitlen((n - 1) / 3))), 0);  // (K - LB >= 4: see imask)
   hv.sh = K - LB;
+  hv.imask = ((1u << LB) - 1u) << 4;
   hv.kmask = (K >= 32) ? 0xffffffffu : ((1u << K) - 1u);
   hv.rmask = (1u << hv.sh) - 1u;
   hv.ck = (unsigned)(0x9E3779B97F4A7C15ull >> (64 - K)) | 1u;
   // (more than 14 remainder bits -- nv beyond what the host sends here -- or the test switch: every lookup bisects the row in global memory)
-  hv.fallback = (flags & (1 << 22)) != 0 || hv.sh > kHrowRemBits;
+  hv.fallback = (flags & (1 << 22)) != 0 || hv.sh > kHrowRemBits || hv.sh < 4;
   const int nb = 1 << LB;
   unsigned *fill32 = reinterpret_cast<unsigned *>(&B.w[0]);
   {
