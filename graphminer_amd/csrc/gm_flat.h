@@ -263,7 +263,7 @@ __device__ __forceinline__ void flat_pass_filtered(LT &L, const int *__restrict_
 
   auto enqueue = [&](const bool cand, const int key, const int owner) {
     const unsigned long long m = __ballot(cand);
-    if (cand) {
+    if (__builtin_amdgcn_inverse_ballot_w64(m)) {  // (exec = the ballot: `if (cand)` made the compiler evaluate the bit test twice)
       const int slot = qcount + rank_below(m);
       L.qkey[slot] = key;
       L.qown[slot] = (unsigned char)owner;
@@ -273,7 +273,7 @@ __device__ __forceinline__ void flat_pass_filtered(LT &L, const int *__restrict_
   int own_from = kQueueCap, cur_owner = 0;  // wave-uniform: slots >= own_from belong to the long list being streamed
   auto enqueue_long = [&](const bool cand, const int key) {
     const unsigned long long m = __ballot(cand);
-    if (cand) L.qkey[qcount + rank_below(m)] = key;
+    if (__builtin_amdgcn_inverse_ballot_w64(m)) L.qkey[qcount + rank_below(m)] = key;
     qcount += __popcll(m);
   };
   auto drain_full_tiles = [&]() {
