@@ -135,11 +135,12 @@ struct RowFilter {
   int skip_clique_wide = 0;                    // > 0: leave out the vertices with clique_is_wide(d, this many matrix words)
   int skip_lo = 0, skip_hi = 0;                // rows with skip_lo < d <= skip_hi are left out (0, 0 = none)
   int only_lo = -1, only_hi = 0x7fffffff;      // rows with only_lo < d <= only_hi are kept
+  int tct = 0;                                 // 1: chunk costs from the task lists of gm_tct.hip (the tasks a chunk hosts, not its own entries)
   __host__ __device__ bool skips(int d) const {
     return (skip_clique_wide > 0 && clique_is_wide(d, skip_clique_wide)) || (d > skip_lo && d <= skip_hi) || !(d > only_lo && d <= only_hi);
   }
   bool operator==(const RowFilter &o) const {
-    return skip_clique_wide == o.skip_clique_wide && skip_lo == o.skip_lo && skip_hi == o.skip_hi && only_lo == o.only_lo && only_hi == o.only_hi;
+    return skip_clique_wide == o.skip_clique_wide && skip_lo == o.skip_lo && skip_hi == o.skip_hi && only_lo == o.only_lo && only_hi == o.only_hi && tct == o.tct;
   }
 };
 
@@ -207,6 +208,8 @@ struct gm_graph {
   int *d_col = nullptr;  // col_idx
   bool own_col = true;
   int2 *d_edesc = nullptr;  // per CSR entry: {rp[col[e]], degree(col[e])}, built on first use (ensure_edesc)
+  int *d_trp = nullptr;     // task lists of the shorter-list-streams triangle count (ensure_tasklists): row offsets (nv + 1)
+  int2 *d_tdesc = nullptr;  // ... and per task {rp[partner], d(partner)}
   std::vector<int> h_rp;  // host copy of the offsets, fetched on first use (host_rp): download, k-clique tables, SgL renumbering
   std::list<ChunkTable> tables;  // list: handed-out pointers stay valid
   unsigned long long *d_counters = nullptr;  // [4] + queue word, 64 B
@@ -314,6 +317,8 @@ extern "C" void gm_graph_free(gm_graph *g) {
   if (g->d_rp) (void)hipFree(g->d_rp);
   if (g->own_col && g->d_col) (void)hipFree(g->d_col);
   if (g->d_edesc) (void)hipFree(g->d_edesc);
+  if (g->d_trp) (void)hipFree(g->d_trp);
+  if (g->d_tdesc) (void)hipFree(g->d_tdesc);
   for (auto &pl : g->wide_plans) {
     if (pl.d_verts) (void)hipFree(pl.d_verts);
     if (pl.d_base) (void)hipFree(pl.d_base);
@@ -884,10 +889,13 @@ __global__ __launch_bounds__(256) void bitmap_build_kernel(const int *__restrict
 // shorter list, d(v) keys (process_chunk's ownership rule).
 __global__ __launch_bounds__(256) void chunk_cost_kernel(const int *__restrict__ rp, const int *__restrict__ col,
                                                          const ChunkRec *__restrict__ chunks, unsigned long long *__restrict__ cost,
-                                                         int owner_rule, int stage_cap) {
+                                                         int owner_rule, int stage_cap, const int *__restrict__ trp = nullptr,
+                                                         const int2 *__restrict__ tdesc = nullptr) {
   const ChunkRec r = chunks[blockIdx.x];
   unsigned long long c = 0;
-  if (owner_rule) {
+  if (owner_rule == 2) {  // gm_tct.hip: the keys of the lists this chunk's vertices host
+    for (int te = trp[r.u_begin] + (int)threadIdx.x; te < trp[r.u_end]; te += 256) c += (unsigned long long)tdesc[te].y + 8ull;
+  } else if (owner_rule) {
     // a key streamed by a SPLIT chunk is a random probe of the hub row's bitmap in HBM, a key of a staged chunk an LDS filter probe
     const unsigned long long w = (r.u_end == r.u_begin + 1 && (r.e_begin != rp[r.u_begin] || r.e_end != rp[r.u_end])) ? (unsigned long long)kProbeCost : 1ull;
     for (int u = r.u_begin; u < r.u_end; ++u) {  // (a SPLIT chunk has one row; a staged chunk few long or many short ones)
@@ -1081,7 +1089,8 @@ static int build_table_device(gm_graph *g, ChunkTable &t, bool sym_table, double
   DevBuf<unsigned long long> cost0;
   HIP_TRY(cost0.alloc((size_t)n0));
   HIP_TRY(hipMemsetAsync(cost0.p, 0, sizeof(unsigned long long) * (size_t)n0, 0));
-  hipLaunchKernelGGL(chunk_cost_kernel, dim3((unsigned)n0), dim3(256), 0, 0, g->d_rp, g->d_col, recs0.p, cost0.p, sym_table ? 1 : 0, kStageCapWide);
+  hipLaunchKernelGGL(chunk_cost_kernel, dim3((unsigned)n0), dim3(256), 0, 0, g->d_rp, g->d_col, recs0.p, cost0.p, t.rf.tct ? 2 : (sym_table ? 1 : 0), kStageCapWide,
+                     g->d_trp, g->d_tdesc);
   DevBuf<int> np, bsz, off;
   HIP_TRY(np.alloc((size_t)n0 + 1));
   HIP_TRY(bsz.alloc((size_t)n0 + 1));
@@ -1405,6 +1414,70 @@ __global__ __launch_bounds__(256) void edesc_kernel(long long ne, const int *__r
     const int r = rp[v];
     out[e] = make_int2(r, rp[v + 1] - r);
   }
+}
+
+// ---- task lists of gm_tct.hip: every edge u -> v of the DAG is a task of the endpoint with the longer out-list -------------------
+__global__ __launch_bounds__(256) void task_keys_kernel(int nv, long long ne, const int *__restrict__ rp, const int *__restrict__ col,
+                                                         unsigned long long *__restrict__ keys, int *__restrict__ cnt) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += stride) {
+    int lo = 0, hi = nv - 1;  // the row of entry e: largest u with rp[u] <= e
+    while (lo < hi) {
+      const int mid = (int)(((long long)lo + hi + 1) >> 1);
+      if (rp[mid] <= e) lo = mid; else hi = mid - 1;
+    }
+    const int u = lo, v = col[e];
+    const int du = rp[u + 1] - rp[u], dv = rp[v + 1] - rp[v];
+    const int host = (du >= dv) ? u : v, partner = (du >= dv) ? v : u;  // (ties: the source hosts)
+    keys[e] = ((unsigned long long)(unsigned)host << 32) | (unsigned)partner;
+    atomicAdd(&cnt[host], 1);
+  }
+}
+__global__ __launch_bounds__(256) void task_desc_kernel(long long ne, const int *__restrict__ rp, const unsigned long long *__restrict__ sorted,
+                                                         int2 *__restrict__ tdesc) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += stride) {
+    const int y = (int)(unsigned)(sorted[e] & 0xffffffffull);
+    const int r = rp[y];
+    tdesc[e] = make_int2(r, rp[y + 1] - r);
+  }
+}
+static int ensure_tasklists(gm_graph *g) {
+  if (g->d_tdesc || g->ne == 0) return GM_OK;
+  std::lock_guard<std::mutex> lk(g->mu);
+  if (g->d_tdesc) return GM_OK;
+  SetupTimer timer;
+  HIP_TRY(hipSetDevice(g->device));
+  const size_t ne = (size_t)g->ne, nv1 = (size_t)g->nv + 1;
+  DevBuf<unsigned long long> keys, sorted;
+  DevBuf<int> cnt;
+  ScanTemp tmp;
+  HIP_TRY(keys.alloc(ne));
+  HIP_TRY(sorted.alloc(ne));
+  HIP_TRY(cnt.alloc(nv1));
+  HIP_TRY(hipMemset(cnt.p, 0, sizeof(int) * nv1));
+  const long long blocks = std::min<long long>(((long long)ne + 255) / 256, (long long)g->cu_count * 32);
+  hipLaunchKernelGGL(task_keys_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, g->nv, g->ne, g->d_rp, g->d_col, keys.p, cnt.p);
+  int bits = 1;
+  while (bits < 32 && (1ll << bits) < (long long)g->nv) ++bits;
+  size_t bytes = 0;
+  HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, keys.p, sorted.p, (int)ne, 0, 32 + bits));
+  HIP_TRY(tmp.reserve(bytes));
+  HIP_TRY(hipcub::DeviceRadixSort::SortKeys(tmp.buf.p, bytes, keys.p, sorted.p, (int)ne, 0, 32 + bits));
+  int *trp = nullptr;
+  int2 *td = nullptr;
+  HIP_TRY(hipMalloc(&trp, sizeof(int) * nv1));
+  hipError_t e = dev_exclusive_sum(tmp, cnt.p, trp, nv1);
+  if (e == hipSuccess) e = hipMalloc(&td, sizeof(int2) * ne);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(task_desc_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, g->ne, g->d_rp, sorted.p, td);
+    e = hipDeviceSynchronize();
+  }
+  if (e != hipSuccess) { (void)hipFree(trp); if (td) (void)hipFree(td); return hip_fail(e, "task lists", __FILE__, __LINE__); }
+  g->d_trp = trp;
+  g->d_tdesc = td;
+  g->setup.table_ms += timer.ms();
+  return GM_OK;
 }
 
 static int ensure_edesc(gm_graph *g) {
@@ -1748,7 +1821,15 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
   // tune[6] & 0x1000 (tests): cut every chunk above 4096 estimated entries into parts
   // chunk costs are estimated keys (DAG patterns: d(u) + d(v) per edge; symmetric patterns: streamed keys, bitmap probes
   // weighted kProbeCost); parts bound the longest task of a launch
-  const unsigned long long part_cap = (la->tune[6] & 0x1000) ? 4096ull : (stage_cap_of(pat) != kStageCapWide ? kPartCostCap
+  // TC: the shorter list of every edge is streamed against the longer one (gm_tct.hip) when every DAG row fits the LDS stage
+  // (tune[6] & 0x4000000: A/B switch, the chunked kernel that streams N+(v) of every out-edge).  Its chunks host the tasks of
+  // their vertices -- a hub hosts 10^5 in-edges -- so their cost is counted from the task lists and heavy chunks are cut into
+  // parts of 1 M keys / world (>= 128 K): one-GPU simulation of an 8-rank share of R-MAT-22, parts of 8 M / 512 K / 128 K / 32 K keys:
+  // 5.36 / 1.18 / 0.99 / 1.15 ms per rank (one GPU: 6.50 / 6.54 / 6.73 / 8.09 ms), profiles/r02/ab_tct_part_cap.log
+  const bool use_tct = pat == PAT_TC && !(la->tune[6] & 0x4000000) && g->max_deg <= kStageCap && la->tune[5] != 1 && g->ne > 0 &&
+                       !getenv("GM_HOST_TABLES");
+  const unsigned long long part_cap = (la->tune[6] & 0x1000) ? 4096ull : (stage_cap_of(pat) != kStageCapWide
+       ? (use_tct ? std::max<unsigned long long>((1ull << 20) / (unsigned long long)world, 128ull << 10) : kPartCostCap)
        // a rank's share is 1/world of the launch: so is the tolerable tail (3-motif's bounded lists make its estimates
        // pessimistic already: measured, 1/8 share 84.8 ms unscaled vs 91.2 ms scaled; diamond 5.2 vs 4.2 ms)
        : (pat == PAT_MOTIF3 ? kPartCostCapSym : std::max<unsigned long long>(kPartCostCapSym / (unsigned long long)world, 256ull << 10)));
@@ -1765,7 +1846,12 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
   // R-MAT-20 6.4 vs 5.7, power law 4.07 vs 4.10, R-MAT-24 458 vs 172). A graph without such rows skips their (empty) tables.
   // tune[6] & 0x100000 forces them on.
   if (use_classes && !(la->tune[6] & 0x100000)) use_classes = g->max_deg > kClassRowMin;
+  if (use_tct) {
+    int rc_t = ensure_tasklists(g);
+    if (rc_t) return rc_t;
+  }
   RowFilter rf;
+  rf.tct = use_tct ? 1 : 0;
   rf.skip_clique_wide = use_wide ? clique_wide_min_words() : 0;
   // Rows of 1025..3072 entries fit the general kernel's stage, but their partner lists (mean 600 keys on R-MAT-24) are cheaper
   // against a hashed set than against the filter + bisection of a multi-row chunk: measured (profiles/r02/ab_hrow_class_lower_bound.log,
@@ -1823,6 +1909,10 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
   rc = ensure_edesc(g);  // (the kernels read them unconditionally; -DGM_EDESC=0 builds gather rp[v] instead, for A/B runs)
   if (rc) return rc;
   p.g.edesc = g->d_edesc;
+  if (use_tct) {
+    p.g.trp = g->d_trp;
+    p.g.tdesc = g->d_tdesc;
+  }
   unsigned long long my_edges = 0;
   // this rank's share of a table: chunk ids first + i*step of the dequeue order (or a contiguous / vertex range)
   auto take_share = [&](ChunkTable *tb, MineParams &q) {
@@ -2048,7 +2138,8 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
       if (rc) return rc;
     }
   }
-  if (p.count > 0) HIP_TRY(launch_mine(pat, p, grid, stream));
+  if (p.count > 0 && use_tct) HIP_TRY(launch_tct(p, (int)std::max<long long>(1, std::min<long long>(want, (long long)g->cu_count * 8)), stream));
+  else if (p.count > 0) HIP_TRY(launch_mine(pat, p, grid, stream));
 #ifdef GM_DEBUG_CHUNKS
   {
     HIP_TRY(hipStreamSynchronize(stream));

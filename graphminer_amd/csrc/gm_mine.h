@@ -72,6 +72,10 @@ struct GraphView {
   // was half of the lines a task edge touches. Takes the place of the reference's COO src/dst lists (8 B per task,
   // include/graph_gpu.h:29-30); nullptr = gather from rp.
   const int2 *edesc = nullptr;
+  // Task lists of the shorter-list-streams triangle count (gm_tct.hip): per vertex the descriptors {rp[partner], d+(partner)}
+  // of the lists it hosts, trp = their row offsets (nv+1); nullptr = not built.
+  const int *trp = nullptr;
+  const int2 *tdesc = nullptr;
 };
 
 enum Pattern : int { PAT_TC = 0, PAT_DIAMOND = 1, PAT_MOTIF3 = 2, PAT_CLIQUE4 = 3, PAT_CLIQUEK = 4 /* k = 5..8 */,
@@ -312,6 +316,7 @@ __host__ __device__ inline int clique_count_class(int d) {
 
 // host-side launchers (gm_mine.hip)
 hipError_t launch_mine(Pattern pat, const MineParams &p, int grid_blocks, hipStream_t stream);
+hipError_t launch_tct(const MineParams &p, int grid_blocks, hipStream_t stream);  // gm_tct.hip
 size_t mine_lds_bytes(Pattern pat);
 // the big-LDS classes (gm_mine_wide.hip): cls = 1 (mid rows) or 2 (big rows); DIAMOND, MOTIF3, MOTIF4E only
 hipError_t launch_mine_wide(Pattern pat, int cls, const MineParams &p, int grid_blocks, hipStream_t stream);

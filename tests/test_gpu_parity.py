@@ -69,12 +69,15 @@ def test_tc_matches_reference(gg):
     assert total == GOLDEN[name]["tc"]
     assert st.tasks == dag.E()  # "edges processed" = |E+| (src/triangle/gpu_base.cu:69)
     assert CliqueSolver(dag, 3) == GOLDEN[name]["tc"]
+    # (default: the shorter list of every edge is streamed, gm_tct.hip; 0x4000000: the chunked kernel that streams N+(v) of every out-edge)
+    assert TCSolver(dag, tune=[0, 0, 0, 0, 0, 0, 0x4000000]) == GOLDEN[name]["tc"]
 
 
 @pytest.mark.parametrize("tune", [
     [64, 1, 0, 0, 0, 0], [256, 4, 0, 0, 0, 1], [1024, 2, 0, 0, 0, 0], [128, 8, 1, 1, 0, 0], [256, 4, 1, 30, 2, 0],
     [0, 0, 0, 0, 0, 0, 0x1000], [0, 0, 0, 0, 0, 0, 0x4000], [0, 0, 0, 0, 0, 0, 0x3000],
     [256, 4, 8, 1, 0, 0],
+    [64, 1, 0, 0, 0, 0, 0x4000000], [256, 4, 1, 30, 2, 0, 0x4000000], [0, 0, 0, 0, 0, 0, 0x4000000 | 0x1000], [128, 8, 1, 1, 0, 0, 0x4000000 | 0x4000],
 ])
 def test_tc_invariant_under_tuning(gg, tune):
     name, _, sym, dag = gg
