@@ -1826,8 +1826,9 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
   // their vertices -- a hub hosts 10^5 in-edges -- so their cost is counted from the task lists and heavy chunks are cut into
   // parts of 1 M keys / world (>= 128 K): one-GPU simulation of an 8-rank share of R-MAT-22, parts of 8 M / 512 K / 128 K / 32 K keys:
   // 5.36 / 1.18 / 0.99 / 1.15 ms per rank (one GPU: 6.50 / 6.54 / 6.73 / 8.09 ms), profiles/r02/ab_tct_part_cap.log
-  const bool use_tct = pat == PAT_TC && !(la->tune[6] & 0x4000000) && g->max_deg <= kStageCap && la->tune[5] != 1 && g->ne > 0 &&
+  const bool use_tct = pat == PAT_TC && !(la->tune[6] & 0x4000000) && g->max_deg <= kTctStageMax && la->tune[5] != 1 && g->ne > 0 &&
                        !getenv("GM_HOST_TABLES");
+  const int tct_stage = g->max_deg <= kStageCap ? kStageCap : kTctStageMax;
   const unsigned long long part_cap = (la->tune[6] & 0x1000) ? 4096ull : (stage_cap_of(pat) != kStageCapWide
        ? (use_tct ? std::max<unsigned long long>((1ull << 20) / (unsigned long long)world, 128ull << 10) : kPartCostCap)
        // a rank's share is 1/world of the launch: so is the tolerable tail (3-motif's bounded lists make its estimates
@@ -1863,7 +1864,7 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
   // dense bitmaps in HBM (tune[6] & 0x1000000: A/B switch, they stay SPLIT chunks of the general kernel)
   const bool use_range = use_classes && !(la->tune[6] & 0x1000000) && hrow_fits(g->nv, 2);  // (its pieces are class-2 sets: nv <= 2^27)
   if (use_classes) { rf.skip_lo = cls_lo; rf.skip_hi = use_range ? 0x7fffffff : kStageCapBig; }
-  int rc = get_table(g, target, !clique, clique ? kBitWords : 0, part_cap, stage_cap_of(pat), &tab, rf, use_classes ? kStageCapBig : kBitmapMinDeg);
+  int rc = get_table(g, target, !clique, clique ? kBitWords : 0, part_cap, use_tct ? tct_stage : stage_cap_of(pat), &tab, rf, use_classes ? kStageCapBig : kBitmapMinDeg);
   if (rc) return rc;
   ChunkTable *tab_cls[4] = {tab, nullptr, nullptr, nullptr};
   if (use_classes) {
@@ -2138,7 +2139,7 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
       if (rc) return rc;
     }
   }
-  if (p.count > 0 && use_tct) HIP_TRY(launch_tct(p, (int)std::max<long long>(1, std::min<long long>(want, (long long)g->cu_count * 8)), stream));
+  if (p.count > 0 && use_tct) HIP_TRY(launch_tct(p, tct_stage, (int)std::max<long long>(1, std::min<long long>(want, (long long)g->cu_count * tct_per_cu(tct_stage))), stream));
   else if (p.count > 0) HIP_TRY(launch_mine(pat, p, grid, stream));
 #ifdef GM_DEBUG_CHUNKS
   {

@@ -316,7 +316,9 @@ __host__ __device__ inline int clique_count_class(int d) {
 
 // host-side launchers (gm_mine.hip)
 hipError_t launch_mine(Pattern pat, const MineParams &p, int grid_blocks, hipStream_t stream);
-hipError_t launch_tct(const MineParams &p, int grid_blocks, hipStream_t stream);  // gm_tct.hip
+constexpr int kTctStageMax = 2048;  // gm_tct.hip: the longest DAG row its stage takes
+hipError_t launch_tct(const MineParams &p, int stage, int grid_blocks, hipStream_t stream);
+int tct_per_cu(int stage);
 size_t mine_lds_bytes(Pattern pat);
 // the big-LDS classes (gm_mine_wide.hip): cls = 1 (mid rows) or 2 (big rows); DIAMOND, MOTIF3, MOTIF4E only
 hipError_t launch_mine_wide(Pattern pat, int cls, const MineParams &p, int grid_blocks, hipStream_t stream);

@@ -6,13 +6,14 @@
 // d+(v)) per edge is 5.0 G keys.  The tasks of a vertex are then its out-edges to shorter-or-equal lists AND its in-edges from
 // shorter lists: a second CSR ("task lists", built once per graph on the device: gm_api.hip ensure_tasklists) whose entries are
 // the descriptors {rp[partner], d+(partner)} of the lists to stream.  A chunk = consecutive vertices whose DAG rows fit the
-// 1024-entry stage (the chunk table of the DAG, unchanged); its tasks = the task-list entries of the same vertices.
+// stage of 1024 entries (2048 where the longest row needs it); its tasks = the task-list entries of the same vertices.
 #include "gm_flat.h"
 
 namespace gm {
 
+template <int STAGE>
 struct alignas(16) TctLds {
-  int stage[kStageCap];            // the chunk's DAG rows (the stationary side)
+  int stage[STAGE];                // the chunk's DAG rows (the stationary side)
   unsigned fbits[kFilterWords];    // hashed membership filter of (local row, id)
   int rpl[kMaxChunkVerts + 1];     // row offsets of the chunk's DAG rows (global entry indices)
   int trpl[kMaxChunkVerts + 1];    // row offsets of its task lists
@@ -31,9 +32,10 @@ __device__ __forceinline__ int local_row(const int *rpl, const int nvl, const in
   return lo;
 }
 
-__global__ __launch_bounds__((kWavesPerBlock * GM_WAVE), 8)
+template <int STAGE>
+__global__ __launch_bounds__((kWavesPerBlock * GM_WAVE), (STAGE <= 1024 ? 8 : 6))
 void tct_kernel(const MineParams p) {
-  __shared__ TctLds B;
+  __shared__ TctLds<STAGE> B;
   const int lane = threadIdx.x & (GM_WAVE - 1);
   const int wave = threadIdx.x >> 6;
   const int tid = threadIdx.x, nthreads = kWavesPerBlock * GM_WAVE;
@@ -97,10 +99,15 @@ void tct_kernel(const MineParams p) {
   if (lane == 0 && s0) atomicAdd(&p.counters[0], s0);
 }
 
-hipError_t launch_tct(const MineParams &p, int grid_blocks, hipStream_t stream) {
-  static_assert(sizeof(TctLds) * 8 <= 163840, "eight workgroups per CU");
+// stage: 1024 (20 KB of LDS, eight workgroups per CU) or 2048 entries (24 KB, six) -- the longest DAG row must fit
+int tct_per_cu(int stage) { return stage <= 1024 ? 8 : 6; }
+hipError_t launch_tct(const MineParams &p, int stage, int grid_blocks, hipStream_t stream) {
+  static_assert(sizeof(TctLds<1024>) * 8 <= 163840, "eight workgroups per CU");
+  static_assert(sizeof(TctLds<kTctStageMax>) * 6 <= 163840, "six workgroups per CU");
   if (p.g.trp == nullptr || p.g.tdesc == nullptr) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(tct_kernel, dim3((unsigned)grid_blocks), dim3(kWavesPerBlock * GM_WAVE), 0, stream, p);
+  const dim3 grid((unsigned)grid_blocks), block(kWavesPerBlock * GM_WAVE);
+  if (stage <= 1024) hipLaunchKernelGGL((tct_kernel<1024>), grid, block, 0, stream, p);
+  else hipLaunchKernelGGL((tct_kernel<kTctStageMax>), grid, block, 0, stream, p);
   return hipGetLastError();
 }
 
