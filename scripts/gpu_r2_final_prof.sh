@@ -30,7 +30,7 @@ for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
         agg = collections.defaultdict(lambda: [0.0, 0])
         for row in csv.DictReader(open(f)):
             k = row.get("Kernel_Name", "")
-            if not any(x in k for x in ("mine_kernel", "hrow_kernel", "giant_kernel")) or "mine_kernel<6" in k: continue
+            if not any(x in k for x in ("mine_kernel", "hrow_kernel", "giant_kernel", "tct_kernel")) or "mine_kernel<6" in k: continue
             agg[(k[:58], row.get("Counter_Name"))][0] += float(row.get("Counter_Value", 0)); agg[(k[:58], row.get("Counter_Name"))][1] += 1
         for (k, c), (s, n) in sorted(agg.items()):
             print(f"{k:58s} {c:24s} per-launch {s/n:18.1f}  launches {n}")
