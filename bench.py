@@ -615,6 +615,12 @@ def finish_record(rec, a, world, ab, floor, traffic, traffic_src, cpu, known, st
                      "frac_basis": "no counter traffic available and the algorithmic formula exceeds the peak: not a roofline"})
     if stream_gbs and roof.get("achieved"):
         roof["frac_of_stream_ceiling"] = round(roof["achieved"] / stream_gbs, 5)
+    if rec["workload"] in ("tc", "motif3f"):
+        roof["note"] = ("tct_kernel streams the SHORTER list of every DAG edge (sum min(d+(u), d+(v)) keys; the section-8(d) formula charges N+(u) and N+(v) "
+                        "per edge); VALU-issue bound (profiles/r02/tc_rmat22_pmc_summary.txt)")
+    elif rec["workload"] in ("diamond", "motif3"):
+        roof["note"] = "rows > 1024 entries are hashed sets in LDS (gm_hrow.hip): every partner list is fetched about once; VALU 80-95 % busy in the class kernels"
+
     out["roofline"] = roof
     if cpu:
         out["cpu_baseline"] = cpu
