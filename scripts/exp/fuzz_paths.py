@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Differential fuzz on the GPU: every pattern through its default path and through the alternative implementation behind the A/B
+switches (TC: task lists vs chunked kernel; diamond / 3-motif / 4-motif: hashed-row classes vs general kernel vs sorted classes;
+4-clique: two-phase wide vertices vs the arena path), on random graphs of varied shape, with rank shares."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+from graphminer_amd import TCSolver, SglSolver, MotifSolver, CliqueSolver
+from graphminer_amd.rmat import csr_from_pairs, rmat_csr_numpy
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+rng = np.random.default_rng(2026)
+bad = 0
+t0 = time.time()
+for case in range(n_cases):
+    kind = case % 4
+    if kind == 0:
+        sc = int(rng.integers(10, 18)); ef = int(rng.integers(4, 33)); g = rmat_csr_numpy(sc, ef, int(rng.integers(1, 1000))); name = f"rmat{sc}_ef{ef}"
+    elif kind == 1:  # hubs of random sizes over a random background
+        nv = int(rng.integers(20000, 200000)); s, d = [rng.integers(0, nv, nv * 6).astype(np.uint64)], [rng.integers(0, nv, nv * 6).astype(np.uint64)]
+        for _ in range(int(rng.integers(1, 6))):
+            n = int(rng.choice([1500, 5000, 9000, 20000, 30000, 60000])); n = min(n, nv - 1)
+            s.append(np.full(n, int(rng.integers(0, nv)), dtype=np.uint64)); d.append(rng.choice(nv, n, replace=False).astype(np.uint64))
+        g = csr_from_pairs(nv, np.concatenate(s), np.concatenate(d)); name = f"hubs_nv{nv}"
+    elif kind == 2:  # dense-ish small graph (wide DAG rows)
+        nv = int(rng.integers(1500, 5000)); m = nv * int(rng.integers(100, 400))
+        g = csr_from_pairs(nv, rng.integers(0, nv, m).astype(np.uint64), rng.integers(0, nv, m).astype(np.uint64)); name = f"dense_nv{nv}_m{m}"
+    else:  # flat degrees
+        nv = int(rng.integers(50000, 400000)); m = nv * int(rng.integers(3, 12))
+        g = csr_from_pairs(nv, rng.integers(0, nv, m).astype(np.uint64), rng.integers(0, nv, m).astype(np.uint64)); name = f"flat_nv{nv}_m{m}"
+    sym = g.to_device(0); dag = sym.orient()
+    T = lambda f: [0, 0, 0, 0, 0, 0, f]
+    res = {
+        "tc": [TCSolver(dag), TCSolver(dag, tune=T(0x4000000)), sum(TCSolver(dag, rank=r, world=3) for r in range(3))],
+        "diamond": [SglSolver(sym, "diamond"), SglSolver(sym, "diamond", tune=T(0x80000)), SglSolver(sym, "diamond", tune=T(0x100000 | 0x400000 | 0x1000000)),
+                    sum(SglSolver(sym, "diamond", rank=r, world=5) for r in range(5))],
+        "motif3": [MotifSolver(sym, 3), MotifSolver(sym, 3, tune=T(0x80000)), MotifSolver(sym, 3, tune=T(0x100000 | 0x2000000))],
+        "clique4": [CliqueSolver(dag, 4), CliqueSolver(dag, 4, tune=T(0x40000))],
+    }
+    ok = all(all(x == v[0] for x in v) for v in res.values())
+    bad += 0 if ok else 1
+    print(f"{case:3d} {name:28s} entries {g.col_idx.size:10d} maxdeg {int(np.diff(g.row_ptr).max()):7d} dag maxdeg {dag.get_max_degree():5d} {'ok' if ok else 'MISMATCH ' + str(res)}", flush=True)
+print("cases", n_cases, "mismatches", bad, "seconds", round(time.time() - t0, 1))
+sys.exit(1 if bad else 0)
