@@ -2,6 +2,7 @@
 the real reference, and size-independent properties. Run on the MI355X box: pytest -m gpu."""
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import pytest
@@ -561,6 +562,18 @@ def test_hashed_row_classes_on_adversarial_ids(dev):
     assert sum(SglSolver(sd, "diamond", rank=r, world=3, tune=[0, 0, 0, 0, 0, 0, 0x100000]) for r in range(3)) == want_d
     parts = [MotifSolver(sd, 3, rank=r, world=5, tune=[0, 0, 0, 0, 0, 0, 0x100000]) for r in range(5)]
     assert [sum(p[i] for p in parts) % 2**64 for i in range(2)] == want_m3
+
+
+def test_differential_fuzz_across_implementation_paths(dev):
+    """scripts/exp/fuzz_paths.py: 24 random graphs (R-MAT, hub, dense, flat), every pattern through its default path and through the
+    alternative implementations behind the A/B switches, plus rank shares -- all counts equal"""
+    import subprocess
+    import sys as _sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([_sys.executable, os.path.join(root, "scripts", "exp", "fuzz_paths.py"), "24"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "mismatches 0" in r.stdout
 
 
 @pytest.mark.parametrize("pattern", ["rectangle", "house", "pentagon"])
