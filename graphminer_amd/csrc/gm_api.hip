@@ -1418,7 +1418,7 @@ __global__ __launch_bounds__(256) void edesc_kernel(long long ne, const int *__r
 
 // ---- task lists of gm_tct.hip: every edge u -> v of the DAG is a task of the endpoint with the longer out-list -------------------
 __global__ __launch_bounds__(256) void task_keys_kernel(int nv, long long ne, const int *__restrict__ rp, const int *__restrict__ col,
-                                                         unsigned long long *__restrict__ keys, int *__restrict__ cnt) {
+                                                         unsigned long long *__restrict__ keys, int *__restrict__ cnt, int stage_max) {
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += stride) {
     int lo = 0, hi = nv - 1;  // the row of entry e: largest u with rp[u] <= e
@@ -1428,7 +1428,12 @@ __global__ __launch_bounds__(256) void task_keys_kernel(int nv, long long ne, co
     }
     const int u = lo, v = col[e];
     const int du = rp[u + 1] - rp[u], dv = rp[v + 1] - rp[v];
-    const int host = (du >= dv) ? u : v, partner = (du >= dv) ? v : u;  // (ties: the source hosts)
+    if (du > stage_max) {  // a row the stage cannot take hosts nothing: its out-edges stay with the chunked kernel (run_pattern)
+      keys[e] = ~0ull;     // (sorts behind every task)
+      continue;
+    }
+    const bool u_hosts = dv > stage_max || du >= dv;  // the longer list hosts (ties: the source) -- unless it does not fit the stage
+    const int host = u_hosts ? u : v, partner = u_hosts ? v : u;
     keys[e] = ((unsigned long long)(unsigned)host << 32) | (unsigned)partner;
     atomicAdd(&cnt[host], 1);
   }
@@ -1437,6 +1442,7 @@ __global__ __launch_bounds__(256) void task_desc_kernel(long long ne, const int 
                                                          int2 *__restrict__ tdesc) {
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += stride) {
+    if (sorted[e] == ~0ull) { tdesc[e] = make_int2(0, 0); continue; }  // (the out-edges of rows beyond the stage: not tasks)
     const int y = (int)(unsigned)(sorted[e] & 0xffffffffull);
     const int r = rp[y];
     tdesc[e] = make_int2(r, rp[y + 1] - r);
@@ -1457,13 +1463,14 @@ static int ensure_tasklists(gm_graph *g) {
   HIP_TRY(cnt.alloc(nv1));
   HIP_TRY(hipMemset(cnt.p, 0, sizeof(int) * nv1));
   const long long blocks = std::min<long long>(((long long)ne + 255) / 256, (long long)g->cu_count * 32);
-  hipLaunchKernelGGL(task_keys_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, g->nv, g->ne, g->d_rp, g->d_col, keys.p, cnt.p);
+  hipLaunchKernelGGL(task_keys_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, g->nv, g->ne, g->d_rp, g->d_col, keys.p, cnt.p, kTctStageMax);
   int bits = 1;
   while (bits < 32 && (1ll << bits) < (long long)g->nv) ++bits;
   size_t bytes = 0;
-  HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, keys.p, sorted.p, (int)ne, 0, 32 + bits));
+  const int end_bit = g->max_deg > kTctStageMax ? 64 : 32 + bits;  // (the all-ones keys of excluded edges need every bit)
+  HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, keys.p, sorted.p, (int)ne, 0, end_bit));
   HIP_TRY(tmp.reserve(bytes));
-  HIP_TRY(hipcub::DeviceRadixSort::SortKeys(tmp.buf.p, bytes, keys.p, sorted.p, (int)ne, 0, 32 + bits));
+  HIP_TRY(hipcub::DeviceRadixSort::SortKeys(tmp.buf.p, bytes, keys.p, sorted.p, (int)ne, 0, end_bit));
   int *trp = nullptr;
   int2 *td = nullptr;
   HIP_TRY(hipMalloc(&trp, sizeof(int) * nv1));
@@ -1826,9 +1833,10 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
   // their vertices -- a hub hosts 10^5 in-edges -- so their cost is counted from the task lists and heavy chunks are cut into
   // parts of 1 M keys / world (>= 128 K): one-GPU simulation of an 8-rank share of R-MAT-22, parts of 8 M / 512 K / 128 K / 32 K keys:
   // 5.36 / 1.18 / 0.99 / 1.15 ms per rank (one GPU: 6.50 / 6.54 / 6.73 / 8.09 ms), profiles/r02/ab_tct_part_cap.log
-  const bool use_tct = pat == PAT_TC && !(la->tune[6] & 0x4000000) && g->max_deg <= kTctStageMax && la->tune[5] != 1 && g->ne > 0 &&
-                       !getenv("GM_HOST_TABLES");
+  const bool use_tct = pat == PAT_TC && !(la->tune[6] & 0x4000000) && la->tune[5] != 1 && g->ne > 0 && !getenv("GM_HOST_TABLES");
   const int tct_stage = g->max_deg <= kStageCap ? kStageCap : kTctStageMax;
+  // (rows beyond the 2048-entry stage host nothing: their out-edges are the tasks of the chunked kernel, on a table of those rows only)
+  const bool tct_long = use_tct && g->max_deg > kTctStageMax;
   const unsigned long long part_cap = (la->tune[6] & 0x1000) ? 4096ull : (stage_cap_of(pat) != kStageCapWide
        ? (use_tct ? std::max<unsigned long long>((1ull << 20) / (unsigned long long)world, 128ull << 10) : kPartCostCap)
        // a rank's share is 1/world of the launch: so is the tolerable tail (3-motif's bounded lists make its estimates
@@ -1853,6 +1861,7 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
   }
   RowFilter rf;
   rf.tct = use_tct ? 1 : 0;
+  if (tct_long) { rf.skip_lo = kTctStageMax; rf.skip_hi = 0x7fffffff; }
   rf.skip_clique_wide = use_wide ? clique_wide_min_words() : 0;
   // Rows of 1025..3072 entries fit the general kernel's stage, but their partner lists (mean 600 keys on R-MAT-24) are cheaper
   // against a hashed set than against the filter + bisection of a multi-row chunk: measured (profiles/r02/ab_hrow_class_lower_bound.log,
@@ -1866,6 +1875,13 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
   if (use_classes) { rf.skip_lo = cls_lo; rf.skip_hi = use_range ? 0x7fffffff : kStageCapBig; }
   int rc = get_table(g, target, !clique, clique ? kBitWords : 0, part_cap, use_tct ? tct_stage : stage_cap_of(pat), &tab, rf, use_classes ? kStageCapBig : kBitmapMinDeg);
   if (rc) return rc;
+  ChunkTable *tab_long = nullptr;
+  if (tct_long) {
+    RowFilter rl;
+    rl.only_lo = kTctStageMax;
+    rc = get_table(g, target, true, 0, kPartCostCap, kStageCap, &tab_long, rl, kBitmapMinDeg);
+    if (rc) return rc;
+  }
   ChunkTable *tab_cls[4] = {tab, nullptr, nullptr, nullptr};
   if (use_classes) {
     RowFilter r1, r2;
@@ -2137,6 +2153,18 @@ static int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int
       else HIP_TRY(launch_mine_wide(pat, cls, q, wgrid, ws));
       rc = side_done(cls, ws);
       if (rc) return rc;
+    }
+  }
+  if (tab_long) {  // TC: the out-edges of the rows beyond the stage, through the chunked kernel (own dequeue word)
+    MineParams q = p;
+    take_share(tab_long, q);
+    q.g.trp = nullptr;
+    q.g.tdesc = nullptr;
+    q.queue = reinterpret_cast<unsigned *>(g->d_counters + 4) + 1;
+    if (q.count > 0) {
+      chunks_total += (uint64_t)q.count;
+      const long long wq = ((long long)q.count + (long long)q.grab - 1) / (long long)q.grab;
+      HIP_TRY(launch_mine(pat, q, (int)std::max<long long>(1, std::min<long long>(wq, (long long)g->cu_count * per_cu)), stream));
     }
   }
   if (p.count > 0 && use_tct) HIP_TRY(launch_tct(p, tct_stage, (int)std::max<long long>(1, std::min<long long>(want, (long long)g->cu_count * tct_per_cu(tct_stage))), stream));

@@ -564,6 +564,27 @@ def test_hashed_row_classes_on_adversarial_ids(dev):
     assert [sum(p[i] for p in parts) % 2**64 for i in range(2)] == want_m3
 
 
+def test_tc_rows_beyond_the_task_list_stage(dev):
+    """A dense core inside a sparse graph: DAG rows beyond the 2048-entry stage of tct_kernel host nothing, their out-edges go through
+    the chunked kernel (own table), every other edge through the task lists -- against the CPU oracle, both A/B paths, rank shares."""
+    rng = np.random.default_rng(5)
+    nv, core = 40000, 2400
+    cs, cd = np.triu_indices(core, 1)
+    keep = rng.random(cs.size) < 0.93
+    s = np.concatenate([cs[keep], rng.integers(0, nv, 300000)]).astype(np.uint64)
+    d = np.concatenate([cd[keep], rng.integers(0, nv, 300000)]).astype(np.uint64)
+    g = csr_from_pairs(nv, s, d)
+    dag = g.to_device(dev).orient()
+    assert dag.get_max_degree() > 2048
+    want = O.tc(O.orient(O.OGraph(g.row_ptr, g.col_idx)))
+    got, st = TCSolver(dag, return_stats=True)
+    assert got == want and st.tasks == dag.E()
+    assert TCSolver(dag, tune=[0, 0, 0, 0, 0, 0, 0x4000000]) == want  # the chunked kernel alone
+    assert sum(TCSolver(dag, rank=r, world=3) for r in range(3)) == want
+    assert sum(TCSolver(dag, rank=r, world=4, policy=2) for r in range(4)) == want
+    assert CliqueSolver(dag, 3) == want
+
+
 def test_differential_fuzz_across_implementation_paths(dev):
     """scripts/exp/fuzz_paths.py: 24 random graphs (R-MAT, hub, dense, flat), every pattern through its default path and through the
     alternative implementations behind the A/B switches, plus rank shares -- all counts equal"""
