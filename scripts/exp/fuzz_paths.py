@@ -8,6 +8,10 @@ import numpy as np
 from graphminer_amd import TCSolver, SglSolver, MotifSolver, CliqueSolver
 from graphminer_amd.rmat import csr_from_pairs, rmat_csr_numpy
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+use_oracle = len(sys.argv) > 2 and sys.argv[2] == "oracle"  # also against the CPU oracle (graphs below 2.5 M entries)
+if use_oracle:
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
+    import oracle as O
 rng = np.random.default_rng(2026)
 bad = 0
 t0 = time.time()
@@ -36,6 +40,9 @@ for case in range(n_cases):
         "motif3": [MotifSolver(sym, 3), MotifSolver(sym, 3, tune=T(0x80000)), MotifSolver(sym, 3, tune=T(0x100000 | 0x2000000))],
         "clique4": [CliqueSolver(dag, 4), CliqueSolver(dag, 4, tune=T(0x40000))],
     }
+    if use_oracle and g.col_idx.size < 2500000:
+        osym = O.OGraph(g.row_ptr, g.col_idx); odag = O.orient(osym)
+        res["tc"].append(O.tc(odag)); res["diamond"].append(O.diamond(osym)); res["motif3"].append(O.motif3(osym)); res["clique4"].append(O.clique(odag, 4))
     ok = all(all(x == v[0] for x in v) for v in res.values())
     bad += 0 if ok else 1
     print(f"{case:3d} {name:28s} entries {g.col_idx.size:10d} maxdeg {int(np.diff(g.row_ptr).max()):7d} dag maxdeg {dag.get_max_degree():5d} {'ok' if ok else 'MISMATCH ' + str(res)}", flush=True)
