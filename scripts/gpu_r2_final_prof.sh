@@ -14,7 +14,7 @@ for name in tc_rmat22 tc_uniform tc_powerlaw diamond_rmat22 clique4_rmat22ef28 m
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$name/trace -o trace -- python $REPO/bench.py ${CASES[$name]} $B > $O/${name}_bench_line.json 2>/dev/null
   find /tmp/p_$name/trace -name "*kernel_stats.csv" -exec sh -c 'head -12 "$1" | cut -c1-200 > "$2"' _ {} $O/${name}_kernel_stats.csv \;
 done
-for name in tc_rmat22 diamond_rmat22 diamond_rmat24 motif3_rmat24; do
+for name in tc_rmat22 tc_uniform diamond_rmat22 diamond_rmat24 motif3_rmat24 clique4_rmat22ef28; do
   i=0
   for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_ANY" \
              "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM" \
@@ -30,7 +30,7 @@ for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
         agg = collections.defaultdict(lambda: [0.0, 0])
         for row in csv.DictReader(open(f)):
             k = row.get("Kernel_Name", "")
-            if not any(x in k for x in ("mine_kernel", "hrow_kernel", "giant_kernel", "tct_kernel")) or "mine_kernel<6" in k: continue
+            if not any(x in k for x in ("mine_kernel", "hrow_kernel", "giant_kernel", "tct_kernel", "clique_build", "clique_count")) or "mine_kernel<6" in k: continue
             agg[(k[:58], row.get("Counter_Name"))][0] += float(row.get("Counter_Value", 0)); agg[(k[:58], row.get("Counter_Name"))][1] += 1
         for (k, c), (s, n) in sorted(agg.items()):
             print(f"{k:58s} {c:24s} per-launch {s/n:18.1f}  launches {n}")
