@@ -30,9 +30,12 @@ constexpr int kHrowTiles = 4;     // 64-key tiles in flight per wave
 
 template <int CLS>
 struct HrowCfg {
-  static constexpr int waves = CLS == 2 ? 16 : 8;
+  // class 1: 2^12 buckets (64 KB) + 12 waves = 76.5 KB, two workgroups = 24 waves per CU; with 2^11 buckets (32 KB, 8 waves, three
+  // workgroups: the same 24 waves) a row of ~7000 entries -- most class-1 rows of R-MAT-24 -- has 16 overflowed buckets, and 40 % of
+  // the key tiles took the surplus path
+  static constexpr int waves = CLS == 2 ? 16 : (kHrowLbMid >= 12 ? 12 : 8);
   static constexpr int lbmax = CLS == 2 ? kHrowLbBig : kHrowLbMid;
-  static constexpr int per_cu = CLS == 2 ? 1 : 3;
+  static constexpr int per_cu = CLS == 2 ? 1 : (kHrowLbMid >= 12 ? 2 : 3);
 };
 
 struct alignas(16) HrowWave {

@@ -325,7 +325,10 @@ hipError_t launch_mine_wide(Pattern pat, int cls, const MineParams &p, int grid_
 size_t mine_wide_lds_bytes(int cls);
 // hashed-row classes (gm_hrow.hip): the row as a hash-partitioned set of 16-bit remainders, 2^LB buckets of eight slots
 constexpr int kClassRowMin = 1024;  // rows longer than this leave the general kernel when the classes are on
-constexpr int kHrowLbMid = 11;  // class 1 (rows of 3073..8191 entries): 32 KB
+#ifndef GM_HROW_LB_MID
+#define GM_HROW_LB_MID 12
+#endif
+constexpr int kHrowLbMid = GM_HROW_LB_MID;  // class 1 (rows of 1025..8191 entries): 2^12 buckets = 64 KB (2^11: 32 KB)
 constexpr int kHrowLbBig = 13;  // class 2 (rows of 8192..24576 entries): 128 KB
 hipError_t launch_hrow(Pattern pat, int cls, const MineParams &p, int grid_blocks, hipStream_t stream);
 size_t hrow_lds_bytes(int cls);
