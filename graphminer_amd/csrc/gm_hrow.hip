@@ -21,6 +21,10 @@
 // Every task edge streams the partner list (pass X); pass Y does not exist here (the longer row hosts, gm_mine.h sym_hosts).
 #include "gm_flat.h"
 
+#ifndef GM_HROW_LB_EXTRA
+#define GM_HROW_LB_EXTRA 1
+#endif
+
 namespace gm {
 
 constexpr int kHrowOvfCap = 128;
@@ -139,7 +143,8 @@ template <bool K24, class LdsT>
 __device__ __forceinline__ void hrow_build(LdsT &B, HrowView &hv, const int *__restrict__ row, const int n, const int lbmax, const int nv,
                                            const int flags, const int tid, const int nthreads) {
   const int K = max(bitlen(nv - 1), 1);
-  const int LB = max(min(min(lbmax, K - 4), max(K - kHrowRemBits, bitlen((n - 1) / 3))), 0);  // (K - LB >= 4: see imask)
+  // 2^LB ~ 2n/3 .. 4n/3 buckets where the table has room (the LDS is allocated for the longest row of the class anyway), n/3 at the top
+  const int LB = max(min(min(lbmax, K - 4), max(K - kHrowRemBits, bitlen((n - 1) / 3) + GM_HROW_LB_EXTRA)), 0);  // (K - LB >= 4: see imask)
   hv.sh = K - LB;
   hv.imask = ((1u << LB) - 1u) << 4;
   hv.kmask = (K >= 32) ? 0xffffffffu : ((1u << K) - 1u);
