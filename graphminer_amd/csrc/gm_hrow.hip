@@ -482,7 +482,7 @@ void hrow_kernel(const MineParams p) {
 // Both the row and every partner list are SORTED: the row is cut into PIECES of <= kGiantPiece consecutive entries, each piece is
 // a hashed set like a class-2 row, and the keys of a partner list that can be in piece p -- those up to the piece's last id --
 // are one contiguous segment.  A chunk is <= kGiantEdges task edges of the row; their per-edge match counts (diamond needs
-// C(n,2) of the TOTAL) stay in LDS while the workgroup walks the pieces, and where the pieces cut each list is found once per
+// C(n,2) of the TOTAL) sit beside the boundaries in the workgroup's scratch slot while it walks the pieces; where the pieces cut each list is found once per
 // chunk (giant_bounds).
 // (First built with LDS bitmaps over id ranges of 2^20 ids, one ds_read_b32 per key: 14 ranges at nv = 2^24 cut the lists
 // into segments of ~160 keys, the flattening of which cost more than the cheaper test won -- 84 ms against 130 for the SPLIT
@@ -503,7 +503,6 @@ constexpr int kGiantGroup = 8;   // boundaries found together (independent bisec
 struct alignas(16) GiantLds {
   unsigned short table[(1 << kGiantLb) * 8];
   HrowWave w[kGiantWaves];
-  unsigned ecnt[kGiantEdges];  // per task edge: matches so far
   int ovf[kHrowOvfCap];
   int n_ovf;
   int next_batch;
@@ -550,6 +549,7 @@ __device__ __forceinline__ void giant_chunk(const MineParams &p, GiantLds &B, co
   const int *__restrict__ row = col + ru;
   const int n_pieces = (n_row + kGiantPiece - 1) / kGiantPiece;
   int *__restrict__ bnd = reinterpret_cast<int *>(p.scratch) + (size_t)blockIdx.x * p.scratch_words;
+  unsigned *__restrict__ ecnt = reinterpret_cast<unsigned *>(bnd) + (size_t)n_pieces * kGiantEdges;  // per task edge: matches so far (behind the boundaries)
   HrowWave &L = B.w[wave];
   for (int eb = r.e_begin; eb < r.e_end; eb += kGiantEdges) {  // (the host cuts the rows into chunks of kGiantEdges task edges)
     const int cnt = min(kGiantEdges, r.e_end - eb);
@@ -564,7 +564,7 @@ __device__ __forceinline__ void giant_chunk(const MineParams &p, GiantLds &B, co
         if (PAT == PAT_MOTIF3) len = lower_bound(col + d.x, d.y, max(u, v));  // only the keys below max(u, v) can count
       }
       if (PAT == PAT_MOTIF3 && i < cnt) acc.c2 += (unsigned long long)(e - ru);  // position of v in the row, ALL directed edges
-      B.ecnt[i] = 0u;
+      if (PAT != PAT_MOTIF3 && i < cnt) ecnt[i] = 0u;
       if (i0 < cnt) giant_bounds(col + d.x, len, row, n_row, n_pieces, bnd, i);  // (wave-uniform condition)
     }
     for (int pc = 0; pc < n_pieces; ++pc) {
@@ -600,7 +600,8 @@ __device__ __forceinline__ void giant_chunk(const MineParams &p, GiantLds &B, co
             acc.c1 += (unsigned long long)s_low;
           }
         } else if (valid) {
-          B.ecnt[le] += L.cnt[lane] + n_long;
+          const unsigned c = L.cnt[lane] + n_long;
+          if (c) ecnt[le] += c;  // (one lane per edge and piece; pieces are separated by workgroup barriers)
         }
         wave_sync();
       }
@@ -608,7 +609,7 @@ __device__ __forceinline__ void giant_chunk(const MineParams &p, GiantLds &B, co
     __syncthreads();
     if (PAT != PAT_MOTIF3) {
       for (int i = tid; i < cnt; i += nthreads) {
-        const unsigned long long tri = B.ecnt[i];
+        const unsigned long long tri = ecnt[i];
         if (PAT == PAT_DIAMOND) {
           acc.c0 += tri * (tri - 1ull) / 2ull;
         } else {  // PAT_MOTIF4E
@@ -662,7 +663,7 @@ void giant_kernel(const MineParams p) {
 
 // scratch words per workgroup: one boundary per piece and task edge of a chunk
 int giant_per_cu() { return kGiantPerCu; }
-unsigned long long giant_scratch_words(int max_deg) { return (unsigned long long)kGiantEdges * (unsigned long long)(max_deg / kGiantPiece + 1); }
+unsigned long long giant_scratch_words(int max_deg) { return (unsigned long long)kGiantEdges * (unsigned long long)(max_deg / kGiantPiece + 2); }  // (+1: the match counts)
 
 hipError_t launch_giant(Pattern pat, const MineParams &p, int grid_blocks, hipStream_t stream) {
   static_assert(sizeof(GiantLds) <= 163840, "the giant-row kernel must fit the 160 KB of one CU");

@@ -334,7 +334,7 @@ hipError_t launch_hrow(Pattern pat, int cls, const MineParams &p, int grid_block
 size_t hrow_lds_bytes(int cls);
 // giant rows (> kStageCapBig entries): pieces of kStageCapBig entries as hashed sets, chunks of kGiantEdges task edges (gm_hrow.hip)
 #ifndef GM_GIANT_EDGES
-#define GM_GIANT_EDGES 2048
+#define GM_GIANT_EDGES 8192
 #endif
 constexpr int kGiantEdges = GM_GIANT_EDGES;
 hipError_t launch_giant(Pattern pat, const MineParams &p, int grid_blocks, hipStream_t stream);
