@@ -564,7 +564,15 @@ def config1_record(a):
             dag.free()
     except Exception as e:
         rec["gpu_count"] = f"error: {e}"
-    rec["count_matches_cpu"] = all(rec.get(k, 1166) == 1166 for k in ("reference_count", "port_count", "gpu_count"))
+    # a CPU count must actually have been produced in THIS run (the binaries under oracle/_ref and oracle/bin are built by
+    # __graft_entry__.build(), not tracked): a missing one is never counted as a match
+    cpu = {k: rec[k] for k in ("reference_count", "port_count") if rec.get(k) is not None}
+    if cpu:
+        rec["count_matches_cpu"] = bool(all(c == 1166 for c in cpu.values()) and rec.get("gpu_count") == 1166)
+        rec["cpu_count_source"] = "this run: " + " + ".join(sorted(cpu))
+    else:
+        rec["count_matches_cpu"] = None
+        rec["cpu_count_source"] = "no CPU binary produced a count in this run (oracle/_ref and oracle/bin not built)"
     return rec
 
 

@@ -27,7 +27,7 @@ struct Cli {
   std::string graph;   // <graph> prefix
   std::string second;  // <pattern> (sgl) or <k> (clique, motif)
   int n_gpu = 1;       // [num_gpu(1)]
-  int chunk = 1024;    // [chunk_size(1024)]
+  int chunk = 0;       // [chunk_size(1024)]: honoured when given; omitted = 0 = the library default (<= 1024 task edges, adapted to the rank count)
   int adj_sorted = 1;  // [adj_sorted(1)] (tc only)
 };
 

@@ -1,0 +1,567 @@
+// gm_graph.hip -- the device graph handle behind include/graphminer_amd.h: upload / adopt (GraphGPU::init, include/graph_gpu.h:69-122),
+// Graph::orientation and Graph::sort_neighbors on the GPU (src/common/graph.cc:233-279,138-146), degree renumbering, download.
+#include "gm_host.h"
+#include "gm_scan.h"
+#include "gm_setops.h"
+using namespace gm;
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+thread_local std::string g_last_error;
+
+int hip_fail(hipError_t e, const char *what, const char *file, int line) {
+  char buf[512];
+  snprintf(buf, sizeof buf, "%s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+  g_last_error = buf;
+  return (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver) ? GM_ERR_NO_DEVICE
+                                                                                                  : GM_ERR_HIP;
+}
+extern "C" const char *gm_strerror(int s) {
+  switch (s) {
+    case GM_OK: return "ok";
+    case GM_ERR_INVALID: return "invalid argument";
+    case GM_ERR_NO_DEVICE: return "no HIP device (this library has no CPU fallback)";
+    case GM_ERR_HIP: return "HIP runtime error";
+    case GM_ERR_TOO_LARGE: return "graph exceeds the 32-bit task index of this build";
+    case GM_ERR_UNSUPPORTED: return "Not implemented";
+    case GM_ERR_IO: return "I/O error";
+    case GM_ERR_FORMAT: return "bad graph format";
+    default: return "unknown status";
+  }
+}
+extern "C" const char *gm_last_error(void) { return g_last_error.c_str(); }
+extern "C" int gm_version(void) { return 100; }
+
+extern "C" int gm_device_count(int *n) {
+  if (!n) return GM_ERR_INVALID;
+  *n = 0;
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) return hip_fail(e, "hipGetDeviceCount", __FILE__, __LINE__);
+  *n = c;
+  return c > 0 ? GM_OK : GM_ERR_NO_DEVICE;
+}
+
+extern "C" int gm_graph_setup_times(const gm_graph *g, gm_setup_times *out) {
+  if (!g || !out) return GM_ERR_INVALID;
+  *out = g->setup;
+  // cached derived handles report through their owner
+  for (const gm_graph *r : {g->dag_cache, g->relabel_cache[0], g->relabel_cache[1]})
+    if (r) {
+      out->orient_ms += r->setup.orient_ms;
+      out->table_ms += r->setup.table_ms;
+      out->bitmap_ms += r->setup.bitmap_ms;
+      out->other_ms += r->setup.other_ms;
+    }
+  return GM_OK;
+}
+extern "C" void gm_graph_free(gm_graph *g) {
+  if (!g) return;
+  if (g->dag_cache) gm_graph_free(g->dag_cache);
+  g->dag_cache = nullptr;
+  for (auto &r : g->relabel_cache) {
+    if (r) gm_graph_free(r);
+    r = nullptr;
+  }
+  (void)hipSetDevice(g->device);
+  free_tables(g);
+  for (auto &b : g->bitmap_sets) {
+    if (b.d_bitmaps) (void)hipFree(b.d_bitmaps);
+    if (b.d_row_slot) (void)hipFree(b.d_row_slot);
+  }
+  if (g->d_rp) (void)hipFree(g->d_rp);
+  if (g->own_col && g->d_col) (void)hipFree(g->d_col);
+  if (g->d_edesc) (void)hipFree(g->d_edesc);
+  if (g->d_trp) (void)hipFree(g->d_trp);
+  if (g->d_tdesc) (void)hipFree(g->d_tdesc);
+  for (auto &pl : g->wide_plans) {
+    if (pl.d_verts) (void)hipFree(pl.d_verts);
+    if (pl.d_base) (void)hipFree(pl.d_base);
+    if (pl.d_chunks) (void)hipFree(pl.d_chunks);
+    if (pl.d_cls_slots) (void)hipFree(pl.d_cls_slots);
+  }
+  if (g->d_wide_mat) (void)hipFree(g->d_wide_mat);
+  if (g->d_wide_sorted) (void)hipFree(g->d_wide_sorted);
+  if (g->d_wide_queue) (void)hipFree(g->d_wide_queue);
+  for (auto &st_ : g->aux_stream) if (st_) (void)hipStreamDestroy(st_);
+  for (auto &ev_ : g->aux_done) if (ev_) (void)hipEventDestroy(ev_);
+  if (g->d_counters) (void)hipFree(g->d_counters);
+  if (g->d_scratch) (void)hipFree(g->d_scratch);
+  if (g->d_idx0) (void)hipFree(g->d_idx0);
+  if (g->d_wblock_prefix) (void)hipFree(g->d_wblock_prefix);
+  if (g->d_house_prefix) (void)hipFree(g->d_house_prefix);
+  if (g->d_pent_touched) (void)hipFree(g->d_pent_touched);
+  if (g->d_house_t) (void)hipFree(g->d_house_t);
+  if (g->d_house_tlt) (void)hipFree(g->d_house_tlt);
+  if (g->d_house_tasks) (void)hipFree(g->d_house_tasks);
+  if (g->d_house_acc) (void)hipFree(g->d_house_acc);
+  if (g->d_house_touched) (void)hipFree(g->d_house_touched);
+  if (g->d_rect_tasks) (void)hipFree(g->d_rect_tasks);
+  if (g->d_rect_acc) (void)hipFree(g->d_rect_acc);
+  for (auto &pr : g->ev)
+    for (auto &e : pr)
+      if (e) (void)hipEventDestroy(e);
+  delete g;
+}
+
+int finish_handle(gm_graph *g) {
+  HIP_TRY(hipMalloc(&g->d_counters, 64));
+  HIP_TRY(hipMemset(g->d_counters, 0, 64));
+  for (auto &pr : g->ev)
+    for (auto &e : pr) HIP_TRY(hipEventCreate(&e));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, g->device));
+  g->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  return GM_OK;  // (max_deg: set by the caller from the device-side pass that produced the offsets)
+}
+
+// host copy of the 32-bit offsets, fetched from the device on first use
+int host_rp(gm_graph *g, const std::vector<int> **out) {
+  if (g->h_rp.size() != (size_t)g->nv + 1) {
+    g->h_rp.resize((size_t)g->nv + 1);
+    HIP_TRY(hipSetDevice(g->device));
+    HIP_TRY(hipMemcpy(g->h_rp.data(), g->d_rp, sizeof(int) * ((size_t)g->nv + 1), hipMemcpyDeviceToHost));
+  }
+  if (out) *out = &g->h_rp;
+  return GM_OK;
+}
+// int64 offsets of the ABI -> the internal int32 copy, validated on the device: err bit 0 = not an offset array (first != 0,
+// last != ne, or decreasing), bit 1 = a row of 2^24 entries or more; info[1] = longest row
+__global__ __launch_bounds__(256) void convert_offsets_kernel(const long long *__restrict__ rp64, int nv, long long ne, int *__restrict__ rp32,
+                                                              int *__restrict__ info) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  int err = 0, md = 0;
+  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v <= nv; v += stride) {
+    const long long x = rp64[v];
+    rp32[v] = (int)x;
+    if (v == 0 && x != 0) err |= 1;
+    if (v == nv && x != ne) err |= 1;
+    if (v > 0) {
+      const long long d = x - rp64[v - 1];
+      if (d < 0) err |= 1;
+      else if (d >= (1 << 24)) err |= 2;  // per-row limit of the flattened scan
+      else md = max(md, (int)d);
+    }
+  }
+  md = gm::wave_max_nonneg(md);
+  err = gm::wave_max_nonneg(err & 1) | (gm::wave_max_nonneg((err >> 1) & 1) << 1);
+  if ((threadIdx.x & 63) == 0) {
+    if (md) atomicMax(&info[1], md);
+    if (err & 3) atomicOr(&info[0], err & 3);
+  }
+}
+
+// d_rp64: DEVICE array of nv + 1 int64 offsets. Allocates and fills g->d_rp, sets g->max_deg.
+static int adopt_offsets(gm_graph *g, const int64_t *d_rp64) {
+  HIP_TRY(hipMalloc(&g->d_rp, sizeof(int) * ((size_t)g->nv + 1)));
+  DevBuf<int> info;
+  HIP_TRY(info.alloc(2));
+  HIP_TRY(hipMemset(info.p, 0, 8));
+  const long long blocks = std::min<long long>(((long long)g->nv + 256) / 256, 4096);
+  hipLaunchKernelGGL(convert_offsets_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, (const long long *)d_rp64, g->nv, g->ne, g->d_rp, info.p);
+  HIP_TRY(hipGetLastError());  // (a failed launch would leave info == 0 and an uninitialised d_rp behind a passing validation)
+  int h[2] = {0, 0};
+  HIP_TRY(hipMemcpy(h, info.p, 8, hipMemcpyDeviceToHost));
+  if (h[0] & 1) return GM_ERR_FORMAT;
+  if (h[0] & 2) return GM_ERR_TOO_LARGE;
+  g->max_deg = h[1];
+  return GM_OK;
+}
+
+static int check_sizes(long long nv, long long ne) {
+  if (nv < 0 || ne < 0) return GM_ERR_INVALID;
+  if (nv >= 0x7ffffffeLL || ne >= 0x7fffffffLL) return GM_ERR_TOO_LARGE;
+  return GM_OK;
+}
+
+int convert_offsets(const int64_t *rp64, int nv, long long ne, std::vector<int> &out) {
+  out.resize((size_t)nv + 1);
+  if (rp64[0] != 0 || rp64[nv] != ne) return GM_ERR_FORMAT;
+  for (int v = 0; v <= nv; ++v) {
+    if (v > 0 && rp64[v] < rp64[v - 1]) return GM_ERR_FORMAT;
+    if (v > 0 && rp64[v] - rp64[v - 1] >= (1 << 24)) return GM_ERR_TOO_LARGE;  // per-row limit of the flattened scan
+    out[v] = (int)rp64[v];
+  }
+  return GM_OK;
+}
+
+extern "C" int gm_graph_upload(const gm_csr *h, int device, gm_graph **out) {
+  if (!h || !out || !h->row_ptr || (h->ne > 0 && !h->col_idx)) return GM_ERR_INVALID;
+  *out = nullptr;
+  int rc = check_sizes(h->nv, h->ne);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(device));
+  gm_graph *g = new gm_graph();
+  g->device = device;
+  g->nv = h->nv;
+  g->ne = h->ne;
+  auto fail = [&](int code) { gm_graph_free(g); return code; };
+  {  // the int64 offsets go up as they are and are narrowed / validated on the device (adopt_offsets)
+    DevBuf<int64_t> rp64;
+    hipError_t e;
+    if ((e = rp64.alloc((size_t)g->nv + 1)) != hipSuccess) return fail(hip_fail(e, "hipMalloc(rp64)", __FILE__, __LINE__));
+    if ((e = hipMemcpy(rp64.p, h->row_ptr, sizeof(int64_t) * ((size_t)g->nv + 1), hipMemcpyHostToDevice)) != hipSuccess) return fail(hip_fail(e, "hipMemcpy(rp)", __FILE__, __LINE__));
+    rc = adopt_offsets(g, rp64.p);
+    if (rc) return fail(rc);
+  }
+  hipError_t e;
+  if ((e = hipMalloc(&g->d_col, sizeof(int) * (size_t)std::max<long long>(g->ne, 1))) != hipSuccess) return fail(hip_fail(e, "hipMalloc(col)", __FILE__, __LINE__));
+  if (g->ne > 0 && (e = hipMemcpy(g->d_col, h->col_idx, sizeof(int) * (size_t)g->ne, hipMemcpyHostToDevice)) != hipSuccess) return fail(hip_fail(e, "hipMemcpy(col)", __FILE__, __LINE__));
+  rc = finish_handle(g);
+  if (rc) return fail(rc);
+  *out = g;
+  return GM_OK;
+}
+
+extern "C" int gm_graph_from_device(int32_t nv, int64_t ne, const int64_t *d_row_ptr, const int32_t *d_col_idx, int device,
+                                    gm_graph **out) {
+  if (!out || !d_row_ptr || (ne > 0 && !d_col_idx)) return GM_ERR_INVALID;
+  *out = nullptr;
+  int rc = check_sizes(nv, ne);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(device));
+  gm_graph *g = new gm_graph();
+  g->device = device;
+  g->nv = nv;
+  g->ne = ne;
+  g->own_col = false;
+  g->d_col = const_cast<int *>(d_col_idx);
+  auto fail = [&](int code) { gm_graph_free(g); return code; };
+  rc = adopt_offsets(g, d_row_ptr);
+  if (rc) return fail(rc);
+  rc = finish_handle(g);
+  if (rc) return fail(rc);
+  *out = g;
+  return GM_OK;
+}
+
+// Graph::sort_neighbors (src/common/graph.cc:138-146: std::sort per row under OpenMP) on the GPU: one segmented radix sort
+// of col_idx with the rows as segments. In place: a borrowed col_idx array (gm_graph_from_device) is overwritten too.
+extern "C" int gm_graph_sort_neighbors(gm_graph *g) {
+  if (!g) return GM_ERR_INVALID;
+  if (g->ne == 0) return GM_OK;
+  // before any solver ran: every cached structure describes the rows as they are now (tables, descriptors, task lists, derived
+  // handles, the per-pattern tables of the SgL / 4-motif paths, hub bitmaps, the sum of C(d,2))
+  if (!g->tables.empty() || g->d_edesc || g->d_trp || g->d_tdesc || g->dag_cache || g->relabel_cache[0] || g->relabel_cache[1] || g->d_idx0 ||
+      g->d_wblock_prefix || g->d_rect_tasks || g->d_house_t || g->d_house_tlt || g->d_house_tasks || g->d_house_prefix || !g->bitmap_sets.empty() ||
+      g->wide_valid || g->sum_c2_valid)
+    return GM_ERR_INVALID;
+  HIP_TRY(hipDeviceSynchronize());  // a caller stream may still be reading a borrowed col_idx array: the sort runs on the null stream
+  HIP_TRY(hipSetDevice(g->device));
+  DevBuf<int> sorted;
+  HIP_TRY(sorted.alloc((size_t)g->ne));
+  ScanTemp tmp;
+  size_t bytes = 0;
+  int bits = 1;
+  while (bits < 31 && (1ll << bits) < (long long)g->nv) ++bits;
+  HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, bytes, g->d_col, sorted.p, (int)g->ne, g->nv, g->d_rp, g->d_rp + 1, 0, bits));
+  HIP_TRY(tmp.reserve(bytes));
+  HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(tmp.buf.p, bytes, g->d_col, sorted.p, (int)g->ne, g->nv, g->d_rp, g->d_rp + 1, 0, bits));
+  HIP_TRY(hipMemcpy(g->d_col, sorted.p, sizeof(int) * (size_t)g->ne, hipMemcpyDeviceToDevice));
+  HIP_TRY(hipDeviceSynchronize());
+  return GM_OK;
+}
+
+extern "C" int gm_graph_meta(const gm_graph *g, gm_csr *m) {
+  if (!g || !m) return GM_ERR_INVALID;
+  m->nv = g->nv;
+  m->ne = g->ne;
+  m->max_deg = g->max_deg;
+  m->row_ptr = nullptr;
+  m->col_idx = nullptr;
+  return GM_OK;
+}
+
+extern "C" int gm_graph_download(const gm_graph *g, int64_t *row_ptr, int32_t *col_idx) {
+  if (!g) return GM_ERR_INVALID;
+  if (row_ptr) {
+    const std::vector<int> *rp = nullptr;
+    int rc = host_rp(const_cast<gm_graph *>(g), &rp);
+    if (rc) return rc;
+    for (int v = 0; v <= g->nv; ++v) row_ptr[v] = (*rp)[(size_t)v];
+  }
+  if (col_idx && g->ne > 0) {
+    HIP_TRY(hipSetDevice(g->device));
+    HIP_TRY(hipMemcpy(col_idx, g->d_col, sizeof(int) * (size_t)g->ne, hipMemcpyDeviceToHost));
+  }
+  return GM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// orientation on the GPU (Graph::orientation, src/common/graph.cc:233-279)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool dag_keep(int ds, int s, int dd, int d) { return dd > ds || (dd == ds && d > s); }
+
+// Orientation kernels: count (pass 0) or compact (pass 1) the kept neighbours, order preserved (ballot + popcount
+// ranks). Short rows (<= kOrientShort entries) take 8 lanes each, 8 rows per wave. Longer rows are cut into
+// SEGMENTS of kOrientSeg entries (table built on the host from the row offsets) so that a 100k-entry hub row is
+// spread over ~100 waves instead of serialising one.
+constexpr int kOrientShort = 64;
+constexpr int kOrientSeg = 1024;
+
+struct OrientSeg {
+  int row, begin, end, out;  // CSR entry range [begin,end) of `row`; out = output offset of the segment (pass 1)
+};
+
+__global__ __launch_bounds__(256) void orient_short_kernel(int nv, const int *__restrict__ rp, const int *__restrict__ col,
+                                                           int *__restrict__ new_deg, const int *__restrict__ new_rp,
+                                                           int *__restrict__ new_col, int pass) {
+  constexpr int G = 8, RPW = 64 / G;
+  const int lane = threadIdx.x & 63;
+  const int grp = lane / G, gl = lane % G;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (int s0 = wave * RPW; s0 < nv; s0 += nwaves * RPW) {
+    const int s = s0 + grp;
+    int b = 0, ds = 0;
+    if (s < nv) { b = rp[s]; ds = rp[s + 1] - b; }
+    const int full = ds;
+    if (ds > kOrientShort) ds = 0;  // long rows belong to the segment kernel
+    const int maxds = wave_max_nonneg(ds);
+    int n = 0;
+    const int ob = (pass && ds > 0) ? new_rp[s] : 0;
+    for (int base = 0; base < maxds; base += G) {
+      const int i = base + gl;
+      bool keep = false;
+      int d = 0;
+      if (i < ds) {
+        d = col[b + i];
+        keep = dag_keep(full, s, rp[d + 1] - rp[d], d);
+      }
+      const unsigned long long m = (__ballot(keep) >> (grp * G)) & 0xffull;
+      if (pass && keep) new_col[ob + n + __popcll(m & ((1ull << gl) - 1ull))] = d;
+      n += __popcll(m);
+    }
+    if (!pass && gl == 0 && s < nv && full <= kOrientShort) new_deg[s] = n;
+  }
+}
+
+// one wave per segment; pass 0 adds the segment's count to its row's new degree (and keeps it per segment for the offsets)
+__global__ __launch_bounds__(256) void orient_seg_kernel(int nseg, const OrientSeg *__restrict__ segs, const int *__restrict__ rp,
+                                                         const int *__restrict__ col, int *__restrict__ seg_count, int *__restrict__ new_deg,
+                                                         int *__restrict__ new_col, int pass) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (int sg = wave; sg < nseg; sg += nwaves) {
+    const OrientSeg q = segs[sg];
+    const int ds = rp[q.row + 1] - rp[q.row];
+    int n = 0;
+    for (int base = q.begin; base < q.end; base += 64) {
+      const int i = base + lane;
+      bool keep = false;
+      int d = 0;
+      if (i < q.end) {
+        d = col[i];
+        keep = dag_keep(ds, q.row, rp[d + 1] - rp[d], d);
+      }
+      const unsigned long long m = __ballot(keep);
+      if (pass && keep) new_col[q.out + n + rank_below(m)] = d;
+      n += __popcll(m);
+    }
+    if (!pass && lane == 0) {
+      seg_count[sg] = n;
+      if (n) atomicAdd(&new_deg[q.row], n);
+    }
+  }
+}
+
+// segment table of the long rows, built on the device: seg_first[v] = exclusive scan of ceil(d/kOrientSeg) over the long rows
+__global__ __launch_bounds__(256) void orient_segcount_kernel(int nv, const int *__restrict__ rp, int *__restrict__ nseg_of) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v > nv) return;
+  int n = 0;
+  if (v < nv) {
+    const int d = rp[v + 1] - rp[v];
+    n = d > kOrientShort ? (d + kOrientSeg - 1) / kOrientSeg : 0;
+  }
+  nseg_of[v] = n;  // (nseg_of[nv] = 0: the scan's last element is the total)
+}
+__global__ __launch_bounds__(256) void orient_segfill_kernel(int nv, const int *__restrict__ rp, const int *__restrict__ seg_first,
+                                                             OrientSeg *__restrict__ segs) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nv) return;
+  const int b = rp[v], e = rp[v + 1];
+  if (e - b <= kOrientShort) return;
+  int k = seg_first[v];
+  for (int s0 = b; s0 < e; s0 += kOrientSeg) segs[k++] = {v, s0, min(s0 + kOrientSeg, e), 0};
+}
+// output offset of every segment: the row's new offset + the kept entries of the row's earlier segments (one thread per long row)
+__global__ __launch_bounds__(256) void orient_segout_kernel(int nv, const int *__restrict__ rp, const int *__restrict__ seg_first,
+                                                            const int *__restrict__ seg_count, const int *__restrict__ new_rp,
+                                                            OrientSeg *__restrict__ segs) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nv) return;
+  if (rp[v + 1] - rp[v] <= kOrientShort) return;
+  int run = new_rp[v];
+  for (int k = seg_first[v]; k < seg_first[v + 1]; ++k) {
+    segs[k].out = run;
+    run += seg_count[k];
+  }
+}
+__global__ __launch_bounds__(256) void max_degree_kernel(int nv, const int *__restrict__ rp, int *__restrict__ out) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  int md = 0;
+  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += stride) md = max(md, rp[v + 1] - rp[v]);
+  md = gm::wave_max_nonneg(md);
+  if ((threadIdx.x & 63) == 0 && md) atomicMax(out, md);
+}
+
+extern "C" int gm_graph_orient(const gm_graph *sym, gm_graph **out) {
+  if (!sym || !out) return GM_ERR_INVALID;
+  *out = nullptr;
+  HIP_TRY(hipSetDevice(sym->device));
+  SetupTimer timer;
+  const int nv = sym->nv;
+  const unsigned vb = (unsigned)((nv + 256) / 256);  // blocks covering v = 0 .. nv
+  ScanTemp tmp;
+  // segment table of the long rows (device): counts -> exclusive scan -> fill
+  DevBuf<int> nseg_of, seg_first, deg, segcnt;
+  DevBuf<OrientSeg> segs;
+  HIP_TRY(nseg_of.alloc((size_t)nv + 1));
+  HIP_TRY(seg_first.alloc((size_t)nv + 1));
+  hipLaunchKernelGGL(orient_segcount_kernel, dim3(vb), dim3(256), 0, 0, nv, sym->d_rp, nseg_of.p);
+  HIP_TRY(dev_exclusive_sum(tmp, nseg_of.p, seg_first.p, (size_t)nv + 1));
+  int nseg = 0;
+  HIP_TRY(hipMemcpy(&nseg, seg_first.p + nv, sizeof(int), hipMemcpyDeviceToHost));
+  HIP_TRY(segs.alloc((size_t)nseg));
+  HIP_TRY(segcnt.alloc((size_t)nseg));
+  if (nseg) hipLaunchKernelGGL(orient_segfill_kernel, dim3(vb), dim3(256), 0, 0, nv, sym->d_rp, seg_first.p, segs.p);
+  // pass 0: new degrees (short rows write, segments of long rows add)
+  HIP_TRY(deg.alloc((size_t)nv + 1));
+  HIP_TRY(hipMemsetAsync(deg.p, 0, sizeof(int) * ((size_t)nv + 1), 0));
+  const int bs = std::max(1, std::min((nv + 31) / 32, sym->cu_count * 8));
+  const int bl = std::max(1, std::min((nseg + 3) / 4, sym->cu_count * 8));
+  hipLaunchKernelGGL(orient_short_kernel, dim3(bs), dim3(256), 0, 0, nv, sym->d_rp, sym->d_col, deg.p, (const int *)nullptr, (int *)nullptr, 0);
+  if (nseg)
+    hipLaunchKernelGGL(orient_seg_kernel, dim3(bl), dim3(256), 0, 0, nseg, segs.p, sym->d_rp, sym->d_col, segcnt.p, deg.p, (int *)nullptr, 0);
+  // new offsets = exclusive scan of the new degrees (parallel_prefix_sum, include/scan.h:5-35)
+  gm_graph *g = new gm_graph();
+  g->device = sym->device;
+  g->nv = nv;
+  auto fail = [&](int code) { gm_graph_free(g); return code; };
+  hipError_t e;
+  if ((e = hipMalloc(&g->d_rp, sizeof(int) * ((size_t)nv + 1))) != hipSuccess) return fail(hip_fail(e, "hipMalloc", __FILE__, __LINE__));
+  if ((e = dev_exclusive_sum(tmp, deg.p, g->d_rp, (size_t)nv + 1)) != hipSuccess) return fail(hip_fail(e, "ExclusiveSum", __FILE__, __LINE__));
+  DevBuf<int> md;
+  if ((e = md.alloc(1)) != hipSuccess) return fail(hip_fail(e, "hipMalloc", __FILE__, __LINE__));
+  (void)hipMemsetAsync(md.p, 0, sizeof(int), 0);
+  hipLaunchKernelGGL(max_degree_kernel, dim3((unsigned)std::min<long long>(((long long)nv + 255) / 256, 2048)), dim3(256), 0, 0, nv, g->d_rp, md.p);
+  int ne_new = 0, max_deg = 0;
+  if ((e = hipMemcpy(&ne_new, g->d_rp + nv, sizeof(int), hipMemcpyDeviceToHost)) != hipSuccess) return fail(hip_fail(e, "hipMemcpy", __FILE__, __LINE__));
+  if ((e = hipMemcpy(&max_deg, md.p, sizeof(int), hipMemcpyDeviceToHost)) != hipSuccess) return fail(hip_fail(e, "hipMemcpy", __FILE__, __LINE__));
+  g->ne = ne_new;
+  g->max_deg = max_deg;
+  if ((e = hipMalloc(&g->d_col, sizeof(int) * (size_t)std::max(ne_new, 1))) != hipSuccess) return fail(hip_fail(e, "hipMalloc", __FILE__, __LINE__));
+  // pass 1: compact
+  if (nseg) hipLaunchKernelGGL(orient_segout_kernel, dim3(vb), dim3(256), 0, 0, nv, sym->d_rp, seg_first.p, segcnt.p, g->d_rp, segs.p);
+  hipLaunchKernelGGL(orient_short_kernel, dim3(bs), dim3(256), 0, 0, nv, sym->d_rp, sym->d_col, (int *)nullptr, g->d_rp, g->d_col, 1);
+  if (nseg)
+    hipLaunchKernelGGL(orient_seg_kernel, dim3(bl), dim3(256), 0, 0, nseg, segs.p, sym->d_rp, sym->d_col, (int *)nullptr, (int *)nullptr, g->d_col, 1);
+  if ((e = hipGetLastError()) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess) return fail(hip_fail(e, "orient kernels", __FILE__, __LINE__));
+  int rc = finish_handle(g);
+  if (rc) { gm_graph_free(g); return rc; }
+  g->setup.orient_ms = timer.ms();
+  *out = g;
+  return GM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Degree renumbering. A pattern count does not depend on the vertex numbering, but the work of the SgL kernels does: they
+// anchor a match at its largest vertex id and walk smaller ids. With ids ascending in degree the 2-path walks of rectangle and the
+// (v0, v1 < v0, v3) tasks of house go through low-degree vertices (R-MAT-16: 522 M -> 128 M 2-paths, 898 M -> 163 M tasks); with
+// ids descending in degree the wedges (v0; v2 < v1 < v0) of pentagon avoid the hubs (99 M -> 33 M). The copy is built once
+// per handle: counting sort of the vertices by degree on the host, one 64-bit key (new row, new neighbour) per CSR entry and
+// a device radix sort (hipCUB) -- the rows come out ascending.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void relabel_keys_kernel(int nv, long long ne, const int *__restrict__ rp, const int *__restrict__ col,
+                                                           const int *__restrict__ newid, unsigned long long *__restrict__ keys) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= ne) return;
+  int lo = 0, hi = nv - 1;  // row of entry e
+  while (lo < hi) {
+    const int mid = (int)(((long long)lo + hi + 1) >> 1);
+    if (rp[mid] <= e) lo = mid; else hi = mid - 1;
+  }
+  keys[e] = ((unsigned long long)(unsigned)newid[lo] << 32) | (unsigned long long)(unsigned)newid[col[e]];
+}
+
+__global__ __launch_bounds__(256) void relabel_cols_kernel(long long ne, const unsigned long long *__restrict__ keys, int *__restrict__ col) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < ne) col[e] = (int)(unsigned)(keys[e] & 0xffffffffull);
+}
+
+int get_relabeled(gm_graph *g, int descending, gm_graph **out) {
+  {
+    std::lock_guard<std::mutex> lk(g->mu);
+    if (g->relabel_cache[descending]) { *out = g->relabel_cache[descending]; return GM_OK; }
+  }
+  HIP_TRY(hipSetDevice(g->device));
+  SetupTimer timer;
+  {
+    int rc = host_rp(g, nullptr);
+    if (rc) return rc;
+  }
+  const int nv = g->nv;
+  const long long ne = g->ne;
+  // counting sort by degree (ties: ascending id)
+  std::vector<int> newid((size_t)std::max(nv, 1));
+  {
+    std::vector<long long> bucket((size_t)g->max_deg + 2, 0);
+    for (int v = 0; v < nv; ++v) bucket[(size_t)(g->h_rp[v + 1] - g->h_rp[v]) + 1]++;
+    for (size_t d = 1; d < bucket.size(); ++d) bucket[d] += bucket[d - 1];
+    for (int v = 0; v < nv; ++v) {
+      const long long pos = bucket[(size_t)(g->h_rp[v + 1] - g->h_rp[v])]++;
+      newid[(size_t)v] = descending ? (int)((long long)nv - 1 - pos) : (int)pos;
+    }
+  }
+  gm_graph *r = new gm_graph();
+  r->device = g->device;
+  r->nv = nv;
+  r->ne = ne;
+  r->h_rp.assign((size_t)nv + 1, 0);
+  for (int v = 0; v < nv; ++v) r->h_rp[(size_t)newid[(size_t)v] + 1] = g->h_rp[v + 1] - g->h_rp[v];
+  for (int v = 0; v < nv; ++v) r->h_rp[(size_t)v + 1] += r->h_rp[(size_t)v];
+  int *d_newid = nullptr;
+  unsigned long long *d_keys = nullptr, *d_sorted = nullptr;
+  void *d_tmp = nullptr;
+  auto cleanup = [&]() {
+    if (d_newid) (void)hipFree(d_newid);
+    if (d_keys) (void)hipFree(d_keys);
+    if (d_sorted) (void)hipFree(d_sorted);
+    if (d_tmp) (void)hipFree(d_tmp);
+  };
+  auto fail = [&](hipError_t e, const char *what) { cleanup(); gm_graph_free(r); return hip_fail(e, what, __FILE__, __LINE__); };
+  hipError_t e;
+  const size_t n1 = (size_t)std::max<long long>(ne, 1);
+  if ((e = hipMalloc(&d_newid, sizeof(int) * (size_t)std::max(nv, 1))) != hipSuccess) return fail(e, "hipMalloc(newid)");
+  if ((e = hipMemcpy(d_newid, newid.data(), sizeof(int) * (size_t)nv, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(newid)");
+  if ((e = hipMalloc(&d_keys, sizeof(unsigned long long) * n1)) != hipSuccess) return fail(e, "hipMalloc(keys)");
+  if ((e = hipMalloc(&d_sorted, sizeof(unsigned long long) * n1)) != hipSuccess) return fail(e, "hipMalloc(sorted)");
+  if ((e = hipMalloc(&r->d_rp, sizeof(int) * ((size_t)nv + 1))) != hipSuccess) return fail(e, "hipMalloc(rp)");
+  if ((e = hipMalloc(&r->d_col, sizeof(int) * n1)) != hipSuccess) return fail(e, "hipMalloc(col)");
+  if ((e = hipMemcpy(r->d_rp, r->h_rp.data(), sizeof(int) * ((size_t)nv + 1), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(rp)");
+  if (ne > 0) {
+    const unsigned blocks = (unsigned)((ne + 255) / 256);
+    hipLaunchKernelGGL(relabel_keys_kernel, dim3(blocks), dim3(256), 0, 0, nv, ne, g->d_rp, g->d_col, d_newid, d_keys);
+    int bits = 1;
+    while (bits < 32 && (1ll << bits) < (long long)nv) ++bits;
+    size_t tmp_bytes = 0;
+    if ((e = hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, d_keys, d_sorted, (int)ne, 0, 32 + bits)) != hipSuccess) return fail(e, "SortKeys(size)");
+    if ((e = hipMalloc(&d_tmp, std::max<size_t>(tmp_bytes, 16))) != hipSuccess) return fail(e, "hipMalloc(sort temp)");
+    if ((e = hipcub::DeviceRadixSort::SortKeys(d_tmp, tmp_bytes, d_keys, d_sorted, (int)ne, 0, 32 + bits)) != hipSuccess) return fail(e, "SortKeys");
+    hipLaunchKernelGGL(relabel_cols_kernel, dim3(blocks), dim3(256), 0, 0, ne, d_sorted, r->d_col);
+    if ((e = hipDeviceSynchronize()) != hipSuccess) return fail(e, "relabel kernels");
+  }
+  cleanup();
+  int rc = finish_handle(r);
+  if (rc) { gm_graph_free(r); return rc; }
+  r->max_deg = g->max_deg;  // (a permutation of the same rows)
+  std::lock_guard<std::mutex> lk(g->mu);
+  g->relabel_cache[descending] = r;
+  g->setup.relabel_ms += timer.ms();
+  *out = r;
+  return GM_OK;
+}
+

@@ -1,0 +1,248 @@
+// gm_host.h -- host-side internals shared by the translation units behind the C ABI (include/graphminer_amd.h):
+//   gm_graph.hip   handle, upload / adopt, orientation, neighbour sort, degree renumbering      (GraphGPU::init, Graph::orientation)
+//   gm_tables.hip  task-chunk tables, edge descriptors, task lists, k-clique plans, partitions  (Graph::init_edgelist, Scheduler)
+//   gm_launch.hip  the solvers: launch prologue / epilogue, run_pattern, gm_tc / gm_sgl / gm_clique / gm_motif
+//   gm_tools.hip   set-op batch, R-MAT generator, PMC / issue-rate calibration kernels, self test
+// Host-side counterparts in the reference:
+//   GraphGPU::init / init_edgelist          include/graph_gpu.h:69-194
+//   launch sizing                            src/triangle/gpu_base.cu:36-45, src/clique/gpu_base.cu:28-50
+//   Scheduler::round_robin                   src/common/scheduler.cc:34-85
+//   Graph::orientation                       src/common/graph.cc:233-279
+// None of that code is reused: tasks are described by a compact chunk table (16 B per ~256 edges)
+// instead of per-GPU COO copies, and the multi-GPU split is index arithmetic on chunk ids.
+#pragma once
+#include "../../include/graphminer_amd.h"
+#include "gm_mine.h"
+#include "gm_setops.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <list>
+#include <mutex>
+#include <string>
+#include <vector>
+
+using namespace gm;  // (internal header: every unit that includes it lives behind the C ABI)
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+extern thread_local std::string g_last_error;
+int hip_fail(hipError_t e, const char *what, const char *file, int line);
+#define HIP_TRY(call)                                              \
+  do {                                                             \
+    hipError_t _e = (call);                                        \
+    if (_e != hipSuccess) return hip_fail(_e, #call, __FILE__, __LINE__); \
+  } while (0)
+
+template <class T>
+struct DevBuf {  // RAII device array
+  T *p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t count) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = count;
+    return hipMalloc(&p, sizeof(T) * std::max<size_t>(count, 1));
+  }
+  T *release() { T *q = p; p = nullptr; n = 0; return q; }
+};
+
+struct ScanTemp {  // temp storage of the hipCUB calls, grown on demand
+  DevBuf<char> buf;
+  hipError_t reserve(size_t bytes) { return bytes <= buf.n ? hipSuccess : buf.alloc(bytes); }
+};
+
+
+// (dev_exclusive_sum, the hipCUB scan over a ScanTemp: gm_scan.h -- only the units that include hipCUB pay for it)
+
+// estimated work (adjacency entries touched) above which a chunk is cut into parts
+// Rows longer than kBitmapMinDeg get a dense vertex-id bitmap, longest first, within kBitmapBudget bytes: SPLIT chunks
+// probe their own row's, pass Y probes the searched row's (one load instead of ~lg d dependent ones). A probe is a random
+// 64 B line, so it only beats a bisection whose upper levels sit in cache when the row is long. Measured (diamond ms on
+// R-MAT-20 / -22 / -24, 3-motif on R-MAT-24): min degree 1024: - / 117 / - / 1037;  2048: 25.8 / 94.8 / - / 1068;
+// 4096: 30.6 / 94.5 / 1539 / 1057;  8192: 30.8 / 89.6 / 1528 / 1073;  16384: 44.7 / 89.8 / 1528 / 1072;
+// 2048 within 256 MB (Infinity-Cache sized): 25.7 / 87.1 / 2275 / 1373;  no pass-Y bitmaps at all: - / 124 / - / 1473.
+#ifndef GM_BITMAP_MIN_DEG
+#define GM_BITMAP_MIN_DEG 2048
+#endif
+#ifndef GM_BITMAP_BUDGET_MB
+#define GM_BITMAP_BUDGET_MB 8192
+#endif
+constexpr int kBitmapMinDeg = GM_BITMAP_MIN_DEG;
+constexpr unsigned long long kBitmapBudget = (unsigned long long)GM_BITMAP_BUDGET_MB << 20;
+constexpr unsigned long long kPartCostCap = 8ull << 20;     // DAG patterns: staged chunks stay whole
+#ifndef GM_PART_CAP_SYM
+#define GM_PART_CAP_SYM (2ull << 20)
+#endif
+constexpr unsigned long long kPartCostCapSym = GM_PART_CAP_SYM;  // symmetric-graph patterns (measured on R-MAT-20/22/24: 1 M best for diamond, 2 M for 3-motif)
+constexpr int kDefaultChunk = 1024;  // task edges per chunk when the caller does not say
+
+// Which rows a chunk table covers. The k-clique table leaves the wide vertices to the two-phase path; the tables of the
+// symmetric-graph patterns come in three: the general one skips the rows of the big-LDS classes, each class table keeps only
+// its own window of row lengths.
+struct RowFilter {
+  int skip_clique_wide = 0;                    // > 0: leave out the vertices with clique_is_wide(d, this many matrix words)
+  int skip_lo = 0, skip_hi = 0;                // rows with skip_lo < d <= skip_hi are left out (0, 0 = none)
+  int only_lo = -1, only_hi = 0x7fffffff;      // rows with only_lo < d <= only_hi are kept
+  int tct = 0;                                 // 1: chunk costs from the task lists of gm_tct.hip (the tasks a chunk hosts, not its own entries)
+  __host__ __device__ bool skips(int d) const {
+    return (skip_clique_wide > 0 && clique_is_wide(d, skip_clique_wide)) || (d > skip_lo && d <= skip_hi) || !(d > only_lo && d <= only_hi);
+  }
+  bool operator==(const RowFilter &o) const {
+    return skip_clique_wide == o.skip_clique_wide && skip_lo == o.skip_lo && skip_hi == o.skip_hi && only_lo == o.only_lo && only_hi == o.only_hi && tct == o.tct;
+  }
+};
+
+struct ChunkTable {
+  int target;       // T: CSR entries per chunk
+  bool allow_split; // rows longer than the staging capacity may be cut across chunks
+  int bit_words;    // clique: LDS bit-matrix budget the chunks were built for (0 = unconstrained)
+  unsigned long long part_cap = 0;  // estimated work above which a chunk is cut into parts; 0 = chunks are never cut (nparts == 1 everywhere)
+  int stage_cap = 0;                // rows longer than this are SPLIT rows
+  RowFilter rf;                     // the rows the table covers
+  int bitmap_min_deg = 0;           // rows longer than this got dense bitmaps (allow_split tables)
+  std::vector<unsigned long long> cost;  // estimated work per chunk (after cutting)
+  ChunkRec *d = nullptr;
+  size_t n = 0;
+  int *d_slot = nullptr;                 // per chunk: hub bitmap slot or -1
+  int *d_row_slot = nullptr;             // per vertex: bitmap slot or -1
+  // dequeue orders of the round-robin policy: [0] chunks well above the mean cost first (heaviest first), the rest in vertex
+  // order (single rank); [1] all chunks by estimated cost, descending (rank r of n owns every n-th entry)
+  int *d_order[2] = {nullptr, nullptr};
+  std::vector<int> order[2];
+  bool own_bitmaps = true;               // false: d_bitmaps / d_row_slot belong to a BitmapSet of the graph (shared by its tables)
+  unsigned *d_bitmaps = nullptr;         // n_bitmaps x bitmap_words
+  size_t n_bitmaps = 0;
+  unsigned long long bitmap_words = 0;
+  unsigned long long max_bit_words = 0;  // largest nel*stride over chunks that exceed bit_words
+  std::vector<unsigned long long> edge_prefix;  // edges owned by chunks [0,i)
+  std::vector<int> first_vertex;                // u_begin of every chunk (ascending; SPLIT chunks repeat it)
+};
+
+struct WidePlan {
+  int rank = 0, world = 1, policy = 0;
+  std::vector<int> verts;  // this rank's wide vertices; slot = index here (heaviest first)
+  struct Round {
+    size_t chunk_begin = 0, chunk_end = 0;  // row-group chunks of the round (phase 1)
+    size_t cls_begin[4] = {0, 0, 0, 0};     // slots of the round per count class S / L / X, in d_cls_slots (phase 2)
+    unsigned long long words = 0;           // arena words of the round
+  };
+  std::vector<Round> rounds;
+  unsigned long long edges = 0;    // task edges of these vertices
+  size_t n_chunks = 0;
+  int *d_verts = nullptr;
+  unsigned long long *d_base = nullptr;  // slot -> word offset inside its round's arena
+  ChunkRec *d_chunks = nullptr;
+  int *d_cls_slots = nullptr;
+};
+
+// Dense vertex-id bitmaps of the hub rows: a property of the graph (which rows: longer than min_deg and not left to a
+// big-LDS class), shared by every chunk table that needs them -- tables differ per world size / tuning, the bitmaps do not
+// (round 1 rebuilt up to 8 GB of them per table: ADVICE r1).
+struct BitmapSet {
+  int min_deg = 0;
+  RowFilter rf;
+  unsigned *d_bitmaps = nullptr;
+  int *d_row_slot = nullptr;
+  size_t n = 0;
+  unsigned long long words = 0;
+};
+
+struct gm_graph {
+  int device = 0;
+  int nv = 0;
+  long long ne = 0;
+  int max_deg = 0;
+  int *d_rp = nullptr;   // int32 offsets, owned
+  int *d_col = nullptr;  // col_idx
+  bool own_col = true;
+  int2 *d_edesc = nullptr;  // per CSR entry: {rp[col[e]], degree(col[e])}, built on first use (ensure_edesc)
+  int *d_trp = nullptr;     // task lists of the shorter-list-streams triangle count (ensure_tasklists): row offsets (nv + 1)
+  int2 *d_tdesc = nullptr;  // ... and per task {rp[partner], d(partner)}
+  std::vector<int> h_rp;  // host copy of the offsets, fetched on first use (host_rp): download, k-clique tables, SgL renumbering
+  std::list<ChunkTable> tables;  // list: handed-out pointers stay valid
+  unsigned long long *d_counters = nullptr;  // [4] + queue word, 64 B
+  unsigned *d_scratch = nullptr;
+  size_t scratch_bytes = 0;
+  static constexpr int kEvRing = 64;  // HIP-event pairs of the most recent launches
+  hipEvent_t ev[kEvRing][2] = {};
+  unsigned long long ev_launches = 0;
+  int cu_count = 256;
+  gm_graph *dag_cache = nullptr;          // oriented copy, built on demand by gm_motif_formula
+  gm_graph *relabel_cache[2] = {nullptr, nullptr};  // copies renumbered by degree (ascending / descending), see get_relabeled
+  const gm_graph *ring_alias = nullptr;
+  const gm_graph *ring_extra[2] = {nullptr, nullptr};  // 4-motif: the handles that ran the other sub-launches of the most recent calls (gm_kernel_times adds them)
+  int *d_idx0 = nullptr;                  // rectangle: #neighbours below v, and the wedge-block prefix
+  unsigned long long *d_wblock_prefix = nullptr;
+  unsigned long long n_wblocks = 0;
+  int4 *d_rect_tasks = nullptr;          // rectangle by wedge accumulation: task list, counter maps
+  unsigned long long n_rect_tasks = 0;
+  unsigned *d_rect_acc = nullptr;
+  size_t rect_acc_bytes = 0;
+  unsigned *d_house_t = nullptr;         // house by wedge accumulation: per-entry tables, task list, 64-bit maps
+  unsigned *d_house_tlt = nullptr;
+  int4 *d_house_tasks = nullptr;
+  unsigned long long n_house_tasks = 0;
+  unsigned long long *d_house_acc = nullptr;
+  size_t house_acc_bytes = 0;
+  int *d_house_touched = nullptr;
+  int *d_pent_touched = nullptr;         // pentagon by wedge accumulation: touched-vertex lists (same shape as d_rect_acc)
+  size_t pent_touched_bytes = 0;
+  unsigned long long *d_house_prefix = nullptr;  // house: per-entry task-block prefix
+  unsigned long long n_house_blocks = 0;   // handle whose event ring holds this handle's most recent launch
+  unsigned long long sum_c2 = 0;          // sum_v C(d(v),2)
+  bool sum_c2_valid = false;
+  // k-clique: the wide DAG vertices (clique_is_wide), longest rows first, and the per-(rank, world, policy) plans of their two
+  // phases (row-group chunks of phase 1, count classes of phase 2, matrix offsets, arena rounds)
+  std::list<BitmapSet> bitmap_sets;
+  int *d_wide_sorted = nullptr;
+  size_t n_wide = 0;
+  bool wide_valid = false;
+  std::list<struct WidePlan> wide_plans;
+  unsigned *d_wide_mat = nullptr;      // matrix arena (largest round so far)
+  size_t wide_mat_bytes = 0;
+  unsigned *d_wide_queue = nullptr;    // dequeue words of the wide launches of one call (zeroed per call)
+  hipStream_t aux_stream[3] = {nullptr, nullptr, nullptr};  // class kernels that cannot fill the chip run beside the others (run_pattern)
+  hipEvent_t aux_done[3] = {nullptr, nullptr, nullptr};
+  gm_setup_times setup = {0, 0, 0, 0, 0};  // accumulated pre-processing time of this handle (gm_graph_setup_times)
+  std::mutex mu;
+};
+
+// wall-clock stopwatch for the setup accounting (host clock: the steps mix host work, copies and synchronised kernels)
+struct SetupTimer {
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
+// scope guard: the enclosed once-per-graph pattern setup (device work included) is charged to setup.other_ms
+struct OtherSetupScope {
+  gm_graph *g;
+  SetupTimer t;
+  explicit OtherSetupScope(gm_graph *g_) : g(g_) {}
+  ~OtherSetupScope() {
+    (void)hipDeviceSynchronize();
+    g->setup.other_ms += t.ms();
+  }
+};
+
+// ---- across translation units ---------------------------------------------------------------------------------------------
+int finish_handle(gm_graph *g);                                 // gm_graph.hip: counters, events, CU count of a new handle
+int host_rp(gm_graph *g, const std::vector<int> **out);          // gm_graph.hip: host copy of the offsets, fetched on first use
+int convert_offsets(const int64_t *rp64, int nv, long long ne, std::vector<int> &out);  // gm_graph.hip: host-side narrowing / validation
+int get_relabeled(gm_graph *g, int descending, gm_graph **out);  // gm_graph.hip: cached copy renumbered by degree
+void free_tables(gm_graph *g);                                   // gm_tables.hip
+int get_table(gm_graph *g, int target, bool allow_split, int bit_words, unsigned long long part_cap, int stage_cap, ChunkTable **out,
+              const RowFilter &rf = RowFilter(), int bitmap_min_deg = kBitmapMinDeg);
+int ensure_edesc(gm_graph *g);
+int ensure_tasklists(gm_graph *g);
+int clique_wide_min_words();
+int get_wide_plan(gm_graph *g, int rank, int world, int policy, WidePlan **out);
+int run_pattern(gm::Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uint64_t *h_out, int nout, gm_stats *st, int fin_mode = -1,
+                unsigned long long fin_base = 0);  // gm_launch.hip

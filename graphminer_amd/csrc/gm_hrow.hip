@@ -548,6 +548,7 @@ __device__ __forceinline__ void giant_chunk(const MineParams &p, GiantLds &B, co
   const int ru = rp[u], n_row = rp[u + 1] - ru;
   const int *__restrict__ row = col + ru;
   const int n_pieces = (n_row + kGiantPiece - 1) / kGiantPiece;
+  if (r.nparts != 1) __builtin_trap();  // (its table is built with part_cap 0: a chunk cut into parts would be counted nparts times)
   int *__restrict__ bnd = reinterpret_cast<int *>(p.scratch) + (size_t)blockIdx.x * p.scratch_words;
   unsigned *__restrict__ ecnt = reinterpret_cast<unsigned *>(bnd) + (size_t)n_pieces * kGiantEdges;  // per task edge: matches so far (behind the boundaries)
   HrowWave &L = B.w[wave];

@@ -1,0 +1,1141 @@
+// gm_launch.hip -- the solvers of the C ABI: launch prologue / epilogue, run_pattern (TC, diamond, 3-motif, k-clique and the per-edge sums
+// of 4-motif: tables, shares, class launches), the SgL map / flat / nested launches, gm_tc / gm_sgl / gm_clique / gm_motif*.
+// Reference launch logic: src/triangle/gpu_base.cu:36-45, src/sgl/gpu_base.cu:37-75, src/clique/gpu_base.cu:28-50, src/motif/gpu_base.cu:42-75.
+#include "gm_host.h"
+
+using namespace gm;
+
+// ------------------------------------------------------------------------------------------------
+// solvers
+// ------------------------------------------------------------------------------------------------
+enum FinMode : int { FIN_COPY = 0, FIN_MOTIF3 = 1, FIN_MOTIF3_FORMULA = 2, FIN_RAW4 = 3, FIN_HALF_SIGNED = 4 };
+
+__global__ void finalize_kernel(int mode, unsigned long long base, const unsigned long long *__restrict__ c,
+                                unsigned long long *__restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (mode == FIN_MOTIF3) {
+    out[0] = c[2] - c[0];  // wedges = sum_e idx(e) - sum_e |A' ^ B|   (automine_base.h:13)
+    out[1] = c[1];         // triangles                                  (automine_base.h:18)
+  } else if (mode == FIN_MOTIF3_FORMULA) {
+    out[0] = base - 3ull * c[0];  // wedges = sum_v C(d,2) - 3T  (src/motif/omp_formula.cc:39-40); base only on rank 0
+    out[1] = c[0];
+  } else if (mode == FIN_RAW4) {
+    out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+  } else if (mode == FIN_HALF_SIGNED) {
+    out[0] = (unsigned long long)((long long)c[0] >> 1);  // an even two's-complement sum (pent_acc_kernel): rank partials add up mod 2^64
+  } else {
+    out[0] = c[0];
+  }
+}
+
+// ---- common launch prologue / epilogue of every mining entry point -----------------------------------------------
+struct LaunchCtx {
+  gm_graph *g = nullptr;
+  gm_launch la;          // caller's launch descriptor, or the all-zero default
+  int world = 1, rank = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t *evp = nullptr;  // event pair of this launch (ring slot)
+};
+
+// validates the arguments, selects the device, zeroes the 64-byte counter block on the launch stream
+static int begin_launch(const gm_graph *cg, const gm_launch *la, const uint64_t *h_out, LaunchCtx &c) {
+  if (!cg) return GM_ERR_INVALID;
+  c.g = const_cast<gm_graph *>(cg);
+  memset(&c.la, 0, sizeof c.la);
+  if (la) c.la = *la;
+  c.world = c.la.world > 1 ? c.la.world : 1;
+  c.rank = c.la.rank;
+  if (c.rank < 0 || c.rank >= c.world) return GM_ERR_INVALID;
+  if (!h_out && !c.la.d_counts) return GM_ERR_INVALID;
+  HIP_TRY(hipSetDevice(c.g->device));
+  c.stream = (hipStream_t)c.la.stream;
+  HIP_TRY(hipMemsetAsync(c.g->d_counters, 0, 64, c.stream));
+  return GM_OK;
+}
+
+static int start_timer(LaunchCtx &c) {
+  c.g->ring_alias = nullptr;
+  c.g->ring_extra[0] = c.g->ring_extra[1] = nullptr;
+  c.evp = c.g->ev[c.g->ev_launches % gm_graph::kEvRing];
+  c.g->ev_launches++;
+  HIP_TRY(hipEventRecord(c.evp[0], c.stream));
+  return GM_OK;
+}
+
+// stops the timer, publishes the counters: to d_counts (device, asynchronous) and / or to h_out (synchronises)
+static int end_launch(LaunchCtx &c, int fin_mode, unsigned long long fin_base, uint64_t *h_out, int nout, gm_stats *st) {
+  HIP_TRY(hipEventRecord(c.evp[1], c.stream));
+  if (c.la.d_counts) {
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, c.stream, fin_mode, fin_base, c.g->d_counters,
+                       (unsigned long long *)c.la.d_counts);
+    HIP_TRY(hipGetLastError());
+    if (!h_out) return GM_OK;  // asynchronous: the caller owns the synchronisation
+  }
+  unsigned long long v[4];
+  HIP_TRY(hipMemcpyAsync(v, c.g->d_counters, sizeof v, hipMemcpyDeviceToHost, c.stream));
+  HIP_TRY(hipStreamSynchronize(c.stream));
+  if (st) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, c.evp[0], c.evp[1]));
+    st->kernel_ms = ms;
+  }
+  if (fin_mode == FIN_MOTIF3) {
+    if (nout > 0) h_out[0] = v[2] - v[0];
+    if (nout > 1) h_out[1] = v[1];
+  } else if (fin_mode == FIN_MOTIF3_FORMULA) {
+    if (nout > 0) h_out[0] = fin_base - 3ull * v[0];
+    if (nout > 1) h_out[1] = v[0];
+  } else if (fin_mode == FIN_RAW4) {
+    for (int i = 0; i < 4 && i < nout; ++i) h_out[i] = v[i];
+  } else if (fin_mode == FIN_HALF_SIGNED) {
+    h_out[0] = (uint64_t)((long long)v[0] >> 1);
+  } else {
+    h_out[0] = v[0];
+  }
+  return GM_OK;
+}
+
+static void fill_stats(gm_stats *st, uint64_t tasks, uint64_t chunks, int grid, int block) {
+  if (!st) return;
+  st->kernel_ms = 0.0;
+  st->tasks = tasks;
+  st->chunks = chunks;
+  st->grid = (uint32_t)grid;
+  st->block = (uint32_t)block;
+}
+
+int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uint64_t *h_out, int nout, gm_stats *st, int fin_mode,
+                unsigned long long fin_base) {
+  if (fin_mode < 0) fin_mode = (pat == PAT_MOTIF3) ? FIN_MOTIF3 : FIN_COPY;
+  LaunchCtx ctx;
+  int rc0 = begin_launch(cg, la, h_out, ctx);
+  if (rc0) return rc0;
+  gm_graph *g = ctx.g;
+  la = &ctx.la;
+  const int world = ctx.world, rank = ctx.rank;
+  hipStream_t stream = ctx.stream;
+
+  // tune[0] = chunk target override, tune[1] = grab, tune[2] = cost_x_step, tune[3] = cost_y_step,
+  // tune[4] = blocks per CU override, tune[5] = force "search in HBM" (no LDS staging) when 1
+  // default chunk size: as large as the LDS stage allows (fewer dequeues, better staging reuse) while every rank still
+  // gets >= ~2 chunks per resident workgroup for the dynamic dequeue to balance (matters for strong scaling at N = 8)
+  int target = kDefaultChunk;
+  while (target > 128 && g->ne / ((long long)world * target) < 2LL * g->cu_count * 7) target >>= 1;
+  if (la->chunk > 0) target = la->chunk;
+  if (la->tune[0] > 0) target = la->tune[0];
+  target = std::max(64, std::min(target, kStageCap));
+  const bool clique = pat == PAT_CLIQUE4 || pat == PAT_CLIQUEK;
+  ChunkTable *tab = nullptr;
+  // tune[6] & 0x1000 (tests): cut every chunk above 4096 estimated entries into parts
+  // chunk costs are estimated keys (DAG patterns: d(u) + d(v) per edge; symmetric patterns: streamed keys, bitmap probes
+  // weighted kProbeCost); parts bound the longest task of a launch
+  // TC: the shorter list of every edge is streamed against the longer one (gm_tct.hip) when every DAG row fits the LDS stage
+  // (tune[6] & 0x4000000: A/B switch, the chunked kernel that streams N+(v) of every out-edge).  Its chunks host the tasks of
+  // their vertices -- a hub hosts 10^5 in-edges -- so their cost is counted from the task lists and heavy chunks are cut into
+  // parts of 1 M keys / world (>= 128 K): one-GPU simulation of an 8-rank share of R-MAT-22, parts of 8 M / 512 K / 128 K / 32 K keys:
+  // 5.36 / 1.18 / 0.99 / 1.15 ms per rank (one GPU: 6.50 / 6.54 / 6.73 / 8.09 ms), profiles/r02/ab_tct_part_cap.log
+  const bool use_tct = pat == PAT_TC && !(la->tune[6] & 0x4000000) && la->tune[5] != 1 && g->ne > 0 && !getenv("GM_HOST_TABLES");
+  const int tct_stage = g->max_deg <= kStageCap ? kStageCap : kTctStageMax;
+  // (rows beyond the 2048-entry stage host nothing: their out-edges are the tasks of the chunked kernel, on a table of those rows only)
+  const bool tct_long = use_tct && g->max_deg > kTctStageMax;
+  const unsigned long long part_cap = (la->tune[6] & 0x1000) ? 4096ull : (stage_cap_of(pat) != kStageCapWide
+       ? (use_tct ? std::max<unsigned long long>((1ull << 20) / (unsigned long long)world, 128ull << 10) : kPartCostCap)
+       // a rank's share is 1/world of the launch: so is the tolerable tail (3-motif's bounded lists make its estimates
+       // pessimistic already: measured, 1/8 share 84.8 ms unscaled vs 91.2 ms scaled; diamond 5.2 vs 4.2 ms)
+       : (pat == PAT_MOTIF3 ? kPartCostCapSym : std::max<unsigned long long>(kPartCostCapSym / (unsigned long long)world, 256ull << 10)));
+  // 4-clique: vertices whose matrix exceeds the 8 KB budget go through the two-phase path (gm_mine.h)
+  // (tune[6] & 0x40000: A/B switch, everything stays in the mining kernel with its arena path)
+  const bool use_wide = pat == PAT_CLIQUE4 && !(la->tune[6] & 0x40000);
+  // symmetric-graph patterns: the rows of more than kClassRowMin entries go to the workgroup classes (gm_hrow.hip: hashed sets in LDS)
+  const bool sym_pat = stage_cap_of(pat) == kStageCapWide;
+  // (tune[6] & 0x80000: A/B switch, every row through the general kernel -- SPLIT chunks and dense HBM bitmaps for the long ones)
+  bool use_classes = sym_pat && !(la->tune[6] & 0x80000) && !(la->tune[5] == 1);
+  // They are separate launches: one whose share of chunks cannot fill the chip runs on a side stream (below), and with that the
+  // classes win or tie wherever there are long rows (profiles/r02/ab_class_threshold.log, general path vs classes, ms: diamond R-MAT-16
+  // 1.68 vs 0.76, R-MAT-18 2.64 vs 2.03, power law 3.94 vs 3.68, R-MAT-22 27.9 vs 16.6, R-MAT-23 255 vs 107; 3-motif R-MAT-16 1.43 vs 0.75,
+  // R-MAT-20 6.4 vs 5.7, power law 4.07 vs 4.10, R-MAT-24 458 vs 172). A graph without such rows skips their (empty) tables.
+  // tune[6] & 0x100000 forces them on.
+  if (use_classes && !(la->tune[6] & 0x100000)) use_classes = g->max_deg > kClassRowMin;
+  if (use_tct) {
+    int rc_t = ensure_tasklists(g);
+    if (rc_t) return rc_t;
+  }
+  RowFilter rf;
+  rf.tct = use_tct ? 1 : 0;
+  if (tct_long) { rf.skip_lo = kTctStageMax; rf.skip_hi = 0x7fffffff; }
+  rf.skip_clique_wide = use_wide ? clique_wide_min_words() : 0;
+  // Rows of 1025..3072 entries fit the general kernel's stage, but their partner lists (mean 600 keys on R-MAT-24) are cheaper
+  // against a hashed set than against the filter + bisection of a multi-row chunk: measured (profiles/r02/ab_hrow_class_lower_bound.log,
+  // ms, lower bound 3072 / 2048 / 1024 / 512 / 256) diamond R-MAT-24 262 / 240 / 239 / 238 / 237, R-MAT-22 21.1 / 21.0 / 17.5 / 17.6 / 17.5,
+  // 3-motif R-MAT-24 185 / 172 / 172 / 171 / 171.
+  int cls_lo = kClassRowMin;
+  if (const char *e = getenv("GM_CLS_LO")) cls_lo = std::max(64, atoi(e));  // (sweeps)
+  // giant rows (> kStageCapBig entries): hashed sets of row pieces (giant_kernel, gm_hrow.hip) instead of SPLIT chunks probing
+  // dense bitmaps in HBM (tune[6] & 0x1000000: A/B switch, they stay SPLIT chunks of the general kernel)
+  const bool use_range = use_classes && !(la->tune[6] & 0x1000000) && hrow_fits(g->nv, 2);  // (its pieces are class-2 sets: nv <= 2^27)
+  if (use_classes) { rf.skip_lo = cls_lo; rf.skip_hi = use_range ? 0x7fffffff : kStageCapBig; }
+  int rc = get_table(g, target, !clique, clique ? kBitWords : 0, part_cap, use_tct ? tct_stage : stage_cap_of(pat), &tab, rf, use_classes ? kStageCapBig : kBitmapMinDeg);
+  if (rc) return rc;
+  ChunkTable *tab_long = nullptr;
+  if (tct_long) {
+    RowFilter rl;
+    rl.only_lo = kTctStageMax;
+    rc = get_table(g, target, true, 0, kPartCostCap, kStageCap, &tab_long, rl, kBitmapMinDeg);
+    if (rc) return rc;
+  }
+  ChunkTable *tab_cls[4] = {tab, nullptr, nullptr, nullptr};
+  if (use_classes) {
+    RowFilter r1, r2;
+    r1.only_lo = cls_lo; r1.only_hi = kStageCapMid;
+    r2.only_lo = kStageCapMid; r2.only_hi = kStageCapBig;
+    // Parts of the one-row chunks: coarse. Measured on MI355X (profiles/r02/ab_sym_classes.log, diamond / 3-motif R-MAT-24, ms):
+    // whole rows (largest chunk 6e7 estimated keys) 636 / 370; parts of 512 K keys 1277 / 765 (16-wave workgroups with ~10
+    // batches per part); 512 K keys with >= 64 batches per part and 4-edge batches 743 / 462 -- every batch pays a few
+    // dependent global round trips (descriptors, the bounded prefix of 3-motif) before it streams, so small batches and
+    // small parts lose more than the shorter tail wins (8 M keys 368 / 634, 32 M keys 363 / 627). Parts of 32 M keys only trim the
+    // few heaviest rows. Side streams for the class kernels: 396 / 667 (GM_CLASSES_STREAMS, off).
+    // (hashed sets: a part costs one table build, ~10 us. A rank's share is 1/world of the launch and so is the tolerable tail -- one-GPU
+    // simulation of 8 rank shares, parts of 32 M / 8 M / 2 M keys: 3-motif R-MAT-24 28.2 / 25.8 / 26.5 ms per rank, diamond R-MAT-22 8.3 / 6.4 / 5.4;
+    // on one GPU the same parts cost 171 / 173 / 181 and 17.5 / 18.3 / 18.4 ms: profiles/r02/ab_class_part_cap.log)
+    unsigned long long cls_cap = (la->tune[6] & 0x1000) ? 4096ull
+                                 : std::max<unsigned long long>(part_cap, std::max<unsigned long long>((32ull << 20) / (unsigned long long)std::max(world, 1), 2ull << 20));
+    if (const char *e = getenv("GM_CLS_CAP_MKEYS")) cls_cap = (unsigned long long)std::max(1, atoi(e)) << 20;  // (sweeps)
+    // (target 1: every row is a chunk of its own -- the class kernels take one-row chunks -- also below the general kernel's chunk target)
+    rc = get_table(g, 1, false, 0, cls_cap, kStageCapMid, &tab_cls[1], r1, 0x7fffffff);
+    if (rc) return rc;
+    rc = get_table(g, 1, false, 0, cls_cap, kStageCapBig, &tab_cls[2], r2, 0x7fffffff);
+    if (rc) return rc;
+    if (use_range) {  // pieces of kGiantEdges task edges, never cut into parts (part_cap 0: giant_kernel ignores part / nparts)
+      RowFilter r3;
+      r3.only_lo = kStageCapBig;
+      rc = get_table(g, kGiantEdges, true, 0, 0ull, kStageCapBig, &tab_cls[3], r3, 0x7fffffff);
+      if (rc) return rc;
+    }
+  }
+  WidePlan *plan = nullptr;
+  if (use_wide) {
+    rc = get_wide_plan(g, rank, world, la->policy == GM_PART_VERTEX ? GM_PART_RANGE : la->policy, &plan);
+    if (rc) return rc;
+  }
+
+  MineParams p;
+  memset(&p, 0, sizeof p);
+  p.g.nv = g->nv;
+  p.g.ne = (int)g->ne;
+  p.g.rp = g->d_rp;
+  p.g.col = g->d_col;
+  rc = ensure_edesc(g);  // (the kernels read them unconditionally; -DGM_EDESC=0 builds gather rp[v] instead, for A/B runs)
+  if (rc) return rc;
+  p.g.edesc = g->d_edesc;
+  if (use_tct) {
+    p.g.trp = g->d_trp;
+    p.g.tdesc = g->d_tdesc;
+  }
+  unsigned long long my_edges = 0;
+  // this rank's share of a table: chunk ids first + i*step of the dequeue order (or a contiguous / vertex range)
+  auto take_share = [&](ChunkTable *tb, MineParams &q) {
+    q.chunks = tb->d;
+    q.chunk_slot = tb->d_slot;
+    q.bitmaps = tb->d_bitmaps;
+    q.bitmap_words = tb->bitmap_words;
+    q.row_slot = tb->d_row_slot;
+    const long long n = (long long)tb->n;
+    long long first = 0, step = 1, count = 0;
+    if (la->policy == GM_PART_VERTEX) {  // contiguous chunk range whose first vertex lies in this rank's vertex range
+      const long long vlo = (long long)g->nv * rank / world, vhi = (long long)g->nv * (rank + 1) / world;
+      auto first_chunk_at = [&](long long v) {
+        long long lo = 0, hi = n;
+        while (lo < hi) {
+          const long long mid = (lo + hi) / 2;
+          if (tb->first_vertex[(size_t)mid] < v) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+      };
+      first = first_chunk_at(vlo);
+      count = first_chunk_at(vhi) - first;
+    } else {
+      gm_partition((int64_t)n, rank, world, la->policy, (int64_t *)&first, (int64_t *)&step, (int64_t *)&count);
+    }
+    q.first = (int)first;
+    q.step = (int)step;
+    q.count = (int)count;
+    // dequeue order (tune[6] & 0x4000: plain chunk-id order; & 0x2000: swap the two orders -- ablation only)
+    // measured on R-MAT (one rank): the cliques want the full cost order (4-clique 220.6 -> 208.6 ms, 5-clique 796 -> 589 ms),
+    // the symmetric-graph patterns the locality-preserving heavy-first order at every world size, TC heavy-first for one
+    // rank and the full order for shares
+    const bool clique_pat = pat == PAT_CLIQUE4 || pat == PAT_CLIQUEK;
+    const int which = (((world > 1 && !sym_pat) || clique_pat) ? 1 : 0) ^ ((la->tune[6] & 0x2000) ? 1 : 0);
+    const bool lpt = la->policy == GM_PART_ROUND_ROBIN && tb->d_order[which] && !(la->tune[6] & 0x4000);
+    q.order = lpt ? tb->d_order[which] : nullptr;
+    if (step == 1) my_edges += tb->edge_prefix[first + count] - tb->edge_prefix[first];  // (any order: the same set)
+    else for (long long j = first; j < n; j += step) {
+      const size_t c = lpt ? (size_t)tb->order[which][(size_t)j] : (size_t)j;
+      my_edges += tb->edge_prefix[c + 1] - tb->edge_prefix[c];
+    }
+  };
+  take_share(tab, p);
+  p.grab = la->tune[1] > 0 ? la->tune[1] : 1;
+  // direction rule: X if b*(xb + xs*lg a) <= a*(yb + ys*lg b); tune[2] = xs+1, tune[3] = ys+1, tune[7] = xb*16 + yb
+  p.cost_x_step = la->tune[2] > 0 ? la->tune[2] - 1 : 1;
+  p.cost_y_step = la->tune[3] > 0 ? la->tune[3] - 1 : 6;
+  p.cost_x_base = (la->tune[7] & 255) > 0 ? ((la->tune[7] >> 4) & 15) : 2;
+  p.cost_y_base = (la->tune[7] & 255) > 0 ? (la->tune[7] & 15) : 2;
+  p.cost_y_bitmap = la->tune[7] >> 8;  // 0 = price pass Y as a bisection even when row v has a bitmap
+  p.k = k;
+  p.flags = (la->tune[5] == 1) ? 1 : 0;
+  p.flags |= (la->tune[6] & 0xffff) << 1;  // debug/ablation: bit1 skip clique phase 2, bit2 skip bit-matrix writes (counts wrong)
+  if (la->tune[6] & 0x2000000) p.flags |= 1 << 23;  // hashed-row classes: the 32-bit multiply of id spaces beyond 2^24 (tests)
+  if (la->tune[6] & 0x800000) p.flags |= 1 << 22;  // hashed-row classes: every lookup through the global-memory fallback (tests)
+  if (la->tune[6] & 0x200000) p.flags |= 1 << 20;  // k >= 5: the any-width pair count instead of the tile walk (tests)
+  p.counters = g->d_counters;
+  p.queue = reinterpret_cast<unsigned *>(g->d_counters + 4);
+
+  const size_t lds = mine_lds_bytes(pat);
+  int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds));
+  if (la->tune[4] > 0) per_cu = la->tune[4];
+  long long want = ((long long)p.count + (long long)p.grab - 1) / (long long)p.grab;
+  int grid = (int)std::max<long long>(1, std::min<long long>(want, (long long)g->cu_count * per_cu));
+
+  if (clique && tab->max_bit_words > 0) {
+    // one arena slot per workgroup; k >= 5 doubles it (second half: compacted sub-matrices, cliquek_count_sub)
+    // k >= 5: k - 2 slots of max_bit_words + 4096 words (the vertex's matrix + one compacted sub-matrix per deeper level; the
+    // margin covers the padding of compacted rows to 64 columns)
+    const unsigned long long slot_words = (pat == PAT_CLIQUEK) ? (unsigned long long)(k - 2) * (tab->max_bit_words + 4096ull) : tab->max_bit_words;
+    const size_t need = (size_t)slot_words * sizeof(unsigned) * (size_t)grid;
+    if (need > g->scratch_bytes) {
+      if (g->d_scratch) (void)hipFree(g->d_scratch);
+      g->d_scratch = nullptr;
+      g->scratch_bytes = 0;
+      HIP_TRY(hipMalloc(&g->d_scratch, need));
+      g->scratch_bytes = need;
+    }
+    p.scratch = g->d_scratch;
+    p.scratch_words = slot_words;
+  }
+
+#ifdef GM_DEBUG_CHUNKS
+  unsigned long long *d_ticks = nullptr;
+  HIP_TRY(hipMalloc(&d_ticks, sizeof(unsigned long long) * std::max<size_t>(tab->n, 1)));
+  HIP_TRY(hipMemset(d_ticks, 0, sizeof(unsigned long long) * std::max<size_t>(tab->n, 1)));
+  p.chunk_ticks = d_ticks;
+#endif
+  if (use_classes) {
+    // everything the class launches may allocate or create, before the timer starts (a first call used to time hipMalloc and
+    // hipStreamCreate between its two events): side streams + their events, and the giant-row kernel's scratch -- per workgroup,
+    // where the pieces of the row cut the partner lists of its chunk, kGiantEdges ints per piece (giant_bounds)
+    for (int i = 0; i < 3; ++i) {
+      if (!g->aux_stream[i]) {
+        HIP_TRY(hipStreamCreateWithFlags(&g->aux_stream[i], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&g->aux_done[i], hipEventDisableTiming));
+      }
+    }
+    if (tab_cls[3] && tab_cls[3]->n > 0) {
+      const size_t need = (size_t)giant_scratch_words(g->max_deg) * sizeof(unsigned) * (size_t)g->cu_count * (size_t)giant_per_cu();
+      if (need > g->scratch_bytes) {
+        if (g->d_scratch) (void)hipFree(g->d_scratch);
+        g->d_scratch = nullptr;
+        g->scratch_bytes = 0;
+        HIP_TRY(hipMalloc(&g->d_scratch, need));
+        g->scratch_bytes = need;
+      }
+    }
+  }
+  rc = start_timer(ctx);
+  if (rc) return rc;
+  if (use_wide && plan && !plan->verts.empty()) {
+    // wide vertices first (the heaviest work of the launch): per round, phase 1 = the mining kernel over the row-group
+    // chunks, phase 2 = the big-LDS count kernels per class; then the mining kernel over everything else
+    my_edges += plan->edges;
+    HIP_TRY(hipMemsetAsync(g->d_wide_queue, 0, 65536, stream));
+    const bool prof = getenv("GM_WIDE_PROFILE") != nullptr;
+    unsigned long long *d_prof = nullptr;
+    if (prof) {
+      HIP_TRY(hipMalloc(&d_prof, 4 * 32));
+      HIP_TRY(hipMemset(d_prof, 0, 4 * 32));
+    }
+    int qword = 0;
+    for (const auto &rd : plan->rounds) {
+      if (qword + 4 > 16384) return GM_ERR_TOO_LARGE;  // (more than 4096 arena rounds)
+      CliqueBuildParams pw;
+      memset(&pw, 0, sizeof pw);
+      pw.g = p.g;
+      pw.chunks = plan->d_chunks + rd.chunk_begin;
+      pw.count = (int)(rd.chunk_end - rd.chunk_begin);
+      pw.queue = g->d_wide_queue + qword++;
+      pw.mat = g->d_wide_mat;
+      pw.base = plan->d_base;
+      pw.cost_x_step = p.cost_x_step; pw.cost_y_step = p.cost_y_step; pw.cost_x_base = p.cost_x_base; pw.cost_y_base = p.cost_y_base;
+      pw.flags = p.flags;
+      const int per_cu_b = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / clique_build_lds_bytes()));
+      const int wgrid = (int)std::max<long long>(1, std::min<long long>(pw.count, (long long)g->cu_count * per_cu_b));
+      if (pw.count > 0) HIP_TRY(launch_clique_build(pw, wgrid, stream));
+      for (int cls = 2; cls >= 0; --cls) {  // X and L (one workgroup per CU) before S
+        CliqueCountParams c;
+        memset(&c, 0, sizeof c);
+        c.rp = g->d_rp;
+        c.verts = plan->d_verts;
+        c.base = plan->d_base;
+        c.mat = g->d_wide_mat;
+        c.slots = plan->d_cls_slots + rd.cls_begin[cls];
+        c.count = (int)(rd.cls_begin[cls + 1] - rd.cls_begin[cls]);
+        c.queue = g->d_wide_queue + qword++;
+        c.counters = g->d_counters;
+        c.profile = prof ? d_prof + 4 * cls : nullptr;
+        if (c.count == 0) continue;
+        const int per_cu_c = (int)std::max<size_t>(1, std::min<size_t>((160 * 1024) / clique_count_lds_bytes(cls), (size_t)(2048 / clique_count_threads(cls))));
+        const int cgrid = (int)std::max<long long>(1, std::min<long long>(c.count, (long long)g->cu_count * per_cu_c));
+        HIP_TRY(launch_clique_count(cls, c, cgrid, stream));
+      }
+    }
+    if (prof) {
+      unsigned long long h[12];
+      HIP_TRY(hipStreamSynchronize(stream));
+      HIP_TRY(hipMemcpy(h, d_prof, sizeof h, hipMemcpyDeviceToHost));
+      (void)hipFree(d_prof);
+      for (int cls = 0; cls < 3; ++cls)
+        if (h[4 * cls + 3])
+          fprintf(stderr, "[wide] count class %c: %llu workgroups; per workgroup ms: load %.2f count %.2f\n", "SLX"[cls], h[4 * cls + 3],
+                  h[4 * cls] / (double)h[4 * cls + 3] / 1e5, h[4 * cls + 1] / (double)h[4 * cls + 3] / 1e5);
+      fprintf(stderr, "[wide] %zu vertices, %zu row-group chunks, %zu round(s), arena %.1f MB\n", plan->verts.size(), plan->n_chunks,
+              plan->rounds.size(), g->wide_mat_bytes / 1048576.0);
+    }
+  }
+  uint64_t chunks_total = (uint64_t)p.count;
+  bool joined[3] = {false, false, false};
+  if (use_classes) {
+    // A class kernel whose share of chunks cannot fill the chip on its own (small graphs, 1/8 shares) runs on a side stream, so
+    // that the kernels launched after it fill the idle CUs; one that can fill it stays on the launch's stream -- there every
+    // kernel has the chip to itself (side streams at R-MAT-24 size: diamond 667 vs 636 ms, the 148 KB workgroups of class 2 wait
+    // for whole CUs to drain). GM_CLASSES_STREAMS=0 / 1 forces one or the other.
+    const char *streams_env = getenv("GM_CLASSES_STREAMS");
+    auto side_stream = [&](int cls, long long count, long long full_grid, hipStream_t *ws) -> int {
+      *ws = stream;
+      const bool side = streams_env ? atoi(streams_env) != 0 : count < full_grid;
+      if (!side) return GM_OK;
+      *ws = g->aux_stream[cls - 1];
+      HIP_TRY(hipStreamWaitEvent(*ws, ctx.evp[0], 0));  // after the counters were zeroed and the timer started
+      return GM_OK;
+    };
+    auto side_done = [&](int cls, hipStream_t ws) -> int {
+      if (ws == stream) return GM_OK;
+      HIP_TRY(hipEventRecord(g->aux_done[cls - 1], ws));
+      joined[cls - 1] = true;
+      return GM_OK;
+    };
+    for (int cls = 3; cls >= 1; --cls) {
+      if (!tab_cls[cls]) continue;
+      MineParams q = p;
+      take_share(tab_cls[cls], q);
+      q.queue = reinterpret_cast<unsigned *>(g->d_counters + 4) + cls;  // its own dequeue word inside the zeroed 64-byte block
+      if (q.count == 0) continue;
+      chunks_total += (uint64_t)q.count;
+      // the row as a hashed set in LDS (gm_hrow.hip) unless the ids are too wide for its 14-bit remainders
+      // (tune[6] & 0x400000: A/B switch, the sorted LDS copy + bit filter + bisection of gm_mine_wide.hip)
+      if (cls == 3) {
+        const int rgrid = (int)std::max<long long>(1, std::min<long long>(q.count, (long long)g->cu_count * giant_per_cu()));
+        const unsigned long long slot_words = giant_scratch_words(g->max_deg);  // (allocated before the timer started)
+        q.scratch = g->d_scratch;
+        q.scratch_words = slot_words;
+        hipStream_t ws;
+        rc = side_stream(cls, q.count, (long long)g->cu_count * giant_per_cu(), &ws);
+        if (rc) return rc;
+        HIP_TRY(launch_giant(pat, q, rgrid, ws));
+        rc = side_done(cls, ws);
+        if (rc) return rc;
+        continue;
+      }
+      const bool hrow = !(la->tune[6] & 0x400000) && p.g.edesc != nullptr && hrow_fits(g->nv, cls);
+      const int per_cu_w = hrow ? hrow_per_cu(cls) : (int)std::max<size_t>(1, (160 * 1024) / mine_wide_lds_bytes(cls));
+      const int wgrid = (int)std::max<long long>(1, std::min<long long>(q.count, (long long)g->cu_count * per_cu_w));
+      hipStream_t ws;
+      rc = side_stream(cls, q.count, (long long)g->cu_count * per_cu_w, &ws);
+      if (rc) return rc;
+      if (hrow) HIP_TRY(launch_hrow(pat, cls, q, wgrid, ws));
+      else HIP_TRY(launch_mine_wide(pat, cls, q, wgrid, ws));
+      rc = side_done(cls, ws);
+      if (rc) return rc;
+    }
+  }
+  if (tab_long) {  // TC: the out-edges of the rows beyond the stage, through the chunked kernel (own dequeue word)
+    MineParams q = p;
+    take_share(tab_long, q);
+    q.g.trp = nullptr;
+    q.g.tdesc = nullptr;
+    q.queue = reinterpret_cast<unsigned *>(g->d_counters + 4) + 1;
+    if (q.count > 0) {
+      chunks_total += (uint64_t)q.count;
+      const long long wq = ((long long)q.count + (long long)q.grab - 1) / (long long)q.grab;
+      HIP_TRY(launch_mine(pat, q, (int)std::max<long long>(1, std::min<long long>(wq, (long long)g->cu_count * per_cu)), stream));
+    }
+  }
+  if (p.count > 0 && use_tct) HIP_TRY(launch_tct(p, tct_stage, (int)std::max<long long>(1, std::min<long long>(want, (long long)g->cu_count * tct_per_cu(tct_stage))), stream));
+  else if (p.count > 0) HIP_TRY(launch_mine(pat, p, grid, stream));
+#ifdef GM_DEBUG_CHUNKS
+  {
+    HIP_TRY(hipStreamSynchronize(stream));
+    std::vector<unsigned long long> ticks(tab->n);
+    HIP_TRY(hipMemcpy(ticks.data(), d_ticks, sizeof(unsigned long long) * tab->n, hipMemcpyDeviceToHost));
+    (void)hipFree(d_ticks);
+    std::vector<ChunkRec> recs(tab->n);
+    HIP_TRY(hipMemcpy(recs.data(), tab->d, sizeof(ChunkRec) * tab->n, hipMemcpyDeviceToHost));
+    std::vector<size_t> idx(tab->n);
+    for (size_t i = 0; i < tab->n; ++i) idx[i] = i;
+    std::sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return ticks[a] > ticks[b]; });
+    unsigned long long tot = 0;
+    for (auto t : ticks) tot += t;
+    if (const char *dump = getenv("GM_CHUNK_DUMP")) {
+      static int dump_no = 0;
+      const std::string name = std::string(dump) + "." + std::to_string(dump_no++) + ".pat" + std::to_string((int)pat);
+      FILE *f = fopen(name.c_str(), "w");
+      if (f) {
+        fprintf(f, "pos,cid,rows,entries,rowlen,whole,part,nparts,cost,us\n");
+        for (size_t pos = 0; pos < tab->n; ++pos) {
+          const size_t cid = p.order ? (size_t)(p.order == tab->d_order[0] ? tab->order[0][pos] : tab->order[1][pos]) : pos;
+          const ChunkRec &r = recs[cid];
+          const bool whole = r.e_begin == g->h_rp[r.u_begin] && r.e_end == g->h_rp[r.u_end];
+          fprintf(f, "%zu,%zu,%d,%d,%d,%d,%d,%d,%llu,%.1f\n", pos, cid, r.u_end - r.u_begin, r.e_end - r.e_begin,
+                  g->h_rp[r.u_begin + 1] - g->h_rp[r.u_begin], (int)whole, r.part, r.nparts, tab->cost[cid], ticks[pos] / 100.0);
+        }
+        fclose(f);
+      }
+    }
+    fprintf(stderr, "[chunks] n=%zu total ticks %llu (100 MHz): mean %.1f us\n", tab->n, tot, tot / 100.0 / std::max<size_t>(tab->n, 1));
+    for (size_t k = 0; k < std::min<size_t>(12, tab->n); ++k) {
+      const size_t pos = idx[k];
+      const size_t cid = p.order ? (size_t)(p.order == tab->d_order[0] ? tab->order[0][pos] : tab->order[1][pos]) : pos;
+      const ChunkRec &r = recs[cid];
+      fprintf(stderr, "[chunks] #%zu pos %zu: %.1f us  rows [%d,%d) entries [%d,%d) n=%d part %d/%d rowlen %d\n", k, pos, ticks[pos] / 100.0,
+              r.u_begin, r.u_end, r.e_begin, r.e_end, r.e_end - r.e_begin, r.part, r.nparts, g->h_rp[r.u_begin + 1] - g->h_rp[r.u_begin]);
+    }
+  }
+#endif
+  for (int i = 0; i < 3; ++i)
+    if (joined[i]) HIP_TRY(hipStreamWaitEvent(stream, g->aux_done[i], 0));  // the launch ends when all three kernels have
+  fill_stats(st, (pat == PAT_DIAMOND || pat == PAT_MOTIF4E) ? my_edges / 2 : my_edges, chunks_total, grid,
+             kWavesPerBlock * GM_WAVE);
+  return end_launch(ctx, fin_mode, fin_base, h_out, nout, st);
+}
+
+extern "C" int gm_kernel_times(const gm_graph *g, int n, double *ms_out, int *n_out) {
+  if (!g || !ms_out || !n_out || n < 0) return GM_ERR_INVALID;
+  if (g->ring_alias) g = g->ring_alias;
+  const unsigned long long have = std::min<unsigned long long>(g->ev_launches, gm_graph::kEvRing);
+  const int m = (int)std::min<unsigned long long>((unsigned long long)n, have);
+  HIP_TRY(hipSetDevice(g->device));
+  for (int i = 0; i < m; ++i) {  // oldest of the last m launches first
+    const unsigned long long idx = (g->ev_launches - (unsigned long long)m + (unsigned long long)i) % gm_graph::kEvRing;
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, g->ev[idx][0], g->ev[idx][1]));
+    ms_out[i] = ms;
+    // 4-motif: one call = the per-edge kernel on this handle + the rectangle kernel on the renumbered copy + the 4-clique kernel on the
+    // cached DAG; the launches of the same recency on those handles belong to the same call
+    for (const gm_graph *x : g->ring_extra) {
+      const unsigned long long back = (unsigned long long)(m - i);
+      if (!x || x->ev_launches < back) continue;
+      const unsigned long long xi = (x->ev_launches - back) % gm_graph::kEvRing;
+      float xms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&xms, x->ev[xi][0], x->ev[xi][1]));
+      ms_out[i] += xms;
+    }
+  }
+  *n_out = m;
+  return GM_OK;
+}
+
+extern "C" int gm_tc(const gm_graph *dag, const gm_launch *la, uint64_t *total, gm_stats *st) {
+  return run_pattern(PAT_TC, dag, la, 3, total, 1, st);
+}
+
+// rectangle, flattened over wedges (rect_flat_kernel in gm_mine.hip)
+static int ensure_idx0(gm_graph *g, const GraphView &gv) {
+  if (g->d_idx0) return GM_OK;
+  OtherSetupScope scope(g);
+  HIP_TRY(hipMalloc(&g->d_idx0, sizeof(int) * (size_t)std::max(g->nv, 1)));
+  HIP_TRY(launch_idx0(gv, g->d_idx0, 0));
+  return GM_OK;
+}
+
+static int run_rect_flat(const gm_graph *cg, const gm_launch *la_in, uint64_t *h_out, gm_stats *st, bool pentagon = false) {
+  LaunchCtx ctx;
+  int rc = begin_launch(cg, la_in, h_out, ctx);
+  if (rc) return rc;
+  gm_graph *g = ctx.g;
+  const gm_launch *la = &ctx.la;
+  GraphView gv;
+  gv.nv = g->nv;
+  gv.ne = (int)g->ne;
+  gv.rp = g->d_rp;
+  gv.col = g->d_col;
+  if (!g->d_wblock_prefix) {  // once per graph: idx0[v] on the device, wedge-block prefix on the host
+    OtherSetupScope scope(g);
+    rc = ensure_idx0(g, gv);
+    if (rc) return rc;
+    std::vector<int> idx0((size_t)std::max(g->nv, 1));
+    HIP_TRY(hipMemcpy(idx0.data(), g->d_idx0, sizeof(int) * (size_t)g->nv, hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> pre((size_t)g->nv + 1);
+    unsigned long long acc = 0;
+    for (int v = 0; v < g->nv; ++v) {
+      pre[v] = acc;
+      const unsigned long long n = (unsigned long long)idx0[v];
+      acc += (n * (n - (n ? 1ull : 0ull)) / 2ull + 63ull) / 64ull;
+    }
+    pre[g->nv] = acc;
+    g->n_wblocks = acc;
+    HIP_TRY(hipMalloc(&g->d_wblock_prefix, sizeof(unsigned long long) * ((size_t)g->nv + 1)));
+    HIP_TRY(hipMemcpy(g->d_wblock_prefix, pre.data(), sizeof(unsigned long long) * ((size_t)g->nv + 1), hipMemcpyHostToDevice));
+  }
+  RectParams p;
+  memset(&p, 0, sizeof p);
+  p.g = gv;
+  p.idx0 = g->d_idx0;
+  p.block_prefix = g->d_wblock_prefix;
+  p.nblocks = g->n_wblocks;
+  p.group = la->chunk > 0 ? la->chunk : (pentagon ? 2 : 16);
+  const long long ngroups = (long long)((p.nblocks + (unsigned long long)p.group - 1) / (unsigned long long)p.group);
+  int64_t first = 0, step = 1, count = 0;
+  gm_partition(ngroups, ctx.rank, ctx.world, la->policy, &first, &step, &count);
+  p.first = (unsigned long long)first;
+  p.step = (unsigned long long)step;
+  p.count = (unsigned long long)count;
+  p.counters = g->d_counters;
+  p.queue = g->d_counters + 4;
+  const int grid = (int)std::max<long long>(1, std::min<long long>((count + 3) / 4, (long long)g->cu_count * 8));
+  rc = start_timer(ctx);
+  if (rc) return rc;
+  if (count > 0) HIP_TRY(launch_rect_flat(p, pentagon, grid, ctx.stream));
+  fill_stats(st, (uint64_t)(g->ne / 2 / ctx.world), (uint64_t)count, grid, 256);
+  return end_launch(ctx, FIN_COPY, 0, h_out, 1, st);
+}
+
+static int ensure_edge_tables(gm_graph *g, const GraphView &gv);
+
+// rectangle (rect_acc_kernel) and pentagon (pent_acc_kernel) by wedge accumulation: same centres, same counter maps
+static int run_rect_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h_out, gm_stats *st, bool pentagon = false) {
+  LaunchCtx ctx;
+  int rc = begin_launch(cg, la_in, h_out, ctx);
+  if (rc) return rc;
+  gm_graph *g = ctx.g;
+  const gm_launch *la = &ctx.la;
+  GraphView gv;
+  gv.nv = g->nv;
+  gv.ne = (int)g->ne;
+  gv.rp = g->d_rp;
+  gv.col = g->d_col;
+  rc = ensure_idx0(g, gv);
+  if (rc) return rc;
+  if (!g->d_rect_tasks) {  // once per graph: 2-path estimate per centre (device), task list (host): heavy first, then light by 4
+    OtherSetupScope scope(g);
+    const size_t nv = (size_t)g->nv;
+    unsigned long long *d_work = nullptr;
+    HIP_TRY(hipMalloc(&d_work, sizeof(unsigned long long) * std::max<size_t>(nv, 1)));
+    std::vector<unsigned long long> work(std::max<size_t>(nv, 1));
+    hipError_t e = nv ? launch_rect_work(gv, g->d_idx0, d_work, 0) : hipSuccess;
+    if (e == hipSuccess) e = hipMemcpy(work.data(), d_work, sizeof(unsigned long long) * nv, hipMemcpyDeviceToHost);
+    (void)hipFree(d_work);
+    if (e != hipSuccess) return hip_fail(e, "rect_work_kernel", __FILE__, __LINE__);
+    std::vector<int> vs;
+    vs.reserve(nv);
+    for (size_t v = 0; v < nv; ++v)
+      if (work[v] > 0) vs.push_back((int)v);
+    std::stable_sort(vs.begin(), vs.end(), [&](int a, int b) { return work[(size_t)a] > work[(size_t)b]; });
+    const unsigned long long heavy = 1ull << 15;  // 2-paths above which a centre gets a whole workgroup
+    std::vector<int4> tasks;
+    size_t i = 0;
+    for (; i < vs.size() && work[(size_t)vs[i]] >= heavy; ++i) tasks.push_back(make_int4(vs[i], -2, -2, -2));
+    for (; i < vs.size(); i += 4) {
+      int4 t = make_int4(-1, -1, -1, -1);
+      t.x = vs[i];
+      if (i + 1 < vs.size()) t.y = vs[i + 1];
+      if (i + 2 < vs.size()) t.z = vs[i + 2];
+      if (i + 3 < vs.size()) t.w = vs[i + 3];
+      tasks.push_back(t);
+    }
+    g->n_rect_tasks = tasks.size();
+    HIP_TRY(hipMalloc(&g->d_rect_tasks, sizeof(int4) * std::max<size_t>(tasks.size(), 1)));
+    if (!tasks.empty()) HIP_TRY(hipMemcpy(g->d_rect_tasks, tasks.data(), sizeof(int4) * tasks.size(), hipMemcpyHostToDevice));
+  }
+  RectAccParams p;
+  memset(&p, 0, sizeof p);
+  p.g = gv;
+  p.idx0 = g->d_idx0;
+  p.tasks = g->d_rect_tasks;
+  int64_t first = 0, step = 1, count = 0;
+  gm_partition((int64_t)g->n_rect_tasks, ctx.rank, ctx.world, la->policy, &first, &step, &count);
+  p.first = (unsigned long long)first;
+  p.step = (unsigned long long)step;
+  p.count = (unsigned long long)count;
+  p.counters = g->d_counters;
+  p.queue = g->d_counters + 4;
+  // one counter map (nv words) per wave, within a memory budget
+  p.acc_stride = ((unsigned long long)g->nv + 63ull) & ~63ull;
+  const unsigned long long per_wg = p.acc_stride * 4ull * kWavesPerBlock;
+  size_t free_b = 0, total_b = 0;
+  (void)hipMemGetInfo(&free_b, &total_b);
+  const unsigned long long budget = std::min<unsigned long long>(32ull << 30, (unsigned long long)free_b / 4 + (unsigned long long)g->rect_acc_bytes);  // (maps + touched lists)
+  long long grid = std::min<long long>((long long)g->cu_count * 8, (long long)std::max<unsigned long long>(1, budget / std::max<unsigned long long>(per_wg, 1)));
+  grid = std::max<long long>(1, std::min<long long>(grid, count));
+  const size_t need = (size_t)per_wg * (size_t)grid;
+  if (need > g->rect_acc_bytes) {
+    if (g->d_rect_acc) (void)hipFree(g->d_rect_acc);
+    g->d_rect_acc = nullptr;
+    g->rect_acc_bytes = 0;
+    HIP_TRY(hipMalloc(&g->d_rect_acc, need));
+    HIP_TRY(hipMemset(g->d_rect_acc, 0, need));  // every launch leaves the maps zeroed again
+    g->rect_acc_bytes = need;
+  }
+  p.acc = g->d_rect_acc;
+  if (need > g->pent_touched_bytes) {  // touched-vertex lists: same shape as the maps (one int list of up to nv entries per wave)
+    if (g->d_pent_touched) (void)hipFree(g->d_pent_touched);
+    g->d_pent_touched = nullptr;
+    g->pent_touched_bytes = 0;
+    HIP_TRY(hipMalloc(&g->d_pent_touched, need));
+    g->pent_touched_bytes = need;
+  }
+  p.touched = g->d_pent_touched;
+  if (pentagon) {
+    rc = ensure_edge_tables(g, gv);
+    if (rc) return rc;
+    PentAccParams q;
+    memset(&q, 0, sizeof q);
+    q.g = gv;
+    q.idx0 = g->d_idx0;
+    q.tlt = g->d_house_tlt;
+    q.tasks = p.tasks;
+    q.first = p.first;
+    q.step = p.step;
+    q.count = p.count;
+    q.acc = p.acc;
+    q.touched = g->d_pent_touched;
+    q.acc_stride = p.acc_stride;
+    q.queue = p.queue;
+    q.counters = p.counters;
+    rc = start_timer(ctx);
+    if (rc) return rc;
+    if (count > 0) HIP_TRY(launch_pent_acc(q, (int)grid, ctx.stream));
+    fill_stats(st, (uint64_t)(g->ne / 2 / ctx.world), (uint64_t)count, (int)grid, 256);
+    return end_launch(ctx, FIN_HALF_SIGNED, 0, h_out, 1, st);
+  }
+  rc = start_timer(ctx);
+  if (rc) return rc;
+  if (count > 0) HIP_TRY(launch_rect_acc(p, (int)grid, ctx.stream));
+  fill_stats(st, (uint64_t)(g->ne / 2 / ctx.world), (uint64_t)count, (int)grid, 256);
+  return end_launch(ctx, FIN_COPY, 0, h_out, 1, st);
+}
+
+// per-entry triangle tables t / tlt (edge_tab_kernel), once per graph; every rank builds the whole tables: they are inputs of
+// every centre of the house / pentagon map kernels
+static int ensure_edge_tables(gm_graph *g, const GraphView &gv) {
+  if (g->d_house_t && g->d_house_tlt) return GM_OK;
+  OtherSetupScope scope(g);
+  const size_t ne1 = (size_t)std::max<long long>(g->ne, 1);
+  DevBuf<unsigned> t, tlt;
+  HIP_TRY(t.alloc(ne1));
+  HIP_TRY(tlt.alloc(ne1));
+  if (g->ne > 0) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemset(g->d_counters, 0, 64));
+    HIP_TRY(launch_edge_tab(gv, t.p, tlt.p, g->d_counters + 4, g->cu_count * 8, 0));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemset(g->d_counters, 0, 64));  // (the table kernel used the dequeue head)
+  }
+  g->d_house_t = t.release();  // (published only after the build kernel has succeeded; the buffers free themselves on the error paths)
+  g->d_house_tlt = tlt.release();
+  return GM_OK;
+}
+
+// house by wedge accumulation (edge_tab_kernel + house_acc_kernel in gm_mine.hip)
+static int run_house_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h_out, gm_stats *st) {
+  LaunchCtx ctx;
+  int rc = begin_launch(cg, la_in, h_out, ctx);
+  if (rc) return rc;
+  gm_graph *g = ctx.g;
+  const gm_launch *la = &ctx.la;
+  GraphView gv;
+  gv.nv = g->nv;
+  gv.ne = (int)g->ne;
+  gv.rp = g->d_rp;
+  gv.col = g->d_col;
+  rc = ensure_edge_tables(g, gv);
+  if (rc) return rc;
+  if (!g->d_house_tasks) {  // once per graph
+    OtherSetupScope scope(g);
+    const size_t nv = (size_t)g->nv;
+    unsigned long long *d_work = nullptr;
+    HIP_TRY(hipMalloc(&d_work, sizeof(unsigned long long) * std::max<size_t>(nv, 1)));
+    std::vector<unsigned long long> work(std::max<size_t>(nv, 1));
+    hipError_t e = nv ? launch_house_work(gv, d_work, 0) : hipSuccess;
+    if (e == hipSuccess) e = hipMemcpy(work.data(), d_work, sizeof(unsigned long long) * nv, hipMemcpyDeviceToHost);
+    (void)hipFree(d_work);
+    if (e != hipSuccess) return hip_fail(e, "house_work_kernel", __FILE__, __LINE__);
+    std::vector<int> vs;
+    vs.reserve(nv);
+    for (size_t v = 0; v < nv; ++v)
+      if (work[v] > 0) vs.push_back((int)v);
+    std::stable_sort(vs.begin(), vs.end(), [&](int a, int b) { return work[(size_t)a] > work[(size_t)b]; });
+    const unsigned long long heavy = 1ull << 15;
+    std::vector<int4> tasks;
+    size_t i = 0;
+    for (; i < vs.size() && work[(size_t)vs[i]] >= heavy; ++i) tasks.push_back(make_int4(vs[i], -2, -2, -2));
+    for (; i < vs.size(); i += 4) {
+      int4 t4 = make_int4(-1, -1, -1, -1);
+      t4.x = vs[i];
+      if (i + 1 < vs.size()) t4.y = vs[i + 1];
+      if (i + 2 < vs.size()) t4.z = vs[i + 2];
+      if (i + 3 < vs.size()) t4.w = vs[i + 3];
+      tasks.push_back(t4);
+    }
+    g->n_house_tasks = tasks.size();
+    HIP_TRY(hipMalloc(&g->d_house_tasks, sizeof(int4) * std::max<size_t>(tasks.size(), 1)));
+    if (!tasks.empty()) HIP_TRY(hipMemcpy(g->d_house_tasks, tasks.data(), sizeof(int4) * tasks.size(), hipMemcpyHostToDevice));
+  }
+  HouseAccParams p;
+  memset(&p, 0, sizeof p);
+  p.g = gv;
+  p.t = g->d_house_t;
+  p.tlt = g->d_house_tlt;
+  p.tasks = g->d_house_tasks;
+  int64_t first = 0, step = 1, count = 0;
+  gm_partition((int64_t)g->n_house_tasks, ctx.rank, ctx.world, la->policy, &first, &step, &count);
+  p.first = (unsigned long long)first;
+  p.step = (unsigned long long)step;
+  p.count = (unsigned long long)count;
+  p.counters = g->d_counters;
+  p.queue = g->d_counters + 4;
+  p.acc_stride = ((unsigned long long)g->nv + 63ull) & ~63ull;
+  const unsigned long long per_wg = p.acc_stride * 8ull * kWavesPerBlock;
+  size_t free_b = 0, total_b = 0;
+  (void)hipMemGetInfo(&free_b, &total_b);
+  const unsigned long long budget = std::min<unsigned long long>(32ull << 30, (unsigned long long)free_b / 3 + (unsigned long long)g->house_acc_bytes);  // (maps + touched lists)
+  long long grid = std::min<long long>((long long)g->cu_count * 8, (long long)std::max<unsigned long long>(1, budget / std::max<unsigned long long>(per_wg, 1)));
+  grid = std::max<long long>(1, std::min<long long>(grid, count));
+  const size_t need = (size_t)per_wg * (size_t)grid;
+  if (need > g->house_acc_bytes) {
+    if (g->d_house_acc) (void)hipFree(g->d_house_acc);
+    g->d_house_acc = nullptr;
+    g->house_acc_bytes = 0;
+    HIP_TRY(hipMalloc(&g->d_house_acc, need));
+    HIP_TRY(hipMemset(g->d_house_acc, 0, need));  // every launch leaves the maps zeroed again
+    if (g->d_house_touched) (void)hipFree(g->d_house_touched);
+    g->d_house_touched = nullptr;
+    HIP_TRY(hipMalloc(&g->d_house_touched, need / 2));  // one int list per map
+    g->house_acc_bytes = need;
+  }
+  p.acc = g->d_house_acc;
+  p.touched = g->d_house_touched;
+  rc = start_timer(ctx);
+  if (rc) return rc;
+  if (count > 0) HIP_TRY(launch_house_acc(p, (int)grid, ctx.stream));
+  fill_stats(st, (uint64_t)(g->ne / 2 / ctx.world), (uint64_t)count, (int)grid, 256);
+  return end_launch(ctx, FIN_COPY, 0, h_out, 1, st);
+}
+
+// house, flattened over (v0, v1, v3) tasks (house_flat_kernel in gm_mine.hip)
+static int run_house_flat(const gm_graph *cg, const gm_launch *la_in, uint64_t *h_out, gm_stats *st) {
+  LaunchCtx ctx;
+  int rc = begin_launch(cg, la_in, h_out, ctx);
+  if (rc) return rc;
+  gm_graph *g = ctx.g;
+  const gm_launch *la = &ctx.la;
+  GraphView gv;
+  gv.nv = g->nv;
+  gv.ne = (int)g->ne;
+  gv.rp = g->d_rp;
+  gv.col = g->d_col;
+  if (!g->d_house_prefix) {  // once per graph: blocks per entry on the device, prefix on the host
+    OtherSetupScope scope(g);
+    const size_t ne = (size_t)g->ne;
+    unsigned *d_nblk = nullptr;
+    HIP_TRY(hipMalloc(&d_nblk, sizeof(unsigned) * std::max<size_t>(ne, 1)));
+    std::vector<unsigned> nblk(std::max<size_t>(ne, 1));
+    hipError_t e = ne ? launch_house_blocks(gv, d_nblk, 0) : hipSuccess;
+    if (e == hipSuccess) e = hipMemcpy(nblk.data(), d_nblk, sizeof(unsigned) * ne, hipMemcpyDeviceToHost);
+    (void)hipFree(d_nblk);
+    if (e != hipSuccess) return hip_fail(e, "house block table", __FILE__, __LINE__);
+    std::vector<unsigned long long> pre(ne + 1);
+    unsigned long long acc = 0;
+    for (size_t i = 0; i < ne; ++i) { pre[i] = acc; acc += nblk[i]; }
+    pre[ne] = acc;
+    g->n_house_blocks = acc;
+    HIP_TRY(hipMalloc(&g->d_house_prefix, sizeof(unsigned long long) * (ne + 1)));
+    HIP_TRY(hipMemcpy(g->d_house_prefix, pre.data(), sizeof(unsigned long long) * (ne + 1), hipMemcpyHostToDevice));
+  }
+  HouseParams p;
+  memset(&p, 0, sizeof p);
+  p.g = gv;
+  p.entry_prefix = g->d_house_prefix;
+  p.nblocks = g->n_house_blocks;
+  p.group = la->chunk > 0 ? la->chunk : 8;
+  p.no_bits = (la->tune[6] & 0x8000) ? 1 : 0;
+  const long long ngroups = (long long)((p.nblocks + (unsigned long long)p.group - 1) / (unsigned long long)p.group);
+  int64_t first = 0, step = 1, count = 0;
+  gm_partition(ngroups, ctx.rank, ctx.world, la->policy, &first, &step, &count);
+  p.first = (unsigned long long)first;
+  p.step = (unsigned long long)step;
+  p.count = (unsigned long long)count;
+  p.counters = g->d_counters;
+  p.queue = g->d_counters + 4;
+  const int grid = (int)std::max<long long>(1, std::min<long long>((count + 3) / 4, (long long)g->cu_count * 8));
+  rc = start_timer(ctx);
+  if (rc) return rc;
+  if (count > 0 && g->ne > 0) HIP_TRY(launch_house_flat(p, grid, ctx.stream));
+  fill_stats(st, (uint64_t)(g->ne / 2 / ctx.world), (uint64_t)count, grid, 256);
+  return end_launch(ctx, FIN_COPY, 0, h_out, 1, st);
+}
+
+// rectangle / house / pentagon: one wave per symmetry-broken edge (gm_sgl.hip)
+static int run_sgl_nested(int pat, const gm_graph *cg, const gm_launch *la_in, uint64_t *h_out, gm_stats *st) {
+  LaunchCtx ctx;
+  int rc = begin_launch(cg, la_in, h_out, ctx);
+  if (rc) return rc;
+  gm_graph *g = ctx.g;
+  const gm_launch *la = &ctx.la;
+  SglParams p;
+  memset(&p, 0, sizeof p);
+  p.g.nv = g->nv;
+  p.g.ne = (int)g->ne;
+  p.g.rp = g->d_rp;
+  p.g.col = g->d_col;
+  p.chunk = la->chunk > 0 ? la->chunk : 64;
+  const long long nchunks = (g->ne + p.chunk - 1) / p.chunk;
+  int64_t first = 0, step = 1, count = 0;
+  gm_partition(nchunks, ctx.rank, ctx.world, la->policy, &first, &step, &count);
+  p.first = first;
+  p.step = step;
+  p.count = count;
+  p.counters = g->d_counters;
+  p.queue = reinterpret_cast<unsigned *>(g->d_counters + 4);
+  p.max_deg = std::max(g->max_deg, 1);
+  const int grid = (int)std::max<long long>(1, std::min<long long>((count + 3) / 4, (long long)g->cu_count * 8));
+  if (pat == SGL_HOUSE || pat == SGL_DIAMOND) {  // per-wave list for the materialised S = N(v0) ^ N(v1)
+    const size_t need = (size_t)grid * 4 * (size_t)p.max_deg * sizeof(int);
+    if (need > g->scratch_bytes) {
+      if (g->d_scratch) (void)hipFree(g->d_scratch);
+      g->d_scratch = nullptr;
+      g->scratch_bytes = 0;
+      HIP_TRY(hipMalloc(&g->d_scratch, need));
+      g->scratch_bytes = need;
+    }
+    p.scratch = reinterpret_cast<int *>(g->d_scratch);
+  }
+  rc = start_timer(ctx);
+  if (rc) return rc;
+  if (count > 0) HIP_TRY(launch_sgl_nested(pat, p, grid, ctx.stream));
+  fill_stats(st, (uint64_t)(g->ne / 2 / ctx.world), (uint64_t)count, grid, 256);
+  return end_launch(ctx, FIN_COPY, 0, h_out, 1, st);
+}
+
+extern "C" int gm_sgl(const gm_graph *sym, const char *pattern, const gm_launch *la, uint64_t *total, gm_stats *st) {
+  if (!pattern) return GM_ERR_INVALID;
+  if (strcmp(pattern, "diamond") == 0) {
+    // tune[6] & 1024: the LISTING (nested) form of the reference, src/sgl/gpu_kernels/diamond_nested.cuh:4-31 -- materialise
+    // S, count_smaller per member -- as a second implementation; the default counts C(|S|,2) per edge (diamond_count.cuh:15-17)
+    if (la && (la->tune[6] & 1024)) return run_sgl_nested(SGL_DIAMOND, sym, la, total, st);
+    return run_pattern(PAT_DIAMOND, sym, la, 4, total, 1, st);
+  }
+  // rectangle / house / pentagon run on a copy of the graph renumbered by degree (get_relabeled; tune[6] & 512: on the
+  // graph as given). tune[6] & 1024: the wave-per-edge loop nests; & 2048: rectangle as wedges + flat intersections,
+  // house without the LDS S-bitmap (A/B, tests).
+  const bool is_rect = strcmp(pattern, "rectangle") == 0, is_house = strcmp(pattern, "house") == 0, is_pent = strcmp(pattern, "pentagon") == 0;
+  if (is_rect || is_house || is_pent) {
+    if (!sym) return GM_ERR_INVALID;
+    const int t6 = la ? la->tune[6] : 0;
+    gm_graph *self = const_cast<gm_graph *>(sym);
+    const gm_graph *run_on = sym;
+    const bool wedge_form = (is_pent || is_rect) && (t6 & 2048);  // anchored wedges: hubs first; 2-path / (v0,v1,v3) forms: hubs last
+    // house: by wedge accumulation (default; its 2-path count does not depend on the numbering, so no renumbered copy), or
+    // the flattened (v0, v1, v3) form (0x800; 0x8000: without the LDS S-bitmap). The packed map holds 24-bit counts and
+    // 40-bit weighted sums: rows of 2^20 entries or more take the flattened form.
+    const bool house_acc = is_house && !(t6 & (1024 | 2048 | 0x8000)) && sym->max_deg < (1 << 20);
+    if (!(t6 & 512) && !(t6 & 1024) && !house_acc) {
+      gm_graph *r = nullptr;
+      int rc = get_relabeled(self, wedge_form ? 1 : 0, &r);
+      if (rc) return rc;
+      run_on = r;
+    }
+    int rc;
+    if (t6 & 1024) rc = run_sgl_nested(is_rect ? SGL_RECTANGLE : is_house ? SGL_HOUSE : SGL_PENTAGON, run_on, la, total, st);
+    else if (house_acc) rc = run_house_acc(run_on, la, total, st);
+    else if (is_house) rc = run_house_flat(run_on, la, total, st);
+    else if (is_pent && (t6 & 2048)) rc = run_rect_flat(run_on, la, total, st, true);
+    else if (is_pent) rc = run_rect_acc(run_on, la, total, st, true);
+    else if (t6 & 2048) rc = run_rect_flat(run_on, la, total, st);
+    else rc = run_rect_acc(run_on, la, total, st);
+    self->ring_alias = (run_on != sym) ? const_cast<gm_graph *>(run_on) : nullptr;
+    return rc;
+  }
+  if (total) *total = 0;  // "Not implemented", total_num = 0 (src/sgl/omp_base.cc:51-53)
+  return GM_ERR_UNSUPPORTED;
+}
+
+extern "C" int gm_clique(const gm_graph *dag, int k, const gm_launch *la, uint64_t *total, gm_stats *st) {
+  if (k == 3) return run_pattern(PAT_TC, dag, la, 3, total, 1, st);
+  if (k < 3 || k > 8) {
+    if (total) *total = 0;
+    return GM_ERR_INVALID;
+  }
+  if (k > 4 && dag && dag->max_deg > 4096) {  // deeper levels sweep a row with two words per lane (cliquek_count_sub)
+    if (total) *total = 0;
+    g_last_error = "gm_clique: k >= 5 needs max out-degree <= 4096 (this DAG: " + std::to_string(dag->max_deg) + ")";
+    return GM_ERR_TOO_LARGE;
+  }
+  return run_pattern(k == 4 ? PAT_CLIQUE4 : PAT_CLIQUEK, dag, la, k, total, 1, st);
+}
+
+// 4-motif, formula form (src/motif/cpu_kernels/automine_formula.h:21-56 + src/motif/omp_formula.cc:41-45):
+// raw[0..3] = the per-edge sums counter[0], counter[1], counter[2], counter[4] (PAT_MOTIF4E, one |N(v0)^N(v1)| per
+// undirected edge), raw[4] = edge-induced 4-cycles (rectangle kernel), raw[5] = 4-cliques (clique kernel on the cached
+// DAG). Every raw value is a plain sum over tasks, so per-rank partials add up; gm_motif4_finish turns the summed raw
+// values into the six vertex-induced counts.
+// With la->d_counts set the six raw sums are left in that DEVICE buffer (raw[0..3] by the per-edge kernel, raw[4] by the
+// rectangle kernel, raw[5] by the clique kernel, all ordered on la->stream) and nothing synchronises unless `raw` is given
+// too -- this is what feeds the RCCL all-reduce of motif_multigpu.
+extern "C" int gm_motif4_partial(const gm_graph *sym, const gm_launch *la, uint64_t raw[6], gm_stats *st) {
+  if (!sym || (!raw && !(la && la->d_counts))) return GM_ERR_INVALID;
+  gm_graph *g = const_cast<gm_graph *>(sym);
+  gm_launch l2;
+  memset(&l2, 0, sizeof l2);
+  if (la) l2 = *la;
+  uint64_t *d_out = l2.d_counts;
+  if (!g->dag_cache) {
+    gm_graph *dag = nullptr;
+    int rc = gm_graph_orient(sym, &dag);
+    if (rc) return rc;
+    g->dag_cache = dag;
+  }
+  gm_stats s1, s2, s3;
+  memset(&s1, 0, sizeof s1); memset(&s2, 0, sizeof s2); memset(&s3, 0, sizeof s3);
+  l2.d_counts = d_out;
+  int rc = run_pattern(PAT_MOTIF4E, sym, &l2, 4, raw, 4, &s1, FIN_RAW4, 0);
+  if (rc) return rc;
+  const gm_graph *rect_handle = sym;
+  {
+    const gm_graph *rect_on = sym;
+    if (!(l2.tune[6] & 512)) {
+      gm_graph *r = nullptr;
+      rc = get_relabeled(g, (l2.tune[6] & 2048) ? 1 : 0, &r);
+      if (rc) return rc;
+      rect_on = r;
+    }
+    l2.d_counts = d_out ? d_out + 4 : nullptr;
+    rc = (l2.tune[6] & 2048) ? run_rect_flat(rect_on, &l2, raw ? &raw[4] : nullptr, &s2)
+                             : run_rect_acc(rect_on, &l2, raw ? &raw[4] : nullptr, &s2);
+    rect_handle = rect_on;
+  }
+  if (rc) return rc;
+  l2.d_counts = d_out ? d_out + 5 : nullptr;
+  rc = run_pattern(PAT_CLIQUE4, g->dag_cache, &l2, 4, raw ? &raw[5] : nullptr, 1, &s3);
+  if (rc) return rc;
+  if (st) {
+    *st = s1;
+    st->kernel_ms = s1.kernel_ms + s2.kernel_ms + s3.kernel_ms;
+  }
+  g->ring_alias = nullptr;
+  g->ring_extra[0] = (rect_handle != sym) ? rect_handle : nullptr;  // (tune[6] & 512: the rectangle kernel ran on this handle itself)
+  g->ring_extra[1] = g->dag_cache;
+  return GM_OK;
+}
+
+// raw sums -> the six vertex-induced counts (host fix-up of src/motif/omp_formula.cc:41-45, same arithmetic on both sides)
+__host__ __device__ static inline void motif4_finish_math(const unsigned long long *raw, unsigned long long *counts) {
+  const unsigned long long k4 = raw[5];
+  const unsigned long long diamond = raw[3] / 2 - 6 * k4;            // total[4] = total[4]/2 - 6*total[5]
+  const unsigned long long tailed = raw[2] / 2 - 2 * diamond;        // total[2] = total[2]/2 - 2*total[4]
+  const unsigned long long cycle4 = raw[4] - diamond - 3 * k4;       // vertex-induced 4-cycles from the edge-induced count
+  const unsigned long long path4 = raw[1] - 4 * cycle4;              // total[1] = total[1] - 4*total[3]
+  const unsigned long long star3 = raw[0] / 6 - tailed / 3;          // total[0] = total[0]/6 - total[2]/3
+  counts[0] = star3; counts[1] = path4; counts[2] = tailed; counts[3] = cycle4; counts[4] = diamond; counts[5] = k4;
+}
+
+__global__ void motif4_finish_kernel(unsigned long long *__restrict__ c) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  unsigned long long raw[6], out[6];
+  for (int i = 0; i < 6; ++i) raw[i] = c[i];
+  motif4_finish_math(raw, out);
+  for (int i = 0; i < 6; ++i) c[i] = out[i];
+}
+
+extern "C" int gm_motif4_finish(const uint64_t raw[6], uint64_t counts[6]) {
+  if (!raw || !counts) return GM_ERR_INVALID;
+  unsigned long long r[6], c[6];
+  for (int i = 0; i < 6; ++i) r[i] = raw[i];
+  motif4_finish_math(r, c);
+  for (int i = 0; i < 6; ++i) counts[i] = c[i];
+  return GM_OK;
+}
+
+extern "C" int gm_motif(const gm_graph *sym, int k, const gm_launch *la, uint64_t *counts, int ncounts, gm_stats *st) {
+  if (k == 4) {
+    const bool async = la && la->d_counts;  // the asynchronous contract of every solver: counts may be NULL then
+    if (ncounts < 6 || (!counts && !async)) return GM_ERR_INVALID;
+    if (la && la->world > 1) return GM_ERR_UNSUPPORTED;  // multi-GPU: gm_motif4_partial + all-reduce + gm_motif4_finish
+    uint64_t raw[6];
+    int rc = gm_motif4_partial(sym, la, counts ? raw : nullptr, st);
+    if (rc) return rc;
+    if (async) {  // finish in place on the device, ordered on the launch stream
+      hipLaunchKernelGGL(motif4_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)la->stream, (unsigned long long *)la->d_counts);
+      HIP_TRY(hipGetLastError());
+    }
+    return counts ? gm_motif4_finish(raw, counts) : GM_OK;
+  }
+  if (k != 3) return GM_ERR_INVALID;
+  if (ncounts < 2) return GM_ERR_INVALID;
+  return run_pattern(PAT_MOTIF3, sym, la, 3, counts, ncounts, st);
+}
+
+// motif_omp_formula / motif_gpu_formula (src/motif/omp_formula.cc:39-46, cpu_kernels/automine_formula.h:2-19):
+// enumerate only the triangles, derive the wedges: wedges = sum_v C(d(v),2) - 3*T. Here the triangles come from the
+// TC kernel on the oriented graph (built once per handle and cached), so the hub rows of the symmetric graph are
+// never intersected. Counts are identical to gm_motif; with world > 1 the sum_v C(d,2) term is contributed by rank 0
+// and the per-rank partial wedge count is only meaningful after the all-reduce (mod 2^64 arithmetic).
+__global__ __launch_bounds__(256) void sum_c2_kernel(int nv, const int *__restrict__ rp, unsigned long long *__restrict__ out) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  unsigned long long s = 0;
+  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += stride) {
+    const unsigned long long d = (unsigned long long)(rp[v + 1] - rp[v]);
+    s += d * (d - 1) / 2;
+  }
+  s = gm::wave_sum_u64(s);
+  if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
+}
+
+extern "C" int gm_motif_formula(const gm_graph *sym, int k, const gm_launch *la, uint64_t *counts, int ncounts, gm_stats *st) {
+  if (!sym) return GM_ERR_INVALID;
+  if (k != 3) return (k == 4) ? GM_ERR_UNSUPPORTED : GM_ERR_INVALID;
+  if (ncounts < 2) return GM_ERR_INVALID;
+  gm_graph *g = const_cast<gm_graph *>(sym);
+  if (!g->dag_cache) {
+    gm_graph *dag = nullptr;
+    int rc = gm_graph_orient(sym, &dag);
+    if (rc) return rc;
+    g->dag_cache = dag;
+  }
+  if (!g->sum_c2_valid) {  // sum_v C(d(v),2): one reduction kernel over the offsets
+    DevBuf<unsigned long long> acc;
+    HIP_TRY(hipSetDevice(g->device));
+    HIP_TRY(acc.alloc(1));
+    HIP_TRY(hipMemset(acc.p, 0, 8));
+    hipLaunchKernelGGL(sum_c2_kernel, dim3((unsigned)std::min<long long>(((long long)g->nv + 255) / 256, 2048)), dim3(256), 0, 0, g->nv, g->d_rp, acc.p);
+    unsigned long long s2 = 0;
+    HIP_TRY(hipMemcpy(&s2, acc.p, 8, hipMemcpyDeviceToHost));
+    g->sum_c2 = s2;
+    g->sum_c2_valid = true;
+  }
+  const int rank = la ? la->rank : 0;
+  const int rc = run_pattern(PAT_TC, g->dag_cache, la, 3, counts, ncounts, st, FIN_MOTIF3_FORMULA, rank == 0 ? g->sum_c2 : 0ull);
+  g->ring_alias = g->dag_cache;
+  return rc;
+}
+
+// Tooling: the level-2 part of SURVEY.md 8(d)'s ALGORITHMIC bytes of one 4-clique launch,
+//   sum_e [ 8|S1| + sum_{v2 in S1} (4(|S1| + d+(v2)) + 16) ]  =  24*sum|S1| + 4*sum|S1|^2 + 4*sum_{matches} d+(v2),
+// from three sums the mining kernel itself produces (PAT_DAGSTATS). The level-1 part 4*sum_e(d+(v0)+d+(v1)) + 40|E+|
+// is the TC formula (computed by the caller from the CSR arrays).
+extern "C" int gm_clique4_level2_bytes(const gm_graph *dag, uint64_t *bytes) {
+  if (!dag || !bytes) return GM_ERR_INVALID;
+  uint64_t raw[4] = {0, 0, 0, 0};  // raw[0] = sum n^2, raw[1] = sum_{matches} d+(v2), raw[2] = sum n
+  const int rc = run_pattern(PAT_DAGSTATS, dag, nullptr, 4, raw, 4, nullptr, FIN_RAW4, 0);
+  if (rc) return rc;
+  *bytes = 24ull * raw[2] + 4ull * raw[0] + 4ull * raw[1];
+  return GM_OK;
+}
+

@@ -1,0 +1,923 @@
+// gm_tables.hip -- task tables, built on the device: chunk tables (replaces Graph::init_edgelist, src/common/graph.cc:297-326, and the
+// per-GPU COO copies of Scheduler::round_robin, src/common/scheduler.cc:34-85), edge descriptors, the task lists of gm_tct.hip, the
+// two-phase plan of the wide k-clique vertices, and the multi-GPU split as index arithmetic (gm_partition).
+#include "gm_host.h"
+#include "gm_scan.h"
+using namespace gm;
+
+static void free_table(ChunkTable &t) {
+  if (t.d) (void)hipFree(t.d);
+  if (t.d_slot) (void)hipFree(t.d_slot);
+  if (t.d_row_slot && t.own_bitmaps) (void)hipFree(t.d_row_slot);
+  for (int i = 0; i < 2; ++i) if (t.d_order[i]) (void)hipFree(t.d_order[i]);
+  if (t.d_bitmaps && t.own_bitmaps) (void)hipFree(t.d_bitmaps);
+  t.d = nullptr; t.d_slot = nullptr; t.d_row_slot = nullptr; t.d_order[0] = t.d_order[1] = nullptr; t.d_bitmaps = nullptr;
+}
+void free_tables(gm_graph *g) {
+  for (auto &t : g->tables) free_table(t);
+  g->tables.clear();
+}
+
+// ------------------------------------------------------------------------------------------------
+// task chunk tables
+// ------------------------------------------------------------------------------------------------
+// The greedy chunk walk over the vertices [v0, v1): a contiguous run of whole rows is closed when it reaches `target` entries,
+// would exceed the LDS stage (or, k-clique, the bit-matrix budget), spans kMaxChunkVerts rows, or meets a row that is left out /
+// too long for the stage; rows longer than the stage are SPLIT into `target`-entry chunks (allow_split) or chunks of their
+// own. Runs on the host (gm_chunk_table, GM_HOST_TABLES) and, one thread per block of kTableBlock vertices, on the device:
+// the walk restarts at every block boundary, so a table is the same whichever side built it.
+constexpr int kTableBlock = 2048;
+struct ChunkWalk {
+  int target, allow_split, bit_words, stage_cap;
+  RowFilter rf;
+};
+template <class Emit>
+__host__ __device__ inline unsigned long long walk_chunks(const ChunkWalk &w, const int *rp, int v0, int v1, Emit emit) {
+  unsigned long long max_bit_words = 0;
+  int u = v0;
+  while (u < v1) {
+    const int d = rp[u + 1] - rp[u];
+    if (d == 0) { ++u; continue; }
+    if (w.rf.skips(d)) { ++u; continue; }
+    if (d > w.stage_cap) {
+      if (w.allow_split) {
+        for (int s0 = rp[u]; s0 < rp[u + 1]; s0 += w.target) emit(ChunkRec{u, u + 1, s0, min(s0 + w.target, rp[u + 1]), 0, 1, GM_WAVE, 0});
+      } else {
+        emit(ChunkRec{u, u + 1, rp[u], rp[u + 1], 0, 1, GM_WAVE, 0});
+        if (w.bit_words) max_bit_words = max(max_bit_words, (unsigned long long)d * (unsigned long long)((d + 31) / 32));
+      }
+      ++u;
+      continue;
+    }
+    const int start = u;
+    int edges = 0, maxd = 0;
+    while (u < v1 && (u - start) < kMaxChunkVerts) {
+      const int du = rp[u + 1] - rp[u];
+      if (du > w.stage_cap) break;
+      if (w.rf.skips(du) && du > 0) break;
+      if (edges > 0 && edges + du > w.stage_cap) break;
+      if (w.bit_words && edges > 0) {
+        const int nm = max(maxd, du);
+        if ((long long)(edges + du) * ((nm + 31) / 32) > w.bit_words) break;
+      }
+      edges += du;
+      maxd = max(maxd, du);
+      ++u;
+      if (edges >= w.target) break;
+    }
+    if (edges > 0) {
+      emit(ChunkRec{start, u, rp[start], rp[u], 0, 1, GM_WAVE, 0});
+      if (w.bit_words) {
+        const unsigned long long bw = (unsigned long long)edges * (unsigned long long)((maxd + 31) / 32);
+        if (bw > (unsigned long long)w.bit_words) max_bit_words = max(max_bit_words, bw);
+      }
+    } else if (u == start) {
+      ++u;  // (cannot happen: the row at `start` fits the stage and is not filtered)
+    }
+  }
+  return max_bit_words;
+}
+
+static void build_chunks(const std::vector<int> &rp, int nv, int target, bool allow_split, int bit_words, int stage_cap,
+                         std::vector<ChunkRec> &out, unsigned long long &max_bit_words, const RowFilter &rf = RowFilter()) {
+  out.clear();
+  max_bit_words = 0;
+  ChunkWalk w{target, allow_split ? 1 : 0, bit_words, stage_cap, rf};
+  for (int v0 = 0; v0 < nv; v0 += kTableBlock)
+    max_bit_words = std::max(max_bit_words, walk_chunks(w, rp.data(), v0, std::min(v0 + kTableBlock, nv), [&](const ChunkRec &r) { out.push_back(r); }));
+}
+
+// one workgroup per hub row: set bit x for every neighbour x of the row
+__global__ __launch_bounds__(256) void bitmap_build_kernel(const int *__restrict__ rp, const int *__restrict__ col,
+                                                           const int *__restrict__ rows, unsigned *__restrict__ bitmaps,
+                                                           unsigned long long words) {
+  const int u = rows[blockIdx.x];
+  unsigned *bm = bitmaps + (size_t)blockIdx.x * words;
+  for (int i = rp[u] + threadIdx.x; i < rp[u + 1]; i += blockDim.x) {
+    const unsigned x = (unsigned)col[i];
+    atomicOr(&bm[x >> 5], 1u << (x & 31u));
+  }
+}
+
+// one workgroup per chunk: estimated work = keys touched. DAG patterns: sum over the task edges (u, v) of d(u) + d(v);
+// symmetric-graph patterns (owner_rule): only the edges whose longer row is u are tasks here, and each streams the
+// shorter list, d(v) keys (process_chunk's ownership rule).
+__global__ __launch_bounds__(256) void chunk_cost_kernel(const int *__restrict__ rp, const int *__restrict__ col,
+                                                         const ChunkRec *__restrict__ chunks, unsigned long long *__restrict__ cost,
+                                                         int owner_rule, int stage_cap, const int *__restrict__ trp = nullptr,
+                                                         const int2 *__restrict__ tdesc = nullptr) {
+  const ChunkRec r = chunks[blockIdx.x];
+  unsigned long long c = 0;
+  if (owner_rule == 2) {  // gm_tct.hip: the keys of the lists this chunk's vertices host
+    for (int te = trp[r.u_begin] + (int)threadIdx.x; te < trp[r.u_end]; te += 256) c += (unsigned long long)tdesc[te].y + 8ull;
+  } else if (owner_rule) {
+    // a key streamed by a SPLIT chunk is a random probe of the hub row's bitmap in HBM, a key of a staged chunk an LDS filter probe
+    const unsigned long long w = (r.u_end == r.u_begin + 1 && (r.e_begin != rp[r.u_begin] || r.e_end != rp[r.u_end])) ? (unsigned long long)kProbeCost : 1ull;
+    for (int u = r.u_begin; u < r.u_end; ++u) {  // (a SPLIT chunk has one row; a staged chunk few long or many short ones)
+      const int a = rp[u + 1] - rp[u];
+      const int lo = max(rp[u], r.e_begin), hi = min(rp[u + 1], r.e_end);
+      for (int e = lo + (int)threadIdx.x; e < hi; e += 256) {
+        const int v = col[e];
+        const int b = rp[v + 1] - rp[v];
+        if (sym_hosts(a, b, u, v, stage_cap)) c += ((unsigned long long)b + 8ull) * w;  // (X streams N(v) whichever is longer)
+      }
+    }
+  } else {
+    for (int e = r.e_begin + (int)threadIdx.x; e < r.e_end; e += 256) {
+      const int v = col[e];
+      c += (unsigned long long)(rp[v + 1] - rp[v]);
+    }
+    for (int u = r.u_begin + (int)threadIdx.x; u < r.u_end; u += 256) {
+      const int lo = max(rp[u], r.e_begin), hi = min(rp[u + 1], r.e_end);
+      c += (unsigned long long)max(hi - lo, 0) * (unsigned long long)(rp[u + 1] - rp[u]);
+    }
+  }
+  c = gm::wave_sum_u64(c);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(&cost[blockIdx.x], c);
+}
+
+// edges per batch of a chunk: 64, or kSplitBatch in the SPLIT chunks of the symmetric-graph patterns whose task edges stream
+// long lists (estimated keys per entry >= kSplitBatchMinKeys)
+static int batch_edges(const ChunkRec &r, const std::vector<int> &rp, int stage_cap, unsigned long long cost) {
+  const bool whole = r.e_begin == rp[(size_t)r.u_begin] && r.e_end == rp[(size_t)r.u_end];
+  const unsigned long long nel = (unsigned long long)std::max(r.e_end - r.e_begin, 1);
+  // (the one-row chunks of the big-LDS classes are in the same situation as SPLIT chunks: every task edge streams a long list)
+  const bool long_lists = cost / nel >= (unsigned long long)kSplitBatchMinKeys;
+  return ((stage_cap == kStageCapWide && !whole && long_lists) || (stage_cap > kStageCapWide && long_lists)) ? kSplitBatch : GM_WAVE;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Task-chunk table, built on the device. The reference builds its COO task list with a serial host loop
+// (Graph::init_edgelist, src/common/graph.cc:297-326) and round 1 of this library walked the vertices on the host too
+// (~100 ms per table at nv = 2^24, three tables for a symmetric-graph pattern). Here:
+//   greedy walk, one thread per block of kTableBlock vertices (count -> exclusive scan -> emit)  ->  cost kernel  ->
+//   parts (scan + expand)  ->  dequeue orders (stable radix sorts)  ->  hub-row bitmaps (select + scatter)
+// What stays on the host is O(chunks) or O(hub rows): the per-chunk edge prefix, the dequeue orders' host copies.
+// (A fully parallel chunk definition -- short rows grouped by floor(prefix / G) -- was tried first: its groups cannot fill
+// the stage as tightly as the greedy walk, the chunks of a flat graph shrank from ~1024 to ~683 entries and TC on the
+// LiveJournal-size flat graph went from 0.873 to 1.145 ms; profiles/r02/ab_setup_device_tables.log.)
+// ------------------------------------------------------------------------------------------------
+// pass 0: chunks per vertex block (+ the k-clique arena requirement); pass 1: the records, at the block's offset.
+// A workgroup (one wave) owns kWalkPerWG blocks: all 64 lanes copy the blocks' offsets into LDS with coalesced loads (128 KB of
+// the CU's 160 KB), then lanes 0 .. kWalkPerWG-1 each walk one block out of LDS -- the walk is a serial chain of dependent
+// reads, ~30 cycles per vertex from LDS against a memory round trip per cache line from HBM (one thread per block straight
+// from memory: 132 ms for the three 3-motif tables of R-MAT-24; this form: see profiles/r02/ab_setup_device_tables.log).
+constexpr int kWalkPerWG = 16;
+__global__ __launch_bounds__(64) void tab_walk_kernel(ChunkWalk w, int nv, const int *__restrict__ rp, int nblocks, int *__restrict__ count,
+                                                      unsigned long long *__restrict__ max_bw, const int *__restrict__ offset, ChunkRec *__restrict__ recs) {
+  __shared__ int rpl[kWalkPerWG][kTableBlock + 1];  // (row stride 2049 words: the walkers' lanes fall into different banks)
+  const int b0 = blockIdx.x * kWalkPerWG;
+  for (int k = 0; k < kWalkPerWG; ++k) {
+    const int v0 = (b0 + k) * kTableBlock;
+    if (v0 >= nv) break;
+    const int n = min(kTableBlock, nv - v0) + 1;
+    for (int i = threadIdx.x; i < n; i += 64) rpl[k][i] = rp[v0 + i];
+  }
+  __syncthreads();
+  const int k = threadIdx.x, b = b0 + k;
+  if (k >= kWalkPerWG || b > nblocks) return;
+  if (b == nblocks) { if (!recs) count[b] = 0; return; }
+  const int v0 = b * kTableBlock, v1 = min(v0 + kTableBlock, nv);
+  const int *lrp = &rpl[k][0] - v0;  // indexed by the absolute vertex id
+  if (!recs) {
+    int n = 0;
+    const unsigned long long bw = walk_chunks(w, lrp, v0, v1, [&](const ChunkRec &) { ++n; });
+    count[b] = n;
+    if (bw) atomicMax(max_bw, bw);
+  } else {
+    int o = offset[b];
+    walk_chunks(w, lrp, v0, v1, [&](const ChunkRec &r) { recs[o++] = r; });
+  }
+}
+struct TableDevParams {
+  int nv;
+  RowFilter rf;
+};
+__device__ __forceinline__ bool rf_skips(const RowFilter &rf, int d) { return rf.skips(d); }
+// parts and batch sizes per chunk (batch_edges + the part rule of the host path)
+__global__ __launch_bounds__(256) void tab_parts_kernel(int n0, const ChunkRec *__restrict__ recs, const int *__restrict__ rp,
+                                                        const unsigned long long *__restrict__ cost, int stage_cap, unsigned long long cap,
+                                                        int cut, int *__restrict__ np_out, int *__restrict__ bsz_out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > n0) return;
+  if (c == n0) { np_out[c] = 0; return; }
+  const ChunkRec r = recs[c];
+  const bool whole = r.e_begin == rp[r.u_begin] && r.e_end == rp[r.u_end];
+  const unsigned long long nel = (unsigned long long)max(r.e_end - r.e_begin, 1);
+  const bool long_lists = cost[c] / nel >= (unsigned long long)kSplitBatchMinKeys;
+  const int bsz = ((stage_cap == kStageCapWide && !whole && long_lists) || (stage_cap > kStageCapWide && long_lists)) ? kSplitBatch : GM_WAVE;
+  int np = 1;
+  if (cut) {
+    const int batches = (r.e_end - r.e_begin + bsz - 1) / bsz;
+    const int min_batches = stage_cap == kStageCapBig ? 64 : (stage_cap == kStageCapMid ? 32 : 1);
+    const unsigned long long want = cost[c] / cap + (cost[c] % cap != 0);  // (no cost + cap - 1: it wraps for huge caps)
+    np = (int)max(1ull, min((unsigned long long)max(batches / min_batches, 1), want));
+  }
+  np_out[c] = np;
+  bsz_out[c] = bsz;
+}
+__global__ __launch_bounds__(256) void tab_expand_kernel(int n0, const ChunkRec *__restrict__ recs, const unsigned long long *__restrict__ cost,
+                                                         const int *__restrict__ np_in, const int *__restrict__ bsz_in, const int *__restrict__ off,
+                                                         ChunkRec *__restrict__ out, unsigned long long *__restrict__ cost_out,
+                                                         int *__restrict__ edges_out, int *__restrict__ first_vertex) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n0) return;
+  ChunkRec r = recs[c];
+  const int np = np_in[c], bsz = bsz_in[c], nel = r.e_end - r.e_begin;
+  r.nparts = np;
+  r.batch = bsz;
+  for (int qd = 0; qd < np; ++qd) {
+    r.part = qd;
+    int mine = 0;  // task edges of a part = the entries of its batches
+    for (int b = qd; b * bsz < nel; b += np) mine += min(bsz, nel - b * bsz);
+    const int o = off[c] + qd;
+    out[o] = r;
+    cost_out[o] = cost[c] / (unsigned long long)np;
+    edges_out[o] = mine;
+    first_vertex[o] = r.u_begin;
+  }
+}
+__global__ __launch_bounds__(256) void tab_orderkeys_kernel(int n, const unsigned long long *__restrict__ cost, unsigned long long heavy, int classes_only,
+                                                            unsigned long long *__restrict__ key0, unsigned long long *__restrict__ key1, int *__restrict__ iota) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  const unsigned long long x = cost[c];
+  key0[c] = x >= heavy ? (classes_only ? 1ull : x) : 0ull;
+  key1[c] = x;
+  iota[c] = c;
+}
+__global__ __launch_bounds__(256) void tab_hubflag_kernel(TableDevParams q, int bitmap_min_deg, const int *__restrict__ rp, int *__restrict__ flag, int *__restrict__ iota) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= q.nv) return;
+  const int d = rp[v + 1] - rp[v];
+  flag[v] = (d > bitmap_min_deg && !rf_skips(q.rf, d)) ? 1 : 0;
+  iota[v] = v;
+}
+__global__ __launch_bounds__(256) void tab_rowslot_kernel(int nb, const int *__restrict__ rows, int *__restrict__ row_slot) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nb) row_slot[rows[i]] = i;
+}
+__global__ __launch_bounds__(256) void tab_chunkslot_kernel(int n, const ChunkRec *__restrict__ recs, const int *__restrict__ rp, int stage_cap,
+                                                            const int *__restrict__ row_slot, int *__restrict__ slots) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  const ChunkRec r = recs[c];
+  slots[c] = (r.u_end == r.u_begin + 1 && rp[r.u_begin + 1] - rp[r.u_begin] > stage_cap) ? row_slot[r.u_begin] : -1;
+}
+__global__ __launch_bounds__(256) void gather_deg_kernel(int m, const int *__restrict__ verts, const int *__restrict__ rp, int *__restrict__ deg) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) deg[i] = rp[verts[i] + 1] - rp[verts[i]];
+}
+
+static int build_table_device(gm_graph *g, ChunkTable &t, bool sym_table, double &bitmap_ms) {
+  const int nv = g->nv;
+  TableDevParams q;
+  q.nv = nv;
+  q.rf = t.rf;
+  ScanTemp tmp;
+  auto blocks = [](long long n) { return dim3((unsigned)std::max<long long>(1, (n + 255) / 256)); };
+  // the greedy walk, one thread per block of kTableBlock vertices: count, scan, emit
+  ChunkWalk w{t.target, t.allow_split ? 1 : 0, t.bit_words, t.stage_cap, t.rf};
+  const int nblk = (nv + kTableBlock - 1) / kTableBlock;
+  DevBuf<int> bcount, boff;
+  DevBuf<unsigned long long> maxbw;
+  HIP_TRY(bcount.alloc((size_t)nblk + 1));
+  HIP_TRY(boff.alloc((size_t)nblk + 1));
+  HIP_TRY(maxbw.alloc(1));
+  HIP_TRY(hipMemsetAsync(maxbw.p, 0, 8, 0));
+  const dim3 wgrid((unsigned)((nblk + 1 + kWalkPerWG - 1) / kWalkPerWG));
+  hipLaunchKernelGGL(tab_walk_kernel, wgrid, dim3(64), 0, 0, w, nv, g->d_rp, nblk, bcount.p, maxbw.p, (const int *)nullptr, (ChunkRec *)nullptr);
+  HIP_TRY(dev_exclusive_sum(tmp, bcount.p, boff.p, (size_t)nblk + 1));
+  int n0 = 0;
+  HIP_TRY(hipMemcpy(&n0, boff.p + nblk, sizeof(int), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(&t.max_bit_words, maxbw.p, 8, hipMemcpyDeviceToHost));
+  t.n = 0;
+  HIP_TRY(hipMalloc(&t.d, sizeof(ChunkRec)));  // (placeholder, replaced below when the table has chunks)
+  if (n0 == 0) {
+    t.edge_prefix.assign(1, 0ull);
+    return GM_OK;
+  }
+  DevBuf<ChunkRec> recs0;
+  HIP_TRY(recs0.alloc((size_t)n0));
+  hipLaunchKernelGGL(tab_walk_kernel, wgrid, dim3(64), 0, 0, w, nv, g->d_rp, nblk, bcount.p, maxbw.p, (const int *)boff.p, recs0.p);
+  // estimated work per chunk, parts
+  DevBuf<unsigned long long> cost0;
+  HIP_TRY(cost0.alloc((size_t)n0));
+  HIP_TRY(hipMemsetAsync(cost0.p, 0, sizeof(unsigned long long) * (size_t)n0, 0));
+  hipLaunchKernelGGL(chunk_cost_kernel, dim3((unsigned)n0), dim3(256), 0, 0, g->d_rp, g->d_col, recs0.p, cost0.p, t.rf.tct ? 2 : (sym_table ? 1 : 0), kStageCapWide,
+                     g->d_trp, g->d_tdesc);
+  DevBuf<int> np, bsz, off;
+  HIP_TRY(np.alloc((size_t)n0 + 1));
+  HIP_TRY(bsz.alloc((size_t)n0 + 1));
+  HIP_TRY(off.alloc((size_t)n0 + 1));
+  hipLaunchKernelGGL(tab_parts_kernel, blocks(n0 + 1), dim3(256), 0, 0, n0, recs0.p, g->d_rp, cost0.p, t.stage_cap,
+                     std::max<unsigned long long>(t.part_cap, 1), ((t.allow_split || sym_table) && t.part_cap != 0) ? 1 : 0, np.p, bsz.p);  // part_cap 0: never cut
+  HIP_TRY(dev_exclusive_sum(tmp, np.p, off.p, (size_t)n0 + 1));
+  int n = 0;
+  HIP_TRY(hipMemcpy(&n, off.p + n0, sizeof(int), hipMemcpyDeviceToHost));
+  (void)hipFree(t.d);
+  t.d = nullptr;
+  HIP_TRY(hipMalloc(&t.d, sizeof(ChunkRec) * (size_t)n));
+  DevBuf<unsigned long long> cost;
+  DevBuf<int> edges, firstv;
+  HIP_TRY(cost.alloc((size_t)n));
+  HIP_TRY(edges.alloc((size_t)n));
+  HIP_TRY(firstv.alloc((size_t)n));
+  hipLaunchKernelGGL(tab_expand_kernel, blocks(n0), dim3(256), 0, 0, n0, recs0.p, cost0.p, np.p, bsz.p, off.p, t.d, cost.p, edges.p, firstv.p);
+  t.n = (size_t)n;
+  // host views of the per-chunk scalars (O(chunks), not O(vertices)): edges -> prefix, first vertex, cost
+  {
+    std::vector<int> h_edges((size_t)n);
+    t.first_vertex.resize((size_t)n);
+    t.cost.resize((size_t)n);
+    HIP_TRY(hipMemcpy(h_edges.data(), edges.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(t.first_vertex.data(), firstv.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(t.cost.data(), cost.p, sizeof(unsigned long long) * (size_t)n, hipMemcpyDeviceToHost));
+    t.edge_prefix.resize((size_t)n + 1);
+    t.edge_prefix[0] = 0;
+    for (size_t i = 0; i < (size_t)n; ++i) t.edge_prefix[i + 1] = t.edge_prefix[i] + (unsigned long long)h_edges[i];
+  }
+  // dequeue orders: stable descending radix sorts of (key, chunk id)
+  {
+    unsigned long long total_cost = 0;
+    for (auto c : t.cost) total_cost += c;
+    const unsigned long long heavy = 2ull * (total_cost / (unsigned long long)n) + 1ull;
+    DevBuf<unsigned long long> key0, key1, keyo;
+    DevBuf<int> iota;
+    HIP_TRY(key0.alloc((size_t)n));
+    HIP_TRY(key1.alloc((size_t)n));
+    HIP_TRY(keyo.alloc((size_t)n));
+    HIP_TRY(iota.alloc((size_t)n));
+    hipLaunchKernelGGL(tab_orderkeys_kernel, blocks(n), dim3(256), 0, 0, n, cost.p, heavy, sym_table ? 1 : 0, key0.p, key1.p, iota.p);
+    for (int m = 0; m < 2; ++m) {
+      HIP_TRY(hipMalloc(&t.d_order[m], sizeof(int) * (size_t)n));
+      size_t bytes = 0;
+      const unsigned long long *keys = m == 0 ? key0.p : key1.p;
+      HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, bytes, keys, keyo.p, iota.p, t.d_order[m], n));
+      HIP_TRY(tmp.reserve(bytes));
+      HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(tmp.buf.p, bytes, keys, keyo.p, iota.p, t.d_order[m], n));
+      t.order[m].resize((size_t)n);
+      HIP_TRY(hipMemcpy(t.order[m].data(), t.d_order[m], sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+    }
+  }
+  if (t.allow_split) {
+    SetupTimer bm_timer;
+    // Hub rows (longer than the LDS stage, cut into SPLIT chunks) get a dense bitmap over the vertex ids, the longest rows
+    // first, within a memory budget (and a quarter of the free device memory): one probe then replaces a ~17-step bisection
+    // in HBM. The set is cached on the graph and shared by its tables.
+    BitmapSet *bs = nullptr;
+    for (auto &b : g->bitmap_sets)
+      if (b.min_deg == t.bitmap_min_deg && b.rf == t.rf) bs = &b;
+    if (!bs) {
+      BitmapSet nb_set;
+      nb_set.min_deg = t.bitmap_min_deg;
+      nb_set.rf = t.rf;
+      const unsigned long long words = ((unsigned long long)nv + 31ull) / 32ull;
+      DevBuf<int> flag, iota, sel, nsel;
+      HIP_TRY(flag.alloc((size_t)nv));
+      HIP_TRY(iota.alloc((size_t)nv));
+      HIP_TRY(sel.alloc((size_t)nv));
+      HIP_TRY(nsel.alloc(1));
+      hipLaunchKernelGGL(tab_hubflag_kernel, blocks(nv), dim3(256), 0, 0, q, t.bitmap_min_deg, g->d_rp, flag.p, iota.p);
+      size_t bytes = 0;
+      HIP_TRY(hipcub::DeviceSelect::Flagged(nullptr, bytes, iota.p, flag.p, sel.p, nsel.p, nv));
+      HIP_TRY(tmp.reserve(bytes));
+      HIP_TRY(hipcub::DeviceSelect::Flagged(tmp.buf.p, bytes, iota.p, flag.p, sel.p, nsel.p, nv));
+      int m = 0;
+      HIP_TRY(hipMemcpy(&m, nsel.p, sizeof(int), hipMemcpyDeviceToHost));
+      size_t free_b = 0, total_b = 0;
+      (void)hipMemGetInfo(&free_b, &total_b);
+      const unsigned long long budget = std::min<unsigned long long>(kBitmapBudget, free_b / 4);
+      const size_t nb_max = words ? (size_t)(budget / (words * 4ull)) : 0;
+      if (m > 0 && nb_max > 0) {
+        DevBuf<int> degs;
+        HIP_TRY(degs.alloc((size_t)m));
+        hipLaunchKernelGGL(gather_deg_kernel, blocks(m), dim3(256), 0, 0, m, sel.p, g->d_rp, degs.p);
+        std::vector<int> hv((size_t)m), hd((size_t)m);
+        HIP_TRY(hipMemcpy(hv.data(), sel.p, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(hd.data(), degs.p, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost));
+        std::vector<int> idx((size_t)m);  // (hub rows only: thousands at most)
+        for (int i = 0; i < m; ++i) idx[(size_t)i] = i;
+        std::stable_sort(idx.begin(), idx.end(), [&](int a_, int b_) { return hd[(size_t)a_] > hd[(size_t)b_]; });
+        const size_t nb = std::min<size_t>((size_t)m, nb_max);
+        std::vector<int> rows(nb);
+        for (size_t i = 0; i < nb; ++i) rows[i] = hv[(size_t)idx[i]];
+        DevBuf<int> d_rows;
+        DevBuf<int> row_slot;
+        DevBuf<unsigned> bitmaps;
+        HIP_TRY(d_rows.alloc(nb));
+        HIP_TRY(hipMemcpy(d_rows.p, rows.data(), sizeof(int) * nb, hipMemcpyHostToDevice));
+        HIP_TRY(row_slot.alloc((size_t)nv));
+        HIP_TRY(hipMemsetAsync(row_slot.p, 0xff, sizeof(int) * (size_t)nv, 0));  // -1
+        hipLaunchKernelGGL(tab_rowslot_kernel, blocks((long long)nb), dim3(256), 0, 0, (int)nb, d_rows.p, row_slot.p);
+        HIP_TRY(bitmaps.alloc((size_t)nb * (size_t)words));
+        HIP_TRY(hipMemsetAsync(bitmaps.p, 0, (size_t)nb * (size_t)words * 4, 0));
+        hipLaunchKernelGGL(bitmap_build_kernel, dim3((unsigned)nb), dim3(256), 0, 0, g->d_rp, g->d_col, d_rows.p, bitmaps.p, words);
+        HIP_TRY(hipDeviceSynchronize());  // (the set is published only after its kernels have succeeded)
+        nb_set.d_bitmaps = bitmaps.release();
+        nb_set.d_row_slot = row_slot.release();
+        nb_set.n = nb;
+        nb_set.words = words;
+      }
+      g->bitmap_sets.push_back(nb_set);
+      bs = &g->bitmap_sets.back();
+    }
+    if (bs->n > 0) {
+      t.own_bitmaps = false;
+      t.d_bitmaps = bs->d_bitmaps;
+      t.d_row_slot = bs->d_row_slot;
+      t.n_bitmaps = bs->n;
+      t.bitmap_words = bs->words;
+      HIP_TRY(hipMalloc(&t.d_slot, sizeof(int) * (size_t)n));
+      hipLaunchKernelGGL(tab_chunkslot_kernel, blocks(n), dim3(256), 0, 0, n, t.d, g->d_rp, t.stage_cap, t.d_row_slot, t.d_slot);
+    }
+    bitmap_ms = bm_timer.ms();
+  }
+  HIP_TRY(hipGetLastError());  // (the setup kernels above are launched unchecked)
+  HIP_TRY(hipDeviceSynchronize());
+  return GM_OK;
+}
+
+int get_table(gm_graph *g, int target, bool allow_split, int bit_words, unsigned long long part_cap, int stage_cap,
+              ChunkTable **out, const RowFilter &rf, int bitmap_min_deg) {
+  std::lock_guard<std::mutex> lk(g->mu);
+  for (auto &t : g->tables)
+    if (t.target == target && t.allow_split == allow_split && t.bit_words == bit_words && t.part_cap == part_cap && t.stage_cap == stage_cap &&
+        t.rf == rf && t.bitmap_min_deg == bitmap_min_deg) { *out = &t; return GM_OK; }
+  SetupTimer timer;
+  double bitmap_ms = 0;
+  const bool sym_table = stage_cap >= kStageCapWide;  // a table of the symmetric-graph patterns (general, mid or big class)
+  std::vector<ChunkRec> recs;
+  ChunkTable t;
+  t.target = target;
+  t.allow_split = allow_split;
+  t.bit_words = bit_words;
+  t.part_cap = part_cap;
+  t.stage_cap = stage_cap;
+  t.rf = rf;
+  t.bitmap_min_deg = bitmap_min_deg;
+  if (!getenv("GM_HOST_TABLES")) {  // (GM_HOST_TABLES: the same walk in a host loop over the vertices, kept for A/B)
+    HIP_TRY(hipSetDevice(g->device));
+    int rc = build_table_device(g, t, sym_table, bitmap_ms);
+    if (rc) { free_table(t); return rc; }  // (a partially built table owns device memory: out-of-memory on a large graph must not leak it)
+    if (getenv("GM_TABLE_INFO")) {
+      unsigned long long tc = 0, mx = 0;
+      for (auto c : t.cost) { tc += c; mx = std::max(mx, c); }
+      fprintf(stderr, "[table/device] stage_cap %d rows (%d,%d] skip (%d,%d]: %zu chunks, est. keys %.3e (max chunk %.3e), %zu bitmaps, edges %llu, %.2f ms\n",
+              stage_cap, rf.only_lo, rf.only_hi, rf.skip_lo, rf.skip_hi, t.n, (double)tc, (double)mx, t.n_bitmaps, t.edge_prefix.back(), timer.ms());
+    }
+    g->setup.bitmap_ms += bitmap_ms;
+    g->setup.table_ms += timer.ms() - bitmap_ms;
+    g->tables.push_back(std::move(t));
+    *out = &g->tables.back();
+    return GM_OK;
+  }
+  {
+    int rc = host_rp(g, nullptr);
+    if (rc) return rc;
+  }
+  build_chunks(g->h_rp, g->nv, target, allow_split, bit_words, stage_cap, recs, t.max_bit_words, rf);
+  // estimated work per chunk (device), then: cut the heavy ones into parts, and fix the dequeue orders
+  std::vector<unsigned long long> cost(recs.size());
+  if (!recs.empty()) {
+    ChunkRec *d_tmp = nullptr;
+    unsigned long long *d_cost = nullptr;
+    hipError_t e = hipMalloc(&d_tmp, sizeof(ChunkRec) * recs.size());
+    if (e == hipSuccess) e = hipMalloc(&d_cost, sizeof(unsigned long long) * recs.size());
+    if (e == hipSuccess) e = hipMemcpy(d_tmp, recs.data(), sizeof(ChunkRec) * recs.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(d_cost, 0, sizeof(unsigned long long) * recs.size());
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(chunk_cost_kernel, dim3((unsigned)recs.size()), dim3(256), 0, 0, g->d_rp, g->d_col, d_tmp, d_cost,
+                         sym_table ? 1 : 0, kStageCapWide);
+      e = hipMemcpy(cost.data(), d_cost, sizeof(unsigned long long) * recs.size(), hipMemcpyDeviceToHost);
+    }
+    if (d_tmp) (void)hipFree(d_tmp);
+    if (d_cost) (void)hipFree(d_cost);
+    if (e != hipSuccess) return hip_fail(e, "chunk_cost_kernel", __FILE__, __LINE__);
+  }
+  if ((allow_split || sym_table) && part_cap != 0) {  // (clique chunks are never cut: their second phase needs the whole bit-matrix; part_cap 0: never)
+    const unsigned long long cap = std::max<unsigned long long>(part_cap, 1);
+    std::vector<ChunkRec> cut;
+    std::vector<unsigned long long> cut_cost;
+    cut.reserve(recs.size());
+    cut_cost.reserve(recs.size());
+    for (size_t i = 0; i < recs.size(); ++i) {
+      const int bsz = batch_edges(recs[i], g->h_rp, stage_cap, cost[i]);
+      const int batches = (recs[i].e_end - recs[i].e_begin + bsz - 1) / bsz;
+      // a part must keep every wave of its workgroup busy for several batches: the 16-wave class takes batches of 4 edges
+      // (its rows' partners are thousands of keys long) and parts of >= 64 batches, the 4-wave classes parts of >= 16
+      const int min_batches = stage_cap == kStageCapBig ? 64 : (stage_cap == kStageCapMid ? 32 : 1);
+      const int np = (int)std::max<unsigned long long>(1, std::min<unsigned long long>((unsigned long long)std::max(batches / min_batches, 1), cost[i] / cap + (cost[i] % cap != 0)));
+      for (int q = 0; q < np; ++q) {
+        ChunkRec r = recs[i];
+        r.part = q;
+        r.nparts = np;
+        r.batch = bsz;
+        cut.push_back(r);
+        cut_cost.push_back(cost[i] / (unsigned long long)np);
+      }
+    }
+    recs.swap(cut);
+    cost.swap(cut_cost);
+  }
+  t.cost = cost;
+  t.n = recs.size();
+  t.first_vertex.resize(t.n);
+  for (size_t i = 0; i < t.n; ++i) t.first_vertex[i] = recs[i].u_begin;
+  t.edge_prefix.resize(t.n + 1);
+  t.edge_prefix[0] = 0;
+  for (size_t i = 0; i < t.n; ++i) {  // task edges of a part = the entries of its batches
+    const int nel = recs[i].e_end - recs[i].e_begin, np = recs[i].nparts;
+    unsigned long long mine = 0;
+    const int bsz = recs[i].batch;
+    for (int b = recs[i].part; b * bsz < nel; b += np) mine += (unsigned long long)std::min(bsz, nel - b * bsz);
+    t.edge_prefix[i + 1] = t.edge_prefix[i] + mine;
+  }
+  HIP_TRY(hipMalloc(&t.d, sizeof(ChunkRec) * std::max<size_t>(t.n, 1)));
+  if (t.n) HIP_TRY(hipMemcpy(t.d, recs.data(), sizeof(ChunkRec) * t.n, hipMemcpyHostToDevice));
+  if (t.n) {
+    // Longest-processing-time-first dequeue order: the dynamic queue then ends on light chunks, so the tail of a launch
+    // (which does not shrink with the number of ranks) stays short; rank r of n owns every n-th entry of this order.
+    unsigned long long total_cost = 0;
+    for (size_t i = 0; i < t.n; ++i) total_cost += cost[i];
+    const unsigned long long heavy = 2ull * (total_cost / t.n) + 1ull;
+    for (int m = 0; m < 2; ++m) {
+      std::vector<int> &o = t.order[m];
+      o.resize(t.n);
+      for (size_t i = 0; i < t.n; ++i) o[i] = (int)i;
+      // order 0 of the symmetric-graph tables keeps chunk-id order INSIDE the heavy class as well: the heavy chunks are the
+      // SPLIT chunks of the hub rows, and consecutive chunks of one row probe the same bitmap -- run together they keep it
+      // in L2 (R-MAT-22 diamond: by cost 47.8 ms, by id 39.5 ms)
+      const bool classes_only = (m == 0) && sym_table;
+      std::stable_sort(o.begin(), o.end(), [&](int a, int b) {
+        unsigned long long ca = cost[(size_t)a], cb = cost[(size_t)b];
+        if (m == 0) { ca = ca >= heavy ? (classes_only ? 1ull : ca) : 0ull; cb = cb >= heavy ? (classes_only ? 1ull : cb) : 0ull; }
+        return ca > cb;
+      });
+      HIP_TRY(hipMalloc(&t.d_order[m], sizeof(int) * t.n));
+      HIP_TRY(hipMemcpy(t.d_order[m], o.data(), sizeof(int) * t.n, hipMemcpyHostToDevice));
+    }
+  }
+  if (allow_split) {
+    SetupTimer bm_timer;
+    // Hub rows (longer than the LDS stage, cut into SPLIT chunks) get a dense bitmap over the vertex ids, the
+    // longest rows first, within a memory budget: one probe then replaces a ~17-step bisection in HBM.
+    const unsigned long long words = ((unsigned long long)g->nv + 31ull) / 32ull;
+    const unsigned long long budget_bytes = kBitmapBudget;
+    std::vector<std::pair<int, int>> big;  // (degree, vertex)
+    for (int v = 0; v < g->nv; ++v) {
+      const int d = g->h_rp[v + 1] - g->h_rp[v];
+      if (d > bitmap_min_deg && !rf.skips(d)) big.push_back({d, v});
+    }
+    std::sort(big.begin(), big.end(), [](const std::pair<int, int> &x, const std::pair<int, int> &y) { return x.first > y.first; });
+    const size_t nb = words ? std::min<size_t>(big.size(), (size_t)(budget_bytes / (words * 4ull))) : 0;
+    if (nb > 0) {
+      std::vector<int> slot_of_row;  // sparse map through a sorted vector
+      std::vector<std::pair<int, int>> row_slot(nb);
+      std::vector<int> rows(nb);
+      for (size_t i = 0; i < nb; ++i) { row_slot[i] = {big[i].second, (int)i}; rows[i] = big[i].second; }
+      std::sort(row_slot.begin(), row_slot.end());
+      std::vector<int> slots(t.n, -1);
+      for (size_t c = 0; c < t.n; ++c) {
+        const ChunkRec &r = recs[c];
+        if (r.u_end == r.u_begin + 1 && (g->h_rp[r.u_begin + 1] - g->h_rp[r.u_begin]) > stage_cap) {
+          auto it = std::lower_bound(row_slot.begin(), row_slot.end(), std::make_pair(r.u_begin, -1));
+          if (it != row_slot.end() && it->first == r.u_begin) slots[c] = it->second;
+        }
+      }
+      HIP_TRY(hipMalloc(&t.d_slot, sizeof(int) * t.n));
+      HIP_TRY(hipMemcpy(t.d_slot, slots.data(), sizeof(int) * t.n, hipMemcpyHostToDevice));
+      {
+        std::vector<int> by_vertex((size_t)g->nv, -1);
+        for (size_t i = 0; i < nb; ++i) by_vertex[(size_t)rows[i]] = (int)i;
+        HIP_TRY(hipMalloc(&t.d_row_slot, sizeof(int) * (size_t)g->nv));
+        HIP_TRY(hipMemcpy(t.d_row_slot, by_vertex.data(), sizeof(int) * (size_t)g->nv, hipMemcpyHostToDevice));
+      }
+      HIP_TRY(hipMalloc(&t.d_bitmaps, (size_t)nb * (size_t)words * 4));
+      HIP_TRY(hipMemset(t.d_bitmaps, 0, (size_t)nb * (size_t)words * 4));
+      int *d_rows = nullptr;
+      HIP_TRY(hipMalloc(&d_rows, sizeof(int) * nb));
+      HIP_TRY(hipMemcpy(d_rows, rows.data(), sizeof(int) * nb, hipMemcpyHostToDevice));
+      hipLaunchKernelGGL(bitmap_build_kernel, dim3((unsigned)nb), dim3(256), 0, 0, g->d_rp, g->d_col, d_rows, t.d_bitmaps, words);
+      hipError_t e = hipDeviceSynchronize();
+      (void)hipFree(d_rows);
+      if (e != hipSuccess) return hip_fail(e, "bitmap_build_kernel", __FILE__, __LINE__);
+      t.n_bitmaps = nb;
+      t.bitmap_words = words;
+    }
+    bitmap_ms = bm_timer.ms();
+  }
+  HIP_TRY(hipDeviceSynchronize());
+  if (getenv("GM_TABLE_INFO")) {  // diagnostics
+    unsigned long long tc = 0, mx = 0;
+    for (auto c : t.cost) { tc += c; mx = std::max(mx, c); }
+    fprintf(stderr, "[table] stage_cap %d rows (%d,%d] skip (%d,%d]: %zu chunks, est. keys %.3e (max chunk %.3e), %zu bitmaps, edges %llu\n", stage_cap,
+            rf.only_lo, rf.only_hi, rf.skip_lo, rf.skip_hi, t.n, (double)tc, (double)mx, t.n_bitmaps, t.edge_prefix.empty() ? 0ull : t.edge_prefix.back());
+  }
+  g->setup.bitmap_ms += bitmap_ms;
+  g->setup.table_ms += timer.ms() - bitmap_ms;
+  g->tables.push_back(std::move(t));
+  *out = &g->tables.back();
+  return GM_OK;
+}
+
+// Edge descriptors (GraphView::edesc): one gather pass over the CSR, once per graph -- the device-side counterpart of
+// Graph::init_edgelist (src/common/graph.cc:297-326), which builds the reference's COO task list serially on the host.
+__global__ __launch_bounds__(256) void edesc_kernel(long long ne, const int *__restrict__ rp, const int *__restrict__ col, int2 *__restrict__ out) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += stride) {
+    const int v = col[e];
+    const int r = rp[v];
+    out[e] = make_int2(r, rp[v + 1] - r);
+  }
+}
+
+// ---- task lists of gm_tct.hip: every edge u -> v of the DAG is a task of the endpoint with the longer out-list -------------------
+__global__ __launch_bounds__(256) void task_keys_kernel(int nv, long long ne, const int *__restrict__ rp, const int *__restrict__ col,
+                                                         unsigned long long *__restrict__ keys, int *__restrict__ cnt, int stage_max) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += stride) {
+    int lo = 0, hi = nv - 1;  // the row of entry e: largest u with rp[u] <= e
+    while (lo < hi) {
+      const int mid = (int)(((long long)lo + hi + 1) >> 1);
+      if (rp[mid] <= e) lo = mid; else hi = mid - 1;
+    }
+    const int u = lo, v = col[e];
+    const int du = rp[u + 1] - rp[u], dv = rp[v + 1] - rp[v];
+    if (du > stage_max) {  // a row the stage cannot take hosts nothing: its out-edges stay with the chunked kernel (run_pattern)
+      keys[e] = ~0ull;     // (sorts behind every task)
+      continue;
+    }
+    const bool u_hosts = dv > stage_max || du >= dv;  // the longer list hosts (ties: the source) -- unless it does not fit the stage
+    const int host = u_hosts ? u : v, partner = u_hosts ? v : u;
+    keys[e] = ((unsigned long long)(unsigned)host << 32) | (unsigned)partner;
+    atomicAdd(&cnt[host], 1);
+  }
+}
+__global__ __launch_bounds__(256) void task_desc_kernel(long long ne, const int *__restrict__ rp, const unsigned long long *__restrict__ sorted,
+                                                         int2 *__restrict__ tdesc) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += stride) {
+    if (sorted[e] == ~0ull) { tdesc[e] = make_int2(0, 0); continue; }  // (the out-edges of rows beyond the stage: not tasks)
+    const int y = (int)(unsigned)(sorted[e] & 0xffffffffull);
+    const int r = rp[y];
+    tdesc[e] = make_int2(r, rp[y + 1] - r);
+  }
+}
+int ensure_tasklists(gm_graph *g) {
+  if (g->d_tdesc || g->ne == 0) return GM_OK;
+  std::lock_guard<std::mutex> lk(g->mu);
+  if (g->d_tdesc) return GM_OK;
+  SetupTimer timer;
+  HIP_TRY(hipSetDevice(g->device));
+  const size_t ne = (size_t)g->ne, nv1 = (size_t)g->nv + 1;
+  DevBuf<unsigned long long> keys, sorted;
+  DevBuf<int> cnt;
+  ScanTemp tmp;
+  HIP_TRY(keys.alloc(ne));
+  HIP_TRY(sorted.alloc(ne));
+  HIP_TRY(cnt.alloc(nv1));
+  HIP_TRY(hipMemset(cnt.p, 0, sizeof(int) * nv1));
+  const long long blocks = std::min<long long>(((long long)ne + 255) / 256, (long long)g->cu_count * 32);
+  hipLaunchKernelGGL(task_keys_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, g->nv, g->ne, g->d_rp, g->d_col, keys.p, cnt.p, kTctStageMax);
+  int bits = 1;
+  while (bits < 32 && (1ll << bits) < (long long)g->nv) ++bits;
+  size_t bytes = 0;
+  const int end_bit = g->max_deg > kTctStageMax ? 64 : 32 + bits;  // (the all-ones keys of excluded edges need every bit)
+  HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, keys.p, sorted.p, (int)ne, 0, end_bit));
+  HIP_TRY(tmp.reserve(bytes));
+  HIP_TRY(hipcub::DeviceRadixSort::SortKeys(tmp.buf.p, bytes, keys.p, sorted.p, (int)ne, 0, end_bit));
+  int *trp = nullptr;
+  int2 *td = nullptr;
+  HIP_TRY(hipMalloc(&trp, sizeof(int) * nv1));
+  hipError_t e = dev_exclusive_sum(tmp, cnt.p, trp, nv1);
+  if (e == hipSuccess) e = hipMalloc(&td, sizeof(int2) * ne);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(task_desc_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, g->ne, g->d_rp, sorted.p, td);
+    e = hipDeviceSynchronize();
+  }
+  if (e != hipSuccess) { (void)hipFree(trp); if (td) (void)hipFree(td); return hip_fail(e, "task lists", __FILE__, __LINE__); }
+  g->d_trp = trp;
+  g->d_tdesc = td;
+  g->setup.table_ms += timer.ms();
+  return GM_OK;
+}
+
+int ensure_edesc(gm_graph *g) {
+  if (g->d_edesc || g->ne == 0) return GM_OK;
+  std::lock_guard<std::mutex> lk(g->mu);
+  if (g->d_edesc) return GM_OK;
+  SetupTimer timer;
+  int2 *d = nullptr;
+  HIP_TRY(hipMalloc(&d, sizeof(int2) * (size_t)g->ne));
+  const long long blocks = std::min<long long>((g->ne + 255) / 256, (long long)g->cu_count * 32);
+  hipLaunchKernelGGL(edesc_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, g->ne, g->d_rp, g->d_col, d);
+  hipError_t e = hipDeviceSynchronize();
+  if (e != hipSuccess) { (void)hipFree(d); return hip_fail(e, "edesc_kernel", __FILE__, __LINE__); }
+  g->d_edesc = d;
+  g->setup.table_ms += timer.ms();
+  return GM_OK;
+}
+
+// k-clique, wide vertices (see gm_mine.h): the plan of one rank's share -- which wide vertices it owns (every world-th of
+// the list sorted by row length, or a contiguous range), where each one's matrix sits in the arena, the row-group chunks of
+// phase 1 and the slots per count class of phase 2. The arena is bounded (GM_WIDE_ARENA_MB, default 16 GiB): a share whose
+// matrices need more is processed in several ROUNDS that reuse it.
+#ifndef GM_WIDE_MIN_WORDS_DEFAULT
+#define GM_WIDE_MIN_WORDS_DEFAULT kBitWords
+#endif
+#ifndef GM_WIDE_ARENA_MB
+#define GM_WIDE_ARENA_MB 16384
+#endif
+__global__ __launch_bounds__(256) void wide_flag_kernel(int nv, const int *__restrict__ rp, int min_words, int *__restrict__ flag, int *__restrict__ iota) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nv) return;
+  flag[v] = clique_is_wide(rp[v + 1] - rp[v], min_words) ? 1 : 0;
+  iota[v] = v;
+}
+// this rank's share of the sorted wide list: slot i = entry first + i * step
+__global__ __launch_bounds__(256) void wide_share_kernel(int count, long long first, long long step, const int *__restrict__ wide_sorted,
+                                                         const int *__restrict__ rp, int *__restrict__ verts, int *__restrict__ degs, int *__restrict__ ngroups) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > count) return;
+  if (i == count) { ngroups[i] = 0; return; }
+  const int u = wide_sorted[first + (long long)i * step];
+  const int d = rp[u + 1] - rp[u];
+  verts[i] = u;
+  degs[i] = d;
+  const int R = clique_group_rows(d);
+  ngroups[i] = (d + R - 1) / R;
+}
+__global__ __launch_bounds__(256) void wide_groups_kernel(int count, const int *__restrict__ verts, const int *__restrict__ rp, const int *__restrict__ goff,
+                                                          int batch, ChunkRec *__restrict__ chunks) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const int u = verts[i], b = rp[u], d = rp[u + 1] - b, R = clique_group_rows(d);
+  int o = goff[i];
+  for (int g0 = 0; g0 < d; g0 += R) chunks[o++] = {u, u + 1, b + g0, b + min(g0 + R, d), 0, 1, batch, i + 1};
+}
+
+int clique_wide_min_words() {
+  static const int v = [] {
+    const char *e = getenv("GM_WIDE_MIN_WORDS");  // (sweeps; read once: tables and plans are cached per graph)
+    return e ? std::max(64, std::min(atoi(e), kBitWords)) : GM_WIDE_MIN_WORDS_DEFAULT;
+  }();
+  return v;
+}
+
+int get_wide_plan(gm_graph *g, int rank, int world, int policy, WidePlan **out) {
+  std::lock_guard<std::mutex> lk(g->mu);
+  SetupTimer timer;
+  HIP_TRY(hipSetDevice(g->device));
+  ScanTemp tmp;
+  auto blocks = [](long long n) { return dim3((unsigned)std::max<long long>(1, (n + 255) / 256)); };
+  if (!g->wide_valid) {  // once per graph: the wide vertices, longest rows first (select + stable radix sort by row length)
+    const int nv = g->nv;
+    DevBuf<int> flag, iota, sel, nsel, degs, keyo;
+    HIP_TRY(flag.alloc((size_t)nv));
+    HIP_TRY(iota.alloc((size_t)nv));
+    HIP_TRY(sel.alloc((size_t)nv));
+    HIP_TRY(nsel.alloc(1));
+    hipLaunchKernelGGL(wide_flag_kernel, blocks(nv), dim3(256), 0, 0, nv, g->d_rp, clique_wide_min_words(), flag.p, iota.p);
+    size_t bytes = 0;
+    HIP_TRY(hipcub::DeviceSelect::Flagged(nullptr, bytes, iota.p, flag.p, sel.p, nsel.p, nv));
+    HIP_TRY(tmp.reserve(bytes));
+    HIP_TRY(hipcub::DeviceSelect::Flagged(tmp.buf.p, bytes, iota.p, flag.p, sel.p, nsel.p, nv));
+    int m = 0;
+    HIP_TRY(hipMemcpy(&m, nsel.p, sizeof(int), hipMemcpyDeviceToHost));
+    g->n_wide = (size_t)m;
+    if (m > 0) {
+      HIP_TRY(degs.alloc((size_t)m));
+      HIP_TRY(keyo.alloc((size_t)m));
+      hipLaunchKernelGGL(gather_deg_kernel, blocks(m), dim3(256), 0, 0, m, sel.p, g->d_rp, degs.p);
+      HIP_TRY(hipMalloc(&g->d_wide_sorted, sizeof(int) * (size_t)m));
+      bytes = 0;
+      HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, bytes, degs.p, keyo.p, sel.p, g->d_wide_sorted, m));
+      HIP_TRY(tmp.reserve(bytes));
+      HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(tmp.buf.p, bytes, degs.p, keyo.p, sel.p, g->d_wide_sorted, m));
+    }
+    g->wide_valid = true;
+  }
+  for (auto &pl : g->wide_plans)
+    if (pl.rank == rank && pl.world == world && pl.policy == policy) { *out = &pl; return GM_OK; }
+  WidePlan pl;
+  pl.rank = rank; pl.world = world; pl.policy = policy;
+  int64_t first = 0, step = 1, count = 0;
+  gm_partition((int64_t)g->n_wide, rank, world, policy, &first, &step, &count);
+  if (count > 0) {
+    DevBuf<int> degs, ngroups, goff;
+    HIP_TRY(hipMalloc(&pl.d_verts, sizeof(int) * (size_t)count));
+    HIP_TRY(degs.alloc((size_t)count));
+    HIP_TRY(ngroups.alloc((size_t)count + 1));
+    HIP_TRY(goff.alloc((size_t)count + 1));
+    hipLaunchKernelGGL(wide_share_kernel, blocks(count + 1), dim3(256), 0, 0, (int)count, (long long)first, (long long)step, g->d_wide_sorted, g->d_rp,
+                       pl.d_verts, degs.p, ngroups.p);
+    HIP_TRY(dev_exclusive_sum(tmp, ngroups.p, goff.p, (size_t)count + 1));
+    int nchunks = 0;
+    HIP_TRY(hipMemcpy(&nchunks, goff.p + count, sizeof(int), hipMemcpyDeviceToHost));
+    pl.n_chunks = (size_t)nchunks;
+    HIP_TRY(hipMalloc(&pl.d_chunks, sizeof(ChunkRec) * (size_t)std::max(nchunks, 1)));
+    const int build_batch = kBuildBatchRows;
+    hipLaunchKernelGGL(wide_groups_kernel, blocks(count), dim3(256), 0, 0, (int)count, pl.d_verts, g->d_rp, goff.p, build_batch, pl.d_chunks);
+    // host part, O(wide vertices of this share): arena offsets, rounds within the arena budget, count classes
+    pl.verts.resize((size_t)count);
+    std::vector<int> hd((size_t)count), hgoff((size_t)count + 1);
+    HIP_TRY(hipMemcpy(pl.verts.data(), pl.d_verts, sizeof(int) * (size_t)count, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hd.data(), degs.p, sizeof(int) * (size_t)count, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hgoff.data(), goff.p, sizeof(int) * ((size_t)count + 1), hipMemcpyDeviceToHost));
+    unsigned long long arena_mb = GM_WIDE_ARENA_MB;
+    if (const char *e = getenv("GM_WIDE_ARENA_MB")) arena_mb = std::max(1ll, atoll(e));  // (tests: force several rounds)
+    const unsigned long long budget_words = (arena_mb << 20) / 4ull;
+    std::vector<unsigned long long> base((size_t)count);
+    std::vector<int> cls_slots;
+    size_t s0 = 0;
+    while (s0 < (size_t)count) {
+      WidePlan::Round rd;
+      rd.chunk_begin = (size_t)hgoff[s0];
+      size_t s1 = s0;
+      unsigned long long words = 0;
+      std::vector<int> by_cls[3];
+      for (; s1 < (size_t)count; ++s1) {
+        const int d = hd[s1];
+        const unsigned long long w = (unsigned long long)d * (unsigned long long)((d + 31) / 32);
+        if (s1 > s0 && words + w > budget_words) break;
+        base[s1] = words;
+        words += w;
+        pl.edges += (unsigned long long)d;
+        by_cls[clique_count_class(d)].push_back((int)s1);
+      }
+      rd.chunk_end = (size_t)hgoff[s1];
+      rd.words = words;
+      for (int c = 0; c < 3; ++c) {
+        rd.cls_begin[c] = cls_slots.size();
+        cls_slots.insert(cls_slots.end(), by_cls[c].begin(), by_cls[c].end());
+      }
+      rd.cls_begin[3] = cls_slots.size();
+      pl.rounds.push_back(rd);
+      s0 = s1;
+    }
+    HIP_TRY(hipMalloc(&pl.d_base, sizeof(unsigned long long) * base.size()));
+    HIP_TRY(hipMemcpy(pl.d_base, base.data(), sizeof(unsigned long long) * base.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&pl.d_cls_slots, sizeof(int) * cls_slots.size()));
+    HIP_TRY(hipMemcpy(pl.d_cls_slots, cls_slots.data(), sizeof(int) * cls_slots.size(), hipMemcpyHostToDevice));
+    unsigned long long need_words = 0;
+    for (auto &rd : pl.rounds) need_words = std::max(need_words, rd.words);
+    const size_t need = (size_t)need_words * 4;
+    if (need > g->wide_mat_bytes) {
+      if (g->d_wide_mat) (void)hipFree(g->d_wide_mat);
+      g->d_wide_mat = nullptr;
+      g->wide_mat_bytes = 0;
+      HIP_TRY(hipMalloc(&g->d_wide_mat, need));
+      g->wide_mat_bytes = need;
+    }
+    if (!g->d_wide_queue) HIP_TRY(hipMalloc(&g->d_wide_queue, 65536));
+    HIP_TRY(hipDeviceSynchronize());
+  }
+  g->wide_plans.push_back(std::move(pl));
+  *out = &g->wide_plans.back();
+  g->setup.table_ms += timer.ms();
+  return GM_OK;
+}
+
+// Scheduler policy as index arithmetic on chunk ids (replaces the per-GPU COO copies of
+// Scheduler::round_robin, src/common/scheduler.cc:34-85, and EVEN_SPLIT, src/clique/multigpu.cu:42-44).
+extern "C" int gm_partition(int64_t n_chunks, int32_t rank, int32_t world, int32_t policy, int64_t *first, int64_t *step,
+                            int64_t *count) {
+  if (!first || !step || !count || n_chunks < 0) return GM_ERR_INVALID;
+  if (world < 1) world = 1;
+  if (rank < 0 || rank >= world) return GM_ERR_INVALID;
+  if (policy == GM_PART_RANGE || policy == GM_PART_VERTEX) {
+    const long long lo = n_chunks * rank / world, hi = n_chunks * (rank + 1) / world;
+    *first = lo;
+    *step = 1;
+    *count = hi - lo;
+  } else {
+    *first = rank;
+    *step = world;
+    *count = n_chunks > rank ? (n_chunks - rank + world - 1) / world : 0;
+  }
+  return GM_OK;
+}
+
+// Host-only view of the task-chunk table (no device needed): used by the CPU-side multi-process tests.
+extern "C" int gm_chunk_table(int32_t nv, const int64_t *row_ptr, int32_t chunk, int32_t for_clique, int32_t *recs,
+                              int64_t cap, int64_t *n_out) {
+  if (!row_ptr || !n_out || nv < 0 || (cap > 0 && !recs)) return GM_ERR_INVALID;
+  std::vector<int> rp;
+  int rc = convert_offsets(row_ptr, nv, row_ptr[nv], rp);
+  if (rc) return rc;
+  int target = chunk > 0 ? chunk : kDefaultChunk;
+  target = std::max(64, std::min(target, kStageCap));
+  std::vector<ChunkRec> out;
+  unsigned long long mb = 0;
+  build_chunks(rp, nv, target, !for_clique, for_clique ? kBitWords : 0, kStageCap, out, mb);  // (the walk the device runs: walk_chunks)
+  *n_out = (int64_t)out.size();
+  for (int64_t i = 0; i < (int64_t)out.size() && i < cap; ++i) {
+    recs[4 * i + 0] = out[i].u_begin;
+    recs[4 * i + 1] = out[i].u_end;
+    recs[4 * i + 2] = out[i].e_begin;
+    recs[4 * i + 3] = out[i].e_end;
+  }
+  return GM_OK;
+}
+

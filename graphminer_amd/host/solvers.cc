@@ -74,7 +74,7 @@ bool run_single(Graph &g, const Job &j, int chunk, uint64_t *out) {
   if (rc) gm_die(rc, "gm_graph_upload");
   gm_launch la;
   std::memset(&la, 0, sizeof la);
-  la.chunk = chunk == 1024 ? 0 : chunk;  // 1024 is the reference's CLI default: keep the library default then
+  la.chunk = chunk > 0 ? chunk : 0;  // honoured as given (src/triangle/main.cc:16); <= 0 = the library default (the apps pass 0 when argv has none)
   gm_stats st;
   std::memset(&st, 0, sizeof st);
   rc = call(j, dg, &la, out, &st);  // first call builds the task-chunk table ("Time on generating the edgelist")
@@ -137,7 +137,7 @@ bool run_multi(Graph &g, const Job &j, int n, int chunk, uint64_t *out) {
       la.rank = i;
       la.world = n;
       la.policy = GM_PART_ROUND_ROBIN;
-      la.chunk = chunk == 1024 ? 0 : chunk;
+      la.chunk = chunk > 0 ? chunk : 0;
       la.d_counts = d_cnt[i];
       int rc = call(j, dg[i], &la, nullptr, nullptr);  // asynchronous: kernels of all GPUs overlap
       if (rc == GM_ERR_UNSUPPORTED) { unsupported = true; return; }

@@ -31,7 +31,7 @@ static void report(const char *name, const gm_stats &st) {
 void TCSolver(Graph &g, uint64_t &total, int, int chunk_size) {  // g is already oriented by the reference's Graph ctor
   gm_graph *dg = upload(g);
   gm_launch la = {};
-  la.chunk = chunk_size == 1024 ? 0 : chunk_size;
+  la.chunk = chunk_size > 0 ? chunk_size : 0;  // the reference main passes its argv value, default 1024: honoured
   gm_stats st = {};
   uint64_t count = 0;
   gm_or_die(gm_tc(dg, &la, &count, &st), "gm_tc");
@@ -43,7 +43,7 @@ void TCSolver(Graph &g, uint64_t &total, int, int chunk_size) {  // g is already
 void SglSolver(Graph &g, Pattern &p, uint64_t &total, int, int chunk_size) {
   gm_graph *dg = upload(g);
   gm_launch la = {};
-  la.chunk = chunk_size == 1024 ? 0 : chunk_size;
+  la.chunk = chunk_size > 0 ? chunk_size : 0;  // the reference main passes its argv value, default 1024: honoured
   gm_stats st = {};
   uint64_t count = 0;
   int rc = gm_sgl(dg, p.get_name().c_str(), &la, &count, &st);
@@ -56,7 +56,7 @@ void SglSolver(Graph &g, Pattern &p, uint64_t &total, int, int chunk_size) {
 void CliqueSolver(Graph &g, int k, uint64_t &total, int, int chunk_size) {
   gm_graph *dg = upload(g);
   gm_launch la = {};
-  la.chunk = chunk_size == 1024 ? 0 : chunk_size;
+  la.chunk = chunk_size > 0 ? chunk_size : 0;  // the reference main passes its argv value, default 1024: honoured
   gm_stats st = {};
   uint64_t count = 0;
   gm_or_die(gm_clique(dg, k, &la, &count, &st), "gm_clique");
@@ -68,7 +68,7 @@ void CliqueSolver(Graph &g, int k, uint64_t &total, int, int chunk_size) {
 void MotifSolver(Graph &g, int k, std::vector<uint64_t> &accum, int, int chunk_size) {
   gm_graph *dg = upload(g);
   gm_launch la = {};
-  la.chunk = chunk_size == 1024 ? 0 : chunk_size;
+  la.chunk = chunk_size > 0 ? chunk_size : 0;  // the reference main passes its argv value, default 1024: honoured
   gm_stats st = {};
   std::vector<uint64_t> c(accum.size(), 0);
   gm_or_die(gm_motif(dg, k, &la, c.data(), (int)c.size(), &st), "gm_motif");

@@ -110,10 +110,12 @@ def counts_for(prefix, heavy=True, have=None):
 
 
 def counts_for_update(prefix, heavy, have):
-    """--update: only the entries golden.json lacks (today: clique8 of the `heavy is True` graphs)"""
+    """--update: only the entries golden.json lacks (round 2: clique6..8; round 3: the 4-motif vector of the `sgl` graphs
+    R-MAT-12 / -14 from motif_omp_formula, the reference's formula solver -- seconds, where motif_omp_base takes hours)"""
     r = Lazy(have)
     for k in (6, 7, 8):
         r.put(f"clique{k}", lambda: last_int(run("clique_omp_recursive", prefix, k), rf"num_{k}-cliques = (\d+)"))
+    r.put("motif4", lambda: [int(x) for x in re.findall(r"pattern \d+: (\d+)", run("motif_omp_formula", prefix, 4))])
     return dict(r)
 
 
@@ -123,6 +125,32 @@ def csr_sha(g: Graph):
     h.update(g.col_idx.astype("<i4").tobytes())
     return h.hexdigest()
 
+
+README_KNOWN = {
+    "mico": {"tc": 12534960, "rectangle": 2016507139, "diamond": 3527170461, "house": 1655449692098, "pentagon": 394942854039,
+             "clique4": 514864225, "clique5": 19246558419, "clique6": 631568259280, "motif3": [53546459, 12534960],
+             "motif4": [2307847995, 4070868075, 3591944265, 33929353, 437985111, 514864225]},
+    "patent_citations": {"tc": 6913764, "rectangle": 293116828, "diamond": 75851456, "house": 6586768851, "pentagon": 3254769712,
+                         "clique4": 3310556, "clique5": 2976152, "clique6": 3132860, "clique7": 1870484, "clique8": 515317,
+                         "motif3": [267600153, 6913764], "motif4": [5148841859, 5764763466, 497680804, 227197040, 55988120, 3310556]},
+    "cit-Patents": {"tc": 7515023, "rectangle": 341906226, "diamond": 83785566, "house": 7375094981, "pentagon": 3663584163, "clique4": 3501071},
+    "youtube": {"tc": 103017122, "rectangle": 1642566152, "diamond": 1806302028, "house": 71503929498, "pentagon": 24702570492,
+                "clique4": 176614367, "clique5": 295551667, "motif3": [1867293654, 103017122],
+                "motif4": [201577267737, 55176204040, 8209274276, 366107225, 746615826, 176614367]},
+    "livej": {"tc": 285730264, "rectangle": 51520572777, "diamond": 76354588342, "house": 53552979463652, "pentagon": 13892452066046,
+              "motif3": [6412312961, 285730264], "clique4": 9933532019, "clique5": 467429836174, "clique6": 20703476954640,
+              "motif4": [6619009156172, 1147811961320, 124769176079, 4966580492, 16753396228, 9933532019]},
+    "com-orkut": {"tc": 627584181, "rectangle": 127533170575, "diamond": 67098889426, "motif3": [43742714028, 627584181],
+                  "clique4": 3221946137, "clique5": 15766607860, "clique6": 75249427585, "clique7": 353962921685, "clique8": 1632691821296,
+                  "motif4": [97824018291804, 18573723211463, 1510018661295, 70100119560, 47767212604, 3221946137]},
+    "twitter20": {"tc": 17295646010, "diamond": 41166070788458, "clique4": 2123679707619, "clique5": 262607691785539,
+                  "motif3": [1780251390046, 17295646010]},
+    "twitter40": {"tc": 34824916864, "diamond": 176266103582254, "clique4": 6622234180319, "motif3": [123331114814249, 34824916864]},
+    "friendster": {"tc": 4173724142, "rectangle": 465803364346, "diamond": 185191258870, "clique4": 8963503263, "clique5": 21710817218,
+                   "clique6": 59926510355, "clique7": 296858496789, "clique8": 3120447373827, "motif3": [708133792538, 4173724142],
+                   "motif4": [247358335700296, 364700730542912, 5787076338289, 307502615265, 131410239292, 8963503263]},
+    "uk2007": {"tc": 286701284103, "motif3": [25162884716555, 286701284103]},
+}
 
 EXTRA = [  # (scale, edge_factor, seed, entries): graphs too big for the full set
     (16, 16, 42, ["tc", "motif3", "motif4"]),
@@ -163,12 +191,11 @@ def main():
                             "ne": g.E(), "max_degree": g.max_degree, "csr_sha256": csr_sha(g),
                             **extra_counts_for(prefix, what, have)}
             print(g.name, gold[g.name])
-    # README known answers for the full-size graphs (no data here; kept for when real files are supplied)
-    gold["_readme_known_answers"] = {
-        "livej": {"tc": 285730264, "diamond": 76354588342, "motif3": [6412312961, 285730264], "clique4": 9933532019},
-        "com-orkut": {"tc": 627584181, "diamond": 67098889426, "motif3": [43742714028, 627584181], "clique4": 3221946137,
-                      "clique5": 15766607860},
-    }
+    # README known answers of the public datasets (no data in the image; checked when real files are supplied through
+    # GM_DATA_DIR/<name>/graph.*, e.g. converted with graphminer_amd/bin/edgelist2bin). Sources: src/triangle/README.md:52-62,
+    # src/sgl/README.md:52-62, src/clique/README.md:54-62, src/motif/README.md:52-60. motif4 in the solver's order
+    # [3-star, 4-path, tailed-triangle, 4-cycle, diamond, 4-clique]; rectangle = edge-induced 4-cycles of sgl.
+    gold["_readme_known_answers"] = README_KNOWN
     with open(path, "w") as f:
         json.dump(gold, f, indent=1, sort_keys=True)
         f.write("\n")

@@ -92,20 +92,32 @@ def test_motif3_rmat22_equals_oracle(rmat_dev):
     assert [sum(p[i] for p in parts) % 2**64 for i in range(2)] == want
 
 
-@pytest.mark.parametrize("name", ["livej", "com-orkut"])
+@pytest.mark.parametrize("name", sorted(GOLDEN["_readme_known_answers"]))
 def test_readme_known_answers_on_real_datasets(name):
-    """golden.json::_readme_known_answers (src/triangle/README.md:58-59, src/sgl/README.md:58, src/clique/README.md:59,
-    src/motif/README.md:59-60) when GM_DATA_DIR/<name>/graph.{meta.txt,vertex.bin,edge.bin} are supplied."""
+    """golden.json::_readme_known_answers (the README tables: src/triangle/README.md:52-62, src/sgl/README.md:52-62,
+    src/clique/README.md:54-62, src/motif/README.md:52-60) when GM_DATA_DIR/<name>/graph.{meta.txt,vertex.bin,edge.bin} are supplied
+    (SNAP text -> the three files: graphminer_amd/bin/edgelist2bin). GM_DATA_PATTERNS=tc,diamond,... restricts the patterns."""
     root = os.environ.get("GM_DATA_DIR", "")
     prefix = os.path.join(root, name, "graph")
     if not root or not os.path.exists(prefix + ".meta.txt"):
         pytest.skip("real dataset not supplied (set GM_DATA_DIR)")
     known = GOLDEN["_readme_known_answers"][name]
+    only = [x for x in os.environ.get("GM_DATA_PATTERNS", "").split(",") if x]
     sym = Graph(prefix).to_device(0)
     dag = sym.orient()
-    assert TCSolver(dag) == known["tc"]
-    assert SglSolver(sym, "diamond") == known["diamond"]
-    assert MotifSolver(sym, 3) == known["motif3"]
-    assert CliqueSolver(dag, 4) == known["clique4"]
-    if "clique5" in known:
-        assert CliqueSolver(dag, 5) == known["clique5"]
+    for key, want in known.items():
+        if only and key not in only:
+            continue
+        if key == "tc":
+            got = TCSolver(dag)
+        elif key in ("diamond", "rectangle", "house", "pentagon"):
+            got = SglSolver(sym, key)
+        elif key.startswith("clique"):
+            if int(key[6:]) > 8:
+                continue
+            got = CliqueSolver(dag, int(key[6:]))
+        elif key.startswith("motif"):
+            got = MotifSolver(sym, int(key[5:]))
+        else:
+            continue
+        assert got == want, (name, key, got, want)

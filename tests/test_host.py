@@ -126,3 +126,80 @@ def test_partition_and_chunk_table_host_api():
     out = (C.c_uint64 * 6)()
     assert lib.gm_motif4_finish(raw, out) == 0
     assert [int(x) for x in out] == GOLDEN["citeseer"]["motif4"]
+
+
+# ---- edgelist2bin: text edge lists -> the three-file format (reference README.md:104 points to an external converter) ----
+E2B = os.path.join(ROOT, "graphminer_amd", "bin", "edgelist2bin")
+
+
+def _e2b(*args):
+    import subprocess
+
+    return subprocess.run([E2B, *map(str, args)], capture_output=True, text=True)
+
+
+@pytest.mark.skipif(not os.path.exists(E2B), reason="edgelist2bin not built (make -C graphminer_amd tools)")
+@pytest.mark.parametrize("name", ["citeseer", "cora"])
+def test_edgelist2bin_round_trip_is_byte_identical(name, tmp_path):
+    """fixture -> text dump (every undirected edge once) -> convert: vertex.bin / edge.bin byte-identical, meta.txt equal"""
+    src = os.path.join(ROOT, "tests", "fixtures", name, "graph")
+    meta = open(src + ".meta.txt").read().split()
+    txt, out = tmp_path / "edges.txt", tmp_path / "graph"
+    assert _e2b("--dump", src, txt).returncode == 0
+    r = _e2b("--meta-tail", " ".join(meta[7:10]), txt, out)
+    assert r.returncode == 0, r.stderr
+    for ext in (".vertex.bin", ".edge.bin"):
+        assert open(str(out) + ext, "rb").read() == open(src + ext, "rb").read(), ext
+    assert open(str(out) + ".meta.txt").read().split() == meta[:10]  # (cora's meta.txt goes on with mask ranges the loader never reads)
+    g = Graph(str(out))  # and the loader (with the reference's asserts) accepts it
+    assert f"|V|: {g.V()}, |E|: {g.E()}, Max Degree: {g.max_degree}" in r.stdout
+
+
+@pytest.mark.skipif(not os.path.exists(E2B), reason="edgelist2bin not built (make -C graphminer_amd tools)")
+def test_edgelist2bin_symmetrises_dedupes_and_renumbers(tmp_path):
+    """directed duplicates, both directions, self loops, comments, 1-based sparse ids, commas and tabs -> csr_from_pairs' graph"""
+    from graphminer_amd.rmat import csr_from_pairs
+
+    rng = np.random.default_rng(5)
+    ids = np.sort(rng.choice(np.arange(1, 5000), size=300, replace=False))  # sparse 1-based id space
+    s, d = rng.integers(0, 300, 4000), rng.integers(0, 300, 4000)
+    txt = tmp_path / "g.txt"
+    with open(txt, "w") as f:
+        f.write("# Directed graph (each unordered pair of nodes is saved once or more)\n# FromNodeId\tToNodeId\n")
+        for i, (a, b) in enumerate(zip(s, d)):
+            sep = ["\t", " ", ",", "  "][i % 4]
+            f.write(f"{ids[a]}{sep}{ids[b]}\n")
+            if i % 7 == 0:
+                f.write(f"{ids[b]} {ids[a]}\n")  # the reverse direction as well
+        f.write("\n")
+    r = _e2b("--one-based", "--compact", txt, tmp_path / "c")
+    assert r.returncode == 0, r.stderr
+    want = csr_from_pairs(300, s.astype(np.uint64), d.astype(np.uint64))
+    got = Graph(str(tmp_path / "c"))
+    # (--compact drops vertices without an edge; the random pairs touch all 300 with overwhelming probability)
+    assert got.V() == want.V() and np.array_equal(got.row_ptr, want.row_ptr) and np.array_equal(got.col_idx, want.col_idx)
+    assert got.max_degree == want.max_degree
+    # without --compact: ids kept (minus one), nv = largest id
+    r = _e2b("--one-based", txt, tmp_path / "k")
+    assert r.returncode == 0, r.stderr
+    keep = Graph(str(tmp_path / "k"))
+    assert keep.V() == int(ids[np.union1d(s, d)].max()) and keep.E() == want.E()
+    deg = np.diff(keep.row_ptr)
+    assert np.array_equal(deg[ids[np.arange(300)] - 1], np.diff(want.row_ptr))
+
+
+@pytest.mark.skipif(not os.path.exists(E2B), reason="edgelist2bin not built (make -C graphminer_amd tools)")
+def test_edgelist2bin_matrix_market_and_errors(tmp_path):
+    mtx = tmp_path / "m.mtx"
+    mtx.write_text("%%MatrixMarket matrix coordinate pattern symmetric\n% comment\n4 4 4\n2 1\n3 1 1.0\n4 3\n3 3\n")
+    assert _e2b(mtx, tmp_path / "m").returncode == 0
+    g = Graph(str(tmp_path / "m"))
+    assert (g.V(), g.E(), g.max_degree) == (4, 6, 2)
+    assert g.col_idx.tolist() == [1, 2, 0, 0, 3, 2]
+    empty = tmp_path / "e.txt"
+    empty.write_text("# nothing\n5 5\n")
+    r = _e2b(empty, tmp_path / "e")
+    assert r.returncode != 0 and "no edge" in r.stderr  # the loader asserts 0 < max_degree < nv (graph.cc:34)
+    bad = tmp_path / "b.txt"
+    bad.write_text("1 x\n")
+    assert _e2b(bad, tmp_path / "b").returncode != 0
