@@ -25,6 +25,17 @@ struct alignas(16) WaveLdsLean {
   unsigned char qown[kQueueCap];
 };
 
+// ... with the STREAM INDEX of every queued candidate beside its key (the re-hosted k-clique build, gm_cbuild.hip: a match found while
+// the owner's list N+(u) is streamed against a staged N+(v) is bit `stream index` of u's row) and one word of per-edge metadata
+struct alignas(16) WaveLdsIdx {
+  int4 desc[GM_WAVE];
+  unsigned char marks[kMarkWindow];
+  int qkey[kQueueCap];
+  unsigned char qown[kQueueCap];
+  unsigned short qidx[kQueueCap];
+  int meta[GM_WAVE];
+};
+
 struct Acc {
   unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
 };
@@ -176,17 +187,19 @@ __device__ __forceinline__ void flat_pass(LT &L, const int *__restrict__ stage, 
 // not written per candidate); slots below carry their owner in L.qown.
 // BM: the candidates are verified with one probe of the dense bitmap `bm` of the (single) searched row instead of a
 // bisection of the LDS stage (SPLIT chunks; positions are not reported, act gets pos = 0).
-template <bool BM, class LT, class Act>
+template <bool BM, bool IDX = false, class LT, class Act>
 __device__ __forceinline__ void drain_candidates(LT &L, const int *__restrict__ stage, const int lane, const int n,
                                                  const int steps, const int own_from, const int cur_owner, Act act,
                                                  const unsigned *__restrict__ bm = nullptr) {
-  int own[kTiles], key[kTiles], sb[kTiles], sl[kTiles], fl[kTiles], lo[kTiles];
+  int own[kTiles], key[kTiles], sb[kTiles], sl[kTiles], fl[kTiles], lo[kTiles], sidx[kTiles];
   bool in[kTiles];
 #pragma unroll
   for (int q = 0; q < kTiles; ++q) {
     const int slot = q * GM_WAVE + lane;  // < kQueueCap: the reads below are always in bounds
     in[q] = slot < n;
     key[q] = L.qkey[slot];
+    sidx[q] = 0;
+    if constexpr (IDX) sidx[q] = (int)L.qidx[slot];
     own[q] = (int)L.qown[slot];
     own[q] = (slot >= own_from) ? cur_owner : own[q];
     own[q] = in[q] ? own[q] : 0;
@@ -229,7 +242,7 @@ __device__ __forceinline__ void drain_candidates(LT &L, const int *__restrict__ 
 #pragma unroll
   for (int q = 0; q < kTiles; ++q) {
     const bool f = in[q] & (lo[q] < sl[q]) & (xf[q] == key[q]);
-    act(f, own[q], 0, lo[q], fl[q], key[q]);
+    act(f, own[q], sidx[q], lo[q], fl[q], key[q]);  // (sidx: the candidate's index in its streamed list when IDX, else 0)
   }
 }
 
@@ -247,7 +260,7 @@ __device__ __forceinline__ void drain_candidates(LT &L, const int *__restrict__ 
 #endif
 constexpr int kLongList = GM_LONG_LIST;
 
-template <int FL2 = kFilterLog2, bool BM = false, class LT, class Act>
+template <int FL2 = kFilterLog2, bool BM = false, bool IDX = false, class LT, class Act>
 __device__ __forceinline__ void flat_pass_filtered(LT &L, const int *__restrict__ stage, const unsigned *__restrict__ fbits,
                                                    const int *__restrict__ col, const int lane, const int llen_all,
                                                    const int key_base, const int s_base_salt, const int s_len_flag, const int dbg, Act act,
@@ -262,35 +275,46 @@ __device__ __forceinline__ void flat_pass_filtered(LT &L, const int *__restrict_
   L.desc[lane] = make_int4(key_base, off, s_base_salt, s_len_flag);
   int qcount = 0;  // wave-uniform number of queued candidates
 
-  auto enqueue = [&](const bool cand, const int key, const int owner) {
+  auto enqueue = [&](const bool cand, const int key, const int owner, const int sidx) {
     const unsigned long long m = __ballot(cand);
     if (__builtin_amdgcn_inverse_ballot_w64(m)) {  // (exec = the ballot: `if (cand)` made the compiler evaluate the bit test twice)
       const int slot = qcount + rank_below(m);
       L.qkey[slot] = key;
       L.qown[slot] = (unsigned char)owner;
+      if constexpr (IDX) L.qidx[slot] = (unsigned short)sidx;
     }
     qcount += __popcll(m);
   };
   int own_from = kQueueCap, cur_owner = 0;  // wave-uniform: slots >= own_from belong to the long list being streamed
-  auto enqueue_long = [&](const bool cand, const int key) {
+  auto enqueue_long = [&](const bool cand, const int key, const int sidx) {
     const unsigned long long m = __ballot(cand);
-    if (__builtin_amdgcn_inverse_ballot_w64(m)) L.qkey[qcount + rank_below(m)] = key;
+    if (__builtin_amdgcn_inverse_ballot_w64(m)) {
+      const int slot = qcount + rank_below(m);
+      L.qkey[slot] = key;
+      if constexpr (IDX) L.qidx[slot] = (unsigned short)sidx;
+    }
     qcount += __popcll(m);
   };
   auto drain_full_tiles = [&]() {
     if (qcount >= GM_WAVE) {  // wave-uniform
       wave_sync();
       const int n = qcount & ~(GM_WAVE - 1);
-      if (!(dbg & 16)) drain_candidates<BM>(L, stage, lane, n, steps, own_from, cur_owner, act, bm);
+      if (!(dbg & 16)) drain_candidates<BM, IDX>(L, stage, lane, n, steps, own_from, cur_owner, act, bm);
       const int rest = qcount - n;  // < 64: move to the front, owners written out
       int k = 0;
       unsigned char o = 0;
+      unsigned short si = 0;
       if (lane < rest) {
         k = L.qkey[n + lane];
         o = (n + lane >= own_from) ? (unsigned char)cur_owner : L.qown[n + lane];
+        if constexpr (IDX) si = L.qidx[n + lane];
       }
       wave_sync();
-      if (lane < rest) { L.qkey[lane] = k; L.qown[lane] = o; }
+      if (lane < rest) {
+        L.qkey[lane] = k;
+        L.qown[lane] = o;
+        if constexpr (IDX) L.qidx[lane] = si;
+      }
       qcount = rest;
       own_from = (own_from < kQueueCap) ? rest : kQueueCap;
     }
@@ -313,7 +337,7 @@ __device__ __forceinline__ void flat_pass_filtered(LT &L, const int *__restrict_
     // many younger loads are in flight and waits with vmcnt(0) -- which also waits for the prefetch it has just issued.
     // The steady-state loop only sees FULL groups whose successor is full too: no range tests, no index clamps, and the
     // load address is scalar base + (lane * 4); the last one or two groups take the general form.
-    auto process = [&](const int *key, const bool *in) {
+    auto process = [&](const int *key, const bool *in, const int t_base) {
       unsigned h[kTiles], fw[kTiles];
 #pragma unroll
       for (int q = 0; q < kTiles; ++q) {
@@ -321,7 +345,7 @@ __device__ __forceinline__ void flat_pass_filtered(LT &L, const int *__restrict_
         fw[q] = fbits[h[q] >> 5];
       }
 #pragma unroll
-      for (int q = 0; q < kTiles; ++q) enqueue_long(in[q] & (((fw[q] >> (h[q] & 31u)) & 1u) != 0u), key[q]);
+      for (int q = 0; q < kTiles; ++q) enqueue_long(in[q] & (((fw[q] >> (h[q] & 31u)) & 1u) != 0u), key[q], t_base + q * GM_WAVE + lane);
       drain_full_tiles();
     };
     constexpr int G = GM_WAVE * kTiles;
@@ -340,7 +364,7 @@ __device__ __forceinline__ void flat_pass_filtered(LT &L, const int *__restrict_
       const int *__restrict__ kn = kp + (t + G);  // wave-uniform
 #pragma unroll
       for (int q = 0; q < kTiles; ++q) nxt[q] = kn[(unsigned)(q * GM_WAVE + lane)];
-      process(key, in);
+      process(key, in, t);
     }
     for (; t < n; t += G) {
       int key[kTiles];
@@ -352,7 +376,7 @@ __device__ __forceinline__ void flat_pass_filtered(LT &L, const int *__restrict_
       }
 #pragma unroll
       for (int q = 0; q < kTiles; ++q) nxt[q] = kp[min(t + G + q * GM_WAVE + lane, n - 1)];
-      process(key, in);
+      process(key, in, t);
     }
     // the list is done: write the owner of what is still queued (< 64 entries), later candidates carry their own
     if (own_from + lane < qcount) L.qown[own_from + lane] = (unsigned char)src;
@@ -370,7 +394,7 @@ __device__ __forceinline__ void flat_pass_filtered(LT &L, const int *__restrict_
     if (llen > 0 && off >= wb && off < wb + kMarkWindow) L.marks[off - wb] = (unsigned char)(lane + 1);
     wave_sync();
     for (int t = 0; t < wn; t += GM_WAVE * kTiles) {
-      int own[kTiles], key[kTiles];
+      int own[kTiles], key[kTiles], sidx[kTiles];
       unsigned h[kTiles], fw[kTiles];
       bool in[kTiles];
 #pragma unroll
@@ -389,20 +413,21 @@ __device__ __forceinline__ void flat_pass_filtered(LT &L, const int *__restrict_
         const int p = wb + t + q * GM_WAVE + lane;
         in[q] = p < total;
         const int4 d = L.desc[in[q] ? own[q] - 1 : 0];
-        key[q] = col[in[q] ? d.x + (p - d.y) : 0];  // unconditional load (select on the index)
+        sidx[q] = p - d.y;
+        key[q] = col[in[q] ? d.x + sidx[q] : 0];  // unconditional load (select on the index)
         h[q] = filter_hash<FL2>(key[q], (unsigned)d.z >> 16);
       }
 #pragma unroll
       for (int q = 0; q < kTiles; ++q) fw[q] = (dbg & 32) ? 0u : fbits[h[q] >> 5];
 #pragma unroll
-      for (int q = 0; q < kTiles; ++q) enqueue(in[q] & (((fw[q] >> (h[q] & 31u)) & 1u) != 0u), key[q], own[q] - 1);
+      for (int q = 0; q < kTiles; ++q) enqueue(in[q] & (((fw[q] >> (h[q] & 31u)) & 1u) != 0u), key[q], own[q] - 1, sidx[q]);
       drain_full_tiles();
     }
     wave_sync();
   }
   if (qcount > 0) {
     wave_sync();
-    drain_candidates<BM>(L, stage, lane, qcount, steps, kQueueCap, 0, act, bm);
+    drain_candidates<BM, IDX>(L, stage, lane, qcount, steps, kQueueCap, 0, act, bm);
   }
   wave_sync();
 }

@@ -47,7 +47,7 @@ extern "C" int gm_graph_setup_times(const gm_graph *g, gm_setup_times *out) {
   if (!g || !out) return GM_ERR_INVALID;
   *out = g->setup;
   // cached derived handles report through their owner
-  for (const gm_graph *r : {g->dag_cache, g->relabel_cache[0], g->relabel_cache[1]})
+  for (const gm_graph *r : {g->dag_cache, g->relabel_cache[0], g->relabel_cache[1], g->relabel_cache[2]})
     if (r) {
       out->orient_ms += r->setup.orient_ms;
       out->table_ms += r->setup.table_ms;
@@ -75,12 +75,7 @@ extern "C" void gm_graph_free(gm_graph *g) {
   if (g->d_edesc) (void)hipFree(g->d_edesc);
   if (g->d_trp) (void)hipFree(g->d_trp);
   if (g->d_tdesc) (void)hipFree(g->d_tdesc);
-  for (auto &pl : g->wide_plans) {
-    if (pl.d_verts) (void)hipFree(pl.d_verts);
-    if (pl.d_base) (void)hipFree(pl.d_base);
-    if (pl.d_chunks) (void)hipFree(pl.d_chunks);
-    if (pl.d_cls_slots) (void)hipFree(pl.d_cls_slots);
-  }
+  free_clique_plans(g);
   if (g->d_wide_mat) (void)hipFree(g->d_wide_mat);
   if (g->d_wide_sorted) (void)hipFree(g->d_wide_sorted);
   if (g->d_wide_queue) (void)hipFree(g->d_wide_queue);
@@ -468,13 +463,39 @@ extern "C" int gm_graph_orient(const gm_graph *sym, gm_graph **out) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Degree renumbering. A pattern count does not depend on the vertex numbering, but the work of the SgL kernels does: they
-// anchor a match at its largest vertex id and walk smaller ids. With ids ascending in degree the 2-path walks of rectangle and the
-// (v0, v1 < v0, v3) tasks of house go through low-degree vertices (R-MAT-16: 522 M -> 128 M 2-paths, 898 M -> 163 M tasks); with
-// ids descending in degree the wedges (v0; v2 < v1 < v0) of pentagon avoid the hubs (99 M -> 33 M). The copy is built once
-// per handle: counting sort of the vertices by degree on the host, one 64-bit key (new row, new neighbour) per CSR entry and
-// a device radix sort (hipCUB) -- the rows come out ascending.
+// Renumbering. A pattern count does not depend on the vertex numbering, but the work of some kernels does:
+//  * the SgL kernels anchor a match at its largest vertex id and walk smaller ids. With ids ascending in degree the 2-path walks of
+//    rectangle and the (v0, v1 < v0, v3) tasks of house go through low-degree vertices (R-MAT-16: 522 M -> 128 M 2-paths, 898 M ->
+//    163 M tasks); with ids descending in degree the wedges (v0; v2 < v1 < v0) of pentagon avoid the hubs (99 M -> 33 M);
+//  * the 4-clique kernels want a TOPOLOGICAL numbering of the DAG (every edge from a smaller to a larger id): the adjacency matrix of
+//    N+(u) is then strictly upper triangular -- the in-edge tasks of gm_cbuild.hip stream half a list, the pair counts skip the words
+//    below the diagonal. Ids ascending in (in-degree + out-degree, old id) are topological for every DAG that Graph::orientation
+//    produced (src/common/graph.cc:246-247 keeps s -> d iff (deg, id) grows); any other DAG is checked and left as it is.
+// The copy is built once per handle, on the device: one 64-bit key (degree, id) per vertex and one (new row, new neighbour) per CSR
+// entry, two hipCUB radix sorts -- the rows come out ascending. (Round 2 sorted the vertices on the host.)
 // ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void relabel_indeg_kernel(long long ne, const int *__restrict__ col, int *__restrict__ indeg) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += stride) atomicAdd(&indeg[col[e]], 1);
+}
+__global__ __launch_bounds__(256) void relabel_vkeys_kernel(int nv, const int *__restrict__ rp, const int *__restrict__ indeg,
+                                                            unsigned long long *__restrict__ keys) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nv) return;
+  const unsigned long long d = (unsigned long long)(rp[v + 1] - rp[v]) + (indeg ? (unsigned long long)indeg[v] : 0ull);
+  keys[v] = (d << 32) | (unsigned long long)(unsigned)v;
+}
+// position i of the sorted (degree, id) keys -> new id (ascending: i; descending: nv - 1 - i); the new row's length rides along
+__global__ __launch_bounds__(256) void relabel_newid_kernel(int nv, const unsigned long long *__restrict__ sorted, int descending,
+                                                            const int *__restrict__ rp, int *__restrict__ newid, int *__restrict__ newdeg) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > nv) return;
+  if (i == nv) { newdeg[nv] = 0; return; }
+  const int v = (int)(unsigned)(sorted[i] & 0xffffffffull);
+  const int id = descending ? nv - 1 - i : i;
+  newid[v] = id;
+  newdeg[id] = rp[v + 1] - rp[v];
+}
 __global__ __launch_bounds__(256) void relabel_keys_kernel(int nv, long long ne, const int *__restrict__ rp, const int *__restrict__ col,
                                                            const int *__restrict__ newid, unsigned long long *__restrict__ keys) {
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -491,75 +512,100 @@ __global__ __launch_bounds__(256) void relabel_cols_kernel(long long ne, const u
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e < ne) col[e] = (int)(unsigned)(keys[e] & 0xffffffffull);
 }
+// rows are ascending: the numbering is topological (every edge u -> v has u < v) iff no row starts at or below its own vertex
+__global__ __launch_bounds__(256) void topo_check_kernel(int nv, const int *__restrict__ rp, const int *__restrict__ col, int *__restrict__ not_topo) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u < nv && rp[u + 1] > rp[u] && col[rp[u]] <= u) *not_topo = 1;
+}
 
-int get_relabeled(gm_graph *g, int descending, gm_graph **out) {
+int graph_is_topological(gm_graph *g, bool *out) {
+  if (g->topo_state == 0) {
+    HIP_TRY(hipSetDevice(g->device));
+    DevBuf<int> flag;
+    HIP_TRY(flag.alloc(1));
+    HIP_TRY(hipMemsetAsync(flag.p, 0, sizeof(int), 0));
+    if (g->nv > 0) hipLaunchKernelGGL(topo_check_kernel, dim3((unsigned)((g->nv + 255) / 256)), dim3(256), 0, 0, g->nv, g->d_rp, g->d_col, flag.p);
+    int not_topo = 0;
+    HIP_TRY(hipMemcpy(&not_topo, flag.p, sizeof(int), hipMemcpyDeviceToHost));
+    g->topo_state = not_topo ? 2 : 1;
+  }
+  *out = g->topo_state == 1;
+  return GM_OK;
+}
+
+// mode 0: ids ascending in degree, 1: descending, 2: ascending in (in-degree + out-degree) -- the topological numbering of an oriented
+// graph; when the result is not topological after all (a DAG oriented by some other rule) *out is the graph itself.
+int get_relabeled(gm_graph *g, int mode, gm_graph **out) {
   {
     std::lock_guard<std::mutex> lk(g->mu);
-    if (g->relabel_cache[descending]) { *out = g->relabel_cache[descending]; return GM_OK; }
+    if (g->relabel_cache[mode]) { *out = g->relabel_cache[mode]; return GM_OK; }
+    if (mode == 2 && g->topo_relabel_failed) { *out = g; return GM_OK; }
   }
   HIP_TRY(hipSetDevice(g->device));
   SetupTimer timer;
-  {
-    int rc = host_rp(g, nullptr);
-    if (rc) return rc;
-  }
   const int nv = g->nv;
   const long long ne = g->ne;
-  // counting sort by degree (ties: ascending id)
-  std::vector<int> newid((size_t)std::max(nv, 1));
-  {
-    std::vector<long long> bucket((size_t)g->max_deg + 2, 0);
-    for (int v = 0; v < nv; ++v) bucket[(size_t)(g->h_rp[v + 1] - g->h_rp[v]) + 1]++;
-    for (size_t d = 1; d < bucket.size(); ++d) bucket[d] += bucket[d - 1];
-    for (int v = 0; v < nv; ++v) {
-      const long long pos = bucket[(size_t)(g->h_rp[v + 1] - g->h_rp[v])]++;
-      newid[(size_t)v] = descending ? (int)((long long)nv - 1 - pos) : (int)pos;
-    }
+  const size_t nv1 = (size_t)nv + 1, n1 = (size_t)std::max<long long>(ne, 1);
+  auto blocks = [](long long n) { return dim3((unsigned)std::max<long long>(1, (n + 255) / 256)); };
+  ScanTemp tmp;
+  DevBuf<int> indeg, newid, newdeg;
+  DevBuf<unsigned long long> vkeys, vsorted, keys, sorted;
+  HIP_TRY(newid.alloc(nv1));
+  HIP_TRY(newdeg.alloc(nv1));
+  HIP_TRY(vkeys.alloc(nv1));
+  HIP_TRY(vsorted.alloc(nv1));
+  if (mode == 2) {
+    HIP_TRY(indeg.alloc(nv1));
+    HIP_TRY(hipMemsetAsync(indeg.p, 0, sizeof(int) * nv1, 0));
+    if (ne > 0) hipLaunchKernelGGL(relabel_indeg_kernel, dim3((unsigned)std::min<long long>((ne + 255) / 256, (long long)g->cu_count * 32)), dim3(256), 0, 0, ne, g->d_col, indeg.p);
   }
+  int bits = 1;
+  while (bits < 32 && (1ll << bits) < (long long)nv) ++bits;
+  if (nv > 0) {
+    hipLaunchKernelGGL(relabel_vkeys_kernel, blocks(nv), dim3(256), 0, 0, nv, g->d_rp, mode == 2 ? indeg.p : (const int *)nullptr, vkeys.p);
+    size_t bytes = 0;
+    HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, vkeys.p, vsorted.p, nv, 0, 64));
+    HIP_TRY(tmp.reserve(bytes));
+    HIP_TRY(hipcub::DeviceRadixSort::SortKeys(tmp.buf.p, bytes, vkeys.p, vsorted.p, nv, 0, 64));
+  }
+  hipLaunchKernelGGL(relabel_newid_kernel, blocks((long long)nv1), dim3(256), 0, 0, nv, vsorted.p, mode == 1 ? 1 : 0, g->d_rp, newid.p, newdeg.p);
   gm_graph *r = new gm_graph();
   r->device = g->device;
   r->nv = nv;
   r->ne = ne;
-  r->h_rp.assign((size_t)nv + 1, 0);
-  for (int v = 0; v < nv; ++v) r->h_rp[(size_t)newid[(size_t)v] + 1] = g->h_rp[v + 1] - g->h_rp[v];
-  for (int v = 0; v < nv; ++v) r->h_rp[(size_t)v + 1] += r->h_rp[(size_t)v];
-  int *d_newid = nullptr;
-  unsigned long long *d_keys = nullptr, *d_sorted = nullptr;
-  void *d_tmp = nullptr;
-  auto cleanup = [&]() {
-    if (d_newid) (void)hipFree(d_newid);
-    if (d_keys) (void)hipFree(d_keys);
-    if (d_sorted) (void)hipFree(d_sorted);
-    if (d_tmp) (void)hipFree(d_tmp);
-  };
-  auto fail = [&](hipError_t e, const char *what) { cleanup(); gm_graph_free(r); return hip_fail(e, what, __FILE__, __LINE__); };
+  auto fail = [&](hipError_t e, const char *what) { gm_graph_free(r); return hip_fail(e, what, __FILE__, __LINE__); };
   hipError_t e;
-  const size_t n1 = (size_t)std::max<long long>(ne, 1);
-  if ((e = hipMalloc(&d_newid, sizeof(int) * (size_t)std::max(nv, 1))) != hipSuccess) return fail(e, "hipMalloc(newid)");
-  if ((e = hipMemcpy(d_newid, newid.data(), sizeof(int) * (size_t)nv, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(newid)");
-  if ((e = hipMalloc(&d_keys, sizeof(unsigned long long) * n1)) != hipSuccess) return fail(e, "hipMalloc(keys)");
-  if ((e = hipMalloc(&d_sorted, sizeof(unsigned long long) * n1)) != hipSuccess) return fail(e, "hipMalloc(sorted)");
-  if ((e = hipMalloc(&r->d_rp, sizeof(int) * ((size_t)nv + 1))) != hipSuccess) return fail(e, "hipMalloc(rp)");
+  if ((e = hipMalloc(&r->d_rp, sizeof(int) * nv1)) != hipSuccess) return fail(e, "hipMalloc(rp)");
   if ((e = hipMalloc(&r->d_col, sizeof(int) * n1)) != hipSuccess) return fail(e, "hipMalloc(col)");
-  if ((e = hipMemcpy(r->d_rp, r->h_rp.data(), sizeof(int) * ((size_t)nv + 1), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(rp)");
+  if ((e = dev_exclusive_sum(tmp, newdeg.p, r->d_rp, nv1)) != hipSuccess) return fail(e, "ExclusiveSum");
   if (ne > 0) {
-    const unsigned blocks = (unsigned)((ne + 255) / 256);
-    hipLaunchKernelGGL(relabel_keys_kernel, dim3(blocks), dim3(256), 0, 0, nv, ne, g->d_rp, g->d_col, d_newid, d_keys);
-    int bits = 1;
-    while (bits < 32 && (1ll << bits) < (long long)nv) ++bits;
-    size_t tmp_bytes = 0;
-    if ((e = hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, d_keys, d_sorted, (int)ne, 0, 32 + bits)) != hipSuccess) return fail(e, "SortKeys(size)");
-    if ((e = hipMalloc(&d_tmp, std::max<size_t>(tmp_bytes, 16))) != hipSuccess) return fail(e, "hipMalloc(sort temp)");
-    if ((e = hipcub::DeviceRadixSort::SortKeys(d_tmp, tmp_bytes, d_keys, d_sorted, (int)ne, 0, 32 + bits)) != hipSuccess) return fail(e, "SortKeys");
-    hipLaunchKernelGGL(relabel_cols_kernel, dim3(blocks), dim3(256), 0, 0, ne, d_sorted, r->d_col);
-    if ((e = hipDeviceSynchronize()) != hipSuccess) return fail(e, "relabel kernels");
+    if ((e = keys.alloc(n1)) != hipSuccess || (e = sorted.alloc(n1)) != hipSuccess) return fail(e, "hipMalloc(keys)");
+    hipLaunchKernelGGL(relabel_keys_kernel, blocks(ne), dim3(256), 0, 0, nv, ne, g->d_rp, g->d_col, newid.p, keys.p);
+    size_t bytes = 0;
+    if ((e = hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, keys.p, sorted.p, (int)ne, 0, 32 + bits)) != hipSuccess) return fail(e, "SortKeys(size)");
+    if ((e = tmp.reserve(bytes)) != hipSuccess) return fail(e, "hipMalloc(sort temp)");
+    if ((e = hipcub::DeviceRadixSort::SortKeys(tmp.buf.p, bytes, keys.p, sorted.p, (int)ne, 0, 32 + bits)) != hipSuccess) return fail(e, "SortKeys");
+    hipLaunchKernelGGL(relabel_cols_kernel, blocks(ne), dim3(256), 0, 0, ne, sorted.p, r->d_col);
   }
-  cleanup();
+  if ((e = hipGetLastError()) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess) return fail(e, "relabel kernels");
   int rc = finish_handle(r);
   if (rc) { gm_graph_free(r); return rc; }
   r->max_deg = g->max_deg;  // (a permutation of the same rows)
+  if (mode == 2) {
+    bool topo = false;
+    rc = graph_is_topological(r, &topo);
+    if (rc) { gm_graph_free(r); return rc; }
+    if (!topo) {  // not an orientation by (degree, id): nothing gained, keep the graph as given
+      gm_graph_free(r);
+      std::lock_guard<std::mutex> lk(g->mu);
+      g->topo_relabel_failed = true;
+      g->setup.relabel_ms += timer.ms();
+      *out = g;
+      return GM_OK;
+    }
+  }
   std::lock_guard<std::mutex> lk(g->mu);
-  g->relabel_cache[descending] = r;
+  g->relabel_cache[mode] = r;
   g->setup.relabel_ms += timer.ms();
   *out = r;
   return GM_OK;

@@ -126,21 +126,34 @@ struct ChunkTable {
   std::vector<int> first_vertex;                // u_begin of every chunk (ascending; SPLIT chunks repeat it)
 };
 
-struct WidePlan {
-  int rank = 0, world = 1, policy = 0;
-  std::vector<int> verts;  // this rank's wide vertices; slot = index here (heaviest first)
-  struct Round {
-    size_t chunk_begin = 0, chunk_end = 0;  // row-group chunks of the round (phase 1)
-    size_t cls_begin[4] = {0, 0, 0, 0};     // slots of the round per count class S / L / X, in d_cls_slots (phase 2)
-    unsigned long long words = 0;           // arena words of the round
-  };
-  std::vector<Round> rounds;
-  unsigned long long edges = 0;    // task edges of these vertices
-  size_t n_chunks = 0;
+// k-clique (k = 4): the plan of one rank's share (gm_mine.h "level 1 re-hosted"; built by get_clique_plan, gm_tables.hip).
+// OWNERS are the vertices whose matrices this rank builds and counts: the vertices of its share of the narrow chunk table + its share
+// of the wide list. The matrix arena is bounded (GM_WIDE_ARENA_MB): a share whose matrices need more is processed in ROUNDS; a round
+// has its own owners, offsets, task lists (every DAG edge of an owner, at the endpoint that hosts it) and host-chunk table.
+struct CliqueRound {
+  long long n_pos0 = 0, n_count = 0;       // narrow chunks: positions [n_pos0, n_pos0 + n_count) of the rank's share of the narrow table
+  size_t w0 = 0, w1 = 0;                    // wide slots [w0, w1) of the plan's vertex list
+  size_t cls_begin[4] = {0, 0, 0, 0};       // the round's slots per count class S / L / X, in d_cls_slots
+  unsigned long long words = 0;             // arena words of the round
+  unsigned long long *d_base = nullptr;     // per vertex: word offset of its matrix (nv + 1; non-owners are empty)
+  gm::CBuildTask *d_tasks = nullptr;
+  size_t n_tasks = 0;
+  int *d_trp = nullptr;                     // task-list offsets per host vertex (nv + 1)
+  ChunkTable host_tab;                      // chunks of host vertices (rows that fit the stage), costs from the task lists
+};
+struct CliquePlan {
+  int rank = 0, world = 1, policy = 0, target = 0, order_which = 1;
+  int stage = 1024;                  // LDS stage of the build kernel: 1024, or kCbMaxDeg when a longer row hosts
+  bool topo = false;                 // every DAG edge goes from a smaller to a larger id: matrices strictly upper triangular
+  ChunkTable *tabN = nullptr;        // narrow chunk table (a table of the graph)
+  long long n_first = 0, n_step = 1, n_count = 0;  // this rank's share of it: positions first + i * step of the dequeue order
+  const int *d_order = nullptr;
+  std::vector<int> verts;            // this rank's wide vertices; slot = index here (longest rows first)
   int *d_verts = nullptr;
-  unsigned long long *d_base = nullptr;  // slot -> word offset inside its round's arena
-  ChunkRec *d_chunks = nullptr;
+  unsigned long long *d_slot_base = nullptr;  // slot -> word offset of its matrix inside its round's arena
   int *d_cls_slots = nullptr;
+  std::vector<CliqueRound> rounds;
+  unsigned long long wide_edges = 0;  // task edges of the wide vertices
 };
 
 // Dense vertex-id bitmaps of the hub rows: a property of the graph (which rows: longer than min_deg and not left to a
@@ -176,7 +189,9 @@ struct gm_graph {
   unsigned long long ev_launches = 0;
   int cu_count = 256;
   gm_graph *dag_cache = nullptr;          // oriented copy, built on demand by gm_motif_formula
-  gm_graph *relabel_cache[2] = {nullptr, nullptr};  // copies renumbered by degree (ascending / descending), see get_relabeled
+  gm_graph *relabel_cache[3] = {nullptr, nullptr, nullptr};  // renumbered copies: by degree ascending / descending, topological (get_relabeled)
+  int topo_state = 0;                // 0 unknown, 1 every edge goes to a larger id, 2 not (graph_is_topological)
+  bool topo_relabel_failed = false;  // the (degree, id) numbering is not topological for this DAG: it runs as given
   const gm_graph *ring_alias = nullptr;
   const gm_graph *ring_extra[2] = {nullptr, nullptr};  // 4-motif: the handles that ran the other sub-launches of the most recent calls (gm_kernel_times adds them)
   int *d_idx0 = nullptr;                  // rectangle: #neighbours below v, and the wedge-block prefix
@@ -205,7 +220,7 @@ struct gm_graph {
   int *d_wide_sorted = nullptr;
   size_t n_wide = 0;
   bool wide_valid = false;
-  std::list<struct WidePlan> wide_plans;
+  std::list<CliquePlan> clique_plans;
   unsigned *d_wide_mat = nullptr;      // matrix arena (largest round so far)
   size_t wide_mat_bytes = 0;
   unsigned *d_wide_queue = nullptr;    // dequeue words of the wide launches of one call (zeroed per call)
@@ -236,13 +251,15 @@ struct OtherSetupScope {
 int finish_handle(gm_graph *g);                                 // gm_graph.hip: counters, events, CU count of a new handle
 int host_rp(gm_graph *g, const std::vector<int> **out);          // gm_graph.hip: host copy of the offsets, fetched on first use
 int convert_offsets(const int64_t *rp64, int nv, long long ne, std::vector<int> &out);  // gm_graph.hip: host-side narrowing / validation
-int get_relabeled(gm_graph *g, int descending, gm_graph **out);  // gm_graph.hip: cached copy renumbered by degree
+int get_relabeled(gm_graph *g, int mode, gm_graph **out);  // gm_graph.hip: cached renumbered copy (0 / 1 by degree, 2 topological)
+int graph_is_topological(gm_graph *g, bool *out);
 void free_tables(gm_graph *g);                                   // gm_tables.hip
 int get_table(gm_graph *g, int target, bool allow_split, int bit_words, unsigned long long part_cap, int stage_cap, ChunkTable **out,
               const RowFilter &rf = RowFilter(), int bitmap_min_deg = kBitmapMinDeg);
 int ensure_edesc(gm_graph *g);
 int ensure_tasklists(gm_graph *g);
 int clique_wide_min_words();
-int get_wide_plan(gm_graph *g, int rank, int world, int policy, WidePlan **out);
+int get_clique_plan(gm_graph *g, int rank, int world, int policy, int target, unsigned long long part_cap, CliquePlan **out);
+void free_clique_plans(gm_graph *g);
 int run_pattern(gm::Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uint64_t *h_out, int nout, gm_stats *st, int fin_mode = -1,
                 unsigned long long fin_base = 0);  // gm_launch.hip

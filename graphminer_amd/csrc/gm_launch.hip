@@ -163,7 +163,9 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
   RowFilter rf;
   rf.tct = use_tct ? 1 : 0;
   if (tct_long) { rf.skip_lo = kTctStageMax; rf.skip_hi = 0x7fffffff; }
-  rf.skip_clique_wide = use_wide ? clique_wide_min_words() : 0;
+  // 4-clique: the first level is re-hosted (gm_cbuild.hip) for every vertex whose row fits its stage -- the narrow chunk table and
+  // the wide list live in the CliquePlan; what is left for THIS table are the rows beyond kCbMaxDeg (mine_kernel's arena path)
+  if (use_wide) rf.only_lo = kCbMaxDeg;
   // Rows of 1025..3072 entries fit the general kernel's stage, but their partner lists (mean 600 keys on R-MAT-24) are cheaper
   // against a hashed set than against the filter + bisection of a multi-row chunk: measured (profiles/r02/ab_hrow_class_lower_bound.log,
   // ms, lower bound 3072 / 2048 / 1024 / 512 / 256) diamond R-MAT-24 262 / 240 / 239 / 238 / 237, R-MAT-22 21.1 / 21.0 / 17.5 / 17.6 / 17.5,
@@ -212,9 +214,9 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
       if (rc) return rc;
     }
   }
-  WidePlan *plan = nullptr;
+  CliquePlan *plan = nullptr;
   if (use_wide) {
-    rc = get_wide_plan(g, rank, world, la->policy == GM_PART_VERTEX ? GM_PART_RANGE : la->policy, &plan);
+    rc = get_clique_plan(g, rank, world, la->policy, target, part_cap, &plan);
     if (rc) return rc;
   }
 
@@ -342,10 +344,19 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
   }
   rc = start_timer(ctx);
   if (rc) return rc;
-  if (use_wide && plan && !plan->verts.empty()) {
-    // wide vertices first (the heaviest work of the launch): per round, phase 1 = the mining kernel over the row-group
-    // chunks, phase 2 = the big-LDS count kernels per class; then the mining kernel over everything else
-    my_edges += plan->edges;
+  uint64_t plan_chunks = 0;
+  if (use_wide && plan) {
+    // 4-clique, re-hosted: per arena round, (1) cbuild_kernel over the round's host chunks builds every row of every owner's matrix,
+    // (2) clique_small_kernel counts the matrices of the narrow chunks, the big-LDS classes X / L / S those of the wide vertices
+    {  // task edges of the share: the entries of its narrow chunks + the rows of its wide vertices
+      ChunkTable *tn = plan->tabN;
+      for (long long i = 0; i < plan->n_count; ++i) {
+        const long long pos = plan->n_first + i * plan->n_step;
+        const size_t c = plan->d_order ? (size_t)tn->order[plan->order_which][(size_t)pos] : (size_t)pos;
+        my_edges += tn->edge_prefix[c + 1] - tn->edge_prefix[c];
+      }
+      my_edges += plan->wide_edges;
+    }
     HIP_TRY(hipMemsetAsync(g->d_wide_queue, 0, 65536, stream));
     const bool prof = getenv("GM_WIDE_PROFILE") != nullptr;
     unsigned long long *d_prof = nullptr;
@@ -355,36 +366,58 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
     }
     int qword = 0;
     for (const auto &rd : plan->rounds) {
-      if (qword + 4 > 16384) return GM_ERR_TOO_LARGE;  // (more than 4096 arena rounds)
-      CliqueBuildParams pw;
-      memset(&pw, 0, sizeof pw);
-      pw.g = p.g;
-      pw.chunks = plan->d_chunks + rd.chunk_begin;
-      pw.count = (int)(rd.chunk_end - rd.chunk_begin);
-      pw.queue = g->d_wide_queue + qword++;
-      pw.mat = g->d_wide_mat;
-      pw.base = plan->d_base;
-      pw.cost_x_step = p.cost_x_step; pw.cost_y_step = p.cost_y_step; pw.cost_x_base = p.cost_x_base; pw.cost_y_base = p.cost_y_base;
-      pw.flags = p.flags;
-      const int per_cu_b = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / clique_build_lds_bytes()));
-      const int wgrid = (int)std::max<long long>(1, std::min<long long>(pw.count, (long long)g->cu_count * per_cu_b));
-      if (pw.count > 0) HIP_TRY(launch_clique_build(pw, wgrid, stream));
+      if (qword + 5 > 16384) return GM_ERR_TOO_LARGE;  // (more than ~3000 arena rounds)
+      if (rd.n_tasks > 0) {
+        CBuildParams pw;
+        memset(&pw, 0, sizeof pw);
+        pw.g = p.g;
+        pw.chunks = rd.host_tab.d;
+        pw.order = rd.host_tab.d_order[1];  // heaviest host chunks first
+        pw.count = (int)rd.host_tab.n;
+        pw.trp = rd.d_trp;
+        pw.tasks = rd.d_tasks;
+        pw.queue = g->d_wide_queue + qword++;
+        pw.mat = g->d_wide_mat;
+        pw.flags = p.flags;
+        const int bgrid = (int)std::max<long long>(1, std::min<long long>(pw.count, (long long)g->cu_count * cbuild_per_cu(plan->stage)));
+        if (pw.count > 0) HIP_TRY(launch_cbuild(pw, plan->stage, bgrid, stream));
+        plan_chunks += (uint64_t)pw.count;
+      }
       for (int cls = 2; cls >= 0; --cls) {  // X and L (one workgroup per CU) before S
         CliqueCountParams c;
         memset(&c, 0, sizeof c);
         c.rp = g->d_rp;
         c.verts = plan->d_verts;
-        c.base = plan->d_base;
+        c.base = plan->d_slot_base;
         c.mat = g->d_wide_mat;
         c.slots = plan->d_cls_slots + rd.cls_begin[cls];
         c.count = (int)(rd.cls_begin[cls + 1] - rd.cls_begin[cls]);
         c.queue = g->d_wide_queue + qword++;
         c.counters = g->d_counters;
         c.profile = prof ? d_prof + 4 * cls : nullptr;
+        c.topo = plan->topo ? 1 : 0;
         if (c.count == 0) continue;
         const int per_cu_c = (int)std::max<size_t>(1, std::min<size_t>((160 * 1024) / clique_count_lds_bytes(cls), (size_t)(2048 / clique_count_threads(cls))));
         const int cgrid = (int)std::max<long long>(1, std::min<long long>(c.count, (long long)g->cu_count * per_cu_c));
         HIP_TRY(launch_clique_count(cls, c, cgrid, stream));
+      }
+      if (rd.n_count > 0) {
+        CliqueSmallParams cs;
+        memset(&cs, 0, sizeof cs);
+        cs.rp = g->d_rp;
+        cs.chunks = plan->tabN->d;
+        cs.order = plan->d_order;
+        cs.first = (int)(plan->n_first + rd.n_pos0 * plan->n_step);
+        cs.step = (int)plan->n_step;
+        cs.count = (int)rd.n_count;
+        cs.base = rd.d_base;
+        cs.mat = g->d_wide_mat;
+        cs.queue = g->d_wide_queue + qword++;
+        cs.counters = g->d_counters;
+        cs.topo = plan->topo ? 1 : 0;
+        const int sgrid = (int)std::max<long long>(1, std::min<long long>(cs.count, (long long)g->cu_count * 8));
+        HIP_TRY(launch_clique_small(cs, sgrid, stream));
+        plan_chunks += (uint64_t)rd.n_count;
       }
     }
     if (prof) {
@@ -396,11 +429,13 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
         if (h[4 * cls + 3])
           fprintf(stderr, "[wide] count class %c: %llu workgroups; per workgroup ms: load %.2f count %.2f\n", "SLX"[cls], h[4 * cls + 3],
                   h[4 * cls] / (double)h[4 * cls + 3] / 1e5, h[4 * cls + 1] / (double)h[4 * cls + 3] / 1e5);
-      fprintf(stderr, "[wide] %zu vertices, %zu row-group chunks, %zu round(s), arena %.1f MB\n", plan->verts.size(), plan->n_chunks,
-              plan->rounds.size(), g->wide_mat_bytes / 1048576.0);
+      size_t nt = 0, nh = 0;
+      for (const auto &rd : plan->rounds) { nt += rd.n_tasks; nh += rd.host_tab.n; }
+      fprintf(stderr, "[clique plan] %zu wide vertices, %lld narrow chunks, %zu tasks in %zu host chunks, %zu round(s), arena %.1f MB, stage %d, %s numbering\n",
+              plan->verts.size(), plan->n_count, nt, nh, plan->rounds.size(), g->wide_mat_bytes / 1048576.0, plan->stage, plan->topo ? "topological" : "arbitrary");
     }
   }
-  uint64_t chunks_total = (uint64_t)p.count;
+  uint64_t chunks_total = (uint64_t)p.count + plan_chunks;
   bool joined[3] = {false, false, false};
   if (use_classes) {
     // A class kernel whose share of chunks cannot fill the chip on its own (small graphs, 1/8 shares) runs on a side stream, so
@@ -977,6 +1012,24 @@ extern "C" int gm_clique(const gm_graph *dag, int k, const gm_launch *la, uint64
     if (total) *total = 0;
     g_last_error = "gm_clique: k >= 5 needs max out-degree <= 4096 (this DAG: " + std::to_string(dag->max_deg) + ")";
     return GM_ERR_TOO_LARGE;
+  }
+  if (k == 4 && !(la && (la->tune[6] & (0x40000 | 0x200)))) {
+    // the re-hosted first level and the pair counts want a TOPOLOGICAL numbering (upper-triangular matrices: gm_cbuild.hip): a DAG
+    // that is not numbered that way runs on its cached renumbered copy (tune[6] & 0x200: on the graph as numbered, like the SgL
+    // patterns; & 0x40000: everything in the mining kernel, which does not care)
+    gm_graph *self = const_cast<gm_graph *>(dag);
+    if (!self) return GM_ERR_INVALID;
+    bool topo = false;
+    int rc = graph_is_topological(self, &topo);
+    if (rc) return rc;
+    gm_graph *run_on = self;
+    if (!topo) {
+      rc = get_relabeled(self, 2, &run_on);
+      if (rc) return rc;
+    }
+    rc = run_pattern(PAT_CLIQUE4, run_on, la, k, total, 1, st);
+    self->ring_alias = (run_on != self) ? run_on : nullptr;
+    return rc;
   }
   return run_pattern(k == 4 ? PAT_CLIQUE4 : PAT_CLIQUEK, dag, la, k, total, 1, st);
 }

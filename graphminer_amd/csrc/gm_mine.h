@@ -240,38 +240,17 @@ struct HouseParams {
 hipError_t launch_house_flat(const HouseParams &p, int grid_blocks, hipStream_t stream);
 hipError_t launch_house_blocks(const GraphView &g, unsigned *nblk, hipStream_t stream);
 
-// ---- k-clique, wide vertices: two phases -----------------------------------------------------------------------------------
-// A DAG vertex u whose d x d adjacency bit-matrix over N+(u) exceeds the mining kernel's 8 KB LDS budget (d+ > 256) is WIDE.
-//  phase 1 (gm_wide.hip, clique_build_kernel): its task edges are cut into ROW RANGES of 256 rows; a range is an independent
-//          task chunk (any workgroup takes it; a lean 22 KB workgroup, 7 per CU) whose waves build 4 rows at a time in LDS with
-//          the flattened passes of gm_flat.h and write them with coalesced stores to the vertex's slot of a MATRIX ARENA in HBM
-//          (sum d * ceil(d/32) words over the wide vertices: 4.4 GB for the com-Orkut stand-in -- HBM capacity is what
-//          MI355X has plenty of);
-//  phase 2 (gm_wide.hip, clique_count_kernel): one big-LDS workgroup per wide vertex copies the finished matrix into LDS
-//          (up to 128 KB) and counts sum_i sum_{j in M_i} popc(M_i & M_j) there.
-// Round 1 kept one arena slot per workgroup, so a wide vertex was built AND counted by a single workgroup (88 % of the
-// kernel time sat in those vertices, 382 GB of arena re-reads per launch).
+// ---- k-clique, wide vertices -----------------------------------------------------------------------------------------------------
+// A DAG vertex u whose d x d adjacency bit-matrix over N+(u) exceeds the 8 KB LDS budget of a narrow chunk (d+ > 256) is WIDE: its
+// matrix is counted by ONE big-LDS workgroup (gm_wide.hip, clique_count_kernel) that copies it from the matrix arena into LDS (up to
+// 128 KB) and counts sum_i sum_{j in M_i} popc(M_i & M_j) there. (Round 1 kept one arena slot per workgroup, so a wide vertex was built
+// AND counted by a single workgroup: 88 % of the kernel time, 382 GB of arena re-reads per launch; round 2 built the rows with a lean
+// kernel that streamed N+(v) of every edge; since round 3 every row is built where the LONGER list is staged: gm_cbuild.hip, below.)
 constexpr int kWideMaxDeg = 2048;   // wider DAG rows stay on the mining kernel's per-workgroup arena path
-// min_words: the matrix size (words) from which a vertex takes the two-phase path; kBitWords = what no longer fits the mining
-// kernel's LDS matrix, smaller values hand more vertices to the lean build kernel + the class-S count (GM_WIDE_MIN_WORDS)
+// min_words: the matrix size (words) from which a vertex is counted by the big-LDS classes; kBitWords = what no longer fits a narrow chunk
 __host__ __device__ inline bool clique_is_wide(int d, int min_words = kBitWords) {
   return (long long)d * ((d + 31) / 32) > min_words && d <= kWideMaxDeg;
 }
-constexpr int kBuildBatchRows = 4;        // task edges (rows) a wave builds at a time in its private LDS rows
-constexpr int kBuildRowsPerChunk = 256;   // rows of a wide vertex per phase-1 chunk (the workgroup stages N+(u) once per chunk)
-__host__ __device__ inline int clique_group_rows(int) { return kBuildRowsPerChunk; }
-struct CliqueBuildParams {
-  GraphView g;
-  const ChunkRec *chunks;         // row groups: {u, u + 1, first entry, last entry + 1, 0, 1, batch, slot + 1}
-  int count;
-  unsigned *queue;                // dequeue head (zeroed before launch; its own word)
-  unsigned *mat;                  // matrix arena
-  const unsigned long long *base; // slot -> word offset of the vertex's matrix
-  int cost_x_step, cost_y_step, cost_x_base, cost_y_base;  // direction rule of the mining kernel
-  int flags;
-};
-hipError_t launch_clique_build(const CliqueBuildParams &p, int grid_blocks, hipStream_t stream);
-size_t clique_build_lds_bytes();
 // padded row stride of the LDS copy: a multiple of 4 words whose quarter is odd, so that the 16-byte row reads of 16 lanes
 // (16 consecutive rows, same word offset) fall into 16 different bank groups
 __host__ __device__ inline int clique_padded_stride(int w) {
@@ -303,6 +282,7 @@ struct CliqueCountParams {
   unsigned *queue;                  // dequeue head (zeroed before launch; its own word)
   unsigned long long *counters;     // [0] += 4-cliques
   unsigned long long *profile;      // GM_WIDE_PROFILE: [0] load ticks, [1] count ticks, [3] workgroups (100 MHz, thread 0)
+  int topo;                         // the DAG is numbered topologically: the matrices are strictly upper triangular
 };
 hipError_t launch_clique_count(int cls, const CliqueCountParams &p, int grid_blocks, hipStream_t stream);
 size_t clique_count_lds_bytes(int cls);
@@ -313,6 +293,52 @@ __host__ __device__ inline int clique_count_class(int d) {
   if ((long long)d * clique_copy_stride(d, w, kCountWordsS) <= kCountWordsS) return 0;
   return (long long)d * clique_copy_stride(d, w, kCountWordsL) <= kCountWordsL ? 1 : 2;
 }
+
+// ---- k-clique (k = 4), level 1 RE-HOSTED (gm_cbuild.hip) -------------------------------------------------------------------------
+// Row i of u's adjacency bit-matrix over N+(u) is N+(u) ^ N+(v), v = N+(u)[i] -- the triangle list of the DAG edge u -> v with
+// positions. Like the triangle count of gm_tct.hip it is symmetric in which list is staged: the edge is a TASK of the endpoint with
+// the LONGER out-list, whose row sits in LDS, and the other list is streamed (sum min(d+(u), d+(v)) keys instead of sum d+(v)):
+//   type A  host = u: N+(v) streamed, a match at position p of the staged N+(u) is bit p of the row;
+//   type B  host = v: N+(u) streamed, a match at stream index k is bit bit_off + k of the row -- under a topological numbering of
+//           the DAG only the keys beyond v can be in N+(v): the stream starts at position i + 1 (= bit_off).
+// Either way the row belongs to u's matrix: every task carries the word offset of ITS row in the MATRIX ARENA (all matrices of the
+// launch, d x ceil(d/32) words per vertex with 3 <= d+ <= kCbMaxDeg, in vertex order) and the wave that built it stores it there.
+// Counting is a second set of launches over finished matrices: clique_small_kernel (matrices of a narrow chunk copied to LDS) and the
+// big-LDS classes S / L / X of gm_wide.hip.
+constexpr int kCbMaxDeg = kWideMaxDeg;  // 2048: the longest row that owns a matrix here / hosts tasks (longer rows: mine_kernel's arena path)
+constexpr int kCbMinDeg = 3;            // a vertex with fewer out-neighbours is in no 4-clique as its smallest member
+constexpr int kCbRowBuf = 256;          // words of finished rows a wave holds before it stores them (a row is <= 64 words)
+struct alignas(16) CBuildTask {
+  int list, len;       // the list to stream: col[list .. list + len)
+  unsigned off_lo;     // word offset of the task's row in the arena, low 32 bits
+  unsigned off_hi_fl;  // bits 0..7 offset >> 32; 8..19 bit_off; 20..26 words of the row (1..64); 31 type B
+};
+struct CBuildParams {
+  GraphView g;
+  const ChunkRec *chunks;   // host chunks: consecutive vertices whose DAG rows fit the stage
+  const int *order;         // dequeue position -> chunk id (nullptr = identity)
+  int count;
+  const int *trp;           // task lists: row offsets per host vertex (nv + 1)
+  const CBuildTask *tasks;
+  unsigned *queue;          // dequeue head (zeroed before launch)
+  unsigned *mat;            // matrix arena
+  int flags;
+};
+hipError_t launch_cbuild(const CBuildParams &p, int stage, int grid_blocks, hipStream_t stream);
+int cbuild_per_cu(int stage);
+// second DFS level of the narrow vertices (matrix <= kBitWords words): one workgroup per chunk of the narrow chunk table
+struct CliqueSmallParams {
+  const int *rp;
+  const ChunkRec *chunks;
+  const int *order;
+  int first, step, count;            // this rank's (round's) share: chunk ids order[first + i * step]
+  const unsigned long long *base;    // per vertex: word offset of its matrix in the arena (nv + 1)
+  const unsigned *mat;
+  unsigned *queue;
+  unsigned long long *counters;      // [0] += 4-cliques
+  int topo;                          // strictly upper triangular matrices: the words below j / 32 of M_j are skipped
+};
+hipError_t launch_clique_small(const CliqueSmallParams &p, int grid_blocks, hipStream_t stream);
 
 // host-side launchers (gm_mine.hip)
 hipError_t launch_mine(Pattern pat, const MineParams &p, int grid_blocks, hipStream_t stream);

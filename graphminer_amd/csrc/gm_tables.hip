@@ -105,11 +105,12 @@ __global__ __launch_bounds__(256) void bitmap_build_kernel(const int *__restrict
 __global__ __launch_bounds__(256) void chunk_cost_kernel(const int *__restrict__ rp, const int *__restrict__ col,
                                                          const ChunkRec *__restrict__ chunks, unsigned long long *__restrict__ cost,
                                                          int owner_rule, int stage_cap, const int *__restrict__ trp = nullptr,
-                                                         const int2 *__restrict__ tdesc = nullptr) {
+                                                         const int *__restrict__ tlen = nullptr, int tstride = 2) {
   const ChunkRec r = chunks[blockIdx.x];
   unsigned long long c = 0;
   if (owner_rule == 2) {  // gm_tct.hip: the keys of the lists this chunk's vertices host
-    for (int te = trp[r.u_begin] + (int)threadIdx.x; te < trp[r.u_end]; te += 256) c += (unsigned long long)tdesc[te].y + 8ull;
+    // (tlen: the length field of the first task record, tstride: ints per record -- int2 {start, len} of gm_tct.hip, CBuildTask of gm_cbuild.hip)
+    for (int te = trp[r.u_begin] + (int)threadIdx.x; te < trp[r.u_end]; te += 256) c += (unsigned long long)tlen[(size_t)te * (size_t)tstride] + 8ull;
   } else if (owner_rule) {
     // a key streamed by a SPLIT chunk is a random probe of the hub row's bitmap in HBM, a key of a staged chunk an LDS filter probe
     const unsigned long long w = (r.u_end == r.u_begin + 1 && (r.e_begin != rp[r.u_begin] || r.e_end != rp[r.u_end])) ? (unsigned long long)kProbeCost : 1ull;
@@ -269,7 +270,14 @@ __global__ __launch_bounds__(256) void gather_deg_kernel(int m, const int *__res
   if (i < m) deg[i] = rp[verts[i] + 1] - rp[verts[i]];
 }
 
-static int build_table_device(gm_graph *g, ChunkTable &t, bool sym_table, double &bitmap_ms) {
+// (trp / tlen / tstride: the task lists the costs of an rf.tct table are counted from; default: the graph's, gm_tct.hip)
+static int build_table_device(gm_graph *g, ChunkTable &t, bool sym_table, double &bitmap_ms, const int *trp = nullptr, const int *tlen = nullptr,
+                              int tstride = 2) {
+  if (!trp) {
+    trp = g->d_trp;
+    tlen = g->d_tdesc ? &g->d_tdesc[0].y : nullptr;
+    tstride = 2;
+  }
   const int nv = g->nv;
   TableDevParams q;
   q.nv = nv;
@@ -305,7 +313,7 @@ static int build_table_device(gm_graph *g, ChunkTable &t, bool sym_table, double
   HIP_TRY(cost0.alloc((size_t)n0));
   HIP_TRY(hipMemsetAsync(cost0.p, 0, sizeof(unsigned long long) * (size_t)n0, 0));
   hipLaunchKernelGGL(chunk_cost_kernel, dim3((unsigned)n0), dim3(256), 0, 0, g->d_rp, g->d_col, recs0.p, cost0.p, t.rf.tct ? 2 : (sym_table ? 1 : 0), kStageCapWide,
-                     g->d_trp, g->d_tdesc);
+                     trp, tlen, tstride);
   DevBuf<int> np, bsz, off;
   HIP_TRY(np.alloc((size_t)n0 + 1));
   HIP_TRY(bsz.alloc((size_t)n0 + 1));
@@ -719,10 +727,8 @@ int ensure_edesc(gm_graph *g) {
   return GM_OK;
 }
 
-// k-clique, wide vertices (see gm_mine.h): the plan of one rank's share -- which wide vertices it owns (every world-th of
-// the list sorted by row length, or a contiguous range), where each one's matrix sits in the arena, the row-group chunks of
-// phase 1 and the slots per count class of phase 2. The arena is bounded (GM_WIDE_ARENA_MB, default 16 GiB): a share whose
-// matrices need more is processed in several ROUNDS that reuse it.
+// k-clique (k = 4): the plan of one rank's share for the re-hosted first level (gm_mine.h, gm_cbuild.hip). Everything below runs on
+// the device except what is O(wide vertices of the share) or O(chunks).
 #ifndef GM_WIDE_MIN_WORDS_DEFAULT
 #define GM_WIDE_MIN_WORDS_DEFAULT kBitWords
 #endif
@@ -737,24 +743,110 @@ __global__ __launch_bounds__(256) void wide_flag_kernel(int nv, const int *__res
 }
 // this rank's share of the sorted wide list: slot i = entry first + i * step
 __global__ __launch_bounds__(256) void wide_share_kernel(int count, long long first, long long step, const int *__restrict__ wide_sorted,
-                                                         const int *__restrict__ rp, int *__restrict__ verts, int *__restrict__ degs, int *__restrict__ ngroups) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i > count) return;
-  if (i == count) { ngroups[i] = 0; return; }
-  const int u = wide_sorted[first + (long long)i * step];
-  const int d = rp[u + 1] - rp[u];
-  verts[i] = u;
-  degs[i] = d;
-  const int R = clique_group_rows(d);
-  ngroups[i] = (d + R - 1) / R;
-}
-__global__ __launch_bounds__(256) void wide_groups_kernel(int count, const int *__restrict__ verts, const int *__restrict__ rp, const int *__restrict__ goff,
-                                                          int batch, ChunkRec *__restrict__ chunks) {
+                                                         const int *__restrict__ rp, int *__restrict__ verts, int *__restrict__ degs) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
-  const int u = verts[i], b = rp[u], d = rp[u + 1] - b, R = clique_group_rows(d);
-  int o = goff[i];
-  for (int g0 = 0; g0 < d; g0 += R) chunks[o++] = {u, u + 1, b + g0, b + min(g0 + R, d), 0, 1, batch, i + 1};
+  const int u = wide_sorted[first + (long long)i * step];
+  verts[i] = u;
+  degs[i] = rp[u + 1] - rp[u];
+}
+__device__ __forceinline__ unsigned long long cb_matrix_words(int d) {
+  return (d >= kCbMinDeg && d <= kCbMaxDeg) ? (unsigned long long)d * (unsigned long long)((d + 31) / 32) : 0ull;
+}
+// words of the matrices of every narrow chunk of the share (position i of the share = chunk order[first + i * step])
+__global__ __launch_bounds__(256) void cb_chunk_words_kernel(long long count, long long first, long long step, const int *__restrict__ order,
+                                                             const ChunkRec *__restrict__ chunks, const int *__restrict__ rp,
+                                                             unsigned long long *__restrict__ words) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const long long pos = first + i * step;
+  const ChunkRec r = chunks[order ? order[pos] : pos];
+  unsigned long long w = 0;
+  for (int u = r.u_begin; u < r.u_end; ++u) w += cb_matrix_words(rp[u + 1] - rp[u]);
+  words[i] = w;
+}
+// owners of a round: the vertices of its narrow chunks ...
+__global__ __launch_bounds__(256) void cb_own_chunks_kernel(long long count, long long first, long long step, const int *__restrict__ order,
+                                                            const ChunkRec *__restrict__ chunks, int *__restrict__ own) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const long long pos = first + i * step;
+  const ChunkRec r = chunks[order ? order[pos] : pos];
+  for (int u = r.u_begin; u < r.u_end; ++u) own[u] = 1;
+}
+// ... and its wide vertices
+__global__ __launch_bounds__(256) void cb_own_verts_kernel(int count, const int *__restrict__ verts, int *__restrict__ own) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) own[verts[i]] = 1;
+}
+// per vertex: matrix words and task edges of an owner (0 for everybody else; [nv] = 0 so that the scans end with the totals)
+__global__ __launch_bounds__(256) void cb_owner_sizes_kernel(int nv, const int *__restrict__ rp, const int *__restrict__ own,
+                                                             unsigned long long *__restrict__ words, int *__restrict__ tasks) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v > nv) return;
+  unsigned long long w = 0;
+  int t = 0;
+  if (v < nv && own[v]) {
+    const int d = rp[v + 1] - rp[v];
+    w = cb_matrix_words(d);
+    t = w ? d : 0;
+  }
+  words[v] = w;
+  tasks[v] = t;
+}
+// one key per task: (host << 32) | entry; value = the owner u. The edge u -> v is hosted by the endpoint with the longer out-list,
+// when that list fits the stage -- like gm_tct.hip's task lists (task_keys_kernel), restricted to the owners' edges.
+__global__ __launch_bounds__(256) void cb_task_keys_kernel(int nv, long long ne, const int *__restrict__ rp, const int *__restrict__ col,
+                                                           const int *__restrict__ ntask_of, const int *__restrict__ tpos,
+                                                           unsigned long long *__restrict__ keys, int *__restrict__ vals, int *__restrict__ cnt) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += stride) {
+    int lo = 0, hi = nv - 1;  // the row of entry e: largest u with rp[u] <= e
+    while (lo < hi) {
+      const int mid = (int)(((long long)lo + hi + 1) >> 1);
+      if (rp[mid] <= e) lo = mid; else hi = mid - 1;
+    }
+    const int u = lo, v = col[e];
+    if (ntask_of[u] == 0) continue;  // not an owner of this round (or no matrix: d+ < 3 / > kCbMaxDeg)
+    const int du = rp[u + 1] - rp[u], dv = rp[v + 1] - rp[v];
+    const int host = (dv > du && dv <= kCbMaxDeg) ? v : u;
+    const long long t = (long long)tpos[u] + (e - rp[u]);
+    keys[t] = ((unsigned long long)(unsigned)host << 32) | (unsigned long long)(unsigned)e;
+    vals[t] = u;
+    atomicAdd(&cnt[host], 1);
+  }
+}
+__global__ __launch_bounds__(256) void cb_task_desc_kernel(long long nt, const int *__restrict__ rp, const int *__restrict__ col,
+                                                           const unsigned long long *__restrict__ keys, const int *__restrict__ owners,
+                                                           const unsigned long long *__restrict__ base, int topo, CBuildTask *__restrict__ out) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < nt; t += stride) {
+    const unsigned long long k = keys[t];
+    const int host = (int)(unsigned)(k >> 32), e = (int)(unsigned)(k & 0xffffffffull);
+    const int u = owners[t], v = col[e];
+    const int ru = rp[u], du = rp[u + 1] - ru, i = e - ru;
+    const int words = (du + 31) / 32;
+    const unsigned long long off = base[u] + (unsigned long long)i * (unsigned long long)words;
+    CBuildTask T;
+    unsigned fl = (unsigned)(off >> 32) & 255u;
+    if (host == u) {  // type A: N+(v) is streamed against the staged N+(u)
+      T.list = rp[v];
+      T.len = rp[v + 1] - rp[v];
+    } else {          // type B: N+(u) -- beyond v when the numbering is topological -- is streamed against the staged N+(v)
+      const int skip = topo ? i + 1 : 0;
+      T.list = ru + skip;
+      T.len = du - skip;
+      fl |= ((unsigned)skip << 8) | 0x80000000u;
+    }
+    T.off_lo = (unsigned)off;
+    T.off_hi_fl = fl | ((unsigned)words << 20);
+    out[t] = T;
+  }
+}
+__global__ __launch_bounds__(256) void cb_slot_base_kernel(int w0, int w1, const int *__restrict__ verts, const unsigned long long *__restrict__ base,
+                                                           unsigned long long *__restrict__ slot_base) {
+  const int s = w0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < w1) slot_base[s] = base[verts[s]];
 }
 
 int clique_wide_min_words() {
@@ -765,116 +857,258 @@ int clique_wide_min_words() {
   return v;
 }
 
-int get_wide_plan(gm_graph *g, int rank, int world, int policy, WidePlan **out) {
-  std::lock_guard<std::mutex> lk(g->mu);
-  SetupTimer timer;
+static void free_clique_plan(CliquePlan &pl) {
+  if (pl.d_verts) (void)hipFree(pl.d_verts);
+  if (pl.d_slot_base) (void)hipFree(pl.d_slot_base);
+  if (pl.d_cls_slots) (void)hipFree(pl.d_cls_slots);
+  for (auto &rd : pl.rounds) {
+    if (rd.d_base) (void)hipFree(rd.d_base);
+    if (rd.d_tasks) (void)hipFree(rd.d_tasks);
+    if (rd.d_trp) (void)hipFree(rd.d_trp);
+    free_table(rd.host_tab);
+  }
+  pl.rounds.clear();
+  pl.d_verts = nullptr; pl.d_slot_base = nullptr; pl.d_cls_slots = nullptr;
+}
+void free_clique_plans(gm_graph *g) {
+  for (auto &pl : g->clique_plans) free_clique_plan(pl);
+  g->clique_plans.clear();
+}
+
+// one round: owners -> offsets -> task lists -> host-chunk table
+static int build_clique_round(gm_graph *g, CliquePlan &pl, CliqueRound &rd, ScanTemp &tmp) {
+  const int nv = g->nv;
+  const size_t nv1 = (size_t)nv + 1;
+  auto blocks = [](long long n) { return dim3((unsigned)std::max<long long>(1, (n + 255) / 256)); };
+  DevBuf<int> own, ntask_of, tpos, cnt, owners, owners_sorted;
+  DevBuf<unsigned long long> words, keys, sorted;
+  HIP_TRY(own.alloc(nv1));
+  HIP_TRY(ntask_of.alloc(nv1));
+  HIP_TRY(tpos.alloc(nv1));
+  HIP_TRY(words.alloc(nv1));
+  HIP_TRY(hipMemsetAsync(own.p, 0, sizeof(int) * nv1, 0));
+  if (rd.n_count > 0)
+    hipLaunchKernelGGL(cb_own_chunks_kernel, blocks(rd.n_count), dim3(256), 0, 0, rd.n_count, pl.n_first + rd.n_pos0 * pl.n_step, pl.n_step, pl.d_order, pl.tabN->d, own.p);
+  if (rd.w1 > rd.w0)
+    hipLaunchKernelGGL(cb_own_verts_kernel, blocks((long long)(rd.w1 - rd.w0)), dim3(256), 0, 0, (int)(rd.w1 - rd.w0), pl.d_verts + rd.w0, own.p);
+  hipLaunchKernelGGL(cb_owner_sizes_kernel, blocks((long long)nv1), dim3(256), 0, 0, nv, g->d_rp, own.p, words.p, ntask_of.p);
+  HIP_TRY(hipMalloc(&rd.d_base, sizeof(unsigned long long) * nv1));
+  HIP_TRY(dev_exclusive_sum(tmp, words.p, rd.d_base, nv1));
+  HIP_TRY(dev_exclusive_sum(tmp, ntask_of.p, tpos.p, nv1));
+  int nt = 0;
+  HIP_TRY(hipMemcpy(&rd.words, rd.d_base + nv, 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(&nt, tpos.p + nv, sizeof(int), hipMemcpyDeviceToHost));
+  rd.n_tasks = (size_t)nt;
+  HIP_TRY(hipMalloc(&rd.d_trp, sizeof(int) * nv1));
+  if (nt == 0) {
+    HIP_TRY(hipMemset(rd.d_trp, 0, sizeof(int) * nv1));
+    return GM_OK;
+  }
+  HIP_TRY(cnt.alloc(nv1));
+  HIP_TRY(hipMemsetAsync(cnt.p, 0, sizeof(int) * nv1, 0));
+  HIP_TRY(keys.alloc((size_t)nt));
+  HIP_TRY(sorted.alloc((size_t)nt));
+  HIP_TRY(owners.alloc((size_t)nt));
+  HIP_TRY(owners_sorted.alloc((size_t)nt));
+  const long long kblocks = std::min<long long>(((long long)g->ne + 255) / 256, (long long)g->cu_count * 32);
+  hipLaunchKernelGGL(cb_task_keys_kernel, dim3((unsigned)kblocks), dim3(256), 0, 0, nv, g->ne, g->d_rp, g->d_col, ntask_of.p, tpos.p, keys.p, owners.p, cnt.p);
+  int bits = 1;
+  while (bits < 32 && (1ll << bits) < (long long)nv) ++bits;
+  size_t bytes = 0;
+  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, keys.p, sorted.p, owners.p, owners_sorted.p, nt, 0, 32 + bits));
+  HIP_TRY(tmp.reserve(bytes));
+  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.buf.p, bytes, keys.p, sorted.p, owners.p, owners_sorted.p, nt, 0, 32 + bits));
+  HIP_TRY(dev_exclusive_sum(tmp, cnt.p, rd.d_trp, nv1));
+  HIP_TRY(hipMalloc(&rd.d_tasks, sizeof(CBuildTask) * (size_t)nt));
+  const long long dblocks = std::min<long long>(((long long)nt + 255) / 256, (long long)g->cu_count * 32);
+  hipLaunchKernelGGL(cb_task_desc_kernel, dim3((unsigned)dblocks), dim3(256), 0, 0, (long long)nt, g->d_rp, g->d_col, sorted.p, owners_sorted.p, rd.d_base,
+                     pl.topo ? 1 : 0, rd.d_tasks);
+  HIP_TRY(hipGetLastError());
+  // host chunks: runs of consecutive vertices whose DAG rows fit the stage (longer rows host nothing), costs from the task lists,
+  // heavy chunks cut into parts like gm_tct.hip's (a hub hosts 10^5 in-edges)
+  ChunkTable &t = rd.host_tab;
+  t.target = std::max(64, std::min(pl.target, pl.stage));
+  t.allow_split = true;
+  t.bit_words = 0;
+  t.part_cap = std::max<unsigned long long>((1ull << 20) / (unsigned long long)std::max(pl.world, 1), 128ull << 10);
+  t.stage_cap = pl.stage;
+  t.rf.tct = 1;
+  t.rf.skip_lo = pl.stage;
+  t.rf.skip_hi = 0x7fffffff;
+  t.bitmap_min_deg = 0x7fffffff;
+  double bm_ms = 0;
+  int rc = build_table_device(g, t, false, bm_ms, rd.d_trp, &rd.d_tasks[0].len, (int)(sizeof(CBuildTask) / sizeof(int)));
+  if (rc) return rc;
+  if (rd.w1 > rd.w0)
+    hipLaunchKernelGGL(cb_slot_base_kernel, blocks((long long)(rd.w1 - rd.w0)), dim3(256), 0, 0, (int)rd.w0, (int)rd.w1, pl.d_verts, rd.d_base, pl.d_slot_base);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  return GM_OK;
+}
+
+int get_clique_plan(gm_graph *g, int rank, int world, int policy, int target, unsigned long long part_cap, CliquePlan **out) {
+  {
+    std::lock_guard<std::mutex> lk(g->mu);
+    for (auto &pl : g->clique_plans)
+      if (pl.rank == rank && pl.world == world && pl.policy == policy && pl.target == target) { *out = &pl; return GM_OK; }
+  }
+  // (built outside the lock: the solvers have ONE caller per handle; get_table below takes the lock itself)
   HIP_TRY(hipSetDevice(g->device));
+  CliquePlan pl;
+  pl.rank = rank; pl.world = world; pl.policy = policy; pl.target = target;
+  pl.stage = g->max_deg <= kStageCapClique ? kStageCapClique : kCbMaxDeg;
+  // narrow chunk table (whole rows, matrices of a chunk <= kBitWords words together; the wide and the huge rows left out)
+  {
+    RowFilter rf;
+    rf.skip_clique_wide = clique_wide_min_words();
+    rf.only_hi = kCbMaxDeg;  // rows beyond the stage of the build kernel: mine_kernel's arena path (run_pattern)
+    const int rc = get_table(g, target, false, kBitWords, part_cap, kStageCapClique, &pl.tabN, rf, kBitmapMinDeg);
+    if (rc) return rc;
+  }
+  SetupTimer timer;
   ScanTemp tmp;
   auto blocks = [](long long n) { return dim3((unsigned)std::max<long long>(1, (n + 255) / 256)); };
   if (!g->wide_valid) {  // once per graph: the wide vertices, longest rows first (select + stable radix sort by row length)
     const int nv = g->nv;
     DevBuf<int> flag, iota, sel, nsel, degs, keyo;
-    HIP_TRY(flag.alloc((size_t)nv));
-    HIP_TRY(iota.alloc((size_t)nv));
-    HIP_TRY(sel.alloc((size_t)nv));
+    HIP_TRY(flag.alloc((size_t)std::max(nv, 1)));
+    HIP_TRY(iota.alloc((size_t)std::max(nv, 1)));
+    HIP_TRY(sel.alloc((size_t)std::max(nv, 1)));
     HIP_TRY(nsel.alloc(1));
-    hipLaunchKernelGGL(wide_flag_kernel, blocks(nv), dim3(256), 0, 0, nv, g->d_rp, clique_wide_min_words(), flag.p, iota.p);
-    size_t bytes = 0;
-    HIP_TRY(hipcub::DeviceSelect::Flagged(nullptr, bytes, iota.p, flag.p, sel.p, nsel.p, nv));
-    HIP_TRY(tmp.reserve(bytes));
-    HIP_TRY(hipcub::DeviceSelect::Flagged(tmp.buf.p, bytes, iota.p, flag.p, sel.p, nsel.p, nv));
     int m = 0;
-    HIP_TRY(hipMemcpy(&m, nsel.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (nv > 0) {
+      hipLaunchKernelGGL(wide_flag_kernel, blocks(nv), dim3(256), 0, 0, nv, g->d_rp, clique_wide_min_words(), flag.p, iota.p);
+      size_t bytes = 0;
+      HIP_TRY(hipcub::DeviceSelect::Flagged(nullptr, bytes, iota.p, flag.p, sel.p, nsel.p, nv));
+      HIP_TRY(tmp.reserve(bytes));
+      HIP_TRY(hipcub::DeviceSelect::Flagged(tmp.buf.p, bytes, iota.p, flag.p, sel.p, nsel.p, nv));
+      HIP_TRY(hipMemcpy(&m, nsel.p, sizeof(int), hipMemcpyDeviceToHost));
+    }
     g->n_wide = (size_t)m;
     if (m > 0) {
       HIP_TRY(degs.alloc((size_t)m));
       HIP_TRY(keyo.alloc((size_t)m));
       hipLaunchKernelGGL(gather_deg_kernel, blocks(m), dim3(256), 0, 0, m, sel.p, g->d_rp, degs.p);
       HIP_TRY(hipMalloc(&g->d_wide_sorted, sizeof(int) * (size_t)m));
-      bytes = 0;
+      size_t bytes = 0;
       HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, bytes, degs.p, keyo.p, sel.p, g->d_wide_sorted, m));
       HIP_TRY(tmp.reserve(bytes));
       HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(tmp.buf.p, bytes, degs.p, keyo.p, sel.p, g->d_wide_sorted, m));
     }
     g->wide_valid = true;
   }
-  for (auto &pl : g->wide_plans)
-    if (pl.rank == rank && pl.world == world && pl.policy == policy) { *out = &pl; return GM_OK; }
-  WidePlan pl;
-  pl.rank = rank; pl.world = world; pl.policy = policy;
-  int64_t first = 0, step = 1, count = 0;
-  gm_partition((int64_t)g->n_wide, rank, world, policy, &first, &step, &count);
-  if (count > 0) {
-    DevBuf<int> degs, ngroups, goff;
-    HIP_TRY(hipMalloc(&pl.d_verts, sizeof(int) * (size_t)count));
-    HIP_TRY(degs.alloc((size_t)count));
-    HIP_TRY(ngroups.alloc((size_t)count + 1));
-    HIP_TRY(goff.alloc((size_t)count + 1));
-    hipLaunchKernelGGL(wide_share_kernel, blocks(count + 1), dim3(256), 0, 0, (int)count, (long long)first, (long long)step, g->d_wide_sorted, g->d_rp,
-                       pl.d_verts, degs.p, ngroups.p);
-    HIP_TRY(dev_exclusive_sum(tmp, ngroups.p, goff.p, (size_t)count + 1));
-    int nchunks = 0;
-    HIP_TRY(hipMemcpy(&nchunks, goff.p + count, sizeof(int), hipMemcpyDeviceToHost));
-    pl.n_chunks = (size_t)nchunks;
-    HIP_TRY(hipMalloc(&pl.d_chunks, sizeof(ChunkRec) * (size_t)std::max(nchunks, 1)));
-    const int build_batch = kBuildBatchRows;
-    hipLaunchKernelGGL(wide_groups_kernel, blocks(count), dim3(256), 0, 0, (int)count, pl.d_verts, g->d_rp, goff.p, build_batch, pl.d_chunks);
-    // host part, O(wide vertices of this share): arena offsets, rounds within the arena budget, count classes
-    pl.verts.resize((size_t)count);
-    std::vector<int> hd((size_t)count), hgoff((size_t)count + 1);
-    HIP_TRY(hipMemcpy(pl.verts.data(), pl.d_verts, sizeof(int) * (size_t)count, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(hd.data(), degs.p, sizeof(int) * (size_t)count, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(hgoff.data(), goff.p, sizeof(int) * ((size_t)count + 1), hipMemcpyDeviceToHost));
-    unsigned long long arena_mb = GM_WIDE_ARENA_MB;
-    if (const char *e = getenv("GM_WIDE_ARENA_MB")) arena_mb = std::max(1ll, atoll(e));  // (tests: force several rounds)
-    const unsigned long long budget_words = (arena_mb << 20) / 4ull;
-    std::vector<unsigned long long> base((size_t)count);
-    std::vector<int> cls_slots;
+  {  // topological numbering? (decides whether the in-edge tasks stream only the part of N+(u) beyond v)
+    bool topo = false;
+    const int rc = graph_is_topological(g, &topo);
+    if (rc) return rc;
+    pl.topo = topo && !getenv("GM_CLIQUE_NO_TOPO");  // (GM_CLIQUE_NO_TOPO: A/B, whole lists streamed)
+  }
+  {  // this rank's share of the narrow table: every world-th chunk of the cost-ordered dequeue list, a contiguous range, or the
+     // chunks of a vertex range
+    ChunkTable *tb = pl.tabN;
+    const long long n = (long long)tb->n;
+    long long first = 0, step = 1, count = 0;
+    if (policy == GM_PART_VERTEX) {
+      const long long vlo = (long long)g->nv * rank / world, vhi = (long long)g->nv * (rank + 1) / world;
+      auto first_chunk_at = [&](long long v) {
+        long long lo = 0, hi = n;
+        while (lo < hi) {
+          const long long mid = (lo + hi) / 2;
+          if (tb->first_vertex[(size_t)mid] < v) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+      };
+      first = first_chunk_at(vlo);
+      count = first_chunk_at(vhi) - first;
+    } else {
+      gm_partition((int64_t)n, rank, world, policy, (int64_t *)&first, (int64_t *)&step, (int64_t *)&count);
+    }
+    pl.n_first = first; pl.n_step = step; pl.n_count = count;
+    pl.d_order = (policy == GM_PART_ROUND_ROBIN) ? tb->d_order[pl.order_which] : nullptr;
+  }
+  // this rank's share of the wide list
+  int64_t wfirst = 0, wstep = 1, wcount = 0;
+  gm_partition((int64_t)g->n_wide, rank, world, policy == GM_PART_VERTEX ? GM_PART_RANGE : policy, &wfirst, &wstep, &wcount);
+  std::vector<int> hd((size_t)wcount);
+  if (wcount > 0) {
+    DevBuf<int> degs;
+    HIP_TRY(hipMalloc(&pl.d_verts, sizeof(int) * (size_t)wcount));
+    HIP_TRY(hipMalloc(&pl.d_slot_base, sizeof(unsigned long long) * (size_t)wcount));
+    HIP_TRY(degs.alloc((size_t)wcount));
+    hipLaunchKernelGGL(wide_share_kernel, blocks(wcount), dim3(256), 0, 0, (int)wcount, (long long)wfirst, (long long)wstep, g->d_wide_sorted, g->d_rp, pl.d_verts, degs.p);
+    pl.verts.resize((size_t)wcount);
+    HIP_TRY(hipMemcpy(pl.verts.data(), pl.d_verts, sizeof(int) * (size_t)wcount, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hd.data(), degs.p, sizeof(int) * (size_t)wcount, hipMemcpyDeviceToHost));
+  }
+  // rounds within the arena budget: the narrow chunks first (in dequeue order), then the wide vertices (longest rows first)
+  unsigned long long arena_mb = GM_WIDE_ARENA_MB;
+  if (const char *e = getenv("GM_WIDE_ARENA_MB")) arena_mb = std::max(1ll, atoll(e));  // (tests: force several rounds)
+  const unsigned long long budget_words = (arena_mb << 20) / 4ull;
+  std::vector<unsigned long long> cw((size_t)pl.n_count);
+  if (pl.n_count > 0) {
+    DevBuf<unsigned long long> dcw;
+    HIP_TRY(dcw.alloc((size_t)pl.n_count));
+    hipLaunchKernelGGL(cb_chunk_words_kernel, blocks(pl.n_count), dim3(256), 0, 0, pl.n_count, pl.n_first, pl.n_step, pl.d_order, pl.tabN->d, g->d_rp, dcw.p);
+    HIP_TRY(hipMemcpy(cw.data(), dcw.p, sizeof(unsigned long long) * (size_t)pl.n_count, hipMemcpyDeviceToHost));
+  }
+  std::vector<int> cls_slots;
+  {
+    long long c0 = 0;
     size_t s0 = 0;
-    while (s0 < (size_t)count) {
-      WidePlan::Round rd;
-      rd.chunk_begin = (size_t)hgoff[s0];
-      size_t s1 = s0;
+    while (c0 < pl.n_count || s0 < (size_t)wcount || pl.rounds.empty()) {
+      CliqueRound rd;
       unsigned long long words = 0;
-      std::vector<int> by_cls[3];
-      for (; s1 < (size_t)count; ++s1) {
-        const int d = hd[s1];
-        const unsigned long long w = (unsigned long long)d * (unsigned long long)((d + 31) / 32);
-        if (s1 > s0 && words + w > budget_words) break;
-        base[s1] = words;
-        words += w;
-        pl.edges += (unsigned long long)d;
-        by_cls[clique_count_class(d)].push_back((int)s1);
+      long long c1 = c0;
+      for (; c1 < pl.n_count; ++c1) {
+        if ((c1 > c0) && words + cw[(size_t)c1] > budget_words) break;
+        words += cw[(size_t)c1];
       }
-      rd.chunk_end = (size_t)hgoff[s1];
-      rd.words = words;
+      size_t s1 = s0;
+      std::vector<int> by_cls[3];
+      if (c1 == pl.n_count) {  // (wide vertices only once the narrow chunks are placed)
+        for (; s1 < (size_t)wcount; ++s1) {
+          const int d = hd[s1];
+          const unsigned long long w = (unsigned long long)d * (unsigned long long)((d + 31) / 32);
+          if ((s1 > s0 || c1 > c0) && words + w > budget_words) break;
+          words += w;
+          pl.wide_edges += (unsigned long long)d;
+          by_cls[clique_count_class(d)].push_back((int)s1);
+        }
+      }
+      rd.n_pos0 = c0; rd.n_count = c1 - c0;
+      rd.w0 = s0; rd.w1 = s1;
       for (int c = 0; c < 3; ++c) {
         rd.cls_begin[c] = cls_slots.size();
         cls_slots.insert(cls_slots.end(), by_cls[c].begin(), by_cls[c].end());
       }
       rd.cls_begin[3] = cls_slots.size();
-      pl.rounds.push_back(rd);
+      pl.rounds.push_back(std::move(rd));
+      c0 = c1;
       s0 = s1;
+      if (c0 >= pl.n_count && s0 >= (size_t)wcount) break;
     }
-    HIP_TRY(hipMalloc(&pl.d_base, sizeof(unsigned long long) * base.size()));
-    HIP_TRY(hipMemcpy(pl.d_base, base.data(), sizeof(unsigned long long) * base.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc(&pl.d_cls_slots, sizeof(int) * cls_slots.size()));
-    HIP_TRY(hipMemcpy(pl.d_cls_slots, cls_slots.data(), sizeof(int) * cls_slots.size(), hipMemcpyHostToDevice));
-    unsigned long long need_words = 0;
-    for (auto &rd : pl.rounds) need_words = std::max(need_words, rd.words);
-    const size_t need = (size_t)need_words * 4;
-    if (need > g->wide_mat_bytes) {
-      if (g->d_wide_mat) (void)hipFree(g->d_wide_mat);
-      g->d_wide_mat = nullptr;
-      g->wide_mat_bytes = 0;
-      HIP_TRY(hipMalloc(&g->d_wide_mat, need));
-      g->wide_mat_bytes = need;
-    }
-    if (!g->d_wide_queue) HIP_TRY(hipMalloc(&g->d_wide_queue, 65536));
-    HIP_TRY(hipDeviceSynchronize());
   }
-  g->wide_plans.push_back(std::move(pl));
-  *out = &g->wide_plans.back();
+  HIP_TRY(hipMalloc(&pl.d_cls_slots, sizeof(int) * std::max<size_t>(cls_slots.size(), 1)));
+  if (!cls_slots.empty()) HIP_TRY(hipMemcpy(pl.d_cls_slots, cls_slots.data(), sizeof(int) * cls_slots.size(), hipMemcpyHostToDevice));
+  unsigned long long need_words = 0;
+  for (size_t r = 0; r < pl.rounds.size(); ++r) {
+    const int rc = build_clique_round(g, pl, pl.rounds[r], tmp);
+    if (rc) { free_clique_plan(pl); return rc; }
+    need_words = std::max(need_words, pl.rounds[r].words);
+  }
+  const size_t need = (size_t)need_words * 4;
+  if (need > g->wide_mat_bytes) {
+    if (g->d_wide_mat) (void)hipFree(g->d_wide_mat);
+    g->d_wide_mat = nullptr;
+    g->wide_mat_bytes = 0;
+    HIP_TRY(hipMalloc(&g->d_wide_mat, std::max<size_t>(need, 16)));
+    g->wide_mat_bytes = need;
+  }
+  if (!g->d_wide_queue) HIP_TRY(hipMalloc(&g->d_wide_queue, 65536));
+  HIP_TRY(hipDeviceSynchronize());
+  std::lock_guard<std::mutex> lk(g->mu);
+  g->clique_plans.push_back(std::move(pl));
+  *out = &g->clique_plans.back();
   g->setup.table_ms += timer.ms();
   return GM_OK;
 }

@@ -204,3 +204,269 @@ extern "C" int gm_selftest(int device, int *n_fail) {
   if (bad) { g_last_error = "wave primitive self test mismatch"; return GM_ERR_HIP; }
   return GM_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Issue-rate calibration (tooling; VERDICT r2: "calibrate issue costs the way FETCH_SIZE was calibrated").
+// W waves per SIMD on every CU each execute `iters` x 64 instructions of ONE kind over 8 independent registers (inline asm, so the
+// compiler neither folds nor reorders them) between two s_memtime reads.  From the per-wave shader cycles c (median over the waves):
+//   cycles per wave-instruction            c / (64 iters)          -- the issue interval one wave sees
+//   wave-instructions per cycle and SIMD   W * 64 iters / c        -- the unit's throughput (VALU, LDS: per SIMD; SALU: x4 = per CU)
+// Run under `rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE` the same launches tell what
+// the SQ counters report for a unit that is KNOWN to be saturated (scripts/issue_calibration.py -> profiles/r03/issue_calibration.txt).
+// The loop itself adds 3 scalar instructions (s_add, s_cmp, s_cbranch) per 64 measured ones.
+enum : int {
+  CAL_V_ADD = 0, CAL_V_MUL_LO = 1, CAL_V_MUL_U24 = 2, CAL_V_CMP_SGPR = 3, CAL_V_DPP = 4, CAL_S_ADD = 5, CAL_DS_READ_B128 = 6,
+  CAL_DS_READ_B32 = 7, CAL_DS_READ_B32_CONFLICT = 8, CAL_V_S_MIX = 9, CAL_V_READLANE = 10, CAL_V_MBCNT = 11, CAL_V_BCNT = 12,
+  CAL_V_CMP_SDWA = 13, CAL_DS_WRITE_B32 = 14, CAL_V_CNDMASK = 15, CAL_V_CNDMASK_SGPR = 16, CAL_V_AND = 17, CAL_V_ASHR = 18, CAL_V_MIN = 19,
+  CAL_V_MAD_U24 = 20, CAL_V_ADD3 = 21, CAL_V_CMP_VCC = 22, CAL_V_CMP_CNDMASK = 23, CAL_V_MOV = 24, CAL_V_SUB_ASHR_AND_ADD = 25, CAL_V_XOR_SGPR = 26,
+  CAL_S_BCNT1 = 27, CAL_KINDS = 28
+};
+
+#define GM_CAL8(OP)  OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7)
+#define GM_CAL64(OP) GM_CAL8(OP) GM_CAL8(OP) GM_CAL8(OP) GM_CAL8(OP) GM_CAL8(OP) GM_CAL8(OP) GM_CAL8(OP) GM_CAL8(OP)
+
+template <int KIND>
+__global__ __launch_bounds__(256) void issue_calib_kernel(int iters, unsigned long long *__restrict__ cycles, unsigned *__restrict__ sink) {
+  extern __shared__ unsigned dyn_lds[];  // sized by the host so that exactly W workgroups fit a CU
+  const int tid = threadIdx.x, lane = tid & 63;
+  unsigned v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (unsigned)(tid * 8 + i) | 1u;
+  unsigned s[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s[i] = (unsigned)(blockIdx.x + i);
+  unsigned long long m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned k = (unsigned)iters | 3u;
+  // LDS addresses: conflict-free (consecutive 16 B / 4 B per lane) or one bank for 32 lanes (stride 256 B: 2 x 32-way)
+  for (int i = tid; i < 4096; i += 256) dyn_lds[i] = (unsigned)i;
+  __syncthreads();
+  const unsigned a128 = (unsigned)tid * 16u, a32 = (unsigned)tid * 4u, aconf = ((unsigned)lane * 256u) & 16383u;
+  uint4 w[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) w[i] = make_uint4(0, 0, 0, 0);
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_s_barrier();
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; ++it) {
+    if constexpr (KIND == CAL_V_ADD) {
+#define OP(i) asm volatile("v_add_u32 %0, %0, %1" : "+v"(v[i]) : "v"(k));
+      GM_CAL64(OP)
+#undef OP
+    } else if constexpr (KIND == CAL_V_MUL_LO) {
+#define OP(i) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(v[i]) : "v"(k));
+      GM_CAL64(OP)
+#undef OP
+    } else if constexpr (KIND == CAL_V_MUL_U24) {
+#define OP(i) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(v[i]) : "v"(k));
+      GM_CAL64(OP)
+#undef OP
+    } else if constexpr (KIND == CAL_V_CMP_SGPR) {
+#define OP(i) asm volatile("v_cmp_lt_u32 %0, %1, %2" : "=s"(m[i]) : "v"(v[i]), "v"(k));
+      GM_CAL64(OP)
+#undef OP
+    } else if constexpr (KIND == CAL_V_DPP) {
+#define OP(i) asm volatile("v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(v[i]));
+      GM_CAL64(OP)
+#undef OP
+    } else if constexpr (KIND == CAL_S_ADD) {
+#define OP(i) asm volatile("s_add_u32 %0, %0, %1" : "+s"(s[i]) : "s"(k) : "scc");
+      GM_CAL64(OP)
+#undef OP
+    } else if constexpr (KIND == CAL_DS_READ_B128) {
+#define OP(i) asm volatile("ds_read_b128 %0, %1" : "=v"(w[i]) : "v"(a128));
+      GM_CAL64(OP)
+#undef OP
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else if constexpr (KIND == CAL_DS_READ_B32) {
+#define OP(i) asm volatile("ds_read_b32 %0, %1" : "=v"(v[i]) : "v"(a32));
+      GM_CAL64(OP)
+#undef OP
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else if constexpr (KIND == CAL_DS_READ_B32_CONFLICT) {
+#define OP(i) asm volatile("ds_read_b32 %0, %1" : "=v"(v[i]) : "v"(aconf));
+      GM_CAL64(OP)
+#undef OP
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else if constexpr (KIND == CAL_V_S_MIX) {  // 32 VALU + 32 SALU interleaved: do they issue side by side?
+#define OP(i) asm volatile("v_add_u32 %0, %0, %2\n\ts_add_u32 %1, %1, %3" : "+v"(v[i]), "+s"(s[i]) : "v"(k), "s"(k) : "scc");
+      GM_CAL8(OP) GM_CAL8(OP) GM_CAL8(OP) GM_CAL8(OP)
+#undef OP
+    } else if constexpr (KIND == CAL_V_READLANE) {
+#define OP(i) asm volatile("v_readlane_b32 %0, %1, 17" : "=s"(s[i]) : "v"(v[i]));
+      GM_CAL64(OP)
+#undef OP
+    } else if constexpr (KIND == CAL_V_MBCNT) {
+#define OP(i) asm volatile("v_mbcnt_lo_u32_b32 %0, %1, %0" : "+v"(v[i]) : "s"(k));
+      GM_CAL64(OP)
+#undef OP
+    } else if constexpr (KIND == CAL_V_BCNT) {
+#define OP(i) asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(v[i]) : "v"(k));
+      GM_CAL64(OP)
+#undef OP
+    } else if constexpr (KIND == CAL_V_CMP_SDWA) {
+#define OP(i) asm volatile("v_cmp_eq_u16_sdwa %0, %1, %2 src0_sel:WORD_1 src1_sel:WORD_0" : "=s"(m[i]) : "v"(v[i]), "v"(k));
+      GM_CAL64(OP)
+#undef OP
+    } else if constexpr (KIND == CAL_DS_WRITE_B32) {
+#define OP(i) asm volatile("ds_write_b32 %0, %1" : : "v"(a32), "v"(v[i]) : "memory");
+      GM_CAL64(OP)
+#undef OP
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else if constexpr (KIND == CAL_V_CNDMASK) {
+#define OP(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(v[i]) : "v"(k) : "vcc");
+      GM_CAL64(OP)
+#undef OP
+    } else if constexpr (KIND == CAL_V_CNDMASK_SGPR) {  // the mask in an SGPR pair (VOP3 form), as a v_cmp ... -> s[a:b] leaves it
+#define OP(i) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(v[i]) : "v"(k), "s"(m[0]));
+      GM_CAL64(OP)
+#undef OP
+    } else if constexpr (KIND == CAL_V_AND) {
+#define OP(i) asm volatile("v_and_b32 %0, %0, %1" : "+v"(v[i]) : "v"(k));
+      GM_CAL64(OP)
+#undef OP
+    } else if constexpr (KIND == CAL_V_ASHR) {
+#define OP(i) asm volatile("v_ashrrev_i32 %0, 1, %0" : "+v"(v[i]));
+      GM_CAL64(OP)
+#undef OP
+    } else if constexpr (KIND == CAL_V_MIN) {
+#define OP(i) asm volatile("v_min_u32 %0, %0, %1" : "+v"(v[i]) : "v"(k));
+      GM_CAL64(OP)
+#undef OP
+    } else if constexpr (KIND == CAL_V_MAD_U24) {
+#define OP(i) asm volatile("v_mad_u32_u24 %0, %0, %1, %1" : "+v"(v[i]) : "v"(k));
+      GM_CAL64(OP)
+#undef OP
+    } else if constexpr (KIND == CAL_V_ADD3) {
+#define OP(i) asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(v[i]) : "v"(k));
+      GM_CAL64(OP)
+#undef OP
+    } else if constexpr (KIND == CAL_V_CMP_VCC) {
+#define OP(i) asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(v[i]), "v"(k) : "vcc");
+      GM_CAL64(OP)
+#undef OP
+    } else if constexpr (KIND == CAL_V_CMP_CNDMASK) {  // the select idiom of a branch-free bisection step: 32 compares + 32 selects
+#define OP(i) asm volatile("v_cmp_lt_u32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(v[i]) : "v"(k) : "vcc");
+      GM_CAL8(OP) GM_CAL8(OP) GM_CAL8(OP) GM_CAL8(OP)
+#undef OP
+    } else if constexpr (KIND == CAL_V_MOV) {
+#define OP(i) asm volatile("v_mov_b32 %0, %1" : "=v"(v[i]) : "v"(k));
+      GM_CAL64(OP)
+#undef OP
+    } else if constexpr (KIND == CAL_V_SUB_ASHR_AND_ADD) {  // the same select as arithmetic: d = x - k; mask = d >> 31; x += mask & k  (16 selects = 64 instructions)
+#define OP(i) asm volatile("v_sub_u32 %1, %0, %2\n\tv_ashrrev_i32 %1, 31, %1\n\tv_and_b32 %1, %1, %2\n\tv_add_u32 %0, %0, %1" : "+v"(v[i]), "+v"(w[i].x) : "v"(k));
+      GM_CAL8(OP) GM_CAL8(OP)
+#undef OP
+    } else if constexpr (KIND == CAL_V_XOR_SGPR) {  // a VALU with a scalar source operand
+#define OP(i) asm volatile("v_xor_b32 %0, %1, %0" : "+v"(v[i]) : "s"(s[i]));
+      GM_CAL64(OP)
+#undef OP
+    } else if constexpr (KIND == CAL_S_BCNT1) {
+#define OP(i) asm volatile("s_bcnt1_i32_b64 %0, %1" : "=s"(s[i]) : "s"(m[i]) : "scc");
+      GM_CAL64(OP)
+#undef OP
+    }
+  }
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  unsigned acc = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc ^= v[i] ^ s[i] ^ (unsigned)m[i] ^ (unsigned)(m[i] >> 32) ^ w[i].x ^ w[i].y ^ w[i].z ^ w[i].w;
+  if (acc == 0x12345u) sink[0] = acc;  // (keeps every chain alive)
+  if (lane == 0) {
+    // per wave: start, end (s_memtime) and where it ran: HW_ID (wave / simd / cu / sh / se fields) and the XCC id
+    unsigned hwid = 0, xcc = 0;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned long long *o = cycles + ((size_t)blockIdx.x * 4 + (tid >> 6)) * 3;
+    o[0] = t0;
+    o[1] = t1;
+    o[2] = ((unsigned long long)xcc << 32) | hwid;
+  }
+}
+
+// residency: the largest number of waves of the launch that were in flight on one SIMD at the same time (from the per-wave start /
+// end stamps and HW_ID): what the "W waves per SIMD" of the request really was
+extern "C" int gm_issue_calib(int kind, int waves_per_simd, int iters, double *cycles_per_wave_inst, double *inst_per_cycle_simd, double *ms,
+                              double *residency) {
+  if (kind < 0 || kind >= CAL_KINDS || waves_per_simd < 1 || waves_per_simd > 8 || iters < 1 || !cycles_per_wave_inst || !inst_per_cycle_simd)
+    return GM_ERR_INVALID;
+  int dev = 0, cus = 256;
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDevice(&dev));
+  HIP_TRY(hipGetDeviceProperties(&prop, dev));
+  if (prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+  const int W = waves_per_simd, grid = cus * W;
+  // exactly W workgroups of 4 waves (one per SIMD) per CU: each claims 1/W of the 160 KB of LDS (at least the 16 KB the kernel touches)
+  size_t lds = std::max<size_t>(16384, ((size_t)(160 * 1024) / (size_t)W) & ~(size_t)1023);
+  if (const char *e = getenv("GM_CAL_LDS")) lds = std::max<size_t>(16384, (size_t)atoll(e));  // (diagnostics: let the dispatcher pack as it likes)
+  DevBuf<unsigned long long> cyc;
+  DevBuf<unsigned> sink;
+  HIP_TRY(cyc.alloc((size_t)grid * 4 * 3));
+  HIP_TRY(sink.alloc(4));
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  float best_ms = 0.f;
+  std::vector<unsigned long long> h((size_t)grid * 4 * 3);
+  for (int rep = 0; rep < 3; ++rep) {  // the last repetition is the one reported (the first warms the instruction cache / clocks)
+    HIP_TRY(hipEventRecord(e0, 0));
+#define GM_CAL_CASE(K) case K: \
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&issue_calib_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL((issue_calib_kernel<K>), dim3((unsigned)grid), dim3(256), lds, 0, iters, cyc.p, sink.p); break;
+    switch (kind) {
+      GM_CAL_CASE(0) GM_CAL_CASE(1) GM_CAL_CASE(2) GM_CAL_CASE(3) GM_CAL_CASE(4) GM_CAL_CASE(5) GM_CAL_CASE(6) GM_CAL_CASE(7)
+      GM_CAL_CASE(8) GM_CAL_CASE(9) GM_CAL_CASE(10) GM_CAL_CASE(11) GM_CAL_CASE(12) GM_CAL_CASE(13) GM_CAL_CASE(14) GM_CAL_CASE(15)
+      GM_CAL_CASE(16) GM_CAL_CASE(17) GM_CAL_CASE(18) GM_CAL_CASE(19) GM_CAL_CASE(20) GM_CAL_CASE(21) GM_CAL_CASE(22) GM_CAL_CASE(23)
+      GM_CAL_CASE(24) GM_CAL_CASE(25) GM_CAL_CASE(26) GM_CAL_CASE(27)
+      default: break;
+    }
+#undef GM_CAL_CASE
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(e1, 0));
+    HIP_TRY(hipEventSynchronize(e1));
+    HIP_TRY(hipEventElapsedTime(&best_ms, e0, e1));
+  }
+  HIP_TRY(hipMemcpy(h.data(), cyc.p, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  const size_t nw = (size_t)grid * 4;
+  std::vector<unsigned long long> dur(nw);
+  for (size_t i = 0; i < nw; ++i) dur[i] = h[3 * i + 1] - h[3 * i];
+  std::sort(dur.begin(), dur.end());
+  const double med = (double)dur[nw / 2], n = 64.0 * (double)iters;
+  // waves in flight per SIMD: sweep over the (start, +1) / (end, -1) events of the waves that share (xcc, se, sh, cu, simd)
+  // (HW_ID, gfx9 layout: wave_id 3:0, simd_id 5:4, pipe_id 7:6, cu_id 11:8, sh_id 12, se_id 15:13; s_memtime is per XCC)
+  double res_sum = 0.0;
+  size_t res_n = 0;
+  {
+    std::vector<std::pair<unsigned long long, std::pair<unsigned long long, int>>> ev;  // (simd key, (time, +-1))
+    ev.reserve(2 * nw);
+    for (size_t i = 0; i < nw; ++i) {
+      const unsigned long long id = h[3 * i + 2];
+      const unsigned long long key = ((id >> 32) << 16) | ((id & 0xffffull) >> 4);  // xcc | se, sh, cu, pipe, simd
+      ev.push_back({key, {h[3 * i], +1}});
+      ev.push_back({key, {h[3 * i + 1], -1}});
+    }
+    std::sort(ev.begin(), ev.end(), [](const auto &x, const auto &y) {
+      if (x.first != y.first) return x.first < y.first;
+      if (x.second.first != y.second.first) return x.second.first < y.second.first;
+      return x.second.second < y.second.second;
+    });
+    for (size_t i = 0; i < ev.size();) {
+      size_t j = i;
+      int cur = 0, mx = 0;
+      for (; j < ev.size() && ev[j].first == ev[i].first; ++j) {
+        cur += ev[j].second.second;
+        mx = std::max(mx, cur);
+      }
+      res_sum += mx;
+      ++res_n;
+      i = j;
+    }
+  }
+  const double res = res_n ? res_sum / (double)res_n : 0.0;
+  *cycles_per_wave_inst = med / n;
+  *inst_per_cycle_simd = (res > 0 ? res : (double)W) * n / med;  // (with the MEASURED residency, not the requested one)
+  if (ms) *ms = best_ms;
+  if (residency) *residency = res;
+  return GM_OK;
+}

@@ -1,5 +1,5 @@
-// gm_wide.hip -- k-clique, phase 2 for WIDE vertices: the second DFS level counted from a big-LDS copy of the vertex's
-// adjacency bit-matrix (see "k-clique, wide vertices" in gm_mine.h; phase 1 = clique_build_kernel below).
+// gm_wide.hip -- k-clique, the second DFS level of the WIDE vertices, counted from a big-LDS copy of the vertex's adjacency
+// bit-matrix (see "k-clique, wide vertices" in gm_mine.h; the matrices are built by cbuild_kernel, gm_cbuild.hip).
 //
 // MI355X gives a CU 160 KB of LDS. The mining kernel spends 21-32 KB per workgroup so that 5-7 workgroups share a CU -- right
 // for the millions of short rows and for BUILDING the matrices (latency-bound streaming: occupancy is what counts), wrong for
@@ -19,115 +19,6 @@
 
 namespace gm {
 
-// ---- phase 1: build rows of a wide vertex ---------------------------------------------------------------------------------
-// The chunk is a ROW RANGE of a wide vertex: the task edges (u, A[t0 .. t0 + rows)), A = N+(u), rows <= kBuildRowsPerChunk.
-// The workgroup stages A and its hashed filter once; then every WAVE takes batches of kBuildBatchRows edges on its own, builds
-// their rows in its private 1 KB of LDS exactly like a staged chunk of the mining kernel (pass X: stream N+(v) through the
-// filter, bisect the survivors in LDS; pass Y: keys of A bisect N+(v) in HBM / L2) and writes the finished rows straight into
-// the vertex's matrix in the arena -- rows are independent, so there is no workgroup barrier between batches. (The first
-// version built 32-row groups with a barrier per group: the group waited for its slowest wave, and the batch size decided
-// the kernel: 32-edge batches 139 ms, 8: 69.6, 4: 64 -- profiles/r02/ab_clique4_build_batch.log.) Building is latency-bound
-// streaming -- occupancy is what counts -- so the workgroup is lean: 4 KB stage + 4 KB filter + 4 x 1 KB of rows + 4 x 2.4 KB of
-// pass scratch = 22 KB, seven workgroups (28 waves) per CU like TC; mine_kernel<PAT_CLIQUE4> (29.5 KB, 95 VGPRs) runs five.
-// Rows longer than the 1024-entry stage (d+ 1025..2048) are searched in HBM / L2.
-struct alignas(16) BuildLds {
-  int stage[kStageCapClique];     // N+(u) (first member: the bisection may read past the row, never past LDS)
-  unsigned fbits[kFilterWords];   // hashed membership filter of the row (salt 0)
-  unsigned bits[kWavesPerBlock][kBuildBatchRows * (kWideMaxDeg / 32)];  // per wave: the rows of its current batch
-  int next_batch;
-  unsigned queue_pos;
-  WaveLdsLean w[kWavesPerBlock];
-};
-
-__global__ __launch_bounds__(kWavesPerBlock *GM_WAVE, 7) void clique_build_kernel(const CliqueBuildParams p) {
-  __shared__ BuildLds B;
-  const int *__restrict__ rp = p.g.rp;
-  const int *__restrict__ col = p.g.col;
-  const int2 *__restrict__ edesc = p.g.edesc;
-  const int tid = threadIdx.x, lane = tid & (GM_WAVE - 1), wave = tid >> 6;
-  constexpr int NT = kWavesPerBlock * GM_WAVE;
-  WaveLdsLean &L = B.w[wave];
-  unsigned *wb = B.bits[wave];
-  for (;;) {
-    if (tid == 0) B.queue_pos = atomicAdd(p.queue, 1u);
-    __syncthreads();
-    const unsigned q = B.queue_pos;
-    if (q >= (unsigned)p.count) break;
-    const ChunkRec r = p.chunks[q];
-    const int u = r.u_begin, ru = rp[u], d = rp[u + 1] - ru, stride = (d + 31) >> 5;
-    const int t0 = r.e_begin - ru, rows = r.e_end - r.e_begin;
-    const bool staged = d <= kStageCapClique;
-    if (staged) {
-      for (int i = tid; i < d; i += NT) B.stage[i] = col[ru + i];
-      for (int i = tid; i < kFilterWords; i += NT) B.fbits[i] = 0u;
-    }
-    if (tid == 0) B.next_batch = 0;
-    __syncthreads();
-    if (staged) {
-      for (int i = tid; i < d; i += NT) {
-        const unsigned h = filter_hash(B.stage[i], 0u);
-        atomicOr(&B.fbits[h >> 5], 1u << (h & 31u));
-      }
-      __syncthreads();
-    }
-    unsigned *__restrict__ gm = p.mat + p.base[r.pad_ - 1] + (size_t)t0 * stride;  // the chunk's rows in the vertex's matrix
-    constexpr int bsz = kBuildBatchRows;
-    for (;;) {  // waves take batches on their own: no workgroup barrier until the chunk is done
-      int bi = 0;
-      if (lane == 0) bi = atomicAdd(&B.next_batch, 1);
-      bi = readfirst(bi);
-      const int l0 = bi * bsz;  // first local row of the batch
-      if (l0 >= rows) break;
-      const int nr = min(bsz, rows - l0);
-      for (int i = lane; i < nr * stride; i += GM_WAVE) wb[i] = 0u;
-      const int lr = l0 + lane;
-      const bool valid = (lane < nr);
-      int rv = 0, b = 0;
-      if (valid) {
-        if (edesc) {
-          const int2 de = edesc[r.e_begin + lr];
-          rv = de.x;
-          b = de.y;
-        } else {
-          const int v = col[r.e_begin + lr];
-          rv = rp[v];
-          b = rp[v + 1] - rv;
-        }
-      }
-      const bool act = valid && b > 0;
-      bool dirx = false;
-      if (act) {
-        if (staged) {  // the direction rule of the mining kernel (process_chunk)
-          const float cx = (float)b * (float)(p.cost_x_base + p.cost_x_step * bitlen(d));
-          const float cy = (float)d * (float)(p.cost_y_base + p.cost_y_step * bitlen(b));
-          dirx = cx <= cy;
-        } else {
-          dirx = b <= d;
-        }
-      }
-      wave_sync();  // the row buffer is zeroed
-      auto set_bit = [&](const int owner, const int cbit) { atomicOr(&wb[owner * stride + (cbit >> 5)], 1u << (cbit & 31)); };
-      auto actx = [&](bool f, int owner, int, int pos, int, int) { if (f) set_bit(owner, pos); };   // pos: position in N+(u)
-      auto acty = [&](bool f, int owner, int kidx, int, int, int) { if (f) set_bit(owner, kidx); };  // kidx: index of the key in N+(u)
-      if (staged) flat_pass_filtered(L, B.stage, B.fbits, col, lane, (act && dirx) ? b : 0, rv, 0, d, 0, actx);
-      else flat_pass<SEARCH_HBM>(L, B.stage, col, nullptr, lane, (act && dirx) ? b : 0, rv, ru, d, actx);
-      flat_pass<SEARCH_HBM>(L, B.stage, col, nullptr, lane, (act && !dirx) ? d : 0, ru, rv, b, acty);
-      wave_sync();
-      for (int i = lane; i < nr * stride; i += GM_WAVE) gm[(size_t)l0 * stride + i] = wb[i];  // finished rows: contiguous in the arena
-      wave_sync();
-    }
-    __syncthreads();  // every wave is done with the stage / filter
-  }
-}
-
-size_t clique_build_lds_bytes() { return sizeof(BuildLds); }
-
-hipError_t launch_clique_build(const CliqueBuildParams &p, int grid_blocks, hipStream_t stream) {
-  static_assert(sizeof(BuildLds) * 7 <= 163840, "seven build workgroups per CU");
-  hipLaunchKernelGGL(clique_build_kernel, dim3((unsigned)grid_blocks), dim3(kWavesPerBlock * GM_WAVE), 0, stream, p);
-  return hipGetLastError();
-}
-
 // ---- phase 2 ----------------------------------------------------------------------------------------------------------------
 
 constexpr int kCountMaxQ = 9;        // 16-byte units of a row (block) held in registers: 36 words
@@ -143,9 +34,33 @@ struct alignas(16) CountLds {
 // The rows of one (column block of a) matrix resident in LDS: sum_i sum_{j in M_i} popc(M_i & M_j) over the block's columns.
 // NQ = 16-byte units per padded row, compile-time: the NQ row reads of a lane are issued back to back and waited for once
 // (with a run-time bound every read sat behind its own branch and its own s_waitcnt: 64 pairs took ~9 LDS round trips).
+// popc(M_i & M_j) over the 16-byte units KS .. NQ-1 of the two rows (KS: compile time, so that the reads of a lane are still issued
+// back to back and waited for once)
+template <int NQ, int KS>
+__device__ __forceinline__ unsigned pair_popc(const uint4 (&mr)[NQ], const uint4 *__restrict__ rj) {
+  unsigned a = 0;
+  constexpr int G = 5;  // units requested together: 9 = 5 + 4 keeps the kernel at 4 waves per SIMD without spills
+#pragma unroll
+  for (int k0 = KS; k0 < NQ; k0 += G) {
+    uint4 m[G];
+#pragma unroll
+    for (int k = 0; k < G; ++k)
+      if (k0 + k < NQ) m[k] = rj[k0 + k];
+#pragma unroll
+    for (int k = 0; k < G; ++k)
+      if (k0 + k < NQ)
+        a += (unsigned)__popc(mr[k0 + k].x & m[k].x) + (unsigned)__popc(mr[k0 + k].y & m[k].y) +
+             (unsigned)__popc(mr[k0 + k].z & m[k].z) + (unsigned)__popc(mr[k0 + k].w & m[k].w);
+  }
+  return a;
+}
+
+// c0: first word of the column block inside the matrix rows; topo: the matrix is strictly upper triangular (row j has no bit at or
+// below column j), so for a tile of ascending j's the units below the first j's own are all zero in every M_j and are skipped
 template <int NQ, bool WHOLE>
 __device__ __forceinline__ unsigned long long count_block(const unsigned *__restrict__ bits, unsigned short *__restrict__ plist, int *next_row,
-                                                          const unsigned *__restrict__ gm, const int d, const int stride, const int lane) {
+                                                          const unsigned *__restrict__ gm, const int d, const int stride, const int lane,
+                                                          const int c0, const bool topo) {
   constexpr int ps = 4 * NQ;
   unsigned long long tot = 0;
   unsigned c = 0;
@@ -208,19 +123,16 @@ __device__ __forceinline__ unsigned long long count_block(const unsigned *__rest
         const int idx = t + lane;
         const int j = (int)plist[min(idx, total - 1)];
         const uint4 *rj = reinterpret_cast<const uint4 *>(&bits[j * ps]);
+        // first useful unit of the tile (wave-uniform): the list is ascending, lane 0 holds the smallest j
+        const int kmin = topo ? min(max(((readfirst(j) >> 5) - c0) >> 2, 0), NQ - 1) : 0;
         unsigned a = 0;
-        constexpr int G = 5;  // units requested together: 9 = 5 + 4 keeps the kernel at 4 waves per SIMD without spills
-#pragma unroll
-        for (int k0 = 0; k0 < NQ; k0 += G) {
-          uint4 m[G];
-#pragma unroll
-          for (int k = 0; k < G; ++k)
-            if (k0 + k < NQ) m[k] = rj[k0 + k];
-#pragma unroll
-          for (int k = 0; k < G; ++k)
-            if (k0 + k < NQ)
-              a += (unsigned)__popc(mr[k0 + k].x & m[k].x) + (unsigned)__popc(mr[k0 + k].y & m[k].y) +
-                   (unsigned)__popc(mr[k0 + k].z & m[k].z) + (unsigned)__popc(mr[k0 + k].w & m[k].w);
+        switch (kmin) {
+#define GM_PAIR_CASE(K) \
+  case K: if constexpr (K < NQ) a = pair_popc<NQ, K>(mr, rj); break;
+          GM_PAIR_CASE(0) GM_PAIR_CASE(1) GM_PAIR_CASE(2) GM_PAIR_CASE(3) GM_PAIR_CASE(4) GM_PAIR_CASE(5) GM_PAIR_CASE(6) GM_PAIR_CASE(7)
+          GM_PAIR_CASE(8)
+#undef GM_PAIR_CASE
+          default: break;
         }
         c += (idx < total) ? a : 0u;
       }
@@ -272,7 +184,7 @@ __global__ __launch_bounds__(WAVES *GM_WAVE, 1) void clique_count_kernel(const C
       const unsigned long long t1 = p.profile ? wall_clock64() : 0ull;
       // (WHOLE instantiations -- classes S / L -- only ever see one block: clique_count_class and the loop above agree)
 #define GM_COUNT_CASE(NQ) \
-  case NQ: tot += count_block<NQ, WHOLE>(S.bits, plist, &S.next_row, gm, d, stride, lane); break;
+  case NQ: tot += count_block<NQ, WHOLE>(S.bits, plist, &S.next_row, gm, d, stride, lane, c0, p.topo != 0); break;
       switch (nq) {
         GM_COUNT_CASE(1)
         GM_COUNT_CASE(2)
@@ -282,7 +194,7 @@ __global__ __launch_bounds__(WAVES *GM_WAVE, 1) void clique_count_kernel(const C
         GM_COUNT_CASE(6)
         GM_COUNT_CASE(7)
         GM_COUNT_CASE(8)
-        default: tot += count_block<9, WHOLE>(S.bits, plist, &S.next_row, gm, d, stride, lane); break;
+        default: tot += count_block<9, WHOLE>(S.bits, plist, &S.next_row, gm, d, stride, lane, c0, p.topo != 0); break;
       }
 #undef GM_COUNT_CASE
       if (p.profile) {

@@ -241,6 +241,15 @@ int gm_calib_stream(const int32_t *d_buf, int64_t n, uint64_t *d_out, void *stre
  * ceiling bench.py prints beside the 8 TB/s spec). */
 int gm_stream_ceiling(const int32_t *d_buf, int64_t n, uint64_t *d_out, void *stream);
 
+/* Issue-rate calibration (tooling): `waves_per_simd` (1..8) waves on every SIMD of every CU each execute iters x 64 instructions of
+ * one kind (0 v_add_u32, 1 v_mul_lo_u32, 2 v_mul_u32_u24, 3 v_cmp -> SGPR pair, 4 v_add_u32 DPP row_shr, 5 s_add_u32, 6 ds_read_b128,
+ * 7 ds_read_b32, 8 ds_read_b32 with 32-way bank conflicts, 9 v_add + s_add interleaved, 10 v_readlane, 11 v_mbcnt, 12 v_bcnt,
+ * 13 v_cmp SDWA, 14 ds_write_b32, 15 v_cndmask) between two s_memtime reads. Outputs: shader cycles per wave-instruction as one wave
+ * sees it (median over the waves) and wave-instructions per cycle and SIMD. The basis of every "unit X is N % busy" statement in
+ * DESIGN.md (scripts/issue_calibration.py -> profiles/r03/issue_calibration.txt). Uses the null stream of the current device. */
+int gm_issue_calib(int kind, int waves_per_simd, int iters, double *cycles_per_wave_inst, double *inst_per_cycle_simd, double *ms,
+                   double *residency /* measured: waves of the launch in flight per SIMD at the same time (mean over SIMDs of the maximum) */);
+
 /* wave-primitive self test (DPP scans, ballot rank, LDS search); returns GM_OK when the device
  * results equal the host expectation. *n_fail receives the number of mismatching lanes. */
 int gm_selftest(int device, int *n_fail);
