@@ -202,6 +202,7 @@ def alg_bytes_device(workload, bg, lib, g):
 
 
 TCT_STAGE_MAX = 2048   # gm_mine.h kTctStageMax: the longest DAG row the shorter-list-streams TC kernel hosts
+TOPO_MIN_MEAN_ROW = 64.0  # gm_launch.hip kTopoMinMeanRow: DAG patterns run on the topologically renumbered copy from this mean row length on
 TRIM_MIN_LIST = 128    # 3-motif: partner lists of >= 128 keys are trimmed to the keys below max(u, v) before they are streamed
 CB_MIN_DEG, CB_MAX_DEG = 3, 2048  # 4-clique (gm_mine.h kCbMinDeg / kCbMaxDeg): the DAG rows that own a bit-matrix in the arena
 
@@ -211,7 +212,8 @@ def own_bytes_device(workload, bg):
     construction -- the keys they stream, the task descriptors, every row staged / hashed once, the offsets, the k-clique arena
     written and read once -- exact, with torch on the GPU. `roofline.achieved` = this / kernel time, so `frac` <= 1 by construction
     (SURVEY 8(d)'s figure, which charges the reference's loop nest, is kept beside it as `algorithmic_*`).
-      tc       4*sum_e min'(d+(u), d+(v)) + 12|E+| + 8(nv+1)       (min': the longer list hosts; a row > 2048 entries hosts nothing)
+      tc       4*sum_e min'(d+(u), d+(v)) + 12|E+| + 8(nv+1)       (min': the longer list hosts -- a row > 2048 entries hosts nothing -- and an
+               in-edge task streams only the part of N+(u) beyond v: the library numbers the DAG topologically)
       diamond  4*sum_{undirected e} min(d(u), d(v)) + 12*ne + 8(nv+1)
       motif3   the same with the streamed list trimmed to its keys < max(u, v) when it has >= 128 keys
       clique4  4*sum_e min''(d+(u), d+(v)) + 16*tasks + 4|E+| + 16(nv+1) + 8*arena words   (min'': the longer list hosts when it fits the
@@ -232,18 +234,9 @@ def own_bytes_device(workload, bg):
         ne = int(s2.numel())
         du, dv = dplus[s2], dplus[d2]
         fixed = 12 * ne + 8 * (nv + 1)
-        if workload != "clique4":
-            u_hosts = (dv > TCT_STAGE_MAX) | (du >= dv)
-            streamed = torch.where(du > TCT_STAGE_MAX, dv, torch.where(u_hosts, dv, du))
-            k = int(streamed.sum().item())
-            return {"bytes": 4 * k + fixed, "streamed_keys": k, "parts": {"streamed_keys_x4": 4 * k, "task_descriptors_and_rows_12_per_edge": 12 * ne, "offsets": 8 * (nv + 1)}}
-        # 4-clique (DESIGN 4.7, gm_cbuild.hip): every edge u -> v of an OWNER u (3 <= d+(u) <= 2048: its matrix lives in the arena) is a
-        # task of the endpoint with the longer list when that list fits the stage, the other list is streamed; an in-edge task streams
-        # only N+(u) beyond v (topological numbering: strictly upper-triangular matrices); rows beyond 2048 entries stream N+(v)
-        owner = (du >= CB_MIN_DEG) & (du <= CB_MAX_DEG)
-        v_hosts = owner & (dv > du) & (dv <= CB_MAX_DEG)
         # position of v in N+(u) under the TOPOLOGICAL numbering the library gives the DAG (ids ascending in (degree, id), gm_graph.hip
-        # get_relabeled mode 2): rank the vertices, sort the edges by (new u, new v)
+        # get_relabeled mode 2): rank the vertices, sort the edges by (new u, new v). An in-edge task (the target hosts) streams only
+        # the part of N+(u) beyond v.
         newid = torch.empty(nv, dtype=torch.long, device=rp.device)
         newid[torch.argsort(deg * (1 << 32) + torch.arange(nv, device=rp.device))] = torch.arange(nv, device=rp.device)
         perm = torch.argsort(newid[s2] * (1 << 32) + newid[d2])
@@ -251,6 +244,19 @@ def own_bytes_device(workload, bg):
         pos = torch.empty(ne, dtype=torch.long, device=rp.device)
         pos[perm] = torch.arange(ne, device=rp.device) - torch.searchsorted(ru, ru)
         del newid, perm, ru
+        # (the library renumbers -- and trims -- only where lists are long: sum d+^2 / |E+| >= 64, gm_launch.hip topo_view)
+        if ne == 0 or float((dplus * dplus).sum().item()) / ne < TOPO_MIN_MEAN_ROW:
+            pos = du - 1  # no trimming: an in-edge task streams the whole list
+        if workload != "clique4":
+            u_hosts = (dv > TCT_STAGE_MAX) | (du >= dv)
+            streamed = torch.where(du > TCT_STAGE_MAX, dv, torch.where(u_hosts, dv, du - pos - 1))
+            k = int(streamed.sum().item())
+            return {"bytes": 4 * k + fixed, "streamed_keys": k, "parts": {"streamed_keys_x4": 4 * k, "task_descriptors_and_rows_12_per_edge": 12 * ne, "offsets": 8 * (nv + 1)}}
+        # 4-clique (DESIGN 4.7, gm_cbuild.hip): every edge u -> v of an OWNER u (3 <= d+(u) <= 2048: its matrix lives in the arena) is a
+        # task of the endpoint with the longer list when that list fits the stage, the other list is streamed; an in-edge task streams
+        # only N+(u) beyond v (topological numbering: strictly upper-triangular matrices); rows beyond 2048 entries stream N+(v)
+        owner = (du >= CB_MIN_DEG) & (du <= CB_MAX_DEG)
+        v_hosts = owner & (dv > du) & (dv <= CB_MAX_DEG)
         streamed = torch.where(v_hosts, du - pos - 1, dv)
         streamed = torch.where(du < CB_MIN_DEG, torch.zeros_like(streamed), streamed)
         k = int(streamed.sum().item())

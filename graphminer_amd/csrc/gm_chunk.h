@@ -402,6 +402,83 @@ __device__ __forceinline__ unsigned long long cliquek_count_sub(unsigned *__rest
   return c;
 }
 
+// The same induced-sub-matrix recursion for rows of ANY width (more than kSubMaxStride words: beyond 4096 columns). Nothing of the
+// row is held in registers or LDS: the set-bit positions of M_i go to a list in the workgroup's global scratch (plist_g, one list per
+// recursion level, plist_step entries apart), the compacted rows are gathered bit by bit from the arena. Slow and exact -- the
+// reference's kernels have no width limit (src/clique/gpu_kernels/clique5_warp_edge.cuh:3-39, edge_warp_iterative.cuh:2-75) and
+// round 2 refused such rows; only the top rows of a DAG that was not oriented by degree ever get here.
+template <int M>
+__device__ __forceinline__ unsigned long long cliquek_count_sub_any(unsigned *__restrict__ sub, int *__restrict__ lds_m, int *__restrict__ plist_g,
+                                                                    const size_t plist_step, const unsigned *__restrict__ gbits,
+                                                                    unsigned *__restrict__ sub_arena, const size_t arena_step, const int tid,
+                                                                    const int lane, const int wave, const int nel, const int stride) {
+  unsigned long long c = 0;
+  for (int i = 0; i < nel; ++i) {
+    __syncthreads();  // the previous row's list / sub-matrix is no longer read
+    if (wave == 0) {  // positions of the set bits of M_i, ascending
+      int m = 0;
+      for (int w0 = 0; w0 < stride; w0 += GM_WAVE) {
+        const unsigned word = (w0 + lane < stride) ? gbits[(size_t)i * stride + w0 + lane] : 0u;
+        const int cw = __popc(word);
+        const int incl = wave_incl_scan_add(cw);
+        unsigned x = word;
+        int k = m + incl - cw;
+        while (x) {
+          plist_g[k++] = (w0 + lane) * 32 + (__ffs((int)x) - 1);
+          x &= x - 1;
+        }
+        m += readlane(incl, GM_WAVE - 1);
+      }
+      if (lane == 0) lds_m[0] = m;
+    }
+    __threadfence();
+    __syncthreads();
+    const int m = lds_m[0];
+    if (m == 0) continue;
+    const bool in_lds = m <= 256;
+    const int words = ((m + 63) >> 6) * 2;
+    const int rw = in_lds ? kSmallWords : words;
+    unsigned *dst = in_lds ? sub : sub_arena;
+    for (int p = wave; p < m; p += kWavesPerBlock) {  // row p of the compacted matrix: M_j restricted to the columns of M_i
+      const unsigned *Mj = gbits + (size_t)plist_g[p] * stride;
+      for (int q0 = 0; q0 < m; q0 += GM_WAVE) {
+        const int pos = plist_g[min(q0 + lane, m - 1)];
+        const bool bit = (q0 + lane < m) && ((Mj[pos >> 5] >> (pos & 31)) & 1u) != 0u;
+        const unsigned long long bl = __ballot(bit);
+        if (lane == 0) {
+          dst[(size_t)p * rw + (q0 >> 5)] = (unsigned)bl;
+          dst[(size_t)p * rw + (q0 >> 5) + 1] = (unsigned)(bl >> 32);
+        }
+      }
+      if (in_lds && lane >= words && lane < kSmallWords) sub[p * kSmallWords + lane] = 0u;
+    }
+    if (in_lds) {
+      __syncthreads();
+      for (int p = tid; p < m; p += kWavesPerBlock * GM_WAVE) {
+        unsigned S[kSmallWords];
+#pragma unroll
+        for (int w = 0; w < kSmallWords; ++w) S[w] = sub[p * kSmallWords + w];
+        c += CliqueSmall<M - 1>::run(S, sub, 0, kSmallWords);
+      }
+    } else {
+      __threadfence();
+      if constexpr (M == 3) {
+        if (words <= GM_WAVE) {
+          c += clique4_count_tiled(sub, sub_arena, tid, lane, wave, m, words);  // (begins with a barrier)
+        } else {
+          __syncthreads();
+          c += clique4_count_anywidth(sub_arena, lane, wave, m, words);
+        }
+      } else {
+        __syncthreads();
+        c += cliquek_count_sub_any<M - 1>(sub, lds_m, plist_g + plist_step, plist_step, sub_arena, sub_arena + arena_step, arena_step, tid, lane, wave, m, words);
+      }
+    }
+  }
+  __syncthreads();
+  return c;
+}
+
 template <int M>
 __device__ __forceinline__ unsigned long long cliquek_count_wide(const unsigned *__restrict__ bits, const int lane, const int wave,
                                                                  const int nel, const int stride) {
@@ -753,11 +830,14 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT,
         if (PAT != PAT_CLIQUEK) break;                                                                       \
         if (wide2 && !((p.flags & 64) && wide))                                                               \
           acc.c0 += cliquek_count_sub<K - 2>(B.bits, B.stage, reinterpret_cast<unsigned short *>(&B.w[0]), gbits,       \
-                                             gbits + p.scratch_words / (K - 3 + 1), p.scratch_words / (K - 3 + 1), tid, lane,   \
+                                             gbits + p.scratch_region, p.scratch_region, tid, lane,   \
                                              wave, nel, stride, (p.flags & (1 << 20)) != 0);                               \
         else if (wide) acc.c0 += cliquek_count_wide<K - 2>(gbits, lane, wave, nel, stride);                      \
         else if (bits_lds) acc.c0 += cliquek_count_small<K - 2>(B.rpl, B.bits, tid, nthreads, eb, nel, nvl, stride); \
-        else acc.c1 += 1; /* row wider than 4096 columns: not supported for k >= 5 (refused by the host) */  \
+        else if (!bits_lds && nvl == 1) /* a row wider than 4096 columns: everything from the workgroup's global scratch */ \
+          acc.c0 += cliquek_count_sub_any<K - 2>(B.bits, &B.next_batch, reinterpret_cast<int *>(gbits + (size_t)(K - 2) * p.scratch_region), \
+                                                 (size_t)p.scratch_plist, gbits, gbits + p.scratch_region, p.scratch_region, tid, lane, wave, nel, stride); \
+        else acc.c1 += 1; /* (cannot happen: a matrix beyond LDS is a one-row chunk) */                        \
         break;
       GM_CLIQUE_CASE(5)
       GM_CLIQUE_CASE(6)

@@ -9,6 +9,7 @@ using namespace gm;
 // error plumbing
 // ------------------------------------------------------------------------------------------------
 thread_local std::string g_last_error;
+thread_local TempPool *g_temp_pool = nullptr;
 
 int hip_fail(hipError_t e, const char *what, const char *file, int line) {
   char buf[512];
@@ -71,8 +72,10 @@ extern "C" void gm_graph_free(gm_graph *g) {
     if (b.d_row_slot) (void)hipFree(b.d_row_slot);
   }
   if (g->d_rp) (void)hipFree(g->d_rp);
+  if (g->d_rp64) (void)hipFree(g->d_rp64);
   if (g->own_col && g->d_col) (void)hipFree(g->d_col);
   if (g->d_edesc) (void)hipFree(g->d_edesc);
+  if (g->d_symdeg) (void)hipFree(g->d_symdeg);
   if (g->d_trp) (void)hipFree(g->d_trp);
   if (g->d_tdesc) (void)hipFree(g->d_tdesc);
   free_clique_plans(g);
@@ -81,6 +84,7 @@ extern "C" void gm_graph_free(gm_graph *g) {
   if (g->d_wide_queue) (void)hipFree(g->d_wide_queue);
   for (auto &st_ : g->aux_stream) if (st_) (void)hipStreamDestroy(st_);
   for (auto &ev_ : g->aux_done) if (ev_) (void)hipEventDestroy(ev_);
+  if (g->pool.base) (void)hipFree(g->pool.base);
   if (g->d_counters) (void)hipFree(g->d_counters);
   if (g->d_scratch) (void)hipFree(g->d_scratch);
   if (g->d_idx0) (void)hipFree(g->d_idx0);
@@ -147,13 +151,50 @@ __global__ __launch_bounds__(256) void convert_offsets_kernel(const long long *_
   }
 }
 
+// validation of 64-bit offsets that stay 64-bit: err bit 0 = not an offset array, bit 1 = a row of 2^31 entries or more; info[1] = longest row
+__global__ __launch_bounds__(256) void check_offsets64_kernel(const long long *__restrict__ rp64, int nv, long long ne, int *__restrict__ info) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  int err = 0, md = 0;
+  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v <= nv; v += stride) {
+    const long long x = rp64[v];
+    if (v == 0 && x != 0) err |= 1;
+    if (v == nv && x != ne) err |= 1;
+    if (v > 0) {
+      const long long d = x - rp64[v - 1];
+      if (d < 0) err |= 1;
+      else if (d >= 0x7fffffffLL) err |= 2;
+      else md = max(md, (int)d);
+    }
+  }
+  md = gm::wave_max_nonneg(md);
+  err = gm::wave_max_nonneg(err & 1) | (gm::wave_max_nonneg((err >> 1) & 1) << 1);
+  if ((threadIdx.x & 63) == 0) {
+    if (md) atomicMax(&info[1], md);
+    if (err & 3) atomicOr(&info[0], err & 3);
+  }
+}
+
 // d_rp64: DEVICE array of nv + 1 int64 offsets. Allocates and fills g->d_rp, sets g->max_deg.
 static int adopt_offsets(gm_graph *g, const int64_t *d_rp64) {
-  HIP_TRY(hipMalloc(&g->d_rp, sizeof(int) * ((size_t)g->nv + 1)));
   DevBuf<int> info;
   HIP_TRY(info.alloc(2));
   HIP_TRY(hipMemset(info.p, 0, 8));
   const long long blocks = std::min<long long>(((long long)g->nv + 256) / 256, 4096);
+  long long big_from = 0x7fffffffLL;
+  if (const char *e = getenv("GM_BIG_NE")) big_from = std::max(0ll, atoll(e));  // (tests: the 64-bit paths on small graphs)
+  if (g->ne >= big_from) {  // a big handle: its own copy of the 64-bit offsets
+    HIP_TRY(hipMalloc(&g->d_rp64, sizeof(long long) * ((size_t)g->nv + 1)));
+    HIP_TRY(hipMemcpy(g->d_rp64, d_rp64, sizeof(long long) * ((size_t)g->nv + 1), hipMemcpyDeviceToDevice));
+    hipLaunchKernelGGL(check_offsets64_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, (const long long *)g->d_rp64, g->nv, g->ne, info.p);
+    HIP_TRY(hipGetLastError());
+    int h[2] = {0, 0};
+    HIP_TRY(hipMemcpy(h, info.p, 8, hipMemcpyDeviceToHost));
+    if (h[0] & 1) return GM_ERR_FORMAT;
+    if (h[0] & 2) return GM_ERR_TOO_LARGE;
+    g->max_deg = h[1];
+    return GM_OK;
+  }
+  HIP_TRY(hipMalloc(&g->d_rp, sizeof(int) * ((size_t)g->nv + 1)));
   hipLaunchKernelGGL(convert_offsets_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, (const long long *)d_rp64, g->nv, g->ne, g->d_rp, info.p);
   HIP_TRY(hipGetLastError());  // (a failed launch would leave info == 0 and an uninitialised d_rp behind a passing validation)
   int h[2] = {0, 0};
@@ -164,11 +205,15 @@ static int adopt_offsets(gm_graph *g, const int64_t *d_rp64) {
   return GM_OK;
 }
 
+// ne >= 2^31: a BIG handle (d_rp64 instead of d_rp). It can be oriented (the DAG of twitter40 / friendster has < 2^31 entries), its
+// triangles / wedges counted through the formula solver (gm_motif, k = 3) and downloaded; the mining kernels that walk the symmetric
+// graph itself index it with 32 bits and refuse it with GM_ERR_TOO_LARGE.
 static int check_sizes(long long nv, long long ne) {
   if (nv < 0 || ne < 0) return GM_ERR_INVALID;
-  if (nv >= 0x7ffffffeLL || ne >= 0x7fffffffLL) return GM_ERR_TOO_LARGE;
+  if (nv >= 0x7ffffffeLL || ne >= (1ll << 40)) return GM_ERR_TOO_LARGE;
   return GM_OK;
 }
+
 
 int convert_offsets(const int64_t *rp64, int nv, long long ne, std::vector<int> &out) {
   out.resize((size_t)nv + 1);
@@ -236,6 +281,7 @@ extern "C" int gm_graph_from_device(int32_t nv, int64_t ne, const int64_t *d_row
 extern "C" int gm_graph_sort_neighbors(gm_graph *g) {
   if (!g) return GM_ERR_INVALID;
   if (g->ne == 0) return GM_OK;
+  if (g->d_rp64) { g_last_error = "gm_graph_sort_neighbors: not for graphs of 2^31 entries or more (the segmented sort counts items in 32 bits)"; return GM_ERR_TOO_LARGE; }
   // before any solver ran: every cached structure describes the rows as they are now (tables, descriptors, task lists, derived
   // handles, the per-pattern tables of the SgL / 4-motif paths, hub bitmaps, the sum of C(d,2))
   if (!g->tables.empty() || g->d_edesc || g->d_trp || g->d_tdesc || g->dag_cache || g->relabel_cache[0] || g->relabel_cache[1] || g->d_idx0 ||
@@ -244,6 +290,7 @@ extern "C" int gm_graph_sort_neighbors(gm_graph *g) {
     return GM_ERR_INVALID;
   HIP_TRY(hipDeviceSynchronize());  // a caller stream may still be reading a borrowed col_idx array: the sort runs on the null stream
   HIP_TRY(hipSetDevice(g->device));
+  PoolScope pool(g);
   DevBuf<int> sorted;
   HIP_TRY(sorted.alloc((size_t)g->ne));
   ScanTemp tmp;
@@ -270,7 +317,10 @@ extern "C" int gm_graph_meta(const gm_graph *g, gm_csr *m) {
 
 extern "C" int gm_graph_download(const gm_graph *g, int64_t *row_ptr, int32_t *col_idx) {
   if (!g) return GM_ERR_INVALID;
-  if (row_ptr) {
+  if (row_ptr && g->d_rp64) {
+    HIP_TRY(hipSetDevice(g->device));
+    HIP_TRY(hipMemcpy(row_ptr, g->d_rp64, sizeof(int64_t) * ((size_t)g->nv + 1), hipMemcpyDeviceToHost));
+  } else if (row_ptr) {
     const std::vector<int> *rp = nullptr;
     int rc = host_rp(const_cast<gm_graph *>(g), &rp);
     if (rc) return rc;
@@ -295,11 +345,17 @@ __device__ __forceinline__ bool dag_keep(int ds, int s, int dd, int d) { return 
 constexpr int kOrientShort = 64;
 constexpr int kOrientSeg = 1024;
 
-struct OrientSeg {
-  int row, begin, end, out;  // CSR entry range [begin,end) of `row`; out = output offset of the segment (pass 1)
+// OffT: the offset type of the SYMMETRIC graph that is read -- int, or long long for a graph of 2^31 entries or more (twitter40,
+// friendster: src/triangle/README.md:60-61); the oriented graph that is written has 32-bit offsets either way.
+template <class OffT>
+struct OrientSegT {
+  int row;
+  OffT begin, end;  // CSR entry range [begin,end) of `row`
+  int out;          // output offset of the segment (pass 1)
 };
 
-__global__ __launch_bounds__(256) void orient_short_kernel(int nv, const int *__restrict__ rp, const int *__restrict__ col,
+template <class OffT>
+__global__ __launch_bounds__(256) void orient_short_kernel(int nv, const OffT *__restrict__ rp, const int *__restrict__ col,
                                                            int *__restrict__ new_deg, const int *__restrict__ new_rp,
                                                            int *__restrict__ new_col, int pass) {
   constexpr int G = 8, RPW = 64 / G;
@@ -309,8 +365,9 @@ __global__ __launch_bounds__(256) void orient_short_kernel(int nv, const int *__
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
   for (int s0 = wave * RPW; s0 < nv; s0 += nwaves * RPW) {
     const int s = s0 + grp;
-    int b = 0, ds = 0;
-    if (s < nv) { b = rp[s]; ds = rp[s + 1] - b; }
+    OffT b = 0;
+    int ds = 0;
+    if (s < nv) { b = rp[s]; ds = (int)(rp[s + 1] - b); }
     const int full = ds;
     if (ds > kOrientShort) ds = 0;  // long rows belong to the segment kernel
     const int maxds = wave_max_nonneg(ds);
@@ -322,7 +379,7 @@ __global__ __launch_bounds__(256) void orient_short_kernel(int nv, const int *__
       int d = 0;
       if (i < ds) {
         d = col[b + i];
-        keep = dag_keep(full, s, rp[d + 1] - rp[d], d);
+        keep = dag_keep(full, s, (int)(rp[d + 1] - rp[d]), d);
       }
       const unsigned long long m = (__ballot(keep) >> (grp * G)) & 0xffull;
       if (pass && keep) new_col[ob + n + __popcll(m & ((1ull << gl) - 1ull))] = d;
@@ -333,23 +390,24 @@ __global__ __launch_bounds__(256) void orient_short_kernel(int nv, const int *__
 }
 
 // one wave per segment; pass 0 adds the segment's count to its row's new degree (and keeps it per segment for the offsets)
-__global__ __launch_bounds__(256) void orient_seg_kernel(int nseg, const OrientSeg *__restrict__ segs, const int *__restrict__ rp,
+template <class OffT>
+__global__ __launch_bounds__(256) void orient_seg_kernel(int nseg, const OrientSegT<OffT> *__restrict__ segs, const OffT *__restrict__ rp,
                                                          const int *__restrict__ col, int *__restrict__ seg_count, int *__restrict__ new_deg,
                                                          int *__restrict__ new_col, int pass) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
   for (int sg = wave; sg < nseg; sg += nwaves) {
-    const OrientSeg q = segs[sg];
-    const int ds = rp[q.row + 1] - rp[q.row];
+    const OrientSegT<OffT> q = segs[sg];
+    const int ds = (int)(rp[q.row + 1] - rp[q.row]);
     int n = 0;
-    for (int base = q.begin; base < q.end; base += 64) {
-      const int i = base + lane;
+    for (OffT base = q.begin; base < q.end; base += 64) {
+      const OffT i = base + lane;
       bool keep = false;
       int d = 0;
       if (i < q.end) {
         d = col[i];
-        keep = dag_keep(ds, q.row, rp[d + 1] - rp[d], d);
+        keep = dag_keep(ds, q.row, (int)(rp[d + 1] - rp[d]), d);
       }
       const unsigned long long m = __ballot(keep);
       if (pass && keep) new_col[q.out + n + rank_below(m)] = d;
@@ -363,29 +421,32 @@ __global__ __launch_bounds__(256) void orient_seg_kernel(int nseg, const OrientS
 }
 
 // segment table of the long rows, built on the device: seg_first[v] = exclusive scan of ceil(d/kOrientSeg) over the long rows
-__global__ __launch_bounds__(256) void orient_segcount_kernel(int nv, const int *__restrict__ rp, int *__restrict__ nseg_of) {
+template <class OffT>
+__global__ __launch_bounds__(256) void orient_segcount_kernel(int nv, const OffT *__restrict__ rp, int *__restrict__ nseg_of) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v > nv) return;
   int n = 0;
   if (v < nv) {
-    const int d = rp[v + 1] - rp[v];
+    const int d = (int)(rp[v + 1] - rp[v]);
     n = d > kOrientShort ? (d + kOrientSeg - 1) / kOrientSeg : 0;
   }
   nseg_of[v] = n;  // (nseg_of[nv] = 0: the scan's last element is the total)
 }
-__global__ __launch_bounds__(256) void orient_segfill_kernel(int nv, const int *__restrict__ rp, const int *__restrict__ seg_first,
-                                                             OrientSeg *__restrict__ segs) {
+template <class OffT>
+__global__ __launch_bounds__(256) void orient_segfill_kernel(int nv, const OffT *__restrict__ rp, const int *__restrict__ seg_first,
+                                                             OrientSegT<OffT> *__restrict__ segs) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= nv) return;
-  const int b = rp[v], e = rp[v + 1];
+  const OffT b = rp[v], e = rp[v + 1];
   if (e - b <= kOrientShort) return;
   int k = seg_first[v];
-  for (int s0 = b; s0 < e; s0 += kOrientSeg) segs[k++] = {v, s0, min(s0 + kOrientSeg, e), 0};
+  for (OffT s0 = b; s0 < e; s0 += kOrientSeg) segs[k++] = {v, s0, (s0 + kOrientSeg < e) ? (OffT)(s0 + kOrientSeg) : e, 0};
 }
 // output offset of every segment: the row's new offset + the kept entries of the row's earlier segments (one thread per long row)
-__global__ __launch_bounds__(256) void orient_segout_kernel(int nv, const int *__restrict__ rp, const int *__restrict__ seg_first,
+template <class OffT>
+__global__ __launch_bounds__(256) void orient_segout_kernel(int nv, const OffT *__restrict__ rp, const int *__restrict__ seg_first,
                                                             const int *__restrict__ seg_count, const int *__restrict__ new_rp,
-                                                            OrientSeg *__restrict__ segs) {
+                                                            OrientSegT<OffT> *__restrict__ segs) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= nv) return;
   if (rp[v + 1] - rp[v] <= kOrientShort) return;
@@ -403,34 +464,46 @@ __global__ __launch_bounds__(256) void max_degree_kernel(int nv, const int *__re
   if ((threadIdx.x & 63) == 0 && md) atomicMax(out, md);
 }
 
-extern "C" int gm_graph_orient(const gm_graph *sym, gm_graph **out) {
-  if (!sym || !out) return GM_ERR_INVALID;
-  *out = nullptr;
+template <class OffT>
+__global__ __launch_bounds__(256) void symdeg_kernel(int nv, const OffT *__restrict__ rp, int *__restrict__ deg) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < nv) deg[v] = (int)(rp[v + 1] - rp[v]);
+}
+// new offsets of an orientation whose input has 64-bit offsets: the scan runs in 64 bits (the result must be checked against the
+// 32-bit limit of the oriented handle before it is narrowed)
+__global__ __launch_bounds__(256) void narrow_offsets_kernel(int nv, const long long *__restrict__ in, int *__restrict__ out) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v <= nv) out[v] = (int)in[v];
+}
+
+template <class OffT>
+static int orient_impl(const gm_graph *sym, const OffT *rp_in, gm_graph **out) {
   HIP_TRY(hipSetDevice(sym->device));
   SetupTimer timer;
+  PoolScope pool(const_cast<gm_graph *>(sym));
   const int nv = sym->nv;
   const unsigned vb = (unsigned)((nv + 256) / 256);  // blocks covering v = 0 .. nv
   ScanTemp tmp;
   // segment table of the long rows (device): counts -> exclusive scan -> fill
   DevBuf<int> nseg_of, seg_first, deg, segcnt;
-  DevBuf<OrientSeg> segs;
+  DevBuf<OrientSegT<OffT>> segs;
   HIP_TRY(nseg_of.alloc((size_t)nv + 1));
   HIP_TRY(seg_first.alloc((size_t)nv + 1));
-  hipLaunchKernelGGL(orient_segcount_kernel, dim3(vb), dim3(256), 0, 0, nv, sym->d_rp, nseg_of.p);
+  hipLaunchKernelGGL((orient_segcount_kernel<OffT>), dim3(vb), dim3(256), 0, 0, nv, rp_in, nseg_of.p);
   HIP_TRY(dev_exclusive_sum(tmp, nseg_of.p, seg_first.p, (size_t)nv + 1));
   int nseg = 0;
   HIP_TRY(hipMemcpy(&nseg, seg_first.p + nv, sizeof(int), hipMemcpyDeviceToHost));
   HIP_TRY(segs.alloc((size_t)nseg));
   HIP_TRY(segcnt.alloc((size_t)nseg));
-  if (nseg) hipLaunchKernelGGL(orient_segfill_kernel, dim3(vb), dim3(256), 0, 0, nv, sym->d_rp, seg_first.p, segs.p);
+  if (nseg) hipLaunchKernelGGL((orient_segfill_kernel<OffT>), dim3(vb), dim3(256), 0, 0, nv, rp_in, seg_first.p, segs.p);
   // pass 0: new degrees (short rows write, segments of long rows add)
   HIP_TRY(deg.alloc((size_t)nv + 1));
   HIP_TRY(hipMemsetAsync(deg.p, 0, sizeof(int) * ((size_t)nv + 1), 0));
   const int bs = std::max(1, std::min((nv + 31) / 32, sym->cu_count * 8));
   const int bl = std::max(1, std::min((nseg + 3) / 4, sym->cu_count * 8));
-  hipLaunchKernelGGL(orient_short_kernel, dim3(bs), dim3(256), 0, 0, nv, sym->d_rp, sym->d_col, deg.p, (const int *)nullptr, (int *)nullptr, 0);
+  hipLaunchKernelGGL((orient_short_kernel<OffT>), dim3(bs), dim3(256), 0, 0, nv, rp_in, sym->d_col, deg.p, (const int *)nullptr, (int *)nullptr, 0);
   if (nseg)
-    hipLaunchKernelGGL(orient_seg_kernel, dim3(bl), dim3(256), 0, 0, nseg, segs.p, sym->d_rp, sym->d_col, segcnt.p, deg.p, (int *)nullptr, 0);
+    hipLaunchKernelGGL((orient_seg_kernel<OffT>), dim3(bl), dim3(256), 0, 0, nseg, segs.p, rp_in, sym->d_col, segcnt.p, deg.p, (int *)nullptr, 0);
   // new offsets = exclusive scan of the new degrees (parallel_prefix_sum, include/scan.h:5-35)
   gm_graph *g = new gm_graph();
   g->device = sym->device;
@@ -438,7 +511,21 @@ extern "C" int gm_graph_orient(const gm_graph *sym, gm_graph **out) {
   auto fail = [&](int code) { gm_graph_free(g); return code; };
   hipError_t e;
   if ((e = hipMalloc(&g->d_rp, sizeof(int) * ((size_t)nv + 1))) != hipSuccess) return fail(hip_fail(e, "hipMalloc", __FILE__, __LINE__));
-  if ((e = dev_exclusive_sum(tmp, deg.p, g->d_rp, (size_t)nv + 1)) != hipSuccess) return fail(hip_fail(e, "ExclusiveSum", __FILE__, __LINE__));
+  if constexpr (sizeof(OffT) == 8) {
+    // the oriented graph of a symmetric graph of >= 2^31 entries: half of them -- checked in 64 bits before the offsets are narrowed
+    DevBuf<long long> rp64;
+    if ((e = rp64.alloc((size_t)nv + 1)) != hipSuccess) return fail(hip_fail(e, "hipMalloc", __FILE__, __LINE__));
+    if ((e = dev_exclusive_sum(tmp, deg.p, rp64.p, (size_t)nv + 1)) != hipSuccess) return fail(hip_fail(e, "ExclusiveSum", __FILE__, __LINE__));
+    long long total = 0;
+    if ((e = hipMemcpy(&total, rp64.p + nv, sizeof(long long), hipMemcpyDeviceToHost)) != hipSuccess) return fail(hip_fail(e, "hipMemcpy", __FILE__, __LINE__));
+    if (total >= 0x7fffffffLL) {
+      g_last_error = "gm_graph_orient: the oriented graph has " + std::to_string(total) + " entries (>= 2^31: beyond the 32-bit task index of the mining kernels)";
+      return fail(GM_ERR_TOO_LARGE);
+    }
+    hipLaunchKernelGGL(narrow_offsets_kernel, dim3(vb), dim3(256), 0, 0, nv, rp64.p, g->d_rp);
+  } else {
+    if ((e = dev_exclusive_sum(tmp, deg.p, g->d_rp, (size_t)nv + 1)) != hipSuccess) return fail(hip_fail(e, "ExclusiveSum", __FILE__, __LINE__));
+  }
   DevBuf<int> md;
   if ((e = md.alloc(1)) != hipSuccess) return fail(hip_fail(e, "hipMalloc", __FILE__, __LINE__));
   (void)hipMemsetAsync(md.p, 0, sizeof(int), 0);
@@ -450,16 +537,26 @@ extern "C" int gm_graph_orient(const gm_graph *sym, gm_graph **out) {
   g->max_deg = max_deg;
   if ((e = hipMalloc(&g->d_col, sizeof(int) * (size_t)std::max(ne_new, 1))) != hipSuccess) return fail(hip_fail(e, "hipMalloc", __FILE__, __LINE__));
   // pass 1: compact
-  if (nseg) hipLaunchKernelGGL(orient_segout_kernel, dim3(vb), dim3(256), 0, 0, nv, sym->d_rp, seg_first.p, segcnt.p, g->d_rp, segs.p);
-  hipLaunchKernelGGL(orient_short_kernel, dim3(bs), dim3(256), 0, 0, nv, sym->d_rp, sym->d_col, (int *)nullptr, g->d_rp, g->d_col, 1);
+  if (nseg) hipLaunchKernelGGL((orient_segout_kernel<OffT>), dim3(vb), dim3(256), 0, 0, nv, rp_in, seg_first.p, segcnt.p, g->d_rp, segs.p);
+  hipLaunchKernelGGL((orient_short_kernel<OffT>), dim3(bs), dim3(256), 0, 0, nv, rp_in, sym->d_col, (int *)nullptr, g->d_rp, g->d_col, 1);
   if (nseg)
-    hipLaunchKernelGGL(orient_seg_kernel, dim3(bl), dim3(256), 0, 0, nseg, segs.p, sym->d_rp, sym->d_col, (int *)nullptr, (int *)nullptr, g->d_col, 1);
+    hipLaunchKernelGGL((orient_seg_kernel<OffT>), dim3(bl), dim3(256), 0, 0, nseg, segs.p, rp_in, sym->d_col, (int *)nullptr, (int *)nullptr, g->d_col, 1);
   if ((e = hipGetLastError()) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess) return fail(hip_fail(e, "orient kernels", __FILE__, __LINE__));
   int rc = finish_handle(g);
   if (rc) { gm_graph_free(g); return rc; }
+  // (the symmetric degrees: what the topological renumbering of this DAG sorts by -- get_relabeled mode 2)
+  if ((e = hipMalloc(&g->d_symdeg, sizeof(int) * (size_t)std::max(nv, 1))) != hipSuccess) return fail(hip_fail(e, "hipMalloc", __FILE__, __LINE__));
+  if (nv > 0) hipLaunchKernelGGL((symdeg_kernel<OffT>), dim3(vb), dim3(256), 0, 0, nv, rp_in, g->d_symdeg);
+  if ((e = hipGetLastError()) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess) return fail(hip_fail(e, "symdeg_kernel", __FILE__, __LINE__));
   g->setup.orient_ms = timer.ms();
   *out = g;
   return GM_OK;
+}
+
+extern "C" int gm_graph_orient(const gm_graph *sym, gm_graph **out) {
+  if (!sym || !out) return GM_ERR_INVALID;
+  *out = nullptr;
+  return sym->d_rp64 ? orient_impl<long long>(sym, sym->d_rp64, out) : orient_impl<int>(sym, sym->d_rp, out);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -478,11 +575,12 @@ __global__ __launch_bounds__(256) void relabel_indeg_kernel(long long ne, const 
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += stride) atomicAdd(&indeg[col[e]], 1);
 }
-__global__ __launch_bounds__(256) void relabel_vkeys_kernel(int nv, const int *__restrict__ rp, const int *__restrict__ indeg,
+// (deg: the sorting degree itself when given -- the symmetric degrees a DAG remembers from its orientation; else out-degree + indeg)
+__global__ __launch_bounds__(256) void relabel_vkeys_kernel(int nv, const int *__restrict__ rp, const int *__restrict__ indeg, const int *__restrict__ deg,
                                                             unsigned long long *__restrict__ keys) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= nv) return;
-  const unsigned long long d = (unsigned long long)(rp[v + 1] - rp[v]) + (indeg ? (unsigned long long)indeg[v] : 0ull);
+  const unsigned long long d = deg ? (unsigned long long)deg[v] : (unsigned long long)(rp[v + 1] - rp[v]) + (indeg ? (unsigned long long)indeg[v] : 0ull);
   keys[v] = (d << 32) | (unsigned long long)(unsigned)v;
 }
 // position i of the sorted (degree, id) keys -> new id (ascending: i; descending: nv - 1 - i); the new row's length rides along
@@ -546,6 +644,7 @@ int get_relabeled(gm_graph *g, int mode, gm_graph **out) {
   const int nv = g->nv;
   const long long ne = g->ne;
   const size_t nv1 = (size_t)nv + 1, n1 = (size_t)std::max<long long>(ne, 1);
+  PoolScope pool(g);  // (the sort buffers: two 64-bit keys per entry + hipCUB's own)
   auto blocks = [](long long n) { return dim3((unsigned)std::max<long long>(1, (n + 255) / 256)); };
   ScanTemp tmp;
   DevBuf<int> indeg, newid, newdeg;
@@ -554,7 +653,7 @@ int get_relabeled(gm_graph *g, int mode, gm_graph **out) {
   HIP_TRY(newdeg.alloc(nv1));
   HIP_TRY(vkeys.alloc(nv1));
   HIP_TRY(vsorted.alloc(nv1));
-  if (mode == 2) {
+  if (mode == 2 && !g->d_symdeg) {  // (a contended atomic pass: 15 ms on the com-Orkut stand-in; a DAG from gm_graph_orient skips it)
     HIP_TRY(indeg.alloc(nv1));
     HIP_TRY(hipMemsetAsync(indeg.p, 0, sizeof(int) * nv1, 0));
     if (ne > 0) hipLaunchKernelGGL(relabel_indeg_kernel, dim3((unsigned)std::min<long long>((ne + 255) / 256, (long long)g->cu_count * 32)), dim3(256), 0, 0, ne, g->d_col, indeg.p);
@@ -562,7 +661,8 @@ int get_relabeled(gm_graph *g, int mode, gm_graph **out) {
   int bits = 1;
   while (bits < 32 && (1ll << bits) < (long long)nv) ++bits;
   if (nv > 0) {
-    hipLaunchKernelGGL(relabel_vkeys_kernel, blocks(nv), dim3(256), 0, 0, nv, g->d_rp, mode == 2 ? indeg.p : (const int *)nullptr, vkeys.p);
+    hipLaunchKernelGGL(relabel_vkeys_kernel, blocks(nv), dim3(256), 0, 0, nv, g->d_rp, (mode == 2 && !g->d_symdeg) ? indeg.p : (const int *)nullptr,
+                       mode == 2 ? g->d_symdeg : (const int *)nullptr, vkeys.p);
     size_t bytes = 0;
     HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, vkeys.p, vsorted.p, nv, 0, 64));
     HIP_TRY(tmp.reserve(bytes));

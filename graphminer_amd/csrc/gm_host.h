@@ -37,21 +37,48 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
     if (_e != hipSuccess) return hip_fail(_e, #call, __FILE__, __LINE__); \
   } while (0)
 
+// The temporaries of the setup paths (a table build has ~20 of them) come out of ONE device allocation per handle: a bump allocator
+// that a PoolScope opens at the top of a setup function and rewinds at its end. hipMalloc / hipFree cost 0.1-0.3 ms each and hipFree
+// synchronises the device: round 2 measured ~10 ms of allocation overhead per table. What does not fit the pool
+// falls through to hipMalloc (and tells the pool how much to ask for next time).
+struct TempPool {
+  char *base = nullptr;
+  size_t cap = 0, off = 0, want = 0;  // want: bytes the open scopes would have liked (pool + fall-through allocations)
+};
+extern thread_local TempPool *g_temp_pool;  // the pool of the innermost open PoolScope of this thread (gm_graph.hip)
+
 template <class T>
-struct DevBuf {  // RAII device array
+struct DevBuf {  // RAII device array; pooled when a PoolScope is open and the pool has room
   T *p = nullptr;
   size_t n = 0;
+  bool pooled = false;
   DevBuf() = default;
   DevBuf(const DevBuf &) = delete;
   DevBuf &operator=(const DevBuf &) = delete;
-  ~DevBuf() { if (p) (void)hipFree(p); }
-  hipError_t alloc(size_t count) {
-    if (p) (void)hipFree(p);
+  ~DevBuf() { drop(); }
+  void drop() {
+    if (p && !pooled) (void)hipFree(p);
     p = nullptr;
-    n = count;
-    return hipMalloc(&p, sizeof(T) * std::max<size_t>(count, 1));
+    pooled = false;
   }
-  T *release() { T *q = p; p = nullptr; n = 0; return q; }
+  // keep = true: the array outlives the scope (release() hands it to a long-lived owner): never from the pool
+  hipError_t alloc(size_t count, bool keep = false) {
+    drop();
+    n = count;
+    const size_t bytes = (sizeof(T) * std::max<size_t>(count, 1) + 255) & ~(size_t)255;
+    TempPool *pool = keep ? nullptr : g_temp_pool;
+    if (pool) {
+      pool->want += bytes;
+      if (pool->off + bytes <= pool->cap) {
+        p = reinterpret_cast<T *>(pool->base + pool->off);
+        pool->off += bytes;
+        pooled = true;
+        return hipSuccess;
+      }
+    }
+    return hipMalloc(&p, bytes);
+  }
+  T *release() { T *q = pooled ? nullptr : p; p = nullptr; n = 0; pooled = false; return q; }  // (a pooled array cannot be handed on: alloc(..., true))
 };
 
 struct ScanTemp {  // temp storage of the hipCUB calls, grown on demand
@@ -174,8 +201,10 @@ struct gm_graph {
   long long ne = 0;
   int max_deg = 0;
   int *d_rp = nullptr;   // int32 offsets, owned
+  long long *d_rp64 = nullptr;  // a BIG handle (ne >= 2^31): 64-bit offsets instead -- orientation, formula 3-motif and download only
   int *d_col = nullptr;  // col_idx
   bool own_col = true;
+  int *d_symdeg = nullptr;  // a DAG made by gm_graph_orient: the degrees of the symmetric graph it came from (its topological numbering sorts by them)
   int2 *d_edesc = nullptr;  // per CSR entry: {rp[col[e]], degree(col[e])}, built on first use (ensure_edesc)
   int *d_trp = nullptr;     // task lists of the shorter-list-streams triangle count (ensure_tasklists): row offsets (nv + 1)
   int2 *d_tdesc = nullptr;  // ... and per task {rp[partner], d(partner)}
@@ -191,6 +220,7 @@ struct gm_graph {
   gm_graph *dag_cache = nullptr;          // oriented copy, built on demand by gm_motif_formula
   gm_graph *relabel_cache[3] = {nullptr, nullptr, nullptr};  // renumbered copies: by degree ascending / descending, topological (get_relabeled)
   int topo_state = 0;                // 0 unknown, 1 every edge goes to a larger id, 2 not (graph_is_topological)
+  double mean_sq_deg = -1.0;         // sum_v d(v)^2 / ne: the mean length of the row an entry sits in (-1: not computed yet; topo_view)
   bool topo_relabel_failed = false;  // the (degree, id) numbering is not topological for this DAG: it runs as given
   const gm_graph *ring_alias = nullptr;
   const gm_graph *ring_extra[2] = {nullptr, nullptr};  // 4-motif: the handles that ran the other sub-launches of the most recent calls (gm_kernel_times adds them)
@@ -226,8 +256,35 @@ struct gm_graph {
   unsigned *d_wide_queue = nullptr;    // dequeue words of the wide launches of one call (zeroed per call)
   hipStream_t aux_stream[3] = {nullptr, nullptr, nullptr};  // class kernels that cannot fill the chip run beside the others (run_pattern)
   hipEvent_t aux_done[3] = {nullptr, nullptr, nullptr};
+  TempPool pool;  // temporaries of the setup paths (PoolScope)
   gm_setup_times setup = {0, 0, 0, 0, 0};  // accumulated pre-processing time of this handle (gm_graph_setup_times)
   std::mutex mu;
+};
+
+// Opens the handle's temp pool for the DevBufs of the enclosing setup function (nested scopes share it, stack discipline). The pool is
+// ONE allocation per handle, made on first use and kept: 24 bytes per vertex + 16 MB, at most 256 MB -- room for the O(nv) and
+// O(chunks) arrays of a table build; the sort buffers of a renumbering or a task-list build (O(ne), once per graph) fall through to
+// hipMalloc. (A pool sized for everything and regrown per scope was measured first: allocating hundreds of MB per table cost more
+// than the twenty small hipMallocs it replaced -- diamond R-MAT-22 table_ms 11.6 -> 40.)
+struct PoolScope {
+  gm_graph *g;
+  TempPool *prev;
+  size_t mark;
+  explicit PoolScope(gm_graph *g_) : g(g_), prev(g_temp_pool) {
+    TempPool &pl = g->pool;
+    if (!pl.base && !getenv("GM_NO_TEMP_POOL")) {
+      const size_t need = std::min<size_t>((size_t)256 << 20, (size_t)24 * ((size_t)g->nv + 1) + ((size_t)16 << 20));
+      if (hipMalloc(&pl.base, need) == hipSuccess) pl.cap = need;
+      else (void)hipGetLastError();  // (no pool: everything falls through to hipMalloc)
+    }
+    mark = pl.off;
+    g_temp_pool = &pl;
+  }
+  ~PoolScope() {
+    (void)hipDeviceSynchronize();  // nothing may still be reading the temporaries when the next scope reuses them
+    g->pool.off = mark;
+    g_temp_pool = prev;
+  }
 };
 
 // wall-clock stopwatch for the setup accounting (host clock: the steps mix host work, copies and synchronised kernels)

@@ -40,6 +40,11 @@ struct LaunchCtx {
 // validates the arguments, selects the device, zeroes the 64-byte counter block on the launch stream
 static int begin_launch(const gm_graph *cg, const gm_launch *la, const uint64_t *h_out, LaunchCtx &c) {
   if (!cg) return GM_ERR_INVALID;
+  if (cg->d_rp64) {  // a big handle (ne >= 2^31): the mining kernels index a graph with 32 bits
+    g_last_error = "this solver walks the graph it is given with a 32-bit task index; " + std::to_string(cg->ne) +
+                   " entries: orient it (gm_graph_orient) for TC / k-clique, gm_motif k = 3 counts through the formula solver";
+    return GM_ERR_TOO_LARGE;
+  }
   c.g = const_cast<gm_graph *>(cg);
   memset(&c.la, 0, sizeof c.la);
   if (la) c.la = *la;
@@ -302,7 +307,22 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
     // one arena slot per workgroup; k >= 5 doubles it (second half: compacted sub-matrices, cliquek_count_sub)
     // k >= 5: k - 2 slots of max_bit_words + 4096 words (the vertex's matrix + one compacted sub-matrix per deeper level; the
     // margin covers the padding of compacted rows to 64 columns)
-    const unsigned long long slot_words = (pat == PAT_CLIQUEK) ? (unsigned long long)(k - 2) * (tab->max_bit_words + 4096ull) : tab->max_bit_words;
+    const unsigned long long region = tab->max_bit_words + 4096ull;
+    const int plist = (g->max_deg + 64) & ~63;  // (rows beyond 4096 columns keep their position lists here: cliquek_count_sub_any)
+    const unsigned long long slot_words = (pat == PAT_CLIQUEK) ? (unsigned long long)(k - 2) * (region + (unsigned long long)plist) : tab->max_bit_words;
+    p.scratch_region = region;
+    p.scratch_plist = plist;
+    {  // a slot per workgroup: with very long rows fewer workgroups, so that the arena stays within half of the free memory
+      size_t free_b = 0, total_b = 0;
+      (void)hipMemGetInfo(&free_b, &total_b);
+      const unsigned long long budget = (unsigned long long)(free_b + g->scratch_bytes) / 2ull;
+      const unsigned long long fit = budget / std::max<unsigned long long>(slot_words * sizeof(unsigned), 1ull);
+      if (fit == 0) {
+        g_last_error = "k-clique: the bit-matrix of the longest DAG row (" + std::to_string(g->max_deg) + " entries) does not fit the device memory";
+        return GM_ERR_TOO_LARGE;
+      }
+      if ((unsigned long long)grid > fit) grid = (int)fit;
+    }
     const size_t need = (size_t)slot_words * sizeof(unsigned) * (size_t)grid;
     if (need > g->scratch_bytes) {
       if (g->d_scratch) (void)hipFree(g->d_scratch);
@@ -553,7 +573,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
 
 extern "C" int gm_kernel_times(const gm_graph *g, int n, double *ms_out, int *n_out) {
   if (!g || !ms_out || !n_out || n < 0) return GM_ERR_INVALID;
-  if (g->ring_alias) g = g->ring_alias;
+  while (g->ring_alias) g = g->ring_alias;  // (a derived handle may itself run on a renumbered copy)
   const unsigned long long have = std::min<unsigned long long>(g->ev_launches, gm_graph::kEvRing);
   const int m = (int)std::min<unsigned long long>((unsigned long long)n, have);
   HIP_TRY(hipSetDevice(g->device));
@@ -566,6 +586,7 @@ extern "C" int gm_kernel_times(const gm_graph *g, int n, double *ms_out, int *n_
     // cached DAG; the launches of the same recency on those handles belong to the same call
     for (const gm_graph *x : g->ring_extra) {
       const unsigned long long back = (unsigned long long)(m - i);
+      while (x && x->ring_alias) x = x->ring_alias;
       if (!x || x->ev_launches < back) continue;
       const unsigned long long xi = (x->ev_launches - back) % gm_graph::kEvRing;
       float xms = 0.f;
@@ -577,9 +598,63 @@ extern "C" int gm_kernel_times(const gm_graph *g, int n, double *ms_out, int *n_
   return GM_OK;
 }
 
-extern "C" int gm_tc(const gm_graph *dag, const gm_launch *la, uint64_t *total, gm_stats *st) {
-  return run_pattern(PAT_TC, dag, la, 3, total, 1, st);
+// The DAG kernels that profit from a TOPOLOGICAL numbering (every edge from a smaller to a larger id: an in-edge task streams only the
+// part of N+(u) beyond v, the k-clique matrices are strictly upper triangular) run on the cached renumbered copy of a DAG that is not
+// numbered that way (get_relabeled mode 2). tune[6] & 0x200: on the graph as numbered, like the SgL patterns.
+// Only where lists are long: the trimmed streams and the triangular counts save work per KEY, the renumbering concentrates the hubs
+// in a few host chunks -- measured (profiles/r03/ab_topo_view.txt, TC ms as numbered / renumbered, whole lists / renumbered, trimmed):
+// R-MAT-22 6.45 / 6.26 / 5.28, LiveJournal-size flat degrees (5.5 keys per task) 0.88 / 0.85 / 0.86, power law with LiveJournal's
+// maximum degree (5.5 keys per task) 1.14 / 1.88 / 1.59. The switch is the mean length of the row a DAG entry sits in, sum d+^2 / |E+|
+// (R-MAT-22: 157, R-MAT-22 ef 28: 322, R-MAT-24: 367; the power-law graph: 11.6, flat: 10.5): >= kTopoMinMeanRow -> renumbered. GM_TOPO_MIN_ROW overrides (0: always).
+__global__ __launch_bounds__(256) void sum_sq_deg_kernel(int nv, const int *__restrict__ rp, unsigned long long *__restrict__ out) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  unsigned long long s = 0;
+  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += stride) {
+    const unsigned long long d = (unsigned long long)(rp[v + 1] - rp[v]);
+    s += d * d;
+  }
+  s = gm::wave_sum_u64(s);
+  if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
 }
+constexpr double kTopoMinMeanRow = 64.0;
+
+static int topo_view(const gm_graph *dag, const gm_launch *la, gm_graph **run_on) {
+  gm_graph *self = const_cast<gm_graph *>(dag);
+  if (!self) return GM_ERR_INVALID;
+  *run_on = self;
+  if (la && (la->tune[6] & 0x200)) return GM_OK;
+  bool topo = false;
+  int rc = graph_is_topological(self, &topo);
+  if (rc || topo) return rc;
+  if (self->mean_sq_deg < 0) {
+    HIP_TRY(hipSetDevice(self->device));
+    unsigned long long *d_s = nullptr, s2 = 0;
+    HIP_TRY(hipMalloc(&d_s, 8));
+    hipError_t e = hipMemset(d_s, 0, 8);
+    if (e == hipSuccess && self->nv > 0)
+      hipLaunchKernelGGL(sum_sq_deg_kernel, dim3((unsigned)std::min<long long>(((long long)self->nv + 255) / 256, 2048)), dim3(256), 0, 0, self->nv, self->d_rp, d_s);
+    if (e == hipSuccess) e = hipMemcpy(&s2, d_s, 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d_s);
+    if (e != hipSuccess) return hip_fail(e, "sum_sq_deg_kernel", __FILE__, __LINE__);
+    self->mean_sq_deg = self->ne > 0 ? (double)s2 / (double)self->ne : 0.0;
+  }
+  double min_row = kTopoMinMeanRow;
+  if (const char *e = getenv("GM_TOPO_MIN_ROW")) min_row = atof(e);
+  if (getenv("GM_TABLE_INFO")) fprintf(stderr, "[topo view] sum d+^2 / |E+| = %.1f (switch at %.1f)\n", self->mean_sq_deg, min_row);
+  if (self->mean_sq_deg < min_row) return GM_OK;  // short lists: as numbered
+  return get_relabeled(self, 2, run_on);
+}
+
+static int run_tc(const gm_graph *dag, const gm_launch *la, uint64_t *out, int nout, gm_stats *st, int fin_mode = -1, unsigned long long fin_base = 0) {
+  gm_graph *run_on = nullptr;
+  int rc = topo_view(dag, la, &run_on);
+  if (rc) return rc;
+  rc = run_pattern(PAT_TC, run_on, la, 3, out, nout, st, fin_mode, fin_base);
+  const_cast<gm_graph *>(dag)->ring_alias = (run_on != dag) ? run_on : nullptr;
+  return rc;
+}
+
+extern "C" int gm_tc(const gm_graph *dag, const gm_launch *la, uint64_t *total, gm_stats *st) { return run_tc(dag, la, total, 1, st); }
 
 // rectangle, flattened over wedges (rect_flat_kernel in gm_mine.hip)
 static int ensure_idx0(gm_graph *g, const GraphView &gv) {
@@ -764,8 +839,8 @@ static int ensure_edge_tables(gm_graph *g, const GraphView &gv) {
   OtherSetupScope scope(g);
   const size_t ne1 = (size_t)std::max<long long>(g->ne, 1);
   DevBuf<unsigned> t, tlt;
-  HIP_TRY(t.alloc(ne1));
-  HIP_TRY(tlt.alloc(ne1));
+  HIP_TRY(t.alloc(ne1, true));  // (handed to the handle below)
+  HIP_TRY(tlt.alloc(ne1, true));
   if (g->ne > 0) {
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemset(g->d_counters, 0, 64));
@@ -1003,30 +1078,18 @@ extern "C" int gm_sgl(const gm_graph *sym, const char *pattern, const gm_launch 
 }
 
 extern "C" int gm_clique(const gm_graph *dag, int k, const gm_launch *la, uint64_t *total, gm_stats *st) {
-  if (k == 3) return run_pattern(PAT_TC, dag, la, 3, total, 1, st);
+  if (k == 3) return run_tc(dag, la, total, 1, st);
   if (k < 3 || k > 8) {
     if (total) *total = 0;
     return GM_ERR_INVALID;
-  }
-  if (k > 4 && dag && dag->max_deg > 4096) {  // deeper levels sweep a row with two words per lane (cliquek_count_sub)
-    if (total) *total = 0;
-    g_last_error = "gm_clique: k >= 5 needs max out-degree <= 4096 (this DAG: " + std::to_string(dag->max_deg) + ")";
-    return GM_ERR_TOO_LARGE;
   }
   if (k == 4 && !(la && (la->tune[6] & (0x40000 | 0x200)))) {
     // the re-hosted first level and the pair counts want a TOPOLOGICAL numbering (upper-triangular matrices: gm_cbuild.hip): a DAG
     // that is not numbered that way runs on its cached renumbered copy (tune[6] & 0x200: on the graph as numbered, like the SgL
     // patterns; & 0x40000: everything in the mining kernel, which does not care)
-    gm_graph *self = const_cast<gm_graph *>(dag);
-    if (!self) return GM_ERR_INVALID;
-    bool topo = false;
-    int rc = graph_is_topological(self, &topo);
+    gm_graph *self = const_cast<gm_graph *>(dag), *run_on = nullptr;
+    int rc = topo_view(dag, la, &run_on);
     if (rc) return rc;
-    gm_graph *run_on = self;
-    if (!topo) {
-      rc = get_relabeled(self, 2, &run_on);
-      if (rc) return rc;
-    }
     rc = run_pattern(PAT_CLIQUE4, run_on, la, k, total, 1, st);
     self->ring_alias = (run_on != self) ? run_on : nullptr;
     return rc;
@@ -1076,7 +1139,7 @@ extern "C" int gm_motif4_partial(const gm_graph *sym, const gm_launch *la, uint6
   }
   if (rc) return rc;
   l2.d_counts = d_out ? d_out + 5 : nullptr;
-  rc = run_pattern(PAT_CLIQUE4, g->dag_cache, &l2, 4, raw ? &raw[5] : nullptr, 1, &s3);
+  rc = gm_clique(g->dag_cache, 4, &l2, raw ? &raw[5] : nullptr, &s3);  // (on the DAG's topological view)
   if (rc) return rc;
   if (st) {
     *st = s1;
@@ -1132,6 +1195,9 @@ extern "C" int gm_motif(const gm_graph *sym, int k, const gm_launch *la, uint64_
   }
   if (k != 3) return GM_ERR_INVALID;
   if (ncounts < 2) return GM_ERR_INVALID;
+  // a graph of 2^31 entries or more: through the reference's OTHER 3-motif solver (motif_omp_formula, src/motif/omp_formula.cc:39-46:
+  // triangles on the oriented graph, wedges = sum C(d,2) - 3T) -- same counts, and the oriented graph fits the 32-bit task index
+  if (sym && sym->d_rp64) return gm_motif_formula(sym, k, la, counts, ncounts, st);
   return run_pattern(PAT_MOTIF3, sym, la, 3, counts, ncounts, st);
 }
 
@@ -1140,7 +1206,8 @@ extern "C" int gm_motif(const gm_graph *sym, int k, const gm_launch *la, uint64_
 // TC kernel on the oriented graph (built once per handle and cached), so the hub rows of the symmetric graph are
 // never intersected. Counts are identical to gm_motif; with world > 1 the sum_v C(d,2) term is contributed by rank 0
 // and the per-rank partial wedge count is only meaningful after the all-reduce (mod 2^64 arithmetic).
-__global__ __launch_bounds__(256) void sum_c2_kernel(int nv, const int *__restrict__ rp, unsigned long long *__restrict__ out) {
+template <class OffT>
+__global__ __launch_bounds__(256) void sum_c2_kernel(int nv, const OffT *__restrict__ rp, unsigned long long *__restrict__ out) {
   const long long stride = (long long)gridDim.x * blockDim.x;
   unsigned long long s = 0;
   for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += stride) {
@@ -1167,14 +1234,16 @@ extern "C" int gm_motif_formula(const gm_graph *sym, int k, const gm_launch *la,
     HIP_TRY(hipSetDevice(g->device));
     HIP_TRY(acc.alloc(1));
     HIP_TRY(hipMemset(acc.p, 0, 8));
-    hipLaunchKernelGGL(sum_c2_kernel, dim3((unsigned)std::min<long long>(((long long)g->nv + 255) / 256, 2048)), dim3(256), 0, 0, g->nv, g->d_rp, acc.p);
+    const dim3 cgrid((unsigned)std::min<long long>(((long long)g->nv + 255) / 256, 2048));
+    if (g->d_rp64) hipLaunchKernelGGL((sum_c2_kernel<long long>), cgrid, dim3(256), 0, 0, g->nv, (const long long *)g->d_rp64, acc.p);
+    else hipLaunchKernelGGL((sum_c2_kernel<int>), cgrid, dim3(256), 0, 0, g->nv, (const int *)g->d_rp, acc.p);
     unsigned long long s2 = 0;
     HIP_TRY(hipMemcpy(&s2, acc.p, 8, hipMemcpyDeviceToHost));
     g->sum_c2 = s2;
     g->sum_c2_valid = true;
   }
   const int rank = la ? la->rank : 0;
-  const int rc = run_pattern(PAT_TC, g->dag_cache, la, 3, counts, ncounts, st, FIN_MOTIF3_FORMULA, rank == 0 ? g->sum_c2 : 0ull);
+  const int rc = run_tc(g->dag_cache, la, counts, ncounts, st, FIN_MOTIF3_FORMULA, rank == 0 ? g->sum_c2 : 0ull);
   g->ring_alias = g->dag_cache;
   return rc;
 }

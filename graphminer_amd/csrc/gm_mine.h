@@ -140,6 +140,10 @@ struct MineParams {
   unsigned long long *counters;  // [4] accumulators (zeroed before launch)
   unsigned *scratch;             // clique: global bit-matrix arena, scratch_words per workgroup
   unsigned long long scratch_words;
+  // k >= 5: the slot is k - 2 REGIONS of scratch_region words (the vertex's matrix, then one compacted sub-matrix per deeper level) followed
+  // by k - 2 position lists of scratch_plist ints (rows beyond 4096 columns: cliquek_count_sub_any)
+  unsigned long long scratch_region;
+  int scratch_plist;
   int cost_x_step;  // direction rule: X if b*(xb + xs*lg a) <= a*(yb + ys*lg b)
   int cost_y_step;
   int cost_x_base;

@@ -26,7 +26,7 @@ void free_tables(gm_graph *g) {
 // too long for the stage; rows longer than the stage are SPLIT into `target`-entry chunks (allow_split) or chunks of their
 // own. Runs on the host (gm_chunk_table, GM_HOST_TABLES) and, one thread per block of kTableBlock vertices, on the device:
 // the walk restarts at every block boundary, so a table is the same whichever side built it.
-constexpr int kTableBlock = 2048;
+constexpr int kTableBlock = 512;  // (2048 until round 3: four times fewer walkers, each four times as long -- the walk is a serial chain)
 struct ChunkWalk {
   int target, allow_split, bit_words, stage_cap;
   RowFilter rf;
@@ -159,12 +159,12 @@ static int batch_edges(const ChunkRec &r, const std::vector<int> &rp, int stage_
 // LiveJournal-size flat graph went from 0.873 to 1.145 ms; profiles/r02/ab_setup_device_tables.log.)
 // ------------------------------------------------------------------------------------------------
 // pass 0: chunks per vertex block (+ the k-clique arena requirement); pass 1: the records, at the block's offset.
-// A workgroup (one wave) owns kWalkPerWG blocks: all 64 lanes copy the blocks' offsets into LDS with coalesced loads (128 KB of
+// A workgroup owns kWalkPerWG blocks: all 256 threads copy the blocks' offsets into LDS with coalesced loads (64 KB of
 // the CU's 160 KB), then lanes 0 .. kWalkPerWG-1 each walk one block out of LDS -- the walk is a serial chain of dependent
 // reads, ~30 cycles per vertex from LDS against a memory round trip per cache line from HBM (one thread per block straight
 // from memory: 132 ms for the three 3-motif tables of R-MAT-24; this form: see profiles/r02/ab_setup_device_tables.log).
-constexpr int kWalkPerWG = 16;
-__global__ __launch_bounds__(64) void tab_walk_kernel(ChunkWalk w, int nv, const int *__restrict__ rp, int nblocks, int *__restrict__ count,
+constexpr int kWalkPerWG = 32;
+__global__ __launch_bounds__(256) void tab_walk_kernel(ChunkWalk w, int nv, const int *__restrict__ rp, int nblocks, int *__restrict__ count,
                                                       unsigned long long *__restrict__ max_bw, const int *__restrict__ offset, ChunkRec *__restrict__ recs) {
   __shared__ int rpl[kWalkPerWG][kTableBlock + 1];  // (row stride 2049 words: the walkers' lanes fall into different banks)
   const int b0 = blockIdx.x * kWalkPerWG;
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(64) void tab_walk_kernel(ChunkWalk w, int nv, const
     const int v0 = (b0 + k) * kTableBlock;
     if (v0 >= nv) break;
     const int n = min(kTableBlock, nv - v0) + 1;
-    for (int i = threadIdx.x; i < n; i += 64) rpl[k][i] = rp[v0 + i];
+    for (int i = threadIdx.x; i < n; i += 256) rpl[k][i] = rp[v0 + i];  // (all four waves fill: a single wave's serial round trips made this 3-5 ms per pass)
   }
   __syncthreads();
   const int k = threadIdx.x, b = b0 + k;
@@ -238,12 +238,16 @@ __global__ __launch_bounds__(256) void tab_expand_kernel(int n0, const ChunkRec 
     first_vertex[o] = r.u_begin;
   }
 }
+// rev_rest: the chunks below the heavy mark go in DESCENDING chunk-id order. On a topologically numbered DAG ids ascend in degree, so
+// ascending vertex order would end the launch on its heaviest ordinary chunks (TC on the power-law LiveJournal stand-in: 1.14 ms as
+// numbered, degrees descending, vs 1.88 ms on the renumbered copy before this)
 __global__ __launch_bounds__(256) void tab_orderkeys_kernel(int n, const unsigned long long *__restrict__ cost, unsigned long long heavy, int classes_only,
-                                                            unsigned long long *__restrict__ key0, unsigned long long *__restrict__ key1, int *__restrict__ iota) {
+                                                            int rev_rest, unsigned long long *__restrict__ key0, unsigned long long *__restrict__ key1,
+                                                            int *__restrict__ iota) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n) return;
   const unsigned long long x = cost[c];
-  key0[c] = x >= heavy ? (classes_only ? 1ull : x) : 0ull;
+  key0[c] = x >= heavy ? (classes_only ? 1ull : x) + (rev_rest ? (1ull << 56) : 0ull) : (rev_rest ? (unsigned long long)c : 0ull);
   key1[c] = x;
   iota[c] = c;
 }
@@ -294,7 +298,7 @@ static int build_table_device(gm_graph *g, ChunkTable &t, bool sym_table, double
   HIP_TRY(maxbw.alloc(1));
   HIP_TRY(hipMemsetAsync(maxbw.p, 0, 8, 0));
   const dim3 wgrid((unsigned)((nblk + 1 + kWalkPerWG - 1) / kWalkPerWG));
-  hipLaunchKernelGGL(tab_walk_kernel, wgrid, dim3(64), 0, 0, w, nv, g->d_rp, nblk, bcount.p, maxbw.p, (const int *)nullptr, (ChunkRec *)nullptr);
+  hipLaunchKernelGGL(tab_walk_kernel, wgrid, dim3(256), 0, 0, w, nv, g->d_rp, nblk, bcount.p, maxbw.p, (const int *)nullptr, (ChunkRec *)nullptr);
   HIP_TRY(dev_exclusive_sum(tmp, bcount.p, boff.p, (size_t)nblk + 1));
   int n0 = 0;
   HIP_TRY(hipMemcpy(&n0, boff.p + nblk, sizeof(int), hipMemcpyDeviceToHost));
@@ -307,7 +311,7 @@ static int build_table_device(gm_graph *g, ChunkTable &t, bool sym_table, double
   }
   DevBuf<ChunkRec> recs0;
   HIP_TRY(recs0.alloc((size_t)n0));
-  hipLaunchKernelGGL(tab_walk_kernel, wgrid, dim3(64), 0, 0, w, nv, g->d_rp, nblk, bcount.p, maxbw.p, (const int *)boff.p, recs0.p);
+  hipLaunchKernelGGL(tab_walk_kernel, wgrid, dim3(256), 0, 0, w, nv, g->d_rp, nblk, bcount.p, maxbw.p, (const int *)boff.p, recs0.p);
   // estimated work per chunk, parts
   DevBuf<unsigned long long> cost0;
   HIP_TRY(cost0.alloc((size_t)n0));
@@ -356,7 +360,8 @@ static int build_table_device(gm_graph *g, ChunkTable &t, bool sym_table, double
     HIP_TRY(key1.alloc((size_t)n));
     HIP_TRY(keyo.alloc((size_t)n));
     HIP_TRY(iota.alloc((size_t)n));
-    hipLaunchKernelGGL(tab_orderkeys_kernel, blocks(n), dim3(256), 0, 0, n, cost.p, heavy, sym_table ? 1 : 0, key0.p, key1.p, iota.p);
+    hipLaunchKernelGGL(tab_orderkeys_kernel, blocks(n), dim3(256), 0, 0, n, cost.p, heavy, sym_table ? 1 : 0, (!sym_table && g->topo_state == 1) ? 1 : 0,
+                       key0.p, key1.p, iota.p);
     for (int m = 0; m < 2; ++m) {
       HIP_TRY(hipMalloc(&t.d_order[m], sizeof(int) * (size_t)n));
       size_t bytes = 0;
@@ -415,10 +420,10 @@ static int build_table_device(gm_graph *g, ChunkTable &t, bool sym_table, double
         DevBuf<unsigned> bitmaps;
         HIP_TRY(d_rows.alloc(nb));
         HIP_TRY(hipMemcpy(d_rows.p, rows.data(), sizeof(int) * nb, hipMemcpyHostToDevice));
-        HIP_TRY(row_slot.alloc((size_t)nv));
+        HIP_TRY(row_slot.alloc((size_t)nv, true));  // (published to the bitmap set below)
         HIP_TRY(hipMemsetAsync(row_slot.p, 0xff, sizeof(int) * (size_t)nv, 0));  // -1
         hipLaunchKernelGGL(tab_rowslot_kernel, blocks((long long)nb), dim3(256), 0, 0, (int)nb, d_rows.p, row_slot.p);
-        HIP_TRY(bitmaps.alloc((size_t)nb * (size_t)words));
+        HIP_TRY(bitmaps.alloc((size_t)nb * (size_t)words, true));
         HIP_TRY(hipMemsetAsync(bitmaps.p, 0, (size_t)nb * (size_t)words * 4, 0));
         hipLaunchKernelGGL(bitmap_build_kernel, dim3((unsigned)nb), dim3(256), 0, 0, g->d_rp, g->d_col, d_rows.p, bitmaps.p, words);
         HIP_TRY(hipDeviceSynchronize());  // (the set is published only after its kernels have succeeded)
@@ -466,6 +471,7 @@ int get_table(gm_graph *g, int target, bool allow_split, int bit_words, unsigned
   t.bitmap_min_deg = bitmap_min_deg;
   if (!getenv("GM_HOST_TABLES")) {  // (GM_HOST_TABLES: the same walk in a host loop over the vertices, kept for A/B)
     HIP_TRY(hipSetDevice(g->device));
+    PoolScope pool(g);
     int rc = build_table_device(g, t, sym_table, bitmap_ms);
     if (rc) { free_table(t); return rc; }  // (a partially built table owns device memory: out-of-memory on a large graph must not leak it)
     if (getenv("GM_TABLE_INFO")) {
@@ -641,8 +647,12 @@ __global__ __launch_bounds__(256) void edesc_kernel(long long ne, const int *__r
 }
 
 // ---- task lists of gm_tct.hip: every edge u -> v of the DAG is a task of the endpoint with the longer out-list -------------------
+// key = (host << 32) | entry; value = how the list to stream is found: -1 = N+(col[entry]) (the host is the source: out-edge task),
+// else the source's list (the host is the target: in-edge task) -- under a TOPOLOGICAL numbering only its part beyond the target can
+// hold a common neighbour, which starts right behind the entry: value = its length; otherwise value = source | 2^30 (the whole list)
 __global__ __launch_bounds__(256) void task_keys_kernel(int nv, long long ne, const int *__restrict__ rp, const int *__restrict__ col,
-                                                         unsigned long long *__restrict__ keys, int *__restrict__ cnt, int stage_max) {
+                                                         unsigned long long *__restrict__ keys, int *__restrict__ vals, int *__restrict__ cnt, int stage_max,
+                                                         int topo) {
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += stride) {
     int lo = 0, hi = nv - 1;  // the row of entry e: largest u with rp[u] <= e
@@ -654,22 +664,29 @@ __global__ __launch_bounds__(256) void task_keys_kernel(int nv, long long ne, co
     const int du = rp[u + 1] - rp[u], dv = rp[v + 1] - rp[v];
     if (du > stage_max) {  // a row the stage cannot take hosts nothing: its out-edges stay with the chunked kernel (run_pattern)
       keys[e] = ~0ull;     // (sorts behind every task)
+      vals[e] = -1;
       continue;
     }
     const bool u_hosts = dv > stage_max || du >= dv;  // the longer list hosts (ties: the source) -- unless it does not fit the stage
-    const int host = u_hosts ? u : v, partner = u_hosts ? v : u;
-    keys[e] = ((unsigned long long)(unsigned)host << 32) | (unsigned)partner;
+    const int host = u_hosts ? u : v;
+    keys[e] = ((unsigned long long)(unsigned)host << 32) | (unsigned long long)(unsigned)e;
+    vals[e] = u_hosts ? -1 : (topo ? (int)(rp[u + 1] - (e + 1)) : (u | (1 << 30)));
     atomicAdd(&cnt[host], 1);
   }
 }
-__global__ __launch_bounds__(256) void task_desc_kernel(long long ne, const int *__restrict__ rp, const unsigned long long *__restrict__ sorted,
-                                                         int2 *__restrict__ tdesc) {
+__global__ __launch_bounds__(256) void task_desc_kernel(long long ne, const int *__restrict__ rp, const int *__restrict__ col,
+                                                         const unsigned long long *__restrict__ sorted, const int *__restrict__ vals, int2 *__restrict__ tdesc) {
   const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += stride) {
-    if (sorted[e] == ~0ull) { tdesc[e] = make_int2(0, 0); continue; }  // (the out-edges of rows beyond the stage: not tasks)
-    const int y = (int)(unsigned)(sorted[e] & 0xffffffffull);
-    const int r = rp[y];
-    tdesc[e] = make_int2(r, rp[y + 1] - r);
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < ne; t += stride) {
+    if (sorted[t] == ~0ull) { tdesc[t] = make_int2(0, 0); continue; }  // (the out-edges of rows beyond the stage: not tasks)
+    const int e = (int)(unsigned)(sorted[t] & 0xffffffffull), val = vals[t];
+    if (val >= 0 && !(val & (1 << 30))) {  // in-edge task, topological numbering: the source's list beyond this entry
+      tdesc[t] = make_int2(e + 1, val);
+    } else {
+      const int y = val < 0 ? col[e] : (val & ~(1 << 30));
+      const int r = rp[y];
+      tdesc[t] = make_int2(r, rp[y + 1] - r);
+    }
   }
 }
 int ensure_tasklists(gm_graph *g) {
@@ -679,29 +696,38 @@ int ensure_tasklists(gm_graph *g) {
   SetupTimer timer;
   HIP_TRY(hipSetDevice(g->device));
   const size_t ne = (size_t)g->ne, nv1 = (size_t)g->nv + 1;
+  PoolScope pool(g);  // (keys + values, twice, + hipCUB's own)
   DevBuf<unsigned long long> keys, sorted;
-  DevBuf<int> cnt;
+  DevBuf<int> cnt, vals, vals_sorted;
   ScanTemp tmp;
+  bool topo = false;
+  {
+    const int rc = graph_is_topological(g, &topo);
+    if (rc) return rc;
+    if (getenv("GM_TC_NO_TRIM")) topo = false;  // (A/B: whole lists streamed on a topologically numbered DAG too)
+  }
   HIP_TRY(keys.alloc(ne));
   HIP_TRY(sorted.alloc(ne));
+  HIP_TRY(vals.alloc(ne));
+  HIP_TRY(vals_sorted.alloc(ne));
   HIP_TRY(cnt.alloc(nv1));
   HIP_TRY(hipMemset(cnt.p, 0, sizeof(int) * nv1));
   const long long blocks = std::min<long long>(((long long)ne + 255) / 256, (long long)g->cu_count * 32);
-  hipLaunchKernelGGL(task_keys_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, g->nv, g->ne, g->d_rp, g->d_col, keys.p, cnt.p, kTctStageMax);
+  hipLaunchKernelGGL(task_keys_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, g->nv, g->ne, g->d_rp, g->d_col, keys.p, vals.p, cnt.p, kTctStageMax, topo ? 1 : 0);
   int bits = 1;
   while (bits < 32 && (1ll << bits) < (long long)g->nv) ++bits;
   size_t bytes = 0;
   const int end_bit = g->max_deg > kTctStageMax ? 64 : 32 + bits;  // (the all-ones keys of excluded edges need every bit)
-  HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, keys.p, sorted.p, (int)ne, 0, end_bit));
+  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, keys.p, sorted.p, vals.p, vals_sorted.p, (int)ne, 0, end_bit));
   HIP_TRY(tmp.reserve(bytes));
-  HIP_TRY(hipcub::DeviceRadixSort::SortKeys(tmp.buf.p, bytes, keys.p, sorted.p, (int)ne, 0, end_bit));
+  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.buf.p, bytes, keys.p, sorted.p, vals.p, vals_sorted.p, (int)ne, 0, end_bit));
   int *trp = nullptr;
   int2 *td = nullptr;
   HIP_TRY(hipMalloc(&trp, sizeof(int) * nv1));
   hipError_t e = dev_exclusive_sum(tmp, cnt.p, trp, nv1);
   if (e == hipSuccess) e = hipMalloc(&td, sizeof(int2) * ne);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(task_desc_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, g->ne, g->d_rp, sorted.p, td);
+    hipLaunchKernelGGL(task_desc_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, g->ne, g->d_rp, g->d_col, sorted.p, vals_sorted.p, td);
     e = hipDeviceSynchronize();
   }
   if (e != hipSuccess) { (void)hipFree(trp); if (td) (void)hipFree(td); return hip_fail(e, "task lists", __FILE__, __LINE__); }
@@ -966,6 +992,7 @@ int get_clique_plan(gm_graph *g, int rank, int world, int policy, int target, un
     if (rc) return rc;
   }
   SetupTimer timer;
+  PoolScope pool(g);  // (the task keys of the share)
   ScanTemp tmp;
   auto blocks = [](long long n) { return dim3((unsigned)std::max<long long>(1, (n + 255) / 256)); };
   if (!g->wide_valid) {  // once per graph: the wide vertices, longest rows first (select + stable radix sort by row length)

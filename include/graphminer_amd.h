@@ -34,7 +34,9 @@ typedef enum gm_status {
   GM_ERR_INVALID = 1,      /* bad argument (null pointer, k out of range, ...) */
   GM_ERR_NO_DEVICE = 2,    /* no HIP device / HIP runtime error before launch */
   GM_ERR_HIP = 3,          /* HIP runtime error (see gm_last_error) */
-  GM_ERR_TOO_LARGE = 4,    /* ne >= 2^31 or nv >= 2^31-1: outside this build's 32-bit task index */
+  GM_ERR_TOO_LARGE = 4,    /* outside the 32-bit task index of the mining kernels: a solver asked to walk a graph of >= 2^31 entries
+                              itself (such a graph CAN be uploaded, oriented, downloaded and 3-motif-counted), nv >= 2^31-1, or an
+                              oriented graph of >= 2^31 entries */
   GM_ERR_UNSUPPORTED = 5,  /* pattern / k not implemented ("Not implemented", src/sgl/omp_base.cc:51) */
   GM_ERR_IO = 6,           /* file could not be opened / short read (custom_alloc.h:38-41) */
   GM_ERR_FORMAT = 7        /* meta.txt violates the loader asserts (src/common/graph.cc:30-34) */
@@ -60,7 +62,10 @@ typedef struct gm_graph gm_graph;
 
 int gm_device_count(int *n);
 
-/* GraphGPU::init (include/graph_gpu.h:69-122): H->D copy of row_ptr / col_idx on `device`. */
+/* GraphGPU::init (include/graph_gpu.h:69-122): H->D copy of row_ptr / col_idx on `device`.
+ * ne >= 2^31 (twitter40, friendster: src/triangle/README.md:60-61; eidType is int64, include/common.h:37) gives a BIG handle: it keeps
+ * 64-bit offsets and supports gm_graph_orient (the oriented graph must have < 2^31 entries: then gm_tc / gm_clique run on it),
+ * gm_motif(k = 3) / gm_motif_formula (the formula solver), gm_graph_meta / _download / _free; every other solver -> GM_ERR_TOO_LARGE. */
 int gm_graph_upload(const gm_csr *host, int device, gm_graph **out);
 /* Adopt CSR arrays that already live in HBM (e.g. built on the GPU); the arrays are BORROWED
  * and must outlive the handle. d_row_ptr is int64[nv+1], d_col_idx int32[ne]. */

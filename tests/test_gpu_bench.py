@@ -146,7 +146,7 @@ def test_own_algorithm_bytes_equal_a_brute_force_count():
     import bench
     from graphminer_amd.rmat import rmat_csr_device
 
-    sym, rp, ci = rmat_csr_device(11, 48, 3, 0)  # dense enough for DAG rows beyond 256 entries and symmetric rows beyond 128
+    sym, rp, ci = rmat_csr_device(11, 128, 3, 0)  # dense enough for long DAG rows (the library renumbers it) and symmetric rows beyond 128
     bg = bench.BenchGraph(sym, rp, ci, "t", 0.0)
     h = sym.download()
     hrp, hci = h.row_ptr, h.col_idx
@@ -173,14 +173,16 @@ def test_own_algorithm_bytes_equal_a_brute_force_count():
     kt = kc = tasks = 0
     rank = np.empty(nv, dtype=np.int64)  # the library's topological numbering of the DAG: ids ascending in (symmetric degree, id)
     rank[np.lexsort((np.arange(nv), deg))] = np.arange(nv)
+    trim = float((dp.astype(np.float64) ** 2).sum()) / dci.size >= bench.TOPO_MIN_MEAN_ROW  # (topo_view: renumbered and trimmed only where rows are long)
+    assert trim, "the graph must be one the library renumbers"
     for u in range(nv):
         row = dci[drp[u]:drp[u + 1]]
         for i, v in enumerate(row[np.argsort(rank[row])]):
-            kt += min(dp[u], dp[v])  # (no row beyond 2048 entries here)
+            kt += dp[v] if dp[u] >= dp[v] else dp[u] - i - 1  # (no row beyond 2048 entries here)
             if bench.CB_MIN_DEG <= dp[u] <= bench.CB_MAX_DEG:
                 tasks += 1
                 kc += dp[u] - i - 1 if dp[v] > dp[u] and dp[v] <= bench.CB_MAX_DEG else dp[v]
-    assert dp.max() > 256, "the graph must have wide DAG rows for this check to mean something"
+    assert dp.max() > 64 and tasks > 0 and kt < int(np.minimum(dp[np.repeat(np.arange(nv), dp)], dp[dci]).sum()), "the graph must have long DAG rows for this check to mean something"
     nd = dci.size
     assert bench.own_bytes_device("tc", bg)["bytes"] == 4 * int(kt) + 12 * nd + 8 * (nv + 1)
     own = dp[(dp >= bench.CB_MIN_DEG) & (dp <= bench.CB_MAX_DEG)].astype(np.int64)

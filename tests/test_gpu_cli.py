@@ -2,6 +2,7 @@
 final result lines must be byte-identical to the reference mains."""
 import os
 import subprocess
+import sys
 
 import pytest
 
@@ -65,18 +66,31 @@ def test_cli_unsorted_neighbor_lists(tmp_path):
     assert out[-1] == f"total_num_triangles = {GOLDEN['citeseer']['tc']}"
 
 
-def test_clique_k5_beyond_the_row_limit_fails_loudly(tmp_path):
-    """a DAG row beyond the k >= 5 limit must not print `num_5-cliques = 0` with exit code 0"""
+def test_clique_k5_on_a_row_beyond_4096_and_loud_failures(tmp_path):
+    """round 2 refused k >= 5 on DAG rows beyond 4096 entries (and round 1 printed `num_5-cliques = 0` with exit code 0, ADVICE r1);
+    now such a row is counted (cliquek_count_sub_any) -- the reference's kernels have no width limit. What still fails (k out of
+    range) prints the reference's "Not implemented yet" and no result line (src/clique/cpu_kernels/automine_omp.h:179-182: exit(0))."""
     import numpy as np
 
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle as O
     from graphminer_amd.rmat import csr_from_pairs
 
     W = 4200
-    s = np.concatenate([np.zeros(W, dtype=np.uint64), np.repeat(np.arange(1, W + 1, dtype=np.uint64), W - 1)])
-    d = np.concatenate([np.arange(1, W + 1, dtype=np.uint64), np.arange(W + 1, W + 1 + W * (W - 1), dtype=np.uint64)])
-    csr_from_pairs(int(W + 1 + W * (W - 1)), s, d).save(str(tmp_path / "graph"))
-    r = subprocess.run([os.path.join(BIN, "clique_gpu_base"), str(tmp_path / "graph"), "5"], capture_output=True, text=True, timeout=300)
-    assert r.returncode != 0 and "num_5-cliques" not in r.stdout and "4096" in r.stderr
+    rng = np.random.default_rng(3)
+    a, b = np.triu_indices(W, 1)
+    keep = rng.random(a.size) < 0.03
+    s = np.concatenate([np.zeros(W, dtype=np.uint64), np.repeat(np.arange(1, W + 1, dtype=np.uint64), W - 1), (a[keep] + 1).astype(np.uint64)])
+    d = np.concatenate([np.arange(1, W + 1, dtype=np.uint64), np.arange(W + 1, W + 1 + W * (W - 1), dtype=np.uint64), (b[keep] + 1).astype(np.uint64)])
+    g = csr_from_pairs(int(W + 1 + W * (W - 1)), s, d)
+    g.save(str(tmp_path / "graph"))
+    want = O.clique(O.orient(O.OGraph(g.row_ptr, g.col_idx)), 5)
+    assert want > 0
+    r = subprocess.run([os.path.join(BIN, "clique_gpu_base"), str(tmp_path / "graph"), "5"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-500:]
+    assert r.stdout.strip().splitlines()[-1] == f"num_5-cliques = {want}"
+    r = subprocess.run([os.path.join(BIN, "clique_gpu_base"), str(tmp_path / "graph"), "9"], capture_output=True, text=True, timeout=300)
+    assert "Not implemented yet" in r.stdout and "num_9-cliques" not in r.stdout
 
 
 def test_cli_usage_exits_1():

@@ -92,6 +92,41 @@ def test_motif3_rmat22_equals_oracle(rmat_dev):
     assert [sum(p[i] for p in parts) % 2**64 for i in range(2)] == want
 
 
+@pytest.mark.timeout(1500)
+def test_graph_of_more_than_2e31_entries():
+    """the reference's offsets are int64 (include/common.h:37) and its README tables run twitter40 (2.4 G entries) and
+    friendster (3.6 G). R-MAT-26 ef 20 has ~2.6 G symmetric entries (11 GB of CSR): it uploads as a BIG handle, orients into a DAG of
+    < 2^31 entries, and TC = 3-clique = the triangles of the 3-motif solver, wedges = sum C(d,2) - 3T."""
+    import torch
+
+    from graphminer_amd import _lib
+    from graphminer_amd.rmat import rmat_csr_device
+
+    free_b, _total = torch.cuda.mem_get_info(0)
+    if free_b < 150 << 30:
+        pytest.skip("needs ~150 GB of free device memory for the generator's sort")
+    try:
+        sym, rp, ci = rmat_csr_device(26, 20, 42, 0)
+    except RuntimeError as e:  # torch.unique on 2.7e9 keys is outside what some torch builds sort
+        pytest.skip(f"generator failed at this size: {str(e)[:120]}")
+    assert sym.E() > 2**31 and sym.V() == 2**26
+    t = time.perf_counter()
+    dag = sym.orient()
+    assert dag.E() * 2 == sym.E() and dag.E() < 2**31
+    tc = TCSolver(dag)
+    assert CliqueSolver(dag, 3) == tc > 0
+    wedges, tri = MotifSolver(sym, 3)
+    deg = rp[1:] - rp[:-1]
+    c2 = int((deg * (deg - 1) // 2).sum().item())
+    assert tri == tc and wedges == c2 - 3 * tc
+    with pytest.raises(_lib.GraphMinerError) as ei:
+        SglSolver(sym, "diamond")
+    assert ei.value.status == _lib.GM_ERR_TOO_LARGE
+    print(f"R-MAT-26 ef 20: {sym.E()} entries, DAG {dag.E()}, {tc} triangles, orient + TC + 3-clique + 3-motif in {time.perf_counter() - t:.1f} s")
+    dag.free()
+    sym.free()
+
+
 @pytest.mark.parametrize("name", sorted(GOLDEN["_readme_known_answers"]))
 def test_readme_known_answers_on_real_datasets(name):
     """golden.json::_readme_known_answers (the README tables: src/triangle/README.md:52-62, src/sgl/README.md:52-62,

@@ -344,17 +344,22 @@ def test_deeper_cliques_on_a_row_wider_than_2048(dev):
         assert CliqueSolver(dg, k) == want
         if k > 4:
             assert CliqueSolver(dg, k, tune=[0, 0, 0, 0, 0, 0, 0x200000]) == want  # any-width pair count instead of the tile walk
-    # and the limit itself: a row of more than 4096 entries is refused with a status, not counted wrong
+    # beyond 4096 entries (round 2 refused k >= 5 there; the reference's kernels have no width limit, clique5_warp_edge.cuh:3-39): the
+    # same construction with a row of 4200 entries -- everything from the workgroup's global scratch (cliquek_count_sub_any)
     W2 = 4200
-    s2 = np.concatenate([np.zeros(W2, dtype=np.uint64), np.repeat(np.arange(1, W2 + 1, dtype=np.uint64), W2 - 1)])
-    d2 = np.concatenate([np.arange(1, W2 + 1, dtype=np.uint64), np.arange(W2 + 1, W2 + 1 + W2 * (W2 - 1), dtype=np.uint64)])
+    a2, b2 = np.triu_indices(W2, 1)
+    keep2 = rng.random(a2.size) < 0.04
+    s2 = np.concatenate([np.zeros(W2, dtype=np.uint64), np.repeat(np.arange(1, W2 + 1, dtype=np.uint64), W2 - 1), (a2[keep2] + 1).astype(np.uint64)])
+    d2 = np.concatenate([np.arange(1, W2 + 1, dtype=np.uint64), np.arange(W2 + 1, W2 + 1 + W2 * (W2 - 1), dtype=np.uint64), (b2[keep2] + 1).astype(np.uint64)])
     g2 = csr_from_pairs(int(W2 + 1 + W2 * (W2 - 1)), s2, d2)
+    odag2 = O.orient(O.OGraph(g2.row_ptr, g2.col_idx))
     d2g = g2.to_device(dev).orient()
-    assert d2g.get_max_degree() == W2
-    assert CliqueSolver(d2g, 4) == 0
-    with pytest.raises(_lib.GraphMinerError) as ei:
-        CliqueSolver(d2g, 5)
-    assert ei.value.status == _lib.GM_ERR_TOO_LARGE
+    assert d2g.get_max_degree() == W2 == int(np.diff(odag2.row_ptr).max())
+    for k in (4, 5, 6):
+        want = O.clique(odag2, k)
+        assert want > 0
+        assert CliqueSolver(d2g, k) == want, k
+    assert sum(CliqueSolver(d2g, 5, rank=r, world=3) for r in range(3)) == O.clique(odag2, 5)
 
 
 def test_deeper_cliques_sub_matrix_path_rmat14(dev):
@@ -404,6 +409,57 @@ def test_clique4_wide_vertices_two_phases(dev, n, p):
         assert sum(CliqueSolver(d, 4, rank=r, world=2, policy=1) for r in range(2)) == got
     finally:
         del os.environ["GM_WIDE_ARENA_MB"]
+
+
+@pytest.mark.parametrize("name", ["citeseer", "rmat12_ef8_s7", "rmat14_ef16_s42"])
+def test_big_handle_paths_on_small_graphs(dev, name, monkeypatch):
+    """A graph of >= 2^31 entries gets a BIG handle (64-bit offsets: upload, orientation, download, the formula 3-motif; every solver
+    that walks the graph itself refuses it). GM_BIG_NE=1 forces that handle for a small graph: the 64-bit orientation kernels must
+    produce the DAG of the 32-bit ones bit for bit, and the counts the goldens."""
+    g = load_graph(name)
+    ref = g.to_device(dev)
+    ref_dag = ref.orient().download()
+    monkeypatch.setenv("GM_BIG_NE", "1")
+    big = g.to_device(dev)
+    monkeypatch.delenv("GM_BIG_NE")
+    back = big.download()
+    assert np.array_equal(back.row_ptr, g.row_ptr) and np.array_equal(back.col_idx, g.col_idx)
+    dag = big.orient()
+    got = dag.download()
+    assert np.array_equal(got.row_ptr, ref_dag.row_ptr) and np.array_equal(got.col_idx, ref_dag.col_idx)
+    e = GOLDEN[name]
+    assert TCSolver(dag) == e["tc"] and CliqueSolver(dag, 4) == e["clique4"]
+    assert MotifSolver(big, 3) == e["motif3"] == MotifSolver(big, 3, formula=True)
+    for bad in (lambda: SglSolver(big, "diamond"), lambda: MotifSolver(big, 4), lambda: TCSolver(big), lambda: SglSolver(big, "rectangle")):
+        with pytest.raises(_lib.GraphMinerError) as ei:
+            bad()
+        assert ei.value.status == _lib.GM_ERR_TOO_LARGE
+    for h in (dag, big, ref):
+        h.free()
+
+
+@pytest.mark.parametrize("name", GRAPH_NAMES)
+def test_dag_patterns_on_the_topological_view(dev, name, monkeypatch):
+    """TC / k-clique / the formula 3-motif on the topologically renumbered copy of the DAG (get_relabeled mode 2: trimmed in-edge tasks,
+    upper-triangular matrices). The library takes that view only where rows are long (sum d+^2 / |E+| >= 64: none of the small golden
+    graphs); GM_TOPO_MIN_ROW=0 forces it. The counts are the goldens; tune[6] & 0x200 runs on the graph as numbered."""
+    monkeypatch.setenv("GM_TOPO_MIN_ROW", "0")
+    g = load_graph(name)
+    sym = g.to_device(dev)
+    dag = sym.orient()
+    e = GOLDEN[name]
+    assert TCSolver(dag) == e["tc"]
+    assert CliqueSolver(dag, 3) == e["tc"]
+    assert CliqueSolver(dag, 4) == e["clique4"]
+    assert MotifSolver(sym, 3, formula=True) == e["motif3"]
+    assert sum(CliqueSolver(dag, 4, rank=r, world=3) for r in range(3)) == e["clique4"]
+    assert sum(TCSolver(dag, rank=r, world=4, policy=1) for r in range(4)) == e["tc"]
+    assert TCSolver(dag, tune=[0, 0, 0, 0, 0, 0, 0x200]) == e["tc"] and CliqueSolver(dag, 4, tune=[0, 0, 0, 0, 0, 0, 0x200]) == e["clique4"]
+    if "motif4" in e:
+        assert MotifSolver(sym, 4) == e["motif4"]
+    # the renumbered copy itself: a permutation of the same graph, topological, rows ascending
+    dag.free()
+    sym.free()
 
 
 def _planted_dag(seed, perm):
