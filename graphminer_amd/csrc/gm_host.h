@@ -220,6 +220,7 @@ struct gm_graph {
   gm_graph *dag_cache = nullptr;          // oriented copy, built on demand by gm_motif_formula
   gm_graph *relabel_cache[3] = {nullptr, nullptr, nullptr};  // renumbered copies: by degree ascending / descending, topological (get_relabeled)
   int topo_state = 0;                // 0 unknown, 1 every edge goes to a larger id, 2 not (graph_is_topological)
+  unsigned long long giant_edges = ~0ull;  // sum of the rows beyond kStageCapBig entries (~0: not computed yet)
   double mean_sq_deg = -1.0;         // sum_v d(v)^2 / ne: the mean length of the row an entry sits in (-1: not computed yet; topo_view)
   bool topo_relabel_failed = false;  // the (degree, id) numbering is not topological for this DAG: it runs as given
   const gm_graph *ring_alias = nullptr;

@@ -28,6 +28,42 @@ __global__ void finalize_kernel(int mode, unsigned long long base, const unsigne
   }
 }
 
+// a big handle (ne >= 2^31, 64-bit offsets): the mining kernels index the graph they walk with 32 bits
+static int reject_big(const gm_graph *g) {
+  if (!g || !g->d_rp64) return GM_OK;
+  g_last_error = "this solver walks the graph it is given with a 32-bit task index; " + std::to_string(g->ne) +
+                 " entries: orient it (gm_graph_orient) for TC / k-clique, gm_motif k = 3 counts through the formula solver";
+  return GM_ERR_TOO_LARGE;
+}
+
+// sum of the lengths of the rows beyond kStageCapBig entries (the task edges of the giant-row kernel), once per graph
+__global__ __launch_bounds__(256) void giant_edges_kernel(int nv, const int *__restrict__ rp, unsigned long long *__restrict__ out) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  unsigned long long s = 0;
+  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += stride) {
+    const int d = rp[v + 1] - rp[v];
+    if (d > kStageCapBig) s += (unsigned long long)d;
+  }
+  s = gm::wave_sum_u64(s);
+  if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
+}
+static int giant_task_edges(gm_graph *g, unsigned long long *out) {
+  if (g->giant_edges == ~0ull) {
+    HIP_TRY(hipSetDevice(g->device));
+    unsigned long long *d_s = nullptr, s = 0;
+    HIP_TRY(hipMalloc(&d_s, 8));
+    hipError_t e = hipMemset(d_s, 0, 8);
+    if (e == hipSuccess && g->nv > 0)
+      hipLaunchKernelGGL(giant_edges_kernel, dim3((unsigned)std::min<long long>(((long long)g->nv + 255) / 256, 2048)), dim3(256), 0, 0, g->nv, g->d_rp, d_s);
+    if (e == hipSuccess) e = hipMemcpy(&s, d_s, 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d_s);
+    if (e != hipSuccess) return hip_fail(e, "giant_edges_kernel", __FILE__, __LINE__);
+    g->giant_edges = s;
+  }
+  *out = g->giant_edges;
+  return GM_OK;
+}
+
 // ---- common launch prologue / epilogue of every mining entry point -----------------------------------------------
 struct LaunchCtx {
   gm_graph *g = nullptr;
@@ -40,11 +76,7 @@ struct LaunchCtx {
 // validates the arguments, selects the device, zeroes the 64-byte counter block on the launch stream
 static int begin_launch(const gm_graph *cg, const gm_launch *la, const uint64_t *h_out, LaunchCtx &c) {
   if (!cg) return GM_ERR_INVALID;
-  if (cg->d_rp64) {  // a big handle (ne >= 2^31): the mining kernels index a graph with 32 bits
-    g_last_error = "this solver walks the graph it is given with a 32-bit task index; " + std::to_string(cg->ne) +
-                   " entries: orient it (gm_graph_orient) for TC / k-clique, gm_motif k = 3 counts through the formula solver";
-    return GM_ERR_TOO_LARGE;
-  }
+  if (int rc = reject_big(cg)) return rc;
   c.g = const_cast<gm_graph *>(cg);
   memset(&c.la, 0, sizeof c.la);
   if (la) c.la = *la;
@@ -124,8 +156,12 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
   // tune[4] = blocks per CU override, tune[5] = force "search in HBM" (no LDS staging) when 1
   // default chunk size: as large as the LDS stage allows (fewer dequeues, better staging reuse) while every rank still
   // gets >= ~2 chunks per resident workgroup for the dynamic dequeue to balance (matters for strong scaling at N = 8)
+  // (round 3: 4 chunks per resident workgroup for a rank of a larger job -- with ~2 the heaviest-first dequeue of a 1/8 share of the
+  // LiveJournal stand-in ended 50 % above its mean, TC 1.01 ms per rank against 0.66 ideal; one rank keeps the round-2 rule)
   int target = kDefaultChunk;
-  while (target > 128 && g->ne / ((long long)world * target) < 2LL * g->cu_count * 7) target >>= 1;
+  long long min_chunks = (world > 1 ? 4LL : 2LL) * g->cu_count * 7;
+  if (const char *e = getenv("GM_MIN_CHUNKS_PER_CU")) min_chunks = (long long)std::max(1, atoi(e)) * g->cu_count;  // (sweeps)
+  while (target > 128 && g->ne / ((long long)world * target) < min_chunks) target >>= 1;
   if (la->chunk > 0) target = la->chunk;
   if (la->tune[0] > 0) target = la->tune[0];
   target = std::max(64, std::min(target, kStageCap));
@@ -143,8 +179,10 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
   const int tct_stage = g->max_deg <= kStageCap ? kStageCap : kTctStageMax;
   // (rows beyond the 2048-entry stage host nothing: their out-edges are the tasks of the chunked kernel, on a table of those rows only)
   const bool tct_long = use_tct && g->max_deg > kTctStageMax;
+  unsigned long long tct_part = std::max<unsigned long long>((1ull << 20) / (unsigned long long)world, 128ull << 10);
+  if (const char *e = getenv("GM_TCT_PART_KKEYS")) tct_part = (unsigned long long)std::max(4, atoi(e)) << 10;  // (sweeps)
   const unsigned long long part_cap = (la->tune[6] & 0x1000) ? 4096ull : (stage_cap_of(pat) != kStageCapWide
-       ? (use_tct ? std::max<unsigned long long>((1ull << 20) / (unsigned long long)world, 128ull << 10) : kPartCostCap)
+       ? (use_tct ? tct_part : kPartCostCap)
        // a rank's share is 1/world of the launch: so is the tolerable tail (3-motif's bounded lists make its estimates
        // pessimistic already: measured, 1/8 share 84.8 ms unscaled vs 91.2 ms scaled; diamond 5.2 vs 4.2 ms)
        : (pat == PAT_MOTIF3 ? kPartCostCapSym : std::max<unsigned long long>(kPartCostCapSym / (unsigned long long)world, 256ull << 10)));
@@ -207,15 +245,30 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
     unsigned long long cls_cap = (la->tune[6] & 0x1000) ? 4096ull
                                  : std::max<unsigned long long>(part_cap, std::max<unsigned long long>((32ull << 20) / (unsigned long long)std::max(world, 1), 2ull << 20));
     if (const char *e = getenv("GM_CLS_CAP_MKEYS")) cls_cap = (unsigned long long)std::max(1, atoi(e)) << 20;  // (sweeps)
+    if (const char *e = getenv("GM_CLS_CAP_KKEYS")) cls_cap = (unsigned long long)std::max(16, atoi(e)) << 10;
     // (target 1: every row is a chunk of its own -- the class kernels take one-row chunks -- also below the general kernel's chunk target)
     rc = get_table(g, 1, false, 0, cls_cap, kStageCapMid, &tab_cls[1], r1, 0x7fffffff);
     if (rc) return rc;
     rc = get_table(g, 1, false, 0, cls_cap, kStageCapBig, &tab_cls[2], r2, 0x7fffffff);
     if (rc) return rc;
-    if (use_range) {  // pieces of kGiantEdges task edges, never cut into parts (part_cap 0: giant_kernel ignores part / nparts)
+    if (use_range) {  // pieces of <= kGiantEdges task edges, never cut into parts (part_cap 0: giant_kernel ignores part / nparts)
       RowFilter r3;
       r3.only_lo = kStageCapBig;
-      rc = get_table(g, kGiantEdges, true, 0, 0ull, kStageCapBig, &tab_cls[3], r3, 0x7fffffff);
+      // A chunk is the unit of the dequeue and costs its whole row's set builds (~20 us per piece of 24576 entries): as large as
+      // kGiantEdges where there are many, smaller where the giant rows of the graph (or of a rank's share) would otherwise be a
+      // handful of chunks -- the LiveJournal stand-in has ~40 chunks of 8192 edges, 3.9 ms each: the whole launch of a 1/8 share
+      // waited for ONE of them (1.9 ms ideal). Aim at 4 chunks per resident workgroup and rank.
+      int gtarget = kGiantEdges;
+      {
+        unsigned long long ge = 0;
+        rc = giant_task_edges(g, &ge);
+        if (rc) return rc;
+        const unsigned long long per = ge / ((unsigned long long)g->cu_count * (unsigned long long)giant_per_cu() * 4ull * (unsigned long long)world);
+        gtarget = (int)std::max<unsigned long long>(512, std::min<unsigned long long>((unsigned long long)kGiantEdges, per));
+        gtarget = (gtarget + 63) & ~63;
+        if (const char *e = getenv("GM_GIANT_TARGET")) gtarget = std::max(64, std::min(atoi(e), kGiantEdges));  // (sweeps)
+      }
+      rc = get_table(g, gtarget, true, 0, 0ull, kStageCapBig, &tab_cls[3], r3, 0x7fffffff);
       if (rc) return rc;
     }
   }
@@ -621,6 +674,7 @@ constexpr double kTopoMinMeanRow = 64.0;
 static int topo_view(const gm_graph *dag, const gm_launch *la, gm_graph **run_on) {
   gm_graph *self = const_cast<gm_graph *>(dag);
   if (!self) return GM_ERR_INVALID;
+  if (int rc = reject_big(self)) return rc;
   *run_on = self;
   if (la && (la->tune[6] & 0x200)) return GM_OK;
   bool topo = false;
@@ -1048,6 +1102,7 @@ extern "C" int gm_sgl(const gm_graph *sym, const char *pattern, const gm_launch 
   const bool is_rect = strcmp(pattern, "rectangle") == 0, is_house = strcmp(pattern, "house") == 0, is_pent = strcmp(pattern, "pentagon") == 0;
   if (is_rect || is_house || is_pent) {
     if (!sym) return GM_ERR_INVALID;
+    if (int rc0 = reject_big(sym)) return rc0;
     const int t6 = la ? la->tune[6] : 0;
     gm_graph *self = const_cast<gm_graph *>(sym);
     const gm_graph *run_on = sym;
@@ -1107,6 +1162,7 @@ extern "C" int gm_clique(const gm_graph *dag, int k, const gm_launch *la, uint64
 // too -- this is what feeds the RCCL all-reduce of motif_multigpu.
 extern "C" int gm_motif4_partial(const gm_graph *sym, const gm_launch *la, uint64_t raw[6], gm_stats *st) {
   if (!sym || (!raw && !(la && la->d_counts))) return GM_ERR_INVALID;
+  if (int rc0 = reject_big(sym)) return rc0;
   gm_graph *g = const_cast<gm_graph *>(sym);
   gm_launch l2;
   memset(&l2, 0, sizeof l2);

@@ -74,13 +74,16 @@ void tct_kernel(const MineParams p) {
       __syncthreads();
       // ---- waves: batches of 64 tasks ---------------------------------------------------------------------------------
       const int tb = B.trpl[0], ntask = B.trpl[nvl] - tb;
+      // (smaller batches for parts with few tasks -- what gm_cbuild.hip does for the thin task lists of a rank's share -- were measured
+      // here and lose: R-MAT-22 5.29 -> 5.51 ms on one GPU, 0.97 -> 0.97 ms per rank of eight; profiles/r03/ab_share_scaling.txt)
+      constexpr int bsz = GM_WAVE;
       for (;;) {
         int bi = 0;
         if (lane == 0) bi = atomicAdd(&B.next_batch, 1);
         bi = readfirst(bi) * r.nparts + r.part;
-        const int t0 = bi * GM_WAVE;
+        const int t0 = bi * bsz;
         if (t0 >= ntask) break;
-        const bool valid = t0 + lane < ntask;
+        const bool valid = lane < bsz && t0 + lane < ntask;
         const int te = tb + min(t0 + lane, ntask - 1);
         const int2 d = tdesc[te];                 // {rp[partner], d+(partner)}: the list to stream, coalesced
         const int lo = local_row(B.trpl, nvl, te);  // the host row of this task

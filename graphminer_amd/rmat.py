@@ -86,9 +86,29 @@ def rmat_csr_device(scale: int, edge_factor: int, seed: int = 42, device: int = 
         stream = torch.cuda.current_stream().cuda_stream
         _lib.check(lib.gm_rmat_keys(scale, n, C.c_uint64(seed), keys.data_ptr(), stream), "gm_rmat_keys")
         # sort as UNSIGNED 64-bit: sentinel 0xFFFF.. (self-loop) is -1 as int64 and sorts first; keys are < 2^62
-        keys = torch.unique(keys)  # sorted ascending (signed): [-1?, k0, k1, ...]
-        if keys.numel() and int(keys[0].item()) == -1:
-            keys = keys[1:]
+        if keys.numel() < (1 << 31):
+            keys = torch.unique(keys)  # sorted ascending (signed): [-1?, k0, k1, ...]
+            if keys.numel() and int(keys[0].item()) == -1:
+                keys = keys[1:]
+        else:
+            # more keys than the device sort takes in one call (2^31 items): sort / dedupe the eight ranges of the three leading
+            # source bits one after the other (R-MAT puts at most 0.76^3 = 44 % of the keys into one of them) and concatenate
+            sh = 32 + max(scale - 3, 0)
+            step = 1 << 30  # (boolean indexing of more than 2^31 elements overflows inside torch as well: slice first)
+            buckets = [[] for _ in range(8)]
+            for lo in range(0, keys.numel(), step):
+                sl = keys[lo:lo + step]
+                top = sl >> sh
+                for b in range(8):
+                    buckets[b].append(sl[(sl >= 0) & (top == b)])
+                del sl, top
+            del keys
+            parts = []
+            for b in range(8):
+                parts.append(torch.unique(torch.cat(buckets[b])))
+                buckets[b] = None
+            keys = torch.cat(parts)
+            del parts, buckets
         src = keys >> 32
         col = (keys & 0xFFFFFFFF).to(torch.int32).contiguous()
         deg = torch.bincount(src, minlength=nv)
