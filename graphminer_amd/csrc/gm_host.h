@@ -305,6 +305,19 @@ struct OtherSetupScope {
   }
 };
 
+// module warm-up: one no-op kernel per translation unit (each is its own code object, loaded on first launch -- 20 ms for the unit
+// with the hipCUB instantiations: without this the first table build / first mining launch of a process pays for it)
+void gm_touch_mine();
+void gm_touch_mine_wide();
+void gm_touch_hrow();
+void gm_touch_tct();
+void gm_touch_cbuild();
+void gm_touch_wide();
+void gm_touch_sgl();
+void gm_touch_tables();
+void gm_touch_launch();
+void gm_touch_tools();
+
 // ---- across translation units ---------------------------------------------------------------------------------------------
 int finish_handle(gm_graph *g);                                 // gm_graph.hip: counters, events, CU count of a new handle
 int host_rp(gm_graph *g, const std::vector<int> **out);          // gm_graph.hip: host copy of the offsets, fetched on first use

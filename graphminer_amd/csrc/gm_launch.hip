@@ -1317,3 +1317,6 @@ extern "C" int gm_clique4_level2_bytes(const gm_graph *dag, uint64_t *bytes) {
   return GM_OK;
 }
 
+// (module warm-up, gm_graph.hip finish_handle: HIP loads the code object of a translation unit when one of its kernels is first launched)
+__global__ void gm_touch_launch_kernel() {}
+void gm_touch_launch() { hipLaunchKernelGGL(gm_touch_launch_kernel, dim3(1), dim3(1), 0, 0); }

@@ -32,3 +32,8 @@ hipError_t launch_mine_wide(Pattern pat, int cls, const MineParams &p, int grid_
 }
 
 }  // namespace gm
+
+// (module warm-up, gm_graph.hip finish_handle: HIP loads the code object of a translation unit when one of its kernels is first launched)
+__global__ void gm_touch_mine_wide_kernel() {}
+void gm_touch_mine_wide() { hipLaunchKernelGGL(gm_touch_mine_wide_kernel, dim3(1), dim3(1), 0, 0); }
+

@@ -115,3 +115,8 @@ hipError_t launch_tct(const MineParams &p, int stage, int grid_blocks, hipStream
 }
 
 }  // namespace gm
+
+// (module warm-up, gm_graph.hip finish_handle: HIP loads the code object of a translation unit when one of its kernels is first launched)
+__global__ void gm_touch_tct_kernel() {}
+void gm_touch_tct() { hipLaunchKernelGGL(gm_touch_tct_kernel, dim3(1), dim3(1), 0, 0); }
+

@@ -109,7 +109,7 @@ typedef struct gm_launch {
                          b*(xb+xs*lg a) <= a*(yb+ys*lg b), [4] workgroups per CU, [5] 1 = never stage adjacency in LDS,
                          [7] bits 0..7 xb*16+yb, bits 8.. price of a pass-Y key against a bitmapped row (0 = as a bisection).
                          [6] bit mask. Alternative implementations (same counts): 0x100 mining kernels ignore the hub bitmaps,
-                         0x200 SgL on the graph as numbered (no degree renumbering), 0x400 SgL wave-per-edge loop nests,
+                         0x200 SgL / TC / 4-clique on the graph as numbered (no degree / topological renumbering), 0x400 SgL wave-per-edge loop nests,
                          0x800 rectangle / pentagon as wedges + flat intersections, house flattened over (v0,v1,v3), 0x1000 cut
                          chunks into parts eagerly, 0x2000 swap the two dequeue orders, 0x4000 plain chunk-id order.
                          Ablation (mining kernels): 0x1 skip clique phase 2, 0x2 skip bit-matrix writes, 0x4 no filter,
@@ -171,10 +171,13 @@ int gm_tc(const gm_graph *dag, const gm_launch *launch, uint64_t *total, gm_stat
 int gm_sgl(const gm_graph *sym, const char *pattern, const gm_launch *launch, uint64_t *total, gm_stats *stats);
 
 /* CliqueSolver on the DAG, 3 <= k <= 8 (src/clique/cpu_kernels/automine_omp.h:67-83,138-157;
- * src/clique/gpu_kernels/clique4_warp_edge.cuh:3-31 ... clique8). k = 3, 4: any out-degree. k >= 5: the deeper levels run on
- * adjacency bit-matrices swept with two words per lane, which takes DAG rows of up to 4096 entries (the degree-ordered DAG of
- * com-Orkut has 535, of a scale-24 R-MAT graph 1744); a longer row -> GM_ERR_TOO_LARGE, *total = 0, gm_last_error names the
- * degree -- the count is refused, never wrong. */
+ * src/clique/gpu_kernels/clique4_warp_edge.cuh:3-31 ... clique8), any out-degree. k = 4: the first DFS level is re-hosted (every
+ * edge at the endpoint with the longer out-list, gm_cbuild.hip), rows of up to 2048 entries keep their adjacency bit-matrix in an
+ * arena in HBM, longer rows one per workgroup. k >= 5: the deeper levels run on induced sub-matrices; rows of up to 4096 entries sweep
+ * them with two words per lane, longer rows out of the workgroup's global scratch (slow, exact; the degree-ordered DAG of com-Orkut has
+ * rows of at most 535 entries, of a scale-24 R-MAT graph 1744). The workgroups' scratch slots must fit the device memory, else
+ * GM_ERR_TOO_LARGE -- a count is refused, never wrong. TC (k = 3) and k = 4 run on a topologically renumbered copy of a DAG whose
+ * rows are long (cached on the handle; tune[6] & 0x200: as numbered). */
 int gm_clique(const gm_graph *dag, int k, const gm_launch *launch, uint64_t *total, gm_stats *stats);
 
 /* MotifSolver on the SYMMETRIC graph. k = 3: counts[0] = wedges, counts[1] = triangles

@@ -101,12 +101,21 @@ def test_empty_and_ragged_host_graphs():
 
 
 def test_size_limits_are_reported_not_wrapped():
-    """maximum sizes: this build indexes tasks with int32; larger graphs must be refused, never truncated"""
+    """maximum sizes: the mining kernels index tasks with int32. A graph of 2^31 entries or more uploads as a BIG handle (64-bit
+    offsets: orientation, formula 3-motif, download -- tests/test_gpu_parity.py); beyond 2^40 entries or 2^31 - 2 vertices it is
+    refused, never truncated (without a device the upload of an acceptable size fails with NO_DEVICE instead)"""
+    import torch
+
     lib = _lib.load()
     dummy = np.zeros(4, dtype=np.int64)
     h = C.c_void_p()
-    big = _lib.gm_csr(10, 2**31, 5, dummy.ctypes.data, dummy.ctypes.data)
+    big = _lib.gm_csr(10, 2**40, 5, dummy.ctypes.data, dummy.ctypes.data)
     assert lib.gm_graph_upload(C.byref(big), 0, C.byref(h)) == _lib.GM_ERR_TOO_LARGE
+    many = _lib.gm_csr(2**31 - 2, 4, 5, dummy.ctypes.data, dummy.ctypes.data)
+    assert lib.gm_graph_upload(C.byref(many), 0, C.byref(h)) == _lib.GM_ERR_TOO_LARGE
+    if not torch.cuda.is_available():
+        ok = _lib.gm_csr(10, 2**31, 5, dummy.ctypes.data, dummy.ctypes.data)
+        assert lib.gm_graph_upload(C.byref(ok), 0, C.byref(h)) == _lib.GM_ERR_NO_DEVICE
     neg = _lib.gm_csr(-1, 0, 0, dummy.ctypes.data, dummy.ctypes.data)
     assert lib.gm_graph_upload(C.byref(neg), 0, C.byref(h)) == _lib.GM_ERR_INVALID
     assert lib.gm_strerror(_lib.GM_ERR_TOO_LARGE).startswith(b"graph exceeds")
