@@ -311,6 +311,7 @@ void gm_touch_mine();
 void gm_touch_mine_wide();
 void gm_touch_hrow();
 void gm_touch_tct();
+void gm_touch_tch();
 void gm_touch_cbuild();
 void gm_touch_wide();
 void gm_touch_sgl();

@@ -576,7 +576,10 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
       HIP_TRY(launch_mine(pat, q, (int)std::max<long long>(1, std::min<long long>(wq, (long long)g->cu_count * per_cu)), stream));
     }
   }
-  if (p.count > 0 && use_tct) HIP_TRY(launch_tct(p, tct_stage, (int)std::max<long long>(1, std::min<long long>(want, (long long)g->cu_count * tct_per_cu(tct_stage))), stream));
+  // (tune[6] & 0x8000000: A/B switch, the sorted LDS copy + bit filter + bisection of gm_tct.hip instead of the hashed set of gm_tch.hip)
+  const bool use_tch = use_tct && !(la->tune[6] & 0x8000000) && !getenv("GM_TC_SORTED");
+  if (p.count > 0 && use_tch) HIP_TRY(launch_tch(p, tct_stage, (int)std::max<long long>(1, std::min<long long>(want, (long long)g->cu_count * tch_per_cu(tct_stage))), stream));
+  else if (p.count > 0 && use_tct) HIP_TRY(launch_tct(p, tct_stage, (int)std::max<long long>(1, std::min<long long>(want, (long long)g->cu_count * tct_per_cu(tct_stage))), stream));
   else if (p.count > 0) HIP_TRY(launch_mine(pat, p, grid, stream));
 #ifdef GM_DEBUG_CHUNKS
   {

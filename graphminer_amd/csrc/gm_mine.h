@@ -349,6 +349,9 @@ hipError_t launch_mine(Pattern pat, const MineParams &p, int grid_blocks, hipStr
 constexpr int kTctStageMax = 2048;  // gm_tct.hip: the longest DAG row its stage takes
 hipError_t launch_tct(const MineParams &p, int stage, int grid_blocks, hipStream_t stream);
 int tct_per_cu(int stage);
+// ... the same tasks against the chunk rows as one hashed (row, id) set in LDS: gm_tch.hip (the default; tune[6] & 0x8000000: tct_kernel)
+hipError_t launch_tch(const MineParams &p, int stage, int grid_blocks, hipStream_t stream);
+int tch_per_cu(int stage);
 size_t mine_lds_bytes(Pattern pat);
 // the big-LDS classes (gm_mine_wide.hip): cls = 1 (mid rows) or 2 (big rows); DIAMOND, MOTIF3, MOTIF4E only
 hipError_t launch_mine_wide(Pattern pat, int cls, const MineParams &p, int grid_blocks, hipStream_t stream);

@@ -1,0 +1,375 @@
+// gm_tch.hip -- triangle counting, the shorter list streamed (gm_tct.hip) against the chunk's DAG rows kept in LDS as ONE HASHED SET of
+// (row, id) pairs instead of a sorted copy behind a bit filter.
+//
+// Why (profiles/r03/tc_rmat22_pmc_summary.txt, section 4.11 of DESIGN.md): tct_kernel issues 66 VALU instructions per 64 streamed
+// keys and keeps the SIMDs 0.65 - 1.1 busy.  22 % of the streamed keys of R-MAT-22 ARE common neighbours (30 % on the com-Orkut
+// stand-in), 27 % pass the bit filter -- and every one of them is written to the per-wave queue, read back and bisected against
+// the sorted LDS copy (8 - 11 dependent LDS reads).  A triangle count needs no position, only membership
+// (src/triangle/gpu_kernels/bs_warp_edge.cuh:9-15 counts the matches of a binary search), so the rows are stored as a set:
+//   * a bucket is four 32-bit slots (one 16-byte LDS line) holding full ids; there are as many buckets as stage entries;
+//   * bucket of (row r, id x) = top bits of x * C  XOR  salt(r), salt(r) = r * 37 mod #buckets: INJECTIVE in the local row (<= 256
+//     rows, >= 1024 buckets), so the same id staged for two rows of the chunk sits in two different buckets and a hit is exact --
+//     the slot needs no row tag;
+//   * lookup = one multiply, one ds_read_b128, four compares whose results stay lane masks in SGPRs, one s_bcnt1: no queue, no
+//     compaction, no bisection;
+//   * a bucket that got more than four entries (0.4 % of them at this load) carries a marker in its last slot; its surplus
+//     entries sit in a list of <= 128 (id, salt) pairs that only the lanes missing in such a bucket consult.  A chunk that overflows
+//     the list (adversarial ids) is looked up by bisection of the row in global memory -- slow, exact (tune[6] & 0x800000 forces it).
+// Chunk table, task lists, parts, dequeue order: those of tct_kernel (the kernel is chosen per launch, gm_launch.hip).
+#include "gm_flat.h"
+
+namespace gm {
+
+constexpr int kTchTiles = 4;  // 64-key tiles in flight per wave
+constexpr int kTchOvfCap = 128;
+constexpr unsigned kTchEmpty = 0xffffffffu, kTchMarker = 0xfffffffeu;  // (ids are < 2^31 - 1)
+constexpr unsigned kTchMul = 0x9E3779B1u;
+
+struct alignas(16) TchWave {
+  int2 desc[GM_WAVE];                // per batch lane: {key_base - offset among the flattened positions, salt of the host row}
+  unsigned char marks[kMarkWindow];  // owner marks of the flattened positions
+};
+
+template <int STAGE>
+struct alignas(16) TchLds {
+  uint4 table[STAGE];              // buckets of four ids
+  int rpl[kMaxChunkVerts + 1];     // row offsets of the chunk's DAG rows (global entry indices)
+  int trpl[kMaxChunkVerts + 1];    // row offsets of its task lists
+  TchWave w[kWavesPerBlock];       // (while the table is built: packed 16-bit fill counters of the buckets)
+  int ovf_key[kTchOvfCap];
+  int ovf_salt[kTchOvfCap];
+  int n_ovf;
+  int next_batch;
+  unsigned queue_pos;
+  int fallback;
+};
+static_assert(kTchOvfCap == 2 * GM_WAVE, "the surplus list is scanned two entries per lane");
+
+template <int STAGE>
+struct TchHash {
+  static constexpr int LB = STAGE == 1024 ? 10 : 11;
+  static_assert((1 << LB) == STAGE, "one bucket per stage entry");
+  static constexpr unsigned kMask = (unsigned)(STAGE - 1) << 4;
+  // byte offset of the bucket of (id x, row salt s)
+  static __device__ __forceinline__ unsigned bucket(int x, unsigned s) { return ((((unsigned)x * kTchMul) >> (28 - LB)) & kMask) ^ s; }
+  static __device__ __forceinline__ unsigned salt(int local_row) { return (((unsigned)local_row * 37u) & (unsigned)(STAGE - 1)) << 4; }
+  static __device__ __forceinline__ int row_of(unsigned s) { return (int)(((s >> 4) * 941u) & (unsigned)(STAGE - 1)); }  // 37 * 941 = 1 mod 2048
+};
+
+__device__ __forceinline__ int tch_local_row(const int *rpl, const int nvl, const int e) {  // largest i with rpl[i] <= e
+  int lo = 0, hi = nvl - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (rpl[mid] <= e) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+// Which of the T keys of this lane are in the row their salt names?  Lane masks throughout (see hrow_probe, gm_hrow.hip):
+// hm = lanes whose key was found, nm = lanes that missed in a bucket that overflowed.
+template <int STAGE, int T>
+__device__ __forceinline__ void tch_probe(const TchLds<STAGE> &B, const int *__restrict__ col, const bool fallback, const int (&key)[T],
+                                          const unsigned (&salt)[T], const unsigned long long (&inm)[T], unsigned long long (&hm)[T],
+                                          unsigned long long (&nm)[T]) {
+  if (fallback) {  // wave-uniform
+#pragma unroll
+    for (int q = 0; q < T; ++q) {
+      bool f = false;
+      if (__builtin_amdgcn_inverse_ballot_w64(inm[q])) {
+        const int lo = TchHash<STAGE>::row_of(salt[q]);
+        const int rs = B.rpl[lo], rn = B.rpl[lo + 1] - rs;
+        const int pos = lower_bound(col + rs, rn, key[q]);
+        f = pos < rn && col[rs + pos] == key[q];
+      }
+      hm[q] = __ballot(f);
+      nm[q] = 0ull;
+    }
+    return;
+  }
+  uint4 w[T];
+#pragma unroll
+  for (int q = 0; q < T; ++q)
+    w[q] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(B.table) + TchHash<STAGE>::bucket(key[q], salt[q]));
+#pragma unroll
+  for (int q = 0; q < T; ++q) {
+    const unsigned k = (unsigned)key[q];
+    const unsigned long long m = __ballot(w[q].x == k) | __ballot(w[q].y == k) | __ballot(w[q].z == k) | __ballot(w[q].w == k);
+    hm[q] = m & inm[q];
+    nm[q] = __ballot(w[q].w == kTchMarker) & ~m & inm[q];
+  }
+}
+
+// The surplus list (<= 128 (id, salt) pairs, unused entries -1) is spread over the lanes, two entries each; a key that needs it is
+// broadcast and compared by all lanes at once.  Returns the number of keys found.
+template <int STAGE, int T>
+__device__ __forceinline__ unsigned tch_surplus(const TchLds<STAGE> &B, const int lane, const int (&key)[T], const unsigned (&salt)[T],
+                                                const unsigned long long (&nm)[T]) {
+  const int k0 = B.ovf_key[lane], k1 = B.ovf_key[lane + GM_WAVE];
+  const int s0 = B.ovf_salt[lane], s1 = B.ovf_salt[lane + GM_WAVE];
+  unsigned c = 0;
+#pragma unroll
+  for (int q = 0; q < T; ++q) {
+    unsigned long long rest = nm[q];
+    while (rest) {
+      const int src = __ffsll((long long)rest) - 1;
+      rest &= rest - 1;
+      const int k = readlane(key[q], src), s = readlane((int)salt[q], src);
+      if (__ballot(((k0 == k) & (s0 == s)) | ((k1 == k) & (s1 == s))) != 0ull) ++c;
+    }
+  }
+  return c;
+}
+
+// One batch of tasks: stream the lists (llen_all keys from col[key_base ..), 0 = no task) against the set; returns the matches (wave-uniform).
+template <int STAGE>
+__device__ __forceinline__ unsigned tch_pass(TchLds<STAGE> &B, TchWave &L, const int *__restrict__ col, const bool fallback, const int lane,
+                                             const int llen_all, const int key_base, const unsigned salt_l) {
+  constexpr int T = kTchTiles;
+  unsigned cnt = 0;
+  if (wave_max_nonneg(llen_all) == 0) return 0u;  // wave-uniform
+  const bool is_long = llen_all >= kLongList;
+  const int llen = is_long ? 0 : llen_all;
+
+  // ---- long lists: one task at a time, wave-uniform base / salt; the keys of the NEXT tile group are requested before the current
+  // group is looked up (unconditional, unclamped loads in the steady state: flat_pass_filtered, gm_flat.h) -----------------------------
+  unsigned long long lm = __ballot(is_long);
+  while (lm) {
+    const int src = __ffsll((long long)lm) - 1;
+    lm &= lm - 1;
+    const int base = readlane(key_base, src);
+    const int n = readlane(llen_all, src);
+    const unsigned s_u = (unsigned)readlane((int)salt_l, src);
+    const int *__restrict__ kp = col + base;
+    auto process = [&](const int (&key)[T], const unsigned long long (&inm)[T]) {
+      unsigned salt[T];
+#pragma unroll
+      for (int q = 0; q < T; ++q) salt[q] = s_u;
+      unsigned long long hm[T], nm[T];
+      tch_probe<STAGE, T>(B, col, fallback, key, salt, inm, hm, nm);
+      unsigned long long any_need = 0ull;
+#pragma unroll
+      for (int q = 0; q < T; ++q) {
+        cnt += (unsigned)__popcll(hm[q]);
+        any_need |= nm[q];
+      }
+      if (any_need != 0ull) cnt += tch_surplus<STAGE, T>(B, lane, key, salt, nm);  // rare
+    };
+    constexpr int G = GM_WAVE * T;
+    int nxt[T];
+#pragma unroll
+    for (int q = 0; q < T; ++q) nxt[q] = kp[min(q * GM_WAVE + lane, n - 1)];
+    int t = 0;
+    for (; t + 2 * G <= n; t += G) {
+      int key[T];
+      unsigned long long inm[T];
+#pragma unroll
+      for (int q = 0; q < T; ++q) {
+        key[q] = nxt[q];
+        inm[q] = ~0ull;
+      }
+      const int *__restrict__ kn = kp + (t + G);
+#pragma unroll
+      for (int q = 0; q < T; ++q) nxt[q] = kn[(unsigned)(q * GM_WAVE + lane)];
+      process(key, inm);
+    }
+    for (; t < n; t += G) {
+      int key[T];
+      unsigned long long inm[T];
+#pragma unroll
+      for (int q = 0; q < T; ++q) {
+        key[q] = nxt[q];
+        inm[q] = __ballot((t + q * GM_WAVE + lane) < n);
+      }
+#pragma unroll
+      for (int q = 0; q < T; ++q) nxt[q] = kp[min(t + G + q * GM_WAVE + lane, n - 1)];
+      process(key, inm);
+    }
+  }
+
+  // ---- short lists: flattened (owner marks + DPP max-scan; tiles without a list boundary skip the scan) ------------------------------
+  const int incl = wave_incl_scan_add(llen);
+  const int total = readlane(incl, GM_WAVE - 1);
+  if (total == 0) return cnt;  // wave-uniform
+  const int off = incl - llen;
+  L.desc[lane] = make_int2(key_base - off, (int)salt_l);
+  unsigned *m32 = reinterpret_cast<unsigned *>(L.marks);
+  int carry = 0;
+  for (int wb = 0; wb < total; wb += kMarkWindow) {
+    const int wn = min(kMarkWindow, total - wb);
+    const int nwords = ((wn + GM_WAVE * T - 1) / (GM_WAVE * T)) * (GM_WAVE * T / 4);
+    for (int i = lane; i < nwords; i += GM_WAVE) m32[i] = 0u;
+    wave_sync();
+    if (llen > 0 && off >= wb && off < wb + kMarkWindow) L.marks[off - wb] = (unsigned char)(lane + 1);
+    wave_sync();
+    for (int t = 0; t < wn; t += GM_WAVE * T) {
+      int own[T], key[T];
+      unsigned salt[T];
+      unsigned long long inm[T];
+#pragma unroll
+      for (int q = 0; q < T; ++q) own[q] = (int)L.marks[t + q * GM_WAVE + lane];
+#pragma unroll
+      for (int q = 0; q < T; ++q) {
+        if (__ballot(own[q] != 0) == 0ull) {
+          own[q] = carry;  // no list starts inside this tile: every position belongs to the running owner
+        } else {
+          own[q] = max(wave_incl_scan_max(own[q]), carry);
+          carry = readlane(own[q], GM_WAVE - 1);
+        }
+      }
+      int2 d[T];
+#pragma unroll
+      for (int q = 0; q < T; ++q) {
+        const bool in = (wb + t + q * GM_WAVE + lane) < total;
+        inm[q] = __ballot(in);
+        d[q] = L.desc[in ? own[q] - 1 : 0];  // unconditional LDS read
+      }
+#pragma unroll
+      for (int q = 0; q < T; ++q) {
+        const bool in = (wb + t + q * GM_WAVE + lane) < total;
+        key[q] = col[in ? d[q].x + (wb + t + q * GM_WAVE + lane) : 0];  // unconditional load (select on the index)
+        salt[q] = (unsigned)d[q].y;
+      }
+      unsigned long long hm[T], nm[T];
+      tch_probe<STAGE, T>(B, col, fallback, key, salt, inm, hm, nm);
+      unsigned long long any_need = 0ull;
+#pragma unroll
+      for (int q = 0; q < T; ++q) {
+        cnt += (unsigned)__popcll(hm[q]);
+        any_need |= nm[q];
+      }
+      if (any_need != 0ull) cnt += tch_surplus<STAGE, T>(B, lane, key, salt, nm);  // rare
+    }
+    wave_sync();
+  }
+  return cnt;
+}
+
+template <int STAGE>
+__global__ __launch_bounds__((kWavesPerBlock * GM_WAVE), (STAGE <= 1024 ? 6 : 4))
+void tch_kernel(const MineParams p) {
+  __shared__ TchLds<STAGE> B;
+  using H = TchHash<STAGE>;
+  const int lane = threadIdx.x & (GM_WAVE - 1);
+  const int wave = threadIdx.x >> 6;
+  const int tid = threadIdx.x, nthreads = kWavesPerBlock * GM_WAVE;
+  const int *__restrict__ rp = p.g.rp;
+  const int *__restrict__ col = p.g.col;
+  const int *__restrict__ trp = p.g.trp;
+  const int2 *__restrict__ tdesc = p.g.tdesc;
+  TchWave &L = B.w[wave];
+  unsigned long long c0 = 0;  // wave-uniform
+  for (;;) {
+    if (tid == 0) B.queue_pos = atomicAdd(p.queue, (unsigned)p.grab);
+    __syncthreads();
+    const unsigned q = B.queue_pos;
+    if (q >= (unsigned)p.count) break;
+    const unsigned qe = min(q + (unsigned)p.grab, (unsigned)p.count);
+    for (unsigned ci = q; ci < qe; ++ci) {
+      const size_t pos = (size_t)p.first + (size_t)ci * (size_t)p.step;
+      const size_t cid = p.order ? (size_t)p.order[pos] : pos;
+      const ChunkRec r = p.chunks[cid];
+      const int ub = r.u_begin, nvl = r.u_end - r.u_begin;
+      const int eb = r.e_begin, nel = r.e_end - r.e_begin;
+      // ---- workgroup: the chunk's DAG rows into the set -----------------------------------------------------------------
+      unsigned *fill32 = reinterpret_cast<unsigned *>(&B.w[0]);
+      for (int i = tid; i <= nvl; i += nthreads) {
+        B.rpl[i] = rp[ub + i];
+        B.trpl[i] = trp[ub + i];
+      }
+      {
+        const uint4 empty = make_uint4(kTchEmpty, kTchEmpty, kTchEmpty, kTchEmpty);
+        for (int i = tid; i < STAGE; i += nthreads) B.table[i] = empty;
+        for (int i = tid; i < STAGE / 2; i += nthreads) fill32[i] = 0u;
+        if (tid < kTchOvfCap) {
+          B.ovf_key[tid] = -1;
+          B.ovf_salt[tid] = -1;
+        }
+        if (tid == 0) {
+          B.n_ovf = 0;
+          B.next_batch = 0;
+        }
+      }
+      __syncthreads();
+      unsigned *slots = reinterpret_cast<unsigned *>(B.table);
+      constexpr int kU = 4;  // entries requested together per thread
+      for (int i0 = tid; i0 < nel; i0 += kU * nthreads) {
+        int x[kU];
+#pragma unroll
+        for (int j = 0; j < kU; ++j) x[j] = col[eb + min(i0 + j * nthreads, nel - 1)];
+#pragma unroll
+        for (int j = 0; j < kU; ++j) {
+          const int i = i0 + j * nthreads;
+          if (i < nel) {
+            const unsigned s = H::salt(tch_local_row(B.rpl, nvl, eb + i));
+            const unsigned b = H::bucket(x[j], s) >> 4;
+            const unsigned shift = (b & 1u) * 16u;
+            const unsigned slot = (atomicAdd(&fill32[b >> 1], 1u << shift) >> shift) & 0xffffu;
+            if (slot < 4u) {
+              slots[(b << 2) + slot] = (unsigned)x[j];
+            } else {
+              const int jo = atomicAdd(&B.n_ovf, 1);
+              if (jo < kTchOvfCap) {
+                B.ovf_key[jo] = x[j];
+                B.ovf_salt[jo] = (int)s;
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();
+      // a bucket that got more than four entries gives up its last slot for the marker; the entry that sat there joins the surplus
+      // list -- its salt comes back from (bucket, id): bucket = hash(id) ^ salt
+      for (int b = tid; b < STAGE; b += nthreads) {
+        const unsigned c = (fill32[b >> 1] >> ((b & 1) * 16)) & 0xffffu;
+        if (c > 4u) {
+          const unsigned x3 = slots[(b << 2) + 3];
+          const int jo = atomicAdd(&B.n_ovf, 1);
+          if (jo < kTchOvfCap) {
+            B.ovf_key[jo] = (int)x3;
+            B.ovf_salt[jo] = (int)(H::bucket((int)x3, 0u) ^ ((unsigned)b << 4));
+          }
+          slots[(b << 2) + 3] = kTchMarker;
+        }
+      }
+      __syncthreads();  // (also: the fill counters are dead, the waves may use their scratch)
+      const bool fallback = B.n_ovf > kTchOvfCap || (p.flags & (1 << 22)) != 0;
+      // ---- waves: batches of 64 tasks ---------------------------------------------------------------------------------
+      const int tb = B.trpl[0], ntask = B.trpl[nvl] - tb;
+      for (;;) {
+        int bi = 0;
+        if (lane == 0) bi = atomicAdd(&B.next_batch, 1);
+        bi = readfirst(bi) * r.nparts + r.part;
+        const int t0 = bi * GM_WAVE;
+        if (t0 >= ntask) break;
+        const bool valid = t0 + lane < ntask;
+        const int te = tb + min(t0 + lane, ntask - 1);
+        const int2 d = tdesc[te];                       // {start, length} of the list to stream, coalesced
+        const int lo = tch_local_row(B.trpl, nvl, te);  // the host row of this task
+        const int ru = B.rpl[lo], a = B.rpl[lo + 1] - ru;
+        const bool act = valid && d.y > 0 && a > 0;
+        c0 += (unsigned long long)tch_pass<STAGE>(B, L, col, fallback, lane, act ? d.y : 0, d.x, H::salt(lo));
+      }
+      __syncthreads();  // the table is rewritten by the next chunk
+    }
+  }
+  if (lane == 0 && c0) atomicAdd(&p.counters[0], c0);
+}
+
+// 1024 buckets (16 KB of LDS + 7.6 KB: six workgroups per CU) or 2048 (32 KB: four) -- the longest DAG row must fit
+int tch_per_cu(int stage) { return stage <= 1024 ? 6 : 4; }
+hipError_t launch_tch(const MineParams &p, int stage, int grid_blocks, hipStream_t stream) {
+  static_assert(sizeof(TchLds<1024>) * 6 <= 163840, "six workgroups per CU");
+  static_assert(sizeof(TchLds<kTctStageMax>) * 4 <= 163840, "four workgroups per CU");
+  static_assert(sizeof(TchWave) * kWavesPerBlock >= (size_t)kTctStageMax * 2, "fill counters alias the wave scratch");
+  if (p.g.trp == nullptr || p.g.tdesc == nullptr) return hipErrorInvalidValue;
+  const dim3 grid((unsigned)grid_blocks), block(kWavesPerBlock * GM_WAVE);
+  if (stage <= 1024) hipLaunchKernelGGL((tch_kernel<1024>), grid, block, 0, stream, p);
+  else hipLaunchKernelGGL((tch_kernel<kTctStageMax>), grid, block, 0, stream, p);
+  return hipGetLastError();
+}
+
+}  // namespace gm
+
+// (module warm-up, gm_graph.hip finish_handle: HIP loads the code object of a translation unit when one of its kernels is first launched)
+__global__ void gm_touch_tch_kernel() {}
+void gm_touch_tch() { hipLaunchKernelGGL(gm_touch_tch_kernel, dim3(1), dim3(1), 0, 0); }

@@ -72,6 +72,10 @@ def test_tc_matches_reference(gg):
     assert CliqueSolver(dag, 3) == GOLDEN[name]["tc"]
     # (default: the shorter list of every edge is streamed, gm_tct.hip; 0x4000000: the chunked kernel that streams N+(v) of every out-edge)
     assert TCSolver(dag, tune=[0, 0, 0, 0, 0, 0, 0x4000000]) == GOLDEN[name]["tc"]
+    # (the task-list kernels: default = the chunk rows as one hashed (row, id) set, gm_tch.hip; 0x8000000: sorted LDS copy + bit filter +
+    # bisection, gm_tct.hip; 0x800000: the hashed kernel on its global-memory fallback lookup)
+    assert TCSolver(dag, tune=[0, 0, 0, 0, 0, 0, 0x8000000]) == GOLDEN[name]["tc"]
+    assert TCSolver(dag, tune=[0, 0, 0, 0, 0, 0, 0x800000]) == GOLDEN[name]["tc"]
 
 
 @pytest.mark.parametrize("tune", [
@@ -79,6 +83,7 @@ def test_tc_matches_reference(gg):
     [0, 0, 0, 0, 0, 0, 0x1000], [0, 0, 0, 0, 0, 0, 0x4000], [0, 0, 0, 0, 0, 0, 0x3000],
     [256, 4, 8, 1, 0, 0],
     [64, 1, 0, 0, 0, 0, 0x4000000], [256, 4, 1, 30, 2, 0, 0x4000000], [0, 0, 0, 0, 0, 0, 0x4000000 | 0x1000], [128, 8, 1, 1, 0, 0, 0x4000000 | 0x4000],
+    [64, 1, 0, 0, 0, 0, 0x8000000], [0, 0, 0, 0, 0, 0, 0x8000000 | 0x1000], [256, 4, 8, 1, 0, 0, 0x8000000], [0, 0, 0, 0, 0, 0, 0x800000 | 0x1000],
 ])
 def test_tc_invariant_under_tuning(gg, tune):
     name, _, sym, dag = gg
@@ -694,6 +699,8 @@ def test_tc_rows_beyond_the_task_list_stage(dev):
     got, st = TCSolver(dag, return_stats=True)
     assert got == want and st.tasks == dag.E()
     assert TCSolver(dag, tune=[0, 0, 0, 0, 0, 0, 0x4000000]) == want  # the chunked kernel alone
+    assert TCSolver(dag, tune=[0, 0, 0, 0, 0, 0, 0x8000000]) == want  # task lists against the sorted LDS copy
+    assert TCSolver(dag, tune=[0, 0, 0, 0, 0, 0, 0x800000]) == want   # ... against the hashed set's fallback lookup
     assert sum(TCSolver(dag, rank=r, world=3) for r in range(3)) == want
     assert sum(TCSolver(dag, rank=r, world=4, policy=2) for r in range(4)) == want
     assert CliqueSolver(dag, 3) == want
@@ -760,3 +767,41 @@ def test_rmat_device_generator_equals_numpy(dev):
         assert np.array_equal(rp.cpu().numpy(), g.row_ptr)
         assert np.array_equal(ci.cpu().numpy(), g.col_idx)
         assert TCSolver(s.orient()) == GOLDEN[g.name]["tc"]
+
+
+def test_tc_hashed_set_with_colliding_ids(dev):
+    """gm_tch.hip keeps a chunk's DAG rows as a hashed set of four-slot buckets (bucket = top bits of id * 0x9E3779B1, XOR a row salt).
+    Ids chosen through the inverse of that multiplier all fall into ONE bucket per row. They are made the high-degree side of the graph,
+    so that they are what the DAG rows hold: rows of 300 of them overflow the surplus list (the whole chunk then bisects its rows in
+    global memory), rows with 6 of them among 40 ordinary ids use the surplus list. Counts against the CPU oracle and the sorted-copy
+    kernel, on the graph as numbered (0x200: these ids reach the kernel) and on the topological copy."""
+    rng = np.random.default_rng(11)
+    nv = 1 << 24
+    cinv = pow(0x9E3779B1, -1, 1 << 32)
+    t = (np.uint64(5) << np.uint64(22)) + np.arange(1 << 22, dtype=np.uint64)
+    x = (t * np.uint64(cinv)) & np.uint64(0xFFFFFFFF)
+    one_bucket = np.sort(x[(x < nv) & (x > 100000)])
+    assert one_bucket.size > 5000
+    plain = rng.choice(np.arange(50000, 100000, dtype=np.uint64), size=400, replace=False)
+    for pool_size, nhub, per, extra in ((600, 2000, 300, 0), (600, 3000, 6, 40)):
+        pool = one_bucket[:pool_size]
+        hubs = np.arange(1, nhub + 1, dtype=np.uint64)
+        s = [np.repeat(hubs, per)]
+        d = [np.concatenate([rng.choice(pool, size=per, replace=False) for _ in hubs])]
+        if extra:
+            s.append(np.repeat(hubs, extra))
+            d.append(np.concatenate([rng.choice(plain, size=extra, replace=False) for _ in hubs]))
+        both = np.concatenate([pool, plain]) if extra else pool
+        s.append(rng.choice(both, size=30000))  # edges among the high-degree vertices, so that triangles exist
+        d.append(rng.choice(both, size=30000))
+        g = csr_from_pairs(int(nv), np.concatenate(s), np.concatenate(d))
+        dag = g.to_device(dev).orient()
+        got = dag.download()
+        rows = np.diff(got.row_ptr)[1:nhub + 1]
+        assert rows.min() >= per  # the hubs' DAG rows do hold the colliding ids
+        want = O.tc(O.orient(O.OGraph(g.row_ptr, g.col_idx)))
+        assert want > 0
+        assert TCSolver(dag) == want
+        assert TCSolver(dag, tune=[0, 0, 0, 0, 0, 0, 0x200]) == want
+        assert TCSolver(dag, tune=[0, 0, 0, 0, 0, 0, 0x200 | 0x8000000]) == want
+        assert sum(TCSolver(dag, rank=r, world=3, tune=[0, 0, 0, 0, 0, 0, 0x200]) for r in range(3)) == want
