@@ -55,15 +55,24 @@ __device__ __forceinline__ unsigned pair_popc(const uint4 (&mr)[NQ], const uint4
   return a;
 }
 
-// c0: first word of the column block inside the matrix rows; topo: the matrix is strictly upper triangular (row j has no bit at or
-// below column j), so for a tile of ascending j's the units below the first j's own are all zero in every M_j and are skipped
-template <int NQ, bool WHOLE>
+// c0: first word of the column block inside the matrix rows, cwb: its words.  topo: the matrix is strictly upper triangular (row j has
+// no bit at or below column j), so
+//   * a pair (i, j), i < j, has common bits only beyond column j: rows and columns at or beyond the block's last column contribute
+//     nothing to this block -- the row loop and the column scan end there;
+//   * for a tile of ascending j's the units below the first j's own are zero in every M_j and are skipped (rows of >= 6 units).
+// The j's of row i (its set bits) are COMPACTED 64 COLUMNS PER STEP -- lane = column, ballot, v_mbcnt rank, one 16-bit LDS write -- into
+// the wave's list, and a tile of 64 pairs runs as soon as 64 are queued: ~8 VALU per 64 columns whatever the bits look like.  (Until
+// round 3 a lane expanded the bits of ITS 32-column word in a loop: the loop ran as long as the densest word of the row -- the hub
+// columns at the end of a topologically numbered matrix: 16 / 26 / 29 iterations per row in classes S / L / X of R-MAT-22 ef 28 for
+// 35 / 164 / 331 pairs, more instructions than the pair counts themselves.)
+template <int NQ, bool WHOLE, int LISTCAP>
 __device__ __forceinline__ unsigned long long count_block(const unsigned *__restrict__ bits, unsigned short *__restrict__ plist, int *next_row,
                                                           const unsigned *__restrict__ gm, const int d, const int stride, const int lane,
-                                                          const int c0, const bool topo) {
+                                                          const int c0, const int cwb, const bool topo) {
   constexpr int ps = 4 * NQ;
   unsigned long long tot = 0;
   unsigned c = 0;
+  const int jend = topo ? min(d, (c0 + cwb) * 32) : d;  // rows / columns that can contribute to this block
   // The set bits of row i over ALL columns drive the enumeration of j. WHOLE (the block is the whole matrix): they are read
   // from LDS. Column blocks: from the arena (L2), and the read of the NEXT row is issued before the current row is
   // processed -- a wave takes its next row index one row early -- so that its ~1 us latency hides behind the pair loop
@@ -81,64 +90,78 @@ __device__ __forceinline__ unsigned long long count_block(const unsigned *__rest
   unsigned mnext = 0u;
   if (!WHOLE) {
     inext = grab();
-    mnext = (inext < d) ? load_row(inext) : 0u;
+    mnext = (inext < jend) ? load_row(inext) : 0u;
   }
   for (;;) {
     int i;
     unsigned mi;
     if (WHOLE) {
       i = grab();
-      if (i >= d) break;
+      if (i >= jend) break;
       mi = load_row(i);
     } else {
       i = inext;
-      if (i >= d) break;
+      if (i >= jend) break;
       mi = (lane < stride) ? mnext : 0u;
       inext = grab();
-      mnext = (inext < d) ? load_row(inext) : 0u;  // wave-uniform condition
+      mnext = (inext < jend) ? load_row(inext) : 0u;  // wave-uniform condition
     }
+    // nothing of row i inside this block's columns: no pair of it counts here
+    if (__ballot(mi != 0u && lane >= c0 && lane < c0 + cwb) == 0ull) continue;
     // row i's words of this block, in registers (every lane reads the same addresses: LDS broadcast)
     uint4 mr[NQ];
     const uint4 *ri = reinterpret_cast<const uint4 *>(&bits[i * ps]);
 #pragma unroll
     for (int k = 0; k < NQ; ++k) mr[k] = ri[k];
-    // the j's of row i, 1024 columns (32 words) at a time: the position list of a wave holds 1024 entries (2 KB)
-    for (int h0 = 0; h0 < stride; h0 += 32) {
-      const int cwn = (lane >= h0 && lane < h0 + 32) ? __popc(mi) : 0;
-      const int incl = wave_incl_scan_add(cwn);
-      const int total = readlane(incl, GM_WAVE - 1);
-      if (total == 0) continue;
-      wave_sync();  // the previous half's list is no longer read
-      if (cwn) {
-        unsigned x = mi;
-        int k = incl - cwn;
-        while (x) {
-          plist[k++] = (unsigned short)(lane * 32 + (__ffs((int)x) - 1));
-          x &= x - 1;
-        }
-      }
-      wave_sync();
-#pragma unroll 1
-      for (int t = 0; t < total; t += GM_WAVE) {  // (not unrolled: one step already has up to 9 independent 16-byte reads in flight)
-        const int idx = t + lane;
-        const int j = (int)plist[min(idx, total - 1)];
-        const uint4 *rj = reinterpret_cast<const uint4 *>(&bits[j * ps]);
-        // first useful unit of the tile (wave-uniform): the list is ascending, lane 0 holds the smallest j
-        // (rows of <= 5 units -- class S -- do not pay for the dispatch: measured 7.5 -> 9.0 ms with it, profiles/r03/ab_clique4_steps.txt)
-        const int kmin = (NQ >= 6 && topo) ? min(max(((readfirst(j) >> 5) - c0) >> 2, 0), NQ - 1) : 0;
-        unsigned a = 0;
-        switch (kmin) {
+    int n = 0, start = 0;  // wave-uniform: list entries [start, n) are queued
+    auto tile = [&](const int cnt) {
+      const int idx = start + lane;
+      const int j = (int)plist[min(idx, start + cnt - 1)];
+      const uint4 *rj = reinterpret_cast<const uint4 *>(&bits[j * ps]);
+      // first useful unit of the tile (wave-uniform): the list is ascending, lane 0 holds the smallest j
+      // (rows of <= 5 units do not pay for the dispatch: measured, class S 7.5 -> 9.0 ms with it, profiles/r03/ab_clique4_steps.txt)
+      const int kmin = (NQ >= 6 && topo) ? min(max(((readfirst(j) >> 5) - c0) >> 2, 0), NQ - 1) : 0;
+      unsigned a = 0;
+      switch (kmin) {
 #define GM_PAIR_CASE(K) \
   case K: if constexpr (K < NQ) a = pair_popc<NQ, K>(mr, rj); break;
-          GM_PAIR_CASE(0) GM_PAIR_CASE(1) GM_PAIR_CASE(2) GM_PAIR_CASE(3) GM_PAIR_CASE(4) GM_PAIR_CASE(5) GM_PAIR_CASE(6) GM_PAIR_CASE(7)
-          GM_PAIR_CASE(8)
+        GM_PAIR_CASE(0) GM_PAIR_CASE(1) GM_PAIR_CASE(2) GM_PAIR_CASE(3) GM_PAIR_CASE(4) GM_PAIR_CASE(5) GM_PAIR_CASE(6) GM_PAIR_CASE(7)
+        GM_PAIR_CASE(8)
 #undef GM_PAIR_CASE
-          default: break;
-        }
-        c += (idx < total) ? a : 0u;
+        default: break;
+      }
+      c += (lane < cnt) ? a : 0u;
+    };
+    const int cbeg = topo ? ((i + 1) & ~63) : 0;
+    for (int cc = cbeg; cc < jend; cc += 64) {  // (cc is a multiple of 64: word cc / 32 is even, at most 62)
+      const unsigned w0 = (unsigned)readlane((int)mi, cc >> 5), w1 = (unsigned)readlane((int)mi, (cc >> 5) + 1);
+      const unsigned wsel = (lane < 32) ? w0 : w1;
+      const unsigned long long m = __ballot((((wsel >> (lane & 31)) & 1u) != 0u) & (cc + lane < jend));
+      if (m == 0ull) continue;
+      if (__builtin_amdgcn_inverse_ballot_w64(m)) plist[n + rank_below(m)] = (unsigned short)(cc + lane);
+      n += __popcll(m);
+      if (n - start >= GM_WAVE) {
+        wave_sync();  // the list entries written above are read below
+        do {
+          tile(GM_WAVE);
+          start += GM_WAVE;
+        } while (n - start >= GM_WAVE);
+      }
+      if (n + GM_WAVE > LISTCAP) {  // the next step may not fit: move the < 64 queued entries to the front
+        const int rest = n - start;
+        wave_sync();
+        const unsigned short v = plist[min(start + min(lane, max(rest - 1, 0)), LISTCAP - 1)];
+        wave_sync();
+        if (lane < rest) plist[lane] = v;
+        n = rest;
+        start = 0;
       }
     }
-    wave_sync();
+    if (n > start) {
+      wave_sync();
+      tile(n - start);
+    }
+    wave_sync();  // the list is rewritten by the next row
     if (c > 0x7fffffffu) { tot += (unsigned long long)c; c = 0; }
   }
   return tot + (unsigned long long)c;
@@ -185,7 +208,7 @@ __global__ __launch_bounds__(WAVES *GM_WAVE, 1) void clique_count_kernel(const C
       const unsigned long long t1 = p.profile ? wall_clock64() : 0ull;
       // (WHOLE instantiations -- classes S / L -- only ever see one block: clique_count_class and the loop above agree)
 #define GM_COUNT_CASE(NQ) \
-  case NQ: tot += count_block<NQ, WHOLE>(S.bits, plist, &S.next_row, gm, d, stride, lane, c0, p.topo != 0); break;
+  case NQ: tot += count_block<NQ, WHOLE, LISTCAP>(S.bits, plist, &S.next_row, gm, d, stride, lane, c0, cwb, p.topo != 0); break;
       switch (nq) {
         GM_COUNT_CASE(1)
         GM_COUNT_CASE(2)
@@ -195,7 +218,7 @@ __global__ __launch_bounds__(WAVES *GM_WAVE, 1) void clique_count_kernel(const C
         GM_COUNT_CASE(6)
         GM_COUNT_CASE(7)
         GM_COUNT_CASE(8)
-        default: tot += count_block<9, WHOLE>(S.bits, plist, &S.next_row, gm, d, stride, lane, c0, p.topo != 0); break;
+        default: tot += count_block<9, WHOLE, LISTCAP>(S.bits, plist, &S.next_row, gm, d, stride, lane, c0, cwb, p.topo != 0); break;
       }
 #undef GM_COUNT_CASE
       if (p.profile) {
