@@ -177,6 +177,7 @@ def test_clique4_matches_reference(gg):
     assert CliqueSolver(dag, 4) == GOLDEN[name]["clique4"]
     assert CliqueSolver(dag, 4, tune=[64, 1, 1, 1, 0, 0]) == GOLDEN[name]["clique4"]
     assert CliqueSolver(dag, 4, tune=[512, 4, 0, 0, 0, 1]) == GOLDEN[name]["clique4"]
+    assert CliqueSolver(dag, 4, tune=[0, 0, 0, 0, 0, 0, 0x800000]) == GOLDEN[name]["clique4"]  # the build's hashed set on its fallback lookup
 
 
 @pytest.mark.parametrize("k", [5, 6, 7, 8])
@@ -406,6 +407,7 @@ def test_clique4_wide_vertices_two_phases(dev, n, p):
     if want is not None:
         assert got == want
     assert CliqueSolver(d, 4, tune=[0, 0, 0, 0, 0, 0, 0x40000]) == got
+    assert CliqueSolver(d, 4, tune=[0, 0, 0, 0, 0, 0, 0x800000]) == got  # the build's hashed set on its fallback lookup
     assert sum(CliqueSolver(d, 4, rank=r, world=3) for r in range(3)) == got
     assert sum(CliqueSolver(d, 4, rank=r, world=5, policy=1) for r in range(5)) == got
     assert CliqueSolver(d, 4, tune=[0, 0, 1, 1, 0, 0]) == got  # another direction rule: pass Y on the wide rows too
@@ -805,3 +807,9 @@ def test_tc_hashed_set_with_colliding_ids(dev):
         assert TCSolver(dag, tune=[0, 0, 0, 0, 0, 0, 0x200]) == want
         assert TCSolver(dag, tune=[0, 0, 0, 0, 0, 0, 0x200 | 0x8000000]) == want
         assert sum(TCSolver(dag, rank=r, world=3, tune=[0, 0, 0, 0, 0, 0, 0x200]) for r in range(3)) == want
+        # the re-hosted 4-clique build keeps the same rows as a hashed (row, id) -> position set (gm_cbuild.hip)
+        want4 = O.clique(O.orient(O.OGraph(g.row_ptr, g.col_idx)), 4)
+        assert CliqueSolver(dag, 4) == want4
+        assert CliqueSolver(dag, 4, tune=[0, 0, 0, 0, 0, 0, 0x200]) == want4
+        assert CliqueSolver(dag, 4, tune=[0, 0, 0, 0, 0, 0, 0x200 | 0x800000]) == want4  # ... on its global-memory fallback lookup
+        assert CliqueSolver(dag, 4, tune=[0, 0, 0, 0, 0, 0, 0x40000]) == want4           # the mining kernel's arena path
