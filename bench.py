@@ -63,13 +63,14 @@ BASELINE_CONFIGS = [
 ]
 # rocprofv3 kernel names that make up one launch of a workload (everything between the library's two timing events)
 KERNELS = {
-    "tc": ["mine_kernel<0,", "tct_kernel"],   # (tct_kernel: the shorter list of every edge streamed, gm_tct.hip)
+    "tc": ["mine_kernel<0,", "tct_kernel", "tch_kernel"],   # (tch_kernel: the shorter list of every edge streamed against a hashed set, gm_tch.hip)
     # general kernel <P, 0> (+ the sorted-copy classes <P, 1>, <P, 2>), the hashed-row classes and the kernel of the giant rows
-    "diamond": ["mine_kernel<1,", "hrow_kernel<1,", "giant_kernel<1,"],
+    # (one GPU: edge supports from the DAG's triangles, gm_sup.hip; several ranks: the per-edge kernels)
+    "diamond": ["sup_kernel", "sup_pairs_kernel", "mine_kernel<1,", "hrow_kernel<1,", "giant_kernel<1,"],
     "motif3": ["mine_kernel<2,", "hrow_kernel<2,", "giant_kernel<2,"],
     "clique4": ["mine_kernel<3,", "cbuild_kernel", "clique_count_kernel", "clique_small_kernel"],
     "clique5": ["mine_kernel<4,"],
-    "motif3f": ["mine_kernel<0,", "tct_kernel"],
+    "motif3f": ["mine_kernel<0,", "tct_kernel", "tch_kernel"],
     "rectangle": ["rect_acc_kernel"],
     "house": ["house_acc_kernel"],
     "pentagon": ["pent_acc_kernel"],

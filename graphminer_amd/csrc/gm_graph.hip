@@ -78,6 +78,8 @@ extern "C" void gm_graph_free(gm_graph *g) {
   if (g->d_symdeg) (void)hipFree(g->d_symdeg);
   if (g->d_trp) (void)hipFree(g->d_trp);
   if (g->d_tdesc) (void)hipFree(g->d_tdesc);
+  if (g->d_tedge) (void)hipFree(g->d_tedge);
+  if (g->d_sup) (void)hipFree(g->d_sup);
   free_clique_plans(g);
   if (g->d_wide_mat) (void)hipFree(g->d_wide_mat);
   if (g->d_wide_sorted) (void)hipFree(g->d_wide_sorted);
@@ -112,6 +114,7 @@ int finish_handle(gm_graph *g) {
     gm_touch_hrow();
     gm_touch_tct();
     gm_touch_tch();
+    gm_touch_sup();
     gm_touch_cbuild();
     gm_touch_wide();
     gm_touch_sgl();

@@ -208,6 +208,8 @@ struct gm_graph {
   int2 *d_edesc = nullptr;  // per CSR entry: {rp[col[e]], degree(col[e])}, built on first use (ensure_edesc)
   int *d_trp = nullptr;     // task lists of the shorter-list-streams triangle count (ensure_tasklists): row offsets (nv + 1)
   int2 *d_tdesc = nullptr;  // ... and per task {rp[partner], d(partner)}
+  int *d_tedge = nullptr;   // ... and (edge supports only: ensure_tasklists(g, true)) the task's own DAG entry
+  unsigned *d_sup = nullptr;  // edge supports: one counter per DAG entry (gm_sup.hip)
   std::vector<int> h_rp;  // host copy of the offsets, fetched on first use (host_rp): download, k-clique tables, SgL renumbering
   std::list<ChunkTable> tables;  // list: handed-out pointers stay valid
   unsigned long long *d_counters = nullptr;  // [4] + queue word, 64 B
@@ -312,6 +314,7 @@ void gm_touch_mine_wide();
 void gm_touch_hrow();
 void gm_touch_tct();
 void gm_touch_tch();
+void gm_touch_sup();
 void gm_touch_cbuild();
 void gm_touch_wide();
 void gm_touch_sgl();
@@ -329,7 +332,7 @@ void free_tables(gm_graph *g);                                   // gm_tables.hi
 int get_table(gm_graph *g, int target, bool allow_split, int bit_words, unsigned long long part_cap, int stage_cap, ChunkTable **out,
               const RowFilter &rf = RowFilter(), int bitmap_min_deg = kBitmapMinDeg);
 int ensure_edesc(gm_graph *g);
-int ensure_tasklists(gm_graph *g);
+int ensure_tasklists(gm_graph *g, bool with_edges = false);
 int clique_wide_min_words();
 int get_clique_plan(gm_graph *g, int rank, int world, int policy, int target, unsigned long long part_cap, CliquePlan **out);
 void free_clique_plans(gm_graph *g);

@@ -143,6 +143,10 @@ static void fill_stats(gm_stats *st, uint64_t tasks, uint64_t chunks, int grid, 
 
 int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uint64_t *h_out, int nout, gm_stats *st, int fin_mode,
                 unsigned long long fin_base) {
+  // edge supports + sum C(t, 2) (gm_sup.hip): the triangle pass of the task lists with another match handler -- everything up to the
+  // launch is the triangle count's
+  const bool support = pat == PAT_SUPPORT;
+  if (support) pat = PAT_TC;
   if (fin_mode < 0) fin_mode = (pat == PAT_MOTIF3) ? FIN_MOTIF3 : FIN_COPY;
   LaunchCtx ctx;
   int rc0 = begin_launch(cg, la, h_out, ctx);
@@ -199,10 +203,12 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
   // R-MAT-20 6.4 vs 5.7, power law 4.07 vs 4.10, R-MAT-24 458 vs 172). A graph without such rows skips their (empty) tables.
   // tune[6] & 0x100000 forces them on.
   if (use_classes && !(la->tune[6] & 0x100000)) use_classes = g->max_deg > kClassRowMin;
+  if (support && (!use_tct || tct_long || world > 1)) return GM_ERR_UNSUPPORTED;  // (the caller takes the per-edge kernels)
   if (use_tct) {
-    int rc_t = ensure_tasklists(g);
+    int rc_t = ensure_tasklists(g, support);
     if (rc_t) return rc_t;
   }
+  if (support && !g->d_sup) HIP_TRY(hipMalloc(&g->d_sup, sizeof(unsigned) * (size_t)std::max<long long>(g->ne, 1)));
   RowFilter rf;
   rf.tct = use_tct ? 1 : 0;
   if (tct_long) { rf.skip_lo = kTctStageMax; rf.skip_hi = 0x7fffffff; }
@@ -290,6 +296,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
   if (use_tct) {
     p.g.trp = g->d_trp;
     p.g.tdesc = g->d_tdesc;
+    p.g.tedge = support ? g->d_tedge : nullptr;
   }
   unsigned long long my_edges = 0;
   // this rank's share of a table: chunk ids first + i*step of the dequeue order (or a contiguous / vertex range)
@@ -578,7 +585,12 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
   }
   // (tune[6] & 0x8000000: A/B switch, the sorted LDS copy + bit filter + bisection of gm_tct.hip instead of the hashed set of gm_tch.hip)
   const bool use_tch = use_tct && !(la->tune[6] & 0x8000000) && !getenv("GM_TC_SORTED");
-  if (p.count > 0 && use_tch) HIP_TRY(launch_tch(p, tct_stage, (int)std::max<long long>(1, std::min<long long>(want, (long long)g->cu_count * tch_per_cu(tct_stage))), stream));
+  if (support) {  // zero the supports, three increments per triangle, then sum C(t, 2): all inside the timed region
+    HIP_TRY(hipMemsetAsync(g->d_sup, 0, sizeof(unsigned) * (size_t)g->ne, stream));
+    p.scratch = g->d_sup;
+    if (p.count > 0) HIP_TRY(launch_sup(p, tct_stage, (int)std::max<long long>(1, std::min<long long>(want, (long long)g->cu_count * sup_per_cu(tct_stage))), stream));
+    HIP_TRY(launch_sup_pairs(g->d_sup, 0, g->ne, g->d_counters, g->cu_count, stream));
+  } else if (p.count > 0 && use_tch) HIP_TRY(launch_tch(p, tct_stage, (int)std::max<long long>(1, std::min<long long>(want, (long long)g->cu_count * tch_per_cu(tct_stage))), stream));
   else if (p.count > 0 && use_tct) HIP_TRY(launch_tct(p, tct_stage, (int)std::max<long long>(1, std::min<long long>(want, (long long)g->cu_count * tct_per_cu(tct_stage))), stream));
   else if (p.count > 0) HIP_TRY(launch_mine(pat, p, grid, stream));
 #ifdef GM_DEBUG_CHUNKS
@@ -1091,12 +1103,46 @@ static int run_sgl_nested(int pat, const gm_graph *cg, const gm_launch *la_in, u
   return end_launch(ctx, FIN_COPY, 0, h_out, 1, st);
 }
 
+// diamond on one GPU: the edge supports of the oriented copy (cached on the handle; on its topological view where lists are long)
+static int run_diamond_supports(const gm_graph *sym, const gm_launch *la, uint64_t *total, gm_stats *st) {
+  gm_graph *g = const_cast<gm_graph *>(sym);
+  if (int rc = reject_big(sym)) return rc;
+  if (!g->dag_cache) {
+    gm_graph *dag = nullptr;
+    int rc = gm_graph_orient(sym, &dag);
+    if (rc) return rc;
+    g->dag_cache = dag;
+  }
+  gm_graph *dag = g->dag_cache, *run_on = nullptr;
+  if (dag->max_deg > kTctStageMax) return GM_ERR_UNSUPPORTED;
+  int rc = topo_view(dag, la, &run_on);
+  if (rc) return rc;
+  rc = run_pattern(PAT_SUPPORT, run_on, la, 3, total, 1, st);
+  if (rc) return rc;
+  dag->ring_alias = (run_on != dag) ? run_on : nullptr;
+  g->ring_alias = dag;
+  g->ring_extra[0] = g->ring_extra[1] = nullptr;
+  return GM_OK;
+}
+
 extern "C" int gm_sgl(const gm_graph *sym, const char *pattern, const gm_launch *la, uint64_t *total, gm_stats *st) {
   if (!pattern) return GM_ERR_INVALID;
   if (strcmp(pattern, "diamond") == 0) {
     // tune[6] & 1024: the LISTING (nested) form of the reference, src/sgl/gpu_kernels/diamond_nested.cuh:4-31 -- materialise
     // S, count_smaller per member -- as a second implementation; the default counts C(|S|,2) per edge (diamond_count.cuh:15-17)
     if (la && (la->tune[6] & 1024)) return run_sgl_nested(SGL_DIAMOND, sym, la, total, st);
+    // One GPU: |N(v0) ^ N(v1)| of EVERY edge from one pass over the triangles of the DAG (edge supports, gm_sup.hip), then sum C(t, 2).
+    // Several ranks, DAG rows beyond the 2048-entry stage, or one of the A/B switches of the per-edge kernels (tune[6] & 0x10000000: that
+    // path on request): one intersection of the two symmetric lists per edge (gm_hrow.hip, gm_chunk.h).
+    {
+      const int t6 = la ? la->tune[6] : 0;
+      const bool per_edge = (t6 & (0x10000000 | 0x80000 | 0x100000 | 0x400000 | 0x1000000 | 0x2000000)) || (la && la->world > 1) ||
+                            (la && la->tune[5] == 1) || getenv("GM_DIAMOND_PER_EDGE") || !sym || sym->d_rp64;
+      if (!per_edge) {
+        const int rc = run_diamond_supports(sym, la, total, st);
+        if (rc != GM_ERR_UNSUPPORTED) return rc;
+      }
+    }
     return run_pattern(PAT_DIAMOND, sym, la, 4, total, 1, st);
   }
   // rectangle / house / pentagon run on a copy of the graph renumbered by degree (get_relabeled; tune[6] & 512: on the

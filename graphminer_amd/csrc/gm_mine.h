@@ -76,11 +76,13 @@ struct GraphView {
   // of the lists it hosts, trp = their row offsets (nv+1); nullptr = not built.
   const int *trp = nullptr;
   const int2 *tdesc = nullptr;
+  const int *tedge = nullptr;  // per task: the DAG entry of its own edge (edge supports, gm_sup.hip); nullptr = not built
 };
 
 enum Pattern : int { PAT_TC = 0, PAT_DIAMOND = 1, PAT_MOTIF3 = 2, PAT_CLIQUE4 = 3, PAT_CLIQUEK = 4 /* k = 5..8 */,
                      PAT_MOTIF4E = 5 /* per-edge sums of the 4-motif formula */,
-                     PAT_DAGSTATS = 6 /* tooling: sum n, sum n^2, sum_{matches} d+(w) for the 4-clique algorithmic bytes */ };
+                     PAT_DAGSTATS = 6 /* tooling: sum n, sum n^2, sum_{matches} d+(w) for the 4-clique algorithmic bytes */,
+                     PAT_SUPPORT = 7 /* edge supports from the DAG's triangles + sum C(t, 2): the diamond count (gm_sup.hip) */ };
 
 // Symmetric-graph patterns stage up to 3072 entries: on skewed graphs thousands of rows have 1-3 K neighbours; with a
 // 1024-entry stage they are SPLIT rows whose keys are bisected in HBM, otherwise ordinary staged chunks behind
@@ -352,6 +354,11 @@ int tct_per_cu(int stage);
 // ... the same tasks against the chunk rows as one hashed (row, id) set in LDS: gm_tch.hip (the default; tune[6] & 0x8000000: tct_kernel)
 hipError_t launch_tch(const MineParams &p, int stage, int grid_blocks, hipStream_t stream);
 int tch_per_cu(int stage);
+// edge supports t(e) = triangles through e, into p.scratch (one 32-bit counter per DAG entry, zeroed by the caller): the task lists'
+// triangle pass with three increments per match (gm_sup.hip); then sum C(t, 2) over a range of entries
+hipError_t launch_sup(const MineParams &p, int stage, int grid_blocks, hipStream_t stream);
+int sup_per_cu(int stage);
+hipError_t launch_sup_pairs(const unsigned *sup, long long first, long long count, unsigned long long *out, int cu_count, hipStream_t stream);
 size_t mine_lds_bytes(Pattern pat);
 // the big-LDS classes (gm_mine_wide.hip): cls = 1 (mid rows) or 2 (big rows); DIAMOND, MOTIF3, MOTIF4E only
 hipError_t launch_mine_wide(Pattern pat, int cls, const MineParams &p, int grid_blocks, hipStream_t stream);

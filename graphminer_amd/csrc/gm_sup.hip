@@ -1,0 +1,147 @@
+// gm_sup.hip -- EDGE SUPPORTS: t(e) = |N(u) ^ N(v)| for every edge e = {u, v} of the symmetric graph, from ONE pass over the
+// triangles of its DAG, and the diamond count  sum_e C(t(e), 2)  from them.
+//
+// The reference's diamond kernel intersects the two SYMMETRIC neighbour lists of every edge (src/sgl/gpu_kernels/diamond_count.cuh:2-19:
+// one warp per edge, n = |N(v0) ^ N(v1)|, count += n (n - 1) / 2), and so did this library until round 3 (gm_hrow.hip: hub rows as
+// hashed sets, the partner lists streamed: 18.6 G keys on the LiveJournal stand-in).  But |N(u) ^ N(v)| is the number of triangles
+// through the edge, and every triangle {a, b, c} of the graph is found exactly ONCE by the triangle kernel on the DAG (gm_tch.hip:
+// 3.4 G keys on the same graph): as a match of one task edge while the shorter of two out-lists is streamed against the longer.
+// A match knows its three edges as DAG entries:
+//   * the task's own edge (one entry per task: tedge[], emitted with the task lists),
+//   * host row start + the POSITION of the match in the host's row  (the hashed set of gm_hset.h returns it),
+//   * the index of the streamed key in col[]  (the streamed list IS a DAG row, or the tail of one),
+// so the kernel is the triangle kernel with three increments per match: the two "third vertex" edges by global atomics (return-less,
+// 4-byte, L2), the task's own edge once per task from a per-batch LDS counter.  A second kernel sums C(t, 2) over the entries.
+// One GPU; rows beyond the 2048-entry stage send the caller back to the per-edge kernels (gm_launch.hip).
+#include "gm_hset.h"
+
+namespace gm {
+
+constexpr int kSupTiles = 4;
+
+template <int STAGE>
+struct alignas(16) SupLds {
+  HsTable<STAGE> set;
+  int trpl[kMaxChunkVerts + 1];  // row offsets of the chunk's task lists
+  HsWave w[kWavesPerBlock];      // (while the set is built: the fill counters of its buckets)
+  unsigned cnt[kWavesPerBlock][GM_WAVE];  // per batch lane: matches of its task
+  int next_batch;
+  unsigned queue_pos;
+  int pad_[2];
+};
+
+template <int STAGE>
+__global__ __launch_bounds__((kWavesPerBlock * GM_WAVE), (STAGE <= 1024 ? 5 : 3))
+void sup_kernel(const MineParams p) {
+  __shared__ SupLds<STAGE> B;
+  using H = HsHash<STAGE>;
+  const int lane = threadIdx.x & (GM_WAVE - 1);
+  const int wave = threadIdx.x >> 6;
+  const int tid = threadIdx.x;
+  constexpr int nthreads = kWavesPerBlock * GM_WAVE;
+  const int *__restrict__ rp = p.g.rp;
+  const int *__restrict__ col = p.g.col;
+  const int *__restrict__ trp = p.g.trp;
+  const int2 *__restrict__ tdesc = p.g.tdesc;
+  const int *__restrict__ tedge = p.g.tedge;
+  unsigned *__restrict__ sup = p.scratch;
+  HsWave &L = B.w[wave];
+  unsigned *cnt = B.cnt[wave];
+  for (;;) {
+    if (tid == 0) B.queue_pos = atomicAdd(p.queue, (unsigned)p.grab);
+    __syncthreads();
+    const unsigned q = B.queue_pos;
+    if (q >= (unsigned)p.count) break;
+    const unsigned qe = min(q + (unsigned)p.grab, (unsigned)p.count);
+    for (unsigned ci = q; ci < qe; ++ci) {
+      const size_t pos = (size_t)p.first + (size_t)ci * (size_t)p.step;
+      const size_t cid = p.order ? (size_t)p.order[pos] : pos;
+      const ChunkRec r = p.chunks[cid];
+      const int ub = r.u_begin, nvl = r.u_end - r.u_begin;
+      const int eb = r.e_begin, nel = r.e_end - r.e_begin;
+      for (int i = tid; i <= nvl; i += nthreads) B.trpl[i] = trp[ub + i];
+      if (tid == 0) B.next_batch = 0;
+      const bool fallback = hs_build<STAGE, nthreads>(B.set, reinterpret_cast<unsigned *>(&B.w[0]), rp, col, ub, nvl, eb, nel,
+                                                       (p.flags & (1 << 22)) != 0, tid);  // (ends with a barrier)
+      const int tb = B.trpl[0], ntask = B.trpl[nvl] - tb;
+      for (;;) {
+        int bi = 0;
+        if (lane == 0) bi = atomicAdd(&B.next_batch, 1);
+        bi = readfirst(bi) * r.nparts + r.part;
+        const int t0 = bi * GM_WAVE;
+        if (t0 >= ntask) break;
+        const bool valid = t0 + lane < ntask;
+        const int te = tb + min(t0 + lane, ntask - 1);
+        const int2 d = tdesc[te];                      // {start, length} of the list to stream, coalesced
+        const int own_e = tedge[te];                   // the task's own DAG entry
+        const int lo = hs_local_row(B.trpl, nvl, te);  // the host row of this task
+        const int ru = B.set.rpl[lo], a = B.set.rpl[lo + 1] - ru;
+        const bool act = valid && d.y > 0 && a > 0;
+        cnt[lane] = 0u;
+        wave_sync();
+        // word = where the host's row starts in col, word2 = the task's batch lane
+        auto hit = [&](const unsigned long long hm, const int row0, const int owner, const unsigned at, const int kidx, const bool uniform) {
+          if (hm == 0ull) return;  // wave-uniform
+          if (uniform) {  // a tile of one task: its count once (64 atomics on one LDS word would serialise)
+            if (lane == 0) atomicAdd(&cnt[owner], (unsigned)__popcll(hm));
+          }
+          if (__builtin_amdgcn_inverse_ballot_w64(hm)) {
+            atomicAdd(&sup[row0 + (int)at], 1u);
+            atomicAdd(&sup[kidx], 1u);
+            if (!uniform) atomicAdd(&cnt[owner], 1u);
+          }
+        };
+        auto hit1 = [&](const int row0, const int owner, const int at, const int kidx) {
+          if (lane == 0) {
+            atomicAdd(&sup[row0 + at], 1u);
+            atomicAdd(&sup[kidx], 1u);
+            atomicAdd(&cnt[owner], 1u);
+          }
+        };
+        hs_pass<STAGE, kSupTiles>(B.set, L, col, fallback, lane, act ? d.y : 0, d.x, H::salt(lo), ru - eb, a, ru, lane, hit, hit1);
+        wave_sync();
+        const unsigned c = cnt[lane];
+        if (valid && c) atomicAdd(&sup[own_e], c);
+        wave_sync();
+      }
+      __syncthreads();  // the set is rewritten by the next chunk
+    }
+  }
+}
+
+// sum over the entries [first, first + count) of C(t, 2)
+__global__ __launch_bounds__(256) void sup_pairs_kernel(const unsigned *__restrict__ sup, long long first, long long count,
+                                                        unsigned long long *__restrict__ out) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  unsigned long long s = 0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+    const unsigned long long t = (unsigned long long)sup[first + i];
+    s += t * (t - (t ? 1ull : 0ull)) / 2ull;
+  }
+  s = wave_sum_u64(s);
+  if ((threadIdx.x & (GM_WAVE - 1)) == 0 && s) atomicAdd(out, s);
+}
+
+int sup_per_cu(int stage) { return stage <= 1024 ? 5 : 3; }
+hipError_t launch_sup(const MineParams &p, int stage, int grid_blocks, hipStream_t stream) {
+  static_assert(sizeof(SupLds<1024>) * 5 <= 163840, "five workgroups per CU");
+  static_assert(sizeof(SupLds<kTctStageMax>) * 3 <= 163840, "three workgroups per CU");
+  static_assert(sizeof(HsWave) * kWavesPerBlock >= (size_t)kTctStageMax * 2, "fill counters alias the wave scratch");
+  if (p.g.trp == nullptr || p.g.tdesc == nullptr || p.g.tedge == nullptr || p.scratch == nullptr) return hipErrorInvalidValue;
+  const dim3 grid((unsigned)grid_blocks), block(kWavesPerBlock * GM_WAVE);
+  if (stage <= 1024) hipLaunchKernelGGL((sup_kernel<1024>), grid, block, 0, stream, p);
+  else hipLaunchKernelGGL((sup_kernel<kTctStageMax>), grid, block, 0, stream, p);
+  return hipGetLastError();
+}
+hipError_t launch_sup_pairs(const unsigned *sup, long long first, long long count, unsigned long long *out, int cu_count, hipStream_t stream) {
+  if (count <= 0) return hipSuccess;
+  const long long blocks = std::min<long long>((count + 255) / 256, (long long)cu_count * 16);
+  hipLaunchKernelGGL(sup_pairs_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, sup, first, count, out);
+  return hipGetLastError();
+}
+
+}  // namespace gm
+
+// (module warm-up, gm_graph.hip finish_handle: HIP loads the code object of a translation unit when one of its kernels is first launched)
+__global__ void gm_touch_sup_kernel() {}
+void gm_touch_sup() { hipLaunchKernelGGL(gm_touch_sup_kernel, dim3(1), dim3(1), 0, 0); }

@@ -675,11 +675,17 @@ __global__ __launch_bounds__(256) void task_keys_kernel(int nv, long long ne, co
   }
 }
 __global__ __launch_bounds__(256) void task_desc_kernel(long long ne, const int *__restrict__ rp, const int *__restrict__ col,
-                                                         const unsigned long long *__restrict__ sorted, const int *__restrict__ vals, int2 *__restrict__ tdesc) {
+                                                         const unsigned long long *__restrict__ sorted, const int *__restrict__ vals, int2 *__restrict__ tdesc,
+                                                         int *__restrict__ tedge) {
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < ne; t += stride) {
-    if (sorted[t] == ~0ull) { tdesc[t] = make_int2(0, 0); continue; }  // (the out-edges of rows beyond the stage: not tasks)
+    if (sorted[t] == ~0ull) {  // (the out-edges of rows beyond the stage: not tasks)
+      tdesc[t] = make_int2(0, 0);
+      if (tedge) tedge[t] = 0;
+      continue;
+    }
     const int e = (int)(unsigned)(sorted[t] & 0xffffffffull), val = vals[t];
+    if (tedge) tedge[t] = e;
     if (val >= 0 && !(val & (1 << 30))) {  // in-edge task, topological numbering: the source's list beyond this entry
       tdesc[t] = make_int2(e + 1, val);
     } else {
@@ -689,10 +695,16 @@ __global__ __launch_bounds__(256) void task_desc_kernel(long long ne, const int 
     }
   }
 }
-int ensure_tasklists(gm_graph *g) {
-  if (g->d_tdesc || g->ne == 0) return GM_OK;
+int ensure_tasklists(gm_graph *g, bool with_edges) {
+  if ((g->d_tdesc && (g->d_tedge || !with_edges)) || g->ne == 0) return GM_OK;
   std::lock_guard<std::mutex> lk(g->mu);
-  if (g->d_tdesc) return GM_OK;
+  if (g->d_tdesc && (g->d_tedge || !with_edges)) return GM_OK;
+  if (g->d_tdesc) {  // built without the tasks' own entries: once more, with them (the order of the tasks is the same)
+    (void)hipFree(g->d_tdesc);
+    (void)hipFree(g->d_trp);
+    g->d_tdesc = nullptr;
+    g->d_trp = nullptr;
+  }
   SetupTimer timer;
   HIP_TRY(hipSetDevice(g->device));
   const size_t ne = (size_t)g->ne, nv1 = (size_t)g->nv + 1;
@@ -721,18 +733,25 @@ int ensure_tasklists(gm_graph *g) {
   HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, keys.p, sorted.p, vals.p, vals_sorted.p, (int)ne, 0, end_bit));
   HIP_TRY(tmp.reserve(bytes));
   HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.buf.p, bytes, keys.p, sorted.p, vals.p, vals_sorted.p, (int)ne, 0, end_bit));
-  int *trp = nullptr;
+  int *trp = nullptr, *tedge = nullptr;
   int2 *td = nullptr;
   HIP_TRY(hipMalloc(&trp, sizeof(int) * nv1));
   hipError_t e = dev_exclusive_sum(tmp, cnt.p, trp, nv1);
   if (e == hipSuccess) e = hipMalloc(&td, sizeof(int2) * ne);
+  if (e == hipSuccess && with_edges) e = hipMalloc(&tedge, sizeof(int) * ne);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(task_desc_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, g->ne, g->d_rp, g->d_col, sorted.p, vals_sorted.p, td);
+    hipLaunchKernelGGL(task_desc_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, g->ne, g->d_rp, g->d_col, sorted.p, vals_sorted.p, td, tedge);
     e = hipDeviceSynchronize();
   }
-  if (e != hipSuccess) { (void)hipFree(trp); if (td) (void)hipFree(td); return hip_fail(e, "task lists", __FILE__, __LINE__); }
+  if (e != hipSuccess) {
+    (void)hipFree(trp);
+    if (td) (void)hipFree(td);
+    if (tedge) (void)hipFree(tedge);
+    return hip_fail(e, "task lists", __FILE__, __LINE__);
+  }
   g->d_trp = trp;
   g->d_tdesc = td;
+  g->d_tedge = tedge;
   g->setup.table_ms += timer.ms();
   return GM_OK;
 }

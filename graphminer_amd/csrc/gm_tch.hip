@@ -20,7 +20,10 @@
 
 namespace gm {
 
-constexpr int kTchTiles = 4;  // 64-key tiles in flight per wave
+#ifndef GM_TCH_TILES
+#define GM_TCH_TILES 4
+#endif
+constexpr int kTchTiles = GM_TCH_TILES;  // 64-key tiles in flight per wave
 constexpr int kTchOvfCap = 128;
 constexpr unsigned kTchEmpty = 0xffffffffu, kTchMarker = 0xfffffffeu;  // (ids are < 2^31 - 1)
 constexpr unsigned kTchMul = 0x9E3779B1u;

@@ -92,6 +92,32 @@ def test_motif3_rmat22_equals_oracle(rmat_dev):
     assert [sum(p[i] for p in parts) % 2**64 for i in range(2)] == want
 
 
+@pytest.mark.timeout(900)
+def test_hashed_sets_exact_on_many_short_rows():
+    """The hashed (row, id) sets of the task-list kernels (gm_tch.hip, gm_hset.h) on a LiveJournal-size power-law graph: mean DAG row 9
+    entries, so a chunk holds up to 256 rows and a bucket mixes entries of many rows. A set that identifies an entry by its hash
+    REMAINDER alone (not also by where the entry sits in the stage) answers "found" for an id of another row about once per 2^22
+    lookups: on this graph that was +515 diamonds (359,557,900 against 359,557,385). Against the CPU oracle and the per-edge kernels;
+    triangles and 4-cliques three ways."""
+    from graphminer_amd.rmat import powerlaw_csr_device
+
+    sym, _rp, _ci = powerlaw_csr_device(4847571, 43000000, 20000, 2.5, 42, 0)
+    h = sym.download()
+    osym = O.OGraph(h.row_ptr, h.col_idx)
+    want_d = O.diamond(osym)
+    assert SglSolver(sym, "diamond") == want_d                                            # edge supports (gm_sup.hip)
+    assert SglSolver(sym, "diamond", tune=[0, 0, 0, 0, 0, 0, 0x10000000]) == want_d       # one intersection per edge
+    assert SglSolver(sym, "diamond", tune=[0, 0, 0, 0, 0, 0, 0x800000]) == want_d         # supports, fallback lookup
+    dag, odag = sym.orient(), O.orient(osym)
+    want_t = O.tc(odag)
+    assert TCSolver(dag) == want_t and TCSolver(dag, tune=[0, 0, 0, 0, 0, 0, 0x8000000]) == want_t and CliqueSolver(dag, 3) == want_t
+    want_4 = O.clique(odag, 4)
+    assert CliqueSolver(dag, 4) == want_4
+    assert CliqueSolver(dag, 4, tune=[0, 0, 0, 0, 0, 0, 0x40000]) == want_4               # the mining kernel's arena path
+    assert CliqueSolver(dag, 4, tune=[0, 0, 0, 0, 0, 0, 0x800000]) == want_4              # the build's set on its fallback lookup
+    assert MotifSolver(sym, 3, formula=True) == MotifSolver(sym, 3)
+
+
 @pytest.mark.timeout(1500)
 def test_graph_of_more_than_2e31_entries():
     """the reference's offsets are int64 (include/common.h:37) and its README tables run twitter40 (2.4 G entries) and

@@ -119,6 +119,15 @@ def test_diamond_matches_reference(gg):
     assert total == GOLDEN[name]["diamond"]
     assert st.tasks == sym.E() // 2
     assert SglSolver(sym, "diamond", tune=[128, 2, 0, 0, 0, 1]) == GOLDEN[name]["diamond"]
+    # one GPU, default: edge supports from the triangles of the DAG (gm_sup.hip), then sum C(t, 2); 0x10000000: one intersection of the
+    # two symmetric lists per edge (what several ranks run); 0x800000: the supports' hashed set on its global-memory fallback lookup;
+    # 0x200: the DAG as numbered; 0x1000: heavy chunks cut into parts
+    P = 0x10000000
+    total, st = SglSolver(sym, "diamond", tune=[0, 0, 0, 0, 0, 0, P], return_stats=True)
+    assert total == GOLDEN[name]["diamond"] and st.tasks == sym.E() // 2
+    for t6 in (0x800000, 0x200, 0x1000, 0x200 | 0x1000, 0x4000, P | 0x1000, P | 0x4000):
+        assert SglSolver(sym, "diamond", tune=[0, 0, 0, 0, 0, 0, t6]) == GOLDEN[name]["diamond"], hex(t6)
+    assert SglSolver(sym, "diamond", tune=[64, 1, 0, 0, 0, 0]) == GOLDEN[name]["diamond"]
 
 
 @pytest.mark.parametrize("pattern", ["rectangle", "house", "pentagon"])
@@ -607,6 +616,7 @@ def test_hub_paths_against_oracle_rmat16(dev):
                  [0, 0, 0, 0, 0, 0, 0x100000 | 0x400000], [0, 0, 0, 0, 0, 0, 0x100000 | 0x400000 | 0x1000], [0, 0, 0, 0, 0, 0, 0x100000 | 0x800000],
                  [0, 0, 0, 0, 0, 0, 0x100000 | 0x2000000]):  # (0x2000000: the hash with the 32-bit multiply of id spaces > 2^24)
         assert SglSolver(s, "diamond", tune=tune) == want_d
+        assert SglSolver(s, "diamond", tune=(tune + [0])[:6] + [(tune + [0] * 7)[6] | 0x10000000]) == want_d  # (the per-edge kernels on one GPU)
         assert MotifSolver(s, 3, tune=tune) == want_m3
     assert sum(SglSolver(s, "diamond", rank=r, world=8) for r in range(8)) == want_d
     assert sum(SglSolver(s, "diamond", rank=r, world=8, tune=[0, 0, 0, 0, 0, 0, G]) for r in range(8)) == want_d
