@@ -66,7 +66,7 @@ KERNELS = {
     "tc": ["mine_kernel<0,", "tct_kernel", "tch_kernel"],   # (tch_kernel: the shorter list of every edge streamed against a hashed set, gm_tch.hip)
     # general kernel <P, 0> (+ the sorted-copy classes <P, 1>, <P, 2>), the hashed-row classes and the kernel of the giant rows
     # (one GPU: edge supports from the DAG's triangles, gm_sup.hip; several ranks: the per-edge kernels)
-    "diamond": ["sup_kernel", "sup_pairs_kernel", "mine_kernel<1,", "hrow_kernel<1,", "giant_kernel<1,"],
+    "diamond": ["gm::sup_kernel", "gm::sup_pairs_kernel", "mine_kernel<1,", "hrow_kernel<1,", "giant_kernel<1,"],
     "motif3": ["mine_kernel<2,", "hrow_kernel<2,", "giant_kernel<2,"],
     "clique4": ["mine_kernel<3,", "cbuild_kernel", "clique_count_kernel", "clique_small_kernel"],
     "clique5": ["mine_kernel<4,"],
@@ -208,14 +208,17 @@ TRIM_MIN_LIST = 128    # 3-motif: partner lists of >= 128 keys are trimmed to th
 CB_MIN_DEG, CB_MAX_DEG = 3, 2048  # 4-clique (gm_mine.h kCbMinDeg / kCbMaxDeg): the DAG rows that own a bit-matrix in the arena
 
 
-def own_bytes_device(workload, bg):
+def own_bytes_device(workload, bg, world=1):
     """OWN-ALGORITHM bytes of one launch over the whole graph: what THIS library's kernels must move by
     construction -- the keys they stream, the task descriptors, every row staged / hashed once, the offsets, the k-clique arena
     written and read once -- exact, with torch on the GPU. `roofline.achieved` = this / kernel time, so `frac` <= 1 by construction
     (SURVEY 8(d)'s figure, which charges the reference's loop nest, is kept beside it as `algorithmic_*`).
       tc       4*sum_e min'(d+(u), d+(v)) + 12|E+| + 8(nv+1)       (min': the longer list hosts -- a row > 2048 entries hosts nothing -- and an
                in-edge task streams only the part of N+(u) beyond v: the library numbers the DAG topologically)
-      diamond  4*sum_{undirected e} min(d(u), d(v)) + 12*ne + 8(nv+1)
+      diamond  one GPU (edge supports from the DAG's triangles, gm_sup.hip): the tc figure + 20|E+| + 4 T  (4 B per task for its own entry,
+               the support array zeroed, read once, and added to once per task and once per staged entry: 4 x 4|E+|; one 4-byte atomic
+               per triangle for the streamed edge; T = triangles, from the library's own count)
+               several ranks (one intersection per edge): 4*sum_{undirected e} min(d(u), d(v)) + 12*ne + 8(nv+1)
       motif3   the same with the streamed list trimmed to its keys < max(u, v) when it has >= 128 keys
       clique4  4*sum_e min''(d+(u), d+(v)) + 16*tasks + 4|E+| + 16(nv+1) + 8*arena words   (min'': the longer list hosts when it fits the
                stage; an in-edge task streams only N+(u) beyond v -- the numbering is topological; rows with d+ < 3 own no matrix)
@@ -267,6 +270,17 @@ def own_bytes_device(workload, bg):
         return {"bytes": 4 * k + 16 * tasks + 4 * ne + 16 * (nv + 1) + 8 * arena_words, "streamed_keys": k,
                 "parts": {"streamed_keys_x4": 4 * k, "task_records_x16": 16 * tasks, "rows_staged_once": 4 * ne, "offsets": 16 * (nv + 1),
                           "arena_words_written_and_read_x8": 8 * arena_words}}
+    if workload == "diamond" and world <= 1:
+        dag = bg.dag()
+        if dag.get_max_degree() <= TCT_STAGE_MAX:  # (longer DAG rows: the library takes the per-edge kernels, below)
+            from graphminer_amd import TCSolver
+
+            del src, dst
+            tcp = own_bytes_device("tc", bg)
+            tri = int(TCSolver(dag))
+            nd = int(dag.E())
+            return {"bytes": tcp["bytes"] + 20 * nd + 4 * tri, "streamed_keys": tcp["streamed_keys"],
+                    "parts": dict(tcp["parts"], own_entry_per_task_x4=4 * nd, supports_zeroed_read_added_x16=16 * nd, streamed_edge_atomics_x4=4 * tri)}
     if workload in ("diamond", "motif3"):
         ne = int(ci.numel())
         und = dst < src  # every undirected edge once
@@ -748,8 +762,12 @@ def finish_record(rec, a, world, ab, floor, traffic, traffic_src, cpu, known, st
     if stream_gbs and roof.get("achieved"):
         roof["frac_of_stream_ceiling"] = round(roof["achieved"] / stream_gbs, 5)
     if rec["workload"] in ("tc", "motif3f"):
-        roof["note"] = ("tct_kernel streams the SHORTER list of every DAG edge (sum min(d+(u), d+(v)) keys; the section-8(d) formula charges N+(u) and N+(v) "
-                        "per edge)")
+        roof["note"] = ("tch_kernel streams the SHORTER list of every DAG edge against the longer one kept as a hashed set in LDS (sum min(d+(u), d+(v)) "
+                        "keys; the section-8(d) formula charges N+(u) and N+(v) per edge)")
+    elif rec["workload"] == "diamond" and world <= 1:
+        roof["note"] = ("one GPU: |N(u) ^ N(v)| of every edge = its triangles, counted in ONE pass over the triangles of the DAG (sup_kernel: the triangle "
+                        "kernel with three increments per match), then sum C(t, 2); the section-8(d) formula charges one intersection of the symmetric "
+                        "lists per edge. A device-scope atomic moves a 64-byte fabric transaction for its 4 bytes: counter traffic is well above the own bytes")
     elif rec["workload"] in ("diamond", "motif3"):
         roof["note"] = "rows > 1024 entries are hashed sets in LDS (gm_hrow.hip): every partner list is fetched about once"
     if rec["nv"] * 8 + rec["ne_sym"] * 4 <= (256 << 20):
@@ -820,7 +838,7 @@ def main():
         rec.update({"id": cid, "config": desc, "graph": bg.name, "input_build_s": bg.build_s})
         if rank == 0:
             bytes_of[w] = alg_bytes_device(w, bg, r.lib, rec["g"])
-            own_of[w] = own_bytes_device(w, bg)
+            own_of[w] = own_bytes_device(w, bg, r.world)
         recs.append(rec)
 
     out = None

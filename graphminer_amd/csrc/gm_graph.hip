@@ -47,13 +47,17 @@ extern "C" int gm_device_count(int *n) {
 extern "C" int gm_graph_setup_times(const gm_graph *g, gm_setup_times *out) {
   if (!g || !out) return GM_ERR_INVALID;
   *out = g->setup;
-  // cached derived handles report through their owner
+  // cached derived handles (the oriented copy, renumbered copies -- and theirs) report through their owner
   for (const gm_graph *r : {g->dag_cache, g->relabel_cache[0], g->relabel_cache[1], g->relabel_cache[2]})
     if (r) {
-      out->orient_ms += r->setup.orient_ms;
-      out->table_ms += r->setup.table_ms;
-      out->bitmap_ms += r->setup.bitmap_ms;
-      out->other_ms += r->setup.other_ms;
+      gm_setup_times t;
+      const int rc = gm_graph_setup_times(r, &t);
+      if (rc) return rc;
+      out->orient_ms += t.orient_ms;
+      out->table_ms += t.table_ms;
+      out->bitmap_ms += t.bitmap_ms;
+      out->relabel_ms += t.relabel_ms;
+      out->other_ms += t.other_ms;
     }
   return GM_OK;
 }

@@ -106,12 +106,16 @@ def test_bench_traffic_of_a_rank_share_on_one_gpu():
     import bench
 
     a = argparse.Namespace(seed=42, scale=14, ef=8, graph="", data_dir="", uniform="", powerlaw="", tune="", policy=0, share_rank=0, share_world=1)
-    whole, src = bench.measure_traffic(a, ["tc", "diamond"])
+    # (diamond runs another algorithm on one GPU -- edge supports -- than a rank of four does: its two figures are both checked for
+    # being there, not against each other)
+    whole, src = bench.measure_traffic(a, ["tc", "motif3", "diamond"])
     assert whole, src
-    share, src = bench.measure_traffic(a, ["tc", "diamond"], share=(0, 4))
+    share, src = bench.measure_traffic(a, ["tc", "motif3", "diamond"], share=(0, 4))
     assert share and "share of rank 0 of 4" in src, src
-    for w in ("tc", "diamond"):
+    for w in ("tc", "motif3"):
         assert 0 < share[w]["fetch_bytes"] < whole[w]["fetch_bytes"], (w, share[w], whole[w])
+    assert share["diamond"]["fetch_bytes"] > 0 and whole["diamond"]["fetch_bytes"] > 0
+    assert any("gm::sup_kernel" in k for k in whole["diamond"]["kernels"]) and not any("gm::sup_kernel" in k for k in share["diamond"]["kernels"])
 
 
 def test_algorithmic_bytes_on_the_device_equal_the_oracle():
@@ -164,7 +168,7 @@ def test_own_algorithm_bytes_equal_a_brute_force_count():
             row = hci[hrp[s]:hrp[s + 1]]
             km += int(np.searchsorted(row, max(u, v))) if n >= bench.TRIM_MIN_LIST else n
     ne = hci.size
-    assert bench.own_bytes_device("diamond", bg)["bytes"] == 4 * kd + 12 * ne + 8 * (nv + 1)
+    assert bench.own_bytes_device("diamond", bg, 2)["bytes"] == 4 * kd + 12 * ne + 8 * (nv + 1)  # (several ranks: one intersection per edge)
     assert bench.own_bytes_device("motif3", bg)["bytes"] == 4 * km + 12 * ne + 8 * (nv + 1) and km < kd
     # DAG patterns
     d = bg.dag().download()
@@ -185,6 +189,13 @@ def test_own_algorithm_bytes_equal_a_brute_force_count():
     assert dp.max() > 64 and tasks > 0 and kt < int(np.minimum(dp[np.repeat(np.arange(nv), dp)], dp[dci]).sum()), "the graph must have long DAG rows for this check to mean something"
     nd = dci.size
     assert bench.own_bytes_device("tc", bg)["bytes"] == 4 * int(kt) + 12 * nd + 8 * (nv + 1)
+    # diamond on one GPU: edge supports from the triangles of the DAG (gm_sup.hip)
+    tri = 0
+    for u in range(nv):
+        ru = set(dci[drp[u]:drp[u + 1]].tolist())
+        for v in dci[drp[u]:drp[u + 1]]:
+            tri += len(ru.intersection(dci[drp[v]:drp[v + 1]].tolist()))
+    assert bench.own_bytes_device("diamond", bg)["bytes"] == 4 * int(kt) + 12 * nd + 8 * (nv + 1) + 20 * nd + 4 * tri
     own = dp[(dp >= bench.CB_MIN_DEG) & (dp <= bench.CB_MAX_DEG)].astype(np.int64)
     arena = int((own * ((own + 31) // 32)).sum())
     assert bench.own_bytes_device("clique4", bg)["bytes"] == 4 * int(kc) + 16 * tasks + 4 * nd + 16 * (nv + 1) + 8 * arena
