@@ -48,6 +48,7 @@ WORKLOADS = {
     "diamond": (22, 10, False, "sgl diamond, LiveJournal stand-in"),
     "clique4": (22, 28, True, "4-clique, com-Orkut stand-in"),
     "motif3": (24, 16, False, "3-motif, R-MAT scale 24"),
+    "motif3e": (24, 16, False, "3-motif, per-edge enumeration (automine_3motif's loop nest), R-MAT scale 24"),
     "rectangle": (16, 16, False, "sgl rectangle (4-cycle), R-MAT scale 16"),
     "house": (16, 16, False, "sgl house, R-MAT scale 16"),
     "pentagon": (16, 16, False, "sgl pentagon, R-MAT scale 16"),
@@ -67,7 +68,9 @@ KERNELS = {
     # general kernel <P, 0> (+ the sorted-copy classes <P, 1>, <P, 2>), the hashed-row classes and the kernel of the giant rows
     # (one GPU: edge supports from the DAG's triangles, gm_sup.hip; several ranks: the per-edge kernels)
     "diamond": ["gm::sup_kernel", "gm::sup_pairs_kernel", "mine_kernel<1,", "hrow_kernel<1,", "giant_kernel<1,"],
-    "motif3": ["mine_kernel<2,", "hrow_kernel<2,", "giant_kernel<2,"],
+    # (gm_motif, k = 3: the triangles of the DAG + wedges = sum C(d,2) - 3T; "motif3e": one bounded intersection per edge of the symmetric graph)
+    "motif3": ["mine_kernel<0,", "tct_kernel", "tch_kernel"],
+    "motif3e": ["mine_kernel<2,", "hrow_kernel<2,", "giant_kernel<2,"],
     "clique4": ["mine_kernel<3,", "cbuild_kernel", "clique_count_kernel", "clique_small_kernel"],
     "clique5": ["mine_kernel<4,"],
     "motif3f": ["mine_kernel<0,", "tct_kernel", "tch_kernel"],
@@ -197,7 +200,7 @@ def alg_bytes_device(workload, bg, lib, g):
     dv = int(deg[ci.long()].sum().item())  # sum_e d(dst)
     if workload == "diamond":  # edges v1 < v0 only: by symmetry exactly half of sum_e (d(v0)+d(v1))
         return 4 * (sq + dv) // 2 + 40 * (ne // 2), floor
-    if workload == "motif3":  # one difference per directed edge + one intersect per v1 < v0 edge
+    if workload in ("motif3", "motif3e"):  # one difference per directed edge + one intersect per v1 < v0 edge
         return 4 * (sq + dv) + 4 * (sq + dv) // 2 + 40 * ne, floor
     return None, floor
 
@@ -219,7 +222,8 @@ def own_bytes_device(workload, bg, world=1):
                the support array zeroed, read once, and added to once per task and once per staged entry: 4 x 4|E+|; one 4-byte atomic
                per triangle for the streamed edge; T = triangles, from the library's own count)
                several ranks (one intersection per edge): 4*sum_{undirected e} min(d(u), d(v)) + 12*ne + 8(nv+1)
-      motif3   the same with the streamed list trimmed to its keys < max(u, v) when it has >= 128 keys
+      motif3   the tc figure (gm_motif k = 3 counts the triangles of the DAG; wedges = sum C(d,2) - 3T)
+      motif3e  (per-edge enumeration) diamond's several-ranks figure with the streamed list trimmed to its keys < max(u, v) when it has >= 128 keys
       clique4  4*sum_e min''(d+(u), d+(v)) + 16*tasks + 4|E+| + 16(nv+1) + 8*arena words   (min'': the longer list hosts when it fits the
                stage; an in-edge task streams only N+(u) beyond v -- the numbering is topological; rows with d+ < 3 own no matrix)
     Returns {"bytes", "streamed_keys", "parts"} or None."""
@@ -230,7 +234,7 @@ def own_bytes_device(workload, bg, world=1):
     deg = rp[1:] - rp[:-1]
     src = torch.repeat_interleave(torch.arange(nv, device=rp.device), deg)
     dst = ci.long()
-    if workload in ("tc", "motif3f", "clique4"):
+    if workload in ("tc", "motif3", "motif3f", "clique4"):  # (motif3 = the triangle kernel on the DAG + a closed form)
         keep = (deg[dst] > deg[src]) | ((deg[dst] == deg[src]) & (dst > src))  # graph.cc:246-247
         s2, d2 = src[keep], dst[keep]
         del src, dst, keep
@@ -281,7 +285,7 @@ def own_bytes_device(workload, bg, world=1):
             nd = int(dag.E())
             return {"bytes": tcp["bytes"] + 20 * nd + 4 * tri, "streamed_keys": tcp["streamed_keys"],
                     "parts": dict(tcp["parts"], own_entry_per_task_x4=4 * nd, supports_zeroed_read_added_x16=16 * nd, streamed_edge_atomics_x4=4 * tri)}
-    if workload in ("diamond", "motif3"):
+    if workload in ("diamond", "motif3e"):
         ne = int(ci.numel())
         und = dst < src  # every undirected edge once
         u, v = src[und], dst[und]
@@ -290,7 +294,7 @@ def own_bytes_device(workload, bg, world=1):
         u_longer = (a > b) | ((a == b) & (u > v))  # sym_hosts (gm_mine.h): the longer row hosts, the shorter list is streamed
         short = torch.where(u_longer, v, u)
         slen = torch.where(u_longer, b, a)
-        if workload == "motif3":
+        if workload == "motif3e":
             hi = torch.maximum(u, v)
             keys = torch.repeat_interleave(torch.arange(nv, device=rp.device), deg) * (1 << 32) + ci.long()  # the CSR as sorted (row, id) keys
             below = torch.searchsorted(keys, short * (1 << 32) + hi) - rp[short]  # keys of N(short) below max(u, v)
@@ -379,6 +383,9 @@ class Runner:
                 rc = lib.gm_clique(g.handle, int(workload[-1]), C.byref(la), None, C.byref(st))
             elif workload == "motif3f":
                 rc = lib.gm_motif_formula(g.handle, 3, C.byref(la), None, 2, C.byref(st))
+            elif workload == "motif3e":
+                la.tune[6] |= 0x10000000
+                rc = lib.gm_motif(g.handle, 3, C.byref(la), None, 2, C.byref(st))
             else:
                 rc = lib.gm_motif(g.handle, 3, C.byref(la), None, 2, C.byref(st))
             self._lib.check(rc, "bench step")
@@ -761,14 +768,14 @@ def finish_record(rec, a, world, ab, floor, traffic, traffic_src, cpu, known, st
                      "frac_basis": "no counter traffic available and the algorithmic formula exceeds the peak: not a roofline"})
     if stream_gbs and roof.get("achieved"):
         roof["frac_of_stream_ceiling"] = round(roof["achieved"] / stream_gbs, 5)
-    if rec["workload"] in ("tc", "motif3f"):
+    if rec["workload"] in ("tc", "motif3", "motif3f"):
         roof["note"] = ("tch_kernel streams the SHORTER list of every DAG edge against the longer one kept as a hashed set in LDS (sum min(d+(u), d+(v)) "
                         "keys; the section-8(d) formula charges N+(u) and N+(v) per edge)")
     elif rec["workload"] == "diamond" and world <= 1:
         roof["note"] = ("one GPU: |N(u) ^ N(v)| of every edge = its triangles, counted in ONE pass over the triangles of the DAG (sup_kernel: the triangle "
                         "kernel with three increments per match), then sum C(t, 2); the section-8(d) formula charges one intersection of the symmetric "
                         "lists per edge. A device-scope atomic moves a 64-byte fabric transaction for its 4 bytes: counter traffic is well above the own bytes")
-    elif rec["workload"] in ("diamond", "motif3"):
+    elif rec["workload"] in ("diamond", "motif3e"):
         roof["note"] = "rows > 1024 entries are hashed sets in LDS (gm_hrow.hip): every partner list is fetched about once"
     if rec["nv"] * 8 + rec["ne_sym"] * 4 <= (256 << 20):
         roof["mall_note"] = ("the CSR fits the 256 MiB Infinity Cache: FETCH_SIZE counts MALL hits too (MI355X_MICROARCH.md), so `traffic` here is "
@@ -886,15 +893,18 @@ def main():
                                 known_answer(a, x["workload"], x["graph"]), stream_gbs, own_of.get(x["workload"]))
             sub = {"id": x["id"], "config": x["config"], **sub, "input_build_s": round(x["input_build_s"], 2)}
             if x["workload"] == "motif3" and isinstance(x["count"], list) and not a.scale:
-                # the reference's OTHER 3-motif solver (motif_omp_formula / motif_gpu_formula, src/motif/omp_formula.cc:39-46):
-                # enumerate only the triangles (TC kernel on the oriented graph), derive the wedges -- same counts, reported beside
-                # the enumeration form that the config names
+                # gm_motif (k = 3) takes the reference's formula solver (motif_omp_formula / motif_gpu_formula, src/motif/omp_formula.cc:39-46:
+                # the triangles of the oriented graph, wedges derived). The ENUMERATION form (automine_3motif: one bounded intersection of
+                # the symmetric lists per edge, tune[6] & 0x10000000) is measured beside it: same counts
                 try:
-                    f = r.run("motif3f", graphs["motif3"], max(2, min(a.steps, 5)), 1, solo=True)  # (rank 0 alone: no collective here)
-                    sub["formula_variant"] = {"kernel_ms_avg": round(f["kernel_ms_avg"], 4), "n_gpus": 1, "counts_equal": bool(f["count"] == x["count"]),
-                                              "note": "gm_motif_formula: TC on the cached DAG + sum_v C(d,2) - 3T"}
+                    f = r.run("motif3e", graphs["motif3"], max(2, min(a.steps, 5)), 1, solo=True)  # (rank 0 alone: no collective here)
+                    own_e = own_bytes_device("motif3e", graphs["motif3"])
+                    sub["per_edge_variant"] = {"kernel_ms_avg": round(f["kernel_ms_avg"], 4), "n_gpus": 1, "counts_equal": bool(f["count"] == x["count"]),
+                                               "own_bytes_per_launch": own_e["bytes"] if own_e else None,
+                                               "frac": round(own_e["bytes"] / (f["kernel_ms_avg"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if own_e else None,
+                                               "note": "gm_motif with tune[6] & 0x10000000: hub rows as hashed sets in LDS, partner lists streamed (gm_hrow.hip)"}
                 except Exception as e:  # a report, never a reason to lose the line
-                    sub["formula_variant"] = {"error": str(e)}
+                    sub["per_edge_variant"] = {"error": str(e)}
             if x["workload"] == "motif3" and isinstance(x["count"], list):
                 # size-independent identity, checked in the run: wedges = sum_v C(d,2) - 3T  (automine_formula.h:2-19)
                 bg = graphs["motif3"]

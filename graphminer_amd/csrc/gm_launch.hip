@@ -1300,9 +1300,19 @@ extern "C" int gm_motif(const gm_graph *sym, int k, const gm_launch *la, uint64_
   }
   if (k != 3) return GM_ERR_INVALID;
   if (ncounts < 2) return GM_ERR_INVALID;
-  // a graph of 2^31 entries or more: through the reference's OTHER 3-motif solver (motif_omp_formula, src/motif/omp_formula.cc:39-46:
-  // triangles on the oriented graph, wedges = sum C(d,2) - 3T) -- same counts, and the oriented graph fits the 32-bit task index
-  if (sym && sym->d_rp64) return gm_motif_formula(sym, k, la, counts, ncounts, st);
+  // Default: the reference's OTHER 3-motif solver (motif_omp_formula / motif_gpu_formula, src/motif/omp_formula.cc:39-46: the triangles
+  // of the oriented graph, wedges = sum C(d,2) - 3T) -- the same two counts from 1/4 of the streamed keys, and the only form a graph
+  // of 2^31 entries or more fits (its oriented copy has a 32-bit task index).  tune[6] & 0x10000000, or one of the A/B switches of
+  // the per-edge kernels: automine_3motif's enumeration (src/motif/cpu_kernels/automine_base.h:2-22), one bounded intersection of the
+  // two symmetric lists per edge (gm_hrow.hip, gm_chunk.h).
+  const int t6 = la ? la->tune[6] : 0;
+  const bool per_edge = ((t6 & (0x10000000 | 0x80000 | 0x100000 | 0x400000 | 0x1000000 | 0x2000000)) || (la && la->tune[5] == 1) ||
+                         getenv("GM_MOTIF3_PER_EDGE")) && !(sym && sym->d_rp64);
+  if (!per_edge) {
+    const int rc = gm_motif_formula(sym, k, la, counts, ncounts, st);
+    if (rc == GM_OK && st) st->tasks *= 2;  // (the graph's directed entries, as the enumeration reports them: two per task edge of the DAG)
+    return rc;
+  }
   return run_pattern(PAT_MOTIF3, sym, la, 3, counts, ncounts, st);
 }
 

@@ -41,3 +41,13 @@ def random_graph(nv, ne_target, seed):
     s = rng.integers(0, nv, ne_target).astype(np.uint64)
     d = rng.integers(0, nv, ne_target).astype(np.uint64)
     return csr_from_pairs(nv, s, d)
+
+
+def MotifSolverE(g, k, tune=None, **kw):
+    """k-motif through the ENUMERATION kernels (tune[6] & 0x10000000: automine_3motif's loop nest, one bounded intersection per edge of
+    the symmetric graph); gm_motif's default for k = 3 is the reference's formula solver (triangles of the DAG, wedges derived)"""
+    from graphminer_amd import MotifSolver
+
+    t = (list(tune or []) + [0] * 7)[:7]
+    t[6] |= 0x10000000
+    return MotifSolver(g, k, tune=t, **kw)

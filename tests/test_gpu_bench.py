@@ -169,7 +169,7 @@ def test_own_algorithm_bytes_equal_a_brute_force_count():
             km += int(np.searchsorted(row, max(u, v))) if n >= bench.TRIM_MIN_LIST else n
     ne = hci.size
     assert bench.own_bytes_device("diamond", bg, 2)["bytes"] == 4 * kd + 12 * ne + 8 * (nv + 1)  # (several ranks: one intersection per edge)
-    assert bench.own_bytes_device("motif3", bg)["bytes"] == 4 * km + 12 * ne + 8 * (nv + 1) and km < kd
+    assert bench.own_bytes_device("motif3e", bg)["bytes"] == 4 * km + 12 * ne + 8 * (nv + 1) and km < kd  # (the enumeration kernels)
     # DAG patterns
     d = bg.dag().download()
     drp, dci = d.row_ptr, d.col_idx
@@ -189,6 +189,7 @@ def test_own_algorithm_bytes_equal_a_brute_force_count():
     assert dp.max() > 64 and tasks > 0 and kt < int(np.minimum(dp[np.repeat(np.arange(nv), dp)], dp[dci]).sum()), "the graph must have long DAG rows for this check to mean something"
     nd = dci.size
     assert bench.own_bytes_device("tc", bg)["bytes"] == 4 * int(kt) + 12 * nd + 8 * (nv + 1)
+    assert bench.own_bytes_device("motif3", bg) == bench.own_bytes_device("tc", bg)  # gm_motif, k = 3: the triangles of the DAG + a closed form
     # diamond on one GPU: edge supports from the triangles of the DAG (gm_sup.hip)
     tri = 0
     for u in range(nv):
@@ -202,7 +203,7 @@ def test_own_algorithm_bytes_equal_a_brute_force_count():
     bg.free()
 
 
-@pytest.mark.parametrize("workload", ["diamond", "clique4", "motif3", "rectangle", "house"])
+@pytest.mark.parametrize("workload", ["diamond", "clique4", "motif3", "motif3e", "rectangle", "house"])
 def test_bench_other_workloads_run(workload):
     d = run_bench("--workload", workload, "--scale", "12", "--ef", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--traffic", "off")
     assert d["value"] > 0 and d["config"]["workload"].startswith(workload)

@@ -10,7 +10,7 @@ import time
 import pytest
 
 import oracle as O
-from common import GOLDEN
+from common import GOLDEN, MotifSolverE
 from graphminer_amd import CliqueSolver, Graph, MotifSolver, SglSolver, TCSolver
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("GM_SKIP_FULLSIZE") == "1", reason="GM_SKIP_FULLSIZE=1")]
@@ -80,15 +80,15 @@ def test_motif3_rmat22_equals_oracle(rmat_dev):
     t = time.perf_counter()
     want = O.motif3(osym)
     print(f"oracle 3-motif R-MAT-22 ef16: {time.perf_counter() - t:.1f} s on {O.num_threads()} threads")
-    got, st = MotifSolver(sym, 3, return_stats=True)
+    got, st = MotifSolverE(sym, 3, return_stats=True)
     assert got == want
     assert st.tasks == osym.ne
-    assert MotifSolver(sym, 3, formula=True) == want
-    assert MotifSolver(sym, 3, tune=[0, 0, 0, 0, 0, 0, 0x100000]) == want  # with the workgroup classes (hashed rows, id-range bitmaps: 4 ranges)
-    assert MotifSolver(sym, 3, tune=[0, 0, 0, 0, 0, 0, 0x100000 | 0x400000 | 0x1000000]) == want  # sorted-copy classes, SPLIT giants
-    assert MotifSolver(sym, 3, tune=[0, 0, 0, 0, 0, 0, 0x100000 | 0x800000]) == want  # hashed-row kernels on their fallback lookup
+    assert MotifSolver(sym, 3, formula=True) == want and MotifSolver(sym, 3) == want
+    assert MotifSolverE(sym, 3, tune=[0, 0, 0, 0, 0, 0, 0x100000]) == want  # with the workgroup classes (hashed rows, id-range bitmaps: 4 ranges)
+    assert MotifSolverE(sym, 3, tune=[0, 0, 0, 0, 0, 0, 0x100000 | 0x400000 | 0x1000000]) == want  # sorted-copy classes, SPLIT giants
+    assert MotifSolverE(sym, 3, tune=[0, 0, 0, 0, 0, 0, 0x100000 | 0x800000]) == want  # hashed-row kernels on their fallback lookup
     assert SglSolver(sym, "diamond", tune=[0, 0, 0, 0, 0, 0, 0x100000]) == SglSolver(sym, "diamond", tune=[0, 0, 0, 0, 0, 0, 0x80000])
-    parts = [MotifSolver(sym, 3, rank=r, world=8) for r in range(8)]
+    parts = [MotifSolverE(sym, 3, rank=r, world=8) for r in range(8)]
     assert [sum(p[i] for p in parts) % 2**64 for i in range(2)] == want
 
 
@@ -115,7 +115,7 @@ def test_hashed_sets_exact_on_many_short_rows():
     assert CliqueSolver(dag, 4) == want_4
     assert CliqueSolver(dag, 4, tune=[0, 0, 0, 0, 0, 0, 0x40000]) == want_4               # the mining kernel's arena path
     assert CliqueSolver(dag, 4, tune=[0, 0, 0, 0, 0, 0, 0x800000]) == want_4              # the build's set on its fallback lookup
-    assert MotifSolver(sym, 3, formula=True) == MotifSolver(sym, 3)
+    assert MotifSolver(sym, 3, formula=True) == MotifSolver(sym, 3) == MotifSolverE(sym, 3)
 
 
 @pytest.mark.timeout(1500)
@@ -141,7 +141,7 @@ def test_graph_of_more_than_2e31_entries():
     assert dag.E() * 2 == sym.E() and dag.E() < 2**31
     tc = TCSolver(dag)
     assert CliqueSolver(dag, 3) == tc > 0
-    wedges, tri = MotifSolver(sym, 3)
+    wedges, tri = MotifSolverE(sym, 3)
     deg = rp[1:] - rp[:-1]
     c2 = int((deg * (deg - 1) // 2).sum().item())
     assert tri == tc and wedges == c2 - 3 * tc

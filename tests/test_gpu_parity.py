@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import oracle as O
-from common import GOLDEN, GRAPH_NAMES, load_graph, random_graph
+from common import GOLDEN, GRAPH_NAMES, MotifSolverE, load_graph, random_graph
 from graphminer_amd import CliqueSolver, DeviceGraph, Graph, MotifSolver, SglSolver, TCSolver, _lib
 from graphminer_amd.rmat import csr_from_pairs, rmat_csr_numpy
 
@@ -88,7 +88,7 @@ def test_tc_matches_reference(gg):
 def test_tc_invariant_under_tuning(gg, tune):
     name, _, sym, dag = gg
     assert TCSolver(dag, tune=tune) == GOLDEN[name]["tc"]
-    assert MotifSolver(sym, 3, tune=tune) == GOLDEN[name]["motif3"]
+    assert MotifSolverE(sym, 3, tune=tune) == GOLDEN[name]["motif3"]
 
 
 def test_heavy_chunks_cut_into_parts(gg):
@@ -217,7 +217,12 @@ def test_algorithmic_bytes_clique4(gg):
 
 def test_motif3_matches_reference(gg):
     name, _, sym, _ = gg
-    assert MotifSolver(sym, 3) == GOLDEN[name]["motif3"]  # [wedges, triangles]: CPU order
+    assert MotifSolverE(sym, 3) == GOLDEN[name]["motif3"]  # [wedges, triangles]: CPU order
+    # gm_motif's default for k = 3 is the formula solver (the triangles of the DAG, wedges derived); it reports the graph's entries as tasks
+    got, st = MotifSolver(sym, 3, return_stats=True)
+    assert got == GOLDEN[name]["motif3"] and st.tasks == sym.E()
+    parts = [MotifSolver(sym, 3, rank=r, world=4) for r in range(4)]
+    assert [sum(p[0] for p in parts) % 2**64, sum(p[1] for p in parts)] == GOLDEN[name]["motif3"]
     # motif_omp_formula variant (src/motif/omp_formula.cc:39-40): identical counts, also when partitioned
     assert MotifSolver(sym, 3, formula=True) == GOLDEN[name]["motif3"]
     parts = [MotifSolver(sym, 3, formula=True, rank=r, world=3) for r in range(3)]
@@ -261,7 +266,7 @@ def test_task_partition_sums_to_the_whole(gg, world, policy):
         tasks += st.tasks
         dia += SglSolver(sym, "diamond", rank=r, world=world, policy=policy)
         k4 += CliqueSolver(dag, 4, rank=r, world=world, policy=policy)
-        m = MotifSolver(sym, 3, rank=r, world=world, policy=policy)
+        m = MotifSolverE(sym, 3, rank=r, world=world, policy=policy)
         m3 = [(m3[0] + m[0]) % 2**64, m3[1] + m[1]]  # per-rank wedge partials are modulo 2^64 (like the uint64 all-reduce)
     assert (tc, dia, k4, m3) == (e["tc"], e["diamond"], e["clique4"], e["motif3"])
     assert tasks == dag.E()
@@ -280,14 +285,14 @@ def test_unsupported_and_invalid_arguments(gg):
 def test_empty_and_tiny_graphs(dev):
     g = Graph(row_ptr=[0, 0, 0, 0], col_idx=[]).to_device(dev)
     d = g.orient()
-    assert TCSolver(d) == 0 and SglSolver(g, "diamond") == 0 and CliqueSolver(d, 4) == 0 and MotifSolver(g, 3) == [0, 0]
+    assert TCSolver(d) == 0 and SglSolver(g, "diamond") == 0 and CliqueSolver(d, 4) == 0 and MotifSolverE(g, 3) == [0, 0]
     # a single edge, a path, a triangle
     for rp, ci, want in [([0, 1, 2], [1, 0], (0, 0, 0, [0, 0])),
                          ([0, 1, 3, 4], [1, 0, 2, 1], (0, 0, 0, [1, 0])),
                          ([0, 2, 4, 6], [1, 2, 0, 2, 0, 1], (1, 0, 0, [0, 1]))]:
         s = Graph(row_ptr=rp, col_idx=ci).to_device(dev)
         o = s.orient()
-        assert (TCSolver(o), SglSolver(s, "diamond"), CliqueSolver(o, 4), MotifSolver(s, 3)) == want
+        assert (TCSolver(o), SglSolver(s, "diamond"), CliqueSolver(o, 4), MotifSolverE(s, 3)) == want
 
 
 @pytest.mark.parametrize("n", [5, 64, 65, 130])
@@ -300,7 +305,7 @@ def test_complete_graph_closed_forms(dev, n):
     for k in ((5, 6, 7, 8) if n <= 65 else (5, 6)):
         assert CliqueSolver(d, k) == math.comb(n, k)
     assert SglSolver(s, "diamond") == math.comb(n, 2) * math.comb(n - 2, 2)
-    assert MotifSolver(s, 3) == [0, math.comb(n, 3)]
+    assert MotifSolverE(s, 3) == [0, math.comb(n, 3)]
 
 
 def test_rows_longer_than_the_lds_staging_capacity(dev):
@@ -311,10 +316,10 @@ def test_rows_longer_than_the_lds_staging_capacity(dev):
     d = s.orient()
     assert d.get_max_degree() == n - 1
     assert TCSolver(d) == math.comb(n, 3)
-    assert MotifSolver(s, 3) == [0, math.comb(n, 3)]
+    assert MotifSolverE(s, 3) == [0, math.comb(n, 3)]
     assert SglSolver(s, "diamond") == math.comb(n, 2) * math.comb(n - 2, 2)
     general = [0, 0, 0, 0, 0, 0, 0x80000]  # (rows > 1024 entries go to the hashed-row class by default; this is the general kernel)
-    assert MotifSolver(s, 3, tune=general) == [0, math.comb(n, 3)]
+    assert MotifSolverE(s, 3, tune=general) == [0, math.comb(n, 3)]
     assert SglSolver(s, "diamond", tune=general) == math.comb(n, 2) * math.comb(n - 2, 2)
     assert CliqueSolver(d, 4) == math.comb(n, 4)
 
@@ -543,10 +548,10 @@ def test_hub_graph_against_oracle(dev):
     s = g.to_device(dev)
     d = s.orient()
     assert TCSolver(d) == O.tc(odag)
-    assert MotifSolver(s, 3) == O.motif3(osym)
+    assert MotifSolverE(s, 3) == O.motif3(osym)
     assert SglSolver(s, "diamond") == O.diamond(osym)
     general = [0, 0, 0, 0, 0, 0, 0x80000]  # (the hub row through the general kernel instead of the hashed-row class)
-    assert MotifSolver(s, 3, tune=general) == O.motif3(osym)
+    assert MotifSolverE(s, 3, tune=general) == O.motif3(osym)
     assert SglSolver(s, "diamond", tune=general) == O.diamond(osym)
     assert CliqueSolver(d, 4) == O.clique(odag, 4)
 
@@ -562,7 +567,7 @@ def test_random_graphs_against_oracle(dev, seed):
     assert SglSolver(s, "diamond") == O.diamond(osym)
     assert CliqueSolver(d, 4) == O.clique(odag, 4)
     assert CliqueSolver(d, 5) == O.clique(odag, 5)
-    assert MotifSolver(s, 3) == O.motif3(osym)
+    assert MotifSolverE(s, 3) == O.motif3(osym)
     if seed == 1:  # the flattened wedge kernels and the 4-motif formula path, against the restated loop nests
         assert SglSolver(s, "rectangle") == O.rectangle(osym)
         assert SglSolver(s, "house") == O.house(osym)
@@ -580,7 +585,7 @@ def test_large_rmat_properties(dev):
     s, rp, ci = rmat_csr_device(18, 16, 42, dev)
     d = s.orient()
     t = TCSolver(d)
-    wedges, tri = MotifSolver(s, 3)
+    wedges, tri = MotifSolverE(s, 3)
     assert tri == t == CliqueSolver(d, 3)
     deg = (rp[1:] - rp[:-1]).cpu().numpy().astype(object)
     assert wedges == int(sum(x * (x - 1) // 2 for x in deg)) - 3 * t
@@ -604,7 +609,7 @@ def test_hub_paths_against_oracle_rmat16(dev):
     s = g.to_device(dev)
     want_d, want_m3 = O.diamond(osym), O.motif3(osym)
     assert SglSolver(s, "diamond") == want_d
-    assert MotifSolver(s, 3) == want_m3
+    assert MotifSolverE(s, 3) == want_m3
     # (default: the workgroup classes take the rows > 1024 entries; 0x80000: every row through the general kernel -- SPLIT chunks, dense
     # bitmaps, the LDS pre-filter; 0x100000: the classes forced on, which is also the default here)
     G = 0x80000
@@ -617,18 +622,18 @@ def test_hub_paths_against_oracle_rmat16(dev):
                  [0, 0, 0, 0, 0, 0, 0x100000 | 0x2000000]):  # (0x2000000: the hash with the 32-bit multiply of id spaces > 2^24)
         assert SglSolver(s, "diamond", tune=tune) == want_d
         assert SglSolver(s, "diamond", tune=(tune + [0])[:6] + [(tune + [0] * 7)[6] | 0x10000000]) == want_d  # (the per-edge kernels on one GPU)
-        assert MotifSolver(s, 3, tune=tune) == want_m3
+        assert MotifSolverE(s, 3, tune=tune) == want_m3
     assert sum(SglSolver(s, "diamond", rank=r, world=8) for r in range(8)) == want_d
     assert sum(SglSolver(s, "diamond", rank=r, world=8, tune=[0, 0, 0, 0, 0, 0, G]) for r in range(8)) == want_d
-    parts = [MotifSolver(s, 3, rank=r, world=3, tune=[0, 0, 0, 0, 0, 0, G]) for r in range(3)]
+    parts = [MotifSolverE(s, 3, rank=r, world=3, tune=[0, 0, 0, 0, 0, 0, G]) for r in range(3)]
     assert [sum(p[i] for p in parts) % 2**64 for i in range(2)] == want_m3
     assert MotifSolver(s, 4, tune=[0, 0, 0, 0, 0, 0, G]) == GOLDEN[g.name]["motif4"]
     assert sum(SglSolver(s, "diamond", rank=r, world=5, tune=[0, 0, 0, 0, 0, 0, 0x100000]) for r in range(5)) == want_d
-    parts = [MotifSolver(s, 3, rank=r, world=4, tune=[0, 0, 0, 0, 0, 0, 0x100000]) for r in range(4)]
+    parts = [MotifSolverE(s, 3, rank=r, world=4, tune=[0, 0, 0, 0, 0, 0, 0x100000]) for r in range(4)]
     assert [sum(p[i] for p in parts) % 2**64 for i in range(2)] == want_m3
     assert MotifSolver(s, 4, tune=[0, 0, 0, 0, 0, 0, 0x100000]) == GOLDEN[g.name]["motif4"]
     assert MotifSolver(s, 4, tune=[0, 0, 0, 0, 0, 0, 0x100000 | 0x400000]) == GOLDEN[g.name]["motif4"]
-    parts = [MotifSolver(s, 3, rank=r, world=3, policy=2) for r in range(3)]
+    parts = [MotifSolverE(s, 3, rank=r, world=3, policy=2) for r in range(3)]
     assert [sum(p[i] for p in parts) % 2**64 for i in range(2)] == want_m3
     # golden.json: tc / motif3 / motif4 of this graph from the reference's tc_omp_base, motif_omp_base, motif_omp_formula
     e = GOLDEN[g.name]
@@ -682,16 +687,16 @@ def test_hashed_row_classes_on_adversarial_ids(dev):
     want_d, want_m3 = O.diamond(osym), O.motif3(osym)
     sd = g.to_device(dev)
     general = [0, 0, 0, 0, 0, 0, 0x80000]
-    assert SglSolver(sd, "diamond", tune=general) == want_d and MotifSolver(sd, 3, tune=general) == want_m3
+    assert SglSolver(sd, "diamond", tune=general) == want_d and MotifSolverE(sd, 3, tune=general) == want_m3
     want_m4 = MotifSolver(sd, 4, tune=general)
     # (0x2000000: the kernels instantiated for id spaces beyond 2^24 -- v_mul_lo_u32 instead of v_mul_u32_u24 in the hash)
     for flags in (0x100000, 0x100000 | 0x800000, 0x100000 | 0x400000, 0x100000 | 0x1000000, 0x100000 | 0x1000, 0x100000 | 0x2000000):
         tune = [0, 0, 0, 0, 0, 0, flags]
         assert SglSolver(sd, "diamond", tune=tune) == want_d, hex(flags)
-        assert MotifSolver(sd, 3, tune=tune) == want_m3, hex(flags)
+        assert MotifSolverE(sd, 3, tune=tune) == want_m3, hex(flags)
         assert MotifSolver(sd, 4, tune=tune) == want_m4, hex(flags)
     assert sum(SglSolver(sd, "diamond", rank=r, world=3, tune=[0, 0, 0, 0, 0, 0, 0x100000]) for r in range(3)) == want_d
-    parts = [MotifSolver(sd, 3, rank=r, world=5, tune=[0, 0, 0, 0, 0, 0, 0x100000]) for r in range(5)]
+    parts = [MotifSolverE(sd, 3, rank=r, world=5, tune=[0, 0, 0, 0, 0, 0, 0x100000]) for r in range(5)]
     assert [sum(p[i] for p in parts) % 2**64 for i in range(2)] == want_m3
 
 
@@ -765,7 +770,7 @@ def test_sort_neighbors_on_the_device(dev):
         assert np.array_equal(back.col_idx, g.col_idx) and np.array_equal(back.row_ptr, g.row_ptr)
         d = s.orient()
         assert TCSolver(d) == GOLDEN[g.name]["tc"]
-        assert MotifSolver(s, 3) == GOLDEN[g.name]["motif3"]
+        assert MotifSolverE(s, 3) == GOLDEN[g.name]["motif3"]
         with pytest.raises(_lib.GraphMinerError):  # (after a solver has built its tables the rows must not move any more)
             s.sort_neighbors()
 
