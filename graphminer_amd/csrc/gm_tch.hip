@@ -24,13 +24,20 @@ namespace gm {
 #define GM_TCH_TILES 4
 #endif
 constexpr int kTchTiles = GM_TCH_TILES;  // 64-key tiles in flight per wave
+// ... in the flattened pass of the short lists, per stage (one group ahead is in flight on top; R-MAT-22 / power law / flat degrees /
+// R-MAT-24 formula 3-motif, ms: 4 tiles 3.02 / 1.08 / 0.86 / 42.9, 8 tiles 3.04 / 1.12 / 0.90 / 42.1 -- the 2048-bucket kernel has the registers for 8)
+constexpr int kTchFlatTilesSmall = 4, kTchFlatTilesBig = 8;
+
 constexpr int kTchOvfCap = 128;
 constexpr unsigned kTchEmpty = 0xffffffffu, kTchMarker = 0xfffffffeu;  // (ids are < 2^31 - 1)
 constexpr unsigned kTchMul = 0x9E3779B1u;
 
+// flattened positions per mark window (a batch of 64 lists below kLongList keys: <= 12224): 8192 beside the 1024-bucket table, 4096
+// beside the 2048-bucket one (the LDS budget of six / four workgroups per CU)
+template <int BITWIN>
 struct alignas(16) TchWave {
-  int2 desc[GM_WAVE];                // per batch lane: {key_base - offset among the flattened positions, salt of the host row}
-  unsigned char marks[kMarkWindow];  // owner marks of the flattened positions
+  int2 desc[GM_WAVE];              // per non-empty list of the batch: {key_base - offset among the flattened positions, salt of the host row}
+  unsigned bits[BITWIN / 32 + 8];  // list-start marks of the flattened positions, one bit each (+ the over-read of the last group)
 };
 
 template <int STAGE>
@@ -38,7 +45,8 @@ struct alignas(16) TchLds {
   uint4 table[STAGE];              // buckets of four ids
   int rpl[kMaxChunkVerts + 1];     // row offsets of the chunk's DAG rows (global entry indices)
   int trpl[kMaxChunkVerts + 1];    // row offsets of its task lists
-  TchWave w[kWavesPerBlock];       // (while the table is built: packed 16-bit fill counters of the buckets)
+  static constexpr int kBitWindow = STAGE <= 1024 ? 8192 : 4096;
+  TchWave<kBitWindow> w[kWavesPerBlock];  // (while the table is built: packed 16-bit fill counters of the buckets)
   int ovf_key[kTchOvfCap];
   int ovf_salt[kTchOvfCap];
   int n_ovf;
@@ -125,9 +133,10 @@ __device__ __forceinline__ unsigned tch_surplus(const TchLds<STAGE> &B, const in
 
 // One batch of tasks: stream the lists (llen_all keys from col[key_base ..), 0 = no task) against the set; returns the matches (wave-uniform).
 template <int STAGE>
-__device__ __forceinline__ unsigned tch_pass(TchLds<STAGE> &B, TchWave &L, const int *__restrict__ col, const bool fallback, const int lane,
+__device__ __forceinline__ unsigned tch_pass(TchLds<STAGE> &B, TchWave<TchLds<STAGE>::kBitWindow> &L, const int *__restrict__ col, const bool fallback, const int lane,
                                              const int llen_all, const int key_base, const unsigned salt_l) {
   constexpr int T = kTchTiles;
+  constexpr int TF = STAGE <= 1024 ? kTchFlatTilesSmall : kTchFlatTilesBig;
   unsigned cnt = 0;
   if (wave_max_nonneg(llen_all) == 0) return 0u;  // wave-uniform
   const bool is_long = llen_all >= kLongList;
@@ -189,66 +198,88 @@ __device__ __forceinline__ unsigned tch_pass(TchLds<STAGE> &B, TchWave &L, const
     }
   }
 
-  // ---- short lists: flattened (owner marks + DPP max-scan; tiles without a list boundary skip the scan) ------------------------------
+  // ---- short lists: flattened.  Position p of the concatenated lists belongs to the LAST list that starts at or before it: every
+  // list but the first of a window leaves one mark BIT at (its start - 1), and the owner of p is the number of marks below p -- one
+  // broadcast 8-byte LDS read and a v_mbcnt pair per tile, a scalar popcount for the carry; a window is 8192 positions (1 KB of
+  // marks), so that -- unlike the 512 byte-marks per window of the other kernels -- a whole batch is usually ONE window and the keys
+  // of the NEXT tile group are requested before the current group is looked up (measured: TF = 8 tiles in flight without the
+  // pipeline R-MAT-22 3.34 -> 3.22 ms) ----------------------------------------------------------------------------------------------
   const int incl = wave_incl_scan_add(llen);
   const int total = readlane(incl, GM_WAVE - 1);
   if (total == 0) return cnt;  // wave-uniform
   const int off = incl - llen;
-  L.desc[lane] = make_int2(key_base - off, (int)salt_l);
-  unsigned *m32 = reinterpret_cast<unsigned *>(L.marks);
-  int carry = 0;
-  for (int wb = 0; wb < total; wb += kMarkWindow) {
-    const int wn = min(kMarkWindow, total - wb);
-    const int nwords = ((wn + GM_WAVE * T - 1) / (GM_WAVE * T)) * (GM_WAVE * T / 4);
-    for (int i = lane; i < nwords; i += GM_WAVE) m32[i] = 0u;
+  const unsigned long long nzm = __ballot(llen > 0);
+  if (llen > 0) L.desc[rank_below(nzm)] = make_int2(key_base - off, (int)salt_l);  // (compacted: the k-th non-empty list)
+  constexpr int G = GM_WAVE * TF, kBitWin = TchLds<STAGE>::kBitWindow;
+  constexpr int TH = 4, NH = TF / TH;  // a group is looked up in halves of four tiles (the 16-byte buckets of eight would not fit the registers)
+  static_assert(TF % TH == 0, "tile groups are made of half-groups of four");
+  struct Grp {
+    int key[NH][TH];
+    unsigned salt[NH][TH];
+    unsigned long long inm[NH][TH];
+  };
+  for (int wb = 0; wb < total; wb += kBitWin) {
+    const int wn = min(kBitWin, total - wb);
+    const int nw = ((wn + G - 1) / G) * (G / 32) + 2;
+    for (int i = lane; i < nw; i += GM_WAVE) L.bits[i] = 0u;
     wave_sync();
-    if (llen > 0 && off >= wb && off < wb + kMarkWindow) L.marks[off - wb] = (unsigned char)(lane + 1);
+    if (llen > 0 && off > wb && off < wb + kBitWin) atomicOr(&L.bits[(off - 1 - wb) >> 5], 1u << ((off - 1 - wb) & 31));
+    int carry = __popcll(__ballot(llen > 0 && off <= wb)) - 1;  // the list that owns position wb
     wave_sync();
-    for (int t = 0; t < wn; t += GM_WAVE * T) {
-      int own[T], key[T];
-      unsigned salt[T];
-      unsigned long long inm[T];
+    auto stage_a = [&](const int g, Grp &r) {  // owners, descriptors, key loads of tile group g of the window
+      int2 d[TF];
+      bool in[TF];
+      // the 2 * TF mark words of the group: one LDS read (lane l holds word l), then two v_readlane per tile
+      const int mw = (int)L.bits[((g * G) >> 5) + (lane & (2 * TF - 1))];
 #pragma unroll
-      for (int q = 0; q < T; ++q) own[q] = (int)L.marks[t + q * GM_WAVE + lane];
+      for (int q = 0; q < TF; ++q) {
+        const unsigned long long m = ((unsigned long long)(unsigned)readlane(mw, 2 * q + 1) << 32) | (unsigned)readlane(mw, 2 * q);
+        const int own = carry + rank_below(m);
+        carry += __popcll(m);
+        in[q] = (wb + g * G + q * GM_WAVE + lane) < total;
+        r.inm[q / TH][q % TH] = __ballot(in[q]);
+        d[q] = L.desc[in[q] ? own : 0];  // unconditional LDS read
+      }
 #pragma unroll
-      for (int q = 0; q < T; ++q) {
-        if (__ballot(own[q] != 0) == 0ull) {
-          own[q] = carry;  // no list starts inside this tile: every position belongs to the running owner
-        } else {
-          own[q] = max(wave_incl_scan_max(own[q]), carry);
-          carry = readlane(own[q], GM_WAVE - 1);
+      for (int q = 0; q < TF; ++q) {
+        r.key[q / TH][q % TH] = col[in[q] ? d[q].x + (wb + g * G + q * GM_WAVE + lane) : 0];  // unconditional load (select on the index)
+        r.salt[q / TH][q % TH] = (unsigned)d[q].y;
+      }
+    };
+    auto stage_b = [&](const Grp &r) {
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        unsigned long long hm[TH], nm[TH];
+        tch_probe<STAGE, TH>(B, col, fallback, r.key[h], r.salt[h], r.inm[h], hm, nm);
+        unsigned long long any_need = 0ull;
+#pragma unroll
+        for (int q = 0; q < TH; ++q) {
+          cnt += (unsigned)__popcll(hm[q]);
+          any_need |= nm[q];
         }
+        if (any_need != 0ull) cnt += tch_surplus<STAGE, TH>(B, lane, r.key[h], r.salt[h], nm);  // rare
       }
-      int2 d[T];
-#pragma unroll
-      for (int q = 0; q < T; ++q) {
-        const bool in = (wb + t + q * GM_WAVE + lane) < total;
-        inm[q] = __ballot(in);
-        d[q] = L.desc[in ? own[q] - 1 : 0];  // unconditional LDS read
-      }
-#pragma unroll
-      for (int q = 0; q < T; ++q) {
-        const bool in = (wb + t + q * GM_WAVE + lane) < total;
-        key[q] = col[in ? d[q].x + (wb + t + q * GM_WAVE + lane) : 0];  // unconditional load (select on the index)
-        salt[q] = (unsigned)d[q].y;
-      }
-      unsigned long long hm[T], nm[T];
-      tch_probe<STAGE, T>(B, col, fallback, key, salt, inm, hm, nm);
-      unsigned long long any_need = 0ull;
-#pragma unroll
-      for (int q = 0; q < T; ++q) {
-        cnt += (unsigned)__popcll(hm[q]);
-        any_need |= nm[q];
-      }
-      if (any_need != 0ull) cnt += tch_surplus<STAGE, T>(B, lane, key, salt, nm);  // rare
+    };
+    const int ng = (wn + G - 1) / G;
+    Grp cur;
+    stage_a(0, cur);
+    for (int g = 0; g + 1 < ng; ++g) {
+      Grp nxt;
+      stage_a(g + 1, nxt);
+      stage_b(cur);
+      cur = nxt;
     }
+    stage_b(cur);
     wave_sync();
   }
   return cnt;
 }
 
+#ifndef GM_TCH_MIN_WG
+#define GM_TCH_MIN_WG 6
+#endif
 template <int STAGE>
-__global__ __launch_bounds__((kWavesPerBlock * GM_WAVE), (STAGE <= 1024 ? 6 : 4))
+__global__ __launch_bounds__((kWavesPerBlock * GM_WAVE), (STAGE <= 1024 ? GM_TCH_MIN_WG : 4))
 void tch_kernel(const MineParams p) {
   __shared__ TchLds<STAGE> B;
   using H = TchHash<STAGE>;
@@ -259,7 +290,7 @@ void tch_kernel(const MineParams p) {
   const int *__restrict__ col = p.g.col;
   const int *__restrict__ trp = p.g.trp;
   const int2 *__restrict__ tdesc = p.g.tdesc;
-  TchWave &L = B.w[wave];
+  auto &L = B.w[wave];
   unsigned long long c0 = 0;  // wave-uniform
   for (;;) {
     if (tid == 0) B.queue_pos = atomicAdd(p.queue, (unsigned)p.grab);
@@ -363,7 +394,7 @@ int tch_per_cu(int stage) { return stage <= 1024 ? 6 : 4; }
 hipError_t launch_tch(const MineParams &p, int stage, int grid_blocks, hipStream_t stream) {
   static_assert(sizeof(TchLds<1024>) * 6 <= 163840, "six workgroups per CU");
   static_assert(sizeof(TchLds<kTctStageMax>) * 4 <= 163840, "four workgroups per CU");
-  static_assert(sizeof(TchWave) * kWavesPerBlock >= (size_t)kTctStageMax * 2, "fill counters alias the wave scratch");
+  static_assert(sizeof(TchWave<4096>) * kWavesPerBlock >= (size_t)kTctStageMax * 2, "fill counters alias the wave scratch");
   if (p.g.trp == nullptr || p.g.tdesc == nullptr) return hipErrorInvalidValue;
   const dim3 grid((unsigned)grid_blocks), block(kWavesPerBlock * GM_WAVE);
   if (stage <= 1024) hipLaunchKernelGGL((tch_kernel<1024>), grid, block, 0, stream, p);
