@@ -26,7 +26,7 @@ struct alignas(16) CBuildLds {
   HsTable<STAGE> set;
   int trpl[kMaxChunkVerts + 1];    // row offsets of the chunk's task lists
   unsigned rows[WAVES][kCbRowBuf];
-  HsWave w[WAVES];                 // (while the set is built: the fill counters of its buckets)
+  HsWave<STAGE> w[WAVES];                 // (while the set is built: the fill counters of its buckets)
   int next_batch;
   unsigned queue_pos;
   int pad_;
@@ -46,7 +46,7 @@ void cbuild_kernel(const CBuildParams p) {
   const int *__restrict__ trp = p.trp;
   const int4 *__restrict__ tasks = reinterpret_cast<const int4 *>(p.tasks);
   unsigned *__restrict__ mat = p.mat;
-  HsWave &L = B.w[wave];
+  HsWave<STAGE> &L = B.w[wave];
   unsigned *rb = B.rows[wave];
   for (;;) {
     if (tid == 0) B.queue_pos = atomicAdd(p.queue, 1u);
@@ -135,7 +135,7 @@ void cbuild_kernel(const CBuildParams p) {
   }
 }
 
-// workgroups of 4 waves on the 1024-entry stage (29.6 KB of LDS: five per CU), of GM_CB_WAVES_BIG on the 2048-entry one
+// workgroups of 4 waves on the 1024-entry stage (32 KB of LDS), of GM_CB_WAVES_BIG on the 2048-entry one
 // (R-MAT-22 ef 28, 4 / 6 / 8 waves: 68.5 / 70.6 / 66.7 ms for the whole pattern)
 #ifndef GM_CB_WAVES_BIG
 #define GM_CB_WAVES_BIG 8
@@ -145,9 +145,9 @@ int cbuild_per_cu(int stage) {
   return (int)(163840 / (stage <= 1024 ? sizeof(CBuildLds<1024, 4>) : sizeof(CBuildLds<kCbMaxDeg, kCbWavesBig>)));
 }
 hipError_t launch_cbuild(const CBuildParams &p, int stage, int grid_blocks, hipStream_t stream) {
-  static_assert(sizeof(CBuildLds<1024, 4>) * 5 <= 163840, "five workgroups per CU");
+  static_assert(sizeof(CBuildLds<1024, 4>) * 3 <= 163840, "three workgroups per CU at least (the registers allow no more)");
   static_assert(sizeof(CBuildLds<kCbMaxDeg, kCbWavesBig>) * 2 <= 163840, "two workgroups per CU");
-  static_assert(sizeof(HsWave) * 4 >= (size_t)kCbMaxDeg * 2, "fill counters alias the wave scratch");
+  static_assert(sizeof(HsWave<kCbMaxDeg>) * 4 >= (size_t)kCbMaxDeg * 2, "fill counters alias the wave scratch");
   static_assert(kCbMaxDeg <= 2048 && kCbRowBuf <= 4096, "positions are 11-bit fields of a slot, bit offsets and row offsets 12-bit fields");
   if (p.trp == nullptr || p.tasks == nullptr || p.mat == nullptr) return hipErrorInvalidValue;
   const dim3 grid((unsigned)grid_blocks);

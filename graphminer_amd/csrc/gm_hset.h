@@ -198,11 +198,15 @@ __device__ __forceinline__ void hs_surplus(const HsTable<STAGE> &S, const int la
 }
 
 // per-wave scratch of the flattened pass of the kernels built on the set
-struct alignas(16) HsWave {
-  int4 desc[GM_WAVE];                // per batch lane: {key_base - offset among the flattened positions, salt, the kernel's two words}
-  int2 rng[GM_WAVE];                 // ... and where its host row sits in the stage: {first entry, entries}
-  unsigned char marks[kMarkWindow];  // owner marks of the flattened positions
+// BITWIN: flattened positions per mark window (a batch of 64 lists below kLongList keys has <= 12224, most have far fewer)
+template <int BITWIN>
+struct alignas(16) HsWaveT {
+  int4 desc[GM_WAVE];              // per non-empty list of the batch: {key_base - offset among the flattened positions, salt, the kernel's two words}
+  int2 rng[GM_WAVE];               // ... and where its host row sits in the stage: {first entry, entries}
+  unsigned bits[BITWIN / 32 + 8];  // list-start marks of the flattened positions, one bit each (+ the over-read of the last group)
 };
+template <int STAGE>
+using HsWave = HsWaveT<4096>;
 
 // One batch of tasks against the set: lane's list = llen_all keys from col[key_base ..) (0 = no task), looked up in the row `salt_l`
 // names = stage entries [rlo_l, rlo_l + rlen_l); word_l, word2_l = two per-task words handed back to the match handler.
@@ -210,7 +214,7 @@ struct alignas(16) HsWave {
 //     uniform (compile-time at every call site): the tile belongs to ONE task, word / word2 are wave-uniform (long lists)
 //   hit1(word, word2, at, kidx): one key found through the surplus list (wave-uniform arguments)
 template <int STAGE, int T, class Hit, class Hit1>
-__device__ __forceinline__ void hs_pass(const HsTable<STAGE> &S, HsWave &L, const int *__restrict__ col, const bool fallback, const int lane,
+__device__ __forceinline__ void hs_pass(const HsTable<STAGE> &S, HsWave<STAGE> &L, const int *__restrict__ col, const bool fallback, const int lane,
                                         const int llen_all, const int key_base, const unsigned salt_l, const int rlo_l, const int rlen_l,
                                         const int word_l, const int word2_l, Hit hit, Hit1 hit1) {
   if (wave_max_nonneg(llen_all) == 0) return;  // wave-uniform
@@ -280,59 +284,69 @@ __device__ __forceinline__ void hs_pass(const HsTable<STAGE> &S, HsWave &L, cons
       process(key, inm, t);
     }
   }
-  // ---- short lists: flattened (owner marks + DPP max-scan; tiles without a list boundary skip the scan) ------------------------------
+  // ---- short lists: flattened.  Position p of the concatenated lists belongs to the LAST list that starts at or before it: every
+  // list but the first of a window leaves one mark BIT at (its start - 1), the owner of p is the number of marks below p (one LDS read
+  // per tile group, v_readlane + v_mbcnt per tile); the keys of the NEXT tile group are requested before the current group is looked
+  // up (gm_tch.hip, where this form was measured first) -----------------------------------------------------------------------------
   const int incl = wave_incl_scan_add(llen);
   const int total = readlane(incl, GM_WAVE - 1);
   if (total == 0) return;  // wave-uniform
   const int offp = incl - llen;
-  L.desc[lane] = make_int4(key_base - offp, (int)salt_l, word_l, word2_l);
-  L.rng[lane] = make_int2(rlo_l, rlen_l);
-  unsigned *m32 = reinterpret_cast<unsigned *>(L.marks);
-  int carry = 0;
-  for (int wb = 0; wb < total; wb += kMarkWindow) {
-    const int wn = min(kMarkWindow, total - wb);
-    const int nwords = ((wn + GM_WAVE * T - 1) / (GM_WAVE * T)) * (GM_WAVE * T / 4);
-    for (int i = lane; i < nwords; i += GM_WAVE) m32[i] = 0u;
+  const unsigned long long nzm = __ballot(llen > 0);
+  if (llen > 0) {  // (compacted: the k-th non-empty list)
+    const int li = rank_below(nzm);
+    L.desc[li] = make_int4(key_base - offp, (int)salt_l, word_l, word2_l);
+    L.rng[li] = make_int2(rlo_l, rlen_l);
+  }
+  constexpr int G = GM_WAVE * T, kBitWin = (int)(sizeof(L.bits) / 4 - 8) * 32;
+  static_assert(2 * T <= GM_WAVE, "the mark words of a tile group are read by its first lanes");
+  struct Grp {
+    int key[T], own[T];
+    unsigned long long inm[T];
+  };
+  for (int wb = 0; wb < total; wb += kBitWin) {
+    const int wn = min(kBitWin, total - wb);
+    const int nw = ((wn + G - 1) / G) * (G / 32) + 2;
+    for (int i = lane; i < nw; i += GM_WAVE) L.bits[i] = 0u;
     wave_sync();
-    if (llen > 0 && offp >= wb && offp < wb + kMarkWindow) L.marks[offp - wb] = (unsigned char)(lane + 1);
+    if (llen > 0 && offp > wb && offp < wb + kBitWin) atomicOr(&L.bits[(offp - 1 - wb) >> 5], 1u << ((offp - 1 - wb) & 31));
+    int carry = __popcll(__ballot(llen > 0 && offp <= wb)) - 1;  // the list that owns position wb
     wave_sync();
-    for (int t = 0; t < wn; t += GM_WAVE * T) {
-      int own[T], key[T], word[T], word2[T], kidx[T];
-      unsigned salt[T], at[T], rlo[T], rlen[T];
-      unsigned long long inm[T];
-#pragma unroll
-      for (int q = 0; q < T; ++q) own[q] = (int)L.marks[t + q * GM_WAVE + lane];
+    auto stage_a = [&](const int g, Grp &r) {  // owners and key loads of tile group g of the window
+      const int mw = (int)L.bits[((g * G) >> 5) + (lane & (2 * T - 1))];  // lane l holds mark word l of the group
+      int dx[T];
 #pragma unroll
       for (int q = 0; q < T; ++q) {
-        if (__ballot(own[q] != 0) == 0ull) {
-          own[q] = carry;  // no list starts inside this tile: every position belongs to the running owner
-        } else {
-          own[q] = max(wave_incl_scan_max(own[q]), carry);
-          carry = readlane(own[q], GM_WAVE - 1);
-        }
+        const unsigned long long m = ((unsigned long long)(unsigned)readlane(mw, 2 * q + 1) << 32) | (unsigned)readlane(mw, 2 * q);
+        const bool in = (wb + g * G + q * GM_WAVE + lane) < total;
+        r.own[q] = in ? carry + rank_below(m) : 0;
+        carry += __popcll(m);
+        r.inm[q] = __ballot(in);
+        dx[q] = L.desc[r.own[q]].x;  // unconditional LDS read
       }
-      int4 dd[T];
 #pragma unroll
       for (int q = 0; q < T; ++q) {
-        const bool in = (wb + t + q * GM_WAVE + lane) < total;
-        inm[q] = __ballot(in);
-        dd[q] = L.desc[in ? own[q] - 1 : 0];  // unconditional LDS reads
-        const int2 rr = L.rng[in ? own[q] - 1 : 0];
+        const int pp = wb + g * G + q * GM_WAVE + lane;
+        r.key[q] = col[(r.inm[q] >> lane) & 1ull ? dx[q] + pp : 0];  // unconditional load (select on the index)
+      }
+    };
+    auto stage_b = [&](const int g, const Grp &r) {
+      int word[T], word2[T], kidx[T];
+      unsigned salt[T], at[T], rlo[T], rlen[T];
+#pragma unroll
+      for (int q = 0; q < T; ++q) {
+        const int4 dd = L.desc[r.own[q]];
+        const int2 rr = L.rng[r.own[q]];
+        const int pp = wb + g * G + q * GM_WAVE + lane;
+        kidx[q] = (r.inm[q] >> lane) & 1ull ? dd.x + pp : 0;
+        salt[q] = (unsigned)dd.y;
+        word[q] = dd.z;
+        word2[q] = dd.w;
         rlo[q] = (unsigned)rr.x;
         rlen[q] = (unsigned)rr.y;
       }
-#pragma unroll
-      for (int q = 0; q < T; ++q) {
-        const int pp = wb + t + q * GM_WAVE + lane;
-        const bool in = pp < total;
-        kidx[q] = in ? dd[q].x + pp : 0;
-        key[q] = col[kidx[q]];  // unconditional load (select on the index)
-        salt[q] = (unsigned)dd[q].y;
-        word[q] = dd[q].z;
-        word2[q] = dd[q].w;
-      }
       unsigned long long hm[T], nm[T];
-      hs_probe<STAGE, T>(S, col, fallback, key, salt, rlo, rlen, inm, at, hm, nm);
+      hs_probe<STAGE, T>(S, col, fallback, r.key, salt, rlo, rlen, r.inm, at, hm, nm);
       unsigned long long any_need = 0ull;
 #pragma unroll
       for (int q = 0; q < T; ++q) {
@@ -340,10 +354,20 @@ __device__ __forceinline__ void hs_pass(const HsTable<STAGE> &S, HsWave &L, cons
         any_need |= nm[q];
       }
       if (any_need != 0ull)  // rare
-        hs_surplus<STAGE, T>(S, lane, key, salt, nm, [&](const int q, const int sl, const int p) {
+        hs_surplus<STAGE, T>(S, lane, r.key, salt, nm, [&](const int q, const int sl, const int p) {
           hit1(readlane(word[q], sl), readlane(word2[q], sl), p, readlane(kidx[q], sl));
         });
+    };
+    const int ng = (wn + G - 1) / G;
+    Grp cur;
+    stage_a(0, cur);
+    for (int g = 0; g + 1 < ng; ++g) {
+      Grp nxt;
+      stage_a(g + 1, nxt);
+      stage_b(g, cur);
+      cur = nxt;
     }
+    stage_b(ng - 1, cur);
     wave_sync();
   }
 }

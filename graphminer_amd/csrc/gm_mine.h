@@ -313,7 +313,10 @@ __host__ __device__ inline int clique_count_class(int d) {
 // big-LDS classes S / L / X of gm_wide.hip.
 constexpr int kCbMaxDeg = kWideMaxDeg;  // 2048: the longest row that owns a matrix here / hosts tasks (longer rows: mine_kernel's arena path)
 constexpr int kCbMinDeg = 3;            // a vertex with fewer out-neighbours is in no 4-clique as its smallest member
-constexpr int kCbRowBuf = 256;          // words of finished rows a wave holds before it stores them (a row is <= 64 words)
+#ifndef GM_CB_ROWBUF
+#define GM_CB_ROWBUF 256
+#endif
+constexpr int kCbRowBuf = GM_CB_ROWBUF;          // words of finished rows a wave holds before it stores them (a row is <= 64 words)
 struct alignas(16) CBuildTask {
   int list, len;       // the list to stream: col[list .. list + len)
   unsigned off_lo;     // word offset of the task's row in the arena, low 32 bits

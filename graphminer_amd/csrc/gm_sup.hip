@@ -27,7 +27,7 @@ template <int STAGE>
 struct alignas(16) SupLds {
   HsTable<STAGE> set;
   int trpl[kMaxChunkVerts + 1];  // row offsets of the chunk's task lists
-  HsWave w[kWavesPerBlock];      // (while the set is built: the fill counters of its buckets)
+  HsWave<STAGE> w[kWavesPerBlock];      // (while the set is built: the fill counters of its buckets)
   unsigned cnt[kWavesPerBlock][GM_WAVE];  // per batch lane: matches of its task
   unsigned ecnt[STAGE];                   // per stage entry: matches found at it
   int next_batch;
@@ -50,7 +50,7 @@ void sup_kernel(const MineParams p) {
   const int2 *__restrict__ tdesc = p.g.tdesc;
   const int *__restrict__ tedge = p.g.tedge;
   unsigned *__restrict__ sup = p.scratch;
-  HsWave &L = B.w[wave];
+  HsWave<STAGE> &L = B.w[wave];
   unsigned *cnt = B.cnt[wave];
   for (;;) {
     if (tid == 0) B.queue_pos = atomicAdd(p.queue, (unsigned)p.grab);
@@ -137,7 +137,7 @@ int sup_per_cu(int stage) { return stage <= 1024 ? 4 : 3; }
 hipError_t launch_sup(const MineParams &p, int stage, int grid_blocks, hipStream_t stream) {
   static_assert(sizeof(SupLds<1024>) * 4 <= 163840, "four workgroups per CU");
   static_assert(sizeof(SupLds<kTctStageMax>) * 3 <= 163840, "three workgroups per CU");
-  static_assert(sizeof(HsWave) * kWavesPerBlock >= (size_t)kTctStageMax * 2, "fill counters alias the wave scratch");
+  static_assert(sizeof(HsWave<kTctStageMax>) * kWavesPerBlock >= (size_t)kTctStageMax * 2, "fill counters alias the wave scratch");
   if (p.g.trp == nullptr || p.g.tdesc == nullptr || p.g.tedge == nullptr || p.scratch == nullptr) return hipErrorInvalidValue;
   const dim3 grid((unsigned)grid_blocks), block(kWavesPerBlock * GM_WAVE);
   if (stage <= 1024) hipLaunchKernelGGL((sup_kernel<1024>), grid, block, 0, stream, p);
