@@ -1106,8 +1106,9 @@ static int run_sgl_nested(int pat, const gm_graph *cg, const gm_launch *la_in, u
 // diamond on one GPU: the edge supports of the oriented copy (cached on the handle; on its topological view where lists are long)
 static int run_diamond_supports(const gm_graph *sym, const gm_launch *la, uint64_t *total, gm_stats *st) {
   gm_graph *g = const_cast<gm_graph *>(sym);
-  if (int rc = reject_big(sym)) return rc;
-  if (!g->dag_cache) {
+  if (!sym) return GM_ERR_INVALID;
+  if (la && la->world > 1) return GM_ERR_UNSUPPORTED;
+  if (!g->dag_cache) {  // (a graph of >= 2^31 entries too: its oriented copy must fit the 32-bit task index, gm_graph_orient checks)
     gm_graph *dag = nullptr;
     int rc = gm_graph_orient(sym, &dag);
     if (rc) return rc;
@@ -1136,11 +1137,13 @@ extern "C" int gm_sgl(const gm_graph *sym, const char *pattern, const gm_launch 
     // path on request): one intersection of the two symmetric lists per edge (gm_hrow.hip, gm_chunk.h).
     {
       const int t6 = la ? la->tune[6] : 0;
-      const bool per_edge = (t6 & (0x10000000 | 0x80000 | 0x100000 | 0x400000 | 0x1000000 | 0x2000000)) || (la && la->world > 1) ||
-                            (la && la->tune[5] == 1) || getenv("GM_DIAMOND_PER_EDGE") || !sym || sym->d_rp64;
+      const bool big = sym && sym->d_rp64;  // (>= 2^31 entries: only the supports of the oriented copy can run; on one GPU)
+      const bool per_edge = ((t6 & (0x10000000 | 0x80000 | 0x100000 | 0x400000 | 0x1000000 | 0x2000000)) || (la && la->world > 1) ||
+                             (la && la->tune[5] == 1) || getenv("GM_DIAMOND_PER_EDGE") || !sym) && !big;
       if (!per_edge) {
         const int rc = run_diamond_supports(sym, la, total, st);
         if (rc != GM_ERR_UNSUPPORTED) return rc;
+        if (big) return reject_big(sym);
       }
     }
     return run_pattern(PAT_DIAMOND, sym, la, 4, total, 1, st);

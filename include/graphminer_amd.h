@@ -111,7 +111,12 @@ typedef struct gm_launch {
                          [6] bit mask. Alternative implementations (same counts): 0x100 mining kernels ignore the hub bitmaps,
                          0x200 SgL / TC / 4-clique on the graph as numbered (no degree / topological renumbering), 0x400 SgL wave-per-edge loop nests,
                          0x800 rectangle / pentagon as wedges + flat intersections, house flattened over (v0,v1,v3), 0x1000 cut
-                         chunks into parts eagerly, 0x2000 swap the two dequeue orders, 0x4000 plain chunk-id order.
+                         chunks into parts eagerly, 0x2000 swap the two dequeue orders, 0x4000 plain chunk-id order,
+                         0x10000000 diamond / 3-motif by one intersection of the two symmetric lists per edge (the reference's loop
+                         nests; default: from the triangles of the oriented copy), 0x8000000 TC against a sorted LDS copy + bit filter +
+                         bisection (gm_tct.hip; default: a hashed set, gm_tch.hip), 0x4000000 TC by the chunked mining kernel,
+                         0x800000 hashed sets on their global-memory fallback lookup, 0x40000 4-clique in the mining kernel alone;
+                         0x80000 / 0x100000 / 0x400000 / 0x1000000 / 0x2000000: variants of the per-edge class kernels (gm_launch.hip).
                          Ablation (mining kernels): 0x1 skip clique phase 2, 0x2 skip bit-matrix writes, 0x4 no filter,
                          0x8 / 0x10 / 0x20 filtered-pass stages, 0x40 skip SPLIT chunks, 0x80 only SPLIT chunks,
                          0x400 skip pass X, 0x8000 skip pass Y (house: flattened form without the LDS S-bitmap) (gm_api.hip / gm_mine.hip). */
@@ -167,7 +172,11 @@ int gm_tc(const gm_graph *dag, const gm_launch *launch, uint64_t *total, gm_stat
 /* SglSolver: edge-induced subgraph listing on the SYMMETRIC graph, pattern by NAME
  * (include/pattern.hh:62-78). Implemented: "diamond" (src/sgl/cpu_kernels/diamond.h:1-14,
  * src/sgl/gpu_kernels/diamond_count.cuh:3-21), "rectangle" (rectangle.h:1-11), "house" (house.h:1-16),
- * "pentagon" (pentagon.h:2-17). Others -> GM_ERR_UNSUPPORTED, *total = 0. */
+ * "pentagon" (pentagon.h:2-17). Others -> GM_ERR_UNSUPPORTED, *total = 0.
+ * diamond = sum over the edges of C(|N(v0) ^ N(v1)|, 2). One GPU: |N(v0) ^ N(v1)| of every edge -- its triangles -- from ONE pass over
+ * the triangles of the oriented copy (edge supports, gm_sup.hip; the copy is built and cached on first use; also for a graph of
+ * >= 2^31 entries); world > 1, a DAG row beyond 2048 entries, or tune[6] & 0x10000000: one intersection of the two symmetric lists per
+ * edge (gm_hrow.hip, gm_chunk.h). Same count. */
 int gm_sgl(const gm_graph *sym, const char *pattern, const gm_launch *launch, uint64_t *total, gm_stats *stats);
 
 /* CliqueSolver on the DAG, 3 <= k <= 8 (src/clique/cpu_kernels/automine_omp.h:67-83,138-157;
@@ -184,8 +193,11 @@ int gm_clique(const gm_graph *dag, int k, const gm_launch *launch, uint64_t *tot
  * (the CPU order, src/motif/cpu_kernels/automine_base.h:13,18; NOT the swapped order of
  * src/motif/gpu_kernels/motif3_edge_warp.cuh:19-22). ncounts must be
  * num_possible_patterns[k] (include/pattern.hh:4-15): 2 for k = 3, 6 for k = 4 (see gm_motif4_partial).
- * With world > 1 a rank's wedge value is a partial modulo 2^64 (one intersection per undirected edge serves both
- * directed edges, which may belong to different ranks); the uint64 sum over ranks is the exact count. */
+ * k = 3 takes the reference's formula solver by default (gm_motif_formula below: the triangles of the oriented copy, wedges derived);
+ * tune[6] & 0x10000000: automine_3motif's enumeration, one bounded intersection of the two symmetric lists per edge. Same counts;
+ * stats->tasks = the graph's directed entries either way.
+ * With world > 1 a rank's wedge value is a partial modulo 2^64 (formula: rank 0 contributes sum C(d,2); enumeration: one intersection
+ * per undirected edge serves both directed edges, which may belong to different ranks); the uint64 sum over ranks is the exact count. */
 int gm_motif(const gm_graph *sym, int k, const gm_launch *launch, uint64_t *counts, int ncounts, gm_stats *stats);
 
 /* 4-motif in the reference's formula form (src/motif/cpu_kernels/automine_formula.h:21-56, host fix-up

@@ -451,7 +451,8 @@ def test_big_handle_paths_on_small_graphs(dev, name, monkeypatch):
     e = GOLDEN[name]
     assert TCSolver(dag) == e["tc"] and CliqueSolver(dag, 4) == e["clique4"]
     assert MotifSolver(big, 3) == e["motif3"] == MotifSolver(big, 3, formula=True)
-    for bad in (lambda: SglSolver(big, "diamond"), lambda: MotifSolver(big, 4), lambda: TCSolver(big), lambda: SglSolver(big, "rectangle")):
+    assert SglSolver(big, "diamond") == e["diamond"]  # (edge supports of the oriented copy, gm_sup.hip)
+    for bad in (lambda: SglSolver(big, "diamond", rank=0, world=2), lambda: MotifSolver(big, 4), lambda: TCSolver(big), lambda: SglSolver(big, "rectangle")):
         with pytest.raises(_lib.GraphMinerError) as ei:
             bad()
         assert ei.value.status == _lib.GM_ERR_TOO_LARGE
