@@ -14,7 +14,11 @@
 //   * the host-row edge into an LDS counter per stage entry, flushed once per chunk (part);
 //   * the task's own edge into an LDS counter per batch lane, flushed once per task;
 //   * the streamed edge by a global atomic (return-less, 4 bytes) -- a device-scope atomic costs about one 64-byte fabric transaction
-//     (measured: with two of them per match R-MAT-22 took 20.2 ms for 750 M triangles, 3.35 ms without any).
+//     (measured: with two of them per match R-MAT-22 took 20.2 ms for 750 M triangles, 3.35 ms without any).  The atomics are not
+//     issued where the match is found: gfx950 counts loads, stores and return-less atomics in ONE counter (vmcnt) and the compiler
+//     must assume they complete out of order, so a pending atomic turns the wait for the current tile group's keys into a wait for
+//     everything -- the next group's prefetched keys included.  The entries of the matches are queued in LDS (256 per wave) and
+//     flushed in bursts, whose latencies overlap each other.
 // A second kernel sums C(t, 2) over the entries.
 // One GPU; rows beyond the 2048-entry stage send the caller back to the per-edge kernels (gm_launch.hip).
 #include "gm_hset.h"
@@ -22,6 +26,7 @@
 namespace gm {
 
 constexpr int kSupTiles = 4;
+constexpr int kSupQueue = 256, kSupFlushAt = kSupQueue - GM_WAVE;  // (a tile adds at most 64 entries)
 
 template <int STAGE>
 struct alignas(16) SupLds {
@@ -30,13 +35,14 @@ struct alignas(16) SupLds {
   HsWave<STAGE> w[kWavesPerBlock];      // (while the set is built: the fill counters of its buckets)
   unsigned cnt[kWavesPerBlock][GM_WAVE];  // per batch lane: matches of its task
   unsigned ecnt[STAGE];                   // per stage entry: matches found at it
+  int hq[kWavesPerBlock][kSupQueue];      // per wave: DAG entries (streamed edges) whose increment is still to be issued
   int next_batch;
   unsigned queue_pos;
   int pad_[2];
 };
 
 template <int STAGE>
-__global__ __launch_bounds__((kWavesPerBlock * GM_WAVE), (STAGE <= 1024 ? 4 : 3))
+__global__ __launch_bounds__((kWavesPerBlock * GM_WAVE), (STAGE <= 1024 ? 4 : 2))
 void sup_kernel(const MineParams p) {
   __shared__ SupLds<STAGE> B;
   using H = HsHash<STAGE>;
@@ -84,6 +90,14 @@ void sup_kernel(const MineParams p) {
         const int ru = B.set.rpl[lo], a = B.set.rpl[lo + 1] - ru;
         const bool act = valid && d.y > 0 && a > 0;
         cnt[lane] = 0u;
+        int *hq = B.hq[wave];
+        int qn = 0;  // wave-uniform: queued entries
+        auto flush = [&]() {
+          wave_sync();
+          for (int i = lane; i < qn; i += GM_WAVE) atomicAdd(&sup[hq[i]], 1u);
+          qn = 0;
+          wave_sync();
+        };
         wave_sync();
         // word = where the host's row starts in the stage, word2 = the task's batch lane
         auto hit = [&](const unsigned long long hm, const int row0, const int owner, const unsigned at, const int kidx, const bool uniform) {
@@ -93,19 +107,23 @@ void sup_kernel(const MineParams p) {
           }
           if (__builtin_amdgcn_inverse_ballot_w64(hm)) {
             atomicAdd(&B.ecnt[row0 + (int)at], 1u);
-            atomicAdd(&sup[kidx], 1u);
+            hq[qn + rank_below(hm)] = kidx;
             if (!uniform) atomicAdd(&cnt[owner], 1u);
           }
+          qn += __popcll(hm);
+          if (qn > kSupFlushAt) flush();
         };
         auto hit1 = [&](const int row0, const int owner, const int at, const int kidx) {
           if (lane == 0) {
             atomicAdd(&B.ecnt[row0 + at], 1u);
-            atomicAdd(&sup[kidx], 1u);
+            hq[qn] = kidx;
             atomicAdd(&cnt[owner], 1u);
           }
+          qn += 1;
+          if (qn > kSupFlushAt) flush();
         };
         hs_pass<STAGE, kSupTiles>(B.set, L, col, fallback, lane, act ? d.y : 0, d.x, H::salt(lo), ru - eb, a, ru - eb, lane, hit, hit1);
-        wave_sync();
+        flush();
         const unsigned c = cnt[lane];
         if (valid && c) atomicAdd(&sup[own_e], c);
         wave_sync();
@@ -133,10 +151,10 @@ __global__ __launch_bounds__(256) void sup_pairs_kernel(const unsigned *__restri
   if ((threadIdx.x & (GM_WAVE - 1)) == 0 && s) atomicAdd(out, s);
 }
 
-int sup_per_cu(int stage) { return stage <= 1024 ? 4 : 3; }
+int sup_per_cu(int stage) { return stage <= 1024 ? 4 : 2; }
 hipError_t launch_sup(const MineParams &p, int stage, int grid_blocks, hipStream_t stream) {
   static_assert(sizeof(SupLds<1024>) * 4 <= 163840, "four workgroups per CU");
-  static_assert(sizeof(SupLds<kTctStageMax>) * 3 <= 163840, "three workgroups per CU");
+  static_assert(sizeof(SupLds<kTctStageMax>) * 2 <= 163840, "two workgroups per CU");
   static_assert(sizeof(HsWave<kTctStageMax>) * kWavesPerBlock >= (size_t)kTctStageMax * 2, "fill counters alias the wave scratch");
   if (p.g.trp == nullptr || p.g.tdesc == nullptr || p.g.tedge == nullptr || p.scratch == nullptr) return hipErrorInvalidValue;
   const dim3 grid((unsigned)grid_blocks), block(kWavesPerBlock * GM_WAVE);
