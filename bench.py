@@ -78,6 +78,7 @@ KERNELS = {
     "house": ["house_acc_kernel"],
     "pentagon": ["pent_acc_kernel"],
 }
+TRAFFIC_MARKER = "issue_calib_kernel"  # the dispatch in front of every workload of the traffic worker (measure_traffic)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (~6.3 TB/s achievable by a stream)
 M64 = (1 << 64) - 1
 
@@ -458,6 +459,7 @@ def traffic_worker(a):
     r = Runner(a)
     todo = [w for w in (a.configs.split(",") if a.configs != "all" else ["tc", "diamond", "clique4", "motif3"])]
     graphs, launches = {}, {}
+    dbl = [C.c_double(0) for _ in range(4)]
     for w in todo:
         scale, ef = (a.scale or WORKLOADS[w][0]), (a.ef or WORKLOADS[w][1])
         prefix = dataset_prefix(a, w)
@@ -467,6 +469,9 @@ def traffic_worker(a):
                 bg.free()
             graphs.clear()
             graphs[key] = build_graph(a, r.local_rank, scale, ef, prefix)
+        # a MARKER dispatch in front of every workload (the tiny issue-calibration kernel): two workloads may launch kernels of the same
+        # name (TC and the 3-motif default both run tch_kernel), the parent attributes a row to the workload whose marker precedes it
+        r._lib.check(r.lib.gm_issue_calib(0, 1, 1, *[C.byref(x) for x in dbl]), "marker")
         r.run(w, graphs[key], a.steps, 1)
         launches[w] = a.steps + 1
     print("TRAFFIC_WORKER " + json.dumps(launches), flush=True)
@@ -519,16 +524,29 @@ def measure_traffic(a, workloads, share=(0, 1), device=0):
             launches = json.loads(m.group(1))
             import csv
 
-            sums = {}
+            rows = []
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
                     if row.get("Counter_Name") == counter:
-                        k = row.get("Kernel_Name", "")
-                        sums[k] = sums.get(k, 0.0) + float(row.get("Counter_Value", 0))
-            if not sums:
+                        rows.append((int(row.get("Dispatch_Id") or row.get("Correlation_Id") or 0), row.get("Kernel_Name", ""), float(row.get("Counter_Value", 0))))
+            if not rows:
                 return None, f"no {counter} rows in the rocprofv3 output"
-            for w in workloads:
+            rows.sort(key=lambda x: x[0])
+            seg_sums, seg, in_marker = [], -1, False  # per workload (in the worker's order): kernel name -> counter sum
+            for did, k, v in rows:
+                if TRAFFIC_MARKER in k:
+                    if not in_marker:  # (one boundary however many dispatches / counter rows the marker call makes)
+                        seg, in_marker = seg + 1, True
+                        seg_sums.append({})
+                    continue
+                in_marker = False
+                if seg >= 0:
+                    seg_sums[seg][k] = seg_sums[seg].get(k, 0.0) + v
+            if len(seg_sums) != len(workloads):
+                return None, f"{len(seg_sums)} marker dispatches for {len(workloads)} workloads in the {counter} pass"
+            for wi, w in enumerate(workloads):
                 tot = 0.0
+                sums = seg_sums[wi]
                 for kname, v in sums.items():
                     if any(p in kname for p in KERNELS.get(w, [])):
                         tot += v

@@ -101,10 +101,12 @@ void cbuild_kernel(const CBuildParams p) {
         // (word = the task's meta, word2 = where its streamed list starts in col)
         auto hit = [&](const unsigned long long hm, const int meta, const int list0, const unsigned at, const int kidx, const bool) {
           if (hm == 0ull) return;  // wave-uniform
+#ifndef GM_CB_ABLATE_HITS  // (A/B builds: what the row-buffer writes cost; counts wrong)
           if (__builtin_amdgcn_inverse_ballot_w64(hm)) {
             const int bit = (meta < 0) ? ((meta >> 12) & 4095) + (kidx - list0) : (int)at;
             atomicOr(&rb[(meta & 4095) + (bit >> 5)], 1u << (bit & 31));
           }
+#endif
         };
         auto hit1 = [&](const int meta, const int list0, const int at, const int kidx) {
           if (lane == 0) {

@@ -31,6 +31,8 @@ def check_roofline(r):
         assert r["frac"] == r["own_frac"] and abs(r["own_GBs"] - r["achieved"]) < 1e-6
         assert r["own_bytes_per_launch"] >= 4 * r["own_streamed_keys_per_launch"] > 0
     assert r["compulsory_floor_bytes"] > 0 and r["stream_ceiling_GBs"] > 1000
+    if r.get("traffic_frac") is not None:  # counter traffic of THIS workload's launches only (two workloads may share a kernel name:
+        assert 0 < r["traffic_frac"] <= 1.0  # the traffic pass separates them by marker dispatches) -- it cannot exceed the peak
 
 
 def test_bench_line_small_tc():
