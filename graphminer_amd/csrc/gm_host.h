@@ -333,6 +333,8 @@ int get_table(gm_graph *g, int target, bool allow_split, int bit_words, unsigned
               const RowFilter &rf = RowFilter(), int bitmap_min_deg = kBitmapMinDeg);
 int ensure_edesc(gm_graph *g);
 int ensure_tasklists(gm_graph *g, bool with_edges = false);
+int ensure_mean_sq_deg(gm_graph *g);
+unsigned long long task_part_cap(gm_graph *g, int world);
 int clique_wide_min_words();
 int get_clique_plan(gm_graph *g, int rank, int world, int policy, int target, unsigned long long part_cap, CliquePlan **out);
 void free_clique_plans(gm_graph *g);

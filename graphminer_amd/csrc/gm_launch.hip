@@ -183,8 +183,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
   const int tct_stage = g->max_deg <= kStageCap ? kStageCap : kTctStageMax;
   // (rows beyond the 2048-entry stage host nothing: their out-edges are the tasks of the chunked kernel, on a table of those rows only)
   const bool tct_long = use_tct && g->max_deg > kTctStageMax;
-  unsigned long long tct_part = std::max<unsigned long long>((1ull << 20) / (unsigned long long)world, 128ull << 10);
-  if (const char *e = getenv("GM_TCT_PART_KKEYS")) tct_part = (unsigned long long)std::max(4, atoi(e)) << 10;  // (sweeps)
+  const unsigned long long tct_part = use_tct ? task_part_cap(g, world) : 0ull;
   const unsigned long long part_cap = (la->tune[6] & 0x1000) ? 4096ull : (stage_cap_of(pat) != kStageCapWide
        ? (use_tct ? tct_part : kPartCostCap)
        // a rank's share is 1/world of the launch: so is the tolerable tail (3-motif's bounded lists make its estimates
@@ -686,15 +685,8 @@ __global__ __launch_bounds__(256) void sum_sq_deg_kernel(int nv, const int *__re
 }
 constexpr double kTopoMinMeanRow = 64.0;
 
-static int topo_view(const gm_graph *dag, const gm_launch *la, gm_graph **run_on) {
-  gm_graph *self = const_cast<gm_graph *>(dag);
-  if (!self) return GM_ERR_INVALID;
-  if (int rc = reject_big(self)) return rc;
-  *run_on = self;
-  if (la && (la->tune[6] & 0x200)) return GM_OK;
-  bool topo = false;
-  int rc = graph_is_topological(self, &topo);
-  if (rc || topo) return rc;
+// sum d^2 / ne of a handle's rows = the mean length of the row an entry sits in (cached)
+int ensure_mean_sq_deg(gm_graph *self) {
   if (self->mean_sq_deg < 0) {
     HIP_TRY(hipSetDevice(self->device));
     unsigned long long *d_s = nullptr, s2 = 0;
@@ -707,6 +699,33 @@ static int topo_view(const gm_graph *dag, const gm_launch *la, gm_graph **run_on
     if (e != hipSuccess) return hip_fail(e, "sum_sq_deg_kernel", __FILE__, __LINE__);
     self->mean_sq_deg = self->ne > 0 ? (double)s2 / (double)self->ne : 0.0;
   }
+  return GM_OK;
+}
+
+// Heavy chunks of the task-list kernels (a hub hosts 10^5 in-edges) are cut into PARTS that share the chunk's batches -- and every part
+// hashes the chunk's rows again (~10 us).  A part bounds the tail of a rank's launch, so its size follows the rank's share: the
+// launch streams about ne * (sum d+^2 / ne) / 2 keys, a part takes 1/6000 of a rank's share of them, between 128 K and 1 M keys.
+// One-GPU simulation of 8 rank shares, TC, parts of 64 K / 128 K / 256 K / 512 K / 1 M keys: R-MAT-24 9.08 / 7.14 / 6.11 / 5.68 / 5.54 ms per
+// rank (ideal 5.25), R-MAT-22 0.63 / 0.56 / 0.55 / 0.55 / 0.78 (profiles/r03/ab_share_scaling.txt); the rule gives 1 M and 128 K.
+unsigned long long task_part_cap(gm_graph *g, int world) {
+  if (const char *e = getenv("GM_TCT_PART_KKEYS")) return (unsigned long long)std::max(4, atoi(e)) << 10;  // (sweeps)
+  double keys = 0.0;
+  if (ensure_mean_sq_deg(g) == GM_OK) keys = (double)g->ne * g->mean_sq_deg * 0.5;
+  const double cap = keys / (6000.0 * (double)std::max(world, 1));
+  return (unsigned long long)std::min(std::max(cap, (double)(128 << 10)), (double)(1 << 20));
+}
+
+static int topo_view(const gm_graph *dag, const gm_launch *la, gm_graph **run_on) {
+  gm_graph *self = const_cast<gm_graph *>(dag);
+  if (!self) return GM_ERR_INVALID;
+  if (int rc = reject_big(self)) return rc;
+  *run_on = self;
+  if (la && (la->tune[6] & 0x200)) return GM_OK;
+  bool topo = false;
+  int rc = graph_is_topological(self, &topo);
+  if (rc || topo) return rc;
+  rc = ensure_mean_sq_deg(self);
+  if (rc) return rc;
   double min_row = kTopoMinMeanRow;
   if (const char *e = getenv("GM_TOPO_MIN_ROW")) min_row = atof(e);
   if (getenv("GM_TABLE_INFO")) fprintf(stderr, "[topo view] sum d+^2 / |E+| = %.1f (switch at %.1f)\n", self->mean_sq_deg, min_row);

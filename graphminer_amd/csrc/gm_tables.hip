@@ -975,7 +975,7 @@ static int build_clique_round(gm_graph *g, CliquePlan &pl, CliqueRound &rd, Scan
   t.target = std::max(64, std::min(pl.target, pl.stage));
   t.allow_split = true;
   t.bit_words = 0;
-  t.part_cap = std::max<unsigned long long>((1ull << 20) / (unsigned long long)std::max(pl.world, 1), 128ull << 10);
+  t.part_cap = task_part_cap(g, pl.world);
   t.stage_cap = pl.stage;
   t.rf.tct = 1;
   t.rf.skip_lo = pl.stage;
