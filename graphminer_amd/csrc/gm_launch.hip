@@ -704,15 +704,16 @@ int ensure_mean_sq_deg(gm_graph *self) {
 
 // Heavy chunks of the task-list kernels (a hub hosts 10^5 in-edges) are cut into PARTS that share the chunk's batches -- and every part
 // hashes the chunk's rows again (~10 us).  A part bounds the tail of a rank's launch, so its size follows the rank's share: the
-// launch streams about ne * (sum d+^2 / ne) / 2 keys, a part takes 1/6000 of a rank's share of them, between 128 K and 1 M keys.
+// launch streams about ne * (sum d+^2 / ne) / 2 keys, a part takes 1/3000 of a rank's share of them, between 128 K and 4 M keys.
 // One-GPU simulation of 8 rank shares, TC, parts of 64 K / 128 K / 256 K / 512 K / 1 M keys: R-MAT-24 9.08 / 7.14 / 6.11 / 5.68 / 5.54 ms per
-// rank (ideal 5.25), R-MAT-22 0.63 / 0.56 / 0.55 / 0.55 / 0.78 (profiles/r03/ab_share_scaling.txt); the rule gives 1 M and 128 K.
+// rank (ideal 5.25), R-MAT-22 0.63 / 0.56 / 0.55 / 0.55 / 0.78; one GPU, 256 K / 512 K / 1 M / 2 M / 4 M: R-MAT-22 3.14 / 3.09 / 3.07 / 3.06 / 3.04 ms,
+// R-MAT-24 47.2 / 43.7 / 41.9 / 41.2 / 40.9 (profiles/r03/ab_share_scaling.txt).
 unsigned long long task_part_cap(gm_graph *g, int world) {
   if (const char *e = getenv("GM_TCT_PART_KKEYS")) return (unsigned long long)std::max(4, atoi(e)) << 10;  // (sweeps)
   double keys = 0.0;
   if (ensure_mean_sq_deg(g) == GM_OK) keys = (double)g->ne * g->mean_sq_deg * 0.5;
-  const double cap = keys / (6000.0 * (double)std::max(world, 1));
-  return (unsigned long long)std::min(std::max(cap, (double)(128 << 10)), (double)(1 << 20));
+  const double cap = keys / (3000.0 * (double)std::max(world, 1));
+  return (unsigned long long)std::min(std::max(cap, (double)(128 << 10)), (double)(4 << 20));
 }
 
 static int topo_view(const gm_graph *dag, const gm_launch *la, gm_graph **run_on) {
