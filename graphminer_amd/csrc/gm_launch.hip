@@ -477,7 +477,8 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
         c.topo = plan->topo ? 1 : 0;
         if (c.count == 0) continue;
         const int per_cu_c = (int)std::max<size_t>(1, std::min<size_t>((160 * 1024) / clique_count_lds_bytes(cls), (size_t)(2048 / clique_count_threads(cls))));
-        const int cgrid = (int)std::max<long long>(1, std::min<long long>(c.count, (long long)g->cu_count * per_cu_c));
+        // (class X: a queue entry is one column block of a vertex, eight entries per vertex: gm_wide.hip)
+        const int cgrid = (int)std::max<long long>(1, std::min<long long>((long long)c.count * (cls == 2 ? 8 : 1), (long long)g->cu_count * per_cu_c));
         HIP_TRY(launch_clique_count(cls, c, cgrid, stream));
       }
       if (rd.n_count > 0) {

@@ -142,6 +142,8 @@ __device__ __forceinline__ unsigned long long count_block(const unsigned *__rest
       n += __popcll(m);
       if (n - start >= GM_WAVE) {
         wave_sync();  // the list entries written above are read below
+        // (two tiles of pairs in flight per wave -- pair_popc over two rows j at once -- was built: 128 - 140 VGPRs with spills against 100,
+        // the scheduler hoists every read to the front; not kept)
         do {
           tile(GM_WAVE);
           start += GM_WAVE;
@@ -177,8 +179,13 @@ __global__ __launch_bounds__(WAVES *GM_WAVE, 1) void clique_count_kernel(const C
     if (tid == 0) S.queue_pos = atomicAdd(p.queue, 1u);
     __syncthreads();
     const unsigned q = S.queue_pos;
-    if (q >= (unsigned)p.count) break;
-    const int slot = p.slots[q];
+    // class X: a queue entry is ONE COLUMN BLOCK of a vertex (entry = vertex * 8 + block; a vertex has at most 8) -- the blocks are
+    // independent sums, and a rank's share of the few X vertices (R-MAT-22 ef 28: 5.4 K in all, 2.6 per CU and rank of eight) balances
+    // block by block instead of waiting for whole vertices
+    constexpr int kBlkShift = WHOLE ? 0 : 3;
+    if (q >= ((unsigned)p.count << kBlkShift)) break;
+    const int slot = p.slots[q >> kBlkShift];
+    const int only_block = WHOLE ? -1 : (int)(q & 7u);
     const int u = p.verts[slot];
     const int d = p.rp[u + 1] - p.rp[u], stride = (d + 31) >> 5;
     const unsigned *__restrict__ gm = p.mat + p.base[slot];
@@ -191,17 +198,20 @@ __global__ __launch_bounds__(WAVES *GM_WAVE, 1) void clique_count_kernel(const C
     }
     const int nq = ps >> 2;
     for (int c0 = 0; c0 < stride; c0 += cw) {
+      if (only_block >= 0 && c0 != only_block * cw) continue;  // (workgroup-uniform)
       const unsigned long long t0 = p.profile ? wall_clock64() : 0ull;
       const int cwb = min(cw, stride - c0);  // words of this block (the last one may be narrower; pads are zero)
       __syncthreads();                       // the previous block / vertex is no longer read
       // copy the block: a wave moves four rows per trip (four independent coalesced reads of <= 144 B in flight); pads zeroed
-      for (int row0 = wave * 4; row0 < d; row0 += WAVES * 4) {
+      // (triangular matrices: the rows at or beyond the block's last column are neither counted nor looked up -- count_block)
+      const int drows = p.topo ? min(d, (c0 + cwb) * 32) : d;
+      for (int row0 = wave * 4; row0 < drows; row0 += WAVES * 4) {
         unsigned v[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = gm[(size_t)min(row0 + k, d - 1) * stride + c0 + min(lane, cwb - 1)];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-          if (row0 + k < d && lane < ps) S.bits[(row0 + k) * ps + lane] = (lane < cwb) ? v[k] : 0u;
+          if (row0 + k < drows && lane < ps) S.bits[(row0 + k) * ps + lane] = (lane < cwb) ? v[k] : 0u;
       }
       if (tid == 0) S.next_row = 0;
       __syncthreads();
