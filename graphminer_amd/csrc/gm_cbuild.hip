@@ -94,27 +94,28 @@ void cbuild_kernel(const CBuildParams p) {
         const int row0 = incl_w - words - consumed;  // this lane's row inside the buffer
         const int used = readlane(incl_w, start + cnt - 1) - consumed;
         for (int i = lane; i < used; i += GM_WAVE) rb[i] = 0u;
-        // the task's word: bits 0..11 the row's first word in the buffer, 12..23 bit_off, 31 type B
-        const int meta_l = (row0 & 4095) | (bit_off << 12) | (type_b ? (int)0x80000000u : 0);
+        // A match sets bit (row0 * 32 + b) of the wave's row buffer, b = the match's position in the host row (type A) or bit_off + its
+        // index in the streamed list (type B: = bit_off - list start + its index in col).  The task's two words fold that into one
+        // v_bfi + one add per match: word = row0 * 32 (+ bit_off - list start for type B), word2 = all ones for type B, else 0.
+        const int base_l = row0 * 32 + (type_b ? bit_off - Tk.x : 0);
+        const int sel_l = type_b ? -1 : 0;
         wave_sync();
-        // a match: bit `position in the host row` (type A) or `bit_off + index in the streamed list` (type B) of the task's row
-        // (word = the task's meta, word2 = where its streamed list starts in col)
-        auto hit = [&](const unsigned long long hm, const int meta, const int list0, const unsigned at, const int kidx, const bool) {
+        auto hit = [&](const unsigned long long hm, const int base, const int sel, const unsigned at, const int kidx, const bool) {
           if (hm == 0ull) return;  // wave-uniform
 #ifndef GM_CB_ABLATE_HITS  // (A/B builds: what the row-buffer writes cost; counts wrong)
           if (__builtin_amdgcn_inverse_ballot_w64(hm)) {
-            const int bit = (meta < 0) ? ((meta >> 12) & 4095) + (kidx - list0) : (int)at;
-            atomicOr(&rb[(meta & 4095) + (bit >> 5)], 1u << (bit & 31));
+            const unsigned bit = (unsigned)base + (((unsigned)kidx & (unsigned)sel) | (at & ~(unsigned)sel));
+            atomicOr(&rb[bit >> 5], 1u << (bit & 31u));
           }
 #endif
         };
-        auto hit1 = [&](const int meta, const int list0, const int at, const int kidx) {
+        auto hit1 = [&](const int base, const int sel, const int at, const int kidx) {
           if (lane == 0) {
-            const int bit = (meta < 0) ? ((meta >> 12) & 4095) + (kidx - list0) : at;
-            atomicOr(&rb[(meta & 4095) + (bit >> 5)], 1u << (bit & 31));
+            const unsigned bit = (unsigned)base + (((unsigned)kidx & (unsigned)sel) | ((unsigned)at & ~(unsigned)sel));
+            atomicOr(&rb[bit >> 5], 1u << (bit & 31u));
           }
         };
-        hs_pass<STAGE, kCbTiles>(B.set, L, col, fallback, lane, (in_sub && a > 0) ? Tk.y : 0, Tk.x, H::salt(lo), ru - eb, a, meta_l, Tk.x, hit, hit1);
+        hs_pass<STAGE, kCbTiles>(B.set, L, col, fallback, lane, (in_sub && a > 0) ? Tk.y : 0, Tk.x, H::salt(lo), ru - eb, a, base_l, sel_l, hit, hit1);
         wave_sync();
         // store the finished rows (all of them: a row without a match is a row of zeros)
         const int maxw = wave_max_nonneg(in_sub ? words : 0);
