@@ -910,6 +910,13 @@ def main():
             sub = finish_record(x, a, world, ab, floor, traffic.get(x["workload"]), traffic_src, cpu.get(x["workload"]),
                                 known_answer(a, x["workload"], x["graph"]), stream_gbs, own_of.get(x["workload"]))
             sub = {"id": x["id"], "config": x["config"], **sub, "input_build_s": round(x["input_build_s"], 2)}
+            if x["workload"] == "motif3":
+                sub["solver"] = ("gm_motif default = the reference's formula solver (src/motif/omp_formula.cc:39-46): triangles of the oriented graph with the TC kernel, "
+                                 "wedges = sum C(d,2) - 3T; the enumeration form (automine_3motif, tune[6] & 0x10000000) is measured in per_edge_variant")
+            elif x["workload"] == "diamond":
+                sub["solver"] = ("one GPU: |N(v0) ^ N(v1)| of every edge from one pass over the triangles of the oriented graph (edge supports, gm_sup.hip), then sum C(t,2); "
+                                 "several ranks: one intersection of the two symmetric lists per edge (tune[6] & 0x10000000 selects it on one GPU)") if world <= 1 else \
+                                "several ranks: one intersection of the two symmetric lists per edge (gm_hrow.hip, gm_chunk.h)"
             if x["workload"] == "motif3" and isinstance(x["count"], list) and not a.scale:
                 # gm_motif (k = 3) takes the reference's formula solver (motif_omp_formula / motif_gpu_formula, src/motif/omp_formula.cc:39-46:
                 # the triangles of the oriented graph, wedges derived). The ENUMERATION form (automine_3motif: one bounded intersection of
