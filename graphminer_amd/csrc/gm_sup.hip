@@ -26,6 +26,10 @@
 namespace gm {
 
 constexpr int kSupTiles = 4;
+#ifndef GM_SUP_TILES_SMALL
+#define GM_SUP_TILES_SMALL 4
+#endif
+constexpr int kSupTilesSmall = GM_SUP_TILES_SMALL;  // (1024-bucket kernel)
 constexpr int kSupQueue = 256, kSupFlushAt = kSupQueue - GM_WAVE;  // (a tile adds at most 64 entries)
 
 template <int STAGE>
@@ -122,7 +126,7 @@ void sup_kernel(const MineParams p) {
           qn += 1;
           if (qn > kSupFlushAt) flush();
         };
-        hs_pass<STAGE, kSupTiles>(B.set, L, col, fallback, lane, act ? d.y : 0, d.x, H::salt(lo), ru - eb, a, ru - eb, lane, hit, hit1);
+        hs_pass<STAGE, (STAGE <= 1024 ? kSupTilesSmall : kSupTiles)>(B.set, L, col, fallback, lane, act ? d.y : 0, d.x, H::salt(lo), ru - eb, a, ru - eb, lane, hit, hit1);
         flush();
         const unsigned c = cnt[lane];
         if (valid && c) atomicAdd(&sup[own_e], c);

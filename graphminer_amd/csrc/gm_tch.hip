@@ -23,7 +23,8 @@ namespace gm {
 #ifndef GM_TCH_TILES
 #define GM_TCH_TILES 4
 #endif
-constexpr int kTchTiles = GM_TCH_TILES;  // 64-key tiles in flight per wave
+constexpr int kTchTiles = GM_TCH_TILES;  // 64-key tiles in flight per wave (long lists, 2048-bucket kernel)
+constexpr int kTchTilesSmall = 2;         // ... 1024-bucket kernel
 // ... in the flattened pass of the short lists, per stage (one group ahead is in flight on top; R-MAT-22 / power law / flat degrees /
 // R-MAT-24 formula 3-motif, ms: 4 tiles 3.02 / 1.08 / 0.86 / 42.9, 8 tiles 3.04 / 1.12 / 0.90 / 42.1 -- the 2048-bucket kernel has the registers for 8)
 constexpr int kTchFlatTilesSmall = 4, kTchFlatTilesBig = 8;
@@ -135,7 +136,9 @@ __device__ __forceinline__ unsigned tch_surplus(const TchLds<STAGE> &B, const in
 template <int STAGE>
 __device__ __forceinline__ unsigned tch_pass(TchLds<STAGE> &B, TchWave<TchLds<STAGE>::kBitWindow> &L, const int *__restrict__ col, const bool fallback, const int lane,
                                              const int llen_all, const int key_base, const unsigned salt_l) {
-  constexpr int T = kTchTiles;
+  // (tiles per group of a long list: a list of 200 .. 300 keys fills groups of 128 keys better than groups of 256 -- R-MAT-22, 1 / 2 / 3 / 4 tiles:
+  // 3.14 / 2.89 / 3.02 / 3.03 ms; the 2048-bucket kernel streams longer lists: R-MAT-24 60.3 / 43.1 / 41.6 / 41.0)
+  constexpr int T = STAGE <= 1024 ? kTchTilesSmall : kTchTiles;
   constexpr int TF = STAGE <= 1024 ? kTchFlatTilesSmall : kTchFlatTilesBig;
   unsigned cnt = 0;
   if (wave_max_nonneg(llen_all) == 0) return 0u;  // wave-uniform
