@@ -16,6 +16,7 @@
 //     entries sit in a list of <= 128 (id, salt) pairs that only the lanes missing in such a bucket consult.  A chunk that overflows
 //     the list (adversarial ids) is looked up by bisection of the row in global memory -- slow, exact (tune[6] & 0x800000 forces it).
 // Chunk table, task lists, parts, dequeue order: those of tct_kernel (the kernel is chosen per launch, gm_launch.hip).
+#include <type_traits>
 #include "gm_flat.h"
 
 namespace gm {
@@ -24,7 +25,10 @@ namespace gm {
 #define GM_TCH_TILES 4
 #endif
 constexpr int kTchTiles = GM_TCH_TILES;  // 64-key tiles in flight per wave (long lists, 2048-bucket kernel)
-constexpr int kTchTilesSmall = 2;         // ... 1024-bucket kernel
+#ifndef GM_TCH_TILES_SMALL
+#define GM_TCH_TILES_SMALL 2
+#endif
+constexpr int kTchTilesSmall = GM_TCH_TILES_SMALL;  // ... 1024-bucket kernel
 // ... in the flattened pass of the short lists, per stage (one group ahead is in flight on top; R-MAT-22 / power law / flat degrees /
 // R-MAT-24 formula 3-motif, ms: 4 tiles 3.02 / 1.08 / 0.86 / 42.9, 8 tiles 3.04 / 1.12 / 0.90 / 42.1 -- the 2048-bucket kernel has the registers for 8)
 constexpr int kTchFlatTilesSmall = 4, kTchFlatTilesBig = 8;
@@ -155,19 +159,26 @@ __device__ __forceinline__ unsigned tch_pass(TchLds<STAGE> &B, TchWave<TchLds<ST
     const int n = readlane(llen_all, src);
     const unsigned s_u = (unsigned)readlane((int)salt_l, src);
     const int *__restrict__ kp = col + base;
-    auto process = [&](const int (&key)[T], const unsigned long long (&inm)[T]) {
-      unsigned salt[T];
+    // the first K tiles of a group (K = T in the steady state; the last group of a list looks up only the tiles it has)
+    auto process = [&](auto kc, const int (&key)[T], const unsigned long long (&inm)[T]) {
+      constexpr int K = decltype(kc)::value;
+      int k2[K];
+      unsigned salt[K];
+      unsigned long long i2[K], hm[K], nm[K];
 #pragma unroll
-      for (int q = 0; q < T; ++q) salt[q] = s_u;
-      unsigned long long hm[T], nm[T];
-      tch_probe<STAGE, T>(B, col, fallback, key, salt, inm, hm, nm);
+      for (int q = 0; q < K; ++q) {
+        k2[q] = key[q];
+        salt[q] = s_u;
+        i2[q] = inm[q];
+      }
+      tch_probe<STAGE, K>(B, col, fallback, k2, salt, i2, hm, nm);
       unsigned long long any_need = 0ull;
 #pragma unroll
-      for (int q = 0; q < T; ++q) {
+      for (int q = 0; q < K; ++q) {
         cnt += (unsigned)__popcll(hm[q]);
         any_need |= nm[q];
       }
-      if (any_need != 0ull) cnt += tch_surplus<STAGE, T>(B, lane, key, salt, nm);  // rare
+      if (any_need != 0ull) cnt += tch_surplus<STAGE, K>(B, lane, k2, salt, nm);  // rare
     };
     constexpr int G = GM_WAVE * T;
     int nxt[T];
@@ -185,7 +196,7 @@ __device__ __forceinline__ unsigned tch_pass(TchLds<STAGE> &B, TchWave<TchLds<ST
       const int *__restrict__ kn = kp + (t + G);
 #pragma unroll
       for (int q = 0; q < T; ++q) nxt[q] = kn[(unsigned)(q * GM_WAVE + lane)];
-      process(key, inm);
+      process(std::integral_constant<int, T>{}, key, inm);
     }
     for (; t < n; t += G) {
       int key[T];
@@ -197,7 +208,13 @@ __device__ __forceinline__ unsigned tch_pass(TchLds<STAGE> &B, TchWave<TchLds<ST
       }
 #pragma unroll
       for (int q = 0; q < T; ++q) nxt[q] = kp[min(t + G + q * GM_WAVE + lane, n - 1)];
-      process(key, inm);
+      const int tiles = min(T, (n - t + GM_WAVE - 1) >> 6);  // wave-uniform
+      if (tiles >= T) process(std::integral_constant<int, T>{}, key, inm);
+      else if (tiles == 1) process(std::integral_constant<int, 1>{}, key, inm);
+      else if constexpr (T > 2) {
+        if (tiles == 2) process(std::integral_constant<int, 2>{}, key, inm);
+        else process(std::integral_constant<int, (T > 2 ? 3 : 1)>{}, key, inm);
+      }
     }
   }
 
