@@ -206,10 +206,17 @@ def alg_bytes_device(workload, bg, lib, g):
     return None, floor
 
 
-TCT_STAGE_MAX = 2048   # gm_mine.h kTctStageMax: the longest DAG row the shorter-list-streams TC kernel hosts
-TOPO_MIN_MEAN_ROW = 64.0  # gm_launch.hip kTopoMinMeanRow: DAG patterns run on the topologically renumbered copy from this mean row length on
-TRIM_MIN_LIST = 128    # 3-motif: partner lists of >= 128 keys are trimmed to the keys below max(u, v) before they are streamed
-CB_MIN_DEG, CB_MAX_DEG = 3, 2048  # 4-clique (gm_mine.h kCbMinDeg / kCbMaxDeg): the DAG rows that own a bit-matrix in the arena
+def kernel_constants():
+    """the kernel constants the own-byte model depends on, read from the library (gm_constant: the headers the kernels are compiled with)"""
+    from graphminer_amd import _lib
+
+    lib = _lib.load()
+    out = {}
+    for name in ("tct_stage_max", "topo_min_mean_row", "motif_trim_min_list", "cb_min_deg", "cb_max_deg"):
+        v = C.c_int64(0)
+        _lib.check(lib.gm_constant(name.encode(), C.byref(v)), "gm_constant " + name)
+        out[name] = int(v.value)
+    return out
 
 
 def own_bytes_device(workload, bg, world=1):
@@ -230,6 +237,9 @@ def own_bytes_device(workload, bg, world=1):
     Returns {"bytes", "streamed_keys", "parts"} or None."""
     import torch
 
+    kc = kernel_constants()
+    TCT_STAGE_MAX, TOPO_MIN_MEAN_ROW, TRIM_MIN_LIST = kc["tct_stage_max"], float(kc["topo_min_mean_row"]), kc["motif_trim_min_list"]
+    CB_MIN_DEG, CB_MAX_DEG = kc["cb_min_deg"], kc["cb_max_deg"]
     rp, ci = bg.rp, bg.ci
     nv = rp.numel() - 1
     deg = rp[1:] - rp[:-1]

@@ -97,6 +97,7 @@ SYMBOLS = [
     ("gm_calib_stream", C.c_int, [_P, C.c_int64, _P, _P]),
     ("gm_stream_ceiling", C.c_int, [_P, C.c_int64, _P, _P]),
     ("gm_issue_calib", C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    ("gm_constant", C.c_int, [C.c_char_p, C.POINTER(C.c_int64)]),
     ("gm_selftest", C.c_int, [C.c_int, C.POINTER(C.c_int)]),
 ]
 

@@ -696,7 +696,7 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT,
       }
       L.cnt[lane] = (unsigned)lo;  // read back by the match handler (rare)
     }
-    if (PAT == PAT_MOTIF3 && act && b >= 128) b = lower_bound(col + rv, b, hi);  // only the keys < hi of N(v) can count: trim B too
+    if (PAT == PAT_MOTIF3 && act && b >= kMotifTrimMinList) b = lower_bound(col + rv, b, hi);  // only the keys < hi of N(v) can count: trim B too
     act = act && al > 0 && b > 0;
     // direction: X streams B = N(v) and bisects A; Y takes keys from A and bisects B in HBM
     bool dirx = false;

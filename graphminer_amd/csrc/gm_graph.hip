@@ -121,6 +121,7 @@ int finish_handle(gm_graph *g) {
     gm_touch_sup();
     gm_touch_cbuild();
     gm_touch_wide();
+    gm_touch_cmma();
     gm_touch_sgl();
     gm_touch_tables();
     gm_touch_launch();

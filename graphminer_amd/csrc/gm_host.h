@@ -161,6 +161,7 @@ struct CliqueRound {
   long long n_pos0 = 0, n_count = 0;       // narrow chunks: positions [n_pos0, n_pos0 + n_count) of the rank's share of the narrow table
   size_t w0 = 0, w1 = 0;                    // wide slots [w0, w1) of the plan's vertex list
   size_t cls_begin[4] = {0, 0, 0, 0};       // the round's slots per count class S / L / X, in d_cls_slots
+  size_t mcls_begin[4] = {0, 0, 0, 0};      // ... per class of the matrix-core count kernel (gm_cmma.hip), in d_mcls_slots
   unsigned long long words = 0;             // arena words of the round
   unsigned long long *d_base = nullptr;     // per vertex: word offset of its matrix (nv + 1; non-owners are empty)
   gm::CBuildTask *d_tasks = nullptr;
@@ -179,6 +180,7 @@ struct CliquePlan {
   int *d_verts = nullptr;
   unsigned long long *d_slot_base = nullptr;  // slot -> word offset of its matrix inside its round's arena
   int *d_cls_slots = nullptr;
+  int *d_mcls_slots = nullptr;
   std::vector<CliqueRound> rounds;
   unsigned long long wide_edges = 0;  // task edges of the wide vertices
 };
@@ -317,6 +319,7 @@ void gm_touch_tch();
 void gm_touch_sup();
 void gm_touch_cbuild();
 void gm_touch_wide();
+void gm_touch_cmma();
 void gm_touch_sgl();
 void gm_touch_tables();
 void gm_touch_launch();

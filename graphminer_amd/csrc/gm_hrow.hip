@@ -264,7 +264,7 @@ __device__ __forceinline__ void hrow_pass(HrowWave &L, const Member &member, con
       for (int q = 0; q < T; ++q) any_need |= nm[q];
       if (any_need != 0ull) member.surplus(key, nm, take);  // rare
     };
-    static_assert(kLongList >= 128, "the lists streamed one at a time must be the ones hrow_chunk trims below max(u, v)");
+    static_assert(kLongList >= kMotifTrimMinList, "the lists streamed one at a time must be the ones hrow_chunk trims below max(u, v)");
     constexpr int G = GM_WAVE * T;
     int nxt[T];
 #pragma unroll
@@ -414,7 +414,7 @@ __device__ __forceinline__ void hrow_chunk(const MineParams &p, HrowLds<CLS> &B,
       // (see process_chunk, gm_chunk.h: one bounded intersection per undirected edge serves both directed edges of
       // automine_3motif; the sum of the positions idx over ALL directed edges is kept per lane)
       if (valid) acc.c2 += (unsigned long long)(e - ru);
-      if (act && b >= 128) b = lower_bound(col + rv, b, max(u, v));  // only the keys below max(u, v) can count
+      if (act && b >= kMotifTrimMinList) b = lower_bound(col + rv, b, max(u, v));  // only the keys below max(u, v) can count
       act = act && b > 0;
     }
     L.cnt[lane] = (PAT == PAT_MOTIF3) ? (unsigned)v : 0u;

@@ -215,9 +215,14 @@ using HsWave = HsWaveT<4096>;
 //   hit1(word, word2, at, kidx): one key found through the surplus list (wave-uniform arguments)
 template <int STAGE, int T, class Hit, class Hit1>
 __device__ __forceinline__ void hs_pass(const HsTable<STAGE> &S, HsWave<STAGE> &L, const int *__restrict__ col, const bool fallback, const int lane,
-                                        const int llen_all, const int key_base, const unsigned salt_l, const int rlo_l, const int rlen_l,
+                                        const int llen_all, const int key_base, const unsigned salt_l, const int rlo_l, const int rlen_in,
                                         const int word_l, const int word2_l, Hit hit, Hit1 hit1) {
   if (wave_max_nonneg(llen_all) == 0) return;  // wave-uniform
+  // The table holds no entry at a stage index >= kPosLimit (those live in the surplus list), but an EMPTY slot / the overflow MARKER
+  // decode to exactly those two indices for every key whose hash has its low 32 - LB bits all ones (ids such as 3461295 for LB = 10):
+  // a row that covers index STAGE - 1 or STAGE - 2 must not accept them.  Clamped once per task: a table hit is only looked for
+  // below kPosLimit; true entries at the two indices are found through their bucket's marker + the surplus list, which does not use rlen.
+  const int rlen_l = min(rlen_in, max(0, (int)HsHash<STAGE>::kPosLimit - rlo_l));
   const bool is_long = llen_all >= kLongList;
   const int llen = is_long ? 0 : llen_all;
   // ---- long lists: one task at a time, wave-uniform base / salt / word; the keys of the NEXT tile group are requested before the

@@ -445,7 +445,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
     }
     int qword = 0;
     for (const auto &rd : plan->rounds) {
-      if (qword + 5 > 16384) return GM_ERR_TOO_LARGE;  // (more than ~3000 arena rounds)
+      if (qword + 8 > 16384) return GM_ERR_TOO_LARGE;  // (more than ~3000 arena rounds)
       if (rd.n_tasks > 0) {
         CBuildParams pw;
         memset(&pw, 0, sizeof pw);
@@ -462,7 +462,26 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
         if (pw.count > 0) HIP_TRY(launch_cbuild(pw, plan->stage, bgrid, stream));
         plan_chunks += (uint64_t)pw.count;
       }
-      for (int cls = 2; cls >= 0; --cls) {  // X and L (one workgroup per CU) before S
+      // pair counts of the wide vertices: on the matrix cores (gm_cmma.hip), or -- tune[6] & 0x20000 -- the vector-ALU classes of round 3
+      const bool valu_counts = (la->tune[6] & 0x20000) != 0;
+      for (int cls = 2; cls >= 0 && !valu_counts; --cls) {  // the column blocks and the one-per-CU workgroups before the small ones
+        CliqueCountParams c;
+        memset(&c, 0, sizeof c);
+        c.rp = g->d_rp;
+        c.verts = plan->d_verts;
+        c.base = plan->d_slot_base;
+        c.mat = g->d_wide_mat;
+        c.slots = plan->d_mcls_slots + rd.mcls_begin[cls];
+        c.count = (int)(rd.mcls_begin[cls + 1] - rd.mcls_begin[cls]);
+        c.queue = g->d_wide_queue + qword++;
+        c.counters = g->d_counters;
+        c.topo = plan->topo ? 1 : 0;
+        if (c.count == 0) continue;
+        const int per_cu_c = (int)std::max<size_t>(1, std::min<size_t>((160 * 1024) / clique_mma_lds_bytes(cls), (size_t)(2048 / clique_mma_threads(cls))));
+        const int cgrid = (int)std::max<long long>(1, std::min<long long>((long long)c.count * (cls == 2 ? 8 : 1), (long long)g->cu_count * per_cu_c));
+        HIP_TRY(launch_clique_mma(cls, c, cgrid, stream));
+      }
+      for (int cls = 2; cls >= 0 && valu_counts; --cls) {  // X and L (one workgroup per CU) before S
         CliqueCountParams c;
         memset(&c, 0, sizeof c);
         c.rp = g->d_rp;
@@ -684,7 +703,6 @@ __global__ __launch_bounds__(256) void sum_sq_deg_kernel(int nv, const int *__re
   s = gm::wave_sum_u64(s);
   if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
 }
-constexpr double kTopoMinMeanRow = 64.0;
 
 // sum d^2 / ne of a handle's rows = the mean length of the row an entry sits in (cached)
 int ensure_mean_sq_deg(gm_graph *self) {
@@ -728,7 +746,7 @@ static int topo_view(const gm_graph *dag, const gm_launch *la, gm_graph **run_on
   if (rc || topo) return rc;
   rc = ensure_mean_sq_deg(self);
   if (rc) return rc;
-  double min_row = kTopoMinMeanRow;
+  double min_row = (double)kTopoMinMeanRow;
   if (const char *e = getenv("GM_TOPO_MIN_ROW")) min_row = atof(e);
   if (getenv("GM_TABLE_INFO")) fprintf(stderr, "[topo view] sum d+^2 / |E+| = %.1f (switch at %.1f)\n", self->mean_sq_deg, min_row);
   if (self->mean_sq_deg < min_row) return GM_OK;  // short lists: as numbered

@@ -300,6 +300,35 @@ __host__ __device__ inline int clique_count_class(int d) {
   return (long long)d * clique_copy_stride(d, w, kCountWordsL) <= kCountWordsL ? 1 : 2;
 }
 
+// ---- the same counts on the matrix cores (gm_cmma.hip; the default since round 4, tune[6] & 0x20000: the vector-ALU classes above) ----
+// sum_{i,j} M_ij (M M^T)_ij as FP4 MFMA over 64 x 64 blocks of (i, j).  LDS copy: rows padded to a multiple of 64, row stride = the
+// (even) block width rounded up to 2 mod 4 words, so that the 64 lanes of an operand fragment (32 rows x 2 adjacent words) read 64
+// different banks.  Classes: 0 = whole matrix in 36 KB (d+ <= 512; 4 waves, four workgroups per CU), 1 = whole matrix in 144 KB
+// (d+ <= 1024; 16 waves, one per CU), 2 = column blocks of an even number of words (<= 8 per vertex, a queue entry each).
+constexpr int kMmaWavesS = 4, kMmaWordsS = 9216;
+constexpr int kMmaWavesL = 16, kMmaWordsL = 36864;
+__host__ __device__ inline int clique_mma_stride(int cw_even) { return (cw_even & 3) == 2 ? cw_even : cw_even + 2; }
+__host__ __device__ inline bool clique_mma_fits(int d, int cw_even, int budget_words) {
+  return (long long)((d + 63) & ~63) * clique_mma_stride(cw_even) <= budget_words;
+}
+// words per column block: the fewest equal blocks (>= 2) whose copy fits
+__host__ __device__ inline int clique_mma_block_words(int d, int budget_words) {
+  const int stride = (d + 31) / 32;
+  for (int nb = 2; nb < 8; ++nb) {
+    const int cw = (((stride + nb - 1) / nb) + 1) & ~1;
+    if (clique_mma_fits(d, cw, budget_words)) return cw;
+  }
+  return (((stride + 7) / 8) + 1) & ~1;
+}
+__host__ __device__ inline int clique_mma_class(int d) {
+  const int cw = (((d + 31) / 32) + 1) & ~1;
+  if (clique_mma_fits(d, cw, kMmaWordsS)) return 0;
+  return clique_mma_fits(d, cw, kMmaWordsL) ? 1 : 2;
+}
+hipError_t launch_clique_mma(int cls, const CliqueCountParams &p, int grid_blocks, hipStream_t stream);
+size_t clique_mma_lds_bytes(int cls);
+int clique_mma_threads(int cls);
+
 // ---- k-clique (k = 4), level 1 RE-HOSTED (gm_cbuild.hip) -------------------------------------------------------------------------
 // Row i of u's adjacency bit-matrix over N+(u) is N+(u) ^ N+(v), v = N+(u)[i] -- the triangle list of the DAG edge u -> v with
 // positions. Like the triangle count of gm_tct.hip it is symmetric in which list is staged: the edge is a TASK of the endpoint with
@@ -348,6 +377,10 @@ struct CliqueSmallParams {
   int topo;                          // strictly upper triangular matrices: the words below j / 32 of M_j are skipped
 };
 hipError_t launch_clique_small(const CliqueSmallParams &p, int grid_blocks, hipStream_t stream);
+
+// constants the byte model of bench.py needs: exported through gm_constant (gm_tools.hip) so that they cannot drift apart
+constexpr int kMotifTrimMinList = 128;  // 3-motif enumeration: a partner list of >= this many keys is trimmed to its keys below max(u, v)
+constexpr int kTopoMinMeanRow = 64;     // DAG patterns run on the topologically renumbered copy from this mean row length (sum d+^2 / |E+|) on
 
 // host-side launchers (gm_mine.hip)
 hipError_t launch_mine(Pattern pat, const MineParams &p, int grid_blocks, hipStream_t stream);

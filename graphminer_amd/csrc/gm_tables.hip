@@ -906,6 +906,7 @@ static void free_clique_plan(CliquePlan &pl) {
   if (pl.d_verts) (void)hipFree(pl.d_verts);
   if (pl.d_slot_base) (void)hipFree(pl.d_slot_base);
   if (pl.d_cls_slots) (void)hipFree(pl.d_cls_slots);
+  if (pl.d_mcls_slots) (void)hipFree(pl.d_mcls_slots);
   for (auto &rd : pl.rounds) {
     if (rd.d_base) (void)hipFree(rd.d_base);
     if (rd.d_tasks) (void)hipFree(rd.d_tasks);
@@ -913,7 +914,7 @@ static void free_clique_plan(CliquePlan &pl) {
     free_table(rd.host_tab);
   }
   pl.rounds.clear();
-  pl.d_verts = nullptr; pl.d_slot_base = nullptr; pl.d_cls_slots = nullptr;
+  pl.d_verts = nullptr; pl.d_slot_base = nullptr; pl.d_cls_slots = nullptr; pl.d_mcls_slots = nullptr;
 }
 void free_clique_plans(gm_graph *g) {
   for (auto &pl : g->clique_plans) free_clique_plan(pl);
@@ -1097,7 +1098,7 @@ int get_clique_plan(gm_graph *g, int rank, int world, int policy, int target, un
     hipLaunchKernelGGL(cb_chunk_words_kernel, blocks(pl.n_count), dim3(256), 0, 0, pl.n_count, pl.n_first, pl.n_step, pl.d_order, pl.tabN->d, g->d_rp, dcw.p);
     HIP_TRY(hipMemcpy(cw.data(), dcw.p, sizeof(unsigned long long) * (size_t)pl.n_count, hipMemcpyDeviceToHost));
   }
-  std::vector<int> cls_slots;
+  std::vector<int> cls_slots, mcls_slots;
   {
     long long c0 = 0;
     size_t s0 = 0;
@@ -1110,7 +1111,7 @@ int get_clique_plan(gm_graph *g, int rank, int world, int policy, int target, un
         words += cw[(size_t)c1];
       }
       size_t s1 = s0;
-      std::vector<int> by_cls[3];
+      std::vector<int> by_cls[3], by_mcls[3];
       if (c1 == pl.n_count) {  // (wide vertices only once the narrow chunks are placed)
         for (; s1 < (size_t)wcount; ++s1) {
           const int d = hd[s1];
@@ -1119,6 +1120,7 @@ int get_clique_plan(gm_graph *g, int rank, int world, int policy, int target, un
           words += w;
           pl.wide_edges += (unsigned long long)d;
           by_cls[clique_count_class(d)].push_back((int)s1);
+          by_mcls[clique_mma_class(d)].push_back((int)s1);
         }
       }
       rd.n_pos0 = c0; rd.n_count = c1 - c0;
@@ -1128,6 +1130,11 @@ int get_clique_plan(gm_graph *g, int rank, int world, int policy, int target, un
         cls_slots.insert(cls_slots.end(), by_cls[c].begin(), by_cls[c].end());
       }
       rd.cls_begin[3] = cls_slots.size();
+      for (int c = 0; c < 3; ++c) {
+        rd.mcls_begin[c] = mcls_slots.size();
+        mcls_slots.insert(mcls_slots.end(), by_mcls[c].begin(), by_mcls[c].end());
+      }
+      rd.mcls_begin[3] = mcls_slots.size();
       pl.rounds.push_back(std::move(rd));
       c0 = c1;
       s0 = s1;
@@ -1136,6 +1143,8 @@ int get_clique_plan(gm_graph *g, int rank, int world, int policy, int target, un
   }
   HIP_TRY(hipMalloc(&pl.d_cls_slots, sizeof(int) * std::max<size_t>(cls_slots.size(), 1)));
   if (!cls_slots.empty()) HIP_TRY(hipMemcpy(pl.d_cls_slots, cls_slots.data(), sizeof(int) * cls_slots.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&pl.d_mcls_slots, sizeof(int) * std::max<size_t>(mcls_slots.size(), 1)));
+  if (!mcls_slots.empty()) HIP_TRY(hipMemcpy(pl.d_mcls_slots, mcls_slots.data(), sizeof(int) * mcls_slots.size(), hipMemcpyHostToDevice));
   unsigned long long need_words = 0;
   for (size_t r = 0; r < pl.rounds.size(); ++r) {
     const int rc = build_clique_round(g, pl, pl.rounds[r], tmp);

@@ -136,6 +136,25 @@ __global__ __launch_bounds__(256) void stream_ceiling_kernel(const gm_v4i *__res
   if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
 }
 
+// Kernel constants the byte model of bench.py (own_bytes_device) depends on, by name -- read from the headers the kernels are compiled
+// with, so the model cannot drift from them.
+extern "C" int gm_constant(const char *name, int64_t *value) {
+  if (!name || !value) return GM_ERR_INVALID;
+  static const struct { const char *name; long long v; } tab[] = {
+      {"tct_stage_max", kTctStageMax},       {"topo_min_mean_row", kTopoMinMeanRow}, {"motif_trim_min_list", kMotifTrimMinList},
+      {"cb_min_deg", kCbMinDeg},             {"cb_max_deg", kCbMaxDeg},               {"long_list", kLongList},
+      {"stage_cap", kStageCap},              {"default_chunk", kDefaultChunk},        {"mma_words_small", kMmaWordsS},
+      {"mma_words_big", kMmaWordsL},         {"wide_max_deg", kWideMaxDeg},           {"bit_words", kBitWords},
+  };
+  for (const auto &e : tab)
+    if (strcmp(e.name, name) == 0) {
+      *value = e.v;
+      return GM_OK;
+    }
+  g_last_error = std::string("gm_constant: unknown name '") + name + "'";
+  return GM_ERR_INVALID;
+}
+
 extern "C" int gm_stream_ceiling(const int32_t *d_buf, int64_t n, uint64_t *d_out, void *stream) {
   if (!d_buf || !d_out || n < 0 || ((uintptr_t)d_buf & 15)) return GM_ERR_INVALID;
   int dev = 0, cus = 256;

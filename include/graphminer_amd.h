@@ -270,6 +270,11 @@ int gm_stream_ceiling(const int32_t *d_buf, int64_t n, uint64_t *d_out, void *st
 int gm_issue_calib(int kind, int waves_per_simd, int iters, double *cycles_per_wave_inst, double *inst_per_cycle_simd, double *ms,
                    double *residency /* measured: waves of the launch in flight per SIMD at the same time (mean over SIMDs of the maximum) */);
 
+/* Tooling: a kernel constant by name ("tct_stage_max", "topo_min_mean_row", "motif_trim_min_list", "cb_min_deg", "cb_max_deg",
+ * "long_list", "stage_cap", "default_chunk", "mma_words_small", "mma_words_big", "wide_max_deg", "bit_words") -- what the byte model
+ * of bench.py needs to know about the kernels, read from the headers they are compiled with. GM_ERR_INVALID for an unknown name. */
+int gm_constant(const char *name, int64_t *value);
+
 /* wave-primitive self test (DPP scans, ballot rank, LDS search); returns GM_OK when the device
  * results equal the host expectation. *n_fail receives the number of mismatching lanes. */
 int gm_selftest(int device, int *n_fail);

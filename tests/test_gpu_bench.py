@@ -168,7 +168,7 @@ def test_own_algorithm_bytes_equal_a_brute_force_count():
             s, n = (v, b) if u_longer else (u, a)
             kd += n
             row = hci[hrp[s]:hrp[s + 1]]
-            km += int(np.searchsorted(row, max(u, v))) if n >= bench.TRIM_MIN_LIST else n
+            km += int(np.searchsorted(row, max(u, v))) if n >= bench.kernel_constants()["motif_trim_min_list"] else n
     ne = hci.size
     assert bench.own_bytes_device("diamond", bg, 2)["bytes"] == 4 * kd + 12 * ne + 8 * (nv + 1)  # (several ranks: one intersection per edge)
     assert bench.own_bytes_device("motif3e", bg)["bytes"] == 4 * km + 12 * ne + 8 * (nv + 1) and km < kd  # (the enumeration kernels)
@@ -179,15 +179,15 @@ def test_own_algorithm_bytes_equal_a_brute_force_count():
     kt = kc = tasks = 0
     rank = np.empty(nv, dtype=np.int64)  # the library's topological numbering of the DAG: ids ascending in (symmetric degree, id)
     rank[np.lexsort((np.arange(nv), deg))] = np.arange(nv)
-    trim = float((dp.astype(np.float64) ** 2).sum()) / dci.size >= bench.TOPO_MIN_MEAN_ROW  # (topo_view: renumbered and trimmed only where rows are long)
+    trim = float((dp.astype(np.float64) ** 2).sum()) / dci.size >= bench.kernel_constants()["topo_min_mean_row"]  # (topo_view: renumbered and trimmed only where rows are long)
     assert trim, "the graph must be one the library renumbers"
     for u in range(nv):
         row = dci[drp[u]:drp[u + 1]]
         for i, v in enumerate(row[np.argsort(rank[row])]):
             kt += dp[v] if dp[u] >= dp[v] else dp[u] - i - 1  # (no row beyond 2048 entries here)
-            if bench.CB_MIN_DEG <= dp[u] <= bench.CB_MAX_DEG:
+            if bench.kernel_constants()["cb_min_deg"] <= dp[u] <= bench.kernel_constants()["cb_max_deg"]:
                 tasks += 1
-                kc += dp[u] - i - 1 if dp[v] > dp[u] and dp[v] <= bench.CB_MAX_DEG else dp[v]
+                kc += dp[u] - i - 1 if dp[v] > dp[u] and dp[v] <= bench.kernel_constants()["cb_max_deg"] else dp[v]
     assert dp.max() > 64 and tasks > 0 and kt < int(np.minimum(dp[np.repeat(np.arange(nv), dp)], dp[dci]).sum()), "the graph must have long DAG rows for this check to mean something"
     nd = dci.size
     assert bench.own_bytes_device("tc", bg)["bytes"] == 4 * int(kt) + 12 * nd + 8 * (nv + 1)
@@ -199,7 +199,7 @@ def test_own_algorithm_bytes_equal_a_brute_force_count():
         for v in dci[drp[u]:drp[u + 1]]:
             tri += len(ru.intersection(dci[drp[v]:drp[v + 1]].tolist()))
     assert bench.own_bytes_device("diamond", bg)["bytes"] == 4 * int(kt) + 12 * nd + 8 * (nv + 1) + 20 * nd + 4 * tri
-    own = dp[(dp >= bench.CB_MIN_DEG) & (dp <= bench.CB_MAX_DEG)].astype(np.int64)
+    own = dp[(dp >= bench.kernel_constants()["cb_min_deg"]) & (dp <= bench.kernel_constants()["cb_max_deg"])].astype(np.int64)
     arena = int((own * ((own + 31) // 32)).sum())
     assert bench.own_bytes_device("clique4", bg)["bytes"] == 4 * int(kc) + 16 * tasks + 4 * nd + 16 * (nv + 1) + 8 * arena
     bg.free()

@@ -829,3 +829,47 @@ def test_tc_hashed_set_with_colliding_ids(dev):
         assert CliqueSolver(dag, 4, tune=[0, 0, 0, 0, 0, 0, 0x200]) == want4
         assert CliqueSolver(dag, 4, tune=[0, 0, 0, 0, 0, 0, 0x200 | 0x800000]) == want4  # ... on its global-memory fallback lookup
         assert CliqueSolver(dag, 4, tune=[0, 0, 0, 0, 0, 0, 0x40000]) == want4           # the mining kernel's arena path
+
+
+@pytest.mark.parametrize("row,x", [(1024, 3461295), (1023, 3461295), (2048, 1364143), (2047, 1364143)])
+def test_hashed_position_set_rejects_the_empty_slot_indices(dev, row, x):
+    """in gm_hset.h an EMPTY slot / the overflow MARKER XOR the probe word decode to the stage indices STAGE - 1 /
+    STAGE - 2 for every key whose hash has its low 32 - LB bits all ones (3461295 for the 1024-entry stage, 1364143 for 2048) -- a
+    host row that covers those indices took such a key for a member.  Vertex 0 gets a DAG row of exactly `row` hubs, hub 1 also points
+    at x (not a neighbour of 0): the task (0 -> 1) streams x against the row.  Diamond (edge supports) and 4-clique (re-hosted build)
+    against the oracle and against the kernels that do not use the position set."""
+    rng = np.random.default_rng(row)
+    hubs = np.arange(1, row + 1, dtype=np.int64)
+    iu, ju = np.triu_indices(row, 1)
+    keep = rng.random(iu.size) < 0.02
+    s, d = [np.zeros(row, dtype=np.int64), hubs[iu[keep]]], [hubs, hubs[ju[keep]]]
+    s.append(np.array([1, 2, 3], dtype=np.int64))  # x beside three hubs, so that the task lists that hold it are short
+    d.append(np.full(3, x, dtype=np.int64))
+    s, d = np.concatenate(s), np.concatenate(d)
+    deg = np.bincount(np.concatenate([s, d]), minlength=x + 1)
+    want_deg = row + rng.integers(0, 17, size=row)  # hubs out-rank vertex 0 (degree `row`, smallest id), in a mixed order among themselves
+    nxt, ls, ld = row + 1, [], []
+    for v, t in list(zip(hubs, want_deg)) + [(x, row + 8)]:
+        n = int(t - deg[v])
+        ids = np.arange(nxt, nxt + n, dtype=np.int64)
+        ids = ids + (ids >= x)  # (leaf ids skip x)
+        nxt += n
+        ls.append(np.full(n, v, dtype=np.int64))
+        ld.append(ids)
+    s, d = np.concatenate([s] + ls), np.concatenate([d] + ld)
+    nv = int(max(x + 1, d.max() + 1))
+    g = csr_from_pairs(nv, s.astype(np.uint64), d.astype(np.uint64))
+    osym = O.OGraph(g.row_ptr, g.col_idx)
+    odag = O.orient(osym)
+    assert int(odag.row_ptr[1] - odag.row_ptr[0]) == row and x not in set(g.col_idx[g.row_ptr[0]:g.row_ptr[1]].tolist())
+    sym = g.to_device(dev)
+    dag = sym.orient()
+    per_edge = [0, 0, 0, 0, 0, 0, 0x10000000]
+    want_d, want_4 = O.diamond(osym), O.clique(odag, 4)
+    assert SglSolver(sym, "diamond", tune=per_edge) == want_d
+    assert CliqueSolver(dag, 4, tune=[0, 0, 0, 0, 0, 0, 0x40000]) == want_4
+    for t6 in (0, 0x200):
+        assert SglSolver(sym, "diamond", tune=[0, 0, 0, 0, 0, 0, t6]) == want_d, hex(t6)
+        assert CliqueSolver(dag, 4, tune=[0, 0, 0, 0, 0, 0, t6]) == want_4, hex(t6)
+    assert TCSolver(dag) == O.tc(odag)
+    sym.free()
