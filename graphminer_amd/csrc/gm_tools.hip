@@ -2,6 +2,7 @@
 // the PMC / stream-ceiling / issue-rate calibration kernels, the wave-primitive self test.
 #include "gm_host.h"
 #include "gm_setops.h"
+#include "gm_flat.h"
 using namespace gm;
 
 // ------------------------------------------------------------------------------------------------
