@@ -1,0 +1,115 @@
+// gm_cgather.hip -- k-clique (k = 4), first DFS level of the WIDE vertices GATHERED from a dense bitmap of the hub core.
+//
+// Row i of u's adjacency bit-matrix over N+(u) = [s_0 < s_1 < ...] is  M_u[i][j] = [s_i -> s_j is an edge]  (j > i under a topological
+// numbering).  The streamed build (gm_cbuild.hip) finds those bits as a set intersection N+(u) ^ N+(s_i): a hashed lookup per streamed
+// key, 44 VALU per 64 keys, 23 G keys on the com-Orkut stand-in -- 34.5 of the 42.5 ms left after the pair counts moved to the matrix
+// cores.  But M_u is just the adjacency matrix of the subgraph induced by N+(u), and for a WIDE vertex (d+ > 256) of a DAG numbered by
+// degree nearly all of N+(u) lies among the LAST few 10^4 ids -- the hubs.  Their adjacency is kept DENSE (gm_graph::d_core: core_h x
+// core_h bits, one row per core vertex, built once per graph), and a row of M_u is a bit GATHER:
+//     M_u[i][j] = core[s_i - base][s_j - base],   j > i, s_i >= base  (then every s_j > s_i is in the core too)
+// -- lane j of a 64-column tile loads the word that holds its bit (the positions are ascending and dense at the top of the id range:
+// 1.4 - 3.8 bytes of 64-byte lines per probe on R-MAT, each gathered dword serves ~3 probes), tests it, and the ballot IS 64 bits of
+// the row: ~10 instructions per 64 probes, no hash, no table build, no LDS atomics.  96 % of the first-level work of the wide vertices
+// of R-MAT graphs has its first endpoint in a core of nv / 32 vertices; the rows whose first endpoint lies below the core (the first
+// entries of the ascending list) stay tasks of the streamed build.  Rows are stored to the matrix arena like the streamed build's;
+// the pair counts (gm_cmma.hip) read them from there.
+// (reference shape: src/clique/gpu_kernels/clique4_warp_edge.cuh:19-21 re-intersects N+(v0) ^ N+(v1) from global memory per edge)
+#include <algorithm>
+#include "gm_flat.h"
+#pragma clang diagnostic ignored "-Winline-asm"  // (M0 on a clobber list: see cg_tile)
+
+namespace gm {
+
+constexpr int kCgWaves = 8;
+constexpr int kCgUnroll = 8;  // tiles of a row whose gathers are in flight together
+
+struct alignas(16) CGatherLds {
+  int2 info[kCbMaxDeg + GM_WAVE];  // per column j: {byte offset of the word of bit s_j - core_base in a core row, s_j - core_base} (-1: below the core)
+  unsigned queue_pos;
+  int k0;
+  int pad_[2];
+};
+
+// tile t of row i: 64 probes of the core row at the columns' positions -> the 64 bits of the row, left in lanes 2t / 2t + 1 of w_out
+// (CHECKED: the tile that holds the diagonal -- only columns beyond i count -- or the end of the row)
+template <bool CHECKED>
+__device__ __forceinline__ void cg_tile(const unsigned w, const int2 inf, const int t, const int i, const int d, const int lane, unsigned &w_out) {
+  bool bit = __builtin_amdgcn_ubfe(w, (unsigned)inf.y, 1u) != 0u;  // (v_bfe_u32 takes the low five bits of the offset)
+  if (CHECKED) {
+    const int j = t * GM_WAVE + lane;
+    bit = bit && j > i && j < d;
+  }
+  const unsigned long long m = __ballot(bit);
+  // (v_writelane_b32: no clang builtin in ROCm 7.2.  Value and lane select are both scalar; gfx950 allows ONE SGPR on the constant
+  // bus, so the lane select goes through M0 -- nothing else in this kernel uses M0)
+  asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(w_out) : "s"((unsigned)m), "s"(2 * t) : "m0");
+  asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(w_out) : "s"((unsigned)(m >> 32)), "s"(2 * t + 1) : "m0");
+}
+
+__global__ __launch_bounds__(kCgWaves *GM_WAVE) void cgather_kernel(const CGatherParams p) {
+  __shared__ CGatherLds S;
+  constexpr int NT = kCgWaves * GM_WAVE;
+  const int tid = threadIdx.x, lane = tid & (GM_WAVE - 1), wave = readfirst(tid >> 6);  // (uniform: rows, tiles and row pointers live in SGPRs)
+  // the core bitmap as ONE buffer resource: a gather is buffer_load_dword with the row's byte offset as the scalar offset and the word's
+  // byte offset inside the row as the lane offset (global_load with a 64-bit lane address cost two more VALU per tile here)
+  const __amdgpu_buffer_rsrc_t core = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(p.core), 0, (int)p.core_bytes, 0x00020000);
+  for (;;) {
+    if (tid == 0) S.queue_pos = atomicAdd(p.queue, 1u);
+    __syncthreads();
+    const unsigned q = S.queue_pos;
+    if (q >= (unsigned)p.count) break;
+    const int slot = p.first_slot + (int)q;
+    const int u = p.verts[slot];
+    const int ru = p.rp[u], d = p.rp[u + 1] - ru, stride = (d + 31) >> 5;
+    unsigned *__restrict__ mu = p.mat + p.base[slot];
+    const int dpad = (d + GM_WAVE - 1) & ~(GM_WAVE - 1);
+    for (int j = tid; j < dpad; j += NT) {
+      const int pj = j < d ? p.col[ru + j] - p.core_base : -1;
+      S.info[j] = make_int2(pj >= 0 ? (pj >> 5) << 2 : 0, pj);
+    }
+    if (tid == 0) S.k0 = lower_bound(p.col + ru, d, p.core_base);  // rows [0, k0): first endpoint below the core -- the streamed build's
+    __syncthreads();
+    const int k0 = S.k0;
+    const int ntiles = dpad >> 6;
+    for (int i = k0 + wave; i < d; i += kCgWaves) {
+      const int rowo = readfirst(S.info[i].y) * p.core_words * 4;  // (scalar: < 2^32 bytes, launch_cgather checks)
+      unsigned w_out = 0u;  // lane L: word L of the row (the words below the diagonal are zero)
+      const int t0 = (i + 1) >> 6;
+      if (t0 < ntiles) {  // the tile of the diagonal
+        const int2 inf = S.info[t0 * GM_WAVE + lane];
+        cg_tile<true>((unsigned)__builtin_amdgcn_raw_buffer_load_b32(core, inf.x, rowo, 0), inf, t0, i, d, lane, w_out);
+      }
+      int tb = t0 + 1;
+      for (; tb + kCgUnroll < ntiles; tb += kCgUnroll) {  // whole tiles beyond it, kCgUnroll gathers in flight
+        int2 inf[kCgUnroll];
+        unsigned w[kCgUnroll];
+#pragma unroll
+        for (int k = 0; k < kCgUnroll; ++k) inf[k] = S.info[(tb + k) * GM_WAVE + lane];
+#pragma unroll
+        for (int k = 0; k < kCgUnroll; ++k) w[k] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(core, inf[k].x, rowo, 0);
+#pragma unroll
+        for (int k = 0; k < kCgUnroll; ++k) cg_tile<false>(w[k], inf[k], tb + k, i, d, lane, w_out);
+      }
+      for (; tb < ntiles; ++tb) {  // the rest, the row's last tile among them
+        const int2 inf = S.info[tb * GM_WAVE + lane];
+        cg_tile<true>((unsigned)__builtin_amdgcn_raw_buffer_load_b32(core, inf.x, rowo, 0), inf, tb, i, d, lane, w_out);
+      }
+      if (lane < stride) mu[(size_t)i * stride + lane] = w_out;
+    }
+    __syncthreads();  // the column table is rewritten by the next vertex
+  }
+}
+
+hipError_t launch_cgather(const CGatherParams &p, int grid_blocks, hipStream_t stream) {
+  static_assert(kCbMaxDeg <= 2048, "a row is at most 64 words: one per lane");
+  if (p.core == nullptr || p.mat == nullptr || p.core_bytes == 0 || p.core_bytes > 0xffffffffull) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(cgather_kernel, dim3((unsigned)grid_blocks), dim3(kCgWaves * GM_WAVE), 0, stream, p);
+  return hipGetLastError();
+}
+int cgather_per_cu() { return (int)std::min<size_t>(163840 / sizeof(CGatherLds), 2048 / (kCgWaves * GM_WAVE)); }
+
+}  // namespace gm
+
+// (module warm-up, gm_graph.hip finish_handle: HIP loads the code object of a translation unit when one of its kernels is first launched)
+__global__ void gm_touch_cgather_kernel() {}
+void gm_touch_cgather() { hipLaunchKernelGGL(gm_touch_cgather_kernel, dim3(1), dim3(1), 0, 0); }

@@ -93,6 +93,7 @@ extern "C" void gm_graph_free(gm_graph *g) {
   if (g->pool.base) (void)hipFree(g->pool.base);
   if (g->d_counters) (void)hipFree(g->d_counters);
   if (g->d_scratch) (void)hipFree(g->d_scratch);
+  if (g->d_core) (void)hipFree(g->d_core);
   if (g->d_idx0) (void)hipFree(g->d_idx0);
   if (g->d_wblock_prefix) (void)hipFree(g->d_wblock_prefix);
   if (g->d_house_prefix) (void)hipFree(g->d_house_prefix);
@@ -122,6 +123,7 @@ int finish_handle(gm_graph *g) {
     gm_touch_cbuild();
     gm_touch_wide();
     gm_touch_cmma();
+    gm_touch_cgather();
     gm_touch_sgl();
     gm_touch_tables();
     gm_touch_launch();

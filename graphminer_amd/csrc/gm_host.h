@@ -181,6 +181,8 @@ struct CliquePlan {
   unsigned long long *d_slot_base = nullptr;  // slot -> word offset of its matrix inside its round's arena
   int *d_cls_slots = nullptr;
   int *d_mcls_slots = nullptr;
+  int core_base = -1;                // >= 0: the rows of the wide vertices' matrices whose first endpoint is >= core_base are gathered from the
+                                     // core bitmap of the graph (gm_cgather.hip); the task lists of the streamed build leave them out
   std::vector<CliqueRound> rounds;
   unsigned long long wide_edges = 0;  // task edges of the wide vertices
 };
@@ -259,6 +261,12 @@ struct gm_graph {
   unsigned *d_wide_mat = nullptr;      // matrix arena (largest round so far)
   size_t wide_mat_bytes = 0;
   unsigned *d_wide_queue = nullptr;    // dequeue words of the wide launches of one call (zeroed per call)
+  // k-clique on a topologically numbered DAG: dense adjacency bitmap of its LAST core_h vertices (the hubs, when the numbering is by
+  // degree) -- row v - core_base holds bit w - core_base for every edge v -> w; the rows of the wide vertices' matrices whose first
+  // endpoint lies in this core are GATHERED from it (gm_cgather.hip) instead of being built by streamed intersections
+  unsigned *d_core = nullptr;
+  int core_h = 0, core_base = 0;       // core_h = 0: not built / not applicable (ensure_core_bitmap)
+  int core_state = 0;                  // 0 unknown, 1 built, 2 not applicable
   hipStream_t aux_stream[3] = {nullptr, nullptr, nullptr};  // class kernels that cannot fill the chip run beside the others (run_pattern)
   hipEvent_t aux_done[3] = {nullptr, nullptr, nullptr};
   TempPool pool;  // temporaries of the setup paths (PoolScope)
@@ -320,6 +328,7 @@ void gm_touch_sup();
 void gm_touch_cbuild();
 void gm_touch_wide();
 void gm_touch_cmma();
+void gm_touch_cgather();
 void gm_touch_sgl();
 void gm_touch_tables();
 void gm_touch_launch();
@@ -331,6 +340,7 @@ int host_rp(gm_graph *g, const std::vector<int> **out);          // gm_graph.hip
 int convert_offsets(const int64_t *rp64, int nv, long long ne, std::vector<int> &out);  // gm_graph.hip: host-side narrowing / validation
 int get_relabeled(gm_graph *g, int mode, gm_graph **out);  // gm_graph.hip: cached renumbered copy (0 / 1 by degree, 2 topological)
 int graph_is_topological(gm_graph *g, bool *out);
+int ensure_core_bitmap(gm_graph *g);  // (gm_tables.hip) d_core / core_h / core_base of a topologically numbered DAG; GM_OK also when not applicable
 void free_tables(gm_graph *g);                                   // gm_tables.hip
 int get_table(gm_graph *g, int target, bool allow_split, int bit_words, unsigned long long part_cap, int stage_cap, ChunkTable **out,
               const RowFilter &rf = RowFilter(), int bitmap_min_deg = kBitmapMinDeg);

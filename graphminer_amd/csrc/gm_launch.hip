@@ -445,7 +445,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
     }
     int qword = 0;
     for (const auto &rd : plan->rounds) {
-      if (qword + 8 > 16384) return GM_ERR_TOO_LARGE;  // (more than ~3000 arena rounds)
+      if (qword + 9 > 16384) return GM_ERR_TOO_LARGE;  // (more than ~3000 arena rounds)
       if (rd.n_tasks > 0) {
         CBuildParams pw;
         memset(&pw, 0, sizeof pw);
@@ -461,6 +461,24 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
         const int bgrid = (int)std::max<long long>(1, std::min<long long>(pw.count, (long long)g->cu_count * cbuild_per_cu(plan->stage)));
         if (pw.count > 0) HIP_TRY(launch_cbuild(pw, plan->stage, bgrid, stream));
         plan_chunks += (uint64_t)pw.count;
+      }
+      if (plan->core_base >= 0 && rd.w1 > rd.w0) {  // the rows of the wide vertices whose first endpoint lies in the hub core: gathered (gm_cgather.hip)
+        CGatherParams cg;
+        memset(&cg, 0, sizeof cg);
+        cg.rp = g->d_rp;
+        cg.col = g->d_col;
+        cg.verts = plan->d_verts;
+        cg.base = plan->d_slot_base;
+        cg.mat = g->d_wide_mat;
+        cg.core = g->d_core;
+        cg.core_base = g->core_base;
+        cg.core_words = (g->core_h + 31) / 32;
+        cg.core_bytes = (unsigned long long)g->core_h * (unsigned long long)cg.core_words * 4ull;
+        cg.first_slot = (int)rd.w0;
+        cg.count = (int)(rd.w1 - rd.w0);
+        cg.queue = g->d_wide_queue + qword++;
+        const int ggrid = (int)std::max<long long>(1, std::min<long long>(cg.count, (long long)g->cu_count * cgather_per_cu()));
+        HIP_TRY(launch_cgather(cg, ggrid, stream));
       }
       // pair counts of the wide vertices: on the matrix cores (gm_cmma.hip), or -- tune[6] & 0x20000 -- the vector-ALU classes of round 3
       const bool valu_counts = (la->tune[6] & 0x20000) != 0;

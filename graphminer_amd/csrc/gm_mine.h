@@ -300,6 +300,21 @@ __host__ __device__ inline int clique_count_class(int d) {
   return (long long)d * clique_copy_stride(d, w, kCountWordsL) <= kCountWordsL ? 1 : 2;
 }
 
+// ---- level 1 of the wide vertices GATHERED from the dense bitmap of the hub core (gm_cgather.hip) ------------------------------------
+struct CGatherParams {
+  const int *rp, *col;
+  const int *verts;                 // slot -> vertex (this rank's wide vertices, longest rows first)
+  const unsigned long long *base;   // slot -> word offset of the vertex's matrix in `mat`
+  unsigned *mat;                    // matrix arena
+  const unsigned *core;             // core bitmap: row v - core_base, bit w - core_base, core_words words per row
+  int core_base, core_words;
+  unsigned long long core_bytes;    // size of the bitmap (< 2^32: one buffer resource addresses it)
+  int first_slot, count;            // the slots of this launch: first_slot + q
+  unsigned *queue;                  // dequeue head (zeroed before launch)
+};
+hipError_t launch_cgather(const CGatherParams &p, int grid_blocks, hipStream_t stream);
+int cgather_per_cu();
+
 // ---- the same counts on the matrix cores (gm_cmma.hip; the default since round 4, tune[6] & 0x20000: the vector-ALU classes above) ----
 // sum_{i,j} M_ij (M M^T)_ij as FP4 MFMA over 64 x 64 blocks of (i, j).  LDS copy: rows padded to a multiple of 64, row stride = the
 // (even) block width rounded up to 2 mod 4 words, so that the 64 lanes of an operand fragment (32 rows x 2 adjacent words) read 64

@@ -822,11 +822,13 @@ __global__ __launch_bounds__(256) void cb_own_chunks_kernel(long long count, lon
 // ... and its wide vertices
 __global__ __launch_bounds__(256) void cb_own_verts_kernel(int count, const int *__restrict__ verts, int *__restrict__ own) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < count) own[verts[i]] = 1;
+  if (i < count) own[verts[i]] = 2;  // (2: a wide vertex -- its rows with a first endpoint in the core are gathered, cb_owner_sizes_kernel)
 }
 // per vertex: matrix words and task edges of an owner (0 for everybody else; [nv] = 0 so that the scans end with the totals)
-__global__ __launch_bounds__(256) void cb_owner_sizes_kernel(int nv, const int *__restrict__ rp, const int *__restrict__ own,
-                                                             unsigned long long *__restrict__ words, int *__restrict__ tasks) {
+// core_base >= 0: a wide owner's rows whose first endpoint is >= core_base come from the core bitmap (gm_cgather.hip): only the
+// entries below it -- the first ones of the ascending row -- are tasks of the streamed build
+__global__ __launch_bounds__(256) void cb_owner_sizes_kernel(int nv, const int *__restrict__ rp, const int *__restrict__ col, const int *__restrict__ own,
+                                                             int core_base, unsigned long long *__restrict__ words, int *__restrict__ tasks) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v > nv) return;
   unsigned long long w = 0;
@@ -835,6 +837,7 @@ __global__ __launch_bounds__(256) void cb_owner_sizes_kernel(int nv, const int *
     const int d = rp[v + 1] - rp[v];
     w = cb_matrix_words(d);
     t = w ? d : 0;
+    if (t && own[v] == 2 && core_base >= 0) t = lower_bound(col + rp[v], d, core_base);
   }
   words[v] = w;
   tasks[v] = t;
@@ -842,7 +845,7 @@ __global__ __launch_bounds__(256) void cb_owner_sizes_kernel(int nv, const int *
 // one key per task: (host << 32) | entry; value = the owner u. The edge u -> v is hosted by the endpoint with the longer out-list,
 // when that list fits the stage -- like gm_tct.hip's task lists (task_keys_kernel), restricted to the owners' edges.
 __global__ __launch_bounds__(256) void cb_task_keys_kernel(int nv, long long ne, const int *__restrict__ rp, const int *__restrict__ col,
-                                                           const int *__restrict__ ntask_of, const int *__restrict__ tpos,
+                                                           const int *__restrict__ ntask_of, const int *__restrict__ tpos, int topo,
                                                            unsigned long long *__restrict__ keys, int *__restrict__ vals, int *__restrict__ cnt) {
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += stride) {
@@ -852,9 +855,13 @@ __global__ __launch_bounds__(256) void cb_task_keys_kernel(int nv, long long ne,
       if (rp[mid] <= e) lo = mid; else hi = mid - 1;
     }
     const int u = lo, v = col[e];
-    if (ntask_of[u] == 0) continue;  // not an owner of this round (or no matrix: d+ < 3 / > kCbMaxDeg)
+    const int i = (int)(e - rp[u]);
+    if (i >= ntask_of[u]) continue;  // not an owner of this round (or no matrix: d+ < 3 / > kCbMaxDeg), or a row the core bitmap supplies
     const int du = rp[u + 1] - rp[u], dv = rp[v + 1] - rp[v];
-    const int host = (dv > du && dv <= kCbMaxDeg) ? v : u;
+    // the endpoint that hosts = the one whose list is NOT streamed: N+(v) whole, or N+(u) -- beyond v under a topological numbering --
+    // whichever is shorter (round 3 compared the whole lists: 15 % more keys on R-MAT)
+    const int tail = topo ? du - i - 1 : du;
+    const int host = (dv > tail && dv <= kCbMaxDeg) ? v : u;
     const long long t = (long long)tpos[u] + (e - rp[u]);
     keys[t] = ((unsigned long long)(unsigned)host << 32) | (unsigned long long)(unsigned)e;
     vals[t] = u;
@@ -892,6 +899,66 @@ __global__ __launch_bounds__(256) void cb_slot_base_kernel(int w0, int w1, const
                                                            unsigned long long *__restrict__ slot_base) {
   const int s = w0 + blockIdx.x * blockDim.x + threadIdx.x;
   if (s < w1) slot_base[s] = base[verts[s]];
+}
+
+// ---- core bitmap: dense adjacency of the last core_h vertices of a topologically numbered DAG (gm_host.h; gathered by gm_cgather.hip) ----
+#ifndef GM_CORE_H_DEFAULT
+#define GM_CORE_H_DEFAULT 32768  // (128 MB of bitmap: R-MAT-22 ef 28, 4-clique ms at 4 K .. 128 K: 32.6 / 30.6 / 29.0 / 27.8 (32 K) / 29.1 / 30.7 -- the gathers are bound by the lines they pull through L2)
+#endif
+__global__ __launch_bounds__(256) void core_fill_kernel(int nv, int base, int words, long long e0, long long e1, const int *__restrict__ rp,
+                                                         const int *__restrict__ col, unsigned *__restrict__ bits) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long e = e0 + (long long)blockIdx.x * blockDim.x + threadIdx.x; e < e1; e += stride) {
+    int lo = base, hi = nv - 1;  // the row of entry e
+    while (lo < hi) {
+      const int mid = (int)(((long long)lo + hi + 1) >> 1);
+      if (rp[mid] <= e) lo = mid; else hi = mid - 1;
+    }
+    const int w = col[e] - base;  // (topological: w > lo - base >= 0)
+    atomicOr(&bits[(size_t)(lo - base) * (size_t)words + (size_t)(w >> 5)], 1u << (w & 31));
+  }
+}
+int ensure_core_bitmap(gm_graph *g) {
+  if (g->core_state) return GM_OK;
+  bool topo = false;
+  int rc = graph_is_topological(g, &topo);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lk(g->mu);
+  if (g->core_state) return GM_OK;
+  long long want = GM_CORE_H_DEFAULT;
+  if (const char *e = getenv("GM_CORE_H")) want = atoll(e);  // (sweeps; 0 switches the gathered build off)
+  if (!topo || g->d_rp == nullptr || g->nv < 64 || want < 64) {
+    g->core_state = 2;
+    return GM_OK;
+  }
+  SetupTimer timer;
+  HIP_TRY(hipSetDevice(g->device));
+  const int h = (int)std::min<long long>((long long)g->nv, want);
+  const int base = g->nv - h;
+  const int words = (h + 31) / 32;
+  const size_t bytes = (size_t)h * (size_t)words * 4;
+  if (hipMalloc(&g->d_core, bytes) != hipSuccess) {  // no room: the streamed build does everything
+    (void)hipGetLastError();
+    g->d_core = nullptr;
+    g->core_state = 2;
+    return GM_OK;
+  }
+  HIP_TRY(hipMemsetAsync(g->d_core, 0, bytes, 0));
+  int e01[2] = {0, 0};
+  HIP_TRY(hipMemcpy(&e01[0], g->d_rp + base, sizeof(int), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(&e01[1], g->d_rp + g->nv, sizeof(int), hipMemcpyDeviceToHost));
+  const long long n = (long long)e01[1] - e01[0];
+  if (n > 0) {
+    const long long blocks = std::min<long long>((n + 255) / 256, (long long)g->cu_count * 32);
+    hipLaunchKernelGGL(core_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, g->nv, base, words, (long long)e01[0], (long long)e01[1], g->d_rp, g->d_col, g->d_core);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipDeviceSynchronize());
+  g->core_h = h;
+  g->core_base = base;
+  g->core_state = 1;
+  g->setup.table_ms += timer.ms();
+  return GM_OK;
 }
 
 int clique_wide_min_words() {
@@ -937,7 +1004,7 @@ static int build_clique_round(gm_graph *g, CliquePlan &pl, CliqueRound &rd, Scan
     hipLaunchKernelGGL(cb_own_chunks_kernel, blocks(rd.n_count), dim3(256), 0, 0, rd.n_count, pl.n_first + rd.n_pos0 * pl.n_step, pl.n_step, pl.d_order, pl.tabN->d, own.p);
   if (rd.w1 > rd.w0)
     hipLaunchKernelGGL(cb_own_verts_kernel, blocks((long long)(rd.w1 - rd.w0)), dim3(256), 0, 0, (int)(rd.w1 - rd.w0), pl.d_verts + rd.w0, own.p);
-  hipLaunchKernelGGL(cb_owner_sizes_kernel, blocks((long long)nv1), dim3(256), 0, 0, nv, g->d_rp, own.p, words.p, ntask_of.p);
+  hipLaunchKernelGGL(cb_owner_sizes_kernel, blocks((long long)nv1), dim3(256), 0, 0, nv, g->d_rp, g->d_col, own.p, pl.core_base, words.p, ntask_of.p);
   HIP_TRY(hipMalloc(&rd.d_base, sizeof(unsigned long long) * nv1));
   HIP_TRY(dev_exclusive_sum(tmp, words.p, rd.d_base, nv1));
   HIP_TRY(dev_exclusive_sum(tmp, ntask_of.p, tpos.p, nv1));
@@ -946,8 +1013,11 @@ static int build_clique_round(gm_graph *g, CliquePlan &pl, CliqueRound &rd, Scan
   HIP_TRY(hipMemcpy(&nt, tpos.p + nv, sizeof(int), hipMemcpyDeviceToHost));
   rd.n_tasks = (size_t)nt;
   HIP_TRY(hipMalloc(&rd.d_trp, sizeof(int) * nv1));
+  if (rd.w1 > rd.w0)  // (before the early return: a round whose wide rows all come from the core bitmap has no streamed task at all)
+    hipLaunchKernelGGL(cb_slot_base_kernel, blocks((long long)(rd.w1 - rd.w0)), dim3(256), 0, 0, (int)rd.w0, (int)rd.w1, pl.d_verts, rd.d_base, pl.d_slot_base);
   if (nt == 0) {
     HIP_TRY(hipMemset(rd.d_trp, 0, sizeof(int) * nv1));
+    HIP_TRY(hipDeviceSynchronize());
     return GM_OK;
   }
   HIP_TRY(cnt.alloc(nv1));
@@ -957,7 +1027,7 @@ static int build_clique_round(gm_graph *g, CliquePlan &pl, CliqueRound &rd, Scan
   HIP_TRY(owners.alloc((size_t)nt));
   HIP_TRY(owners_sorted.alloc((size_t)nt));
   const long long kblocks = std::min<long long>(((long long)g->ne + 255) / 256, (long long)g->cu_count * 32);
-  hipLaunchKernelGGL(cb_task_keys_kernel, dim3((unsigned)kblocks), dim3(256), 0, 0, nv, g->ne, g->d_rp, g->d_col, ntask_of.p, tpos.p, keys.p, owners.p, cnt.p);
+  hipLaunchKernelGGL(cb_task_keys_kernel, dim3((unsigned)kblocks), dim3(256), 0, 0, nv, g->ne, g->d_rp, g->d_col, ntask_of.p, tpos.p, pl.topo ? 1 : 0, keys.p, owners.p, cnt.p);
   int bits = 1;
   while (bits < 32 && (1ll << bits) < (long long)nv) ++bits;
   size_t bytes = 0;
@@ -985,8 +1055,6 @@ static int build_clique_round(gm_graph *g, CliquePlan &pl, CliqueRound &rd, Scan
   double bm_ms = 0;
   int rc = build_table_device(g, t, false, bm_ms, rd.d_trp, &rd.d_tasks[0].len, (int)(sizeof(CBuildTask) / sizeof(int)));
   if (rc) return rc;
-  if (rd.w1 > rd.w0)
-    hipLaunchKernelGGL(cb_slot_base_kernel, blocks((long long)(rd.w1 - rd.w0)), dim3(256), 0, 0, (int)rd.w0, (int)rd.w1, pl.d_verts, rd.d_base, pl.d_slot_base);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
   return GM_OK;
@@ -1049,6 +1117,11 @@ int get_clique_plan(gm_graph *g, int rank, int world, int policy, int target, un
     const int rc = graph_is_topological(g, &topo);
     if (rc) return rc;
     pl.topo = topo && !getenv("GM_CLIQUE_NO_TOPO");  // (GM_CLIQUE_NO_TOPO: A/B, whole lists streamed)
+    if (pl.topo) {  // the dense hub core: rows of the wide vertices' matrices are gathered from it (gm_cgather.hip)
+      const int rc2 = ensure_core_bitmap(g);
+      if (rc2) return rc2;
+      if (g->core_state == 1) pl.core_base = g->core_base;
+    }
   }
   {  // this rank's share of the narrow table: every world-th chunk of the cost-ordered dequeue list, a contiguous range, or the
      // chunks of a vertex range
