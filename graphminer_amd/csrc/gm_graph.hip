@@ -636,10 +636,20 @@ __global__ __launch_bounds__(256) void relabel_cols_kernel(long long ne, const u
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e < ne) col[e] = (int)(unsigned)(keys[e] & 0xffffffffull);
 }
-// rows are ascending: the numbering is topological (every edge u -> v has u < v) iff no row starts at or below its own vertex
-__global__ __launch_bounds__(256) void topo_check_kernel(int nv, const int *__restrict__ rp, const int *__restrict__ col, int *__restrict__ not_topo) {
-  const int u = blockIdx.x * blockDim.x + threadIdx.x;
-  if (u < nv && rp[u + 1] > rp[u] && col[rp[u]] <= u) *not_topo = 1;
+// "topological" as the task lists use it (an in-edge task streams only the entries BEHIND its own: gm_tables.hip) needs BOTH: every edge
+// u -> v has u < v, AND every row is strictly ascending -- checked per entry, so that a DAG uploaded with unsorted rows (adj_sorted = 0
+// without gm_graph_sort_neighbors) runs with whole lists instead of silently losing triangles (the first entry alone was tested)
+__global__ __launch_bounds__(256) void topo_check_kernel(int nv, long long ne, const int *__restrict__ rp, const int *__restrict__ col, int *__restrict__ not_topo) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += stride) {
+    int lo = 0, hi = nv - 1;  // the row of entry e: largest u with rp[u] <= e
+    while (lo < hi) {
+      const int mid = (int)(((long long)lo + hi + 1) >> 1);
+      if (rp[mid] <= e) lo = mid; else hi = mid - 1;
+    }
+    const int v = col[e];
+    if (v <= lo || (e > rp[lo] && col[e - 1] >= v)) *not_topo = 1;
+  }
 }
 
 int graph_is_topological(gm_graph *g, bool *out) {
@@ -648,7 +658,10 @@ int graph_is_topological(gm_graph *g, bool *out) {
     DevBuf<int> flag;
     HIP_TRY(flag.alloc(1));
     HIP_TRY(hipMemsetAsync(flag.p, 0, sizeof(int), 0));
-    if (g->nv > 0) hipLaunchKernelGGL(topo_check_kernel, dim3((unsigned)((g->nv + 255) / 256)), dim3(256), 0, 0, g->nv, g->d_rp, g->d_col, flag.p);
+    if (g->nv > 0 && g->ne > 0) {
+      const long long blocks = std::min<long long>((g->ne + 255) / 256, (long long)g->cu_count * 32);
+      hipLaunchKernelGGL(topo_check_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, g->nv, g->ne, g->d_rp, g->d_col, flag.p);
+    }
     int not_topo = 0;
     HIP_TRY(hipMemcpy(&not_topo, flag.p, sizeof(int), hipMemcpyDeviceToHost));
     g->topo_state = not_topo ? 2 : 1;

@@ -272,6 +272,7 @@ struct gm_graph {
   TempPool pool;  // temporaries of the setup paths (PoolScope)
   gm_setup_times setup = {0, 0, 0, 0, 0};  // accumulated pre-processing time of this handle (gm_graph_setup_times)
   std::mutex mu;
+  std::mutex dag_mu;  // guards the lazy creation of dag_cache (ensure_dag_cache, gm_launch.hip)
 };
 
 // Opens the handle's temp pool for the DevBufs of the enclosing setup function (nested scopes share it, stack discipline). The pool is

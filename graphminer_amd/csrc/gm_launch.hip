@@ -1160,16 +1160,27 @@ static int run_sgl_nested(int pat, const gm_graph *cg, const gm_launch *la_in, u
   return end_launch(ctx, FIN_COPY, 0, h_out, 1, st);
 }
 
+// The oriented copy of a symmetric handle (gm_graph_orient), built once under its own lock: two solvers called on the same handle from two
+// threads -- the formula 3-motif and the one-GPU diamond share it -- must not both orient and leak a handle.  A graph of
+// >= 2^31 entries too: its oriented copy must fit the 32-bit task index, gm_graph_orient checks.
+static int ensure_dag_cache(gm_graph *g) {
+  std::lock_guard<std::mutex> lk(g->dag_mu);
+  if (g->dag_cache) return GM_OK;
+  gm_graph *dag = nullptr;
+  const int rc = gm_graph_orient(g, &dag);
+  if (rc) return rc;
+  g->dag_cache = dag;
+  return GM_OK;
+}
+
 // diamond on one GPU: the edge supports of the oriented copy (cached on the handle; on its topological view where lists are long)
 static int run_diamond_supports(const gm_graph *sym, const gm_launch *la, uint64_t *total, gm_stats *st) {
   gm_graph *g = const_cast<gm_graph *>(sym);
   if (!sym) return GM_ERR_INVALID;
   if (la && la->world > 1) return GM_ERR_UNSUPPORTED;
-  if (!g->dag_cache) {  // (a graph of >= 2^31 entries too: its oriented copy must fit the 32-bit task index, gm_graph_orient checks)
-    gm_graph *dag = nullptr;
-    int rc = gm_graph_orient(sym, &dag);
-    if (rc) return rc;
-    g->dag_cache = dag;
+  {  // (the oriented copy, cached on the handle)
+    const int rc_dag = ensure_dag_cache(g);
+    if (rc_dag) return rc_dag;
   }
   gm_graph *dag = g->dag_cache, *run_on = nullptr;
   if (dag->max_deg > kTctStageMax) return GM_ERR_UNSUPPORTED;
@@ -1277,11 +1288,9 @@ extern "C" int gm_motif4_partial(const gm_graph *sym, const gm_launch *la, uint6
   memset(&l2, 0, sizeof l2);
   if (la) l2 = *la;
   uint64_t *d_out = l2.d_counts;
-  if (!g->dag_cache) {
-    gm_graph *dag = nullptr;
-    int rc = gm_graph_orient(sym, &dag);
-    if (rc) return rc;
-    g->dag_cache = dag;
+  {  // (the oriented copy, cached on the handle)
+    const int rc_dag = ensure_dag_cache(g);
+    if (rc_dag) return rc_dag;
   }
   gm_stats s1, s2, s3;
   memset(&s1, 0, sizeof s1); memset(&s2, 0, sizeof s2); memset(&s3, 0, sizeof s3);
@@ -1398,11 +1407,9 @@ extern "C" int gm_motif_formula(const gm_graph *sym, int k, const gm_launch *la,
   if (k != 3) return (k == 4) ? GM_ERR_UNSUPPORTED : GM_ERR_INVALID;
   if (ncounts < 2) return GM_ERR_INVALID;
   gm_graph *g = const_cast<gm_graph *>(sym);
-  if (!g->dag_cache) {
-    gm_graph *dag = nullptr;
-    int rc = gm_graph_orient(sym, &dag);
-    if (rc) return rc;
-    g->dag_cache = dag;
+  {  // (the oriented copy, cached on the handle)
+    const int rc_dag = ensure_dag_cache(g);
+    if (rc_dag) return rc_dag;
   }
   if (!g->sum_c2_valid) {  // sum_v C(d(v),2): one reduction kernel over the offsets
     DevBuf<unsigned long long> acc;

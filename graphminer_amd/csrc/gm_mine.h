@@ -395,6 +395,10 @@ hipError_t launch_clique_small(const CliqueSmallParams &p, int grid_blocks, hipS
 
 // constants the byte model of bench.py needs: exported through gm_constant (gm_tools.hip) so that they cannot drift apart
 constexpr int kMotifTrimMinList = 128;  // 3-motif enumeration: a partner list of >= this many keys is trimmed to its keys below max(u, v)
+constexpr int kWideMinWordsDefault = kBitWords;  // k-clique: a matrix of more words is counted by the wide classes (GM_WIDE_MIN_WORDS overrides)
+// k-clique: vertices of the dense hub core (gm_cgather.hip), GM_CORE_H overrides.  32 K = 128 MB of bitmap; 4-clique on R-MAT-22 ef 28 at
+// 4 K .. 128 K: 32.6 / 30.6 / 29.0 / 27.8 (32 K) / 29.1 / 30.7 ms -- the gathers are bound by the lines they pull through L2
+constexpr int kCoreHDefault = 32768;
 constexpr int kTopoMinMeanRow = 64;     // DAG patterns run on the topologically renumbered copy from this mean row length (sum d+^2 / |E+|) on
 
 // host-side launchers (gm_mine.hip)

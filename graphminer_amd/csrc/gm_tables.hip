@@ -667,7 +667,11 @@ __global__ __launch_bounds__(256) void task_keys_kernel(int nv, long long ne, co
       vals[e] = -1;
       continue;
     }
-    const bool u_hosts = dv > stage_max || du >= dv;  // the longer list hosts (ties: the source) -- unless it does not fit the stage
+    // the host = the endpoint whose list is NOT streamed: N+(v) whole, or N+(u) -- under a topological numbering only its part beyond
+    // v -- whichever is shorter (ties: the source hosts); a list that does not fit the stage never hosts.  (Round 3 compared the
+    // whole lists: 15 % more streamed keys on R-MAT.)
+    const int tail = topo ? (int)(rp[u + 1] - (e + 1)) : du;
+    const bool u_hosts = dv > stage_max || tail >= dv;
     const int host = u_hosts ? u : v;
     keys[e] = ((unsigned long long)(unsigned)host << 32) | (unsigned long long)(unsigned)e;
     vals[e] = u_hosts ? -1 : (topo ? (int)(rp[u + 1] - (e + 1)) : (u | (1 << 30)));
@@ -695,16 +699,13 @@ __global__ __launch_bounds__(256) void task_desc_kernel(long long ne, const int 
     }
   }
 }
-int ensure_tasklists(gm_graph *g, bool with_edges) {
-  if ((g->d_tdesc && (g->d_tedge || !with_edges)) || g->ne == 0) return GM_OK;
+int ensure_tasklists(gm_graph *g, bool /*with_edges*/) {
+  // The tasks' own entries (tedge, 4 B per edge: what the edge supports need) are always built with the lists.  Round 3 built them on
+  // demand by freeing and rebuilding trp / tdesc -- under a launch of another thread that had already copied those pointers.
+  const bool with_edges = true;
+  if (g->d_tdesc || g->ne == 0) return GM_OK;
   std::lock_guard<std::mutex> lk(g->mu);
-  if (g->d_tdesc && (g->d_tedge || !with_edges)) return GM_OK;
-  if (g->d_tdesc) {  // built without the tasks' own entries: once more, with them (the order of the tasks is the same)
-    (void)hipFree(g->d_tdesc);
-    (void)hipFree(g->d_trp);
-    g->d_tdesc = nullptr;
-    g->d_trp = nullptr;
-  }
+  if (g->d_tdesc) return GM_OK;
   SetupTimer timer;
   HIP_TRY(hipSetDevice(g->device));
   const size_t ne = (size_t)g->ne, nv1 = (size_t)g->nv + 1;
@@ -774,9 +775,6 @@ int ensure_edesc(gm_graph *g) {
 
 // k-clique (k = 4): the plan of one rank's share for the re-hosted first level (gm_mine.h, gm_cbuild.hip). Everything below runs on
 // the device except what is O(wide vertices of the share) or O(chunks).
-#ifndef GM_WIDE_MIN_WORDS_DEFAULT
-#define GM_WIDE_MIN_WORDS_DEFAULT kBitWords
-#endif
 #ifndef GM_WIDE_ARENA_MB
 #define GM_WIDE_ARENA_MB 16384
 #endif
@@ -902,9 +900,6 @@ __global__ __launch_bounds__(256) void cb_slot_base_kernel(int w0, int w1, const
 }
 
 // ---- core bitmap: dense adjacency of the last core_h vertices of a topologically numbered DAG (gm_host.h; gathered by gm_cgather.hip) ----
-#ifndef GM_CORE_H_DEFAULT
-#define GM_CORE_H_DEFAULT 32768  // (128 MB of bitmap: R-MAT-22 ef 28, 4-clique ms at 4 K .. 128 K: 32.6 / 30.6 / 29.0 / 27.8 (32 K) / 29.1 / 30.7 -- the gathers are bound by the lines they pull through L2)
-#endif
 __global__ __launch_bounds__(256) void core_fill_kernel(int nv, int base, int words, long long e0, long long e1, const int *__restrict__ rp,
                                                          const int *__restrict__ col, unsigned *__restrict__ bits) {
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -925,7 +920,7 @@ int ensure_core_bitmap(gm_graph *g) {
   if (rc) return rc;
   std::lock_guard<std::mutex> lk(g->mu);
   if (g->core_state) return GM_OK;
-  long long want = GM_CORE_H_DEFAULT;
+  long long want = kCoreHDefault;
   if (const char *e = getenv("GM_CORE_H")) want = atoll(e);  // (sweeps; 0 switches the gathered build off)
   if (!topo || g->d_rp == nullptr || g->nv < 64 || want < 64) {
     g->core_state = 2;
@@ -964,7 +959,7 @@ int ensure_core_bitmap(gm_graph *g) {
 int clique_wide_min_words() {
   static const int v = [] {
     const char *e = getenv("GM_WIDE_MIN_WORDS");  // (sweeps; read once: tables and plans are cached per graph)
-    return e ? std::max(64, std::min(atoi(e), kBitWords)) : GM_WIDE_MIN_WORDS_DEFAULT;
+    return e ? std::max(64, std::min(atoi(e), kBitWords)) : kWideMinWordsDefault;
   }();
   return v;
 }

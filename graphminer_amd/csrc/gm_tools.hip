@@ -145,7 +145,8 @@ extern "C" int gm_constant(const char *name, int64_t *value) {
       {"tct_stage_max", kTctStageMax},       {"topo_min_mean_row", kTopoMinMeanRow}, {"motif_trim_min_list", kMotifTrimMinList},
       {"cb_min_deg", kCbMinDeg},             {"cb_max_deg", kCbMaxDeg},               {"long_list", kLongList},
       {"stage_cap", kStageCap},              {"default_chunk", kDefaultChunk},        {"mma_words_small", kMmaWordsS},
-      {"mma_words_big", kMmaWordsL},         {"wide_max_deg", kWideMaxDeg},           {"bit_words", kBitWords},
+      {"mma_words_big", kMmaWordsL},         {"core_h_default", kCoreHDefault},  {"wide_min_words", kWideMinWordsDefault},
+              {"wide_max_deg", kWideMaxDeg},           {"bit_words", kBitWords},
   };
   for (const auto &e : tab)
     if (strcmp(e.name, name) == 0) {

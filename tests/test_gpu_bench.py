@@ -27,9 +27,14 @@ def check_roofline(r):
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] > 0
     if r.get("frac") is not None:
         assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0 < r["frac"] <= 1.0
-    if "own_bytes_per_launch" in r:  # frac = own-algorithm bytes / kernel time / peak: recomputable from the line
-        assert r["frac"] == r["own_frac"] and abs(r["own_GBs"] - r["achieved"]) < 1e-6
-        assert r["own_bytes_per_launch"] >= 4 * r["own_streamed_keys_per_launch"] > 0
+    if r.get("traffic_frac") is not None:  # frac = counter traffic / kernel time / peak whenever the PMC pass succeeded
+        assert r["frac"] == r["traffic_frac"] and abs(r["traffic_GBs"] - r["achieved"]) < 1e-6 and "counter traffic" in r["frac_basis"]
+    elif "own_bytes_per_launch" in r:  # no counters in this run: the own-algorithm bytes, and the basis says so
+        assert r["frac"] == r["own_frac"] and abs(r["own_GBs"] - r["achieved"]) < 1e-6 and r["frac_basis"].startswith("NO counter pass")
+    if "own_bytes_per_launch" in r:
+        assert r["own_bytes_per_launch"] >= 4 * r["own_streamed_keys_per_launch"] >= 0 and 0 < r["own_frac"] <= 1.0
+    if "algorithmic_frac" in r:
+        assert r["frac_8d_valid"] == (r["algorithmic_frac"] <= 1.0)
     assert r["compulsory_floor_bytes"] > 0 and r["stream_ceiling_GBs"] > 1000
     if r.get("traffic_frac") is not None:  # counter traffic of THIS workload's launches only (two workloads may share a kernel name:
         assert 0 < r["traffic_frac"] <= 1.0  # the traffic pass separates them by marker dispatches) -- it cannot exceed the peak
@@ -71,6 +76,10 @@ def test_bench_default_mode_carries_the_five_configs():
         else:
             assert b["count_matches_gpu"] is True
     assert cfg[4]["identity_wedges_eq_sumC2_minus_3T"] is True
+    assert cfg[4]["tasks_of_the_formula_solver"] * 2 == cfg[4]["tasks"] and all("end_to_end_ms" in c for c in cfg[1:])
+    t24 = d["tc_rmat24"]  # (the headline workload on config 5's graph; at this size it is config 2's graph again)
+    assert t24["workload"] == "tc" and t24["count"] == cfg[4]["count"][1] and t24["count_equals_motif3_triangles"] is True
+    check_roofline(t24["roofline"])
     assert cfg[1]["count"] == cfg[4]["count"][1]  # triangles: TC kernel on the DAG == 3-motif kernel on the symmetric graph
 
 
@@ -152,7 +161,7 @@ def test_own_algorithm_bytes_equal_a_brute_force_count():
     import bench
     from graphminer_amd.rmat import rmat_csr_device
 
-    sym, rp, ci = rmat_csr_device(11, 128, 3, 0)  # dense enough for long DAG rows (the library renumbers it) and symmetric rows beyond 128
+    sym, rp, ci = rmat_csr_device(11, 500, 3, 0)  # dense enough for long DAG rows (the library renumbers it), wide vertices (d+ > 256: gathered rows) and symmetric rows beyond 128
     bg = bench.BenchGraph(sym, rp, ci, "t", 0.0)
     h = sym.download()
     hrp, hci = h.row_ptr, h.col_idx
@@ -181,13 +190,24 @@ def test_own_algorithm_bytes_equal_a_brute_force_count():
     rank[np.lexsort((np.arange(nv), deg))] = np.arange(nv)
     trim = float((dp.astype(np.float64) ** 2).sum()) / dci.size >= bench.kernel_constants()["topo_min_mean_row"]  # (topo_view: renumbered and trimmed only where rows are long)
     assert trim, "the graph must be one the library renumbers"
+    K = bench.kernel_constants()
+    core_base = nv - min(nv, K["core_h_default"])  # (new ids; the whole of this small graph lies in the hub core)
+    gathered = core_rows = 0
     for u in range(nv):
         row = dci[drp[u]:drp[u + 1]]
+        srow = np.sort(rank[row])  # N+(u) under the library's numbering
+        wide = dp[u] * ((dp[u] + 31) // 32) > K["wide_min_words"] and dp[u] <= K["cb_max_deg"]
         for i, v in enumerate(row[np.argsort(rank[row])]):
-            kt += dp[v] if dp[u] >= dp[v] else dp[u] - i - 1  # (no row beyond 2048 entries here)
-            if bench.kernel_constants()["cb_min_deg"] <= dp[u] <= bench.kernel_constants()["cb_max_deg"]:
-                tasks += 1
-                kc += dp[u] - i - 1 if dp[v] > dp[u] and dp[v] <= bench.kernel_constants()["cb_max_deg"] else dp[v]
+            tail = dp[u] - i - 1
+            kt += dp[v] if tail >= dp[v] else tail  # the shorter stream (no row beyond 2048 entries here)
+            if K["cb_min_deg"] <= dp[u] <= K["cb_max_deg"]:
+                if wide and rank[v] >= core_base:  # gathered from the core bitmap: the distinct words of the columns beyond i
+                    core_rows += 1
+                    gathered += len(set(((srow[i + 1:] - core_base) >> 5).tolist()))
+                else:
+                    tasks += 1
+                    kc += tail if dp[v] > tail and dp[v] <= K["cb_max_deg"] else dp[v]
+    assert core_rows > 0, "the graph must have wide vertices for this check to cover the gathered rows"
     assert dp.max() > 64 and tasks > 0 and kt < int(np.minimum(dp[np.repeat(np.arange(nv), dp)], dp[dci]).sum()), "the graph must have long DAG rows for this check to mean something"
     nd = dci.size
     assert bench.own_bytes_device("tc", bg)["bytes"] == 4 * int(kt) + 12 * nd + 8 * (nv + 1)
@@ -201,7 +221,7 @@ def test_own_algorithm_bytes_equal_a_brute_force_count():
     assert bench.own_bytes_device("diamond", bg)["bytes"] == 4 * int(kt) + 12 * nd + 8 * (nv + 1) + 20 * nd + 4 * tri
     own = dp[(dp >= bench.kernel_constants()["cb_min_deg"]) & (dp <= bench.kernel_constants()["cb_max_deg"])].astype(np.int64)
     arena = int((own * ((own + 31) // 32)).sum())
-    assert bench.own_bytes_device("clique4", bg)["bytes"] == 4 * int(kc) + 16 * tasks + 4 * nd + 16 * (nv + 1) + 8 * arena
+    assert bench.own_bytes_device("clique4", bg)["bytes"] == 4 * int(kc) + 16 * tasks + 4 * nd + 16 * (nv + 1) + 8 * arena + 4 * gathered
     bg.free()
 
 
