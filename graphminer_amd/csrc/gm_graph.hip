@@ -83,6 +83,11 @@ extern "C" void gm_graph_free(gm_graph *g) {
   if (g->d_trp) (void)hipFree(g->d_trp);
   if (g->d_tdesc) (void)hipFree(g->d_tdesc);
   if (g->d_tedge) (void)hipFree(g->d_tedge);
+  if (g->d_colk) (void)hipFree(g->d_colk);
+  if (g->d_tdesck) (void)hipFree(g->d_tdesck);
+  if (g->d_kst_rp) (void)hipFree(g->d_kst_rp);
+  if (g->d_trpl) (void)hipFree(g->d_trpl);
+  if (g->d_tdescl) (void)hipFree(g->d_tdescl);
   if (g->d_sup) (void)hipFree(g->d_sup);
   free_clique_plans(g);
   if (g->d_wide_mat) (void)hipFree(g->d_wide_mat);
@@ -328,6 +333,8 @@ extern "C" int gm_graph_sort_neighbors(gm_graph *g) {
   HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(tmp.buf.p, bytes, g->d_col, sorted.p, (int)g->ne, g->nv, g->d_rp, g->d_rp + 1, 0, bits));
   HIP_TRY(hipMemcpy(g->d_col, sorted.p, sizeof(int) * (size_t)g->ne, hipMemcpyDeviceToDevice));
   HIP_TRY(hipDeviceSynchronize());
+  g->sorted_state = 0;  // (checked again by the first solver: duplicates are still not "strictly ascending")
+  g->topo_state = 0;
   return GM_OK;
 }
 
@@ -636,35 +643,62 @@ __global__ __launch_bounds__(256) void relabel_cols_kernel(long long ne, const u
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e < ne) col[e] = (int)(unsigned)(keys[e] & 0xffffffffull);
 }
-// "topological" as the task lists use it (an in-edge task streams only the entries BEHIND its own: gm_tables.hip) needs BOTH: every edge
-// u -> v has u < v, AND every row is strictly ascending -- checked per entry, so that a DAG uploaded with unsorted rows (adj_sorted = 0
-// without gm_graph_sort_neighbors) runs with whole lists instead of silently losing triangles (the first entry alone was tested)
-__global__ __launch_bounds__(256) void topo_check_kernel(int nv, long long ne, const int *__restrict__ rp, const int *__restrict__ col, int *__restrict__ not_topo) {
+// Rows strictly ascending?  Every solver relies on it (bisection, trimmed tasks, position = rank); the reference sorts on request
+// (adj_sorted = 0 -> Graph::sort_neighbors, src/common/graph.cc:138).  One pass: a descent col[e - 1] >= col[e] is legitimate only where a
+// row starts -- verified by a bisection of the offsets, for the descents only.
+__global__ __launch_bounds__(256) void sorted_check_kernel(int nv, long long ne, const int *__restrict__ rp, const int *__restrict__ col, int *__restrict__ not_sorted) {
   const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += stride) {
+  for (long long e = 1 + (long long)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += stride) {
+    if (col[e - 1] < col[e]) continue;
     int lo = 0, hi = nv - 1;  // the row of entry e: largest u with rp[u] <= e
     while (lo < hi) {
       const int mid = (int)(((long long)lo + hi + 1) >> 1);
       if (rp[mid] <= e) lo = mid; else hi = mid - 1;
     }
-    const int v = col[e];
-    if (v <= lo || (e > rp[lo] && col[e - 1] >= v)) *not_topo = 1;
+    if (rp[lo] != e) *not_sorted = 1;
   }
 }
+// rows are ascending: the numbering is topological (every edge u -> v has u < v) iff no row starts at or below its own vertex
+__global__ __launch_bounds__(256) void topo_check_kernel(int nv, const int *__restrict__ rp, const int *__restrict__ col, int *__restrict__ not_topo) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u < nv && rp[u + 1] > rp[u] && col[rp[u]] <= u) *not_topo = 1;
+}
 
+int graph_rows_sorted(gm_graph *g, bool *out) {
+  if (g->sorted_state == 0) {
+    if (g->d_rp == nullptr || g->ne < 2) {  // (a handle of >= 2^31 entries is validated when it is oriented)
+      g->sorted_state = 1;
+    } else {
+      HIP_TRY(hipSetDevice(g->device));
+      DevBuf<int> flag;
+      HIP_TRY(flag.alloc(1));
+      HIP_TRY(hipMemsetAsync(flag.p, 0, sizeof(int), 0));
+      const long long blocks = std::min<long long>((g->ne + 255) / 256, (long long)g->cu_count * 32);
+      hipLaunchKernelGGL(sorted_check_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, g->nv, g->ne, g->d_rp, g->d_col, flag.p);
+      int bad = 0;
+      HIP_TRY(hipMemcpy(&bad, flag.p, sizeof(int), hipMemcpyDeviceToHost));
+      g->sorted_state = bad ? 2 : 1;
+    }
+  }
+  *out = g->sorted_state == 1;
+  return GM_OK;
+}
+
+// "topological" as the task lists use it (an in-edge task streams only the entries BEHIND its own: gm_tables.hip): every edge u -> v has
+// u < v AND the rows are ascending (the first entry of a row alone was tested, which says nothing about an unsorted row)
 int graph_is_topological(gm_graph *g, bool *out) {
   if (g->topo_state == 0) {
+    bool sorted = false;
+    const int rc = graph_rows_sorted(g, &sorted);
+    if (rc) return rc;
     HIP_TRY(hipSetDevice(g->device));
     DevBuf<int> flag;
     HIP_TRY(flag.alloc(1));
     HIP_TRY(hipMemsetAsync(flag.p, 0, sizeof(int), 0));
-    if (g->nv > 0 && g->ne > 0) {
-      const long long blocks = std::min<long long>((g->ne + 255) / 256, (long long)g->cu_count * 32);
-      hipLaunchKernelGGL(topo_check_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, g->nv, g->ne, g->d_rp, g->d_col, flag.p);
-    }
+    if (g->nv > 0) hipLaunchKernelGGL(topo_check_kernel, dim3((unsigned)((g->nv + 255) / 256)), dim3(256), 0, 0, g->nv, g->d_rp, g->d_col, flag.p);
     int not_topo = 0;
     HIP_TRY(hipMemcpy(&not_topo, flag.p, sizeof(int), hipMemcpyDeviceToHost));
-    g->topo_state = not_topo ? 2 : 1;
+    g->topo_state = (not_topo || !sorted) ? 2 : 1;
   }
   *out = g->topo_state == 1;
   return GM_OK;

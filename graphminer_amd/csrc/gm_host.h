@@ -213,6 +213,18 @@ struct gm_graph {
   int *d_trp = nullptr;     // task lists of the shorter-list-streams triangle count (ensure_tasklists): row offsets (nv + 1)
   int2 *d_tdesc = nullptr;  // ... and per task {rp[partner], d(partner)}
   int *d_tedge = nullptr;   // ... and (edge supports only: ensure_tasklists(g, true)) the task's own DAG entry
+  // ... and TASK-MAJOR COPIES of the short lists (ensure_tasklists): d_colk = col followed by the keys of every list of <= GM_TC_INLINE_MAX
+  // entries in task order, d_tdesck = the descriptors pointing at the copies.  Consecutive tasks of a host then stream consecutive
+  // lines instead of one random 64-byte line (or two) each: what bounds the triangle count on LiveJournal-shaped graphs (mean list 9)
+  int *d_colk = nullptr;
+  int2 *d_tdesck = nullptr;
+  unsigned long long n_inline_keys = 0;
+  // nv <= 2^24: instead of descriptors that point at the copies, the copies ARE the task list of the short lists -- a key stream in host
+  // order, every key tagged with its host's low 8 bits (GraphView::kst), offsets per host vertex, and the longer lists as their own
+  // task lists (d_trpl / d_tdescl).  No descriptor, no row search, no flattening for the short lists: one coalesced load per 64 keys.
+  int *d_kst_rp = nullptr;
+  int *d_trpl = nullptr;
+  int2 *d_tdescl = nullptr;
   unsigned *d_sup = nullptr;  // edge supports: one counter per DAG entry (gm_sup.hip)
   std::vector<int> h_rp;  // host copy of the offsets, fetched on first use (host_rp): download, k-clique tables, SgL renumbering
   std::list<ChunkTable> tables;  // list: handed-out pointers stay valid
@@ -225,6 +237,7 @@ struct gm_graph {
   int cu_count = 256;
   gm_graph *dag_cache = nullptr;          // oriented copy, built on demand by gm_motif_formula
   gm_graph *relabel_cache[3] = {nullptr, nullptr, nullptr};  // renumbered copies: by degree ascending / descending, topological (get_relabeled)
+  int sorted_state = 0;              // 0 unknown, 1 every row strictly ascending, 2 not (graph_rows_sorted): the solvers refuse such a handle
   int topo_state = 0;                // 0 unknown, 1 every edge goes to a larger id, 2 not (graph_is_topological)
   unsigned long long giant_edges = ~0ull;  // sum of the rows beyond kStageCapBig entries (~0: not computed yet)
   double mean_sq_deg = -1.0;         // sum_v d(v)^2 / ne: the mean length of the row an entry sits in (-1: not computed yet; topo_view)
@@ -341,6 +354,7 @@ int host_rp(gm_graph *g, const std::vector<int> **out);          // gm_graph.hip
 int convert_offsets(const int64_t *rp64, int nv, long long ne, std::vector<int> &out);  // gm_graph.hip: host-side narrowing / validation
 int get_relabeled(gm_graph *g, int mode, gm_graph **out);  // gm_graph.hip: cached renumbered copy (0 / 1 by degree, 2 topological)
 int graph_is_topological(gm_graph *g, bool *out);
+int graph_rows_sorted(gm_graph *g, bool *out);
 int ensure_core_bitmap(gm_graph *g);  // (gm_tables.hip) d_core / core_h / core_base of a topologically numbered DAG; GM_OK also when not applicable
 void free_tables(gm_graph *g);                                   // gm_tables.hip
 int get_table(gm_graph *g, int target, bool allow_split, int bit_words, unsigned long long part_cap, int stage_cap, ChunkTable **out,

@@ -85,6 +85,14 @@ static int begin_launch(const gm_graph *cg, const gm_launch *la, const uint64_t 
   if (c.rank < 0 || c.rank >= c.world) return GM_ERR_INVALID;
   if (!h_out && !c.la.d_counts) return GM_ERR_INVALID;
   HIP_TRY(hipSetDevice(c.g->device));
+  {  // every solver relies on ascending rows (checked once per handle; the reference sorts on request: adj_sorted = 0)
+    bool sorted = false;
+    if (int rc = graph_rows_sorted(c.g, &sorted)) return rc;
+    if (!sorted) {
+      g_last_error = "the neighbour lists of this graph are not strictly ascending: call gm_graph_sort_neighbors first (Graph::sort_neighbors, adj_sorted = 0)";
+      return GM_ERR_INVALID;
+    }
+  }
   c.stream = (hipStream_t)c.la.stream;
   HIP_TRY(hipMemsetAsync(c.g->d_counters, 0, 64, c.stream));
   return GM_OK;
@@ -296,6 +304,20 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
     p.g.trp = g->d_trp;
     p.g.tdesc = g->d_tdesc;
     p.g.tedge = support ? g->d_tedge : nullptr;
+    // the triangle count streams the short lists from their task-major copies (gm_host.h d_colk; tune[6] & 0x20000000: from their rows);
+    // the edge supports need the entries of the streamed keys in col[] itself
+    const bool use_tch_k = !(la->tune[6] & 0x8000000) && !getenv("GM_TC_SORTED");  // (the key stream is read by tch_kernel only)
+    if (!support && g->d_colk && !(la->tune[6] & 0x20000000)) {
+      if (g->d_kst_rp && g->d_trpl && g->d_tdescl && use_tch_k) {  // short lists as one tagged key stream, the longer ones as tasks
+        p.g.kst = reinterpret_cast<const unsigned *>(g->d_colk) + g->ne;
+        p.g.kst_rp = g->d_kst_rp;
+        p.g.trp = g->d_trpl;
+        p.g.tdesc = g->d_tdescl;
+      } else if (g->d_tdesck) {
+        p.g.col = g->d_colk;
+        p.g.tdesc = g->d_tdesck;
+      }
+    }
   }
   unsigned long long my_edges = 0;
   // this rank's share of a table: chunk ids first + i*step of the dequeue order (or a contiguous / vertex range)

@@ -77,6 +77,11 @@ struct GraphView {
   const int *trp = nullptr;
   const int2 *tdesc = nullptr;
   const int *tedge = nullptr;  // per task: the DAG entry of its own edge (edge supports, gm_sup.hip); nullptr = not built
+  // KEY STREAM of the short lists (gm_tch.hip; built with the task lists when nv <= 2^24): the keys of every list of <= GM_TC_INLINE_MAX
+  // entries in task order -- hosts ascending -- each tagged with the low 8 bits of its host vertex in bits 24..31; kst_rp = offsets per
+  // host vertex (nv + 1).  A chunk of hosts streams ONE contiguous range; trp / tdesc then hold only the longer lists.
+  const unsigned *kst = nullptr;
+  const int *kst_rp = nullptr;
 };
 
 enum Pattern : int { PAT_TC = 0, PAT_DIAMOND = 1, PAT_MOTIF3 = 2, PAT_CLIQUE4 = 3, PAT_CLIQUEK = 4 /* k = 5..8 */,

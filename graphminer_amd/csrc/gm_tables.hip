@@ -699,6 +699,105 @@ __global__ __launch_bounds__(256) void task_desc_kernel(long long ne, const int 
     }
   }
 }
+// ---- task-major copies of the short lists (gm_host.h: d_colk / d_tdesck) ------------------------------------------------------------
+#ifndef GM_TC_INLINE_MAX_DEFAULT
+#define GM_TC_INLINE_MAX_DEFAULT 32
+#endif
+// len[t] = keys of task t that go into the copies (0: none), lng[t] = 1 when the task stays a task of its own (a longer list)
+__global__ __launch_bounds__(256) void inl_len_kernel(long long nt, const int2 *__restrict__ tdesc, int lmax, unsigned long long *__restrict__ len,
+                                                       unsigned long long *__restrict__ lng) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t <= nt; t += stride) {
+    const int n = t < nt ? tdesc[t].y : 0;
+    len[t] = (n > 0 && n <= lmax) ? (unsigned long long)n : 0ull;
+    if (lng) lng[t] = n > lmax ? 1ull : 0ull;
+  }
+}
+// eight lanes per task: its keys move from their row of col[] to their place in task order.  tag: every key carries the low 8 bits of
+// its host vertex in bits 24..31 (key stream) and the longer lists are compacted into their own task list; else the descriptor follows.
+__global__ __launch_bounds__(256) void inl_copy_kernel(long long nt, const int2 *__restrict__ tdesc, const unsigned long long *__restrict__ off, int lmax,
+                                                        long long ne, int *__restrict__ colk, int2 *__restrict__ tdesck,
+                                                        const unsigned long long *__restrict__ sorted, const unsigned long long *__restrict__ loff,
+                                                        int2 *__restrict__ tdescl) {
+  const long long stride = ((long long)gridDim.x * blockDim.x) >> 3;
+  const int sub = threadIdx.x & 7;
+  for (long long t = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 3; t < nt; t += stride) {
+    const int2 d = tdesc[t];
+    if (d.y > 0 && d.y <= lmax) {
+      const long long o = ne + (long long)off[t];
+      const unsigned tag = sorted ? ((unsigned)(sorted[t] >> 32) & 255u) << 24 : 0u;
+      for (int i = sub; i < d.y; i += 8) colk[o + i] = (int)((unsigned)colk[d.x + i] | tag);  // (the first ne entries of colk are col itself)
+      if (sub == 0 && tdesck) tdesck[t] = make_int2((int)o, d.y);
+    } else if (sub == 0) {
+      if (tdesck) tdesck[t] = d;
+      if (tdescl && d.y > lmax) tdescl[loff[t]] = d;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void inl_offsets_kernel(int nv, const int *__restrict__ trp, const unsigned long long *__restrict__ off,
+                                                           const unsigned long long *__restrict__ loff, int *__restrict__ kst_rp, int *__restrict__ trpl) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v > nv) return;
+  const int t = trp[v];
+  kst_rp[v] = (int)off[t];
+  trpl[v] = (int)loff[t];
+}
+// after d_tdesc: failures here leave the handle without copies (the kernels then stream the rows themselves).
+// sorted[t] = (host << 32) | entry of task t.
+static void build_inline_copies(gm_graph *g, ScanTemp &tmp, const unsigned long long *sorted) {
+  int lmax = GM_TC_INLINE_MAX_DEFAULT;
+  if (const char *e = getenv("GM_TC_INLINE_MAX")) lmax = atoi(e);  // (sweeps; 0: no copies)
+  if (lmax <= 0 || g->ne <= 0 || g->d_tdesc == nullptr) return;
+  const bool stream = g->nv <= (1 << 24) && !getenv("GM_TC_NO_KEY_STREAM");  // ids must leave bits 24..31 to the host tag
+  const long long nt = g->ne;
+  const size_t nv1 = (size_t)g->nv + 1;
+  unsigned long long *off = nullptr, *loff = nullptr;  // (lengths in, offsets out: the scans run in place)
+  int *colk = nullptr, *krp = nullptr, *trpl = nullptr;
+  int2 *tdk = nullptr, *tdl = nullptr;
+  auto fail = [&]() {
+    (void)hipGetLastError();
+    for (void *p : {(void *)off, (void *)loff, (void *)colk, (void *)krp, (void *)trpl, (void *)tdk, (void *)tdl})
+      if (p) (void)hipFree(p);
+  };
+  if (hipMalloc(&off, 8 * (size_t)(nt + 1)) != hipSuccess) return fail();
+  if (stream && hipMalloc(&loff, 8 * (size_t)(nt + 1)) != hipSuccess) return fail();
+  const long long blocks = std::min<long long>((nt + 256) / 256, (long long)g->cu_count * 32);
+  unsigned long long total = 0, nlong = 0;
+  for (;;) {  // the copies share the 32-bit index space of col[]: halve the limit until they fit
+    hipLaunchKernelGGL(inl_len_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, nt, g->d_tdesc, lmax, off, loff);
+    if (dev_exclusive_sum(tmp, off, off, (size_t)nt + 1) != hipSuccess) return fail();
+    if (hipMemcpy(&total, off + nt, 8, hipMemcpyDeviceToHost) != hipSuccess) return fail();
+    if ((unsigned long long)nt + total < 0x7fffff00ull) break;
+    lmax >>= 1;
+    if (lmax < 4) return fail();
+  }
+  if (total == 0) return fail();
+  if (stream) {
+    if (dev_exclusive_sum(tmp, loff, loff, (size_t)nt + 1) != hipSuccess) return fail();
+    if (hipMemcpy(&nlong, loff + nt, 8, hipMemcpyDeviceToHost) != hipSuccess) return fail();
+    if (hipMalloc(&krp, 4 * nv1) != hipSuccess || hipMalloc(&trpl, 4 * nv1) != hipSuccess ||
+        hipMalloc(&tdl, sizeof(int2) * (size_t)std::max<unsigned long long>(nlong, 1)) != hipSuccess)
+      return fail();
+  } else if (hipMalloc(&tdk, sizeof(int2) * (size_t)nt) != hipSuccess) {
+    return fail();
+  }
+  if (hipMalloc(&colk, 4 * ((size_t)nt + (size_t)total)) != hipSuccess) return fail();
+  if (hipMemcpyAsync(colk, g->d_col, 4 * (size_t)nt, hipMemcpyDeviceToDevice, 0) != hipSuccess) return fail();
+  const long long cblocks = std::min<long long>((nt * 8 + 255) / 256, (long long)g->cu_count * 64);
+  hipLaunchKernelGGL(inl_copy_kernel, dim3((unsigned)cblocks), dim3(256), 0, 0, nt, g->d_tdesc, off, lmax, nt, colk, tdk, stream ? sorted : nullptr, loff, tdl);
+  if (stream)
+    hipLaunchKernelGGL(inl_offsets_kernel, dim3((unsigned)((nv1 + 255) / 256)), dim3(256), 0, 0, g->nv, g->d_trp, off, loff, krp, trpl);
+  if (hipDeviceSynchronize() != hipSuccess) return fail();
+  (void)hipFree(off);
+  if (loff) (void)hipFree(loff);
+  g->d_colk = colk;
+  g->d_tdesck = tdk;
+  g->d_kst_rp = krp;
+  g->d_trpl = trpl;
+  g->d_tdescl = tdl;
+  g->n_inline_keys = total;
+}
+
 int ensure_tasklists(gm_graph *g, bool /*with_edges*/) {
   // The tasks' own entries (tedge, 4 B per edge: what the edge supports need) are always built with the lists.  Round 3 built them on
   // demand by freeing and rebuilding trp / tdesc -- under a launch of another thread that had already copied those pointers.
@@ -753,6 +852,7 @@ int ensure_tasklists(gm_graph *g, bool /*with_edges*/) {
   g->d_trp = trp;
   g->d_tdesc = td;
   g->d_tedge = tedge;
+  build_inline_copies(g, tmp, sorted.p);
   g->setup.table_ms += timer.ms();
   return GM_OK;
 }

@@ -57,7 +57,7 @@ struct alignas(16) TchLds {
   int n_ovf;
   int next_batch;
   unsigned queue_pos;
-  int fallback;
+  int next_group;  // key stream of the short lists: the next group of tiles
 };
 static_assert(kTchOvfCap == 2 * GM_WAVE, "the surplus list is scanned two entries per lane");
 
@@ -341,6 +341,7 @@ void tch_kernel(const MineParams p) {
         if (tid == 0) {
           B.n_ovf = 0;
           B.next_batch = 0;
+          B.next_group = 0;
         }
       }
       __syncthreads();
@@ -387,6 +388,54 @@ void tch_kernel(const MineParams p) {
       }
       __syncthreads();  // (also: the fill counters are dead, the waves may use their scratch)
       const bool fallback = B.n_ovf > kTchOvfCap || (p.flags & (1 << 22)) != 0;
+      // ---- waves: the KEY STREAM of the chunk's short lists (GraphView::kst) -- the keys of every list of <= GM_TC_INLINE_MAX entries
+      // its vertices host, in task order, each tagged with the low 8 bits of its host: one contiguous range per chunk, one coalesced
+      // load per 64 keys, no descriptor, no row search, no flattening (a task of LiveJournal's shape -- nine keys -- cost a random
+      // 64-byte line or two and its share of the batch bookkeeping); the next group's keys are requested before the current one is
+      // looked up.  Parts of a heavy chunk interleave the groups like they interleave the batches below.
+      if (p.g.kst != nullptr) {
+        constexpr int TS = 4, GS = TS * GM_WAVE;
+        const int kb = p.g.kst_rp[ub], kn = p.g.kst_rp[ub + nvl] - kb;
+        const unsigned *__restrict__ kp = p.g.kst + kb;
+        auto grab = [&]() {
+          int gi = 0;
+          if (lane == 0) gi = atomicAdd(&B.next_group, 1);
+          return (readfirst(gi) * r.nparts + r.part) * GS;
+        };
+        unsigned nxt[TS];
+        int g0 = kn > 0 ? grab() : 0;
+        if (g0 < kn) {
+#pragma unroll
+          for (int q = 0; q < TS; ++q) nxt[q] = kp[min(g0 + q * GM_WAVE + lane, kn - 1)];
+        }
+        while (g0 < kn) {  // wave-uniform
+          const int gc = g0;
+          int key[TS];
+          unsigned salt[TS];
+          unsigned long long inm[TS], hm[TS], nm[TS];
+#pragma unroll
+          for (int q = 0; q < TS; ++q) {
+            key[q] = (int)(nxt[q] & 0xffffffu);
+            salt[q] = H::salt((int)(((nxt[q] >> 24) - (unsigned)ub) & 255u));  // host = ub + local row, local row < 256
+            inm[q] = __ballot(gc + q * GM_WAVE + lane < kn);
+          }
+          g0 = grab();
+          if (g0 < kn) {
+#pragma unroll
+            for (int q = 0; q < TS; ++q) nxt[q] = kp[min(g0 + q * GM_WAVE + lane, kn - 1)];
+          }
+          tch_probe<STAGE, TS>(B, col, fallback, key, salt, inm, hm, nm);
+          unsigned long long any_need = 0ull;
+          unsigned cnt = 0;
+#pragma unroll
+          for (int q = 0; q < TS; ++q) {
+            cnt += (unsigned)__popcll(hm[q]);
+            any_need |= nm[q];
+          }
+          if (any_need != 0ull) cnt += tch_surplus<STAGE, TS>(B, lane, key, salt, nm);  // rare
+          c0 += (unsigned long long)cnt;
+        }
+      }
       // ---- waves: batches of 64 tasks ---------------------------------------------------------------------------------
       const int tb = B.trpl[0], ntask = B.trpl[nvl] - tb;
       for (;;) {

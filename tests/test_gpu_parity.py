@@ -875,10 +875,11 @@ def test_hashed_position_set_rejects_the_empty_slot_indices(dev, row, x):
     sym.free()
 
 
-def test_dag_with_unsorted_rows_is_not_taken_for_topological(dev):
-    """the hashed-set kernels do not need ascending rows, but the task lists of a TOPOLOGICALLY numbered DAG stream only the
-    entries behind a task's own -- which is "the ids beyond v" only in an ascending row. A hand-built DAG (every edge to a larger id) whose
-    rows are stored DESCENDING passed the old check (first entry of each row above its vertex) and lost triangles; the check is per entry now."""
+def test_unsorted_rows_are_refused_until_sorted(dev):
+    """every solver relies on ascending rows (bisection, positions, the trimmed tasks of a topologically numbered DAG). A
+    hand-built DAG (every edge to a larger id) whose rows are stored DESCENDING used to pass the topological check (first entry of each
+    row above its vertex) and lose triangles silently; now the first solver call checks the rows once per handle and refuses, and
+    gm_graph_sort_neighbors (the reference's adj_sorted = 0 path) makes the handle usable."""
     g = _planted_dag(5, False)
     odag = O.OGraph(g.row_ptr, g.col_idx)
     want3, want4 = O.tc(odag), O.clique(odag, 4)
@@ -888,9 +889,10 @@ def test_dag_with_unsorted_rows_is_not_taken_for_topological(dev):
         rev[a:b] = rev[a:b][::-1]
     u = Graph(row_ptr=g.row_ptr.copy(), col_idx=rev, name="planted5_descending")
     with u.to_device(dev) as d:
-        as_numbered = [0, 0, 0, 0, 0, 0, 0x200]
-        assert TCSolver(d, tune=as_numbered) == want3  # (whole lists streamed against hashed sets: no order needed)
-        assert CliqueSolver(d, 3, tune=as_numbered) == want3
-        assert TCSolver(d) == want3 and CliqueSolver(d, 4) == want4  # (the renumbered copy is sorted by construction)
-    with g.to_device(dev) as d:
+        for call in (lambda: TCSolver(d), lambda: CliqueSolver(d, 4), lambda: TCSolver(d, tune=[0, 0, 0, 0, 0, 0, 0x200])):
+            with pytest.raises(_lib.GraphMinerError) as ei:
+                call()
+            assert ei.value.status == _lib.GM_ERR_INVALID and b"ascending" in _lib.load().gm_last_error()
+        d.sort_neighbors()
+        assert TCSolver(d) == want3 and CliqueSolver(d, 4) == want4
         assert TCSolver(d, tune=[0, 0, 0, 0, 0, 0, 0x200]) == want3 and CliqueSolver(d, 4, tune=[0, 0, 0, 0, 0, 0, 0x200]) == want4
