@@ -359,16 +359,25 @@ class Runner:
         if self.world != a.gpus:
             raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={self.world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
         assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path to measure)"
+        # GM_BENCH_ONE_GPU=1 (scripts/scale_dryrun.sh): every rank of a several-rank job on GPU 0 -- the N > 1 code path (shares, collective,
+        # max-over-ranks timing, rank-0-only reporting with the others parked at the barrier) on a one-GPU box, over gloo
+        self.one_gpu = os.environ.get("GM_BENCH_ONE_GPU") == "1"
+        if self.one_gpu:
+            self.local_rank = 0
         torch.cuda.set_device(self.local_rank)
         self.dev = torch.device("cuda", self.local_rank)
         self.use_dist = self.world > 1 or os.environ.get("GM_BENCH_FORCE_DIST") == "1"  # the latter: exercise RCCL with one rank
+        self.backend = os.environ.get("GM_BENCH_BACKEND", "nccl")  # "nccl" = RCCL over xGMI; "gloo": the dry run (counts staged through the host)
         if self.use_dist:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
             import datetime
 
             # (rank 0 reports alone at the end -- CPU baselines, rocprofv3 passes -- while the others wait in the closing barrier)
-            dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev, timeout=datetime.timedelta(minutes=60))
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev, timeout=datetime.timedelta(minutes=60))
+            else:
+                dist.init_process_group(self.backend, rank=self.rank, world_size=self.world, timeout=datetime.timedelta(minutes=60))
         from graphminer_amd import _lib
 
         self._lib = _lib
@@ -376,6 +385,16 @@ class Runner:
         self.counts = torch.zeros(8, dtype=torch.int64, device=self.dev)
         # the share of the task chunks this process launches: its rank of the job, or (traffic worker) a named share on one GPU
         self.launch_rank, self.launch_world = (self.rank, self.world) if self.world > 1 else (a.share_rank, max(a.share_world, 1))
+
+    def all_reduce(self, t, op=None):
+        """the job's collective: RCCL on the device tensor, or -- gloo dry run -- the same reduction staged through the host"""
+        op = op if op is not None else self.dist.ReduceOp.SUM
+        if self.backend == "nccl":
+            self.dist.all_reduce(t, op=op)
+        else:
+            h = t.cpu()
+            self.dist.all_reduce(h, op=op)
+            t.copy_(h)
 
     def fence(self):
         self.torch.cuda.synchronize()
@@ -412,7 +431,30 @@ class Runner:
                 la.tune[i] = int(t)
         st = gm_stats()
 
+        # diamond on several ranks: the one-GPU algorithm at every N (graphminer_amd.dist.diamond_step: a share of the triangle pass, ONE
+        # reduce-scatter of the support arrays over xGMI, sum C(t, 2) of the rank's slice) -- unless the per-edge kernels are asked for
+        # (--tune ... 0x10000000) or a row of the oriented copy exceeds the stage (GM_ERR_UNSUPPORTED at the first call)
+        dstate = {"on": workload == "diamond" and la.world > 1 and not (la.tune[6] & 0x10000000) and not os.environ.get("GM_DIAMOND_PER_EDGE"),
+                  "buf": None}
+
+        def diamond_sup_step():
+            from graphminer_amd import dist as gdist
+
+            buf = dstate["buf"]
+            # (RCCL: reduce_scatter_tensor; the gloo dry run stages the exchange through the host, graphminer_amd.dist.reduce_scatter_sum)
+            # (a named share on one GPU -- the traffic worker -- runs the same two launches on its slice, without the collectives)
+            dstate["buf"], _ = gdist.diamond_step(g, la.rank, la.world, self.counts, buf=buf, stream=la.stream or 0, tune=list(la.tune))
+            if use_dist:
+                self.all_reduce(self.counts)
+
         def step():
+            if dstate["on"]:
+                try:
+                    return diamond_sup_step()
+                except self._lib.GraphMinerError as e:
+                    if e.status != self._lib.GM_ERR_UNSUPPORTED:
+                        raise
+                    dstate["on"] = False
             if workload == "tc":
                 rc = lib.gm_tc(g.handle, C.byref(la), None, C.byref(st))
             elif workload in ("diamond", "rectangle", "house", "pentagon"):
@@ -428,7 +470,7 @@ class Runner:
                 rc = lib.gm_motif(g.handle, 3, C.byref(la), None, 2, C.byref(st))
             self._lib.check(rc, "bench step")
             if use_dist:
-                self.dist.all_reduce(self.counts)  # ONE RCCL all-reduce of the 64-bit counts (int64 add wraps like uint64)
+                self.all_reduce(self.counts)  # ONE RCCL all-reduce of the 64-bit counts (int64 add wraps like uint64)
 
         # first call: builds the per-graph task tables ("Time on generating the edgelist" of the reference) -- timed apart
         fence()
@@ -446,16 +488,20 @@ class Runner:
         elapsed = time.perf_counter() - t0
         if use_dist:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=self.dev)
-            self.dist.all_reduce(tmax, op=self.dist.ReduceOp.MAX)
+            self.all_reduce(tmax, op=self.dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
         result = [int(x) & M64 for x in self.counts.cpu().tolist()]
-        kms = g.kernel_times_ms(min(steps, 64))
-        k_avg = sum(kms) / max(len(kms), 1)
+        if dstate["on"]:  # two launches per step (the share of the triangle pass, sum C(t, 2) of the slice): their sum is the step's kernel time
+            kms = g.kernel_times_ms(min(2 * steps, 64))
+            k_avg = sum(kms) / max(len(kms) // 2, 1)
+        else:
+            kms = g.kernel_times_ms(min(steps, 64))
+            k_avg = sum(kms) / max(len(kms), 1)
         per_gpu = [k_avg]
         if use_dist:  # per-GPU kernel time, as the reference prints runtime[gpu i] (src/clique/multigpu.cu:136-137)
             tk = torch.zeros(self.world, dtype=torch.float64, device=self.dev)
             tk[self.rank] = k_avg
-            self.dist.all_reduce(tk)
+            self.all_reduce(tk)
             per_gpu = [float(x) for x in tk.cpu().tolist()]
         sym_e = bg.sym.E()
         # "edges processed" = the reference's nnz (src/triangle/gpu_base.cu:69): |E+| (tc, clique), ne/2 (diamond), ne (motif)
@@ -469,6 +515,7 @@ class Runner:
             # of a DAG workload, which bench.py asks for before the call (the symmetric-graph solvers orient inside their first call)
             "end_to_end_ms": 1e3 * first_call_s + (float(setup.get("orient_ms", 0.0)) if oriented else 0.0),
             "nv": g.V(), "ne_sym": sym_e, "max_degree": g.get_max_degree(), "stats": {"grid": int(st.grid), "block": int(st.block)},
+            "diamond_supports_across_ranks": bool(dstate["on"]),
         }
 
     def stream_ceiling(self):
@@ -553,7 +600,7 @@ def measure_traffic(a, workloads, share=(0, 1), device=0):
                 if val:
                     cmd += [flag, val]
             env = dict(os.environ, TMPDIR="/tmp")
-            for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "GM_BENCH_FORCE_DIST", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+            for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "GM_BENCH_FORCE_DIST", "GM_BENCH_ONE_GPU", "GM_BENCH_BACKEND", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
                 env.pop(k, None)
             vis = [x for x in os.environ.get("HIP_VISIBLE_DEVICES", "").split(",") if x]
             env["HIP_VISIBLE_DEVICES"] = vis[device] if device < len(vis) else str(device)  # the child sees this rank's GPU as device 0
@@ -836,7 +883,7 @@ def finish_record(rec, a, world, ab, floor, traffic, traffic_src, cpu, known, st
     if rec["workload"] in ("tc", "motif3", "motif3f"):
         roof["note"] = ("tch_kernel streams the SHORTER list of every DAG edge against the longer one kept as a hashed set in LDS (sum min(d+(u), d+(v)) "
                         "keys; the section-8(d) formula charges N+(u) and N+(v) per edge)")
-    elif rec["workload"] == "diamond" and world <= 1:
+    elif rec["workload"] == "diamond" and (world <= 1 or rec.get("diamond_supports_across_ranks")):
         roof["note"] = ("one GPU: |N(u) ^ N(v)| of every edge = its triangles, counted in ONE pass over the triangles of the DAG (sup_kernel: the triangle "
                         "kernel with three increments per match), then sum C(t, 2); the section-8(d) formula charges one intersection of the symmetric "
                         "lists per edge. A device-scope atomic moves a 64-byte fabric transaction for its 4 bytes: counter traffic is well above the own bytes")
@@ -910,7 +957,8 @@ def main():
         rec.update({"id": cid, "config": desc, "graph": bg.name, "input_build_s": bg.build_s})
         if rank == 0:
             bytes_of[w] = alg_bytes_device(w, bg, r.lib, rec["g"])
-            own_of[w] = own_bytes_device(w, bg, r.world)
+            # (diamond across ranks through the shared triangle pass: the one-GPU byte model, a rank's share of it)
+            own_of[w] = own_bytes_device(w, bg, 1 if rec.get("diamond_supports_across_ranks") else r.world)
         recs.append(rec)
 
     out = None
@@ -963,7 +1011,9 @@ def main():
             elif x["workload"] == "diamond":
                 sub["solver"] = ("one GPU: |N(v0) ^ N(v1)| of every edge from one pass over the triangles of the oriented graph (edge supports, gm_sup.hip), then sum C(t,2); "
                                  "several ranks: one intersection of the two symmetric lists per edge (tune[6] & 0x10000000 selects it on one GPU)") if world <= 1 else \
-                                "several ranks: one intersection of the two symmetric lists per edge (gm_hrow.hip, gm_chunk.h)"
+                                ("several ranks: the same shared triangle pass, a rank's share each, ONE reduce-scatter of the support arrays (uint32 per DAG entry) over "
+                                 "xGMI, sum C(t,2) of the rank's slice, then the all-reduce of the count" if x.get("diamond_supports_across_ranks") else
+                                 "several ranks: one intersection of the two symmetric lists per edge (gm_hrow.hip, gm_chunk.h)")
             if x["workload"] == "motif3" and isinstance(x["count"], list) and not a.scale:
                 # gm_motif (k = 3) takes the reference's formula solver (motif_omp_formula / motif_gpu_formula, src/motif/omp_formula.cc:39-46:
                 # the triangles of the oriented graph, wedges derived). The ENUMERATION form (automine_3motif: one bounded intersection of

@@ -367,4 +367,4 @@ int clique_wide_min_words();
 int get_clique_plan(gm_graph *g, int rank, int world, int policy, int target, unsigned long long part_cap, CliquePlan **out);
 void free_clique_plans(gm_graph *g);
 int run_pattern(gm::Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uint64_t *h_out, int nout, gm_stats *st, int fin_mode = -1,
-                unsigned long long fin_base = 0);  // gm_launch.hip
+                unsigned long long fin_base = 0, unsigned *sup_out = nullptr);  // gm_launch.hip (sup_out: PAT_SUPPORT_PART's buffer)

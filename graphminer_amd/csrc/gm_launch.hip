@@ -150,10 +150,14 @@ static void fill_stats(gm_stats *st, uint64_t tasks, uint64_t chunks, int grid, 
 }
 
 int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uint64_t *h_out, int nout, gm_stats *st, int fin_mode,
-                unsigned long long fin_base) {
+                unsigned long long fin_base, unsigned *sup_out) {
   // edge supports + sum C(t, 2) (gm_sup.hip): the triangle pass of the task lists with another match handler -- everything up to the
   // launch is the triangle count's
-  const bool support = pat == PAT_SUPPORT;
+  // (PAT_SUPPORT_PART: the share of a rank -- any world -- of the supports only, added into the caller's zeroed buffer: the ranks' arrays
+  // are summed by a reduce-scatter and gm_diamond_support_finish takes sum C(t, 2) of a slice)
+  const bool sup_part = pat == PAT_SUPPORT_PART;
+  const bool support = pat == PAT_SUPPORT || sup_part;
+  if (sup_part && !sup_out) return GM_ERR_INVALID;
   if (support) pat = PAT_TC;
   if (fin_mode < 0) fin_mode = (pat == PAT_MOTIF3) ? FIN_MOTIF3 : FIN_COPY;
   LaunchCtx ctx;
@@ -210,12 +214,12 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
   // R-MAT-20 6.4 vs 5.7, power law 4.07 vs 4.10, R-MAT-24 458 vs 172). A graph without such rows skips their (empty) tables.
   // tune[6] & 0x100000 forces them on.
   if (use_classes && !(la->tune[6] & 0x100000)) use_classes = g->max_deg > kClassRowMin;
-  if (support && (!use_tct || tct_long || world > 1)) return GM_ERR_UNSUPPORTED;  // (the caller takes the per-edge kernels)
+  if (support && (!use_tct || tct_long || (world > 1 && !sup_part))) return GM_ERR_UNSUPPORTED;  // (the caller takes the per-edge kernels)
   if (use_tct) {
     int rc_t = ensure_tasklists(g, support);
     if (rc_t) return rc_t;
   }
-  if (support && !g->d_sup) HIP_TRY(hipMalloc(&g->d_sup, sizeof(unsigned) * (size_t)std::max<long long>(g->ne, 1)));
+  if (support && !sup_part && !g->d_sup) HIP_TRY(hipMalloc(&g->d_sup, sizeof(unsigned) * (size_t)std::max<long long>(g->ne, 1)));
   RowFilter rf;
   rf.tct = use_tct ? 1 : 0;
   if (tct_long) { rf.skip_lo = kTctStageMax; rf.skip_hi = 0x7fffffff; }
@@ -645,10 +649,11 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
   // (tune[6] & 0x8000000: A/B switch, the sorted LDS copy + bit filter + bisection of gm_tct.hip instead of the hashed set of gm_tch.hip)
   const bool use_tch = use_tct && !(la->tune[6] & 0x8000000) && !getenv("GM_TC_SORTED");
   if (support) {  // zero the supports, three increments per triangle, then sum C(t, 2): all inside the timed region
-    HIP_TRY(hipMemsetAsync(g->d_sup, 0, sizeof(unsigned) * (size_t)g->ne, stream));
-    p.scratch = g->d_sup;
+    unsigned *sup = sup_part ? sup_out : g->d_sup;
+    HIP_TRY(hipMemsetAsync(sup, 0, sizeof(unsigned) * (size_t)(sup_part ? diamond_support_entries(g->ne, world) : g->ne), stream));
+    p.scratch = sup;
     if (p.count > 0) HIP_TRY(launch_sup(p, tct_stage, (int)std::max<long long>(1, std::min<long long>(want, (long long)g->cu_count * sup_per_cu(tct_stage))), stream));
-    HIP_TRY(launch_sup_pairs(g->d_sup, 0, g->ne, g->d_counters, g->cu_count, stream));
+    if (!sup_part) HIP_TRY(launch_sup_pairs(sup, 0, g->ne, g->d_counters, g->cu_count, stream));
   } else if (p.count > 0 && use_tch) HIP_TRY(launch_tch(p, tct_stage, (int)std::max<long long>(1, std::min<long long>(want, (long long)g->cu_count * tch_per_cu(tct_stage))), stream));
   else if (p.count > 0 && use_tct) HIP_TRY(launch_tct(p, tct_stage, (int)std::max<long long>(1, std::min<long long>(want, (long long)g->cu_count * tct_per_cu(tct_stage))), stream));
   else if (p.count > 0) HIP_TRY(launch_mine(pat, p, grid, stream));
@@ -1210,6 +1215,67 @@ static int run_diamond_supports(const gm_graph *sym, const gm_launch *la, uint64
   if (rc) return rc;
   rc = run_pattern(PAT_SUPPORT, run_on, la, 3, total, 1, st);
   if (rc) return rc;
+  dag->ring_alias = (run_on != dag) ? run_on : nullptr;
+  g->ring_alias = dag;
+  g->ring_extra[0] = g->ring_extra[1] = nullptr;
+  return GM_OK;
+}
+
+// ---- diamond on several ranks: ONE shared pass over the triangles (the one-GPU algorithm at every N) --------------------------------------
+// Every rank runs its share of the triangle pass into its own zeroed support array (one uint32 per entry of the oriented copy, padded so
+// that every rank gets the same number of entries), the arrays are summed by ONE reduce-scatter over xGMI (ncclReduceScatter, ncclUint32,
+// ncclSum: rank r receives the entries [r n / world, (r + 1) n / world)), every rank takes sum C(t, 2) of its slice, and the 64-bit
+// counts meet in the usual all-reduce.  The reference has no multi-GPU diamond at all (src/sgl/multigpu.cu:117 is commented out).
+static int diamond_run_on(const gm_graph *sym, const gm_launch *la, gm_graph **run_on) {
+  gm_graph *g = const_cast<gm_graph *>(sym);
+  if (!sym) return GM_ERR_INVALID;
+  {  // (the oriented copy, cached on the handle)
+    const int rc_dag = ensure_dag_cache(g);
+    if (rc_dag) return rc_dag;
+  }
+  gm_graph *dag = g->dag_cache;
+  if (dag->max_deg > kTctStageMax) return GM_ERR_UNSUPPORTED;  // (rows beyond the stage: the per-edge kernels, gm_sgl)
+  return topo_view(dag, la, run_on);
+}
+extern "C" int gm_diamond_support_size(const gm_graph *sym, int world, int64_t *n_entries) {
+  if (!sym || !n_entries || world < 1) return GM_ERR_INVALID;
+  gm_graph *run_on = nullptr;
+  const int rc = diamond_run_on(sym, nullptr, &run_on);
+  if (rc) return rc;
+  *n_entries = diamond_support_entries(run_on->ne, world);
+  return GM_OK;
+}
+extern "C" int gm_diamond_support_partial(const gm_graph *sym, const gm_launch *la, uint32_t *d_support, int64_t n_entries, gm_stats *st) {
+  if (!d_support) return GM_ERR_INVALID;
+  gm_graph *g = const_cast<gm_graph *>(sym), *run_on = nullptr;
+  int rc = diamond_run_on(sym, la, &run_on);
+  if (rc) return rc;
+  const int world = (la && la->world > 1) ? la->world : 1;
+  if (n_entries < diamond_support_entries(run_on->ne, world)) return GM_ERR_INVALID;
+  uint64_t dummy = 0;
+  rc = run_pattern(PAT_SUPPORT_PART, run_on, la, 3, (la && la->d_counts) ? nullptr : &dummy, 1, st, -1, 0, d_support);
+  if (rc) return rc;
+  gm_graph *dag = g->dag_cache;
+  dag->ring_alias = (run_on != dag) ? run_on : nullptr;
+  g->ring_alias = dag;
+  g->ring_extra[0] = g->ring_extra[1] = nullptr;
+  return GM_OK;
+}
+extern "C" int gm_diamond_support_finish(const gm_graph *sym, const gm_launch *la, const uint32_t *d_support, int64_t count, uint64_t *total, gm_stats *st) {
+  if (!d_support || count < 0) return GM_ERR_INVALID;
+  gm_graph *g = const_cast<gm_graph *>(sym), *run_on = nullptr;
+  int rc = diamond_run_on(sym, la, &run_on);
+  if (rc) return rc;
+  LaunchCtx ctx;
+  rc = begin_launch(run_on, la, total, ctx);
+  if (rc) return rc;
+  rc = start_timer(ctx);
+  if (rc) return rc;
+  HIP_TRY(launch_sup_pairs(d_support, 0, (long long)count, run_on->d_counters, run_on->cu_count, ctx.stream));
+  fill_stats(st, (uint64_t)count, 0, 0, 256);
+  rc = end_launch(ctx, FIN_COPY, 0, total, 1, st);
+  if (rc) return rc;
+  gm_graph *dag = g->dag_cache;
   dag->ring_alias = (run_on != dag) ? run_on : nullptr;
   g->ring_alias = dag;
   g->ring_extra[0] = g->ring_extra[1] = nullptr;

@@ -87,7 +87,8 @@ struct GraphView {
 enum Pattern : int { PAT_TC = 0, PAT_DIAMOND = 1, PAT_MOTIF3 = 2, PAT_CLIQUE4 = 3, PAT_CLIQUEK = 4 /* k = 5..8 */,
                      PAT_MOTIF4E = 5 /* per-edge sums of the 4-motif formula */,
                      PAT_DAGSTATS = 6 /* tooling: sum n, sum n^2, sum_{matches} d+(w) for the 4-clique algorithmic bytes */,
-                     PAT_SUPPORT = 7 /* edge supports from the DAG's triangles + sum C(t, 2): the diamond count (gm_sup.hip) */ };
+                     PAT_SUPPORT = 7 /* edge supports from the DAG's triangles + sum C(t, 2): the diamond count (gm_sup.hip) */,
+                     PAT_SUPPORT_PART = 8 /* ... a rank's share of the supports only, into the caller's buffer (gm_diamond_support_partial) */ };
 
 // Symmetric-graph patterns stage up to 3072 entries: on skewed graphs thousands of rows have 1-3 K neighbours; with a
 // 1024-entry stage they are SPLIT rows whose keys are bisected in HBM, otherwise ordinary staged chunks behind
@@ -398,6 +399,12 @@ struct CliqueSmallParams {
 };
 hipError_t launch_clique_small(const CliqueSmallParams &p, int grid_blocks, hipStream_t stream);
 
+// entries of a rank's support array in the several-rank diamond (gm_diamond_support_*): |E+| rounded up so that every rank's slice of the
+// reduce-scatter has the same, 256-byte aligned size
+__host__ __device__ inline long long diamond_support_entries(long long ne, int world) {
+  const long long q = 64ll * (world > 1 ? world : 1);
+  return ((ne > 0 ? ne : 1) + q - 1) / q * q;
+}
 // constants the byte model of bench.py needs: exported through gm_constant (gm_tools.hip) so that they cannot drift apart
 constexpr int kMotifTrimMinList = 128;  // 3-motif enumeration: a partner list of >= this many keys is trimmed to its keys below max(u, v)
 constexpr int kWideMinWordsDefault = kBitWords;  // k-clique: a matrix of more words is counted by the wide classes (GM_WIDE_MIN_WORDS overrides)

@@ -646,59 +646,7 @@ __global__ __launch_bounds__(256) void edesc_kernel(long long ne, const int *__r
   }
 }
 
-// ---- task lists of gm_tct.hip: every edge u -> v of the DAG is a task of the endpoint with the longer out-list -------------------
-// key = (host << 32) | entry; value = how the list to stream is found: -1 = N+(col[entry]) (the host is the source: out-edge task),
-// else the source's list (the host is the target: in-edge task) -- under a TOPOLOGICAL numbering only its part beyond the target can
-// hold a common neighbour, which starts right behind the entry: value = its length; otherwise value = source | 2^30 (the whole list)
-__global__ __launch_bounds__(256) void task_keys_kernel(int nv, long long ne, const int *__restrict__ rp, const int *__restrict__ col,
-                                                         unsigned long long *__restrict__ keys, int *__restrict__ vals, int *__restrict__ cnt, int stage_max,
-                                                         int topo) {
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += stride) {
-    int lo = 0, hi = nv - 1;  // the row of entry e: largest u with rp[u] <= e
-    while (lo < hi) {
-      const int mid = (int)(((long long)lo + hi + 1) >> 1);
-      if (rp[mid] <= e) lo = mid; else hi = mid - 1;
-    }
-    const int u = lo, v = col[e];
-    const int du = rp[u + 1] - rp[u], dv = rp[v + 1] - rp[v];
-    if (du > stage_max) {  // a row the stage cannot take hosts nothing: its out-edges stay with the chunked kernel (run_pattern)
-      keys[e] = ~0ull;     // (sorts behind every task)
-      vals[e] = -1;
-      continue;
-    }
-    // the host = the endpoint whose list is NOT streamed: N+(v) whole, or N+(u) -- under a topological numbering only its part beyond
-    // v -- whichever is shorter (ties: the source hosts); a list that does not fit the stage never hosts.  (Round 3 compared the
-    // whole lists: 15 % more streamed keys on R-MAT.)
-    const int tail = topo ? (int)(rp[u + 1] - (e + 1)) : du;
-    const bool u_hosts = dv > stage_max || tail >= dv;
-    const int host = u_hosts ? u : v;
-    keys[e] = ((unsigned long long)(unsigned)host << 32) | (unsigned long long)(unsigned)e;
-    vals[e] = u_hosts ? -1 : (topo ? (int)(rp[u + 1] - (e + 1)) : (u | (1 << 30)));
-    atomicAdd(&cnt[host], 1);
-  }
-}
-__global__ __launch_bounds__(256) void task_desc_kernel(long long ne, const int *__restrict__ rp, const int *__restrict__ col,
-                                                         const unsigned long long *__restrict__ sorted, const int *__restrict__ vals, int2 *__restrict__ tdesc,
-                                                         int *__restrict__ tedge) {
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < ne; t += stride) {
-    if (sorted[t] == ~0ull) {  // (the out-edges of rows beyond the stage: not tasks)
-      tdesc[t] = make_int2(0, 0);
-      if (tedge) tedge[t] = 0;
-      continue;
-    }
-    const int e = (int)(unsigned)(sorted[t] & 0xffffffffull), val = vals[t];
-    if (tedge) tedge[t] = e;
-    if (val >= 0 && !(val & (1 << 30))) {  // in-edge task, topological numbering: the source's list beyond this entry
-      tdesc[t] = make_int2(e + 1, val);
-    } else {
-      const int y = val < 0 ? col[e] : (val & ~(1 << 30));
-      const int r = rp[y];
-      tdesc[t] = make_int2(r, rp[y + 1] - r);
-    }
-  }
-}
+// ---- task lists of gm_tct.hip / gm_tch.hip: every edge u -> v of the DAG is a task of ONE of its endpoints (ensure_tasklists, below) ------
 // ---- task-major copies of the short lists (gm_host.h: d_colk / d_tdesck) ------------------------------------------------------------
 #ifndef GM_TC_INLINE_MAX_DEFAULT
 #define GM_TC_INLINE_MAX_DEFAULT 32
@@ -717,7 +665,7 @@ __global__ __launch_bounds__(256) void inl_len_kernel(long long nt, const int2 *
 // its host vertex in bits 24..31 (key stream) and the longer lists are compacted into their own task list; else the descriptor follows.
 __global__ __launch_bounds__(256) void inl_copy_kernel(long long nt, const int2 *__restrict__ tdesc, const unsigned long long *__restrict__ off, int lmax,
                                                         long long ne, int *__restrict__ colk, int2 *__restrict__ tdesck,
-                                                        const unsigned long long *__restrict__ sorted, const unsigned long long *__restrict__ loff,
+                                                        const unsigned char *__restrict__ ttag, const unsigned long long *__restrict__ loff,
                                                         int2 *__restrict__ tdescl) {
   const long long stride = ((long long)gridDim.x * blockDim.x) >> 3;
   const int sub = threadIdx.x & 7;
@@ -725,7 +673,7 @@ __global__ __launch_bounds__(256) void inl_copy_kernel(long long nt, const int2 
     const int2 d = tdesc[t];
     if (d.y > 0 && d.y <= lmax) {
       const long long o = ne + (long long)off[t];
-      const unsigned tag = sorted ? ((unsigned)(sorted[t] >> 32) & 255u) << 24 : 0u;
+      const unsigned tag = ttag ? (unsigned)ttag[t] << 24 : 0u;
       for (int i = sub; i < d.y; i += 8) colk[o + i] = (int)((unsigned)colk[d.x + i] | tag);  // (the first ne entries of colk are col itself)
       if (sub == 0 && tdesck) tdesck[t] = make_int2((int)o, d.y);
     } else if (sub == 0) {
@@ -743,8 +691,8 @@ __global__ __launch_bounds__(256) void inl_offsets_kernel(int nv, const int *__r
   trpl[v] = (int)loff[t];
 }
 // after d_tdesc: failures here leave the handle without copies (the kernels then stream the rows themselves).
-// sorted[t] = (host << 32) | entry of task t.
-static void build_inline_copies(gm_graph *g, ScanTemp &tmp, const unsigned long long *sorted) {
+// ttag[t] = the low 8 bits of the host of task t.
+static void build_inline_copies(gm_graph *g, ScanTemp &tmp, const unsigned char *ttag) {
   int lmax = GM_TC_INLINE_MAX_DEFAULT;
   if (const char *e = getenv("GM_TC_INLINE_MAX")) lmax = atoi(e);  // (sweeps; 0: no copies)
   if (lmax <= 0 || g->ne <= 0 || g->d_tdesc == nullptr) return;
@@ -784,7 +732,7 @@ static void build_inline_copies(gm_graph *g, ScanTemp &tmp, const unsigned long 
   if (hipMalloc(&colk, 4 * ((size_t)nt + (size_t)total)) != hipSuccess) return fail();
   if (hipMemcpyAsync(colk, g->d_col, 4 * (size_t)nt, hipMemcpyDeviceToDevice, 0) != hipSuccess) return fail();
   const long long cblocks = std::min<long long>((nt * 8 + 255) / 256, (long long)g->cu_count * 64);
-  hipLaunchKernelGGL(inl_copy_kernel, dim3((unsigned)cblocks), dim3(256), 0, 0, nt, g->d_tdesc, off, lmax, nt, colk, tdk, stream ? sorted : nullptr, loff, tdl);
+  hipLaunchKernelGGL(inl_copy_kernel, dim3((unsigned)cblocks), dim3(256), 0, 0, nt, g->d_tdesc, off, lmax, nt, colk, tdk, stream ? ttag : nullptr, loff, tdl);
   if (stream)
     hipLaunchKernelGGL(inl_offsets_kernel, dim3((unsigned)((nv1 + 255) / 256)), dim3(256), 0, 0, g->nv, g->d_trp, off, loff, krp, trpl);
   if (hipDeviceSynchronize() != hipSuccess) return fail();
@@ -798,19 +746,57 @@ static void build_inline_copies(gm_graph *g, ScanTemp &tmp, const unsigned long 
   g->n_inline_keys = total;
 }
 
+// The task lists by COUNTING PLACEMENT (round 4; until then: one (host, entry) key per edge found by a bisection of the offsets, a radix
+// sort of 40 - 260 M key / value pairs, a descriptor pass): eight lanes walk a row; pass 1 counts the tasks of every host, a scan gives
+// the offsets, pass 2 repeats the walk and drops every task at its host's cursor -- descriptor, own entry and the low 8 bits of the host
+// (the tag of the key stream) written where they stay.  The partner's {start, length} comes from the edge descriptors (coalesced) instead
+// of two random reads of the offsets.  The order of a host's tasks is the order of arrival: nothing depends on it.
+template <bool PLACE>
+__global__ __launch_bounds__(256) void task_rows_kernel(int nv, const int *__restrict__ rp, const int *__restrict__ col, const int2 *__restrict__ edesc,
+                                                         int stage_max, int topo, int *__restrict__ cnt /* PLACE: the cursors */,
+                                                         const int *__restrict__ trp, int2 *__restrict__ tdesc, int *__restrict__ tedge,
+                                                         unsigned char *__restrict__ ttag) {
+  const long long stride = ((long long)gridDim.x * blockDim.x) >> 3;
+  const int sub = threadIdx.x & 7;
+  for (long long u = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 3; u < nv; u += stride) {
+    const int ru = rp[u], du = rp[u + 1] - ru;
+    if (du > stage_max) continue;  // a row the stage cannot take hosts nothing, and its out-edges stay with the chunked kernel (run_pattern)
+    for (int i = sub; i < du; i += 8) {
+      const int e = ru + i;
+      const int2 dv = edesc[e];  // {rp[v], d+(v)} of the entry's target v
+      // the host = the endpoint whose list is NOT streamed: N+(v) whole, or N+(u) -- under a topological numbering only its part beyond
+      // v -- whichever is shorter (ties: the source hosts); a list that does not fit the stage never hosts
+      const int tail = topo ? du - i - 1 : du;
+      const bool u_hosts = dv.y > stage_max || tail >= dv.y;
+      const int host = u_hosts ? (int)u : col[e];
+      if (!PLACE) {
+        atomicAdd(&cnt[host], 1);
+      } else {
+        const int slot = trp[host] + atomicAdd(&cnt[host], 1);
+        tdesc[slot] = u_hosts ? dv : (topo ? make_int2(e + 1, tail) : make_int2(ru, du));
+        tedge[slot] = e;
+        ttag[slot] = (unsigned char)(host & 255);
+      }
+    }
+  }
+}
+
 int ensure_tasklists(gm_graph *g, bool /*with_edges*/) {
   // The tasks' own entries (tedge, 4 B per edge: what the edge supports need) are always built with the lists.  Round 3 built them on
   // demand by freeing and rebuilding trp / tdesc -- under a launch of another thread that had already copied those pointers.
-  const bool with_edges = true;
   if (g->d_tdesc || g->ne == 0) return GM_OK;
+  {
+    const int rc = ensure_edesc(g);  // (takes the lock itself)
+    if (rc) return rc;
+  }
   std::lock_guard<std::mutex> lk(g->mu);
   if (g->d_tdesc) return GM_OK;
   SetupTimer timer;
   HIP_TRY(hipSetDevice(g->device));
   const size_t ne = (size_t)g->ne, nv1 = (size_t)g->nv + 1;
-  PoolScope pool(g);  // (keys + values, twice, + hipCUB's own)
-  DevBuf<unsigned long long> keys, sorted;
-  DevBuf<int> cnt, vals, vals_sorted;
+  PoolScope pool(g);
+  DevBuf<int> cnt;
+  DevBuf<unsigned char> ttag;
   ScanTemp tmp;
   bool topo = false;
   {
@@ -818,29 +804,24 @@ int ensure_tasklists(gm_graph *g, bool /*with_edges*/) {
     if (rc) return rc;
     if (getenv("GM_TC_NO_TRIM")) topo = false;  // (A/B: whole lists streamed on a topologically numbered DAG too)
   }
-  HIP_TRY(keys.alloc(ne));
-  HIP_TRY(sorted.alloc(ne));
-  HIP_TRY(vals.alloc(ne));
-  HIP_TRY(vals_sorted.alloc(ne));
   HIP_TRY(cnt.alloc(nv1));
-  HIP_TRY(hipMemset(cnt.p, 0, sizeof(int) * nv1));
-  const long long blocks = std::min<long long>(((long long)ne + 255) / 256, (long long)g->cu_count * 32);
-  hipLaunchKernelGGL(task_keys_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, g->nv, g->ne, g->d_rp, g->d_col, keys.p, vals.p, cnt.p, kTctStageMax, topo ? 1 : 0);
-  int bits = 1;
-  while (bits < 32 && (1ll << bits) < (long long)g->nv) ++bits;
-  size_t bytes = 0;
-  const int end_bit = g->max_deg > kTctStageMax ? 64 : 32 + bits;  // (the all-ones keys of excluded edges need every bit)
-  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, keys.p, sorted.p, vals.p, vals_sorted.p, (int)ne, 0, end_bit));
-  HIP_TRY(tmp.reserve(bytes));
-  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.buf.p, bytes, keys.p, sorted.p, vals.p, vals_sorted.p, (int)ne, 0, end_bit));
+  HIP_TRY(ttag.alloc(ne));
+  HIP_TRY(hipMemsetAsync(cnt.p, 0, sizeof(int) * nv1, 0));
+  const long long blocks = std::min<long long>(((long long)g->nv * 8 + 255) / 256, (long long)g->cu_count * 64);
+  hipLaunchKernelGGL((task_rows_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, 0, g->nv, g->d_rp, g->d_col, g->d_edesc, kTctStageMax, topo ? 1 : 0, cnt.p,
+                     nullptr, nullptr, nullptr, nullptr);
   int *trp = nullptr, *tedge = nullptr;
   int2 *td = nullptr;
   HIP_TRY(hipMalloc(&trp, sizeof(int) * nv1));
   hipError_t e = dev_exclusive_sum(tmp, cnt.p, trp, nv1);
   if (e == hipSuccess) e = hipMalloc(&td, sizeof(int2) * ne);
-  if (e == hipSuccess && with_edges) e = hipMalloc(&tedge, sizeof(int) * ne);
+  if (e == hipSuccess) e = hipMalloc(&tedge, sizeof(int) * ne);
+  if (e == hipSuccess) e = hipMemsetAsync(td, 0, sizeof(int2) * ne, 0);  // (the edges of rows beyond the stage are no tasks: empty descriptors at the end)
+  if (e == hipSuccess) e = hipMemsetAsync(tedge, 0, sizeof(int) * ne, 0);
+  if (e == hipSuccess) e = hipMemsetAsync(cnt.p, 0, sizeof(int) * nv1, 0);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(task_desc_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, g->ne, g->d_rp, g->d_col, sorted.p, vals_sorted.p, td, tedge);
+    hipLaunchKernelGGL((task_rows_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, 0, g->nv, g->d_rp, g->d_col, g->d_edesc, kTctStageMax, topo ? 1 : 0, cnt.p,
+                       trp, td, tedge, ttag.p);
     e = hipDeviceSynchronize();
   }
   if (e != hipSuccess) {
@@ -852,7 +833,7 @@ int ensure_tasklists(gm_graph *g, bool /*with_edges*/) {
   g->d_trp = trp;
   g->d_tdesc = td;
   g->d_tedge = tedge;
-  build_inline_copies(g, tmp, sorted.p);
+  build_inline_copies(g, tmp, ttag.p);
   g->setup.table_ms += timer.ms();
   return GM_OK;
 }
@@ -940,57 +921,50 @@ __global__ __launch_bounds__(256) void cb_owner_sizes_kernel(int nv, const int *
   words[v] = w;
   tasks[v] = t;
 }
-// one key per task: (host << 32) | entry; value = the owner u. The edge u -> v is hosted by the endpoint with the longer out-list,
-// when that list fits the stage -- like gm_tct.hip's task lists (task_keys_kernel), restricted to the owners' edges.
-__global__ __launch_bounds__(256) void cb_task_keys_kernel(int nv, long long ne, const int *__restrict__ rp, const int *__restrict__ col,
-                                                           const int *__restrict__ ntask_of, const int *__restrict__ tpos, int topo,
-                                                           unsigned long long *__restrict__ keys, int *__restrict__ vals, int *__restrict__ cnt) {
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += stride) {
-    int lo = 0, hi = nv - 1;  // the row of entry e: largest u with rp[u] <= e
-    while (lo < hi) {
-      const int mid = (int)(((long long)lo + hi + 1) >> 1);
-      if (rp[mid] <= e) lo = mid; else hi = mid - 1;
-    }
-    const int u = lo, v = col[e];
-    const int i = (int)(e - rp[u]);
-    if (i >= ntask_of[u]) continue;  // not an owner of this round (or no matrix: d+ < 3 / > kCbMaxDeg), or a row the core bitmap supplies
-    const int du = rp[u + 1] - rp[u], dv = rp[v + 1] - rp[v];
-    // the endpoint that hosts = the one whose list is NOT streamed: N+(v) whole, or N+(u) -- beyond v under a topological numbering --
-    // whichever is shorter (round 3 compared the whole lists: 15 % more keys on R-MAT)
-    const int tail = topo ? du - i - 1 : du;
-    const int host = (dv > tail && dv <= kCbMaxDeg) ? v : u;
-    const long long t = (long long)tpos[u] + (e - rp[u]);
-    keys[t] = ((unsigned long long)(unsigned)host << 32) | (unsigned long long)(unsigned)e;
-    vals[t] = u;
-    atomicAdd(&cnt[host], 1);
-  }
-}
-__global__ __launch_bounds__(256) void cb_task_desc_kernel(long long nt, const int *__restrict__ rp, const int *__restrict__ col,
-                                                           const unsigned long long *__restrict__ keys, const int *__restrict__ owners,
-                                                           const unsigned long long *__restrict__ base, int topo, CBuildTask *__restrict__ out) {
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < nt; t += stride) {
-    const unsigned long long k = keys[t];
-    const int host = (int)(unsigned)(k >> 32), e = (int)(unsigned)(k & 0xffffffffull);
-    const int u = owners[t], v = col[e];
-    const int ru = rp[u], du = rp[u + 1] - ru, i = e - ru;
+// The task records of a round by counting placement (like ensure_tasklists: until round 4 one (host, entry) key per task found by a
+// bisection per entry, a radix sort of 109 M key / owner pairs on the com-Orkut stand-in, a record pass).  Eight lanes walk the row of an
+// owner u: the first ntask_of[u] entries are its streamed tasks (all of them, or -- a wide vertex beside a core bitmap -- those below the
+// core).  The edge u -> v is hosted by the endpoint whose list is NOT streamed: N+(v) whole, or N+(u) -- beyond v under a topological
+// numbering -- whichever is shorter (round 3 compared the whole lists: 15 % more keys on R-MAT), when it fits the stage.
+template <bool PLACE>
+__global__ __launch_bounds__(256) void cb_task_rows_kernel(int nv, const int *__restrict__ rp, const int *__restrict__ col, const int2 *__restrict__ edesc,
+                                                           const int *__restrict__ ntask_of, int topo, int *__restrict__ cnt /* PLACE: the cursors */,
+                                                           const int *__restrict__ trp, const unsigned long long *__restrict__ base,
+                                                           CBuildTask *__restrict__ out) {
+  const long long stride = ((long long)gridDim.x * blockDim.x) >> 3;
+  const int sub = threadIdx.x & 7;
+  for (long long u = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 3; u < nv; u += stride) {
+    const int nt = ntask_of[u];
+    if (nt == 0) continue;  // not an owner of this round, or no matrix (d+ < 3 / > kCbMaxDeg), or every row comes from the core bitmap
+    const int ru = rp[u], du = rp[u + 1] - ru;
     const int words = (du + 31) / 32;
-    const unsigned long long off = base[u] + (unsigned long long)i * (unsigned long long)words;
-    CBuildTask T;
-    unsigned fl = (unsigned)(off >> 32) & 255u;
-    if (host == u) {  // type A: N+(v) is streamed against the staged N+(u)
-      T.list = rp[v];
-      T.len = rp[v + 1] - rp[v];
-    } else {          // type B: N+(u) -- beyond v when the numbering is topological -- is streamed against the staged N+(v)
-      const int skip = topo ? i + 1 : 0;
-      T.list = ru + skip;
-      T.len = du - skip;
-      fl |= ((unsigned)skip << 8) | 0x80000000u;
+    for (int i = sub; i < nt; i += 8) {
+      const int e = ru + i;
+      const int2 dv = edesc[e];  // {rp[v], d+(v)}
+      const int tail = topo ? du - i - 1 : du;
+      const bool v_hosts = dv.y > tail && dv.y <= kCbMaxDeg;
+      const int host = v_hosts ? col[e] : (int)u;
+      if (!PLACE) {
+        atomicAdd(&cnt[host], 1);
+        continue;
+      }
+      const int slot = trp[host] + atomicAdd(&cnt[host], 1);
+      const unsigned long long off = base[u] + (unsigned long long)i * (unsigned long long)words;
+      CBuildTask T;
+      unsigned fl = (unsigned)(off >> 32) & 255u;
+      if (!v_hosts) {  // type A: N+(v) is streamed against the staged N+(u)
+        T.list = dv.x;
+        T.len = dv.y;
+      } else {         // type B: N+(u) -- beyond v when the numbering is topological -- is streamed against the staged N+(v)
+        const int skip = topo ? i + 1 : 0;
+        T.list = ru + skip;
+        T.len = du - skip;
+        fl |= ((unsigned)skip << 8) | 0x80000000u;
+      }
+      T.off_lo = (unsigned)off;
+      T.off_hi_fl = fl | ((unsigned)words << 20);
+      out[slot] = T;
     }
-    T.off_lo = (unsigned)off;
-    T.off_hi_fl = fl | ((unsigned)words << 20);
-    out[t] = T;
   }
 }
 __global__ __launch_bounds__(256) void cb_slot_base_kernel(int w0, int w1, const int *__restrict__ verts, const unsigned long long *__restrict__ base,
@@ -1088,8 +1062,8 @@ static int build_clique_round(gm_graph *g, CliquePlan &pl, CliqueRound &rd, Scan
   const int nv = g->nv;
   const size_t nv1 = (size_t)nv + 1;
   auto blocks = [](long long n) { return dim3((unsigned)std::max<long long>(1, (n + 255) / 256)); };
-  DevBuf<int> own, ntask_of, tpos, cnt, owners, owners_sorted;
-  DevBuf<unsigned long long> words, keys, sorted;
+  DevBuf<int> own, ntask_of, tpos, cnt;
+  DevBuf<unsigned long long> words;
   HIP_TRY(own.alloc(nv1));
   HIP_TRY(ntask_of.alloc(nv1));
   HIP_TRY(tpos.alloc(nv1));
@@ -1117,23 +1091,14 @@ static int build_clique_round(gm_graph *g, CliquePlan &pl, CliqueRound &rd, Scan
   }
   HIP_TRY(cnt.alloc(nv1));
   HIP_TRY(hipMemsetAsync(cnt.p, 0, sizeof(int) * nv1, 0));
-  HIP_TRY(keys.alloc((size_t)nt));
-  HIP_TRY(sorted.alloc((size_t)nt));
-  HIP_TRY(owners.alloc((size_t)nt));
-  HIP_TRY(owners_sorted.alloc((size_t)nt));
-  const long long kblocks = std::min<long long>(((long long)g->ne + 255) / 256, (long long)g->cu_count * 32);
-  hipLaunchKernelGGL(cb_task_keys_kernel, dim3((unsigned)kblocks), dim3(256), 0, 0, nv, g->ne, g->d_rp, g->d_col, ntask_of.p, tpos.p, pl.topo ? 1 : 0, keys.p, owners.p, cnt.p);
-  int bits = 1;
-  while (bits < 32 && (1ll << bits) < (long long)nv) ++bits;
-  size_t bytes = 0;
-  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, keys.p, sorted.p, owners.p, owners_sorted.p, nt, 0, 32 + bits));
-  HIP_TRY(tmp.reserve(bytes));
-  HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.buf.p, bytes, keys.p, sorted.p, owners.p, owners_sorted.p, nt, 0, 32 + bits));
+  const long long kblocks = std::min<long long>(((long long)nv * 8 + 255) / 256, (long long)g->cu_count * 64);
+  hipLaunchKernelGGL((cb_task_rows_kernel<false>), dim3((unsigned)kblocks), dim3(256), 0, 0, nv, g->d_rp, g->d_col, g->d_edesc, ntask_of.p, pl.topo ? 1 : 0, cnt.p,
+                     nullptr, nullptr, nullptr);
   HIP_TRY(dev_exclusive_sum(tmp, cnt.p, rd.d_trp, nv1));
   HIP_TRY(hipMalloc(&rd.d_tasks, sizeof(CBuildTask) * (size_t)nt));
-  const long long dblocks = std::min<long long>(((long long)nt + 255) / 256, (long long)g->cu_count * 32);
-  hipLaunchKernelGGL(cb_task_desc_kernel, dim3((unsigned)dblocks), dim3(256), 0, 0, (long long)nt, g->d_rp, g->d_col, sorted.p, owners_sorted.p, rd.d_base,
-                     pl.topo ? 1 : 0, rd.d_tasks);
+  HIP_TRY(hipMemsetAsync(cnt.p, 0, sizeof(int) * nv1, 0));
+  hipLaunchKernelGGL((cb_task_rows_kernel<true>), dim3((unsigned)kblocks), dim3(256), 0, 0, nv, g->d_rp, g->d_col, g->d_edesc, ntask_of.p, pl.topo ? 1 : 0, cnt.p,
+                     rd.d_trp, rd.d_base, rd.d_tasks);
   HIP_TRY(hipGetLastError());
   // host chunks: runs of consecutive vertices whose DAG rows fit the stage (longer rows host nothing), costs from the task lists,
   // heavy chunks cut into parts like gm_tct.hip's (a hub hosts 10^5 in-edges)
@@ -1174,8 +1139,12 @@ int get_clique_plan(gm_graph *g, int rank, int world, int policy, int target, un
     const int rc = get_table(g, target, false, kBitWords, part_cap, kStageCapClique, &pl.tabN, rf, kBitmapMinDeg);
     if (rc) return rc;
   }
+  {
+    const int rc = ensure_edesc(g);  // (the task records read the targets' {start, length} from the edge descriptors)
+    if (rc) return rc;
+  }
   SetupTimer timer;
-  PoolScope pool(g);  // (the task keys of the share)
+  PoolScope pool(g);  // (the per-vertex arrays of the rounds)
   ScanTemp tmp;
   auto blocks = [](long long n) { return dim3((unsigned)std::max<long long>(1, (n + 255) / 256)); };
   if (!g->wide_valid) {  // once per graph: the wide vertices, longest rows first (select + stable radix sort by row length)

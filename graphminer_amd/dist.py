@@ -73,3 +73,43 @@ def chunk_table(row_ptr, chunk: int = 0, for_clique: bool = False) -> np.ndarray
     _lib.check(lib.gm_chunk_table(rp.size - 1, rp.ctypes.data, chunk, int(for_clique), recs.ctypes.data, n.value, C.byref(n)),
                "gm_chunk_table")
     return recs[: n.value]
+
+
+def reduce_scatter_sum(buf, rank: int, world: int):
+    """Sum the ranks' equal-sized 1-D integer tensors and return THIS rank's slice [rank * n / world, (rank + 1) * n / world) of the sum:
+    `torch.distributed.reduce_scatter_tensor` over RCCL (one ncclReduceScatter over xGMI: every rank receives n / world entries), or --
+    gloo, which has no reduce-scatter -- an all-reduce of the host copy followed by the slice (CPU tests, the one-GPU dry run).
+    Unsigned 32-bit counters travel as int32: addition wraps the same way."""
+    import torch
+    import torch.distributed as dist
+
+    n = buf.numel()
+    assert n % world == 0, (n, world)
+    per = n // world
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return buf[rank * per:(rank + 1) * per]
+    if dist.get_backend() == "nccl":
+        out = torch.empty(per, dtype=buf.dtype, device=buf.device)
+        dist.reduce_scatter_tensor(out, buf)
+        return out
+    h = buf.cpu()
+    dist.all_reduce(h)
+    return h[rank * per:(rank + 1) * per].to(buf.device)
+
+
+def diamond_step(sym, rank: int, world: int, counts, buf=None, stream=0, **kw):
+    """One step of the several-rank diamond (the one-GPU algorithm at every N, include/graphminer_amd.h gm_diamond_support_*): this rank's
+    share of the triangle pass -> ONE reduce-scatter of the support arrays -> sum C(t, 2) of the rank's slice into counts[0] (an int64
+    device tensor) -> the caller all-reduces `counts` as for every other pattern. `buf`: the rank's support array (int32 tensor of
+    diamond_support_size entries) to reuse between steps. Returns (buf, slice tensor)."""
+    import torch
+
+    from .solvers import diamond_support_finish, diamond_support_partial, diamond_support_size
+
+    n = diamond_support_size(sym, world)
+    if buf is None or buf.numel() != n:
+        buf = torch.empty(n, dtype=torch.int32, device=counts.device)
+    diamond_support_partial(sym, buf.data_ptr(), n, rank=rank, world=world, stream=stream, d_counts=counts.data_ptr(), **kw)
+    mine = reduce_scatter_sum(buf, rank, world)
+    diamond_support_finish(sym, mine.data_ptr(), mine.numel(), stream=stream, d_counts=counts.data_ptr())
+    return buf, mine

@@ -129,7 +129,57 @@ bool run_multi(Graph &g, const Job &j, int n, int chunk, uint64_t *out) {
   std::cout << "Time on replicating the CSR to " << n << " GPUs (1 PCIe copy + RCCL broadcast over xGMI): " << tb.Seconds()
             << " sec\n";
 
+  // diamond on several GPUs: the one-GPU algorithm at every N (include/graphminer_amd.h gm_diamond_support_*): every GPU's share of the
+  // triangle pass into its own support array, ONE ncclReduceScatter (uint32, sum) over xGMI, sum C(t, 2) of the received slice, then the
+  // all-reduce of the counts like every other pattern.  (GM_DIAMOND_PER_EDGE, or rows beyond the 2048-entry stage: the per-edge kernels.)
+  std::vector<uint32_t *> d_sup(n, nullptr);
+  int64_t sup_n = 0;
+  bool diamond_sup = j.kind == Job::SGL && j.pattern && std::strcmp(j.pattern, "diamond") == 0 && !std::getenv("GM_DIAMOND_PER_EDGE");
+  if (diamond_sup) {
+    for (int i = 0; i < n && diamond_sup; ++i) {
+      HIP_OK(hipSetDevice(i));
+      int64_t m = 0;
+      int rc = gm_diamond_support_size(dg[i], n, &m);
+      if (rc == GM_ERR_UNSUPPORTED) { diamond_sup = false; break; }
+      if (rc) gm_die(rc, "gm_diamond_support_size");
+      sup_n = m;
+      HIP_OK(hipMalloc(&d_sup[i], sizeof(uint32_t) * size_t(m)));
+    }
+  }
+  auto launch_diamond = [&]() {
+    const size_t per = size_t(sup_n) / size_t(n);
+    std::vector<gm_launch> las(n);
+    for (int i = 0; i < n; ++i) {
+      gm_launch &la = las[i];
+      std::memset(&la, 0, sizeof la);
+      la.stream = streams[i];
+      la.rank = i;
+      la.world = n;
+      la.policy = GM_PART_ROUND_ROBIN;
+      la.chunk = chunk > 0 ? chunk : 0;
+      la.d_counts = d_cnt[i];
+      int rc = gm_diamond_support_partial(dg[i], &la, d_sup[i], sup_n, nullptr);
+      if (rc) gm_die(rc, "gm_diamond_support_partial");
+    }
+    NCCL_OK(ncclGroupStart());
+    for (int i = 0; i < n; ++i)  // in place: GPU i receives its slice where it lies in its own array
+      NCCL_OK(ncclReduceScatter(d_sup[i], d_sup[i] + size_t(i) * per, per, ncclUint32, ncclSum, comms[i], streams[i]));
+    NCCL_OK(ncclGroupEnd());
+    for (int i = 0; i < n; ++i) {
+      int rc = gm_diamond_support_finish(dg[i], &las[i], d_sup[i] + size_t(i) * per, int64_t(per), nullptr, nullptr);
+      if (rc) gm_die(rc, "gm_diamond_support_finish");
+    }
+    NCCL_OK(ncclGroupStart());
+    for (int i = 0; i < n; ++i)
+      NCCL_OK(ncclAllReduce(d_cnt[i], d_cnt[i], 1, ncclUint64, ncclSum, comms[i], streams[i]));
+    NCCL_OK(ncclGroupEnd());
+    for (int i = 0; i < n; ++i) {
+      HIP_OK(hipSetDevice(i));
+      HIP_OK(hipStreamSynchronize(streams[i]));
+    }
+  };
   auto launch_all = [&](bool &unsupported) {
+    if (diamond_sup) return launch_diamond();
     for (int i = 0; i < n; ++i) {
       gm_launch la;
       std::memset(&la, 0, sizeof la);
@@ -160,9 +210,14 @@ bool run_multi(Graph &g, const Job &j, int n, int chunk, uint64_t *out) {
     launch_all(unsupported);
     t.Stop();
     for (int i = 0; i < n; ++i) {
-      double ms = 0;
+      double ms = 0, two[2] = {0, 0};
       int got = 0;
-      gm_kernel_times(dg[i], 1, &ms, &got);
+      if (diamond_sup) {  // (two launches per step: the share of the triangle pass + sum C(t, 2) of the slice)
+        gm_kernel_times(dg[i], 2, two, &got);
+        ms = two[0] + two[1];
+      } else {
+        gm_kernel_times(dg[i], 1, &ms, &got);
+      }
       std::cout << "runtime[gpu" << i << "] = " << ms * 1e-3 << " sec\n";  // src/clique/multigpu.cu:136-137
     }
     std::cout << "runtime [" << j.name << "] = " << t.Seconds() << " sec\n";
@@ -178,6 +233,7 @@ bool run_multi(Graph &g, const Job &j, int n, int chunk, uint64_t *out) {
   for (int i = 0; i < n; ++i) {
     HIP_OK(hipSetDevice(i));
     gm_graph_free(dg[i]);
+    if (d_sup[i]) HIP_OK(hipFree(d_sup[i]));
     HIP_OK(hipFree(d_rp[i]));
     HIP_OK(hipFree(d_ci[i]));
     HIP_OK(hipFree(d_cnt[i]));

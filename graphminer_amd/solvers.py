@@ -90,3 +90,27 @@ def MotifSolver(g: DeviceGraph, k: int, *, rank=0, world=1, chunk=0, return_stat
     _lib.check(fn(g.handle, k, C.byref(la), out, n, C.byref(st)), "gm_motif")
     res = [int(out[i]) for i in range(n)]
     return (res, _stats(st)) if return_stats else res
+
+
+# ---- diamond on several ranks with the one-GPU algorithm (include/graphminer_amd.h: gm_diamond_support_*) ------------------------------
+def diamond_support_size(g: DeviceGraph, world: int = 1) -> int:
+    """uint32 entries of a rank's support array: |E+| of the oriented copy, padded so that every rank's reduce-scatter slice is equal"""
+    n = C.c_int64(0)
+    _lib.check(_lib.load().gm_diamond_support_size(g.handle, world, C.byref(n)), "gm_diamond_support_size")
+    return int(n.value)
+
+
+def diamond_support_partial(g: DeviceGraph, d_support: int, n_entries: int, *, rank=0, world=1, chunk=0, return_stats=False, **kw):
+    """this rank's share of the triangle pass adds its increments into the caller's DEVICE buffer (zeroed by the call); asynchronous on
+    `stream` when `d_counts` is given"""
+    la, st = _launch(rank, world, chunk, **kw), gm_stats()
+    _lib.check(_lib.load().gm_diamond_support_partial(g.handle, C.byref(la), d_support, n_entries, C.byref(st)), "gm_diamond_support_partial")
+    return _stats(st) if return_stats else None
+
+
+def diamond_support_finish(g: DeviceGraph, d_support: int, count: int, *, return_stats=False, **kw):
+    """sum C(t, 2) over `count` reduced support entries at `d_support` (a rank's slice) -> this rank's part of the diamond count"""
+    la, st, total = _launch(0, 1, 0, **kw), gm_stats(), C.c_uint64(0)
+    _lib.check(_lib.load().gm_diamond_support_finish(g.handle, C.byref(la), d_support, count, None if la.d_counts else C.byref(total), C.byref(st)),
+               "gm_diamond_support_finish")
+    return (int(total.value), _stats(st)) if return_stats else int(total.value)

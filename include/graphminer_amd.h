@@ -179,6 +179,21 @@ int gm_tc(const gm_graph *dag, const gm_launch *launch, uint64_t *total, gm_stat
  * edge (gm_hrow.hip, gm_chunk.h). Same count. */
 int gm_sgl(const gm_graph *sym, const char *pattern, const gm_launch *launch, uint64_t *total, gm_stats *stats);
 
+/* Diamond on SEVERAL ranks with the one-GPU algorithm (one shared pass over the triangles of the oriented copy; the reference has no
+ * multi-GPU diamond: src/sgl/multigpu.cu:117 is commented out).  Per step, on every rank:
+ *   1. gm_diamond_support_partial: the rank's share (launch->rank / world) of the triangle pass adds its three increments per triangle
+ *      into d_support -- the caller's DEVICE buffer of n_entries uint32 (>= gm_diamond_support_size: |E+| of the oriented copy rounded
+ *      up so that every rank's slice is equal and 256-byte aligned), zeroed by the call, ordered on launch->stream;
+ *   2. the caller sums the ranks' arrays with ONE reduce-scatter (ncclReduceScatter, ncclUint32, ncclSum / torch reduce_scatter_tensor):
+ *      rank r receives the n_entries / world entries from r * n_entries / world on;
+ *   3. gm_diamond_support_finish: sum C(t, 2) over `count` entries at d_support (the rank's reduced slice) -> total / launch->d_counts;
+ *   4. the usual all-reduce of the 64-bit count.
+ * GM_ERR_UNSUPPORTED when a row of the oriented copy exceeds the 2048-entry stage (gm_sgl's per-edge kernels then run at any world). */
+int gm_diamond_support_size(const gm_graph *sym, int world, int64_t *n_entries);
+int gm_diamond_support_partial(const gm_graph *sym, const gm_launch *launch, uint32_t *d_support, int64_t n_entries, gm_stats *stats);
+int gm_diamond_support_finish(const gm_graph *sym, const gm_launch *launch, const uint32_t *d_support, int64_t count, uint64_t *total,
+                              gm_stats *stats);
+
 /* CliqueSolver on the DAG, 3 <= k <= 8 (src/clique/cpu_kernels/automine_omp.h:67-83,138-157;
  * src/clique/gpu_kernels/clique4_warp_edge.cuh:3-31 ... clique8), any out-degree. k = 4: the first DFS level is re-hosted (every
  * edge at the endpoint with the longer out-list, gm_cbuild.hip), rows of up to 2048 entries keep their adjacency bit-matrix in an

@@ -25,7 +25,22 @@ run = {
     "diamond": lambda **kw: SglSolver(sym, "diamond", return_stats=True, **kw),
     "clique4": lambda **kw: CliqueSolver(dag, 4, return_stats=True, **kw),
     "motif3": lambda **kw: MotifSolver(sym, 3, return_stats=True, **kw),
-}[a.workload]
+}.get(a.workload)
+def diamond_sup(rank=0, world=1, policy=0, chunk=0, tune=None):
+    """a rank's part of the several-rank diamond (gm_diamond_support_partial + _finish on its slice; the reduce-scatter itself -- 4 B per
+    DAG entry over xGMI -- is not simulated): kernel ms of the two launches"""
+    from graphminer_amd.solvers import diamond_support_finish, diamond_support_partial, diamond_support_size
+    n = diamond_support_size(sym, world)
+    buf = torch.empty(n, dtype=torch.int32, device="cuda:0")
+    st1 = diamond_support_partial(sym, buf.data_ptr(), n, rank=rank, world=world, policy=policy, chunk=chunk, tune=tune, return_stats=True)
+    per = n // world
+    _, st2 = diamond_support_finish(sym, buf[rank * per:(rank + 1) * per].data_ptr(), per, return_stats=True)
+    st1.kernel_ms += st2.kernel_ms
+    return None, st1
+
+
+if a.workload == "diamond_sup":
+    run = diamond_sup
 base = None
 tune = [int(x) for x in a.tune.split(',')] if a.tune else None
 for world in [int(x) for x in a.worlds.split(',')]:

@@ -148,3 +148,62 @@ def test_allreduce_counts_single_process_keeps_uint64_range():
     from graphminer_amd import dist
 
     assert dist.allreduce_counts([2**64 - 5, 0, 2**63, 7]) == [2**64 - 5, 0, 2**63, 7]
+
+
+def _diamond_worker(rank, world, port, name, q):
+    """the several-rank diamond on CPU: this rank's share of the DAG's task edges (every world-th one) contributes three support increments
+    per triangle it finds; reduce_scatter_sum adds the ranks' arrays and hands every rank its slice; sum C(t, 2) of the slice; all-reduce"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+    import torch
+
+    import oracle as O
+    from common import load_graph
+    from graphminer_amd import dist
+
+    dist.init_from_env("gloo")
+    g = load_graph(name)
+    dag = O.orient(O.OGraph(g.row_ptr, g.col_idx))
+    rp, ci = np.asarray(dag.row_ptr), np.asarray(dag.col_idx)
+    ne = int(ci.size)
+    n = (ne + 64 * world - 1) // (64 * world) * (64 * world)  # gm_diamond_support_size
+    sup = np.zeros(n, dtype=np.int64)
+    src = np.repeat(np.arange(dag.nv, dtype=np.int64), np.diff(rp))
+    for e in range(rank, ne, world):  # task edge (u, v): every common out-neighbour w closes a triangle with the entries u->v, u->w, v->w
+        u, v = int(src[e]), int(ci[e])
+        a, b = ci[rp[u]:rp[u + 1]], ci[rp[v]:rp[v + 1]]
+        common, ia, ib = np.intersect1d(a, b, assume_unique=True, return_indices=True)
+        sup[e] += common.size
+        np.add.at(sup, rp[u] + ia, 1)
+        np.add.at(sup, rp[v] + ib, 1)
+    mine = dist.reduce_scatter_sum(torch.from_numpy(sup.astype(np.int32)), rank, world)
+    t = mine.to(torch.int64)
+    part = int((t * (t - 1) // 2).sum())
+    total = dist.allreduce_counts([part, int(sup.sum())])
+    q.put((rank, part, total, int(mine.numel()), n))
+    import torch.distributed as td
+    td.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,name", [(2, "citeseer"), (3, "rmat10_ef16_s42")])
+def test_diamond_supports_reduce_scatter_to_the_golden_total(world, name):
+    """the exchange step of the several-rank diamond (graphminer_amd.dist.reduce_scatter_sum; RCCL on the GPU box, gloo here): per-rank
+    support arrays from disjoint task shares -> every rank's slice of their sum -> sum C(t, 2) -> the reference's diamond count"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from common import GOLDEN
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_diamond_worker, args=(r, world, port, name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for _, _, total, per, n in res:
+        assert total == [GOLDEN[name]["diamond"], 3 * GOLDEN[name]["tc"]] and per * world == n
+    assert sum(r[1] for r in res) == GOLDEN[name]["diamond"]

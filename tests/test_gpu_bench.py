@@ -117,8 +117,6 @@ def test_bench_traffic_of_a_rank_share_on_one_gpu():
     import bench
 
     a = argparse.Namespace(seed=42, scale=14, ef=8, graph="", data_dir="", uniform="", powerlaw="", tune="", policy=0, share_rank=0, share_world=1)
-    # (diamond runs another algorithm on one GPU -- edge supports -- than a rank of four does: its two figures are both checked for
-    # being there, not against each other)
     whole, src = bench.measure_traffic(a, ["tc", "motif3", "diamond"])
     assert whole, src
     share, src = bench.measure_traffic(a, ["tc", "motif3", "diamond"], share=(0, 4))
@@ -126,7 +124,9 @@ def test_bench_traffic_of_a_rank_share_on_one_gpu():
     for w in ("tc", "motif3"):
         assert 0 < share[w]["fetch_bytes"] < whole[w]["fetch_bytes"], (w, share[w], whole[w])
     assert share["diamond"]["fetch_bytes"] > 0 and whole["diamond"]["fetch_bytes"] > 0
-    assert any("gm::sup_kernel" in k for k in whole["diamond"]["kernels"]) and not any("gm::sup_kernel" in k for k in share["diamond"]["kernels"])
+    # (round 4: a rank's share of the diamond is a share of the SAME triangle pass -- gm_diamond_support_partial -- not another algorithm)
+    assert any("gm::sup_kernel" in k for k in whole["diamond"]["kernels"]) and any("gm::sup_kernel" in k for k in share["diamond"]["kernels"])
+    assert share["diamond"]["fetch_bytes"] < whole["diamond"]["fetch_bytes"]
 
 
 def test_algorithmic_bytes_on_the_device_equal_the_oracle():
@@ -229,3 +229,24 @@ def test_own_algorithm_bytes_equal_a_brute_force_count():
 def test_bench_other_workloads_run(workload):
     d = run_bench("--workload", workload, "--scale", "12", "--ef", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--traffic", "off")
     assert d["value"] > 0 and d["config"]["workload"].startswith(workload)
+
+
+def test_scale_dryrun_two_ranks_on_one_gpu():
+    """scripts/scale_dryrun.sh: the driver's N > 1 launch line with two ranks on GPU 0 over gloo -- rank shares, the summed counts, the
+    per-rank kernel times, the CPU-baseline record and the rank-0-only counter passes (the other rank waits at the barrier) all run, so the
+    first 8-GPU job is not the first execution of any of it"""
+    out = subprocess.run(["bash", os.path.join(ROOT, "scripts", "scale_dryrun.sh"), "2", "--scale", "13", "--ef", "8", "--steps", "2", "--warmup", "1",
+                          "--cpu-seconds", "3"], capture_output=True, text=True, timeout=1500, cwd=ROOT, env=dict(os.environ, MASTER_PORT="29547"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]  # rank 0 alone prints
+    d = json.loads(lines[0])
+    ref = run_bench("--scale", "13", "--ef", "8", "--steps", "2", "--warmup", "1", "--cpu-seconds", "3", "--traffic", "off")
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert [c["count"] for c in d["configs"][1:]] == [c["count"] for c in ref["configs"][1:]]  # the two shares add up to the whole
+    assert d["all_counts_match_cpu"] is True
+    for c in d["configs"][1:]:
+        assert len(c["per_gpu_kernel_ms"]["all"]) == 2 and min(c["per_gpu_kernel_ms"]["all"]) > 0
+        assert c["cpu_baseline"]["value"] > 0
+        assert c["roofline"]["traffic"] and c["roofline"]["traffic"] > 0, c["roofline"]["traffic_source"]
+        assert "share of rank 0 of 2" in c["roofline"]["traffic_source"]

@@ -896,3 +896,30 @@ def test_unsorted_rows_are_refused_until_sorted(dev):
         d.sort_neighbors()
         assert TCSolver(d) == want3 and CliqueSolver(d, 4) == want4
         assert TCSolver(d, tune=[0, 0, 0, 0, 0, 0, 0x200]) == want3 and CliqueSolver(d, 4, tune=[0, 0, 0, 0, 0, 0, 0x200]) == want4
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_diamond_supports_of_rank_shares_add_up(gg, world, dev):
+    """the several-rank diamond (gm_diamond_support_partial / _finish): ONE GPU plays every rank -- each rank's share of the triangle pass
+    into its own support array, the arrays summed (what the reduce-scatter does), every rank's slice through sum C(t, 2): the parts add up
+    to the reference's count; the sum of the arrays is the one-rank support array."""
+    import torch
+
+    from graphminer_amd.solvers import diamond_support_finish, diamond_support_partial, diamond_support_size
+
+    name, g, s, d = gg
+    want = GOLDEN[name]["diamond"]
+    n = diamond_support_size(s, world)
+    assert n % (64 * world) == 0 and n >= d.E()
+    bufs = [torch.full((n,), 7, dtype=torch.int32, device=f"cuda:{dev}") for _ in range(world)]  # (garbage in: the call zeroes its buffer)
+    for r in range(world):
+        diamond_support_partial(s, bufs[r].data_ptr(), n, rank=r, world=world)
+    total = torch.stack(bufs).sum(0, dtype=torch.int64).to(torch.int32)
+    one = torch.empty(diamond_support_size(s, 1), dtype=torch.int32, device=f"cuda:{dev}")
+    diamond_support_partial(s, one.data_ptr(), one.numel())
+    assert torch.equal(total[:d.E()], one[:d.E()]) and int(total[d.E():].abs().sum()) == 0
+    assert int(total.sum()) == 3 * GOLDEN[name]["tc"]  # three increments per triangle
+    per = n // world
+    parts = [diamond_support_finish(s, total[r * per:(r + 1) * per].contiguous().data_ptr(), per) for r in range(world)]
+    assert sum(parts) == want, (world, parts)
+    assert SglSolver(s, "diamond") == want
