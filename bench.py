@@ -898,7 +898,7 @@ def finish_record(rec, a, world, ab, floor, traffic, traffic_src, cpu, known, st
         out["cpu_baseline"] = cpu
     # count check: against the CPU count of this run when one exists, else against the recorded full-size oracle answers
     chk = {}
-    if cpu and "count_matches_gpu" in cpu and "count_matches_gpu_on" not in cpu:
+    if cpu and "count_matches_gpu" in cpu and ("count_matches_gpu_on" not in cpu or cpu["count_matches_gpu_on"] == rec["graph"]):  # (a "reduced" graph that IS the bench graph: small --scale runs)
         chk = {"count_matches_cpu": cpu["count_matches_gpu"], "cpu_count_source": f"this run: {cpu['kind']} ({cpu['sample'][:60]}...)"}
     elif known is not None and cpu and "count_matches_gpu_on" in cpu:  # full size: recorded answer; reduced scale: this run
         chk = {"count_matches_cpu": bool(known["count"] == rec["count"]) and bool(cpu["count_matches_gpu"]),
