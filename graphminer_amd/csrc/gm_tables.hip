@@ -751,34 +751,102 @@ static void build_inline_copies(gm_graph *g, ScanTemp &tmp, const unsigned char 
 // the offsets, pass 2 repeats the walk and drops every task at its host's cursor -- descriptor, own entry and the low 8 bits of the host
 // (the tag of the key stream) written where they stay.  The partner's {start, length} comes from the edge descriptors (coalesced) instead
 // of two random reads of the offsets.  The order of a host's tasks is the order of arrival: nothing depends on it.
-template <bool PLACE>
-__global__ __launch_bounds__(256) void task_rows_kernel(int nv, const int *__restrict__ rp, const int *__restrict__ col, const int2 *__restrict__ edesc,
-                                                         int stage_max, int topo, int *__restrict__ cnt /* PLACE: the cursors */,
-                                                         const int *__restrict__ trp, int2 *__restrict__ tdesc, int *__restrict__ tedge,
-                                                         unsigned char *__restrict__ ttag) {
+// Same-address atomics are what such a placement costs on a skewed graph (a hub of R-MAT-22 hosts 10^5 in-edges: 4.3 + 4.6 ms for the two
+// passes, no better than the sort): (i) the tasks a row hosts itself are counted per 8-lane group, one atomic per group and step;
+// (ii) on a topologically numbered DAG the hubs are the LAST ids: in-edge tasks of the last kHubWin hosts are counted in an LDS
+// histogram per workgroup -- pass 2 reserves a range per (workgroup, hub) with one atomic and ranks its tasks inside it in LDS.
+constexpr int kHubWin = 4096;
+struct TaskWalk {
+  int nv, stage_max, topo, hub0;  // hosts >= hub0 are aggregated in LDS (nv: none)
+  const int *rp, *col;
+  const int2 *edesc;
+};
+// calls f(u, i, e, ru, du, dv, tail, u_hosts) for every task edge of the rows this workgroup walks (all 64 lanes of a wave stay together:
+// f may use wave ballots; `act` = the lane holds a task)
+template <class F>
+__device__ __forceinline__ void task_walk(const TaskWalk &w, F f) {
   const long long stride = ((long long)gridDim.x * blockDim.x) >> 3;
   const int sub = threadIdx.x & 7;
-  for (long long u = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 3; u < nv; u += stride) {
-    const int ru = rp[u], du = rp[u + 1] - ru;
-    if (du > stage_max) continue;  // a row the stage cannot take hosts nothing, and its out-edges stay with the chunked kernel (run_pattern)
-    for (int i = sub; i < du; i += 8) {
-      const int e = ru + i;
-      const int2 dv = edesc[e];  // {rp[v], d+(v)} of the entry's target v
+  const long long u0 = ((long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63)) >> 3;  // first row of this wave (8 rows per wave and trip)
+  for (long long ub = u0; ub < w.nv; ub += stride) {
+    const long long u = ub + ((threadIdx.x & 63) >> 3);
+    int ru = 0, du = 0;
+    if (u < w.nv) {
+      ru = w.rp[u];
+      du = w.rp[u + 1] - ru;
+      if (du > w.stage_max) du = 0;  // a row the stage cannot take hosts nothing, and its out-edges stay with the chunked kernel (run_pattern)
+    }
+    const int dmax = wave_max_nonneg(du);
+    for (int i = sub; i - sub < dmax; i += 8) {  // wave-uniform trip count
+      const bool act = i < du;
+      const int e = ru + (act ? i : 0);
+      const int2 dv = act ? w.edesc[e] : make_int2(0, 0);  // {rp[v], d+(v)} of the entry's target v
       // the host = the endpoint whose list is NOT streamed: N+(v) whole, or N+(u) -- under a topological numbering only its part beyond
       // v -- whichever is shorter (ties: the source hosts); a list that does not fit the stage never hosts
-      const int tail = topo ? du - i - 1 : du;
-      const bool u_hosts = dv.y > stage_max || tail >= dv.y;
-      const int host = u_hosts ? (int)u : col[e];
-      if (!PLACE) {
+      const int tail = w.topo ? du - i - 1 : du;
+      const bool u_hosts = dv.y > w.stage_max || tail >= dv.y;
+      f(act, (int)u, i, e, ru, du, dv, tail, u_hosts);
+    }
+  }
+}
+
+template <bool PLACE>
+__global__ __launch_bounds__(256) void task_rows_kernel(const TaskWalk w, int *__restrict__ cnt /* PLACE: the cursors */, const int *__restrict__ trp,
+                                                         int2 *__restrict__ tdesc, int *__restrict__ tedge, unsigned char *__restrict__ ttag) {
+  __shared__ int hist[kHubWin];
+  __shared__ int hbase[PLACE ? kHubWin : 1];
+  for (int h = threadIdx.x; h < kHubWin; h += 256) hist[h] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, sub = lane & 7, g8 = lane & ~7;
+  auto put = [&](const int slot, const int host, const int e, const int ru, const int du, const int2 dv, const int tail, const bool u_hosts) {
+    tdesc[slot] = u_hosts ? dv : (w.topo ? make_int2(e + 1, tail) : make_int2(ru, du));
+    tedge[slot] = e;
+    ttag[slot] = (unsigned char)(host & 255);
+  };
+  task_walk(w, [&](const bool act, const int u, const int i, const int e, const int ru, const int du, const int2 dv, const int tail, const bool u_hosts) {
+    // (i) the tasks the row hosts itself: one atomic per 8-lane group
+    const unsigned long long mu = __ballot(act && u_hosts);
+    const unsigned gm = (unsigned)(mu >> g8) & 255u;
+    int ubase = 0;
+    if (gm != 0u && sub == (int)__builtin_ctz(gm)) ubase = atomicAdd(&cnt[u], (int)__builtin_popcount(gm));
+    if (PLACE && gm != 0u) {
+      ubase = __shfl(ubase, g8 + (int)__builtin_ctz(gm));
+      if (act && u_hosts) put(trp[u] + ubase + (int)__builtin_popcount(gm & ((1u << sub) - 1u)), u, e, ru, du, dv, tail, true);
+    }
+    // (ii) in-edge tasks: the target hosts -- a hub through the LDS histogram, anybody else through its global cursor
+    if (act && !u_hosts) {
+      const int host = w.col[e];
+      if (host >= w.hub0) {
+        atomicAdd(&hist[host - w.hub0], 1);
+      } else if (!PLACE) {
         atomicAdd(&cnt[host], 1);
       } else {
-        const int slot = trp[host] + atomicAdd(&cnt[host], 1);
-        tdesc[slot] = u_hosts ? dv : (topo ? make_int2(e + 1, tail) : make_int2(ru, du));
-        tedge[slot] = e;
-        ttag[slot] = (unsigned char)(host & 255);
+        put(trp[host] + atomicAdd(&cnt[host], 1), host, e, ru, du, dv, tail, false);
+      }
+    }
+  });
+  __syncthreads();
+  for (int h = threadIdx.x; h < kHubWin; h += 256) {
+    const int c = hist[h];
+    if (c) {
+      const int b = atomicAdd(&cnt[w.hub0 + h], c);  // pass 1: the count; pass 2: this workgroup's range among the hub's tasks
+      if (PLACE) {
+        hbase[h] = b;
+        hist[h] = 0;
       }
     }
   }
+  if (!PLACE) return;
+  __syncthreads();
+  task_walk(w, [&](const bool act, const int u, const int i, const int e, const int ru, const int du, const int2 dv, const int tail, const bool u_hosts) {
+    if (act && !u_hosts) {
+      const int host = w.col[e];
+      if (host >= w.hub0) {
+        const int h = host - w.hub0;
+        put(trp[host] + hbase[h] + atomicAdd(&hist[h], 1), host, e, ru, du, dv, tail, false);
+      }
+    }
+  });
 }
 
 int ensure_tasklists(gm_graph *g, bool /*with_edges*/) {
@@ -807,9 +875,14 @@ int ensure_tasklists(gm_graph *g, bool /*with_edges*/) {
   HIP_TRY(cnt.alloc(nv1));
   HIP_TRY(ttag.alloc(ne));
   HIP_TRY(hipMemsetAsync(cnt.p, 0, sizeof(int) * nv1, 0));
-  const long long blocks = std::min<long long>(((long long)g->nv * 8 + 255) / 256, (long long)g->cu_count * 64);
-  hipLaunchKernelGGL((task_rows_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, 0, g->nv, g->d_rp, g->d_col, g->d_edesc, kTctStageMax, topo ? 1 : 0, cnt.p,
-                     nullptr, nullptr, nullptr, nullptr);
+  // (few, fat workgroups: a workgroup's LDS histogram of the hub hosts pays when it sees many rows)
+  // (where no hub window exists -- a DAG that is not numbered topologically -- many thin workgroups: power-law LJ-size 30.9 vs 9.8 ms)
+  const long long blocks = std::min<long long>(((long long)g->nv * 8 + 255) / 256, (long long)g->cu_count * (topo ? 4 : 64));
+  TaskWalk tw;
+  tw.nv = g->nv; tw.stage_max = kTctStageMax; tw.topo = topo ? 1 : 0;
+  tw.hub0 = topo ? std::max(0, g->nv - kHubWin) : g->nv;
+  tw.rp = g->d_rp; tw.col = g->d_col; tw.edesc = g->d_edesc;
+  hipLaunchKernelGGL((task_rows_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, 0, tw, cnt.p, nullptr, nullptr, nullptr, nullptr);
   int *trp = nullptr, *tedge = nullptr;
   int2 *td = nullptr;
   HIP_TRY(hipMalloc(&trp, sizeof(int) * nv1));
@@ -820,8 +893,7 @@ int ensure_tasklists(gm_graph *g, bool /*with_edges*/) {
   if (e == hipSuccess) e = hipMemsetAsync(tedge, 0, sizeof(int) * ne, 0);
   if (e == hipSuccess) e = hipMemsetAsync(cnt.p, 0, sizeof(int) * nv1, 0);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL((task_rows_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, 0, g->nv, g->d_rp, g->d_col, g->d_edesc, kTctStageMax, topo ? 1 : 0, cnt.p,
-                       trp, td, tedge, ttag.p);
+    hipLaunchKernelGGL((task_rows_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, 0, tw, cnt.p, trp, td, tedge, ttag.p);
     e = hipDeviceSynchronize();
   }
   if (e != hipSuccess) {
@@ -926,44 +998,89 @@ __global__ __launch_bounds__(256) void cb_owner_sizes_kernel(int nv, const int *
 // owner u: the first ntask_of[u] entries are its streamed tasks (all of them, or -- a wide vertex beside a core bitmap -- those below the
 // core).  The edge u -> v is hosted by the endpoint whose list is NOT streamed: N+(v) whole, or N+(u) -- beyond v under a topological
 // numbering -- whichever is shorter (round 3 compared the whole lists: 15 % more keys on R-MAT), when it fits the stage.
+// (same-address atomics aggregated like task_rows_kernel's: per 8-lane group for the tasks a row hosts itself, per workgroup in an LDS
+// histogram for the in-edge tasks of the last kHubWin hosts of a topologically numbered DAG)
 template <bool PLACE>
 __global__ __launch_bounds__(256) void cb_task_rows_kernel(int nv, const int *__restrict__ rp, const int *__restrict__ col, const int2 *__restrict__ edesc,
-                                                           const int *__restrict__ ntask_of, int topo, int *__restrict__ cnt /* PLACE: the cursors */,
+                                                           const int *__restrict__ ntask_of, int topo, int hub0, int *__restrict__ cnt /* PLACE: the cursors */,
                                                            const int *__restrict__ trp, const unsigned long long *__restrict__ base,
                                                            CBuildTask *__restrict__ out) {
+  __shared__ int hist[kHubWin];
+  __shared__ int hbase[PLACE ? kHubWin : 1];
+  for (int h = threadIdx.x; h < kHubWin; h += 256) hist[h] = 0;
+  __syncthreads();
   const long long stride = ((long long)gridDim.x * blockDim.x) >> 3;
-  const int sub = threadIdx.x & 7;
-  for (long long u = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 3; u < nv; u += stride) {
-    const int nt = ntask_of[u];
-    if (nt == 0) continue;  // not an owner of this round, or no matrix (d+ < 3 / > kCbMaxDeg), or every row comes from the core bitmap
-    const int ru = rp[u], du = rp[u + 1] - ru;
+  const int lane = threadIdx.x & 63, sub = lane & 7, g8 = lane & ~7;
+  const long long u0 = ((long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63)) >> 3;
+  auto put = [&](const int slot, const int u, const int i, const int ru, const int du, const int2 dv, const bool v_hosts) {
     const int words = (du + 31) / 32;
-    for (int i = sub; i < nt; i += 8) {
-      const int e = ru + i;
-      const int2 dv = edesc[e];  // {rp[v], d+(v)}
-      const int tail = topo ? du - i - 1 : du;
-      const bool v_hosts = dv.y > tail && dv.y <= kCbMaxDeg;
-      const int host = v_hosts ? col[e] : (int)u;
-      if (!PLACE) {
-        atomicAdd(&cnt[host], 1);
-        continue;
+    const unsigned long long off = base[u] + (unsigned long long)i * (unsigned long long)words;
+    CBuildTask T;
+    unsigned fl = (unsigned)(off >> 32) & 255u;
+    if (!v_hosts) {  // type A: N+(v) is streamed against the staged N+(u)
+      T.list = dv.x;
+      T.len = dv.y;
+    } else {         // type B: N+(u) -- beyond v when the numbering is topological -- is streamed against the staged N+(v)
+      const int skip = topo ? i + 1 : 0;
+      T.list = ru + skip;
+      T.len = du - skip;
+      fl |= ((unsigned)skip << 8) | 0x80000000u;
+    }
+    T.off_lo = (unsigned)off;
+    T.off_hi_fl = fl | ((unsigned)words << 20);
+    out[slot] = T;
+  };
+  for (int phase = 0; phase < (PLACE ? 2 : 1); ++phase) {
+    for (long long ub = u0; ub < nv; ub += stride) {
+      const long long u = ub + (lane >> 3);
+      int nt = 0, ru = 0, du = 0;
+      if (u < nv) {
+        nt = ntask_of[u];  // 0: not an owner of this round, or no matrix (d+ < 3 / > kCbMaxDeg), or every row comes from the core bitmap
+        ru = rp[u];
+        du = rp[u + 1] - ru;
       }
-      const int slot = trp[host] + atomicAdd(&cnt[host], 1);
-      const unsigned long long off = base[u] + (unsigned long long)i * (unsigned long long)words;
-      CBuildTask T;
-      unsigned fl = (unsigned)(off >> 32) & 255u;
-      if (!v_hosts) {  // type A: N+(v) is streamed against the staged N+(u)
-        T.list = dv.x;
-        T.len = dv.y;
-      } else {         // type B: N+(u) -- beyond v when the numbering is topological -- is streamed against the staged N+(v)
-        const int skip = topo ? i + 1 : 0;
-        T.list = ru + skip;
-        T.len = du - skip;
-        fl |= ((unsigned)skip << 8) | 0x80000000u;
+      const int nmax = wave_max_nonneg(nt);
+      for (int i = sub; i - sub < nmax; i += 8) {  // wave-uniform trip count
+        const bool act = i < nt;
+        const int e = ru + (act ? i : 0);
+        const int2 dv = act ? edesc[e] : make_int2(0, 0);  // {rp[v], d+(v)}
+        const int tail = topo ? du - i - 1 : du;
+        const bool v_hosts = dv.y > tail && dv.y <= kCbMaxDeg;
+        if (phase == 0) {
+          const unsigned long long mu = __ballot(act && !v_hosts);
+          const unsigned gm = (unsigned)(mu >> g8) & 255u;
+          int ubase = 0;
+          if (gm != 0u && sub == (int)__builtin_ctz(gm)) ubase = atomicAdd(&cnt[u], (int)__builtin_popcount(gm));
+          if (PLACE && gm != 0u) {
+            ubase = __shfl(ubase, g8 + (int)__builtin_ctz(gm));
+            if (act && !v_hosts) put(trp[u] + ubase + (int)__builtin_popcount(gm & ((1u << sub) - 1u)), (int)u, i, ru, du, dv, false);
+          }
+        }
+        if (act && v_hosts) {
+          const int host = col[e];
+          if (host >= hub0) {
+            if (phase == 0) atomicAdd(&hist[host - hub0], 1);
+            else put(trp[host] + hbase[host - hub0] + atomicAdd(&hist[host - hub0], 1), (int)u, i, ru, du, dv, true);
+          } else if (phase == 0) {
+            if (!PLACE) atomicAdd(&cnt[host], 1);
+            else put(trp[host] + atomicAdd(&cnt[host], 1), (int)u, i, ru, du, dv, true);
+          }
+        }
       }
-      T.off_lo = (unsigned)off;
-      T.off_hi_fl = fl | ((unsigned)words << 20);
-      out[slot] = T;
+    }
+    if (phase == 0) {
+      __syncthreads();
+      for (int h = threadIdx.x; h < kHubWin; h += 256) {
+        const int c = hist[h];
+        if (c) {
+          const int b = atomicAdd(&cnt[hub0 + h], c);  // pass 1: the count; pass 2: this workgroup's range among the hub's tasks
+          if (PLACE) {
+            hbase[h] = b;
+            hist[h] = 0;
+          }
+        }
+      }
+      __syncthreads();
     }
   }
 }
@@ -1091,14 +1208,15 @@ static int build_clique_round(gm_graph *g, CliquePlan &pl, CliqueRound &rd, Scan
   }
   HIP_TRY(cnt.alloc(nv1));
   HIP_TRY(hipMemsetAsync(cnt.p, 0, sizeof(int) * nv1, 0));
-  const long long kblocks = std::min<long long>(((long long)nv * 8 + 255) / 256, (long long)g->cu_count * 64);
-  hipLaunchKernelGGL((cb_task_rows_kernel<false>), dim3((unsigned)kblocks), dim3(256), 0, 0, nv, g->d_rp, g->d_col, g->d_edesc, ntask_of.p, pl.topo ? 1 : 0, cnt.p,
-                     nullptr, nullptr, nullptr);
+  const long long kblocks = std::min<long long>(((long long)nv * 8 + 255) / 256, (long long)g->cu_count * (pl.topo ? 4 : 64));
+  const int hub0 = pl.topo ? std::max(0, nv - kHubWin) : nv;
+  hipLaunchKernelGGL((cb_task_rows_kernel<false>), dim3((unsigned)kblocks), dim3(256), 0, 0, nv, g->d_rp, g->d_col, g->d_edesc, ntask_of.p, pl.topo ? 1 : 0, hub0,
+                     cnt.p, nullptr, nullptr, nullptr);
   HIP_TRY(dev_exclusive_sum(tmp, cnt.p, rd.d_trp, nv1));
   HIP_TRY(hipMalloc(&rd.d_tasks, sizeof(CBuildTask) * (size_t)nt));
   HIP_TRY(hipMemsetAsync(cnt.p, 0, sizeof(int) * nv1, 0));
-  hipLaunchKernelGGL((cb_task_rows_kernel<true>), dim3((unsigned)kblocks), dim3(256), 0, 0, nv, g->d_rp, g->d_col, g->d_edesc, ntask_of.p, pl.topo ? 1 : 0, cnt.p,
-                     rd.d_trp, rd.d_base, rd.d_tasks);
+  hipLaunchKernelGGL((cb_task_rows_kernel<true>), dim3((unsigned)kblocks), dim3(256), 0, 0, nv, g->d_rp, g->d_col, g->d_edesc, ntask_of.p, pl.topo ? 1 : 0, hub0,
+                     cnt.p, rd.d_trp, rd.d_base, rd.d_tasks);
   HIP_TRY(hipGetLastError());
   // host chunks: runs of consecutive vertices whose DAG rows fit the stage (longer rows host nothing), costs from the task lists,
   // heavy chunks cut into parts like gm_tct.hip's (a hub hosts 10^5 in-edges)
