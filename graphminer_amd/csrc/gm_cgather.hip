@@ -15,6 +15,7 @@
 // the pair counts (gm_cmma.hip) read them from there.
 // (reference shape: src/clique/gpu_kernels/clique4_warp_edge.cuh:19-21 re-intersects N+(v0) ^ N+(v1) from global memory per edge)
 #include <algorithm>
+#include <cstdlib>
 #include "gm_flat.h"
 #pragma clang diagnostic ignored "-Winline-asm"  // (M0 on a clobber list: see cg_tile)
 
@@ -106,7 +107,16 @@ hipError_t launch_cgather(const CGatherParams &p, int grid_blocks, hipStream_t s
   hipLaunchKernelGGL(cgather_kernel, dim3((unsigned)grid_blocks), dim3(kCgWaves * GM_WAVE), 0, stream, p);
   return hipGetLastError();
 }
-int cgather_per_cu() { return (int)std::min<size_t>(163840 / sizeof(CGatherLds), 2048 / (kCgWaves * GM_WAVE)); }
+// workgroups per CU the launch asks for (GM_CG_PER_CU: sweeps).  The gathers are bound by the lines they pull through L2, yet they want
+// every wave a CU has: 4 / 2 workgroups per CU 27.7 / 35.6 ms for the whole pattern.
+int cgather_per_cu() {
+  static const int v = [] {
+    const char *e = getenv("GM_CG_PER_CU");
+    const int cap = (int)std::min<size_t>(163840 / sizeof(CGatherLds), 2048 / (kCgWaves * GM_WAVE));
+    return e ? std::max(1, std::min(atoi(e), cap)) : cap;
+  }();
+  return v;
+}
 
 }  // namespace gm
 

@@ -426,6 +426,14 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
   HIP_TRY(hipMemset(d_ticks, 0, sizeof(unsigned long long) * std::max<size_t>(tab->n, 1)));
   p.chunk_ticks = d_ticks;
 #endif
+  if (use_wide && plan && plan->core_base >= 0) {  // (4-clique: the gathered build runs beside the streamed one on a side stream, below)
+    for (int i = 0; i < 2; ++i) {
+      if (!g->aux_stream[i]) {
+        HIP_TRY(hipStreamCreateWithFlags(&g->aux_stream[i], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&g->aux_done[i], hipEventDisableTiming));
+      }
+    }
+  }
   if (use_classes) {
     // everything the class launches may allocate or create, before the timer starts (a first call used to time hipMalloc and
     // hipStreamCreate between its two events): side streams + their events, and the giant-row kernel's scratch -- per workgroup,
@@ -472,22 +480,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
     int qword = 0;
     for (const auto &rd : plan->rounds) {
       if (qword + 9 > 16384) return GM_ERR_TOO_LARGE;  // (more than ~3000 arena rounds)
-      if (rd.n_tasks > 0) {
-        CBuildParams pw;
-        memset(&pw, 0, sizeof pw);
-        pw.g = p.g;
-        pw.chunks = rd.host_tab.d;
-        pw.order = rd.host_tab.d_order[1];  // heaviest host chunks first
-        pw.count = (int)rd.host_tab.n;
-        pw.trp = rd.d_trp;
-        pw.tasks = rd.d_tasks;
-        pw.queue = g->d_wide_queue + qword++;
-        pw.mat = g->d_wide_mat;
-        pw.flags = p.flags;
-        const int bgrid = (int)std::max<long long>(1, std::min<long long>(pw.count, (long long)g->cu_count * cbuild_per_cu(plan->stage)));
-        if (pw.count > 0) HIP_TRY(launch_cbuild(pw, plan->stage, bgrid, stream));
-        plan_chunks += (uint64_t)pw.count;
-      }
+      bool gather_joined = false;
       if (plan->core_base >= 0 && rd.w1 > rd.w0) {  // the rows of the wide vertices whose first endpoint lies in the hub core: gathered (gm_cgather.hip)
         CGatherParams cg;
         memset(&cg, 0, sizeof cg);
@@ -504,8 +497,56 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
         cg.count = (int)(rd.w1 - rd.w0);
         cg.queue = g->d_wide_queue + qword++;
         const int ggrid = (int)std::max<long long>(1, std::min<long long>(cg.count, (long long)g->cu_count * cgather_per_cu()));
-        HIP_TRY(launch_cgather(cg, ggrid, stream));
+        // (GM_CLIQUE_SIDE_STREAM=1: on a side stream beside the streamed build and the counts of the narrow vertices -- they touch other rows
+        // of the arena.  Measured and not taken: the gathers want all 32 waves of a CU -- 4 / 3 / 2 / 1 workgroups per CU beside the streamed
+        // build: 29.2 / 29.5 / 33.8 / 53.4 ms against 27.7 one after the other, profiles/r04/ab_clique4_side_stream.txt)
+        const bool side = getenv("GM_CLIQUE_SIDE_STREAM") != nullptr;
+        hipStream_t gs = side ? g->aux_stream[0] : stream;
+        if (side) {
+          HIP_TRY(hipEventRecord(g->aux_done[1], stream));  // after the queue words were zeroed / the previous round's counts read the arena
+          HIP_TRY(hipStreamWaitEvent(gs, g->aux_done[1], 0));
+        }
+        HIP_TRY(launch_cgather(cg, ggrid, gs));
+        if (side) {
+          HIP_TRY(hipEventRecord(g->aux_done[0], gs));
+          gather_joined = true;
+        }
       }
+      if (rd.n_tasks > 0) {
+        CBuildParams pw;
+        memset(&pw, 0, sizeof pw);
+        pw.g = p.g;
+        pw.chunks = rd.host_tab.d;
+        pw.order = rd.host_tab.d_order[1];  // heaviest host chunks first
+        pw.count = (int)rd.host_tab.n;
+        pw.trp = rd.d_trp;
+        pw.tasks = rd.d_tasks;
+        pw.queue = g->d_wide_queue + qword++;
+        pw.mat = g->d_wide_mat;
+        pw.flags = p.flags;
+        const int bgrid = (int)std::max<long long>(1, std::min<long long>(pw.count, (long long)g->cu_count * cbuild_per_cu(plan->stage)));
+        if (pw.count > 0) HIP_TRY(launch_cbuild(pw, plan->stage, bgrid, stream));
+        plan_chunks += (uint64_t)pw.count;
+      }
+      if (rd.n_count > 0) {
+        CliqueSmallParams cs;
+        memset(&cs, 0, sizeof cs);
+        cs.rp = g->d_rp;
+        cs.chunks = plan->tabN->d;
+        cs.order = plan->d_order;
+        cs.first = (int)(plan->n_first + rd.n_pos0 * plan->n_step);
+        cs.step = (int)plan->n_step;
+        cs.count = (int)rd.n_count;
+        cs.base = rd.d_base;
+        cs.mat = g->d_wide_mat;
+        cs.queue = g->d_wide_queue + qword++;
+        cs.counters = g->d_counters;
+        cs.topo = plan->topo ? 1 : 0;
+        const int sgrid = (int)std::max<long long>(1, std::min<long long>(cs.count, (long long)g->cu_count * 8));
+        HIP_TRY(launch_clique_small(cs, sgrid, stream));
+        plan_chunks += (uint64_t)rd.n_count;
+      }
+      if (gather_joined) HIP_TRY(hipStreamWaitEvent(stream, g->aux_done[0], 0));  // the wide vertices' rows are complete
       // pair counts of the wide vertices: on the matrix cores (gm_cmma.hip), or -- tune[6] & 0x20000 -- the vector-ALU classes of round 3
       const bool valu_counts = (la->tune[6] & 0x20000) != 0;
       for (int cls = 2; cls >= 0 && !valu_counts; --cls) {  // the column blocks and the one-per-CU workgroups before the small ones
@@ -543,24 +584,6 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
         // (class X: a queue entry is one column block of a vertex, eight entries per vertex: gm_wide.hip)
         const int cgrid = (int)std::max<long long>(1, std::min<long long>((long long)c.count * (cls == 2 ? 8 : 1), (long long)g->cu_count * per_cu_c));
         HIP_TRY(launch_clique_count(cls, c, cgrid, stream));
-      }
-      if (rd.n_count > 0) {
-        CliqueSmallParams cs;
-        memset(&cs, 0, sizeof cs);
-        cs.rp = g->d_rp;
-        cs.chunks = plan->tabN->d;
-        cs.order = plan->d_order;
-        cs.first = (int)(plan->n_first + rd.n_pos0 * plan->n_step);
-        cs.step = (int)plan->n_step;
-        cs.count = (int)rd.n_count;
-        cs.base = rd.d_base;
-        cs.mat = g->d_wide_mat;
-        cs.queue = g->d_wide_queue + qword++;
-        cs.counters = g->d_counters;
-        cs.topo = plan->topo ? 1 : 0;
-        const int sgrid = (int)std::max<long long>(1, std::min<long long>(cs.count, (long long)g->cu_count * 8));
-        HIP_TRY(launch_clique_small(cs, sgrid, stream));
-        plan_chunks += (uint64_t)rd.n_count;
       }
     }
     if (prof) {
