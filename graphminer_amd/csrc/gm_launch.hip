@@ -192,7 +192,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
   // parts of 1 M keys / world (>= 128 K): one-GPU simulation of an 8-rank share of R-MAT-22, parts of 8 M / 512 K / 128 K / 32 K keys:
   // 5.36 / 1.18 / 0.99 / 1.15 ms per rank (one GPU: 6.50 / 6.54 / 6.73 / 8.09 ms), profiles/r02/ab_tct_part_cap.log
   const bool use_tct = pat == PAT_TC && !(la->tune[6] & 0x4000000) && la->tune[5] != 1 && g->ne > 0 && !getenv("GM_HOST_TABLES");
-  const int tct_stage = g->max_deg <= kStageCap ? kStageCap : kTctStageMax;
+  const int tct_stage = (g->max_deg <= kStageCap && !getenv("GM_TCT_STAGE_BIG")) ? kStageCap : kTctStageMax;  // (GM_TCT_STAGE_BIG: A/B, the 2048-entry stage everywhere)
   // (rows beyond the 2048-entry stage host nothing: their out-edges are the tasks of the chunked kernel, on a table of those rows only)
   const bool tct_long = use_tct && g->max_deg > kTctStageMax;
   const unsigned long long tct_part = use_tct ? task_part_cap(g, world) : 0ull;
@@ -367,6 +367,10 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
   };
   take_share(tab, p);
   p.grab = la->tune[1] > 0 ? la->tune[1] : 1;
+  // the task-list kernels take TWO chunks per dequeue where a resident workgroup has many to take (one device atomic + one workgroup
+  // barrier less per chunk: flat LJ-size TC 0.605 -> 0.427 ms, power law 0.77 -> 0.71, R-MAT-22 2.57 -> 2.48; four: 0.423 / 0.71 / 3.37 --
+  // the heavy chunks at the head of the queue then pair up, profiles/r04/ab_tc_grab.txt)
+  if (la->tune[1] <= 0 && use_tct && p.count >= 8ll * (long long)g->cu_count * (long long)(tct_stage <= kStageCap ? 6 : 4)) p.grab = 2;
   // direction rule: X if b*(xb + xs*lg a) <= a*(yb + ys*lg b); tune[2] = xs+1, tune[3] = ys+1, tune[7] = xb*16 + yb
   p.cost_x_step = la->tune[2] > 0 ? la->tune[2] - 1 : 1;
   p.cost_y_step = la->tune[3] > 0 ? la->tune[3] - 1 : 6;
