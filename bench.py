@@ -1029,6 +1029,12 @@ def main():
                                                "note": "gm_motif with tune[6] & 0x10000000: hub rows as hashed sets in LDS, partner lists streamed (gm_hrow.hip)"}
                 except Exception as e:  # a report, never a reason to lose the line
                     sub["per_edge_variant"] = {"error": str(e)}
+            if x["workload"] in ("diamond", "motif3"):
+                # (the default diamond / 3-motif run on structures the FIRST call builds and caches on the caller's symmetric handle --
+                # an oriented copy, its topologically renumbered copy where rows are long, task lists with the tasks' own entries, the key
+                # stream of the short lists, 4 B of support counter per DAG entry for diamond; none of it is inside kernel_ms)
+                sub["first_call_builds"] = ("oriented copy + renumbered copy + task lists / key stream (+ edge supports): setup_ms = orient_ms + relabel_ms + table_ms, "
+                                            "end_to_end_ms = graph resident -> first count; about 36 B of HBM per DAG edge beside the symmetric CSR")
             if x["workload"] == "motif3":
                 # (`value` divides the reference's nnz for motif -- ne_sym directed edges, src/motif/gpu_base.cu:34,47 -- by the step time; the
                 # formula solver itself walks the |E+| = ne_sym / 2 task edges of the oriented graph, like motif_omp_formula's TC pass)

@@ -318,17 +318,36 @@ void tch_kernel(const MineParams p) {
     const unsigned q = B.queue_pos;
     if (q >= (unsigned)p.count) break;
     const unsigned qe = min(q + (unsigned)p.grab, (unsigned)p.count);
-    for (unsigned ci = q; ci < qe; ++ci) {
+    // The NEXT chunk of the dequeue is requested while the current one streams: its record, then (two dependent round trips that used to
+    // sit between two chunks, with every wave of the workgroup waiting) its first kU * nthreads row entries and its offsets.
+    constexpr int kU = 4;  // entries requested together per thread
+    auto chunk_at = [&](const unsigned ci) {
       const size_t pos = (size_t)p.first + (size_t)ci * (size_t)p.step;
-      const size_t cid = p.order ? (size_t)p.order[pos] : pos;
-      const ChunkRec r = p.chunks[cid];
+      return p.chunks[p.order ? (size_t)p.order[pos] : pos];
+    };
+    ChunkRec rn = chunk_at(q);
+    bool have_pre = false;
+    int xn[kU], rpn = 0, trpn = 0;
+    for (unsigned ci = q; ci < qe; ++ci) {
+      const ChunkRec r = rn;
       const int ub = r.u_begin, nvl = r.u_end - r.u_begin;
       const int eb = r.e_begin, nel = r.e_end - r.e_begin;
       // ---- workgroup: the chunk's DAG rows into the set -----------------------------------------------------------------
       unsigned *fill32 = reinterpret_cast<unsigned *>(&B.w[0]);
-      for (int i = tid; i <= nvl; i += nthreads) {
-        B.rpl[i] = rp[ub + i];
-        B.trpl[i] = trp[ub + i];
+      if (have_pre) {  // (requested during the previous chunk; rows beyond 256 threads' reach: below)
+        if (tid <= nvl) {
+          B.rpl[tid] = rpn;
+          B.trpl[tid] = trpn;
+        }
+        for (int i = tid + nthreads; i <= nvl; i += nthreads) {
+          B.rpl[i] = rp[ub + i];
+          B.trpl[i] = trp[ub + i];
+        }
+      } else {
+        for (int i = tid; i <= nvl; i += nthreads) {
+          B.rpl[i] = rp[ub + i];
+          B.trpl[i] = trp[ub + i];
+        }
       }
       {
         const uint4 empty = make_uint4(kTchEmpty, kTchEmpty, kTchEmpty, kTchEmpty);
@@ -346,11 +365,15 @@ void tch_kernel(const MineParams p) {
       }
       __syncthreads();
       unsigned *slots = reinterpret_cast<unsigned *>(B.table);
-      constexpr int kU = 4;  // entries requested together per thread
       for (int i0 = tid; i0 < nel; i0 += kU * nthreads) {
         int x[kU];
+        if (have_pre && i0 == tid) {
 #pragma unroll
-        for (int j = 0; j < kU; ++j) x[j] = col[eb + min(i0 + j * nthreads, nel - 1)];
+          for (int j = 0; j < kU; ++j) x[j] = xn[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < kU; ++j) x[j] = col[eb + min(i0 + j * nthreads, nel - 1)];
+        }
 #pragma unroll
         for (int j = 0; j < kU; ++j) {
           const int i = i0 + j * nthreads;
@@ -388,6 +411,15 @@ void tch_kernel(const MineParams p) {
       }
       __syncthreads();  // (also: the fill counters are dead, the waves may use their scratch)
       const bool fallback = B.n_ovf > kTchOvfCap || (p.flags & (1 << 22)) != 0;
+      have_pre = ci + 1 < qe;  // (workgroup-uniform)
+      if (have_pre) {
+        rn = chunk_at(ci + 1);
+        const int nel_n = rn.e_end - rn.e_begin, nvl_n = rn.u_end - rn.u_begin;
+#pragma unroll
+        for (int j = 0; j < kU; ++j) xn[j] = col[rn.e_begin + min(tid + j * nthreads, max(nel_n - 1, 0))];
+        rpn = rp[rn.u_begin + min(tid, nvl_n)];
+        trpn = trp[rn.u_begin + min(tid, nvl_n)];
+      }
       // ---- waves: the KEY STREAM of the chunk's short lists (GraphView::kst) -- the keys of every list of <= GM_TC_INLINE_MAX entries
       // its vertices host, in task order, each tagged with the low 8 bits of its host: one contiguous range per chunk, one coalesced
       // load per 64 keys, no descriptor, no row search, no flattening (a task of LiveJournal's shape -- nine keys -- cost a random
