@@ -225,6 +225,11 @@ struct gm_graph {
   int *d_kst_rp = nullptr;
   int *d_trpl = nullptr;
   int2 *d_tdescl = nullptr;
+  // the rows beyond the stage of the task-list kernels (> 2048 entries; ensure_long_rows): ids and the prefix of their lengths
+  int *d_long_rows = nullptr;
+  long long *d_long_prefix = nullptr;
+  int n_long_rows = -1;               // -1: not looked for yet
+  long long long_edges = 0;
   unsigned *d_sup = nullptr;  // edge supports: one counter per DAG entry (gm_sup.hip)
   std::vector<int> h_rp;  // host copy of the offsets, fetched on first use (host_rp): download, k-clique tables, SgL renumbering
   std::list<ChunkTable> tables;  // list: handed-out pointers stay valid
@@ -355,6 +360,7 @@ int convert_offsets(const int64_t *rp64, int nv, long long ne, std::vector<int> 
 int get_relabeled(gm_graph *g, int mode, gm_graph **out);  // gm_graph.hip: cached renumbered copy (0 / 1 by degree, 2 topological)
 int graph_is_topological(gm_graph *g, bool *out);
 int graph_rows_sorted(gm_graph *g, bool *out);
+int ensure_long_rows(gm_graph *g);  // (gm_tables.hip) d_long_rows / d_long_prefix: the rows of more than kTctStageMax entries
 int ensure_core_bitmap(gm_graph *g);  // (gm_tables.hip) d_core / core_h / core_base of a topologically numbered DAG; GM_OK also when not applicable
 void free_tables(gm_graph *g);                                   // gm_tables.hip
 int get_table(gm_graph *g, int target, bool allow_split, int bit_words, unsigned long long part_cap, int stage_cap, ChunkTable **out,

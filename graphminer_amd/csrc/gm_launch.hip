@@ -214,7 +214,11 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
   // R-MAT-20 6.4 vs 5.7, power law 4.07 vs 4.10, R-MAT-24 458 vs 172). A graph without such rows skips their (empty) tables.
   // tune[6] & 0x100000 forces them on.
   if (use_classes && !(la->tune[6] & 0x100000)) use_classes = g->max_deg > kClassRowMin;
-  if (support && (!use_tct || tct_long || (world > 1 && !sup_part))) return GM_ERR_UNSUPPORTED;  // (the caller takes the per-edge kernels)
+  if (support && (!use_tct || (world > 1 && !sup_part))) return GM_ERR_UNSUPPORTED;  // (the caller takes the per-edge kernels)
+  if (support && tct_long) {  // the out-edges of the rows beyond the stage: sup_long_kernel, below
+    const int rc_l = ensure_long_rows(g);
+    if (rc_l) return rc_l;
+  }
   if (use_tct) {
     int rc_t = ensure_tasklists(g, support);
     if (rc_t) return rc_t;
@@ -239,7 +243,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
   int rc = get_table(g, target, !clique, clique ? kBitWords : 0, part_cap, use_tct ? tct_stage : stage_cap_of(pat), &tab, rf, use_classes ? kStageCapBig : kBitmapMinDeg);
   if (rc) return rc;
   ChunkTable *tab_long = nullptr;
-  if (tct_long) {
+  if (tct_long && !support) {
     RowFilter rl;
     rl.only_lo = kTctStageMax;
     rc = get_table(g, target, true, 0, kPartCostCap, kStageCap, &tab_long, rl, kBitmapMinDeg);
@@ -680,6 +684,22 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
     HIP_TRY(hipMemsetAsync(sup, 0, sizeof(unsigned) * (size_t)(sup_part ? diamond_support_entries(g->ne, world) : g->ne), stream));
     p.scratch = sup;
     if (p.count > 0) HIP_TRY(launch_sup(p, tct_stage, (int)std::max<long long>(1, std::min<long long>(want, (long long)g->cu_count * sup_per_cu(tct_stage))), stream));
+    if (tct_long && g->n_long_rows > 0) {
+      SupLongParams sl;
+      memset(&sl, 0, sizeof sl);
+      sl.rp = g->d_rp;
+      sl.col = g->d_col;
+      sl.rows = g->d_long_rows;
+      sl.prefix = g->d_long_prefix;
+      sl.nrows = g->n_long_rows;
+      sl.total = g->long_edges;
+      sl.sup = sup;
+      sl.topo = (g->topo_state == 1 && !getenv("GM_TC_NO_TRIM")) ? 1 : 0;
+      sl.rank = rank;
+      sl.world = world;
+      HIP_TRY(launch_sup_long(sl, g->cu_count, stream));
+      my_edges += (unsigned long long)((g->long_edges - rank + world - 1) / world);
+    }
     if (!sup_part) HIP_TRY(launch_sup_pairs(sup, 0, g->ne, g->d_counters, g->cu_count, stream));
   } else if (p.count > 0 && use_tch) HIP_TRY(launch_tch(p, tct_stage, (int)std::max<long long>(1, std::min<long long>(want, (long long)g->cu_count * tch_per_cu(tct_stage))), stream));
   else if (p.count > 0 && use_tct) HIP_TRY(launch_tct(p, tct_stage, (int)std::max<long long>(1, std::min<long long>(want, (long long)g->cu_count * tct_per_cu(tct_stage))), stream));
@@ -1237,7 +1257,6 @@ static int run_diamond_supports(const gm_graph *sym, const gm_launch *la, uint64
     if (rc_dag) return rc_dag;
   }
   gm_graph *dag = g->dag_cache, *run_on = nullptr;
-  if (dag->max_deg > kTctStageMax) return GM_ERR_UNSUPPORTED;
   int rc = topo_view(dag, la, &run_on);
   if (rc) return rc;
   rc = run_pattern(PAT_SUPPORT, run_on, la, 3, total, 1, st);
@@ -1261,8 +1280,7 @@ static int diamond_run_on(const gm_graph *sym, const gm_launch *la, gm_graph **r
     if (rc_dag) return rc_dag;
   }
   gm_graph *dag = g->dag_cache;
-  if (dag->max_deg > kTctStageMax) return GM_ERR_UNSUPPORTED;  // (rows beyond the stage: the per-edge kernels, gm_sgl)
-  return topo_view(dag, la, run_on);
+  return topo_view(dag, la, run_on);  // (rows beyond the 2048-entry stage: their out-edges through sup_long_kernel)
 }
 extern "C" int gm_diamond_support_size(const gm_graph *sym, int world, int64_t *n_entries) {
   if (!sym || !n_entries || world < 1) return GM_ERR_INVALID;

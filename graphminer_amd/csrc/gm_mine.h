@@ -425,6 +425,17 @@ int tch_per_cu(int stage);
 // triangle pass with three increments per match (gm_sup.hip); then sum C(t, 2) over a range of entries
 hipError_t launch_sup(const MineParams &p, int stage, int grid_blocks, hipStream_t stream);
 int sup_per_cu(int stage);
+// edge supports of the out-edges of the rows beyond the stage (gm_sup.hip sup_long_kernel)
+struct SupLongParams {
+  const int *rp, *col;
+  const int *rows;            // the rows beyond the stage
+  const long long *prefix;    // prefix[r] = task edges of the rows before r (nrows + 1)
+  int nrows;
+  long long total;
+  unsigned *sup;
+  int topo, rank, world;
+};
+hipError_t launch_sup_long(const SupLongParams &p, int cu_count, hipStream_t stream);
 hipError_t launch_sup_pairs(const unsigned *sup, long long first, long long count, unsigned long long *out, int cu_count, hipStream_t stream);
 size_t mine_lds_bytes(Pattern pat);
 // the big-LDS classes (gm_mine_wide.hip): cls = 1 (mid rows) or 2 (big rows); DIAMOND, MOTIF3, MOTIF4E only

@@ -155,6 +155,49 @@ __global__ __launch_bounds__(256) void sup_pairs_kernel(const unsigned *__restri
   if ((threadIdx.x & (GM_WAVE - 1)) == 0 && s) atomicAdd(out, s);
 }
 
+// The out-edges of the FEW rows beyond the 2048-entry stage (no hashed set holds such a row; the triangle count sends them to the chunked
+// kernel): one wave per task edge u -> v, the shorter of N+(u) -- beyond v under a topological numbering -- and N+(v) streamed by the lanes,
+// the longer one bisected in global memory, the same three increments per match.  Slow per key, exact, a handful of rows per graph
+// (R-MAT-26: a few dozen).  Several ranks take every world-th edge.
+__global__ __launch_bounds__(256) void sup_long_kernel(const SupLongParams p) {
+  const int lane = threadIdx.x & (GM_WAVE - 1);
+  const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+  for (long long t = (long long)p.rank + wave0 * (long long)p.world; t < p.total; t += nwaves * (long long)p.world) {
+    int lo = 0, hi = p.nrows - 1;  // the long row of edge t: largest r with prefix[r] <= t (wave-uniform)
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (p.prefix[mid] <= t) lo = mid; else hi = mid - 1;
+    }
+    const int u = p.rows[lo], i = (int)(t - p.prefix[lo]);
+    const int ru = p.rp[u], du = p.rp[u + 1] - ru, e = ru + i, v = p.col[e];
+    const int rv = p.rp[v], dv = p.rp[v + 1] - rv;
+    const int skip = p.topo ? i + 1 : 0;
+    const int abase = ru + skip, a = du - skip;
+    // stream the shorter list, bisect the longer
+    const bool a_short = a <= dv;
+    const int sbase = a_short ? abase : rv, sn = a_short ? a : dv, lbase = a_short ? rv : abase, ln = a_short ? dv : a;
+    unsigned cnt = 0;
+    for (int k = lane; k < sn; k += GM_WAVE) {
+      const int key = p.col[sbase + k];
+      const int pos = lower_bound(p.col + lbase, ln, key);
+      if (pos < ln && p.col[lbase + pos] == key) {
+        atomicAdd(&p.sup[sbase + k], 1u);
+        atomicAdd(&p.sup[lbase + pos], 1u);
+        ++cnt;
+      }
+    }
+    const int total = wave_sum((int)cnt);
+    if (lane == 0 && total) atomicAdd(&p.sup[e], (unsigned)total);
+  }
+}
+hipError_t launch_sup_long(const SupLongParams &p, int cu_count, hipStream_t stream) {
+  if (p.total <= 0 || p.nrows <= 0) return hipSuccess;
+  const long long waves = (p.total + p.world - 1) / p.world;
+  const long long blocks = std::min<long long>((waves + 3) / 4, (long long)cu_count * 8);
+  hipLaunchKernelGGL(sup_long_kernel, dim3((unsigned)std::max<long long>(1, blocks)), dim3(256), 0, stream, p);
+  return hipGetLastError();
+}
+
 int sup_per_cu(int stage) { return stage <= 1024 ? 4 : 2; }
 hipError_t launch_sup(const MineParams &p, int stage, int grid_blocks, hipStream_t stream) {
   static_assert(sizeof(SupLds<1024>) * 4 <= 163840, "four workgroups per CU");

@@ -910,6 +910,35 @@ int ensure_tasklists(gm_graph *g, bool /*with_edges*/) {
   return GM_OK;
 }
 
+// the rows beyond the stage of the task-list kernels: a handful per graph, found on the host copy of the offsets
+int ensure_long_rows(gm_graph *g) {
+  if (g->n_long_rows >= 0) return GM_OK;
+  const std::vector<int> *rp = nullptr;
+  int rc = host_rp(g, &rp);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lk(g->mu);
+  if (g->n_long_rows >= 0) return GM_OK;
+  std::vector<int> rows;
+  std::vector<long long> prefix(1, 0);
+  for (int v = 0; v < g->nv; ++v) {
+    const int d = (*rp)[(size_t)v + 1] - (*rp)[(size_t)v];
+    if (d > kTctStageMax) {
+      rows.push_back(v);
+      prefix.push_back(prefix.back() + d);
+    }
+  }
+  if (!rows.empty()) {
+    HIP_TRY(hipSetDevice(g->device));
+    HIP_TRY(hipMalloc(&g->d_long_rows, sizeof(int) * rows.size()));
+    HIP_TRY(hipMalloc(&g->d_long_prefix, sizeof(long long) * prefix.size()));
+    HIP_TRY(hipMemcpy(g->d_long_rows, rows.data(), sizeof(int) * rows.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(g->d_long_prefix, prefix.data(), sizeof(long long) * prefix.size(), hipMemcpyHostToDevice));
+  }
+  g->long_edges = prefix.back();
+  g->n_long_rows = (int)rows.size();
+  return GM_OK;
+}
+
 int ensure_edesc(gm_graph *g) {
   if (g->d_edesc || g->ne == 0) return GM_OK;
   std::lock_guard<std::mutex> lk(g->mu);

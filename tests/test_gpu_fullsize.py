@@ -145,8 +145,20 @@ def test_graph_of_more_than_2e31_entries():
     deg = rp[1:] - rp[:-1]
     c2 = int((deg * (deg - 1) // 2).sum().item())
     assert tri == tc and wedges == c2 - 3 * tc
-    with pytest.raises(_lib.GraphMinerError) as ei:
-        SglSolver(sym, "diamond")
+    # diamond on the big handle: through the edge supports of the oriented copy -- rows beyond the 2048-entry stage
+    # included (sup_long_kernel) -- checked by the identities  sum_e t_e = 3 T  and  diamond = sum_e C(t_e, 2)  on the support array itself
+    from graphminer_amd.solvers import diamond_support_partial, diamond_support_size
+
+    n = diamond_support_size(sym, 1)
+    sup = torch.empty(n, dtype=torch.int32, device="cuda:0")
+    diamond_support_partial(sym, sup.data_ptr(), n)
+    t64 = sup.to(torch.int64)
+    assert int(t64.sum()) == 3 * tc
+    diamonds = SglSolver(sym, "diamond")
+    assert diamonds == int((t64 * (t64 - 1) // 2).sum()) > 0
+    del sup, t64
+    with pytest.raises(_lib.GraphMinerError) as ei:  # (what still needs 32-bit entry indices of the symmetric graph itself)
+        SglSolver(sym, "rectangle")
     assert ei.value.status == _lib.GM_ERR_TOO_LARGE
     print(f"R-MAT-26 ef 20: {sym.E()} entries, DAG {dag.E()}, {tc} triangles, orient + TC + 3-clique + 3-motif in {time.perf_counter() - t:.1f} s")
     dag.free()

@@ -923,3 +923,33 @@ def test_diamond_supports_of_rank_shares_add_up(gg, world, dev):
     parts = [diamond_support_finish(s, total[r * per:(r + 1) * per].contiguous().data_ptr(), per) for r in range(world)]
     assert sum(parts) == want, (world, parts)
     assert SglSolver(s, "diamond") == want
+
+
+def test_diamond_supports_with_rows_beyond_the_stage(dev):
+    """a DAG row of more than 2048 entries fits no hashed set: the triangle count sends its out-edges to the chunked kernel, and until
+    round 4 the edge supports gave up (gm_sgl fell back to one intersection per edge; a handle of >= 2^31 entries got GM_ERR_TOO_LARGE).
+    sup_long_kernel takes those edges now -- one wave per edge, bisection in global memory: diamond from the supports against the per-edge
+    kernels, the oracle, and rank shares through gm_diamond_support_partial / _finish."""
+    import torch
+
+    from graphminer_amd.solvers import diamond_support_finish, diamond_support_partial, diamond_support_size
+
+    g = _dense_random_graph(2300, 0.95, 23)
+    osym = O.OGraph(g.row_ptr, g.col_idx)
+    odag = O.orient(osym)
+    assert int(np.diff(odag.row_ptr).max()) > 2048
+    want = O.diamond(osym)
+    with g.to_device(dev) as s:
+        assert SglSolver(s, "diamond", tune=[0, 0, 0, 0, 0, 0, 0x10000000]) == want  # one intersection per edge
+        assert SglSolver(s, "diamond") == want                                        # edge supports, long rows included
+        assert SglSolver(s, "diamond", tune=[0, 0, 0, 0, 0, 0, 0x200]) == want        # ... on the oriented copy as numbered
+        world = 3
+        n = diamond_support_size(s, world)
+        bufs = [torch.empty(n, dtype=torch.int32, device=f"cuda:{dev}") for _ in range(world)]
+        for r in range(world):
+            diamond_support_partial(s, bufs[r].data_ptr(), n, rank=r, world=world)
+        total = torch.stack(bufs).sum(0, dtype=torch.int64)
+        assert int(total.sum()) == 3 * O.tc(odag)
+        tt = total.to(torch.int32)
+        per = n // world
+        assert sum(diamond_support_finish(s, tt[r * per:(r + 1) * per].contiguous().data_ptr(), per) for r in range(world)) == want
