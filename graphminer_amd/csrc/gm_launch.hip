@@ -374,7 +374,9 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
   // the task-list kernels take TWO chunks per dequeue where a resident workgroup has many to take (one device atomic + one workgroup
   // barrier less per chunk: flat LJ-size TC 0.605 -> 0.427 ms, power law 0.77 -> 0.71, R-MAT-22 2.57 -> 2.48; four: 0.423 / 0.71 / 3.37 --
   // the heavy chunks at the head of the queue then pair up, profiles/r04/ab_tc_grab.txt)
-  if (la->tune[1] <= 0 && use_tct && p.count >= 8ll * (long long)g->cu_count * (long long)(tct_stage <= kStageCap ? 6 : 4)) p.grab = 2;
+  // (not the edge supports: their launch time is the atomics', and a rank's share loses -- diamond R-MAT-22 at 2 / 4 ranks 6.06 / 4.79 ms with two
+  // chunks per dequeue against 4.44 / 3.13 with one)
+  if (la->tune[1] <= 0 && use_tct && !support && p.count >= 8ll * (long long)g->cu_count * (long long)(tct_stage <= kStageCap ? 6 : 4)) p.grab = 2;
   // direction rule: X if b*(xb + xs*lg a) <= a*(yb + ys*lg b); tune[2] = xs+1, tune[3] = ys+1, tune[7] = xb*16 + yb
   p.cost_x_step = la->tune[2] > 0 ? la->tune[2] - 1 : 1;
   p.cost_y_step = la->tune[3] > 0 ? la->tune[3] - 1 : 6;
