@@ -231,7 +231,8 @@ def own_bytes_device(workload, bg, world=1):
                per triangle for the streamed edge; T = triangles, from the library's own count)
                several ranks (one intersection per edge): 4*sum_{undirected e} min(d(u), d(v)) + 12*ne + 8(nv+1)
       motif3   the tc figure (gm_motif k = 3 counts the triangles of the DAG; wedges = sum C(d,2) - 3T)
-      motif3e  (per-edge enumeration) diamond's several-ranks figure with the streamed list trimmed to its keys < max(u, v) when it has >= 128 keys
+      motif3e  (per-edge enumeration) diamond's several-ranks figure on the copy numbered by DESCENDING degree, the streamed list trimmed to its
+               keys < max(u, v) -- its neighbours of higher degree -- when it has >= 128 keys
       clique4  4*K + 16*tasks + 4|E+| + 16(nv+1) + 8*arena words + 4*gathered words   (rows of the WIDE vertices -- d+ > 256 -- whose first
                endpoint lies in the hub core are gathered from the dense core bitmap: the distinct words that hold the probed bits; every other edge
                of an owner is a streamed task, K as for tc with the stage limit 2048; rows with d+ < 3 own no matrix)
@@ -325,6 +326,19 @@ def own_bytes_device(workload, bg, world=1):
                     "parts": dict(tcp["parts"], own_entry_per_task_x4=4 * nd, supports_zeroed_read_added_x16=16 * nd, streamed_edge_atomics_x4=4 * tri)}
     if workload in ("diamond", "motif3e"):
         ne = int(ci.numel())
+        if workload == "motif3e":
+            # the enumeration runs on the library's copy numbered by DESCENDING degree (gm_motif, gm_graph.hip get_relabeled mode 1: new id =
+            # nv - 1 - rank in ascending (degree, id)): "below max(u, v)" then means "of higher degree", and the trimmed lists are short
+            rank_ = torch.empty(nv, dtype=torch.long, device=rp.device)
+            rank_[torch.argsort(deg * (1 << 32) + torch.arange(nv, device=rp.device))] = torch.arange(nv, device=rp.device)
+            newid = nv - 1 - rank_
+            src, dst = newid[src], newid[dst]
+            deg = torch.bincount(src, minlength=nv)  # degrees by new id
+            rp = torch.cat([torch.zeros(1, dtype=deg.dtype, device=deg.device), torch.cumsum(deg, 0)])
+            order_ = torch.argsort(src * (1 << 32) + dst)
+            src, dst = src[order_], dst[order_]
+            ci = dst
+            del rank_, newid, order_
         und = dst < src  # every undirected edge once
         u, v = src[und], dst[und]
         del src, dst, und

@@ -1517,7 +1517,20 @@ extern "C" int gm_motif(const gm_graph *sym, int k, const gm_launch *la, uint64_
     if (rc == GM_OK && st) st->tasks *= 2;  // (the graph's directed entries, as the enumeration reports them: two per task edge of the DAG)
     return rc;
   }
-  return run_pattern(PAT_MOTIF3, sym, la, 3, counts, ncounts, st);
+  // The enumeration's two totals do not depend on the vertex numbering, its WORK does: for an edge {lo < hi} only the common neighbours
+  // below hi count, and the kernels trim the streamed list to them.  Numbered by DESCENDING degree (the cached copy the SgL wedge forms use),
+  // "below hi" = "of higher degree than hi": the trimmed list is what an oriented row would be -- sum_v d+(v)^2 streamed keys instead of
+  // sum_e min(d(u), d(v)) over the symmetric lists (R-MAT-24: 150 G).  GM_MOTIF3E_AS_NUMBERED / tune[6] & 512: on the graph as given.
+  const gm_graph *run_on = sym;
+  if (!(t6 & 512) && !getenv("GM_MOTIF3E_AS_NUMBERED")) {
+    gm_graph *r = nullptr;
+    const int rc = get_relabeled(const_cast<gm_graph *>(sym), 1, &r);
+    if (rc) return rc;
+    run_on = r;
+  }
+  const int rc = run_pattern(PAT_MOTIF3, run_on, la, 3, counts, ncounts, st);
+  if (run_on != sym) const_cast<gm_graph *>(sym)->ring_alias = run_on;
+  return rc;
 }
 
 // motif_omp_formula / motif_gpu_formula (src/motif/omp_formula.cc:39-46, cpu_kernels/automine_formula.h:2-19):

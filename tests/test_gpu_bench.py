@@ -168,6 +168,10 @@ def test_own_algorithm_bytes_equal_a_brute_force_count():
     nv, deg = hrp.size - 1, np.diff(hrp)
     # symmetric-graph patterns
     kd = km = 0
+    trim_min = bench.kernel_constants()["motif_trim_min_list"]
+    rk = np.empty(nv, dtype=np.int64)  # the enumeration runs on the copy numbered by DESCENDING degree: new id = nv - 1 - rank in (degree, id)
+    rk[np.lexsort((np.arange(nv), deg))] = np.arange(nv)
+    new = nv - 1 - rk
     for u in range(nv):
         for v in hci[hrp[u]:hrp[u + 1]]:
             if v >= u:
@@ -176,8 +180,11 @@ def test_own_algorithm_bytes_equal_a_brute_force_count():
             u_longer = a > b or (a == b and u > v)
             s, n = (v, b) if u_longer else (u, a)
             kd += n
-            row = hci[hrp[s]:hrp[s + 1]]
-            km += int(np.searchsorted(row, max(u, v))) if n >= bench.kernel_constants()["motif_trim_min_list"] else n
+            # (same edge under the new numbering: the longer row hosts -- ties: the larger NEW id -- and the streamed list keeps its keys below max)
+            nu, nw = new[u], new[v]
+            m_longer = a > b or (a == b and nu > nw)
+            ms, mn = (v, b) if m_longer else (u, a)
+            km += int((new[hci[hrp[ms]:hrp[ms + 1]]] < max(nu, nw)).sum()) if mn >= trim_min else mn
     ne = hci.size
     assert bench.own_bytes_device("diamond", bg, 2)["bytes"] == 4 * kd + 12 * ne + 8 * (nv + 1)  # (several ranks: one intersection per edge)
     assert bench.own_bytes_device("motif3e", bg)["bytes"] == 4 * km + 12 * ne + 8 * (nv + 1) and km < kd  # (the enumeration kernels)
