@@ -192,7 +192,12 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
   // parts of 1 M keys / world (>= 128 K): one-GPU simulation of an 8-rank share of R-MAT-22, parts of 8 M / 512 K / 128 K / 32 K keys:
   // 5.36 / 1.18 / 0.99 / 1.15 ms per rank (one GPU: 6.50 / 6.54 / 6.73 / 8.09 ms), profiles/r02/ab_tct_part_cap.log
   const bool use_tct = pat == PAT_TC && !(la->tune[6] & 0x4000000) && la->tune[5] != 1 && g->ne > 0 && !getenv("GM_HOST_TABLES");
-  const int tct_stage = (g->max_deg <= kStageCap && !getenv("GM_TCT_STAGE_BIG")) ? kStageCap : kTctStageMax;  // (GM_TCT_STAGE_BIG: A/B, the 2048-entry stage everywhere)
+  // The 2048-entry stage costs occupancy (four instead of six workgroups per CU, R-MAT-22 on it: 3.04 vs 2.57 ms), and only the few hosts with
+  // rows of 1025 .. 2048 entries need it: a graph that has such rows runs TWO tables -- hosts with rows <= 1024 on the 1024-entry kernel,
+  // the others on the 2048-entry one (own dequeue word).  GM_TCT_STAGE_BIG: the 2048-entry stage for every host (A/B).
+  const bool stage_big_all = getenv("GM_TCT_STAGE_BIG") != nullptr;
+  const bool split_stage = use_tct && g->max_deg > kStageCap && !stage_big_all && !getenv("GM_TCT_NO_SPLIT_STAGE");
+  const int tct_stage = ((g->max_deg <= kStageCap && !stage_big_all) || split_stage) ? kStageCap : kTctStageMax;
   // (rows beyond the 2048-entry stage host nothing: their out-edges are the tasks of the chunked kernel, on a table of those rows only)
   const bool tct_long = use_tct && g->max_deg > kTctStageMax;
   const unsigned long long tct_part = use_tct ? task_part_cap(g, world) : 0ull;
@@ -227,6 +232,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
   RowFilter rf;
   rf.tct = use_tct ? 1 : 0;
   if (tct_long) { rf.skip_lo = kTctStageMax; rf.skip_hi = 0x7fffffff; }
+  if (split_stage) { rf.skip_lo = kStageCap; rf.skip_hi = 0x7fffffff; }  // (this table: the hosts whose rows fit the 1024-entry stage)
   // 4-clique: the first level is re-hosted (gm_cbuild.hip) for every vertex whose row fits its stage -- the narrow chunk table and
   // the wide list live in the CliquePlan; what is left for THIS table are the rows beyond kCbMaxDeg (mine_kernel's arena path)
   if (use_wide) rf.only_lo = kCbMaxDeg;
@@ -242,6 +248,15 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
   if (use_classes) { rf.skip_lo = cls_lo; rf.skip_hi = use_range ? 0x7fffffff : kStageCapBig; }
   int rc = get_table(g, target, !clique, clique ? kBitWords : 0, part_cap, use_tct ? tct_stage : stage_cap_of(pat), &tab, rf, use_classes ? kStageCapBig : kBitmapMinDeg);
   if (rc) return rc;
+  ChunkTable *tab_big = nullptr;  // the hosts with rows of 1025 .. 2048 entries, on the 2048-entry kernel
+  if (split_stage) {
+    RowFilter rb;
+    rb.tct = 1;
+    rb.only_lo = kStageCap;
+    rb.only_hi = kTctStageMax;
+    rc = get_table(g, target, true, 0, part_cap, kTctStageMax, &tab_big, rb, kBitmapMinDeg);
+    if (rc) return rc;
+  }
   ChunkTable *tab_long = nullptr;
   if (tct_long && !support) {
     RowFilter rl;
@@ -685,6 +700,14 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
     unsigned *sup = sup_part ? sup_out : g->d_sup;
     HIP_TRY(hipMemsetAsync(sup, 0, sizeof(unsigned) * (size_t)(sup_part ? diamond_support_entries(g->ne, world) : g->ne), stream));
     p.scratch = sup;
+    if (tab_big) {  // the hosts with rows of 1025 .. 2048 entries first (the heaviest tasks), on the 2048-entry kernel
+      MineParams q = p;
+      take_share(tab_big, q);
+      q.grab = 1;
+      q.queue = reinterpret_cast<unsigned *>(g->d_counters + 4) + 2;
+      chunks_total += (uint64_t)q.count;
+      if (q.count > 0) HIP_TRY(launch_sup(q, kTctStageMax, (int)std::max<long long>(1, std::min<long long>(q.count, (long long)g->cu_count * sup_per_cu(kTctStageMax))), stream));
+    }
     if (p.count > 0) HIP_TRY(launch_sup(p, tct_stage, (int)std::max<long long>(1, std::min<long long>(want, (long long)g->cu_count * sup_per_cu(tct_stage))), stream));
     if (tct_long && g->n_long_rows > 0) {
       SupLongParams sl;
@@ -703,9 +726,19 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
       my_edges += (unsigned long long)((g->long_edges - rank + world - 1) / world);
     }
     if (!sup_part) HIP_TRY(launch_sup_pairs(sup, 0, g->ne, g->d_counters, g->cu_count, stream));
-  } else if (p.count > 0 && use_tch) HIP_TRY(launch_tch(p, tct_stage, (int)std::max<long long>(1, std::min<long long>(want, (long long)g->cu_count * tch_per_cu(tct_stage))), stream));
-  else if (p.count > 0 && use_tct) HIP_TRY(launch_tct(p, tct_stage, (int)std::max<long long>(1, std::min<long long>(want, (long long)g->cu_count * tct_per_cu(tct_stage))), stream));
-  else if (p.count > 0) HIP_TRY(launch_mine(pat, p, grid, stream));
+  } else if (use_tct) {
+    if (tab_big) {  // the hosts with rows of 1025 .. 2048 entries first (the heaviest tasks), on the 2048-entry kernel
+      MineParams q = p;
+      take_share(tab_big, q);
+      q.grab = 1;
+      q.queue = reinterpret_cast<unsigned *>(g->d_counters + 4) + 2;
+      chunks_total += (uint64_t)q.count;
+      if (q.count > 0 && use_tch) HIP_TRY(launch_tch(q, kTctStageMax, (int)std::max<long long>(1, std::min<long long>(q.count, (long long)g->cu_count * tch_per_cu(kTctStageMax))), stream));
+      else if (q.count > 0) HIP_TRY(launch_tct(q, kTctStageMax, (int)std::max<long long>(1, std::min<long long>(q.count, (long long)g->cu_count * tct_per_cu(kTctStageMax))), stream));
+    }
+    if (p.count > 0 && use_tch) HIP_TRY(launch_tch(p, tct_stage, (int)std::max<long long>(1, std::min<long long>(want, (long long)g->cu_count * tch_per_cu(tct_stage))), stream));
+    else if (p.count > 0) HIP_TRY(launch_tct(p, tct_stage, (int)std::max<long long>(1, std::min<long long>(want, (long long)g->cu_count * tct_per_cu(tct_stage))), stream));
+  } else if (p.count > 0) HIP_TRY(launch_mine(pat, p, grid, stream));
 #ifdef GM_DEBUG_CHUNKS
   {
     HIP_TRY(hipStreamSynchronize(stream));
