@@ -87,6 +87,7 @@ extern "C" void gm_graph_free(gm_graph *g) {
   if (g->d_long_prefix) (void)hipFree(g->d_long_prefix);
   if (g->d_colk) (void)hipFree(g->d_colk);
   if (g->d_tdesck) (void)hipFree(g->d_tdesck);
+  if (g->d_kst) (void)hipFree(g->d_kst);
   if (g->d_kst_rp) (void)hipFree(g->d_kst_rp);
   if (g->d_trpl) (void)hipFree(g->d_trpl);
   if (g->d_tdescl) (void)hipFree(g->d_tdescl);
@@ -317,7 +318,7 @@ extern "C" int gm_graph_sort_neighbors(gm_graph *g) {
   if (g->d_rp64) { g_last_error = "gm_graph_sort_neighbors: not for graphs of 2^31 entries or more (the segmented sort counts items in 32 bits)"; return GM_ERR_TOO_LARGE; }
   // before any solver ran: every cached structure describes the rows as they are now (tables, descriptors, task lists, derived
   // handles, the per-pattern tables of the SgL / 4-motif paths, hub bitmaps, the sum of C(d,2))
-  if (!g->tables.empty() || g->d_edesc || g->d_trp || g->d_tdesc || g->dag_cache || g->relabel_cache[0] || g->relabel_cache[1] || g->d_idx0 ||
+  if (!g->tables.empty() || g->d_edesc || g->d_trp || g->d_tdesc || g->d_kst_rp || g->dag_cache || g->relabel_cache[0] || g->relabel_cache[1] || g->d_idx0 ||
       g->d_wblock_prefix || g->d_rect_tasks || g->d_house_t || g->d_house_tlt || g->d_house_tasks || g->d_house_prefix || !g->bitmap_sets.empty() ||
       g->wide_valid || g->sum_c2_valid)
     return GM_ERR_INVALID;
@@ -516,6 +517,7 @@ static int orient_impl(const gm_graph *sym, const OffT *rp_in, gm_graph **out) {
   HIP_TRY(hipSetDevice(sym->device));
   SetupTimer timer;
   PoolScope pool(const_cast<gm_graph *>(sym));
+  setup_trace("orient: begin");
   const int nv = sym->nv;
   const unsigned vb = (unsigned)((nv + 256) / 256);  // blocks covering v = 0 .. nv
   ScanTemp tmp;
@@ -539,6 +541,7 @@ static int orient_impl(const gm_graph *sym, const OffT *rp_in, gm_graph **out) {
   hipLaunchKernelGGL((orient_short_kernel<OffT>), dim3(bs), dim3(256), 0, 0, nv, rp_in, sym->d_col, deg.p, (const int *)nullptr, (int *)nullptr, 0);
   if (nseg)
     hipLaunchKernelGGL((orient_seg_kernel<OffT>), dim3(bl), dim3(256), 0, 0, nseg, segs.p, rp_in, sym->d_col, segcnt.p, deg.p, (int *)nullptr, 0);
+  setup_trace("orient: segments + degrees");
   // new offsets = exclusive scan of the new degrees (parallel_prefix_sum, include/scan.h:5-35)
   gm_graph *g = new gm_graph();
   g->device = sym->device;
@@ -571,18 +574,21 @@ static int orient_impl(const gm_graph *sym, const OffT *rp_in, gm_graph **out) {
   g->ne = ne_new;
   g->max_deg = max_deg;
   if ((e = hipMalloc(&g->d_col, sizeof(int) * (size_t)std::max(ne_new, 1))) != hipSuccess) return fail(hip_fail(e, "hipMalloc", __FILE__, __LINE__));
+  setup_trace("orient: scan, max degree, allocations");
   // pass 1: compact
   if (nseg) hipLaunchKernelGGL((orient_segout_kernel<OffT>), dim3(vb), dim3(256), 0, 0, nv, rp_in, seg_first.p, segcnt.p, g->d_rp, segs.p);
   hipLaunchKernelGGL((orient_short_kernel<OffT>), dim3(bs), dim3(256), 0, 0, nv, rp_in, sym->d_col, (int *)nullptr, g->d_rp, g->d_col, 1);
   if (nseg)
     hipLaunchKernelGGL((orient_seg_kernel<OffT>), dim3(bl), dim3(256), 0, 0, nseg, segs.p, rp_in, sym->d_col, (int *)nullptr, (int *)nullptr, g->d_col, 1);
   if ((e = hipGetLastError()) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess) return fail(hip_fail(e, "orient kernels", __FILE__, __LINE__));
+  setup_trace("orient: compact");
   int rc = finish_handle(g);
   if (rc) { gm_graph_free(g); return rc; }
   // (the symmetric degrees: what the topological renumbering of this DAG sorts by -- get_relabeled mode 2)
   if ((e = hipMalloc(&g->d_symdeg, sizeof(int) * (size_t)std::max(nv, 1))) != hipSuccess) return fail(hip_fail(e, "hipMalloc", __FILE__, __LINE__));
   if (nv > 0) hipLaunchKernelGGL((symdeg_kernel<OffT>), dim3(vb), dim3(256), 0, 0, nv, rp_in, g->d_symdeg);
   if ((e = hipGetLastError()) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess) return fail(hip_fail(e, "symdeg_kernel", __FILE__, __LINE__));
+  setup_trace("orient: finish_handle + degrees");
   g->setup.orient_ms = timer.ms();
   *out = g;
   return GM_OK;
@@ -641,9 +647,15 @@ __global__ __launch_bounds__(256) void relabel_keys_kernel(int nv, long long ne,
   keys[e] = ((unsigned long long)(unsigned)newid[lo] << 32) | (unsigned long long)(unsigned)newid[col[e]];
 }
 
-__global__ __launch_bounds__(256) void relabel_cols_kernel(long long ne, const unsigned long long *__restrict__ keys, int *__restrict__ col) {
+// (dup: set when two sorted keys are equal -- a duplicate entry of a row.  The rows of the copy are ascending by construction, so this
+// is all that graph_rows_sorted would look for: the copy is marked without the 0.5 ms pass over its entries.)
+__global__ __launch_bounds__(256) void relabel_cols_kernel(long long ne, const unsigned long long *__restrict__ keys, int *__restrict__ col,
+                                                           int *__restrict__ dup) {
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < ne) col[e] = (int)(unsigned)(keys[e] & 0xffffffffull);
+  if (e >= ne) return;
+  const unsigned long long k = keys[e];
+  col[e] = (int)(unsigned)(k & 0xffffffffull);
+  if (e > 0 && keys[e - 1] == k) *dup = 1;
 }
 // Rows strictly ascending?  Every solver relies on it (bisection, trimmed tasks, position = rank); the reference sorts on request
 // (adj_sorted = 0 -> Graph::sort_neighbors, src/common/graph.cc:138).  One pass: a descent col[e - 1] >= col[e] is legitimate only where a
@@ -720,10 +732,14 @@ int get_relabeled(gm_graph *g, int mode, gm_graph **out) {
   const long long ne = g->ne;
   const size_t nv1 = (size_t)nv + 1, n1 = (size_t)std::max<long long>(ne, 1);
   PoolScope pool(g);  // (the sort buffers: two 64-bit keys per entry + hipCUB's own)
+  setup_trace("relabel: begin");
   auto blocks = [](long long n) { return dim3((unsigned)std::max<long long>(1, (n + 255) / 256)); };
   ScanTemp tmp;
   DevBuf<int> indeg, newid, newdeg;
   DevBuf<unsigned long long> vkeys, vsorted, keys, sorted;
+  DevBuf<int> dupflag;
+  HIP_TRY(dupflag.alloc(1));
+  HIP_TRY(hipMemsetAsync(dupflag.p, 0, sizeof(int), 0));
   HIP_TRY(newid.alloc(nv1));
   HIP_TRY(newdeg.alloc(nv1));
   HIP_TRY(vkeys.alloc(nv1));
@@ -744,6 +760,7 @@ int get_relabeled(gm_graph *g, int mode, gm_graph **out) {
     HIP_TRY(hipcub::DeviceRadixSort::SortKeys(tmp.buf.p, bytes, vkeys.p, vsorted.p, nv, 0, 64));
   }
   hipLaunchKernelGGL(relabel_newid_kernel, blocks((long long)nv1), dim3(256), 0, 0, nv, vsorted.p, mode == 1 ? 1 : 0, g->d_rp, newid.p, newdeg.p);
+  setup_trace("relabel: vertex sort");
   gm_graph *r = new gm_graph();
   r->device = g->device;
   r->nv = nv;
@@ -756,16 +773,24 @@ int get_relabeled(gm_graph *g, int mode, gm_graph **out) {
   if (ne > 0) {
     if ((e = keys.alloc(n1)) != hipSuccess || (e = sorted.alloc(n1)) != hipSuccess) return fail(e, "hipMalloc(keys)");
     hipLaunchKernelGGL(relabel_keys_kernel, blocks(ne), dim3(256), 0, 0, nv, ne, g->d_rp, g->d_col, newid.p, keys.p);
+  setup_trace("relabel: allocations + entry keys");
     size_t bytes = 0;
     if ((e = hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, keys.p, sorted.p, (int)ne, 0, 32 + bits)) != hipSuccess) return fail(e, "SortKeys(size)");
     if ((e = tmp.reserve(bytes)) != hipSuccess) return fail(e, "hipMalloc(sort temp)");
     if ((e = hipcub::DeviceRadixSort::SortKeys(tmp.buf.p, bytes, keys.p, sorted.p, (int)ne, 0, 32 + bits)) != hipSuccess) return fail(e, "SortKeys");
-    hipLaunchKernelGGL(relabel_cols_kernel, blocks(ne), dim3(256), 0, 0, ne, sorted.p, r->d_col);
+    hipLaunchKernelGGL(relabel_cols_kernel, blocks(ne), dim3(256), 0, 0, ne, sorted.p, r->d_col, dupflag.p);
   }
+  setup_trace("relabel: entry sort + columns");
   if ((e = hipGetLastError()) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess) return fail(e, "relabel kernels");
+  {
+    int dup = 0;
+    if ((e = hipMemcpy(&dup, dupflag.p, sizeof(int), hipMemcpyDeviceToHost)) != hipSuccess) return fail(e, "hipMemcpy");
+    r->sorted_state = dup ? 2 : 1;
+  }
   int rc = finish_handle(r);
   if (rc) { gm_graph_free(r); return rc; }
   r->max_deg = g->max_deg;  // (a permutation of the same rows)
+  setup_trace("relabel: finish_handle");
   if (mode == 2) {
     bool topo = false;
     rc = graph_is_topological(r, &topo);

@@ -149,9 +149,18 @@ struct ChunkTable {
   size_t n_bitmaps = 0;
   unsigned long long bitmap_words = 0;
   unsigned long long max_bit_words = 0;  // largest nel*stride over chunks that exceed bit_words
+  // Host views of the per-chunk scalars: what a SHARE of the table needs (a rank of a larger job: its task edges, the vertex-range policy;
+  // the k-clique plan; the chunk dumps).  A device-built table keeps them on the device and table_host_views() fetches them on first use --
+  // one rank never does: the first pageable device-to-host copy of a process costs ~10 ms in the runtime, which was the largest single
+  // item of a first triangle count (GM_SETUP_TRACE).  total_edges / total_cost are fetched with the table (16 bytes).
   std::vector<unsigned long long> edge_prefix;  // edges owned by chunks [0,i)
   std::vector<int> first_vertex;                // u_begin of every chunk (ascending; SPLIT chunks repeat it)
+  bool host_ready = false;
+  unsigned long long total_edges = 0, total_cost = 0;
+  int *d_edges = nullptr, *d_firstv = nullptr;  // device twins of the host views (device-built tables)
+  unsigned long long *d_cost = nullptr;
 };
+int table_host_views(gm_graph *g, ChunkTable *t);  // gm_tables.hip
 
 // k-clique (k = 4): the plan of one rank's share (gm_mine.h "level 1 re-hosted"; built by get_clique_plan, gm_tables.hip).
 // OWNERS are the vertices whose matrices this rank builds and counts: the vertices of its share of the narrow chunk table + its share
@@ -222,6 +231,9 @@ struct gm_graph {
   // nv <= 2^24: instead of descriptors that point at the copies, the copies ARE the task list of the short lists -- a key stream in host
   // order, every key tagged with its host's low 8 bits (GraphView::kst), offsets per host vertex, and the longer lists as their own
   // task lists (d_trpl / d_tdescl).  No descriptor, no row search, no flattening for the short lists: one coalesced load per 64 keys.
+  unsigned *d_kst = nullptr;  // the stream itself (ensure_keystream, gm_tables.hip)
+  int kst_state = 0;          // 2: this handle cannot have one (ids beyond 24 bits, GM_TC_NO_KEY_STREAM)
+  int n_long_tasks = 0;
   int *d_kst_rp = nullptr;
   int *d_trpl = nullptr;
   int2 *d_tdescl = nullptr;
@@ -325,6 +337,20 @@ struct SetupTimer {
   double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
 };
 
+// GM_SETUP_TRACE: wall-clock marks of the setup steps on stderr, each after a device synchronisation (where do the milliseconds of a
+// first call go: kernels, allocations, copies back?).  Off: one predictable branch.
+inline void setup_trace(const char *what) {
+  static const bool on = getenv("GM_SETUP_TRACE") != nullptr;
+  if (!on) return;
+  static std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+  const auto t0 = std::chrono::steady_clock::now();
+  (void)hipDeviceSynchronize();
+  const auto t1 = std::chrono::steady_clock::now();
+  fprintf(stderr, "[setup] %-34s %8.3f ms (+ %.3f waiting for the device)\n", what, std::chrono::duration<double, std::milli>(t0 - last).count(),
+          std::chrono::duration<double, std::milli>(t1 - t0).count());
+  last = std::chrono::steady_clock::now();
+}
+
 // scope guard: the enclosed once-per-graph pattern setup (device work included) is charged to setup.other_ms
 struct OtherSetupScope {
   gm_graph *g;
@@ -367,6 +393,7 @@ int get_table(gm_graph *g, int target, bool allow_split, int bit_words, unsigned
               const RowFilter &rf = RowFilter(), int bitmap_min_deg = kBitmapMinDeg);
 int ensure_edesc(gm_graph *g);
 int ensure_tasklists(gm_graph *g, bool with_edges = false);
+int ensure_keystream(gm_graph *g, bool *built);
 int ensure_mean_sq_deg(gm_graph *g);
 unsigned long long task_part_cap(gm_graph *g, int world);
 int clique_wide_min_words();

@@ -167,6 +167,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
   la = &ctx.la;
   const int world = ctx.world, rank = ctx.rank;
   hipStream_t stream = ctx.stream;
+  setup_trace("run_pattern: begin_launch");
 
   // tune[0] = chunk target override, tune[1] = grab, tune[2] = cost_x_step, tune[3] = cost_y_step,
   // tune[4] = blocks per CU override, tune[5] = force "search in HBM" (no LDS staging) when 1
@@ -224,11 +225,22 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
     const int rc_l = ensure_long_rows(g);
     if (rc_l) return rc_l;
   }
+  // the triangle count reads the key stream + the lists of the longer tasks (ensure_keystream); the edge supports, the kernels without the
+  // stream (tune[6] & 0x8000000 / 0x20000000, GM_TC_SORTED) and the handles that cannot have one read the full task lists
+  const bool use_tch_k = !(la->tune[6] & 0x8000000) && !getenv("GM_TC_SORTED");  // (the key stream is read by tch_kernel only)
+  bool use_kst = false;
   if (use_tct) {
-    int rc_t = ensure_tasklists(g, support);
-    if (rc_t) return rc_t;
+    if (!support && use_tch_k && !(la->tune[6] & 0x20000000)) {
+      const int rc_k = ensure_keystream(g, &use_kst);
+      if (rc_k) return rc_k;
+    }
+    if (!use_kst) {
+      const int rc_t = ensure_tasklists(g, support);
+      if (rc_t) return rc_t;
+    }
   }
   if (support && !sup_part && !g->d_sup) HIP_TRY(hipMalloc(&g->d_sup, sizeof(unsigned) * (size_t)std::max<long long>(g->ne, 1)));
+  setup_trace("run_pattern: task lists");
   RowFilter rf;
   rf.tct = use_tct ? 1 : 0;
   if (tct_long) { rf.skip_lo = kTctStageMax; rf.skip_hi = 0x7fffffff; }
@@ -314,6 +326,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
     if (rc) return rc;
   }
 
+  setup_trace("run_pattern: tables / plan");
   MineParams p;
   memset(&p, 0, sizeof p);
   p.g.nv = g->nv;
@@ -329,21 +342,19 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
     p.g.tedge = support ? g->d_tedge : nullptr;
     // the triangle count streams the short lists from their task-major copies (gm_host.h d_colk; tune[6] & 0x20000000: from their rows);
     // the edge supports need the entries of the streamed keys in col[] itself
-    const bool use_tch_k = !(la->tune[6] & 0x8000000) && !getenv("GM_TC_SORTED");  // (the key stream is read by tch_kernel only)
-    if (!support && g->d_colk && !(la->tune[6] & 0x20000000)) {
-      if (g->d_kst_rp && g->d_trpl && g->d_tdescl && use_tch_k) {  // short lists as one tagged key stream, the longer ones as tasks
-        p.g.kst = reinterpret_cast<const unsigned *>(g->d_colk) + g->ne;
-        p.g.kst_rp = g->d_kst_rp;
-        p.g.trp = g->d_trpl;
-        p.g.tdesc = g->d_tdescl;
-      } else if (g->d_tdesck) {
-        p.g.col = g->d_colk;
-        p.g.tdesc = g->d_tdesck;
-      }
+    if (use_kst) {  // short lists as one tagged key stream, the longer ones as tasks
+      p.g.kst = g->d_kst;
+      p.g.kst_rp = g->d_kst_rp;
+      p.g.trp = g->d_trpl;
+      p.g.tdesc = g->d_tdescl;
+    } else if (!support && g->d_colk && g->d_tdesck && !(la->tune[6] & 0x20000000)) {
+      p.g.col = g->d_colk;
+      p.g.tdesc = g->d_tdesck;
     }
   }
   unsigned long long my_edges = 0;
   // this rank's share of a table: chunk ids first + i*step of the dequeue order (or a contiguous / vertex range)
+  int share_rc = GM_OK;  // (take_share: a failed fetch of a table's host views)
   auto take_share = [&](ChunkTable *tb, MineParams &q) {
     q.chunks = tb->d;
     q.chunk_slot = tb->d_slot;
@@ -353,6 +364,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
     const long long n = (long long)tb->n;
     long long first = 0, step = 1, count = 0;
     if (la->policy == GM_PART_VERTEX) {  // contiguous chunk range whose first vertex lies in this rank's vertex range
+      if (int rcv = table_host_views(g, tb)) { share_rc = rcv; return; }
       const long long vlo = (long long)g->nv * rank / world, vhi = (long long)g->nv * (rank + 1) / world;
       auto first_chunk_at = [&](long long v) {
         long long lo = 0, hi = n;
@@ -378,6 +390,9 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
     const int which = (((world > 1 && !sym_pat) || clique_pat) ? 1 : 0) ^ ((la->tune[6] & 0x2000) ? 1 : 0);
     const bool lpt = la->policy == GM_PART_ROUND_ROBIN && tb->d_order[which] && !(la->tune[6] & 0x4000);
     q.order = lpt ? tb->d_order[which] : nullptr;
+    // task edges of the share (gm_stats): the whole table's total came with the table; a share reads the per-chunk host views
+    if (first == 0 && step == 1 && count == n) { my_edges += tb->total_edges; return; }
+    if (int rcv = table_host_views(g, tb)) { share_rc = rcv; return; }
     if (step == 1) my_edges += tb->edge_prefix[first + count] - tb->edge_prefix[first];  // (any order: the same set)
     else for (long long j = first; j < n; j += step) {
       const size_t c = lpt ? (size_t)tb->order[which][(size_t)j] : (size_t)j;
@@ -385,6 +400,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
     }
   };
   take_share(tab, p);
+  if (share_rc) return share_rc;
   p.grab = la->tune[1] > 0 ? la->tune[1] : 1;
   // the task-list kernels take TWO chunks per dequeue where a resident workgroup has many to take (one device atomic + one workgroup
   // barrier less per chunk: flat LJ-size TC 0.605 -> 0.427 ms, power law 0.77 -> 0.71, R-MAT-22 2.57 -> 2.48; four: 0.423 / 0.71 / 3.37 --
@@ -488,7 +504,13 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
     // (2) clique_small_kernel counts the matrices of the narrow chunks, the big-LDS classes X / L / S those of the wide vertices
     {  // task edges of the share: the entries of its narrow chunks + the rows of its wide vertices
       ChunkTable *tn = plan->tabN;
-      for (long long i = 0; i < plan->n_count; ++i) {
+      if (plan->n_count == (long long)tn->n) {
+        my_edges += tn->total_edges;
+      } else {
+        rc = table_host_views(g, tn);
+        if (rc) return rc;
+      }
+      for (long long i = 0; i < plan->n_count && plan->n_count != (long long)tn->n; ++i) {
         const long long pos = plan->n_first + i * plan->n_step;
         const size_t c = plan->d_order ? (size_t)tn->order[plan->order_which][(size_t)pos] : (size_t)pos;
         my_edges += tn->edge_prefix[c + 1] - tn->edge_prefix[c];
@@ -652,6 +674,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
       if (!tab_cls[cls]) continue;
       MineParams q = p;
       take_share(tab_cls[cls], q);
+      if (share_rc) return share_rc;
       q.queue = reinterpret_cast<unsigned *>(g->d_counters + 4) + cls;  // its own dequeue word inside the zeroed 64-byte block
       if (q.count == 0) continue;
       chunks_total += (uint64_t)q.count;
@@ -685,6 +708,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
   if (tab_long) {  // TC: the out-edges of the rows beyond the stage, through the chunked kernel (own dequeue word)
     MineParams q = p;
     take_share(tab_long, q);
+    if (share_rc) return share_rc;
     q.g.trp = nullptr;
     q.g.tdesc = nullptr;
     q.queue = reinterpret_cast<unsigned *>(g->d_counters + 4) + 1;
@@ -703,6 +727,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
     if (tab_big) {  // the hosts with rows of 1025 .. 2048 entries first (the heaviest tasks), on the 2048-entry kernel
       MineParams q = p;
       take_share(tab_big, q);
+      if (share_rc) return share_rc;
       q.grab = 1;
       q.queue = reinterpret_cast<unsigned *>(g->d_counters + 4) + 2;
       chunks_total += (uint64_t)q.count;
@@ -730,6 +755,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
     if (tab_big) {  // the hosts with rows of 1025 .. 2048 entries first (the heaviest tasks), on the 2048-entry kernel
       MineParams q = p;
       take_share(tab_big, q);
+      if (share_rc) return share_rc;
       q.grab = 1;
       q.queue = reinterpret_cast<unsigned *>(g->d_counters + 4) + 2;
       chunks_total += (uint64_t)q.count;
@@ -747,6 +773,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
     (void)hipFree(d_ticks);
     std::vector<ChunkRec> recs(tab->n);
     HIP_TRY(hipMemcpy(recs.data(), tab->d, sizeof(ChunkRec) * tab->n, hipMemcpyDeviceToHost));
+    if (int rcv = table_host_views(g, tab)) return rcv;
     std::vector<size_t> idx(tab->n);
     for (size_t i = 0; i < tab->n; ++i) idx[i] = i;
     std::sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return ticks[a] > ticks[b]; });

@@ -11,6 +11,10 @@ static void free_table(ChunkTable &t) {
   if (t.d_row_slot && t.own_bitmaps) (void)hipFree(t.d_row_slot);
   for (int i = 0; i < 2; ++i) if (t.d_order[i]) (void)hipFree(t.d_order[i]);
   if (t.d_bitmaps && t.own_bitmaps) (void)hipFree(t.d_bitmaps);
+  if (t.d_edges) (void)hipFree(t.d_edges);
+  if (t.d_firstv) (void)hipFree(t.d_firstv);
+  if (t.d_cost) (void)hipFree(t.d_cost);
+  t.d_edges = t.d_firstv = nullptr; t.d_cost = nullptr;
   t.d = nullptr; t.d_slot = nullptr; t.d_row_slot = nullptr; t.d_order[0] = t.d_order[1] = nullptr; t.d_bitmaps = nullptr;
 }
 void free_tables(gm_graph *g) {
@@ -105,12 +109,18 @@ __global__ __launch_bounds__(256) void bitmap_build_kernel(const int *__restrict
 __global__ __launch_bounds__(256) void chunk_cost_kernel(const int *__restrict__ rp, const int *__restrict__ col,
                                                          const ChunkRec *__restrict__ chunks, unsigned long long *__restrict__ cost,
                                                          int owner_rule, int stage_cap, const int *__restrict__ trp = nullptr,
-                                                         const int *__restrict__ tlen = nullptr, int tstride = 2) {
+                                                         const int *__restrict__ tlen = nullptr, int tstride = 2, const int *__restrict__ kst_rp = nullptr) {
   const ChunkRec r = chunks[blockIdx.x];
   unsigned long long c = 0;
   if (owner_rule == 2) {  // gm_tct.hip: the keys of the lists this chunk's vertices host
     // (tlen: the length field of the first task record, tstride: ints per record -- int2 {start, len} of gm_tct.hip, CBuildTask of gm_cbuild.hip)
-    for (int te = trp[r.u_begin] + (int)threadIdx.x; te < trp[r.u_end]; te += 256) c += (unsigned long long)tlen[(size_t)te * (size_t)tstride] + 8ull;
+    // (gridDim.y workgroups share a chunk: a hub of R-MAT-22 hosts 2 * 10^5 tasks -- one workgroup walking them alone was 1.6 of the kernel's 1.7 ms)
+    const int t0 = trp[r.u_begin], t1 = trp[r.u_end];
+    const int ny = max(1, min((int)gridDim.y, (t1 - t0 + 1023) >> 10));  // workgroups that take part: one per 1024 tasks
+    if ((int)blockIdx.y >= ny) return;
+    // (kst_rp: trp / tlen hold the longer lists only; the keys of the short ones are the hosts' range of the key stream -- no per-task cost there)
+    if (kst_rp && blockIdx.y == 0 && threadIdx.x == 0) c += (unsigned long long)(kst_rp[r.u_end] - kst_rp[r.u_begin]);
+    for (int te = t0 + (int)blockIdx.y * 256 + (int)threadIdx.x; te < t1; te += 256 * ny) c += (unsigned long long)tlen[(size_t)te * (size_t)tstride] + 8ull;
   } else if (owner_rule) {
     // a key streamed by a SPLIT chunk is a random probe of the hub row's bitmap in HBM, a key of a staged chunk an LDS filter probe
     const unsigned long long w = (r.u_end == r.u_begin + 1 && (r.e_begin != rp[r.u_begin] || r.e_end != rp[r.u_end])) ? (unsigned long long)kProbeCost : 1ull;
@@ -238,6 +248,20 @@ __global__ __launch_bounds__(256) void tab_expand_kernel(int n0, const ChunkRec 
     first_vertex[o] = r.u_begin;
   }
 }
+__global__ __launch_bounds__(256) void tab_totals_kernel(int n, const int *__restrict__ edges, const unsigned long long *__restrict__ cost,
+                                                         unsigned long long *__restrict__ out) {
+  unsigned long long se = 0, sc = 0;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
+    se += (unsigned long long)edges[c];
+    sc += cost[c];
+  }
+  se = gm::wave_sum_u64(se);
+  sc = gm::wave_sum_u64(sc);
+  if ((threadIdx.x & 63) == 0) {
+    if (se) atomicAdd(&out[0], se);
+    if (sc) atomicAdd(&out[1], sc);
+  }
+}
 // rev_rest: the chunks below the heavy mark go in DESCENDING chunk-id order. On a topologically numbered DAG ids ascend in degree, so
 // ascending vertex order would end the launch on its heaviest ordinary chunks (TC on the power-law LiveJournal stand-in: 1.14 ms as
 // numbered, degrees descending, vs 1.88 ms on the renumbered copy before this)
@@ -277,7 +301,13 @@ __global__ __launch_bounds__(256) void gather_deg_kernel(int m, const int *__res
 // (trp / tlen / tstride: the task lists the costs of an rf.tct table are counted from; default: the graph's, gm_tct.hip)
 static int build_table_device(gm_graph *g, ChunkTable &t, bool sym_table, double &bitmap_ms, const int *trp = nullptr, const int *tlen = nullptr,
                               int tstride = 2) {
-  if (!trp) {
+  const int *kst_rp = nullptr;
+  if (!trp && g->d_kst_rp) {  // the costs of the triangle count's tables: the key stream + the longer lists
+    trp = g->d_trpl;
+    tlen = &g->d_tdescl[0].y;
+    tstride = 2;
+    kst_rp = g->d_kst_rp;
+  } else if (!trp) {
     trp = g->d_trp;
     tlen = g->d_tdesc ? &g->d_tdesc[0].y : nullptr;
     tstride = 2;
@@ -290,6 +320,7 @@ static int build_table_device(gm_graph *g, ChunkTable &t, bool sym_table, double
   auto blocks = [](long long n) { return dim3((unsigned)std::max<long long>(1, (n + 255) / 256)); };
   // the greedy walk, one thread per block of kTableBlock vertices: count, scan, emit
   ChunkWalk w{t.target, t.allow_split ? 1 : 0, t.bit_words, t.stage_cap, t.rf};
+  setup_trace("table: begin");
   const int nblk = (nv + kTableBlock - 1) / kTableBlock;
   DevBuf<int> bcount, boff;
   DevBuf<unsigned long long> maxbw;
@@ -303,10 +334,12 @@ static int build_table_device(gm_graph *g, ChunkTable &t, bool sym_table, double
   int n0 = 0;
   HIP_TRY(hipMemcpy(&n0, boff.p + nblk, sizeof(int), hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(&t.max_bit_words, maxbw.p, 8, hipMemcpyDeviceToHost));
+  setup_trace("table: walk count + scan");
   t.n = 0;
   HIP_TRY(hipMalloc(&t.d, sizeof(ChunkRec)));  // (placeholder, replaced below when the table has chunks)
   if (n0 == 0) {
     t.edge_prefix.assign(1, 0ull);
+    t.host_ready = true;
     return GM_OK;
   }
   DevBuf<ChunkRec> recs0;
@@ -316,8 +349,8 @@ static int build_table_device(gm_graph *g, ChunkTable &t, bool sym_table, double
   DevBuf<unsigned long long> cost0;
   HIP_TRY(cost0.alloc((size_t)n0));
   HIP_TRY(hipMemsetAsync(cost0.p, 0, sizeof(unsigned long long) * (size_t)n0, 0));
-  hipLaunchKernelGGL(chunk_cost_kernel, dim3((unsigned)n0), dim3(256), 0, 0, g->d_rp, g->d_col, recs0.p, cost0.p, t.rf.tct ? 2 : (sym_table ? 1 : 0), kStageCapWide,
-                     trp, tlen, tstride);
+  hipLaunchKernelGGL(chunk_cost_kernel, dim3((unsigned)n0, t.rf.tct ? 16u : 1u), dim3(256), 0, 0, g->d_rp, g->d_col, recs0.p, cost0.p, t.rf.tct ? 2 : (sym_table ? 1 : 0), kStageCapWide,
+                     trp, tlen, tstride, kst_rp);
   DevBuf<int> np, bsz, off;
   HIP_TRY(np.alloc((size_t)n0 + 1));
   HIP_TRY(bsz.alloc((size_t)n0 + 1));
@@ -327,40 +360,39 @@ static int build_table_device(gm_graph *g, ChunkTable &t, bool sym_table, double
   HIP_TRY(dev_exclusive_sum(tmp, np.p, off.p, (size_t)n0 + 1));
   int n = 0;
   HIP_TRY(hipMemcpy(&n, off.p + n0, sizeof(int), hipMemcpyDeviceToHost));
+  setup_trace("table: walk emit, cost, parts");
   (void)hipFree(t.d);
   t.d = nullptr;
   HIP_TRY(hipMalloc(&t.d, sizeof(ChunkRec) * (size_t)n));
-  DevBuf<unsigned long long> cost;
-  DevBuf<int> edges, firstv;
-  HIP_TRY(cost.alloc((size_t)n));
-  HIP_TRY(edges.alloc((size_t)n));
-  HIP_TRY(firstv.alloc((size_t)n));
-  hipLaunchKernelGGL(tab_expand_kernel, blocks(n0), dim3(256), 0, 0, n0, recs0.p, cost0.p, np.p, bsz.p, off.p, t.d, cost.p, edges.p, firstv.p);
+  setup_trace("table: free + alloc of the records");
+  // per-chunk scalars (cost, task edges, first vertex): they stay on the device, the host takes the two totals (table_host_views: the rest, on demand)
+  HIP_TRY(hipMalloc(&t.d_cost, sizeof(unsigned long long) * (size_t)n));
+  HIP_TRY(hipMalloc(&t.d_edges, sizeof(int) * (size_t)n));
+  HIP_TRY(hipMalloc(&t.d_firstv, sizeof(int) * (size_t)n));
+  DevBuf<unsigned long long> totals;
+  HIP_TRY(totals.alloc(2));
+  HIP_TRY(hipMemsetAsync(totals.p, 0, 16, 0));
+  hipLaunchKernelGGL(tab_expand_kernel, blocks(n0), dim3(256), 0, 0, n0, recs0.p, cost0.p, np.p, bsz.p, off.p, t.d, t.d_cost, t.d_edges, t.d_firstv);
+  hipLaunchKernelGGL(tab_totals_kernel, dim3((unsigned)std::min<long long>(((long long)n + 255) / 256, 1024)), dim3(256), 0, 0, n, t.d_edges, t.d_cost, totals.p);
   t.n = (size_t)n;
-  // host views of the per-chunk scalars (O(chunks), not O(vertices)): edges -> prefix, first vertex, cost
   {
-    std::vector<int> h_edges((size_t)n);
-    t.first_vertex.resize((size_t)n);
-    t.cost.resize((size_t)n);
-    HIP_TRY(hipMemcpy(h_edges.data(), edges.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(t.first_vertex.data(), firstv.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(t.cost.data(), cost.p, sizeof(unsigned long long) * (size_t)n, hipMemcpyDeviceToHost));
-    t.edge_prefix.resize((size_t)n + 1);
-    t.edge_prefix[0] = 0;
-    for (size_t i = 0; i < (size_t)n; ++i) t.edge_prefix[i + 1] = t.edge_prefix[i] + (unsigned long long)h_edges[i];
+    unsigned long long h_tot[2] = {0, 0};
+    HIP_TRY(hipMemcpy(h_tot, totals.p, 16, hipMemcpyDeviceToHost));
+    t.total_edges = h_tot[0];
+    t.total_cost = h_tot[1];
   }
+  setup_trace("table: expand + totals");
   // dequeue orders: stable descending radix sorts of (key, chunk id)
   {
-    unsigned long long total_cost = 0;
-    for (auto c : t.cost) total_cost += c;
-    const unsigned long long heavy = 2ull * (total_cost / (unsigned long long)n) + 1ull;
+    const unsigned long long heavy = 2ull * (t.total_cost / (unsigned long long)n) + 1ull;
+    unsigned long long *const cost_p = t.d_cost;
     DevBuf<unsigned long long> key0, key1, keyo;
     DevBuf<int> iota;
     HIP_TRY(key0.alloc((size_t)n));
     HIP_TRY(key1.alloc((size_t)n));
     HIP_TRY(keyo.alloc((size_t)n));
     HIP_TRY(iota.alloc((size_t)n));
-    hipLaunchKernelGGL(tab_orderkeys_kernel, blocks(n), dim3(256), 0, 0, n, cost.p, heavy, sym_table ? 1 : 0, (!sym_table && g->topo_state == 1) ? 1 : 0,
+    hipLaunchKernelGGL(tab_orderkeys_kernel, blocks(n), dim3(256), 0, 0, n, cost_p, heavy, sym_table ? 1 : 0, (!sym_table && g->topo_state == 1) ? 1 : 0,
                        key0.p, key1.p, iota.p);
     for (int m = 0; m < 2; ++m) {
       HIP_TRY(hipMalloc(&t.d_order[m], sizeof(int) * (size_t)n));
@@ -369,10 +401,9 @@ static int build_table_device(gm_graph *g, ChunkTable &t, bool sym_table, double
       HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, bytes, keys, keyo.p, iota.p, t.d_order[m], n));
       HIP_TRY(tmp.reserve(bytes));
       HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(tmp.buf.p, bytes, keys, keyo.p, iota.p, t.d_order[m], n));
-      t.order[m].resize((size_t)n);
-      HIP_TRY(hipMemcpy(t.order[m].data(), t.d_order[m], sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
     }
   }
+  setup_trace("table: dequeue orders");
   if (t.allow_split) {
     SetupTimer bm_timer;
     // Hub rows (longer than the LDS stage, cut into SPLIT chunks) get a dense bitmap over the vertex ids, the longest rows
@@ -446,8 +477,34 @@ static int build_table_device(gm_graph *g, ChunkTable &t, bool sym_table, double
     }
     bitmap_ms = bm_timer.ms();
   }
+  setup_trace("table: bitmaps");
   HIP_TRY(hipGetLastError());  // (the setup kernels above are launched unchecked)
   HIP_TRY(hipDeviceSynchronize());
+  return GM_OK;
+}
+
+// the host views of a device-built table (gm_host.h ChunkTable), fetched when a caller first needs them
+int table_host_views(gm_graph *g, ChunkTable *t) {
+  std::lock_guard<std::mutex> lk(g->mu);
+  if (t->host_ready) return GM_OK;
+  HIP_TRY(hipSetDevice(g->device));
+  const size_t n = t->n;
+  t->edge_prefix.assign(n + 1, 0ull);
+  t->first_vertex.resize(n);
+  t->cost.resize(n);
+  if (n) {
+    std::vector<int> h_edges(n);
+    HIP_TRY(hipMemcpy(h_edges.data(), t->d_edges, sizeof(int) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(t->first_vertex.data(), t->d_firstv, sizeof(int) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(t->cost.data(), t->d_cost, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) t->edge_prefix[i + 1] = t->edge_prefix[i] + (unsigned long long)h_edges[i];
+    for (int m = 0; m < 2; ++m)
+      if (t->d_order[m]) {
+        t->order[m].resize(n);
+        HIP_TRY(hipMemcpy(t->order[m].data(), t->d_order[m], sizeof(int) * n, hipMemcpyDeviceToHost));
+      }
+  }
+  t->host_ready = true;
   return GM_OK;
 }
 
@@ -474,12 +531,9 @@ int get_table(gm_graph *g, int target, bool allow_split, int bit_words, unsigned
     PoolScope pool(g);
     int rc = build_table_device(g, t, sym_table, bitmap_ms);
     if (rc) { free_table(t); return rc; }  // (a partially built table owns device memory: out-of-memory on a large graph must not leak it)
-    if (getenv("GM_TABLE_INFO")) {
-      unsigned long long tc = 0, mx = 0;
-      for (auto c : t.cost) { tc += c; mx = std::max(mx, c); }
-      fprintf(stderr, "[table/device] stage_cap %d rows (%d,%d] skip (%d,%d]: %zu chunks, est. keys %.3e (max chunk %.3e), %zu bitmaps, edges %llu, %.2f ms\n",
-              stage_cap, rf.only_lo, rf.only_hi, rf.skip_lo, rf.skip_hi, t.n, (double)tc, (double)mx, t.n_bitmaps, t.edge_prefix.back(), timer.ms());
-    }
+    if (getenv("GM_TABLE_INFO"))
+      fprintf(stderr, "[table/device] stage_cap %d rows (%d,%d] skip (%d,%d]: %zu chunks, est. keys %.3e, %zu bitmaps, edges %llu, %.2f ms\n",
+              stage_cap, rf.only_lo, rf.only_hi, rf.skip_lo, rf.skip_hi, t.n, (double)t.total_cost, t.n_bitmaps, t.total_edges, timer.ms());
     g->setup.bitmap_ms += bitmap_ms;
     g->setup.table_ms += timer.ms() - bitmap_ms;
     g->tables.push_back(std::move(t));
@@ -547,6 +601,10 @@ int get_table(gm_graph *g, int target, bool allow_split, int bit_words, unsigned
     for (int b = recs[i].part; b * bsz < nel; b += np) mine += (unsigned long long)std::min(bsz, nel - b * bsz);
     t.edge_prefix[i + 1] = t.edge_prefix[i] + mine;
   }
+  t.total_edges = t.edge_prefix.back();
+  t.total_cost = 0;
+  for (auto c : t.cost) t.total_cost += c;
+  t.host_ready = true;
   HIP_TRY(hipMalloc(&t.d, sizeof(ChunkRec) * std::max<size_t>(t.n, 1)));
   if (t.n) HIP_TRY(hipMemcpy(t.d, recs.data(), sizeof(ChunkRec) * t.n, hipMemcpyHostToDevice));
   if (t.n) {
@@ -647,72 +705,53 @@ __global__ __launch_bounds__(256) void edesc_kernel(long long ne, const int *__r
 }
 
 // ---- task lists of gm_tct.hip / gm_tch.hip: every edge u -> v of the DAG is a task of ONE of its endpoints (ensure_tasklists, below) ------
-// ---- task-major copies of the short lists (gm_host.h: d_colk / d_tdesck) ------------------------------------------------------------
+// ---- task-major copies of the short lists (gm_host.h: d_colk / d_tdesck) -- for the handles that cannot have the key stream -----------
 #ifndef GM_TC_INLINE_MAX_DEFAULT
 #define GM_TC_INLINE_MAX_DEFAULT 32
 #endif
-// len[t] = keys of task t that go into the copies (0: none), lng[t] = 1 when the task stays a task of its own (a longer list)
-__global__ __launch_bounds__(256) void inl_len_kernel(long long nt, const int2 *__restrict__ tdesc, int lmax, unsigned long long *__restrict__ len,
-                                                       unsigned long long *__restrict__ lng) {
+// len[t] = keys of task t that go into the copies (0: none)
+__global__ __launch_bounds__(256) void inl_len_kernel(long long nt, const int2 *__restrict__ tdesc, int lmax, unsigned long long *__restrict__ len) {
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t <= nt; t += stride) {
     const int n = t < nt ? tdesc[t].y : 0;
     len[t] = (n > 0 && n <= lmax) ? (unsigned long long)n : 0ull;
-    if (lng) lng[t] = n > lmax ? 1ull : 0ull;
   }
 }
-// eight lanes per task: its keys move from their row of col[] to their place in task order.  tag: every key carries the low 8 bits of
-// its host vertex in bits 24..31 (key stream) and the longer lists are compacted into their own task list; else the descriptor follows.
+// eight lanes per task: its keys move from their row of col[] to their place in task order, the descriptor follows
 __global__ __launch_bounds__(256) void inl_copy_kernel(long long nt, const int2 *__restrict__ tdesc, const unsigned long long *__restrict__ off, int lmax,
-                                                        long long ne, int *__restrict__ colk, int2 *__restrict__ tdesck,
-                                                        const unsigned char *__restrict__ ttag, const unsigned long long *__restrict__ loff,
-                                                        int2 *__restrict__ tdescl) {
+                                                        long long ne, int *__restrict__ colk, int2 *__restrict__ tdesck) {
   const long long stride = ((long long)gridDim.x * blockDim.x) >> 3;
   const int sub = threadIdx.x & 7;
   for (long long t = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 3; t < nt; t += stride) {
     const int2 d = tdesc[t];
     if (d.y > 0 && d.y <= lmax) {
       const long long o = ne + (long long)off[t];
-      const unsigned tag = ttag ? (unsigned)ttag[t] << 24 : 0u;
-      for (int i = sub; i < d.y; i += 8) colk[o + i] = (int)((unsigned)colk[d.x + i] | tag);  // (the first ne entries of colk are col itself)
-      if (sub == 0 && tdesck) tdesck[t] = make_int2((int)o, d.y);
+      for (int i = sub; i < d.y; i += 8) colk[o + i] = colk[d.x + i];  // (the first ne entries of colk are col itself)
+      if (sub == 0) tdesck[t] = make_int2((int)o, d.y);
     } else if (sub == 0) {
-      if (tdesck) tdesck[t] = d;
-      if (tdescl && d.y > lmax) tdescl[loff[t]] = d;
+      tdesck[t] = d;
     }
   }
 }
-__global__ __launch_bounds__(256) void inl_offsets_kernel(int nv, const int *__restrict__ trp, const unsigned long long *__restrict__ off,
-                                                           const unsigned long long *__restrict__ loff, int *__restrict__ kst_rp, int *__restrict__ trpl) {
-  const int v = blockIdx.x * blockDim.x + threadIdx.x;
-  if (v > nv) return;
-  const int t = trp[v];
-  kst_rp[v] = (int)off[t];
-  trpl[v] = (int)loff[t];
-}
-// after d_tdesc: failures here leave the handle without copies (the kernels then stream the rows themselves).
-// ttag[t] = the low 8 bits of the host of task t.
-static void build_inline_copies(gm_graph *g, ScanTemp &tmp, const unsigned char *ttag) {
+// after d_tdesc: failures here leave the handle without copies (the kernels then stream the rows themselves)
+static void build_inline_copies(gm_graph *g, ScanTemp &tmp) {
   int lmax = GM_TC_INLINE_MAX_DEFAULT;
   if (const char *e = getenv("GM_TC_INLINE_MAX")) lmax = atoi(e);  // (sweeps; 0: no copies)
   if (lmax <= 0 || g->ne <= 0 || g->d_tdesc == nullptr) return;
-  const bool stream = g->nv <= (1 << 24) && !getenv("GM_TC_NO_KEY_STREAM");  // ids must leave bits 24..31 to the host tag
   const long long nt = g->ne;
-  const size_t nv1 = (size_t)g->nv + 1;
-  unsigned long long *off = nullptr, *loff = nullptr;  // (lengths in, offsets out: the scans run in place)
-  int *colk = nullptr, *krp = nullptr, *trpl = nullptr;
-  int2 *tdk = nullptr, *tdl = nullptr;
+  unsigned long long *off = nullptr;  // (lengths in, offsets out: the scan runs in place)
+  int *colk = nullptr;
+  int2 *tdk = nullptr;
   auto fail = [&]() {
     (void)hipGetLastError();
-    for (void *p : {(void *)off, (void *)loff, (void *)colk, (void *)krp, (void *)trpl, (void *)tdk, (void *)tdl})
+    for (void *p : {(void *)off, (void *)colk, (void *)tdk})
       if (p) (void)hipFree(p);
   };
   if (hipMalloc(&off, 8 * (size_t)(nt + 1)) != hipSuccess) return fail();
-  if (stream && hipMalloc(&loff, 8 * (size_t)(nt + 1)) != hipSuccess) return fail();
   const long long blocks = std::min<long long>((nt + 256) / 256, (long long)g->cu_count * 32);
-  unsigned long long total = 0, nlong = 0;
+  unsigned long long total = 0;
   for (;;) {  // the copies share the 32-bit index space of col[]: halve the limit until they fit
-    hipLaunchKernelGGL(inl_len_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, nt, g->d_tdesc, lmax, off, loff);
+    hipLaunchKernelGGL(inl_len_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, nt, g->d_tdesc, lmax, off);
     if (dev_exclusive_sum(tmp, off, off, (size_t)nt + 1) != hipSuccess) return fail();
     if (hipMemcpy(&total, off + nt, 8, hipMemcpyDeviceToHost) != hipSuccess) return fail();
     if ((unsigned long long)nt + total < 0x7fffff00ull) break;
@@ -720,29 +759,15 @@ static void build_inline_copies(gm_graph *g, ScanTemp &tmp, const unsigned char 
     if (lmax < 4) return fail();
   }
   if (total == 0) return fail();
-  if (stream) {
-    if (dev_exclusive_sum(tmp, loff, loff, (size_t)nt + 1) != hipSuccess) return fail();
-    if (hipMemcpy(&nlong, loff + nt, 8, hipMemcpyDeviceToHost) != hipSuccess) return fail();
-    if (hipMalloc(&krp, 4 * nv1) != hipSuccess || hipMalloc(&trpl, 4 * nv1) != hipSuccess ||
-        hipMalloc(&tdl, sizeof(int2) * (size_t)std::max<unsigned long long>(nlong, 1)) != hipSuccess)
-      return fail();
-  } else if (hipMalloc(&tdk, sizeof(int2) * (size_t)nt) != hipSuccess) {
-    return fail();
-  }
+  if (hipMalloc(&tdk, sizeof(int2) * (size_t)nt) != hipSuccess) return fail();
   if (hipMalloc(&colk, 4 * ((size_t)nt + (size_t)total)) != hipSuccess) return fail();
   if (hipMemcpyAsync(colk, g->d_col, 4 * (size_t)nt, hipMemcpyDeviceToDevice, 0) != hipSuccess) return fail();
   const long long cblocks = std::min<long long>((nt * 8 + 255) / 256, (long long)g->cu_count * 64);
-  hipLaunchKernelGGL(inl_copy_kernel, dim3((unsigned)cblocks), dim3(256), 0, 0, nt, g->d_tdesc, off, lmax, nt, colk, tdk, stream ? ttag : nullptr, loff, tdl);
-  if (stream)
-    hipLaunchKernelGGL(inl_offsets_kernel, dim3((unsigned)((nv1 + 255) / 256)), dim3(256), 0, 0, g->nv, g->d_trp, off, loff, krp, trpl);
+  hipLaunchKernelGGL(inl_copy_kernel, dim3((unsigned)cblocks), dim3(256), 0, 0, nt, g->d_tdesc, off, lmax, nt, colk, tdk);
   if (hipDeviceSynchronize() != hipSuccess) return fail();
   (void)hipFree(off);
-  if (loff) (void)hipFree(loff);
   g->d_colk = colk;
   g->d_tdesck = tdk;
-  g->d_kst_rp = krp;
-  g->d_trpl = trpl;
-  g->d_tdescl = tdl;
   g->n_inline_keys = total;
 }
 
@@ -792,7 +817,7 @@ __device__ __forceinline__ void task_walk(const TaskWalk &w, F f) {
 
 template <bool PLACE>
 __global__ __launch_bounds__(256) void task_rows_kernel(const TaskWalk w, int *__restrict__ cnt /* PLACE: the cursors */, const int *__restrict__ trp,
-                                                         int2 *__restrict__ tdesc, int *__restrict__ tedge, unsigned char *__restrict__ ttag) {
+                                                         int2 *__restrict__ tdesc, int *__restrict__ tedge) {
   __shared__ int hist[kHubWin];
   __shared__ int hbase[PLACE ? kHubWin : 1];
   for (int h = threadIdx.x; h < kHubWin; h += 256) hist[h] = 0;
@@ -801,7 +826,6 @@ __global__ __launch_bounds__(256) void task_rows_kernel(const TaskWalk w, int *_
   auto put = [&](const int slot, const int host, const int e, const int ru, const int du, const int2 dv, const int tail, const bool u_hosts) {
     tdesc[slot] = u_hosts ? dv : (w.topo ? make_int2(e + 1, tail) : make_int2(ru, du));
     tedge[slot] = e;
-    ttag[slot] = (unsigned char)(host & 255);
   };
   task_walk(w, [&](const bool act, const int u, const int i, const int e, const int ru, const int du, const int2 dv, const int tail, const bool u_hosts) {
     // (i) the tasks the row hosts itself: one atomic per 8-lane group
@@ -849,6 +873,201 @@ __global__ __launch_bounds__(256) void task_rows_kernel(const TaskWalk w, int *_
   });
 }
 
+// ---- the key stream of the triangle count, built DIRECTLY (round 4: until then from the task lists above -- every task placed as a 13-byte
+// record by scattered stores, three scans over the edges, the records read back to copy their keys: 7.9 of the 18 ms a first triangle count
+// of R-MAT-22 took, 43 of 119 on R-MAT-24).  The same two walks with one packed counter per host -- keys of the short lists in the low
+// 32 bits, tasks with longer lists in the high 32: pass 1 counts, two scans over the VERTICES give the hosts' offsets, pass 2 reserves a
+// task's place with the same atomic and writes the keys (tagged with the host's low byte) or the {start, length} of a longer list where
+// they stay.  A group of eight lanes copies the short lists of its eight tasks together, eight keys a step.  The order of a host's keys
+// is the order of arrival: the kernel looks every key up on its own.
+static bool keystream_possible(const gm_graph *g) {  // ids must leave bits 24..31 to the host tag
+  return g->nv <= (1 << 24) && !getenv("GM_TC_NO_KEY_STREAM");
+}
+struct KeyCopy { int src, dst, len; unsigned tag; };
+template <bool PLACE>
+__global__ __launch_bounds__(256) void kst_rows_kernel(const TaskWalk w, const int lmax, unsigned long long *__restrict__ cnt /* PLACE: the cursors */,
+                                                        const int *__restrict__ kst_rp, const int *__restrict__ trpl, unsigned *__restrict__ kst,
+                                                        int2 *__restrict__ tdescl) {
+  __shared__ unsigned long long hist[kHubWin];
+  for (int h = threadIdx.x; h < kHubWin; h += 256) hist[h] = 0ull;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, sub = lane & 7, g8 = lane & ~7;
+  // the list a task streams, and its weight in the packed counters
+  auto task_list = [&](const bool act, const int e, const int ru, const int du, const int2 dv, const int tail, const bool u_hosts, int &start, int &len) {
+    start = u_hosts ? dv.x : (w.topo ? e + 1 : ru);
+    len = !act ? 0 : (u_hosts ? dv.y : (w.topo ? tail : du));
+    return len == 0 ? 0ull : (len <= lmax ? (unsigned long long)len : (1ull << 32));
+  };
+  auto copy_group = [&](const KeyCopy c) {  // c.len = 0: nothing of this lane's
+    for (int j = 0; j < 8; ++j) {
+      const int lj = __shfl(c.len, g8 + j), sj = __shfl(c.src, g8 + j), dj = __shfl(c.dst, g8 + j);
+      const unsigned tj = (unsigned)__shfl((int)c.tag, g8 + j);
+      for (int i = sub; i < lj; i += 8) kst[dj + i] = (unsigned)w.col[sj + i] | tj;
+    }
+  };
+  auto put = [&](const bool mine, const int host, const unsigned long long pos, const int start, const int len) {
+    KeyCopy c{start, 0, 0, (unsigned)(host & 255) << 24};
+    if (mine) {
+      if (len > lmax) tdescl[trpl[host] + (int)(pos >> 32)] = make_int2(start, len);
+      else { c.dst = kst_rp[host] + (int)(unsigned)pos; c.len = len; }
+    }
+    copy_group(c);
+  };
+  task_walk(w, [&](const bool act, const int u, const int i, const int e, const int ru, const int du, const int2 dv, const int tail, const bool u_hosts) {
+    int start, len;
+    const unsigned long long wgt = task_list(act, e, ru, du, dv, tail, u_hosts, start, len);
+    // (i) the tasks the row hosts itself: one atomic per 8-lane group (an inclusive scan of the packed weights over the group)
+    const unsigned long long mine = u_hosts ? wgt : 0ull;
+    unsigned long long incl = mine;
+#pragma unroll
+    for (int d = 1; d < 8; d <<= 1) {
+      const unsigned lo = (unsigned)__shfl((int)(unsigned)incl, lane - d), hi = (unsigned)__shfl((int)(unsigned)(incl >> 32), lane - d);
+      if (sub >= d) incl += ((unsigned long long)hi << 32) | lo;
+    }
+    const unsigned long long total = ((unsigned long long)(unsigned)__shfl((int)(unsigned)(incl >> 32), g8 + 7) << 32) | (unsigned)__shfl((int)(unsigned)incl, g8 + 7);
+    unsigned long long ubase = 0ull;
+    if (total != 0ull && sub == 0) ubase = atomicAdd(&cnt[u], total);
+    // (ii) in-edge tasks: the target hosts -- a hub through the LDS histogram, anybody else through its global cursor
+    int host = u;
+    unsigned long long pos = 0ull;
+    bool now = mine != 0ull;
+    if (!u_hosts && wgt != 0ull) {
+      host = w.col[e];
+      if (host >= w.hub0) atomicAdd(&hist[host - w.hub0], wgt);
+      else { pos = atomicAdd(&cnt[host], wgt); now = true; }
+    }
+    if (PLACE) {
+      if (total != 0ull) {
+        ubase = ((unsigned long long)(unsigned)__shfl((int)(unsigned)(ubase >> 32), g8) << 32) | (unsigned)__shfl((int)(unsigned)ubase, g8);
+        if (mine != 0ull) pos = ubase + incl - mine;
+      }
+      put(now, host, pos, start, len);
+    }
+  });
+  __syncthreads();
+  for (int h = threadIdx.x; h < kHubWin; h += 256) {
+    const unsigned long long c = hist[h];
+    if (c) {
+      const unsigned long long b = atomicAdd(&cnt[w.hub0 + h], c);  // pass 1: the count; pass 2: this workgroup's range among the hub's
+      if (PLACE) hist[h] = b;
+    }
+  }
+  if (!PLACE || w.hub0 >= w.nv) return;
+  __syncthreads();
+  task_walk(w, [&](const bool act, const int u, const int i, const int e, const int ru, const int du, const int2 dv, const int tail, const bool u_hosts) {
+    int start, len;
+    const unsigned long long wgt = task_list(act, e, ru, du, dv, tail, u_hosts, start, len);
+    int host = 0;
+    unsigned long long pos = 0ull;
+    bool now = false;
+    if (!u_hosts && wgt != 0ull) {
+      host = w.col[e];
+      if (host >= w.hub0) { pos = atomicAdd(&hist[host - w.hub0], wgt); now = true; }
+    }
+    put(now, host, pos, start, len);
+  });
+}
+__global__ __launch_bounds__(256) void kst_unpack_kernel(int nv, const unsigned long long *__restrict__ cnt, unsigned long long *__restrict__ keys, int *__restrict__ longs) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v > nv) return;
+  const unsigned long long c = v < nv ? cnt[v] : 0ull;
+  keys[v] = c & 0xffffffffull;
+  longs[v] = (int)(c >> 32);
+}
+__global__ __launch_bounds__(256) void kst_narrow_kernel(int nv, const unsigned long long *__restrict__ in, int *__restrict__ out) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v <= nv) out[v] = (int)in[v];
+}
+
+// d_kst / d_kst_rp / d_trpl / d_tdescl of a handle (gm_host.h): GM_OK also when the handle cannot have them (ids beyond 24 bits, keys
+// beyond the 32-bit index space at every list limit) -- *built says which
+int ensure_keystream(gm_graph *g, bool *built) {
+  *built = g->d_kst_rp != nullptr;
+  if (*built || g->kst_state == 2 || g->ne == 0) return GM_OK;
+  {
+    const int rc = ensure_edesc(g);  // (takes the lock itself)
+    if (rc) return rc;
+  }
+  std::lock_guard<std::mutex> lk(g->mu);
+  *built = g->d_kst_rp != nullptr;
+  if (*built || g->kst_state == 2) return GM_OK;
+  int lmax = GM_TC_INLINE_MAX_DEFAULT;
+  if (const char *e = getenv("GM_TC_INLINE_MAX")) lmax = atoi(e);  // (sweeps)
+  if (!keystream_possible(g) || lmax < 4) {
+    g->kst_state = 2;
+    return GM_OK;
+  }
+  SetupTimer timer;
+  HIP_TRY(hipSetDevice(g->device));
+  const size_t nv1 = (size_t)g->nv + 1;
+  PoolScope pool(g);
+  ScanTemp tmp;
+  bool topo = false;
+  {
+    const int rc = graph_is_topological(g, &topo);
+    if (rc) return rc;
+    if (getenv("GM_TC_NO_TRIM")) topo = false;  // (A/B: whole lists streamed on a topologically numbered DAG too)
+  }
+  DevBuf<unsigned long long> cnt, keys, keyoff;
+  DevBuf<int> longs;
+  HIP_TRY(cnt.alloc(nv1));
+  HIP_TRY(keys.alloc(nv1));
+  HIP_TRY(keyoff.alloc(nv1));
+  HIP_TRY(longs.alloc(nv1));
+  // (few, fat workgroups where a hub window exists: a workgroup's LDS histogram of the hub hosts pays when it sees many rows)
+  const long long blocks = std::min<long long>(((long long)g->nv * 8 + 255) / 256, (long long)g->cu_count * (topo ? 4 : 64));
+  TaskWalk tw;
+  tw.nv = g->nv; tw.stage_max = kTctStageMax; tw.topo = topo ? 1 : 0;
+  tw.hub0 = topo ? std::max(0, g->nv - kHubWin) : g->nv;
+  tw.rp = g->d_rp; tw.col = g->d_col; tw.edesc = g->d_edesc;
+  int *krp = nullptr, *trpl = nullptr;
+  unsigned *kst = nullptr;
+  int2 *tdl = nullptr;
+  auto fail = [&](hipError_t e, const char *what) {
+    for (void *q : {(void *)krp, (void *)trpl, (void *)kst, (void *)tdl})
+      if (q) (void)hipFree(q);
+    return hip_fail(e, what, __FILE__, __LINE__);
+  };
+  hipError_t e = hipSuccess;
+  if ((e = hipMalloc(&krp, sizeof(int) * nv1)) != hipSuccess || (e = hipMalloc(&trpl, sizeof(int) * nv1)) != hipSuccess) return fail(e, "hipMalloc(key stream offsets)");
+  unsigned long long total = 0;
+  int nlong = 0;
+  for (;;) {  // the stream is indexed with 32 bits: halve the limit of a "short" list until it fits
+    if ((e = hipMemsetAsync(cnt.p, 0, sizeof(unsigned long long) * nv1, 0)) != hipSuccess) return fail(e, "hipMemsetAsync");
+    hipLaunchKernelGGL((kst_rows_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, 0, tw, lmax, cnt.p, nullptr, nullptr, nullptr, nullptr);
+    hipLaunchKernelGGL(kst_unpack_kernel, dim3((unsigned)((nv1 + 255) / 256)), dim3(256), 0, 0, g->nv, cnt.p, keys.p, longs.p);
+    if ((e = dev_exclusive_sum(tmp, keys.p, keyoff.p, nv1)) != hipSuccess) return fail(e, "ExclusiveSum");
+    if ((e = dev_exclusive_sum(tmp, longs.p, trpl, nv1)) != hipSuccess) return fail(e, "ExclusiveSum");
+    if ((e = hipMemcpy(&total, keyoff.p + g->nv, 8, hipMemcpyDeviceToHost)) != hipSuccess) return fail(e, "hipMemcpy");
+    if ((e = hipMemcpy(&nlong, trpl + g->nv, sizeof(int), hipMemcpyDeviceToHost)) != hipSuccess) return fail(e, "hipMemcpy");
+    if (total < 0x7fffff00ull) break;
+    lmax >>= 1;
+    if (lmax < 4) {
+      (void)hipFree(krp);
+      (void)hipFree(trpl);
+      g->kst_state = 2;
+      return GM_OK;
+    }
+  }
+  setup_trace("key stream: count pass + scans");
+  hipLaunchKernelGGL(kst_narrow_kernel, dim3((unsigned)((nv1 + 255) / 256)), dim3(256), 0, 0, g->nv, keyoff.p, krp);
+  if ((e = hipMalloc(&kst, sizeof(unsigned) * (size_t)std::max<unsigned long long>(total, 1))) != hipSuccess) return fail(e, "hipMalloc(key stream)");
+  if ((e = hipMalloc(&tdl, sizeof(int2) * (size_t)std::max(nlong, 1))) != hipSuccess) return fail(e, "hipMalloc(long lists)");
+  if ((e = hipMemsetAsync(cnt.p, 0, sizeof(unsigned long long) * nv1, 0)) != hipSuccess) return fail(e, "hipMemsetAsync");
+  hipLaunchKernelGGL((kst_rows_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, 0, tw, lmax, cnt.p, krp, trpl, kst, tdl);
+  if ((e = hipGetLastError()) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess) return fail(e, "kst_rows_kernel");
+  setup_trace("key stream: place pass");
+  g->d_kst = kst;
+  g->d_trpl = trpl;
+  g->d_tdescl = tdl;
+  g->n_inline_keys = total;
+  g->n_long_tasks = nlong;
+  g->d_kst_rp = krp;
+  g->setup.table_ms += timer.ms();
+  *built = true;
+  return GM_OK;
+}
+
 int ensure_tasklists(gm_graph *g, bool /*with_edges*/) {
   // The tasks' own entries (tedge, 4 B per edge: what the edge supports need) are always built with the lists.  Round 3 built them on
   // demand by freeing and rebuilding trp / tdesc -- under a launch of another thread that had already copied those pointers.
@@ -864,7 +1083,6 @@ int ensure_tasklists(gm_graph *g, bool /*with_edges*/) {
   const size_t ne = (size_t)g->ne, nv1 = (size_t)g->nv + 1;
   PoolScope pool(g);
   DevBuf<int> cnt;
-  DevBuf<unsigned char> ttag;
   ScanTemp tmp;
   bool topo = false;
   {
@@ -872,8 +1090,8 @@ int ensure_tasklists(gm_graph *g, bool /*with_edges*/) {
     if (rc) return rc;
     if (getenv("GM_TC_NO_TRIM")) topo = false;  // (A/B: whole lists streamed on a topologically numbered DAG too)
   }
+  setup_trace("tasks: sorted / topological check");
   HIP_TRY(cnt.alloc(nv1));
-  HIP_TRY(ttag.alloc(ne));
   HIP_TRY(hipMemsetAsync(cnt.p, 0, sizeof(int) * nv1, 0));
   // (few, fat workgroups: a workgroup's LDS histogram of the hub hosts pays when it sees many rows)
   // (where no hub window exists -- a DAG that is not numbered topologically -- many thin workgroups: power-law LJ-size 30.9 vs 9.8 ms)
@@ -882,7 +1100,8 @@ int ensure_tasklists(gm_graph *g, bool /*with_edges*/) {
   tw.nv = g->nv; tw.stage_max = kTctStageMax; tw.topo = topo ? 1 : 0;
   tw.hub0 = topo ? std::max(0, g->nv - kHubWin) : g->nv;
   tw.rp = g->d_rp; tw.col = g->d_col; tw.edesc = g->d_edesc;
-  hipLaunchKernelGGL((task_rows_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, 0, tw, cnt.p, nullptr, nullptr, nullptr, nullptr);
+  hipLaunchKernelGGL((task_rows_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, 0, tw, cnt.p, nullptr, nullptr, nullptr);
+  setup_trace("tasks: count pass");
   int *trp = nullptr, *tedge = nullptr;
   int2 *td = nullptr;
   HIP_TRY(hipMalloc(&trp, sizeof(int) * nv1));
@@ -892,8 +1111,9 @@ int ensure_tasklists(gm_graph *g, bool /*with_edges*/) {
   if (e == hipSuccess) e = hipMemsetAsync(td, 0, sizeof(int2) * ne, 0);  // (the edges of rows beyond the stage are no tasks: empty descriptors at the end)
   if (e == hipSuccess) e = hipMemsetAsync(tedge, 0, sizeof(int) * ne, 0);
   if (e == hipSuccess) e = hipMemsetAsync(cnt.p, 0, sizeof(int) * nv1, 0);
+  setup_trace("tasks: scan, allocations, clears");
   if (e == hipSuccess) {
-    hipLaunchKernelGGL((task_rows_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, 0, tw, cnt.p, trp, td, tedge, ttag.p);
+    hipLaunchKernelGGL((task_rows_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, 0, tw, cnt.p, trp, td, tedge);
     e = hipDeviceSynchronize();
   }
   if (e != hipSuccess) {
@@ -905,7 +1125,9 @@ int ensure_tasklists(gm_graph *g, bool /*with_edges*/) {
   g->d_trp = trp;
   g->d_tdesc = td;
   g->d_tedge = tedge;
-  build_inline_copies(g, tmp, ttag.p);
+  setup_trace("tasks: place pass");
+  if (!keystream_possible(g)) build_inline_copies(g, tmp);  // (a handle that cannot have the key stream: task-major copies of the short lists)
+  setup_trace("tasks: inline copies");
   g->setup.table_ms += timer.ms();
   return GM_OK;
 }
@@ -949,6 +1171,7 @@ int ensure_edesc(gm_graph *g) {
   const long long blocks = std::min<long long>((g->ne + 255) / 256, (long long)g->cu_count * 32);
   hipLaunchKernelGGL(edesc_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, g->ne, g->d_rp, g->d_col, d);
   hipError_t e = hipDeviceSynchronize();
+  setup_trace("edge descriptors");
   if (e != hipSuccess) { (void)hipFree(d); return hip_fail(e, "edesc_kernel", __FILE__, __LINE__); }
   g->d_edesc = d;
   g->setup.table_ms += timer.ms();
@@ -1340,6 +1563,8 @@ int get_clique_plan(gm_graph *g, int rank, int world, int policy, int target, un
     const long long n = (long long)tb->n;
     long long first = 0, step = 1, count = 0;
     if (policy == GM_PART_VERTEX) {
+      const int rc = table_host_views(g, tb);
+      if (rc) return rc;
       const long long vlo = (long long)g->nv * rank / world, vhi = (long long)g->nv * (rank + 1) / world;
       auto first_chunk_at = [&](long long v) {
         long long lo = 0, hi = n;
