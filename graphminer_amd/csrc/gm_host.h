@@ -300,6 +300,8 @@ struct gm_graph {
   hipStream_t aux_stream[3] = {nullptr, nullptr, nullptr};  // class kernels that cannot fill the chip run beside the others (run_pattern)
   hipEvent_t aux_done[3] = {nullptr, nullptr, nullptr};
   TempPool pool;  // temporaries of the setup paths (PoolScope)
+  gm_graph *pool_owner = nullptr;  // a derived handle (renumbered copy, cached orientation) borrows its owner's pool: the owner outlives it,
+                                   // and one caller works on a handle family at a time -- a pool of its own is ~0.8 ms of hipMalloc
   gm_setup_times setup = {0, 0, 0, 0, 0};  // accumulated pre-processing time of this handle (gm_graph_setup_times)
   std::mutex mu;
   std::mutex dag_mu;  // guards the lazy creation of dag_cache (ensure_dag_cache, gm_launch.hip)
@@ -315,6 +317,7 @@ struct PoolScope {
   TempPool *prev;
   size_t mark;
   explicit PoolScope(gm_graph *g_) : g(g_), prev(g_temp_pool) {
+    while (g->pool_owner) g = g->pool_owner;
     TempPool &pl = g->pool;
     if (!pl.base && !getenv("GM_NO_TEMP_POOL")) {
       const size_t need = std::min<size_t>((size_t)256 << 20, (size_t)24 * ((size_t)g->nv + 1) + ((size_t)16 << 20));
@@ -336,6 +339,30 @@ struct SetupTimer {
   std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
   double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
 };
+
+// Device-to-host copies of the O(chunks) / O(hub rows) arrays of the setup paths.  The FIRST device-to-host copy of 64 KB or more in a
+// process costs 8 - 10 ms of one-time initialisation inside the HIP runtime (pageable or pinned destination alike; copies of 16 KB
+// do not take that path: 15 us each -- measured with a bare HIP program, profiles/r04/ab_setup_first_call.txt).  Up to 1 MB goes in
+// 16 KB pieces, so a first call on a fresh process does not pay for it; larger copies are worth the real path.
+inline hipError_t copy_to_host(void *dst, const void *src, size_t bytes) {
+  constexpr size_t kPiece = (size_t)16 << 10;
+  if (bytes > ((size_t)1 << 20)) return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost);
+  for (size_t o = 0; o < bytes; o += kPiece) {
+    const hipError_t e = hipMemcpy((char *)dst + o, (const char *)src + o, std::min(kPiece, bytes - o), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+inline hipError_t copy_to_device(void *dst, const void *src, size_t bytes) {  // (the same one-time cost the other way round)
+  constexpr size_t kPiece = (size_t)16 << 10;
+  if (bytes > ((size_t)1 << 20)) return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+  for (size_t o = 0; o < bytes; o += kPiece) {
+    const hipError_t e = hipMemcpy((char *)dst + o, (const char *)src + o, std::min(kPiece, bytes - o), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
 
 // GM_SETUP_TRACE: wall-clock marks of the setup steps on stderr, each after a device synchronisation (where do the milliseconds of a
 // first call go: kernels, allocations, copies back?).  Off: one predictable branch.

@@ -467,7 +467,8 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
   HIP_TRY(hipMemset(d_ticks, 0, sizeof(unsigned long long) * std::max<size_t>(tab->n, 1)));
   p.chunk_ticks = d_ticks;
 #endif
-  if (use_wide && plan && plan->core_base >= 0) {  // (4-clique: the gathered build runs beside the streamed one on a side stream, below)
+  // (a side stream is a hardware queue: ~17 ms each to create -- GM_SETUP_TRACE, the first 4-clique call spent 35 ms here for a variant that is off)
+  if (use_wide && plan && plan->core_base >= 0 && getenv("GM_CLIQUE_SIDE_STREAM")) {  // (4-clique A/B: the gathered build beside the streamed one, below)
     for (int i = 0; i < 2; ++i) {
       if (!g->aux_stream[i]) {
         HIP_TRY(hipStreamCreateWithFlags(&g->aux_stream[i], hipStreamNonBlocking));
@@ -476,15 +477,10 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
     }
   }
   if (use_classes) {
-    // everything the class launches may allocate or create, before the timer starts (a first call used to time hipMalloc and
-    // hipStreamCreate between its two events): side streams + their events, and the giant-row kernel's scratch -- per workgroup,
-    // where the pieces of the row cut the partner lists of its chunk, kGiantEdges ints per piece (giant_bounds)
-    for (int i = 0; i < 3; ++i) {
-      if (!g->aux_stream[i]) {
-        HIP_TRY(hipStreamCreateWithFlags(&g->aux_stream[i], hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&g->aux_done[i], hipEventDisableTiming));
-      }
-    }
+    // what the class launches may allocate, before the timer starts: the giant-row kernel's scratch -- per workgroup, where the pieces of
+    // the row cut the partner lists of its chunk, kGiantEdges ints per piece (giant_bounds).  (The side streams are created by the first
+    // launch that sends a class to one -- a class whose chunks cannot fill the chip: small graphs, shares of a rank -- and that launch's
+    // time then includes it; creating all three up front cost every first call ~50 ms.)
     if (tab_cls[3] && tab_cls[3]->n > 0) {
       const size_t need = (size_t)giant_scratch_words(g->max_deg) * sizeof(unsigned) * (size_t)g->cu_count * (size_t)giant_per_cu();
       if (need > g->scratch_bytes) {
@@ -518,6 +514,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
       my_edges += plan->wide_edges;
     }
     HIP_TRY(hipMemsetAsync(g->d_wide_queue, 0, 65536, stream));
+    setup_trace("launch: clique prologue");
     const bool prof = getenv("GM_WIDE_PROFILE") != nullptr;
     unsigned long long *d_prof = nullptr;
     if (prof) {
@@ -554,6 +551,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
           HIP_TRY(hipStreamWaitEvent(gs, g->aux_done[1], 0));
         }
         HIP_TRY(launch_cgather(cg, ggrid, gs));
+        setup_trace("launch: core gather");
         if (side) {
           HIP_TRY(hipEventRecord(g->aux_done[0], gs));
           gather_joined = true;
@@ -573,6 +571,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
         pw.flags = p.flags;
         const int bgrid = (int)std::max<long long>(1, std::min<long long>(pw.count, (long long)g->cu_count * cbuild_per_cu(plan->stage)));
         if (pw.count > 0) HIP_TRY(launch_cbuild(pw, plan->stage, bgrid, stream));
+        setup_trace("launch: streamed build");
         plan_chunks += (uint64_t)pw.count;
       }
       if (rd.n_count > 0) {
@@ -591,6 +590,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
         cs.topo = plan->topo ? 1 : 0;
         const int sgrid = (int)std::max<long long>(1, std::min<long long>(cs.count, (long long)g->cu_count * 8));
         HIP_TRY(launch_clique_small(cs, sgrid, stream));
+        setup_trace("launch: narrow counts");
         plan_chunks += (uint64_t)rd.n_count;
       }
       if (gather_joined) HIP_TRY(hipStreamWaitEvent(stream, g->aux_done[0], 0));  // the wide vertices' rows are complete
@@ -612,6 +612,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
         const int per_cu_c = (int)std::max<size_t>(1, std::min<size_t>((160 * 1024) / clique_mma_lds_bytes(cls), (size_t)(2048 / clique_mma_threads(cls))));
         const int cgrid = (int)std::max<long long>(1, std::min<long long>((long long)c.count * (cls == 2 ? 8 : 1), (long long)g->cu_count * per_cu_c));
         HIP_TRY(launch_clique_mma(cls, c, cgrid, stream));
+        setup_trace("launch: matrix-core counts");
       }
       for (int cls = 2; cls >= 0 && valu_counts; --cls) {  // X and L (one workgroup per CU) before S
         CliqueCountParams c;
@@ -660,6 +661,10 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
       *ws = stream;
       const bool side = streams_env ? atoi(streams_env) != 0 : count < full_grid;
       if (!side) return GM_OK;
+      if (!g->aux_stream[cls - 1]) {
+        HIP_TRY(hipStreamCreateWithFlags(&g->aux_stream[cls - 1], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&g->aux_done[cls - 1], hipEventDisableTiming));
+      }
       *ws = g->aux_stream[cls - 1];
       HIP_TRY(hipStreamWaitEvent(*ws, ctx.evp[0], 0));  // after the counters were zeroed and the timer started
       return GM_OK;
@@ -1305,6 +1310,7 @@ static int ensure_dag_cache(gm_graph *g) {
   gm_graph *dag = nullptr;
   const int rc = gm_graph_orient(g, &dag);
   if (rc) return rc;
+  dag->pool_owner = g;
   g->dag_cache = dag;
   return GM_OK;
 }

@@ -438,8 +438,8 @@ static int build_table_device(gm_graph *g, ChunkTable &t, bool sym_table, double
         HIP_TRY(degs.alloc((size_t)m));
         hipLaunchKernelGGL(gather_deg_kernel, blocks(m), dim3(256), 0, 0, m, sel.p, g->d_rp, degs.p);
         std::vector<int> hv((size_t)m), hd((size_t)m);
-        HIP_TRY(hipMemcpy(hv.data(), sel.p, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(hd.data(), degs.p, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost));
+        HIP_TRY(copy_to_host(hv.data(), sel.p, sizeof(int) * (size_t)m));
+        HIP_TRY(copy_to_host(hd.data(), degs.p, sizeof(int) * (size_t)m));
         std::vector<int> idx((size_t)m);  // (hub rows only: thousands at most)
         for (int i = 0; i < m; ++i) idx[(size_t)i] = i;
         std::stable_sort(idx.begin(), idx.end(), [&](int a_, int b_) { return hd[(size_t)a_] > hd[(size_t)b_]; });
@@ -450,7 +450,7 @@ static int build_table_device(gm_graph *g, ChunkTable &t, bool sym_table, double
         DevBuf<int> row_slot;
         DevBuf<unsigned> bitmaps;
         HIP_TRY(d_rows.alloc(nb));
-        HIP_TRY(hipMemcpy(d_rows.p, rows.data(), sizeof(int) * nb, hipMemcpyHostToDevice));
+        HIP_TRY(copy_to_device(d_rows.p, rows.data(), sizeof(int) * nb));
         HIP_TRY(row_slot.alloc((size_t)nv, true));  // (published to the bitmap set below)
         HIP_TRY(hipMemsetAsync(row_slot.p, 0xff, sizeof(int) * (size_t)nv, 0));  // -1
         hipLaunchKernelGGL(tab_rowslot_kernel, blocks((long long)nb), dim3(256), 0, 0, (int)nb, d_rows.p, row_slot.p);
@@ -494,14 +494,14 @@ int table_host_views(gm_graph *g, ChunkTable *t) {
   t->cost.resize(n);
   if (n) {
     std::vector<int> h_edges(n);
-    HIP_TRY(hipMemcpy(h_edges.data(), t->d_edges, sizeof(int) * n, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(t->first_vertex.data(), t->d_firstv, sizeof(int) * n, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(t->cost.data(), t->d_cost, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(copy_to_host(h_edges.data(), t->d_edges, sizeof(int) * n));
+    HIP_TRY(copy_to_host(t->first_vertex.data(), t->d_firstv, sizeof(int) * n));
+    HIP_TRY(copy_to_host(t->cost.data(), t->d_cost, sizeof(unsigned long long) * n));
     for (size_t i = 0; i < n; ++i) t->edge_prefix[i + 1] = t->edge_prefix[i] + (unsigned long long)h_edges[i];
     for (int m = 0; m < 2; ++m)
       if (t->d_order[m]) {
         t->order[m].resize(n);
-        HIP_TRY(hipMemcpy(t->order[m].data(), t->d_order[m], sizeof(int) * n, hipMemcpyDeviceToHost));
+        HIP_TRY(copy_to_host(t->order[m].data(), t->d_order[m], sizeof(int) * n));
       }
   }
   t->host_ready = true;
@@ -1015,7 +1015,9 @@ int ensure_keystream(gm_graph *g, bool *built) {
   HIP_TRY(keyoff.alloc(nv1));
   HIP_TRY(longs.alloc(nv1));
   // (few, fat workgroups where a hub window exists: a workgroup's LDS histogram of the hub hosts pays when it sees many rows)
-  const long long blocks = std::min<long long>(((long long)g->nv * 8 + 255) / 256, (long long)g->cu_count * (topo ? 4 : 64));
+  int per_cu = topo ? 8 : 64;  // (4 / 5 / 8 / 16 per CU: place pass of R-MAT-22 2.84 / 3.09 / 2.79 / 2.70 ms, R-MAT-24 15.3 / 18.1 / 15.0 / 15.0)
+  if (const char *e = getenv("GM_KST_WG_PER_CU")) per_cu = std::max(1, atoi(e));  // (sweeps)
+  const long long blocks = std::min<long long>(((long long)g->nv * 8 + 255) / 256, (long long)g->cu_count * per_cu);
   TaskWalk tw;
   tw.nv = g->nv; tw.stage_max = kTctStageMax; tw.topo = topo ? 1 : 0;
   tw.hub0 = topo ? std::max(0, g->nv - kHubWin) : g->nv;
@@ -1153,8 +1155,8 @@ int ensure_long_rows(gm_graph *g) {
     HIP_TRY(hipSetDevice(g->device));
     HIP_TRY(hipMalloc(&g->d_long_rows, sizeof(int) * rows.size()));
     HIP_TRY(hipMalloc(&g->d_long_prefix, sizeof(long long) * prefix.size()));
-    HIP_TRY(hipMemcpy(g->d_long_rows, rows.data(), sizeof(int) * rows.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(g->d_long_prefix, prefix.data(), sizeof(long long) * prefix.size(), hipMemcpyHostToDevice));
+    HIP_TRY(copy_to_device(g->d_long_rows, rows.data(), sizeof(int) * rows.size()));
+    HIP_TRY(copy_to_device(g->d_long_prefix, prefix.data(), sizeof(long long) * prefix.size()));
   }
   g->long_edges = prefix.back();
   g->n_long_rows = (int)rows.size();
@@ -1394,6 +1396,7 @@ int ensure_core_bitmap(gm_graph *g) {
   HIP_TRY(hipDeviceSynchronize());
   g->core_h = h;
   g->core_base = base;
+  setup_trace("clique: core bitmap");
   g->core_state = 1;
   g->setup.table_ms += timer.ms();
   return GM_OK;
@@ -1512,6 +1515,7 @@ int get_clique_plan(gm_graph *g, int rank, int world, int policy, int target, un
   {
     const int rc = ensure_edesc(g);  // (the task records read the targets' {start, length} from the edge descriptors)
     if (rc) return rc;
+    setup_trace("clique: narrow table + edge descriptors");
   }
   SetupTimer timer;
   PoolScope pool(g);  // (the per-vertex arrays of the rounds)
@@ -1593,9 +1597,10 @@ int get_clique_plan(gm_graph *g, int rank, int world, int policy, int target, un
     HIP_TRY(degs.alloc((size_t)wcount));
     hipLaunchKernelGGL(wide_share_kernel, blocks(wcount), dim3(256), 0, 0, (int)wcount, (long long)wfirst, (long long)wstep, g->d_wide_sorted, g->d_rp, pl.d_verts, degs.p);
     pl.verts.resize((size_t)wcount);
-    HIP_TRY(hipMemcpy(pl.verts.data(), pl.d_verts, sizeof(int) * (size_t)wcount, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(hd.data(), degs.p, sizeof(int) * (size_t)wcount, hipMemcpyDeviceToHost));
+    HIP_TRY(copy_to_host(pl.verts.data(), pl.d_verts, sizeof(int) * (size_t)wcount));
+    HIP_TRY(copy_to_host(hd.data(), degs.p, sizeof(int) * (size_t)wcount));
   }
+  setup_trace("clique: wide share to the host");
   // rounds within the arena budget: the narrow chunks first (in dequeue order), then the wide vertices (longest rows first)
   unsigned long long arena_mb = GM_WIDE_ARENA_MB;
   if (const char *e = getenv("GM_WIDE_ARENA_MB")) arena_mb = std::max(1ll, atoll(e));  // (tests: force several rounds)
@@ -1605,8 +1610,9 @@ int get_clique_plan(gm_graph *g, int rank, int world, int policy, int target, un
     DevBuf<unsigned long long> dcw;
     HIP_TRY(dcw.alloc((size_t)pl.n_count));
     hipLaunchKernelGGL(cb_chunk_words_kernel, blocks(pl.n_count), dim3(256), 0, 0, pl.n_count, pl.n_first, pl.n_step, pl.d_order, pl.tabN->d, g->d_rp, dcw.p);
-    HIP_TRY(hipMemcpy(cw.data(), dcw.p, sizeof(unsigned long long) * (size_t)pl.n_count, hipMemcpyDeviceToHost));
+    HIP_TRY(copy_to_host(cw.data(), dcw.p, sizeof(unsigned long long) * (size_t)pl.n_count));
   }
+  setup_trace("clique: words of the narrow chunks to the host");
   std::vector<int> cls_slots, mcls_slots;
   {
     long long c0 = 0;
@@ -1651,15 +1657,18 @@ int get_clique_plan(gm_graph *g, int rank, int world, int policy, int target, un
     }
   }
   HIP_TRY(hipMalloc(&pl.d_cls_slots, sizeof(int) * std::max<size_t>(cls_slots.size(), 1)));
-  if (!cls_slots.empty()) HIP_TRY(hipMemcpy(pl.d_cls_slots, cls_slots.data(), sizeof(int) * cls_slots.size(), hipMemcpyHostToDevice));
+  setup_trace("clique: rounds (host loop)");
+  if (!cls_slots.empty()) HIP_TRY(copy_to_device(pl.d_cls_slots, cls_slots.data(), sizeof(int) * cls_slots.size()));
   HIP_TRY(hipMalloc(&pl.d_mcls_slots, sizeof(int) * std::max<size_t>(mcls_slots.size(), 1)));
-  if (!mcls_slots.empty()) HIP_TRY(hipMemcpy(pl.d_mcls_slots, mcls_slots.data(), sizeof(int) * mcls_slots.size(), hipMemcpyHostToDevice));
+  if (!mcls_slots.empty()) HIP_TRY(copy_to_device(pl.d_mcls_slots, mcls_slots.data(), sizeof(int) * mcls_slots.size()));
+  setup_trace("clique: wide list, classes, rounds (host)");
   unsigned long long need_words = 0;
   for (size_t r = 0; r < pl.rounds.size(); ++r) {
     const int rc = build_clique_round(g, pl, pl.rounds[r], tmp);
     if (rc) { free_clique_plan(pl); return rc; }
     need_words = std::max(need_words, pl.rounds[r].words);
   }
+  setup_trace("clique: rounds built");
   const size_t need = (size_t)need_words * 4;
   if (need > g->wide_mat_bytes) {
     if (g->d_wide_mat) (void)hipFree(g->d_wide_mat);
@@ -1669,6 +1678,7 @@ int get_clique_plan(gm_graph *g, int rank, int world, int policy, int target, un
     g->wide_mat_bytes = need;
   }
   if (!g->d_wide_queue) HIP_TRY(hipMalloc(&g->d_wide_queue, 65536));
+  setup_trace("clique: arena");
   HIP_TRY(hipDeviceSynchronize());
   std::lock_guard<std::mutex> lk(g->mu);
   g->clique_plans.push_back(std::move(pl));
