@@ -197,8 +197,8 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
   // rows of 1025 .. 2048 entries need it: a graph that has such rows runs TWO tables -- hosts with rows <= 1024 on the 1024-entry kernel,
   // the others on the 2048-entry one (own dequeue word).  GM_TCT_STAGE_BIG: the 2048-entry stage for every host (A/B).
   const bool stage_big_all = getenv("GM_TCT_STAGE_BIG") != nullptr;
-  const bool split_stage = use_tct && g->max_deg > kStageCap && !stage_big_all && !getenv("GM_TCT_NO_SPLIT_STAGE");
-  const int tct_stage = ((g->max_deg <= kStageCap && !stage_big_all) || split_stage) ? kStageCap : kTctStageMax;
+  bool split_stage = use_tct && g->max_deg > kStageCap && !stage_big_all && !getenv("GM_TCT_NO_SPLIT_STAGE");
+  int tct_stage = ((g->max_deg <= kStageCap && !stage_big_all) || split_stage) ? kStageCap : kTctStageMax;
   // (rows beyond the 2048-entry stage host nothing: their out-edges are the tasks of the chunked kernel, on a table of those rows only)
   const bool tct_long = use_tct && g->max_deg > kTctStageMax;
   const unsigned long long tct_part = use_tct ? task_part_cap(g, world) : 0ull;
@@ -241,6 +241,24 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
   }
   if (support && !sup_part && !g->d_sup) HIP_TRY(hipMalloc(&g->d_sup, sizeof(unsigned) * (size_t)std::max<long long>(g->ne, 1)));
   setup_trace("run_pattern: task lists");
+  // the hosts with rows of 1025 .. 2048 entries, on the 2048-entry kernel -- when a rank's share of them can fill the chip about twice: the two
+  // launches follow each other on the stream, and the second waits for the first one's last chunk.  R-MAT-24 has 8.5 K such chunks with a
+  // third of all keys: split / one table, ms per rank at world 1 / 2 / 4 / 8: TC 32.3 / 16.1 / 9.26 / 5.20 against 36.2 / 18.2 / 9.30 / 4.82,
+  // edge supports - / 51.0 / 26.0 / 16.7 against - / 60.5 / 30.4 / 15.5 (profiles/r04/ab_split_stage.txt).  GM_TCT_SPLIT_ALWAYS: at every world.
+  ChunkTable *tab_big = nullptr;
+  if (split_stage) {
+    RowFilter rb;
+    rb.tct = 1;
+    rb.only_lo = kStageCap;
+    rb.only_hi = kTctStageMax;
+    const int rc_b = get_table(g, target, true, 0, part_cap, kTctStageMax, &tab_big, rb, kBitmapMinDeg);
+    if (rc_b) return rc_b;
+    if ((long long)tab_big->n / world < 2ll * g->cu_count * 4 && !getenv("GM_TCT_SPLIT_ALWAYS")) {
+      tab_big = nullptr;
+      split_stage = false;
+      tct_stage = kTctStageMax;
+    }
+  }
   RowFilter rf;
   rf.tct = use_tct ? 1 : 0;
   if (tct_long) { rf.skip_lo = kTctStageMax; rf.skip_hi = 0x7fffffff; }
@@ -260,15 +278,6 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
   if (use_classes) { rf.skip_lo = cls_lo; rf.skip_hi = use_range ? 0x7fffffff : kStageCapBig; }
   int rc = get_table(g, target, !clique, clique ? kBitWords : 0, part_cap, use_tct ? tct_stage : stage_cap_of(pat), &tab, rf, use_classes ? kStageCapBig : kBitmapMinDeg);
   if (rc) return rc;
-  ChunkTable *tab_big = nullptr;  // the hosts with rows of 1025 .. 2048 entries, on the 2048-entry kernel
-  if (split_stage) {
-    RowFilter rb;
-    rb.tct = 1;
-    rb.only_lo = kStageCap;
-    rb.only_hi = kTctStageMax;
-    rc = get_table(g, target, true, 0, part_cap, kTctStageMax, &tab_big, rb, kBitmapMinDeg);
-    if (rc) return rc;
-  }
   ChunkTable *tab_long = nullptr;
   if (tct_long && !support) {
     RowFilter rl;

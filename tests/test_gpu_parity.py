@@ -953,3 +953,28 @@ def test_diamond_supports_with_rows_beyond_the_stage(dev):
         tt = total.to(torch.int32)
         per = n // world
         assert sum(diamond_support_finish(s, tt[r * per:(r + 1) * per].contiguous().data_ptr(), per) for r in range(world)) == want
+
+
+@pytest.mark.gpu
+def test_two_stage_tables_when_forced_on_a_small_graph(dev, monkeypatch):
+    """DAG rows of 1025 .. 2048 entries: a graph with enough of them runs TWO task tables -- hosts with rows <= 1024 on the 1024-entry
+    kernel, the others on the 2048-entry one (gm_launch.hip, split_stage).  The rule wants a rank's share of the second table to fill the
+    chip twice, which no test-sized graph does: GM_TCT_SPLIT_ALWAYS forces it.  Triangle count, 3-motif (formula) and the diamond from
+    the edge supports against the oracle, whole and as rank shares; then the same handle family without the switch (one table)."""
+    g = _dense_random_graph(2000, 0.9, 77)
+    osym = O.OGraph(g.row_ptr, g.col_idx)
+    odag = O.orient(osym)
+    dmax = int(np.diff(odag.row_ptr).max())
+    assert 1024 < dmax <= 2048
+    want_tc, want_dia = O.tc(odag), O.diamond(osym)
+    monkeypatch.setenv("GM_TCT_SPLIT_ALWAYS", "1")
+    with g.to_device(dev) as s:
+        d = s.orient()
+        assert TCSolver(d) == want_tc
+        assert sum(TCSolver(d, rank=r, world=3) for r in range(3)) == want_tc
+        assert SglSolver(s, "diamond") == want_dia
+    monkeypatch.delenv("GM_TCT_SPLIT_ALWAYS")
+    with g.to_device(dev) as s:
+        d = s.orient()
+        assert TCSolver(d) == want_tc
+        assert SglSolver(s, "diamond") == want_dia
