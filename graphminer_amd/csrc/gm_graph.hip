@@ -392,6 +392,7 @@ struct OrientSegT {
 
 template <class OffT>
 __global__ __launch_bounds__(256) void orient_short_kernel(int nv, const OffT *__restrict__ rp, const int *__restrict__ col,
+                                                           const int *__restrict__ sdeg /* symmetric degrees: one random load per entry instead of two offsets */,
                                                            int *__restrict__ new_deg, const int *__restrict__ new_rp,
                                                            int *__restrict__ new_col, int pass) {
   constexpr int G = 8, RPW = 64 / G;
@@ -415,7 +416,7 @@ __global__ __launch_bounds__(256) void orient_short_kernel(int nv, const OffT *_
       int d = 0;
       if (i < ds) {
         d = col[b + i];
-        keep = dag_keep(full, s, (int)(rp[d + 1] - rp[d]), d);
+        keep = dag_keep(full, s, sdeg[d], d);
       }
       const unsigned long long m = (__ballot(keep) >> (grp * G)) & 0xffull;
       if (pass && keep) new_col[ob + n + __popcll(m & ((1ull << gl) - 1ull))] = d;
@@ -428,8 +429,8 @@ __global__ __launch_bounds__(256) void orient_short_kernel(int nv, const OffT *_
 // one wave per segment; pass 0 adds the segment's count to its row's new degree (and keeps it per segment for the offsets)
 template <class OffT>
 __global__ __launch_bounds__(256) void orient_seg_kernel(int nseg, const OrientSegT<OffT> *__restrict__ segs, const OffT *__restrict__ rp,
-                                                         const int *__restrict__ col, int *__restrict__ seg_count, int *__restrict__ new_deg,
-                                                         int *__restrict__ new_col, int pass) {
+                                                         const int *__restrict__ col, const int *__restrict__ sdeg, int *__restrict__ seg_count,
+                                                         int *__restrict__ new_deg, int *__restrict__ new_col, int pass) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -443,7 +444,7 @@ __global__ __launch_bounds__(256) void orient_seg_kernel(int nseg, const OrientS
       int d = 0;
       if (i < q.end) {
         d = col[i];
-        keep = dag_keep(ds, q.row, (int)(rp[d + 1] - rp[d]), d);
+        keep = dag_keep(ds, q.row, sdeg[d], d);
       }
       const unsigned long long m = __ballot(keep);
       if (pass && keep) new_col[q.out + n + rank_below(m)] = d;
@@ -521,6 +522,12 @@ static int orient_impl(const gm_graph *sym, const OffT *rp_in, gm_graph **out) {
   const int nv = sym->nv;
   const unsigned vb = (unsigned)((nv + 256) / 256);  // blocks covering v = 0 .. nv
   ScanTemp tmp;
+  // the symmetric degrees first: the passes compare (degree, id) of both endpoints of every entry; the oriented handle keeps them (what
+  // the topological renumbering of this DAG sorts by -- get_relabeled mode 2)
+  int *sdeg = nullptr;
+  HIP_TRY(hipMalloc(&sdeg, sizeof(int) * (size_t)std::max(nv, 1)));
+  struct SdegGuard { int *&p; ~SdegGuard() { if (p) (void)hipFree(p); } } sdeg_guard{sdeg};
+  if (nv > 0) hipLaunchKernelGGL((symdeg_kernel<OffT>), dim3(vb), dim3(256), 0, 0, nv, rp_in, sdeg);
   // segment table of the long rows (device): counts -> exclusive scan -> fill
   DevBuf<int> nseg_of, seg_first, deg, segcnt;
   DevBuf<OrientSegT<OffT>> segs;
@@ -538,9 +545,9 @@ static int orient_impl(const gm_graph *sym, const OffT *rp_in, gm_graph **out) {
   HIP_TRY(hipMemsetAsync(deg.p, 0, sizeof(int) * ((size_t)nv + 1), 0));
   const int bs = std::max(1, std::min((nv + 31) / 32, sym->cu_count * 8));
   const int bl = std::max(1, std::min((nseg + 3) / 4, sym->cu_count * 8));
-  hipLaunchKernelGGL((orient_short_kernel<OffT>), dim3(bs), dim3(256), 0, 0, nv, rp_in, sym->d_col, deg.p, (const int *)nullptr, (int *)nullptr, 0);
+  hipLaunchKernelGGL((orient_short_kernel<OffT>), dim3(bs), dim3(256), 0, 0, nv, rp_in, sym->d_col, sdeg, deg.p, (const int *)nullptr, (int *)nullptr, 0);
   if (nseg)
-    hipLaunchKernelGGL((orient_seg_kernel<OffT>), dim3(bl), dim3(256), 0, 0, nseg, segs.p, rp_in, sym->d_col, segcnt.p, deg.p, (int *)nullptr, 0);
+    hipLaunchKernelGGL((orient_seg_kernel<OffT>), dim3(bl), dim3(256), 0, 0, nseg, segs.p, rp_in, sym->d_col, sdeg, segcnt.p, deg.p, (int *)nullptr, 0);
   setup_trace("orient: segments + degrees");
   // new offsets = exclusive scan of the new degrees (parallel_prefix_sum, include/scan.h:5-35)
   gm_graph *g = new gm_graph();
@@ -577,17 +584,15 @@ static int orient_impl(const gm_graph *sym, const OffT *rp_in, gm_graph **out) {
   setup_trace("orient: scan, max degree, allocations");
   // pass 1: compact
   if (nseg) hipLaunchKernelGGL((orient_segout_kernel<OffT>), dim3(vb), dim3(256), 0, 0, nv, rp_in, seg_first.p, segcnt.p, g->d_rp, segs.p);
-  hipLaunchKernelGGL((orient_short_kernel<OffT>), dim3(bs), dim3(256), 0, 0, nv, rp_in, sym->d_col, (int *)nullptr, g->d_rp, g->d_col, 1);
+  hipLaunchKernelGGL((orient_short_kernel<OffT>), dim3(bs), dim3(256), 0, 0, nv, rp_in, sym->d_col, sdeg, (int *)nullptr, g->d_rp, g->d_col, 1);
   if (nseg)
-    hipLaunchKernelGGL((orient_seg_kernel<OffT>), dim3(bl), dim3(256), 0, 0, nseg, segs.p, rp_in, sym->d_col, (int *)nullptr, (int *)nullptr, g->d_col, 1);
+    hipLaunchKernelGGL((orient_seg_kernel<OffT>), dim3(bl), dim3(256), 0, 0, nseg, segs.p, rp_in, sym->d_col, sdeg, (int *)nullptr, (int *)nullptr, g->d_col, 1);
   if ((e = hipGetLastError()) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess) return fail(hip_fail(e, "orient kernels", __FILE__, __LINE__));
   setup_trace("orient: compact");
   int rc = finish_handle(g);
   if (rc) { gm_graph_free(g); return rc; }
-  // (the symmetric degrees: what the topological renumbering of this DAG sorts by -- get_relabeled mode 2)
-  if ((e = hipMalloc(&g->d_symdeg, sizeof(int) * (size_t)std::max(nv, 1))) != hipSuccess) return fail(hip_fail(e, "hipMalloc", __FILE__, __LINE__));
-  if (nv > 0) hipLaunchKernelGGL((symdeg_kernel<OffT>), dim3(vb), dim3(256), 0, 0, nv, rp_in, g->d_symdeg);
-  if ((e = hipGetLastError()) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess) return fail(hip_fail(e, "symdeg_kernel", __FILE__, __LINE__));
+  g->d_symdeg = sdeg;
+  sdeg = nullptr;
   setup_trace("orient: finish_handle + degrees");
   g->setup.orient_ms = timer.ms();
   *out = g;

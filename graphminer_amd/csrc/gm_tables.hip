@@ -35,50 +35,50 @@ struct ChunkWalk {
   int target, allow_split, bit_words, stage_cap;
   RowFilter rf;
 };
+// (One loop over the vertices with the open chunk as STATE -- no nested loops: the device runs 32 walkers per wave, and with a loop per
+// chunk inside the loop over vertices every walker sat in a branch of its own: 0.6 ms per pass over 4 M vertices, all of it divergence.)
 template <class Emit>
 __host__ __device__ inline unsigned long long walk_chunks(const ChunkWalk &w, const int *rp, int v0, int v1, Emit emit) {
   unsigned long long max_bit_words = 0;
-  int u = v0;
-  while (u < v1) {
+  bool open = false;  // a chunk [start, u) of whole rows with `edges` > 0 entries is being filled
+  int start = 0, edges = 0, maxd = 0;
+  auto close = [&](int end) {
+    emit(ChunkRec{start, end, rp[start], rp[end], 0, 1, GM_WAVE, 0});
+    if (w.bit_words) {
+      const unsigned long long bw = (unsigned long long)edges * (unsigned long long)((maxd + 31) / 32);
+      if (bw > (unsigned long long)w.bit_words) max_bit_words = max(max_bit_words, bw);
+    }
+    open = false;
+  };
+  for (int u = v0; u < v1; ++u) {
     const int d = rp[u + 1] - rp[u];
-    if (d == 0) { ++u; continue; }
-    if (w.rf.skips(d)) { ++u; continue; }
-    if (d > w.stage_cap) {
-      if (w.allow_split) {
-        for (int s0 = rp[u]; s0 < rp[u + 1]; s0 += w.target) emit(ChunkRec{u, u + 1, s0, min(s0 + w.target, rp[u + 1]), 0, 1, GM_WAVE, 0});
-      } else {
-        emit(ChunkRec{u, u + 1, rp[u], rp[u + 1], 0, 1, GM_WAVE, 0});
-        if (w.bit_words) max_bit_words = max(max_bit_words, (unsigned long long)d * (unsigned long long)((d + 31) / 32));
-      }
-      ++u;
-      continue;
+    const bool left_out = d > 0 && w.rf.skips(d);
+    if (open) {  // does row u still go into the open chunk?  (an empty row does, a row that is left out or too long ends it)
+      bool joins = (u - start) < kMaxChunkVerts && d <= w.stage_cap && !left_out && edges + d <= w.stage_cap;
+      if (joins && w.bit_words) joins = (long long)(edges + d) * ((max(maxd, d) + 31) / 32) <= (long long)w.bit_words;
+      if (!joins) close(u);
     }
-    const int start = u;
-    int edges = 0, maxd = 0;
-    while (u < v1 && (u - start) < kMaxChunkVerts) {
-      const int du = rp[u + 1] - rp[u];
-      if (du > w.stage_cap) break;
-      if (w.rf.skips(du) && du > 0) break;
-      if (edges > 0 && edges + du > w.stage_cap) break;
-      if (w.bit_words && edges > 0) {
-        const int nm = max(maxd, du);
-        if ((long long)(edges + du) * ((nm + 31) / 32) > w.bit_words) break;
+    if (!open) {  // row u starts a chunk, is a chunk (or several) of its own, or is passed over
+      if (d == 0 || left_out) continue;
+      if (d > w.stage_cap) {
+        if (w.allow_split) {
+          for (int s0 = rp[u]; s0 < rp[u + 1]; s0 += w.target) emit(ChunkRec{u, u + 1, s0, min(s0 + w.target, rp[u + 1]), 0, 1, GM_WAVE, 0});
+        } else {
+          emit(ChunkRec{u, u + 1, rp[u], rp[u + 1], 0, 1, GM_WAVE, 0});
+          if (w.bit_words) max_bit_words = max(max_bit_words, (unsigned long long)d * (unsigned long long)((d + 31) / 32));
+        }
+        continue;
       }
-      edges += du;
-      maxd = max(maxd, du);
-      ++u;
-      if (edges >= w.target) break;
+      open = true;
+      start = u;
+      edges = 0;
+      maxd = 0;
     }
-    if (edges > 0) {
-      emit(ChunkRec{start, u, rp[start], rp[u], 0, 1, GM_WAVE, 0});
-      if (w.bit_words) {
-        const unsigned long long bw = (unsigned long long)edges * (unsigned long long)((maxd + 31) / 32);
-        if (bw > (unsigned long long)w.bit_words) max_bit_words = max(max_bit_words, bw);
-      }
-    } else if (u == start) {
-      ++u;  // (cannot happen: the row at `start` fits the stage and is not filtered)
-    }
+    edges += d;
+    maxd = max(maxd, d);
+    if (edges >= w.target) close(u + 1);
   }
+  if (open) close(v1);
   return max_bit_words;
 }
 
@@ -884,12 +884,13 @@ static bool keystream_possible(const gm_graph *g) {  // ids must leave bits 24..
   return g->nv <= (1 << 24) && !getenv("GM_TC_NO_KEY_STREAM");
 }
 struct KeyCopy { int src, dst, len; unsigned tag; };
-template <bool PLACE>
+template <bool PLACE, int WIN>
 __global__ __launch_bounds__(256) void kst_rows_kernel(const TaskWalk w, const int lmax, unsigned long long *__restrict__ cnt /* PLACE: the cursors */,
                                                         const int *__restrict__ kst_rp, const int *__restrict__ trpl, unsigned *__restrict__ kst,
                                                         int2 *__restrict__ tdescl) {
-  __shared__ unsigned long long hist[kHubWin];
-  for (int h = threadIdx.x; h < kHubWin; h += 256) hist[h] = 0ull;
+  __shared__ unsigned long long hist[WIN];
+  const int hubwin = w.nv - w.hub0;  // (<= WIN: ensure_keystream)
+  for (int h = threadIdx.x; h < hubwin; h += 256) hist[h] = 0ull;
   __syncthreads();
   const int lane = threadIdx.x & 63, sub = lane & 7, g8 = lane & ~7;
   // the list a task streams, and its weight in the packed counters
@@ -945,7 +946,7 @@ __global__ __launch_bounds__(256) void kst_rows_kernel(const TaskWalk w, const i
     }
   });
   __syncthreads();
-  for (int h = threadIdx.x; h < kHubWin; h += 256) {
+  for (int h = threadIdx.x; h < hubwin; h += 256) {
     const unsigned long long c = hist[h];
     if (c) {
       const unsigned long long b = atomicAdd(&cnt[w.hub0 + h], c);  // pass 1: the count; pass 2: this workgroup's range among the hub's
@@ -1015,13 +1016,21 @@ int ensure_keystream(gm_graph *g, bool *built) {
   HIP_TRY(keyoff.alloc(nv1));
   HIP_TRY(longs.alloc(nv1));
   // (few, fat workgroups where a hub window exists: a workgroup's LDS histogram of the hub hosts pays when it sees many rows)
-  int per_cu = topo ? 8 : 64;  // (4 / 5 / 8 / 16 per CU: place pass of R-MAT-22 2.84 / 3.09 / 2.79 / 2.70 ms, R-MAT-24 15.3 / 18.1 / 15.0 / 15.0)
-  if (const char *e = getenv("GM_KST_WG_PER_CU")) per_cu = std::max(1, atoi(e));  // (sweeps)
-  const long long blocks = std::min<long long>(((long long)g->nv * 8 + 255) / 256, (long long)g->cu_count * per_cu);
+  // The two passes choose their windows independently (a window only says which hosts are aggregated in LDS): the count pass is all
+  // atomics and wants the larger one, the place pass waits for its returning atomics and the lists it copies and wants more workgroups
+  // per CU.  Measured, window / workgroups per CU, count + place ms: R-MAT-22 4096 / 8: 1.38 + 2.51, 2048 / 16: 1.43 + 2.16;
+  // R-MAT-24 4096 / 8: 8.5 + 14.7, 2048 / 16: 10.1 + 13.6.
+  int win_count = kHubWin, win_place = 2048, per_cu_count = topo ? 8 : 64, per_cu_place = topo ? 16 : 64;
+  if (const char *e = getenv("GM_KST_HUB_WIN")) win_count = win_place = std::max(0, std::min(atoi(e), kHubWin));  // (sweeps)
+  if (const char *e = getenv("GM_KST_WG_PER_CU")) per_cu_count = per_cu_place = std::max(1, atoi(e));
+  const long long blocks_count = std::min<long long>(((long long)g->nv * 8 + 255) / 256, (long long)g->cu_count * per_cu_count);
+  const long long blocks_place = std::min<long long>(((long long)g->nv * 8 + 255) / 256, (long long)g->cu_count * per_cu_place);
   TaskWalk tw;
   tw.nv = g->nv; tw.stage_max = kTctStageMax; tw.topo = topo ? 1 : 0;
-  tw.hub0 = topo ? std::max(0, g->nv - kHubWin) : g->nv;
   tw.rp = g->d_rp; tw.col = g->d_col; tw.edesc = g->d_edesc;
+  TaskWalk tw_count = tw, tw_place = tw;
+  tw_count.hub0 = topo ? std::max(0, g->nv - win_count) : g->nv;
+  tw_place.hub0 = topo ? std::max(0, g->nv - win_place) : g->nv;
   int *krp = nullptr, *trpl = nullptr;
   unsigned *kst = nullptr;
   int2 *tdl = nullptr;
@@ -1036,7 +1045,8 @@ int ensure_keystream(gm_graph *g, bool *built) {
   int nlong = 0;
   for (;;) {  // the stream is indexed with 32 bits: halve the limit of a "short" list until it fits
     if ((e = hipMemsetAsync(cnt.p, 0, sizeof(unsigned long long) * nv1, 0)) != hipSuccess) return fail(e, "hipMemsetAsync");
-    hipLaunchKernelGGL((kst_rows_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, 0, tw, lmax, cnt.p, nullptr, nullptr, nullptr, nullptr);
+    if (win_count <= 2048) hipLaunchKernelGGL((kst_rows_kernel<false, 2048>), dim3((unsigned)blocks_count), dim3(256), 0, 0, tw_count, lmax, cnt.p, nullptr, nullptr, nullptr, nullptr);
+    else hipLaunchKernelGGL((kst_rows_kernel<false, kHubWin>), dim3((unsigned)blocks_count), dim3(256), 0, 0, tw_count, lmax, cnt.p, nullptr, nullptr, nullptr, nullptr);
     hipLaunchKernelGGL(kst_unpack_kernel, dim3((unsigned)((nv1 + 255) / 256)), dim3(256), 0, 0, g->nv, cnt.p, keys.p, longs.p);
     if ((e = dev_exclusive_sum(tmp, keys.p, keyoff.p, nv1)) != hipSuccess) return fail(e, "ExclusiveSum");
     if ((e = dev_exclusive_sum(tmp, longs.p, trpl, nv1)) != hipSuccess) return fail(e, "ExclusiveSum");
@@ -1056,7 +1066,8 @@ int ensure_keystream(gm_graph *g, bool *built) {
   if ((e = hipMalloc(&kst, sizeof(unsigned) * (size_t)std::max<unsigned long long>(total, 1))) != hipSuccess) return fail(e, "hipMalloc(key stream)");
   if ((e = hipMalloc(&tdl, sizeof(int2) * (size_t)std::max(nlong, 1))) != hipSuccess) return fail(e, "hipMalloc(long lists)");
   if ((e = hipMemsetAsync(cnt.p, 0, sizeof(unsigned long long) * nv1, 0)) != hipSuccess) return fail(e, "hipMemsetAsync");
-  hipLaunchKernelGGL((kst_rows_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, 0, tw, lmax, cnt.p, krp, trpl, kst, tdl);
+  if (win_place <= 2048) hipLaunchKernelGGL((kst_rows_kernel<true, 2048>), dim3((unsigned)blocks_place), dim3(256), 0, 0, tw_place, lmax, cnt.p, krp, trpl, kst, tdl);
+  else hipLaunchKernelGGL((kst_rows_kernel<true, kHubWin>), dim3((unsigned)blocks_place), dim3(256), 0, 0, tw_place, lmax, cnt.p, krp, trpl, kst, tdl);
   if ((e = hipGetLastError()) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess) return fail(e, "kst_rows_kernel");
   setup_trace("key stream: place pass");
   g->d_kst = kst;
