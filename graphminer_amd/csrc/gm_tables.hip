@@ -1041,7 +1041,8 @@ int ensure_keystream(gm_graph *g, bool *built) {
   };
   hipError_t e = hipSuccess;
   if ((e = hipMalloc(&krp, sizeof(int) * nv1)) != hipSuccess || (e = hipMalloc(&trpl, sizeof(int) * nv1)) != hipSuccess) return fail(e, "hipMalloc(key stream offsets)");
-  unsigned long long total = 0;
+  unsigned long long total = 0, key_limit = 0x7fffff00ull;
+  if (const char *e = getenv("GM_KST_MAX_KEYS")) key_limit = std::min<unsigned long long>(key_limit, (unsigned long long)std::max(1ll, atoll(e)));  // (tests)
   int nlong = 0;
   for (;;) {  // the stream is indexed with 32 bits: halve the limit of a "short" list until it fits
     if ((e = hipMemsetAsync(cnt.p, 0, sizeof(unsigned long long) * nv1, 0)) != hipSuccess) return fail(e, "hipMemsetAsync");
@@ -1052,7 +1053,7 @@ int ensure_keystream(gm_graph *g, bool *built) {
     if ((e = dev_exclusive_sum(tmp, longs.p, trpl, nv1)) != hipSuccess) return fail(e, "ExclusiveSum");
     if ((e = hipMemcpy(&total, keyoff.p + g->nv, 8, hipMemcpyDeviceToHost)) != hipSuccess) return fail(e, "hipMemcpy");
     if ((e = hipMemcpy(&nlong, trpl + g->nv, sizeof(int), hipMemcpyDeviceToHost)) != hipSuccess) return fail(e, "hipMemcpy");
-    if (total < 0x7fffff00ull) break;
+    if (total < key_limit) break;
     lmax >>= 1;
     if (lmax < 4) {
       (void)hipFree(krp);

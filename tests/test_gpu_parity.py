@@ -978,3 +978,23 @@ def test_two_stage_tables_when_forced_on_a_small_graph(dev, monkeypatch):
         d = s.orient()
         assert TCSolver(d) == want_tc
         assert SglSolver(s, "diamond") == want_dia
+
+
+@pytest.mark.gpu
+def test_key_stream_with_a_smaller_list_limit_and_without(dev, monkeypatch):
+    """the key stream of the triangle count is indexed with 32 bits: when the keys of all lists of <= 32 entries do not fit, the limit of
+    a "short" list is halved until they do, and below 4 the handle goes without a stream (full task lists).  GM_KST_MAX_KEYS lowers
+    the bound so that a test-sized graph takes both exits: same count as the oracle either way, and as rank shares."""
+    g = rmat_csr_numpy(13, 12, seed=5)
+    osym = O.OGraph(g.row_ptr, g.col_idx)
+    want = O.tc(O.orient(osym))
+    with g.to_device(dev) as s:
+        assert TCSolver(s.orient()) == want
+    ne_dag = int(O.orient(osym).row_ptr[-1])  # (the keys of the short lists are a small multiple of the DAG's entries)
+    for limit in (2 * ne_dag, ne_dag // 2, 16):  # the limit halved once or twice, more often, and no stream at all
+        monkeypatch.setenv("GM_KST_MAX_KEYS", str(max(limit, 1)))
+        with g.to_device(dev) as s:
+            d = s.orient()
+            assert TCSolver(d) == want
+            assert sum(TCSolver(d, rank=r, world=2) for r in range(2)) == want
+    monkeypatch.delenv("GM_KST_MAX_KEYS")
