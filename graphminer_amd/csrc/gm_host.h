@@ -237,6 +237,13 @@ struct gm_graph {
   int *d_kst_rp = nullptr;
   int *d_trpl = nullptr;
   int2 *d_tdescl = nullptr;
+  // the same for the edge supports (ensure_keystream(g, true)): per key the DAG entry it was copied from and the entry of its task's own
+  // edge, per longer list the entry of its task's own edge.  They belong to d_kst / d_tdescl when the stream was built with them, else to
+  // a second set d_kst2 / d_tdescl2 (same offsets, its own order of arrival).
+  int *d_kst_e = nullptr, *d_kst_t = nullptr, *d_tedgel = nullptr;
+  unsigned *d_kst2 = nullptr;
+  int2 *d_tdescl2 = nullptr;
+  int kst_lmax = 0;  // the limit of a "short" list the stream was built with
   // the rows beyond the stage of the task-list kernels (> 2048 entries; ensure_long_rows): ids and the prefix of their lengths
   int *d_long_rows = nullptr;
   long long *d_long_prefix = nullptr;
@@ -420,7 +427,7 @@ int get_table(gm_graph *g, int target, bool allow_split, int bit_words, unsigned
               const RowFilter &rf = RowFilter(), int bitmap_min_deg = kBitmapMinDeg);
 int ensure_edesc(gm_graph *g);
 int ensure_tasklists(gm_graph *g, bool with_edges = false);
-int ensure_keystream(gm_graph *g, bool *built);
+int ensure_keystream(gm_graph *g, bool edges, bool *built);
 int ensure_mean_sq_deg(gm_graph *g);
 unsigned long long task_part_cap(gm_graph *g, int world);
 int clique_wide_min_words();

@@ -230,8 +230,17 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
   const bool use_tch_k = !(la->tune[6] & 0x8000000) && !getenv("GM_TC_SORTED");  // (the key stream is read by tch_kernel only)
   bool use_kst = false;
   if (use_tct) {
-    if (!support && use_tch_k && !(la->tune[6] & 0x20000000)) {
-      const int rc_k = ensure_keystream(g, &use_kst);
+    // The edge supports take the stream only where matches are RARE: a match of a streamed key costs them two gathers (the entries beside
+    // the stream) and two global atomics, where a task of the lists costs one atomic per match and one per task.  Flat / power-law LJ-size
+    // 1.06 / 1.55 -> 0.70 / 1.32 ms, but R-MAT-22 8.50 -> 10.95 and R-MAT-24 102 -> 115: the switch is the one that decides the renumbering
+    // (sum d+^2 / |E+| below kTopoMinMeanRow: short lists, few triangles per edge).  GM_SUP_STREAM=0 / 1 forces it.
+    bool sup_stream = false;
+    if (support && !(la->tune[6] & 0x20000000)) {
+      if (const char *e = getenv("GM_SUP_STREAM")) sup_stream = atoi(e) != 0;
+      else sup_stream = ensure_mean_sq_deg(g) == GM_OK && g->mean_sq_deg < (double)kTopoMinMeanRow;
+    }
+    if ((sup_stream || (!support && use_tch_k)) && !(la->tune[6] & 0x20000000)) {
+      const int rc_k = ensure_keystream(g, support, &use_kst);
       if (rc_k) return rc_k;
     }
     if (!use_kst) {
@@ -351,7 +360,15 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
     p.g.tedge = support ? g->d_tedge : nullptr;
     // the triangle count streams the short lists from their task-major copies (gm_host.h d_colk; tune[6] & 0x20000000: from their rows);
     // the edge supports need the entries of the streamed keys in col[] itself
-    if (use_kst) {  // short lists as one tagged key stream, the longer ones as tasks
+    if (use_kst && support) {  // ... with the entries the supports need beside them (the second set when the stream was built without)
+      p.g.kst = g->d_kst2 ? g->d_kst2 : g->d_kst;
+      p.g.kst_rp = g->d_kst_rp;
+      p.g.kst_e = g->d_kst_e;
+      p.g.kst_t = g->d_kst_t;
+      p.g.trp = g->d_trpl;
+      p.g.tdesc = g->d_tdescl2 ? g->d_tdescl2 : g->d_tdescl;
+      p.g.tedge = g->d_tedgel;
+    } else if (use_kst) {  // short lists as one tagged key stream, the longer ones as tasks
       p.g.kst = g->d_kst;
       p.g.kst_rp = g->d_kst_rp;
       p.g.trp = g->d_trpl;

@@ -42,7 +42,8 @@ struct alignas(16) SupLds {
   int hq[kWavesPerBlock][kSupQueue];      // per wave: DAG entries (streamed edges) whose increment is still to be issued
   int next_batch;
   unsigned queue_pos;
-  int pad_[2];
+  int next_group;  // key stream of the short lists: the next group of tiles
+  int pad_;
 };
 
 template <int STAGE>
@@ -76,9 +77,92 @@ void sup_kernel(const MineParams p) {
       const int eb = r.e_begin, nel = r.e_end - r.e_begin;
       for (int i = tid; i <= nvl; i += nthreads) B.trpl[i] = trp[ub + i];
       for (int i = tid; i < nel; i += nthreads) B.ecnt[i] = 0u;
-      if (tid == 0) B.next_batch = 0;
+      if (tid == 0) {
+        B.next_batch = 0;
+        B.next_group = 0;
+      }
       const bool fallback = hs_build<STAGE, nthreads>(B.set, reinterpret_cast<unsigned *>(&B.w[0]), rp, col, ub, nvl, eb, nel,
                                                        (p.flags & (1 << 22)) != 0, tid);  // (ends with a barrier)
+      // ---- waves: the KEY STREAM of the chunk's short lists (GraphView::kst, gm_tch.hip) -- one contiguous range per chunk, one coalesced
+      // load per 64 keys, no descriptor, no row search, no flattening.  What a match needs beyond the triangle count's -- the DAG entry of
+      // the streamed key and of the task's own edge -- lies beside the stream (kst_e / kst_t) and is read by the lanes that found their key.
+      if (p.g.kst != nullptr) {
+        constexpr int TS = STAGE <= 1024 ? kSupTilesSmall : kSupTiles, GS = TS * GM_WAVE;
+        const int kb = p.g.kst_rp[ub], kn = p.g.kst_rp[ub + nvl] - kb;
+        const unsigned *__restrict__ kp = p.g.kst + kb;
+        int *hq = B.hq[wave];
+        int qn = 0;  // wave-uniform: queued entries
+        auto flush = [&]() {
+          wave_sync();
+          for (int i = lane; i < qn; i += GM_WAVE) atomicAdd(&sup[hq[i]], 1u);
+          qn = 0;
+          wave_sync();
+        };
+        auto grab = [&]() {
+          int gi = 0;
+          if (lane == 0) gi = atomicAdd(&B.next_group, 1);
+          return (readfirst(gi) * r.nparts + r.part) * GS;
+        };
+        unsigned nxt[TS];
+        int g0 = kn > 0 ? grab() : 0;
+        if (g0 < kn) {
+#pragma unroll
+          for (int q = 0; q < TS; ++q) nxt[q] = kp[min(g0 + q * GM_WAVE + lane, kn - 1)];
+        }
+        wave_sync();
+        while (g0 < kn) {  // wave-uniform
+          const int gc = g0;
+          int key[TS];
+          unsigned salt[TS], rlo[TS], rlen[TS], at[TS];
+          unsigned long long inm[TS], hm[TS], nm[TS];
+#pragma unroll
+          for (int q = 0; q < TS; ++q) {
+            key[q] = (int)(nxt[q] & 0xffffffu);
+            const int lo = (int)(((nxt[q] >> 24) - (unsigned)ub) & 255u);  // host = ub + local row, local row < 256
+            salt[q] = H::salt(lo);
+            const int rs = B.set.rpl[lo];
+            rlo[q] = (unsigned)(rs - eb);
+            // (a table hit is only looked for below the stage indices the table holds: gm_hset.h hs_pass)
+            rlen[q] = (unsigned)min(B.set.rpl[lo + 1] - rs, max(0, (int)H::kPosLimit - (rs - eb)));
+            inm[q] = __ballot(gc + q * GM_WAVE + lane < kn);
+          }
+          g0 = grab();
+          if (g0 < kn) {
+#pragma unroll
+            for (int q = 0; q < TS; ++q) nxt[q] = kp[min(g0 + q * GM_WAVE + lane, kn - 1)];
+          }
+          hs_probe<STAGE, TS>(B.set, col, fallback, key, salt, rlo, rlen, inm, at, hm, nm);
+          unsigned long long any_need = 0ull;
+#pragma unroll
+          for (int q = 0; q < TS; ++q) {
+            any_need |= nm[q];
+            if (hm[q] == 0ull) continue;  // wave-uniform
+            const int nh = 2 * (int)__popcll(hm[q]);
+            if (qn + nh > kSupQueue) flush();
+            if (__builtin_amdgcn_inverse_ballot_w64(hm[q])) {
+              const int pos = kb + gc + q * GM_WAVE + lane;
+              atomicAdd(&B.ecnt[rlo[q] + at[q]], 1u);
+              const int slot = qn + 2 * rank_below(hm[q]);
+              hq[slot] = p.g.kst_e[pos];
+              hq[slot + 1] = p.g.kst_t[pos];
+            }
+            qn += nh;
+          }
+          if (any_need != 0ull)  // rare
+            hs_surplus<STAGE, TS>(B.set, lane, key, salt, nm, [&](const int q, const int sl, const int pat) {
+              if (qn + 2 > kSupQueue) flush();
+              const int pos = kb + gc + q * GM_WAVE + sl;
+              const unsigned r0 = (unsigned)readlane((int)rlo[q], sl);
+              if (lane == 0) {
+                atomicAdd(&B.ecnt[r0 + (unsigned)pat], 1u);
+                hq[qn] = p.g.kst_e[pos];
+                hq[qn + 1] = p.g.kst_t[pos];
+              }
+              qn += 2;
+            });
+        }
+        flush();
+      }
       const int tb = B.trpl[0], ntask = B.trpl[nvl] - tb;
       for (;;) {
         int bi = 0;

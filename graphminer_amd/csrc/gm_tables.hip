@@ -883,11 +883,14 @@ __global__ __launch_bounds__(256) void task_rows_kernel(const TaskWalk w, int *_
 static bool keystream_possible(const gm_graph *g) {  // ids must leave bits 24..31 to the host tag
   return g->nv <= (1 << 24) && !getenv("GM_TC_NO_KEY_STREAM");
 }
-struct KeyCopy { int src, dst, len; unsigned tag; };
-template <bool PLACE, int WIN>
+struct KeyCopy { int src, dst, len, own; unsigned tag; };
+// EDGES (the edge supports, gm_sup.hip): beside every key the DAG entry it was copied from and the entry of its task's own edge, beside
+// every longer list the entry of its task's own edge -- read only where a key is found
+struct KstEdges { int *kst_e, *kst_t, *tedgel; };
+template <bool PLACE, int WIN, bool EDGES>
 __global__ __launch_bounds__(256) void kst_rows_kernel(const TaskWalk w, const int lmax, unsigned long long *__restrict__ cnt /* PLACE: the cursors */,
                                                         const int *__restrict__ kst_rp, const int *__restrict__ trpl, unsigned *__restrict__ kst,
-                                                        int2 *__restrict__ tdescl) {
+                                                        int2 *__restrict__ tdescl, const KstEdges ed) {
   __shared__ unsigned long long hist[WIN];
   const int hubwin = w.nv - w.hub0;  // (<= WIN: ensure_keystream)
   for (int h = threadIdx.x; h < hubwin; h += 256) hist[h] = 0ull;
@@ -904,13 +907,26 @@ __global__ __launch_bounds__(256) void kst_rows_kernel(const TaskWalk w, const i
       const int lj = __shfl(c.len, g8 + j), sj = __shfl(c.src, g8 + j), dj = __shfl(c.dst, g8 + j);
       const unsigned tj = (unsigned)__shfl((int)c.tag, g8 + j);
       for (int i = sub; i < lj; i += 8) kst[dj + i] = (unsigned)w.col[sj + i] | tj;
+      if (EDGES) {
+        const int oj = __shfl(c.own, g8 + j);
+        for (int i = sub; i < lj; i += 8) {
+          ed.kst_e[dj + i] = sj + i;
+          ed.kst_t[dj + i] = oj;
+        }
+      }
     }
   };
-  auto put = [&](const bool mine, const int host, const unsigned long long pos, const int start, const int len) {
-    KeyCopy c{start, 0, 0, (unsigned)(host & 255) << 24};
+  auto put = [&](const bool mine, const int host, const unsigned long long pos, const int start, const int len, const int e) {
+    KeyCopy c{start, 0, 0, e, (unsigned)(host & 255) << 24};
     if (mine) {
-      if (len > lmax) tdescl[trpl[host] + (int)(pos >> 32)] = make_int2(start, len);
-      else { c.dst = kst_rp[host] + (int)(unsigned)pos; c.len = len; }
+      if (len > lmax) {
+        const int slot = trpl[host] + (int)(pos >> 32);
+        tdescl[slot] = make_int2(start, len);
+        if (EDGES) ed.tedgel[slot] = e;
+      } else {
+        c.dst = kst_rp[host] + (int)(unsigned)pos;
+        c.len = len;
+      }
     }
     copy_group(c);
   };
@@ -942,7 +958,7 @@ __global__ __launch_bounds__(256) void kst_rows_kernel(const TaskWalk w, const i
         ubase = ((unsigned long long)(unsigned)__shfl((int)(unsigned)(ubase >> 32), g8) << 32) | (unsigned)__shfl((int)(unsigned)ubase, g8);
         if (mine != 0ull) pos = ubase + incl - mine;
       }
-      put(now, host, pos, start, len);
+      put(now, host, pos, start, len, e);
     }
   });
   __syncthreads();
@@ -965,7 +981,7 @@ __global__ __launch_bounds__(256) void kst_rows_kernel(const TaskWalk w, const i
       host = w.col[e];
       if (host >= w.hub0) { pos = atomicAdd(&hist[host - w.hub0], wgt); now = true; }
     }
-    put(now, host, pos, start, len);
+    put(now, host, pos, start, len, e);
   });
 }
 __global__ __launch_bounds__(256) void kst_unpack_kernel(int nv, const unsigned long long *__restrict__ cnt, unsigned long long *__restrict__ keys, int *__restrict__ longs) {
@@ -982,21 +998,27 @@ __global__ __launch_bounds__(256) void kst_narrow_kernel(int nv, const unsigned 
 
 // d_kst / d_kst_rp / d_trpl / d_tdescl of a handle (gm_host.h): GM_OK also when the handle cannot have them (ids beyond 24 bits, keys
 // beyond the 32-bit index space at every list limit) -- *built says which
-int ensure_keystream(gm_graph *g, bool *built) {
-  *built = g->d_kst_rp != nullptr;
+// edges: with the entries the edge supports need (gm_host.h KeyStream): a handle whose stream was built without them gets a SECOND set of
+// keys / longer lists with them -- same offsets (the counts per host do not depend on the order of arrival), its own order.
+int ensure_keystream(gm_graph *g, bool edges, bool *built) {
+  auto have = [&]() { return g->d_kst_rp != nullptr && (!edges || g->d_kst_e != nullptr); };
+  *built = have();
   if (*built || g->kst_state == 2 || g->ne == 0) return GM_OK;
   {
     const int rc = ensure_edesc(g);  // (takes the lock itself)
     if (rc) return rc;
   }
   std::lock_guard<std::mutex> lk(g->mu);
-  *built = g->d_kst_rp != nullptr;
+  *built = have();
   if (*built || g->kst_state == 2) return GM_OK;
-  int lmax = GM_TC_INLINE_MAX_DEFAULT;
-  if (const char *e = getenv("GM_TC_INLINE_MAX")) lmax = atoi(e);  // (sweeps)
-  if (!keystream_possible(g) || lmax < 4) {
-    g->kst_state = 2;
-    return GM_OK;
+  const bool second = g->d_kst_rp != nullptr;  // the offsets exist: only the place pass, into the second set
+  int lmax = second ? g->kst_lmax : GM_TC_INLINE_MAX_DEFAULT;
+  if (!second) {
+    if (const char *e = getenv("GM_TC_INLINE_MAX")) lmax = atoi(e);  // (sweeps)
+    if (!keystream_possible(g) || lmax < 4) {
+      g->kst_state = 2;
+      return GM_OK;
+    }
   }
   SetupTimer timer;
   HIP_TRY(hipSetDevice(g->device));
@@ -1031,23 +1053,24 @@ int ensure_keystream(gm_graph *g, bool *built) {
   TaskWalk tw_count = tw, tw_place = tw;
   tw_count.hub0 = topo ? std::max(0, g->nv - win_count) : g->nv;
   tw_place.hub0 = topo ? std::max(0, g->nv - win_place) : g->nv;
-  int *krp = nullptr, *trpl = nullptr;
+  int *krp = second ? g->d_kst_rp : nullptr, *trpl = second ? g->d_trpl : nullptr;
   unsigned *kst = nullptr;
   int2 *tdl = nullptr;
+  KstEdges ed{nullptr, nullptr, nullptr};
   auto fail = [&](hipError_t e, const char *what) {
-    for (void *q : {(void *)krp, (void *)trpl, (void *)kst, (void *)tdl})
+    for (void *q : {second ? nullptr : (void *)krp, second ? nullptr : (void *)trpl, (void *)kst, (void *)tdl, (void *)ed.kst_e, (void *)ed.kst_t, (void *)ed.tedgel})
       if (q) (void)hipFree(q);
     return hip_fail(e, what, __FILE__, __LINE__);
   };
   hipError_t e = hipSuccess;
-  if ((e = hipMalloc(&krp, sizeof(int) * nv1)) != hipSuccess || (e = hipMalloc(&trpl, sizeof(int) * nv1)) != hipSuccess) return fail(e, "hipMalloc(key stream offsets)");
-  unsigned long long total = 0, key_limit = 0x7fffff00ull;
+  if (!second && ((e = hipMalloc(&krp, sizeof(int) * nv1)) != hipSuccess || (e = hipMalloc(&trpl, sizeof(int) * nv1)) != hipSuccess)) return fail(e, "hipMalloc(key stream offsets)");
+  unsigned long long total = second ? g->n_inline_keys : 0, key_limit = 0x7fffff00ull;
   if (const char *e = getenv("GM_KST_MAX_KEYS")) key_limit = std::min<unsigned long long>(key_limit, (unsigned long long)std::max(1ll, atoll(e)));  // (tests)
-  int nlong = 0;
-  for (;;) {  // the stream is indexed with 32 bits: halve the limit of a "short" list until it fits
+  int nlong = second ? g->n_long_tasks : 0;
+  while (!second) {  // the stream is indexed with 32 bits: halve the limit of a "short" list until it fits
     if ((e = hipMemsetAsync(cnt.p, 0, sizeof(unsigned long long) * nv1, 0)) != hipSuccess) return fail(e, "hipMemsetAsync");
-    if (win_count <= 2048) hipLaunchKernelGGL((kst_rows_kernel<false, 2048>), dim3((unsigned)blocks_count), dim3(256), 0, 0, tw_count, lmax, cnt.p, nullptr, nullptr, nullptr, nullptr);
-    else hipLaunchKernelGGL((kst_rows_kernel<false, kHubWin>), dim3((unsigned)blocks_count), dim3(256), 0, 0, tw_count, lmax, cnt.p, nullptr, nullptr, nullptr, nullptr);
+    if (win_count <= 2048) hipLaunchKernelGGL((kst_rows_kernel<false, 2048, false>), dim3((unsigned)blocks_count), dim3(256), 0, 0, tw_count, lmax, cnt.p, nullptr, nullptr, nullptr, nullptr, ed);
+    else hipLaunchKernelGGL((kst_rows_kernel<false, kHubWin, false>), dim3((unsigned)blocks_count), dim3(256), 0, 0, tw_count, lmax, cnt.p, nullptr, nullptr, nullptr, nullptr, ed);
     hipLaunchKernelGGL(kst_unpack_kernel, dim3((unsigned)((nv1 + 255) / 256)), dim3(256), 0, 0, g->nv, cnt.p, keys.p, longs.p);
     if ((e = dev_exclusive_sum(tmp, keys.p, keyoff.p, nv1)) != hipSuccess) return fail(e, "ExclusiveSum");
     if ((e = dev_exclusive_sum(tmp, longs.p, trpl, nv1)) != hipSuccess) return fail(e, "ExclusiveSum");
@@ -1063,20 +1086,39 @@ int ensure_keystream(gm_graph *g, bool *built) {
     }
   }
   setup_trace("key stream: count pass + scans");
-  hipLaunchKernelGGL(kst_narrow_kernel, dim3((unsigned)((nv1 + 255) / 256)), dim3(256), 0, 0, g->nv, keyoff.p, krp);
-  if ((e = hipMalloc(&kst, sizeof(unsigned) * (size_t)std::max<unsigned long long>(total, 1))) != hipSuccess) return fail(e, "hipMalloc(key stream)");
-  if ((e = hipMalloc(&tdl, sizeof(int2) * (size_t)std::max(nlong, 1))) != hipSuccess) return fail(e, "hipMalloc(long lists)");
+  if (!second) hipLaunchKernelGGL(kst_narrow_kernel, dim3((unsigned)((nv1 + 255) / 256)), dim3(256), 0, 0, g->nv, keyoff.p, krp);
+  const size_t nk = (size_t)std::max<unsigned long long>(total, 1), nl = (size_t)std::max(nlong, 1);
+  if ((e = hipMalloc(&kst, sizeof(unsigned) * nk)) != hipSuccess) return fail(e, "hipMalloc(key stream)");
+  if ((e = hipMalloc(&tdl, sizeof(int2) * nl)) != hipSuccess) return fail(e, "hipMalloc(long lists)");
+  if (edges && ((e = hipMalloc(&ed.kst_e, sizeof(int) * nk)) != hipSuccess || (e = hipMalloc(&ed.kst_t, sizeof(int) * nk)) != hipSuccess ||
+                (e = hipMalloc(&ed.tedgel, sizeof(int) * nl)) != hipSuccess))
+    return fail(e, "hipMalloc(key stream entries)");
   if ((e = hipMemsetAsync(cnt.p, 0, sizeof(unsigned long long) * nv1, 0)) != hipSuccess) return fail(e, "hipMemsetAsync");
-  if (win_place <= 2048) hipLaunchKernelGGL((kst_rows_kernel<true, 2048>), dim3((unsigned)blocks_place), dim3(256), 0, 0, tw_place, lmax, cnt.p, krp, trpl, kst, tdl);
-  else hipLaunchKernelGGL((kst_rows_kernel<true, kHubWin>), dim3((unsigned)blocks_place), dim3(256), 0, 0, tw_place, lmax, cnt.p, krp, trpl, kst, tdl);
+  const dim3 pg((unsigned)blocks_place), pb(256);
+  if (edges) {
+    if (win_place <= 2048) hipLaunchKernelGGL((kst_rows_kernel<true, 2048, true>), pg, pb, 0, 0, tw_place, lmax, cnt.p, krp, trpl, kst, tdl, ed);
+    else hipLaunchKernelGGL((kst_rows_kernel<true, kHubWin, true>), pg, pb, 0, 0, tw_place, lmax, cnt.p, krp, trpl, kst, tdl, ed);
+  } else {
+    if (win_place <= 2048) hipLaunchKernelGGL((kst_rows_kernel<true, 2048, false>), pg, pb, 0, 0, tw_place, lmax, cnt.p, krp, trpl, kst, tdl, ed);
+    else hipLaunchKernelGGL((kst_rows_kernel<true, kHubWin, false>), pg, pb, 0, 0, tw_place, lmax, cnt.p, krp, trpl, kst, tdl, ed);
+  }
   if ((e = hipGetLastError()) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess) return fail(e, "kst_rows_kernel");
   setup_trace("key stream: place pass");
-  g->d_kst = kst;
-  g->d_trpl = trpl;
-  g->d_tdescl = tdl;
-  g->n_inline_keys = total;
-  g->n_long_tasks = nlong;
-  g->d_kst_rp = krp;
+  if (second) {  // (the first set stays what the triangle count reads)
+    g->d_kst2 = kst;
+    g->d_tdescl2 = tdl;
+  } else {
+    g->d_kst = kst;
+    g->d_trpl = trpl;
+    g->d_tdescl = tdl;
+    g->n_inline_keys = total;
+    g->n_long_tasks = nlong;
+    g->kst_lmax = lmax;
+  }
+  g->d_tedgel = ed.tedgel;
+  g->d_kst_t = ed.kst_t;
+  g->d_kst_e = ed.kst_e;
+  if (!second) g->d_kst_rp = krp;
   g->setup.table_ms += timer.ms();
   *built = true;
   return GM_OK;

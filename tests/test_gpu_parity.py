@@ -998,3 +998,34 @@ def test_key_stream_with_a_smaller_list_limit_and_without(dev, monkeypatch):
             assert TCSolver(d) == want
             assert sum(TCSolver(d, rank=r, world=2) for r in range(2)) == want
     monkeypatch.delenv("GM_KST_MAX_KEYS")
+
+
+@pytest.mark.gpu
+def test_edge_supports_from_the_key_stream(dev, monkeypatch):
+    """the edge supports read the short lists from the key stream (with the entries of the streamed key and of the task's own edge beside
+    it) where matches are rare; GM_SUP_STREAM forces either path on a graph with many triangles per edge: diamond against the oracle and
+    the per-edge kernels, after a triangle count built the stream without the entries (second set) and before one, and as rank shares."""
+    import torch
+
+    from graphminer_amd.solvers import diamond_support_finish, diamond_support_partial, diamond_support_size
+
+    g = rmat_csr_numpy(12, 24, seed=9)
+    osym = O.OGraph(g.row_ptr, g.col_idx)
+    want, want_tc = O.diamond(osym), O.tc(O.orient(osym))
+    for stream in ("1", "0"):
+        monkeypatch.setenv("GM_SUP_STREAM", stream)
+        with g.to_device(dev) as s:
+            assert SglSolver(s, "diamond") == want                   # the stream built WITH the entries (or the task lists)
+            assert TCSolver(s.orient()) == want_tc
+        with g.to_device(dev) as s:
+            assert MotifSolver(s, 3)[1] == want_tc                   # formula 3-motif: the triangle count builds the stream of the cached DAG
+            assert SglSolver(s, "diamond") == want                   # ... and the supports add the second set
+            world = 3
+            n = diamond_support_size(s, world)
+            bufs = [torch.zeros(n, dtype=torch.int32, device=f"cuda:{dev}") for _ in range(world)]
+            for r in range(world):
+                diamond_support_partial(s, bufs[r].data_ptr(), n, rank=r, world=world)
+            total = torch.stack(bufs).sum(0, dtype=torch.int64).to(torch.int32)
+            per = n // world
+            assert sum(diamond_support_finish(s, total[r * per:(r + 1) * per].contiguous().data_ptr(), per) for r in range(world)) == want
+    monkeypatch.delenv("GM_SUP_STREAM")
