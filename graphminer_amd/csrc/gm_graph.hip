@@ -88,7 +88,7 @@ extern "C" void gm_graph_free(gm_graph *g) {
   if (g->d_colk) (void)hipFree(g->d_colk);
   if (g->d_tdesck) (void)hipFree(g->d_tdesck);
   if (g->d_kst) (void)hipFree(g->d_kst);
-  for (void *q : {(void *)g->d_kst_e, (void *)g->d_kst_t, (void *)g->d_tedgel, (void *)g->d_kst2, (void *)g->d_tdescl2})
+  for (void *q : {(void *)g->d_kst_et, (void *)g->d_tedgel, (void *)g->d_kst2, (void *)g->d_tdescl2})
     if (q) (void)hipFree(q);
   if (g->d_kst_rp) (void)hipFree(g->d_kst_rp);
   if (g->d_trpl) (void)hipFree(g->d_trpl);

@@ -240,7 +240,8 @@ struct gm_graph {
   // the same for the edge supports (ensure_keystream(g, true)): per key the DAG entry it was copied from and the entry of its task's own
   // edge, per longer list the entry of its task's own edge.  They belong to d_kst / d_tdescl when the stream was built with them, else to
   // a second set d_kst2 / d_tdescl2 (same offsets, its own order of arrival).
-  int *d_kst_e = nullptr, *d_kst_t = nullptr, *d_tedgel = nullptr;
+  int2 *d_kst_et = nullptr;  // per key: {entry it was copied from, entry of its task's own edge}
+  int *d_tedgel = nullptr;
   unsigned *d_kst2 = nullptr;
   int2 *d_tdescl2 = nullptr;
   int kst_lmax = 0;  // the limit of a "short" list the stream was built with

@@ -363,8 +363,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
     if (use_kst && support) {  // ... with the entries the supports need beside them (the second set when the stream was built without)
       p.g.kst = g->d_kst2 ? g->d_kst2 : g->d_kst;
       p.g.kst_rp = g->d_kst_rp;
-      p.g.kst_e = g->d_kst_e;
-      p.g.kst_t = g->d_kst_t;
+      p.g.kst_et = g->d_kst_et;
       p.g.trp = g->d_trpl;
       p.g.tdesc = g->d_tdescl2 ? g->d_tdescl2 : g->d_tdescl;
       p.g.tedge = g->d_tedgel;

@@ -82,7 +82,7 @@ struct GraphView {
   // host vertex (nv + 1).  A chunk of hosts streams ONE contiguous range; trp / tdesc then hold only the longer lists.
   const unsigned *kst = nullptr;
   const int *kst_rp = nullptr;
-  const int *kst_e = nullptr, *kst_t = nullptr;  // edge supports: per key of kst the DAG entry it was copied from / the entry of its task's own edge
+  const int2 *kst_et = nullptr;  // edge supports: per key of kst {the DAG entry it was copied from, the entry of its task's own edge}
 };
 
 enum Pattern : int { PAT_TC = 0, PAT_DIAMOND = 1, PAT_MOTIF3 = 2, PAT_CLIQUE4 = 3, PAT_CLIQUEK = 4 /* k = 5..8 */,

@@ -85,7 +85,7 @@ void sup_kernel(const MineParams p) {
                                                        (p.flags & (1 << 22)) != 0, tid);  // (ends with a barrier)
       // ---- waves: the KEY STREAM of the chunk's short lists (GraphView::kst, gm_tch.hip) -- one contiguous range per chunk, one coalesced
       // load per 64 keys, no descriptor, no row search, no flattening.  What a match needs beyond the triangle count's -- the DAG entry of
-      // the streamed key and of the task's own edge -- lies beside the stream (kst_e / kst_t) and is read by the lanes that found their key.
+      // the streamed key and of the task's own edge -- lies beside the stream (kst_et) and is read by the lanes that found their key.
       if (p.g.kst != nullptr) {
         constexpr int TS = STAGE <= 1024 ? kSupTilesSmall : kSupTiles, GS = TS * GM_WAVE;
         const int kb = p.g.kst_rp[ub], kn = p.g.kst_rp[ub + nvl] - kb;
@@ -143,8 +143,9 @@ void sup_kernel(const MineParams p) {
               const int pos = kb + gc + q * GM_WAVE + lane;
               atomicAdd(&B.ecnt[rlo[q] + at[q]], 1u);
               const int slot = qn + 2 * rank_below(hm[q]);
-              hq[slot] = p.g.kst_e[pos];
-              hq[slot + 1] = p.g.kst_t[pos];
+              const int2 et = p.g.kst_et[pos];
+              hq[slot] = et.x;
+              hq[slot + 1] = et.y;
             }
             qn += nh;
           }
@@ -155,8 +156,9 @@ void sup_kernel(const MineParams p) {
               const unsigned r0 = (unsigned)readlane((int)rlo[q], sl);
               if (lane == 0) {
                 atomicAdd(&B.ecnt[r0 + (unsigned)pat], 1u);
-                hq[qn] = p.g.kst_e[pos];
-                hq[qn + 1] = p.g.kst_t[pos];
+                const int2 et = p.g.kst_et[pos];
+                hq[qn] = et.x;
+                hq[qn + 1] = et.y;
               }
               qn += 2;
             });

@@ -886,7 +886,7 @@ static bool keystream_possible(const gm_graph *g) {  // ids must leave bits 24..
 struct KeyCopy { int src, dst, len, own; unsigned tag; };
 // EDGES (the edge supports, gm_sup.hip): beside every key the DAG entry it was copied from and the entry of its task's own edge, beside
 // every longer list the entry of its task's own edge -- read only where a key is found
-struct KstEdges { int *kst_e, *kst_t, *tedgel; };
+struct KstEdges { int2 *kst_et; int *tedgel; };  // kst_et[k] = {entry of key k, entry of its task's own edge}
 template <bool PLACE, int WIN, bool EDGES>
 __global__ __launch_bounds__(256) void kst_rows_kernel(const TaskWalk w, const int lmax, unsigned long long *__restrict__ cnt /* PLACE: the cursors */,
                                                         const int *__restrict__ kst_rp, const int *__restrict__ trpl, unsigned *__restrict__ kst,
@@ -909,10 +909,7 @@ __global__ __launch_bounds__(256) void kst_rows_kernel(const TaskWalk w, const i
       for (int i = sub; i < lj; i += 8) kst[dj + i] = (unsigned)w.col[sj + i] | tj;
       if (EDGES) {
         const int oj = __shfl(c.own, g8 + j);
-        for (int i = sub; i < lj; i += 8) {
-          ed.kst_e[dj + i] = sj + i;
-          ed.kst_t[dj + i] = oj;
-        }
+        for (int i = sub; i < lj; i += 8) ed.kst_et[dj + i] = make_int2(sj + i, oj);
       }
     }
   };
@@ -1001,7 +998,7 @@ __global__ __launch_bounds__(256) void kst_narrow_kernel(int nv, const unsigned 
 // edges: with the entries the edge supports need (gm_host.h KeyStream): a handle whose stream was built without them gets a SECOND set of
 // keys / longer lists with them -- same offsets (the counts per host do not depend on the order of arrival), its own order.
 int ensure_keystream(gm_graph *g, bool edges, bool *built) {
-  auto have = [&]() { return g->d_kst_rp != nullptr && (!edges || g->d_kst_e != nullptr); };
+  auto have = [&]() { return g->d_kst_rp != nullptr && (!edges || g->d_kst_et != nullptr); };
   *built = have();
   if (*built || g->kst_state == 2 || g->ne == 0) return GM_OK;
   {
@@ -1056,9 +1053,9 @@ int ensure_keystream(gm_graph *g, bool edges, bool *built) {
   int *krp = second ? g->d_kst_rp : nullptr, *trpl = second ? g->d_trpl : nullptr;
   unsigned *kst = nullptr;
   int2 *tdl = nullptr;
-  KstEdges ed{nullptr, nullptr, nullptr};
+  KstEdges ed{nullptr, nullptr};
   auto fail = [&](hipError_t e, const char *what) {
-    for (void *q : {second ? nullptr : (void *)krp, second ? nullptr : (void *)trpl, (void *)kst, (void *)tdl, (void *)ed.kst_e, (void *)ed.kst_t, (void *)ed.tedgel})
+    for (void *q : {second ? nullptr : (void *)krp, second ? nullptr : (void *)trpl, (void *)kst, (void *)tdl, (void *)ed.kst_et, (void *)ed.tedgel})
       if (q) (void)hipFree(q);
     return hip_fail(e, what, __FILE__, __LINE__);
   };
@@ -1090,8 +1087,7 @@ int ensure_keystream(gm_graph *g, bool edges, bool *built) {
   const size_t nk = (size_t)std::max<unsigned long long>(total, 1), nl = (size_t)std::max(nlong, 1);
   if ((e = hipMalloc(&kst, sizeof(unsigned) * nk)) != hipSuccess) return fail(e, "hipMalloc(key stream)");
   if ((e = hipMalloc(&tdl, sizeof(int2) * nl)) != hipSuccess) return fail(e, "hipMalloc(long lists)");
-  if (edges && ((e = hipMalloc(&ed.kst_e, sizeof(int) * nk)) != hipSuccess || (e = hipMalloc(&ed.kst_t, sizeof(int) * nk)) != hipSuccess ||
-                (e = hipMalloc(&ed.tedgel, sizeof(int) * nl)) != hipSuccess))
+  if (edges && ((e = hipMalloc(&ed.kst_et, sizeof(int2) * nk)) != hipSuccess || (e = hipMalloc(&ed.tedgel, sizeof(int) * nl)) != hipSuccess))
     return fail(e, "hipMalloc(key stream entries)");
   if ((e = hipMemsetAsync(cnt.p, 0, sizeof(unsigned long long) * nv1, 0)) != hipSuccess) return fail(e, "hipMemsetAsync");
   const dim3 pg((unsigned)blocks_place), pb(256);
@@ -1115,9 +1111,10 @@ int ensure_keystream(gm_graph *g, bool edges, bool *built) {
     g->n_long_tasks = nlong;
     g->kst_lmax = lmax;
   }
-  g->d_tedgel = ed.tedgel;
-  g->d_kst_t = ed.kst_t;
-  g->d_kst_e = ed.kst_e;
+  if (edges) {
+    g->d_tedgel = ed.tedgel;
+    g->d_kst_et = ed.kst_et;
+  }
   if (!second) g->d_kst_rp = krp;
   g->setup.table_ms += timer.ms();
   *built = true;
