@@ -157,6 +157,7 @@ struct ChunkTable {
   std::vector<int> first_vertex;                // u_begin of every chunk (ascending; SPLIT chunks repeat it)
   bool host_ready = false;
   unsigned long long total_edges = 0, total_cost = 0;
+  size_t n_with_cost = 0;  // chunks of non-zero cost (device-built tables): they are the first n_with_cost entries of d_order[1]
   int *d_edges = nullptr, *d_firstv = nullptr;  // device twins of the host views (device-built tables)
   unsigned long long *d_cost = nullptr;
 };

@@ -588,7 +588,9 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
         pw.g = p.g;
         pw.chunks = rd.host_tab.d;
         pw.order = rd.host_tab.d_order[1];  // heaviest host chunks first
-        pw.count = (int)rd.host_tab.n;
+        // (a chunk of hosts without a task of this rank's owners has cost 0 and sits at the end of the cost order: not dequeued at all --
+        // a rank of eight found its 7 M tasks in 97.5 K chunks, most of them empty for it)
+        pw.count = (int)std::min(rd.host_tab.n, rd.host_tab.n_with_cost);
         pw.trp = rd.d_trp;
         pw.tasks = rd.d_tasks;
         pw.queue = g->d_wide_queue + qword++;

@@ -250,16 +250,19 @@ __global__ __launch_bounds__(256) void tab_expand_kernel(int n0, const ChunkRec 
 }
 __global__ __launch_bounds__(256) void tab_totals_kernel(int n, const int *__restrict__ edges, const unsigned long long *__restrict__ cost,
                                                          unsigned long long *__restrict__ out) {
-  unsigned long long se = 0, sc = 0;
+  unsigned long long se = 0, sc = 0, nz = 0;
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
     se += (unsigned long long)edges[c];
     sc += cost[c];
+    nz += cost[c] != 0ull ? 1ull : 0ull;
   }
   se = gm::wave_sum_u64(se);
   sc = gm::wave_sum_u64(sc);
+  nz = gm::wave_sum_u64(nz);
   if ((threadIdx.x & 63) == 0) {
     if (se) atomicAdd(&out[0], se);
     if (sc) atomicAdd(&out[1], sc);
+    if (nz) atomicAdd(&out[2], nz);  // chunks with any work: the head of the cost-ordered dequeue list (d_order[1])
   }
 }
 // rev_rest: the chunks below the heavy mark go in DESCENDING chunk-id order. On a topologically numbered DAG ids ascend in degree, so
@@ -370,16 +373,17 @@ static int build_table_device(gm_graph *g, ChunkTable &t, bool sym_table, double
   HIP_TRY(hipMalloc(&t.d_edges, sizeof(int) * (size_t)n));
   HIP_TRY(hipMalloc(&t.d_firstv, sizeof(int) * (size_t)n));
   DevBuf<unsigned long long> totals;
-  HIP_TRY(totals.alloc(2));
-  HIP_TRY(hipMemsetAsync(totals.p, 0, 16, 0));
+  HIP_TRY(totals.alloc(3));
+  HIP_TRY(hipMemsetAsync(totals.p, 0, 24, 0));
   hipLaunchKernelGGL(tab_expand_kernel, blocks(n0), dim3(256), 0, 0, n0, recs0.p, cost0.p, np.p, bsz.p, off.p, t.d, t.d_cost, t.d_edges, t.d_firstv);
   hipLaunchKernelGGL(tab_totals_kernel, dim3((unsigned)std::min<long long>(((long long)n + 255) / 256, 1024)), dim3(256), 0, 0, n, t.d_edges, t.d_cost, totals.p);
   t.n = (size_t)n;
   {
-    unsigned long long h_tot[2] = {0, 0};
-    HIP_TRY(hipMemcpy(h_tot, totals.p, 16, hipMemcpyDeviceToHost));
+    unsigned long long h_tot[3] = {0, 0, 0};
+    HIP_TRY(hipMemcpy(h_tot, totals.p, 24, hipMemcpyDeviceToHost));
     t.total_edges = h_tot[0];
     t.total_cost = h_tot[1];
+    t.n_with_cost = (size_t)h_tot[2];
   }
   setup_trace("table: expand + totals");
   // dequeue orders: stable descending radix sorts of (key, chunk id)
