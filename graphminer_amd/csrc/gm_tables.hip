@@ -408,7 +408,7 @@ static int build_table_device(gm_graph *g, ChunkTable &t, bool sym_table, double
     }
   }
   setup_trace("table: dequeue orders");
-  if (t.allow_split) {
+  if (t.allow_split && t.bitmap_min_deg != 0x7fffffff) {  // (0x7fffffff: a table whose kernels never probe a bitmap -- no select pass for nothing)
     SetupTimer bm_timer;
     // Hub rows (longer than the LDS stage, cut into SPLIT chunks) get a dense bitmap over the vertex ids, the longest rows
     // first, within a memory budget (and a quarter of the free device memory): one probe then replaces a ~17-step bisection
@@ -1518,7 +1518,7 @@ static int build_clique_round(gm_graph *g, CliquePlan &pl, CliqueRound &rd, Scan
   }
   HIP_TRY(cnt.alloc(nv1));
   HIP_TRY(hipMemsetAsync(cnt.p, 0, sizeof(int) * nv1, 0));
-  const long long kblocks = std::min<long long>(((long long)nv * 8 + 255) / 256, (long long)g->cu_count * (pl.topo ? 4 : 64));
+  const long long kblocks = std::min<long long>(((long long)nv * 8 + 255) / 256, (long long)g->cu_count * (pl.topo ? 8 : 64));
   const int hub0 = pl.topo ? std::max(0, nv - kHubWin) : nv;
   hipLaunchKernelGGL((cb_task_rows_kernel<false>), dim3((unsigned)kblocks), dim3(256), 0, 0, nv, g->d_rp, g->d_col, g->d_edesc, ntask_of.p, pl.topo ? 1 : 0, hub0,
                      cnt.p, nullptr, nullptr, nullptr);
