@@ -248,6 +248,12 @@ __global__ __launch_bounds__(256) void tab_expand_kernel(int n0, const ChunkRec 
     first_vertex[o] = r.u_begin;
   }
 }
+__global__ __launch_bounds__(256) void sum_u64_kernel(long long n, const unsigned long long *__restrict__ x, unsigned long long *__restrict__ out) {
+  unsigned long long s = 0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) s += x[i];
+  s = gm::wave_sum_u64(s);
+  if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
+}
 __global__ __launch_bounds__(256) void tab_totals_kernel(int n, const int *__restrict__ edges, const unsigned long long *__restrict__ cost,
                                                          unsigned long long *__restrict__ out) {
   unsigned long long se = 0, sc = 0, nz = 0;
@@ -1660,12 +1666,21 @@ int get_clique_plan(gm_graph *g, int rank, int world, int policy, int target, un
   unsigned long long arena_mb = GM_WIDE_ARENA_MB;
   if (const char *e = getenv("GM_WIDE_ARENA_MB")) arena_mb = std::max(1ll, atoll(e));  // (tests: force several rounds)
   const unsigned long long budget_words = (arena_mb << 20) / 4ull;
-  std::vector<unsigned long long> cw((size_t)pl.n_count);
+  // (the per-chunk words come to the host only when the narrow chunks alone overflow the arena: one round needs their sum)
+  std::vector<unsigned long long> cw;
+  unsigned long long cw_total = 0;
   if (pl.n_count > 0) {
-    DevBuf<unsigned long long> dcw;
+    DevBuf<unsigned long long> dcw, dsum;
     HIP_TRY(dcw.alloc((size_t)pl.n_count));
+    HIP_TRY(dsum.alloc(1));
+    HIP_TRY(hipMemsetAsync(dsum.p, 0, 8, 0));
     hipLaunchKernelGGL(cb_chunk_words_kernel, blocks(pl.n_count), dim3(256), 0, 0, pl.n_count, pl.n_first, pl.n_step, pl.d_order, pl.tabN->d, g->d_rp, dcw.p);
-    HIP_TRY(copy_to_host(cw.data(), dcw.p, sizeof(unsigned long long) * (size_t)pl.n_count));
+    hipLaunchKernelGGL(sum_u64_kernel, dim3((unsigned)std::min<long long>((pl.n_count + 255) / 256, 1024)), dim3(256), 0, 0, pl.n_count, dcw.p, dsum.p);
+    HIP_TRY(hipMemcpy(&cw_total, dsum.p, 8, hipMemcpyDeviceToHost));
+    if (cw_total > budget_words) {
+      cw.resize((size_t)pl.n_count);
+      HIP_TRY(copy_to_host(cw.data(), dcw.p, sizeof(unsigned long long) * (size_t)pl.n_count));
+    }
   }
   setup_trace("clique: words of the narrow chunks to the host");
   std::vector<int> cls_slots, mcls_slots;
@@ -1676,9 +1691,14 @@ int get_clique_plan(gm_graph *g, int rank, int world, int policy, int target, un
       CliqueRound rd;
       unsigned long long words = 0;
       long long c1 = c0;
-      for (; c1 < pl.n_count; ++c1) {
-        if ((c1 > c0) && words + cw[(size_t)c1] > budget_words) break;
-        words += cw[(size_t)c1];
+      if (cw.empty()) {  // every narrow chunk fits one round: the first
+        if (c0 < pl.n_count) words = cw_total;
+        c1 = pl.n_count;
+      } else {
+        for (; c1 < pl.n_count; ++c1) {
+          if ((c1 > c0) && words + cw[(size_t)c1] > budget_words) break;
+          words += cw[(size_t)c1];
+        }
       }
       size_t s1 = s0;
       std::vector<int> by_cls[3], by_mcls[3];
