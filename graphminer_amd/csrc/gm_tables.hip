@@ -829,7 +829,6 @@ template <bool PLACE>
 __global__ __launch_bounds__(256) void task_rows_kernel(const TaskWalk w, int *__restrict__ cnt /* PLACE: the cursors */, const int *__restrict__ trp,
                                                          int2 *__restrict__ tdesc, int *__restrict__ tedge) {
   __shared__ int hist[kHubWin];
-  __shared__ int hbase[PLACE ? kHubWin : 1];
   for (int h = threadIdx.x; h < kHubWin; h += 256) hist[h] = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63, sub = lane & 7, g8 = lane & ~7;
@@ -864,10 +863,7 @@ __global__ __launch_bounds__(256) void task_rows_kernel(const TaskWalk w, int *_
     const int c = hist[h];
     if (c) {
       const int b = atomicAdd(&cnt[w.hub0 + h], c);  // pass 1: the count; pass 2: this workgroup's range among the hub's tasks
-      if (PLACE) {
-        hbase[h] = b;
-        hist[h] = 0;
-      }
+      if (PLACE) hist[h] = b;  // (the ranks inside the range are taken from the same word)
     }
   }
   if (!PLACE) return;
@@ -877,7 +873,7 @@ __global__ __launch_bounds__(256) void task_rows_kernel(const TaskWalk w, int *_
       const int host = w.col[e];
       if (host >= w.hub0) {
         const int h = host - w.hub0;
-        put(trp[host] + hbase[h] + atomicAdd(&hist[h], 1), host, e, ru, du, dv, tail, false);
+        put(trp[host] + atomicAdd(&hist[h], 1), host, e, ru, du, dv, tail, false);
       }
     }
   });
@@ -1158,7 +1154,7 @@ int ensure_tasklists(gm_graph *g, bool /*with_edges*/) {
   HIP_TRY(hipMemsetAsync(cnt.p, 0, sizeof(int) * nv1, 0));
   // (few, fat workgroups: a workgroup's LDS histogram of the hub hosts pays when it sees many rows)
   // (where no hub window exists -- a DAG that is not numbered topologically -- many thin workgroups: power-law LJ-size 30.9 vs 9.8 ms)
-  const long long blocks = std::min<long long>(((long long)g->nv * 8 + 255) / 256, (long long)g->cu_count * (topo ? 4 : 64));
+  const long long blocks = std::min<long long>(((long long)g->nv * 8 + 255) / 256, (long long)g->cu_count * (topo ? 8 : 64));
   TaskWalk tw;
   tw.nv = g->nv; tw.stage_max = kTctStageMax; tw.topo = topo ? 1 : 0;
   tw.hub0 = topo ? std::max(0, g->nv - kHubWin) : g->nv;
@@ -1176,7 +1172,8 @@ int ensure_tasklists(gm_graph *g, bool /*with_edges*/) {
   if (e == hipSuccess) e = hipMemsetAsync(cnt.p, 0, sizeof(int) * nv1, 0);
   setup_trace("tasks: scan, allocations, clears");
   if (e == hipSuccess) {
-    hipLaunchKernelGGL((task_rows_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, 0, tw, cnt.p, trp, td, tedge);
+    const long long pblocks = std::min<long long>(((long long)g->nv * 8 + 255) / 256, (long long)g->cu_count * (topo ? 16 : 64));  // (the place pass waits for its returning atomics)
+    hipLaunchKernelGGL((task_rows_kernel<true>), dim3((unsigned)pblocks), dim3(256), 0, 0, tw, cnt.p, trp, td, tedge);
     e = hipDeviceSynchronize();
   }
   if (e != hipSuccess) {
@@ -1321,7 +1318,6 @@ __global__ __launch_bounds__(256) void cb_task_rows_kernel(int nv, const int *__
                                                            const int *__restrict__ trp, const unsigned long long *__restrict__ base,
                                                            CBuildTask *__restrict__ out) {
   __shared__ int hist[kHubWin];
-  __shared__ int hbase[PLACE ? kHubWin : 1];
   for (int h = threadIdx.x; h < kHubWin; h += 256) hist[h] = 0;
   __syncthreads();
   const long long stride = ((long long)gridDim.x * blockDim.x) >> 3;
@@ -1375,7 +1371,7 @@ __global__ __launch_bounds__(256) void cb_task_rows_kernel(int nv, const int *__
           const int host = col[e];
           if (host >= hub0) {
             if (phase == 0) atomicAdd(&hist[host - hub0], 1);
-            else put(trp[host] + hbase[host - hub0] + atomicAdd(&hist[host - hub0], 1), (int)u, i, ru, du, dv, true);
+            else put(trp[host] + atomicAdd(&hist[host - hub0], 1), (int)u, i, ru, du, dv, true);
           } else if (phase == 0) {
             if (!PLACE) atomicAdd(&cnt[host], 1);
             else put(trp[host] + atomicAdd(&cnt[host], 1), (int)u, i, ru, du, dv, true);
@@ -1389,10 +1385,7 @@ __global__ __launch_bounds__(256) void cb_task_rows_kernel(int nv, const int *__
         const int c = hist[h];
         if (c) {
           const int b = atomicAdd(&cnt[hub0 + h], c);  // pass 1: the count; pass 2: this workgroup's range among the hub's tasks
-          if (PLACE) {
-            hbase[h] = b;
-            hist[h] = 0;
-          }
+          if (PLACE) hist[h] = b;  // (the ranks inside the range are taken from the same word)
         }
       }
       __syncthreads();
