@@ -78,6 +78,7 @@ SYMBOLS = [
     ("gm_graph_sort_neighbors", C.c_int, [_P]),
     ("gm_graph_meta", C.c_int, [_P, C.POINTER(gm_csr)]),
     ("gm_graph_download", C.c_int, [_P, _P, _P]),
+    ("gm_graph_renumbered", C.c_int, [_P, C.c_int, C.POINTER(_P)]),
     ("gm_graph_free", None, [_P]),
     ("gm_partition", C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                C.POINTER(C.c_int64)]),

@@ -396,7 +396,7 @@ template <class OffT>
 __global__ __launch_bounds__(256) void orient_short_kernel(int nv, const OffT *__restrict__ rp, const int *__restrict__ col,
                                                            const int *__restrict__ sdeg /* symmetric degrees: one random load per entry instead of two offsets */,
                                                            int *__restrict__ new_deg, const int *__restrict__ new_rp,
-                                                           int *__restrict__ new_col, int pass) {
+                                                           int *__restrict__ new_col, int pass, int *__restrict__ tmp_col) {
   constexpr int G = 8, RPW = 64 / G;
   const int lane = threadIdx.x & 63;
   const int grp = lane / G, gl = lane % G;
@@ -421,7 +421,11 @@ __global__ __launch_bounds__(256) void orient_short_kernel(int nv, const OffT *_
         keep = dag_keep(full, s, sdeg[d], d);
       }
       const unsigned long long m = (__ballot(keep) >> (grp * G)) & 0xffull;
-      if (pass && keep) new_col[ob + n + __popcll(m & ((1ull << gl) - 1ull))] = d;
+      if (keep) {
+        const int at = n + __popcll(m & ((1ull << gl) - 1ull));
+        if (pass) new_col[ob + at] = d;
+        else if (tmp_col) tmp_col[b + at] = d;  // kept entries packed at the row's own place: pass 1 is then a copy, not a second gather
+      }
       n += __popcll(m);
     }
     if (!pass && gl == 0 && s < nv && full <= kOrientShort) new_deg[s] = n;
@@ -432,7 +436,7 @@ __global__ __launch_bounds__(256) void orient_short_kernel(int nv, const OffT *_
 template <class OffT>
 __global__ __launch_bounds__(256) void orient_seg_kernel(int nseg, const OrientSegT<OffT> *__restrict__ segs, const OffT *__restrict__ rp,
                                                          const int *__restrict__ col, const int *__restrict__ sdeg, int *__restrict__ seg_count,
-                                                         int *__restrict__ new_deg, int *__restrict__ new_col, int pass) {
+                                                         int *__restrict__ new_deg, int *__restrict__ new_col, int pass, int *__restrict__ tmp_col) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -449,7 +453,10 @@ __global__ __launch_bounds__(256) void orient_seg_kernel(int nseg, const OrientS
         keep = dag_keep(ds, q.row, sdeg[d], d);
       }
       const unsigned long long m = __ballot(keep);
-      if (pass && keep) new_col[q.out + n + rank_below(m)] = d;
+      if (keep) {
+        if (pass) new_col[q.out + n + rank_below(m)] = d;
+        else if (tmp_col) tmp_col[q.begin + n + rank_below(m)] = d;
+      }
       n += __popcll(m);
     }
     if (!pass && lane == 0) {
@@ -493,6 +500,36 @@ __global__ __launch_bounds__(256) void orient_segout_kernel(int nv, const OffT *
   for (int k = seg_first[v]; k < seg_first[v + 1]; ++k) {
     segs[k].out = run;
     run += seg_count[k];
+  }
+}
+// pass 1 as a copy: the kept entries of a short row sit packed at the row's old offset (pass 0), eight lanes move them to the new one
+template <class OffT>
+__global__ __launch_bounds__(256) void orient_copy_short_kernel(int nv, const OffT *__restrict__ rp, const int *__restrict__ new_rp,
+                                                                const int *__restrict__ tmp_col, int *__restrict__ new_col) {
+  constexpr int G = 8, RPW = 64 / G;
+  const int lane = threadIdx.x & 63;
+  const int grp = lane / G, gl = lane % G;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (int s0 = wave * RPW; s0 < nv; s0 += nwaves * RPW) {
+    const int s = s0 + grp;
+    if (s >= nv) continue;
+    const OffT b = rp[s];
+    if (rp[s + 1] - b > kOrientShort) continue;
+    const int ob = new_rp[s], n = new_rp[s + 1] - ob;
+    for (int i = gl; i < n; i += G) new_col[ob + i] = tmp_col[b + i];
+  }
+}
+template <class OffT>
+__global__ __launch_bounds__(256) void orient_copy_seg_kernel(int nseg, const OrientSegT<OffT> *__restrict__ segs, const int *__restrict__ seg_count,
+                                                              const int *__restrict__ tmp_col, int *__restrict__ new_col) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (int sg = wave; sg < nseg; sg += nwaves) {
+    const OrientSegT<OffT> q = segs[sg];
+    const int n = seg_count[sg];
+    for (int i = lane; i < n; i += 64) new_col[q.out + i] = tmp_col[q.begin + i];
   }
 }
 __global__ __launch_bounds__(256) void max_degree_kernel(int nv, const int *__restrict__ rp, int *__restrict__ out) {
@@ -547,9 +584,15 @@ static int orient_impl(const gm_graph *sym, const OffT *rp_in, gm_graph **out) {
   HIP_TRY(hipMemsetAsync(deg.p, 0, sizeof(int) * ((size_t)nv + 1), 0));
   const int bs = std::max(1, std::min((nv + 31) / 32, sym->cu_count * 8));
   const int bl = std::max(1, std::min((nseg + 3) / 4, sym->cu_count * 8));
-  hipLaunchKernelGGL((orient_short_kernel<OffT>), dim3(bs), dim3(256), 0, 0, nv, rp_in, sym->d_col, sdeg, deg.p, (const int *)nullptr, (int *)nullptr, 0);
+  // (the kept entries packed in a scratch copy at their rows' old offsets: pass 1 copies instead of gathering the degrees again --
+  //  the gathers are the cost of a pass, one 64-byte sector per entry; GM_ORIENT_TWO_GATHERS=1 keeps round 3's second gather pass)
+  const char *env_two = getenv("GM_ORIENT_TWO_GATHERS");
+  const bool two_gathers = env_two && *env_two == '1';
+  DevBuf<int> packed;
+  if (!two_gathers && sym->ne > 0 && packed.alloc((size_t)sym->ne) != hipSuccess) { (void)hipGetLastError(); packed.p = nullptr; }  // (no room: gather twice)
+  hipLaunchKernelGGL((orient_short_kernel<OffT>), dim3(bs), dim3(256), 0, 0, nv, rp_in, sym->d_col, sdeg, deg.p, (const int *)nullptr, (int *)nullptr, 0, packed.p);
   if (nseg)
-    hipLaunchKernelGGL((orient_seg_kernel<OffT>), dim3(bl), dim3(256), 0, 0, nseg, segs.p, rp_in, sym->d_col, sdeg, segcnt.p, deg.p, (int *)nullptr, 0);
+    hipLaunchKernelGGL((orient_seg_kernel<OffT>), dim3(bl), dim3(256), 0, 0, nseg, segs.p, rp_in, sym->d_col, sdeg, segcnt.p, deg.p, (int *)nullptr, 0, packed.p);
   setup_trace("orient: segments + degrees");
   // new offsets = exclusive scan of the new degrees (parallel_prefix_sum, include/scan.h:5-35)
   gm_graph *g = new gm_graph();
@@ -586,9 +629,14 @@ static int orient_impl(const gm_graph *sym, const OffT *rp_in, gm_graph **out) {
   setup_trace("orient: scan, max degree, allocations");
   // pass 1: compact
   if (nseg) hipLaunchKernelGGL((orient_segout_kernel<OffT>), dim3(vb), dim3(256), 0, 0, nv, rp_in, seg_first.p, segcnt.p, g->d_rp, segs.p);
-  hipLaunchKernelGGL((orient_short_kernel<OffT>), dim3(bs), dim3(256), 0, 0, nv, rp_in, sym->d_col, sdeg, (int *)nullptr, g->d_rp, g->d_col, 1);
-  if (nseg)
-    hipLaunchKernelGGL((orient_seg_kernel<OffT>), dim3(bl), dim3(256), 0, 0, nseg, segs.p, rp_in, sym->d_col, sdeg, (int *)nullptr, (int *)nullptr, g->d_col, 1);
+  if (packed.p) {
+    hipLaunchKernelGGL((orient_copy_short_kernel<OffT>), dim3(bs), dim3(256), 0, 0, nv, rp_in, g->d_rp, packed.p, g->d_col);
+    if (nseg) hipLaunchKernelGGL((orient_copy_seg_kernel<OffT>), dim3(bl), dim3(256), 0, 0, nseg, segs.p, segcnt.p, packed.p, g->d_col);
+  } else {
+    hipLaunchKernelGGL((orient_short_kernel<OffT>), dim3(bs), dim3(256), 0, 0, nv, rp_in, sym->d_col, sdeg, (int *)nullptr, g->d_rp, g->d_col, 1, (int *)nullptr);
+    if (nseg)
+      hipLaunchKernelGGL((orient_seg_kernel<OffT>), dim3(bl), dim3(256), 0, 0, nseg, segs.p, rp_in, sym->d_col, sdeg, (int *)nullptr, (int *)nullptr, g->d_col, 1, (int *)nullptr);
+  }
   if ((e = hipGetLastError()) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess) return fail(hip_fail(e, "orient kernels", __FILE__, __LINE__));
   setup_trace("orient: compact");
   int rc = finish_handle(g);
@@ -599,6 +647,14 @@ static int orient_impl(const gm_graph *sym, const OffT *rp_in, gm_graph **out) {
   g->setup.orient_ms = timer.ms();
   *out = g;
   return GM_OK;
+}
+
+// the renumbered copy a solver would run on (get_relabeled), borrowed: for tests and tools that want to look at it
+extern "C" int gm_graph_renumbered(gm_graph *g, int mode, gm_graph **view) {
+  if (!g || !view || mode < 0 || mode > 2) return GM_ERR_INVALID;
+  *view = nullptr;
+  if (g->d_rp64) return GM_ERR_TOO_LARGE;
+  return get_relabeled(g, mode, view);
 }
 
 extern "C" int gm_graph_orient(const gm_graph *sym, gm_graph **out) {
@@ -664,6 +720,124 @@ __global__ __launch_bounds__(256) void relabel_keys_kernel(int nv, long long ne,
       row = (unsigned long long)(unsigned)newid[lo] << bits;
     }
     keys[e] = row | (unsigned long long)(unsigned)newid[col[e]];
+  }
+}
+
+// The rows of the copy WITHOUT a device-wide sort (round 4; rows of at most kRelabelLdsMax entries): the new rows are walked in their new
+// order (oldid = the sorted vertex keys), so the writes are coalesced and the eight rows of a wave have neighbouring degrees.
+//  * a row of <= 64 entries: eight lanes gather the new ids of its entries into LDS and every entry's place is its RANK, the number of
+//    entries of the row below it (n LDS broadcasts against <= 8 values per lane);
+//  * a longer row: one wave, bitonic network in LDS over the next power of two.
+// Two equal entries of a row (a duplicate in the input) set *dup, like the sorted keys did.
+constexpr int kRelabelShort = 64;
+constexpr int kRelabelLdsMax = 4096;
+
+__global__ __launch_bounds__(256) void relabel_rows_short_kernel(int nv, const unsigned long long *__restrict__ vsorted, int descending,
+                                                                 const int *__restrict__ rp, const int *__restrict__ col,
+                                                                 const int *__restrict__ newid, const int *__restrict__ new_rp,
+                                                                 int *__restrict__ new_col, int *__restrict__ dup) {
+  constexpr int G = 8, RPW = 64 / G, K = kRelabelShort / G;
+  __shared__ int vals[4][RPW][kRelabelShort];
+  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+  const int grp = lane / G, gl = lane % G;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  int *mine = vals[wib][grp];
+  for (int r0 = wave * RPW; r0 < nv; r0 += nwaves * RPW) {
+    const int r = r0 + grp;  // new row
+    int n = 0, b = 0, ob = 0;
+    if (r < nv) {
+      const int v = (int)(unsigned)(vsorted[descending ? nv - 1 - r : r] & 0xffffffffull);
+      b = rp[v];
+      n = rp[v + 1] - b;
+      ob = new_rp[r];
+      if (n > kRelabelShort) n = 0;  // the long-row kernel's
+    }
+    const int maxn = wave_max_nonneg(n);
+    if (maxn == 0) continue;
+    const int steps = (maxn + G - 1) / G;
+    int x[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      x[k] = 0x7fffffff;
+      if (k < steps) {
+        const int i = k * G + gl;
+        if (i < n) {
+          x[k] = newid[col[b + i]];
+          mine[i] = x[k];
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    int below[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) below[k] = 0;
+    bool same = false;
+    for (int j = 0; j < maxn; ++j) {
+      if (j < n) {
+        const int y = mine[j];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          if (k < steps) {
+            below[k] += (y < x[k]) ? 1 : 0;
+            same |= (y == x[k]) && (j != k * G + gl);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      if (k < steps && k * G + gl < n) new_col[ob + below[k]] = x[k];
+    if (same) *dup = 1;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+__global__ __launch_bounds__(256) void relabel_rows_long_kernel(int nv, const unsigned long long *__restrict__ vsorted, int descending,
+                                                                const int *__restrict__ rp, const int *__restrict__ col,
+                                                                const int *__restrict__ newid, const int *__restrict__ new_rp,
+                                                                int *__restrict__ new_col, int *__restrict__ dup) {
+  extern __shared__ int lds_rows[];  // kRelabelLdsMax entries per wave
+  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  int *a = lds_rows + wib * kRelabelLdsMax;
+  for (int r0 = wave * 64; r0 < nv; r0 += nwaves * 64) {
+    const int rr = r0 + lane;
+    int nn = 0;
+    if (rr < nv) nn = new_rp[rr + 1] - new_rp[rr];
+    unsigned long long todo = __ballot(nn > kRelabelShort);
+    while (todo) {
+      const int l = __builtin_ctzll(todo);
+      todo &= todo - 1;
+      const int r = r0 + l;
+      const int v = (int)(unsigned)(vsorted[descending ? nv - 1 - r : r] & 0xffffffffull);
+      const int b = rp[v], n = rp[v + 1] - b, ob = new_rp[r];
+      int P = 128;
+      while (P < n) P <<= 1;
+      for (int i = lane; i < P; i += 64) a[i] = i < n ? newid[col[b + i]] : 0x7fffffff;
+      __builtin_amdgcn_wave_barrier();
+      for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+          for (int t = lane; t < (P >> 1); t += 64) {
+            const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // the pair (i, i + j) of compare-exchange t
+            const int p = i | j;
+            const int lo = a[i], hi = a[p];
+            const bool up = (i & k) == 0;
+            if ((lo > hi) == up) { a[i] = hi; a[p] = lo; }
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+      bool same = false;
+      for (int i = lane; i < n; i += 64) {
+        const int y = a[i];
+        new_col[ob + i] = y;
+        same |= i > 0 && a[i - 1] == y;
+      }
+      if (same) *dup = 1;
+      __builtin_amdgcn_wave_barrier();
+    }
   }
 }
 
@@ -790,7 +964,21 @@ int get_relabeled(gm_graph *g, int mode, gm_graph **out) {
   if ((e = hipMalloc(&r->d_rp, sizeof(int) * nv1)) != hipSuccess) return fail(e, "hipMalloc(rp)");
   if ((e = hipMalloc(&r->d_col, sizeof(int) * n1)) != hipSuccess) return fail(e, "hipMalloc(col)");
   if ((e = dev_exclusive_sum(tmp, newdeg.p, r->d_rp, nv1)) != hipSuccess) return fail(e, "ExclusiveSum");
-  if (ne > 0) {
+  // rows of at most kRelabelLdsMax entries are sorted inside the kernels that write them (rank / bitonic network in LDS): no key per
+  // entry, no device-wide sort (GM_RELABEL_GLOBAL_SORT=1: round 3's 64-bit keys + radix sort, also what longer rows fall back on)
+  const char *env_gs = getenv("GM_RELABEL_GLOBAL_SORT");
+  const bool global_sort = env_gs && *env_gs == '1';
+  const bool rows_in_lds = !global_sort && g->max_deg <= kRelabelLdsMax;
+  if (ne > 0 && rows_in_lds) {
+    const int wg = std::max(1, std::min((nv + 31) / 32, g->cu_count * 8));
+    hipLaunchKernelGGL(relabel_rows_short_kernel, dim3(wg), dim3(256), 0, 0, nv, vsorted.p, mode == 1 ? 1 : 0, g->d_rp, g->d_col, newid.p, r->d_rp, r->d_col, dupflag.p);
+    if (g->max_deg > kRelabelShort) {
+      const int wl = std::max(1, std::min((nv + 255) / 256, g->cu_count * 2));
+      hipLaunchKernelGGL(relabel_rows_long_kernel, dim3(wl), dim3(256), sizeof(int) * 4 * kRelabelLdsMax, 0, nv, vsorted.p, mode == 1 ? 1 : 0, g->d_rp, g->d_col, newid.p, r->d_rp,
+                         r->d_col, dupflag.p);
+    }
+    setup_trace("relabel: rows sorted in LDS");
+  } else if (ne > 0) {
     if ((e = keys.alloc(n1)) != hipSuccess || (e = sorted.alloc(n1)) != hipSuccess) return fail(e, "hipMalloc(keys)");
     hipLaunchKernelGGL(relabel_keys_kernel, blocks((ne + 3) / 4), dim3(256), 0, 0, nv, ne, g->d_rp, g->d_col, newid.p, bits, keys.p);
   setup_trace("relabel: allocations + entry keys");

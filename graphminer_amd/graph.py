@@ -151,6 +151,19 @@ class DeviceGraph:
         _lib.check(_lib.load().gm_graph_sort_neighbors(self._h), "gm_graph_sort_neighbors")
         return self
 
+    def renumbered(self, mode: int) -> Graph:
+        """the renumbered copy the solvers take (gm_graph_renumbered: 0 / 1 by degree, 2 topological), downloaded; the device copy
+        stays with this handle"""
+        lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(lib.gm_graph_renumbered(self._h, mode, C.byref(h)), "gm_graph_renumbered")
+        m = gm_csr()
+        _lib.check(lib.gm_graph_meta(h, C.byref(m)), "gm_graph_meta")
+        rp = np.empty(int(m.nv) + 1, dtype=np.int64)
+        ci = np.empty(int(m.ne), dtype=np.int32)
+        _lib.check(lib.gm_graph_download(h, rp.ctypes.data, ci.ctypes.data), "gm_graph_download")
+        return Graph(row_ptr=rp, col_idx=ci)
+
     def download(self) -> Graph:
         rp = np.empty(self.nv + 1, dtype=np.int64)
         ci = np.empty(self.ne, dtype=np.int32)

@@ -82,6 +82,11 @@ int gm_graph_sort_neighbors(gm_graph *g);
 int gm_graph_meta(const gm_graph *g, gm_csr *meta);
 /* D->H copy (row_ptr: nv+1 int64, col_idx: ne int32); either pointer may be NULL. */
 int gm_graph_download(const gm_graph *g, int64_t *row_ptr, int32_t *col_idx);
+/* The renumbered copy the solvers take for this handle, BORROWED (owned by g, freed with it; do not gm_graph_free it): mode 0 / 1 ids
+ * ascending / descending in degree (the SgL kernels), 2 the topological numbering of an oriented graph (TC, k-clique; *view == g when
+ * the handle is a DAG that some other rule oriented). A permutation of the same graph with every row ascending; built once on the device
+ * (the reference has no counterpart: its kernels walk the graph as numbered, src/common/graph.cc:233-279). For tests and tools. */
+int gm_graph_renumbered(gm_graph *g, int mode, gm_graph **view);
 void gm_graph_free(gm_graph *g);
 
 /* Scheduler policy for the multi-GPU task split (include/scheduler.h, src/common/scheduler.cc). */

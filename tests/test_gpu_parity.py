@@ -1029,3 +1029,65 @@ def test_edge_supports_from_the_key_stream(dev, monkeypatch):
             per = n // world
             assert sum(diamond_support_finish(s, total[r * per:(r + 1) * per].contiguous().data_ptr(), per) for r in range(world)) == want
     monkeypatch.delenv("GM_SUP_STREAM")
+
+
+def _renumbered_expected(g, keydeg, descending):
+    """numpy restatement of get_relabeled: ids by (degree, old id), rows ascending"""
+    nv = g.V()
+    order = np.lexsort((np.arange(nv), keydeg))
+    newid = np.empty(nv, dtype=np.int64)
+    newid[order] = (nv - 1 - np.arange(nv)) if descending else np.arange(nv)
+    src = np.repeat(np.arange(nv), np.diff(g.row_ptr))
+    keys = np.sort((newid[src] << 32) | newid[g.col_idx.astype(np.int64)])
+    rp = np.zeros(nv + 1, dtype=np.int64)
+    np.cumsum(np.bincount(keys >> 32, minlength=nv), out=rp[1:])
+    return rp, (keys & 0xFFFFFFFF).astype(np.int32)
+
+
+def _hub_graph(seed, hub_degs, nv=9000, background=30000):
+    """a sparse random symmetric graph with planted hubs of the given degrees (rows on either side of the 64-entry / LDS limits of
+    the renumbering kernels)"""
+    rng = np.random.default_rng(seed)
+    s = [rng.integers(0, nv, background)]
+    d = [rng.integers(0, nv, background)]
+    for u, k in enumerate(hub_degs):
+        s.append(np.full(k, u))
+        d.append(rng.choice(np.arange(len(hub_degs), nv), size=k, replace=False))
+    return csr_from_pairs(nv, np.concatenate(s).astype(np.uint64), np.concatenate(d).astype(np.uint64))
+
+
+@pytest.mark.parametrize("path", ["lds", "global_sort"])
+@pytest.mark.parametrize("graph", ["citeseer", "rmat12", "hubs_lds", "hubs_beyond_lds"])
+def test_renumbered_copies_are_the_permuted_graph(dev, graph, path, monkeypatch):
+    """gm_graph_renumbered (the copies the SgL / TC / k-clique kernels run on): modes 0 / 1 of the symmetric graph, mode 2 of its
+    orientation, against a numpy restatement -- for the rows sorted inside the writing kernels (rank among <= 64 entries, bitonic
+    network in LDS up to 4096) and for the device-wide radix sort (GM_RELABEL_GLOBAL_SORT=1; also what a row of more than 4096
+    entries falls back on). Orientation with the kept entries packed in pass 0 against the two-gather passes."""
+    if path == "global_sort":
+        monkeypatch.setenv("GM_RELABEL_GLOBAL_SORT", "1")
+        monkeypatch.setenv("GM_ORIENT_TWO_GATHERS", "1")
+    if graph == "citeseer":
+        g = load_graph("citeseer")
+    elif graph == "rmat12":
+        g = rmat_csr_numpy(12, 8, 7)
+    elif graph == "hubs_lds":
+        g = _hub_graph(5, [63, 64, 65, 66, 127, 128, 129, 300, 1023, 1024, 1025, 2049, 4000, 4060])
+    else:
+        g = _hub_graph(6, [64, 65, 4096, 4097, 6000])
+    sdeg = np.diff(g.row_ptr)
+    sym = g.to_device(dev)
+    for mode in (0, 1):
+        got = sym.renumbered(mode)
+        rp, ci = _renumbered_expected(g, sdeg, mode == 1)
+        assert np.array_equal(got.row_ptr, rp) and np.array_equal(got.col_idx, ci), (graph, mode)
+    dag = sym.orient()
+    want = O.orient(O.OGraph(g.row_ptr, g.col_idx))
+    host_dag = dag.download()
+    assert np.array_equal(host_dag.row_ptr, want.row_ptr) and np.array_equal(host_dag.col_idx, want.col_idx)
+    got = dag.renumbered(2)
+    rp, ci = _renumbered_expected(host_dag, sdeg, False)
+    assert np.array_equal(got.row_ptr, rp) and np.array_equal(got.col_idx, ci), (graph, 2)
+    src = np.repeat(np.arange(g.V()), np.diff(got.row_ptr))
+    assert np.all(got.col_idx > src)  # topological: every edge from a smaller to a larger id
+    dag.free()
+    sym.free()
