@@ -730,12 +730,15 @@ __global__ __launch_bounds__(256) void relabel_keys_kernel(int nv, long long ne,
 //  * a longer row: one wave, bitonic network in LDS over the next power of two.
 // Two equal entries of a row (a duplicate in the input) set *dup, like the sorted keys did.
 constexpr int kRelabelShort = 64;
+constexpr int kRelabelMid = 1024;
 constexpr int kRelabelLdsMax = 4096;
 
 __global__ __launch_bounds__(256) void relabel_rows_short_kernel(int nv, const unsigned long long *__restrict__ vsorted, int descending,
                                                                  const int *__restrict__ rp, const int *__restrict__ col,
                                                                  const int *__restrict__ newid, const int *__restrict__ new_rp,
-                                                                 int *__restrict__ new_col, int *__restrict__ dup) {
+                                                                 int *__restrict__ new_col, int *__restrict__ dup,
+                                                                 int *__restrict__ long_rows /* [cap]: rows of 65 .. kRelabelMid from the front, longer from the back */,
+                                                                 int cap, int *__restrict__ long_count /* [2] */) {
   constexpr int G = 8, RPW = 64 / G, K = kRelabelShort / G;
   __shared__ int vals[4][RPW][kRelabelShort];
   const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
@@ -751,7 +754,13 @@ __global__ __launch_bounds__(256) void relabel_rows_short_kernel(int nv, const u
       b = rp[v];
       n = rp[v + 1] - b;
       ob = new_rp[r];
-      if (n > kRelabelShort) n = 0;  // the long-row kernel's
+      if (n > kRelabelShort) {  // the long-row kernels': listed (in the order the waves get here: neighbours in degree spread over the list)
+        if (gl == 0) {
+          if (n <= kRelabelMid) long_rows[atomicAdd(&long_count[0], 1)] = r;
+          else long_rows[cap - 1 - atomicAdd(&long_count[1], 1)] = r;
+        }
+        n = 0;
+      }
     }
     const int maxn = wave_max_nonneg(n);
     if (maxn == 0) continue;
@@ -793,51 +802,50 @@ __global__ __launch_bounds__(256) void relabel_rows_short_kernel(int nv, const u
   }
 }
 
+// one wave per listed row, the longest last listed first; CAP entries of LDS per wave (kRelabelMid: ten blocks per CU; kRelabelLdsMax: two)
+template <int CAP>
 __global__ __launch_bounds__(256) void relabel_rows_long_kernel(int nv, const unsigned long long *__restrict__ vsorted, int descending,
                                                                 const int *__restrict__ rp, const int *__restrict__ col,
                                                                 const int *__restrict__ newid, const int *__restrict__ new_rp,
-                                                                int *__restrict__ new_col, int *__restrict__ dup) {
-  extern __shared__ int lds_rows[];  // kRelabelLdsMax entries per wave
+                                                                int *__restrict__ new_col, int *__restrict__ dup,
+                                                                const int *__restrict__ long_rows, int cap, const int *__restrict__ long_count) {
+  __shared__ int lds_rows[4 * CAP];
   const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
-  int *a = lds_rows + wib * kRelabelLdsMax;
-  for (int r0 = wave * 64; r0 < nv; r0 += nwaves * 64) {
-    const int rr = r0 + lane;
-    int nn = 0;
-    if (rr < nv) nn = new_rp[rr + 1] - new_rp[rr];
-    unsigned long long todo = __ballot(nn > kRelabelShort);
-    while (todo) {
-      const int l = __builtin_ctzll(todo);
-      todo &= todo - 1;
-      const int r = r0 + l;
-      const int v = (int)(unsigned)(vsorted[descending ? nv - 1 - r : r] & 0xffffffffull);
-      const int b = rp[v], n = rp[v + 1] - b, ob = new_rp[r];
-      int P = 128;
-      while (P < n) P <<= 1;
-      for (int i = lane; i < P; i += 64) a[i] = i < n ? newid[col[b + i]] : 0x7fffffff;
-      __builtin_amdgcn_wave_barrier();
-      for (int k = 2; k <= P; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-          for (int t = lane; t < (P >> 1); t += 64) {
-            const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // the pair (i, i + j) of compare-exchange t
-            const int p = i | j;
-            const int lo = a[i], hi = a[p];
-            const bool up = (i & k) == 0;
-            if ((lo > hi) == up) { a[i] = hi; a[p] = lo; }
-          }
-          __builtin_amdgcn_wave_barrier();
+  int *a = lds_rows + wib * CAP;
+  const int count = long_count[CAP == kRelabelMid ? 0 : 1];
+  for (int q = wave; q < count; q += nwaves) {
+    const int r = CAP == kRelabelMid ? long_rows[count - 1 - q] : long_rows[cap - count + q];
+    const int v = (int)(unsigned)(vsorted[descending ? nv - 1 - r : r] & 0xffffffffull);
+    const int b = rp[v], n = rp[v + 1] - b, ob = new_rp[r];
+    int P = 256;  // (>= 256: half a network step is then a whole number of 128-exchange rounds)
+    while (P < n) P <<= 1;
+    for (int i = lane; i < P; i += 64) a[i] = i < n ? newid[col[b + i]] : 0x7fffffff;
+    __builtin_amdgcn_wave_barrier();
+    const int half = P >> 1;
+    for (int k = 2; k <= P; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        // compare-exchange t works on the pair (i, i | j); two of them per lane and step so that four LDS reads are in flight
+        for (int t = lane; t < half; t += 128) {
+          const int t2 = t + 64;
+          const int i0 = ((t & ~(j - 1)) << 1) | (t & (j - 1)), i1 = ((t2 & ~(j - 1)) << 1) | (t2 & (j - 1));
+          const int lo0 = a[i0], hi0 = a[i0 | j];
+          const int lo1 = a[i1], hi1 = a[i1 | j];
+          if ((lo0 > hi0) == ((i0 & k) == 0)) { a[i0] = hi0; a[i0 | j] = lo0; }
+          if ((lo1 > hi1) == ((i1 & k) == 0)) { a[i1] = hi1; a[i1 | j] = lo1; }
         }
+        __builtin_amdgcn_wave_barrier();
       }
-      bool same = false;
-      for (int i = lane; i < n; i += 64) {
-        const int y = a[i];
-        new_col[ob + i] = y;
-        same |= i > 0 && a[i - 1] == y;
-      }
-      if (same) *dup = 1;
-      __builtin_amdgcn_wave_barrier();
     }
+    bool same = false;
+    for (int i = lane; i < n; i += 64) {
+      const int y = a[i];
+      new_col[ob + i] = y;
+      same |= i > 0 && a[i - 1] == y;
+    }
+    if (same) *dup = 1;
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -970,13 +978,20 @@ int get_relabeled(gm_graph *g, int mode, gm_graph **out) {
   const bool global_sort = env_gs && *env_gs == '1';
   const bool rows_in_lds = !global_sort && g->max_deg <= kRelabelLdsMax;
   if (ne > 0 && rows_in_lds) {
+    DevBuf<int> long_rows, long_count;
+    const int cap = (int)(ne / (kRelabelShort + 1)) + 1;
+    if ((e = long_rows.alloc((size_t)cap)) != hipSuccess || (e = long_count.alloc(2)) != hipSuccess) return fail(e, "hipMalloc(long rows)");
+    (void)hipMemsetAsync(long_count.p, 0, sizeof(int) * 2, 0);
+    const int desc = mode == 1 ? 1 : 0;
     const int wg = std::max(1, std::min((nv + 31) / 32, g->cu_count * 8));
-    hipLaunchKernelGGL(relabel_rows_short_kernel, dim3(wg), dim3(256), 0, 0, nv, vsorted.p, mode == 1 ? 1 : 0, g->d_rp, g->d_col, newid.p, r->d_rp, r->d_col, dupflag.p);
-    if (g->max_deg > kRelabelShort) {
-      const int wl = std::max(1, std::min((nv + 255) / 256, g->cu_count * 2));
-      hipLaunchKernelGGL(relabel_rows_long_kernel, dim3(wl), dim3(256), sizeof(int) * 4 * kRelabelLdsMax, 0, nv, vsorted.p, mode == 1 ? 1 : 0, g->d_rp, g->d_col, newid.p, r->d_rp,
-                         r->d_col, dupflag.p);
-    }
+    hipLaunchKernelGGL(relabel_rows_short_kernel, dim3(wg), dim3(256), 0, 0, nv, vsorted.p, desc, g->d_rp, g->d_col, newid.p, r->d_rp, r->d_col, dupflag.p, long_rows.p, cap,
+                       long_count.p);
+    if (g->max_deg > kRelabelShort)
+      hipLaunchKernelGGL((relabel_rows_long_kernel<kRelabelMid>), dim3(g->cu_count * 8), dim3(256), 0, 0, nv, vsorted.p, desc, g->d_rp, g->d_col, newid.p, r->d_rp, r->d_col,
+                         dupflag.p, long_rows.p, cap, long_count.p);
+    if (g->max_deg > kRelabelMid)
+      hipLaunchKernelGGL((relabel_rows_long_kernel<kRelabelLdsMax>), dim3(g->cu_count * 2), dim3(256), 0, 0, nv, vsorted.p, desc, g->d_rp, g->d_col, newid.p, r->d_rp, r->d_col,
+                         dupflag.p, long_rows.p, cap, long_count.p);
     setup_trace("relabel: rows sorted in LDS");
   } else if (ne > 0) {
     if ((e = keys.alloc(n1)) != hipSuccess || (e = sorted.alloc(n1)) != hipSuccess) return fail(e, "hipMalloc(keys)");
