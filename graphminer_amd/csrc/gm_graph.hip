@@ -412,21 +412,33 @@ __global__ __launch_bounds__(256) void orient_short_kernel(int nv, const OffT *_
     const int maxds = wave_max_nonneg(ds);
     int n = 0;
     const int ob = (pass && ds > 0) ? new_rp[s] : 0;
-    for (int base = 0; base < maxds; base += G) {
-      const int i = base + gl;
-      bool keep = false;
-      int d = 0;
-      if (i < ds) {
-        d = col[b + i];
-        keep = dag_keep(full, s, sdeg[d], d);
+    // every entry of the (<= 64-entry) rows is requested before the first is looked at, then every degree: two memory latencies per
+    // trip instead of two per eight entries (the passes were latency bound: 94 G entries/s whatever the gather touched)
+    constexpr int KS = kOrientShort / G;
+    int xd[KS], xg[KS];
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      xd[k] = -1;
+      if (k * G < maxds && k * G + gl < ds) xd[k] = col[b + k * G + gl];
+    }
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      xg[k] = 0;
+      if (k * G < maxds && xd[k] >= 0) xg[k] = sdeg[xd[k]];
+    }
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      if (k * G < maxds) {
+        const int d = xd[k];
+        const bool keep = d >= 0 && dag_keep(full, s, xg[k], d);
+        const unsigned long long m = (__ballot(keep) >> (grp * G)) & 0xffull;
+        if (keep) {
+          const int at = n + __popcll(m & ((1ull << gl) - 1ull));
+          if (pass) new_col[ob + at] = d;
+          else if (tmp_col) tmp_col[b + at] = d;  // kept entries packed at the row's own place: pass 1 is then a copy, not a second gather
+        }
+        n += __popcll(m);
       }
-      const unsigned long long m = (__ballot(keep) >> (grp * G)) & 0xffull;
-      if (keep) {
-        const int at = n + __popcll(m & ((1ull << gl) - 1ull));
-        if (pass) new_col[ob + at] = d;
-        else if (tmp_col) tmp_col[b + at] = d;  // kept entries packed at the row's own place: pass 1 is then a copy, not a second gather
-      }
-      n += __popcll(m);
     }
     if (!pass && gl == 0 && s < nv && full <= kOrientShort) new_deg[s] = n;
   }
@@ -444,20 +456,26 @@ __global__ __launch_bounds__(256) void orient_seg_kernel(int nseg, const OrientS
     const OrientSegT<OffT> q = segs[sg];
     const int ds = (int)(rp[q.row + 1] - rp[q.row]);
     int n = 0;
-    for (OffT base = q.begin; base < q.end; base += 64) {
-      const OffT i = base + lane;
-      bool keep = false;
-      int d = 0;
-      if (i < q.end) {
-        d = col[i];
-        keep = dag_keep(ds, q.row, sdeg[d], d);
+    for (OffT base = q.begin; base < q.end; base += 256) {  // four 64-entry steps requested together
+      int xd[4], xg[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const OffT i = base + k * 64 + lane;
+        xd[k] = i < q.end ? col[i] : -1;
       }
-      const unsigned long long m = __ballot(keep);
-      if (keep) {
-        if (pass) new_col[q.out + n + rank_below(m)] = d;
-        else if (tmp_col) tmp_col[q.begin + n + rank_below(m)] = d;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) xg[k] = xd[k] >= 0 ? sdeg[xd[k]] : 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int d = xd[k];
+        const bool keep = d >= 0 && dag_keep(ds, q.row, xg[k], d);
+        const unsigned long long m = __ballot(keep);
+        if (keep) {
+          if (pass) new_col[q.out + n + rank_below(m)] = d;
+          else if (tmp_col) tmp_col[q.begin + n + rank_below(m)] = d;
+        }
+        n += __popcll(m);
       }
-      n += __popcll(m);
     }
     if (!pass && lane == 0) {
       seg_count[sg] = n;
@@ -819,7 +837,7 @@ __global__ __launch_bounds__(256) void relabel_rows_long_kernel(int nv, const un
     const int r = CAP == kRelabelMid ? long_rows[count - 1 - q] : long_rows[cap - count + q];
     const int v = (int)(unsigned)(vsorted[descending ? nv - 1 - r : r] & 0xffffffffull);
     const int b = rp[v], n = rp[v + 1] - b, ob = new_rp[r];
-    int P = 256;  // (>= 256: half a network step is then a whole number of 128-exchange rounds)
+    int P = 128;
     while (P < n) P <<= 1;
     for (int i = lane; i < P; i += 64) a[i] = i < n ? newid[col[b + i]] : 0x7fffffff;
     __builtin_amdgcn_wave_barrier();
@@ -831,9 +849,11 @@ __global__ __launch_bounds__(256) void relabel_rows_long_kernel(int nv, const un
           const int t2 = t + 64;
           const int i0 = ((t & ~(j - 1)) << 1) | (t & (j - 1)), i1 = ((t2 & ~(j - 1)) << 1) | (t2 & (j - 1));
           const int lo0 = a[i0], hi0 = a[i0 | j];
-          const int lo1 = a[i1], hi1 = a[i1 | j];
+          const bool two = t2 < half;  // (wave-uniform: only the 128-entry network has a single round of 64 exchanges)
+          int lo1 = 0, hi1 = 0;
+          if (two) { lo1 = a[i1]; hi1 = a[i1 | j]; }
           if ((lo0 > hi0) == ((i0 & k) == 0)) { a[i0] = hi0; a[i0 | j] = lo0; }
-          if ((lo1 > hi1) == ((i1 & k) == 0)) { a[i1] = hi1; a[i1 | j] = lo1; }
+          if (two && (lo1 > hi1) == ((i1 & k) == 0)) { a[i1] = hi1; a[i1 | j] = lo1; }
         }
         __builtin_amdgcn_wave_barrier();
       }
@@ -860,19 +880,27 @@ __global__ __launch_bounds__(256) void relabel_cols_kernel(long long ne, const u
   if (e > 0 && keys[e - 1] == k) *dup = 1;
 }
 // Rows strictly ascending?  Every solver relies on it (bisection, trimmed tasks, position = rank); the reference sorts on request
-// (adj_sorted = 0 -> Graph::sort_neighbors, src/common/graph.cc:138).  One pass: a descent col[e - 1] >= col[e] is legitimate only where a
-// row starts -- verified by a bisection of the offsets, for the descents only.
-__global__ __launch_bounds__(256) void sorted_check_kernel(int nv, long long ne, const int *__restrict__ rp, const int *__restrict__ col, int *__restrict__ not_sorted) {
+// (adj_sorted = 0 -> Graph::sort_neighbors, src/common/graph.cc:138).  A descent col[e - 1] >= col[e] is legitimate only where a row
+// starts: one pass over the entries counts the descents, one over the rows counts those that sit at the start of a row -- the rows are
+// ascending iff the two counts are equal.  (Until round 4 every descent bisected the offsets for its row: one bisection per row of a
+// sorted graph, 3.0 ms on R-MAT-24.)
+__global__ __launch_bounds__(256) void sorted_check_kernel(long long ne, const int *__restrict__ col, unsigned long long *__restrict__ counts) {
   const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long e = 1 + (long long)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += stride) {
-    if (col[e - 1] < col[e]) continue;
-    int lo = 0, hi = nv - 1;  // the row of entry e: largest u with rp[u] <= e
-    while (lo < hi) {
-      const int mid = (int)(((long long)lo + hi + 1) >> 1);
-      if (rp[mid] <= e) lo = mid; else hi = mid - 1;
-    }
-    if (rp[lo] != e) *not_sorted = 1;
+  unsigned long long n = 0;
+  for (long long e = 1 + (long long)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += stride) n += col[e - 1] >= col[e];
+  n = wave_sum_u64(n);
+  if ((threadIdx.x & 63) == 0 && n) atomicAdd(&counts[0], n);
+}
+__global__ __launch_bounds__(256) void sorted_rowstart_kernel(int nv, const int *__restrict__ rp, const int *__restrict__ col, unsigned long long *__restrict__ counts) {
+  unsigned long long n = 0;
+  for (long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x; u < nv; u += (long long)gridDim.x * blockDim.x) {
+    const int b = rp[u];
+    if (b > 0 && rp[u + 1] > b) n += col[b - 1] >= col[b];
   }
+  // (one atomic per wave of a bounded grid: same-address atomics are served one after the other, ~10 ns each -- a wave per 64 rows of
+  //  R-MAT-24 spent 2.6 of this kernel's 3.0 ms queueing 260 k of them)
+  n = wave_sum_u64(n);
+  if ((threadIdx.x & 63) == 0 && n) atomicAdd(&counts[1], n);
 }
 // rows are ascending: the numbering is topological (every edge u -> v has u < v) iff no row starts at or below its own vertex
 __global__ __launch_bounds__(256) void topo_check_kernel(int nv, const int *__restrict__ rp, const int *__restrict__ col, int *__restrict__ not_topo) {
@@ -886,14 +914,15 @@ int graph_rows_sorted(gm_graph *g, bool *out) {
       g->sorted_state = 1;
     } else {
       HIP_TRY(hipSetDevice(g->device));
-      DevBuf<int> flag;
-      HIP_TRY(flag.alloc(1));
-      HIP_TRY(hipMemsetAsync(flag.p, 0, sizeof(int), 0));
-      const long long blocks = std::min<long long>((g->ne + 255) / 256, (long long)g->cu_count * 32);
-      hipLaunchKernelGGL(sorted_check_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, g->nv, g->ne, g->d_rp, g->d_col, flag.p);
-      int bad = 0;
-      HIP_TRY(hipMemcpy(&bad, flag.p, sizeof(int), hipMemcpyDeviceToHost));
-      g->sorted_state = bad ? 2 : 1;
+      DevBuf<unsigned long long> counts;
+      HIP_TRY(counts.alloc(2));
+      HIP_TRY(hipMemsetAsync(counts.p, 0, sizeof(unsigned long long) * 2, 0));
+      const long long blocks = std::min<long long>((g->ne + 255) / 256, (long long)g->cu_count * 8);
+      hipLaunchKernelGGL(sorted_check_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, g->ne, g->d_col, counts.p);
+      hipLaunchKernelGGL(sorted_rowstart_kernel, dim3((unsigned)std::min<long long>(((long long)g->nv + 255) / 256, (long long)g->cu_count * 8)), dim3(256), 0, 0, g->nv, g->d_rp, g->d_col, counts.p);
+      unsigned long long c[2] = {0, 0};
+      HIP_TRY(hipMemcpy(c, counts.p, sizeof(c), hipMemcpyDeviceToHost));
+      g->sorted_state = c[0] != c[1] ? 2 : 1;
     }
   }
   *out = g->sorted_state == 1;

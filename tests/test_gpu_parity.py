@@ -1091,3 +1091,29 @@ def test_renumbered_copies_are_the_permuted_graph(dev, graph, path, monkeypatch)
     assert np.all(got.col_idx > src)  # topological: every edge from a smaller to a larger id
     dag.free()
     sym.free()
+
+
+@pytest.mark.parametrize("two_gathers", [False, True])
+def test_orientation_around_the_byte_cap_of_the_degrees(dev, two_gathers, monkeypatch):
+    """the orientation passes compare degrees capped at 255 in one byte per vertex and read the exact degree only for an entry between
+    two vertices of >= 255 neighbours: hubs of 253 .. 257 / 300 neighbours, ties on either side of the cap, every pair of hubs adjacent,
+    against the oracle's Graph::orientation (GM_ORIENT_TWO_GATHERS=1: the exact degrees gathered in both passes)"""
+    if two_gathers:
+        monkeypatch.setenv("GM_ORIENT_TWO_GATHERS", "1")
+    degs = [253, 254, 254, 255, 255, 255, 256, 256, 257, 300, 300, 1500]
+    nh = len(degs)
+    s, d, nxt = [], [], nh
+    for u, k in enumerate(degs):
+        leaves = k - (nh - 1)
+        s.append(np.full(leaves, u)); d.append(np.arange(nxt, nxt + leaves)); nxt += leaves
+        s.append(np.full(nh - 1 - u, u)); d.append(np.arange(u + 1, nh))
+    g = csr_from_pairs(nxt, np.concatenate(s).astype(np.uint64), np.concatenate(d).astype(np.uint64))
+    assert sorted(np.diff(g.row_ptr)[:nh].tolist()) == sorted(degs)
+    sym = g.to_device(dev)
+    dag = sym.orient()
+    want = O.orient(O.OGraph(g.row_ptr, g.col_idx))
+    got = dag.download()
+    assert np.array_equal(got.row_ptr, want.row_ptr) and np.array_equal(got.col_idx, want.col_idx)
+    assert TCSolver(dag) == math.comb(nh, 3)
+    dag.free()
+    sym.free()
