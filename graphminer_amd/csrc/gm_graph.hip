@@ -756,7 +756,8 @@ __global__ __launch_bounds__(256) void relabel_rows_short_kernel(int nv, const u
                                                                  const int *__restrict__ newid, const int *__restrict__ new_rp,
                                                                  int *__restrict__ new_col, int *__restrict__ dup,
                                                                  int *__restrict__ long_rows /* [cap]: rows of 65 .. kRelabelMid from the front, longer from the back */,
-                                                                 int cap, int *__restrict__ long_count /* [2] */) {
+                                                                 int cap, int *__restrict__ long_count /* [3] */,
+                                                                 int *__restrict__ huge_rows /* rows beyond kRelabelLdsMax entries */) {
   constexpr int G = 8, RPW = 64 / G, K = kRelabelShort / G;
   __shared__ int vals[4][RPW][kRelabelShort];
   const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
@@ -775,7 +776,8 @@ __global__ __launch_bounds__(256) void relabel_rows_short_kernel(int nv, const u
       if (n > kRelabelShort) {  // the long-row kernels': listed (in the order the waves get here: neighbours in degree spread over the list)
         if (gl == 0) {
           if (n <= kRelabelMid) long_rows[atomicAdd(&long_count[0], 1)] = r;
-          else long_rows[cap - 1 - atomicAdd(&long_count[1], 1)] = r;
+          else if (n <= kRelabelLdsMax) long_rows[cap - 1 - atomicAdd(&long_count[1], 1)] = r;
+          else huge_rows[atomicAdd(&long_count[2], 1)] = r;
         }
         n = 0;
       }
@@ -866,6 +868,77 @@ __global__ __launch_bounds__(256) void relabel_rows_long_kernel(int nv, const un
     }
     if (same) *dup = 1;
     __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// a listed row of 1025 .. CAP = kRelabelLdsMax entries: the whole workgroup, bitonic network in LDS (a wave per such row: 5.9 ms on the
+// symmetric R-MAT-24, the workgroup 3.1).  (A 32768-entry instance in 128 KB of LDS for the hubs was measured too: 14.5 ms of kernel
+// at one workgroup per CU and ~190 ms for the first launch of a kernel with more than 64 KB of LDS -- the hubs go through a segmented
+// radix sort instead.)
+template <int CAP>
+__global__ __launch_bounds__(256) void relabel_rows_block_kernel(int nv, const unsigned long long *__restrict__ vsorted, int descending,
+                                                                 const int *__restrict__ rp, const int *__restrict__ col,
+                                                                 const int *__restrict__ newid, const int *__restrict__ new_rp,
+                                                                 int *__restrict__ new_col, int *__restrict__ dup,
+                                                                 const int *__restrict__ rows, int cap, const int *__restrict__ long_count) {
+  extern __shared__ int lds_row[];
+  int *a = lds_row;
+  const int tid = threadIdx.x;
+  const int count = long_count[1];
+  for (int q = blockIdx.x; q < count; q += gridDim.x) {
+    const int r = rows[cap - count + q];
+    const int v = (int)(unsigned)(vsorted[descending ? nv - 1 - r : r] & 0xffffffffull);
+    const int b = rp[v], n = rp[v + 1] - b, ob = new_rp[r];
+    if (n > CAP) continue;  // (workgroup-uniform)
+    int P = 1024;
+    while (P < n) P <<= 1;
+    for (int i = tid; i < P; i += 256) a[i] = i < n ? newid[col[b + i]] : 0x7fffffff;
+    __syncthreads();
+    const int half = P >> 1;
+    for (int k = 2; k <= P; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int t = tid; t < half; t += 512) {  // (half >= 512: two exchanges per thread and round)
+          const int t2 = t + 256;
+          const int i0 = ((t & ~(j - 1)) << 1) | (t & (j - 1)), i1 = ((t2 & ~(j - 1)) << 1) | (t2 & (j - 1));
+          const int lo0 = a[i0], hi0 = a[i0 | j];
+          const int lo1 = a[i1], hi1 = a[i1 | j];
+          if ((lo0 > hi0) == ((i0 & k) == 0)) { a[i0] = hi0; a[i0 | j] = lo0; }
+          if ((lo1 > hi1) == ((i1 & k) == 0)) { a[i1] = hi1; a[i1 | j] = lo1; }
+        }
+        __syncthreads();
+      }
+    }
+    bool same = false;
+    for (int i = tid; i < n; i += 256) {
+      const int y = a[i];
+      new_col[ob + i] = y;
+      same |= i > 0 && a[i - 1] == y;
+    }
+    if (same) *dup = 1;
+    __syncthreads();
+  }
+}
+
+// rows beyond kRelabelLdsMax entries (the hubs of a symmetric graph: a few thousand rows at most): one workgroup per row writes the
+// new ids of its entries, unsorted, into a scratch copy at the row's new place and the row's segment; ONE segmented radix sort over
+// those segments alone moves them, sorted, into the copy (PHASE 0).  PHASE 1 looks for two equal neighbours.
+template <int PHASE>
+__global__ __launch_bounds__(256) void relabel_rows_huge_kernel(int nv, const unsigned long long *__restrict__ vsorted, int descending,
+                                                                const int *__restrict__ rp, const int *__restrict__ col,
+                                                                const int *__restrict__ newid, const int *__restrict__ new_rp,
+                                                                const int *__restrict__ huge_rows, int *__restrict__ scratch,
+                                                                int *__restrict__ seg_begin, int *__restrict__ seg_end,
+                                                                const int *__restrict__ new_col, int *__restrict__ dup) {
+  const int r = huge_rows[blockIdx.x];
+  const int v = (int)(unsigned)(vsorted[descending ? nv - 1 - r : r] & 0xffffffffull);
+  const int b = rp[v], n = rp[v + 1] - b, ob = new_rp[r];
+  if (PHASE == 0) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) scratch[ob + i] = newid[col[b + i]];
+    if (threadIdx.x == 0) { seg_begin[blockIdx.x] = ob; seg_end[blockIdx.x] = ob + n; }
+  } else {
+    bool same = false;
+    for (int i = 1 + threadIdx.x; i < n; i += blockDim.x) same |= new_col[ob + i - 1] == new_col[ob + i];
+    if (same) *dup = 1;
   }
 }
 
@@ -1002,25 +1075,47 @@ int get_relabeled(gm_graph *g, int mode, gm_graph **out) {
   if ((e = hipMalloc(&r->d_col, sizeof(int) * n1)) != hipSuccess) return fail(e, "hipMalloc(col)");
   if ((e = dev_exclusive_sum(tmp, newdeg.p, r->d_rp, nv1)) != hipSuccess) return fail(e, "ExclusiveSum");
   // rows of at most kRelabelLdsMax entries are sorted inside the kernels that write them (rank / bitonic network in LDS): no key per
-  // entry, no device-wide sort (GM_RELABEL_GLOBAL_SORT=1: round 3's 64-bit keys + radix sort, also what longer rows fall back on)
+  // entry, no device-wide sort; the few rows beyond that -- the hubs of a symmetric graph -- through one segmented radix sort of their
+  // segments (GM_RELABEL_GLOBAL_SORT=1: round 3's 64-bit keys + radix sort of every entry)
   const char *env_gs = getenv("GM_RELABEL_GLOBAL_SORT");
   const bool global_sort = env_gs && *env_gs == '1';
-  const bool rows_in_lds = !global_sort && g->max_deg <= kRelabelLdsMax;
+  const bool rows_in_lds = !global_sort;
   if (ne > 0 && rows_in_lds) {
-    DevBuf<int> long_rows, long_count;
-    const int cap = (int)(ne / (kRelabelShort + 1)) + 1;
-    if ((e = long_rows.alloc((size_t)cap)) != hipSuccess || (e = long_count.alloc(2)) != hipSuccess) return fail(e, "hipMalloc(long rows)");
-    (void)hipMemsetAsync(long_count.p, 0, sizeof(int) * 2, 0);
+    DevBuf<int> long_rows, long_count, huge_rows;
+    const int cap = (int)(ne / (kRelabelShort + 1)) + 1, hcap = (int)(ne / (kRelabelLdsMax + 1)) + 1;
+    if ((e = long_rows.alloc((size_t)cap)) != hipSuccess || (e = long_count.alloc(3)) != hipSuccess || (e = huge_rows.alloc((size_t)hcap)) != hipSuccess)
+      return fail(e, "hipMalloc(long rows)");
+    (void)hipMemsetAsync(long_count.p, 0, sizeof(int) * 3, 0);
     const int desc = mode == 1 ? 1 : 0;
     const int wg = std::max(1, std::min((nv + 31) / 32, g->cu_count * 8));
     hipLaunchKernelGGL(relabel_rows_short_kernel, dim3(wg), dim3(256), 0, 0, nv, vsorted.p, desc, g->d_rp, g->d_col, newid.p, r->d_rp, r->d_col, dupflag.p, long_rows.p, cap,
-                       long_count.p);
+                       long_count.p, huge_rows.p);
     if (g->max_deg > kRelabelShort)
       hipLaunchKernelGGL((relabel_rows_long_kernel<kRelabelMid>), dim3(g->cu_count * 8), dim3(256), 0, 0, nv, vsorted.p, desc, g->d_rp, g->d_col, newid.p, r->d_rp, r->d_col,
                          dupflag.p, long_rows.p, cap, long_count.p);
     if (g->max_deg > kRelabelMid)
-      hipLaunchKernelGGL((relabel_rows_long_kernel<kRelabelLdsMax>), dim3(g->cu_count * 2), dim3(256), 0, 0, nv, vsorted.p, desc, g->d_rp, g->d_col, newid.p, r->d_rp, r->d_col,
-                         dupflag.p, long_rows.p, cap, long_count.p);
+      hipLaunchKernelGGL((relabel_rows_block_kernel<kRelabelLdsMax>), dim3(g->cu_count * 8), dim3(256), sizeof(int) * kRelabelLdsMax, 0, nv, vsorted.p, desc, g->d_rp,
+                         g->d_col, newid.p, r->d_rp, r->d_col, dupflag.p, long_rows.p, cap, long_count.p);
+    if (g->max_deg > kRelabelLdsMax) {  // the hubs of a symmetric graph: their segments through one segmented radix sort
+      int nhuge = 0;
+      if ((e = hipMemcpy(&nhuge, long_count.p + 2, sizeof(int), hipMemcpyDeviceToHost)) != hipSuccess) return fail(e, "hipMemcpy");
+      if (nhuge > 0) {
+        DevBuf<int> scratch, seg_begin, seg_end;
+        if ((e = scratch.alloc(n1)) != hipSuccess || (e = seg_begin.alloc((size_t)nhuge)) != hipSuccess || (e = seg_end.alloc((size_t)nhuge)) != hipSuccess)
+          return fail(e, "hipMalloc(huge rows)");
+        hipLaunchKernelGGL((relabel_rows_huge_kernel<0>), dim3((unsigned)nhuge), dim3(256), 0, 0, nv, vsorted.p, desc, g->d_rp, g->d_col, newid.p, r->d_rp, huge_rows.p,
+                           scratch.p, seg_begin.p, seg_end.p, (const int *)nullptr, dupflag.p);
+        size_t bytes = 0;
+        if ((e = hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, bytes, scratch.p, r->d_col, (int)ne, nhuge, seg_begin.p, seg_end.p, 0, bits)) != hipSuccess)
+          return fail(e, "SegmentedSortKeys(size)");
+        if ((e = tmp.reserve(bytes)) != hipSuccess) return fail(e, "hipMalloc(sort temp)");
+        if ((e = hipcub::DeviceSegmentedRadixSort::SortKeys(tmp.buf.p, bytes, scratch.p, r->d_col, (int)ne, nhuge, seg_begin.p, seg_end.p, 0, bits)) != hipSuccess)
+          return fail(e, "SegmentedSortKeys");
+        hipLaunchKernelGGL((relabel_rows_huge_kernel<1>), dim3((unsigned)nhuge), dim3(256), 0, 0, nv, vsorted.p, desc, g->d_rp, g->d_col, newid.p, r->d_rp, huge_rows.p,
+                           (int *)nullptr, (int *)nullptr, (int *)nullptr, (const int *)r->d_col, dupflag.p);
+        if ((e = hipDeviceSynchronize()) != hipSuccess) return fail(e, "relabel huge rows");  // (the scratch arrays go out of scope)
+      }
+    }
     setup_trace("relabel: rows sorted in LDS");
   } else if (ne > 0) {
     if ((e = keys.alloc(n1)) != hipSuccess || (e = sorted.alloc(n1)) != hipSuccess) return fail(e, "hipMalloc(keys)");

@@ -1057,12 +1057,12 @@ def _hub_graph(seed, hub_degs, nv=9000, background=30000):
 
 
 @pytest.mark.parametrize("path", ["lds", "global_sort"])
-@pytest.mark.parametrize("graph", ["citeseer", "rmat12", "hubs_lds", "hubs_beyond_lds"])
+@pytest.mark.parametrize("graph", ["citeseer", "rmat12", "hubs_lds", "hubs_beyond_lds", "hubs_beyond_block"])
 def test_renumbered_copies_are_the_permuted_graph(dev, graph, path, monkeypatch):
     """gm_graph_renumbered (the copies the SgL / TC / k-clique kernels run on): modes 0 / 1 of the symmetric graph, mode 2 of its
     orientation, against a numpy restatement -- for the rows sorted inside the writing kernels (rank among <= 64 entries, bitonic
-    network in LDS up to 4096) and for the device-wide radix sort (GM_RELABEL_GLOBAL_SORT=1; also what a row of more than 4096
-    entries falls back on). Orientation with the kept entries packed in pass 0 against the two-gather passes."""
+    network in LDS: a wave up to 1024 entries, a workgroup up to 4096; longer rows through a segmented radix sort of their
+    segments) and for the device-wide radix sort of 64-bit entry keys (GM_RELABEL_GLOBAL_SORT=1). Orientation with the kept entries packed in pass 0 against the two-gather passes."""
     if path == "global_sort":
         monkeypatch.setenv("GM_RELABEL_GLOBAL_SORT", "1")
         monkeypatch.setenv("GM_ORIENT_TWO_GATHERS", "1")
@@ -1072,8 +1072,10 @@ def test_renumbered_copies_are_the_permuted_graph(dev, graph, path, monkeypatch)
         g = rmat_csr_numpy(12, 8, 7)
     elif graph == "hubs_lds":
         g = _hub_graph(5, [63, 64, 65, 66, 127, 128, 129, 300, 1023, 1024, 1025, 2049, 4000, 4060])
-    else:
+    elif graph == "hubs_beyond_lds":
         g = _hub_graph(6, [64, 65, 4096, 4097, 6000])
+    else:  # hubs of tens of thousands of entries through the segmented radix sort
+        g = _hub_graph(8, [1000, 5000, 32768, 32769, 33000, 45000], nv=50000, background=100000)
     sdeg = np.diff(g.row_ptr)
     sym = g.to_device(dev)
     for mode in (0, 1):
