@@ -741,11 +741,14 @@ __global__ __launch_bounds__(256) void relabel_keys_kernel(int nv, long long ne,
   }
 }
 
-// The rows of the copy WITHOUT a device-wide sort (round 4; rows of at most kRelabelLdsMax entries): the new rows are walked in their new
-// order (oldid = the sorted vertex keys), so the writes are coalesced and the eight rows of a wave have neighbouring degrees.
-//  * a row of <= 64 entries: eight lanes gather the new ids of its entries into LDS and every entry's place is its RANK, the number of
-//    entries of the row below it (n LDS broadcasts against <= 8 values per lane);
-//  * a longer row: one wave, bitonic network in LDS over the next power of two.
+// The rows of the copy WITHOUT a device-wide sort (round 4): the new rows are walked in their new order (oldid = the sorted vertex keys),
+// so the writes are coalesced and the eight rows of a wave have neighbouring degrees.
+//  * a row of <= kRelabelShort entries: eight lanes gather the new ids of its entries into LDS and every entry's place is its RANK, the
+//    number of entries of the row below it (n LDS broadcasts against <= 8 values per lane); longer rows are LISTED by this kernel;
+//  * a listed row of <= kRelabelMid entries: one wave, bitonic network in LDS over the next power of two (relabel_rows_long_kernel);
+//  * a listed row of <= kRelabelLdsMax entries: the same network by a whole workgroup (relabel_rows_block_kernel);
+//  * a row beyond that (the hubs of a symmetric graph): new ids written unsorted, one segmented radix sort over those rows' segments
+//    (relabel_rows_huge_kernel + get_relabeled).
 // Two equal entries of a row (a duplicate in the input) set *dup, like the sorted keys did.
 constexpr int kRelabelShort = 64;
 constexpr int kRelabelMid = 1024;
@@ -822,7 +825,7 @@ __global__ __launch_bounds__(256) void relabel_rows_short_kernel(int nv, const u
   }
 }
 
-// one wave per listed row, the longest last listed first; CAP entries of LDS per wave (kRelabelMid: ten blocks per CU; kRelabelLdsMax: two)
+// one wave per listed row of 65 .. CAP = kRelabelMid entries, the last listed (longest) first; CAP entries of LDS per wave
 template <int CAP>
 __global__ __launch_bounds__(256) void relabel_rows_long_kernel(int nv, const unsigned long long *__restrict__ vsorted, int descending,
                                                                 const int *__restrict__ rp, const int *__restrict__ col,
