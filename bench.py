@@ -109,6 +109,7 @@ def parse():
     ap.add_argument("--share-world", type=int, default=1, help=argparse.SUPPRESS)  # ... of this world on ONE GPU (rank / world are launch arguments)
     ap.add_argument("--tune", default="", help="comma separated gm_launch.tune[] override")
     ap.add_argument("--policy", type=int, default=0, help="0 = chunked round robin, 1 = contiguous ranges")
+    ap.add_argument("--detail", default="", help="where the FULL record goes (default gpurun_out/bench_detail.json); stdout carries one compact line")
     return ap.parse_args()
 
 
@@ -381,7 +382,9 @@ class Runner:
         torch.cuda.set_device(self.local_rank)
         self.dev = torch.device("cuda", self.local_rank)
         self.use_dist = self.world > 1 or os.environ.get("GM_BENCH_FORCE_DIST") == "1"  # the latter: exercise RCCL with one rank
-        self.backend = os.environ.get("GM_BENCH_BACKEND", "nccl")  # "nccl" = RCCL over xGMI; "gloo": the dry run (counts staged through the host)
+        # "nccl" = RCCL over xGMI; "gloo": the dry run (counts staged through the host) -- the default when every rank shares GPU 0,
+        # where RCCL refuses two ranks on one device
+        self.backend = os.environ.get("GM_BENCH_BACKEND", "gloo" if (self.one_gpu and self.world > 1) else "nccl")
         if self.use_dist:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
@@ -392,6 +395,13 @@ class Runner:
                 dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev, timeout=datetime.timedelta(minutes=60))
             else:
                 dist.init_process_group(self.backend, rank=self.rank, world_size=self.world, timeout=datetime.timedelta(minutes=60))
+        # the ranks the collective actually reaches: an all-reduce of ones (1 without a process group)
+        self.ranks_seen = 1
+        if self.use_dist:
+            ones = torch.ones(1, dtype=torch.int64, device=self.dev)
+            self.all_reduce(ones)
+            self.ranks_seen = int(ones.item())
+            assert self.ranks_seen == self.world, f"the all-reduce saw {self.ranks_seen} ranks of {self.world}"
         from graphminer_amd import _lib
 
         self._lib = _lib
@@ -910,6 +920,10 @@ def finish_record(rec, a, world, ab, floor, traffic, traffic_src, cpu, known, st
 
     out["roofline"] = roof
     if cpu:
+        fs = full_size_cpu(rec["workload"], rec["graph"], rec["tasks"])
+        if fs:  # the stated baseline ON the bench graph, beside this run's reduced-scale check
+            fs["count_equals_gpu_count_of_this_run"] = bool(known is not None and known["count"] == rec["count"])
+            cpu = dict(cpu, full_size=fs)
         out["cpu_baseline"] = cpu
     # count check: against the CPU count of this run when one exists, else against the recorded full-size oracle answers
     chk = {}
@@ -924,6 +938,18 @@ def finish_record(rec, a, world, ab, floor, traffic, traffic_src, cpu, known, st
         chk = {"count_matches_cpu": None, "cpu_count_source": "no full CPU count for this graph (sampled baseline only)"}
     out.update(chk)
     return out
+
+
+def full_size_cpu(workload, graph_name, tasks):
+    """the recorded run of the reference's binary on the WHOLE bench graph (minutes: not repeated inside bench.py) -- tests/golden/fullsize.json"""
+    try:
+        e = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize.json"))).get(f"{workload}:{graph_name}") or {}
+        if "reference_seconds" not in e:
+            return None
+        return {"seconds": e["reference_seconds"], "threads": e.get("threads"), "binary": e.get("binary"), "recorded": e.get("recorded"),
+                "value": round(tasks / e["reference_seconds"] / 1e6, 4), "unit": "Medges/s", "count_equals_gpu_count_of_this_run": None}
+    except Exception:
+        return None
 
 
 def known_answer(a, workload, graph_name):
@@ -942,10 +968,100 @@ def known_answer(a, workload, graph_name):
         return None
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks here (the reference's *_multigpu binaries take
+    n_gpu as an argument and spawn their own threads, src/clique/multigpu.cu:20,109-115) -- re-exec under torch.distributed.run, one
+    process per GPU, rendezvous on 127.0.0.1. Under an external launcher (WORLD_SIZE set) nothing happens here."""
+    if a.gpus <= 1 or "WORLD_SIZE" in os.environ or a.traffic_worker:
+        return
+    import socket
+
+    import torch
+
+    have = torch.cuda.device_count()
+    if os.environ.get("GM_BENCH_ONE_GPU") != "1" and have < a.gpus:
+        raise SystemExit(f"bench.py --gpus {a.gpus}: only {have} HIP device(s) visible on this node (HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES', '')!r}); "
+                         f"run with --gpus {max(have, 1)}, or GM_BENCH_ONE_GPU=1 for the one-GPU dry run of the {a.gpus}-rank path")
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), GM_BENCH_SELF_LAUNCHED="1")
+    env.pop("MASTER_PORT", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__), *sys.argv[1:]]
+    print(f"[bench] --gpus {a.gpus} without a launcher: starting {a.gpus} ranks: {' '.join(cmd[1:9])} ...", file=sys.stderr, flush=True)
+    sys.stdout.flush()
+    os.execve(sys.executable, cmd, env)
+
+
+SHORT_BASIS = (("counter traffic", "counter_traffic: rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE / HIP-event kernel time / 8 TB/s"),
+               ("NO counter pass", "own_bytes (no counter pass in this run) / kernel time / 8 TB/s"),
+               ("algorithmic bytes", "algorithmic bytes (SURVEY 8d) / kernel time / 8 TB/s"))
+
+
+def compact_roofline(r):
+    """the roofline object of the stdout line: the contract's keys + the three byte figures, no prose"""
+    keys = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "own_bytes_per_launch", "own_frac", "algorithmic_bytes_per_launch",
+            "algorithmic_GBs", "frac_8d_valid", "compulsory_floor_bytes", "stream_ceiling_GBs", "frac_of_stream_ceiling")
+    out = {k: r[k] for k in keys if k in r}
+    basis = r.get("frac_basis") or ""
+    out["frac_basis"] = next((short for head, short in SHORT_BASIS if basis.startswith(head)), basis[:80])
+    return out
+
+
+def compact_cpu(c):
+    if not c:
+        return None
+    out = {k: c[k] for k in ("value", "unit", "cores", "kind", "seconds", "count_matches_gpu", "count_matches_gpu_on", "full_size", "carried_from") if k in c}
+    out["sample"] = c.get("sample", "")[:160]
+    return out
+
+
+def compact_line(out, detail_path):
+    """The ONE stdout line (< 4 KB, the driver keeps an 8 KB tail): the contract's keys with the headline's roofline and
+    cpu_baseline, a six-field summary per BASELINE config, and the path of the full record. (The reference prints one short TEPS line,
+    src/triangle/gpu_base.cu:68-71.)"""
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                                "dtype", "data") if k in out}
+    line["config"] = {k: out["config"][k] for k in ("workload", "graph", "nv", "ne_sym", "tasks", "parallelism") if k in out["config"]}
+    line.update({"count": out["count"], "count_matches_cpu": out.get("count_matches_cpu"), "kernel_ms_avg": out["kernel_ms_avg"],
+                 "first_call_ms": out["first_call_ms"], "rccl_ranks_seen": out.get("rccl_ranks_seen", 1)})
+    line["per_gpu_kernel_ms"] = {k: out["per_gpu_kernel_ms"][k] for k in ("max", "mean")}
+    line["roofline"] = compact_roofline(out["roofline"])
+    line["cpu_baseline"] = compact_cpu(out.get("cpu_baseline"))
+    if "configs" in out:
+        cfgs = []
+        for c in out["configs"]:
+            if c["id"] == 1:
+                cfgs.append({"id": 1, "workload": "tc_omp_base citeseer", "count": c.get("gpu_count"), "count_ok": c.get("count_matches_cpu")})
+                continue
+            rf, cb = c["roofline"], c.get("cpu_baseline") or {}
+            e = {"id": c["id"], "workload": c["workload"], "graph": c["graph"], "kernel_ms": c["kernel_ms_avg"], "value": c["value"], "count": c["count"],
+                 "count_ok": c.get("count_matches_cpu"), "frac": rf.get("frac"), "traffic_GB": round(rf["traffic"] / 1e9, 2) if rf.get("traffic") else None,
+                 "own_frac": rf.get("own_frac"), "first_call_ms": c["first_call_ms"], "cpu_value": cb.get("value"), "cpu_kind": cb.get("kind")}
+            if cb.get("full_size"):
+                e["cpu_full_size_s"] = cb["full_size"].get("seconds")
+            if "per_edge_variant" in c and "kernel_ms_avg" in c["per_edge_variant"]:
+                e["enumeration_kernel_ms"] = c["per_edge_variant"]["kernel_ms_avg"]
+                e["enumeration_frac"] = c["per_edge_variant"].get("frac")
+            cfgs.append(e)
+        line["configs"] = cfgs
+        line["all_counts_match_cpu"] = out.get("all_counts_match_cpu")
+    if isinstance(out.get("tc_rmat24"), dict) and "roofline" in out["tc_rmat24"]:
+        t = out["tc_rmat24"]
+        line["tc_rmat24"] = {"kernel_ms": t["kernel_ms_avg"], "value": t["value"], "frac": t["roofline"].get("frac"), "own_frac": t["roofline"].get("own_frac")}
+    line["detail"] = detail_path
+    line["bench_wall_s"] = out.get("bench_wall_s")
+    return line
+
+
 def main():
     a = parse()
     if a.traffic_worker:
         return traffic_worker(a)
+    self_launch(a)
     r = Runner(a)
     world, rank = r.world, r.rank
     single = bool(a.workload or a.graph or a.uniform or a.powerlaw)
@@ -1125,8 +1241,25 @@ def main():
         if not single:
             out["configs"] = [config1_record(a)] + subs
             out["all_counts_match_cpu"] = all(s.get("count_matches_cpu") is True for s in out["configs"])
+        out["rccl_ranks_seen"] = r.ranks_seen
+        out["collective_backend"] = (r.backend if r.use_dist else None)
         out["bench_wall_s"] = round(time.perf_counter() - t_start, 1)
-        print(json.dumps(out), flush=True)
+        # the full record goes to a file; stdout carries ONE compact line (the driver parses the last line of an 8 KB tail)
+        detail = a.detail or os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(detail)), exist_ok=True)
+            with open(detail, "w") as f:
+                json.dump(out, f)
+        except OSError as e:
+            print(f"[bench] could not write {detail}: {e}", file=sys.stderr)
+            detail = None
+        rec = compact_line(out, os.path.relpath(detail, ROOT) if detail and os.path.abspath(detail).startswith(ROOT) else detail)
+        for drop in ("", "tc_rmat24", "per_gpu_kernel_ms", "all_counts_match_cpu"):  # (never reached with the five configs: a guard, not a plan)
+            rec.pop(drop, None)
+            line = json.dumps(rec, separators=(",", ":"))
+            if len(line) < 4000:
+                break
+        print(line, flush=True)
     r.close()
 
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Full-size parity evidence: GPU counts vs the CPU oracle (OpenMP, all host cores) on the BASELINE stand-in graphs.
-Usage: fullsize_check.py <workload: diamond|motif3|clique4> <scale> <ef> [--ref]   -- prints one JSON line.
+Usage: fullsize_check.py <workload: diamond|motif3|motif3f|clique4> <scale> <ef> [--ref]   (motif3f: --ref runs motif_omp_formula)   -- prints one JSON line.
 --ref: the CPU answer comes from the REFERENCE's own binary (oracle/_ref/{sgl,motif,clique}_omp_base, built by oracle/ref/Makefile from the
 sources under /root/reference; all host threads, its own Timer) instead of the oracle restatement -- VERDICT r3 item 8: the full-size
 answers of tests/golden/fullsize.json pinned to the reference once."""
@@ -28,7 +28,8 @@ if use_ref:
     try:
         host.save(os.path.join(tmp, "graph"))
         exe, args, pat, nvals = {"clique4": ("clique_omp_base", ["4"], r"num_4-cliques = (\d+)", 1), "diamond": ("sgl_omp_base", ["diamond"], r"total_num = (\d+)", 1),
-                                 "motif3": ("motif_omp_base", ["3"], r"pattern \d+: (\d+)", 2)}[w]
+                                 "motif3": ("motif_omp_base", ["3"], r"pattern \d+: (\d+)", 2),
+                                 "motif3f": ("motif_omp_formula", ["3"], r"pattern \d+: (\d+)", 2)}[w]
         env = dict(os.environ, OMP_NUM_THREADS=str(O.num_threads()), OMP_PROC_BIND="spread")
         r = subprocess.run([os.path.join(ROOT, "oracle", "_ref", exe), os.path.join(tmp, "graph"), *args], capture_output=True, text=True, env=env, timeout=7200)
         c = [int(x) for x in re.findall(pat, r.stdout)]

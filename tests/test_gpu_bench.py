@@ -14,13 +14,42 @@ REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
             "dtype", "data", "config", "roofline", "cpu_baseline"]
 
 
-def run_bench(*args, env=None):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=900, cwd=ROOT,
-                         env=dict(os.environ, **(env or {})))
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
-    return json.loads(lines[0])
+LINE_KEYS = REQUIRED + ["count", "rccl_ranks_seen", "detail"]
+ROOF_KEYS = ["bound", "achieved", "peak", "unit", "frac", "traffic", "frac_basis", "kernel", "stream_ceiling_GBs"]
+
+
+def check_line(line, raw):
+    """the stdout line the driver parses: short, self-contained, the contract's keys"""
+    assert len(raw) < 4096, len(raw)
+    for k in LINE_KEYS:
+        assert k in line, k
+    for k in ROOF_KEYS:
+        assert k in line["roofline"], k
+    if line["cpu_baseline"] is not None:
+        for k in ("value", "unit", "cores", "kind", "sample"):
+            assert k in line["cpu_baseline"], k
+    assert "workload" in line["config"] and "model" not in line["config"]
+
+
+def run_bench(*args, env=None, launcher=None):
+    """runs bench.py; returns the FULL record (the --detail file) with the parsed stdout line under "_line" """
+    import tempfile
+
+    with tempfile.TemporaryDirectory(prefix="gm_bench_test_") as tmp:
+        detail = os.path.join(tmp, "detail.json")
+        cmd = (launcher or [sys.executable]) + [os.path.join(ROOT, "bench.py"), *args, "--detail", detail]
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=ROOT, env=dict(os.environ, **(env or {})))
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1 and out.stdout.rstrip().splitlines()[-1] == lines[0], out.stdout[-2000:]  # ONE line, and it is the last
+        line = json.loads(lines[0])
+        check_line(line, lines[0])
+        d = json.load(open(detail))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "count"):  # the line is a projection of the record
+        assert line[k] == d[k], k
+    assert line["roofline"]["frac"] == d["roofline"]["frac"] and line["roofline"]["traffic"] == d["roofline"]["traffic"]
+    d["_line"] = line
+    return d
 
 
 def check_roofline(r):
@@ -51,6 +80,19 @@ def test_bench_line_small_tc():
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c.get("count_matches_gpu", True)
     assert "workload" in d["config"] and "model" not in d["config"]
     assert set(d["setup_ms"]) == {"orient_ms", "table_ms", "bitmap_ms", "relabel_ms", "other_ms"} and d["setup_ms"]["table_ms"] > 0
+
+
+def test_bench_last_line_is_short():
+    """the default mode's stdout: exactly one JSON line < 4 KB with roofline + cpu_baseline and a summary per config (r04's 24 KB line
+    did not parse at the driver)"""
+    d = run_bench("--scale", "12", "--ef", "8", "--steps", "2", "--warmup", "1", "--cpu-seconds", "2", "--traffic", "off")
+    line = d["_line"]
+    assert [c["id"] for c in line["configs"]] == [1, 2, 3, 4, 5]
+    for c, full in zip(line["configs"][1:], d["configs"][1:]):
+        assert c["workload"] == full["workload"] and c["count"] == full["count"] and c["kernel_ms"] == full["kernel_ms_avg"]
+        assert c["count_ok"] is True
+    assert line["all_counts_match_cpu"] is True and line["rccl_ranks_seen"] == 1
+    assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["count_matches_gpu"] is True
 
 
 def test_bench_default_mode_carries_the_five_configs():
@@ -242,12 +284,18 @@ def test_scale_dryrun_two_ranks_on_one_gpu():
     """scripts/scale_dryrun.sh: the driver's N > 1 launch line with two ranks on GPU 0 over gloo -- rank shares, the summed counts, the
     per-rank kernel times, the CPU-baseline record and the rank-0-only counter passes (the other rank waits at the barrier) all run, so the
     first 8-GPU job is not the first execution of any of it"""
-    out = subprocess.run(["bash", os.path.join(ROOT, "scripts", "scale_dryrun.sh"), "2", "--scale", "13", "--ef", "8", "--steps", "2", "--warmup", "1",
-                          "--cpu-seconds", "3"], capture_output=True, text=True, timeout=1500, cwd=ROOT, env=dict(os.environ, MASTER_PORT="29547"))
-    assert out.returncode == 0, out.stderr[-3000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]  # rank 0 alone prints
-    d = json.loads(lines[0])
+    import tempfile
+
+    with tempfile.TemporaryDirectory(prefix="gm_bench_test_") as tmp:
+        out = subprocess.run(["bash", os.path.join(ROOT, "scripts", "scale_dryrun.sh"), "2", "--scale", "13", "--ef", "8", "--steps", "2", "--warmup", "1",
+                              "--cpu-seconds", "3", "--detail", os.path.join(tmp, "d.json")], capture_output=True, text=True, timeout=1500, cwd=ROOT,
+                             env=dict(os.environ, MASTER_PORT="29547"))
+        assert out.returncode == 0, out.stderr[-3000:]
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, out.stdout[-2000:]  # rank 0 alone prints
+        check_line(json.loads(lines[0]), lines[0])
+        assert json.loads(lines[0])["rccl_ranks_seen"] == 2
+        d = json.load(open(os.path.join(tmp, "d.json")))
     ref = run_bench("--scale", "13", "--ef", "8", "--steps", "2", "--warmup", "1", "--cpu-seconds", "3", "--traffic", "off")
     assert d["n_gpus"] == 2 and d["scaling"] == "strong"
     assert [c["count"] for c in d["configs"][1:]] == [c["count"] for c in ref["configs"][1:]]  # the two shares add up to the whole
@@ -257,3 +305,21 @@ def test_scale_dryrun_two_ranks_on_one_gpu():
         assert c["cpu_baseline"]["value"] > 0
         assert c["roofline"]["traffic"] and c["roofline"]["traffic"] > 0, c["roofline"]["traffic_source"]
         assert "share of rank 0 of 2" in c["roofline"]["traffic_source"]
+
+
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher around it: bench.py re-execs under torch.distributed.run. On this
+    one-GPU box through GM_BENCH_ONE_GPU=1 (both ranks on GPU 0, gloo); without that switch the same command must refuse clearly."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    d = run_bench("--gpus", "2", "--scale", "12", "--ef", "8", "--steps", "2", "--warmup", "1", "--cpu-seconds", "2", "--traffic", "off",
+                  env=dict(env, GM_BENCH_ONE_GPU="1"))
+    assert d["n_gpus"] == 2 and d["_line"]["rccl_ranks_seen"] == 2 and d["collective_backend"] == "gloo"
+    assert d["all_counts_match_cpu"] is True
+    for c in d["configs"][1:]:
+        assert len(c["per_gpu_kernel_ms"]["all"]) == 2
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scale", "12"], capture_output=True, text=True, timeout=300,
+                             cwd=ROOT, env=env)
+        assert out.returncode != 0 and "only 1 HIP device" in out.stderr and not out.stdout.strip()
