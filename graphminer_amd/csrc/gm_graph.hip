@@ -11,7 +11,9 @@ using namespace gm;
 thread_local std::string g_last_error;
 thread_local TempPool *g_temp_pool = nullptr;
 
+thread_local int g_last_hip_error = 0;
 int hip_fail(hipError_t e, const char *what, const char *file, int line) {
+  g_last_hip_error = (int)e;
   char buf[512];
   snprintf(buf, sizeof buf, "%s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
   g_last_error = buf;
@@ -672,7 +674,22 @@ extern "C" int gm_graph_renumbered(gm_graph *g, int mode, gm_graph **view) {
   if (!g || !view || mode < 0 || mode > 2) return GM_ERR_INVALID;
   *view = nullptr;
   if (g->d_rp64) return GM_ERR_TOO_LARGE;
-  return get_relabeled(g, mode, view);
+  // a row with a DUPLICATE neighbour has no renumbered row (an entry's place is its rank among the row's new ids: two equal ids take one
+  // slot and leave another unwritten); such a handle is refused here as the solvers refuse it
+  bool sorted = false;
+  const int rc = graph_rows_sorted(g, &sorted);
+  if (rc) return rc;
+  if (!sorted) {
+    g_last_error = "gm_graph_renumbered: the rows are not strictly ascending (unsorted or duplicate neighbours); gm_graph_sort_neighbors sorts, duplicates must be removed by the caller";
+    return GM_ERR_INVALID;
+  }
+  const int rc2 = get_relabeled(g, mode, view);
+  if (rc2 == GM_OK && *view && (*view)->sorted_state == 2) {
+    *view = nullptr;
+    g_last_error = "gm_graph_renumbered: the renumbered copy has duplicate neighbours";
+    return GM_ERR_INVALID;
+  }
+  return rc2;
 }
 
 extern "C" int gm_graph_orient(const gm_graph *sym, gm_graph **out) {
@@ -800,7 +817,7 @@ __global__ __launch_bounds__(256) void relabel_rows_short_kernel(int nv, const u
         }
       }
     }
-    __builtin_amdgcn_wave_barrier();
+    wave_sync();
     int below[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) below[k] = 0;
@@ -821,7 +838,7 @@ __global__ __launch_bounds__(256) void relabel_rows_short_kernel(int nv, const u
     for (int k = 0; k < K; ++k)
       if (k < steps && k * G + gl < n) new_col[ob + below[k]] = x[k];
     if (same) *dup = 1;
-    __builtin_amdgcn_wave_barrier();
+    wave_sync();
   }
 }
 
@@ -845,7 +862,7 @@ __global__ __launch_bounds__(256) void relabel_rows_long_kernel(int nv, const un
     int P = 128;
     while (P < n) P <<= 1;
     for (int i = lane; i < P; i += 64) a[i] = i < n ? newid[col[b + i]] : 0x7fffffff;
-    __builtin_amdgcn_wave_barrier();
+    wave_sync();
     const int half = P >> 1;
     for (int k = 2; k <= P; k <<= 1) {
       for (int j = k >> 1; j > 0; j >>= 1) {
@@ -860,7 +877,7 @@ __global__ __launch_bounds__(256) void relabel_rows_long_kernel(int nv, const un
           if ((lo0 > hi0) == ((i0 & k) == 0)) { a[i0] = hi0; a[i0 | j] = lo0; }
           if (two && (lo1 > hi1) == ((i1 & k) == 0)) { a[i1] = hi1; a[i1 | j] = lo1; }
         }
-        __builtin_amdgcn_wave_barrier();
+        wave_sync();
       }
     }
     bool same = false;
@@ -870,7 +887,7 @@ __global__ __launch_bounds__(256) void relabel_rows_long_kernel(int nv, const un
       same |= i > 0 && a[i - 1] == y;
     }
     if (same) *dup = 1;
-    __builtin_amdgcn_wave_barrier();
+    wave_sync();
   }
 }
 

@@ -22,6 +22,7 @@
 #include <list>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace gm;  // (internal header: every unit that includes it lives behind the C ABI)
@@ -30,6 +31,7 @@ using namespace gm;  // (internal header: every unit that includes it lives behi
 // error plumbing
 // ------------------------------------------------------------------------------------------------
 extern thread_local std::string g_last_error;
+extern thread_local int g_last_hip_error;  // the hipError_t of the most recent hip_fail of this thread (out of memory: optional structures are skipped)
 int hip_fail(hipError_t e, const char *what, const char *file, int line);
 #define HIP_TRY(call)                                              \
   do {                                                             \
@@ -44,6 +46,13 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
 struct TempPool {
   char *base = nullptr;
   size_t cap = 0, off = 0, want = 0;  // want: bytes the open scopes would have liked (pool + fall-through allocations)
+  // A handle family (a graph + its cached orientation and renumbered copies) shares the root's pool, and two threads may work on two
+  // members at once under their own handle locks.  The pool belongs to ONE thread at a time: the first PoolScope claims it,
+  // nested scopes of that thread share it (stack discipline), and a scope opened by another thread meanwhile gets no pool -- its
+  // DevBufs fall through to hipMalloc.  No lock is held across a scope, so there is no lock order to get wrong.
+  std::mutex claim_mu;
+  std::thread::id owner;
+  int depth = 0;
 };
 extern thread_local TempPool *g_temp_pool;  // the pool of the innermost open PoolScope of this thread (gm_graph.hip)
 
@@ -324,10 +333,23 @@ struct gm_graph {
 struct PoolScope {
   gm_graph *g;
   TempPool *prev;
-  size_t mark;
+  size_t mark = 0;
+  bool mine = false;  // this scope holds (a level of) the claim on the root's pool
   explicit PoolScope(gm_graph *g_) : g(g_), prev(g_temp_pool) {
     while (g->pool_owner) g = g->pool_owner;
     TempPool &pl = g->pool;
+    {
+      std::lock_guard<std::mutex> lk(pl.claim_mu);
+      if (pl.depth == 0 || pl.owner == std::this_thread::get_id()) {
+        pl.owner = std::this_thread::get_id();
+        ++pl.depth;
+        mine = true;
+      }
+    }
+    if (!mine) {  // another thread is inside a scope of this handle family: no pool for this one
+      g_temp_pool = nullptr;
+      return;
+    }
     if (!pl.base && !getenv("GM_NO_TEMP_POOL")) {
       const size_t need = std::min<size_t>((size_t)256 << 20, (size_t)24 * ((size_t)g->nv + 1) + ((size_t)16 << 20));
       if (hipMalloc(&pl.base, need) == hipSuccess) pl.cap = need;
@@ -338,7 +360,12 @@ struct PoolScope {
   }
   ~PoolScope() {
     (void)hipDeviceSynchronize();  // nothing may still be reading the temporaries when the next scope reuses them
-    g->pool.off = mark;
+    if (mine) {
+      TempPool &pl = g->pool;
+      pl.off = mark;
+      std::lock_guard<std::mutex> lk(pl.claim_mu);
+      --pl.depth;
+    }
     g_temp_pool = prev;
   }
 };

@@ -1391,7 +1391,7 @@ extern "C" int gm_diamond_support_partial(const gm_graph *sym, const gm_launch *
   int rc = diamond_run_on(sym, la, &run_on);
   if (rc) return rc;
   const int world = (la && la->world > 1) ? la->world : 1;
-  if (n_entries < diamond_support_entries(run_on->ne, world)) return GM_ERR_INVALID;
+  if (n_entries != diamond_support_entries(run_on->ne, world)) return GM_ERR_INVALID;  // (exactly gm_diamond_support_size: the slices are n_entries / world)
   uint64_t dummy = 0;
   rc = run_pattern(PAT_SUPPORT_PART, run_on, la, 3, (la && la->d_counts) ? nullptr : &dummy, 1, st, -1, 0, d_support);
   if (rc) return rc;
@@ -1618,8 +1618,14 @@ extern "C" int gm_motif(const gm_graph *sym, int k, const gm_launch *la, uint64_
   if (!(t6 & 512) && !getenv("GM_MOTIF3E_AS_NUMBERED")) {
     gm_graph *r = nullptr;
     const int rc = get_relabeled(const_cast<gm_graph *>(sym), 1, &r);
-    if (rc) return rc;
-    run_on = r;
+    if (rc == GM_ERR_HIP && g_last_hip_error == (int)hipErrorOutOfMemory) {  // (the copy is an optimisation -- about the size of the graph again: without it the graph runs as numbered)
+      (void)hipGetLastError();
+      g_last_error.clear();
+    } else if (rc) {
+      return rc;
+    } else {
+      run_on = r;
+    }
   }
   const int rc = run_pattern(PAT_MOTIF3, run_on, la, 3, counts, ncounts, st);
   if (run_on != sym) const_cast<gm_graph *>(sym)->ring_alias = run_on;

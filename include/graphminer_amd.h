@@ -187,13 +187,14 @@ int gm_sgl(const gm_graph *sym, const char *pattern, const gm_launch *launch, ui
 /* Diamond on SEVERAL ranks with the one-GPU algorithm (one shared pass over the triangles of the oriented copy; the reference has no
  * multi-GPU diamond: src/sgl/multigpu.cu:117 is commented out).  Per step, on every rank:
  *   1. gm_diamond_support_partial: the rank's share (launch->rank / world) of the triangle pass adds its three increments per triangle
- *      into d_support -- the caller's DEVICE buffer of n_entries uint32 (>= gm_diamond_support_size: |E+| of the oriented copy rounded
- *      up so that every rank's slice is equal and 256-byte aligned), zeroed by the call, ordered on launch->stream;
+ *      into d_support -- the caller's DEVICE buffer of n_entries uint32 (EXACTLY gm_diamond_support_size: |E+| of the oriented copy
+ *      rounded up so that every rank's slice is equal and 256-byte aligned; any other size -> GM_ERR_INVALID), zeroed by the call,
+ *      ordered on launch->stream;
  *   2. the caller sums the ranks' arrays with ONE reduce-scatter (ncclReduceScatter, ncclUint32, ncclSum / torch reduce_scatter_tensor):
  *      rank r receives the n_entries / world entries from r * n_entries / world on;
  *   3. gm_diamond_support_finish: sum C(t, 2) over `count` entries at d_support (the rank's reduced slice) -> total / launch->d_counts;
  *   4. the usual all-reduce of the 64-bit count.
- * GM_ERR_UNSUPPORTED when a row of the oriented copy exceeds the 2048-entry stage (gm_sgl's per-edge kernels then run at any world). */
+ * Rows of the oriented copy beyond the 2048-entry stage take sup_long_kernel (one wave per edge) inside the same call. */
 int gm_diamond_support_size(const gm_graph *sym, int world, int64_t *n_entries);
 int gm_diamond_support_partial(const gm_graph *sym, const gm_launch *launch, uint32_t *d_support, int64_t n_entries, gm_stats *stats);
 int gm_diamond_support_finish(const gm_graph *sym, const gm_launch *launch, const uint32_t *d_support, int64_t count, uint64_t *total,
