@@ -1,0 +1,274 @@
+// multi.cc -- the one-GPU / n-GPU runner behind the four link-time solver entry points (host/multi.h).
+//
+//   TCSolver      src/triangle/gpu_base.cu:25-72, multi-GPU src/triangle/multigpu_base.cu:25-105
+//   SglSolver     src/sgl/gpu_base.cu:21-103
+//   CliqueSolver  src/clique/gpu_base.cu:14-80,  multi-GPU src/clique/multigpu.cu:20-139
+//   MotifSolver   src/motif/gpu_base.cu:21-110
+//
+// Single GPU: upload (GraphGPU::init), one gm_* call, print the reference's runtime / throughput lines.
+// Multi GPU (n_gpu > 1), one process, n devices:
+//   * the CSR goes over PCIe ONCE (to GPU 0) and is replicated with ncclBroadcast over xGMI, instead of
+//     the reference's n host->device copies (src/clique/multigpu.cu:57-66);
+//   * the task split is index arithmetic on chunk ids inside the library (rank i owns chunks i mod n,
+//     Scheduler::round_robin policy, src/common/scheduler.cc:34-85) -- no per-GPU COO copies;
+//   * the per-GPU 64-bit counts are combined by ONE ncclAllReduce(ncclUint64, ncclSum) instead of the
+//     host-side `total += h_counts[i]` (src/clique/multigpu.cu:134) / MPI_Allreduce (src/triangle/dist_cpu.cpp:56).
+#include "multi.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <sys/time.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <vector>
+
+namespace gmhost {
+namespace {
+
+struct Stopwatch {  // (the reference's Timer, include/timer.h:6-33: gettimeofday around the region)
+  void Start() { gettimeofday(&a, nullptr); }
+  void Stop() { gettimeofday(&b, nullptr); }
+  double Seconds() const { return (b.tv_sec - a.tv_sec) + 1e-6 * (b.tv_usec - a.tv_usec); }
+  timeval a{}, b{};
+};
+
+[[noreturn]] void die(int status, const char *where) {  // message + exit: CUDA_SAFE_CALL's reaction (include/cutil_subset.h:4-10)
+  std::fprintf(stderr, "error: %s: %s", where, gm_strerror(status));
+  const char *d = gm_last_error();
+  if (d && *d) std::fprintf(stderr, " [%s]", d);
+  std::fprintf(stderr, "\n");
+  std::exit(EXIT_FAILURE);
+}
+
+
+#define HIP_OK(call)                                                                                   \
+  do {                                                                                                 \
+    hipError_t e_ = (call);                                                                            \
+    if (e_ != hipSuccess) {                                                                            \
+      std::fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__);      \
+      std::exit(EXIT_FAILURE);                                                                         \
+    }                                                                                                  \
+  } while (0)
+#define NCCL_OK(call)                                                                                  \
+  do {                                                                                                 \
+    ncclResult_t r_ = (call);                                                                          \
+    if (r_ != ncclSuccess) {                                                                           \
+      std::fprintf(stderr, "RCCL error %s at %s:%d\n", ncclGetErrorString(r_), __FILE__, __LINE__);    \
+      std::exit(EXIT_FAILURE);                                                                         \
+    }                                                                                                  \
+  } while (0)
+
+
+int call(const Job &j, gm_graph *g, const gm_launch *la, uint64_t *out, gm_stats *st) {
+  switch (j.kind) {
+    case Job::TC: return gm_tc(g, la, out, st);
+    case Job::SGL: return gm_sgl(g, j.pattern, la, out, st);
+    case Job::CLIQUE: return gm_clique(g, j.k, la, out, st);
+    case Job::MOTIF:
+      // 4-motif on several GPUs: every rank leaves its six RAW sums on the device (gm_motif4_partial), the all-reduce adds
+      // them, run_multi applies gm_motif4_finish to the reduced sums (src/motif/omp_formula.cc:41-45)
+      // (also with one device under GM_FORCE_RCCL_PATH, so that a one-GPU test box exercises this path)
+      if (j.k == 4 && la && la->d_counts && !out) return gm_motif4_partial(g, la, out, st);
+      return gm_motif(g, j.k, la, out, j.ncounts, st);
+  }
+  return GM_ERR_INVALID;
+}
+
+// returns false when the pattern / k is not implemented (caller prints the reference's message)
+bool run_single(const gm_csr &h, const Job &j, int chunk, uint64_t *out) {
+  gm_graph *dg = nullptr;
+  int rc = gm_graph_upload(&h, 0, &dg);
+  if (rc) die(rc, "gm_graph_upload");
+  gm_launch la;
+  std::memset(&la, 0, sizeof la);
+  la.chunk = chunk > 0 ? chunk : 0;  // honoured as given (src/triangle/main.cc:16); <= 0 = the library default (the apps pass 0 when argv has none)
+  gm_stats st;
+  std::memset(&st, 0, sizeof st);
+  rc = call(j, dg, &la, out, &st);  // first call builds the task-chunk table ("Time on generating the edgelist")
+  if (rc == GM_ERR_UNSUPPORTED) { gm_graph_free(dg); return false; }
+  if (rc) die(rc, "mining kernel");
+  rc = call(j, dg, &la, out, &st);  // timed call: kernel only, like the reference's Timer (gpu_base.cu:53-65)
+  if (rc) die(rc, "mining kernel");
+  std::cout << "HIP " << j.name << " (" << st.grid << " workgroups, " << st.block << " threads/workgroup)\n";
+  const double sec = st.kernel_ms * 1e-3;
+  std::cout << "runtime [" << j.name << "] = " << sec << " sec\n";
+  std::cout << "throughput = " << double(st.tasks) / sec / 1e9 << " billion Traversed Edges Per Second (TEPS)\n";
+  gm_graph_free(dg);
+  return true;
+}
+
+bool run_multi(const gm_csr &g, const Job &j, int n, int chunk, uint64_t *out) {
+  std::vector<int> devs(n);
+  for (int i = 0; i < n; ++i) devs[i] = i;
+  std::vector<ncclComm_t> comms(n);
+  NCCL_OK(ncclCommInitAll(comms.data(), n, devs.data()));
+  const size_t nv = size_t(g.nv), ne = size_t(g.ne);
+  std::vector<int64_t *> d_rp(n);
+  std::vector<int32_t *> d_ci(n);
+  std::vector<uint64_t *> d_cnt(n);
+  std::vector<hipStream_t> streams(n);
+  Stopwatch tb;
+  tb.Start();
+  for (int i = 0; i < n; ++i) {
+    HIP_OK(hipSetDevice(i));
+    HIP_OK(hipStreamCreate(&streams[i]));
+    HIP_OK(hipMalloc(&d_rp[i], sizeof(int64_t) * (nv + 1)));
+    HIP_OK(hipMalloc(&d_ci[i], sizeof(int32_t) * (ne ? ne : 1)));
+    HIP_OK(hipMalloc(&d_cnt[i], sizeof(uint64_t) * 8));
+  }
+  HIP_OK(hipSetDevice(0));
+  HIP_OK(hipMemcpyAsync(d_rp[0], g.row_ptr, sizeof(int64_t) * (nv + 1), hipMemcpyHostToDevice, streams[0]));
+  HIP_OK(hipMemcpyAsync(d_ci[0], g.col_idx, sizeof(int32_t) * ne, hipMemcpyHostToDevice, streams[0]));
+  NCCL_OK(ncclGroupStart());
+  for (int i = 0; i < n; ++i) {
+    NCCL_OK(ncclBroadcast(d_rp[i], d_rp[i], nv + 1, ncclInt64, 0, comms[i], streams[i]));
+    NCCL_OK(ncclBroadcast(d_ci[i], d_ci[i], ne, ncclInt32, 0, comms[i], streams[i]));
+  }
+  NCCL_OK(ncclGroupEnd());
+  std::vector<gm_graph *> dg(n, nullptr);
+  for (int i = 0; i < n; ++i) {
+    HIP_OK(hipSetDevice(i));
+    HIP_OK(hipStreamSynchronize(streams[i]));
+    int rc = gm_graph_from_device(int32_t(nv), int64_t(ne), d_rp[i], d_ci[i], i, &dg[i]);
+    if (rc) die(rc, "gm_graph_from_device");
+  }
+  tb.Stop();
+  std::cout << "Time on replicating the CSR to " << n << " GPUs (1 PCIe copy + RCCL broadcast over xGMI): " << tb.Seconds()
+            << " sec\n";
+
+  // diamond on several GPUs: the one-GPU algorithm at every N (include/graphminer_amd.h gm_diamond_support_*): every GPU's share of the
+  // triangle pass into its own support array, ONE ncclReduceScatter (uint32, sum) over xGMI, sum C(t, 2) of the received slice, then the
+  // all-reduce of the counts like every other pattern.  (GM_DIAMOND_PER_EDGE, or rows beyond the 2048-entry stage: the per-edge kernels.)
+  std::vector<uint32_t *> d_sup(n, nullptr);
+  int64_t sup_n = 0;
+  bool diamond_sup = j.kind == Job::SGL && j.pattern && std::strcmp(j.pattern, "diamond") == 0 && !std::getenv("GM_DIAMOND_PER_EDGE");
+  if (diamond_sup) {
+    for (int i = 0; i < n && diamond_sup; ++i) {
+      HIP_OK(hipSetDevice(i));
+      int64_t m = 0;
+      int rc = gm_diamond_support_size(dg[i], n, &m);
+      if (rc == GM_ERR_UNSUPPORTED) { diamond_sup = false; break; }
+      if (rc) die(rc, "gm_diamond_support_size");
+      sup_n = m;
+      HIP_OK(hipMalloc(&d_sup[i], sizeof(uint32_t) * size_t(m)));
+    }
+  }
+  auto launch_diamond = [&]() {
+    const size_t per = size_t(sup_n) / size_t(n);
+    std::vector<gm_launch> las(n);
+    for (int i = 0; i < n; ++i) {
+      gm_launch &la = las[i];
+      std::memset(&la, 0, sizeof la);
+      la.stream = streams[i];
+      la.rank = i;
+      la.world = n;
+      la.policy = GM_PART_ROUND_ROBIN;
+      la.chunk = chunk > 0 ? chunk : 0;
+      la.d_counts = d_cnt[i];
+      int rc = gm_diamond_support_partial(dg[i], &la, d_sup[i], sup_n, nullptr);
+      if (rc) die(rc, "gm_diamond_support_partial");
+    }
+    NCCL_OK(ncclGroupStart());
+    for (int i = 0; i < n; ++i)  // in place: GPU i receives its slice where it lies in its own array
+      NCCL_OK(ncclReduceScatter(d_sup[i], d_sup[i] + size_t(i) * per, per, ncclUint32, ncclSum, comms[i], streams[i]));
+    NCCL_OK(ncclGroupEnd());
+    for (int i = 0; i < n; ++i) {
+      int rc = gm_diamond_support_finish(dg[i], &las[i], d_sup[i] + size_t(i) * per, int64_t(per), nullptr, nullptr);
+      if (rc) die(rc, "gm_diamond_support_finish");
+    }
+    NCCL_OK(ncclGroupStart());
+    for (int i = 0; i < n; ++i)
+      NCCL_OK(ncclAllReduce(d_cnt[i], d_cnt[i], 1, ncclUint64, ncclSum, comms[i], streams[i]));
+    NCCL_OK(ncclGroupEnd());
+    for (int i = 0; i < n; ++i) {
+      HIP_OK(hipSetDevice(i));
+      HIP_OK(hipStreamSynchronize(streams[i]));
+    }
+  };
+  auto launch_all = [&](bool &unsupported) {
+    if (diamond_sup) return launch_diamond();
+    for (int i = 0; i < n; ++i) {
+      gm_launch la;
+      std::memset(&la, 0, sizeof la);
+      la.stream = streams[i];
+      la.rank = i;
+      la.world = n;
+      la.policy = GM_PART_ROUND_ROBIN;
+      la.chunk = chunk > 0 ? chunk : 0;
+      la.d_counts = d_cnt[i];
+      int rc = call(j, dg[i], &la, nullptr, nullptr);  // asynchronous: kernels of all GPUs overlap
+      if (rc == GM_ERR_UNSUPPORTED) { unsupported = true; return; }
+      if (rc) die(rc, "mining kernel");
+    }
+    NCCL_OK(ncclGroupStart());
+    for (int i = 0; i < n; ++i)
+      NCCL_OK(ncclAllReduce(d_cnt[i], d_cnt[i], size_t(j.ncounts), ncclUint64, ncclSum, comms[i], streams[i]));
+    NCCL_OK(ncclGroupEnd());
+    for (int i = 0; i < n; ++i) {
+      HIP_OK(hipSetDevice(i));
+      HIP_OK(hipStreamSynchronize(streams[i]));
+    }
+  };
+  bool unsupported = false;
+  launch_all(unsupported);  // warm-up: builds the chunk tables
+  if (!unsupported) {
+    Stopwatch t;
+    t.Start();
+    launch_all(unsupported);
+    t.Stop();
+    for (int i = 0; i < n; ++i) {
+      double ms = 0, two[2] = {0, 0};
+      int got = 0;
+      if (diamond_sup) {  // (two launches per step: the share of the triangle pass + sum C(t, 2) of the slice)
+        gm_kernel_times(dg[i], 2, two, &got);
+        ms = two[0] + two[1];
+      } else {
+        gm_kernel_times(dg[i], 1, &ms, &got);
+      }
+      std::cout << "runtime[gpu" << i << "] = " << ms * 1e-3 << " sec\n";  // src/clique/multigpu.cu:136-137
+    }
+    std::cout << "runtime [" << j.name << "] = " << t.Seconds() << " sec\n";
+    HIP_OK(hipSetDevice(0));
+    HIP_OK(hipMemcpy(out, d_cnt[0], sizeof(uint64_t) * size_t(j.ncounts), hipMemcpyDeviceToHost));
+    if (j.kind == Job::MOTIF && j.k == 4) {  // reduced raw sums -> the six vertex-induced counts
+      uint64_t raw[6];
+      std::memcpy(raw, out, sizeof raw);
+      int rc = gm_motif4_finish(raw, out);
+      if (rc) die(rc, "gm_motif4_finish");
+    }
+  }
+  for (int i = 0; i < n; ++i) {
+    HIP_OK(hipSetDevice(i));
+    gm_graph_free(dg[i]);
+    if (d_sup[i]) HIP_OK(hipFree(d_sup[i]));
+    HIP_OK(hipFree(d_rp[i]));
+    HIP_OK(hipFree(d_ci[i]));
+    HIP_OK(hipFree(d_cnt[i]));
+    HIP_OK(hipStreamDestroy(streams[i]));
+    ncclCommDestroy(comms[i]);
+  }
+  return !unsupported;
+}
+
+}  // namespace
+
+bool run(const gm_csr &g, Job j, int n_gpu, int chunk, uint64_t *out) {
+  int ndev = 0;
+  int rc = gm_device_count(&ndev);
+  if (rc) die(rc, "gm_device_count");
+  if (n_gpu > ndev) {
+    std::cout << "requested " << n_gpu << " GPUs, " << ndev << " available\n";
+    n_gpu = ndev;
+  }
+  // GM_FORCE_RCCL_PATH=1 drives the multi-GPU code (broadcast + all-reduce) even with one device,
+  // so the RCCL path is exercised on a single-GPU test box.
+  if (n_gpu <= 1 && !std::getenv("GM_FORCE_RCCL_PATH")) return run_single(g, j, chunk, out);
+  if (n_gpu < 1) n_gpu = 1;
+  j.name = "multigpu";
+  return run_multi(g, j, n_gpu, chunk, out);
+}
+
+}  // namespace gmhost

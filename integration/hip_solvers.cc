@@ -1,79 +1,76 @@
-// hip_solvers.cc -- the solver objects a GraphMiner maintainer links INSTEAD of omp_base.o / gpu_base.o
+// hip_solvers.cc -- the solver objects a GraphMiner maintainer links INSTEAD of omp_base.o / gpu_base.o / multigpu.o
 // (INTEGRATION.md section 2). Compiled against the REFERENCE's own headers (include/graph.h, include/pattern.hh) and
 // linked with the reference's own main.cc + graph.cc + VertexSet.cc by oracle/ref/Makefile into
-// oracle/_ref/{tc,sgl,clique,motif}_hip_base -- the drop-in is exercised end to end, reference loader and CLI included.
-// Exactly one of GM_SHIM_TC / GM_SHIM_SGL / GM_SHIM_CLIQUE / GM_SHIM_MOTIF is defined per object.
+// oracle/_ref/{tc,sgl,clique,motif}_hip_base and {tc,clique}_hip_multigpu -- the drop-in is exercised end to end, reference
+// loader and CLI included. Exactly one of GM_SHIM_TC / GM_SHIM_SGL / GM_SHIM_CLIQUE / GM_SHIM_MOTIF is defined per object.
+//
+// n_gpu (argv[2] / argv[3] of the reference's mains, src/triangle/main.cc:14, src/clique/main.cc:17) is HONOURED: the runner
+// (graphminer_amd/host/multi.cc, which takes a plain gm_csr) uploads to one GPU, or replicates the CSR with ncclBroadcast, gives every
+// device its share of the task chunks and combines the counts with ONE ncclAllReduce(ncclUint64) -- the seam of the reference's
+// `clique_multigpu` (src/clique/multigpu.cu:20: void CliqueSolver(Graph &g, int k, uint64_t &total, int n_gpus, int chunk_size)).
 #include "graph.h"
 #if defined(GM_SHIM_SGL) || defined(GM_SHIM_MOTIF)
 #include "pattern.hh"
 #endif
 #include "graphminer_amd.h"
+#include "../graphminer_amd/host/multi.h"
 
-static void gm_or_die(int rc, const char *what) {
-  if (rc == GM_OK) return;
-  fprintf(stderr, "%s: %s [%s]\n", what, gm_strerror(rc), gm_last_error());
-  exit(EXIT_FAILURE);  // same reaction as CUDA_SAFE_CALL (include/cutil_subset.h:4-10)
-}
+using gmhost::Job;
 
-static gm_graph *upload(Graph &g) {
-  gm_csr h = {g.V(), (int64_t)g.E(), g.get_max_degree(), (const int64_t *)g.out_rowptr(), (const int32_t *)g.out_colidx()};
-  gm_graph *dg = nullptr;
-  gm_or_die(gm_graph_upload(&h, 0, &dg), "gm_graph_upload");
-  return dg;
-}
-
-static void report(const char *name, const gm_stats &st) {
-  std::cout << "runtime [" << name << "] = " << st.kernel_ms * 1e-3 << " sec\n";
-  std::cout << "throughput = " << double(st.tasks) / (st.kernel_ms * 1e-3) / 1e9 << " billion Traversed Edges Per Second (TEPS)\n";
+static bool run(Graph &g, const Job &j, int n_gpu, int chunk, uint64_t *out) {
+  // exactly what Graph::out_rowptr() / out_colidx() / V() / E() / get_max_degree() expose (include/graph.h:63-64,73,83-84)
+  const gm_csr h = {g.V(), (int64_t)g.E(), g.get_max_degree(), (const int64_t *)g.out_rowptr(), (const int32_t *)g.out_colidx()};
+  return gmhost::run(h, j, n_gpu, chunk, out);
 }
 
 #if defined(GM_SHIM_TC)
-void TCSolver(Graph &g, uint64_t &total, int, int chunk_size) {  // g is already oriented by the reference's Graph ctor
-  gm_graph *dg = upload(g);
-  gm_launch la = {};
-  la.chunk = chunk_size > 0 ? chunk_size : 0;  // the reference main passes its argv value, default 1024: honoured
-  gm_stats st = {};
-  uint64_t count = 0;
-  gm_or_die(gm_tc(dg, &la, &count, &st), "gm_tc");
-  report("hip_base", st);
-  total = count;
-  gm_graph_free(dg);
+void TCSolver(Graph &g, uint64_t &total, int n_gpu, int chunk_size) {  // g is already oriented by the reference's Graph ctor
+  Job j;
+  j.kind = Job::TC;
+  j.name = "hip_base";
+  uint64_t out[8] = {0};
+  run(g, j, n_gpu, chunk_size, out);
+  total += out[0];  // the multi-GPU solvers '+=' into the caller-zeroed total (src/triangle/multigpu.cu:84)
 }
 #elif defined(GM_SHIM_SGL)
-void SglSolver(Graph &g, Pattern &p, uint64_t &total, int, int chunk_size) {
-  gm_graph *dg = upload(g);
-  gm_launch la = {};
-  la.chunk = chunk_size > 0 ? chunk_size : 0;  // the reference main passes its argv value, default 1024: honoured
-  gm_stats st = {};
-  uint64_t count = 0;
-  int rc = gm_sgl(dg, p.get_name().c_str(), &la, &count, &st);
-  if (rc == GM_ERR_UNSUPPORTED) std::cout << "Not implemented\n";  // src/sgl/omp_base.cc:51-53
-  else { gm_or_die(rc, "gm_sgl"); report("hip_base", st); }
-  total = count;
-  gm_graph_free(dg);
+void SglSolver(Graph &g, Pattern &p, uint64_t &total, int n_devices, int chunk_size) {
+  Job j;
+  j.kind = Job::SGL;
+  j.name = "hip_base";
+  const std::string name = p.get_name();
+  j.pattern = name.c_str();
+  uint64_t out[8] = {0};
+  if (!run(g, j, n_devices, chunk_size, out)) {
+    std::cout << "Not implemented\n";  // src/sgl/omp_base.cc:51-53: total stays 0
+    return;
+  }
+  total += out[0];
 }
 #elif defined(GM_SHIM_CLIQUE)
-void CliqueSolver(Graph &g, int k, uint64_t &total, int, int chunk_size) {
-  gm_graph *dg = upload(g);
-  gm_launch la = {};
-  la.chunk = chunk_size > 0 ? chunk_size : 0;  // the reference main passes its argv value, default 1024: honoured
-  gm_stats st = {};
-  uint64_t count = 0;
-  gm_or_die(gm_clique(dg, k, &la, &count, &st), "gm_clique");
-  report("hip_base", st);
-  total = count;
-  gm_graph_free(dg);
+void CliqueSolver(Graph &g, int k, uint64_t &total, int n_gpu, int chunk_size) {
+  Job j;
+  j.kind = Job::CLIQUE;
+  j.k = k;
+  j.name = "hip_base";
+  uint64_t out[8] = {0};
+  if (!run(g, j, n_gpu, chunk_size, out)) {
+    std::cout << "Not supported right now\n";  // src/clique/gpu_base.cu:70
+    return;
+  }
+  total += out[0];
 }
 #elif defined(GM_SHIM_MOTIF)
-void MotifSolver(Graph &g, int k, std::vector<uint64_t> &accum, int, int chunk_size) {
-  gm_graph *dg = upload(g);
-  gm_launch la = {};
-  la.chunk = chunk_size > 0 ? chunk_size : 0;  // the reference main passes its argv value, default 1024: honoured
-  gm_stats st = {};
-  std::vector<uint64_t> c(accum.size(), 0);
-  gm_or_die(gm_motif(dg, k, &la, c.data(), (int)c.size(), &st), "gm_motif");
-  report("hip_base", st);
-  for (size_t i = 0; i < accum.size(); ++i) accum[i] += c[i];
-  gm_graph_free(dg);
+void MotifSolver(Graph &g, int k, std::vector<uint64_t> &accum, int n_gpu, int chunk_size) {
+  Job j;
+  j.kind = Job::MOTIF;
+  j.k = k;
+  j.ncounts = (int)accum.size();
+  j.name = "hip_base";
+  uint64_t out[8] = {0};
+  if (!run(g, j, n_gpu, chunk_size, out)) {
+    std::cout << "Not supported right now\n";  // src/motif/gpu_base.cu:101
+    return;
+  }
+  for (size_t i = 0; i < accum.size() && i < 8; ++i) accum[i] += out[i];
 }
 #endif

@@ -38,3 +38,30 @@ def test_reference_mains_with_hip_solvers(name):
     for k, n in ((3, 2), (4, 6)):
         hip, omp = run("motif_hip_base", prefix, k), run("motif_omp_base", prefix, k)
         assert hip[-n:] == omp[-n:]
+
+
+@pytest.mark.parametrize("name", ["citeseer", "cora"])
+def test_reference_mains_with_hip_solvers_multigpu_seam(name):
+    """The n_gpu argument of the reference's mains reaches the n-GPU runner (graphminer_amd/host/multi.cc) through the reference's own
+    Graph class: `clique_hip_multigpu <graph> 4 <n_gpu> <chunk>` = the seam of the reference's clique_multigpu (src/clique/multigpu.cu:20),
+    `tc_hip_multigpu <graph> <n_gpu> <chunk>` = tc_multigpu_base's. One GPU here: GM_FORCE_RCCL_PATH=1 drives the RCCL path (communicator,
+    ncclBroadcast of the CSR, ncclAllReduce of the count) with one rank; a request for more GPUs than present is clamped with a message."""
+    e = GOLDEN[name]
+    prefix = os.path.join(ROOT, "tests", "fixtures", name, "graph")
+    os.environ["GM_FORCE_RCCL_PATH"] = "1"
+    try:
+        for ngpu in (1, 2):
+            hip = run("clique_hip_multigpu", prefix, 4, ngpu, 256)
+            assert hip[-1] == run("clique_omp_base", prefix, 4)[-1] == f"num_4-cliques = {e['clique4']}"
+            assert any("RCCL broadcast" in l for l in hip) and any(l.startswith("runtime[gpu0]") for l in hip), hip
+            hip = run("tc_hip_multigpu", prefix, ngpu, 128)
+            assert hip[-1] == f"total_num_triangles = {e['tc']}" and any("RCCL broadcast" in l for l in hip)
+        hip = run("sgl_hip_base", prefix, "diamond", 1)  # diamond across "ranks": supports + reduce-scatter + all-reduce with one rank
+        assert hip[-1] == f"total_num = {e['diamond']}" and any("RCCL broadcast" in l for l in hip)
+        hip = run("motif_hip_base", prefix, 4, 1)
+        assert hip[-6:] == run("motif_omp_base", prefix, 4)[-6:]
+    finally:
+        del os.environ["GM_FORCE_RCCL_PATH"]
+    # without the switch and with one device the same binaries take the one-GPU path
+    hip = run("clique_hip_multigpu", prefix, 4)
+    assert hip[-1] == f"num_4-cliques = {e['clique4']}" and not any("RCCL broadcast" in l for l in hip)
