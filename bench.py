@@ -118,6 +118,15 @@ def parse():
 # ---------------------------------------------------------------------------------------------------------------
 # graphs
 # ---------------------------------------------------------------------------------------------------------------
+def flush_c_stdio():
+    """fflush(NULL): whatever native libraries left in the C stdio buffers of this process goes out now"""
+    try:
+        C.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+
+
 class BenchGraph:
     """symmetric CSR resident in HBM (+ torch views of its arrays) and, on demand, its oriented copy"""
 
@@ -404,6 +413,10 @@ class Runner:
             self.all_reduce(ones)
             self.ranks_seen = int(ones.item())
             assert self.ranks_seen == self.world, f"the all-reduce saw {self.ranks_seen} ranks of {self.world}"
+            # RCCL prints a version banner (RCCL / HIP / ROCm version, hostname, library path) through C stdio when its first communicator
+            # comes up; on a pipe that buffer is flushed at process exit -- AFTER the JSON line.  Flush it now, on every rank: the JSON
+            # line must be the last thing on stdout.
+            flush_c_stdio()
         from graphminer_amd import _lib
 
         self._lib = _lib
@@ -430,8 +443,10 @@ class Runner:
 
     def close(self):
         if self.use_dist:
+            flush_c_stdio()
             self.dist.barrier()  # rank 0 finishes its host-side reporting before any rank tears the communicator down
             self.dist.destroy_process_group()
+            flush_c_stdio()
 
     def run(self, workload, bg, steps, warmup, solo=False):
         """Returns a dict with the timing and the counts of `workload` on graph `bg`. solo: this process alone, the whole graph, no
@@ -1288,8 +1303,13 @@ def main():
             line = json.dumps(rec, separators=(",", ":"))
             if len(line) < 4000:
                 break
-        print(line, flush=True)
     r.close()
+    if rank == 0:
+        # the LAST thing on stdout, after the communicator is gone and every C buffer of this process is flushed; the other ranks print
+        # nothing themselves and get a moment to exit (their RCCL teardown may write through stdio too)
+        if r.use_dist and world > 1:
+            time.sleep(1.0)
+        print(line, flush=True)
 
 
 if __name__ == "__main__":
