@@ -54,6 +54,7 @@ WORKLOADS = {
     "pentagon": (16, 16, False, "sgl pentagon, R-MAT scale 16"),
     "clique5": (20, 16, True, "5-clique, R-MAT scale 20"),
     "motif3f": (24, 16, False, "3-motif, formula variant (motif_gpu_formula), R-MAT scale 24"),
+    "motif4": (18, 16, False, "4-motif (formula form: per-edge sums + 4-cycles + 4-cliques), R-MAT scale 18"),
 }
 # BASELINE.json configs[1..4] (configs[0] = the CPU plumbing case, handled by config1_record)
 BASELINE_CONFIGS = [
@@ -77,6 +78,9 @@ KERNELS = {
     "rectangle": ["rect_acc_kernel"],
     "house": ["house_acc_kernel"],
     "pentagon": ["pent_acc_kernel"],
+    # (gm_motif, k = 4: per-edge sums of the symmetric graph + rectangle by wedge accumulation + 4-clique of the oriented copy)
+    "motif4": ["mine_kernel<5,", "hrow_kernel<5,", "giant_kernel<5,", "rect_acc_kernel", "mine_kernel<3,", "cbuild_kernel", "cgather_kernel", "clique_mma_kernel",
+               "clique_count_kernel", "clique_small_kernel", "tch_kernel"],
 }
 TRAFFIC_MARKER = "issue_calib_kernel"  # the dispatch in front of every workload of the traffic worker (measure_traffic)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (~6.3 TB/s achievable by a stream)
@@ -505,6 +509,8 @@ class Runner:
                 rc = lib.gm_clique(hd, int(workload[-1]), C.byref(la), None, C.byref(st))
             elif workload == "motif3f":
                 rc = lib.gm_motif_formula(hd, 3, C.byref(la), None, 2, C.byref(st))
+            elif workload == "motif4":
+                rc = lib.gm_motif(hd, 4, C.byref(la), None, 6, C.byref(st))
             elif workload == "motif3e":
                 la.tune[6] |= 0x10000000
                 rc = lib.gm_motif(hd, 3, C.byref(la), None, 2, C.byref(st))
@@ -576,7 +582,7 @@ class Runner:
         setup = g.setup_times_ms()  # (the DAG handle carries the orientation time of the graph it was made from)
         return {
             "workload": workload, "g": g, "tasks": tasks, "elapsed": elapsed, "steps": steps,
-            "ms_per_step": 1e3 * elapsed / steps, "count": result[:2] if workload.startswith("motif3") else result[0],
+            "ms_per_step": 1e3 * elapsed / steps, "count": result[:2] if workload.startswith("motif3") else (result[:6] if workload == "motif4" else result[0]),
             "kernel_ms_avg": k_avg, "per_gpu_kernel_ms": per_gpu, "first_call_ms": median([x["first_call_ms"] for x in first_runs]), "setup_ms": setup,
             "first_call_runs_ms": [round(x["first_call_ms"], 2) for x in first_runs],
             # graph resident in HBM -> first count: the first call (builds tables, renumbered copies, task lists, runs once) + the orientation

@@ -261,6 +261,12 @@ struct gm_graph {
   int n_long_rows = -1;               // -1: not looked for yet
   long long long_edges = 0;
   unsigned *d_sup = nullptr;  // edge supports: one counter per DAG entry (gm_sup.hip)
+  // ... and the MATCH MASKS of the in-edge tasks with long tails (ensure_sup_masks, gm_tables.hip): per DAG entry / per task the offset of
+  // the task's mask in the arena (64-bit words; kNoMask: the task keeps its atomics), the arena itself (written and read by every launch)
+  unsigned *d_emoff = nullptr, *d_tmoff = nullptr;
+  unsigned long long *d_smask = nullptr;
+  unsigned long long smask_words = 0;
+  int smask_state = 0;  // 0 unknown, 1 built, 2 not applicable (DAG not topological, arena beyond 2^32 words, GM_SUP_NO_MASKS)
   std::vector<int> h_rp;  // host copy of the offsets, fetched on first use (host_rp): download, k-clique tables, SgL renumbering
   std::list<ChunkTable> tables;  // list: handed-out pointers stay valid
   unsigned long long *d_counters = nullptr;  // [4] + queue word, 64 B
@@ -457,6 +463,8 @@ int get_table(gm_graph *g, int target, bool allow_split, int bit_words, unsigned
 int ensure_edesc(gm_graph *g);
 int ensure_tasklists(gm_graph *g, bool with_edges = false);
 int ensure_keystream(gm_graph *g, bool edges, bool *built);
+int sup_mask_min_tail();            // (gm_tables.hip) kSupMaskMinTail or GM_SUP_MASK_MIN
+int ensure_sup_masks(gm_graph *g);  // (gm_tables.hip) d_emoff / d_tmoff / d_smask of a topologically numbered DAG with task lists; GM_OK also when not applicable
 int ensure_mean_sq_deg(gm_graph *g);
 unsigned long long task_part_cap(gm_graph *g, int world);
 int clique_wide_min_words();

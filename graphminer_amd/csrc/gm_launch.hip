@@ -249,6 +249,14 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
     }
   }
   if (support && !sup_part && !g->d_sup) HIP_TRY(hipMalloc(&g->d_sup, sizeof(unsigned) * (size_t)std::max<long long>(g->ne, 1)));
+  // match masks instead of one atomic per streamed edge (gm_sup.hip): one GPU, the task lists, a topologically numbered DAG
+  // (tune[6] & 0x40000000: A/B switch, every streamed edge by an atomic)
+  bool sup_masks = false;
+  if (support && !sup_part && world == 1 && use_tct && !use_kst && !(la->tune[6] & 0x40000000)) {
+    const int rc_m = ensure_sup_masks(g);
+    if (rc_m) return rc_m;
+    sup_masks = g->smask_state == 1;
+  }
   setup_trace("run_pattern: task lists");
   // the hosts with rows of 1025 .. 2048 entries, on the 2048-entry kernel -- when a rank's share of them can fill the chip about twice: the two
   // launches follow each other on the stream, and the second waits for the first one's last chunk.  R-MAT-24 has 8.5 K such chunks with a
@@ -358,6 +366,10 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
     p.g.trp = g->d_trp;
     p.g.tdesc = g->d_tdesc;
     p.g.tedge = support ? g->d_tedge : nullptr;
+    if (sup_masks) {
+      p.g.tmoff = g->d_tmoff;
+      p.smask = g->d_smask;
+    }
     // the triangle count streams the short lists from their task-major copies (gm_host.h d_colk; tune[6] & 0x20000000: from their rows);
     // the edge supports need the entries of the streamed keys in col[] itself
     if (use_kst && support) {  // ... with the entries the supports need beside them (the second set when the stream was built without)
@@ -781,6 +793,18 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
       sl.world = world;
       HIP_TRY(launch_sup_long(sl, g->cu_count, stream));
       my_edges += (unsigned long long)((g->long_edges - rank + world - 1) / world);
+    }
+    if (sup_masks) {  // the masks of the in-edge tasks, summed by column into the supports of their rows
+      SupColsParams sc;
+      memset(&sc, 0, sizeof sc);
+      sc.nv = g->nv;
+      sc.lmin = sup_mask_min_tail();
+      sc.rp = g->d_rp;
+      sc.emoff = g->d_emoff;
+      sc.smask = g->d_smask;
+      sc.sup = sup;
+      sc.queue = reinterpret_cast<unsigned *>(g->d_counters + 4) + 3;
+      HIP_TRY(launch_sup_cols(sc, g->cu_count, stream));
     }
     if (!sup_part) HIP_TRY(launch_sup_pairs(sup, 0, g->ne, g->d_counters, g->cu_count, stream));
   } else if (use_tct) {

@@ -77,6 +77,9 @@ struct GraphView {
   const int *trp = nullptr;
   const int2 *tdesc = nullptr;
   const int *tedge = nullptr;  // per task: the DAG entry of its own edge (edge supports, gm_sup.hip); nullptr = not built
+  // edge supports, MATCH MASKS (gm_sup.hip): per task the offset -- in 64-bit words -- of its match mask in the mask arena
+  // (MineParams::smask), kNoMask = the task reports its streamed edges with atomics; nullptr = no masks in this launch
+  const unsigned *tmoff = nullptr;
   // KEY STREAM of the short lists (gm_tch.hip; built with the task lists when nv <= 2^24): the keys of every list of <= GM_TC_INLINE_MAX
   // entries in task order -- hosts ascending -- each tagged with the low 8 bits of its host vertex in bits 24..31; kst_rp = offsets per
   // host vertex (nv + 1).  A chunk of hosts streams ONE contiguous range; trp / tdesc then hold only the longer lists.
@@ -84,6 +87,13 @@ struct GraphView {
   const int *kst_rp = nullptr;
   const int2 *kst_et = nullptr;  // edge supports: per key of kst {the DAG entry it was copied from, the entry of its task's own edge}
 };
+
+constexpr unsigned kNoMask = 0xffffffffu;
+// edge supports: an in-edge task whose tail has at least this many keys reports its streamed edges as a match mask (gm_sup.hip)
+#ifndef GM_SUP_MASK_MIN_TAIL
+#define GM_SUP_MASK_MIN_TAIL 32
+#endif
+constexpr int kSupMaskMinTail = GM_SUP_MASK_MIN_TAIL;
 
 enum Pattern : int { PAT_TC = 0, PAT_DIAMOND = 1, PAT_MOTIF3 = 2, PAT_CLIQUE4 = 3, PAT_CLIQUEK = 4 /* k = 5..8 */,
                      PAT_MOTIF4E = 5 /* per-edge sums of the 4-motif formula */,
@@ -159,6 +169,7 @@ struct MineParams {
   int cost_y_base;
   int cost_y_bitmap;  // pass Y cost per key when row v has a dense bitmap (one random probe)
   int k;
+  unsigned long long *smask;  // edge supports: the match-mask arena (GraphView::tmoff), nullptr = none
   int flags;  // bit 0: never stage adjacency in LDS; bit 3: no hashed filter in front of the LDS bisection; bit 9: ignore hub bitmaps (A/B switches)
 };
 
@@ -437,6 +448,16 @@ struct SupLongParams {
   int topo, rank, world;
 };
 hipError_t launch_sup_long(const SupLongParams &p, int cu_count, hipStream_t stream);
+// edge supports, second pass: the match masks of the in-edge tasks summed by column into the supports (gm_sup.hip sup_cols_kernel)
+struct SupColsParams {
+  int nv, lmin;                  // lmin: the shortest tail that has a mask
+  const int *rp;
+  const unsigned *emoff;         // per DAG entry: the offset of its task's mask (64-bit words), kNoMask = none
+  const unsigned long long *smask;
+  unsigned *sup;
+  unsigned *queue;               // dequeue word of the 64-vertex blocks (zeroed before the launch)
+};
+hipError_t launch_sup_cols(const SupColsParams &p, int cu_count, hipStream_t stream);
 hipError_t launch_sup_pairs(const unsigned *sup, long long first, long long count, unsigned long long *out, int cu_count, hipStream_t stream);
 size_t mine_lds_bytes(Pattern pat);
 // the big-LDS classes (gm_mine_wide.hip): cls = 1 (mid rows) or 2 (big rows); DIAMOND, MOTIF3, MOTIF4E only

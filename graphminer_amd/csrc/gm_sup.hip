@@ -19,6 +19,14 @@
 //     must assume they complete out of order, so a pending atomic turns the wait for the current tile group's keys into a wait for
 //     everything -- the next group's prefetched keys included.  The entries of the matches are queued in LDS (256 per wave) and
 //     flushed in bursts, whose latencies overlap each other.
+// MATCH MASKS (round 5).  87 % of the triangles of an R-MAT graph are found by IN-EDGE tasks (the target s_i of u -> s_i hosts, the tail
+// N+(u)[i + 1 ..) is streamed): the streamed edge (u, s_j) of such a match is an entry of row u right behind the task's own entry, and the
+// task needs no atomic to report it -- it stores WHICH keys of its tail matched (bit k of its mask = key k), 64 keys per plain 8-byte
+// store, and sup_cols_kernel sums the masks of a row by column: entry j of row u += sum_{i < j} bit (j - i - 1) of the mask of entry i.
+// Masks: the in-edge tasks with tails of >= kSupMaskMinTail keys (ensure_sup_masks, gm_tables.hip: offsets per task / per entry); long
+// tails (>= kLongList keys, one task at a time) store their tiles' ballots directly, the tails of the flattened pass collect theirs in six
+// LDS words per batch lane.  Out-edge tasks, short tails and the surplus-list matches of unmasked tasks keep the atomics.  One GPU, a
+// topologically numbered DAG; a rank's share of a larger job (gm_diamond_support_partial) runs without masks.
 // A second kernel sums C(t, 2) over the entries.
 // One GPU; rows beyond the 2048-entry stage send the caller back to the per-edge kernels (gm_launch.hip).
 #include "gm_hset.h"
@@ -30,14 +38,18 @@ constexpr int kSupTiles = 4;
 #define GM_SUP_TILES_SMALL 4
 #endif
 constexpr int kSupTilesSmall = GM_SUP_TILES_SMALL;  // (1024-bucket kernel)
-constexpr int kSupQueue = 256, kSupFlushAt = kSupQueue - GM_WAVE;  // (a tile adds at most 64 entries)
+constexpr int kSupQueue = 128, kSupFlushAt = kSupQueue - GM_WAVE;  // (a tile adds at most 64 entries; the key stream's tiles two per match)
+constexpr int kSupMaskWords = (kLongList + 31) / 32;                // 32-bit LDS words of a flattened task's mask (tails below kLongList keys)
+static_assert(kSupMaskWords % 2 == 0, "the LDS mask of a batch lane is copied out as 64-bit words");
 
 template <int STAGE>
 struct alignas(16) SupLds {
   HsTable<STAGE> set;
   int trpl[kMaxChunkVerts + 1];  // row offsets of the chunk's task lists
   HsWave<STAGE> w[kWavesPerBlock];      // (while the set is built: the fill counters of its buckets)
-  unsigned cnt[kWavesPerBlock][GM_WAVE];  // per batch lane: matches of its task
+  // per batch lane: word 0 = the matches of its task -- or, for a task of the flattened pass that reports a match mask, the mask itself
+  // (bit k = key k of its tail; its matches are the mask's popcount)
+  unsigned mw[kWavesPerBlock][GM_WAVE][kSupMaskWords];
   unsigned ecnt[STAGE];                   // per stage entry: matches found at it
   int hq[kWavesPerBlock][kSupQueue];      // per wave: DAG entries (streamed edges) whose increment is still to be issued
   int next_batch;
@@ -46,7 +58,7 @@ struct alignas(16) SupLds {
   int pad_;
 };
 
-template <int STAGE>
+template <int STAGE, bool MASKS>
 __global__ __launch_bounds__((kWavesPerBlock * GM_WAVE), (STAGE <= 1024 ? 4 : 2))
 void sup_kernel(const MineParams p) {
   __shared__ SupLds<STAGE> B;
@@ -62,7 +74,8 @@ void sup_kernel(const MineParams p) {
   const int *__restrict__ tedge = p.g.tedge;
   unsigned *__restrict__ sup = p.scratch;
   HsWave<STAGE> &L = B.w[wave];
-  unsigned *cnt = B.cnt[wave];
+  unsigned (*mw)[kSupMaskWords] = B.mw[wave];
+  unsigned long long *__restrict__ smask = p.smask;
   for (;;) {
     if (tid == 0) B.queue_pos = atomicAdd(p.queue, (unsigned)p.grab);
     __syncthreads();
@@ -179,7 +192,11 @@ void sup_kernel(const MineParams p) {
         const int lo = hs_local_row(B.trpl, nvl, te);  // the host row of this task
         const int ru = B.set.rpl[lo], a = B.set.rpl[lo + 1] - ru;
         const bool act = valid && d.y > 0 && a > 0;
-        cnt[lane] = 0u;
+        // tm: where this task's match mask goes (64-bit words into the arena), kNoMask = its streamed edges are reported by atomics
+        const unsigned tm = (MASKS && act) ? p.g.tmoff[te] : kNoMask;
+        const bool masked = MASKS && tm != kNoMask;
+#pragma unroll
+        for (int k = 0; k < (MASKS ? kSupMaskWords : 1); ++k) mw[lane][k] = 0u;
         int *hq = B.hq[wave];
         int qn = 0;  // wave-uniform: queued entries
         auto flush = [&]() {
@@ -189,32 +206,87 @@ void sup_kernel(const MineParams p) {
           wave_sync();
         };
         wave_sync();
-        // word = where the host's row starts in the stage, word2 = the task's batch lane
-        auto hit = [&](const unsigned long long hm, const int row0, const int owner, const unsigned at, const int kidx, const bool uniform) {
-          if (hm == 0ull) return;  // wave-uniform
-          if (uniform) {  // a tile of one task: its count once (64 atomics on one LDS word would serialise)
-            if (lane == 0) atomicAdd(&cnt[owner], (unsigned)__popcll(hm));
+        // word = where the host's row starts in the stage, word2 = the task's batch lane (bit 31: the task reports a mask)
+        auto hit = [&](const unsigned long long hm, const int row0, const int word2, const unsigned at, const int kidx, const bool uniform) {
+          if (uniform) {  // a tile of ONE task (long lists): word2 is wave-uniform
+            const int owner = readfirst(word2) & (GM_WAVE - 1);
+            if (MASKS && readfirst(word2) < 0) {  // the tile's ballot IS 64 bits of the mask: one plain store, matches or not
+              const int k0 = readfirst(kidx) - readlane(d.x, owner);  // (key index of lane 0: a multiple of 64)
+              if (k0 < readlane(d.y, owner)) {  // (the last group of a list looks all its tiles up, also those behind the list's end)
+                if (lane == 0) smask[(size_t)(unsigned)readlane((int)tm, owner) + (size_t)(k0 >> 6)] = hm;
+              }
+              if (hm == 0ull) return;
+              if (lane == 0) atomicAdd(&mw[owner][0], (unsigned)__popcll(hm));  // (its LDS mask words are unused: word 0 counts)
+              if (__builtin_amdgcn_inverse_ballot_w64(hm)) atomicAdd(&B.ecnt[row0 + (int)at], 1u);
+              return;
+            }
+            if (hm == 0ull) return;
+            if (lane == 0) atomicAdd(&mw[owner][0], (unsigned)__popcll(hm));  // its count once (64 atomics on one LDS word would serialise)
+            if (__builtin_amdgcn_inverse_ballot_w64(hm)) {
+              atomicAdd(&B.ecnt[row0 + (int)at], 1u);
+              hq[qn + rank_below(hm)] = kidx;
+            }
+            qn += __popcll(hm);
+            if (qn > kSupFlushAt) flush();
+            return;
           }
+          if (hm == 0ull) return;  // wave-uniform
+          const int owner = word2 & (GM_WAVE - 1);
+          // a masked task of the flattened pass: bit (kidx - start of its list) of the LDS mask of its batch lane
+          const int start = MASKS ? __builtin_amdgcn_ds_bpermute(owner << 2, d.x) : 0;  // (every lane takes part)
+          const unsigned long long am = MASKS ? hm & __ballot(word2 >= 0) : hm;  // the matches that are reported by atomics
           if (__builtin_amdgcn_inverse_ballot_w64(hm)) {
             atomicAdd(&B.ecnt[row0 + (int)at], 1u);
-            hq[qn + rank_below(hm)] = kidx;
-            if (!uniform) atomicAdd(&cnt[owner], 1u);
+            if (MASKS && word2 < 0) {
+              const int k = kidx - start;
+              atomicOr(&mw[owner][k >> 5], 1u << (k & 31));
+            } else {
+              hq[qn + rank_below(am)] = kidx;
+              atomicAdd(&mw[owner][0], 1u);
+            }
           }
-          qn += __popcll(hm);
+          qn += __popcll(am);
           if (qn > kSupFlushAt) flush();
         };
-        auto hit1 = [&](const int row0, const int owner, const int at, const int kidx) {
+        auto hit1 = [&](const int row0, const int word2, const int at, const int kidx) {  // one key found through the surplus list (wave-uniform)
+          const int owner = word2 & (GM_WAVE - 1);
+          if (MASKS && word2 < 0) {  // its bit joins the mask: in LDS (flattened pass) or behind the tile's store (long lists)
+            const int k = kidx - readlane(d.x, owner);
+            if (lane == 0) {
+              atomicAdd(&B.ecnt[row0 + at], 1u);
+              if (readlane(d.y, owner) >= kLongList) {
+                atomicOr(&smask[(size_t)(unsigned)readlane((int)tm, owner) + (size_t)(k >> 6)], 1ull << (k & 63));
+                atomicAdd(&mw[owner][0], 1u);
+              } else {
+                atomicOr(&mw[owner][k >> 5], 1u << (k & 31));
+              }
+            }
+            return;
+          }
           if (lane == 0) {
             atomicAdd(&B.ecnt[row0 + at], 1u);
             hq[qn] = kidx;
-            atomicAdd(&cnt[owner], 1u);
+            atomicAdd(&mw[owner][0], 1u);
           }
           qn += 1;
           if (qn > kSupFlushAt) flush();
         };
-        hs_pass<STAGE, (STAGE <= 1024 ? kSupTilesSmall : kSupTiles)>(B.set, L, col, fallback, lane, act ? d.y : 0, d.x, H::salt(lo), ru - eb, a, ru - eb, lane, hit, hit1);
+        hs_pass<STAGE, (STAGE <= 1024 ? kSupTilesSmall : kSupTiles)>(B.set, L, col, fallback, lane, act ? d.y : 0, d.x, H::salt(lo), ru - eb, a, ru - eb,
+                                                                      lane | (masked ? (int)0x80000000 : 0), hit, hit1);
         flush();
-        const unsigned c = cnt[lane];
+        unsigned c = mw[lane][0];
+        if (masked && d.y < kLongList) {  // the mask of a flattened task goes out: ceil(len / 64) 64-bit words; its matches = its popcount
+          const unsigned long long *m64 = reinterpret_cast<const unsigned long long *>(mw[lane]);
+          c = 0u;
+#pragma unroll
+          for (int k = 0; k < kSupMaskWords / 2; ++k) {
+            if (k * 64 < d.y) {
+              const unsigned long long m = m64[k];
+              smask[(size_t)tm + (size_t)k] = m;
+              c += (unsigned)__popcll(m);
+            }
+          }
+        }
         if (valid && c) atomicAdd(&sup[own_e], c);
         wave_sync();
       }
@@ -226,6 +298,68 @@ void sup_kernel(const MineParams p) {
       __syncthreads();
     }
   }
+}
+
+// The masks of a row summed by COLUMN: entry j of row u += sum over the masked entries i < j of bit (j - i - 1) of the mask of entry i
+// (the streamed edges of the matches the in-edge tasks of row u found).  A wave takes 64 vertices at a time from the top of the id range
+// (the widest rows first) and, for every row with masked entries, counts in LDS -- lane = row i of a 64-row block, word after word of
+// its mask, one LDS atomic per set bit -- then adds the counters to the row's supports with plain stores: nobody else touches them
+// in this kernel, and the triangle pass is complete.
+constexpr int kSupColsWaves = 4;
+__global__ __launch_bounds__(kSupColsWaves *GM_WAVE) void sup_cols_kernel(const SupColsParams p) {
+  __shared__ unsigned counters[kSupColsWaves][kTctStageMax];
+  const int lane = threadIdx.x & (GM_WAVE - 1);
+  unsigned *cc = counters[threadIdx.x >> 6];
+  for (;;) {
+    int blk = 0;
+    if (lane == 0) blk = (int)atomicAdd(p.queue, 1u);
+    blk = readfirst(blk);
+    const long long v0 = (long long)p.nv - (long long)GM_WAVE * ((long long)blk + 1);
+    if (v0 + GM_WAVE <= 0) break;
+    const long long v = v0 + lane;
+    int ru = 0, d = 0;
+    if (v >= 0) {
+      ru = p.rp[v];
+      d = p.rp[v + 1] - ru;
+      if (d > kTctStageMax) d = 0;  // (a row beyond the stage has no tasks: sup_long_kernel)
+    }
+    unsigned long long rows = __ballot(d - 1 >= p.lmin);  // entry 0 of the row has a tail of d - 1 keys
+    while (rows) {
+      const int src = __ffsll((long long)rows) - 1;
+      rows &= rows - 1;
+      const int r0 = readlane(ru, src), dd = readlane(d, src);
+      for (int j = lane; j < dd; j += GM_WAVE) cc[j] = 0u;
+      wave_sync();
+      const int nrows = dd - p.lmin;  // entries [0, nrows) have tails of >= lmin keys
+      for (int ib = 0; ib < nrows; ib += GM_WAVE) {
+        const int i = ib + lane;
+        const unsigned off = i < nrows ? p.emoff[r0 + i] : kNoMask;
+        const int nw = off != kNoMask ? (dd - 1 - i + 63) >> 6 : 0;
+        const int nwmax = wave_max_nonneg(nw);
+        for (int w = 0; w < nwmax; ++w) {
+          unsigned long long x = w < nw ? p.smask[(size_t)off + (size_t)w] : 0ull;
+          const int base = i + 1 + 64 * w;
+          while (x) {
+            atomicAdd(&cc[base + (int)__builtin_ctzll(x)], 1u);
+            x &= x - 1;
+          }
+        }
+      }
+      wave_sync();
+      for (int j = lane; j < dd; j += GM_WAVE) {
+        const unsigned c = cc[j];
+        if (c) p.sup[r0 + j] += c;
+      }
+      wave_sync();
+    }
+  }
+}
+hipError_t launch_sup_cols(const SupColsParams &p, int cu_count, hipStream_t stream) {
+  static_assert(sizeof(unsigned) * kSupColsWaves * kTctStageMax * 5 <= 163840, "five workgroups per CU");
+  if (p.nv <= 0 || !p.emoff || !p.smask) return hipSuccess;
+  const long long blocks = std::min<long long>(((long long)p.nv + GM_WAVE * kSupColsWaves - 1) / (GM_WAVE * kSupColsWaves), (long long)cu_count * 5);
+  hipLaunchKernelGGL(sup_cols_kernel, dim3((unsigned)std::max<long long>(1, blocks)), dim3(kSupColsWaves * GM_WAVE), 0, stream, p);
+  return hipGetLastError();
 }
 
 // sum over the entries [first, first + count) of C(t, 2)
@@ -287,12 +421,15 @@ hipError_t launch_sup_long(const SupLongParams &p, int cu_count, hipStream_t str
 int sup_per_cu(int stage) { return stage <= 1024 ? 4 : 2; }
 hipError_t launch_sup(const MineParams &p, int stage, int grid_blocks, hipStream_t stream) {
   static_assert(sizeof(SupLds<1024>) * 4 <= 163840, "four workgroups per CU");
+  const bool masks = p.g.tmoff != nullptr && p.smask != nullptr;
   static_assert(sizeof(SupLds<kTctStageMax>) * 2 <= 163840, "two workgroups per CU");
   static_assert(sizeof(HsWave<kTctStageMax>) * kWavesPerBlock >= (size_t)kTctStageMax * 2, "fill counters alias the wave scratch");
   if (p.g.trp == nullptr || p.g.tdesc == nullptr || p.g.tedge == nullptr || p.scratch == nullptr) return hipErrorInvalidValue;
   const dim3 grid((unsigned)grid_blocks), block(kWavesPerBlock * GM_WAVE);
-  if (stage <= 1024) hipLaunchKernelGGL((sup_kernel<1024>), grid, block, 0, stream, p);
-  else hipLaunchKernelGGL((sup_kernel<kTctStageMax>), grid, block, 0, stream, p);
+  if (stage <= 1024 && masks) hipLaunchKernelGGL((sup_kernel<1024, true>), grid, block, 0, stream, p);
+  else if (stage <= 1024) hipLaunchKernelGGL((sup_kernel<1024, false>), grid, block, 0, stream, p);
+  else if (masks) hipLaunchKernelGGL((sup_kernel<kTctStageMax, true>), grid, block, 0, stream, p);
+  else hipLaunchKernelGGL((sup_kernel<kTctStageMax, false>), grid, block, 0, stream, p);
   return hipGetLastError();
 }
 hipError_t launch_sup_pairs(const unsigned *sup, long long first, long long count, unsigned long long *out, int cu_count, hipStream_t stream) {
