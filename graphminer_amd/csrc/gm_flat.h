@@ -255,10 +255,7 @@ __device__ __forceinline__ void drain_candidates(LT &L, const int *__restrict__ 
 //     (scalar base address, scalar salt): no owner marks, no scans -- this is where skewed graphs spend their time;
 //   * the remaining short lists of the batch are flattened (owner marks + DPP max-scan), with a fast path for
 //     tiles that contain no list boundary.
-#ifndef GM_LONG_LIST
-#define GM_LONG_LIST 192
-#endif
-constexpr int kLongList = GM_LONG_LIST;
+// (kLongList: gm_mine.h -- the setup of the edge supports' match masks sizes them by it)
 
 template <int FL2 = kFilterLog2, bool BM = false, bool IDX = false, class LT, class Act>
 __device__ __forceinline__ void flat_pass_filtered(LT &L, const int *__restrict__ stage, const unsigned *__restrict__ fbits,

@@ -85,7 +85,7 @@ extern "C" void gm_graph_free(gm_graph *g) {
   if (g->d_trp) (void)hipFree(g->d_trp);
   if (g->d_tdesc) (void)hipFree(g->d_tdesc);
   if (g->d_tedge) (void)hipFree(g->d_tedge);
-  for (void *q : {(void *)g->d_emoff, (void *)g->d_tmoff, (void *)g->d_smask})
+  for (void *q : {(void *)g->d_emoff, (void *)g->d_tmoff, (void *)g->d_smask, (void *)g->d_sup_far_rows})
     if (q) (void)hipFree(q);
   if (g->d_long_rows) (void)hipFree(g->d_long_rows);
   if (g->d_long_prefix) (void)hipFree(g->d_long_prefix);

@@ -266,6 +266,8 @@ struct gm_graph {
   unsigned *d_emoff = nullptr, *d_tmoff = nullptr;
   unsigned long long *d_smask = nullptr;
   unsigned long long smask_words = 0;
+  int *d_sup_far_rows = nullptr;  // the rows with tails of more than 64 keys (masks of several words), widest ids first
+  int n_sup_far_rows = 0;
   int smask_state = 0;  // 0 unknown, 1 built, 2 not applicable (DAG not topological, arena beyond 2^32 words, GM_SUP_NO_MASKS)
   std::vector<int> h_rp;  // host copy of the offsets, fetched on first use (host_rp): download, k-clique tables, SgL renumbering
   std::list<ChunkTable> tables;  // list: handed-out pointers stay valid

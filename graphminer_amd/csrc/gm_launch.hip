@@ -798,12 +798,14 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
       SupColsParams sc;
       memset(&sc, 0, sizeof sc);
       sc.nv = g->nv;
+      sc.ne = g->ne;
       sc.lmin = sup_mask_min_tail();
       sc.rp = g->d_rp;
       sc.emoff = g->d_emoff;
       sc.smask = g->d_smask;
       sc.sup = sup;
-      sc.queue = reinterpret_cast<unsigned *>(g->d_counters + 4) + 3;
+      sc.far_rows = g->d_sup_far_rows;
+      sc.n_far_rows = g->n_sup_far_rows;
       HIP_TRY(launch_sup_cols(sc, g->cu_count, stream));
     }
     if (!sup_part) HIP_TRY(launch_sup_pairs(sup, 0, g->ne, g->d_counters, g->cu_count, stream));

@@ -88,12 +88,19 @@ struct GraphView {
   const int2 *kst_et = nullptr;  // edge supports: per key of kst {the DAG entry it was copied from, the entry of its task's own edge}
 };
 
+// lookup lists of at least this many keys are streamed one task at a time with a wave-uniform descriptor, shorter ones flattened 64 to a batch
+// (gm_flat.h, gm_hset.h, gm_tch.hip)
+#ifndef GM_LONG_LIST
+#define GM_LONG_LIST 192
+#endif
+constexpr int kLongList = GM_LONG_LIST;
 constexpr unsigned kNoMask = 0xffffffffu;
 // edge supports: an in-edge task whose tail has at least this many keys reports its streamed edges as a match mask (gm_sup.hip)
 #ifndef GM_SUP_MASK_MIN_TAIL
-#define GM_SUP_MASK_MIN_TAIL 32
+#define GM_SUP_MASK_MIN_TAIL 8
 #endif
 constexpr int kSupMaskMinTail = GM_SUP_MASK_MIN_TAIL;
+constexpr int kSupMaskSpare = 3;  // spare 64-bit words behind the mask of a long list (tile groups of at most kSupMaskSpare + 1 tiles)
 
 enum Pattern : int { PAT_TC = 0, PAT_DIAMOND = 1, PAT_MOTIF3 = 2, PAT_CLIQUE4 = 3, PAT_CLIQUEK = 4 /* k = 5..8 */,
                      PAT_MOTIF4E = 5 /* per-edge sums of the 4-motif formula */,
@@ -451,11 +458,13 @@ hipError_t launch_sup_long(const SupLongParams &p, int cu_count, hipStream_t str
 // edge supports, second pass: the match masks of the in-edge tasks summed by column into the supports (gm_sup.hip sup_cols_kernel)
 struct SupColsParams {
   int nv, lmin;                  // lmin: the shortest tail that has a mask
+  long long ne;
+  const int *far_rows;           // the rows with tails of more than 64 keys, widest ids first (sup_far_kernel: wave w takes rows w, w + W, ...)
+  int n_far_rows;
   const int *rp;
   const unsigned *emoff;         // per DAG entry: the offset of its task's mask (64-bit words), kNoMask = none
   const unsigned long long *smask;
   unsigned *sup;
-  unsigned *queue;               // dequeue word of the 64-vertex blocks (zeroed before the launch)
 };
 hipError_t launch_sup_cols(const SupColsParams &p, int cu_count, hipStream_t stream);
 hipError_t launch_sup_pairs(const unsigned *sup, long long first, long long count, unsigned long long *out, int cu_count, hipStream_t stream);

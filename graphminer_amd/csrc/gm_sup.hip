@@ -41,6 +41,7 @@ constexpr int kSupTilesSmall = GM_SUP_TILES_SMALL;  // (1024-bucket kernel)
 constexpr int kSupQueue = 128, kSupFlushAt = kSupQueue - GM_WAVE;  // (a tile adds at most 64 entries; the key stream's tiles two per match)
 constexpr int kSupMaskWords = (kLongList + 31) / 32;                // 32-bit LDS words of a flattened task's mask (tails below kLongList keys)
 static_assert(kSupMaskWords % 2 == 0, "the LDS mask of a batch lane is copied out as 64-bit words");
+static_assert(kSupTiles - 1 <= kSupMaskSpare && kSupTilesSmall - 1 <= kSupMaskSpare, "the mask of a long list has spare words for the tiles behind its end");
 
 template <int STAGE>
 struct alignas(16) SupLds {
@@ -206,19 +207,22 @@ void sup_kernel(const MineParams p) {
           wave_sync();
         };
         wave_sync();
-        // word = where the host's row starts in the stage, word2 = the task's batch lane (bit 31: the task reports a mask)
-        auto hit = [&](const unsigned long long hm, const int row0, const int word2, const unsigned at, const int kidx, const bool uniform) {
-          if (uniform) {  // a tile of ONE task (long lists): word2 is wave-uniform
-            const int owner = readfirst(word2) & (GM_WAVE - 1);
-            if (MASKS && readfirst(word2) < 0) {  // the tile's ballot IS 64 bits of the mask: one plain store, matches or not
-              const int k0 = readfirst(kidx) - readlane(d.x, owner);  // (key index of lane 0: a multiple of 64)
-              if (k0 < readlane(d.y, owner)) {  // (the last group of a list looks all its tiles up, also those behind the list's end)
-                if (lane == 0) smask[(size_t)(unsigned)readlane((int)tm, owner) + (size_t)(k0 >> 6)] = hm;
-              }
+        // The two per-task words handed back to the match handler (wave-uniform for the tiles of a long list):
+        //   word  = where the host's row starts in the stage (bits 0..11) | the task's batch lane << 12 | bit 31: the task reports a mask
+        //   word2 = a masked task of the flattened pass: the start of its list (bit k of its LDS mask = key k);
+        //           a masked LONG list: tm - (start >> 6) -- the tile of 64 keys from col[kidx0 ..) is word (kidx0 >> 6) behind it, because
+        //           kidx0 - start is a multiple of 64 (its mask has kSupTiles - 1 spare words: the last group looks all its tiles up)
+        constexpr int kOwnerShift = 12;
+        static_assert(STAGE <= (1 << kOwnerShift), "the stage index shares a word with the batch lane");
+        auto hit = [&](const unsigned long long hm, const int word, const int word2, const unsigned at, const int kidx, const bool uniform) {
+          if (uniform) {  // a tile of ONE task (long lists): word / word2 are wave-uniform
+            const int wu = readfirst(word);
+            const int row0 = wu & ((1 << kOwnerShift) - 1), owner = (wu >> kOwnerShift) & (GM_WAVE - 1);
+            if (MASKS && wu < 0) {  // the tile's ballot IS 64 bits of the mask: one plain store, matches or not
+              if (lane == 0) smask[(size_t)((unsigned)readfirst(word2) + ((unsigned)readfirst(kidx) >> 6))] = hm;
               if (hm == 0ull) return;
-              if (lane == 0) atomicAdd(&mw[owner][0], (unsigned)__popcll(hm));  // (its LDS mask words are unused: word 0 counts)
               if (__builtin_amdgcn_inverse_ballot_w64(hm)) atomicAdd(&B.ecnt[row0 + (int)at], 1u);
-              return;
+              return;  // (the task's own edge: the popcount of its mask, added by the second pass)
             }
             if (hm == 0ull) return;
             if (lane == 0) atomicAdd(&mw[owner][0], (unsigned)__popcll(hm));  // its count once (64 atomics on one LDS word would serialise)
@@ -231,14 +235,12 @@ void sup_kernel(const MineParams p) {
             return;
           }
           if (hm == 0ull) return;  // wave-uniform
-          const int owner = word2 & (GM_WAVE - 1);
-          // a masked task of the flattened pass: bit (kidx - start of its list) of the LDS mask of its batch lane
-          const int start = MASKS ? __builtin_amdgcn_ds_bpermute(owner << 2, d.x) : 0;  // (every lane takes part)
-          const unsigned long long am = MASKS ? hm & __ballot(word2 >= 0) : hm;  // the matches that are reported by atomics
+          const int row0 = word & ((1 << kOwnerShift) - 1), owner = (word >> kOwnerShift) & (GM_WAVE - 1);
+          const unsigned long long am = MASKS ? hm & __ballot(word >= 0) : hm;  // the matches that are reported by atomics
           if (__builtin_amdgcn_inverse_ballot_w64(hm)) {
             atomicAdd(&B.ecnt[row0 + (int)at], 1u);
-            if (MASKS && word2 < 0) {
-              const int k = kidx - start;
+            if (MASKS && word < 0) {  // a masked task of the flattened pass: bit (kidx - start of its list) of the LDS mask of its batch lane
+              const int k = kidx - word2;
               atomicOr(&mw[owner][k >> 5], 1u << (k & 31));
             } else {
               hq[qn + rank_below(am)] = kidx;
@@ -248,18 +250,15 @@ void sup_kernel(const MineParams p) {
           qn += __popcll(am);
           if (qn > kSupFlushAt) flush();
         };
-        auto hit1 = [&](const int row0, const int word2, const int at, const int kidx) {  // one key found through the surplus list (wave-uniform)
-          const int owner = word2 & (GM_WAVE - 1);
-          if (MASKS && word2 < 0) {  // its bit joins the mask: in LDS (flattened pass) or behind the tile's store (long lists)
-            const int k = kidx - readlane(d.x, owner);
+        auto hit1 = [&](const int word, const int word2, const int at, const int kidx) {  // one key found through the surplus list (wave-uniform)
+          const int row0 = word & ((1 << kOwnerShift) - 1), owner = (word >> kOwnerShift) & (GM_WAVE - 1);
+          if (MASKS && word < 0) {  // its bit joins the mask: in LDS (flattened pass) or behind the tile's store (long lists)
             if (lane == 0) {
               atomicAdd(&B.ecnt[row0 + at], 1u);
-              if (readlane(d.y, owner) >= kLongList) {
-                atomicOr(&smask[(size_t)(unsigned)readlane((int)tm, owner) + (size_t)(k >> 6)], 1ull << (k & 63));
-                atomicAdd(&mw[owner][0], 1u);
-              } else {
-                atomicOr(&mw[owner][k >> 5], 1u << (k & 31));
-              }
+              const int start = readlane(d.x, owner);
+              const int k = kidx - start;
+              if (readlane(d.y, owner) >= kLongList) atomicOr(&smask[(size_t)((unsigned)word2 + ((unsigned)start >> 6) + ((unsigned)k >> 6))], 1ull << (k & 63));
+              else atomicOr(&mw[owner][k >> 5], 1u << (k & 31));
             }
             return;
           }
@@ -271,21 +270,16 @@ void sup_kernel(const MineParams p) {
           qn += 1;
           if (qn > kSupFlushAt) flush();
         };
-        hs_pass<STAGE, (STAGE <= 1024 ? kSupTilesSmall : kSupTiles)>(B.set, L, col, fallback, lane, act ? d.y : 0, d.x, H::salt(lo), ru - eb, a, ru - eb,
-                                                                      lane | (masked ? (int)0x80000000 : 0), hit, hit1);
+        const int word_l = (ru - eb) | (lane << kOwnerShift) | (masked ? (int)0x80000000 : 0);
+        const int word2_l = !masked ? 0 : (d.y >= kLongList ? (int)(tm - ((unsigned)d.x >> 6)) : d.x);
+        hs_pass<STAGE, (STAGE <= 1024 ? kSupTilesSmall : kSupTiles)>(B.set, L, col, fallback, lane, act ? d.y : 0, d.x, H::salt(lo), ru - eb, a, word_l, word2_l, hit, hit1);
         flush();
-        unsigned c = mw[lane][0];
-        if (masked && d.y < kLongList) {  // the mask of a flattened task goes out: ceil(len / 64) 64-bit words; its matches = its popcount
+        const unsigned c = masked ? 0u : mw[lane][0];  // (a masked task's own edge: the popcount of its mask, added by the second pass)
+        if (masked && d.y < kLongList) {  // the mask of a flattened task goes out: ceil(len / 64) 64-bit words
           const unsigned long long *m64 = reinterpret_cast<const unsigned long long *>(mw[lane]);
-          c = 0u;
 #pragma unroll
-          for (int k = 0; k < kSupMaskWords / 2; ++k) {
-            if (k * 64 < d.y) {
-              const unsigned long long m = m64[k];
-              smask[(size_t)tm + (size_t)k] = m;
-              c += (unsigned)__popcll(m);
-            }
-          }
+          for (int k = 0; k < kSupMaskWords / 2; ++k)
+            if (k * 64 < d.y) smask[(size_t)tm + (size_t)k] = m64[k];
         }
         if (valid && c) atomicAdd(&sup[own_e], c);
         wave_sync();
@@ -300,65 +294,93 @@ void sup_kernel(const MineParams p) {
   }
 }
 
-// The masks of a row summed by COLUMN: entry j of row u += sum over the masked entries i < j of bit (j - i - 1) of the mask of entry i
-// (the streamed edges of the matches the in-edge tasks of row u found).  A wave takes 64 vertices at a time from the top of the id range
-// (the widest rows first) and, for every row with masked entries, counts in LDS -- lane = row i of a 64-row block, word after word of
-// its mask, one LDS atomic per set bit -- then adds the counters to the row's supports with plain stores: nobody else touches them
-// in this kernel, and the triangle pass is complete.
+// The masks summed by COLUMN into the supports: entry j of row u += sum over the masked entries i < j of bit (j - i - 1) of the mask of
+// entry i (the streamed edges of the matches the in-edge tasks of row u found), and entry i += the popcount of its own mask (its task's
+// own edge: a masked task adds nothing itself).  Two kernels, plain read-modify-writes -- the triangle pass is complete and every
+// entry has one writer per kernel:
+//   * NEAR (sup_near_kernel): word 0 of every mask, entry-parallel.  Bit k of the mask of entry e' belongs to entry e' + 1 + k of the SAME
+//     row -- bits past the row's end are never set -- so entry e += sum_{t = 1 .. 64} bit (t - 1) of word0[e - t] needs no row bounds at
+//     all: a 128-entry window of words in LDS per wave, t runs to the highest bit set in the window.  Covers every row of <= 65 entries.
+//   * FAR (sup_far_kernel): the words beyond the first (tails of more than 64 keys), row by row: lane = row i of a 64-row block, word
+//     after word of its mask, one LDS atomic per set bit into a counter per column.  The rows that have such tails are listed once per graph
+//     (ensure_sup_masks), from the last ids of the DAG -- the widest rows under a numbering by degree -- down, and dealt out to the
+//     waves round robin: a wave that took 64 consecutive wide rows in one dequeue WAS the kernel's duration (1.8 ms of 2.1).
 constexpr int kSupColsWaves = 4;
-__global__ __launch_bounds__(kSupColsWaves *GM_WAVE) void sup_cols_kernel(const SupColsParams p) {
+__global__ __launch_bounds__(256) void sup_near_kernel(const SupColsParams p) {
+  __shared__ unsigned long long win[4][2 * GM_WAVE];
+  const int lane = threadIdx.x & (GM_WAVE - 1);
+  unsigned long long *w = win[threadIdx.x >> 6];
+  const long long nwin = (p.ne + GM_WAVE - 1) / GM_WAVE;
+  const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+  for (long long wi = wave0; wi < nwin; wi += nwaves) {
+    const long long e = wi * GM_WAVE + lane, ep = e - GM_WAVE;
+    const unsigned oc = e < p.ne ? p.emoff[e] : kNoMask, op = ep >= 0 ? p.emoff[ep] : kNoMask;
+    const unsigned long long mc = oc != kNoMask ? p.smask[oc] : 0ull, mp = op != kNoMask ? p.smask[op] : 0ull;
+    w[lane] = mp;
+    w[GM_WAVE + lane] = mc;
+    const int hb = max(mc ? 64 - (int)__builtin_clzll(mc) : 0, mp ? 64 - (int)__builtin_clzll(mp) : 0);  // bit k reaches the entry k + 1 behind
+    const int tmax = wave_max_nonneg(hb);
+    wave_sync();
+    unsigned acc = (unsigned)__popcll(mc);
+    for (int t = 1; t <= tmax; ++t) acc += (unsigned)((w[GM_WAVE + lane - t] >> (t - 1)) & 1ull);
+    if (acc) p.sup[e] += acc;  // (acc != 0 implies e < ne: a lane beyond the end has no word and no entry before it points past the end)
+    wave_sync();
+  }
+}
+
+__global__ __launch_bounds__(kSupColsWaves *GM_WAVE) void sup_far_kernel(const SupColsParams p) {
   __shared__ unsigned counters[kSupColsWaves][kTctStageMax];
   const int lane = threadIdx.x & (GM_WAVE - 1);
   unsigned *cc = counters[threadIdx.x >> 6];
-  for (;;) {
-    int blk = 0;
-    if (lane == 0) blk = (int)atomicAdd(p.queue, 1u);
-    blk = readfirst(blk);
-    const long long v0 = (long long)p.nv - (long long)GM_WAVE * ((long long)blk + 1);
-    if (v0 + GM_WAVE <= 0) break;
-    const long long v = v0 + lane;
-    int ru = 0, d = 0;
-    if (v >= 0) {
-      ru = p.rp[v];
-      d = p.rp[v + 1] - ru;
-      if (d > kTctStageMax) d = 0;  // (a row beyond the stage has no tasks: sup_long_kernel)
-    }
-    unsigned long long rows = __ballot(d - 1 >= p.lmin);  // entry 0 of the row has a tail of d - 1 keys
-    while (rows) {
-      const int src = __ffsll((long long)rows) - 1;
-      rows &= rows - 1;
-      const int r0 = readlane(ru, src), dd = readlane(d, src);
-      for (int j = lane; j < dd; j += GM_WAVE) cc[j] = 0u;
-      wave_sync();
-      const int nrows = dd - p.lmin;  // entries [0, nrows) have tails of >= lmin keys
-      for (int ib = 0; ib < nrows; ib += GM_WAVE) {
-        const int i = ib + lane;
-        const unsigned off = i < nrows ? p.emoff[r0 + i] : kNoMask;
-        const int nw = off != kNoMask ? (dd - 1 - i + 63) >> 6 : 0;
-        const int nwmax = wave_max_nonneg(nw);
-        for (int w = 0; w < nwmax; ++w) {
-          unsigned long long x = w < nw ? p.smask[(size_t)off + (size_t)w] : 0ull;
-          const int base = i + 1 + 64 * w;
+  const int wave0 = (int)(((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6), nwaves = (int)(((long long)gridDim.x * blockDim.x) >> 6);
+  // (the list runs from the widest ids down: row r of it to wave r mod W -- every wave gets its share of the wide rows, no dequeue)
+  for (int r = wave0; r < p.n_far_rows; r += nwaves) {
+    const int u = p.far_rows[r];
+    const int r0 = p.rp[u], dd = p.rp[u + 1] - r0;
+    for (int j = lane; j < dd; j += GM_WAVE) cc[j] = 0u;
+    wave_sync();
+    const int nrows = dd - 1 - GM_WAVE;  // entries [0, nrows) have tails of more than 64 keys
+    for (int ib = 0; ib < nrows; ib += GM_WAVE) {
+      const int i = ib + lane;
+      const unsigned off = i < nrows ? p.emoff[r0 + i] : kNoMask;
+      const int nw = off != kNoMask ? (dd - 1 - i + 63) >> 6 : 0;
+      const int nwmax = wave_max_nonneg(nw);
+      unsigned own = 0u;
+      constexpr int kU = 8;  // words of a row requested together
+      for (int w0 = 1; w0 < nwmax; w0 += kU) {
+        unsigned long long xs[kU];
+#pragma unroll
+        for (int k = 0; k < kU; ++k) xs[k] = w0 + k < nw ? p.smask[(size_t)off + (size_t)(w0 + k)] : 0ull;
+#pragma unroll
+        for (int k = 0; k < kU; ++k) {
+          unsigned long long x = xs[k];
+          own += (unsigned)__popcll(x);
+          const int base = i + 1 + 64 * (w0 + k);
           while (x) {
             atomicAdd(&cc[base + (int)__builtin_ctzll(x)], 1u);
             x &= x - 1;
           }
         }
       }
-      wave_sync();
-      for (int j = lane; j < dd; j += GM_WAVE) {
-        const unsigned c = cc[j];
-        if (c) p.sup[r0 + j] += c;
-      }
-      wave_sync();
+      if (own) atomicAdd(&cc[i], own);
     }
+    wave_sync();
+    for (int j = lane; j < dd; j += GM_WAVE) {
+      const unsigned c = cc[j];
+      if (c) p.sup[r0 + j] += c;
+    }
+    wave_sync();
   }
 }
 hipError_t launch_sup_cols(const SupColsParams &p, int cu_count, hipStream_t stream) {
   static_assert(sizeof(unsigned) * kSupColsWaves * kTctStageMax * 5 <= 163840, "five workgroups per CU");
-  if (p.nv <= 0 || !p.emoff || !p.smask) return hipSuccess;
-  const long long blocks = std::min<long long>(((long long)p.nv + GM_WAVE * kSupColsWaves - 1) / (GM_WAVE * kSupColsWaves), (long long)cu_count * 5);
-  hipLaunchKernelGGL(sup_cols_kernel, dim3((unsigned)std::max<long long>(1, blocks)), dim3(kSupColsWaves * GM_WAVE), 0, stream, p);
+  if (p.nv <= 0 || p.ne <= 0 || !p.emoff || !p.smask) return hipSuccess;
+  const long long nwin = (p.ne + GM_WAVE - 1) / GM_WAVE;
+  hipLaunchKernelGGL(sup_near_kernel, dim3((unsigned)std::max<long long>(1, std::min<long long>((nwin + 3) / 4, (long long)cu_count * 8))), dim3(256), 0, stream, p);
+  if (p.n_far_rows > 0) {
+    const long long blocks = std::min<long long>(((long long)p.n_far_rows + kSupColsWaves - 1) / kSupColsWaves, (long long)cu_count * 5);
+    hipLaunchKernelGGL(sup_far_kernel, dim3((unsigned)std::max<long long>(1, blocks)), dim3(kSupColsWaves * GM_WAVE), 0, stream, p);
+  }
   return hipGetLastError();
 }
 

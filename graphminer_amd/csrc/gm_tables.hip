@@ -1200,7 +1200,8 @@ int ensure_tasklists(gm_graph *g, bool /*with_edges*/) {
 // out-edge task, a tail below `lmin`, a row beyond the stage), their offsets by one scan, and the offsets again in task order.
 __global__ __launch_bounds__(256) void sup_mask_size_kernel(const TaskWalk w, const int lmin, unsigned long long *__restrict__ sz) {
   task_walk(w, [&](const bool act, const int, const int, const int e, const int, const int, const int2, const int tail, const bool u_hosts) {
-    if (act && !u_hosts && tail >= lmin) sz[e] = (unsigned long long)((tail + 63) >> 6);
+    // (a LONG list -- streamed one task at a time, gm_hset.h -- looks all the tiles of its last group up: kSupTiles - 1 spare words)
+    if (act && !u_hosts && tail >= lmin) sz[e] = (unsigned long long)(((tail + 63) >> 6) + (tail >= kLongList ? kSupMaskSpare : 0));
   });
 }
 __global__ __launch_bounds__(256) void sup_mask_off_kernel(const long long ne, const unsigned long long *__restrict__ off, unsigned *__restrict__ emoff) {
@@ -1215,6 +1216,18 @@ __global__ __launch_bounds__(256) void sup_mask_task_kernel(const long long nt, 
     // (an in-edge task streams the entries right behind its own: start == own entry + 1; an out-edge task of the same entry has no mask)
     tmoff[t] = (d.y > 0 && d.x == e + 1) ? emoff[e] : kNoMask;
   }
+}
+
+// the rows with tails of more than 64 keys (a second mask word: sup_far_kernel), widest ids first: flag, scan, scatter
+__global__ __launch_bounds__(256) void sup_far_flag_kernel(const int nv, const int *__restrict__ rp, const int lmin, const int stage_max, int *__restrict__ flag) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;  // position k = vertex nv - 1 - k
+  if (k >= nv) return;
+  const int v = nv - 1 - k, d = rp[v + 1] - rp[v];
+  flag[k] = (d <= stage_max && d - 1 > GM_WAVE && d - 1 >= lmin) ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void sup_far_list_kernel(const int nv, const int *__restrict__ flag, const int *__restrict__ pos, int *__restrict__ rows) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < nv && flag[k]) rows[pos[k]] = nv - 1 - k;
 }
 
 int sup_mask_min_tail() {
@@ -1261,9 +1274,21 @@ int ensure_sup_masks(gm_graph *g) {
     g->setup.table_ms += timer.ms();
     return GM_OK;
   }
+  // the rows that have a second mask word, from the top of the id range
+  DevBuf<int> fflag, fpos;
+  HIP_TRY(fflag.alloc((size_t)g->nv + 1));
+  HIP_TRY(fpos.alloc((size_t)g->nv + 1));
+  HIP_TRY(hipMemsetAsync(fflag.p, 0, sizeof(int) * ((size_t)g->nv + 1), 0));
+  hipLaunchKernelGGL(sup_far_flag_kernel, dim3((unsigned)((g->nv + 255) / 256)), dim3(256), 0, 0, g->nv, g->d_rp, sup_mask_min_tail(), kTctStageMax, fflag.p);
+  HIP_TRY(dev_exclusive_sum(tmp, fflag.p, fpos.p, (size_t)g->nv + 1));
+  int nfar = 0;
+  HIP_TRY(hipMemcpy(&nfar, fpos.p + g->nv, sizeof nfar, hipMemcpyDeviceToHost));
   unsigned *emoff = nullptr, *tmoff = nullptr;
   unsigned long long *arena = nullptr;
+  int *far_rows = nullptr;
   hipError_t e = hipMalloc(&emoff, sizeof(unsigned) * ne);
+  if (e == hipSuccess) e = hipMalloc(&far_rows, sizeof(int) * (size_t)std::max(nfar, 1));
+  if (e == hipSuccess) hipLaunchKernelGGL(sup_far_list_kernel, dim3((unsigned)((g->nv + 255) / 256)), dim3(256), 0, 0, g->nv, fflag.p, fpos.p, far_rows);
   if (e == hipSuccess) e = hipMalloc(&tmoff, sizeof(unsigned) * ne);
   if (e == hipSuccess) e = hipMalloc(&arena, sizeof(unsigned long long) * (size_t)total);
   if (e == hipSuccess) {
@@ -1273,7 +1298,7 @@ int ensure_sup_masks(gm_graph *g) {
     e = hipDeviceSynchronize();
   }
   if (e != hipSuccess) {  // (an optimisation that did not fit: the atomics stay)
-    for (void *q : {(void *)emoff, (void *)tmoff, (void *)arena})
+    for (void *q : {(void *)emoff, (void *)tmoff, (void *)arena, (void *)far_rows})
       if (q) (void)hipFree(q);
     (void)hipGetLastError();
     g->smask_state = 2;
@@ -1283,6 +1308,8 @@ int ensure_sup_masks(gm_graph *g) {
   g->d_emoff = emoff;
   g->d_tmoff = tmoff;
   g->d_smask = arena;
+  g->d_sup_far_rows = far_rows;
+  g->n_sup_far_rows = nfar;
   g->smask_words = total;
   g->smask_state = 1;
   setup_trace("support masks: offsets");
