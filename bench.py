@@ -228,7 +228,7 @@ def kernel_constants():
 
     lib = _lib.load()
     out = {}
-    for name in ("tct_stage_max", "topo_min_mean_row", "motif_trim_min_list", "cb_min_deg", "cb_max_deg", "core_h_default", "wide_min_words"):
+    for name in ("tct_stage_max", "topo_min_mean_row", "motif_trim_min_list", "cb_min_deg", "cb_max_deg", "core_h_default", "wide_min_words", "long_list"):
         v = C.c_int64(0)
         _lib.check(lib.gm_constant(name.encode(), C.byref(v)), "gm_constant " + name)
         out[name] = int(v.value)
@@ -242,9 +242,10 @@ def own_bytes_device(workload, bg, world=1):
     (SURVEY 8(d)'s figure, which charges the reference's loop nest, is kept beside it as `algorithmic_*`).
       tc       4*sum_e min(d+(v), tail_u(v)) + 12|E+| + 8(nv+1)       (the host of an edge u -> v = the endpoint whose list is NOT streamed: N+(v)
                whole, or the tail of N+(u) beyond v -- the library numbers the DAG topologically -- whichever is shorter; a row > 2048 entries hosts nothing)
-      diamond  one GPU (edge supports from the DAG's triangles, gm_sup.hip): the tc figure + 20|E+| + 4 T  (4 B per task for its own entry,
-               the support array zeroed, read once, and added to once per task and once per staged entry: 4 x 4|E+|; one 4-byte atomic
-               per triangle for the streamed edge; T = triangles, from the library's own count)
+      diamond  one GPU (edge supports from the DAG's triangles, gm_sup.hip): the tc figure + 20|E+| + 4 A + 16 W + 8|E+|  (4 B per task for its own
+               entry, the support array zeroed, read once, and added to once per task and once per staged entry: 4 x 4|E+|; A = streamed edges
+               reported by a 4-byte atomic, W = 64-bit words of the match masks the other streamed edges are reported through, written and
+               read once, 8 B of mask offsets per entry; A and W from the library after a launch, gm_diamond_support_info; no masks: A = T)
                several ranks (one intersection per edge): 4*sum_{undirected e} min(d(u), d(v)) + 12*ne + 8(nv+1)
       motif3   the tc figure (gm_motif k = 3 counts the triangles of the DAG; wedges = sum C(d,2) - 3T)
       motif3e  (per-edge enumeration) diamond's several-ranks figure on the copy numbered by DESCENDING degree, the streamed list trimmed to its
@@ -332,14 +333,27 @@ def own_bytes_device(workload, bg, world=1):
     if workload == "diamond" and world <= 1:
         dag = bg.dag()
         if dag.get_max_degree() <= TCT_STAGE_MAX:  # (longer DAG rows: the library takes the per-edge kernels, below)
-            from graphminer_amd import TCSolver
+            from graphminer_amd import SglSolver, TCSolver, _lib
 
             del src, dst
             tcp = own_bytes_device("tc", bg)
             tri = int(TCSolver(dag))
             nd = int(dag.E())
-            return {"bytes": tcp["bytes"] + 20 * nd + 4 * tri, "streamed_keys": tcp["streamed_keys"],
-                    "parts": dict(tcp["parts"], own_entry_per_task_x4=4 * nd, supports_zeroed_read_added_x16=16 * nd, streamed_edge_atomics_x4=4 * tri)}
+            # the streamed edges: match masks where the library uses them (round 5, gm_sup.hip: in-edge tasks store which keys of their tail
+            # matched, two kernels sum the masks by column) -- the mask arena written and read once (16 B per 64-bit word), 8 B per entry for
+            # the two offset arrays -- and one 4-byte atomic for every other streamed edge; both figures are the library's own
+            # (gm_diamond_support_info after a launch).  Without masks: one atomic per triangle.
+            SglSolver(bg.sym, "diamond")
+            info = (C.c_int64 * 4)()
+            _lib.check(_lib.load().gm_diamond_support_info(bg.sym.handle, info), "gm_diamond_support_info")
+            mask_words, atomics = int(info[0]), int(info[1])
+            if not mask_words:
+                atomics = tri
+            extra = 16 * mask_words + (8 * nd if mask_words else 0)
+            return {"bytes": tcp["bytes"] + 20 * nd + 4 * atomics + extra, "streamed_keys": tcp["streamed_keys"],
+                    "parts": dict(tcp["parts"], own_entry_per_task_x4=4 * nd, supports_zeroed_read_added_x16=16 * nd, streamed_edge_atomics_x4=4 * atomics,
+                                  match_mask_words_written_and_read_x16=16 * mask_words, mask_offsets_per_entry_x8=8 * nd if mask_words else 0,
+                                  triangles=tri, shortest_masked_tail=int(info[3]))}
     if workload in ("diamond", "motif3e"):
         ne = int(ci.numel())
         if workload == "motif3e":

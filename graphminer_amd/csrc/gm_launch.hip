@@ -1411,6 +1411,22 @@ extern "C" int gm_diamond_support_size(const gm_graph *sym, int world, int64_t *
   *n_entries = diamond_support_entries(run_on->ne, world);
   return GM_OK;
 }
+// tooling (the byte model of bench.py, tests): what the most recent one-GPU diamond of this handle did with its streamed edges
+extern "C" int gm_diamond_support_info(const gm_graph *sym, int64_t info[4]) {
+  if (!sym || !info) return GM_ERR_INVALID;
+  gm_graph *run_on = nullptr;
+  const int rc = diamond_run_on(sym, nullptr, &run_on);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(run_on->device));
+  HIP_TRY(hipDeviceSynchronize());
+  unsigned long long at = 0;
+  HIP_TRY(hipMemcpy(&at, run_on->d_counters + 2, sizeof at, hipMemcpyDeviceToHost));
+  info[0] = run_on->smask_state == 1 ? (int64_t)run_on->smask_words : 0;  // 64-bit words of the match-mask arena (0: no masks)
+  info[1] = (int64_t)at;                                                  // increments issued as global atomics from the waves' queues
+  info[2] = run_on->smask_state == 1 ? (int64_t)run_on->n_sup_far_rows : 0;
+  info[3] = (int64_t)sup_mask_min_tail();
+  return GM_OK;
+}
 extern "C" int gm_diamond_support_partial(const gm_graph *sym, const gm_launch *la, uint32_t *d_support, int64_t n_entries, gm_stats *st) {
   if (!d_support) return GM_ERR_INVALID;
   gm_graph *g = const_cast<gm_graph *>(sym), *run_on = nullptr;

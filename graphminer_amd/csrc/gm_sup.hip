@@ -77,6 +77,7 @@ void sup_kernel(const MineParams p) {
   HsWave<STAGE> &L = B.w[wave];
   unsigned (*mw)[kSupMaskWords] = B.mw[wave];
   unsigned long long *__restrict__ smask = p.smask;
+  unsigned long long n_at = 0;  // wave-uniform: the increments this wave issued as global atomics from its queue (tooling: counters[2])
   for (;;) {
     if (tid == 0) B.queue_pos = atomicAdd(p.queue, (unsigned)p.grab);
     __syncthreads();
@@ -109,6 +110,7 @@ void sup_kernel(const MineParams p) {
         auto flush = [&]() {
           wave_sync();
           for (int i = lane; i < qn; i += GM_WAVE) atomicAdd(&sup[hq[i]], 1u);
+          n_at += (unsigned long long)qn;
           qn = 0;
           wave_sync();
         };
@@ -203,6 +205,7 @@ void sup_kernel(const MineParams p) {
         auto flush = [&]() {
           wave_sync();
           for (int i = lane; i < qn; i += GM_WAVE) atomicAdd(&sup[hq[i]], 1u);
+          n_at += (unsigned long long)qn;
           qn = 0;
           wave_sync();
         };
@@ -292,6 +295,7 @@ void sup_kernel(const MineParams p) {
       __syncthreads();
     }
   }
+  if (lane == 0 && n_at) atomicAdd(&p.counters[2], n_at);
 }
 
 // The masks summed by COLUMN into the supports: entry j of row u += sum over the masked entries i < j of bit (j - i - 1) of the mask of

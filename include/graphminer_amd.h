@@ -197,6 +197,11 @@ int gm_sgl(const gm_graph *sym, const char *pattern, const gm_launch *launch, ui
  *   4. the usual all-reduce of the 64-bit count.
  * Rows of the oriented copy beyond the 2048-entry stage take sup_long_kernel (one wave per edge) inside the same call. */
 int gm_diamond_support_size(const gm_graph *sym, int world, int64_t *n_entries);
+/* Tooling (bench.py's byte model, tests): after a one-GPU gm_sgl(.., "diamond") on this handle -- info[0] = 64-bit words of the match-mask
+ * arena (the in-edge tasks of the triangle pass report their streamed edges as bit masks of their tails, gm_sup.hip; 0 = no masks on this
+ * graph), info[1] = streamed-edge increments the most recent launch issued as global atomics, info[2] = rows with masks of several words,
+ * info[3] = the shortest tail that gets a mask.  Synchronises the device. */
+int gm_diamond_support_info(const gm_graph *sym, int64_t info[4]);
 int gm_diamond_support_partial(const gm_graph *sym, const gm_launch *launch, uint32_t *d_support, int64_t n_entries, gm_stats *stats);
 int gm_diamond_support_finish(const gm_graph *sym, const gm_launch *launch, const uint32_t *d_support, int64_t count, uint64_t *total,
                               gm_stats *stats);

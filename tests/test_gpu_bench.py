@@ -1,5 +1,6 @@
 """bench.py contract (driver-facing): one JSON line with the required fields, roofline and cpu_baseline objects, the five
 BASELINE configs as sub-records, and the torch.distributed (RCCL) path exercised with one rank."""
+import ctypes as C
 import json
 import os
 import subprocess
@@ -261,13 +262,32 @@ def test_own_algorithm_bytes_equal_a_brute_force_count():
     nd = dci.size
     assert bench.own_bytes_device("tc", bg)["bytes"] == 4 * int(kt) + 12 * nd + 8 * (nv + 1)
     assert bench.own_bytes_device("motif3", bg) == bench.own_bytes_device("tc", bg)  # gm_motif, k = 3: the triangles of the DAG + a closed form
-    # diamond on one GPU: edge supports from the triangles of the DAG (gm_sup.hip)
-    tri = 0
+    # diamond on one GPU: edge supports from the triangles of the DAG (gm_sup.hip).  Round 5: an IN-EDGE task (the target hosts, the tail of
+    # N+(u) is streamed) with a tail of >= `lmin` keys reports its streamed edges as a bit mask of the tail -- ceil(tail / 64) 64-bit words,
+    # three spare ones behind a list of >= long_list keys -- every other task by one atomic per match
+    from graphminer_amd import _lib as L
+
+    lmin_info = (C.c_int64 * 4)()
+    own_d = bench.own_bytes_device("diamond", bg)
+    L.check(L.load().gm_diamond_support_info(bg.sym.handle, lmin_info), "gm_diamond_support_info")
+    lmin, long_list = int(lmin_info[3]), K["long_list"]
+    tri = atomics = words = 0
+    nbr = [set(rank[dci[drp[u]:drp[u + 1]]].tolist()) for u in range(nv)]
     for u in range(nv):
-        ru = set(dci[drp[u]:drp[u + 1]].tolist())
-        for v in dci[drp[u]:drp[u + 1]]:
-            tri += len(ru.intersection(dci[drp[v]:drp[v + 1]].tolist()))
-    assert bench.own_bytes_device("diamond", bg)["bytes"] == 4 * int(kt) + 12 * nd + 8 * (nv + 1) + 20 * nd + 4 * tri
+        row = dci[drp[u]:drp[u + 1]]
+        for i, v in enumerate(row[np.argsort(rank[row])]):
+            t = len(nbr[u] & nbr[v])
+            tri += t
+            tail = dp[u] - i - 1
+            masked = tail < dp[v] and tail >= lmin  # (v hosts: the shorter stream; no row beyond the stage here)
+            if masked:
+                words += (tail + 63) // 64 + (3 if tail >= long_list else 0)
+            else:
+                atomics += t
+    assert words > 0 and 0 < atomics < tri, "the graph must exercise masked and unmasked tasks"
+    assert (int(lmin_info[0]), int(lmin_info[1])) == (words, atomics)
+    assert own_d["bytes"] == 4 * int(kt) + 12 * nd + 8 * (nv + 1) + 20 * nd + 4 * atomics + 16 * words + 8 * nd
+    assert own_d["parts"]["triangles"] == tri
     own = dp[(dp >= bench.kernel_constants()["cb_min_deg"]) & (dp <= bench.kernel_constants()["cb_max_deg"])].astype(np.int64)
     arena = int((own * ((own + 31) // 32)).sum())
     assert bench.own_bytes_device("clique4", bg)["bytes"] == 4 * int(kc) + 16 * tasks + 4 * nd + 16 * (nv + 1) + 8 * arena + 4 * gathered
