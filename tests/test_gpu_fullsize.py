@@ -194,3 +194,37 @@ def test_readme_known_answers_on_real_datasets(name):
         else:
             continue
         assert got == want, (name, key, got, want)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("workload,scale,ef", [("clique4", 22, 28), ("motif3", 24, 16), ("tc", 22, 10), ("diamond", 22, 10)])
+def test_bench_size_configs_equal_the_recorded_reference_answers(workload, scale, ef):
+    """BASELINE configs 2 - 5 AT BENCH SIZE inside `pytest -m gpu`: the graph bench.py generates, the HIP path's count
+    against tests/golden/fullsize.json -- the answers of the REFERENCE's own binaries on that graph (tc_omp_base / sgl_omp_base in every
+    bench run, clique_omp_base 4 in 655 s and motif_omp_base 3 in 361 s on the box's 128 threads: profiles/r04/fullsize_*_ref.json)."""
+    import json
+
+    from common import ROOT
+    from graphminer_amd.rmat import rmat_csr_device
+
+    full = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize.json")))
+    want = full[f"{workload}:rmat_s{scale}_ef{ef}_seed42"]["count"]
+    sym, _rp, _ci = rmat_csr_device(scale, ef, 42, 0)
+    try:
+        if workload == "clique4":
+            dag = sym.orient()
+            assert CliqueSolver(dag, 4) == want
+            assert sum(CliqueSolver(dag, 4, rank=r, world=8) for r in range(8)) == want  # config 4's split: eight rank shares
+            dag.free()
+        elif workload == "motif3":
+            assert MotifSolver(sym, 3) == want                      # the formula solver gm_motif takes
+            assert MotifSolverE(sym, 3) == want                     # automine_3motif's loop nest (set difference + bounded intersection)
+        elif workload == "tc":
+            dag = sym.orient()
+            assert TCSolver(dag) == want
+            dag.free()
+        else:
+            assert SglSolver(sym, "diamond") == want                                       # match masks + column sums (round 5)
+            assert SglSolver(sym, "diamond", tune=[0, 0, 0, 0, 0, 0, 0x40000000]) == want  # one atomic per streamed edge
+    finally:
+        sym.free()
