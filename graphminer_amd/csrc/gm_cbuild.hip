@@ -2,7 +2,7 @@
 // out-list, the other list is streamed against it, and the finished row of u's adjacency bit-matrix is stored into the matrix arena
 // (see "k-clique, level 1 re-hosted" in gm_mine.h).  The reference's kernel re-intersects N+(v0) ^ N+(v1) per edge with the shorter
 // list searched in the longer (src/clique/gpu_kernels/clique4_warp_edge.cuh:19-27) and never keeps the result; round 2 of this
-// library streamed N+(v) of every edge whichever was longer (12.6 vs 5.0 G keys on the LiveJournal stand-in, gm_tct.hip).
+// library streamed N+(v) of every edge whichever was longer (12.6 vs 5.0 G keys on the LiveJournal stand-in, gm_tch.hip).
 //
 // Kernel = the shorter-list-streams triangle kernel with positions: a chunk is a run of consecutive vertices whose DAG rows fit the LDS
 // stage; its tasks are the task-list entries of those vertices, 64 per batch.  A match is either bit `position in the host's row`

@@ -111,7 +111,7 @@ hipError_t launch_cgather(const CGatherParams &p, int grid_blocks, hipStream_t s
 // every wave a CU has: 4 / 2 workgroups per CU 27.7 / 35.6 ms for the whole pattern.
 int cgather_per_cu() {
   static const int v = [] {
-    const char *e = getenv("GM_CG_PER_CU");
+    const char *e = gm_sweep_env("GM_CG_PER_CU");
     const int cap = (int)std::min<size_t>(163840 / sizeof(CGatherLds), 2048 / (kCgWaves * GM_WAVE));
     return e ? std::max(1, std::min(atoi(e), cap)) : cap;
   }();

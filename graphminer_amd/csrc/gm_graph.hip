@@ -131,11 +131,9 @@ int finish_handle(gm_graph *g) {
     gm_touch_mine();
     gm_touch_mine_wide();
     gm_touch_hrow();
-    gm_touch_tct();
     gm_touch_tch();
     gm_touch_sup();
     gm_touch_cbuild();
-    gm_touch_wide();
     gm_touch_cmma();
     gm_touch_cgather();
     gm_touch_sgl();

@@ -127,7 +127,7 @@ struct RowFilter {
   int skip_clique_wide = 0;                    // > 0: leave out the vertices with clique_is_wide(d, this many matrix words)
   int skip_lo = 0, skip_hi = 0;                // rows with skip_lo < d <= skip_hi are left out (0, 0 = none)
   int only_lo = -1, only_hi = 0x7fffffff;      // rows with only_lo < d <= only_hi are kept
-  int tct = 0;                                 // 1: chunk costs from the task lists of gm_tct.hip (the tasks a chunk hosts, not its own entries)
+  int tct = 0;                                 // 1: chunk costs from the task lists of gm_tch.hip (the tasks a chunk hosts, not its own entries)
   __host__ __device__ bool skips(int d) const {
     return (skip_clique_wide > 0 && clique_is_wide(d, skip_clique_wide)) || (d > skip_lo && d <= skip_hi) || !(d > only_lo && d <= only_hi);
   }
@@ -179,7 +179,6 @@ int table_host_views(gm_graph *g, ChunkTable *t);  // gm_tables.hip
 struct CliqueRound {
   long long n_pos0 = 0, n_count = 0;       // narrow chunks: positions [n_pos0, n_pos0 + n_count) of the rank's share of the narrow table
   size_t w0 = 0, w1 = 0;                    // wide slots [w0, w1) of the plan's vertex list
-  size_t cls_begin[4] = {0, 0, 0, 0};       // the round's slots per count class S / L / X, in d_cls_slots
   size_t mcls_begin[4] = {0, 0, 0, 0};      // ... per class of the matrix-core count kernel (gm_cmma.hip), in d_mcls_slots
   unsigned long long words = 0;             // arena words of the round
   unsigned long long *d_base = nullptr;     // per vertex: word offset of its matrix (nv + 1; non-owners are empty)
@@ -198,7 +197,6 @@ struct CliquePlan {
   std::vector<int> verts;            // this rank's wide vertices; slot = index here (longest rows first)
   int *d_verts = nullptr;
   unsigned long long *d_slot_base = nullptr;  // slot -> word offset of its matrix inside its round's arena
-  int *d_cls_slots = nullptr;
   int *d_mcls_slots = nullptr;
   int core_base = -1;                // >= 0: the rows of the wide vertices' matrices whose first endpoint is >= core_base are gathered from the
                                      // core bitmap of the graph (gm_cgather.hip); the task lists of the streamed build leave them out
@@ -438,11 +436,9 @@ struct OtherSetupScope {
 void gm_touch_mine();
 void gm_touch_mine_wide();
 void gm_touch_hrow();
-void gm_touch_tct();
 void gm_touch_tch();
 void gm_touch_sup();
 void gm_touch_cbuild();
-void gm_touch_wide();
 void gm_touch_cmma();
 void gm_touch_cgather();
 void gm_touch_sgl();

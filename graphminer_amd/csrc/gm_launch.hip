@@ -177,7 +177,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
   // LiveJournal stand-in ended 50 % above its mean, TC 1.01 ms per rank against 0.66 ideal; one rank keeps the round-2 rule)
   int target = kDefaultChunk;
   long long min_chunks = (world > 1 ? 4LL : 2LL) * g->cu_count * 7;
-  if (const char *e = getenv("GM_MIN_CHUNKS_PER_CU")) min_chunks = (long long)std::max(1, atoi(e)) * g->cu_count;  // (sweeps)
+  if (const char *e = gm_sweep_env("GM_MIN_CHUNKS_PER_CU")) min_chunks = (long long)std::max(1, atoi(e)) * g->cu_count;  // (sweeps)
   while (target > 128 && g->ne / ((long long)world * target) < min_chunks) target >>= 1;
   if (la->chunk > 0) target = la->chunk;
   if (la->tune[0] > 0) target = la->tune[0];
@@ -187,17 +187,17 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
   // tune[6] & 0x1000 (tests): cut every chunk above 4096 estimated entries into parts
   // chunk costs are estimated keys (DAG patterns: d(u) + d(v) per edge; symmetric patterns: streamed keys, bitmap probes
   // weighted kProbeCost); parts bound the longest task of a launch
-  // TC: the shorter list of every edge is streamed against the longer one (gm_tct.hip) when every DAG row fits the LDS stage
+  // TC: the shorter list of every edge is streamed against the longer one (gm_tch.hip) when every DAG row fits the LDS stage
   // (tune[6] & 0x4000000: A/B switch, the chunked kernel that streams N+(v) of every out-edge).  Its chunks host the tasks of
   // their vertices -- a hub hosts 10^5 in-edges -- so their cost is counted from the task lists and heavy chunks are cut into
   // parts of 1 M keys / world (>= 128 K): one-GPU simulation of an 8-rank share of R-MAT-22, parts of 8 M / 512 K / 128 K / 32 K keys:
   // 5.36 / 1.18 / 0.99 / 1.15 ms per rank (one GPU: 6.50 / 6.54 / 6.73 / 8.09 ms), profiles/r02/ab_tct_part_cap.log
-  const bool use_tct = pat == PAT_TC && !(la->tune[6] & 0x4000000) && la->tune[5] != 1 && g->ne > 0 && !getenv("GM_HOST_TABLES");
+  const bool use_tct = pat == PAT_TC && !(la->tune[6] & 0x4000000) && la->tune[5] != 1 && g->ne > 0 && !gm_sweep_env("GM_HOST_TABLES");
   // The 2048-entry stage costs occupancy (four instead of six workgroups per CU, R-MAT-22 on it: 3.04 vs 2.57 ms), and only the few hosts with
   // rows of 1025 .. 2048 entries need it: a graph that has such rows runs TWO tables -- hosts with rows <= 1024 on the 1024-entry kernel,
   // the others on the 2048-entry one (own dequeue word).  GM_TCT_STAGE_BIG: the 2048-entry stage for every host (A/B).
-  const bool stage_big_all = getenv("GM_TCT_STAGE_BIG") != nullptr;
-  bool split_stage = use_tct && g->max_deg > kStageCap && !stage_big_all && !getenv("GM_TCT_NO_SPLIT_STAGE");
+  const bool stage_big_all = gm_sweep_env("GM_TCT_STAGE_BIG") != nullptr;
+  bool split_stage = use_tct && g->max_deg > kStageCap && !stage_big_all && !gm_sweep_env("GM_TCT_NO_SPLIT_STAGE");
   int tct_stage = ((g->max_deg <= kStageCap && !stage_big_all) || split_stage) ? kStageCap : kTctStageMax;
   // (rows beyond the 2048-entry stage host nothing: their out-edges are the tasks of the chunked kernel, on a table of those rows only)
   const bool tct_long = use_tct && g->max_deg > kTctStageMax;
@@ -226,8 +226,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
     if (rc_l) return rc_l;
   }
   // the triangle count reads the key stream + the lists of the longer tasks (ensure_keystream); the edge supports, the kernels without the
-  // stream (tune[6] & 0x8000000 / 0x20000000, GM_TC_SORTED) and the handles that cannot have one read the full task lists
-  const bool use_tch_k = !(la->tune[6] & 0x8000000) && !getenv("GM_TC_SORTED");  // (the key stream is read by tch_kernel only)
+  // stream (tune[6] & 0x20000000) and the handles that cannot have one read the full task lists
   bool use_kst = false;
   if (use_tct) {
     // The edge supports take the stream only where matches are RARE: a match of a streamed key costs them two gathers (the entries beside
@@ -239,7 +238,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
       if (const char *e = getenv("GM_SUP_STREAM")) sup_stream = atoi(e) != 0;
       else sup_stream = ensure_mean_sq_deg(g) == GM_OK && g->mean_sq_deg < (double)kTopoMinMeanRow;
     }
-    if ((sup_stream || (!support && use_tch_k)) && !(la->tune[6] & 0x20000000)) {
+    if ((sup_stream || !support) && !(la->tune[6] & 0x20000000)) {
       const int rc_k = ensure_keystream(g, support, &use_kst);
       if (rc_k) return rc_k;
     }
@@ -288,7 +287,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
   // ms, lower bound 3072 / 2048 / 1024 / 512 / 256) diamond R-MAT-24 262 / 240 / 239 / 238 / 237, R-MAT-22 21.1 / 21.0 / 17.5 / 17.6 / 17.5,
   // 3-motif R-MAT-24 185 / 172 / 172 / 171 / 171.
   int cls_lo = kClassRowMin;
-  if (const char *e = getenv("GM_CLS_LO")) cls_lo = std::max(64, atoi(e));  // (sweeps)
+  if (const char *e = gm_sweep_env("GM_CLS_LO")) cls_lo = std::max(64, atoi(e));  // (sweeps)
   // giant rows (> kStageCapBig entries): hashed sets of row pieces (giant_kernel, gm_hrow.hip) instead of SPLIT chunks probing
   // dense bitmaps in HBM (tune[6] & 0x1000000: A/B switch, they stay SPLIT chunks of the general kernel)
   const bool use_range = use_classes && !(la->tune[6] & 0x1000000) && hrow_fits(g->nv, 2);  // (its pieces are class-2 sets: nv <= 2^27)
@@ -318,8 +317,8 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
     // on one GPU the same parts cost 171 / 173 / 181 and 17.5 / 18.3 / 18.4 ms: profiles/r02/ab_class_part_cap.log)
     unsigned long long cls_cap = (la->tune[6] & 0x1000) ? 4096ull
                                  : std::max<unsigned long long>(part_cap, std::max<unsigned long long>((32ull << 20) / (unsigned long long)std::max(world, 1), 2ull << 20));
-    if (const char *e = getenv("GM_CLS_CAP_MKEYS")) cls_cap = (unsigned long long)std::max(1, atoi(e)) << 20;  // (sweeps)
-    if (const char *e = getenv("GM_CLS_CAP_KKEYS")) cls_cap = (unsigned long long)std::max(16, atoi(e)) << 10;
+    if (const char *e = gm_sweep_env("GM_CLS_CAP_MKEYS")) cls_cap = (unsigned long long)std::max(1, atoi(e)) << 20;  // (sweeps)
+    if (const char *e = gm_sweep_env("GM_CLS_CAP_KKEYS")) cls_cap = (unsigned long long)std::max(16, atoi(e)) << 10;
     // (target 1: every row is a chunk of its own -- the class kernels take one-row chunks -- also below the general kernel's chunk target)
     rc = get_table(g, 1, false, 0, cls_cap, kStageCapMid, &tab_cls[1], r1, 0x7fffffff);
     if (rc) return rc;
@@ -340,7 +339,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
         const unsigned long long per = ge / ((unsigned long long)g->cu_count * (unsigned long long)giant_per_cu() * 4ull * (unsigned long long)world);
         gtarget = (int)std::max<unsigned long long>(512, std::min<unsigned long long>((unsigned long long)kGiantEdges, per));
         gtarget = (gtarget + 63) & ~63;
-        if (const char *e = getenv("GM_GIANT_TARGET")) gtarget = std::max(64, std::min(atoi(e), kGiantEdges));  // (sweeps)
+        if (const char *e = gm_sweep_env("GM_GIANT_TARGET")) gtarget = std::max(64, std::min(atoi(e), kGiantEdges));  // (sweeps)
       }
       rc = get_table(g, gtarget, true, 0, 0ull, kStageCapBig, &tab_cls[3], r3, 0x7fffffff);
       if (rc) return rc;
@@ -505,7 +504,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
   p.chunk_ticks = d_ticks;
 #endif
   // (a side stream is a hardware queue: ~17 ms each to create -- GM_SETUP_TRACE, the first 4-clique call spent 35 ms here for a variant that is off)
-  if (use_wide && plan && plan->core_base >= 0 && getenv("GM_CLIQUE_SIDE_STREAM")) {  // (4-clique A/B: the gathered build beside the streamed one, below)
+  if (use_wide && plan && plan->core_base >= 0 && gm_sweep_env("GM_CLIQUE_SIDE_STREAM")) {  // (4-clique A/B: the gathered build beside the streamed one, below)
     for (int i = 0; i < 2; ++i) {
       if (!g->aux_stream[i]) {
         HIP_TRY(hipStreamCreateWithFlags(&g->aux_stream[i], hipStreamNonBlocking));
@@ -552,12 +551,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
     }
     HIP_TRY(hipMemsetAsync(g->d_wide_queue, 0, 65536, stream));
     setup_trace("launch: clique prologue");
-    const bool prof = getenv("GM_WIDE_PROFILE") != nullptr;
-    unsigned long long *d_prof = nullptr;
-    if (prof) {
-      HIP_TRY(hipMalloc(&d_prof, 4 * 32));
-      HIP_TRY(hipMemset(d_prof, 0, 4 * 32));
-    }
+    const bool prof = gm_sweep_env("GM_WIDE_PROFILE") != nullptr;
     int qword = 0;
     for (const auto &rd : plan->rounds) {
       if (qword + 9 > 16384) return GM_ERR_TOO_LARGE;  // (more than ~3000 arena rounds)
@@ -581,7 +575,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
         // (GM_CLIQUE_SIDE_STREAM=1: on a side stream beside the streamed build and the counts of the narrow vertices -- they touch other rows
         // of the arena.  Measured and not taken: the gathers want all 32 waves of a CU -- 4 / 3 / 2 / 1 workgroups per CU beside the streamed
         // build: 29.2 / 29.5 / 33.8 / 53.4 ms against 27.7 one after the other, profiles/r04/ab_clique4_side_stream.txt)
-        const bool side = getenv("GM_CLIQUE_SIDE_STREAM") != nullptr;
+        const bool side = gm_sweep_env("GM_CLIQUE_SIDE_STREAM") != nullptr;
         hipStream_t gs = side ? g->aux_stream[0] : stream;
         if (side) {
           HIP_TRY(hipEventRecord(g->aux_done[1], stream));  // after the queue words were zeroed / the previous round's counts read the arena
@@ -633,9 +627,8 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
         plan_chunks += (uint64_t)rd.n_count;
       }
       if (gather_joined) HIP_TRY(hipStreamWaitEvent(stream, g->aux_done[0], 0));  // the wide vertices' rows are complete
-      // pair counts of the wide vertices: on the matrix cores (gm_cmma.hip), or -- tune[6] & 0x20000 -- the vector-ALU classes of round 3
-      const bool valu_counts = (la->tune[6] & 0x20000) != 0;
-      for (int cls = 2; cls >= 0 && !valu_counts; --cls) {  // the column blocks and the one-per-CU workgroups before the small ones
+      // pair counts of the wide vertices on the matrix cores (gm_cmma.hip)
+      for (int cls = 2; cls >= 0; --cls) {  // the column blocks and the one-per-CU workgroups before the small ones
         CliqueCountParams c;
         memset(&c, 0, sizeof c);
         c.rp = g->d_rp;
@@ -653,35 +646,9 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
         HIP_TRY(launch_clique_mma(cls, c, cgrid, stream));
         setup_trace("launch: matrix-core counts");
       }
-      for (int cls = 2; cls >= 0 && valu_counts; --cls) {  // X and L (one workgroup per CU) before S
-        CliqueCountParams c;
-        memset(&c, 0, sizeof c);
-        c.rp = g->d_rp;
-        c.verts = plan->d_verts;
-        c.base = plan->d_slot_base;
-        c.mat = g->d_wide_mat;
-        c.slots = plan->d_cls_slots + rd.cls_begin[cls];
-        c.count = (int)(rd.cls_begin[cls + 1] - rd.cls_begin[cls]);
-        c.queue = g->d_wide_queue + qword++;
-        c.counters = g->d_counters;
-        c.profile = prof ? d_prof + 4 * cls : nullptr;
-        c.topo = plan->topo ? 1 : 0;
-        if (c.count == 0) continue;
-        const int per_cu_c = (int)std::max<size_t>(1, std::min<size_t>((160 * 1024) / clique_count_lds_bytes(cls), (size_t)(2048 / clique_count_threads(cls))));
-        // (class X: a queue entry is one column block of a vertex, eight entries per vertex: gm_wide.hip)
-        const int cgrid = (int)std::max<long long>(1, std::min<long long>((long long)c.count * (cls == 2 ? 8 : 1), (long long)g->cu_count * per_cu_c));
-        HIP_TRY(launch_clique_count(cls, c, cgrid, stream));
-      }
     }
     if (prof) {
-      unsigned long long h[12];
       HIP_TRY(hipStreamSynchronize(stream));
-      HIP_TRY(hipMemcpy(h, d_prof, sizeof h, hipMemcpyDeviceToHost));
-      (void)hipFree(d_prof);
-      for (int cls = 0; cls < 3; ++cls)
-        if (h[4 * cls + 3])
-          fprintf(stderr, "[wide] count class %c: %llu workgroups; per workgroup ms: load %.2f count %.2f\n", "SLX"[cls], h[4 * cls + 3],
-                  h[4 * cls] / (double)h[4 * cls + 3] / 1e5, h[4 * cls + 1] / (double)h[4 * cls + 3] / 1e5);
       size_t nt = 0, nh = 0;
       for (const auto &rd : plan->rounds) { nt += rd.n_tasks; nh += rd.host_tab.n; }
       fprintf(stderr, "[clique plan] %zu wide vertices, %lld narrow chunks, %zu tasks in %zu host chunks, %zu round(s), arena %.1f MB, stage %d, %s numbering\n",
@@ -695,7 +662,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
     // that the kernels launched after it fill the idle CUs; one that can fill it stays on the launch's stream -- there every
     // kernel has the chip to itself (side streams at R-MAT-24 size: diamond 667 vs 636 ms, the 148 KB workgroups of class 2 wait
     // for whole CUs to drain). GM_CLASSES_STREAMS=0 / 1 forces one or the other.
-    const char *streams_env = getenv("GM_CLASSES_STREAMS");
+    const char *streams_env = gm_sweep_env("GM_CLASSES_STREAMS");
     auto side_stream = [&](int cls, long long count, long long full_grid, hipStream_t *ws) -> int {
       *ws = stream;
       const bool side = streams_env ? atoi(streams_env) != 0 : count < full_grid;
@@ -762,8 +729,6 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
       HIP_TRY(launch_mine(pat, q, (int)std::max<long long>(1, std::min<long long>(wq, (long long)g->cu_count * per_cu)), stream));
     }
   }
-  // (tune[6] & 0x8000000: A/B switch, the sorted LDS copy + bit filter + bisection of gm_tct.hip instead of the hashed set of gm_tch.hip)
-  const bool use_tch = use_tct && !(la->tune[6] & 0x8000000) && !getenv("GM_TC_SORTED");
   if (support) {  // zero the supports, three increments per triangle, then sum C(t, 2): all inside the timed region
     unsigned *sup = sup_part ? sup_out : g->d_sup;
     HIP_TRY(hipMemsetAsync(sup, 0, sizeof(unsigned) * (size_t)(sup_part ? diamond_support_entries(g->ne, world) : g->ne), stream));
@@ -788,7 +753,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
       sl.nrows = g->n_long_rows;
       sl.total = g->long_edges;
       sl.sup = sup;
-      sl.topo = (g->topo_state == 1 && !getenv("GM_TC_NO_TRIM")) ? 1 : 0;
+      sl.topo = (g->topo_state == 1 && !gm_sweep_env("GM_TC_NO_TRIM")) ? 1 : 0;
       sl.rank = rank;
       sl.world = world;
       HIP_TRY(launch_sup_long(sl, g->cu_count, stream));
@@ -817,11 +782,9 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
       q.grab = 1;
       q.queue = reinterpret_cast<unsigned *>(g->d_counters + 4) + 2;
       chunks_total += (uint64_t)q.count;
-      if (q.count > 0 && use_tch) HIP_TRY(launch_tch(q, kTctStageMax, (int)std::max<long long>(1, std::min<long long>(q.count, (long long)g->cu_count * tch_per_cu(kTctStageMax))), stream));
-      else if (q.count > 0) HIP_TRY(launch_tct(q, kTctStageMax, (int)std::max<long long>(1, std::min<long long>(q.count, (long long)g->cu_count * tct_per_cu(kTctStageMax))), stream));
+      if (q.count > 0) HIP_TRY(launch_tch(q, kTctStageMax, (int)std::max<long long>(1, std::min<long long>(q.count, (long long)g->cu_count * tch_per_cu(kTctStageMax))), stream));
     }
-    if (p.count > 0 && use_tch) HIP_TRY(launch_tch(p, tct_stage, (int)std::max<long long>(1, std::min<long long>(want, (long long)g->cu_count * tch_per_cu(tct_stage))), stream));
-    else if (p.count > 0) HIP_TRY(launch_tct(p, tct_stage, (int)std::max<long long>(1, std::min<long long>(want, (long long)g->cu_count * tct_per_cu(tct_stage))), stream));
+    if (p.count > 0) HIP_TRY(launch_tch(p, tct_stage, (int)std::max<long long>(1, std::min<long long>(want, (long long)g->cu_count * tch_per_cu(tct_stage))), stream));
   } else if (p.count > 0) HIP_TRY(launch_mine(pat, p, grid, stream));
 #ifdef GM_DEBUG_CHUNKS
   {
@@ -837,7 +800,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
     std::sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return ticks[a] > ticks[b]; });
     unsigned long long tot = 0;
     for (auto t : ticks) tot += t;
-    if (const char *dump = getenv("GM_CHUNK_DUMP")) {
+    if (const char *dump = gm_sweep_env("GM_CHUNK_DUMP")) {
       static int dump_no = 0;
       const std::string name = std::string(dump) + "." + std::to_string(dump_no++) + ".pat" + std::to_string((int)pat);
       FILE *f = fopen(name.c_str(), "w");
@@ -940,7 +903,7 @@ int ensure_mean_sq_deg(gm_graph *self) {
 // rank (ideal 5.25), R-MAT-22 0.63 / 0.56 / 0.55 / 0.55 / 0.78; one GPU, 256 K / 512 K / 1 M / 2 M / 4 M: R-MAT-22 3.14 / 3.09 / 3.07 / 3.06 / 3.04 ms,
 // R-MAT-24 47.2 / 43.7 / 41.9 / 41.2 / 40.9 (profiles/r03/ab_share_scaling.txt).
 unsigned long long task_part_cap(gm_graph *g, int world) {
-  if (const char *e = getenv("GM_TCT_PART_KKEYS")) return (unsigned long long)std::max(4, atoi(e)) << 10;  // (sweeps)
+  if (const char *e = gm_sweep_env("GM_TCT_PART_KKEYS")) return (unsigned long long)std::max(4, atoi(e)) << 10;  // (sweeps)
   double keys = 0.0;
   if (ensure_mean_sq_deg(g) == GM_OK) keys = (double)g->ne * g->mean_sq_deg * 0.5;
   const double cap = keys / (3000.0 * (double)std::max(world, 1));
@@ -960,7 +923,7 @@ static int topo_view(const gm_graph *dag, const gm_launch *la, gm_graph **run_on
   if (rc) return rc;
   double min_row = (double)kTopoMinMeanRow;
   if (const char *e = getenv("GM_TOPO_MIN_ROW")) min_row = atof(e);
-  if (getenv("GM_TABLE_INFO")) fprintf(stderr, "[topo view] sum d+^2 / |E+| = %.1f (switch at %.1f)\n", self->mean_sq_deg, min_row);
+  if (gm_sweep_env("GM_TABLE_INFO")) fprintf(stderr, "[topo view] sum d+^2 / |E+| = %.1f (switch at %.1f)\n", self->mean_sq_deg, min_row);
   if (self->mean_sq_deg < min_row) return GM_OK;  // short lists: as numbered
   return get_relabeled(self, 2, run_on);
 }
@@ -1646,7 +1609,7 @@ extern "C" int gm_motif(const gm_graph *sym, int k, const gm_launch *la, uint64_
   // two symmetric lists per edge (gm_hrow.hip, gm_chunk.h).
   const int t6 = la ? la->tune[6] : 0;
   const bool per_edge = ((t6 & (0x10000000 | 0x80000 | 0x100000 | 0x400000 | 0x1000000 | 0x2000000)) || (la && la->tune[5] == 1) ||
-                         getenv("GM_MOTIF3_PER_EDGE")) && !(sym && sym->d_rp64);
+                         gm_sweep_env("GM_MOTIF3_PER_EDGE")) && !(sym && sym->d_rp64);
   if (!per_edge) {
     const int rc = gm_motif_formula(sym, k, la, counts, ncounts, st);
     if (rc == GM_OK && st) st->tasks *= 2;  // (the graph's directed entries, as the enumeration reports them: two per task edge of the DAG)
@@ -1657,7 +1620,7 @@ extern "C" int gm_motif(const gm_graph *sym, int k, const gm_launch *la, uint64_
   // "below hi" = "of higher degree than hi": the trimmed list is what an oriented row would be -- sum_v d+(v)^2 streamed keys instead of
   // sum_e min(d(u), d(v)) over the symmetric lists (R-MAT-24: 150 G).  GM_MOTIF3E_AS_NUMBERED / tune[6] & 512: on the graph as given.
   const gm_graph *run_on = sym;
-  if (!(t6 & 512) && !getenv("GM_MOTIF3E_AS_NUMBERED")) {
+  if (!(t6 & 512) && !gm_sweep_env("GM_MOTIF3E_AS_NUMBERED")) {
     gm_graph *r = nullptr;
     const int rc = get_relabeled(const_cast<gm_graph *>(sym), 1, &r);
     if (rc == GM_ERR_HIP && g_last_hip_error == (int)hipErrorOutOfMemory) {  // (the copy is an optimisation -- about the size of the graph again: without it the graph runs as numbered)

@@ -3,6 +3,22 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+
+// ENVIRONMENT SWITCHES.  Read in every build: the documented fallbacks and the hooks tests need to reach a path on a small graph --
+//   GM_SETUP_TRACE (setup steps on stderr), GM_DIAMOND_PER_EDGE, GM_SUP_STREAM / GM_SUP_NO_MASKS / GM_SUP_MASK_MIN (edge supports),
+//   GM_BIG_NE, GM_KST_MAX_KEYS, GM_TOPO_MIN_ROW, GM_WIDE_ARENA_MB, GM_TCT_SPLIT_ALWAYS (limits lowered for tests), GM_ORIENT_TWO_GATHERS,
+//   GM_RELABEL_GLOBAL_SORT (the previous setup paths, compared in tests), GM_NO_TEMP_POOL.
+// SWEEP switches (tile counts, workgroups per CU, thresholds, rejected variants: the A/B runs recorded under profiles/) exist only in
+// -DGM_DEVEL builds (make DEVEL=1): gm_sweep_env() is a constant nullptr otherwise and the branches behind it fold away.
+inline const char *gm_sweep_env(const char *name) {
+#ifdef GM_DEVEL
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
 
 namespace gm {
 
@@ -72,7 +88,7 @@ struct GraphView {
   // was half of the lines a task edge touches. Takes the place of the reference's COO src/dst lists (8 B per task,
   // include/graph_gpu.h:29-30); nullptr = gather from rp.
   const int2 *edesc = nullptr;
-  // Task lists of the shorter-list-streams triangle count (gm_tct.hip): per vertex the descriptors {rp[partner], d+(partner)}
+  // Task lists of the shorter-list-streams triangle count (gm_tch.hip): per vertex the descriptors {rp[partner], d+(partner)}
   // of the lists it hosts, trp = their row offsets (nv+1); nullptr = not built.
   const int *trp = nullptr;
   const int2 *tdesc = nullptr;
@@ -273,8 +289,8 @@ hipError_t launch_house_blocks(const GraphView &g, unsigned *nblk, hipStream_t s
 
 // ---- k-clique, wide vertices -----------------------------------------------------------------------------------------------------
 // A DAG vertex u whose d x d adjacency bit-matrix over N+(u) exceeds the 8 KB LDS budget of a narrow chunk (d+ > 256) is WIDE: its
-// matrix is counted by ONE big-LDS workgroup (gm_wide.hip, clique_count_kernel) that copies it from the matrix arena into LDS (up to
-// 128 KB) and counts sum_i sum_{j in M_i} popc(M_i & M_j) there. (Round 1 kept one arena slot per workgroup, so a wide vertex was built
+// matrix is counted by ONE big-LDS workgroup (gm_cmma.hip, clique_mma_kernel) that copies it from the matrix arena into LDS (up to
+// 144 KB) and counts sum_{i,j} M_ij (M M^T)_ij there on the matrix cores (rounds 2 - 3: popcounts on the vector ALU, deleted in round 5). (Round 1 kept one arena slot per workgroup, so a wide vertex was built
 // AND counted by a single workgroup: 88 % of the kernel time, 382 GB of arena re-reads per launch; round 2 built the rows with a lean
 // kernel that streamed N+(v) of every edge; since round 3 every row is built where the LONGER list is staged: gm_cbuild.hip, below.)
 constexpr int kWideMaxDeg = 2048;   // wider DAG rows stay on the mining kernel's per-workgroup arena path
@@ -282,27 +298,6 @@ constexpr int kWideMaxDeg = 2048;   // wider DAG rows stay on the mining kernel'
 __host__ __device__ inline bool clique_is_wide(int d, int min_words = kBitWords) {
   return (long long)d * ((d + 31) / 32) > min_words && d <= kWideMaxDeg;
 }
-// padded row stride of the LDS copy: a multiple of 4 words whose quarter is odd, so that the 16-byte row reads of 16 lanes
-// (16 consecutive rows, same word offset) fall into 16 different bank groups
-__host__ __device__ inline int clique_padded_stride(int w) {
-  int p = (w + 3) & ~3;
-  if (((p >> 2) & 1) == 0) p += 4;
-  return p;
-}
-// ... but the padding is dropped when only the unpadded copy fits the budget: a whole matrix with some bank conflicts beats
-// column blocks (class X) -- rows of 897..1000 entries (stride 29..32 -> 32 words instead of 36)
-__host__ __device__ inline int clique_copy_stride(int d, int w, int budget_words) {
-  const int p = clique_padded_stride(w), q = (w + 3) & ~3;
-  return ((long long)d * p <= budget_words || (long long)d * q > budget_words) ? p : q;
-}
-// count classes (LDS budget of the copy, in words): S = 4 waves / 32 KB (3 workgroups per CU), L = 16 waves / 112 KB (one per CU),
-// X = rows wider than L's budget: counted in COLUMN BLOCKS of the matrix
-#ifndef GM_COUNT_WAVES_L
-#define GM_COUNT_WAVES_L 16
-#endif
-constexpr int kCountWavesS = 4, kCountWordsS = 8192;
-constexpr int kCountWavesL = GM_COUNT_WAVES_L, kCountWordsL = 32000;  // 125 KB + 16 x 2 KB of position lists: 157 KB
-constexpr int kCountWavesX = GM_COUNT_WAVES_L;
 struct CliqueCountParams {
   const int *rp;
   const int *verts;                 // slot -> vertex (this rank's wide vertices of the round)
@@ -312,18 +307,8 @@ struct CliqueCountParams {
   int count;
   unsigned *queue;                  // dequeue head (zeroed before launch; its own word)
   unsigned long long *counters;     // [0] += 4-cliques
-  unsigned long long *profile;      // GM_WIDE_PROFILE: [0] load ticks, [1] count ticks, [3] workgroups (100 MHz, thread 0)
   int topo;                         // the DAG is numbered topologically: the matrices are strictly upper triangular
 };
-hipError_t launch_clique_count(int cls, const CliqueCountParams &p, int grid_blocks, hipStream_t stream);
-size_t clique_count_lds_bytes(int cls);
-int clique_count_threads(int cls);
-// class of a wide vertex: 0 = S, 1 = L (whole padded matrix in LDS), 2 = X (column blocks, runs on the L instantiation)
-__host__ __device__ inline int clique_count_class(int d) {
-  const int w = (d + 31) / 32;
-  if ((long long)d * clique_copy_stride(d, w, kCountWordsS) <= kCountWordsS) return 0;
-  return (long long)d * clique_copy_stride(d, w, kCountWordsL) <= kCountWordsL ? 1 : 2;
-}
 
 // ---- level 1 of the wide vertices GATHERED from the dense bitmap of the hub core (gm_cgather.hip) ------------------------------------
 struct CGatherParams {
@@ -371,7 +356,7 @@ int clique_mma_threads(int cls);
 
 // ---- k-clique (k = 4), level 1 RE-HOSTED (gm_cbuild.hip) -------------------------------------------------------------------------
 // Row i of u's adjacency bit-matrix over N+(u) is N+(u) ^ N+(v), v = N+(u)[i] -- the triangle list of the DAG edge u -> v with
-// positions. Like the triangle count of gm_tct.hip it is symmetric in which list is staged: the edge is a TASK of the endpoint with
+// positions. Like the triangle count of gm_tch.hip it is symmetric in which list is staged: the edge is a TASK of the endpoint with
 // the LONGER out-list, whose row sits in LDS, and the other list is streamed (sum min(d+(u), d+(v)) keys instead of sum d+(v)):
 //   type A  host = u: N+(v) streamed, a match at position p of the staged N+(u) is bit p of the row;
 //   type B  host = v: N+(u) streamed, a match at stream index k is bit bit_off + k of the row -- under a topological numbering of
@@ -434,10 +419,9 @@ constexpr int kTopoMinMeanRow = 64;     // DAG patterns run on the topologically
 
 // host-side launchers (gm_mine.hip)
 hipError_t launch_mine(Pattern pat, const MineParams &p, int grid_blocks, hipStream_t stream);
-constexpr int kTctStageMax = 2048;  // gm_tct.hip: the longest DAG row its stage takes
-hipError_t launch_tct(const MineParams &p, int stage, int grid_blocks, hipStream_t stream);
-int tct_per_cu(int stage);
-// ... the same tasks against the chunk rows as one hashed (row, id) set in LDS: gm_tch.hip (the default; tune[6] & 0x8000000: tct_kernel)
+constexpr int kTctStageMax = 2048;  // gm_tch.hip: the longest DAG row its stage takes
+// the tasks of a chunk against its rows as one hashed (row, id) set in LDS: gm_tch.hip (rounds 2 - 3: a sorted LDS copy behind a bit filter,
+// tct_kernel -- deleted in round 5)
 hipError_t launch_tch(const MineParams &p, int stage, int grid_blocks, hipStream_t stream);
 int tch_per_cu(int stage);
 // edge supports t(e) = triangles through e, into p.scratch (one 32-bit counter per DAG entry, zeroed by the caller): the task lists'

@@ -1,5 +1,5 @@
 // gm_tables.hip -- task tables, built on the device: chunk tables (replaces Graph::init_edgelist, src/common/graph.cc:297-326, and the
-// per-GPU COO copies of Scheduler::round_robin, src/common/scheduler.cc:34-85), edge descriptors, the task lists of gm_tct.hip, the
+// per-GPU COO copies of Scheduler::round_robin, src/common/scheduler.cc:34-85), edge descriptors, the task lists of gm_tch.hip, the
 // two-phase plan of the wide k-clique vertices, and the multi-GPU split as index arithmetic (gm_partition).
 #include "gm_host.h"
 #include "gm_scan.h"
@@ -112,8 +112,8 @@ __global__ __launch_bounds__(256) void chunk_cost_kernel(const int *__restrict__
                                                          const int *__restrict__ tlen = nullptr, int tstride = 2, const int *__restrict__ kst_rp = nullptr) {
   const ChunkRec r = chunks[blockIdx.x];
   unsigned long long c = 0;
-  if (owner_rule == 2) {  // gm_tct.hip: the keys of the lists this chunk's vertices host
-    // (tlen: the length field of the first task record, tstride: ints per record -- int2 {start, len} of gm_tct.hip, CBuildTask of gm_cbuild.hip)
+  if (owner_rule == 2) {  // gm_tch.hip: the keys of the lists this chunk's vertices host
+    // (tlen: the length field of the first task record, tstride: ints per record -- int2 {start, len} of gm_tch.hip, CBuildTask of gm_cbuild.hip)
     // (gridDim.y workgroups share a chunk: a hub of R-MAT-22 hosts 2 * 10^5 tasks -- one workgroup walking them alone was 1.6 of the kernel's 1.7 ms)
     const int t0 = trp[r.u_begin], t1 = trp[r.u_end];
     const int ny = max(1, min((int)gridDim.y, (t1 - t0 + 1023) >> 10));  // workgroups that take part: one per 1024 tasks
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void gather_deg_kernel(int m, const int *__res
   if (i < m) deg[i] = rp[verts[i] + 1] - rp[verts[i]];
 }
 
-// (trp / tlen / tstride: the task lists the costs of an rf.tct table are counted from; default: the graph's, gm_tct.hip)
+// (trp / tlen / tstride: the task lists the costs of an rf.tct table are counted from; default: the graph's, gm_tch.hip)
 static int build_table_device(gm_graph *g, ChunkTable &t, bool sym_table, double &bitmap_ms, const int *trp = nullptr, const int *tlen = nullptr,
                               int tstride = 2) {
   const int *kst_rp = nullptr;
@@ -536,12 +536,12 @@ int get_table(gm_graph *g, int target, bool allow_split, int bit_words, unsigned
   t.stage_cap = stage_cap;
   t.rf = rf;
   t.bitmap_min_deg = bitmap_min_deg;
-  if (!getenv("GM_HOST_TABLES")) {  // (GM_HOST_TABLES: the same walk in a host loop over the vertices, kept for A/B)
+  if (!gm_sweep_env("GM_HOST_TABLES")) {  // (GM_HOST_TABLES: the same walk in a host loop over the vertices, kept for A/B)
     HIP_TRY(hipSetDevice(g->device));
     PoolScope pool(g);
     int rc = build_table_device(g, t, sym_table, bitmap_ms);
     if (rc) { free_table(t); return rc; }  // (a partially built table owns device memory: out-of-memory on a large graph must not leak it)
-    if (getenv("GM_TABLE_INFO"))
+    if (gm_sweep_env("GM_TABLE_INFO"))
       fprintf(stderr, "[table/device] stage_cap %d rows (%d,%d] skip (%d,%d]: %zu chunks, est. keys %.3e, %zu bitmaps, edges %llu, %.2f ms\n",
               stage_cap, rf.only_lo, rf.only_hi, rf.skip_lo, rf.skip_hi, t.n, (double)t.total_cost, t.n_bitmaps, t.total_edges, timer.ms());
     g->setup.bitmap_ms += bitmap_ms;
@@ -690,7 +690,7 @@ int get_table(gm_graph *g, int target, bool allow_split, int bit_words, unsigned
     bitmap_ms = bm_timer.ms();
   }
   HIP_TRY(hipDeviceSynchronize());
-  if (getenv("GM_TABLE_INFO")) {  // diagnostics
+  if (gm_sweep_env("GM_TABLE_INFO")) {  // diagnostics
     unsigned long long tc = 0, mx = 0;
     for (auto c : t.cost) { tc += c; mx = std::max(mx, c); }
     fprintf(stderr, "[table] stage_cap %d rows (%d,%d] skip (%d,%d]: %zu chunks, est. keys %.3e (max chunk %.3e), %zu bitmaps, edges %llu\n", stage_cap,
@@ -714,7 +714,7 @@ __global__ __launch_bounds__(256) void edesc_kernel(long long ne, const int *__r
   }
 }
 
-// ---- task lists of gm_tct.hip / gm_tch.hip: every edge u -> v of the DAG is a task of ONE of its endpoints (ensure_tasklists, below) ------
+// ---- task lists of gm_tch.hip / gm_tch.hip: every edge u -> v of the DAG is a task of ONE of its endpoints (ensure_tasklists, below) ------
 // ---- task-major copies of the short lists (gm_host.h: d_colk / d_tdesck) -- for the handles that cannot have the key stream -----------
 #ifndef GM_TC_INLINE_MAX_DEFAULT
 #define GM_TC_INLINE_MAX_DEFAULT 32
@@ -746,7 +746,7 @@ __global__ __launch_bounds__(256) void inl_copy_kernel(long long nt, const int2 
 // after d_tdesc: failures here leave the handle without copies (the kernels then stream the rows themselves)
 static void build_inline_copies(gm_graph *g, ScanTemp &tmp) {
   int lmax = GM_TC_INLINE_MAX_DEFAULT;
-  if (const char *e = getenv("GM_TC_INLINE_MAX")) lmax = atoi(e);  // (sweeps; 0: no copies)
+  if (const char *e = gm_sweep_env("GM_TC_INLINE_MAX")) lmax = atoi(e);  // (sweeps; 0: no copies)
   if (lmax <= 0 || g->ne <= 0 || g->d_tdesc == nullptr) return;
   const long long nt = g->ne;
   unsigned long long *off = nullptr;  // (lengths in, offsets out: the scan runs in place)
@@ -887,7 +887,7 @@ __global__ __launch_bounds__(256) void task_rows_kernel(const TaskWalk w, int *_
 // they stay.  A group of eight lanes copies the short lists of its eight tasks together, eight keys a step.  The order of a host's keys
 // is the order of arrival: the kernel looks every key up on its own.
 static bool keystream_possible(const gm_graph *g) {  // ids must leave bits 24..31 to the host tag
-  return g->nv <= (1 << 24) && !getenv("GM_TC_NO_KEY_STREAM");
+  return g->nv <= (1 << 24) && !gm_sweep_env("GM_TC_NO_KEY_STREAM");
 }
 struct KeyCopy { int src, dst, len, own; unsigned tag; };
 // EDGES (the edge supports, gm_sup.hip): beside every key the DAG entry it was copied from and the entry of its task's own edge, beside
@@ -1017,7 +1017,7 @@ int ensure_keystream(gm_graph *g, bool edges, bool *built) {
   const bool second = g->d_kst_rp != nullptr;  // the offsets exist: only the place pass, into the second set
   int lmax = second ? g->kst_lmax : GM_TC_INLINE_MAX_DEFAULT;
   if (!second) {
-    if (const char *e = getenv("GM_TC_INLINE_MAX")) lmax = atoi(e);  // (sweeps)
+    if (const char *e = gm_sweep_env("GM_TC_INLINE_MAX")) lmax = atoi(e);  // (sweeps)
     if (!keystream_possible(g) || lmax < 4) {
       g->kst_state = 2;
       return GM_OK;
@@ -1032,7 +1032,7 @@ int ensure_keystream(gm_graph *g, bool edges, bool *built) {
   {
     const int rc = graph_is_topological(g, &topo);
     if (rc) return rc;
-    if (getenv("GM_TC_NO_TRIM")) topo = false;  // (A/B: whole lists streamed on a topologically numbered DAG too)
+    if (gm_sweep_env("GM_TC_NO_TRIM")) topo = false;  // (A/B: whole lists streamed on a topologically numbered DAG too)
   }
   DevBuf<unsigned long long> cnt, keys, keyoff;
   DevBuf<int> longs;
@@ -1046,8 +1046,8 @@ int ensure_keystream(gm_graph *g, bool edges, bool *built) {
   // per CU.  Measured, window / workgroups per CU, count + place ms: R-MAT-22 4096 / 8: 1.38 + 2.51, 2048 / 16: 1.43 + 2.16;
   // R-MAT-24 4096 / 8: 8.5 + 14.7, 2048 / 16: 10.1 + 13.6.
   int win_count = kHubWin, win_place = 2048, per_cu_count = topo ? 8 : 64, per_cu_place = topo ? 16 : 64;
-  if (const char *e = getenv("GM_KST_HUB_WIN")) win_count = win_place = std::max(0, std::min(atoi(e), kHubWin));  // (sweeps)
-  if (const char *e = getenv("GM_KST_WG_PER_CU")) per_cu_count = per_cu_place = std::max(1, atoi(e));
+  if (const char *e = gm_sweep_env("GM_KST_HUB_WIN")) win_count = win_place = std::max(0, std::min(atoi(e), kHubWin));  // (sweeps)
+  if (const char *e = gm_sweep_env("GM_KST_WG_PER_CU")) per_cu_count = per_cu_place = std::max(1, atoi(e));
   const long long blocks_count = std::min<long long>(((long long)g->nv * 8 + 255) / 256, (long long)g->cu_count * per_cu_count);
   const long long blocks_place = std::min<long long>(((long long)g->nv * 8 + 255) / 256, (long long)g->cu_count * per_cu_place);
   TaskWalk tw;
@@ -1147,7 +1147,7 @@ int ensure_tasklists(gm_graph *g, bool /*with_edges*/) {
   {
     const int rc = graph_is_topological(g, &topo);
     if (rc) return rc;
-    if (getenv("GM_TC_NO_TRIM")) topo = false;  // (A/B: whole lists streamed on a topologically numbered DAG too)
+    if (gm_sweep_env("GM_TC_NO_TRIM")) topo = false;  // (A/B: whole lists streamed on a topologically numbered DAG too)
   }
   setup_trace("tasks: sorted / topological check");
   HIP_TRY(cnt.alloc(nv1));
@@ -1248,7 +1248,7 @@ int ensure_sup_masks(gm_graph *g) {
   }
   std::lock_guard<std::mutex> lk(g->mu);
   if (g->smask_state != 0) return GM_OK;
-  if (!topo || getenv("GM_TC_NO_TRIM") || getenv("GM_SUP_NO_MASKS") || g->ne < 1) {  // (tails exist on a topologically numbered DAG only)
+  if (!topo || gm_sweep_env("GM_TC_NO_TRIM") || getenv("GM_SUP_NO_MASKS") || g->ne < 1) {  // (tails exist on a topologically numbered DAG only)
     g->smask_state = 2;
     return GM_OK;
   }
@@ -1545,7 +1545,7 @@ int ensure_core_bitmap(gm_graph *g) {
   std::lock_guard<std::mutex> lk(g->mu);
   if (g->core_state) return GM_OK;
   long long want = kCoreHDefault;
-  if (const char *e = getenv("GM_CORE_H")) want = atoll(e);  // (sweeps; 0 switches the gathered build off)
+  if (const char *e = gm_sweep_env("GM_CORE_H")) want = atoll(e);  // (sweeps; 0 switches the gathered build off)
   if (!topo || g->d_rp == nullptr || g->nv < 64 || want < 64) {
     g->core_state = 2;
     return GM_OK;
@@ -1583,7 +1583,7 @@ int ensure_core_bitmap(gm_graph *g) {
 
 int clique_wide_min_words() {
   static const int v = [] {
-    const char *e = getenv("GM_WIDE_MIN_WORDS");  // (sweeps; read once: tables and plans are cached per graph)
+    const char *e = gm_sweep_env("GM_WIDE_MIN_WORDS");  // (sweeps; read once: tables and plans are cached per graph)
     return e ? std::max(64, std::min(atoi(e), kBitWords)) : kWideMinWordsDefault;
   }();
   return v;
@@ -1592,7 +1592,6 @@ int clique_wide_min_words() {
 static void free_clique_plan(CliquePlan &pl) {
   if (pl.d_verts) (void)hipFree(pl.d_verts);
   if (pl.d_slot_base) (void)hipFree(pl.d_slot_base);
-  if (pl.d_cls_slots) (void)hipFree(pl.d_cls_slots);
   if (pl.d_mcls_slots) (void)hipFree(pl.d_mcls_slots);
   for (auto &rd : pl.rounds) {
     if (rd.d_base) (void)hipFree(rd.d_base);
@@ -1601,7 +1600,7 @@ static void free_clique_plan(CliquePlan &pl) {
     free_table(rd.host_tab);
   }
   pl.rounds.clear();
-  pl.d_verts = nullptr; pl.d_slot_base = nullptr; pl.d_cls_slots = nullptr; pl.d_mcls_slots = nullptr;
+  pl.d_verts = nullptr; pl.d_slot_base = nullptr; pl.d_mcls_slots = nullptr;
 }
 void free_clique_plans(gm_graph *g) {
   for (auto &pl : g->clique_plans) free_clique_plan(pl);
@@ -1653,7 +1652,7 @@ static int build_clique_round(gm_graph *g, CliquePlan &pl, CliqueRound &rd, Scan
                      cnt.p, rd.d_trp, rd.d_base, rd.d_tasks);
   HIP_TRY(hipGetLastError());
   // host chunks: runs of consecutive vertices whose DAG rows fit the stage (longer rows host nothing), costs from the task lists,
-  // heavy chunks cut into parts like gm_tct.hip's (a hub hosts 10^5 in-edges)
+  // heavy chunks cut into parts like gm_tch.hip's (a hub hosts 10^5 in-edges)
   ChunkTable &t = rd.host_tab;
   t.target = std::max(64, std::min(pl.target, pl.stage));
   t.allow_split = true;
@@ -1733,7 +1732,7 @@ int get_clique_plan(gm_graph *g, int rank, int world, int policy, int target, un
     bool topo = false;
     const int rc = graph_is_topological(g, &topo);
     if (rc) return rc;
-    pl.topo = topo && !getenv("GM_CLIQUE_NO_TOPO");  // (GM_CLIQUE_NO_TOPO: A/B, whole lists streamed)
+    pl.topo = topo && !gm_sweep_env("GM_CLIQUE_NO_TOPO");  // (GM_CLIQUE_NO_TOPO: A/B, whole lists streamed)
     if (pl.topo) {  // the dense hub core: rows of the wide vertices' matrices are gathered from it (gm_cgather.hip)
       const int rc2 = ensure_core_bitmap(g);
       if (rc2) return rc2;
@@ -1819,7 +1818,7 @@ int get_clique_plan(gm_graph *g, int rank, int world, int policy, int target, un
         }
       }
       size_t s1 = s0;
-      std::vector<int> by_cls[3], by_mcls[3];
+      std::vector<int> by_mcls[3];
       if (c1 == pl.n_count) {  // (wide vertices only once the narrow chunks are placed)
         for (; s1 < (size_t)wcount; ++s1) {
           const int d = hd[s1];
@@ -1827,17 +1826,11 @@ int get_clique_plan(gm_graph *g, int rank, int world, int policy, int target, un
           if ((s1 > s0 || c1 > c0) && words + w > budget_words) break;
           words += w;
           pl.wide_edges += (unsigned long long)d;
-          by_cls[clique_count_class(d)].push_back((int)s1);
           by_mcls[clique_mma_class(d)].push_back((int)s1);
         }
       }
       rd.n_pos0 = c0; rd.n_count = c1 - c0;
       rd.w0 = s0; rd.w1 = s1;
-      for (int c = 0; c < 3; ++c) {
-        rd.cls_begin[c] = cls_slots.size();
-        cls_slots.insert(cls_slots.end(), by_cls[c].begin(), by_cls[c].end());
-      }
-      rd.cls_begin[3] = cls_slots.size();
       for (int c = 0; c < 3; ++c) {
         rd.mcls_begin[c] = mcls_slots.size();
         mcls_slots.insert(mcls_slots.end(), by_mcls[c].begin(), by_mcls[c].end());
@@ -1849,9 +1842,7 @@ int get_clique_plan(gm_graph *g, int rank, int world, int policy, int target, un
       if (c0 >= pl.n_count && s0 >= (size_t)wcount) break;
     }
   }
-  HIP_TRY(hipMalloc(&pl.d_cls_slots, sizeof(int) * std::max<size_t>(cls_slots.size(), 1)));
   setup_trace("clique: rounds (host loop)");
-  if (!cls_slots.empty()) HIP_TRY(copy_to_device(pl.d_cls_slots, cls_slots.data(), sizeof(int) * cls_slots.size()));
   HIP_TRY(hipMalloc(&pl.d_mcls_slots, sizeof(int) * std::max<size_t>(mcls_slots.size(), 1)));
   if (!mcls_slots.empty()) HIP_TRY(copy_to_device(pl.d_mcls_slots, mcls_slots.data(), sizeof(int) * mcls_slots.size()));
   setup_trace("clique: wide list, classes, rounds (host)");

@@ -1,4 +1,4 @@
-// gm_tch.hip -- triangle counting, the shorter list streamed (gm_tct.hip) against the chunk's DAG rows kept in LDS as ONE HASHED SET of
+// gm_tch.hip -- triangle counting, the shorter list streamed (gm_tch.hip) against the chunk's DAG rows kept in LDS as ONE HASHED SET of
 // (row, id) pairs instead of a sorted copy behind a bit filter.
 //
 // Why (profiles/r03/tc_rmat22_pmc_summary.txt, section 4.11 of DESIGN.md): tct_kernel issues 66 VALU instructions per 64 streamed

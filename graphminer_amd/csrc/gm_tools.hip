@@ -418,7 +418,7 @@ extern "C" int gm_issue_calib(int kind, int waves_per_simd, int iters, double *c
   const int W = waves_per_simd, grid = cus * W;
   // exactly W workgroups of 4 waves (one per SIMD) per CU: each claims 1/W of the 160 KB of LDS (at least the 16 KB the kernel touches)
   size_t lds = std::max<size_t>(16384, ((size_t)(160 * 1024) / (size_t)W) & ~(size_t)1023);
-  if (const char *e = getenv("GM_CAL_LDS")) lds = std::max<size_t>(16384, (size_t)atoll(e));  // (diagnostics: let the dispatcher pack as it likes)
+  if (const char *e = gm_sweep_env("GM_CAL_LDS")) lds = std::max<size_t>(16384, (size_t)atoll(e));  // (diagnostics: let the dispatcher pack as it likes)
   DevBuf<unsigned long long> cyc;
   DevBuf<unsigned> sink;
   HIP_TRY(cyc.alloc((size_t)grid * 4 * 3));

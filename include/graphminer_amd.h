@@ -118,8 +118,8 @@ typedef struct gm_launch {
                          0x800 rectangle / pentagon as wedges + flat intersections, house flattened over (v0,v1,v3), 0x1000 cut
                          chunks into parts eagerly, 0x2000 swap the two dequeue orders, 0x4000 plain chunk-id order,
                          0x10000000 diamond / 3-motif by one intersection of the two symmetric lists per edge (the reference's loop
-                         nests; default: from the triangles of the oriented copy), 0x8000000 TC against a sorted LDS copy + bit filter +
-                         bisection (gm_tct.hip; default: a hashed set, gm_tch.hip), 0x4000000 TC by the chunked mining kernel,
+                         nests; default: from the triangles of the oriented copy), 0x4000000 TC by the chunked mining kernel (default: the shorter list
+                         of every edge against a hashed set, gm_tch.hip),
                          0x800000 hashed sets on their global-memory fallback lookup, 0x40000 4-clique in the mining kernel alone,
                          0x40000000 edge supports (diamond) with one atomic per streamed edge instead of the match masks (gm_sup.hip);
                          0x80000 / 0x100000 / 0x400000 / 0x1000000 / 0x2000000: variants of the per-edge class kernels (gm_launch.hip).

@@ -110,7 +110,7 @@ def test_hashed_sets_exact_on_many_short_rows():
     assert SglSolver(sym, "diamond", tune=[0, 0, 0, 0, 0, 0, 0x800000]) == want_d         # supports, fallback lookup
     dag, odag = sym.orient(), O.orient(osym)
     want_t = O.tc(odag)
-    assert TCSolver(dag) == want_t and TCSolver(dag, tune=[0, 0, 0, 0, 0, 0, 0x8000000]) == want_t and CliqueSolver(dag, 3) == want_t
+    assert TCSolver(dag) == want_t and TCSolver(dag, tune=[0, 0, 0, 0, 0, 0, 0x4000000]) == want_t and CliqueSolver(dag, 3) == want_t
     want_4 = O.clique(odag, 4)
     assert CliqueSolver(dag, 4) == want_4
     assert CliqueSolver(dag, 4, tune=[0, 0, 0, 0, 0, 0, 0x40000]) == want_4               # the mining kernel's arena path

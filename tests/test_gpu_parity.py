@@ -70,11 +70,9 @@ def test_tc_matches_reference(gg):
     assert total == GOLDEN[name]["tc"]
     assert st.tasks == dag.E()  # "edges processed" = |E+| (src/triangle/gpu_base.cu:69)
     assert CliqueSolver(dag, 3) == GOLDEN[name]["tc"]
-    # (default: the shorter list of every edge is streamed, gm_tct.hip; 0x4000000: the chunked kernel that streams N+(v) of every out-edge)
+    # (default: the shorter list of every edge streamed against the chunk's rows as one hashed (row, id) set, gm_tch.hip; 0x4000000: the
+    # chunked mining kernel that streams N+(v) of every out-edge -- an independent kernel; 0x800000: the hashed set's global-memory fallback)
     assert TCSolver(dag, tune=[0, 0, 0, 0, 0, 0, 0x4000000]) == GOLDEN[name]["tc"]
-    # (the task-list kernels: default = the chunk rows as one hashed (row, id) set, gm_tch.hip; 0x8000000: sorted LDS copy + bit filter +
-    # bisection, gm_tct.hip; 0x800000: the hashed kernel on its global-memory fallback lookup)
-    assert TCSolver(dag, tune=[0, 0, 0, 0, 0, 0, 0x8000000]) == GOLDEN[name]["tc"]
     assert TCSolver(dag, tune=[0, 0, 0, 0, 0, 0, 0x800000]) == GOLDEN[name]["tc"]
 
 
@@ -83,7 +81,7 @@ def test_tc_matches_reference(gg):
     [0, 0, 0, 0, 0, 0, 0x1000], [0, 0, 0, 0, 0, 0, 0x4000], [0, 0, 0, 0, 0, 0, 0x3000],
     [256, 4, 8, 1, 0, 0],
     [64, 1, 0, 0, 0, 0, 0x4000000], [256, 4, 1, 30, 2, 0, 0x4000000], [0, 0, 0, 0, 0, 0, 0x4000000 | 0x1000], [128, 8, 1, 1, 0, 0, 0x4000000 | 0x4000],
-    [64, 1, 0, 0, 0, 0, 0x8000000], [0, 0, 0, 0, 0, 0, 0x8000000 | 0x1000], [256, 4, 8, 1, 0, 0, 0x8000000], [0, 0, 0, 0, 0, 0, 0x800000 | 0x1000],
+    [256, 4, 8, 1, 0, 0, 0x4000000], [0, 0, 0, 0, 0, 0, 0x800000 | 0x1000],
 ])
 def test_tc_invariant_under_tuning(gg, tune):
     name, _, sym, dag = gg
@@ -717,7 +715,7 @@ def test_tc_rows_beyond_the_task_list_stage(dev):
     got, st = TCSolver(dag, return_stats=True)
     assert got == want and st.tasks == dag.E()
     assert TCSolver(dag, tune=[0, 0, 0, 0, 0, 0, 0x4000000]) == want  # the chunked kernel alone
-    assert TCSolver(dag, tune=[0, 0, 0, 0, 0, 0, 0x8000000]) == want  # task lists against the sorted LDS copy
+    assert TCSolver(dag, tune=[0, 0, 0, 0, 0, 0, 0x4000000]) == want  # the chunked mining kernel
     assert TCSolver(dag, tune=[0, 0, 0, 0, 0, 0, 0x800000]) == want   # ... against the hashed set's fallback lookup
     assert sum(TCSolver(dag, rank=r, world=3) for r in range(3)) == want
     assert sum(TCSolver(dag, rank=r, world=4, policy=2) for r in range(4)) == want
@@ -821,7 +819,7 @@ def test_tc_hashed_set_with_colliding_ids(dev):
         assert want > 0
         assert TCSolver(dag) == want
         assert TCSolver(dag, tune=[0, 0, 0, 0, 0, 0, 0x200]) == want
-        assert TCSolver(dag, tune=[0, 0, 0, 0, 0, 0, 0x200 | 0x8000000]) == want
+        assert TCSolver(dag, tune=[0, 0, 0, 0, 0, 0, 0x200 | 0x4000000]) == want
         assert sum(TCSolver(dag, rank=r, world=3, tune=[0, 0, 0, 0, 0, 0, 0x200]) for r in range(3)) == want
         # the re-hosted 4-clique build keeps the same rows as a hashed (row, id) -> position set (gm_cbuild.hip)
         want4 = O.clique(O.orient(O.OGraph(g.row_ptr, g.col_idx)), 4)
