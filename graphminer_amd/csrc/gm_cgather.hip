@@ -101,150 +101,23 @@ __global__ __launch_bounds__(kCgWaves *GM_WAVE) void cgather_kernel(const CGathe
   }
 }
 
-// ---- the core rows shared out to the XCDs (round 5) ------------------------------------------------------------------------------
-// The gathers are bound by the lines they pull past L2 (53 GB per launch on the com-Orkut stand-in at an L2 hit rate of 0.26): the 128 MB
-// core does not fit an XCD's 4 MB L2.  Shared out -- the workgroups that run on XCD k gather only the rows whose core row is = k mod 8 --
-// an L2 sees an eighth of the core: round 4 measured 35 GB (hit rate 0.44) but lost the gain to a dequeue -> header -> column table ->
-// barrier prologue per (matrix, share) with an eighth of a matrix's rows behind it.  Here a work unit is a BATCH of matrices x one share:
-// the column tables of up to kCgBatchCols columns (2 .. 16 matrices, by degree class) sit in LDS together, the rows of the share are
-// listed once (ballot + rank) and the waves take them from that list.  A workgroup whose own share has no batch left helps the next
-// one, so the result does not depend on where workgroups land.
-constexpr int kCgBatchCols = 4096;   // columns of a batch (sum of the matrices' padded widths)
-constexpr int kCgBatchMax = 16;      // matrices of a batch
-struct alignas(16) CGatherShareLds {
-  int pj[kCgBatchCols + GM_WAVE];          // per column: s_j - core_base (< 0: below the core)
-  unsigned short row_m[kCgBatchCols];      // the rows of this share: matrix of the batch ...
-  unsigned short row_i[kCgBatchCols];      // ... and row of the matrix
-  int ru[kCgBatchMax], d[kCgBatchMax], col0[kCgBatchMax], k0[kCgBatchMax];
-  unsigned long long base[kCgBatchMax];
-  int n_rows, next_row, unit, share;
-};
-
-__device__ __forceinline__ int cg_xcd_id() {
-  int x;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
-  return x & 7;
-}
-
-__global__ __launch_bounds__(kCgWaves *GM_WAVE) void cgather_share_kernel(const CGatherParams p) {
-  __shared__ CGatherShareLds S;
-  constexpr int NT = kCgWaves * GM_WAVE;
-  const int tid = threadIdx.x, lane = tid & (GM_WAVE - 1), wave = readfirst(tid >> 6);
-  const __amdgpu_buffer_rsrc_t core = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(p.core), 0, (int)p.core_bytes, 0x00020000);
-  const int my = cg_xcd_id();
-  int tried = 0, share = my;
-  for (;;) {
-    if (tid == 0) {
-      int u_ = -1, k_ = share, t_ = tried;
-      while (t_ < 8) {  // this XCD's share first, then the next ones
-        const unsigned q = atomicAdd(p.queue + k_, 1u);
-        if (q < (unsigned)p.n_units) { u_ = (int)q; break; }
-        k_ = (k_ + 1) & 7;
-        ++t_;
-      }
-      S.unit = u_;
-      S.share = (k_ << 8) | t_;
-    }
-    __syncthreads();
-    const int unit = S.unit;
-    share = S.share >> 8;
-    tried = S.share & 255;
-    if (unit < 0) break;
-    // unit -> segment (degree class) -> slots
-    int seg = 0, ub = unit;
-    while (seg < 2 && ub >= p.seg_units[seg]) { ub -= p.seg_units[seg]; ++seg; }
-    const int bsz = p.seg_batch[seg];
-    const int s0 = p.seg_first[seg] + ub * bsz, s1 = min(s0 + bsz, p.seg_first[seg] + p.seg_count[seg]);
-    const int nm = s1 - s0;
-    if (tid < nm) {
-      const int slot = p.first_slot + s0 + tid;
-      const int u = p.verts[slot];
-      const int ru = p.rp[u], d = p.rp[u + 1] - ru;
-      S.ru[tid] = ru;
-      S.d[tid] = d;
-      S.base[tid] = p.base[slot];
-      S.k0[tid] = lower_bound(p.col + ru, d, p.core_base);
-    }
-    if (tid == 0) { S.n_rows = 0; S.next_row = 0; }
-    __syncthreads();
-    if (tid == 0) {
-      int c = 0;
-      for (int m = 0; m < nm; ++m) { S.col0[m] = c; c += (S.d[m] + GM_WAVE - 1) & ~(GM_WAVE - 1); }
-    }
-    __syncthreads();
-    for (int m = 0; m < nm; ++m) {  // column tables + the rows of this share
-      const int ru = S.ru[m], d = S.d[m], c0 = S.col0[m], k0 = S.k0[m];
-      const int dpad = (d + GM_WAVE - 1) & ~(GM_WAVE - 1);
-      for (int j = tid; j < dpad; j += NT) {
-        const int pj = j < d ? p.col[ru + j] - p.core_base : -1;
-        S.pj[c0 + j] = pj;
-        const bool mine = j >= k0 && j < d && (pj & 7) == share;
-        const unsigned long long mm = __ballot(mine);
-        int b0 = 0;
-        if (lane == 0 && mm) b0 = atomicAdd(&S.n_rows, (int)__popcll(mm));
-        b0 = readfirst(b0);
-        if (mine) {
-          const int r = b0 + rank_below(mm);
-          S.row_m[r] = (unsigned short)m;
-          S.row_i[r] = (unsigned short)j;
-        }
-      }
-    }
-    __syncthreads();
-    const int n_rows = S.n_rows;
-    for (;;) {
-      int r = 0;
-      if (lane == 0) r = atomicAdd(&S.next_row, 1);
-      r = readfirst(r);
-      if (r >= n_rows) break;
-      const int m = S.row_m[r], i = S.row_i[r];
-      const int d = S.d[m], c0 = S.col0[m], stride = (d + 31) >> 5;
-      const int ntiles = (d + GM_WAVE - 1) >> 6;
-      const int rowo = readfirst(S.pj[c0 + i]) * p.core_words * 4;
-      unsigned w_out = 0u;
-      const int t0 = (i + 1) >> 6;
-      auto info_of = [&](const int t) {
-        const int pj = S.pj[c0 + t * GM_WAVE + lane];
-        return make_int2(pj >= 0 ? (pj >> 5) << 2 : 0, pj);
-      };
-      if (t0 < ntiles) {
-        const int2 inf = info_of(t0);
-        cg_tile<true>((unsigned)__builtin_amdgcn_raw_buffer_load_b32(core, inf.x, rowo, 0), inf, t0, i, d, lane, w_out);
-      }
-      int tb = t0 + 1;
-      for (; tb + kCgUnroll < ntiles; tb += kCgUnroll) {
-        int2 inf[kCgUnroll];
-        unsigned w[kCgUnroll];
-#pragma unroll
-        for (int k = 0; k < kCgUnroll; ++k) inf[k] = info_of(tb + k);
-#pragma unroll
-        for (int k = 0; k < kCgUnroll; ++k) w[k] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(core, inf[k].x, rowo, 0);
-#pragma unroll
-        for (int k = 0; k < kCgUnroll; ++k) cg_tile<false>(w[k], inf[k], tb + k, i, d, lane, w_out);
-      }
-      for (; tb < ntiles; ++tb) {
-        const int2 inf = info_of(tb);
-        cg_tile<true>((unsigned)__builtin_amdgcn_raw_buffer_load_b32(core, inf.x, rowo, 0), inf, tb, i, d, lane, w_out);
-      }
-      if (lane < stride) (p.mat + S.base[m])[(size_t)i * stride + lane] = w_out;
-    }
-    __syncthreads();  // the tables are rewritten by the next unit
-  }
-}
-
 hipError_t launch_cgather(const CGatherParams &p, int grid_blocks, hipStream_t stream) {
   static_assert(kCbMaxDeg <= 2048, "a row is at most 64 words: one per lane");
   if (p.core == nullptr || p.mat == nullptr || p.core_bytes == 0 || p.core_bytes > 0xffffffffull) return hipErrorInvalidValue;
-  if (p.n_units > 0) hipLaunchKernelGGL(cgather_share_kernel, dim3((unsigned)grid_blocks), dim3(kCgWaves * GM_WAVE), 0, stream, p);
-  else hipLaunchKernelGGL(cgather_kernel, dim3((unsigned)grid_blocks), dim3(kCgWaves * GM_WAVE), 0, stream, p);
+  hipLaunchKernelGGL(cgather_kernel, dim3((unsigned)grid_blocks), dim3(kCgWaves * GM_WAVE), 0, stream, p);
   return hipGetLastError();
 }
+// (Round 5 tried the core rows SHARED OUT to the XCDs once more -- the workgroups of XCD k gather only the rows whose core row is
+// = k mod 8, a work unit = a batch of 2 .. 8 matrices x one share with their column tables together in LDS and the share's rows listed
+// once: traffic 53.6 -> 36.0 GB, L2 hit rate 0.27 -> 0.44 as in round 4, but 5.9 instead of 2.9 G vector instructions and 13.3 instead
+// of 11.9 ms -- with a third less traffic the kernel is bound by its instruction stream and the latency of a row's gathers, not by
+// lines.  profiles/r05/ab_clique4_gather_shares.txt; not in the tree.)
 // workgroups per CU the launch asks for (GM_CG_PER_CU: sweeps).  The gathers are bound by the lines they pull through L2, yet they want
 // every wave a CU has: 4 / 2 workgroups per CU 27.7 / 35.6 ms for the whole pattern.
 int cgather_per_cu() {
   static const int v = [] {
     const char *e = gm_sweep_env("GM_CG_PER_CU");
-    const int cap = (int)std::min<size_t>(163840 / std::max(sizeof(CGatherLds), sizeof(CGatherShareLds)), 2048 / (kCgWaves * GM_WAVE));
+    const int cap = (int)std::min<size_t>(163840 / sizeof(CGatherLds), 2048 / (kCgWaves * GM_WAVE));
     return e ? std::max(1, std::min(atoi(e), cap)) : cap;
   }();
   return v;

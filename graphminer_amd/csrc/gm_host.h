@@ -195,7 +195,6 @@ struct CliquePlan {
   long long n_first = 0, n_step = 1, n_count = 0;  // this rank's share of it: positions first + i * step of the dequeue order
   const int *d_order = nullptr;
   std::vector<int> verts;            // this rank's wide vertices; slot = index here (longest rows first)
-  std::vector<int> vdeg;             // ... and their DAG degrees (non-increasing): the degree classes of the gathered build's batches
   int *d_verts = nullptr;
   unsigned long long *d_slot_base = nullptr;  // slot -> word offset of its matrix inside its round's arena
   int *d_mcls_slots = nullptr;

@@ -554,7 +554,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
     const bool prof = gm_sweep_env("GM_WIDE_PROFILE") != nullptr;
     int qword = 0;
     for (const auto &rd : plan->rounds) {
-      if (qword + 16 > 16384) return GM_ERR_TOO_LARGE;  // (more than ~3000 arena rounds)
+      if (qword + 9 > 16384) return GM_ERR_TOO_LARGE;  // (more than ~3000 arena rounds)
       bool gather_joined = false;
       if (plan->core_base >= 0 && rd.w1 > rd.w0) {  // the rows of the wide vertices whose first endpoint lies in the hub core: gathered (gm_cgather.hip)
         CGatherParams cg;
@@ -570,25 +570,8 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
         cg.core_bytes = (unsigned long long)g->core_h * (unsigned long long)cg.core_words * 4ull;
         cg.first_slot = (int)rd.w0;
         cg.count = (int)(rd.w1 - rd.w0);
-        cg.queue = g->d_wide_queue + qword;
-        qword += 8;  // (one dequeue word per XCD share)
-        // the core rows shared out to the XCDs: batches of matrices by degree class (tune[6] & 0x80000000: whole matrices, round 4's kernel)
-        if (!(la->tune[6] & (int)0x80000000) && plan->vdeg.size() == plan->verts.size() &&
-            std::is_sorted(plan->vdeg.begin() + (long)rd.w0, plan->vdeg.begin() + (long)rd.w1, std::greater<int>())) {
-          const auto b = plan->vdeg.begin() + (long)rd.w0, e = plan->vdeg.begin() + (long)rd.w1;
-          const int c0 = (int)(std::partition_point(b, e, [](int d) { return d > 1024; }) - b);
-          const int c1 = (int)(std::partition_point(b, e, [](int d) { return d > 512; }) - b);
-          const int first[3] = {0, c0, c1}, count[3] = {c0, c1 - c0, cg.count - c1}, batch[3] = {2, 4, 8};
-          for (int sgi = 0; sgi < 3; ++sgi) {
-            cg.seg_first[sgi] = first[sgi];
-            cg.seg_count[sgi] = count[sgi];
-            cg.seg_batch[sgi] = batch[sgi];
-            cg.seg_units[sgi] = (count[sgi] + batch[sgi] - 1) / batch[sgi];
-            cg.n_units += cg.seg_units[sgi];
-          }
-        }
-        const long long gunits = cg.n_units > 0 ? 8ll * cg.n_units : (long long)cg.count;
-        const int ggrid = (int)std::max<long long>(1, std::min<long long>(gunits, (long long)g->cu_count * cgather_per_cu()));
+        cg.queue = g->d_wide_queue + qword++;
+        const int ggrid = (int)std::max<long long>(1, std::min<long long>(cg.count, (long long)g->cu_count * cgather_per_cu()));
         // (GM_CLIQUE_SIDE_STREAM=1: on a side stream beside the streamed build and the counts of the narrow vertices -- they touch other rows
         // of the arena.  Measured and not taken: the gathers want all 32 waves of a CU -- 4 / 3 / 2 / 1 workgroups per CU beside the streamed
         // build: 29.2 / 29.5 / 33.8 / 53.4 ms against 27.7 one after the other, profiles/r04/ab_clique4_side_stream.txt)

@@ -320,12 +320,7 @@ struct CGatherParams {
   int core_base, core_words;
   unsigned long long core_bytes;    // size of the bitmap (< 2^32: one buffer resource addresses it)
   int first_slot, count;            // the slots of this launch: first_slot + q
-  unsigned *queue;                  // dequeue head (zeroed before launch); the shared-out form: eight of them, one per XCD share
-  // the core rows shared out to the XCDs (cgather_share_kernel): a work unit = a batch of matrices of one degree class x one share.
-  // n_units = 0: whole matrices (cgather_kernel)
-  int n_units;                      // batches of the launch (every share walks all of them)
-  int seg_first[3], seg_count[3];   // the launch's slots by class, relative to first_slot: d+ > 1024, 512 < d+ <= 1024, the rest
-  int seg_batch[3], seg_units[3];   // matrices per batch and batches of the class
+  unsigned *queue;                  // dequeue head (zeroed before launch)
 };
 hipError_t launch_cgather(const CGatherParams &p, int grid_blocks, hipStream_t stream);
 int cgather_per_cu();

@@ -1777,7 +1777,6 @@ int get_clique_plan(gm_graph *g, int rank, int world, int policy, int target, un
     pl.verts.resize((size_t)wcount);
     HIP_TRY(copy_to_host(pl.verts.data(), pl.d_verts, sizeof(int) * (size_t)wcount));
     HIP_TRY(copy_to_host(hd.data(), degs.p, sizeof(int) * (size_t)wcount));
-    pl.vdeg = hd;
   }
   setup_trace("clique: wide share to the host");
   // rounds within the arena budget: the narrow chunks first (in dequeue order), then the wide vertices (longest rows first)
