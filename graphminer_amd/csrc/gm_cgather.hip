@@ -22,7 +22,8 @@
 namespace gm {
 
 constexpr int kCgWaves = 8;
-constexpr int kCgUnroll = 8;  // tiles of a row whose gathers are in flight together
+constexpr int kCgUnroll = 8;  // tiles of a row whose gathers are in flight together (beyond its head)
+constexpr int kCgHead = 8;    // tiles of the NEXT row of the wave requested ahead
 
 struct alignas(16) CGatherLds {
   int2 info[kCbMaxDeg + GM_WAVE];  // per column j: {byte offset of the word of bit s_j - core_base in a core row, s_j - core_base} (-1: below the core)
@@ -72,16 +73,33 @@ __global__ __launch_bounds__(kCgWaves *GM_WAVE) void cgather_kernel(const CGathe
     __syncthreads();
     const int k0 = S.k0;
     const int ntiles = dpad >> 6;
-    for (int i = k0 + wave; i < d; i += kCgWaves) {
-      const int rowo = readfirst(S.info[i].y) * p.core_words * 4;  // (scalar: < 2^32 bytes, launch_cgather checks)
+    // Two rows of a wave in flight: the gathers of the first kCgHead tiles of row i + kCgWaves are requested before the tiles of row i are
+    // turned into bits -- a row is one dependent chain (column table -> buffer_load -> ballot -> writelane) and at the 32 waves a CU holds
+    // the kernel waited 0.79 of its cycles for it (profiles/r04/clique4_rmat22ef28_pmc_summary.txt).
+    struct Head {
+      int2 inf[kCgHead];
+      unsigned w[kCgHead];
+    };
+    auto issue = [&](const int i, Head &h) {  // (wave-uniform i; tiles at or beyond the row's last one are not requested)
+      const int rowo = readfirst(S.info[i].y) * p.core_words * 4;
+      const int t0 = (i + 1) >> 6;
+#pragma unroll
+      for (int k = 0; k < kCgHead; ++k) {
+        if (t0 + k < ntiles) {
+          h.inf[k] = S.info[(t0 + k) * GM_WAVE + lane];
+          h.w[k] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(core, h.inf[k].x, rowo, 0);
+        }
+      }
+    };
+    auto finish = [&](const int i, const Head &h) {
+      const int rowo = readfirst(S.info[i].y) * p.core_words * 4;
       unsigned w_out = 0u;  // lane L: word L of the row (the words below the diagonal are zero)
       const int t0 = (i + 1) >> 6;
-      if (t0 < ntiles) {  // the tile of the diagonal
-        const int2 inf = S.info[t0 * GM_WAVE + lane];
-        cg_tile<true>((unsigned)__builtin_amdgcn_raw_buffer_load_b32(core, inf.x, rowo, 0), inf, t0, i, d, lane, w_out);
-      }
-      int tb = t0 + 1;
-      for (; tb + kCgUnroll < ntiles; tb += kCgUnroll) {  // whole tiles beyond it, kCgUnroll gathers in flight
+#pragma unroll
+      for (int k = 0; k < kCgHead; ++k)
+        if (t0 + k < ntiles) cg_tile<true>(h.w[k], h.inf[k], t0 + k, i, d, lane, w_out);
+      int tb = t0 + kCgHead;
+      for (; tb + kCgUnroll < ntiles; tb += kCgUnroll) {  // whole tiles beyond the head, kCgUnroll gathers in flight
         int2 inf[kCgUnroll];
         unsigned w[kCgUnroll];
 #pragma unroll
@@ -96,6 +114,15 @@ __global__ __launch_bounds__(kCgWaves *GM_WAVE) void cgather_kernel(const CGathe
         cg_tile<true>((unsigned)__builtin_amdgcn_raw_buffer_load_b32(core, inf.x, rowo, 0), inf, tb, i, d, lane, w_out);
       }
       if (lane < stride) mu[(size_t)i * stride + lane] = w_out;
+    };
+    int i = k0 + wave;
+    Head cur, nxt;
+    if (i < d) issue(i, cur);
+    for (; i < d; i += kCgWaves) {
+      const int in = i + kCgWaves;
+      if (in < d) issue(in, nxt);
+      finish(i, cur);
+      cur = nxt;
     }
     __syncthreads();  // the column table is rewritten by the next vertex
   }
