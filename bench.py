@@ -83,6 +83,7 @@ KERNELS = {
                "clique_count_kernel", "clique_small_kernel", "tch_kernel"],
 }
 TRAFFIC_MARKER = "issue_calib_kernel"  # the dispatch in front of every workload of the traffic worker (measure_traffic)
+DIAMOND_SUPPORTS_MAX_WORLD = int(os.environ.get("GM_DIAMOND_SUPPORTS_MAX_WORLD", "4"))  # (graphminer_amd/host/multi.cc has the same rule)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (~6.3 TB/s achievable by a stream)
 M64 = (1 << 64) - 1
 
@@ -493,7 +494,10 @@ class Runner:
         # diamond on several ranks: the one-GPU algorithm at every N (graphminer_amd.dist.diamond_step: a share of the triangle pass, ONE
         # reduce-scatter of the support arrays over xGMI, sum C(t, 2) of the rank's slice) -- unless the per-edge kernels are asked for
         # (--tune ... 0x10000000) or a row of the oriented copy exceeds the stage (GM_ERR_UNSUPPORTED at the first call)
-        dstate = {"on": workload == "diamond" and la.world > 1 and not (la.tune[6] & 0x10000000) and not os.environ.get("GM_DIAMOND_PER_EDGE"),
+        # ... up to DIAMOND_SUPPORTS_MAX_WORLD ranks: beyond, a rank's share of the per-edge kernels + the single 8-byte all-reduce north_star
+        # names is the better deal (one-GPU simulation of the shares, profiles/r05/sim_scale_one_gpu.txt, R-MAT-22 at 2 / 4 / 8 ranks: shared
+        # triangle pass 4.48 / 3.04 / 2.35 ms + a reduce-scatter of 81 / 122 / 142 MB per rank, per-edge kernels 8.20 / 4.75 / 2.90 ms + 8 bytes)
+        dstate = {"on": workload == "diamond" and 1 < la.world <= DIAMOND_SUPPORTS_MAX_WORLD and not (la.tune[6] & 0x10000000) and not os.environ.get("GM_DIAMOND_PER_EDGE"),
                   "buf": None}
 
         def diamond_sup_step():

@@ -144,7 +144,13 @@ bool run_multi(const gm_csr &g, const Job &j, int n, int chunk, uint64_t *out) {
   // all-reduce of the counts like every other pattern.  (GM_DIAMOND_PER_EDGE, or rows beyond the 2048-entry stage: the per-edge kernels.)
   std::vector<uint32_t *> d_sup(n, nullptr);
   int64_t sup_n = 0;
-  bool diamond_sup = j.kind == Job::SGL && j.pattern && std::strcmp(j.pattern, "diamond") == 0 && !std::getenv("GM_DIAMOND_PER_EDGE");
+  // Up to four GPUs: beyond, a GPU's share of the per-edge kernels + the single 8-byte all-reduce is the better deal (one-GPU simulation of
+  // the shares on R-MAT-22 at 2 / 4 / 8 ranks: shared triangle pass 4.48 / 3.04 / 2.35 ms + a reduce-scatter of 81 / 122 / 142 MB per rank,
+  // per-edge kernels 8.20 / 4.75 / 2.90 ms: profiles/r05/sim_scale_one_gpu.txt).  GM_DIAMOND_SUPPORTS_MAX_WORLD overrides the limit.
+  int sup_max_world = 4;
+  if (const char *e = std::getenv("GM_DIAMOND_SUPPORTS_MAX_WORLD")) sup_max_world = std::atoi(e);
+  bool diamond_sup = j.kind == Job::SGL && j.pattern && std::strcmp(j.pattern, "diamond") == 0 && !std::getenv("GM_DIAMOND_PER_EDGE") &&
+                     (n <= sup_max_world || std::getenv("GM_FORCE_RCCL_PATH"));
   if (diamond_sup) {
     for (int i = 0; i < n && diamond_sup; ++i) {
       HIP_OK(hipSetDevice(i));
