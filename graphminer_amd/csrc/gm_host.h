@@ -136,6 +136,18 @@ struct RowFilter {
   }
 };
 
+// A rank's SHARE of a chunk table (world > 1): the records it dequeues, in dequeue order.  All PARTS of a chunk go to the same rank:
+// a part is "every nparts-th batch of the chunk's task list", and the order of a host's tasks is the order in which the placement's
+// atomics arrived -- different in every process.  Two ranks that split the parts of one chunk would each cut THEIR OWN order of its
+// tasks, and the union would not be the chunk (round 5: bench.py --gpus 2 at full size counted 750,563,783 triangles for 750,506,260;
+// the in-process rank-share tests of rounds 2 - 4 shared one handle and could not see it).
+struct ShareOrder {
+  int world = 1, rank = 0, policy = 0, which = -1;  // which: the dequeue order it was cut from (-1: plain record order)
+  int *d = nullptr;
+  long long n = 0;
+  unsigned long long edges = 0;  // task edges of the share
+};
+
 struct ChunkTable {
   int target;       // T: CSR entries per chunk
   bool allow_split; // rows longer than the staging capacity may be cut across chunks
@@ -169,8 +181,12 @@ struct ChunkTable {
   size_t n_with_cost = 0;  // chunks of non-zero cost (device-built tables): they are the first n_with_cost entries of d_order[1]
   int *d_edges = nullptr, *d_firstv = nullptr;  // device twins of the host views (device-built tables)
   unsigned long long *d_cost = nullptr;
+  std::list<ShareOrder> shares;  // the shares handed out so far (get_share_order)
 };
 int table_host_views(gm_graph *g, ChunkTable *t);  // gm_tables.hip
+// the share of rank / world under `policy` (round robin: every world-th CHUNK of the order; range: a contiguous run of chunks), cut from
+// dequeue order `which` (0 / 1, or -1 = record order); needs the device twins of the per-record scalars (a device-built table)
+int get_share_order(gm_graph *g, ChunkTable *t, int world, int rank, int policy, int which, const ShareOrder **out);
 
 // k-clique (k = 4): the plan of one rank's share (gm_mine.h "level 1 re-hosted"; built by get_clique_plan, gm_tables.hip).
 // OWNERS are the vertices whose matrices this rank builds and counts: the vertices of its share of the narrow chunk table + its share

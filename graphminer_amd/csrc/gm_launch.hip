@@ -399,6 +399,25 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
     q.row_slot = tb->d_row_slot;
     const long long n = (long long)tb->n;
     long long first = 0, step = 1, count = 0;
+    // dequeue order (tune[6] & 0x4000: plain chunk-id order; & 0x2000: swap the two orders -- ablation only)
+    // measured on R-MAT (one rank): the cliques want the full cost order (4-clique 220.6 -> 208.6 ms, 5-clique 796 -> 589 ms),
+    // the symmetric-graph patterns the locality-preserving heavy-first order at every world size, TC heavy-first for one
+    // rank and the full order for shares
+    const bool clique_pat = pat == PAT_CLIQUE4 || pat == PAT_CLIQUEK;
+    const int which = (((world > 1 && !sym_pat) || clique_pat) ? 1 : 0) ^ ((la->tune[6] & 0x2000) ? 1 : 0);
+    const bool lpt = la->policy == GM_PART_ROUND_ROBIN && tb->d_order[which] && !(la->tune[6] & 0x4000);
+    q.order = lpt ? tb->d_order[which] : nullptr;
+    if (world > 1 && la->policy != GM_PART_VERTEX && tb->d_edges) {
+      // a rank of a larger job: its records as a list of their own -- every part of a chunk with the same rank (ShareOrder, gm_host.h)
+      const ShareOrder *so = nullptr;
+      if (int rcs = get_share_order(g, tb, world, rank, la->policy, lpt ? which : -1, &so)) { share_rc = rcs; return; }
+      q.first = 0;
+      q.step = 1;
+      q.count = (int)so->n;
+      q.order = so->d;
+      my_edges += so->edges;
+      return;
+    }
     if (la->policy == GM_PART_VERTEX) {  // contiguous chunk range whose first vertex lies in this rank's vertex range
       if (int rcv = table_host_views(g, tb)) { share_rc = rcv; return; }
       const long long vlo = (long long)g->nv * rank / world, vhi = (long long)g->nv * (rank + 1) / world;
@@ -418,14 +437,6 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
     q.first = (int)first;
     q.step = (int)step;
     q.count = (int)count;
-    // dequeue order (tune[6] & 0x4000: plain chunk-id order; & 0x2000: swap the two orders -- ablation only)
-    // measured on R-MAT (one rank): the cliques want the full cost order (4-clique 220.6 -> 208.6 ms, 5-clique 796 -> 589 ms),
-    // the symmetric-graph patterns the locality-preserving heavy-first order at every world size, TC heavy-first for one
-    // rank and the full order for shares
-    const bool clique_pat = pat == PAT_CLIQUE4 || pat == PAT_CLIQUEK;
-    const int which = (((world > 1 && !sym_pat) || clique_pat) ? 1 : 0) ^ ((la->tune[6] & 0x2000) ? 1 : 0);
-    const bool lpt = la->policy == GM_PART_ROUND_ROBIN && tb->d_order[which] && !(la->tune[6] & 0x4000);
-    q.order = lpt ? tb->d_order[which] : nullptr;
     // task edges of the share (gm_stats): the whole table's total came with the table; a share reads the per-chunk host views
     if (first == 0 && step == 1 && count == n) { my_edges += tb->total_edges; return; }
     if (int rcv = table_host_views(g, tb)) { share_rc = rcv; return; }

@@ -14,6 +14,9 @@ static void free_table(ChunkTable &t) {
   if (t.d_edges) (void)hipFree(t.d_edges);
   if (t.d_firstv) (void)hipFree(t.d_firstv);
   if (t.d_cost) (void)hipFree(t.d_cost);
+  for (auto &sh : t.shares)
+    if (sh.d) (void)hipFree(sh.d);
+  t.shares.clear();
   t.d_edges = t.d_firstv = nullptr; t.d_cost = nullptr;
   t.d = nullptr; t.d_slot = nullptr; t.d_row_slot = nullptr; t.d_order[0] = t.d_order[1] = nullptr; t.d_bitmaps = nullptr;
 }
@@ -515,6 +518,86 @@ int table_host_views(gm_graph *g, ChunkTable *t) {
       }
   }
   t->host_ready = true;
+  return GM_OK;
+}
+
+// ---- rank shares with whole chunks (see ShareOrder, gm_host.h) -------------------------------------------------------------------
+// Position pos of the order holds record order[pos]; the parts of a chunk are consecutive records of equal cost, and the stable sorts
+// behind the dequeue orders keep them consecutive and in part order.  head[pos] = the record is part 0; the chunk's ordinal in the
+// order = (inclusive scan of head)[pos] - 1; round robin: ordinal mod world == rank; range: ordinal in the rank's run of the chunks.
+__global__ __launch_bounds__(256) void share_head_kernel(const int n, const ChunkRec *__restrict__ recs, const int *__restrict__ order, int *__restrict__ head) {
+  const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pos < n) head[pos] = recs[order ? order[pos] : pos].part == 0 ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void share_flag_kernel(const int n, const int *__restrict__ head, const int *__restrict__ ord_excl, const int world,
+                                                         const int rank, const long long lo, const long long hi, int *__restrict__ flag) {
+  const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pos >= n) return;
+  const long long ordinal = (long long)ord_excl[pos] + head[pos] - 1;  // the chunk this record is a part of
+  flag[pos] = lo < 0 ? (ordinal % world == rank ? 1 : 0) : (ordinal >= lo && ordinal < hi ? 1 : 0);
+}
+__global__ __launch_bounds__(256) void share_emit_kernel(const int n, const int *__restrict__ order, const int *__restrict__ flag, const int *__restrict__ off,
+                                                         const int *__restrict__ edges, int *__restrict__ out, unsigned long long *__restrict__ edge_sum) {
+  const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long e = 0;
+  if (pos < n && flag[pos]) {
+    const int rec = order ? order[pos] : pos;
+    out[off[pos]] = rec;
+    e = (unsigned long long)edges[rec];
+  }
+  e = gm::wave_sum_u64(e);
+  if ((threadIdx.x & 63) == 0 && e) atomicAdd(edge_sum, e);
+}
+
+int get_share_order(gm_graph *g, ChunkTable *t, int world, int rank, int policy, int which, const ShareOrder **out) {
+  std::lock_guard<std::mutex> lk(g->mu);
+  for (const auto &sh : t->shares)
+    if (sh.world == world && sh.rank == rank && sh.policy == policy && sh.which == which) { *out = &sh; return GM_OK; }
+  if (!t->d_edges) return GM_ERR_UNSUPPORTED;  // (a host-built table: GM_HOST_TABLES devel builds)
+  SetupTimer timer;
+  HIP_TRY(hipSetDevice(g->device));
+  const int n = (int)t->n;
+  ShareOrder sh;
+  sh.world = world; sh.rank = rank; sh.policy = policy; sh.which = which;
+  if (n > 0) {
+    PoolScope pool(g);
+    ScanTemp tmp;
+    DevBuf<int> head, ord, flag, off;
+    DevBuf<unsigned long long> esum;
+    HIP_TRY(head.alloc((size_t)n + 1));
+    HIP_TRY(ord.alloc((size_t)n + 1));
+    HIP_TRY(flag.alloc((size_t)n + 1));
+    HIP_TRY(off.alloc((size_t)n + 1));
+    HIP_TRY(esum.alloc(1));
+    HIP_TRY(hipMemsetAsync(head.p, 0, sizeof(int) * ((size_t)n + 1), 0));
+    HIP_TRY(hipMemsetAsync(flag.p, 0, sizeof(int) * ((size_t)n + 1), 0));
+    HIP_TRY(hipMemsetAsync(esum.p, 0, sizeof(unsigned long long), 0));
+    const int *order = which >= 0 ? t->d_order[which] : nullptr;
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    hipLaunchKernelGGL(share_head_kernel, grid, block, 0, 0, n, t->d, order, head.p);
+    HIP_TRY(dev_exclusive_sum(tmp, head.p, ord.p, (size_t)n + 1));
+    long long lo = -1, hi = -1;
+    if (policy != GM_PART_ROUND_ROBIN) {  // a contiguous run of the CHUNKS (not of the records)
+      int nchunks = 0;
+      HIP_TRY(hipMemcpy(&nchunks, ord.p + n, sizeof(int), hipMemcpyDeviceToHost));
+      lo = (long long)nchunks * rank / world;
+      hi = (long long)nchunks * (rank + 1) / world;
+    }
+    hipLaunchKernelGGL(share_flag_kernel, grid, block, 0, 0, n, head.p, ord.p, world, rank, lo, hi, flag.p);
+    HIP_TRY(dev_exclusive_sum(tmp, flag.p, off.p, (size_t)n + 1));
+    int cnt = 0;
+    HIP_TRY(hipMemcpy(&cnt, off.p + n, sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMalloc(&sh.d, sizeof(int) * (size_t)std::max(cnt, 1)));
+    hipLaunchKernelGGL(share_emit_kernel, grid, block, 0, 0, n, order, flag.p, off.p, t->d_edges, sh.d, esum.p);
+    if (hipMemcpy(&sh.edges, esum.p, sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) {
+      (void)hipFree(sh.d);
+      return hip_fail(hipGetLastError(), "share order", __FILE__, __LINE__);
+    }
+    sh.n = cnt;
+  }
+  t->shares.push_back(sh);
+  *out = &t->shares.back();
+  g->setup.table_ms += timer.ms();
   return GM_OK;
 }
 

@@ -1117,3 +1117,30 @@ def test_orientation_around_the_byte_cap_of_the_degrees(dev, two_gathers, monkey
     assert TCSolver(dag) == math.comb(nh, 3)
     dag.free()
     sym.free()
+
+
+@pytest.mark.parametrize("world,policy", [(2, 0), (3, 0), (8, 0), (4, 1)])
+def test_rank_shares_of_separate_handles_add_up(dev, world, policy):
+    """What a real N-GPU job does and the in-process share tests of rounds 2 - 4 did not: every rank builds ITS OWN task lists (their
+    order inside a host is the order in which the placement's atomics arrived -- different on every build) and takes its share of the
+    chunks.  A heavy chunk is cut into parts = every nparts-th batch of the host's task list: parts of one chunk split between two
+    ranks would each cut their own order, and the shares would not add up (round 5: bench.py --gpus 2 on R-MAT-22 counted 750,563,783
+    triangles for 750,506,260).  All parts of a chunk go to one rank now (ShareOrder, gm_host.h).  One handle per rank here, parts
+    forced on a small graph (tune[6] & 0x1000); several builds, because an order of arrival can coincide."""
+    g = rmat_csr_numpy(15, 24, seed=11)
+    osym = O.OGraph(g.row_ptr, g.col_idx)
+    odag = O.orient(osym)
+    want_tc, want_m3 = O.tc(odag), O.motif3(osym)
+    parts = [0, 0, 0, 0, 0, 0, 0x1000]
+    for attempt in range(3):
+        syms = [g.to_device(dev) for _ in range(world)]
+        dags = [s.orient() for s in syms]
+        try:
+            assert sum(TCSolver(dags[r], rank=r, world=world, policy=policy, tune=parts) for r in range(world)) == want_tc, attempt
+            assert sum(TCSolver(dags[r], rank=r, world=world, policy=policy) for r in range(world)) == want_tc, attempt
+            got = [MotifSolver(syms[r], 3, rank=r, world=world, policy=policy, tune=parts) for r in range(world)]  # (formula: partials mod 2^64)
+            assert [sum(x[i] for x in got) % 2**64 for i in range(2)] == want_m3, attempt
+            assert sum(CliqueSolver(dags[r], 4, rank=r, world=world, policy=policy, tune=parts) for r in range(world)) == O.clique(odag, 4)
+        finally:
+            for h in dags + syms:
+                h.free()
