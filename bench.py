@@ -65,22 +65,22 @@ BASELINE_CONFIGS = [
 ]
 # rocprofv3 kernel names that make up one launch of a workload (everything between the library's two timing events)
 KERNELS = {
-    "tc": ["mine_kernel<0,", "tct_kernel", "tch_kernel"],   # (tch_kernel: the shorter list of every edge streamed against a hashed set, gm_tch.hip)
+    "tc": ["tch_kernel", "mine_kernel<0,"],   # (tch_kernel: the shorter list of every edge streamed against a hashed set, gm_tch.hip; mine_kernel<0>: rows beyond its stage)
     # general kernel <P, 0> (+ the sorted-copy classes <P, 1>, <P, 2>), the hashed-row classes and the kernel of the giant rows
     # (one GPU: edge supports from the DAG's triangles, gm_sup.hip; several ranks: the per-edge kernels)
-    "diamond": ["gm::sup_kernel", "gm::sup_pairs_kernel", "mine_kernel<1,", "hrow_kernel<1,", "giant_kernel<1,"],
+    "diamond": ["gm::sup_kernel", "gm::sup_near_kernel", "gm::sup_far_kernel", "gm::sup_long_kernel", "gm::sup_pairs_kernel", "mine_kernel<1,", "hrow_kernel<1,", "giant_kernel<1,"],
     # (gm_motif, k = 3: the triangles of the DAG + wedges = sum C(d,2) - 3T; "motif3e": one bounded intersection per edge of the symmetric graph)
-    "motif3": ["mine_kernel<0,", "tct_kernel", "tch_kernel"],
+    "motif3": ["tch_kernel", "mine_kernel<0,"],
     "motif3e": ["mine_kernel<2,", "hrow_kernel<2,", "giant_kernel<2,"],
-    "clique4": ["mine_kernel<3,", "cbuild_kernel", "cgather_kernel", "clique_mma_kernel", "clique_count_kernel", "clique_small_kernel"],
+    "clique4": ["cgather_kernel", "cbuild_kernel", "clique_mma_kernel", "clique_small_kernel", "mine_kernel<3,"],
     "clique5": ["mine_kernel<4,"],
-    "motif3f": ["mine_kernel<0,", "tct_kernel", "tch_kernel"],
+    "motif3f": ["tch_kernel", "mine_kernel<0,"],
     "rectangle": ["rect_acc_kernel"],
     "house": ["house_acc_kernel"],
     "pentagon": ["pent_acc_kernel"],
     # (gm_motif, k = 4: per-edge sums of the symmetric graph + rectangle by wedge accumulation + 4-clique of the oriented copy)
     "motif4": ["mine_kernel<5,", "hrow_kernel<5,", "giant_kernel<5,", "rect_acc_kernel", "mine_kernel<3,", "cbuild_kernel", "cgather_kernel", "clique_mma_kernel",
-               "clique_count_kernel", "clique_small_kernel", "tch_kernel"],
+               "clique_small_kernel", "tch_kernel"],
 }
 TRAFFIC_MARKER = "issue_calib_kernel"  # the dispatch in front of every workload of the traffic worker (measure_traffic)
 DIAMOND_SUPPORTS_MAX_WORLD = int(os.environ.get("GM_DIAMOND_SUPPORTS_MAX_WORLD", "4"))  # (graphminer_amd/host/multi.cc has the same rule)
@@ -123,6 +123,15 @@ def parse():
 # ---------------------------------------------------------------------------------------------------------------
 # graphs
 # ---------------------------------------------------------------------------------------------------------------
+_T0 = time.perf_counter()
+
+
+def progress(msg):
+    """phase marks on stderr (rank 0): where a long run is, and where a stuck one stopped"""
+    if os.environ.get("RANK", "0") == "0":
+        print(f"[bench +{time.perf_counter() - _T0:7.1f} s] {msg}", file=sys.stderr, flush=True)
+
+
 def flush_c_stdio():
     """fflush(NULL): whatever native libraries left in the C stdio buffers of this process goes out now"""
     try:
@@ -635,6 +644,7 @@ class Runner:
 # ---------------------------------------------------------------------------------------------------------------
 def traffic_worker(a):
     """Child of measure_traffic(): runs every requested workload (1 warm-up + `steps` launches), prints the launch counts."""
+    a.first_call_repeats = 0  # (the child's launches are counted: steps + 1 per workload, nothing else of the same kernels)
     r = Runner(a)
     todo = [w for w in (a.configs.split(",") if a.configs != "all" else ["tc", "diamond", "clique4", "motif3"])]
     graphs, launches = {}, {}
@@ -813,6 +823,7 @@ def cpu_baselines(a, r, recs, graphs):
         prefixes = {}
         for rec in recs:
             w, bg = rec["workload"], graphs[rec["workload"]]
+            progress(f"  cpu baseline of {w}")
             try:
                 if w in ("tc", "diamond"):
                     if bg.name not in prefixes:
@@ -1152,6 +1163,7 @@ def main():
             keep[key] = build_graph(a, r.local_rank, scale, ef, prefix)
         bg = keep[key]
         graphs[w] = bg
+        progress(f"config {cid} {w} on {bg.name}: {a.warmup} + {a.steps} steps")
         rec = r.run(w, bg, a.steps, a.warmup)
         rec.update({"id": cid, "config": desc, "graph": bg.name, "input_build_s": bg.build_s})
         if rank == 0:
@@ -1162,6 +1174,7 @@ def main():
 
     out = None
     if rank == 0:
+        progress("stream ceiling, counter passes")
         stream_gbs = r.stream_ceiling()
         # ---- HBM-side traffic ------------------------------------------------------------------------------------
         traffic, traffic_src = {}, "off"
@@ -1192,12 +1205,14 @@ def main():
                 except Exception:
                     cpu = {}
             if not cpu:
+                progress("CPU baselines (reference binaries on the host cores)")
                 cpu = cpu_baselines(a, r, cpu_recs, graphs)
                 if world == 1 and not r.use_dist and cpu:
                     try:
                         json.dump(cpu, open(cache, "w"))
                     except Exception:
                         pass
+        progress("records")
         subs = []
         for x in recs:
             ab, floor = bytes_of[x["workload"]]
