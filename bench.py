@@ -245,6 +245,21 @@ def kernel_constants():
     return out
 
 
+def tc_core(bg, workload):
+    """the hub corner the triangle count of this graph takes on the matrix cores (gm_tc_core_info, after a launch): tc -> the DAG handle,
+    motif3 -> the symmetric handle (its cached oriented copy)"""
+    try:
+        from graphminer_amd.solvers import tc_core_info
+
+        if workload == "tc":
+            return tc_core_info(bg.dag())
+        if workload in ("motif3", "motif3f"):
+            return tc_core_info(bg.sym)
+    except Exception:
+        pass
+    return None
+
+
 def own_bytes_device(workload, bg, world=1):
     """OWN-ALGORITHM bytes of one launch over the whole graph: what THIS library's kernels must move by
     construction -- the keys they stream, the task descriptors, every row staged / hashed once, the offsets, the k-clique arena
@@ -301,8 +316,26 @@ def own_bytes_device(workload, bg, world=1):
             # a row beyond the stage hosts nothing, and its own out-edges stream N+(v) on the chunked kernel
             u_hosts = (dv > TCT_STAGE_MAX) | (tail >= dv)
             streamed = torch.where(du > TCT_STAGE_MAX, dv, torch.where(u_hosts, dv, tail))
+            # the hub corner (gm_ctc.hip): the out-edges of the last H vertices of the renumbered DAG are no tasks of the stream -- one masked
+            # bit-matrix product instead: every 256 x 256 block pair IB <= JB stages 2 x 256 rows x 64 B per 512-column chunk from JB / 2 on
+            core = tc_core(bg, workload)
+            corner_bytes, corner_keys = 0, 0
+            if core and core["h"] > 0:
+                in_corner = new_u >= nv - core["h"]
+                corner_keys = int(streamed[in_corner].sum().item())
+                streamed = torch.where(in_corner, torch.zeros_like(streamed), streamed)
+                if core["h"] % 512 == 0:
+                    nb, nc = core["h"] // 256, core["h"] // 512
+                    corner_bytes = sum((jb + 1) * (nc - jb // 2) for jb in range(nb)) * 32768
+                else:
+                    nj, wt = (core["h"] + 63) // 64, (core["h"] + 31) // 32
+                    corner_bytes = sum((jb + 1) * max((wt + 1) // 2 - jb, 0) for jb in range(nj)) * 1024
             k = int(streamed.sum().item())
-            return {"bytes": 4 * k + fixed, "streamed_keys": k, "parts": {"streamed_keys_x4": 4 * k, "task_descriptors_and_rows_12_per_edge": 12 * ne, "offsets": 8 * (nv + 1)}}
+            parts = {"streamed_keys_x4": 4 * k, "task_descriptors_and_rows_12_per_edge": 12 * ne, "offsets": 8 * (nv + 1)}
+            if core and core["h"] > 0:
+                parts.update({"corner_operand_chunks": corner_bytes, "corner_h": core["h"], "corner_edges": core["edges"],
+                              "keys_the_corner_edges_would_stream": corner_keys})
+            return {"bytes": 4 * k + fixed + corner_bytes, "streamed_keys": k, "parts": parts}
         # 4-clique (gm_cbuild.hip / gm_cgather.hip / gm_cmma.hip): u OWNS a bit-matrix when 3 <= d+(u) <= 2048.
         #  * a WIDE owner (matrix > 2048 words: d+ > 256) on a topologically numbered DAG takes its rows whose first endpoint lies in the hub
         #    core (the last core_h ids) by GATHER from the dense core bitmap: bytes by construction = the distinct 4-byte words that hold

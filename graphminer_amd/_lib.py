@@ -100,6 +100,7 @@ SYMBOLS = [
     ("gm_issue_calib", C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("gm_diamond_support_size", C.c_int, [_P, C.c_int, C.POINTER(C.c_int64)]),
     ("gm_diamond_support_info", C.c_int, [_P, C.POINTER(C.c_int64)]),
+    ("gm_tc_core_info", C.c_int, [_P, C.POINTER(C.c_int64)]),
     ("gm_diamond_support_partial", C.c_int, [_P, C.POINTER(gm_launch), _P, C.c_int64, C.POINTER(gm_stats)]),
     ("gm_diamond_support_finish", C.c_int, [_P, C.POINTER(gm_launch), _P, C.c_int64, C.POINTER(C.c_uint64), C.POINTER(gm_stats)]),
     ("gm_constant", C.c_int, [C.c_char_p, C.POINTER(C.c_int64)]),

@@ -136,6 +136,7 @@ int finish_handle(gm_graph *g) {
     gm_touch_cbuild();
     gm_touch_cmma();
     gm_touch_cgather();
+    gm_touch_ctc();
     gm_touch_sgl();
     gm_touch_tables();
     gm_touch_launch();

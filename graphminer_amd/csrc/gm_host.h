@@ -337,6 +337,11 @@ struct gm_graph {
   unsigned *d_core = nullptr;
   int core_h = 0, core_base = 0;       // core_h = 0: not built / not applicable (ensure_core_bitmap)
   int core_state = 0;                  // 0 unknown, 1 built, 2 not applicable
+  // triangle count: the out-edges of the last tc_core_h vertices are counted on the matrix cores from the corner of d_core (gm_ctc.hip) and
+  // the key stream / the longer lists of this handle hold no task of a row >= kst_skip_from (ensure_keystream); 0 / nv: no such corner
+  int tc_core_h = 0;
+  int kst_skip_from = 0x7fffffff;
+  long long tc_core_edges = 0;         // entries of the rows >= kst_skip_from
   hipStream_t aux_stream[3] = {nullptr, nullptr, nullptr};  // class kernels that cannot fill the chip run beside the others (run_pattern)
   hipEvent_t aux_done[3] = {nullptr, nullptr, nullptr};
   TempPool pool;  // temporaries of the setup paths (PoolScope)
@@ -457,6 +462,7 @@ void gm_touch_sup();
 void gm_touch_cbuild();
 void gm_touch_cmma();
 void gm_touch_cgather();
+void gm_touch_ctc();
 void gm_touch_sgl();
 void gm_touch_tables();
 void gm_touch_launch();
@@ -476,7 +482,7 @@ int get_table(gm_graph *g, int target, bool allow_split, int bit_words, unsigned
               const RowFilter &rf = RowFilter(), int bitmap_min_deg = kBitmapMinDeg);
 int ensure_edesc(gm_graph *g);
 int ensure_tasklists(gm_graph *g, bool with_edges = false);
-int ensure_keystream(gm_graph *g, bool edges, bool *built);
+int ensure_keystream(gm_graph *g, bool edges, bool *built, bool allow_core = false);  // allow_core: the rows of the hub core may stay out (gm_ctc.hip)
 int sup_mask_min_tail();            // (gm_tables.hip) kSupMaskMinTail or GM_SUP_MASK_MIN
 int ensure_sup_masks(gm_graph *g);  // (gm_tables.hip) d_emoff / d_tmoff / d_smask of a topologically numbered DAG with task lists; GM_OK also when not applicable
 int ensure_mean_sq_deg(gm_graph *g);

@@ -239,7 +239,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
       else sup_stream = ensure_mean_sq_deg(g) == GM_OK && g->mean_sq_deg < (double)kTopoMinMeanRow;
     }
     if ((sup_stream || !support) && !(la->tune[6] & 0x20000000)) {
-      const int rc_k = ensure_keystream(g, support, &use_kst);
+      const int rc_k = ensure_keystream(g, support, &use_kst, !support && !tct_long);  // (the triangle count: the hub corner may stay out, gm_ctc.hip)
       if (rc_k) return rc_k;
     }
     if (!use_kst) {
@@ -264,7 +264,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
   ChunkTable *tab_big = nullptr;
   if (split_stage) {
     RowFilter rb;
-    rb.tct = 1;
+    rb.tct = (use_kst && !support && g->kst_skip_from < g->nv) ? 2 : 1;
     rb.only_lo = kStageCap;
     rb.only_hi = kTctStageMax;
     const int rc_b = get_table(g, target, true, 0, part_cap, kTctStageMax, &tab_big, rb, kBitmapMinDeg);
@@ -275,8 +275,10 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
       tct_stage = kTctStageMax;
     }
   }
+  // the triangles of the hub corner on the matrix cores (gm_ctc.hip): this handle's key stream holds no task of the corner's rows
+  const bool tc_core = use_kst && !support && g->kst_skip_from < g->nv;
   RowFilter rf;
-  rf.tct = use_tct ? 1 : 0;
+  rf.tct = use_tct ? (tc_core ? 2 : 1) : 0;
   if (tct_long) { rf.skip_lo = kTctStageMax; rf.skip_hi = 0x7fffffff; }
   if (split_stage) { rf.skip_lo = kStageCap; rf.skip_hi = 0x7fffffff; }  // (this table: the hosts whose rows fit the 1024-entry stage)
   // 4-clique: the first level is re-hosted (gm_cbuild.hip) for every vertex whose row fits its stage -- the narrow chunk table and
@@ -796,6 +798,21 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
       if (q.count > 0) HIP_TRY(launch_tch(q, kTctStageMax, (int)std::max<long long>(1, std::min<long long>(q.count, (long long)g->cu_count * tch_per_cu(kTctStageMax))), stream));
     }
     if (p.count > 0) HIP_TRY(launch_tch(p, tct_stage, (int)std::max<long long>(1, std::min<long long>(want, (long long)g->cu_count * tch_per_cu(tct_stage))), stream));
+    if (tc_core) {  // the out-edges of the hub corner: one masked bit-matrix product; a rank takes every world-th block
+      CoreTcParams cp;
+      cp.core = g->d_core;
+      cp.row_words = (g->core_h + 31) / 32;
+      cp.row0 = g->kst_skip_from - g->core_base;
+      cp.word0 = cp.row0 >> 5;
+      cp.h = g->tc_core_h;
+      cp.ntasks = 0;
+      cp.first = rank;
+      cp.step = world;
+      cp.queue = reinterpret_cast<unsigned *>(g->d_counters + 4) + 4;  // (its own dequeue word inside the zeroed 64-byte block)
+      cp.counters = g->d_counters;
+      HIP_TRY(launch_core_tc(cp, g->cu_count, stream));
+      // (gm_stats.tasks: a table's task edges are its rows' entries -- the corner's rows are chunks of the table like any other)
+    }
   } else if (p.count > 0) HIP_TRY(launch_mine(pat, p, grid, stream));
 #ifdef GM_DEBUG_CHUNKS
   {
@@ -949,6 +966,21 @@ static int run_tc(const gm_graph *dag, const gm_launch *la, uint64_t *out, int n
 }
 
 extern "C" int gm_tc(const gm_graph *dag, const gm_launch *la, uint64_t *total, gm_stats *st) { return run_tc(dag, la, total, 1, st); }
+// tooling (the byte model of bench.py, tests): the hub corner the triangle count of this handle takes on the matrix cores (after a first gm_tc)
+extern "C" int gm_tc_core_info(const gm_graph *dag, int64_t info[4]) {
+  if (!dag || !info) return GM_ERR_INVALID;
+  gm_graph *run_on = nullptr;
+  // (a symmetric handle: the oriented copy its formula 3-motif counts the triangles of)
+  const int rc = topo_view(dag->dag_cache ? dag->dag_cache : dag, nullptr, &run_on);
+  if (rc) return rc;
+  const bool on = run_on->kst_skip_from < run_on->nv;
+  const long long nJ = on ? (run_on->tc_core_h + 63) >> 6 : 0;
+  info[0] = on ? run_on->tc_core_h : 0;           // vertices of the corner (0: every edge is a task of the key stream)
+  info[1] = on ? run_on->tc_core_edges : 0;       // DAG entries inside it
+  info[2] = nJ * (nJ + 1) / 2;                    // 64 x 64 blocks of the masked product
+  info[3] = on ? run_on->core_h : 0;              // vertices of the core bitmap the corner is a part of
+  return GM_OK;
+}
 
 // rectangle, flattened over wedges (rect_flat_kernel in gm_mine.hip)
 static int ensure_idx0(gm_graph *g, const GraphView &gv) {

@@ -325,6 +325,25 @@ struct CGatherParams {
 hipError_t launch_cgather(const CGatherParams &p, int grid_blocks, hipStream_t stream);
 int cgather_per_cu();
 
+// ---- triangle count: the triangles of the hub core on the matrix cores (gm_ctc.hip) ---------------------------------------------------
+// The corner of the core bitmap that holds the out-edges of the LAST h vertices, sum_{i,j} M_ij (M M^T)_ij over 64 x 64 blocks of (i, j):
+// one wave per block, blocks dealt by a dequeue word, t = first + q * step for a rank's share.
+constexpr int kCtcWaves = 4;
+constexpr int kCtcMaxH = 32768;        // f32 accumulators stay exact; the core bitmap (kCoreHDefault) is no larger
+constexpr int kTcCoreHDefault = 32768; // the largest corner considered (tc_core_size, gm_tables.hip: by density); GM_TC_CORE_H overrides
+struct CoreTcParams {
+  const unsigned *core;      // the core bitmap (gm_host.h d_core): row_words words per row
+  int row_words;
+  int row0, word0;           // the corner: first row of the bitmap, first word of its rows
+  int h;                     // vertices of the corner
+  int ntasks;                // blocks (x pieces of their column range): filled in by launch_core_tc
+  int first, step;           // this launch takes the tasks first + q * step (rank, world)
+  unsigned *queue;           // dequeue word (zeroed before launch)
+  unsigned long long *counters;
+};
+hipError_t launch_core_tc(CoreTcParams p, int cu_count, hipStream_t stream);
+bool core_tc_fast_path(const CoreTcParams &p);
+
 // ---- the same counts on the matrix cores (gm_cmma.hip; the default since round 4, tune[6] & 0x20000: the vector-ALU classes above) ----
 // sum_{i,j} M_ij (M M^T)_ij as FP4 MFMA over 64 x 64 blocks of (i, j).  LDS copy: rows padded to a multiple of 64, row stride = the
 // (even) block width rounded up to 2 mod 4 words, so that the 64 lanes of an operand fragment (32 rows x 2 adjacent words) read 64

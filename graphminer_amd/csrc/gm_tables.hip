@@ -314,7 +314,10 @@ __global__ __launch_bounds__(256) void gather_deg_kernel(int m, const int *__res
 static int build_table_device(gm_graph *g, ChunkTable &t, bool sym_table, double &bitmap_ms, const int *trp = nullptr, const int *tlen = nullptr,
                               int tstride = 2) {
   const int *kst_rp = nullptr;
-  if (!trp && g->d_kst_rp) {  // the costs of the triangle count's tables: the key stream + the longer lists
+  // (a stream without the rows of the hub core, gm_ctc.hip, prices the triangle count's own tables -- rf.tct == 2 -- only: the edge supports
+  // walk every task)
+  const bool kst_costs = g->d_kst_rp && (g->kst_skip_from >= g->nv ? t.rf.tct != 2 : (t.rf.tct == 2 || !g->d_trp));
+  if (!trp && kst_costs) {  // the costs of the triangle count's tables: the key stream + the longer lists
     trp = g->d_trpl;
     tlen = &g->d_tdescl[0].y;
     tstride = 2;
@@ -878,6 +881,7 @@ struct TaskWalk {
   int nv, stage_max, topo, hub0;  // hosts >= hub0 are aggregated in LDS (nv: none)
   const int *rp, *col;
   const int2 *edesc;
+  int skip_from = 0x7fffffff;     // the out-edges of the rows >= skip_from are no tasks (the triangle count takes them from the core bitmap, gm_ctc.hip)
 };
 // calls f(u, i, e, ru, du, dv, tail, u_hosts) for every task edge of the rows this workgroup walks (all 64 lanes of a wave stay together:
 // f may use wave ballots; `act` = the lane holds a task)
@@ -892,7 +896,7 @@ __device__ __forceinline__ void task_walk(const TaskWalk &w, F f) {
     if (u < w.nv) {
       ru = w.rp[u];
       du = w.rp[u + 1] - ru;
-      if (du > w.stage_max) du = 0;  // a row the stage cannot take hosts nothing, and its out-edges stay with the chunked kernel (run_pattern)
+      if (du > w.stage_max || u >= w.skip_from) du = 0;  // a row the stage cannot take hosts nothing, and its out-edges stay with the chunked kernel (run_pattern)
     }
     const int dmax = wave_max_nonneg(du);
     for (int i = sub; i - sub < dmax; i += 8) {  // wave-uniform trip count
@@ -1086,17 +1090,50 @@ __global__ __launch_bounds__(256) void kst_narrow_kernel(int nv, const unsigned 
 // beyond the 32-bit index space at every list limit) -- *built says which
 // edges: with the entries the edge supports need (gm_host.h KeyStream): a handle whose stream was built without them gets a SECOND set of
 // keys / longer lists with them -- same offsets (the counts per host do not depend on the order of arrival), its own order.
-int ensure_keystream(gm_graph *g, bool edges, bool *built) {
+// the hub corner the triangle count takes on the matrix cores (gm_ctc.hip): its size on this handle -- the last h vertices, word-aligned in the
+// core bitmap -- or 0.  The masked product costs h^3 / 6 bit-products whatever the corner holds, the streamed kernel ~rho^2 h^3 / 8 keys for
+// a corner of density rho (|E| = rho h^2 / 2 edges, lists of rho h / 2 keys, half of a list streamed), so the corner pays from a density
+// on: measured (profiles/r05/ab_tc_core.txt) R-MAT-22 at h = 8 K / 16 K / 32 K (11 / 4.5 / 2.0 %): 1.96 / 1.89 / 3.09 ms against 2.47
+// without, R-MAT-24 at 16 K / 32 K (12.7 / 5.4 %): 26.1 / 24.5 against 32.2 -- the largest power-of-two fraction of the core bitmap whose
+// density is >= kTcCoreMinDensity.  GM_TC_CORE_H = 0 switches the corner off, any other value forces that size (tests: small graphs).
+constexpr double kTcCoreMinDensity = 0.03;
+static int tc_core_size(gm_graph *g) {
+  long long want = kTcCoreHDefault;
+  bool forced = false;
+  if (const char *e = getenv("GM_TC_CORE_H")) { want = atoll(e); forced = true; }
+  if (want <= 0 || g->nv < 64) return 0;
+  if (ensure_core_bitmap(g) != GM_OK || g->core_state != 1) return 0;  // (not topologically numbered, no room: everything through the stream)
+  const long long cap = std::min<long long>((long long)g->core_h, (long long)kCtcMaxH);
+  auto aligned = [&](long long h) {  // the corner starts at a word of the bitmap's rows
+    const long long off = ((long long)g->core_h - h + 31) / 32 * 32;
+    return off >= g->core_h ? 0ll : (long long)g->core_h - off;
+  };
+  if (forced) return (int)aligned(std::min(want, cap));
+  // a corner is worth its MFMA pass where the hubs are a small part of the graph: at most a quarter of the vertices, at least 1024 of them
+  for (long long h = cap; h >= 1024; h >>= 1) {
+    if ((long long)g->nv < 4 * h) continue;
+    int e0 = 0;
+    if (hipMemcpy(&e0, g->d_rp + (g->nv - h), sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    const double rho = (double)(g->ne - (long long)e0) / (0.5 * (double)h * (double)h);
+    if (rho >= kTcCoreMinDensity) return (int)aligned(h);
+  }
+  return 0;
+}
+int ensure_keystream(gm_graph *g, bool edges, bool *built, bool allow_core) {
   auto have = [&]() { return g->d_kst_rp != nullptr && (!edges || g->d_kst_et != nullptr); };
   *built = have();
   if (*built || g->kst_state == 2 || g->ne == 0) return GM_OK;
+  // (a stream without the hub corner's rows cannot carry the edge supports: they take the task lists)
+  if (edges && g->d_kst_rp != nullptr && g->kst_skip_from < g->nv) return GM_OK;
   {
     const int rc = ensure_edesc(g);  // (takes the lock itself)
     if (rc) return rc;
   }
+  const int tc_h = (allow_core && !edges && g->d_kst_rp == nullptr) ? tc_core_size(g) : 0;  // (takes the lock itself)
   std::lock_guard<std::mutex> lk(g->mu);
   *built = have();
   if (*built || g->kst_state == 2) return GM_OK;
+  if (edges && g->d_kst_rp != nullptr && g->kst_skip_from < g->nv) return GM_OK;
   const bool second = g->d_kst_rp != nullptr;  // the offsets exist: only the place pass, into the second set
   int lmax = second ? g->kst_lmax : GM_TC_INLINE_MAX_DEFAULT;
   if (!second) {
@@ -1136,6 +1173,14 @@ int ensure_keystream(gm_graph *g, bool edges, bool *built) {
   TaskWalk tw;
   tw.nv = g->nv; tw.stage_max = kTctStageMax; tw.topo = topo ? 1 : 0;
   tw.rp = g->d_rp; tw.col = g->d_col; tw.edesc = g->d_edesc;
+  const int skip_from = (!second && topo && tc_h > 0) ? g->nv - tc_h : 0x7fffffff;
+  tw.skip_from = skip_from;
+  long long core_edges = 0;
+  if (skip_from < g->nv) {
+    int e0 = 0;
+    HIP_TRY(hipMemcpy(&e0, g->d_rp + skip_from, sizeof(int), hipMemcpyDeviceToHost));
+    core_edges = g->ne - (long long)e0;
+  }
   TaskWalk tw_count = tw, tw_place = tw;
   tw_count.hub0 = topo ? std::max(0, g->nv - win_count) : g->nv;
   tw_place.hub0 = topo ? std::max(0, g->nv - win_place) : g->nv;
@@ -1199,6 +1244,11 @@ int ensure_keystream(gm_graph *g, bool edges, bool *built) {
     g->n_inline_keys = total;
     g->n_long_tasks = nlong;
     g->kst_lmax = lmax;
+    if (skip_from < g->nv) {
+      g->tc_core_edges = core_edges;
+      g->tc_core_h = g->nv - skip_from;
+      g->kst_skip_from = skip_from;
+    }
   }
   if (edges) {
     g->d_tedgel = ed.tedgel;

@@ -54,6 +54,13 @@ def TCSolver(g: DeviceGraph, *, rank=0, world=1, chunk=0, return_stats=False, **
     return (int(total.value), _stats(st)) if return_stats else int(total.value)
 
 
+def tc_core_info(g: DeviceGraph) -> dict:
+    """the hub corner the triangle count of this ORIENTED graph takes on the matrix cores (gm_tc_core_info; after a first TCSolver call)"""
+    info = (C.c_int64 * 4)()
+    _lib.check(_lib.load().gm_tc_core_info(g.handle, info), "gm_tc_core_info")
+    return {"h": int(info[0]), "edges": int(info[1]), "blocks": int(info[2]), "core_h": int(info[3])}
+
+
 def SglSolver(g: DeviceGraph, pattern: str, *, rank=0, world=1, chunk=0, return_stats=False, **kw):
     """Edge-induced subgraph listing on the SYMMETRIC graph; pattern by name (include/pattern.hh:62-78).
 

@@ -174,6 +174,13 @@ int gm_kernel_times(const gm_graph *g, int n, double *ms_out, int *n_out);
 /* TCSolver: total = sum_{(u,v) in DAG} |N+(u) ^ N+(v)|  (src/triangle/omp_base.cc:15-21,
  * src/triangle/gpu_kernels/bs_warp_edge.cuh:2-18). `dag` must be an ORIENTED graph. */
 int gm_tc(const gm_graph *dag, const gm_launch *launch, uint64_t *total, gm_stats *stats);
+/* Tooling (tests, the byte model of bench.py): on a DAG whose hubs are its last ids (the topologically renumbered copy of a graph with long
+ * rows) the triangles whose smallest member is one of the last H vertices are counted as ONE masked bit-matrix product on the matrix
+ * cores (csrc/gm_ctc.hip: sum_{i<j, M_ij} popc(M_i & M_j) over the H x H corner of the adjacency matrix -- the loop of omp_base.cc:15-21 on
+ * bit rows) and the streamed kernel takes every other edge.  After a first gm_tc: info[0] = H (0: no such corner on this handle),
+ * info[1] = DAG entries inside the corner, info[2] = 64 x 64 blocks of the product, info[3] = vertices of the core bitmap.
+ * GM_TC_CORE_H in the environment (read when the handle's key stream is built): 0 = off, any other value = that H. */
+int gm_tc_core_info(const gm_graph *dag, int64_t info[4]);
 
 /* SglSolver: edge-induced subgraph listing on the SYMMETRIC graph, pattern by NAME
  * (include/pattern.hh:62-78). Implemented: "diamond" (src/sgl/cpu_kernels/diamond.h:1-14,
