@@ -65,23 +65,24 @@ BASELINE_CONFIGS = [
 ]
 # rocprofv3 kernel names that make up one launch of a workload (everything between the library's two timing events)
 KERNELS = {
-    "tc": ["tch_kernel", "mine_kernel<0,"],   # (tch_kernel: the shorter list of every edge streamed against a hashed set, gm_tch.hip; mine_kernel<0>: rows beyond its stage)
+    "tc": ["tch_kernel", "mine_kernel<0,", "core_tc_"],   # (core_tc_*: the triangles of the hub corner on the matrix cores, gm_ctc.hip; tch_kernel: the shorter list of every edge streamed against a hashed set, gm_tch.hip; mine_kernel<0>: rows beyond its stage)
     # general kernel <P, 0> (+ the sorted-copy classes <P, 1>, <P, 2>), the hashed-row classes and the kernel of the giant rows
     # (one GPU: edge supports from the DAG's triangles, gm_sup.hip; several ranks: the per-edge kernels)
-    "diamond": ["gm::sup_kernel", "gm::sup_near_kernel", "gm::sup_far_kernel", "gm::sup_long_kernel", "gm::sup_pairs_kernel", "mine_kernel<1,", "hrow_kernel<1,", "giant_kernel<1,"],
+    "diamond": ["core_tc_", "gm::sup_kernel", "gm::sup_near_kernel", "gm::sup_far_kernel", "gm::sup_long_kernel", "gm::sup_pairs_kernel", "mine_kernel<1,", "hrow_kernel<1,", "giant_kernel<1,"],
     # (gm_motif, k = 3: the triangles of the DAG + wedges = sum C(d,2) - 3T; "motif3e": one bounded intersection per edge of the symmetric graph)
-    "motif3": ["tch_kernel", "mine_kernel<0,"],
+    "motif3": ["tch_kernel", "mine_kernel<0,", "core_tc_"],
     "motif3e": ["mine_kernel<2,", "hrow_kernel<2,", "giant_kernel<2,"],
     "clique4": ["cgather_kernel", "cbuild_kernel", "clique_mma_kernel", "clique_small_kernel", "mine_kernel<3,"],
     "clique5": ["mine_kernel<4,"],
-    "motif3f": ["tch_kernel", "mine_kernel<0,"],
+    "motif3f": ["tch_kernel", "mine_kernel<0,", "core_tc_"],
     "rectangle": ["rect_acc_kernel"],
     "house": ["house_acc_kernel"],
     "pentagon": ["pent_acc_kernel"],
     # (gm_motif, k = 4: per-edge sums of the symmetric graph + rectangle by wedge accumulation + 4-clique of the oriented copy)
     "motif4": ["mine_kernel<5,", "hrow_kernel<5,", "giant_kernel<5,", "rect_acc_kernel", "mine_kernel<3,", "cbuild_kernel", "cgather_kernel", "clique_mma_kernel",
-               "clique_small_kernel", "tch_kernel"],
+               "clique_small_kernel", "tch_kernel", "core_tc_"],
 }
+CORNER_KERNEL = "core_tc_"  # (the MFMA kernels of gm_ctc.hip: their time and traffic are taken out of the HBM roofline of the streamed kernels)
 TRAFFIC_MARKER = "issue_calib_kernel"  # the dispatch in front of every workload of the traffic worker (measure_traffic)
 DIAMOND_SUPPORTS_MAX_WORLD = int(os.environ.get("GM_DIAMOND_SUPPORTS_MAX_WORLD", "4"))  # (graphminer_amd/host/multi.cc has the same rule)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (~6.3 TB/s achievable by a stream)
@@ -260,7 +261,7 @@ def tc_core(bg, workload):
     return None
 
 
-def own_bytes_device(workload, bg, world=1):
+def own_bytes_device(workload, bg, world=1, core_override=None):
     """OWN-ALGORITHM bytes of one launch over the whole graph: what THIS library's kernels must move by
     construction -- the keys they stream, the task descriptors, every row staged / hashed once, the offsets, the k-clique arena
     written and read once -- exact, with torch on the GPU. `roofline.achieved` = this / kernel time, so `frac` <= 1 by construction
@@ -318,13 +319,16 @@ def own_bytes_device(workload, bg, world=1):
             streamed = torch.where(du > TCT_STAGE_MAX, dv, torch.where(u_hosts, dv, tail))
             # the hub corner (gm_ctc.hip): the out-edges of the last H vertices of the renumbered DAG are no tasks of the stream -- one masked
             # bit-matrix product instead: every 256 x 256 block pair IB <= JB stages 2 x 256 rows x 64 B per 512-column chunk from JB / 2 on
-            core = tc_core(bg, workload)
+            core = core_override if core_override is not None else tc_core(bg, workload)
             corner_bytes, corner_keys = 0, 0
             if core and core["h"] > 0:
                 in_corner = new_u >= nv - core["h"]
                 corner_keys = int(streamed[in_corner].sum().item())
                 streamed = torch.where(in_corner, torch.zeros_like(streamed), streamed)
-                if core["h"] % 512 == 0:
+                if core.get("whole_column_range"):  # the edge supports: (A A)_ij over every column chunk, + the positions and the adds
+                    nb, nc = core["h"] // 256, core["h"] // 512
+                    corner_bytes = nb * (nb + 1) // 2 * nc * 32768 + 10 * core["edges"]
+                elif core["h"] % 512 == 0:
                     nb, nc = core["h"] // 256, core["h"] // 512
                     corner_bytes = sum((jb + 1) * (nc - jb // 2) for jb in range(nb)) * 32768
                 else:
@@ -379,7 +383,10 @@ def own_bytes_device(workload, bg, world=1):
             from graphminer_amd import SglSolver, TCSolver, _lib
 
             del src, dst
-            tcp = own_bytes_device("tc", bg)
+            SglSolver(bg.sym, "diamond")
+            cinfo = (C.c_int64 * 4)()
+            _lib.check(_lib.load().gm_sup_core_info(bg.sym.handle, cinfo), "gm_sup_core_info")
+            tcp = own_bytes_device("tc", bg, core_override={"h": int(cinfo[0]), "edges": int(cinfo[1]), "whole_column_range": True})
             tri = int(TCSolver(dag))
             nd = int(dag.E())
             # the streamed edges: match masks where the library uses them (round 5, gm_sup.hip: in-edge tasks store which keys of their tail
@@ -630,6 +637,8 @@ class Runner:
         else:
             kms = g.kernel_times_ms(min(steps, 64))
             k_avg = sum(kms) / max(len(kms), 1)
+        cms = g.corner_times_ms(min(2 * steps if dstate["on"] else steps, 64))
+        corner_avg = sum(cms) / max(len(cms) // (2 if dstate["on"] else 1), 1)
         per_gpu = [k_avg]
         if use_dist:  # per-GPU kernel time, as the reference prints runtime[gpu i] (src/clique/multigpu.cu:136-137)
             tk = torch.zeros(self.world, dtype=torch.float64, device=self.dev)
@@ -643,7 +652,7 @@ class Runner:
         return {
             "workload": workload, "g": g, "tasks": tasks, "elapsed": elapsed, "steps": steps,
             "ms_per_step": 1e3 * elapsed / steps, "count": result[:2] if workload.startswith("motif3") else (result[:6] if workload == "motif4" else result[0]),
-            "kernel_ms_avg": k_avg, "per_gpu_kernel_ms": per_gpu, "first_call_ms": median([x["first_call_ms"] for x in first_runs]), "setup_ms": setup,
+            "kernel_ms_avg": k_avg, "corner_ms_avg": corner_avg, "per_gpu_kernel_ms": per_gpu, "first_call_ms": median([x["first_call_ms"] for x in first_runs]), "setup_ms": setup,
             "first_call_runs_ms": [round(x["first_call_ms"], 2) for x in first_runs],
             # graph resident in HBM -> first count: the first call (builds tables, renumbered copies, task lists, runs once) + the orientation
             # of a DAG workload, which bench.py asks for before the call (the symmetric-graph solvers orient inside their first call)
@@ -978,6 +987,28 @@ def finish_record(rec, a, world, ab, floor, traffic, traffic_src, cpu, known, st
         alg_gbs = per_launch / t / 1e9
         roof.update({"algorithmic_bytes_per_launch": int(per_launch), "algorithmic_GBs": round(alg_gbs, 2),
                      "algorithmic_frac": round(alg_gbs / HBM_PEAK_GBS, 5)})
+    # A launch with a hub-corner kernel on the matrix cores (gm_ctc.hip): the HBM roofline is the STREAMED kernels' -- their counter traffic over
+    # their time (launch - corner, both HIP events of the library); the corner kernel is reported beside it against the dense FP4 MFMA peak
+    corner_ms = float(rec.get("corner_ms_avg") or 0.0)
+    t_launch = t
+    if corner_ms > 0 and corner_ms < rec["kernel_ms_avg"]:
+        t = (rec["kernel_ms_avg"] - corner_ms) * 1e-3
+        ctr = {"ms": round(corner_ms, 4), "bound": "mfma", "peak": 10000.0, "unit": "TFLOP/s (dense FP4, v_mfma_scale_f32_32x32x64_f8f6f4)"}
+        if own is not None and own.get("parts", {}).get("corner_operand_chunks"):
+            mf = own["parts"]["corner_operand_chunks"] // 32768 * 512  # MFMA instructions: 8 waves x 64 per (block pair, chunk)
+            ctr.update({"mfma_instructions": int(mf), "achieved": round(mf * 131072 / (corner_ms * 1e-3) / 1e12, 1)})
+            ctr["frac"] = round(ctr["achieved"] / ctr["peak"], 4)
+        if traffic and traffic.get("kernels"):
+            cb = sum(v.get("FETCH_SIZE", 0) * 2048.0 + v.get("WRITE_SIZE", 0) * 1024.0 for k, v in traffic["kernels"].items() if CORNER_KERNEL in k)
+            ctr["traffic"] = int(cb)
+            traffic = dict(traffic)
+            traffic["fetch_bytes"] = sum(v.get("FETCH_SIZE", 0) * 2048.0 for k, v in traffic["kernels"].items() if CORNER_KERNEL not in k)
+            traffic["write_bytes"] = sum(v.get("WRITE_SIZE", 0) * 1024.0 for k, v in traffic["kernels"].items() if CORNER_KERNEL not in k)
+        roof["corner_kernel"] = ctr
+        roof["streamed_kernels_ms"] = round(t * 1e3, 4)
+        roof["kernel"] = " + ".join(k for k in roof["kernel"].split(" + ") if CORNER_KERNEL not in k) + "  (HBM roofline of the streamed kernels; corner_kernel: the MFMA part)"
+        if own is not None and own.get("parts", {}).get("corner_operand_chunks"):
+            own = dict(own, bytes=own["bytes"] - own["parts"]["corner_operand_chunks"])
     tr_gbs = None
     if traffic:
         tb = traffic.get("fetch_bytes", 0.0) + traffic.get("write_bytes", 0.0)
@@ -1116,8 +1147,12 @@ SHORT_BASIS = (("counter traffic", "counter_traffic: rocprofv3 --pmc FETCH_SIZE 
 def compact_roofline(r):
     """the roofline object of the stdout line: the contract's keys + the three byte figures, no prose"""
     keys = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "own_bytes_per_launch", "own_frac", "algorithmic_bytes_per_launch",
-            "algorithmic_GBs", "frac_8d_valid", "compulsory_floor_bytes", "stream_ceiling_GBs", "frac_of_stream_ceiling")
+            "algorithmic_GBs", "frac_8d_valid", "compulsory_floor_bytes", "stream_ceiling_GBs", "frac_of_stream_ceiling", "streamed_kernels_ms")
     out = {k: r[k] for k in keys if k in r}
+    if "kernel" in out:
+        out["kernel"] = out["kernel"][:96]
+    if r.get("corner_kernel"):
+        out["corner_kernel"] = {k: r["corner_kernel"][k] for k in ("ms", "bound", "achieved", "peak", "frac", "traffic") if k in r["corner_kernel"]}
     basis = r.get("frac_basis") or ""
     out["frac_basis"] = next((short for head, short in SHORT_BASIS if basis.startswith(head)), basis[:80])
     return out

@@ -85,6 +85,7 @@ SYMBOLS = [
     ("gm_chunk_table", C.c_int, [C.c_int32, _P, C.c_int32, C.c_int32, _P, C.c_int64, C.POINTER(C.c_int64)]),
     ("gm_graph_setup_times", C.c_int, [_P, C.POINTER(gm_setup_times)]),
     ("gm_kernel_times", C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    ("gm_corner_times", C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     ("gm_tc", C.c_int, [_P, C.POINTER(gm_launch), C.POINTER(C.c_uint64), C.POINTER(gm_stats)]),
     ("gm_sgl", C.c_int, [_P, C.c_char_p, C.POINTER(gm_launch), C.POINTER(C.c_uint64), C.POINTER(gm_stats)]),
     ("gm_clique", C.c_int, [_P, C.c_int, C.POINTER(gm_launch), C.POINTER(C.c_uint64), C.POINTER(gm_stats)]),
@@ -101,6 +102,7 @@ SYMBOLS = [
     ("gm_diamond_support_size", C.c_int, [_P, C.c_int, C.POINTER(C.c_int64)]),
     ("gm_diamond_support_info", C.c_int, [_P, C.POINTER(C.c_int64)]),
     ("gm_tc_core_info", C.c_int, [_P, C.POINTER(C.c_int64)]),
+    ("gm_sup_core_info", C.c_int, [_P, C.POINTER(C.c_int64)]),
     ("gm_diamond_support_partial", C.c_int, [_P, C.POINTER(gm_launch), _P, C.c_int64, C.POINTER(gm_stats)]),
     ("gm_diamond_support_finish", C.c_int, [_P, C.POINTER(gm_launch), _P, C.c_int64, C.POINTER(C.c_uint64), C.POINTER(gm_stats)]),
     ("gm_constant", C.c_int, [C.c_char_p, C.POINTER(C.c_int64)]),

@@ -137,6 +137,10 @@ __host__ __device__ inline int ctc_block_tasks(int h) {  // (pair of 256-row blo
   return nb * (nb + 1) / 2 * ((nc + kCtcBPiece - 1) / kCtcBPiece);
 }
 
+// SUP (edge supports, gm_sup.hip): `core` is the SYMMETRIC corner A = M + M^T, the column range is whole (a triangle's third vertex lies
+// before, between or behind i and j: t(i, j) = (A A)_ij), and the epilogue adds every masked accumulator to the support of its edge --
+// DAG entry rp[base + i] + first[i][word of j] + the set bits of the word below j -- instead of summing them
+template <bool SUP>
 __global__ __launch_bounds__(kCtcBWaves *GM_WAVE) void core_tc_block_kernel(const CoreTcParams p) {
   __shared__ CtcBlockLds S;
   const int tid = threadIdx.x, lane = tid & (GM_WAVE - 1), wave = readfirst(tid >> 6);
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(kCtcBWaves *GM_WAVE) void core_tc_block_kernel(cons
     while (JB * (JB + 1) / 2 > pair) --JB;
     const int IB = pair - JB * (JB + 1) / 2;
     // chunks below the J block hold no bit of its rows (strictly upper triangular); the chunk with the diagonal is taken whole
-    const int cb = (JB >> 1) + piece * kCtcBPiece, ce = min(cb + kCtcBPiece, nc);
+    const int cb = (SUP ? 0 : (JB >> 1)) + piece * kCtcBPiece, ce = min(cb + kCtcBPiece, nc);
     if (cb >= nc) continue;  // (workgroup-uniform: this pair has fewer pieces)
     // (the first chunk is requested before the mask words: one round trip for both)
     const uint4 *g0 = reinterpret_cast<const uint4 *>(M + (size_t)(256 * IB + srow) * rw) + seg;
@@ -184,8 +188,13 @@ __global__ __launch_bounds__(kCtcBWaves *GM_WAVE) void core_tc_block_kernel(cons
       const unsigned *row = M + (size_t)(256 * IB + 64 * wi + 32 * ii + l31) * rw + 8 * JB + 4 * wj;
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
-        mw[jj][ii] = row[jj];
-        any_bits |= mw[jj][ii];
+        unsigned w = row[jj];
+        if (SUP && IB == JB) {  // the symmetric matrix: only the edges i < j of a diagonal block
+          const int below = 64 * wi + 32 * ii + l31 - (128 * wj + 32 * jj);  // columns 0 .. below of this word are <= i
+          w = below >= 31 ? 0u : (below >= 0 ? w & ~((2u << below) - 1u) : w);
+        }
+        mw[jj][ii] = w;
+        any_bits |= w;
       }
     }
     const bool any = __ballot(any_bits != 0u) != 0ull;  // (wave-uniform) no edge (i, j) in this part: the wave only helps staging
@@ -230,7 +239,26 @@ __global__ __launch_bounds__(kCtcBWaves *GM_WAVE) void core_tc_block_kernel(cons
         }
       }
     }
-    if (any) {
+    if (any && SUP) {
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        const int i = 256 * IB + 64 * wi + 32 * ii + l31;
+        const int e_row = p.rp[p.base + i];
+        const unsigned short *__restrict__ fr = p.first_pos + (size_t)i * (size_t)rw + 8 * JB + 4 * wj;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const unsigned w = mw[jj][ii];
+          if (w == 0u) continue;
+          const int e_word = e_row + (int)fr[jj];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {  // register r of this lane: bit (r & 3) + 8 (r >> 2) + 4 h of the word
+            const int b = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const unsigned v = (unsigned)acc[jj][ii][r];
+            if (((w >> b) & 1u) && v) atomicAdd(&p.sup[e_word + __builtin_popcount(w & ((1u << b) - 1u))], v);
+          }
+        }
+      }
+    } else if (any) {
       float s = 0.f;  // <= 8 tiles x 16 registers x 8192 columns of a piece: exact in f32
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj)
@@ -243,6 +271,7 @@ __global__ __launch_bounds__(kCtcBWaves *GM_WAVE) void core_tc_block_kernel(cons
       }
     }
   }
+  if (SUP) return;
   tot += (unsigned long long)c;
   const unsigned long long s0 = wave_sum_u64(tot);
   if (lane == 0 && s0) atomicAdd(&p.counters[0], s0);
@@ -264,11 +293,50 @@ hipError_t launch_core_tc(CoreTcParams p, int cu_count, hipStream_t stream) {
   if (mine <= 0) return hipSuccess;
   if (fast) {
     const int grid = (int)std::max<long long>(1, std::min<long long>(mine, (long long)cu_count));
-    hipLaunchKernelGGL(core_tc_block_kernel, dim3((unsigned)grid), dim3(kCtcBWaves * GM_WAVE), 0, stream, p);
+    hipLaunchKernelGGL((core_tc_block_kernel<false>), dim3((unsigned)grid), dim3(kCtcBWaves * GM_WAVE), 0, stream, p);
   } else {
     const int grid = (int)std::max<long long>(1, std::min<long long>((mine + kCtcWaves - 1) / kCtcWaves, (long long)cu_count * 3));
     hipLaunchKernelGGL(core_tc_kernel, dim3((unsigned)grid), dim3(kCtcWaves * GM_WAVE), 0, stream, p);
   }
+  return hipGetLastError();
+}
+
+// ---- the symmetric corner of the edge supports: A = M + M^T as a bit matrix of its own (h / 32 words per row) and, per (row, word), the
+// position inside the row's DAG entries of the first entry whose bit lies in that word (rows of at most kTctStageMax entries)
+__global__ __launch_bounds__(256) void core_sym_fill_kernel(int nv, int base, int words, long long e0, long long e1, const int *__restrict__ rp,
+                                                             const int *__restrict__ col, unsigned *__restrict__ bits, unsigned short *__restrict__ first_pos) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long e = e0 + (long long)blockIdx.x * blockDim.x + threadIdx.x; e < e1; e += stride) {
+    int lo = base, hi = nv - 1;  // the row of entry e
+    while (lo < hi) {
+      const int mid = (int)(((long long)lo + hi + 1) >> 1);
+      if (rp[mid] <= e) lo = mid; else hi = mid - 1;
+    }
+    const int u = lo - base, v = col[e] - base;  // (topological: v > u >= 0)
+    atomicOr(&bits[(size_t)u * (size_t)words + (size_t)(v >> 5)], 1u << (v & 31));
+    atomicOr(&bits[(size_t)v * (size_t)words + (size_t)(u >> 5)], 1u << (u & 31));
+    const long long er = (long long)rp[lo];
+    if (e == er || ((col[e - 1] - base) >> 5) != (v >> 5)) first_pos[(size_t)u * (size_t)words + (size_t)(v >> 5)] = (unsigned short)(e - er);
+  }
+}
+hipError_t launch_core_sym_fill(int nv, int base, int words, long long e0, long long e1, const int *rp, const int *col, unsigned *bits,
+                                unsigned short *first_pos, int cu_count, hipStream_t stream) {
+  if (e1 <= e0) return hipSuccess;
+  const long long blocks = std::min<long long>((e1 - e0 + 255) / 256, (long long)cu_count * 32);
+  hipLaunchKernelGGL(core_sym_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, nv, base, words, e0, e1, rp, col, bits, first_pos);
+  return hipGetLastError();
+}
+// the supports of the corner's edges: p.core = the symmetric corner (row_words = h / 32, row0 = word0 = 0), p.rp / p.base / p.first_pos / p.sup
+hipError_t launch_core_sup(CoreTcParams p, int cu_count, hipStream_t stream) {
+  if (p.core == nullptr || p.sup == nullptr || p.first_pos == nullptr || p.rp == nullptr || p.h < 512 || p.h % 512 != 0 || p.h > kCtcMaxH ||
+      p.row_words != p.h / 32 || p.row0 != 0 || p.word0 != 0 || p.step < 1 || p.first < 0 || p.first >= p.step)
+    return hipErrorInvalidValue;
+  const int nb = p.h >> 8, nc = p.h >> 9;
+  p.ntasks = nb * (nb + 1) / 2 * ((nc + kCtcBPiece - 1) / kCtcBPiece);
+  const long long mine = ((long long)p.ntasks - p.first + p.step - 1) / p.step;
+  if (mine <= 0) return hipSuccess;
+  const int grid = (int)std::max<long long>(1, std::min<long long>(mine, (long long)cu_count));
+  hipLaunchKernelGGL((core_tc_block_kernel<true>), dim3((unsigned)grid), dim3(kCtcBWaves * GM_WAVE), 0, stream, p);
   return hipGetLastError();
 }
 

@@ -108,6 +108,8 @@ extern "C" void gm_graph_free(gm_graph *g) {
   if (g->d_counters) (void)hipFree(g->d_counters);
   if (g->d_scratch) (void)hipFree(g->d_scratch);
   if (g->d_core) (void)hipFree(g->d_core);
+  if (g->d_csym) (void)hipFree(g->d_csym);
+  if (g->d_cfirst) (void)hipFree(g->d_cfirst);
   if (g->d_idx0) (void)hipFree(g->d_idx0);
   if (g->d_wblock_prefix) (void)hipFree(g->d_wblock_prefix);
   if (g->d_house_prefix) (void)hipFree(g->d_house_prefix);

@@ -289,7 +289,8 @@ struct gm_graph {
   unsigned *d_scratch = nullptr;
   size_t scratch_bytes = 0;
   static constexpr int kEvRing = 64;  // HIP-event pairs of the most recent launches
-  hipEvent_t ev[kEvRing][2] = {};
+  hipEvent_t ev[kEvRing][4] = {};      // [0], [1]: around the launch; [2], [3]: around its hub-corner kernel (gm_ctc.hip) when it has one
+  bool ev_corner[kEvRing] = {};
   unsigned long long ev_launches = 0;
   int cu_count = 256;
   gm_graph *dag_cache = nullptr;          // oriented copy, built on demand by gm_motif_formula
@@ -342,6 +343,13 @@ struct gm_graph {
   int tc_core_h = 0;
   int kst_skip_from = 0x7fffffff;
   long long tc_core_edges = 0;         // entries of the rows >= kst_skip_from
+  // the same for the TASK LISTS (ensure_tasklists: the edge supports, the triangle count without a key stream): no task of a row >= tl_skip_from;
+  // the supports of the corner's edges come from the symmetric corner d_csym (tl_core_h / 32 words per row) with d_cfirst[row][word] = position
+  // of the word's first entry inside its row (ensure_sup_corner, gm_tables.hip; core_tc_block_kernel<true>, gm_ctc.hip)
+  int tl_core_h = 0;
+  int tl_skip_from = 0x7fffffff;
+  unsigned *d_csym = nullptr;
+  unsigned short *d_cfirst = nullptr;
   hipStream_t aux_stream[3] = {nullptr, nullptr, nullptr};  // class kernels that cannot fill the chip run beside the others (run_pattern)
   hipEvent_t aux_done[3] = {nullptr, nullptr, nullptr};
   TempPool pool;  // temporaries of the setup paths (PoolScope)
@@ -484,6 +492,7 @@ int ensure_edesc(gm_graph *g);
 int ensure_tasklists(gm_graph *g, bool with_edges = false);
 int ensure_keystream(gm_graph *g, bool edges, bool *built, bool allow_core = false);  // allow_core: the rows of the hub core may stay out (gm_ctc.hip)
 int sup_mask_min_tail();            // (gm_tables.hip) kSupMaskMinTail or GM_SUP_MASK_MIN
+int ensure_sup_corner(gm_graph *g);  // (gm_tables.hip) d_csym / d_cfirst of a handle whose task lists leave a hub corner out
 int ensure_sup_masks(gm_graph *g);  // (gm_tables.hip) d_emoff / d_tmoff / d_smask of a topologically numbered DAG with task lists; GM_OK also when not applicable
 int ensure_mean_sq_deg(gm_graph *g);
 unsigned long long task_part_cap(gm_graph *g, int world);

@@ -102,6 +102,7 @@ static int start_timer(LaunchCtx &c) {
   c.g->ring_alias = nullptr;
   c.g->ring_extra[0] = c.g->ring_extra[1] = nullptr;
   c.evp = c.g->ev[c.g->ev_launches % gm_graph::kEvRing];
+  c.g->ev_corner[c.g->ev_launches % gm_graph::kEvRing] = false;
   c.g->ev_launches++;
   HIP_TRY(hipEventRecord(c.evp[0], c.stream));
   return GM_OK;
@@ -264,7 +265,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
   ChunkTable *tab_big = nullptr;
   if (split_stage) {
     RowFilter rb;
-    rb.tct = (use_kst && !support && g->kst_skip_from < g->nv) ? 2 : 1;
+    rb.tct = (use_kst && !support && g->kst_skip_from < g->nv) ? 2 : 1;  // (2: priced from the stream without the hub corner, gm_tables.hip)
     rb.only_lo = kStageCap;
     rb.only_hi = kTctStageMax;
     const int rc_b = get_table(g, target, true, 0, part_cap, kTctStageMax, &tab_big, rb, kBitmapMinDeg);
@@ -276,9 +277,15 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
     }
   }
   // the triangles of the hub corner on the matrix cores (gm_ctc.hip): this handle's key stream holds no task of the corner's rows
-  const bool tc_core = use_kst && !support && g->kst_skip_from < g->nv;
+  const int corner_from = use_kst ? g->kst_skip_from : (use_tct ? g->tl_skip_from : 0x7fffffff);  // the rows the stream / the task lists in use leave out
+  const bool tc_core = use_tct && !support && corner_from < g->nv;
+  const bool sup_core = support && !use_kst && corner_from < g->nv;
+  if (sup_core) {
+    const int rc_c = ensure_sup_corner(g);
+    if (rc_c) return rc_c;
+  }
   RowFilter rf;
-  rf.tct = use_tct ? (tc_core ? 2 : 1) : 0;
+  rf.tct = use_tct ? ((tc_core && use_kst) ? 2 : 1) : 0;
   if (tct_long) { rf.skip_lo = kTctStageMax; rf.skip_hi = 0x7fffffff; }
   if (split_stage) { rf.skip_lo = kStageCap; rf.skip_hi = 0x7fffffff; }  // (this table: the hosts whose rows fit the 1024-entry stage)
   // 4-clique: the first level is re-hosted (gm_cbuild.hip) for every vertex whose row fits its stage -- the narrow chunk table and
@@ -772,6 +779,25 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
       HIP_TRY(launch_sup_long(sl, g->cu_count, stream));
       my_edges += (unsigned long long)((g->long_edges - rank + world - 1) / world);
     }
+    if (sup_core) {  // the supports of the hub corner's edges: (A A)_ij on the matrix cores (gm_ctc.hip); a rank takes every world-th block
+      CoreTcParams cp;
+      memset(&cp, 0, sizeof cp);
+      cp.core = g->d_csym;
+      cp.h = g->tl_core_h;
+      cp.row_words = cp.h / 32;
+      cp.first = rank;
+      cp.step = world;
+      cp.queue = reinterpret_cast<unsigned *>(g->d_counters + 4) + 4;  // (its own dequeue word inside the zeroed 64-byte block)
+      cp.counters = g->d_counters;
+      cp.rp = g->d_rp;
+      cp.base = corner_from;
+      cp.first_pos = g->d_cfirst;
+      cp.sup = sup;
+      HIP_TRY(hipEventRecord(ctx.evp[2], stream));
+      HIP_TRY(launch_core_sup(cp, g->cu_count, stream));
+      HIP_TRY(hipEventRecord(ctx.evp[3], stream));
+      g->ev_corner[(g->ev_launches - 1) % gm_graph::kEvRing] = true;
+    }
     if (sup_masks) {  // the masks of the in-edge tasks, summed by column into the supports of their rows
       SupColsParams sc;
       memset(&sc, 0, sizeof sc);
@@ -800,17 +826,21 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
     if (p.count > 0) HIP_TRY(launch_tch(p, tct_stage, (int)std::max<long long>(1, std::min<long long>(want, (long long)g->cu_count * tch_per_cu(tct_stage))), stream));
     if (tc_core) {  // the out-edges of the hub corner: one masked bit-matrix product; a rank takes every world-th block
       CoreTcParams cp;
+      memset(&cp, 0, sizeof cp);
       cp.core = g->d_core;
       cp.row_words = (g->core_h + 31) / 32;
-      cp.row0 = g->kst_skip_from - g->core_base;
+      cp.row0 = corner_from - g->core_base;
       cp.word0 = cp.row0 >> 5;
-      cp.h = g->tc_core_h;
+      cp.h = g->nv - corner_from;
       cp.ntasks = 0;
       cp.first = rank;
       cp.step = world;
       cp.queue = reinterpret_cast<unsigned *>(g->d_counters + 4) + 4;  // (its own dequeue word inside the zeroed 64-byte block)
       cp.counters = g->d_counters;
+      HIP_TRY(hipEventRecord(ctx.evp[2], stream));
       HIP_TRY(launch_core_tc(cp, g->cu_count, stream));
+      HIP_TRY(hipEventRecord(ctx.evp[3], stream));
+      g->ev_corner[(g->ev_launches - 1) % gm_graph::kEvRing] = true;
       // (gm_stats.tasks: a table's task edges are its rows' entries -- the corner's rows are chunks of the table like any other)
     }
   } else if (p.count > 0) HIP_TRY(launch_mine(pat, p, grid, stream));
@@ -883,6 +913,24 @@ extern "C" int gm_kernel_times(const gm_graph *g, int n, double *ms_out, int *n_
       HIP_TRY(hipEventElapsedTime(&xms, x->ev[xi][0], x->ev[xi][1]));
       ms_out[i] += xms;
     }
+  }
+  *n_out = m;
+  return GM_OK;
+}
+
+// the part of gm_kernel_times' durations that the hub-corner kernel of a launch took (gm_ctc.hip; 0 for a launch without one): the
+// streamed kernels' time is the difference -- what bench.py prices against the HBM roofline
+extern "C" int gm_corner_times(const gm_graph *g, int n, double *ms_out, int *n_out) {
+  if (!g || !ms_out || !n_out || n < 0) return GM_ERR_INVALID;
+  while (g->ring_alias) g = g->ring_alias;
+  const unsigned long long have = std::min<unsigned long long>(g->ev_launches, gm_graph::kEvRing);
+  const int m = (int)std::min<unsigned long long>((unsigned long long)n, have);
+  HIP_TRY(hipSetDevice(g->device));
+  for (int i = 0; i < m; ++i) {
+    const unsigned long long idx = (g->ev_launches - (unsigned long long)m + (unsigned long long)i) % gm_graph::kEvRing;
+    float ms = 0.f;
+    if (g->ev_corner[idx]) HIP_TRY(hipEventElapsedTime(&ms, g->ev[idx][2], g->ev[idx][3]));
+    ms_out[i] = ms;
   }
   *n_out = m;
   return GM_OK;
@@ -1431,6 +1479,26 @@ extern "C" int gm_diamond_support_info(const gm_graph *sym, int64_t info[4]) {
   info[1] = (int64_t)at;                                                  // increments issued as global atomics from the waves' queues
   info[2] = run_on->smask_state == 1 ? (int64_t)run_on->n_sup_far_rows : 0;
   info[3] = (int64_t)sup_mask_min_tail();
+  return GM_OK;
+}
+// tooling: the hub corner whose supports the one-GPU diamond of this handle takes on the matrix cores (after a first diamond)
+extern "C" int gm_sup_core_info(const gm_graph *sym, int64_t info[4]) {
+  if (!sym || !info) return GM_ERR_INVALID;
+  gm_graph *run_on = nullptr;
+  const int rc = diamond_run_on(sym, nullptr, &run_on);
+  if (rc) return rc;
+  const bool on = run_on->tl_skip_from < run_on->nv;
+  const long long nb = on ? run_on->tl_core_h >> 8 : 0;
+  info[0] = on ? run_on->tl_core_h : 0;  // vertices of the corner (0: every edge's support comes from the triangle pass)
+  info[1] = 0;
+  if (on) {
+    int e0 = 0;
+    HIP_TRY(hipSetDevice(run_on->device));
+    HIP_TRY(hipMemcpy(&e0, run_on->d_rp + run_on->tl_skip_from, sizeof(int), hipMemcpyDeviceToHost));
+    info[1] = run_on->ne - (long long)e0;  // DAG entries inside it
+  }
+  info[2] = nb * (nb + 1) / 2;           // pairs of 256-row blocks of the product
+  info[3] = on ? (run_on->tl_core_h >> 9) : 0;  // 512-column chunks of a row
   return GM_OK;
 }
 extern "C" int gm_diamond_support_partial(const gm_graph *sym, const gm_launch *la, uint32_t *d_support, int64_t n_entries, gm_stats *st) {

@@ -340,8 +340,17 @@ struct CoreTcParams {
   int first, step;           // this launch takes the tasks first + q * step (rank, world)
   unsigned *queue;           // dequeue word (zeroed before launch)
   unsigned long long *counters;
+  // the edge supports' corner (launch_core_sup): DAG offsets, first vertex of the corner, per (row, word) the position of the word's first
+  // entry inside its row, the support array
+  const int *rp;
+  int base;
+  const unsigned short *first_pos;
+  unsigned *sup;
 };
 hipError_t launch_core_tc(CoreTcParams p, int cu_count, hipStream_t stream);
+hipError_t launch_core_sup(CoreTcParams p, int cu_count, hipStream_t stream);
+hipError_t launch_core_sym_fill(int nv, int base, int words, long long e0, long long e1, const int *rp, const int *col, unsigned *bits,
+                                unsigned short *first_pos, int cu_count, hipStream_t stream);
 bool core_tc_fast_path(const CoreTcParams &p);
 
 // ---- the same counts on the matrix cores (gm_cmma.hip; the default since round 4, tune[6] & 0x20000: the vector-ALU classes above) ----

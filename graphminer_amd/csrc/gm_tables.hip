@@ -1097,10 +1097,10 @@ __global__ __launch_bounds__(256) void kst_narrow_kernel(int nv, const unsigned 
 // without, R-MAT-24 at 16 K / 32 K (12.7 / 5.4 %): 26.1 / 24.5 against 32.2 -- the largest power-of-two fraction of the core bitmap whose
 // density is >= kTcCoreMinDensity.  GM_TC_CORE_H = 0 switches the corner off, any other value forces that size (tests: small graphs).
 constexpr double kTcCoreMinDensity = 0.03;
-static int tc_core_size(gm_graph *g) {
+static int tc_core_size(gm_graph *g, const char *env = "GM_TC_CORE_H", bool blocks_only = false) {
   long long want = kTcCoreHDefault;
   bool forced = false;
-  if (const char *e = getenv("GM_TC_CORE_H")) { want = atoll(e); forced = true; }
+  if (const char *e = getenv(env)) { want = atoll(e); forced = true; }
   if (want <= 0 || g->nv < 64) return 0;
   if (ensure_core_bitmap(g) != GM_OK || g->core_state != 1) return 0;  // (not topologically numbered, no room: everything through the stream)
   const long long cap = std::min<long long>((long long)g->core_h, (long long)kCtcMaxH);
@@ -1108,14 +1108,17 @@ static int tc_core_size(gm_graph *g) {
     const long long off = ((long long)g->core_h - h + 31) / 32 * 32;
     return off >= g->core_h ? 0ll : (long long)g->core_h - off;
   };
-  if (forced) return (int)aligned(std::min(want, cap));
+  if (forced) {
+    const long long h = aligned(std::min(want, cap));
+    return (int)((blocks_only && h % 512 != 0) ? 0 : h);  // (the supports' corner runs on the block kernel only)
+  }
   // a corner is worth its MFMA pass where the hubs are a small part of the graph: at most a quarter of the vertices, at least 1024 of them
   for (long long h = cap; h >= 1024; h >>= 1) {
     if ((long long)g->nv < 4 * h) continue;
     int e0 = 0;
     if (hipMemcpy(&e0, g->d_rp + (g->nv - h), sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return 0; }
     const double rho = (double)(g->ne - (long long)e0) / (0.5 * (double)h * (double)h);
-    if (rho >= kTcCoreMinDensity) return (int)aligned(h);
+    if (rho >= kTcCoreMinDensity && !(blocks_only && aligned(h) % 512 != 0)) return (int)aligned(h);
   }
   return 0;
 }
@@ -1268,6 +1271,9 @@ int ensure_tasklists(gm_graph *g, bool /*with_edges*/) {
     const int rc = ensure_edesc(g);  // (takes the lock itself)
     if (rc) return rc;
   }
+  // the hub corner (gm_ctc.hip): its edges' supports / triangles come from the matrix cores -- where every row fits the stage (the rows beyond
+  // it are the chunked kernel's, run_pattern) and the corner is a whole number of 512-vertex chunks
+  const int tl_h = g->max_deg <= kTctStageMax ? tc_core_size(g, "GM_SUP_CORE_H", true) : 0;  // (takes the lock itself)
   std::lock_guard<std::mutex> lk(g->mu);
   if (g->d_tdesc) return GM_OK;
   SetupTimer timer;
@@ -1292,6 +1298,8 @@ int ensure_tasklists(gm_graph *g, bool /*with_edges*/) {
   tw.nv = g->nv; tw.stage_max = kTctStageMax; tw.topo = topo ? 1 : 0;
   tw.hub0 = topo ? std::max(0, g->nv - kHubWin) : g->nv;
   tw.rp = g->d_rp; tw.col = g->d_col; tw.edesc = g->d_edesc;
+  const int tl_skip = (topo && tl_h > 0) ? g->nv - tl_h : 0x7fffffff;
+  tw.skip_from = tl_skip;
   hipLaunchKernelGGL((task_rows_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, 0, tw, cnt.p, nullptr, nullptr, nullptr);
   setup_trace("tasks: count pass");
   int *trp = nullptr, *tedge = nullptr;
@@ -1318,6 +1326,10 @@ int ensure_tasklists(gm_graph *g, bool /*with_edges*/) {
   g->d_trp = trp;
   g->d_tdesc = td;
   g->d_tedge = tedge;
+  if (tl_skip < g->nv) {
+    g->tl_skip_from = tl_skip;
+    g->tl_core_h = g->nv - tl_skip;
+  }
   setup_trace("tasks: place pass");
   if (!keystream_possible(g)) build_inline_copies(g, tmp);  // (a handle that cannot have the key stream: task-major copies of the short lists)
   setup_trace("tasks: inline copies");
@@ -1352,15 +1364,47 @@ __global__ __launch_bounds__(256) void sup_mask_task_kernel(const long long nt, 
 }
 
 // the rows with tails of more than 64 keys (a second mask word: sup_far_kernel), widest ids first: flag, scan, scatter
-__global__ __launch_bounds__(256) void sup_far_flag_kernel(const int nv, const int *__restrict__ rp, const int lmin, const int stage_max, int *__restrict__ flag) {
+__global__ __launch_bounds__(256) void sup_far_flag_kernel(const int nv, const int *__restrict__ rp, const int lmin, const int stage_max, const int skip_from,
+                                                           int *__restrict__ flag) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;  // position k = vertex nv - 1 - k
   if (k >= nv) return;
   const int v = nv - 1 - k, d = rp[v + 1] - rp[v];
-  flag[k] = (d <= stage_max && d - 1 > GM_WAVE && d - 1 >= lmin) ? 1 : 0;
+  flag[k] = (v < skip_from && d <= stage_max && d - 1 > GM_WAVE && d - 1 >= lmin) ? 1 : 0;
 }
 __global__ __launch_bounds__(256) void sup_far_list_kernel(const int nv, const int *__restrict__ flag, const int *__restrict__ pos, int *__restrict__ rows) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k < nv && flag[k]) rows[pos[k]] = nv - 1 - k;
+}
+
+// d_csym / d_cfirst: the symmetric bit matrix of the hub corner the task lists leave out, and the positions the supports' epilogue needs
+int ensure_sup_corner(gm_graph *g) {
+  if (g->tl_skip_from >= g->nv || g->d_csym) return GM_OK;
+  std::lock_guard<std::mutex> lk(g->mu);
+  if (g->d_csym) return GM_OK;
+  SetupTimer timer;
+  HIP_TRY(hipSetDevice(g->device));
+  const int h = g->tl_core_h, words = h / 32;
+  const size_t cells = (size_t)h * (size_t)words;
+  unsigned *bits = nullptr;
+  unsigned short *first_pos = nullptr;
+  HIP_TRY(hipMalloc(&bits, cells * sizeof(unsigned)));
+  hipError_t e = hipMalloc(&first_pos, cells * sizeof(unsigned short));
+  if (e == hipSuccess) e = hipMemsetAsync(bits, 0, cells * sizeof(unsigned), 0);
+  if (e == hipSuccess) e = hipMemsetAsync(first_pos, 0, cells * sizeof(unsigned short), 0);
+  int e0 = 0;
+  if (e == hipSuccess) e = hipMemcpy(&e0, g->d_rp + g->tl_skip_from, sizeof(int), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = launch_core_sym_fill(g->nv, g->tl_skip_from, words, (long long)e0, g->ne, g->d_rp, g->d_col, bits, first_pos, g->cu_count, 0);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) {
+    (void)hipFree(bits);
+    if (first_pos) (void)hipFree(first_pos);
+    return hip_fail(e, "symmetric corner", __FILE__, __LINE__);
+  }
+  g->d_cfirst = first_pos;
+  g->d_csym = bits;
+  setup_trace("supports: symmetric corner");
+  g->setup.table_ms += timer.ms();
+  return GM_OK;
 }
 
 int sup_mask_min_tail() {
@@ -1396,6 +1440,7 @@ int ensure_sup_masks(gm_graph *g) {
   TaskWalk tw;
   tw.nv = g->nv; tw.stage_max = kTctStageMax; tw.topo = 1; tw.hub0 = g->nv;
   tw.rp = g->d_rp; tw.col = g->d_col; tw.edesc = g->d_edesc;
+  tw.skip_from = g->tl_skip_from;  // (the corner's rows have no tasks: no masks)
   const long long blocks = std::min<long long>(((long long)g->nv * 8 + 255) / 256, (long long)g->cu_count * 32);
   hipLaunchKernelGGL(sup_mask_size_kernel, dim3((unsigned)std::max<long long>(1, blocks)), dim3(256), 0, 0, tw, sup_mask_min_tail(), off.p);
   HIP_TRY(dev_exclusive_sum(tmp, off.p, off.p, ne + 1));
@@ -1412,7 +1457,7 @@ int ensure_sup_masks(gm_graph *g) {
   HIP_TRY(fflag.alloc((size_t)g->nv + 1));
   HIP_TRY(fpos.alloc((size_t)g->nv + 1));
   HIP_TRY(hipMemsetAsync(fflag.p, 0, sizeof(int) * ((size_t)g->nv + 1), 0));
-  hipLaunchKernelGGL(sup_far_flag_kernel, dim3((unsigned)((g->nv + 255) / 256)), dim3(256), 0, 0, g->nv, g->d_rp, sup_mask_min_tail(), kTctStageMax, fflag.p);
+  hipLaunchKernelGGL(sup_far_flag_kernel, dim3((unsigned)((g->nv + 255) / 256)), dim3(256), 0, 0, g->nv, g->d_rp, sup_mask_min_tail(), kTctStageMax, g->tl_skip_from, fflag.p);
   HIP_TRY(dev_exclusive_sum(tmp, fflag.p, fpos.p, (size_t)g->nv + 1));
   int nfar = 0;
   HIP_TRY(hipMemcpy(&nfar, fpos.p + g->nv, sizeof nfar, hipMemcpyDeviceToHost));

@@ -186,6 +186,13 @@ class DeviceGraph:
         _lib.check(_lib.load().gm_kernel_times(self.handle, n, buf, C.byref(got)), "gm_kernel_times")
         return [float(buf[i]) for i in range(got.value)]
 
+    def corner_times_ms(self, n: int = 64):
+        """the part of kernel_times_ms() spent in the launches' hub-corner kernel on the matrix cores (gm_corner_times; 0: none)"""
+        buf = (C.c_double * max(n, 1))()
+        got = C.c_int(0)
+        _lib.check(_lib.load().gm_corner_times(self.handle, n, buf, C.byref(got)), "gm_corner_times")
+        return [float(buf[i]) for i in range(got.value)]
+
     def setup_times_ms(self) -> dict:
         """Accumulated pre-processing time of this handle (gm_graph_setup_times): orientation, task tables, hub
         bitmaps, renumbered copies, per-pattern tables -- the steps the reference leaves untimed."""

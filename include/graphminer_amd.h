@@ -167,6 +167,9 @@ int gm_graph_setup_times(const gm_graph *g, gm_setup_times *out);
  * This is how an asynchronous (d_counts) caller reads the kernel time the reference prints as
  * "runtime [gpu_base]" (src/triangle/gpu_base.cu:53-68). */
 int gm_kernel_times(const gm_graph *g, int n, double *ms_out, int *n_out);
+/* The part of those durations spent in the launch's hub-corner kernel on the matrix cores (csrc/gm_ctc.hip; 0 for a launch without one):
+ * the rest is the streamed kernels' -- the time bench.py prices against the HBM roofline. Same order, same synchronisation rule. */
+int gm_corner_times(const gm_graph *g, int n, double *ms_out, int *n_out);
 
 /* ---- solvers ------------------------------------------------------------------------------ */
 /* launch may be NULL (single GPU, null stream, defaults). stats may be NULL. */
@@ -209,6 +212,11 @@ int gm_diamond_support_size(const gm_graph *sym, int world, int64_t *n_entries);
  * graph), info[1] = streamed-edge increments the most recent launch issued as global atomics, info[2] = rows with masks of several words,
  * info[3] = the shortest tail that gets a mask.  Synchronises the device. */
 int gm_diamond_support_info(const gm_graph *sym, int64_t info[4]);
+/* Tooling: the supports of the edges inside the hub corner (the last H vertices of the renumbered oriented copy) are one bit-matrix product
+ * on the matrix cores, t(i, j) = (A A)_ij over the symmetric corner A (csrc/gm_ctc.hip), and the triangle pass leaves the corner's rows
+ * out: info[0] = H (0: none), info[1] = DAG entries inside the corner, info[2] = pairs of 256-row blocks, info[3] = 512-column chunks per
+ * row.  GM_SUP_CORE_H in the environment (read when the handle's task lists are built): 0 = off, a multiple of 512 = that H. */
+int gm_sup_core_info(const gm_graph *sym, int64_t info[4]);
 int gm_diamond_support_partial(const gm_graph *sym, const gm_launch *launch, uint32_t *d_support, int64_t n_entries, gm_stats *stats);
 int gm_diamond_support_finish(const gm_graph *sym, const gm_launch *launch, const uint32_t *d_support, int64_t count, uint64_t *total,
                               gm_stats *stats);
