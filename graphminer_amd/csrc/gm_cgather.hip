@@ -48,6 +48,46 @@ __device__ __forceinline__ void cg_tile(const unsigned w, const int2 inf, const 
   asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(w_out) : "s"((unsigned)(m >> 32)), "s"(2 * t + 1) : "m0");
 }
 
+// The same with the 64 bits left in lanes 2 K / 2 K + 1 of a GROUP register, K a compile-time constant: v_writelane_b32 takes the lane as an
+// inline constant, no M0 -- the dynamic lane select cost two scalar instructions per v_writelane (s_add, s_mov m0: 37 scalar instructions
+// per eight tiles, the one scalar unit of a CU 0.70 busy: profiles/r05/clique4_rmat22ef28_pmc_summary.txt).  cg_merge moves a group's sixteen
+// lanes to lanes 2 t0 .. 2 t0 + 15 of the row register with one ds_bpermute_b32.
+template <bool CHECKED, int K>
+__device__ __forceinline__ void cg_tile_k(const unsigned w, const int2 inf, const int t, const int i, const int d, const int lane, unsigned &grp) {
+  bool bit = __builtin_amdgcn_ubfe(w, (unsigned)inf.y, 1u) != 0u;
+  if (CHECKED) {
+    const int j = t * GM_WAVE + lane;
+    bit = bit && j > i && j < d;
+  }
+  const unsigned long long m = __ballot(bit);
+  // (the ballot is a VALU write of an SGPR pair: the compiler's hazard recogniser does not look inside inline assembly, and without the
+  // wait states a v_writelane right behind the v_cmp now and then read the pair too early -- counts off by 0.3 % from run to run)
+  asm("s_nop 3\n\tv_writelane_b32 %0, %1, %2" : "+v"(grp) : "s"((unsigned)m), "n"(2 * K));
+  asm("v_writelane_b32 %0, %1, %2" : "+v"(grp) : "s"((unsigned)(m >> 32)), "n"(2 * K + 1));
+}
+__device__ __forceinline__ void cg_merge(unsigned &w_out, const unsigned grp, const int t0, const int lane) {
+  const int src = lane - 2 * t0;  // lane src of the group belongs to this lane of the row
+  const unsigned v = (unsigned)__builtin_amdgcn_ds_bpermute(src << 2, (int)grp);
+  if ((unsigned)src < 2u * (unsigned)kCgUnroll) w_out = v;
+}
+
+template <int K, class HeadT>
+__device__ __forceinline__ void cg_head(const HeadT &h, const int t0, const int ntiles, const int i, const int d, const int lane, unsigned &grp) {
+  if constexpr (K < kCgHead) {
+    if (t0 + K < ntiles) cg_tile_k<true, K>(h.w[K], h.inf[K], t0 + K, i, d, lane, grp);
+    cg_head<K + 1>(h, t0, ntiles, i, d, lane, grp);
+  }
+}
+template <int K>
+__device__ __forceinline__ void cg_group(const unsigned (&w)[kCgUnroll], const int2 (&inf)[kCgUnroll], const int tb, const int i, const int d, const int lane,
+                                         unsigned &grp) {
+  if constexpr (K < kCgUnroll) {
+    cg_tile_k<false, K>(w[K], inf[K], tb + K, i, d, lane, grp);
+    cg_group<K + 1>(w, inf, tb, i, d, lane, grp);
+  }
+}
+static_assert(kCgHead == kCgUnroll, "cg_merge moves sixteen lanes");
+
 __global__ __launch_bounds__(kCgWaves *GM_WAVE) void cgather_kernel(const CGatherParams p) {
   __shared__ CGatherLds S;
   constexpr int NT = kCgWaves * GM_WAVE;
@@ -95,9 +135,11 @@ __global__ __launch_bounds__(kCgWaves *GM_WAVE) void cgather_kernel(const CGathe
       const int rowo = readfirst(S.info[i].y) * p.core_words * 4;
       unsigned w_out = 0u;  // lane L: word L of the row (the words below the diagonal are zero)
       const int t0 = (i + 1) >> 6;
-#pragma unroll
-      for (int k = 0; k < kCgHead; ++k)
-        if (t0 + k < ntiles) cg_tile<true>(h.w[k], h.inf[k], t0 + k, i, d, lane, w_out);
+      {
+        unsigned grp = 0u;  // (tiles at or beyond the row's last one: zero words, never stored)
+        cg_head<0>(h, t0, ntiles, i, d, lane, grp);
+        cg_merge(w_out, grp, t0, lane);
+      }
       int tb = t0 + kCgHead;
       for (; tb + kCgUnroll < ntiles; tb += kCgUnroll) {  // whole tiles beyond the head, kCgUnroll gathers in flight
         int2 inf[kCgUnroll];
@@ -106,8 +148,9 @@ __global__ __launch_bounds__(kCgWaves *GM_WAVE) void cgather_kernel(const CGathe
         for (int k = 0; k < kCgUnroll; ++k) inf[k] = S.info[(tb + k) * GM_WAVE + lane];
 #pragma unroll
         for (int k = 0; k < kCgUnroll; ++k) w[k] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(core, inf[k].x, rowo, 0);
-#pragma unroll
-        for (int k = 0; k < kCgUnroll; ++k) cg_tile<false>(w[k], inf[k], tb + k, i, d, lane, w_out);
+        unsigned grp = 0u;
+        cg_group<0>(w, inf, tb, i, d, lane, grp);
+        cg_merge(w_out, grp, tb, lane);
       }
       for (; tb < ntiles; ++tb) {  // the rest, the row's last tile among them
         const int2 inf = S.info[tb * GM_WAVE + lane];

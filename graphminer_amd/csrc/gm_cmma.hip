@@ -9,8 +9,8 @@
 // 32 x 64 by 64 x 32 of them in 32 cycles (65,536 bit-products per instruction against 2,048 per v_and), the f32 accumulators hold
 // exact integers <= 2048.  "No MFMA" in the north star describes the sorted-list intersections; this half of the pattern IS a GEMM.
 //   * operands: lane l of a fragment holds row (l & 31), columns 32 * (l >> 5) .. + 31 of a 32 x 64 bit tile = ONE 32-bit word of the
-//     matrix, expanded in registers to 32 nibbles with 7 VALU (x << 1, x, x >> 1, x >> 2, each & 0x22222222: nibble p of register r is
-//     bit 4 p + r).  The order of the columns inside a fragment does not matter -- both operands are rows of the same matrix, expanded
+//     matrix, expanded in registers to 32 nibbles with 5 - 7 VALU (shifts and masks: nibble p of register r is bit 4 p + r; mma_expand_a /
+//     _b below).  The order of the columns inside a fragment does not matter -- both operands are rows of the same matrix, laid out
 //     the same way -- so no transposition is ever needed (M M^T: both operands are "row-major in k");
 //   * a wave owns a 64 x 64 block of (i, j) pairs = 2 x 2 accumulator tiles and runs over the column steps of 64; with a topological
 //     numbering M is strictly upper triangular, so only blocks I <= J and steps K >= J exist (1/6 of the cube), and a block whose
@@ -34,9 +34,15 @@ struct alignas(16) MmaLds {
   int pad_[2];
 };
 
-__device__ __forceinline__ mma_v8i mma_expand(const unsigned x) {
-  constexpr unsigned m = 0x22222222u;
-  mma_v8i r = {(int)((x << 1) & m), (int)(x & m), (int)((x >> 1) & m), (int)((x >> 2) & m), 0, 0, 0, 0};
+// (round 5: the two operands encode a set bit differently -- bit class r = 0 / 1 / 2 / 3 is 0.5 / 1 / 2 / 2 in the A operand and 2 / 1 / 0.5 /
+// 0.5 in the B operand, every product of two set bits exactly 1 -- so that five and seven vector instructions expand a word instead of seven
+// and seven: gm_ctc.hip ctc_expand_a / _b)
+__device__ __forceinline__ mma_v8i mma_expand_a(const unsigned x) {
+  mma_v8i r = {(int)(x & 0x11111111u), (int)(x & 0x22222222u), (int)(x & 0x44444444u), (int)((x >> 1) & 0x44444444u), 0, 0, 0, 0};
+  return r;
+}
+__device__ __forceinline__ mma_v8i mma_expand_b(const unsigned x) {
+  mma_v8i r = {(int)((x << 2) & 0x44444444u), (int)(x & 0x22222222u), (int)((x >> 2) & 0x11111111u), (int)((x >> 3) & 0x11111111u), 0, 0, 0, 0};
   return r;
 }
 
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(WAVES *GM_WAVE) void clique_mma_kernel(const Clique
       const int xi = (IB * 64 + l31) * ps + h - c0, xj = (JB * 64 + l31) * ps + h - c0, hop = 32 * ps;
       for (int ks = ks0; ks < kb1; ++ks) {
         const unsigned wi0 = S.bits[xi + 2 * ks], wi1 = S.bits[xi + 2 * ks + hop], wj0 = S.bits[xj + 2 * ks], wj1 = S.bits[xj + 2 * ks + hop];
-        const mma_v8i fi0 = mma_expand(wi0), fi1 = mma_expand(wi1), fj0 = mma_expand(wj0), fj1 = mma_expand(wj1);
+        const mma_v8i fi0 = mma_expand_b(wi0), fi1 = mma_expand_b(wi1), fj0 = mma_expand_a(wj0), fj1 = mma_expand_a(wj1);
         // unit scales (E8M0 127); formats: 4 = FP4 (E2M1) for both operands
         acc[0][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fj0, fi0, acc[0][0], 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
         acc[0][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fj0, fi1, acc[0][1], 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);

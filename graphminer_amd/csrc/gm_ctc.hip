@@ -12,7 +12,7 @@
 // column steps K >= J (1/6 of the cube: H = 16 K is 1.1 * 10^7 v_mfma_scale_f32_32x32x64_f8f6f4, ~0.2 ms of the chip), a block whose mask
 // is empty skipped.  The key stream and the task lists of the triangle count leave the rows >= nv - H out (TaskWalk::skip_from).
 //   * core_tc_block_kernel (corners of a multiple of 512 vertices, 16-byte aligned rows: every real graph): a workgroup of eight waves takes a
-//     256 x 256 block of (i, j), wave (wi, wj) its 64 x 128 part (2 x 4 accumulator tiles: six operand words expanded per eight MFMAs), over
+//     256 x 256 block of (i, j), wave (wi, wj) its 64 x 128 part (2 x 4 accumulator tiles: six operand words expanded per eight MFMAs, 34 vector instructions), over
 //     column chunks of 512: the chunk of the 256 I rows and the 256 J rows (32 KB, 64 contiguous bytes per row) goes global -> registers
 //     -> LDS, the next chunk's loads in flight while this one is multiplied; LDS rows of 20 words (the sixteen lanes of a quarter of a
 //     ds_read_b128 hit sixteen different bank groups).  The order of the columns inside an operand fragment does not matter and neither
@@ -31,9 +31,16 @@ namespace gm {
 typedef int ctc_v8i __attribute__((ext_vector_type(8)));
 typedef float ctc_v16f __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ ctc_v8i ctc_expand(const unsigned x) {  // 32 bits -> 32 FP4 nibbles (0010 = 1.0): nibble p of register r = bit 4 p + r
-  constexpr unsigned m = 0x22222222u;
-  ctc_v8i r = {(int)((x << 1) & m), (int)(x & m), (int)((x >> 1) & m), (int)((x >> 2) & m), 0, 0, 0, 0};
+// 32 bits -> 32 FP4 (E2M1) nibbles, bit 4 p + r of the word in nibble p of register r.  The two operands of a product encode a set bit
+// DIFFERENTLY so that most registers need no shift: bit class r = 0 / 1 / 2 / 3 is 0.5 / 1 / 2 / 2 in the A operand (nibble 0001 / 0010 /
+// 0100 / 0100) and 2 / 1 / 0.5 / 0.5 in the B operand -- every product of two set bits is exactly 1.  Five and seven vector instructions
+// (both operands as 1.0 -- x << 1, x, x >> 1, x >> 2, each & 0x22222222 -- cost seven each).
+__device__ __forceinline__ ctc_v8i ctc_expand_a(const unsigned x) {
+  ctc_v8i r = {(int)(x & 0x11111111u), (int)(x & 0x22222222u), (int)(x & 0x44444444u), (int)((x >> 1) & 0x44444444u), 0, 0, 0, 0};
+  return r;
+}
+__device__ __forceinline__ ctc_v8i ctc_expand_b(const unsigned x) {
+  ctc_v8i r = {(int)((x << 2) & 0x44444444u), (int)(x & 0x22222222u), (int)((x >> 2) & 0x11111111u), (int)((x >> 3) & 0x11111111u), 0, 0, 0, 0};
   return r;
 }
 // sum of the accumulators whose mask bit is set: register r of this lane is bit (r & 3) + 8 (r >> 2) of w (already shifted by 4 (l >> 5))
@@ -99,8 +106,8 @@ __global__ __launch_bounds__(kCtcWaves *GM_WAVE) void core_tc_kernel(const CoreT
       const bool in = wc < wtc;
       const int wx = in ? wc : 0;
       const unsigned a0 = pi0[wx], a1 = pi1[wx], b0 = pj0[wx], b1 = pj1[wx];
-      const ctc_v8i fi0 = ctc_expand((in && vi0) ? a0 : 0u), fi1 = ctc_expand((in && vi1) ? a1 : 0u);
-      const ctc_v8i fj0 = ctc_expand((in && vj0) ? b0 : 0u), fj1 = ctc_expand((in && vj1) ? b1 : 0u);
+      const ctc_v8i fi0 = ctc_expand_b((in && vi0) ? a0 : 0u), fi1 = ctc_expand_b((in && vi1) ? a1 : 0u);
+      const ctc_v8i fj0 = ctc_expand_a((in && vj0) ? b0 : 0u), fj1 = ctc_expand_a((in && vj1) ? b1 : 0u);
       acc[0][0] = CTC_MFMA(fj0, fi0, acc[0][0]);
       acc[0][1] = CTC_MFMA(fj0, fi1, acc[0][1]);
       acc[1][0] = CTC_MFMA(fj1, fi0, acc[1][0]);
@@ -225,8 +232,8 @@ __global__ __launch_bounds__(kCtcBWaves *GM_WAVE) void core_tc_block_kernel(cons
           const unsigned wj2[4] = {xj2.x, xj2.y, xj2.z, xj2.w}, wj3[4] = {xj3.x, xj3.y, xj3.z, xj3.w};
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
-            const ctc_v8i fi0 = ctc_expand(wi0[s]), fi1 = ctc_expand(wi1[s]);
-            const ctc_v8i fj0 = ctc_expand(wj0[s]), fj1 = ctc_expand(wj1[s]), fj2 = ctc_expand(wj2[s]), fj3 = ctc_expand(wj3[s]);
+            const ctc_v8i fi0 = ctc_expand_b(wi0[s]), fi1 = ctc_expand_b(wi1[s]);  // (the four J words take the cheaper encoding)
+            const ctc_v8i fj0 = ctc_expand_a(wj0[s]), fj1 = ctc_expand_a(wj1[s]), fj2 = ctc_expand_a(wj2[s]), fj3 = ctc_expand_a(wj3[s]);
             acc[0][0] = CTC_MFMA(fj0, fi0, acc[0][0]);
             acc[0][1] = CTC_MFMA(fj0, fi1, acc[0][1]);
             acc[1][0] = CTC_MFMA(fj1, fi0, acc[1][0]);
