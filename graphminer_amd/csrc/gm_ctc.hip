@@ -133,7 +133,8 @@ __global__ __launch_bounds__(kCtcWaves *GM_WAVE) void core_tc_kernel(const CoreT
 constexpr int kCtcBWaves = 8;        // wave (wi = w & 3, wj = w >> 2): I rows 64 wi .. + 63, J rows 128 wj .. + 127 of the block
 // (a column chunk: 512 columns = 16 words = 64 bytes of a row)
 constexpr int kCtcBStride = 20;      // LDS words per row (16 + 4: see the header)
-constexpr int kCtcBPiece = 16;       // chunks per task
+constexpr int kCtcBPiece = 16;       // chunks per task (triangle count)
+constexpr int kCtcBPieceSup = 32;    // ... of the edge supports' product: every piece ends with an epilogue of atomics per edge
 struct alignas(16) CtcBlockLds {
   unsigned pan[512 * kCtcBStride];  // rows 0 .. 255: the I rows' chunk, 256 .. 511: the J rows'
   unsigned queue_pos;
@@ -154,7 +155,8 @@ __global__ __launch_bounds__(kCtcBWaves *GM_WAVE) void core_tc_block_kernel(cons
   const int l31 = lane & 31, h = lane >> 5;
   const int wi = wave & 3, wj = wave >> 2;
   const int H = p.h, rw = p.row_words;
-  const int nc = H >> 9, maxp = (nc + kCtcBPiece - 1) / kCtcBPiece;
+  constexpr int kPiece = SUP ? kCtcBPieceSup : kCtcBPiece;
+  const int nc = H >> 9, maxp = (nc + kPiece - 1) / kPiece;
   const unsigned *__restrict__ M = p.core + (size_t)p.row0 * (size_t)rw + (size_t)p.word0;
   // this thread's four 16-byte pieces of a chunk: piece x = tid + 512 k -> row x >> 2 of the 512 staged rows, segment x & 3 of its 64 bytes
   const int seg = tid & 3, srow = tid >> 2;  // rows srow, srow + 128 (I), srow + 256, srow + 384 (J)
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(kCtcBWaves *GM_WAVE) void core_tc_block_kernel(cons
     while (JB * (JB + 1) / 2 > pair) --JB;
     const int IB = pair - JB * (JB + 1) / 2;
     // chunks below the J block hold no bit of its rows (strictly upper triangular); the chunk with the diagonal is taken whole
-    const int cb = (SUP ? 0 : (JB >> 1)) + piece * kCtcBPiece, ce = min(cb + kCtcBPiece, nc);
+    const int cb = (SUP ? 0 : (JB >> 1)) + piece * kPiece, ce = min(cb + kPiece, nc);
     if (cb >= nc) continue;  // (workgroup-uniform: this pair has fewer pieces)
     // (the first chunk is requested before the mask words: one round trip for both)
     const uint4 *g0 = reinterpret_cast<const uint4 *>(M + (size_t)(256 * IB + srow) * rw) + seg;
@@ -292,6 +294,7 @@ bool core_tc_fast_path(const CoreTcParams &p) {  // whole chunks of 512 columns,
 hipError_t launch_core_tc(CoreTcParams p, int cu_count, hipStream_t stream) {
   static_assert(sizeof(CtcBlockLds) <= 65536, "one workgroup per CU, static LDS");
   static_assert(kCtcBPiece * 512 * 128 < (1 << 24), "a piece's masked sum stays exact in f32");
+  static_assert(kCtcBPieceSup * 512 < (1 << 24), "an accumulator of a supports' piece stays exact in f32");
   if (p.core == nullptr || p.h < 1 || p.h > kCtcMaxH || p.step < 1 || p.first < 0 || p.first >= p.step) return hipErrorInvalidValue;
   const bool fast = core_tc_fast_path(p);
   const int nJ = (p.h + 63) >> 6;
@@ -339,7 +342,7 @@ hipError_t launch_core_sup(CoreTcParams p, int cu_count, hipStream_t stream) {
       p.row_words != p.h / 32 || p.row0 != 0 || p.word0 != 0 || p.step < 1 || p.first < 0 || p.first >= p.step)
     return hipErrorInvalidValue;
   const int nb = p.h >> 8, nc = p.h >> 9;
-  p.ntasks = nb * (nb + 1) / 2 * ((nc + kCtcBPiece - 1) / kCtcBPiece);
+  p.ntasks = nb * (nb + 1) / 2 * ((nc + kCtcBPieceSup - 1) / kCtcBPieceSup);
   const long long mine = ((long long)p.ntasks - p.first + p.step - 1) / p.step;
   if (mine <= 0) return hipSuccess;
   const int grid = (int)std::max<long long>(1, std::min<long long>(mine, (long long)cu_count));
