@@ -1006,7 +1006,7 @@ def finish_record(rec, a, world, ab, floor, traffic, traffic_src, cpu, known, st
             traffic["write_bytes"] = sum(v.get("WRITE_SIZE", 0) * 1024.0 for k, v in traffic["kernels"].items() if CORNER_KERNEL not in k)
         roof["corner_kernel"] = ctr
         roof["streamed_kernels_ms"] = round(t * 1e3, 4)
-        roof["kernel"] = " + ".join(k for k in roof["kernel"].split(" + ") if CORNER_KERNEL not in k) + "  (HBM roofline of the streamed kernels; corner_kernel: the MFMA part)"
+        roof["kernel"] = " + ".join(k for k in roof["kernel"].split(" + ") if CORNER_KERNEL not in k) + " (streamed kernels; corner_kernel = the MFMA part)"
         if own is not None and own.get("parts", {}).get("corner_operand_chunks"):
             own = dict(own, bytes=own["bytes"] - own["parts"]["corner_operand_chunks"])
     tr_gbs = None

@@ -14,7 +14,7 @@
 //   * core_tc_block_kernel (corners of a multiple of 512 vertices, 16-byte aligned rows: every real graph): a workgroup of eight waves takes a
 //     256 x 256 block of (i, j), wave (wi, wj) its 64 x 128 part (2 x 4 accumulator tiles: six operand words expanded per eight MFMAs, 34 vector instructions), over
 //     column chunks of 512: the chunk of the 256 I rows and the 256 J rows (32 KB, 64 contiguous bytes per row) goes global -> registers
-//     -> LDS, the next chunk's loads in flight while this one is multiplied; LDS rows of 20 words (the sixteen lanes of a quarter of a
+//     -> LDS (two stages: one workgroup barrier per chunk), the next chunk's loads in flight while this one is multiplied; LDS rows of 20 words (the sixteen lanes of a quarter of a
 //     ds_read_b128 hit sixteen different bank groups).  The order of the columns inside an operand fragment does not matter and neither
 //     does the assignment of column words to MFMA steps -- both operands are rows of the same matrix, expanded the same way -- so lane
 //     (row l & 31, half h = l >> 5) reads the four words 4 (2 q + h) .. + 3 of its row with one 16-byte read and feeds word w to step
@@ -135,8 +135,13 @@ constexpr int kCtcBWaves = 8;        // wave (wi = w & 3, wj = w >> 2): I rows 6
 constexpr int kCtcBStride = 20;      // LDS words per row (16 + 4: see the header)
 constexpr int kCtcBPiece = 16;       // chunks per task (triangle count)
 constexpr int kCtcBPieceSup = 32;    // ... of the edge supports' product: every piece ends with an epilogue of atomics per edge
+#ifndef GM_CTC_DOUBLE
+#define GM_CTC_DOUBLE 1  // two LDS stages (80 KB), one workgroup barrier per chunk; 0: one stage, two barriers (A/B: profiles/r05/ab_tc_core.txt: 5 - 6 % slower)
+#endif
+constexpr int kCtcBStages = GM_CTC_DOUBLE ? 2 : 1;
+constexpr int kCtcBPanWords = 512 * kCtcBStride;
 struct alignas(16) CtcBlockLds {
-  unsigned pan[512 * kCtcBStride];  // rows 0 .. 255: the I rows' chunk, 256 .. 511: the J rows'
+  unsigned pan[kCtcBStages * kCtcBPanWords];  // per stage -- rows 0 .. 255: the I rows' chunk, 256 .. 511: the J rows'
   unsigned queue_pos;
   int pad_[3];
 };
@@ -214,21 +219,34 @@ __global__ __launch_bounds__(kCtcBWaves *GM_WAVE) void core_tc_block_kernel(cons
       for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[jj][ii][r] = 0.f;
-    for (int ch = cb; ch < ce; ++ch) {
-      __syncthreads();  // the previous chunk has been read
-      *reinterpret_cast<uint4 *>(&S.pan[(srow) * kCtcBStride + 4 * seg]) = r0;
-      *reinterpret_cast<uint4 *>(&S.pan[(srow + 128) * kCtcBStride + 4 * seg]) = r1;
-      *reinterpret_cast<uint4 *>(&S.pan[(srow + 256) * kCtcBStride + 4 * seg]) = r2;
-      *reinterpret_cast<uint4 *>(&S.pan[(srow + 384) * kCtcBStride + 4 * seg]) = r3;
+    auto stage_store = [&](const int st) {
+      unsigned *pan = S.pan + st * kCtcBPanWords;
+      *reinterpret_cast<uint4 *>(&pan[(srow) * kCtcBStride + 4 * seg]) = r0;
+      *reinterpret_cast<uint4 *>(&pan[(srow + 128) * kCtcBStride + 4 * seg]) = r1;
+      *reinterpret_cast<uint4 *>(&pan[(srow + 256) * kCtcBStride + 4 * seg]) = r2;
+      *reinterpret_cast<uint4 *>(&pan[(srow + 384) * kCtcBStride + 4 * seg]) = r3;
+    };
+    if (GM_CTC_DOUBLE) {  // chunk cb into stage 0, chunk cb + 1 requested (the stages of the previous task were last read before its final barrier)
+      stage_store(0);
       __syncthreads();
-      if (ch + 1 < ce) {  // the next chunk's loads stay in flight while this one is multiplied
-        r0 = g0[4 * ch + 4]; r1 = g1[4 * ch + 4]; r2 = g2[4 * ch + 4]; r3 = g3[4 * ch + 4];
+      if (cb + 1 < ce) { r0 = g0[4 * cb + 4]; r1 = g1[4 * cb + 4]; r2 = g2[4 * cb + 4]; r3 = g3[4 * cb + 4]; }
+    }
+    for (int ch = cb; ch < ce; ++ch) {
+      const int st = GM_CTC_DOUBLE ? ((ch - cb) & 1) : 0;
+      if (!GM_CTC_DOUBLE) {
+        __syncthreads();  // the previous chunk has been read
+        stage_store(0);
+        __syncthreads();
+        if (ch + 1 < ce) {  // the next chunk's loads stay in flight while this one is multiplied
+          r0 = g0[4 * ch + 4]; r1 = g1[4 * ch + 4]; r2 = g2[4 * ch + 4]; r3 = g3[4 * ch + 4];
+        }
       }
+      const int so = st * (kCtcBPanWords / 4);  // (uint4 units)
       if (any) {
 #pragma unroll
         for (int qq = 0; qq < 2; ++qq) {  // words 4 (2 qq + h) .. + 3 of the chunk: word w feeds step 4 qq + w
-          const uint4 xi0 = li[0][2 * qq], xi1 = li[1][2 * qq];
-          const uint4 xj0 = lj[0][2 * qq], xj1 = lj[1][2 * qq], xj2 = lj[2][2 * qq], xj3 = lj[3][2 * qq];
+          const uint4 xi0 = li[0][so + 2 * qq], xi1 = li[1][so + 2 * qq];
+          const uint4 xj0 = lj[0][so + 2 * qq], xj1 = lj[1][so + 2 * qq], xj2 = lj[2][so + 2 * qq], xj3 = lj[3][so + 2 * qq];
           const unsigned wi0[4] = {xi0.x, xi0.y, xi0.z, xi0.w}, wi1[4] = {xi1.x, xi1.y, xi1.z, xi1.w};
           const unsigned wj0[4] = {xj0.x, xj0.y, xj0.z, xj0.w}, wj1[4] = {xj1.x, xj1.y, xj1.z, xj1.w};
           const unsigned wj2[4] = {xj2.x, xj2.y, xj2.z, xj2.w}, wj3[4] = {xj3.x, xj3.y, xj3.z, xj3.w};
@@ -246,6 +264,11 @@ __global__ __launch_bounds__(kCtcBWaves *GM_WAVE) void core_tc_block_kernel(cons
             acc[3][1] = CTC_MFMA(fj3, fi1, acc[3][1]);
           }
         }
+      }
+      if (GM_CTC_DOUBLE) {  // chunk ch + 1 into the other stage (its loads had this chunk's products to land), chunk ch + 2 requested
+        if (ch + 1 < ce) stage_store(st ^ 1);
+        if (ch + 2 < ce) { r0 = g0[4 * ch + 8]; r1 = g1[4 * ch + 8]; r2 = g2[4 * ch + 8]; r3 = g3[4 * ch + 8]; }
+        __syncthreads();  // everybody has read stage st and written stage st ^ 1
       }
     }
     if (any && SUP) {
@@ -292,7 +315,7 @@ bool core_tc_fast_path(const CoreTcParams &p) {  // whole chunks of 512 columns,
 
 // p.first / p.step = the rank and the world of the launch (every world-th task); ntasks is filled in here
 hipError_t launch_core_tc(CoreTcParams p, int cu_count, hipStream_t stream) {
-  static_assert(sizeof(CtcBlockLds) <= 65536, "one workgroup per CU, static LDS");
+  static_assert(sizeof(CtcBlockLds) <= (GM_CTC_DOUBLE ? 163840 : 65536), "one workgroup per CU, static LDS");
   static_assert(kCtcBPiece * 512 * 128 < (1 << 24), "a piece's masked sum stays exact in f32");
   static_assert(kCtcBPieceSup * 512 < (1 << 24), "an accumulator of a supports' piece stays exact in f32");
   if (p.core == nullptr || p.h < 1 || p.h > kCtcMaxH || p.step < 1 || p.first < 0 || p.first >= p.step) return hipErrorInvalidValue;

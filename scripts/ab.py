@@ -24,9 +24,10 @@ for case in cases:
                 if l.startswith("["):
                     print("    ", l[:200], flush=True)
             d = json.loads(line[0])
+            corner = (d.get("roofline") or {}).get("corner_kernel") or {}
             res[f"{label}/{v}"] = {"kernel_ms": d["kernel_ms_avg"], "ms_per_step": d["ms_per_step"], "count": d["count"],
-                                   "frac": d["roofline"].get("algorithmic_frac"), "setup": d["setup_ms"], "first_call_ms": d["first_call_ms"]}
-            print(f"{label:28s} {v:12s} kernel {d['kernel_ms_avg']:10.4f} ms  alg_frac {d['roofline'].get('algorithmic_frac')}  count {d['count']}  setup {d['setup_ms']}", flush=True)
+                                   "corner_ms": corner.get("ms"), "first_call_ms": d.get("first_call_ms")}
+            print(f"{label:28s} {v:12s} kernel {d['kernel_ms_avg']:10.4f} ms  corner {corner.get('ms')}  count {d['count']}  first call {d.get('first_call_ms')}", flush=True)
         except Exception as e:
             res[f"{label}/{v}"] = {"error": str(e)}
             print(label, v, "EXC", e, flush=True)

@@ -6,7 +6,7 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 ( time timeout 3000 python -m pytest tests -m gpu -q -x ) > "$out/pytest_gpu.log" 2>&1
 echo "pytest rc=$?"; tail -3 "$out/pytest_gpu.log"
-timeout 1200 python bench.py --steps 20 --warmup 3 > "$out/bench_default_line.json" 2> "$out/bench_default.err"
+timeout 1200 python bench.py --gpus 1 --steps 20 --warmup 5 --detail "$out/bench_default_detail.json" > "$out/bench_default_line.json" 2> "$out/bench_default.err"
 echo "bench rc=$?"; python - "$out/bench_default_line.json" <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
