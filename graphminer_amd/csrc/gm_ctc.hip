@@ -305,8 +305,16 @@ __global__ __launch_bounds__(kCtcBWaves *GM_WAVE) void core_tc_block_kernel(cons
   }
   if (SUP) return;
   tot += (unsigned long long)c;
-  const unsigned long long s0 = wave_sum_u64(tot);
-  if (lane == 0 && s0) atomicAdd(&p.counters[0], s0);
+  const unsigned long long s0 = wave_sum_u64(tot);  // one atomic per workgroup (same-address atomics queue up, ~10 ns each)
+  __syncthreads();
+  unsigned long long *part = reinterpret_cast<unsigned long long *>(S.pan);
+  if (lane == 0) part[wave] = s0;
+  __syncthreads();
+  if (tid == 0) {
+    unsigned long long t = 0;
+    for (int w = 0; w < kCtcBWaves; ++w) t += part[w];
+    if (t) atomicAdd(&p.counters[0], t);
+  }
 }
 
 bool core_tc_fast_path(const CoreTcParams &p) {  // whole chunks of 512 columns, rows and the corner 16-byte aligned
