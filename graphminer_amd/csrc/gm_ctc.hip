@@ -135,10 +135,7 @@ constexpr int kCtcBWaves = 8;        // wave (wi = w & 3, wj = w >> 2): I rows 6
 constexpr int kCtcBStride = 20;      // LDS words per row (16 + 4: see the header)
 constexpr int kCtcBPiece = 16;       // chunks per task (triangle count)
 constexpr int kCtcBPieceSup = 32;    // ... of the edge supports' product: every piece ends with an epilogue of atomics per edge
-#ifndef GM_CTC_DOUBLE
-#define GM_CTC_DOUBLE 1  // two LDS stages (80 KB), one workgroup barrier per chunk; 0: one stage, two barriers (A/B: profiles/r05/ab_tc_core.txt: 5 - 6 % slower)
-#endif
-constexpr int kCtcBStages = GM_CTC_DOUBLE ? 2 : 1;
+constexpr int kCtcBStages = 2;  // two LDS stages (80 KB): ONE workgroup barrier per chunk (one stage, two barriers: 5 - 6 % slower, profiles/r05/ab_tc_core.txt)
 constexpr int kCtcBPanWords = 512 * kCtcBStride;
 struct alignas(16) CtcBlockLds {
   unsigned pan[kCtcBStages * kCtcBPanWords];  // per stage -- rows 0 .. 255: the I rows' chunk, 256 .. 511: the J rows'
@@ -226,21 +223,12 @@ __global__ __launch_bounds__(kCtcBWaves *GM_WAVE) void core_tc_block_kernel(cons
       *reinterpret_cast<uint4 *>(&pan[(srow + 256) * kCtcBStride + 4 * seg]) = r2;
       *reinterpret_cast<uint4 *>(&pan[(srow + 384) * kCtcBStride + 4 * seg]) = r3;
     };
-    if (GM_CTC_DOUBLE) {  // chunk cb into stage 0, chunk cb + 1 requested (the stages of the previous task were last read before its final barrier)
-      stage_store(0);
-      __syncthreads();
-      if (cb + 1 < ce) { r0 = g0[4 * cb + 4]; r1 = g1[4 * cb + 4]; r2 = g2[4 * cb + 4]; r3 = g3[4 * cb + 4]; }
-    }
+    // chunk cb into stage 0, chunk cb + 1 requested (the stages of the previous task were last read before its final barrier)
+    stage_store(0);
+    __syncthreads();
+    if (cb + 1 < ce) { r0 = g0[4 * cb + 4]; r1 = g1[4 * cb + 4]; r2 = g2[4 * cb + 4]; r3 = g3[4 * cb + 4]; }
     for (int ch = cb; ch < ce; ++ch) {
-      const int st = GM_CTC_DOUBLE ? ((ch - cb) & 1) : 0;
-      if (!GM_CTC_DOUBLE) {
-        __syncthreads();  // the previous chunk has been read
-        stage_store(0);
-        __syncthreads();
-        if (ch + 1 < ce) {  // the next chunk's loads stay in flight while this one is multiplied
-          r0 = g0[4 * ch + 4]; r1 = g1[4 * ch + 4]; r2 = g2[4 * ch + 4]; r3 = g3[4 * ch + 4];
-        }
-      }
+      const int st = (ch - cb) & 1;
       const int so = st * (kCtcBPanWords / 4);  // (uint4 units)
       if (any) {
 #pragma unroll
@@ -265,11 +253,10 @@ __global__ __launch_bounds__(kCtcBWaves *GM_WAVE) void core_tc_block_kernel(cons
           }
         }
       }
-      if (GM_CTC_DOUBLE) {  // chunk ch + 1 into the other stage (its loads had this chunk's products to land), chunk ch + 2 requested
-        if (ch + 1 < ce) stage_store(st ^ 1);
-        if (ch + 2 < ce) { r0 = g0[4 * ch + 8]; r1 = g1[4 * ch + 8]; r2 = g2[4 * ch + 8]; r3 = g3[4 * ch + 8]; }
-        __syncthreads();  // everybody has read stage st and written stage st ^ 1
-      }
+      // chunk ch + 1 into the other stage (its loads had this chunk's products to land), chunk ch + 2 requested
+      if (ch + 1 < ce) stage_store(st ^ 1);
+      if (ch + 2 < ce) { r0 = g0[4 * ch + 8]; r1 = g1[4 * ch + 8]; r2 = g2[4 * ch + 8]; r3 = g3[4 * ch + 8]; }
+      __syncthreads();  // everybody has read stage st and written stage st ^ 1
     }
     if (any && SUP) {
 #pragma unroll
@@ -323,7 +310,7 @@ bool core_tc_fast_path(const CoreTcParams &p) {  // whole chunks of 512 columns,
 
 // p.first / p.step = the rank and the world of the launch (every world-th task); ntasks is filled in here
 hipError_t launch_core_tc(CoreTcParams p, int cu_count, hipStream_t stream) {
-  static_assert(sizeof(CtcBlockLds) <= (GM_CTC_DOUBLE ? 163840 : 65536), "one workgroup per CU, static LDS");
+  static_assert(sizeof(CtcBlockLds) <= 163840, "one workgroup per CU (two waves per SIMD: 246 registers), static LDS");
   static_assert(kCtcBPiece * 512 * 128 < (1 << 24), "a piece's masked sum stays exact in f32");
   static_assert(kCtcBPieceSup * 512 < (1 << 24), "an accumulator of a supports' piece stays exact in f32");
   if (p.core == nullptr || p.h < 1 || p.h > kCtcMaxH || p.step < 1 || p.first < 0 || p.first >= p.step) return hipErrorInvalidValue;
