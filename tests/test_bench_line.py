@@ -32,6 +32,24 @@ def test_compact_line_of_the_round_4_record():
     assert "model" not in line["config"] and line["config"]["workload"].startswith("tc")
 
 
+def test_compact_line_of_the_round_5_record_carries_the_corner_kernel():
+    """round 5: the headline's launch has a hub-corner kernel on the matrix cores (csrc/gm_ctc.hip) -- the line prices the streamed kernels
+    against the HBM roofline and carries the MFMA part beside it, and still fits 4 KB"""
+    import bench
+
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05", "bench_default_detail.json")))
+    line = bench.compact_line(full, "gpurun_out/bench_detail.json")
+    raw = json.dumps(line, separators=(",", ":"))
+    assert len(raw) < 4096, len(raw)
+    for k in REQUIRED:
+        assert k in line, k
+    roof = line["roofline"]
+    assert roof["bound"] == "hbm" and 0 < roof["frac"] <= 1 and roof["streamed_kernels_ms"] < line["kernel_ms_avg"]
+    ck = roof["corner_kernel"]
+    assert ck["bound"] == "mfma" and 0 < ck["frac"] <= 1 and abs(ck["ms"] + roof["streamed_kernels_ms"] - line["kernel_ms_avg"]) < 0.02
+    assert all(c["count_ok"] for c in line["configs"])
+
+
 def test_full_size_cpu_records_are_on_the_bench_graphs():
     import bench
 
