@@ -97,3 +97,39 @@ def test_default_rule_takes_a_corner_on_rmat20_and_the_formula_motif_follows(dev
         wedges_tri = MotifSolver(s, 3, formula=True)
         assert wedges_tri[1] == want
         assert MotifSolver(s, 3) == wedges_tri
+
+
+def _dense_random_graph(n, p, seed):
+    rng = np.random.default_rng(seed)
+    s, d = np.triu_indices(n, 1)
+    keep = rng.random(s.size) < p
+    return csr_from_pairs(n, s[keep].astype(np.uint64), d[keep].astype(np.uint64))
+
+
+@pytest.mark.parametrize("n,p,h", [(2000, 0.9, 1024), (2000, 0.9, 2000), (2300, 0.95, 1024)])
+def test_corner_beside_the_two_stage_tables_and_rows_beyond_the_stage(dev, n, p, h, monkeypatch):
+    """dense graphs whose DAG rows reach 1025 .. 2048 entries (two task tables: the 1024- and the 2048-entry kernel, forced on this small
+    graph) and, for n = 2300, rows beyond the 2048-entry stage -- there the corner must stay OFF (those rows' out-edges are the chunked
+    kernel's / sup_long_kernel's): triangle count against the oracle, diamond against the per-edge kernels (one intersection of the symmetric
+    lists per edge: no corner, no triangle pass; the oracle's diamond takes minutes on these graphs) with a corner forced"""
+    from graphminer_amd import SglSolver
+
+    monkeypatch.setenv("GM_TOPO_MIN_ROW", "0")
+    monkeypatch.setenv("GM_TCT_SPLIT_ALWAYS", "1")
+    monkeypatch.setenv("GM_TC_CORE_H", str(h))
+    monkeypatch.setenv("GM_SUP_CORE_H", "1024")
+    g = _dense_random_graph(n, p, n + h)
+    osym = O.OGraph(g.row_ptr, g.col_idx)
+    odag = O.orient(osym)
+    dmax = int(np.diff(odag.row_ptr).max())
+    assert (dmax > 2048) == (n == 2300) and dmax > 1024
+    want_tc = O.tc(odag)
+    with g.to_device(dev) as s, s.orient() as dag:
+        assert TCSolver(dag) == want_tc
+        info = tc_core_info(dag)
+        assert (info["h"] == 0) == (n == 2300), info
+        assert sum(TCSolver(dag, rank=r, world=3) for r in range(3)) == want_tc
+        assert TCSolver(dag, tune=[0, 0, 0, 0, 0, 0, 0x20000000]) == want_tc
+        want_dia = SglSolver(s, "diamond", tune=[0, 0, 0, 0, 0, 0, 0x10000000])
+        assert want_dia > 0 and SglSolver(s, "diamond") == want_dia
+        assert SglSolver(s, "diamond", tune=[0, 0, 0, 0, 0, 0, 0x40000000]) == want_dia
