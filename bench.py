@@ -1006,6 +1006,9 @@ def finish_record(rec, a, world, ab, floor, traffic, traffic_src, cpu, known, st
             traffic["write_bytes"] = sum(v.get("WRITE_SIZE", 0) * 1024.0 for k, v in traffic["kernels"].items() if CORNER_KERNEL not in k)
         roof["corner_kernel"] = ctr
         roof["streamed_kernels_ms"] = round(t * 1e3, 4)
+        if traffic and "traffic" in ctr:  # (for comparison with the rounds before the corner: every kernel's counter traffic over the whole launch)
+            whole = (traffic.get("fetch_bytes", 0.0) + traffic.get("write_bytes", 0.0) + ctr["traffic"]) / (rec["kernel_ms_avg"] * 1e-3) / 1e9
+            roof["whole_launch_frac"] = round(whole / HBM_PEAK_GBS, 5)
         roof["kernel"] = " + ".join(k for k in roof["kernel"].split(" + ") if CORNER_KERNEL not in k) + " (streamed kernels; corner_kernel = the MFMA part)"
         if own is not None and own.get("parts", {}).get("corner_operand_chunks"):
             own = dict(own, bytes=own["bytes"] - own["parts"]["corner_operand_chunks"])
@@ -1147,7 +1150,7 @@ SHORT_BASIS = (("counter traffic", "counter_traffic: rocprofv3 --pmc FETCH_SIZE 
 def compact_roofline(r):
     """the roofline object of the stdout line: the contract's keys + the three byte figures, no prose"""
     keys = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "own_bytes_per_launch", "own_frac", "algorithmic_bytes_per_launch",
-            "algorithmic_GBs", "frac_8d_valid", "compulsory_floor_bytes", "stream_ceiling_GBs", "frac_of_stream_ceiling", "streamed_kernels_ms")
+            "algorithmic_GBs", "frac_8d_valid", "compulsory_floor_bytes", "stream_ceiling_GBs", "frac_of_stream_ceiling", "streamed_kernels_ms", "whole_launch_frac")
     out = {k: r[k] for k in keys if k in r}
     if "kernel" in out:
         out["kernel"] = out["kernel"][:96]

@@ -11,6 +11,88 @@ using namespace gm;
 thread_local std::string g_last_error;
 thread_local TempPool *g_temp_pool = nullptr;
 
+// ---- the cache of large temporaries (gm_host.h DevBuf) ----
+namespace {
+struct BigBlock { void *p; size_t bytes; int device; };
+std::mutex g_big_mu;
+std::vector<BigBlock> g_big_blocks;
+size_t g_big_total = 0;
+constexpr size_t kBigCacheBudget = (size_t)16 << 30;
+bool big_cache_on() {
+  static const bool on = getenv("GM_NO_TEMP_POOL") == nullptr;  // (the switch of the tests that compare with the plain hipMalloc / hipFree path)
+  return on;
+}
+}  // namespace
+hipError_t big_cache_get(void **p, size_t bytes, size_t *block_bytes) {
+  *block_bytes = 0;
+  if (big_cache_on()) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    void *hit = nullptr;
+    size_t hit_bytes = 0;
+    {
+      std::lock_guard<std::mutex> lk(g_big_mu);
+      size_t best = g_big_blocks.size();
+      for (size_t i = 0; i < g_big_blocks.size(); ++i) {  // the smallest block that holds the request without wasting more than 3 / 4 of itself
+        const BigBlock &b = g_big_blocks[i];
+        if (b.device == dev && b.bytes >= bytes && b.bytes / 4 <= bytes && (best == g_big_blocks.size() || b.bytes < g_big_blocks[best].bytes)) best = i;
+      }
+      if (best != g_big_blocks.size()) {
+        hit = g_big_blocks[best].p;
+        hit_bytes = g_big_blocks[best].bytes;
+        g_big_total -= hit_bytes;
+        g_big_blocks.erase(g_big_blocks.begin() + (long)best);
+      }
+    }
+    if (hit) {
+      *p = hit;
+      *block_bytes = hit_bytes;
+      return hipSuccess;  // (big_cache_put synchronised the device before the block went in)
+    }
+  }
+  const hipError_t e = hipMalloc(p, bytes);
+  if (e == hipSuccess && big_cache_on()) *block_bytes = bytes;
+  if (e != hipSuccess && big_cache_on()) {  // no room: give the cached blocks back and try once more
+    (void)hipGetLastError();
+    big_cache_trim();
+    const hipError_t e2 = hipMalloc(p, bytes);
+    if (e2 == hipSuccess) *block_bytes = bytes;
+    return e2;
+  }
+  return e;
+}
+void big_cache_put(void *p, size_t block_bytes) {
+  if (!p) return;
+  (void)hipDeviceSynchronize();  // what hipFree did implicitly: nothing may still be using the block when it is handed out again
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  {
+    std::lock_guard<std::mutex> lk(g_big_mu);
+    if (big_cache_on() && g_big_total + block_bytes <= kBigCacheBudget && g_big_blocks.size() < 64) {
+      g_big_blocks.push_back({p, block_bytes, dev});
+      g_big_total += block_bytes;
+      return;
+    }
+  }
+  (void)hipFree(p);
+}
+void big_cache_trim() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::vector<BigBlock> mine;
+  {
+    std::lock_guard<std::mutex> lk(g_big_mu);
+    for (size_t i = 0; i < g_big_blocks.size();) {
+      if (g_big_blocks[i].device == dev) {
+        mine.push_back(g_big_blocks[i]);
+        g_big_total -= g_big_blocks[i].bytes;
+        g_big_blocks.erase(g_big_blocks.begin() + (long)i);
+      } else ++i;
+    }
+  }
+  for (auto &b : mine) (void)hipFree(b.p);
+}
+
 thread_local int g_last_hip_error = 0;
 int hip_fail(hipError_t e, const char *what, const char *file, int line) {
   g_last_hip_error = (int)e;
@@ -124,7 +206,9 @@ extern "C" void gm_graph_free(gm_graph *g) {
   for (auto &pr : g->ev)
     for (auto &e : pr)
       if (e) (void)hipEventDestroy(e);
+  const bool root = g->pool_owner == nullptr;
   delete g;
+  if (root) big_cache_trim();  // the large temporaries kept for reuse go back to the driver with the handle (not inside a timed call)
 }
 
 int finish_handle(gm_graph *g) {

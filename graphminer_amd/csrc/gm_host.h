@@ -56,19 +56,35 @@ struct TempPool {
 };
 extern thread_local TempPool *g_temp_pool;  // the pool of the innermost open PoolScope of this thread (gm_graph.hip)
 
+// Temporaries that do not fit the pool (the GB-sized scratch copies of orientation / renumbering / the key stream on a large graph) are
+// kept in a small per-device CACHE instead of going back to the driver: hipFree of a large buffer costs 0.2 ms on a good day and 30 ms
+// per GB on a bad one (scripts/alloc_jitter.hip: p90 of hipFree(1 GB) = 30 ms, in phases), and that -- not a kernel -- was the 441 ms
+// first call of config 5 the round-4 driver run recorded against the builder's 80 (reproduced in round 5: orientation 88 instead of 7.5
+// ms, tables 227 instead of 28, every kernel time unchanged).  A block is handed out again to a request of at least a quarter of its size,
+// after a device synchronisation; the cache is emptied when a root handle is freed (gm_graph.hip).
+hipError_t big_cache_get(void **p, size_t bytes, size_t *block_bytes);  // a cached block or a fresh hipMalloc
+void big_cache_put(void *p, size_t block_bytes);                         // synchronises the device; beyond the cache's budget: hipFree
+void big_cache_trim();                                                   // hipFree of every cached block of the current device
+constexpr size_t kBigCacheMinBytes = (size_t)4 << 20;
+
 template <class T>
 struct DevBuf {  // RAII device array; pooled when a PoolScope is open and the pool has room
   T *p = nullptr;
   size_t n = 0;
   bool pooled = false;
+  size_t block_bytes = 0;  // > 0: a block of the large-temporary cache (returned there by drop())
   DevBuf() = default;
   DevBuf(const DevBuf &) = delete;
   DevBuf &operator=(const DevBuf &) = delete;
   ~DevBuf() { drop(); }
   void drop() {
-    if (p && !pooled) (void)hipFree(p);
+    if (p && !pooled) {
+      if (block_bytes) big_cache_put(p, block_bytes);
+      else (void)hipFree(p);
+    }
     p = nullptr;
     pooled = false;
+    block_bytes = 0;
   }
   // keep = true: the array outlives the scope (release() hands it to a long-lived owner): never from the pool
   hipError_t alloc(size_t count, bool keep = false) {
@@ -85,9 +101,11 @@ struct DevBuf {  // RAII device array; pooled when a PoolScope is open and the p
         return hipSuccess;
       }
     }
+    if (!keep && bytes >= kBigCacheMinBytes) return big_cache_get(reinterpret_cast<void **>(&p), bytes, &block_bytes);
     return hipMalloc(&p, bytes);
   }
-  T *release() { T *q = pooled ? nullptr : p; p = nullptr; n = 0; pooled = false; return q; }  // (a pooled array cannot be handed on: alloc(..., true))
+  // (a pooled array cannot be handed on: alloc(..., true); a cached block can -- it is an allocation of its own, only larger than asked for)
+  T *release() { T *q = pooled ? nullptr : p; p = nullptr; n = 0; pooled = false; block_bytes = 0; return q; }
 };
 
 struct ScanTemp {  // temp storage of the hipCUB calls, grown on demand
