@@ -82,7 +82,7 @@ KERNELS = {
     "motif4": ["mine_kernel<5,", "hrow_kernel<5,", "giant_kernel<5,", "rect_acc_kernel", "mine_kernel<3,", "cbuild_kernel", "cgather_kernel", "clique_mma_kernel",
                "clique_small_kernel", "tch_kernel", "core_tc_"],
 }
-CORNER_KERNEL = "core_tc_"  # (the MFMA kernels of gm_ctc.hip: their time and traffic are taken out of the HBM roofline of the streamed kernels)
+CORNER_KERNEL = "core_tc_"  # (the MFMA kernels of gm_ctc.hip: reported beside the whole-launch HBM roofline against the FP4 peak)
 TRAFFIC_MARKER = "issue_calib_kernel"  # the dispatch in front of every workload of the traffic worker (measure_traffic)
 DIAMOND_SUPPORTS_MAX_WORLD = int(os.environ.get("GM_DIAMOND_SUPPORTS_MAX_WORLD", "4"))  # (graphminer_amd/host/multi.cc has the same rule)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (~6.3 TB/s achievable by a stream)
@@ -546,7 +546,7 @@ class Runner:
         # ... up to DIAMOND_SUPPORTS_MAX_WORLD ranks: beyond, a rank's share of the per-edge kernels + the single 8-byte all-reduce north_star
         # names is the better deal (one-GPU simulation of the shares, profiles/r05/sim_scale_one_gpu.txt, R-MAT-22 at 2 / 4 / 8 ranks: shared
         # triangle pass 4.48 / 3.04 / 2.35 ms + a reduce-scatter of 81 / 122 / 142 MB per rank, per-edge kernels 8.20 / 4.75 / 2.90 ms + 8 bytes)
-        dstate = {"on": workload == "diamond" and 1 < la.world <= DIAMOND_SUPPORTS_MAX_WORLD and not (la.tune[6] & 0x10000000) and not os.environ.get("GM_DIAMOND_PER_EDGE"),
+        dstate = {"on": workload == "diamond" and 1 < la.world <= DIAMOND_SUPPORTS_MAX_WORLD and not (la.tune[6] & 0x10000000),
                   "buf": None}
 
         def diamond_sup_step():
@@ -987,31 +987,30 @@ def finish_record(rec, a, world, ab, floor, traffic, traffic_src, cpu, known, st
         alg_gbs = per_launch / t / 1e9
         roof.update({"algorithmic_bytes_per_launch": int(per_launch), "algorithmic_GBs": round(alg_gbs, 2),
                      "algorithmic_frac": round(alg_gbs / HBM_PEAK_GBS, 5)})
-    # A launch with a hub-corner kernel on the matrix cores (gm_ctc.hip): the HBM roofline is the STREAMED kernels' -- their counter traffic over
-    # their time (launch - corner, both HIP events of the library); the corner kernel is reported beside it against the dense FP4 MFMA peak
+    # A launch with a hub-corner kernel on the matrix cores (gm_ctc.hip).  `achieved` / `frac` stay WHOLE-LAUNCH figures (every
+    # kernel's counter traffic, the corner's included, over kernel_ms_avg -- the time the library's two events bracket); the streamed
+    # kernels alone (their traffic over launch - corner) go under `streamed_kernels`, the corner kernel under `corner_kernel` against the
+    # dense FP4 MFMA peak.
     corner_ms = float(rec.get("corner_ms_avg") or 0.0)
-    t_launch = t
     if corner_ms > 0 and corner_ms < rec["kernel_ms_avg"]:
-        t = (rec["kernel_ms_avg"] - corner_ms) * 1e-3
+        t_str = (rec["kernel_ms_avg"] - corner_ms) * 1e-3
         ctr = {"ms": round(corner_ms, 4), "bound": "mfma", "peak": 10000.0, "unit": "TFLOP/s (dense FP4, v_mfma_scale_f32_32x32x64_f8f6f4)"}
         if own is not None and own.get("parts", {}).get("corner_operand_chunks"):
             mf = own["parts"]["corner_operand_chunks"] // 32768 * 512  # MFMA instructions: 8 waves x 64 per (block pair, chunk)
             ctr.update({"mfma_instructions": int(mf), "achieved": round(mf * 131072 / (corner_ms * 1e-3) / 1e12, 1)})
             ctr["frac"] = round(ctr["achieved"] / ctr["peak"], 4)
+        streamed = {"ms": round(t_str * 1e3, 4)}
         if traffic and traffic.get("kernels"):
             cb = sum(v.get("FETCH_SIZE", 0) * 2048.0 + v.get("WRITE_SIZE", 0) * 1024.0 for k, v in traffic["kernels"].items() if CORNER_KERNEL in k)
             ctr["traffic"] = int(cb)
-            traffic = dict(traffic)
-            traffic["fetch_bytes"] = sum(v.get("FETCH_SIZE", 0) * 2048.0 for k, v in traffic["kernels"].items() if CORNER_KERNEL not in k)
-            traffic["write_bytes"] = sum(v.get("WRITE_SIZE", 0) * 1024.0 for k, v in traffic["kernels"].items() if CORNER_KERNEL not in k)
-        roof["corner_kernel"] = ctr
-        roof["streamed_kernels_ms"] = round(t * 1e3, 4)
-        if traffic and "traffic" in ctr:  # (for comparison with the rounds before the corner: every kernel's counter traffic over the whole launch)
-            whole = (traffic.get("fetch_bytes", 0.0) + traffic.get("write_bytes", 0.0) + ctr["traffic"]) / (rec["kernel_ms_avg"] * 1e-3) / 1e9
-            roof["whole_launch_frac"] = round(whole / HBM_PEAK_GBS, 5)
-        roof["kernel"] = " + ".join(k for k in roof["kernel"].split(" + ") if CORNER_KERNEL not in k) + " (streamed kernels; corner_kernel = the MFMA part)"
+            sb = sum(v.get("FETCH_SIZE", 0) * 2048.0 + v.get("WRITE_SIZE", 0) * 1024.0 for k, v in traffic["kernels"].items() if CORNER_KERNEL not in k)
+            streamed.update({"traffic": int(sb), "GBs": round(sb / t_str / 1e9, 2), "frac": round(sb / t_str / 1e9 / HBM_PEAK_GBS, 5)})
         if own is not None and own.get("parts", {}).get("corner_operand_chunks"):
-            own = dict(own, bytes=own["bytes"] - own["parts"]["corner_operand_chunks"])
+            ob = (own["bytes"] - own["parts"]["corner_operand_chunks"]) / world
+            streamed.update({"own_bytes": int(ob), "own_frac": round(ob / t_str / 1e9 / HBM_PEAK_GBS, 5)})
+        roof["corner_kernel"] = ctr
+        roof["streamed_kernels"] = streamed
+        roof["streamed_kernels_ms"] = streamed["ms"]
     tr_gbs = None
     if traffic:
         tb = traffic.get("fetch_bytes", 0.0) + traffic.get("write_bytes", 0.0)
@@ -1156,6 +1155,8 @@ def compact_roofline(r):
         out["kernel"] = out["kernel"][:96]
     if r.get("corner_kernel"):
         out["corner_kernel"] = {k: r["corner_kernel"][k] for k in ("ms", "bound", "achieved", "peak", "frac", "traffic") if k in r["corner_kernel"]}
+    if r.get("streamed_kernels"):  # (round 6: `frac` is the whole launch; the streamed kernels alone beside it)
+        out["streamed_kernels"] = {k: r["streamed_kernels"][k] for k in ("ms", "traffic", "frac", "own_frac") if k in r["streamed_kernels"]}
     basis = r.get("frac_basis") or ""
     out["frac_basis"] = next((short for head, short in SHORT_BASIS if basis.startswith(head)), basis[:80])
     return out

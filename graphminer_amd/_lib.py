@@ -107,6 +107,8 @@ SYMBOLS = [
     ("gm_diamond_support_finish", C.c_int, [_P, C.POINTER(gm_launch), _P, C.c_int64, C.POINTER(C.c_uint64), C.POINTER(gm_stats)]),
     ("gm_constant", C.c_int, [C.c_char_p, C.POINTER(C.c_int64)]),
     ("gm_selftest", C.c_int, [C.c_int, C.POINTER(C.c_int)]),
+    ("gm_dev_option", C.c_int, [C.c_char_p, C.c_char_p]),
+    ("gm_dev_option_get", C.c_char_p, [C.c_char_p]),
 ]
 
 _lib = None
@@ -136,6 +138,15 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def dev_option(name, value=None):
+    """Set (value) / remove (None) a developer option of the library; name = None removes all (include/graphminer_amd.h gm_dev_option:
+    the switches tests and A/B runs use -- the library reads no algorithm switch from the environment)."""
+    lib = load()
+    st = lib.gm_dev_option(None if name is None else str(name).encode(), None if value is None else str(value).encode())
+    if st != GM_OK:
+        raise GraphMinerError(st, "gm_dev_option", str(name))
 
 
 def check(status: int, where: str):

@@ -11,6 +11,7 @@
 #include <string>
 #include <vector>
 
+#include "../../include/graphminer_amd.h"
 #include "../host/host_graph.h"
 
 #define GM_TC 1
@@ -62,7 +63,29 @@ void usage_and_exit(const char *self) {
 
 }  // namespace
 
+// `--dev NAME=VALUE` anywhere on the command line sets a developer option of the library (gm_dev_option, include/graphminer_amd.h: the
+// switches tests use to reach a path on a small graph) and is removed from argv before the reference's positional layout is read.
+// Nothing is read from the environment.
+static int strip_dev_options(int argc, char **argv) {
+  int n = 0;
+  for (int i = 0; i < argc; ++i) {
+    if (std::string(argv[i]) == "--dev" && i + 1 < argc) {
+      const std::string kv = argv[++i];
+      const size_t eq = kv.find('=');
+      const int rc = eq == std::string::npos ? gm_dev_option(kv.c_str(), "1") : gm_dev_option(kv.substr(0, eq).c_str(), kv.substr(eq + 1).c_str());
+      if (rc != GM_OK) {
+        std::fprintf(stderr, "bad --dev option: %s\n", kv.c_str());
+        std::exit(1);
+      }
+      continue;
+    }
+    argv[n++] = argv[i];
+  }
+  return n;
+}
+
 int main(int argc, char **argv) {
+  argc = strip_dev_options(argc, argv);
   const bool has_second = (GM_APP != GM_TC);
   if (argc < (has_second ? 3 : 2)) usage_and_exit(argv[0]);
   const Cli c = parse(argc, argv, has_second);

@@ -11,21 +11,61 @@ using namespace gm;
 thread_local std::string g_last_error;
 thread_local TempPool *g_temp_pool = nullptr;
 
+// ---- developer options (gm_mine.h; include/graphminer_amd.h gm_dev_option) ----
+namespace {
+std::mutex g_opt_mu;
+std::list<std::pair<std::string, std::string>> g_opts;  // (a list: the strings gm_opt hands out stay where they are while other options change)
+}  // namespace
+const char *gm_opt(const char *name) {
+  if (!name) return nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_opt_mu);
+    for (const auto &kv : g_opts)
+      if (kv.first == name) return kv.second.c_str();
+  }
+#ifdef GM_DEVEL
+  return getenv(name);
+#else
+  return nullptr;
+#endif
+}
+extern "C" const char *gm_dev_option_get(const char *name) { return gm_opt(name); }
+extern "C" int gm_dev_option(const char *name, const char *value) {
+  std::lock_guard<std::mutex> lk(g_opt_mu);
+  if (!name) {
+    g_opts.clear();
+    return GM_OK;
+  }
+  if (!*name) return GM_ERR_INVALID;
+  for (auto it = g_opts.begin(); it != g_opts.end(); ++it)
+    if (it->first == name) {
+      g_opts.erase(it);
+      break;
+    }
+  if (value) g_opts.emplace_back(name, value);
+  return GM_OK;
+}
+
 // ---- the cache of large temporaries (gm_host.h DevBuf) ----
 namespace {
 struct BigBlock { void *p; size_t bytes; int device; };
 std::mutex g_big_mu;
 std::vector<BigBlock> g_big_blocks;
-size_t g_big_total = 0;
-constexpr size_t kBigCacheBudget = (size_t)16 << 30;
-bool big_cache_on() {
-  static const bool on = getenv("GM_NO_TEMP_POOL") == nullptr;  // (the switch of the tests that compare with the plain hipMalloc / hipFree path)
-  return on;
-}
+constexpr size_t kBigCacheBudget = (size_t)16 << 30;  // per device
+constexpr size_t kBigCacheBlocks = 64;                // per device
+bool big_cache_on() { return gm_opt("GM_NO_TEMP_POOL") == nullptr; }  // (read at every call: tests switch it inside one process)
 }  // namespace
+hipError_t dev_malloc_bytes(void **p, size_t bytes) {
+  const hipError_t e = hipMalloc(p, bytes);
+  if (e != hipErrorOutOfMemory) return e;
+  (void)hipGetLastError();  // no room: the cached temporaries of this device go back to the driver, then once more
+  big_cache_trim();
+  return hipMalloc(p, bytes);
+}
 hipError_t big_cache_get(void **p, size_t bytes, size_t *block_bytes) {
   *block_bytes = 0;
-  if (big_cache_on()) {
+  const bool on = big_cache_on();
+  if (on) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     void *hit = nullptr;
@@ -40,7 +80,6 @@ hipError_t big_cache_get(void **p, size_t bytes, size_t *block_bytes) {
       if (best != g_big_blocks.size()) {
         hit = g_big_blocks[best].p;
         hit_bytes = g_big_blocks[best].bytes;
-        g_big_total -= hit_bytes;
         g_big_blocks.erase(g_big_blocks.begin() + (long)best);
       }
     }
@@ -50,15 +89,8 @@ hipError_t big_cache_get(void **p, size_t bytes, size_t *block_bytes) {
       return hipSuccess;  // (big_cache_put synchronised the device before the block went in)
     }
   }
-  const hipError_t e = hipMalloc(p, bytes);
-  if (e == hipSuccess && big_cache_on()) *block_bytes = bytes;
-  if (e != hipSuccess && big_cache_on()) {  // no room: give the cached blocks back and try once more
-    (void)hipGetLastError();
-    big_cache_trim();
-    const hipError_t e2 = hipMalloc(p, bytes);
-    if (e2 == hipSuccess) *block_bytes = bytes;
-    return e2;
-  }
+  const hipError_t e = dev_malloc_bytes(p, bytes);
+  if (e == hipSuccess && on) *block_bytes = bytes;  // (0: a plain allocation, freed by hipFree)
   return e;
 }
 void big_cache_put(void *p, size_t block_bytes) {
@@ -66,11 +98,13 @@ void big_cache_put(void *p, size_t block_bytes) {
   (void)hipDeviceSynchronize();  // what hipFree did implicitly: nothing may still be using the block when it is handed out again
   int dev = 0;
   (void)hipGetDevice(&dev);
-  {
+  if (big_cache_on()) {
     std::lock_guard<std::mutex> lk(g_big_mu);
-    if (big_cache_on() && g_big_total + block_bytes <= kBigCacheBudget && g_big_blocks.size() < 64) {
+    size_t total = 0, blocks = 0;  // this device's share of the cache
+    for (const BigBlock &b : g_big_blocks)
+      if (b.device == dev) total += b.bytes, ++blocks;
+    if (total + block_bytes <= kBigCacheBudget && blocks < kBigCacheBlocks) {
       g_big_blocks.push_back({p, block_bytes, dev});
-      g_big_total += block_bytes;
       return;
     }
   }
@@ -85,7 +119,6 @@ void big_cache_trim() {
     for (size_t i = 0; i < g_big_blocks.size();) {
       if (g_big_blocks[i].device == dev) {
         mine.push_back(g_big_blocks[i]);
-        g_big_total -= g_big_blocks[i].bytes;
         g_big_blocks.erase(g_big_blocks.begin() + (long)i);
       } else ++i;
     }
@@ -230,7 +263,7 @@ int finish_handle(gm_graph *g) {
     (void)hipDeviceSynchronize();
     (void)hipGetLastError();
   });
-  HIP_TRY(hipMalloc(&g->d_counters, 64));
+  HIP_TRY(dev_malloc(&g->d_counters, 64));
   HIP_TRY(hipMemset(g->d_counters, 0, 64));
   for (auto &pr : g->ev)
     for (auto &e : pr) HIP_TRY(hipEventCreate(&e));
@@ -306,9 +339,9 @@ static int adopt_offsets(gm_graph *g, const int64_t *d_rp64) {
   HIP_TRY(hipMemset(info.p, 0, 8));
   const long long blocks = std::min<long long>(((long long)g->nv + 256) / 256, 4096);
   long long big_from = 0x7fffffffLL;
-  if (const char *e = getenv("GM_BIG_NE")) big_from = std::max(0ll, atoll(e));  // (tests: the 64-bit paths on small graphs)
+  if (const char *e = gm_opt("GM_BIG_NE")) big_from = std::max(0ll, atoll(e));  // (tests: the 64-bit paths on small graphs)
   if (g->ne >= big_from) {  // a big handle: its own copy of the 64-bit offsets
-    HIP_TRY(hipMalloc(&g->d_rp64, sizeof(long long) * ((size_t)g->nv + 1)));
+    HIP_TRY(dev_malloc(&g->d_rp64, sizeof(long long) * ((size_t)g->nv + 1)));
     HIP_TRY(hipMemcpy(g->d_rp64, d_rp64, sizeof(long long) * ((size_t)g->nv + 1), hipMemcpyDeviceToDevice));
     hipLaunchKernelGGL(check_offsets64_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, (const long long *)g->d_rp64, g->nv, g->ne, info.p);
     HIP_TRY(hipGetLastError());
@@ -319,7 +352,7 @@ static int adopt_offsets(gm_graph *g, const int64_t *d_rp64) {
     g->max_deg = h[1];
     return GM_OK;
   }
-  HIP_TRY(hipMalloc(&g->d_rp, sizeof(int) * ((size_t)g->nv + 1)));
+  HIP_TRY(dev_malloc(&g->d_rp, sizeof(int) * ((size_t)g->nv + 1)));
   hipLaunchKernelGGL(convert_offsets_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, (const long long *)d_rp64, g->nv, g->ne, g->d_rp, info.p);
   HIP_TRY(hipGetLastError());  // (a failed launch would leave info == 0 and an uninitialised d_rp behind a passing validation)
   int h[2] = {0, 0};
@@ -371,7 +404,7 @@ extern "C" int gm_graph_upload(const gm_csr *h, int device, gm_graph **out) {
     if (rc) return fail(rc);
   }
   hipError_t e;
-  if ((e = hipMalloc(&g->d_col, sizeof(int) * (size_t)std::max<long long>(g->ne, 1))) != hipSuccess) return fail(hip_fail(e, "hipMalloc(col)", __FILE__, __LINE__));
+  if ((e = dev_malloc(&g->d_col, sizeof(int) * (size_t)std::max<long long>(g->ne, 1))) != hipSuccess) return fail(hip_fail(e, "hipMalloc(col)", __FILE__, __LINE__));
   if (g->ne > 0 && (e = hipMemcpy(g->d_col, h->col_idx, sizeof(int) * (size_t)g->ne, hipMemcpyHostToDevice)) != hipSuccess) return fail(hip_fail(e, "hipMemcpy(col)", __FILE__, __LINE__));
   rc = finish_handle(g);
   if (rc) return fail(rc);
@@ -671,7 +704,7 @@ static int orient_impl(const gm_graph *sym, const OffT *rp_in, gm_graph **out) {
   // the symmetric degrees first: the passes compare (degree, id) of both endpoints of every entry; the oriented handle keeps them (what
   // the topological renumbering of this DAG sorts by -- get_relabeled mode 2)
   int *sdeg = nullptr;
-  HIP_TRY(hipMalloc(&sdeg, sizeof(int) * (size_t)std::max(nv, 1)));
+  HIP_TRY(dev_malloc(&sdeg, sizeof(int) * (size_t)std::max(nv, 1)));
   struct SdegGuard { int *&p; ~SdegGuard() { if (p) (void)hipFree(p); } } sdeg_guard{sdeg};
   if (nv > 0) hipLaunchKernelGGL((symdeg_kernel<OffT>), dim3(vb), dim3(256), 0, 0, nv, rp_in, sdeg);
   // segment table of the long rows (device): counts -> exclusive scan -> fill
@@ -693,7 +726,7 @@ static int orient_impl(const gm_graph *sym, const OffT *rp_in, gm_graph **out) {
   const int bl = std::max(1, std::min((nseg + 3) / 4, sym->cu_count * 8));
   // (the kept entries packed in a scratch copy at their rows' old offsets: pass 1 copies instead of gathering the degrees again --
   //  the gathers are the cost of a pass, one 64-byte sector per entry; GM_ORIENT_TWO_GATHERS=1 keeps round 3's second gather pass)
-  const char *env_two = getenv("GM_ORIENT_TWO_GATHERS");
+  const char *env_two = gm_opt("GM_ORIENT_TWO_GATHERS");
   const bool two_gathers = env_two && *env_two == '1';
   DevBuf<int> packed;
   if (!two_gathers && sym->ne > 0 && packed.alloc((size_t)sym->ne) != hipSuccess) { (void)hipGetLastError(); packed.p = nullptr; }  // (no room: gather twice)
@@ -707,7 +740,7 @@ static int orient_impl(const gm_graph *sym, const OffT *rp_in, gm_graph **out) {
   g->nv = nv;
   auto fail = [&](int code) { gm_graph_free(g); return code; };
   hipError_t e;
-  if ((e = hipMalloc(&g->d_rp, sizeof(int) * ((size_t)nv + 1))) != hipSuccess) return fail(hip_fail(e, "hipMalloc", __FILE__, __LINE__));
+  if ((e = dev_malloc(&g->d_rp, sizeof(int) * ((size_t)nv + 1))) != hipSuccess) return fail(hip_fail(e, "hipMalloc", __FILE__, __LINE__));
   if constexpr (sizeof(OffT) == 8) {
     // the oriented graph of a symmetric graph of >= 2^31 entries: half of them -- checked in 64 bits before the offsets are narrowed
     DevBuf<long long> rp64;
@@ -732,7 +765,7 @@ static int orient_impl(const gm_graph *sym, const OffT *rp_in, gm_graph **out) {
   if ((e = hipMemcpy(&max_deg, md.p, sizeof(int), hipMemcpyDeviceToHost)) != hipSuccess) return fail(hip_fail(e, "hipMemcpy", __FILE__, __LINE__));
   g->ne = ne_new;
   g->max_deg = max_deg;
-  if ((e = hipMalloc(&g->d_col, sizeof(int) * (size_t)std::max(ne_new, 1))) != hipSuccess) return fail(hip_fail(e, "hipMalloc", __FILE__, __LINE__));
+  if ((e = dev_malloc(&g->d_col, sizeof(int) * (size_t)std::max(ne_new, 1))) != hipSuccess) return fail(hip_fail(e, "hipMalloc", __FILE__, __LINE__));
   setup_trace("orient: scan, max degree, allocations");
   // pass 1: compact
   if (nseg) hipLaunchKernelGGL((orient_segout_kernel<OffT>), dim3(vb), dim3(256), 0, 0, nv, rp_in, seg_first.p, segcnt.p, g->d_rp, segs.p);
@@ -1178,13 +1211,13 @@ int get_relabeled(gm_graph *g, int mode, gm_graph **out) {
   r->ne = ne;
   auto fail = [&](hipError_t e, const char *what) { gm_graph_free(r); return hip_fail(e, what, __FILE__, __LINE__); };
   hipError_t e;
-  if ((e = hipMalloc(&r->d_rp, sizeof(int) * nv1)) != hipSuccess) return fail(e, "hipMalloc(rp)");
-  if ((e = hipMalloc(&r->d_col, sizeof(int) * n1)) != hipSuccess) return fail(e, "hipMalloc(col)");
+  if ((e = dev_malloc(&r->d_rp, sizeof(int) * nv1)) != hipSuccess) return fail(e, "hipMalloc(rp)");
+  if ((e = dev_malloc(&r->d_col, sizeof(int) * n1)) != hipSuccess) return fail(e, "hipMalloc(col)");
   if ((e = dev_exclusive_sum(tmp, newdeg.p, r->d_rp, nv1)) != hipSuccess) return fail(e, "ExclusiveSum");
   // rows of at most kRelabelLdsMax entries are sorted inside the kernels that write them (rank / bitonic network in LDS): no key per
   // entry, no device-wide sort; the few rows beyond that -- the hubs of a symmetric graph -- through one segmented radix sort of their
   // segments (GM_RELABEL_GLOBAL_SORT=1: round 3's 64-bit keys + radix sort of every entry)
-  const char *env_gs = getenv("GM_RELABEL_GLOBAL_SORT");
+  const char *env_gs = gm_opt("GM_RELABEL_GLOBAL_SORT");
   const bool global_sort = env_gs && *env_gs == '1';
   const bool rows_in_lds = !global_sort;
   if (ne > 0 && rows_in_lds) {

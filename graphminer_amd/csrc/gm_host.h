@@ -57,7 +57,7 @@ struct TempPool {
 extern thread_local TempPool *g_temp_pool;  // the pool of the innermost open PoolScope of this thread (gm_graph.hip)
 
 // Temporaries that do not fit the pool (the GB-sized scratch copies of orientation / renumbering / the key stream on a large graph) are
-// kept in a small per-device CACHE instead of going back to the driver: hipFree of a large buffer costs 0.2 ms on a good day and 30 ms
+// kept in a small per-device CACHE (a budget of 16 GB and 64 blocks PER DEVICE) instead of going back to the driver: hipFree of a large buffer costs 0.2 ms on a good day and 30 ms
 // per GB on a bad one (scripts/alloc_jitter.hip: p90 of hipFree(1 GB) = 30 ms, in phases), and that -- not a kernel -- was the 441 ms
 // first call of config 5 the round-4 driver run recorded against the builder's 80 (reproduced in round 5: orientation 88 instead of 7.5
 // ms, tables 227 instead of 28, every kernel time unchanged).  A block is handed out again to a request of at least a quarter of its size,
@@ -66,6 +66,12 @@ hipError_t big_cache_get(void **p, size_t bytes, size_t *block_bytes);  // a cac
 void big_cache_put(void *p, size_t block_bytes);                         // synchronises the device; beyond the cache's budget: hipFree
 void big_cache_trim();                                                   // hipFree of every cached block of the current device
 constexpr size_t kBigCacheMinBytes = (size_t)4 << 20;
+// EVERY device allocation of the library goes through here: hipMalloc, and when the device is out of memory the cached
+// temporaries of this device go back to the driver and the request is made once more -- the cache may park up to its budget of memory
+// that nothing else can reach, and a setup path must not fail (or quietly drop an optimisation) while it does.
+hipError_t dev_malloc_bytes(void **p, size_t bytes);
+template <class T>
+inline hipError_t dev_malloc(T **p, size_t bytes) { return dev_malloc_bytes(reinterpret_cast<void **>(p), bytes); }
 
 template <class T>
 struct DevBuf {  // RAII device array; pooled when a PoolScope is open and the pool has room
@@ -102,7 +108,7 @@ struct DevBuf {  // RAII device array; pooled when a PoolScope is open and the p
       }
     }
     if (!keep && bytes >= kBigCacheMinBytes) return big_cache_get(reinterpret_cast<void **>(&p), bytes, &block_bytes);
-    return hipMalloc(&p, bytes);
+    return dev_malloc(&p, bytes);
   }
   // (a pooled array cannot be handed on: alloc(..., true); a cached block can -- it is an allocation of its own, only larger than asked for)
   T *release() { T *q = pooled ? nullptr : p; p = nullptr; n = 0; pooled = false; block_bytes = 0; return q; }
@@ -300,6 +306,7 @@ struct gm_graph {
   unsigned long long smask_words = 0;
   int *d_sup_far_rows = nullptr;  // the rows with tails of more than 64 keys (masks of several words), widest ids first
   int n_sup_far_rows = 0;
+  int smask_min_tail = 0;  // (0: kSupMaskMinTail)
   int smask_state = 0;  // 0 unknown, 1 built, 2 not applicable (DAG not topological, arena beyond 2^32 words, GM_SUP_NO_MASKS)
   std::vector<int> h_rp;  // host copy of the offsets, fetched on first use (host_rp): download, k-clique tables, SgL renumbering
   std::list<ChunkTable> tables;  // list: handed-out pointers stay valid
@@ -403,9 +410,9 @@ struct PoolScope {
       g_temp_pool = nullptr;
       return;
     }
-    if (!pl.base && !getenv("GM_NO_TEMP_POOL")) {
+    if (!pl.base && !gm_opt("GM_NO_TEMP_POOL")) {
       const size_t need = std::min<size_t>((size_t)256 << 20, (size_t)24 * ((size_t)g->nv + 1) + ((size_t)16 << 20));
-      if (hipMalloc(&pl.base, need) == hipSuccess) pl.cap = need;
+      if (dev_malloc(&pl.base, need) == hipSuccess) pl.cap = need;
       else (void)hipGetLastError();  // (no pool: everything falls through to hipMalloc)
     }
     mark = pl.off;
@@ -509,7 +516,7 @@ int get_table(gm_graph *g, int target, bool allow_split, int bit_words, unsigned
 int ensure_edesc(gm_graph *g);
 int ensure_tasklists(gm_graph *g, bool with_edges = false);
 int ensure_keystream(gm_graph *g, bool edges, bool *built, bool allow_core = false);  // allow_core: the rows of the hub core may stay out (gm_ctc.hip)
-int sup_mask_min_tail();            // (gm_tables.hip) kSupMaskMinTail or GM_SUP_MASK_MIN
+int sup_mask_min_tail(const gm_graph *g);  // (gm_tables.hip) kSupMaskMinTail or the option GM_SUP_MASK_MIN when the handle's masks were laid out
 int ensure_sup_corner(gm_graph *g);  // (gm_tables.hip) d_csym / d_cfirst of a handle whose task lists leave a hub corner out
 int ensure_sup_masks(gm_graph *g);  // (gm_tables.hip) d_emoff / d_tmoff / d_smask of a topologically numbered DAG with task lists; GM_OK also when not applicable
 int ensure_mean_sq_deg(gm_graph *g);

@@ -51,7 +51,7 @@ static int giant_task_edges(gm_graph *g, unsigned long long *out) {
   if (g->giant_edges == ~0ull) {
     HIP_TRY(hipSetDevice(g->device));
     unsigned long long *d_s = nullptr, s = 0;
-    HIP_TRY(hipMalloc(&d_s, 8));
+    HIP_TRY(dev_malloc(&d_s, 8));
     hipError_t e = hipMemset(d_s, 0, 8);
     if (e == hipSuccess && g->nv > 0)
       hipLaunchKernelGGL(giant_edges_kernel, dim3((unsigned)std::min<long long>(((long long)g->nv + 255) / 256, 2048)), dim3(256), 0, 0, g->nv, g->d_rp, d_s);
@@ -236,7 +236,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
     // (sum d+^2 / |E+| below kTopoMinMeanRow: short lists, few triangles per edge).  GM_SUP_STREAM=0 / 1 forces it.
     bool sup_stream = false;
     if (support && !(la->tune[6] & 0x20000000)) {
-      if (const char *e = getenv("GM_SUP_STREAM")) sup_stream = atoi(e) != 0;
+      if (const char *e = gm_opt("GM_SUP_STREAM")) sup_stream = atoi(e) != 0;
       else sup_stream = ensure_mean_sq_deg(g) == GM_OK && g->mean_sq_deg < (double)kTopoMinMeanRow;
     }
     if ((sup_stream || !support) && !(la->tune[6] & 0x20000000)) {
@@ -248,7 +248,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
       if (rc_t) return rc_t;
     }
   }
-  if (support && !sup_part && !g->d_sup) HIP_TRY(hipMalloc(&g->d_sup, sizeof(unsigned) * (size_t)std::max<long long>(g->ne, 1)));
+  if (support && !sup_part && !g->d_sup) HIP_TRY(dev_malloc(&g->d_sup, sizeof(unsigned) * (size_t)std::max<long long>(g->ne, 1)));
   // match masks instead of one atomic per streamed edge (gm_sup.hip): one GPU, the task lists, a topologically numbered DAG
   // (tune[6] & 0x40000000: A/B switch, every streamed edge by an atomic)
   bool sup_masks = false;
@@ -270,7 +270,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
     rb.only_hi = kTctStageMax;
     const int rc_b = get_table(g, target, true, 0, part_cap, kTctStageMax, &tab_big, rb, kBitmapMinDeg);
     if (rc_b) return rc_b;
-    if ((long long)tab_big->n / world < 2ll * g->cu_count * 4 && !getenv("GM_TCT_SPLIT_ALWAYS")) {
+    if ((long long)tab_big->n / world < 2ll * g->cu_count * 4 && !gm_opt("GM_TCT_SPLIT_ALWAYS")) {
       tab_big = nullptr;
       split_stage = false;
       tct_stage = kTctStageMax;
@@ -510,7 +510,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
       if (g->d_scratch) (void)hipFree(g->d_scratch);
       g->d_scratch = nullptr;
       g->scratch_bytes = 0;
-      HIP_TRY(hipMalloc(&g->d_scratch, need));
+      HIP_TRY(dev_malloc(&g->d_scratch, need));
       g->scratch_bytes = need;
     }
     p.scratch = g->d_scratch;
@@ -519,7 +519,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
 
 #ifdef GM_DEBUG_CHUNKS
   unsigned long long *d_ticks = nullptr;
-  HIP_TRY(hipMalloc(&d_ticks, sizeof(unsigned long long) * std::max<size_t>(tab->n, 1)));
+  HIP_TRY(dev_malloc(&d_ticks, sizeof(unsigned long long) * std::max<size_t>(tab->n, 1)));
   HIP_TRY(hipMemset(d_ticks, 0, sizeof(unsigned long long) * std::max<size_t>(tab->n, 1)));
   p.chunk_ticks = d_ticks;
 #endif
@@ -543,7 +543,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
         if (g->d_scratch) (void)hipFree(g->d_scratch);
         g->d_scratch = nullptr;
         g->scratch_bytes = 0;
-        HIP_TRY(hipMalloc(&g->d_scratch, need));
+        HIP_TRY(dev_malloc(&g->d_scratch, need));
         g->scratch_bytes = need;
       }
     }
@@ -803,7 +803,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
       memset(&sc, 0, sizeof sc);
       sc.nv = g->nv;
       sc.ne = g->ne;
-      sc.lmin = sup_mask_min_tail();
+      sc.lmin = sup_mask_min_tail(g);
       sc.rp = g->d_rp;
       sc.emoff = g->d_emoff;
       sc.smask = g->d_smask;
@@ -960,7 +960,7 @@ int ensure_mean_sq_deg(gm_graph *self) {
   if (self->mean_sq_deg < 0) {
     HIP_TRY(hipSetDevice(self->device));
     unsigned long long *d_s = nullptr, s2 = 0;
-    HIP_TRY(hipMalloc(&d_s, 8));
+    HIP_TRY(dev_malloc(&d_s, 8));
     hipError_t e = hipMemset(d_s, 0, 8);
     if (e == hipSuccess && self->nv > 0)
       hipLaunchKernelGGL(sum_sq_deg_kernel, dim3((unsigned)std::min<long long>(((long long)self->nv + 255) / 256, 2048)), dim3(256), 0, 0, self->nv, self->d_rp, d_s);
@@ -998,7 +998,7 @@ static int topo_view(const gm_graph *dag, const gm_launch *la, gm_graph **run_on
   rc = ensure_mean_sq_deg(self);
   if (rc) return rc;
   double min_row = (double)kTopoMinMeanRow;
-  if (const char *e = getenv("GM_TOPO_MIN_ROW")) min_row = atof(e);
+  if (const char *e = gm_opt("GM_TOPO_MIN_ROW")) min_row = atof(e);
   if (gm_sweep_env("GM_TABLE_INFO")) fprintf(stderr, "[topo view] sum d+^2 / |E+| = %.1f (switch at %.1f)\n", self->mean_sq_deg, min_row);
   if (self->mean_sq_deg < min_row) return GM_OK;  // short lists: as numbered
   return get_relabeled(self, 2, run_on);
@@ -1034,7 +1034,7 @@ extern "C" int gm_tc_core_info(const gm_graph *dag, int64_t info[4]) {
 static int ensure_idx0(gm_graph *g, const GraphView &gv) {
   if (g->d_idx0) return GM_OK;
   OtherSetupScope scope(g);
-  HIP_TRY(hipMalloc(&g->d_idx0, sizeof(int) * (size_t)std::max(g->nv, 1)));
+  HIP_TRY(dev_malloc(&g->d_idx0, sizeof(int) * (size_t)std::max(g->nv, 1)));
   HIP_TRY(launch_idx0(gv, g->d_idx0, 0));
   return GM_OK;
 }
@@ -1065,7 +1065,7 @@ static int run_rect_flat(const gm_graph *cg, const gm_launch *la_in, uint64_t *h
     }
     pre[g->nv] = acc;
     g->n_wblocks = acc;
-    HIP_TRY(hipMalloc(&g->d_wblock_prefix, sizeof(unsigned long long) * ((size_t)g->nv + 1)));
+    HIP_TRY(dev_malloc(&g->d_wblock_prefix, sizeof(unsigned long long) * ((size_t)g->nv + 1)));
     HIP_TRY(hipMemcpy(g->d_wblock_prefix, pre.data(), sizeof(unsigned long long) * ((size_t)g->nv + 1), hipMemcpyHostToDevice));
   }
   RectParams p;
@@ -1111,7 +1111,7 @@ static int run_rect_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h_
     OtherSetupScope scope(g);
     const size_t nv = (size_t)g->nv;
     unsigned long long *d_work = nullptr;
-    HIP_TRY(hipMalloc(&d_work, sizeof(unsigned long long) * std::max<size_t>(nv, 1)));
+    HIP_TRY(dev_malloc(&d_work, sizeof(unsigned long long) * std::max<size_t>(nv, 1)));
     std::vector<unsigned long long> work(std::max<size_t>(nv, 1));
     hipError_t e = nv ? launch_rect_work(gv, g->d_idx0, d_work, 0) : hipSuccess;
     if (e == hipSuccess) e = hipMemcpy(work.data(), d_work, sizeof(unsigned long long) * nv, hipMemcpyDeviceToHost);
@@ -1135,7 +1135,7 @@ static int run_rect_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h_
       tasks.push_back(t);
     }
     g->n_rect_tasks = tasks.size();
-    HIP_TRY(hipMalloc(&g->d_rect_tasks, sizeof(int4) * std::max<size_t>(tasks.size(), 1)));
+    HIP_TRY(dev_malloc(&g->d_rect_tasks, sizeof(int4) * std::max<size_t>(tasks.size(), 1)));
     if (!tasks.empty()) HIP_TRY(hipMemcpy(g->d_rect_tasks, tasks.data(), sizeof(int4) * tasks.size(), hipMemcpyHostToDevice));
   }
   RectAccParams p;
@@ -1163,7 +1163,7 @@ static int run_rect_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h_
     if (g->d_rect_acc) (void)hipFree(g->d_rect_acc);
     g->d_rect_acc = nullptr;
     g->rect_acc_bytes = 0;
-    HIP_TRY(hipMalloc(&g->d_rect_acc, need));
+    HIP_TRY(dev_malloc(&g->d_rect_acc, need));
     HIP_TRY(hipMemset(g->d_rect_acc, 0, need));  // every launch leaves the maps zeroed again
     g->rect_acc_bytes = need;
   }
@@ -1172,7 +1172,7 @@ static int run_rect_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h_
     if (g->d_pent_touched) (void)hipFree(g->d_pent_touched);
     g->d_pent_touched = nullptr;
     g->pent_touched_bytes = 0;
-    HIP_TRY(hipMalloc(&g->d_pent_touched, need));
+    HIP_TRY(dev_malloc(&g->d_pent_touched, need));
     g->pent_touched_bytes = need;
   }
   p.touched = g->d_pent_touched;
@@ -1245,7 +1245,7 @@ static int run_house_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h
     OtherSetupScope scope(g);
     const size_t nv = (size_t)g->nv;
     unsigned long long *d_work = nullptr;
-    HIP_TRY(hipMalloc(&d_work, sizeof(unsigned long long) * std::max<size_t>(nv, 1)));
+    HIP_TRY(dev_malloc(&d_work, sizeof(unsigned long long) * std::max<size_t>(nv, 1)));
     std::vector<unsigned long long> work(std::max<size_t>(nv, 1));
     hipError_t e = nv ? launch_house_work(gv, d_work, 0) : hipSuccess;
     if (e == hipSuccess) e = hipMemcpy(work.data(), d_work, sizeof(unsigned long long) * nv, hipMemcpyDeviceToHost);
@@ -1269,7 +1269,7 @@ static int run_house_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h
       tasks.push_back(t4);
     }
     g->n_house_tasks = tasks.size();
-    HIP_TRY(hipMalloc(&g->d_house_tasks, sizeof(int4) * std::max<size_t>(tasks.size(), 1)));
+    HIP_TRY(dev_malloc(&g->d_house_tasks, sizeof(int4) * std::max<size_t>(tasks.size(), 1)));
     if (!tasks.empty()) HIP_TRY(hipMemcpy(g->d_house_tasks, tasks.data(), sizeof(int4) * tasks.size(), hipMemcpyHostToDevice));
   }
   HouseAccParams p;
@@ -1297,11 +1297,11 @@ static int run_house_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h
     if (g->d_house_acc) (void)hipFree(g->d_house_acc);
     g->d_house_acc = nullptr;
     g->house_acc_bytes = 0;
-    HIP_TRY(hipMalloc(&g->d_house_acc, need));
+    HIP_TRY(dev_malloc(&g->d_house_acc, need));
     HIP_TRY(hipMemset(g->d_house_acc, 0, need));  // every launch leaves the maps zeroed again
     if (g->d_house_touched) (void)hipFree(g->d_house_touched);
     g->d_house_touched = nullptr;
-    HIP_TRY(hipMalloc(&g->d_house_touched, need / 2));  // one int list per map
+    HIP_TRY(dev_malloc(&g->d_house_touched, need / 2));  // one int list per map
     g->house_acc_bytes = need;
   }
   p.acc = g->d_house_acc;
@@ -1329,7 +1329,7 @@ static int run_house_flat(const gm_graph *cg, const gm_launch *la_in, uint64_t *
     OtherSetupScope scope(g);
     const size_t ne = (size_t)g->ne;
     unsigned *d_nblk = nullptr;
-    HIP_TRY(hipMalloc(&d_nblk, sizeof(unsigned) * std::max<size_t>(ne, 1)));
+    HIP_TRY(dev_malloc(&d_nblk, sizeof(unsigned) * std::max<size_t>(ne, 1)));
     std::vector<unsigned> nblk(std::max<size_t>(ne, 1));
     hipError_t e = ne ? launch_house_blocks(gv, d_nblk, 0) : hipSuccess;
     if (e == hipSuccess) e = hipMemcpy(nblk.data(), d_nblk, sizeof(unsigned) * ne, hipMemcpyDeviceToHost);
@@ -1340,7 +1340,7 @@ static int run_house_flat(const gm_graph *cg, const gm_launch *la_in, uint64_t *
     for (size_t i = 0; i < ne; ++i) { pre[i] = acc; acc += nblk[i]; }
     pre[ne] = acc;
     g->n_house_blocks = acc;
-    HIP_TRY(hipMalloc(&g->d_house_prefix, sizeof(unsigned long long) * (ne + 1)));
+    HIP_TRY(dev_malloc(&g->d_house_prefix, sizeof(unsigned long long) * (ne + 1)));
     HIP_TRY(hipMemcpy(g->d_house_prefix, pre.data(), sizeof(unsigned long long) * (ne + 1), hipMemcpyHostToDevice));
   }
   HouseParams p;
@@ -1396,7 +1396,7 @@ static int run_sgl_nested(int pat, const gm_graph *cg, const gm_launch *la_in, u
       if (g->d_scratch) (void)hipFree(g->d_scratch);
       g->d_scratch = nullptr;
       g->scratch_bytes = 0;
-      HIP_TRY(hipMalloc(&g->d_scratch, need));
+      HIP_TRY(dev_malloc(&g->d_scratch, need));
       g->scratch_bytes = need;
     }
     p.scratch = reinterpret_cast<int *>(g->d_scratch);
@@ -1478,7 +1478,7 @@ extern "C" int gm_diamond_support_info(const gm_graph *sym, int64_t info[4]) {
   info[0] = run_on->smask_state == 1 ? (int64_t)run_on->smask_words : 0;  // 64-bit words of the match-mask arena (0: no masks)
   info[1] = (int64_t)at;                                                  // increments issued as global atomics from the waves' queues
   info[2] = run_on->smask_state == 1 ? (int64_t)run_on->n_sup_far_rows : 0;
-  info[3] = (int64_t)sup_mask_min_tail();
+  info[3] = (int64_t)sup_mask_min_tail(run_on);
   return GM_OK;
 }
 // tooling: the hub corner whose supports the one-GPU diamond of this handle takes on the matrix cores (after a first diamond)
@@ -1507,7 +1507,8 @@ extern "C" int gm_diamond_support_partial(const gm_graph *sym, const gm_launch *
   int rc = diamond_run_on(sym, la, &run_on);
   if (rc) return rc;
   const int world = (la && la->world > 1) ? la->world : 1;
-  if (n_entries != diamond_support_entries(run_on->ne, world)) return GM_ERR_INVALID;  // (exactly gm_diamond_support_size: the slices are n_entries / world)
+  // (at least gm_diamond_support_size; the ranks' slices are cut from THAT size -- size / world entries each -- whatever the buffer holds beyond it)
+  if (n_entries < diamond_support_entries(run_on->ne, world)) return GM_ERR_INVALID;
   uint64_t dummy = 0;
   rc = run_pattern(PAT_SUPPORT_PART, run_on, la, 3, (la && la->d_counts) ? nullptr : &dummy, 1, st, -1, 0, d_support);
   if (rc) return rc;
@@ -1551,7 +1552,7 @@ extern "C" int gm_sgl(const gm_graph *sym, const char *pattern, const gm_launch 
       const int t6 = la ? la->tune[6] : 0;
       const bool big = sym && sym->d_rp64;  // (>= 2^31 entries: only the supports of the oriented copy can run; on one GPU)
       const bool per_edge = ((t6 & (0x10000000 | 0x80000 | 0x100000 | 0x400000 | 0x1000000 | 0x2000000)) || (la && la->world > 1) ||
-                             (la && la->tune[5] == 1) || getenv("GM_DIAMOND_PER_EDGE") || !sym) && !big;
+                             (la && la->tune[5] == 1) || gm_opt("GM_DIAMOND_PER_EDGE") || !sym) && !big;
       if (!per_edge) {
         const int rc = run_diamond_supports(sym, la, total, st);
         if (rc != GM_ERR_UNSUPPORTED) return rc;

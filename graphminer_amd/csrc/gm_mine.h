@@ -5,12 +5,17 @@
 #include <stdint.h>
 #include <stdlib.h>
 
-// ENVIRONMENT SWITCHES.  Read in every build: the documented fallbacks and the hooks tests need to reach a path on a small graph --
-//   GM_SETUP_TRACE (setup steps on stderr), GM_DIAMOND_PER_EDGE, GM_SUP_STREAM / GM_SUP_NO_MASKS / GM_SUP_MASK_MIN (edge supports),
+// DEVELOPER OPTIONS.  The shipped library reads NO algorithm switch from the environment (a drop-in behind someone
+// else's main must not change what it runs on an ambient variable).  What tests need to reach a path on a small graph, and the documented
+// fallbacks, are named options set through the C ABI -- gm_dev_option(name, value), include/graphminer_amd.h -- and read with gm_opt():
+//   GM_DIAMOND_PER_EDGE, GM_SUP_STREAM / GM_SUP_NO_MASKS / GM_SUP_MASK_MIN (edge supports), GM_TC_CORE_H / GM_SUP_CORE_H (hub corner),
 //   GM_BIG_NE, GM_KST_MAX_KEYS, GM_TOPO_MIN_ROW, GM_WIDE_ARENA_MB, GM_TCT_SPLIT_ALWAYS (limits lowered for tests), GM_ORIENT_TWO_GATHERS,
-//   GM_RELABEL_GLOBAL_SORT (the previous setup paths, compared in tests), GM_NO_TEMP_POOL.
-// SWEEP switches (tile counts, workgroups per CU, thresholds, rejected variants: the A/B runs recorded under profiles/) exist only in
-// -DGM_DEVEL builds (make DEVEL=1): gm_sweep_env() is a constant nullptr otherwise and the branches behind it fold away.
+//   GM_RELABEL_GLOBAL_SORT (the previous setup paths, compared in tests), GM_NO_TEMP_POOL, and the n-GPU runner's GM_FORCE_RCCL_PATH /
+//   GM_DIAMOND_SUPPORTS_MAX_WORLD (host/multi.cc).  Only GM_SETUP_TRACE (setup steps on stderr: diagnostics, no algorithm) is an
+//   environment variable.  In -DGM_DEVEL builds (make DEVEL=1) an option that is not set falls back to the environment, and the
+// SWEEP switches (tile counts, workgroups per CU, thresholds, rejected variants: the A/B runs recorded under profiles/) exist only there:
+// gm_sweep_env() is a constant nullptr otherwise and the branches behind it fold away.
+const char *gm_opt(const char *name);  // (gm_graph.hip) the value of a developer option or nullptr
 inline const char *gm_sweep_env(const char *name) {
 #ifdef GM_DEVEL
   return getenv(name);

@@ -360,6 +360,9 @@ __global__ __launch_bounds__(kSupColsWaves *GM_WAVE) void sup_far_kernel(const S
           unsigned long long x = xs[k];
           own += (unsigned)__popcll(x);
           const int base = i + 1 + 64 * (w0 + k);
+          // (only bits of entries of this row count: a word the current launch did not rewrite -- a filtered or aborted launch -- must
+          // not index past the row's counters; the arena starts zeroed, ensure_sup_masks)
+          if (dd - base < 64) x &= dd > base ? (1ull << (dd - base)) - 1ull : 0ull;
           while (x) {
             atomicAdd(&cc[base + (int)__builtin_ctzll(x)], 1u);
             x &= x - 1;

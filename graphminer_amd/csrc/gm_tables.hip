@@ -351,7 +351,7 @@ static int build_table_device(gm_graph *g, ChunkTable &t, bool sym_table, double
   HIP_TRY(hipMemcpy(&t.max_bit_words, maxbw.p, 8, hipMemcpyDeviceToHost));
   setup_trace("table: walk count + scan");
   t.n = 0;
-  HIP_TRY(hipMalloc(&t.d, sizeof(ChunkRec)));  // (placeholder, replaced below when the table has chunks)
+  HIP_TRY(dev_malloc(&t.d, sizeof(ChunkRec)));  // (placeholder, replaced below when the table has chunks)
   if (n0 == 0) {
     t.edge_prefix.assign(1, 0ull);
     t.host_ready = true;
@@ -378,12 +378,12 @@ static int build_table_device(gm_graph *g, ChunkTable &t, bool sym_table, double
   setup_trace("table: walk emit, cost, parts");
   (void)hipFree(t.d);
   t.d = nullptr;
-  HIP_TRY(hipMalloc(&t.d, sizeof(ChunkRec) * (size_t)n));
+  HIP_TRY(dev_malloc(&t.d, sizeof(ChunkRec) * (size_t)n));
   setup_trace("table: free + alloc of the records");
   // per-chunk scalars (cost, task edges, first vertex): they stay on the device, the host takes the two totals (table_host_views: the rest, on demand)
-  HIP_TRY(hipMalloc(&t.d_cost, sizeof(unsigned long long) * (size_t)n));
-  HIP_TRY(hipMalloc(&t.d_edges, sizeof(int) * (size_t)n));
-  HIP_TRY(hipMalloc(&t.d_firstv, sizeof(int) * (size_t)n));
+  HIP_TRY(dev_malloc(&t.d_cost, sizeof(unsigned long long) * (size_t)n));
+  HIP_TRY(dev_malloc(&t.d_edges, sizeof(int) * (size_t)n));
+  HIP_TRY(dev_malloc(&t.d_firstv, sizeof(int) * (size_t)n));
   DevBuf<unsigned long long> totals;
   HIP_TRY(totals.alloc(3));
   HIP_TRY(hipMemsetAsync(totals.p, 0, 24, 0));
@@ -411,7 +411,7 @@ static int build_table_device(gm_graph *g, ChunkTable &t, bool sym_table, double
     hipLaunchKernelGGL(tab_orderkeys_kernel, blocks(n), dim3(256), 0, 0, n, cost_p, heavy, sym_table ? 1 : 0, (!sym_table && g->topo_state == 1) ? 1 : 0,
                        key0.p, key1.p, iota.p);
     for (int m = 0; m < 2; ++m) {
-      HIP_TRY(hipMalloc(&t.d_order[m], sizeof(int) * (size_t)n));
+      HIP_TRY(dev_malloc(&t.d_order[m], sizeof(int) * (size_t)n));
       size_t bytes = 0;
       const unsigned long long *keys = m == 0 ? key0.p : key1.p;
       HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, bytes, keys, keyo.p, iota.p, t.d_order[m], n));
@@ -488,7 +488,7 @@ static int build_table_device(gm_graph *g, ChunkTable &t, bool sym_table, double
       t.d_row_slot = bs->d_row_slot;
       t.n_bitmaps = bs->n;
       t.bitmap_words = bs->words;
-      HIP_TRY(hipMalloc(&t.d_slot, sizeof(int) * (size_t)n));
+      HIP_TRY(dev_malloc(&t.d_slot, sizeof(int) * (size_t)n));
       hipLaunchKernelGGL(tab_chunkslot_kernel, blocks(n), dim3(256), 0, 0, n, t.d, g->d_rp, t.stage_cap, t.d_row_slot, t.d_slot);
     }
     bitmap_ms = bm_timer.ms();
@@ -590,7 +590,7 @@ int get_share_order(gm_graph *g, ChunkTable *t, int world, int rank, int policy,
     HIP_TRY(dev_exclusive_sum(tmp, flag.p, off.p, (size_t)n + 1));
     int cnt = 0;
     HIP_TRY(hipMemcpy(&cnt, off.p + n, sizeof(int), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMalloc(&sh.d, sizeof(int) * (size_t)std::max(cnt, 1)));
+    HIP_TRY(dev_malloc(&sh.d, sizeof(int) * (size_t)std::max(cnt, 1)));
     hipLaunchKernelGGL(share_emit_kernel, grid, block, 0, 0, n, order, flag.p, off.p, t->d_edges, sh.d, esum.p);
     if (hipMemcpy(&sh.edges, esum.p, sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) {
       (void)hipFree(sh.d);
@@ -646,8 +646,8 @@ int get_table(gm_graph *g, int target, bool allow_split, int bit_words, unsigned
   if (!recs.empty()) {
     ChunkRec *d_tmp = nullptr;
     unsigned long long *d_cost = nullptr;
-    hipError_t e = hipMalloc(&d_tmp, sizeof(ChunkRec) * recs.size());
-    if (e == hipSuccess) e = hipMalloc(&d_cost, sizeof(unsigned long long) * recs.size());
+    hipError_t e = dev_malloc(&d_tmp, sizeof(ChunkRec) * recs.size());
+    if (e == hipSuccess) e = dev_malloc(&d_cost, sizeof(unsigned long long) * recs.size());
     if (e == hipSuccess) e = hipMemcpy(d_tmp, recs.data(), sizeof(ChunkRec) * recs.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(d_cost, 0, sizeof(unsigned long long) * recs.size());
     if (e == hipSuccess) {
@@ -701,7 +701,7 @@ int get_table(gm_graph *g, int target, bool allow_split, int bit_words, unsigned
   t.total_cost = 0;
   for (auto c : t.cost) t.total_cost += c;
   t.host_ready = true;
-  HIP_TRY(hipMalloc(&t.d, sizeof(ChunkRec) * std::max<size_t>(t.n, 1)));
+  HIP_TRY(dev_malloc(&t.d, sizeof(ChunkRec) * std::max<size_t>(t.n, 1)));
   if (t.n) HIP_TRY(hipMemcpy(t.d, recs.data(), sizeof(ChunkRec) * t.n, hipMemcpyHostToDevice));
   if (t.n) {
     // Longest-processing-time-first dequeue order: the dynamic queue then ends on light chunks, so the tail of a launch
@@ -722,7 +722,7 @@ int get_table(gm_graph *g, int target, bool allow_split, int bit_words, unsigned
         if (m == 0) { ca = ca >= heavy ? (classes_only ? 1ull : ca) : 0ull; cb = cb >= heavy ? (classes_only ? 1ull : cb) : 0ull; }
         return ca > cb;
       });
-      HIP_TRY(hipMalloc(&t.d_order[m], sizeof(int) * t.n));
+      HIP_TRY(dev_malloc(&t.d_order[m], sizeof(int) * t.n));
       HIP_TRY(hipMemcpy(t.d_order[m], o.data(), sizeof(int) * t.n, hipMemcpyHostToDevice));
     }
   }
@@ -753,18 +753,18 @@ int get_table(gm_graph *g, int target, bool allow_split, int bit_words, unsigned
           if (it != row_slot.end() && it->first == r.u_begin) slots[c] = it->second;
         }
       }
-      HIP_TRY(hipMalloc(&t.d_slot, sizeof(int) * t.n));
+      HIP_TRY(dev_malloc(&t.d_slot, sizeof(int) * t.n));
       HIP_TRY(hipMemcpy(t.d_slot, slots.data(), sizeof(int) * t.n, hipMemcpyHostToDevice));
       {
         std::vector<int> by_vertex((size_t)g->nv, -1);
         for (size_t i = 0; i < nb; ++i) by_vertex[(size_t)rows[i]] = (int)i;
-        HIP_TRY(hipMalloc(&t.d_row_slot, sizeof(int) * (size_t)g->nv));
+        HIP_TRY(dev_malloc(&t.d_row_slot, sizeof(int) * (size_t)g->nv));
         HIP_TRY(hipMemcpy(t.d_row_slot, by_vertex.data(), sizeof(int) * (size_t)g->nv, hipMemcpyHostToDevice));
       }
-      HIP_TRY(hipMalloc(&t.d_bitmaps, (size_t)nb * (size_t)words * 4));
+      HIP_TRY(dev_malloc(&t.d_bitmaps, (size_t)nb * (size_t)words * 4));
       HIP_TRY(hipMemset(t.d_bitmaps, 0, (size_t)nb * (size_t)words * 4));
       int *d_rows = nullptr;
-      HIP_TRY(hipMalloc(&d_rows, sizeof(int) * nb));
+      HIP_TRY(dev_malloc(&d_rows, sizeof(int) * nb));
       HIP_TRY(hipMemcpy(d_rows, rows.data(), sizeof(int) * nb, hipMemcpyHostToDevice));
       hipLaunchKernelGGL(bitmap_build_kernel, dim3((unsigned)nb), dim3(256), 0, 0, g->d_rp, g->d_col, d_rows, t.d_bitmaps, words);
       hipError_t e = hipDeviceSynchronize();
@@ -843,7 +843,7 @@ static void build_inline_copies(gm_graph *g, ScanTemp &tmp) {
     for (void *p : {(void *)off, (void *)colk, (void *)tdk})
       if (p) (void)hipFree(p);
   };
-  if (hipMalloc(&off, 8 * (size_t)(nt + 1)) != hipSuccess) return fail();
+  if (dev_malloc(&off, 8 * (size_t)(nt + 1)) != hipSuccess) return fail();
   const long long blocks = std::min<long long>((nt + 256) / 256, (long long)g->cu_count * 32);
   unsigned long long total = 0;
   for (;;) {  // the copies share the 32-bit index space of col[]: halve the limit until they fit
@@ -855,8 +855,8 @@ static void build_inline_copies(gm_graph *g, ScanTemp &tmp) {
     if (lmax < 4) return fail();
   }
   if (total == 0) return fail();
-  if (hipMalloc(&tdk, sizeof(int2) * (size_t)nt) != hipSuccess) return fail();
-  if (hipMalloc(&colk, 4 * ((size_t)nt + (size_t)total)) != hipSuccess) return fail();
+  if (dev_malloc(&tdk, sizeof(int2) * (size_t)nt) != hipSuccess) return fail();
+  if (dev_malloc(&colk, 4 * ((size_t)nt + (size_t)total)) != hipSuccess) return fail();
   if (hipMemcpyAsync(colk, g->d_col, 4 * (size_t)nt, hipMemcpyDeviceToDevice, 0) != hipSuccess) return fail();
   const long long cblocks = std::min<long long>((nt * 8 + 255) / 256, (long long)g->cu_count * 64);
   hipLaunchKernelGGL(inl_copy_kernel, dim3((unsigned)cblocks), dim3(256), 0, 0, nt, g->d_tdesc, off, lmax, nt, colk, tdk);
@@ -1100,7 +1100,7 @@ constexpr double kTcCoreMinDensity = 0.03;
 static int tc_core_size(gm_graph *g, const char *env = "GM_TC_CORE_H", bool blocks_only = false) {
   long long want = kTcCoreHDefault;
   bool forced = false;
-  if (const char *e = getenv(env)) { want = atoll(e); forced = true; }
+  if (const char *e = gm_opt(env)) { want = atoll(e); forced = true; }
   if (want <= 0 || g->nv < 64) return 0;
   if (ensure_core_bitmap(g) != GM_OK || g->core_state != 1) return 0;  // (not topologically numbered, no room: everything through the stream)
   const long long cap = std::min<long long>((long long)g->core_h, (long long)kCtcMaxH);
@@ -1197,9 +1197,9 @@ int ensure_keystream(gm_graph *g, bool edges, bool *built, bool allow_core) {
     return hip_fail(e, what, __FILE__, __LINE__);
   };
   hipError_t e = hipSuccess;
-  if (!second && ((e = hipMalloc(&krp, sizeof(int) * nv1)) != hipSuccess || (e = hipMalloc(&trpl, sizeof(int) * nv1)) != hipSuccess)) return fail(e, "hipMalloc(key stream offsets)");
+  if (!second && ((e = dev_malloc(&krp, sizeof(int) * nv1)) != hipSuccess || (e = dev_malloc(&trpl, sizeof(int) * nv1)) != hipSuccess)) return fail(e, "hipMalloc(key stream offsets)");
   unsigned long long total = second ? g->n_inline_keys : 0, key_limit = 0x7fffff00ull;
-  if (const char *e = getenv("GM_KST_MAX_KEYS")) key_limit = std::min<unsigned long long>(key_limit, (unsigned long long)std::max(1ll, atoll(e)));  // (tests)
+  if (const char *e = gm_opt("GM_KST_MAX_KEYS")) key_limit = std::min<unsigned long long>(key_limit, (unsigned long long)std::max(1ll, atoll(e)));  // (tests)
   int nlong = second ? g->n_long_tasks : 0;
   while (!second) {  // the stream is indexed with 32 bits: halve the limit of a "short" list until it fits
     if ((e = hipMemsetAsync(cnt.p, 0, sizeof(unsigned long long) * nv1, 0)) != hipSuccess) return fail(e, "hipMemsetAsync");
@@ -1222,9 +1222,9 @@ int ensure_keystream(gm_graph *g, bool edges, bool *built, bool allow_core) {
   setup_trace("key stream: count pass + scans");
   if (!second) hipLaunchKernelGGL(kst_narrow_kernel, dim3((unsigned)((nv1 + 255) / 256)), dim3(256), 0, 0, g->nv, keyoff.p, krp);
   const size_t nk = (size_t)std::max<unsigned long long>(total, 1), nl = (size_t)std::max(nlong, 1);
-  if ((e = hipMalloc(&kst, sizeof(unsigned) * nk)) != hipSuccess) return fail(e, "hipMalloc(key stream)");
-  if ((e = hipMalloc(&tdl, sizeof(int2) * nl)) != hipSuccess) return fail(e, "hipMalloc(long lists)");
-  if (edges && ((e = hipMalloc(&ed.kst_et, sizeof(int2) * nk)) != hipSuccess || (e = hipMalloc(&ed.tedgel, sizeof(int) * nl)) != hipSuccess))
+  if ((e = dev_malloc(&kst, sizeof(unsigned) * nk)) != hipSuccess) return fail(e, "hipMalloc(key stream)");
+  if ((e = dev_malloc(&tdl, sizeof(int2) * nl)) != hipSuccess) return fail(e, "hipMalloc(long lists)");
+  if (edges && ((e = dev_malloc(&ed.kst_et, sizeof(int2) * nk)) != hipSuccess || (e = dev_malloc(&ed.tedgel, sizeof(int) * nl)) != hipSuccess))
     return fail(e, "hipMalloc(key stream entries)");
   if ((e = hipMemsetAsync(cnt.p, 0, sizeof(unsigned long long) * nv1, 0)) != hipSuccess) return fail(e, "hipMemsetAsync");
   const dim3 pg((unsigned)blocks_place), pb(256);
@@ -1266,7 +1266,7 @@ int ensure_keystream(gm_graph *g, bool edges, bool *built, bool allow_core) {
 int ensure_tasklists(gm_graph *g, bool /*with_edges*/) {
   // The tasks' own entries (tedge, 4 B per edge: what the edge supports need) are always built with the lists.  Round 3 built them on
   // demand by freeing and rebuilding trp / tdesc -- under a launch of another thread that had already copied those pointers.
-  if (g->d_tdesc || g->ne == 0) return GM_OK;
+  if (__atomic_load_n(&g->d_tdesc, __ATOMIC_ACQUIRE) || g->ne == 0) return GM_OK;
   {
     const int rc = ensure_edesc(g);  // (takes the lock itself)
     if (rc) return rc;
@@ -1304,10 +1304,10 @@ int ensure_tasklists(gm_graph *g, bool /*with_edges*/) {
   setup_trace("tasks: count pass");
   int *trp = nullptr, *tedge = nullptr;
   int2 *td = nullptr;
-  HIP_TRY(hipMalloc(&trp, sizeof(int) * nv1));
+  HIP_TRY(dev_malloc(&trp, sizeof(int) * nv1));
   hipError_t e = dev_exclusive_sum(tmp, cnt.p, trp, nv1);
-  if (e == hipSuccess) e = hipMalloc(&td, sizeof(int2) * ne);
-  if (e == hipSuccess) e = hipMalloc(&tedge, sizeof(int) * ne);
+  if (e == hipSuccess) e = dev_malloc(&td, sizeof(int2) * ne);
+  if (e == hipSuccess) e = dev_malloc(&tedge, sizeof(int) * ne);
   if (e == hipSuccess) e = hipMemsetAsync(td, 0, sizeof(int2) * ne, 0);  // (the edges of rows beyond the stage are no tasks: empty descriptors at the end)
   if (e == hipSuccess) e = hipMemsetAsync(tedge, 0, sizeof(int) * ne, 0);
   if (e == hipSuccess) e = hipMemsetAsync(cnt.p, 0, sizeof(int) * nv1, 0);
@@ -1323,13 +1323,15 @@ int ensure_tasklists(gm_graph *g, bool /*with_edges*/) {
     if (tedge) (void)hipFree(tedge);
     return hip_fail(e, "task lists", __FILE__, __LINE__);
   }
-  g->d_trp = trp;
-  g->d_tdesc = td;
-  g->d_tedge = tedge;
   if (tl_skip < g->nv) {
     g->tl_skip_from = tl_skip;
     g->tl_core_h = g->nv - tl_skip;
   }
+  g->d_trp = trp;
+  g->d_tedge = tedge;
+  // d_tdesc is what the lock-free check at the top reads: published LAST, with release order, so that a first caller on another thread
+  // that sees it also sees the corner's skip row and the other arrays
+  __atomic_store_n(&g->d_tdesc, td, __ATOMIC_RELEASE);
   setup_trace("tasks: place pass");
   if (!keystream_possible(g)) build_inline_copies(g, tmp);  // (a handle that cannot have the key stream: task-major copies of the short lists)
   setup_trace("tasks: inline copies");
@@ -1387,8 +1389,8 @@ int ensure_sup_corner(gm_graph *g) {
   const size_t cells = (size_t)h * (size_t)words;
   unsigned *bits = nullptr;
   unsigned short *first_pos = nullptr;
-  HIP_TRY(hipMalloc(&bits, cells * sizeof(unsigned)));
-  hipError_t e = hipMalloc(&first_pos, cells * sizeof(unsigned short));
+  HIP_TRY(dev_malloc(&bits, cells * sizeof(unsigned)));
+  hipError_t e = dev_malloc(&first_pos, cells * sizeof(unsigned short));
   if (e == hipSuccess) e = hipMemsetAsync(bits, 0, cells * sizeof(unsigned), 0);
   if (e == hipSuccess) e = hipMemsetAsync(first_pos, 0, cells * sizeof(unsigned short), 0);
   int e0 = 0;
@@ -1407,13 +1409,9 @@ int ensure_sup_corner(gm_graph *g) {
   return GM_OK;
 }
 
-int sup_mask_min_tail() {
-  static const int v = [] {
-    const char *e = getenv("GM_SUP_MASK_MIN");
-    return e ? std::max(1, atoi(e)) : kSupMaskMinTail;
-  }();
-  return v;
-}
+// the shortest tail that gets a mask on this handle: kSupMaskMinTail, or the option GM_SUP_MASK_MIN as it stood when the handle's masks
+// were laid out (ensure_sup_masks) -- the kernels must use the value the offsets were built with
+int sup_mask_min_tail(const gm_graph *g) { return g->smask_min_tail > 0 ? g->smask_min_tail : kSupMaskMinTail; }
 
 int ensure_sup_masks(gm_graph *g) {
   if (g->smask_state != 0) return GM_OK;
@@ -1425,10 +1423,11 @@ int ensure_sup_masks(gm_graph *g) {
   }
   std::lock_guard<std::mutex> lk(g->mu);
   if (g->smask_state != 0) return GM_OK;
-  if (!topo || gm_sweep_env("GM_TC_NO_TRIM") || getenv("GM_SUP_NO_MASKS") || g->ne < 1) {  // (tails exist on a topologically numbered DAG only)
+  if (!topo || gm_sweep_env("GM_TC_NO_TRIM") || gm_opt("GM_SUP_NO_MASKS") || g->ne < 1) {  // (tails exist on a topologically numbered DAG only)
     g->smask_state = 2;
     return GM_OK;
   }
+  if (const char *e = gm_opt("GM_SUP_MASK_MIN")) g->smask_min_tail = std::max(1, atoi(e));
   SetupTimer timer;
   HIP_TRY(hipSetDevice(g->device));
   const size_t ne = (size_t)g->ne;
@@ -1442,7 +1441,7 @@ int ensure_sup_masks(gm_graph *g) {
   tw.rp = g->d_rp; tw.col = g->d_col; tw.edesc = g->d_edesc;
   tw.skip_from = g->tl_skip_from;  // (the corner's rows have no tasks: no masks)
   const long long blocks = std::min<long long>(((long long)g->nv * 8 + 255) / 256, (long long)g->cu_count * 32);
-  hipLaunchKernelGGL(sup_mask_size_kernel, dim3((unsigned)std::max<long long>(1, blocks)), dim3(256), 0, 0, tw, sup_mask_min_tail(), off.p);
+  hipLaunchKernelGGL(sup_mask_size_kernel, dim3((unsigned)std::max<long long>(1, blocks)), dim3(256), 0, 0, tw, sup_mask_min_tail(g), off.p);
   HIP_TRY(dev_exclusive_sum(tmp, off.p, off.p, ne + 1));
   unsigned long long total = 0;
   HIP_TRY(hipMemcpy(&total, off.p + ne, sizeof total, hipMemcpyDeviceToHost));
@@ -1457,18 +1456,21 @@ int ensure_sup_masks(gm_graph *g) {
   HIP_TRY(fflag.alloc((size_t)g->nv + 1));
   HIP_TRY(fpos.alloc((size_t)g->nv + 1));
   HIP_TRY(hipMemsetAsync(fflag.p, 0, sizeof(int) * ((size_t)g->nv + 1), 0));
-  hipLaunchKernelGGL(sup_far_flag_kernel, dim3((unsigned)((g->nv + 255) / 256)), dim3(256), 0, 0, g->nv, g->d_rp, sup_mask_min_tail(), kTctStageMax, g->tl_skip_from, fflag.p);
+  hipLaunchKernelGGL(sup_far_flag_kernel, dim3((unsigned)((g->nv + 255) / 256)), dim3(256), 0, 0, g->nv, g->d_rp, sup_mask_min_tail(g), kTctStageMax, g->tl_skip_from, fflag.p);
   HIP_TRY(dev_exclusive_sum(tmp, fflag.p, fpos.p, (size_t)g->nv + 1));
   int nfar = 0;
   HIP_TRY(hipMemcpy(&nfar, fpos.p + g->nv, sizeof nfar, hipMemcpyDeviceToHost));
   unsigned *emoff = nullptr, *tmoff = nullptr;
   unsigned long long *arena = nullptr;
   int *far_rows = nullptr;
-  hipError_t e = hipMalloc(&emoff, sizeof(unsigned) * ne);
-  if (e == hipSuccess) e = hipMalloc(&far_rows, sizeof(int) * (size_t)std::max(nfar, 1));
+  hipError_t e = dev_malloc(&emoff, sizeof(unsigned) * ne);
+  if (e == hipSuccess) e = dev_malloc(&far_rows, sizeof(int) * (size_t)std::max(nfar, 1));
   if (e == hipSuccess) hipLaunchKernelGGL(sup_far_list_kernel, dim3((unsigned)((g->nv + 255) / 256)), dim3(256), 0, 0, g->nv, fflag.p, fpos.p, far_rows);
-  if (e == hipSuccess) e = hipMalloc(&tmoff, sizeof(unsigned) * ne);
-  if (e == hipSuccess) e = hipMalloc(&arena, sizeof(unsigned long long) * (size_t)total);
+  if (e == hipSuccess) e = dev_malloc(&tmoff, sizeof(unsigned) * ne);
+  if (e == hipSuccess) e = dev_malloc(&arena, sizeof(unsigned long long) * (size_t)total);
+  // (every launch rewrites the words of the tasks it runs; a launch that leaves masked tasks out -- a chunk filter, an aborted launch --
+  // must find zeros, not what hipMalloc handed over: ADVICE r5)
+  if (e == hipSuccess) e = hipMemsetAsync(arena, 0, sizeof(unsigned long long) * (size_t)total, 0);
   if (e == hipSuccess) {
     const long long eb = std::min<long long>(((long long)ne + 255) / 256, (long long)g->cu_count * 32);
     hipLaunchKernelGGL(sup_mask_off_kernel, dim3((unsigned)eb), dim3(256), 0, 0, (long long)ne, off.p, emoff);
@@ -1514,8 +1516,8 @@ int ensure_long_rows(gm_graph *g) {
   }
   if (!rows.empty()) {
     HIP_TRY(hipSetDevice(g->device));
-    HIP_TRY(hipMalloc(&g->d_long_rows, sizeof(int) * rows.size()));
-    HIP_TRY(hipMalloc(&g->d_long_prefix, sizeof(long long) * prefix.size()));
+    HIP_TRY(dev_malloc(&g->d_long_rows, sizeof(int) * rows.size()));
+    HIP_TRY(dev_malloc(&g->d_long_prefix, sizeof(long long) * prefix.size()));
     HIP_TRY(copy_to_device(g->d_long_rows, rows.data(), sizeof(int) * rows.size()));
     HIP_TRY(copy_to_device(g->d_long_prefix, prefix.data(), sizeof(long long) * prefix.size()));
   }
@@ -1530,7 +1532,7 @@ int ensure_edesc(gm_graph *g) {
   if (g->d_edesc) return GM_OK;
   SetupTimer timer;
   int2 *d = nullptr;
-  HIP_TRY(hipMalloc(&d, sizeof(int2) * (size_t)g->ne));
+  HIP_TRY(dev_malloc(&d, sizeof(int2) * (size_t)g->ne));
   const long long blocks = std::min<long long>((g->ne + 255) / 256, (long long)g->cu_count * 32);
   hipLaunchKernelGGL(edesc_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, g->ne, g->d_rp, g->d_col, d);
   hipError_t e = hipDeviceSynchronize();
@@ -1734,7 +1736,7 @@ int ensure_core_bitmap(gm_graph *g) {
   const int base = g->nv - h;
   const int words = (h + 31) / 32;
   const size_t bytes = (size_t)h * (size_t)words * 4;
-  if (hipMalloc(&g->d_core, bytes) != hipSuccess) {  // no room: the streamed build does everything
+  if (dev_malloc(&g->d_core, bytes) != hipSuccess) {  // no room: the streamed build does everything
     (void)hipGetLastError();
     g->d_core = nullptr;
     g->core_state = 2;
@@ -1802,14 +1804,14 @@ static int build_clique_round(gm_graph *g, CliquePlan &pl, CliqueRound &rd, Scan
   if (rd.w1 > rd.w0)
     hipLaunchKernelGGL(cb_own_verts_kernel, blocks((long long)(rd.w1 - rd.w0)), dim3(256), 0, 0, (int)(rd.w1 - rd.w0), pl.d_verts + rd.w0, own.p);
   hipLaunchKernelGGL(cb_owner_sizes_kernel, blocks((long long)nv1), dim3(256), 0, 0, nv, g->d_rp, g->d_col, own.p, pl.core_base, words.p, ntask_of.p);
-  HIP_TRY(hipMalloc(&rd.d_base, sizeof(unsigned long long) * nv1));
+  HIP_TRY(dev_malloc(&rd.d_base, sizeof(unsigned long long) * nv1));
   HIP_TRY(dev_exclusive_sum(tmp, words.p, rd.d_base, nv1));
   HIP_TRY(dev_exclusive_sum(tmp, ntask_of.p, tpos.p, nv1));
   int nt = 0;
   HIP_TRY(hipMemcpy(&rd.words, rd.d_base + nv, 8, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(&nt, tpos.p + nv, sizeof(int), hipMemcpyDeviceToHost));
   rd.n_tasks = (size_t)nt;
-  HIP_TRY(hipMalloc(&rd.d_trp, sizeof(int) * nv1));
+  HIP_TRY(dev_malloc(&rd.d_trp, sizeof(int) * nv1));
   if (rd.w1 > rd.w0)  // (before the early return: a round whose wide rows all come from the core bitmap has no streamed task at all)
     hipLaunchKernelGGL(cb_slot_base_kernel, blocks((long long)(rd.w1 - rd.w0)), dim3(256), 0, 0, (int)rd.w0, (int)rd.w1, pl.d_verts, rd.d_base, pl.d_slot_base);
   if (nt == 0) {
@@ -1824,7 +1826,7 @@ static int build_clique_round(gm_graph *g, CliquePlan &pl, CliqueRound &rd, Scan
   hipLaunchKernelGGL((cb_task_rows_kernel<false>), dim3((unsigned)kblocks), dim3(256), 0, 0, nv, g->d_rp, g->d_col, g->d_edesc, ntask_of.p, pl.topo ? 1 : 0, hub0,
                      cnt.p, nullptr, nullptr, nullptr);
   HIP_TRY(dev_exclusive_sum(tmp, cnt.p, rd.d_trp, nv1));
-  HIP_TRY(hipMalloc(&rd.d_tasks, sizeof(CBuildTask) * (size_t)nt));
+  HIP_TRY(dev_malloc(&rd.d_tasks, sizeof(CBuildTask) * (size_t)nt));
   HIP_TRY(hipMemsetAsync(cnt.p, 0, sizeof(int) * nv1, 0));
   hipLaunchKernelGGL((cb_task_rows_kernel<true>), dim3((unsigned)kblocks), dim3(256), 0, 0, nv, g->d_rp, g->d_col, g->d_edesc, ntask_of.p, pl.topo ? 1 : 0, hub0,
                      cnt.p, rd.d_trp, rd.d_base, rd.d_tasks);
@@ -1898,7 +1900,7 @@ int get_clique_plan(gm_graph *g, int rank, int world, int policy, int target, un
       HIP_TRY(degs.alloc((size_t)m));
       HIP_TRY(keyo.alloc((size_t)m));
       hipLaunchKernelGGL(gather_deg_kernel, blocks(m), dim3(256), 0, 0, m, sel.p, g->d_rp, degs.p);
-      HIP_TRY(hipMalloc(&g->d_wide_sorted, sizeof(int) * (size_t)m));
+      HIP_TRY(dev_malloc(&g->d_wide_sorted, sizeof(int) * (size_t)m));
       size_t bytes = 0;
       HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, bytes, degs.p, keyo.p, sel.p, g->d_wide_sorted, m));
       HIP_TRY(tmp.reserve(bytes));
@@ -1948,8 +1950,8 @@ int get_clique_plan(gm_graph *g, int rank, int world, int policy, int target, un
   std::vector<int> hd((size_t)wcount);
   if (wcount > 0) {
     DevBuf<int> degs;
-    HIP_TRY(hipMalloc(&pl.d_verts, sizeof(int) * (size_t)wcount));
-    HIP_TRY(hipMalloc(&pl.d_slot_base, sizeof(unsigned long long) * (size_t)wcount));
+    HIP_TRY(dev_malloc(&pl.d_verts, sizeof(int) * (size_t)wcount));
+    HIP_TRY(dev_malloc(&pl.d_slot_base, sizeof(unsigned long long) * (size_t)wcount));
     HIP_TRY(degs.alloc((size_t)wcount));
     hipLaunchKernelGGL(wide_share_kernel, blocks(wcount), dim3(256), 0, 0, (int)wcount, (long long)wfirst, (long long)wstep, g->d_wide_sorted, g->d_rp, pl.d_verts, degs.p);
     pl.verts.resize((size_t)wcount);
@@ -1959,7 +1961,7 @@ int get_clique_plan(gm_graph *g, int rank, int world, int policy, int target, un
   setup_trace("clique: wide share to the host");
   // rounds within the arena budget: the narrow chunks first (in dequeue order), then the wide vertices (longest rows first)
   unsigned long long arena_mb = GM_WIDE_ARENA_MB;
-  if (const char *e = getenv("GM_WIDE_ARENA_MB")) arena_mb = std::max(1ll, atoll(e));  // (tests: force several rounds)
+  if (const char *e = gm_opt("GM_WIDE_ARENA_MB")) arena_mb = std::max(1ll, atoll(e));  // (tests: force several rounds)
   const unsigned long long budget_words = (arena_mb << 20) / 4ull;
   // (the per-chunk words come to the host only when the narrow chunks alone overflow the arena: one round needs their sum)
   std::vector<unsigned long long> cw;
@@ -2021,7 +2023,7 @@ int get_clique_plan(gm_graph *g, int rank, int world, int policy, int target, un
     }
   }
   setup_trace("clique: rounds (host loop)");
-  HIP_TRY(hipMalloc(&pl.d_mcls_slots, sizeof(int) * std::max<size_t>(mcls_slots.size(), 1)));
+  HIP_TRY(dev_malloc(&pl.d_mcls_slots, sizeof(int) * std::max<size_t>(mcls_slots.size(), 1)));
   if (!mcls_slots.empty()) HIP_TRY(copy_to_device(pl.d_mcls_slots, mcls_slots.data(), sizeof(int) * mcls_slots.size()));
   setup_trace("clique: wide list, classes, rounds (host)");
   unsigned long long need_words = 0;
@@ -2036,10 +2038,10 @@ int get_clique_plan(gm_graph *g, int rank, int world, int policy, int target, un
     if (g->d_wide_mat) (void)hipFree(g->d_wide_mat);
     g->d_wide_mat = nullptr;
     g->wide_mat_bytes = 0;
-    HIP_TRY(hipMalloc(&g->d_wide_mat, std::max<size_t>(need, 16)));
+    HIP_TRY(dev_malloc(&g->d_wide_mat, std::max<size_t>(need, 16)));
     g->wide_mat_bytes = need;
   }
-  if (!g->d_wide_queue) HIP_TRY(hipMalloc(&g->d_wide_queue, 65536));
+  if (!g->d_wide_queue) HIP_TRY(dev_malloc(&g->d_wide_queue, 65536));
   setup_trace("clique: arena");
   HIP_TRY(hipDeviceSynchronize());
   std::lock_guard<std::mutex> lk(g->mu);

@@ -195,7 +195,7 @@ extern "C" int gm_selftest(int device, int *n_fail) {
   if (n_fail) *n_fail = -1;
   HIP_TRY(hipSetDevice(device));
   int *d = nullptr;
-  HIP_TRY(hipMalloc(&d, sizeof(int) * 512));
+  HIP_TRY(dev_malloc(&d, sizeof(int) * 512));
   hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, 0, d);
   int h[512];
   hipError_t e = hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);

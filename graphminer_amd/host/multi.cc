@@ -6,7 +6,9 @@
 //   MotifSolver   src/motif/gpu_base.cu:21-110
 //
 // Single GPU: upload (GraphGPU::init), one gm_* call, print the reference's runtime / throughput lines.
-// Multi GPU (n_gpu > 1), one process, n devices:
+// Multi GPU (n_gpu > 1), one process, n devices, ONE HOST THREAD PER DEVICE (the reference's shape: src/triangle/multigpu.cu:67,
+// src/clique/multigpu.cu:109 start a std::thread per GPU) -- a gm_* launch is several kernels + memsets + share-table lookups, and at
+// 0.4 ms of kernel per rank eight of them issued one after the other by one thread were on the critical path:
 //   * the CSR goes over PCIe ONCE (to GPU 0) and is replicated with ncclBroadcast over xGMI, instead of
 //     the reference's n host->device copies (src/clique/multigpu.cu:57-66);
 //   * the task split is index arithmetic on chunk ids inside the library (rank i owns chunks i mod n,
@@ -19,10 +21,14 @@
 #include <rccl/rccl.h>
 #include <sys/time.h>
 
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <iostream>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 namespace gmhost {
@@ -34,6 +40,65 @@ struct Stopwatch {  // (the reference's Timer, include/timer.h:6-33: gettimeofda
   double Seconds() const { return (b.tv_sec - a.tv_sec) + 1e-6 * (b.tv_usec - a.tv_usec); }
   timeval a{}, b{};
 };
+
+// n persistent host threads, thread i bound to device i: run(f) has every thread execute f(i) and returns when all have finished.
+// (persistent: a std::thread costs ~50 us to start, which would sit inside every timed step)
+class DeviceThreads {
+ public:
+  explicit DeviceThreads(int n) : n_(n) {
+    for (int i = 0; i < n; ++i) th_.emplace_back([this, i] { loop(i); });
+  }
+  ~DeviceThreads() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      quit_ = true;
+      ++gen_;
+    }
+    cv_.notify_all();
+    for (auto &t : th_) t.join();
+  }
+  void run(const std::function<void(int)> &f) {
+    std::unique_lock<std::mutex> lk(mu_);
+    job_ = &f;
+    left_ = n_;
+    ++gen_;
+    cv_.notify_all();
+    done_.wait(lk, [this] { return left_ == 0; });
+    job_ = nullptr;
+  }
+
+ private:
+  void loop(int i) {
+    (void)hipSetDevice(i);  // (the current device is per host thread)
+    unsigned long long seen = 0;
+    for (;;) {
+      const std::function<void(int)> *f = nullptr;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return gen_ != seen; });
+        seen = gen_;
+        if (quit_) return;
+        f = job_;
+      }
+      (*f)(i);
+      {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (--left_ == 0) done_.notify_one();
+      }
+    }
+  }
+  int n_;
+  std::vector<std::thread> th_;
+  std::mutex mu_;
+  std::condition_variable cv_, done_;
+  const std::function<void(int)> *job_ = nullptr;
+  unsigned long long gen_ = 0;
+  int left_ = 0;
+  bool quit_ = false;
+};
+
+// developer options of the library (include/graphminer_amd.h gm_dev_option): nothing here reads the environment
+bool opt_set(const char *name) { return gm_dev_option_get(name) != nullptr; }
 
 [[noreturn]] void die(int status, const char *where) {  // message + exit: CUDA_SAFE_CALL's reaction (include/cutil_subset.h:4-10)
   std::fprintf(stderr, "error: %s: %s", where, gm_strerror(status));
@@ -70,7 +135,7 @@ int call(const Job &j, gm_graph *g, const gm_launch *la, uint64_t *out, gm_stats
     case Job::MOTIF:
       // 4-motif on several GPUs: every rank leaves its six RAW sums on the device (gm_motif4_partial), the all-reduce adds
       // them, run_multi applies gm_motif4_finish to the reduced sums (src/motif/omp_formula.cc:41-45)
-      // (also with one device under GM_FORCE_RCCL_PATH, so that a one-GPU test box exercises this path)
+      // (also with one device under the developer option GM_FORCE_RCCL_PATH, so that a one-GPU test box exercises this path)
       if (j.k == 4 && la && la->d_counts && !out) return gm_motif4_partial(g, la, out, st);
       return gm_motif(g, j.k, la, out, j.ncounts, st);
   }
@@ -146,11 +211,11 @@ bool run_multi(const gm_csr &g, const Job &j, int n, int chunk, uint64_t *out) {
   int64_t sup_n = 0;
   // Up to four GPUs: beyond, a GPU's share of the per-edge kernels + the single 8-byte all-reduce is the better deal (one-GPU simulation of
   // the shares on R-MAT-22 at 2 / 4 / 8 ranks: shared triangle pass 4.48 / 3.04 / 2.35 ms + a reduce-scatter of 81 / 122 / 142 MB per rank,
-  // per-edge kernels 8.20 / 4.75 / 2.90 ms: profiles/r05/sim_scale_one_gpu.txt).  GM_DIAMOND_SUPPORTS_MAX_WORLD overrides the limit.
+  // per-edge kernels 8.20 / 4.75 / 2.90 ms: profiles/r05/sim_scale_one_gpu.txt).  The developer option GM_DIAMOND_SUPPORTS_MAX_WORLD overrides the limit.
   int sup_max_world = 4;
-  if (const char *e = std::getenv("GM_DIAMOND_SUPPORTS_MAX_WORLD")) sup_max_world = std::atoi(e);
-  bool diamond_sup = j.kind == Job::SGL && j.pattern && std::strcmp(j.pattern, "diamond") == 0 && !std::getenv("GM_DIAMOND_PER_EDGE") &&
-                     (n <= sup_max_world || std::getenv("GM_FORCE_RCCL_PATH"));
+  if (const char *e = gm_dev_option_get("GM_DIAMOND_SUPPORTS_MAX_WORLD")) sup_max_world = std::atoi(e);
+  bool diamond_sup = j.kind == Job::SGL && j.pattern && std::strcmp(j.pattern, "diamond") == 0 && !opt_set("GM_DIAMOND_PER_EDGE") &&
+                     (n <= sup_max_world || opt_set("GM_FORCE_RCCL_PATH"));
   if (diamond_sup) {
     for (int i = 0; i < n && diamond_sup; ++i) {
       HIP_OK(hipSetDevice(i));
@@ -162,60 +227,47 @@ bool run_multi(const gm_csr &g, const Job &j, int n, int chunk, uint64_t *out) {
       HIP_OK(hipMalloc(&d_sup[i], sizeof(uint32_t) * size_t(m)));
     }
   }
+  DeviceThreads threads(n);  // thread i drives device i: its launches, its collectives, its synchronisation
+  std::vector<gm_launch> las(n);
+  for (int i = 0; i < n; ++i) {
+    gm_launch &la = las[i];
+    std::memset(&la, 0, sizeof la);
+    la.stream = streams[i];
+    la.rank = i;
+    la.world = n;
+    la.policy = GM_PART_ROUND_ROBIN;
+    la.chunk = chunk > 0 ? chunk : 0;
+    la.d_counts = d_cnt[i];
+  }
+  // (RCCL: one communicator per device, each used by its own thread -- collectives are enqueued on the device's stream without a group
+  // call, which would have to be opened and closed by one thread for all of them)
   auto launch_diamond = [&]() {
     const size_t per = size_t(sup_n) / size_t(n);
-    std::vector<gm_launch> las(n);
-    for (int i = 0; i < n; ++i) {
-      gm_launch &la = las[i];
-      std::memset(&la, 0, sizeof la);
-      la.stream = streams[i];
-      la.rank = i;
-      la.world = n;
-      la.policy = GM_PART_ROUND_ROBIN;
-      la.chunk = chunk > 0 ? chunk : 0;
-      la.d_counts = d_cnt[i];
-      int rc = gm_diamond_support_partial(dg[i], &la, d_sup[i], sup_n, nullptr);
+    threads.run([&](int i) {
+      int rc = gm_diamond_support_partial(dg[i], &las[i], d_sup[i], sup_n, nullptr);
       if (rc) die(rc, "gm_diamond_support_partial");
-    }
-    NCCL_OK(ncclGroupStart());
-    for (int i = 0; i < n; ++i)  // in place: GPU i receives its slice where it lies in its own array
+      // in place: GPU i receives its slice where it lies in its own array
       NCCL_OK(ncclReduceScatter(d_sup[i], d_sup[i] + size_t(i) * per, per, ncclUint32, ncclSum, comms[i], streams[i]));
-    NCCL_OK(ncclGroupEnd());
-    for (int i = 0; i < n; ++i) {
-      int rc = gm_diamond_support_finish(dg[i], &las[i], d_sup[i] + size_t(i) * per, int64_t(per), nullptr, nullptr);
+      rc = gm_diamond_support_finish(dg[i], &las[i], d_sup[i] + size_t(i) * per, int64_t(per), nullptr, nullptr);
       if (rc) die(rc, "gm_diamond_support_finish");
-    }
-    NCCL_OK(ncclGroupStart());
-    for (int i = 0; i < n; ++i)
       NCCL_OK(ncclAllReduce(d_cnt[i], d_cnt[i], 1, ncclUint64, ncclSum, comms[i], streams[i]));
-    NCCL_OK(ncclGroupEnd());
-    for (int i = 0; i < n; ++i) {
-      HIP_OK(hipSetDevice(i));
       HIP_OK(hipStreamSynchronize(streams[i]));
-    }
+    });
   };
   auto launch_all = [&](bool &unsupported) {
     if (diamond_sup) return launch_diamond();
-    for (int i = 0; i < n; ++i) {
-      gm_launch la;
-      std::memset(&la, 0, sizeof la);
-      la.stream = streams[i];
-      la.rank = i;
-      la.world = n;
-      la.policy = GM_PART_ROUND_ROBIN;
-      la.chunk = chunk > 0 ? chunk : 0;
-      la.d_counts = d_cnt[i];
-      int rc = call(j, dg[i], &la, nullptr, nullptr);  // asynchronous: kernels of all GPUs overlap
-      if (rc == GM_ERR_UNSUPPORTED) { unsupported = true; return; }
-      if (rc) die(rc, "mining kernel");
-    }
-    NCCL_OK(ncclGroupStart());
-    for (int i = 0; i < n; ++i)
+    std::vector<int> rcs(n, GM_OK);
+    threads.run([&](int i) {
+      rcs[i] = call(j, dg[i], &las[i], nullptr, nullptr);  // asynchronous: returns when the kernels are enqueued
+      // (every rank gets the same verdict on "unsupported" / invalid -- it depends on the pattern, not on the share -- so either all
+      // ranks join the all-reduce or none does)
+      if (rcs[i] != GM_OK) return;
       NCCL_OK(ncclAllReduce(d_cnt[i], d_cnt[i], size_t(j.ncounts), ncclUint64, ncclSum, comms[i], streams[i]));
-    NCCL_OK(ncclGroupEnd());
-    for (int i = 0; i < n; ++i) {
-      HIP_OK(hipSetDevice(i));
       HIP_OK(hipStreamSynchronize(streams[i]));
+    });
+    for (int i = 0; i < n; ++i) {
+      if (rcs[i] == GM_ERR_UNSUPPORTED) { unsupported = true; return; }
+      if (rcs[i]) die(rcs[i], "mining kernel");
     }
   };
   bool unsupported = false;
@@ -269,9 +321,9 @@ bool run(const gm_csr &g, Job j, int n_gpu, int chunk, uint64_t *out) {
     std::cout << "requested " << n_gpu << " GPUs, " << ndev << " available\n";
     n_gpu = ndev;
   }
-  // GM_FORCE_RCCL_PATH=1 drives the multi-GPU code (broadcast + all-reduce) even with one device,
+  // gm_dev_option("GM_FORCE_RCCL_PATH", "1") drives the multi-GPU code (broadcast + all-reduce) even with one device,
   // so the RCCL path is exercised on a single-GPU test box.
-  if (n_gpu <= 1 && !std::getenv("GM_FORCE_RCCL_PATH")) return run_single(g, j, chunk, out);
+  if (n_gpu <= 1 && !opt_set("GM_FORCE_RCCL_PATH")) return run_single(g, j, chunk, out);
   if (n_gpu < 1) n_gpu = 1;
   j.name = "multigpu";
   return run_multi(g, j, n_gpu, chunk, out);

@@ -1,5 +1,5 @@
-// multi.h -- the runner behind the four solver entry points: one GPU, or n GPUs of one node from ONE process (one host thread, n
-// devices, RCCL) -- the shape of the reference's *_multigpu binaries, which take n_gpu from argv and drive the devices themselves
+// multi.h -- the runner behind the four solver entry points: one GPU, or n GPUs of one node from ONE process (one host thread per
+// device, RCCL) -- the shape of the reference's *_multigpu binaries, which take n_gpu from argv and drive the devices themselves
 // (src/clique/multigpu.cu:20,109-139; src/triangle/multigpu_base.cu:25-105).
 //
 // It takes the graph as a gm_csr (five plain fields) -- NOT a Graph class -- so that the same object links under this build's own
@@ -21,7 +21,7 @@ struct Job {
 };
 
 // Runs the job on min(n_gpu, devices present) GPUs and leaves the count(s) in out[0 .. ncounts).  One device: upload + one call
-// (+ one timed call); several (or GM_FORCE_RCCL_PATH=1 with one): one PCIe copy + ncclBroadcast of the CSR, every device's share of
+// (+ one timed call); several (or one under the developer option GM_FORCE_RCCL_PATH): one PCIe copy + ncclBroadcast of the CSR, every device's share of
 // the task chunks, ONE ncclAllReduce(ncclUint64) of the counts.  Prints the reference's runtime / throughput lines.
 // Returns false when the pattern / k is not implemented (the caller prints the reference's message); device errors exit(1).
 bool run(const gm_csr &h, Job j, int n_gpu, int chunk, uint64_t *out);

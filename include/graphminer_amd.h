@@ -198,11 +198,11 @@ int gm_sgl(const gm_graph *sym, const char *pattern, const gm_launch *launch, ui
 /* Diamond on SEVERAL ranks with the one-GPU algorithm (one shared pass over the triangles of the oriented copy; the reference has no
  * multi-GPU diamond: src/sgl/multigpu.cu:117 is commented out).  Per step, on every rank:
  *   1. gm_diamond_support_partial: the rank's share (launch->rank / world) of the triangle pass adds its three increments per triangle
- *      into d_support -- the caller's DEVICE buffer of n_entries uint32 (EXACTLY gm_diamond_support_size: |E+| of the oriented copy
- *      rounded up so that every rank's slice is equal and 256-byte aligned; any other size -> GM_ERR_INVALID), zeroed by the call,
- *      ordered on launch->stream;
+ *      into d_support -- the caller's DEVICE buffer of n_entries uint32 (AT LEAST gm_diamond_support_size = S: |E+| of the oriented copy
+ *      rounded up so that every rank's slice is equal and 256-byte aligned; fewer -> GM_ERR_INVALID; a larger buffer is accepted and only
+ *      its first S entries are used), zeroed by the call, ordered on launch->stream;
  *   2. the caller sums the ranks' arrays with ONE reduce-scatter (ncclReduceScatter, ncclUint32, ncclSum / torch reduce_scatter_tensor):
- *      rank r receives the n_entries / world entries from r * n_entries / world on;
+ *      rank r receives the S / world entries from r * S / world on (S = gm_diamond_support_size, not the buffer's own length);
  *   3. gm_diamond_support_finish: sum C(t, 2) over `count` entries at d_support (the rank's reduced slice) -> total / launch->d_counts;
  *   4. the usual all-reduce of the 64-bit count.
  * Rows of the oriented copy beyond the 2048-entry stage take sup_long_kernel (one wave per edge) inside the same call. */
@@ -215,7 +215,7 @@ int gm_diamond_support_info(const gm_graph *sym, int64_t info[4]);
 /* Tooling: the supports of the edges inside the hub corner (the last H vertices of the renumbered oriented copy) are one bit-matrix product
  * on the matrix cores, t(i, j) = (A A)_ij over the symmetric corner A (csrc/gm_ctc.hip), and the triangle pass leaves the corner's rows
  * out: info[0] = H (0: none), info[1] = DAG entries inside the corner, info[2] = pairs of 256-row blocks, info[3] = 512-column chunks per
- * row.  GM_SUP_CORE_H in the environment (read when the handle's task lists are built): 0 = off, a multiple of 512 = that H. */
+ * row.  gm_dev_option("GM_SUP_CORE_H", ..) (read when the handle's task lists are built): 0 = off, a multiple of 512 = that H. */
 int gm_sup_core_info(const gm_graph *sym, int64_t info[4]);
 int gm_diamond_support_partial(const gm_graph *sym, const gm_launch *launch, uint32_t *d_support, int64_t n_entries, gm_stats *stats);
 int gm_diamond_support_finish(const gm_graph *sym, const gm_launch *launch, const uint32_t *d_support, int64_t count, uint64_t *total,
@@ -316,6 +316,14 @@ int gm_issue_calib(int kind, int waves_per_simd, int iters, double *cycles_per_w
  * "long_list", "stage_cap", "default_chunk", "mma_words_small", "mma_words_big", "wide_max_deg", "bit_words") -- what the byte model
  * of bench.py needs to know about the kernels, read from the headers they are compiled with. GM_ERR_INVALID for an unknown name. */
 int gm_constant(const char *name, int64_t *value);
+
+/* Developer / test options (tooling).  The library reads NO algorithm switch from the environment; the named switches that tests and A/B
+ * runs need -- forcing a path on a small graph, the documented fallbacks (csrc/gm_mine.h lists them) -- are set here, process-wide:
+ * value = NULL removes `name`, name = NULL removes every option.  Options that shape a handle's cached tables are read when those tables
+ * are built (use a fresh handle after changing one).  gm_dev_option_get: the current value or NULL.  Nothing in a production caller
+ * needs either. */
+int gm_dev_option(const char *name, const char *value);
+const char *gm_dev_option_get(const char *name);
 
 /* wave-primitive self test (DPP scans, ballot rank, LDS search); returns GM_OK when the device
  * results equal the host expectation. *n_fail receives the number of mismatching lanes. */

@@ -21,3 +21,13 @@ def root():
 @pytest.fixture(scope="session")
 def fixtures_dir():
     return os.path.join(ROOT, "tests", "fixtures")
+
+
+@pytest.fixture
+def devopt():
+    """devopt(name, value) sets a developer option of the library for this test (value None removes it); all options are removed
+    afterwards. The library reads no algorithm switch from the environment (include/graphminer_amd.h gm_dev_option)."""
+    from graphminer_amd._lib import dev_option
+
+    yield dev_option
+    dev_option(None)

@@ -12,11 +12,12 @@ pytestmark = pytest.mark.gpu
 BIN = os.path.join(ROOT, "graphminer_amd", "bin")
 
 
-def run(exe, *args, env=None):
+def run(exe, *args, dev=None):
+    """dev: developer options of the library, handed over as `--dev NAME=VALUE` (the apps read nothing from the environment)"""
     p = os.path.join(BIN, exe)
     assert os.path.exists(p), f"{p} not built (make -C graphminer_amd)"
-    e = dict(os.environ, **(env or {}))
-    r = subprocess.run([p, *map(str, args)], capture_output=True, text=True, env=e, timeout=300)
+    extra = [a for k, v in (dev or {}).items() for a in ("--dev", f"{k}={v}")]
+    r = subprocess.run([p, *map(str, args), *extra], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     return r.stdout.strip().splitlines()
 
@@ -102,11 +103,15 @@ def test_rccl_path_on_one_gpu():
     """broadcast + ncclAllReduce(uint64, sum) code path, forced with a single device"""
     e = GOLDEN["citeseer"]
     prefix = os.path.join(ROOT, "tests", "fixtures", "citeseer", "graph")
-    env = {"GM_FORCE_RCCL_PATH": "1"}
-    assert run("tc_multigpu", prefix, 1, env=env)[-1] == f"total_num_triangles = {e['tc']}"
-    assert run("clique_multigpu", prefix, 4, 1, env=env)[-1] == f"num_4-cliques = {e['clique4']}"
-    out = run("motif_multigpu", prefix, 3, 1, env=env)
+    dev = {"GM_FORCE_RCCL_PATH": "1"}
+    assert run("tc_multigpu", prefix, 1, dev=dev)[-1] == f"total_num_triangles = {e['tc']}"
+    assert run("clique_multigpu", prefix, 4, 1, dev=dev)[-1] == f"num_4-cliques = {e['clique4']}"
+    out = run("motif_multigpu", prefix, 3, 1, dev=dev)
     assert out[-2:] == [f"pattern 0: {e['motif3'][0]}", f"pattern 1: {e['motif3'][1]}"]
-    assert run("sgl_multigpu", prefix, "diamond", 1, env=env)[-1] == f"total_num = {e['diamond']}"
+    assert run("sgl_multigpu", prefix, "diamond", 1, dev=dev)[-1] == f"total_num = {e['diamond']}"
+    # the environment is NOT a switch: the same variable there changes nothing (one device -> the one-GPU path, no broadcast line)
+    r = subprocess.run([os.path.join(BIN, "tc_multigpu"), prefix, "1"], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, GM_FORCE_RCCL_PATH="1"))
+    assert r.returncode == 0 and "RCCL broadcast" not in r.stdout and r.stdout.strip().splitlines()[-1] == f"total_num_triangles = {e['tc']}"
     # asking for more GPUs than present clamps (the reference would fail in cudaSetDevice)
     assert run("tc_multigpu", prefix, 8)[-1] == f"total_num_triangles = {e['tc']}"

@@ -10,6 +10,7 @@ import pytest
 import oracle as O
 from common import GOLDEN, GRAPH_NAMES, MotifSolverE, load_graph, random_graph
 from graphminer_amd import CliqueSolver, DeviceGraph, Graph, MotifSolver, SglSolver, TCSolver, _lib
+from graphminer_amd._lib import dev_option
 from graphminer_amd.rmat import csr_from_pairs, rmat_csr_numpy
 
 pytestmark = pytest.mark.gpu
@@ -423,24 +424,24 @@ def test_clique4_wide_vertices_two_phases(dev, n, p):
     assert sum(CliqueSolver(d, 4, rank=r, world=3) for r in range(3)) == got
     assert sum(CliqueSolver(d, 4, rank=r, world=5, policy=1) for r in range(5)) == got
     assert CliqueSolver(d, 4, tune=[0, 0, 1, 1, 0, 0]) == got  # another direction rule: pass Y on the wide rows too
-    os.environ["GM_WIDE_ARENA_MB"] = "4"  # 4 MiB arena: plans are cached per (rank, world, policy), so use a fresh share
+    dev_option("GM_WIDE_ARENA_MB", "4")  # 4 MiB arena: plans are cached per (rank, world, policy), so use a fresh share
     try:
         assert sum(CliqueSolver(d, 4, rank=r, world=2, policy=1) for r in range(2)) == got
     finally:
-        del os.environ["GM_WIDE_ARENA_MB"]
+        dev_option("GM_WIDE_ARENA_MB", None)
 
 
 @pytest.mark.parametrize("name", ["citeseer", "rmat12_ef8_s7", "rmat14_ef16_s42"])
-def test_big_handle_paths_on_small_graphs(dev, name, monkeypatch):
+def test_big_handle_paths_on_small_graphs(dev, name, devopt):
     """A graph of >= 2^31 entries gets a BIG handle (64-bit offsets: upload, orientation, download, the formula 3-motif; every solver
     that walks the graph itself refuses it). GM_BIG_NE=1 forces that handle for a small graph: the 64-bit orientation kernels must
     produce the DAG of the 32-bit ones bit for bit, and the counts the goldens."""
     g = load_graph(name)
     ref = g.to_device(dev)
     ref_dag = ref.orient().download()
-    monkeypatch.setenv("GM_BIG_NE", "1")
+    devopt("GM_BIG_NE", "1")
     big = g.to_device(dev)
-    monkeypatch.delenv("GM_BIG_NE")
+    devopt("GM_BIG_NE", None)
     back = big.download()
     assert np.array_equal(back.row_ptr, g.row_ptr) and np.array_equal(back.col_idx, g.col_idx)
     dag = big.orient()
@@ -459,11 +460,11 @@ def test_big_handle_paths_on_small_graphs(dev, name, monkeypatch):
 
 
 @pytest.mark.parametrize("name", GRAPH_NAMES)
-def test_dag_patterns_on_the_topological_view(dev, name, monkeypatch):
+def test_dag_patterns_on_the_topological_view(dev, name, devopt):
     """TC / k-clique / the formula 3-motif on the topologically renumbered copy of the DAG (get_relabeled mode 2: trimmed in-edge tasks,
     upper-triangular matrices). The library takes that view only where rows are long (sum d+^2 / |E+| >= 64: none of the small golden
     graphs); GM_TOPO_MIN_ROW=0 forces it. The counts are the goldens; tune[6] & 0x200 runs on the graph as numbered."""
-    monkeypatch.setenv("GM_TOPO_MIN_ROW", "0")
+    devopt("GM_TOPO_MIN_ROW", "0")
     g = load_graph(name)
     sym = g.to_device(dev)
     dag = sym.orient()
@@ -532,11 +533,11 @@ def test_clique4_planted_wide_rows_against_oracle(dev, perm):
     assert TCSolver(d) == CliqueSolver(d, 3) == O.tc(odag)
     for world, policy in ((3, 0), (4, 1), (2, 2)):
         assert sum(CliqueSolver(d, 4, rank=r, world=world, policy=policy) for r in range(world)) == want, (world, policy)
-    os.environ["GM_WIDE_ARENA_MB"] = "1"  # 1 MiB arena: the narrow chunks and the wide rows need several rounds (fresh share: plans are cached)
+    dev_option("GM_WIDE_ARENA_MB", "1")  # 1 MiB arena: the narrow chunks and the wide rows need several rounds (fresh share: plans are cached)
     try:
         assert sum(CliqueSolver(d, 4, rank=r, world=2, policy=0, chunk=256) for r in range(2)) == want
     finally:
-        del os.environ["GM_WIDE_ARENA_MB"]
+        dev_option("GM_WIDE_ARENA_MB", None)
     d.free()
 
 
@@ -954,7 +955,7 @@ def test_diamond_supports_with_rows_beyond_the_stage(dev):
 
 
 @pytest.mark.gpu
-def test_two_stage_tables_when_forced_on_a_small_graph(dev, monkeypatch):
+def test_two_stage_tables_when_forced_on_a_small_graph(dev, devopt):
     """DAG rows of 1025 .. 2048 entries: a graph with enough of them runs TWO task tables -- hosts with rows <= 1024 on the 1024-entry
     kernel, the others on the 2048-entry one (gm_launch.hip, split_stage).  The rule wants a rank's share of the second table to fill the
     chip twice, which no test-sized graph does: GM_TCT_SPLIT_ALWAYS forces it.  Triangle count, 3-motif (formula) and the diamond from
@@ -965,13 +966,13 @@ def test_two_stage_tables_when_forced_on_a_small_graph(dev, monkeypatch):
     dmax = int(np.diff(odag.row_ptr).max())
     assert 1024 < dmax <= 2048
     want_tc, want_dia = O.tc(odag), O.diamond(osym)
-    monkeypatch.setenv("GM_TCT_SPLIT_ALWAYS", "1")
+    devopt("GM_TCT_SPLIT_ALWAYS", "1")
     with g.to_device(dev) as s:
         d = s.orient()
         assert TCSolver(d) == want_tc
         assert sum(TCSolver(d, rank=r, world=3) for r in range(3)) == want_tc
         assert SglSolver(s, "diamond") == want_dia
-    monkeypatch.delenv("GM_TCT_SPLIT_ALWAYS")
+    devopt("GM_TCT_SPLIT_ALWAYS", None)
     with g.to_device(dev) as s:
         d = s.orient()
         assert TCSolver(d) == want_tc
@@ -979,7 +980,7 @@ def test_two_stage_tables_when_forced_on_a_small_graph(dev, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_key_stream_with_a_smaller_list_limit_and_without(dev, monkeypatch):
+def test_key_stream_with_a_smaller_list_limit_and_without(dev, devopt):
     """the key stream of the triangle count is indexed with 32 bits: when the keys of all lists of <= 32 entries do not fit, the limit of
     a "short" list is halved until they do, and below 4 the handle goes without a stream (full task lists).  GM_KST_MAX_KEYS lowers
     the bound so that a test-sized graph takes both exits: same count as the oracle either way, and as rank shares."""
@@ -990,16 +991,16 @@ def test_key_stream_with_a_smaller_list_limit_and_without(dev, monkeypatch):
         assert TCSolver(s.orient()) == want
     ne_dag = int(O.orient(osym).row_ptr[-1])  # (the keys of the short lists are a small multiple of the DAG's entries)
     for limit in (2 * ne_dag, ne_dag // 2, 16):  # the limit halved once or twice, more often, and no stream at all
-        monkeypatch.setenv("GM_KST_MAX_KEYS", str(max(limit, 1)))
+        devopt("GM_KST_MAX_KEYS", str(max(limit, 1)))
         with g.to_device(dev) as s:
             d = s.orient()
             assert TCSolver(d) == want
             assert sum(TCSolver(d, rank=r, world=2) for r in range(2)) == want
-    monkeypatch.delenv("GM_KST_MAX_KEYS")
+    devopt("GM_KST_MAX_KEYS", None)
 
 
 @pytest.mark.gpu
-def test_edge_supports_from_the_key_stream(dev, monkeypatch):
+def test_edge_supports_from_the_key_stream(dev, devopt):
     """the edge supports read the short lists from the key stream (with the entries of the streamed key and of the task's own edge beside
     it) where matches are rare; GM_SUP_STREAM forces either path on a graph with many triangles per edge: diamond against the oracle and
     the per-edge kernels, after a triangle count built the stream without the entries (second set) and before one, and as rank shares."""
@@ -1011,7 +1012,7 @@ def test_edge_supports_from_the_key_stream(dev, monkeypatch):
     osym = O.OGraph(g.row_ptr, g.col_idx)
     want, want_tc = O.diamond(osym), O.tc(O.orient(osym))
     for stream in ("1", "0"):
-        monkeypatch.setenv("GM_SUP_STREAM", stream)
+        devopt("GM_SUP_STREAM", stream)
         with g.to_device(dev) as s:
             assert SglSolver(s, "diamond") == want                   # the stream built WITH the entries (or the task lists)
             assert TCSolver(s.orient()) == want_tc
@@ -1026,7 +1027,7 @@ def test_edge_supports_from_the_key_stream(dev, monkeypatch):
             total = torch.stack(bufs).sum(0, dtype=torch.int64).to(torch.int32)
             per = n // world
             assert sum(diamond_support_finish(s, total[r * per:(r + 1) * per].contiguous().data_ptr(), per) for r in range(world)) == want
-    monkeypatch.delenv("GM_SUP_STREAM")
+    devopt("GM_SUP_STREAM", None)
 
 
 def _renumbered_expected(g, keydeg, descending):
@@ -1056,14 +1057,14 @@ def _hub_graph(seed, hub_degs, nv=9000, background=30000):
 
 @pytest.mark.parametrize("path", ["lds", "global_sort"])
 @pytest.mark.parametrize("graph", ["citeseer", "rmat12", "hubs_lds", "hubs_beyond_lds", "hubs_beyond_block"])
-def test_renumbered_copies_are_the_permuted_graph(dev, graph, path, monkeypatch):
+def test_renumbered_copies_are_the_permuted_graph(dev, graph, path, devopt):
     """gm_graph_renumbered (the copies the SgL / TC / k-clique kernels run on): modes 0 / 1 of the symmetric graph, mode 2 of its
     orientation, against a numpy restatement -- for the rows sorted inside the writing kernels (rank among <= 64 entries, bitonic
     network in LDS: a wave up to 1024 entries, a workgroup up to 4096; longer rows through a segmented radix sort of their
     segments) and for the device-wide radix sort of 64-bit entry keys (GM_RELABEL_GLOBAL_SORT=1). Orientation with the kept entries packed in pass 0 against the two-gather passes."""
     if path == "global_sort":
-        monkeypatch.setenv("GM_RELABEL_GLOBAL_SORT", "1")
-        monkeypatch.setenv("GM_ORIENT_TWO_GATHERS", "1")
+        devopt("GM_RELABEL_GLOBAL_SORT", "1")
+        devopt("GM_ORIENT_TWO_GATHERS", "1")
     if graph == "citeseer":
         g = load_graph("citeseer")
     elif graph == "rmat12":
@@ -1094,12 +1095,12 @@ def test_renumbered_copies_are_the_permuted_graph(dev, graph, path, monkeypatch)
 
 
 @pytest.mark.parametrize("two_gathers", [False, True])
-def test_orientation_around_the_byte_cap_of_the_degrees(dev, two_gathers, monkeypatch):
+def test_orientation_around_the_byte_cap_of_the_degrees(dev, two_gathers, devopt):
     """the orientation passes compare degrees capped at 255 in one byte per vertex and read the exact degree only for an entry between
     two vertices of >= 255 neighbours: hubs of 253 .. 257 / 300 neighbours, ties on either side of the cap, every pair of hubs adjacent,
     against the oracle's Graph::orientation (GM_ORIENT_TWO_GATHERS=1: the exact degrees gathered in both passes)"""
     if two_gathers:
-        monkeypatch.setenv("GM_ORIENT_TWO_GATHERS", "1")
+        devopt("GM_ORIENT_TWO_GATHERS", "1")
     degs = [253, 254, 254, 255, 255, 255, 256, 256, 257, 300, 300, 1500]
     nh = len(degs)
     s, d, nxt = [], [], nh

@@ -37,10 +37,10 @@ def _supports(s, dev, world=1):
 
 
 @pytest.mark.parametrize("h", [0, 512, 1024, 4096, 1 << 14])
-def test_diamond_with_every_corner_size_equals_the_oracle(dev, h, monkeypatch):
-    monkeypatch.setenv("GM_TOPO_MIN_ROW", "0")
-    monkeypatch.setenv("GM_SUP_CORE_H", str(h))
-    monkeypatch.setenv("GM_SUP_STREAM", "0")
+def test_diamond_with_every_corner_size_equals_the_oracle(dev, h, devopt):
+    devopt("GM_TOPO_MIN_ROW", "0")
+    devopt("GM_SUP_CORE_H", str(h))
+    devopt("GM_SUP_STREAM", "0")
     g = rmat_csr_numpy(14, 24, seed=3 + h)
     osym = O.OGraph(g.row_ptr, g.col_idx)
     odag = O.orient(osym)
@@ -60,11 +60,11 @@ def test_diamond_with_every_corner_size_equals_the_oracle(dev, h, monkeypatch):
             assert sum(TCSolver(dag, tune=NO_STREAM, rank=r, world=3) for r in range(3)) == want_tc
 
 
-def test_diamond_corner_on_a_dense_block_with_leaves(dev, monkeypatch):
+def test_diamond_corner_on_a_dense_block_with_leaves(dev, devopt):
     """600 hubs, nearly complete among themselves, and leaves that give them strictly ascending degrees: every block of the corner's product
     is nearly full and the diagonal blocks matter (edges i < j only)"""
-    monkeypatch.setenv("GM_TOPO_MIN_ROW", "0")
-    monkeypatch.setenv("GM_SUP_CORE_H", "1024")
+    devopt("GM_TOPO_MIN_ROW", "0")
+    devopt("GM_SUP_CORE_H", "1024")
     rng = np.random.default_rng(5)
     n = 600
     iu, ju = np.triu_indices(n, 1)

@@ -2,7 +2,9 @@
 mask of their tail (plain stores) and sup_cols_kernel sums the masks of a row by column, instead of one memory-side atomic per match.
 Diamond = sum C(t_e, 2) is sensitive to every single support, so equality with the oracle / the atomics path checks the whole array.
 
-GM_SUP_MASK_MIN (the shortest tail that gets a mask) is read once per process: the variants run the CLI binary in a subprocess."""
+The developer option GM_SUP_MASK_MIN (the shortest tail that gets a mask) is read when a handle's masks are laid out: the variants run
+on fresh handles, and through the CLI binary (`--dev NAME=VALUE`)."""
+import ctypes as C
 import os
 import re
 import subprocess
@@ -12,7 +14,7 @@ import pytest
 
 import oracle as O
 from common import ROOT
-from graphminer_amd import SglSolver, TCSolver
+from graphminer_amd import SglSolver, TCSolver, _lib
 from graphminer_amd.rmat import csr_from_pairs, rmat_csr_numpy
 
 pytestmark = pytest.mark.gpu
@@ -28,17 +30,19 @@ def dev():
     return 0
 
 
-def cli_diamond(prefix, **env):
+def cli_diamond(prefix, **opts):
+    """sgl_gpu_base <graph> diamond with developer options handed over as `--dev NAME=VALUE` (the apps read nothing from the environment)"""
     exe = os.path.join(ROOT, "graphminer_amd", "bin", "sgl_gpu_base")
-    r = subprocess.run([exe, prefix, "diamond"], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+    dev = [a for k, v in opts.items() for a in ("--dev", f"{k}={v}")]
+    r = subprocess.run([exe, prefix, "diamond", *dev], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     return int(re.search(r"total_num = (\d+)", r.stdout).group(1))
 
 
 @pytest.mark.parametrize("scale,ef,seed", [(12, 24, 9), (14, 16, 42), (13, 64, 5)])
-def test_masks_equal_atomics_and_oracle_on_rmat(dev, scale, ef, seed, monkeypatch, tmp_path):
+def test_masks_equal_atomics_and_oracle_on_rmat(dev, scale, ef, seed, devopt, tmp_path):
     """dense R-MAT graphs (tails of every length up to several hundred keys: the flattened pass AND the long lists), task-list path forced"""
-    monkeypatch.setenv("GM_SUP_STREAM", "0")
+    devopt("GM_SUP_STREAM", "0")
     g = rmat_csr_numpy(scale, ef, seed=seed)
     osym = O.OGraph(g.row_ptr, g.col_idx)
     want = O.diamond(osym)
@@ -58,6 +62,13 @@ def test_masks_equal_atomics_and_oracle_on_rmat(dev, scale, ef, seed, monkeypatc
     g.save(str(tmp_path / "graph"))
     for lmin in ("1", "7", "192", "5000"):
         assert cli_diamond(str(tmp_path / "graph"), GM_SUP_MASK_MIN=lmin, GM_SUP_STREAM="0") == want, lmin
+        devopt("GM_SUP_MASK_MIN", lmin)  # (read when a handle's masks are laid out: a fresh handle per value)
+        with g.to_device(dev) as s:
+            got = SglSolver(s, "diamond")
+            info = (C.c_int64 * 4)()
+            _lib.check(_lib.load().gm_diamond_support_info(s.handle, info), "gm_diamond_support_info")
+            assert got == want and info[3] == int(lmin), (lmin, got, list(info))
+    devopt("GM_SUP_MASK_MIN", None)
     assert cli_diamond(str(tmp_path / "graph"), GM_SUP_NO_MASKS="1", GM_SUP_STREAM="0") == want
 
 
@@ -79,10 +90,10 @@ def _clique_with_leaves(n, p, seed, base=0):
 
 
 @pytest.mark.parametrize("n,p", [(40, 0.9), (200, 0.5), (700, 0.3), (1100, 0.25), (2048, 0.1)])
-def test_masks_on_planted_dense_blocks(dev, n, p, monkeypatch):
+def test_masks_on_planted_dense_blocks(dev, n, p, devopt):
     """one dense block of n hubs: DAG rows up to n - 1 entries (both stages, rows of exactly 2048 entries included), tails of every
     length, in-edge and out-edge tasks mixed by the host rule"""
-    monkeypatch.setenv("GM_SUP_STREAM", "0")
+    devopt("GM_SUP_STREAM", "0")
     s, d, nv = _clique_with_leaves(n + (1 if n == 2048 else 0), p, seed=n)
     g = csr_from_pairs(nv, s, d)
     osym = O.OGraph(g.row_ptr, g.col_idx)
@@ -93,10 +104,10 @@ def test_masks_on_planted_dense_blocks(dev, n, p, monkeypatch):
         assert SglSolver(sym, "diamond", tune=[0, 0, 0, 0, 0, 0, 0x800000]) == want
 
 
-def test_masks_with_surplus_list_matches(dev, monkeypatch):
+def test_masks_with_surplus_list_matches(dev, devopt):
     """ids that collide in the hashed position set (inverse of the hash multiplier): the bucket overflows, keys are found through the
     surplus list (hit1) -- their bits join the masks of the tasks that found them"""
-    monkeypatch.setenv("GM_SUP_STREAM", "0")
+    devopt("GM_SUP_STREAM", "0")
     inv = pow(0x9E3779B1, -1, 1 << 32)
     # ids whose hash has the same top bits: x = inv * (b << 22 | j) mod 2^32, kept below 2^22
     cand = [(inv * ((5 << 22) | j)) & 0xFFFFFFFF for j in range(1, 1 << 16)]

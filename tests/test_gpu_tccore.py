@@ -41,9 +41,9 @@ def _run(g, dev, want, h_expected=None, worlds=(2, 3)):
 
 
 @pytest.mark.parametrize("h", [0, 64, 100, 256, 1000, 1024, 4096, 1 << 14])
-def test_every_corner_size_counts_the_oracle_triangles(dev, h, monkeypatch):
-    monkeypatch.setenv("GM_TOPO_MIN_ROW", "0")  # renumber whatever the mean row
-    monkeypatch.setenv("GM_TC_CORE_H", str(h))
+def test_every_corner_size_counts_the_oracle_triangles(dev, h, devopt):
+    devopt("GM_TOPO_MIN_ROW", "0")  # renumber whatever the mean row
+    devopt("GM_TC_CORE_H", str(h))
     g = rmat_csr_numpy(14, 24, seed=11 + h)
     osym = O.OGraph(g.row_ptr, g.col_idx)
     want = O.tc(O.orient(osym))
@@ -57,10 +57,10 @@ def test_every_corner_size_counts_the_oracle_triangles(dev, h, monkeypatch):
 
 
 @pytest.mark.parametrize("nv_odd", [777, 2050, 5001])
-def test_corner_of_a_graph_whose_size_is_no_multiple_of_anything(dev, nv_odd, monkeypatch):
+def test_corner_of_a_graph_whose_size_is_no_multiple_of_anything(dev, nv_odd, devopt):
     """core bitmap rows of an odd number of words, the whole graph inside the corner (H >= nv)"""
-    monkeypatch.setenv("GM_TOPO_MIN_ROW", "0")
-    monkeypatch.setenv("GM_TC_CORE_H", "32768")
+    devopt("GM_TOPO_MIN_ROW", "0")
+    devopt("GM_TC_CORE_H", "32768")
     rng = np.random.default_rng(nv_odd)
     m = nv_odd * 40
     s = rng.integers(0, nv_odd, m).astype(np.uint64)
@@ -72,10 +72,10 @@ def test_corner_of_a_graph_whose_size_is_no_multiple_of_anything(dev, nv_odd, mo
     assert info["h"] > 0
 
 
-def test_complete_graph_inside_the_corner(dev, monkeypatch):
+def test_complete_graph_inside_the_corner(dev, devopt):
     """K_n: every block of the product is full -- C(n, 3)"""
-    monkeypatch.setenv("GM_TOPO_MIN_ROW", "0")
-    monkeypatch.setenv("GM_TC_CORE_H", "512")
+    devopt("GM_TOPO_MIN_ROW", "0")
+    devopt("GM_TC_CORE_H", "512")
     n = 512
     iu, ju = np.triu_indices(n, 1)
     g = csr_from_pairs(n, iu.astype(np.uint64), ju.astype(np.uint64))
@@ -107,17 +107,17 @@ def _dense_random_graph(n, p, seed):
 
 
 @pytest.mark.parametrize("n,p,h", [(2000, 0.9, 1024), (2000, 0.9, 2000), (2300, 0.95, 1024)])
-def test_corner_beside_the_two_stage_tables_and_rows_beyond_the_stage(dev, n, p, h, monkeypatch):
+def test_corner_beside_the_two_stage_tables_and_rows_beyond_the_stage(dev, n, p, h, devopt):
     """dense graphs whose DAG rows reach 1025 .. 2048 entries (two task tables: the 1024- and the 2048-entry kernel, forced on this small
     graph) and, for n = 2300, rows beyond the 2048-entry stage -- there the corner must stay OFF (those rows' out-edges are the chunked
     kernel's / sup_long_kernel's): triangle count against the oracle, diamond against the per-edge kernels (one intersection of the symmetric
     lists per edge: no corner, no triangle pass; the oracle's diamond takes minutes on these graphs) with a corner forced"""
     from graphminer_amd import SglSolver
 
-    monkeypatch.setenv("GM_TOPO_MIN_ROW", "0")
-    monkeypatch.setenv("GM_TCT_SPLIT_ALWAYS", "1")
-    monkeypatch.setenv("GM_TC_CORE_H", str(h))
-    monkeypatch.setenv("GM_SUP_CORE_H", "1024")
+    devopt("GM_TOPO_MIN_ROW", "0")
+    devopt("GM_TCT_SPLIT_ALWAYS", "1")
+    devopt("GM_TC_CORE_H", str(h))
+    devopt("GM_SUP_CORE_H", "1024")
     g = _dense_random_graph(n, p, n + h)
     osym = O.OGraph(g.row_ptr, g.col_idx)
     odag = O.orient(osym)
