@@ -175,6 +175,358 @@ __global__ __launch_bounds__(kCgWaves *GM_WAVE) void cgather_kernel(const CGathe
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------------
+// The BLOCKED gather (round 6; gm_mine.h CGatherBParams).  cgather_kernel above pulls, for every (vertex u, core neighbour s_i), the 128-byte
+// lines of the 4 KB core row s_i that the columns N+(u) beyond s_i fall into -- ~12 probes per line at the bottom of the core, 53.6 GB for 21 GB
+// of words (profiles/r05/clique4_rmat22ef28_pmc_summary.txt), at the rate of the fabric.  Here the loop nest is turned round: a BLOCK of
+// consecutive core rows (only their words right of the diagonal: 16 rows at the bottom of the core, ~1000 at its top, where most vertices'
+// rows are) sits in LDS, and the UNITS (vertex u, its rows inside the block: ~3 on R-MAT-22 ef 28) listed for the block once per plan are
+// streamed past it.  A unit reads the part of N+(u) beyond its first row -- coalesced, 4 bytes per column, once for all its rows -- and every
+// probe is one ds_read_b32; the bits of eight tiles are collected as above (ballot -> v_writelane into a group register) and the group's
+// sixteen words are stored to the row directly.  A wave keeps THREE units in flight: the record, the row ids and the first eight column tiles of the unit
+// after next are requested before the current one is probed (records: one vector load per sixteen units, extracted with v_readlane -- no scalar-load
+// round trip per unit).
+// Geometry (the A/B builds of profiles/r06/ab_clique4_blocked_gather.txt set these): the kernel is bound by the latency of each wave's own
+// dependent chain (v_readlane -> v_add -> ds_read -> v_bfe -> v_cmp -> v_writelane), not by a unit or by bytes -- at four waves per SIMD (two
+// 8-wave workgroups per CU, 109 registers, two units requested ahead, the next row's LDS reads issued early) it took 10.3 ms whatever the
+// instruction count; EIGHT waves per SIMD (two 16-wave workgroups, 64 registers: one unit ahead, five table dwords ahead, no second set of
+// word registers) 7.5 ms.
+#ifndef CGB_WAVES
+#define CGB_WAVES 16
+#endif
+#ifndef CGB_DEPTH
+#define CGB_DEPTH 1
+#endif
+#ifndef CGB_WPE
+#define CGB_WPE 8
+#endif
+#ifndef CGB_PINGPONG
+#define CGB_PINGPONG 0
+#endif
+#ifndef CGB_HEAD
+#define CGB_HEAD 5
+#endif
+constexpr int kCgbWaves = CGB_WAVES;
+struct alignas(16) CGatherBLds {
+  unsigned img[kCgbWords];
+  int rb4[kCgbMaxRows];  // per row of the block: byte offset of its image row, minus the bytes of its first stored word: + (q >> 5) * 4 = the word of column q
+  unsigned queue_pos;
+  int pad_[3];
+};
+struct CgbUnit {  // (wave-uniform)
+  int d, i0, r;
+  unsigned px, mbase;  // px: start of the vertex's column table
+};
+constexpr int kCgbHead = CGB_HEAD;  // dwords of a unit's table requested ahead: tile pairs T0 .. T0 + 8 (T0 = t0 >> 1) = the first two tile groups
+struct CgbHead {
+  unsigned rowq;           // lane l < min(r, 64): position q of row i0 + l
+  unsigned hd[kCgbHead];
+};
+__device__ __forceinline__ unsigned long long cgb_mask_gt(const int i, const int lo) {  // lanes l of the tile at column lo with lo + l > i
+  const int s = i + 1 - lo;  // first valid lane
+  return s <= 0 ? ~0ull : (s >= 64 ? 0ull : (~0ull << s));
+}
+__device__ __forceinline__ unsigned long long cgb_mask_lt(const int d, const int lo) {  // ... with lo + l < d
+  const int s = d - lo;
+  return s >= 64 ? ~0ull : (s <= 0 ? 0ull : ((1ull << s) - 1ull));
+}
+__device__ __forceinline__ unsigned cgb_lds(const unsigned *img, const int byte_off) {
+  return *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(img) + byte_off);
+}
+// The ballots of N tiles -> lanes 0 .. 2 N - 1 of the group register (constant lanes: no M0), as ONE block of assembly: the wait states
+// between the last v_cmp and the first v_writelane that reads its SGPR pair once (the hazard recogniser does not look inside inline assembly:
+// cg_tile_k), and no s_nop between the v_writelane -- the compiler puts one between any two asm statements.
+#define CGB_WL(K) "v_writelane_b32 %0, %" #K "\n\t"
+template <int N>
+__device__ __forceinline__ unsigned cgb_put(const unsigned long long (&m)[kCgUnroll]) {
+  unsigned grp = 0u;
+#define CGB_M(k) "s"(__builtin_amdgcn_readfirstlane((unsigned)m[k])), "s"(__builtin_amdgcn_readfirstlane((unsigned)(m[k] >> 32)))  /* (folds away on a scalar value; the "s" constraint alone does not force one) */
+  if constexpr (N == 1)
+    asm volatile("s_nop 3\n\tv_writelane_b32 %0, %1, 0\n\tv_writelane_b32 %0, %2, 1" : "+v"(grp) : CGB_M(0));
+  else if constexpr (N == 2)
+    asm volatile("s_nop 3\n\tv_writelane_b32 %0, %1, 0\n\tv_writelane_b32 %0, %2, 1\n\tv_writelane_b32 %0, %3, 2\n\tv_writelane_b32 %0, %4, 3" : "+v"(grp) : CGB_M(0), CGB_M(1));
+  else if constexpr (N == 3)
+    asm volatile("s_nop 3\n\tv_writelane_b32 %0, %1, 0\n\tv_writelane_b32 %0, %2, 1\n\tv_writelane_b32 %0, %3, 2\n\tv_writelane_b32 %0, %4, 3\n\t"
+                 "v_writelane_b32 %0, %5, 4\n\tv_writelane_b32 %0, %6, 5"
+                 : "+v"(grp) : CGB_M(0), CGB_M(1), CGB_M(2));
+  else if constexpr (N == 4)
+    asm volatile("s_nop 3\n\tv_writelane_b32 %0, %1, 0\n\tv_writelane_b32 %0, %2, 1\n\tv_writelane_b32 %0, %3, 2\n\tv_writelane_b32 %0, %4, 3\n\t"
+                 "v_writelane_b32 %0, %5, 4\n\tv_writelane_b32 %0, %6, 5\n\tv_writelane_b32 %0, %7, 6\n\tv_writelane_b32 %0, %8, 7"
+                 : "+v"(grp) : CGB_M(0), CGB_M(1), CGB_M(2), CGB_M(3));
+  else if constexpr (N == 5)
+    asm volatile("s_nop 3\n\tv_writelane_b32 %0, %1, 0\n\tv_writelane_b32 %0, %2, 1\n\tv_writelane_b32 %0, %3, 2\n\tv_writelane_b32 %0, %4, 3\n\t"
+                 "v_writelane_b32 %0, %5, 4\n\tv_writelane_b32 %0, %6, 5\n\tv_writelane_b32 %0, %7, 6\n\tv_writelane_b32 %0, %8, 7\n\t"
+                 "v_writelane_b32 %0, %9, 8\n\tv_writelane_b32 %0, %10, 9"
+                 : "+v"(grp) : CGB_M(0), CGB_M(1), CGB_M(2), CGB_M(3), CGB_M(4));
+  else if constexpr (N == 6)
+    asm volatile("s_nop 3\n\tv_writelane_b32 %0, %1, 0\n\tv_writelane_b32 %0, %2, 1\n\tv_writelane_b32 %0, %3, 2\n\tv_writelane_b32 %0, %4, 3\n\t"
+                 "v_writelane_b32 %0, %5, 4\n\tv_writelane_b32 %0, %6, 5\n\tv_writelane_b32 %0, %7, 6\n\tv_writelane_b32 %0, %8, 7\n\t"
+                 "v_writelane_b32 %0, %9, 8\n\tv_writelane_b32 %0, %10, 9\n\tv_writelane_b32 %0, %11, 10\n\tv_writelane_b32 %0, %12, 11"
+                 : "+v"(grp) : CGB_M(0), CGB_M(1), CGB_M(2), CGB_M(3), CGB_M(4), CGB_M(5));
+  else if constexpr (N == 7)
+    asm volatile("s_nop 3\n\tv_writelane_b32 %0, %1, 0\n\tv_writelane_b32 %0, %2, 1\n\tv_writelane_b32 %0, %3, 2\n\tv_writelane_b32 %0, %4, 3\n\t"
+                 "v_writelane_b32 %0, %5, 4\n\tv_writelane_b32 %0, %6, 5\n\tv_writelane_b32 %0, %7, 6\n\tv_writelane_b32 %0, %8, 7\n\t"
+                 "v_writelane_b32 %0, %9, 8\n\tv_writelane_b32 %0, %10, 9\n\tv_writelane_b32 %0, %11, 10\n\tv_writelane_b32 %0, %12, 11\n\t"
+                 "v_writelane_b32 %0, %13, 12\n\tv_writelane_b32 %0, %14, 13"
+                 : "+v"(grp) : CGB_M(0), CGB_M(1), CGB_M(2), CGB_M(3), CGB_M(4), CGB_M(5), CGB_M(6));
+  else
+    asm volatile("s_nop 3\n\tv_writelane_b32 %0, %1, 0\n\tv_writelane_b32 %0, %2, 1\n\tv_writelane_b32 %0, %3, 2\n\tv_writelane_b32 %0, %4, 3\n\t"
+                 "v_writelane_b32 %0, %5, 4\n\tv_writelane_b32 %0, %6, 5\n\tv_writelane_b32 %0, %7, 6\n\tv_writelane_b32 %0, %8, 7\n\t"
+                 "v_writelane_b32 %0, %9, 8\n\tv_writelane_b32 %0, %10, 9\n\tv_writelane_b32 %0, %11, 10\n\tv_writelane_b32 %0, %12, 11\n\t"
+                 "v_writelane_b32 %0, %13, 12\n\tv_writelane_b32 %0, %14, 13\n\tv_writelane_b32 %0, %15, 14\n\tv_writelane_b32 %0, %16, 15"
+                 : "+v"(grp) : CGB_M(0), CGB_M(1), CGB_M(2), CGB_M(3), CGB_M(4), CGB_M(5), CGB_M(6), CGB_M(7));
+#undef CGB_M
+  return grp;
+}
+#undef CGB_WL
+// the words of N tiles of one row -> their bits in the group register
+template <int N>
+__device__ __forceinline__ unsigned cgb_bits(const unsigned (&w)[kCgUnroll], const int (&inf)[kCgUnroll], const unsigned long long mfirst,
+                                             const unsigned long long mlast) {
+  unsigned long long m[kCgUnroll];
+#pragma unroll
+  for (int k = 0; k < kCgUnroll; ++k) m[k] = 0ull;
+#pragma unroll
+  for (int k = 0; k < N; ++k) m[k] = __ballot(__builtin_amdgcn_ubfe(w[k], (unsigned)inf[k], 1u) != 0u);  // (v_bfe_u32 takes the low five bits of the id)
+  m[0] &= mfirst;
+  m[N - 1] &= mlast;
+  return cgb_put<N>(m);
+}
+template <int N>
+__device__ __forceinline__ void cgb_read(const unsigned *img, const int rb4, const int (&wo)[kCgUnroll], unsigned (&w)[kCgUnroll]) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) w[k] = cgb_lds(img, rb4 + wo[k]);
+}
+// The rows [g, gend) of a unit that share their diagonal tile t0, against ONE group of N column tiles (tb .. tb + N - 1): the LDS reads of the
+// next row are requested before the current row's words are turned into bits, and the group's sixteen words go straight to the row in the
+// arena -- a row's tile groups own disjoint words, so nothing is merged in registers and the COLUMNS of a group are taken once per unit, not
+// once per row.  pr: the five table dwords that hold the group's tiles (tile kk = half (K0 + kk) & 1 of dword (K0 + kk) >> 1; K0 = tb & 1) --
+// only the N tiles the group has are unpacked.  head (tb = t0): mgt = the lanes right of the first row's diagonal in tile t0 (one lane fewer
+// per row), and the words below the diagonal's (zlane: lanes < 2 t0) are written as zeros.  mlt: the lanes of tile N - 1 that are columns of
+// the vertex at all.
+template <int N, int K0>
+__device__ __forceinline__ void cgb_rows(const unsigned *img, const int rb4v, const unsigned (&pr)[5], int g, const int gend, const bool head,
+                                         unsigned long long mgt, const unsigned long long mlt, const __amdgpu_buffer_rsrc_t mrs, int soff, const int stride4,
+                                         const int voff_d, const int voff_z) {
+  int inf[kCgUnroll], wo[kCgUnroll];
+#pragma unroll
+  for (int kk = 0; kk < kCgUnroll; ++kk) {
+    inf[kk] = 0;
+    wo[kk] = 0;
+  }
+#pragma unroll
+  for (int kk = 0; kk < N; ++kk) {
+    const int k = K0 + kk;
+    inf[kk] = (k & 1) ? (int)(pr[k >> 1] >> 16) : (int)(pr[k >> 1] & 0xffffu);
+    wo[kk] = (inf[kk] >> 3) & ~3;
+  }
+  const unsigned long long nh = head ? 0ull : ~0ull;  // (a group that is not the rows' first masks nothing in its first tile)
+  unsigned wa[kCgUnroll], wb[kCgUnroll];
+  // (the stores are buffer stores: the lanes that have no word of the row carry an offset beyond the resource and are dropped -- no EXEC juggling)
+  auto row = [&](const unsigned (&w)[kCgUnroll]) {
+    const unsigned grp = cgb_bits<N>(w, inf, mgt | nh, mlt);  // lanes 0 .. 15: the words wfirst .. wfirst + 15 of the row
+    __builtin_amdgcn_raw_buffer_store_b32(grp, mrs, voff_d, soff, 0);
+    if (head) __builtin_amdgcn_raw_buffer_store_b32(0u, mrs, voff_z, soff, 0);  // (wave-uniform) the words below the diagonal's
+    soff += stride4;
+    mgt <<= 1;
+  };
+#if CGB_PINGPONG
+  cgb_read<N>(img, readlane(rb4v, g & (GM_WAVE - 1)), wo, wa);
+  for (;;) {
+    if (g + 1 < gend) cgb_read<N>(img, readlane(rb4v, (g + 1) & (GM_WAVE - 1)), wo, wb);  // (wave-uniform)
+    row(wa);
+    if (++g >= gend) break;
+    if (g + 1 < gend) cgb_read<N>(img, readlane(rb4v, (g + 1) & (GM_WAVE - 1)), wo, wa);
+    row(wb);
+    if (++g >= gend) break;
+  }
+#else
+  (void)wb;
+  for (; g < gend; ++g) {
+    cgb_read<N>(img, readlane(rb4v, g & (GM_WAVE - 1)), wo, wa);
+    row(wa);
+  }
+#endif
+}
+template <int K0>
+__device__ __forceinline__ void cgb_rows_n(const int nt, const unsigned *img, const int rb4v, const unsigned (&pr)[5], const int g, const int gend, const bool head,
+                                           const unsigned long long mgt, const unsigned long long mlt, const __amdgpu_buffer_rsrc_t mrs, const int soff,
+                                           const int stride4, const int voff_d, const int voff_z) {
+  switch (nt) {  // (wave-uniform)
+    case 1: cgb_rows<1, K0>(img, rb4v, pr, g, gend, head, mgt, mlt, mrs, soff, stride4, voff_d, voff_z); break;
+    case 2: cgb_rows<2, K0>(img, rb4v, pr, g, gend, head, mgt, mlt, mrs, soff, stride4, voff_d, voff_z); break;
+    case 3: cgb_rows<3, K0>(img, rb4v, pr, g, gend, head, mgt, mlt, mrs, soff, stride4, voff_d, voff_z); break;
+    case 4: cgb_rows<4, K0>(img, rb4v, pr, g, gend, head, mgt, mlt, mrs, soff, stride4, voff_d, voff_z); break;
+    case 5: cgb_rows<5, K0>(img, rb4v, pr, g, gend, head, mgt, mlt, mrs, soff, stride4, voff_d, voff_z); break;
+    case 6: cgb_rows<6, K0>(img, rb4v, pr, g, gend, head, mgt, mlt, mrs, soff, stride4, voff_d, voff_z); break;
+    case 7: cgb_rows<7, K0>(img, rb4v, pr, g, gend, head, mgt, mlt, mrs, soff, stride4, voff_d, voff_z); break;
+    default: cgb_rows<8, K0>(img, rb4v, pr, g, gend, head, mgt, mlt, mrs, soff, stride4, voff_d, voff_z); break;
+  }
+}
+
+// (two workgroups of eight waves per CU -- the block images take 68 KB each -- are four waves per SIMD: 128 registers)
+__global__ __launch_bounds__(kCgbWaves *GM_WAVE) __attribute__((amdgpu_waves_per_eu(CGB_WPE, CGB_WPE))) void cgatherb_kernel(const CGatherBParams p) {
+  __shared__ CGatherBLds S;
+  constexpr int NT = kCgbWaves * GM_WAVE;
+  const int tid = threadIdx.x, lane = tid & (GM_WAVE - 1), wave = readfirst(tid >> 6);
+  int cur_block = -1, q0 = 0;  // q0: position q of the block's first row
+  for (;;) {
+    if (tid == 0) S.queue_pos = atomicAdd(p.queue, 1u);
+    __syncthreads();
+    const unsigned q = S.queue_pos;
+    if (q >= (unsigned)p.count) break;
+    const int2 it = p.items[q];
+    const int uend = p.items[q + 1].x;
+    if (it.y != cur_block) {  // (the waves left the previous image at the barrier that ends an item)
+      const int4 b = p.blk[it.y];
+      const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(p.tri + b.z);
+      uint4 *dst = reinterpret_cast<uint4 *>(S.img);
+      for (int i = tid; i < (b.w + 3) >> 2; i += NT) dst[i] = src[i];
+      for (int i = tid; i < b.y; i += NT) S.rb4[i] = p.rowbase[b.x + i] << 2;
+      cur_block = it.y;
+      q0 = p.delta + b.x;
+      __syncthreads();
+    }
+    // units it.x + wave, + kCgbWaves, ...: their records sixteen at a time -- lane l holds dword l & 3 of the record of unit k + kCgbWaves * (l >> 2)
+    int k = it.x + wave;
+    unsigned recv = 0u;
+    int rec_k0 = k;  // the unit whose record sits in lanes 0 .. 3
+    auto load_recs = [&](const int kf) {
+      const long long idx = (long long)kf + (long long)kCgbWaves * (lane >> 2);
+      recv = idx < uend ? reinterpret_cast<const unsigned *>(p.units)[idx * 4 + (lane & 3)] : 0u;
+      rec_k0 = kf;
+    };
+    auto unit_of = [&](const int kk) {
+      const int l = ((kk - rec_k0) / kCgbWaves) << 2;
+      CgbUnit u;
+      u.px = (unsigned)readlane((int)recv, l);
+      u.mbase = (unsigned)readlane((int)recv, l + 1);
+      const unsigned z = (unsigned)readlane((int)recv, l + 2);
+      u.d = (int)(z & 0xffffu);
+      u.i0 = (int)(z >> 16);
+      u.r = readlane((int)recv, l + 3);
+      return u;
+    };
+    // dword `pair * 64 + lane` of the vertex's table (pairs beyond the last one: the last one again -- their tiles are masked)
+    auto tab_at = [&](const CgbUnit &u, const int pair) {
+      const int npairs = (((u.d + GM_WAVE - 1) >> 6) + 1) >> 1;
+      return p.tab[(size_t)u.px + (size_t)(unsigned)((min(pair, npairs - 1) << 6) + lane)];
+    };
+    // position q of column j (per lane)
+    auto q_at = [&](const CgbUnit &u, const int j) {
+      const int jj = min(j, u.d - 1);
+      const unsigned dw = p.tab[(size_t)u.px + (size_t)(unsigned)(((jj >> 7) << 6) + (jj & (GM_WAVE - 1)))];
+      return (jj & GM_WAVE) ? dw >> 16 : dw & 0xffffu;
+    };
+    auto issue = [&](const CgbUnit &u, CgbHead &h) {
+      h.rowq = q_at(u, u.i0 + lane);
+      // nine dwords at ONE 32-bit byte offset from the table's (scalar) base + immediates: no clamp -- the table buffer has the slack, and what
+      // lies beyond the vertex's last pair belongs to tiles it does not have
+      const char *tb = reinterpret_cast<const char *>(p.tab);
+      const unsigned off = (u.px + (unsigned)((((u.i0 + 1) >> 7) << 6) + lane)) << 2;
+#pragma unroll
+      for (int kk = 0; kk < kCgbHead; ++kk) h.hd[kk] = *reinterpret_cast<const unsigned *>(tb + off + (unsigned)(kk << 8));
+    };
+    auto finish = [&](const CgbUnit &u, const CgbHead &h) {
+      const int stride = (u.d + 31) >> 5, ntiles = (u.d + GM_WAVE - 1) >> 6;
+      // the vertex's matrix as a buffer resource: a row is `soffset`, a lane's word `voffset` -- and a lane that has no word to store carries
+      // kDrop, beyond the resource's range: dropped by the range check, no EXEC mask to set and restore around every store
+      const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(p.mat + u.mbase, 0, 0x7fff0000, 0x00020000);
+      constexpr int kDrop = (int)0x80000000u;
+      int rb4v = S.rb4[min(max((int)h.rowq - q0, 0), kCgbMaxRows - 1)];
+      int g = 0;
+      while (g < u.r) {
+        // a chunk: the rows that share their diagonal tile t0 (and this register of row offsets) -- nearly always the whole unit
+        const int i = u.i0 + g, t0 = (i + 1) >> 6;
+        if (g && (g & (GM_WAVE - 1)) == 0)  // (units of more than 64 rows: the top blocks)
+          rb4v = S.rb4[min(max((int)q_at(u, i + lane) - q0, 0), kCgbMaxRows - 1)];
+        const int gend = min(min(u.r, ((t0 + 1) << 6) - 1 - u.i0), (g | (GM_WAVE - 1)) + 1);
+        const int soff = i * stride * 4;  // (< 2048 x 64 x 4)
+        const int voff_z = lane < 2 * t0 ? lane << 2 : kDrop;
+        if (t0 >= ntiles) {  // no column beyond these rows (the last row of a vertex whose d+ is a multiple of 64): zero words, all below 2 t0
+          for (int gg = g, so = soff; gg < gend; ++gg, so += stride * 4) __builtin_amdgcn_raw_buffer_store_b32(0u, mrs, voff_z, so, 0);
+        }
+        int gi = 0;
+        for (int tb = t0; tb < ntiles; tb += kCgUnroll, ++gi) {  // the tile groups of the chunk's rows: eight column tiles = sixteen words each
+          unsigned pr[5];  // the table dwords of the group's tiles: pairs (tb >> 1) .. + 4
+          if (g == 0 && gi == 0) {  // (wave-uniform) out of the registers requested a unit ago
+#pragma unroll
+            for (int x = 0; x < 5; ++x) pr[x] = h.hd[x];
+          } else if (kCgbHead >= 9 && g == 0 && gi == 1) {
+#pragma unroll
+            for (int x = 0; x < 5; ++x) pr[x] = h.hd[kCgbHead >= 9 ? 4 + x : x];
+          } else {  // (rows beyond the head's tiles; a unit whose rows cross a tile)
+#pragma unroll
+            for (int x = 0; x < 5; ++x) pr[x] = tab_at(u, (tb >> 1) + x);
+          }
+          const int nt = min(kCgUnroll, ntiles - tb);
+          const unsigned long long mlt = (tb + nt == ntiles) ? cgb_mask_lt(u.d, (tb + nt - 1) << 6) : ~0ull;
+          const int voff_d = lane < min(2 * kCgUnroll, stride - 2 * tb) ? (2 * tb + lane) << 2 : kDrop;
+          const bool head = tb == t0;
+          if (tb & 1) cgb_rows_n<1>(nt, S.img, rb4v, pr, g, gend, head, cgb_mask_gt(i, t0 << 6), mlt, mrs, soff, stride * 4, voff_d, voff_z);
+          else cgb_rows_n<0>(nt, S.img, rb4v, pr, g, gend, head, cgb_mask_gt(i, t0 << 6), mlt, mrs, soff, stride * 4, voff_d, voff_z);
+        }
+        g = gend;
+      }
+    };
+#if CGB_DEPTH == 2
+    CgbUnit ucur, unxt, unn;
+    CgbHead hcur, hnxt, hnn;
+    if (k < uend) {
+      load_recs(k);
+      ucur = unit_of(k);
+      issue(ucur, hcur);
+      if (k + kCgbWaves < uend) {
+        unxt = unit_of(k + kCgbWaves);
+        issue(unxt, hnxt);
+      }
+    }
+    while (k < uend) {
+      const int k2 = k + 2 * kCgbWaves;
+      if (k2 < uend) {
+        if (k2 - rec_k0 >= 16 * kCgbWaves) load_recs(k2);
+        unn = unit_of(k2);
+        issue(unn, hnn);
+      }
+      finish(ucur, hcur);
+      ucur = unxt;
+      hcur = hnxt;
+      unxt = unn;
+      hnxt = hnn;
+      k += kCgbWaves;
+    }
+#else
+    CgbUnit ucur, unxt;
+    CgbHead hcur, hnxt;
+    if (k < uend) {
+      load_recs(k);
+      ucur = unit_of(k);
+      issue(ucur, hcur);
+    }
+    while (k < uend) {
+      const int k1 = k + kCgbWaves;
+      if (k1 < uend) {
+        if (k1 - rec_k0 >= 16 * kCgbWaves) load_recs(k1);
+        unxt = unit_of(k1);
+        issue(unxt, hnxt);
+      }
+      finish(ucur, hcur);
+      ucur = unxt;
+      hcur = hnxt;
+      k = k1;
+    }
+#endif
+    __syncthreads();  // the image and the queue word are rewritten by the next item
+  }
+}
+hipError_t launch_cgatherb(const CGatherBParams &p, int grid_blocks, hipStream_t stream) {
+  static_assert(kCgUnroll == 8, "cg_merge moves sixteen lanes; cgb_row dispatches one to eight tiles");
+  if (p.tri == nullptr || p.mat == nullptr || p.units == nullptr || p.items == nullptr || p.tab == nullptr) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(cgatherb_kernel, dim3((unsigned)grid_blocks), dim3(kCgbWaves * GM_WAVE), 0, stream, p);
+  return hipGetLastError();
+}
+int cgatherb_per_cu() { return (int)std::min<size_t>(163840 / sizeof(CGatherBLds), 2048 / (kCgbWaves * GM_WAVE)); }
+
 hipError_t launch_cgather(const CGatherParams &p, int grid_blocks, hipStream_t stream) {
   static_assert(kCbMaxDeg <= 2048, "a row is at most 64 words: one per lane");
   if (p.core == nullptr || p.mat == nullptr || p.core_bytes == 0 || p.core_bytes > 0xffffffffull) return hipErrorInvalidValue;

@@ -223,6 +223,8 @@ extern "C" void gm_graph_free(gm_graph *g) {
   if (g->d_counters) (void)hipFree(g->d_counters);
   if (g->d_scratch) (void)hipFree(g->d_scratch);
   if (g->d_core) (void)hipFree(g->d_core);
+  for (void *q : {(void *)g->d_cg_tri, (void *)g->d_cg_rowbase, (void *)g->d_cg_bid, (void *)g->d_cg_blk})
+    if (q) (void)hipFree(q);
   if (g->d_csym) (void)hipFree(g->d_csym);
   if (g->d_cfirst) (void)hipFree(g->d_cfirst);
   if (g->d_idx0) (void)hipFree(g->d_idx0);

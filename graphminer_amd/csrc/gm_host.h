@@ -226,6 +226,12 @@ struct CliqueRound {
   size_t n_tasks = 0;
   int *d_trp = nullptr;                     // task-list offsets per host vertex (nv + 1)
   ChunkTable host_tab;                      // chunks of host vertices (rows that fit the stage), costs from the task lists
+  // the blocked gather of the wide rows (gm_cgather.hip cgatherb_kernel): the (vertex, block of core rows) units of this round's wide
+  // slots sorted by block, cut into work items of about equal probe counts
+  uint4 *d_gunits = nullptr;
+  unsigned *d_gtab = nullptr;              // the column tables of the round's slots (16-bit positions, two tiles per dword)
+  int2 *d_gitems = nullptr;
+  size_t n_gunits = 0, n_gitems = 0;
 };
 struct CliquePlan {
   int rank = 0, world = 1, policy = 0, target = 0, order_which = 1;
@@ -363,6 +369,13 @@ struct gm_graph {
   unsigned *d_core = nullptr;
   int core_h = 0, core_base = 0;       // core_h = 0: not built / not applicable (ensure_core_bitmap)
   int core_state = 0;                  // 0 unknown, 1 built, 2 not applicable
+  // ... and the same bits cut into BLOCKS of consecutive rows for the blocked gather (gm_cgather.hip cgatherb_kernel; ensure_core_tri)
+  unsigned *d_cg_tri = nullptr;        // block images: of every core row the words from its diagonal word on
+  int *d_cg_rowbase = nullptr;         // per core row: offset inside its block's image - first stored word
+  int *d_cg_bid = nullptr;             // per core row: its block
+  int4 *d_cg_blk = nullptr;            // per block: {first row, rows, image offset, image words}
+  int n_cg_blocks = 0;
+  int cg_tri_state = 0;                // 0 unknown, 1 built, 2 not applicable (no core bitmap, no room)
   // triangle count: the out-edges of the last tc_core_h vertices are counted on the matrix cores from the corner of d_core (gm_ctc.hip) and
   // the key stream / the longer lists of this handle hold no task of a row >= kst_skip_from (ensure_keystream); 0 / nv: no such corner
   int tc_core_h = 0;
@@ -509,6 +522,7 @@ int get_relabeled(gm_graph *g, int mode, gm_graph **out);  // gm_graph.hip: cach
 int graph_is_topological(gm_graph *g, bool *out);
 int graph_rows_sorted(gm_graph *g, bool *out);
 int ensure_long_rows(gm_graph *g);  // (gm_tables.hip) d_long_rows / d_long_prefix: the rows of more than kTctStageMax entries
+int ensure_core_tri(gm_graph *g);     // (gm_tables.hip) d_cg_* of a handle with a core bitmap; GM_OK also when not applicable
 int ensure_core_bitmap(gm_graph *g);  // (gm_tables.hip) d_core / core_h / core_base of a topologically numbered DAG; GM_OK also when not applicable
 void free_tables(gm_graph *g);                                   // gm_tables.hip
 int get_table(gm_graph *g, int target, bool allow_split, int bit_words, unsigned long long part_cap, int stage_cap, ChunkTable **out,

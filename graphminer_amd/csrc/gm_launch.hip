@@ -576,7 +576,26 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
     for (const auto &rd : plan->rounds) {
       if (qword + 9 > 16384) return GM_ERR_TOO_LARGE;  // (more than ~3000 arena rounds)
       bool gather_joined = false;
-      if (plan->core_base >= 0 && rd.w1 > rd.w0) {  // the rows of the wide vertices whose first endpoint lies in the hub core: gathered (gm_cgather.hip)
+      // the rows of the wide vertices whose first endpoint lies in the hub core: gathered (gm_cgather.hip) -- by blocks of core rows resident in
+      // LDS where the plan lists the round's (vertex, block) units (round 6), row by row from the bitmap otherwise (tune[6] & 0x8000000: on request)
+      const bool blocked = plan->core_base >= 0 && rd.w1 > rd.w0 && rd.d_gunits != nullptr && rd.n_gitems > 0 && !(la->tune[6] & 0x8000000);
+      if (blocked) {
+        CGatherBParams cb;
+        memset(&cb, 0, sizeof cb);
+        cb.mat = g->d_wide_mat;
+        cb.tri = g->d_cg_tri;
+        cb.rowbase = g->d_cg_rowbase;
+        cb.blk = g->d_cg_blk;
+        cb.tab = rd.d_gtab;
+        cb.units = rd.d_gunits;
+        cb.items = rd.d_gitems;
+        cb.delta = g->core_base & 31;
+        cb.count = (int)rd.n_gitems;
+        cb.queue = g->d_wide_queue + qword++;
+        const int ggrid = (int)std::max<long long>(1, std::min<long long>(cb.count, (long long)g->cu_count * cgatherb_per_cu()));
+        HIP_TRY(launch_cgatherb(cb, ggrid, stream));
+        setup_trace("launch: core gather (blocked)");
+      } else if (plan->core_base >= 0 && rd.w1 > rd.w0) {
         CGatherParams cg;
         memset(&cg, 0, sizeof cg);
         cg.rp = g->d_rp;

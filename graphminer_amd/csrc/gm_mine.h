@@ -330,6 +330,33 @@ struct CGatherParams {
 hipError_t launch_cgather(const CGatherParams &p, int grid_blocks, hipStream_t stream);
 int cgather_per_cu();
 
+// ---- k-clique (k = 4), first level of the wide vertices, BLOCKED gather (gm_cgather.hip, round 6) -------------------------------------
+// The same rows as launch_cgather, the loop nest turned round: a BLOCK of consecutive core rows -- as many as fit kCgbWords words of LDS,
+// a row keeping only its words right of the diagonal, so a block is 16 rows at the bottom of the core and ~1000 at its top -- is resident in
+// LDS, and the (vertex, rows of the vertex inside the block) UNITS listed for it once per plan are streamed past it: a unit reads its
+// vertex's column table (2 bytes per column, coalesced, once for all its rows in the block) instead of 128-byte lines of 4 KB core rows for a
+// few probes each.  R-MAT-22 ef 28 (scripts/exp/cgather_blocks.py): 51.7 M rows = 16.5 G probes pull 46 GB of lines; 17.2 M units read ~12 GB.
+constexpr int kCgbWords = 16384;   // LDS words of a block image (64 KB: two workgroups per CU)
+constexpr int kCgbMaxRows = 1024;  // rows of a block (their LDS offsets: 4 KB)
+struct CGatherBParams {
+  unsigned *mat;          // matrix arena of the round
+  const unsigned *tri;    // the block images one after the other: of every core row the words from its diagonal word on (gm_host.h d_cg_tri)
+  const int *rowbase;     // per core row: (word offset of the row inside its block's image) - (index of its first stored word)
+  const int4 *blk;        // per block: {first core row, rows, image offset in tri (words, a multiple of 4), image words}
+  const unsigned *tab;    // column tables: per vertex, dword 64 T + l = q(128 T + l) | q(128 T + 64 + l) << 16, q = id - (core_base & ~31)
+  const uint4 *units;     // {start of the vertex's column table, word offset of its matrix in mat, d | first row index << 16, rows}; by block
+  const int2 *items;      // work items: {first unit, block}; items[count].x = number of units
+  int delta, count;       // delta = core_base & 31
+  unsigned *queue;        // dequeue head (zeroed before launch)
+};
+hipError_t launch_cgatherb(const CGatherBParams &p, int grid_blocks, hipStream_t stream);
+int cgatherb_per_cu();
+// (host side of the block geometry, shared by the setup and its tests)
+// column bits are counted from the core's base rounded down to a multiple of 32 (delta = core_base & 31 phantom columns in front): the
+// word of a column is then (vertex id >> 5) - (base >> 5) on every graph
+__host__ __device__ inline int cgb_first_word(int p, int delta) { return (p + delta + 1) >> 5; }  // first stored word of core row p: the one that holds column p + 1
+__host__ __device__ inline int cgb_words(int h, int delta) { return (h + delta + 31) >> 5; }       // words of a whole row
+
 // ---- triangle count: the triangles of the hub core on the matrix cores (gm_ctc.hip) ---------------------------------------------------
 // The corner of the core bitmap that holds the out-edges of the LAST h vertices, sum_{i,j} M_ij (M M^T)_ij over 64 x 64 blocks of (i, j):
 // one wave per block, blocks dealt by a dequeue word, t = first + q * step for a rank's share.

@@ -1761,6 +1761,290 @@ int ensure_core_bitmap(gm_graph *g) {
   return GM_OK;
 }
 
+// ---- the core bitmap cut into blocks of rows for the blocked gather (gm_mine.h CGatherBParams; gm_cgather.hip cgatherb_kernel) ----------
+// A block = consecutive core rows whose stored words (row p keeps the words from cgb_first_word(p) on: the columns right of its diagonal)
+// fit kCgbWords, at most kCgbMaxRows of them: 16 rows of 4 KB at the bottom of a 32 K core, ~1000 rows of a few words at its top -- where
+// the rows that most vertices hold are.
+// (bit positions are taken relative to the core's base rounded DOWN to a multiple of 32 -- `delta` = core_base & 31 phantom columns in front --
+// so that the word of a column is (vertex id >> 5) minus a constant whatever the graph's size: the kernel folds the constant into the rows'
+// LDS offsets and never subtracts the base from a column)
+__global__ __launch_bounds__(256) void core_tri_fill_kernel(int nv, int base, long long e0, long long e1, const int *__restrict__ rp, const int *__restrict__ col,
+                                                             const int *__restrict__ bid, const int *__restrict__ rowbase, const int4 *__restrict__ blk,
+                                                             unsigned *__restrict__ tri) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const int base32 = base & ~31;
+  for (long long e = e0 + (long long)blockIdx.x * blockDim.x + threadIdx.x; e < e1; e += stride) {
+    int lo = base, hi = nv - 1;  // the row of entry e
+    while (lo < hi) {
+      const int mid = (int)(((long long)lo + hi + 1) >> 1);
+      if (rp[mid] <= e) lo = mid; else hi = mid - 1;
+    }
+    const int p = lo - base, q = col[e] - base32;  // (topological: col[e] > lo)
+    atomicOr(&tri[(long long)blk[bid[p]].z + rowbase[p] + (q >> 5)], 1u << (q & 31));
+  }
+}
+int ensure_core_tri(gm_graph *g) {
+  if (g->cg_tri_state) return GM_OK;
+  {
+    const int rc = ensure_core_bitmap(g);  // (takes the lock itself)
+    if (rc) return rc;
+  }
+  std::lock_guard<std::mutex> lk(g->mu);
+  if (g->cg_tri_state) return GM_OK;
+  if (g->core_state != 1 || g->core_h < 64) {
+    g->cg_tri_state = 2;
+    return GM_OK;
+  }
+  SetupTimer timer;
+  HIP_TRY(hipSetDevice(g->device));
+  const int h = g->core_h, delta = g->core_base & 31, words = cgb_words(h, delta);
+  std::vector<int> bid((size_t)h), rowbase((size_t)h);
+  std::vector<int4> blk;
+  long long total = 0;
+  {
+    int p0 = 0, used = 0;
+    for (int p = 0; p <= h; ++p) {
+      const int span = p < h ? words - cgb_first_word(p, delta) : 0;
+      if (p == h || used + span > kCgbWords || p - p0 >= kCgbMaxRows) {  // close the block [p0, p)
+        if (p > p0) {
+          blk.push_back(make_int4(p0, p - p0, (int)total, used));
+          total += (used + 3) & ~3;  // (images start at multiples of four words: 16-byte copies)
+        }
+        p0 = p;
+        used = 0;
+        if (p == h) break;
+      }
+      bid[(size_t)p] = (int)blk.size();
+      rowbase[(size_t)p] = used - cgb_first_word(p, delta);
+      used += span;
+    }
+  }
+  if (total >= (1ll << 31) || blk.size() >= 65536) {
+    g->cg_tri_state = 2;
+    return GM_OK;
+  }
+  unsigned *tri = nullptr;
+  int *d_bid = nullptr, *d_rowbase = nullptr;
+  int4 *d_blk = nullptr;
+  int e01[2] = {0, 0};
+  hipError_t e = dev_malloc(&tri, sizeof(unsigned) * (size_t)std::max<long long>(total, 4));
+  if (e == hipSuccess) e = dev_malloc(&d_bid, sizeof(int) * (size_t)h);
+  if (e == hipSuccess) e = dev_malloc(&d_rowbase, sizeof(int) * (size_t)h);
+  if (e == hipSuccess) e = dev_malloc(&d_blk, sizeof(int4) * blk.size());
+  if (e == hipSuccess) e = hipMemsetAsync(tri, 0, sizeof(unsigned) * (size_t)std::max<long long>(total, 4), 0);
+  if (e == hipSuccess) e = copy_to_device(d_bid, bid.data(), sizeof(int) * (size_t)h);
+  if (e == hipSuccess) e = copy_to_device(d_rowbase, rowbase.data(), sizeof(int) * (size_t)h);
+  if (e == hipSuccess) e = copy_to_device(d_blk, blk.data(), sizeof(int4) * blk.size());
+  if (e == hipSuccess) e = hipMemcpy(&e01[0], g->d_rp + g->core_base, sizeof(int), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(&e01[1], g->d_rp + g->nv, sizeof(int), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) {
+    const long long n = (long long)e01[1] - e01[0];
+    if (n > 0)
+      hipLaunchKernelGGL(core_tri_fill_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, (long long)g->cu_count * 32)), dim3(256), 0, 0, g->nv, g->core_base,
+                         (long long)e01[0], (long long)e01[1], g->d_rp, g->d_col, d_bid, d_rowbase, d_blk, tri);
+    e = hipDeviceSynchronize();
+  }
+  if (e != hipSuccess) {  // (no room: the row-major gather does the work)
+    for (void *q : {(void *)tri, (void *)d_bid, (void *)d_rowbase, (void *)d_blk})
+      if (q) (void)hipFree(q);
+    (void)hipGetLastError();
+    g->cg_tri_state = 2;
+    return GM_OK;
+  }
+  g->d_cg_tri = tri;
+  g->d_cg_bid = d_bid;
+  g->d_cg_rowbase = d_rowbase;
+  g->d_cg_blk = d_blk;
+  g->n_cg_blocks = (int)blk.size();
+  g->cg_tri_state = 1;
+  setup_trace("clique: core blocks");
+  g->setup.table_ms += timer.ms();
+  return GM_OK;
+}
+
+__global__ __launch_bounds__(256) void iota_u32_kernel(long long n, unsigned *__restrict__ out) {
+  const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) out[k] = (unsigned)k;
+}
+// The units of a round's wide slots.  One wave per slot walks the core part of the vertex's row: a unit starts where the block of the
+// row's core position changes.  EMIT = false: units per slot;  EMIT = true: the records {start of the vertex's column table, matrix offset, d | first row << 16, rows}
+// + the block as sort key, at the slot's offset.
+template <bool EMIT>
+__global__ __launch_bounds__(256) void cgb_units_kernel(int w0, int nslots, const int *__restrict__ verts, const int *__restrict__ rp, const int *__restrict__ col,
+                                                         const unsigned long long *__restrict__ slot_base, int core_base, const int *__restrict__ bid,
+                                                         int *__restrict__ cnt, const int *__restrict__ uoff, const unsigned *__restrict__ poff,
+                                                         unsigned *__restrict__ keys, uint4 *__restrict__ recs) {
+  const int lane = threadIdx.x & 63;
+  const int s = (int)(((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  if (s >= nslots) return;  // (wave-uniform)
+  const int u = verts[w0 + s];
+  const int ru = rp[u], d = rp[u + 1] - ru;
+  const int k0 = lower_bound(col + ru, d, core_base);
+  int n = 0;
+  const int out0 = EMIT ? uoff[s] : 0;
+  const unsigned mbase = EMIT ? (unsigned)slot_base[w0 + s] : 0u;
+  for (int jb = k0; jb < d; jb += 64) {
+    const int j = jb + lane;
+    const int b = j < d ? bid[col[ru + j] - core_base] : -1;
+    const int bp = (j > k0 && j < d) ? bid[col[ru + j - 1] - core_base] : -2;
+    const bool start = j < d && b != bp;
+    const unsigned long long m = __ballot(start);
+    if (EMIT && start) {
+      // rows of the unit: up to the next start in this tile, else scan ahead (units are short: a few rows)
+      int e = j + 1;
+      while (e < d && bid[col[ru + e] - core_base] == b) ++e;
+      const int k = out0 + n + (int)__popcll(m & ((1ull << lane) - 1ull));
+      keys[k] = (unsigned)b;
+      recs[k] = make_uint4(poff[s], mbase, (unsigned)d | ((unsigned)j << 16), (unsigned)(e - j));
+    }
+    n += (int)__popcll(m);
+  }
+  if (!EMIT && lane == 0) cnt[s] = n;
+}
+// The COLUMN TABLES the blocked gather reads instead of col: per wide slot, the positions of N+(u) as 16-bit numbers q = id - (core_base & ~31)
+// (0: a neighbour below the core, or padding), swizzled so that ONE dword load per lane fetches two column tiles -- dword 64 T + l of a vertex
+// = q(128 T + l) | q(128 T + 64 + l) << 16: half the bytes of col and half the loads.
+__global__ __launch_bounds__(256) void cgb_table_size_kernel(int w0, int nslots, const int *__restrict__ verts, const int *__restrict__ rp, unsigned *__restrict__ sz) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s > nslots) return;
+  unsigned v = 0u;
+  if (s < nslots) {
+    const int u = verts[w0 + s];
+    const int d = rp[u + 1] - rp[u];
+    v = 64u * (unsigned)(((d + 63) / 64 + 1) / 2);
+  }
+  sz[s] = v;
+}
+__global__ __launch_bounds__(256) void cgb_table_fill_kernel(int w0, int nslots, const int *__restrict__ verts, const int *__restrict__ rp, const int *__restrict__ col,
+                                                              int core_base, const unsigned *__restrict__ poff, unsigned *__restrict__ tab) {
+  const int lane = threadIdx.x & 63;
+  const int s = (int)(((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  if (s >= nslots) return;  // (wave-uniform)
+  const int u = verts[w0 + s];
+  const int ru = rp[u], d = rp[u + 1] - ru, base32 = core_base & ~31;
+  unsigned *__restrict__ out = tab + poff[s];
+  const int npairs = ((d + 63) / 64 + 1) / 2;
+  for (int t = 0; t < npairs; ++t) {
+    const int j0 = 128 * t + lane, j1 = j0 + 64;
+    const int c0 = j0 < d ? col[ru + j0] : 0, c1 = j1 < d ? col[ru + j1] : 0;
+    const unsigned q0 = c0 >= core_base ? (unsigned)(c0 - base32) : 0u, q1 = c1 >= core_base ? (unsigned)(c1 - base32) : 0u;
+    out[64 * t + lane] = q0 | (q1 << 16);
+  }
+}
+// sorted order: record k = recs[idx[k]]; its probes = sum over its rows i of (d - 1 - i)
+__global__ __launch_bounds__(256) void cgb_gather_kernel(long long n, const unsigned *__restrict__ idx, const uint4 *__restrict__ recs, uint4 *__restrict__ out,
+                                                          unsigned long long *__restrict__ cost) {
+  const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const uint4 r = recs[idx[k]];
+  out[k] = r;
+  const long long d = r.z & 0xffffu, i0 = r.z >> 16, rows = r.w;
+  cost[k] = (unsigned long long)(rows * (d - 1 - i0) - rows * (rows - 1) / 2 + 64 * rows + 256);  // (+ per row and per unit overheads, in probes)
+}
+__global__ __launch_bounds__(256) void cgb_item_flag_kernel(long long n, const unsigned *__restrict__ keys, const unsigned long long *__restrict__ cum,
+                                                             unsigned long long target, int *__restrict__ flag) {
+  const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  flag[k] = (k == 0 || keys[k] != keys[k - 1] || cum[k] / target != cum[k - 1] / target) ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void cgb_item_place_kernel(long long n, const unsigned *__restrict__ keys, const int *__restrict__ flag, const int *__restrict__ pos,
+                                                              int2 *__restrict__ items, int n_items) {
+  const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k == 0) items[n_items] = make_int2((int)n, -1);
+  if (k >= n) return;
+  if (flag[k]) items[pos[k]] = make_int2((int)k, (int)keys[k]);
+}
+constexpr unsigned long long kCgbItemCost = 1ull << 20;  // probes (+ overheads) of a work item: ~80 us of one workgroup
+static int build_gather_index(gm_graph *g, CliquePlan &pl, CliqueRound &rd, ScanTemp &tmp) {
+  const int nslots = (int)(rd.w1 - rd.w0);
+  if (nslots <= 0 || pl.core_base < 0 || g->cg_tri_state != 1 || rd.words >= (1ull << 32)) return GM_OK;  // (no index: the row-major gather)
+  auto blocks = [](long long n) { return dim3((unsigned)std::max<long long>(1, (n + 255) / 256)); };
+  DevBuf<int> cnt, uoff;
+  HIP_TRY(cnt.alloc((size_t)nslots + 1));
+  HIP_TRY(uoff.alloc((size_t)nslots + 1));
+  HIP_TRY(hipMemsetAsync(cnt.p, 0, sizeof(int) * ((size_t)nslots + 1), 0));
+  const dim3 wgrid((unsigned)(((long long)nslots + 3) / 4));
+  hipLaunchKernelGGL((cgb_units_kernel<false>), wgrid, dim3(256), 0, 0, (int)rd.w0, nslots, pl.d_verts, g->d_rp, g->d_col, pl.d_slot_base, pl.core_base, g->d_cg_bid,
+                     cnt.p, nullptr, nullptr, nullptr, nullptr);
+  HIP_TRY(dev_exclusive_sum(tmp, cnt.p, uoff.p, (size_t)nslots + 1));
+  int nu = 0;
+  HIP_TRY(hipMemcpy(&nu, uoff.p + nslots, sizeof(int), hipMemcpyDeviceToHost));
+  if (nu <= 0) return GM_OK;
+  // the column tables of the round's slots
+  DevBuf<unsigned> tsz, poff;
+  HIP_TRY(tsz.alloc((size_t)nslots + 1));
+  HIP_TRY(poff.alloc((size_t)nslots + 1));
+  hipLaunchKernelGGL(cgb_table_size_kernel, blocks((long long)nslots + 1), dim3(256), 0, 0, (int)rd.w0, nslots, pl.d_verts, g->d_rp, tsz.p);
+  HIP_TRY(dev_exclusive_sum(tmp, tsz.p, poff.p, (size_t)nslots + 1));
+  unsigned tab_words = 0;
+  HIP_TRY(hipMemcpy(&tab_words, poff.p + nslots, sizeof(unsigned), hipMemcpyDeviceToHost));
+  unsigned *tab = nullptr;
+  // (+ nine tile pairs of slack: the kernel requests nine pairs from a unit's first one on without looking at the table's end -- what lies
+  // beyond belongs to tiles the vertex does not have and is never used; byte offsets are 32 bits)
+  if ((unsigned long long)tab_words * 4ull + 4096ull >= (1ull << 32)) return GM_OK;  // (no index: the row-major gather)
+  HIP_TRY(dev_malloc(&tab, sizeof(unsigned) * ((size_t)std::max(tab_words, 64u) + 9 * 64)));
+  hipLaunchKernelGGL(cgb_table_fill_kernel, wgrid, dim3(256), 0, 0, (int)rd.w0, nslots, pl.d_verts, g->d_rp, g->d_col, pl.core_base, poff.p, tab);
+  struct TabGuard {  // (the table belongs to the round once the index is complete)
+    unsigned *p;
+    ~TabGuard() { if (p) (void)hipFree(p); }
+  } tab_guard{tab};
+  DevBuf<unsigned> keys, keys_s, idx, idx_s;
+  DevBuf<uint4> recs;
+  DevBuf<unsigned long long> cost, cum;
+  DevBuf<int> flag, pos;
+  HIP_TRY(keys.alloc((size_t)nu));
+  HIP_TRY(keys_s.alloc((size_t)nu));
+  HIP_TRY(idx.alloc((size_t)nu));
+  HIP_TRY(idx_s.alloc((size_t)nu));
+  HIP_TRY(recs.alloc((size_t)nu));
+  hipLaunchKernelGGL((cgb_units_kernel<true>), wgrid, dim3(256), 0, 0, (int)rd.w0, nslots, pl.d_verts, g->d_rp, g->d_col, pl.d_slot_base, pl.core_base, g->d_cg_bid,
+                     nullptr, uoff.p, poff.p, keys.p, recs.p);
+  hipLaunchKernelGGL(iota_u32_kernel, blocks(nu), dim3(256), 0, 0, (long long)nu, idx.p);
+  {
+    int bits = 1;
+    while ((1 << bits) < g->n_cg_blocks) ++bits;
+    size_t bytes = 0;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, keys.p, keys_s.p, idx.p, idx_s.p, nu, 0, bits));
+    HIP_TRY(tmp.reserve(bytes));
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.buf.p, bytes, keys.p, keys_s.p, idx.p, idx_s.p, nu, 0, bits));  // (stable: a block's units stay in slot order)
+  }
+  uint4 *units = nullptr;
+  HIP_TRY(dev_malloc(&units, sizeof(uint4) * (size_t)nu));
+  hipError_t e = cost.alloc((size_t)nu + 1);
+  if (e == hipSuccess) e = cum.alloc((size_t)nu + 1);
+  if (e == hipSuccess) e = flag.alloc((size_t)nu + 1);
+  if (e == hipSuccess) e = pos.alloc((size_t)nu + 1);
+  int ni = 0;
+  int2 *items = nullptr;
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(cgb_gather_kernel, blocks(nu), dim3(256), 0, 0, (long long)nu, idx_s.p, recs.p, units, cost.p);
+    e = dev_exclusive_sum(tmp, cost.p, cum.p, (size_t)nu);
+  }
+  if (e == hipSuccess) e = hipMemsetAsync(flag.p + nu, 0, sizeof(int), 0);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(cgb_item_flag_kernel, blocks(nu), dim3(256), 0, 0, (long long)nu, keys_s.p, cum.p, kCgbItemCost, flag.p);
+    e = dev_exclusive_sum(tmp, flag.p, pos.p, (size_t)nu + 1);
+  }
+  if (e == hipSuccess) e = hipMemcpy(&ni, pos.p + nu, sizeof(int), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = dev_malloc(&items, sizeof(int2) * ((size_t)ni + 1));
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(cgb_item_place_kernel, blocks(nu), dim3(256), 0, 0, (long long)nu, keys_s.p, flag.p, pos.p, items, ni);
+    e = hipDeviceSynchronize();
+  }
+  if (e != hipSuccess) {
+    (void)hipFree(units);
+    if (items) (void)hipFree(items);
+    return hip_fail(e, "gather index", __FILE__, __LINE__);
+  }
+  rd.d_gunits = units;
+  rd.d_gtab = tab;
+  tab_guard.p = nullptr;
+  rd.d_gitems = items;
+  rd.n_gunits = (size_t)nu;
+  rd.n_gitems = (size_t)ni;
+  return GM_OK;
+}
+
 int clique_wide_min_words() {
   static const int v = [] {
     const char *e = gm_sweep_env("GM_WIDE_MIN_WORDS");  // (sweeps; read once: tables and plans are cached per graph)
@@ -1777,6 +2061,9 @@ static void free_clique_plan(CliquePlan &pl) {
     if (rd.d_base) (void)hipFree(rd.d_base);
     if (rd.d_tasks) (void)hipFree(rd.d_tasks);
     if (rd.d_trp) (void)hipFree(rd.d_trp);
+    if (rd.d_gunits) (void)hipFree(rd.d_gunits);
+    if (rd.d_gtab) (void)hipFree(rd.d_gtab);
+    if (rd.d_gitems) (void)hipFree(rd.d_gitems);
     free_table(rd.host_tab);
   }
   pl.rounds.clear();
@@ -2030,6 +2317,11 @@ int get_clique_plan(gm_graph *g, int rank, int world, int policy, int target, un
   for (size_t r = 0; r < pl.rounds.size(); ++r) {
     const int rc = build_clique_round(g, pl, pl.rounds[r], tmp);
     if (rc) { free_clique_plan(pl); return rc; }
+    if (pl.core_base >= 0) {
+      int rc2 = ensure_core_tri(g);
+      if (rc2 == GM_OK) rc2 = build_gather_index(g, pl, pl.rounds[r], tmp);
+      if (rc2) { free_clique_plan(pl); return rc2; }
+    }
     need_words = std::max(need_words, pl.rounds[r].words);
   }
   setup_trace("clique: rounds built");

@@ -60,6 +60,7 @@ def test_masks_equal_atomics_and_oracle_on_rmat(dev, scale, ef, seed, devopt, tm
         assert TCSolver(s.orient()) == O.tc(odag)
     # the shortest masked tail: 1 (every in-edge task), 7, the default, 192 (only the long lists), 5000 (none)
     g.save(str(tmp_path / "graph"))
+    masked = False
     for lmin in ("1", "7", "192", "5000"):
         assert cli_diamond(str(tmp_path / "graph"), GM_SUP_MASK_MIN=lmin, GM_SUP_STREAM="0") == want, lmin
         devopt("GM_SUP_MASK_MIN", lmin)  # (read when a handle's masks are laid out: a fresh handle per value)
@@ -67,8 +68,12 @@ def test_masks_equal_atomics_and_oracle_on_rmat(dev, scale, ef, seed, devopt, tm
             got = SglSolver(s, "diamond")
             info = (C.c_int64 * 4)()
             _lib.check(_lib.load().gm_diamond_support_info(s.handle, info), "gm_diamond_support_info")
-            assert got == want and info[3] == int(lmin), (lmin, got, list(info))
+            assert got == want, (lmin, got)
+            # (info[0] = 0: no masks on this graph at all -- its oriented copy is not renumbered -- and the option has nothing to shape)
+            assert info[0] == 0 or info[3] == int(lmin), (lmin, list(info))
+            masked = masked or info[0] > 0
     devopt("GM_SUP_MASK_MIN", None)
+    assert masked or (scale, ef) != (13, 64), "the dense graph must run with match masks"
     assert cli_diamond(str(tmp_path / "graph"), GM_SUP_NO_MASKS="1", GM_SUP_STREAM="0") == want
 
 
