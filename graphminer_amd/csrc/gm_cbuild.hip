@@ -19,7 +19,14 @@ namespace gm {
 #ifndef GM_CB_TILES
 #define GM_CB_TILES 4
 #endif
-constexpr int kCbTiles = GM_CB_TILES;  // 64-key tiles in flight per wave
+constexpr int kCbTiles = GM_CB_TILES;  // 64-key tiles in flight per wave (1024-entry stage)
+// The 2048-entry stage (61 KB of set + wave scratch: two workgroups per CU) is bound by the latency of each wave's own chain load -> hash -> bucket ->
+// compare, like the blocked gather (profiles/r06/ab_clique4_blocked_gather.txt): TWELVE waves per workgroup with two tiles in flight (80 registers,
+// six waves per SIMD) instead of eight with four (128 registers, four per SIMD): 22.69 -> 22.16 ms for the whole pattern; sixteen waves at 64
+// registers spill (22.96).  profiles/r06/ab_clique4_cbuild_occupancy.txt
+#ifndef GM_CB_TILES_BIG
+#define GM_CB_TILES_BIG 2
+#endif
 
 template <int STAGE, int WAVES>
 struct alignas(16) CBuildLds {
@@ -33,7 +40,7 @@ struct alignas(16) CBuildLds {
 };
 
 template <int STAGE, int WAVES>
-__global__ __launch_bounds__(WAVES * GM_WAVE)
+__global__ __launch_bounds__(WAVES * GM_WAVE) __attribute__((amdgpu_waves_per_eu(STAGE <= 1024 ? 1 : (WAVES * 2) / 4)))
 void cbuild_kernel(const CBuildParams p) {
   __shared__ CBuildLds<STAGE, WAVES> B;
   using H = HsHash<STAGE>;
@@ -115,7 +122,7 @@ void cbuild_kernel(const CBuildParams p) {
             atomicOr(&rb[bit >> 5], 1u << (bit & 31u));
           }
         };
-        hs_pass<STAGE, kCbTiles>(B.set, L, col, fallback, lane, (in_sub && a > 0) ? Tk.y : 0, Tk.x, H::salt(lo), ru - eb, a, base_l, sel_l, hit, hit1);
+        hs_pass<STAGE, (STAGE <= 1024 ? kCbTiles : GM_CB_TILES_BIG)>(B.set, L, col, fallback, lane, (in_sub && a > 0) ? Tk.y : 0, Tk.x, H::salt(lo), ru - eb, a, base_l, sel_l, hit, hit1);
         wave_sync();
         // store the finished rows (all of them: a row without a match is a row of zeros)
         const int maxw = wave_max_nonneg(in_sub ? words : 0);
@@ -141,7 +148,7 @@ void cbuild_kernel(const CBuildParams p) {
 // workgroups of 4 waves on the 1024-entry stage (32 KB of LDS), of GM_CB_WAVES_BIG on the 2048-entry one
 // (R-MAT-22 ef 28, 4 / 6 / 8 waves: 68.5 / 70.6 / 66.7 ms for the whole pattern)
 #ifndef GM_CB_WAVES_BIG
-#define GM_CB_WAVES_BIG 8
+#define GM_CB_WAVES_BIG 12
 #endif
 constexpr int kCbWavesBig = GM_CB_WAVES_BIG;
 int cbuild_per_cu(int stage) {

@@ -34,6 +34,13 @@
 namespace gm {
 
 constexpr int kSupTiles = 4;
+#ifndef GM_SUP_WAVES
+#define GM_SUP_WAVES 4
+#endif
+// (round 6 tried the blocked gather's recipe here -- 12-wave workgroups, two tiles in flight, 80 registers, six waves per SIMD: diamond R-MAT-22
+// 5.71 against 5.11 ms, R-MAT-24 69.6 against 66.0; four waves with two tiles 5.27: this kernel wants its four tiles in flight more than it wants
+// waves.  profiles/r06/ab_diamond_sup_occupancy.txt)
+constexpr int kSupWaves = GM_SUP_WAVES;  // waves of a sup_kernel workgroup
 #ifndef GM_SUP_TILES_SMALL
 #define GM_SUP_TILES_SMALL 4
 #endif
@@ -47,12 +54,12 @@ template <int STAGE>
 struct alignas(16) SupLds {
   HsTable<STAGE> set;
   int trpl[kMaxChunkVerts + 1];  // row offsets of the chunk's task lists
-  HsWave<STAGE> w[kWavesPerBlock];      // (while the set is built: the fill counters of its buckets)
+  HsWave<STAGE> w[kSupWaves];      // (while the set is built: the fill counters of its buckets)
   // per batch lane: word 0 = the matches of its task -- or, for a task of the flattened pass that reports a match mask, the mask itself
   // (bit k = key k of its tail; its matches are the mask's popcount)
-  unsigned mw[kWavesPerBlock][GM_WAVE][kSupMaskWords];
+  unsigned mw[kSupWaves][GM_WAVE][kSupMaskWords];
   unsigned ecnt[STAGE];                   // per stage entry: matches found at it
-  int hq[kWavesPerBlock][kSupQueue];      // per wave: DAG entries (streamed edges) whose increment is still to be issued
+  int hq[kSupWaves][kSupQueue];      // per wave: DAG entries (streamed edges) whose increment is still to be issued
   int next_batch;
   unsigned queue_pos;
   int next_group;  // key stream of the short lists: the next group of tiles
@@ -60,14 +67,14 @@ struct alignas(16) SupLds {
 };
 
 template <int STAGE, bool MASKS>
-__global__ __launch_bounds__((kWavesPerBlock * GM_WAVE), (STAGE <= 1024 ? 4 : 2))
+__global__ __launch_bounds__((kSupWaves * GM_WAVE), (STAGE <= 1024 ? 4 : 2))
 void sup_kernel(const MineParams p) {
   __shared__ SupLds<STAGE> B;
   using H = HsHash<STAGE>;
   const int lane = threadIdx.x & (GM_WAVE - 1);
   const int wave = threadIdx.x >> 6;
   const int tid = threadIdx.x;
-  constexpr int nthreads = kWavesPerBlock * GM_WAVE;
+  constexpr int nthreads = kSupWaves * GM_WAVE;
   const int *__restrict__ rp = p.g.rp;
   const int *__restrict__ col = p.g.col;
   const int *__restrict__ trp = p.g.trp;
@@ -461,14 +468,16 @@ hipError_t launch_sup_long(const SupLongParams &p, int cu_count, hipStream_t str
   return hipGetLastError();
 }
 
-int sup_per_cu(int stage) { return stage <= 1024 ? 4 : 2; }
+int sup_per_cu(int stage) {
+  const size_t lds = stage <= 1024 ? sizeof(SupLds<1024>) : sizeof(SupLds<kTctStageMax>);
+  return (int)std::max<size_t>(1, std::min<size_t>(163840 / lds, 2048 / (kSupWaves * GM_WAVE)));
+}
 hipError_t launch_sup(const MineParams &p, int stage, int grid_blocks, hipStream_t stream) {
-  static_assert(sizeof(SupLds<1024>) * 4 <= 163840, "four workgroups per CU");
   const bool masks = p.g.tmoff != nullptr && p.smask != nullptr;
-  static_assert(sizeof(SupLds<kTctStageMax>) * 2 <= 163840, "two workgroups per CU");
-  static_assert(sizeof(HsWave<kTctStageMax>) * kWavesPerBlock >= (size_t)kTctStageMax * 2, "fill counters alias the wave scratch");
+  static_assert(sizeof(SupLds<kTctStageMax>) <= 163840, "one workgroup per CU at least");
+  static_assert(sizeof(HsWave<kTctStageMax>) * kSupWaves >= (size_t)kTctStageMax * 2, "fill counters alias the wave scratch");
   if (p.g.trp == nullptr || p.g.tdesc == nullptr || p.g.tedge == nullptr || p.scratch == nullptr) return hipErrorInvalidValue;
-  const dim3 grid((unsigned)grid_blocks), block(kWavesPerBlock * GM_WAVE);
+  const dim3 grid((unsigned)grid_blocks), block(kSupWaves * GM_WAVE);
   if (stage <= 1024 && masks) hipLaunchKernelGGL((sup_kernel<1024, true>), grid, block, 0, stream, p);
   else if (stage <= 1024) hipLaunchKernelGGL((sup_kernel<1024, false>), grid, block, 0, stream, p);
   else if (masks) hipLaunchKernelGGL((sup_kernel<kTctStageMax, true>), grid, block, 0, stream, p);
