@@ -72,7 +72,7 @@ KERNELS = {
     # (gm_motif, k = 3: the triangles of the DAG + wedges = sum C(d,2) - 3T; "motif3e": one bounded intersection per edge of the symmetric graph)
     "motif3": ["tch_kernel", "mine_kernel<0,", "core_tc_"],
     "motif3e": ["mine_kernel<2,", "hrow_kernel<2,", "giant_kernel<2,"],
-    "clique4": ["cgather_kernel", "cbuild_kernel", "clique_mma_kernel", "clique_small_kernel", "mine_kernel<3,"],
+    "clique4": ["cgather_kernel", "cgatherb_kernel", "cbuild_kernel", "clique_mma_kernel", "clique_small_kernel", "mine_kernel<3,"],
     "clique5": ["mine_kernel<4,"],
     "motif3f": ["tch_kernel", "mine_kernel<0,", "core_tc_"],
     "rectangle": ["rect_acc_kernel"],
@@ -80,7 +80,7 @@ KERNELS = {
     "pentagon": ["pent_acc_kernel"],
     # (gm_motif, k = 4: per-edge sums of the symmetric graph + rectangle by wedge accumulation + 4-clique of the oriented copy)
     "motif4": ["mine_kernel<5,", "hrow_kernel<5,", "giant_kernel<5,", "rect_acc_kernel", "mine_kernel<3,", "cbuild_kernel", "cgather_kernel", "clique_mma_kernel",
-               "clique_small_kernel", "tch_kernel", "core_tc_"],
+               "clique_small_kernel", "cgatherb_kernel", "tch_kernel", "core_tc_"],
 }
 CORNER_KERNEL = "core_tc_"  # (the MFMA kernels of gm_ctc.hip: reported beside the whole-launch HBM roofline against the FP4 peak)
 TRAFFIC_MARKER = "issue_calib_kernel"  # the dispatch in front of every workload of the traffic worker (measure_traffic)
@@ -371,11 +371,28 @@ def own_bytes_device(workload, bg, world=1, core_override=None):
             # distinct words among the edges idx + 1 .. row_end: the (row, word) starts in that range, + 1 when edge idx + 1 continues idx's word
             dist = torch.where(has_next, cf[row_end] - cf[nxt] + 1, torch.zeros_like(cf))
             gather_words = int(dist[core_s].sum().item())
+        # round 6: the BLOCKED gather (gm_cgather.hip cgatherb_kernel) reads column tables instead of core rows -- its own bytes are the
+        # library's figure for the plan it built (records + row positions + 2 B per column from a unit's first row on + one 64 KB block image
+        # per work item); the row-major figure stays in the parts for comparison
+        gather_bytes, blocked = 4 * gather_words, None
+        try:
+            from graphminer_amd import CliqueSolver, _lib as _l
+
+            dagc = bg.dag()
+            CliqueSolver(dagc, 4)
+            gi = (C.c_int64 * 4)()
+            _l.check(_l.load().gm_clique4_gather_info(dagc.handle, gi), "gm_clique4_gather_info")
+            if int(gi[0]) > 0:
+                blocked = {"units": int(gi[0]), "unit_bytes": int(gi[1]), "items": int(gi[2]), "blocks": int(gi[3])}
+                gather_bytes = int(gi[1]) + int(gi[2]) * 65536
+        except Exception:
+            pass
         dw = dplus[(dplus >= CB_MIN_DEG) & (dplus <= CB_MAX_DEG)]
         arena_words = int((dw * ((dw + 31) // 32)).sum().item())
-        return {"bytes": 4 * k + 16 * tasks + 4 * ne + 16 * (nv + 1) + 8 * arena_words + 4 * gather_words, "streamed_keys": k,
+        return {"bytes": 4 * k + 16 * tasks + 4 * ne + 16 * (nv + 1) + 8 * arena_words + gather_bytes, "streamed_keys": k,
                 "parts": {"streamed_keys_x4": 4 * k, "task_records_x16": 16 * tasks, "rows_staged_once": 4 * ne, "offsets": 16 * (nv + 1),
-                          "arena_words_written_and_read_x8": 8 * arena_words, "core_words_gathered_x4": 4 * gather_words,
+                          "arena_words_written_and_read_x8": 8 * arena_words, "core_words_gathered_x4_row_major": 4 * gather_words,
+                          "blocked_gather": blocked, "gather_bytes": gather_bytes,
                           "core_rows_gathered": int(in_core.sum().item()), "core_h": core_h}}
     if workload == "diamond" and world <= 1:
         dag = bg.dag()
@@ -657,6 +674,10 @@ class Runner:
             # graph resident in HBM -> first count: the first call (builds tables, renumbered copies, task lists, runs once) + the orientation
             # of a DAG workload, which bench.py asks for before the call (the symmetric-graph solvers orient inside their first call)
             "end_to_end_ms": 1e3 * first_call_s + (float(setup.get("orient_ms", 0.0)) if oriented else 0.0),
+            # ONE SHOT, as `tc_gpu_base <graph>` is used: a fresh handle over the resident CSR -> orientation -> every table ->
+            # one count, wall clock, the median of the fresh-handle runs (None when none was made: several ranks, --first-call-repeats 0)
+            "single_shot_ms": (median([x["end_to_end_ms"] for x in first_runs if x.get("end_to_end_ms") is not None])
+                               if any(x.get("end_to_end_ms") is not None for x in first_runs) else None),
             "nv": g.V(), "ne_sym": sym_e, "max_degree": g.get_max_degree(), "stats": {"grid": int(st.grid), "block": int(st.block)},
             "diamond_supports_across_ranks": bool(dstate["on"]),
         }
@@ -720,19 +741,26 @@ def dataset_prefix(a, workload):
     return p if p and os.path.exists(p + ".meta.txt") else ""
 
 
-def measure_traffic(a, workloads, share=(0, 1), device=0):
-    """{workload: {"fetch_bytes", "write_bytes", "launches", "kernels": {...}}} per launch, or (None, reason).
+ISSUE_PASSES = (("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "GRBM_GUI_ACTIVE"), ("SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES"))
+
+
+def measure_traffic(a, workloads, share=(0, 1), device=0, issue=True):
+    """{workload: {"fetch_bytes", "write_bytes", "launches", "kernels": {...}, "pmc": {kernel: {counter: per launch}}}} per launch, or (None, reason).
     share = (rank, world): the launches of the child cover that rank's share of the task chunks (N > 1: rank 0 measures ITS share on
-    its own GPU while the other ranks wait; rank / world are launch arguments, no second GPU is involved)."""
+    its own GPU while the other ranks wait; rank / world are launch arguments, no second GPU is involved).
+    Passes (each its own rocprofv3 run, --kernel-trace --pmc only): FETCH_SIZE, WRITE_SIZE, and -- issue = True -- the two groups of ISSUE_PASSES
+    behind the issue-side roofline; a failing issue pass costs only the `issue` object, never the traffic."""
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
-    out = {w: {"kernels": {}} for w in workloads}
+    out = {w: {"kernels": {}, "pmc": {}} for w in workloads}
     tmp = tempfile.mkdtemp(prefix="gm_traffic_", dir="/tmp")
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = os.path.join(tmp, counter)
-            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+        for pi, group in enumerate((("FETCH_SIZE",), ("WRITE_SIZE",)) + (ISSUE_PASSES if issue else ())):
+            counter = group[0]
+            optional = pi >= 2
+            d = os.path.join(tmp, f"pass{pi}")
+            cmd = [exe, "--kernel-trace", "--pmc", *group, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
                    sys.executable, os.path.abspath(__file__), "--traffic-worker", "--configs", ",".join(workloads), "--steps", "2",
                    "--traffic", "off", "--no-cpu-baseline", "--seed", str(a.seed)]
             for flag, val in (("--scale", a.scale), ("--ef", a.ef)):
@@ -751,6 +779,10 @@ def measure_traffic(a, workloads, share=(0, 1), device=0):
             r = subprocess.run(cmd, capture_output=True, text=True, cwd="/tmp", env=env, timeout=900)
             m = re.search(r"TRAFFIC_WORKER (\{.*\})", r.stdout)
             if r.returncode != 0 or not m:
+                if optional:
+                    for w in workloads:
+                        out[w]["pmc_error"] = f"rocprofv3 --pmc {' '.join(group)} failed (rc {r.returncode})"
+                    continue
                 return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {(r.stderr or r.stdout)[-300:]}"
             launches = json.loads(m.group(1))
             import csv
@@ -758,13 +790,16 @@ def measure_traffic(a, workloads, share=(0, 1), device=0):
             rows = []
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if row.get("Counter_Name") == counter:
-                        rows.append((int(row.get("Dispatch_Id") or row.get("Correlation_Id") or 0), row.get("Kernel_Name", ""), float(row.get("Counter_Value", 0))))
+                    if row.get("Counter_Name") in group:
+                        rows.append((int(row.get("Dispatch_Id") or row.get("Correlation_Id") or 0), row.get("Kernel_Name", ""), row.get("Counter_Name"),
+                                     float(row.get("Counter_Value", 0))))
             if not rows:
+                if optional:
+                    continue
                 return None, f"no {counter} rows in the rocprofv3 output"
             rows.sort(key=lambda x: x[0])
-            seg_sums, seg, in_marker = [], -1, False  # per workload (in the worker's order): kernel name -> counter sum
-            for did, k, v in rows:
+            seg_sums, seg, in_marker = [], -1, False  # per workload (in the worker's order): (kernel name, counter) -> sum
+            for did, k, cn, v in rows:
                 if TRAFFIC_MARKER in k:
                     if not in_marker:  # (one boundary however many dispatches / counter rows the marker call makes)
                         seg, in_marker = seg + 1, True
@@ -772,13 +807,20 @@ def measure_traffic(a, workloads, share=(0, 1), device=0):
                     continue
                 in_marker = False
                 if seg >= 0:
-                    seg_sums[seg][k] = seg_sums[seg].get(k, 0.0) + v
+                    seg_sums[seg][(k, cn)] = seg_sums[seg].get((k, cn), 0.0) + v
             if len(seg_sums) != len(workloads):
+                if optional:
+                    continue
                 return None, f"{len(seg_sums)} marker dispatches for {len(workloads)} workloads in the {counter} pass"
             for wi, w in enumerate(workloads):
-                tot = 0.0
                 sums = seg_sums[wi]
-                for kname, v in sums.items():
+                if optional:
+                    for (kname, cn), v in sums.items():
+                        if any(p in kname for p in KERNELS.get(w, [])):
+                            out[w]["pmc"].setdefault(kname[:60], {})[cn] = v / launches[w]
+                    continue
+                tot = 0.0
+                for (kname, cn), v in sums.items():
                     if any(p in kname for p in KERNELS.get(w, [])):
                         tot += v
                         out[w]["kernels"][kname[:60]] = out[w]["kernels"].get(kname[:60], {})
@@ -788,7 +830,7 @@ def measure_traffic(a, workloads, share=(0, 1), device=0):
                 # WRITE_SIZE is uncalibrated (x1)
                 scale = 2048.0 if counter == "FETCH_SIZE" else 1024.0
                 if counter == "FETCH_SIZE" and tot <= 0:
-                    return None, f"no FETCH_SIZE rows matched the kernels of {w} ({KERNELS.get(w)}): " + ", ".join(sorted(k[:40] for k in sums)[:6])
+                    return None, f"no FETCH_SIZE rows matched the kernels of {w} ({KERNELS.get(w)}): " + ", ".join(sorted(k[0][:40] for k in sums)[:6])
                 out[w]["fetch_bytes" if counter == "FETCH_SIZE" else "write_bytes"] = tot * scale / launches[w]
                 out[w]["launches"] = launches[w]
         return out, ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of the same workloads in this run; FETCH x2 (gfx950 calibration), KB units"
@@ -797,6 +839,34 @@ def measure_traffic(a, workloads, share=(0, 1), device=0):
         return None, f"traffic measurement failed: {e}"
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def issue_roofline(pmc):
+    """The ISSUE-side roofline of a workload's dominant kernel (most GRBM_GUI_ACTIVE cycles) out of the counters of ISSUE_PASSES, priced with the
+    calibrated issue costs of profiles/r03/issue_calibration.txt as scripts/summarize_pmc.py does: a wave64 VALU instruction occupies its
+    SIMD 2.4 (add / logic / shift / mov) .. 4.1 cycles (the rest) -- SQ_INSTS_VALU does not tell the classes apart, hence a range; a SALU
+    instruction the CU's one scalar unit 1.0 cycle; SQ_LDS_IDX_ACTIVE = busy cycles of the LDS.  `binds`: the busiest unit, or the waves' own
+    latency when no unit is above 0.6 and the waves wait more than half of their cycles."""
+    best = None
+    for k, c in (pmc or {}).items():
+        if c.get("GRBM_GUI_ACTIVE", 0) > (best[1].get("GRBM_GUI_ACTIVE", 0) if best else 0):
+            best = (k, c)
+    if not best:
+        return None
+    k, c = best
+    cyc = c["GRBM_GUI_ACTIVE"] / 8.0  # (summed over the 8 XCDs)
+    v, sa, lds = c.get("SQ_INSTS_VALU", 0.0), c.get("SQ_INSTS_SALU", 0.0), c.get("SQ_LDS_IDX_ACTIVE")
+    r = {"kernel": k[:48], "valu": [round(v * 2.4 / 1024 / cyc, 3), round(min(v * 4.1 / 1024 / cyc, 9.99), 3)], "salu": round(sa / 256 / cyc, 3)}
+    if lds is not None:
+        r["lds"] = round(lds / 256 / cyc, 3)
+        r["lds_conflict"] = round(c.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(lds, 1.0), 3)
+    if c.get("SQ_WAVE_CYCLES"):
+        r["waiting"] = round(c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 3)
+    units = {"valu": r["valu"][1], "salu": r["salu"], "lds": r.get("lds", 0.0)}
+    top = max(units, key=units.get)
+    r["binds"] = top if units[top] >= 0.6 or r.get("waiting", 0.0) <= 0.5 else "latency of the waves' own chains (no unit above 0.6 busy)"
+    r["kernel_cycles"] = int(cyc)
+    return r
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -974,6 +1044,7 @@ def finish_record(rec, a, world, ab, floor, traffic, traffic_src, cpu, known, st
         "kernel_ms_avg": round(rec["kernel_ms_avg"], 4), "value": round(rec["tasks"] / step_t / 1e6, 3), "unit": "Medges/s",
         "count": rec["count"], "matches_per_sec": round((rec["count"][1] if isinstance(rec["count"], list) else rec["count"]) / step_t, 1),
         "first_call_ms": round(rec["first_call_ms"], 2), "first_call_runs_ms": rec.get("first_call_runs_ms"), "setup_ms": rec["setup_ms"], "end_to_end_ms": round(rec.get("end_to_end_ms", rec["first_call_ms"]), 2),
+        "single_shot_ms": round(rec["single_shot_ms"], 2) if rec.get("single_shot_ms") is not None else None,
         "per_gpu_kernel_ms": {"max": round(max(rec["per_gpu_kernel_ms"]), 4), "mean": round(sum(rec["per_gpu_kernel_ms"]) / len(rec["per_gpu_kernel_ms"]), 4),
                               "all": [round(x, 4) for x in rec["per_gpu_kernel_ms"]],
                               "skew_max_over_mean": round(max(rec["per_gpu_kernel_ms"]) / max(sum(rec["per_gpu_kernel_ms"]) / len(rec["per_gpu_kernel_ms"]), 1e-9), 4)},
@@ -1063,6 +1134,10 @@ def finish_record(rec, a, world, ab, floor, traffic, traffic_src, cpu, known, st
         roof["mall_note"] = ("the CSR fits the 256 MiB Infinity Cache: FETCH_SIZE counts MALL hits too (MI355X_MICROARCH.md), so `traffic` here is "
                              "fabric traffic, most of it served from the Infinity Cache, not HBM reads")
 
+    if traffic and traffic.get("pmc"):
+        iss = issue_roofline(traffic["pmc"])
+        if iss:
+            roof["issue"] = iss
     out["roofline"] = roof
     if cpu:
         fs = full_size_cpu(rec["workload"], rec["graph"], rec["tasks"])
@@ -1155,6 +1230,8 @@ def compact_roofline(r):
         out["kernel"] = out["kernel"][:96]
     if r.get("corner_kernel"):
         out["corner_kernel"] = {k: r["corner_kernel"][k] for k in ("ms", "bound", "achieved", "peak", "frac", "traffic") if k in r["corner_kernel"]}
+    if isinstance(r.get("issue"), dict):
+        out["issue"] = {k: (r["issue"][k][:32] if k == "kernel" else r["issue"][k]) for k in ("kernel", "valu", "salu", "lds", "lds_conflict", "waiting", "binds") if k in r["issue"]}
     if r.get("streamed_kernels"):  # (round 6: `frac` is the whole launch; the streamed kernels alone beside it)
         out["streamed_kernels"] = {k: r["streamed_kernels"][k] for k in ("ms", "traffic", "frac", "own_frac") if k in r["streamed_kernels"]}
     basis = r.get("frac_basis") or ""
@@ -1191,15 +1268,29 @@ def compact_line(out, detail_path):
             rf, cb = c["roofline"], c.get("cpu_baseline") or {}
             e = {"id": c["id"], "workload": c["workload"], "graph": c["graph"], "kernel_ms": c["kernel_ms_avg"], "value": c["value"], "count": c["count"],
                  "count_ok": c.get("count_matches_cpu"), "frac": rf.get("frac"), "traffic_GB": round(rf["traffic"] / 1e9, 2) if rf.get("traffic") else None,
-                 "own_frac": rf.get("own_frac"), "first_call_ms": c["first_call_ms"], "first_call_runs_ms": c.get("first_call_runs_ms"), "cpu_value": cb.get("value"), "cpu_kind": cb.get("kind")}
+                 "own_frac": rf.get("own_frac"), "first_call_ms": c["first_call_ms"], "single_shot_ms": c.get("single_shot_ms"), "cpu_value": cb.get("value"), "cpu_kind": cb.get("kind")}
+            if isinstance(rf.get("issue"), dict):  # which unit binds the dominant kernel and how busy it is (issue-side roofline; the detail file has all of it)
+                iss = rf["issue"]
+                busy = {"valu": iss["valu"][1], "salu": iss["salu"], "lds": iss.get("lds", 0.0)}
+                e["binds"] = f"{iss['binds'][:7]} {max(busy.values()):.2f}, waiting {iss.get('waiting', 0):.2f}"
             if cb.get("full_size"):
                 e["cpu_full_size_s"] = cb["full_size"].get("seconds")
             if "per_edge_variant" in c and "kernel_ms_avg" in c["per_edge_variant"]:
                 e["enumeration_kernel_ms"] = c["per_edge_variant"]["kernel_ms_avg"]
                 e["enumeration_frac"] = c["per_edge_variant"].get("frac")
+                try:  # both CPU pairs of config 5: motif_omp_formula <-> the formula ms above, motif_omp_base <-> the enumeration ms
+                    fs = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize.json"))).get(f"motif3:{c['graph']}") or {}
+                    if fs.get("enumeration_reference_seconds"):
+                        e["enumeration_cpu_full_size_s"] = fs["enumeration_reference_seconds"]
+                except Exception:
+                    pass
             cfgs.append(e)
         line["configs"] = cfgs
         line["all_counts_match_cpu"] = out.get("all_counts_match_cpu")
+    if out.get("livejournal_standins"):  # LiveJournal-sized graphs of the two other shapes (ids 2a / 2b: TC, 3a / 3b: diamond)
+        tags = {("tc", "uniform"): "2a", ("tc", "powerlaw"): "2b", ("diamond", "uniform"): "3a", ("diamond", "powerlaw"): "3b"}
+        line["standins"] = [{"id": tags.get((x["workload"], x["graph"].split("_")[0]), "?"), "kernel_ms": x["kernel_ms_avg"], "value": x["value"], "count": x["count"],
+                             **({"traffic_frac": x["traffic_frac"]} if x.get("traffic_frac") is not None else {"own_frac": x.get("frac")})} for x in out["livejournal_standins"]]
     if isinstance(out.get("tc_rmat24"), dict) and "roofline" in out["tc_rmat24"]:
         t = out["tc_rmat24"]
         line["tc_rmat24"] = {"kernel_ms": t["kernel_ms_avg"], "value": t["value"], "frac": t["roofline"].get("frac"), "own_frac": t["roofline"].get("own_frac")}
@@ -1374,6 +1465,10 @@ def main():
                 a2 = argparse.Namespace(**vars(a))
                 a2.uniform, a2.powerlaw = (spec, "") if kind == "uniform" else ("", spec)
                 bg2 = build_graph(a2, r.local_rank, 0, 0)
+                tr2 = {}
+                if a.traffic == "auto":  # counter traffic of the LiveJournal-sized graphs too (two more passes per graph, the triangle count only)
+                    got2, _src2 = measure_traffic(a2, ["tc"], device=r.local_rank, issue=False)
+                    tr2 = got2 or {}
                 for w in ("tc", "diamond"):
                     rec2 = r.run(w, bg2, a.steps, a.warmup)
                     ab2, fl2 = alg_bytes_device(w, bg2, r.lib, rec2["g"])
@@ -1385,7 +1480,10 @@ def main():
                                   "algorithmic_frac": round(ab2 / t2 / 1e9 / HBM_PEAK_GBS, 5) if ab2 and t2 > 0 else None,
                                   "own_bytes_per_launch": own2["bytes"] if own2 else None, "own_streamed_keys": own2["streamed_keys"] if own2 else None,
                                   "frac": round(own2["bytes"] / t2 / 1e9 / HBM_PEAK_GBS, 5) if own2 and t2 > 0 else None,
-                                  "compulsory_floor_bytes": fl2, "setup_ms": rec2["setup_ms"]})
+                                  "compulsory_floor_bytes": fl2, "setup_ms": rec2["setup_ms"],
+                                  "traffic": int(tr2[w]["fetch_bytes"] + tr2[w].get("write_bytes", 0.0)) if w in tr2 and "fetch_bytes" in tr2[w] else None,
+                                  "traffic_frac": (round((tr2[w]["fetch_bytes"] + tr2[w].get("write_bytes", 0.0)) / t2 / 1e9 / HBM_PEAK_GBS, 5)
+                                                   if w in tr2 and "fetch_bytes" in tr2[w] and t2 > 0 else None)})
                 bg2.free()
             out["livejournal_standins"] = extra
         if tc24 is not None:
@@ -1409,7 +1507,7 @@ def main():
             print(f"[bench] could not write {detail}: {e}", file=sys.stderr)
             detail = None
         rec = compact_line(out, os.path.relpath(detail, ROOT) if detail and os.path.abspath(detail).startswith(ROOT) else detail)
-        for drop in ("", "tc_rmat24", "per_gpu_kernel_ms", "all_counts_match_cpu"):  # (never reached with the five configs: a guard, not a plan)
+        for drop in ("", "tc_rmat24", "per_gpu_kernel_ms", "all_counts_match_cpu", "standins"):  # (never reached with the five configs: a guard, not a plan)
             rec.pop(drop, None)
             line = json.dumps(rec, separators=(",", ":"))
             if len(line) < 4000:

@@ -96,6 +96,7 @@ SYMBOLS = [
     ("gm_setop_batch", C.c_int, [C.c_int, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     ("gm_rmat_keys", C.c_int, [C.c_int, C.c_int64, C.c_uint64, _P, _P]),
     ("gm_clique4_level2_bytes", C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    ("gm_clique4_gather_info", C.c_int, [_P, C.POINTER(C.c_int64)]),
     ("gm_calib_stream", C.c_int, [_P, C.c_int64, _P, _P]),
     ("gm_stream_ceiling", C.c_int, [_P, C.c_int64, _P, _P]),
     ("gm_issue_calib", C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

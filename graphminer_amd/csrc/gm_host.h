@@ -232,6 +232,7 @@ struct CliqueRound {
   unsigned *d_gtab = nullptr;              // the column tables of the round's slots (16-bit positions, two tiles per dword)
   int2 *d_gitems = nullptr;
   size_t n_gunits = 0, n_gitems = 0;
+  unsigned long long gather_table_bytes = 0;  // records + row positions + table dwords the units read by construction (tooling: gm_clique4_gather_info)
 };
 struct CliquePlan {
   int rank = 0, world = 1, policy = 0, target = 0, order_which = 1;

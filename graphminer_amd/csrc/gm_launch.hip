@@ -1826,6 +1826,25 @@ extern "C" int gm_clique4_level2_bytes(const gm_graph *dag, uint64_t *bytes) {
   return GM_OK;
 }
 
+// tooling (the byte model of bench.py): the blocked gather of the most recent whole-graph 4-clique plan of this handle
+extern "C" int gm_clique4_gather_info(const gm_graph *dag, int64_t info[4]) {
+  if (!dag || !info) return GM_ERR_INVALID;
+  gm_graph *g = const_cast<gm_graph *>(dag);
+  info[0] = info[1] = info[2] = info[3] = 0;
+  std::lock_guard<std::mutex> lk(g->mu);
+  for (auto &pl : g->clique_plans) {
+    if (pl.world != 1) continue;
+    for (auto &rd : pl.rounds) {
+      info[0] += (int64_t)rd.n_gunits;             // (vertex, block) units
+      info[1] += (int64_t)rd.gather_table_bytes;   // bytes they read by construction: 16 B record + 4 B per row + their table dwords
+      info[2] += (int64_t)rd.n_gitems;             // work items (each loads one block image of <= 64 KB unless it shares it with its predecessor)
+    }
+    info[3] = g->n_cg_blocks;
+    break;
+  }
+  return GM_OK;
+}
+
 // (module warm-up, gm_graph.hip finish_handle: HIP loads the code object of a translation unit when one of its kernels is first launched)
 __global__ void gm_touch_launch_kernel() {}
 void gm_touch_launch() { hipLaunchKernelGGL(gm_touch_launch_kernel, dim3(1), dim3(1), 0, 0); }

@@ -1933,13 +1933,16 @@ __global__ __launch_bounds__(256) void cgb_table_fill_kernel(int w0, int nslots,
 }
 // sorted order: record k = recs[idx[k]]; its probes = sum over its rows i of (d - 1 - i)
 __global__ __launch_bounds__(256) void cgb_gather_kernel(long long n, const unsigned *__restrict__ idx, const uint4 *__restrict__ recs, uint4 *__restrict__ out,
-                                                          unsigned long long *__restrict__ cost) {
+                                                          unsigned long long *__restrict__ cost, unsigned long long *__restrict__ tbytes) {
   const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   const uint4 r = recs[idx[k]];
   out[k] = r;
   const long long d = r.z & 0xffffu, i0 = r.z >> 16, rows = r.w;
   cost[k] = (unsigned long long)(rows * (d - 1 - i0) - rows * (rows - 1) / 2 + 64 * rows + 256);  // (+ per row and per unit overheads, in probes)
+  // what the unit reads by construction: its record, its rows' positions, the table dwords of the tile pairs from its first row's on
+  const long long npairs = ((d + 63) / 64 + 1) / 2, t0 = (i0 + 1) >> 7;
+  tbytes[k] = (unsigned long long)(16 + 4 * rows + 256 * (npairs > t0 ? npairs - t0 : 0));
 }
 __global__ __launch_bounds__(256) void cgb_item_flag_kernel(long long n, const unsigned *__restrict__ keys, const unsigned long long *__restrict__ cum,
                                                              unsigned long long target, int *__restrict__ flag) {
@@ -2017,8 +2020,15 @@ static int build_gather_index(gm_graph *g, CliquePlan &pl, CliqueRound &rd, Scan
   int ni = 0;
   int2 *items = nullptr;
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(cgb_gather_kernel, blocks(nu), dim3(256), 0, 0, (long long)nu, idx_s.p, recs.p, units, cost.p);
-    e = dev_exclusive_sum(tmp, cost.p, cum.p, (size_t)nu);
+    hipLaunchKernelGGL(cgb_gather_kernel, blocks(nu), dim3(256), 0, 0, (long long)nu, idx_s.p, recs.p, units, cost.p, cum.p);
+    size_t bytes = 0;  // (cum holds the units' table bytes for a moment: their sum is the kernel's own bytes, gm_clique4_gather_info)
+    DevBuf<unsigned long long> tsum;
+    e = tsum.alloc(1);
+    if (e == hipSuccess) e = hipcub::DeviceReduce::Sum(nullptr, bytes, cum.p, tsum.p, nu);
+    if (e == hipSuccess) e = tmp.reserve(bytes);
+    if (e == hipSuccess) e = hipcub::DeviceReduce::Sum(tmp.buf.p, bytes, cum.p, tsum.p, nu);
+    if (e == hipSuccess) e = hipMemcpy(&rd.gather_table_bytes, tsum.p, 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = dev_exclusive_sum(tmp, cost.p, cum.p, (size_t)nu);
   }
   if (e == hipSuccess) e = hipMemsetAsync(flag.p + nu, 0, sizeof(int), 0);
   if (e == hipSuccess) {

@@ -293,6 +293,11 @@ int gm_rmat_keys(int scale, int64_t n_edges, uint64_t seed, uint64_t *d_keys, vo
  * kernel (per-edge |S1| and the out-degrees of the matched vertices). */
 int gm_clique4_level2_bytes(const gm_graph *dag, uint64_t *bytes);
 
+/* Tooling (bench.py's byte model): after a whole-graph gm_clique(dag, 4) -- the blocked gather of the wide vertices' core rows
+ * (csrc/gm_cgather.hip): info[0] = (vertex, block of core rows) units, info[1] = the bytes they read by construction (a 16-byte record, 4 B per
+ * row, the 16-bit column table from the unit's first row on), info[2] = work items, info[3] = blocks of the core.  All 0: the row-major gather. */
+int gm_clique4_gather_info(const gm_graph *dag, int64_t info[4]);
+
 /* PMC calibration (tooling): one pass of dword-per-lane coalesced loads over d_buf[0..n), sum -> *d_out.
  * Exactly 4n bytes are read once; run under `rocprofv3 --pmc FETCH_SIZE` to get the counter scale for the
  * access width the mining kernels use (MI355X_MICROARCH.md: FETCH_SIZE is calibrated only for 16 B/lane). */

@@ -10,7 +10,7 @@ mkdir -p $O
 CFGS=("$@")
 if [ ${#CFGS[@]} -eq 0 ]; then
   CFGS=("tc_rmat22:tch_kernel,core_tc_,mine_kernel<0:--workload;tc" "diamond_rmat22:sup_kernel<,core_tc_,sup_pairs_kernel,sup_near_kernel,sup_far_kernel:--workload;diamond"
-        "clique4_rmat22ef28:cbuild_kernel,cgather_kernel,clique_mma_kernel,clique_small_kernel,mine_kernel<3:--workload;clique4"
+        "clique4_rmat22ef28:cbuild_kernel,cgather_kernel,cgatherb_kernel,clique_mma_kernel,clique_small_kernel,mine_kernel<3:--workload;clique4"
         "motif3_rmat24:tch_kernel,core_tc_,mine_kernel<0:--workload;motif3" "motif3e_rmat24:hrow_kernel<2,giant_kernel<2,mine_kernel<2:--workload;motif3e" "diamond_rmat24:sup_kernel<,core_tc_,sup_pairs_kernel,sup_near_kernel,sup_far_kernel:--workload;diamond;--scale;24;--ef;16" "tc_uniform:tch_kernel:--workload;tc;--uniform;4847571,43000000"
         "tc_powerlaw:tch_kernel:--workload;tc;--powerlaw;4847571,43000000,20000")
 fi
