@@ -1829,8 +1829,12 @@ extern "C" int gm_clique4_level2_bytes(const gm_graph *dag, uint64_t *bytes) {
 // tooling (the byte model of bench.py): the blocked gather of the most recent whole-graph 4-clique plan of this handle
 extern "C" int gm_clique4_gather_info(const gm_graph *dag, int64_t info[4]) {
   if (!dag || !info) return GM_ERR_INVALID;
-  gm_graph *g = const_cast<gm_graph *>(dag);
   info[0] = info[1] = info[2] = info[3] = 0;
+  gm_graph *g = nullptr;
+  {  // (the plan belongs to the handle the count runs on: the topologically renumbered copy of a DAG that is not numbered that way)
+    const int rc = topo_view(dag, nullptr, &g);
+    if (rc) return rc;
+  }
   std::lock_guard<std::mutex> lk(g->mu);
   for (auto &pl : g->clique_plans) {
     if (pl.world != 1) continue;

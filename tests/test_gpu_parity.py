@@ -1145,3 +1145,38 @@ def test_rank_shares_of_separate_handles_add_up(dev, world, policy):
         finally:
             for h in dags + syms:
                 h.free()
+
+
+@pytest.mark.parametrize("nv", [40003, 33000, 36864])
+def test_clique4_blocked_gather_with_an_unaligned_core_base(dev, nv):
+    """the BLOCKED gather of the wide vertices' core rows (csrc/gm_cgather.hip cgatherb_kernel, round 6) on graphs of more than 32768 vertices
+    whose size is NOT a multiple of 32: the core's base is then not word aligned (core_base & 31 = 3 / 8; 36864: aligned) and the column
+    tables / block images count their bits from the base rounded down.  A dense block of hubs (DAG rows of every wide class up to ~800
+    entries) + leaves hanging on them; blocked = row-major gather (tune[6] & 0x8000000) = the all-in-the-mining-kernel build = oracle,
+    rank shares included, and the library confirms that the blocked path ran."""
+    rng = np.random.default_rng(nv)
+    nh = 1500
+    iu, ju = np.triu_indices(nh, 1)
+    keep = rng.random(iu.size) < 0.5
+    s, d = [iu[keep]], [ju[keep]]
+    leaves = np.arange(nh, nv)
+    for _ in range(3):  # every leaf on three hubs: the hubs keep the highest degrees, the leaves fill the core below them
+        s.append(rng.integers(0, nh, leaves.size))
+        d.append(leaves)
+    g = csr_from_pairs(nv, np.concatenate(s).astype(np.uint64), np.concatenate(d).astype(np.uint64))
+    osym = O.OGraph(g.row_ptr, g.col_idx)
+    odag = O.orient(osym)
+    assert int(np.diff(odag.row_ptr).max()) > 512
+    want = O.clique(odag, 4)
+    with g.to_device(dev) as sym:
+        dag = sym.orient()
+        got = CliqueSolver(dag, 4)
+        info = (C.c_int64 * 4)()
+        _lib.check(_lib.load().gm_clique4_gather_info(dag.handle, info), "gm_clique4_gather_info")
+        assert info[0] > 0 and info[2] > 0 and info[3] > 1, list(info)  # units, work items, blocks: the blocked gather ran
+        assert got == want
+        assert CliqueSolver(dag, 4, tune=[0, 0, 0, 0, 0, 0, 0x8000000]) == want  # the row-major gather of round 5
+        assert CliqueSolver(dag, 4, tune=[0, 0, 0, 0, 0, 0, 0x40000]) == want
+        assert sum(CliqueSolver(dag, 4, rank=r, world=3) for r in range(3)) == want
+        assert sum(CliqueSolver(dag, 4, rank=r, world=2, policy=1, tune=[0, 0, 0, 0, 0, 0, 0x8000000]) for r in range(2)) == want
+        dag.free()
