@@ -47,6 +47,7 @@ __device__ __forceinline__ mma_v8i mma_expand_b(const unsigned x) {
 }
 
 // sum of the accumulators whose mask bit is set: register r of this lane is bit (r & 3) + 8 (r >> 2) of w (already shifted by 4 (l >> 5))
+// (round 6: two registers per v_pk_fma_f32 -- 24 instead of 32 + 8 instructions per tile -- made the whole pattern 0.7 ms SLOWER: not kept)
 __device__ __forceinline__ float mma_masked_sum(const mma_v16f &acc, const unsigned w) {
   float s = 0.f;
 #pragma unroll
@@ -57,6 +58,19 @@ __device__ __forceinline__ float mma_masked_sum(const mma_v16f &acc, const unsig
   }
   return s;
 }
+
+// task t of a triangular matrix = the block pair (JB, IB), IB <= JB, t = JB (JB + 1) / 2 + IB: a table instead of a square root and two correcting
+// loops per block (round 6: a block of a d+ <= 512 matrix is ~10 MFMA, and everything around them counts)
+constexpr int kMmaTriMax = 33 * 32 / 2;  // nJ <= 32 (2048 rows)
+struct MmaTri {
+  unsigned short v[kMmaTriMax];
+  constexpr MmaTri() : v() {
+    int t = 0;
+    for (int jb = 0; jb < 32; ++jb)
+      for (int ib = 0; ib <= jb; ++ib) v[t++] = (unsigned short)((jb << 8) | ib);
+  }
+};
+__constant__ MmaTri kMmaTri = MmaTri();
 
 template <int WAVES, int WORDS, bool BLOCKS>
 __global__ __launch_bounds__(WAVES *GM_WAVE) void clique_mma_kernel(const CliqueCountParams p) {
@@ -120,10 +134,9 @@ __global__ __launch_bounds__(WAVES *GM_WAVE) void clique_mma_kernel(const Clique
       if (t >= ntasks) break;
       int JB, IB;
       if (topo) {  // t = JB (JB + 1) / 2 + IB, IB <= JB: the blocks with the longest column range first
-        JB = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
-        while ((JB + 1) * (JB + 2) / 2 <= t) ++JB;
-        while (JB * (JB + 1) / 2 > t) --JB;
-        IB = t - JB * (JB + 1) / 2;
+        const unsigned e = kMmaTri.v[t];  // (t is wave-uniform: a scalar load)
+        JB = (int)(e >> 8);
+        IB = (int)(e & 255u);
       } else {
         JB = t / nJ;
         IB = t - JB * nJ;
@@ -138,21 +151,29 @@ __global__ __launch_bounds__(WAVES *GM_WAVE) void clique_mma_kernel(const Clique
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
           const int wc = JB * 2 + jj;
-          const bool in = row < d && wc < stride;
-          const unsigned v = gm[in ? (size_t)row * stride + wc : 0];
-          mw[jj][ii] = in ? v : 0u;
+          if (!BLOCKS) {  // the whole matrix is in LDS (rows and columns beyond it are zero there: rows_alloc x ps words)
+            mw[jj][ii] = wc < ps ? S.bits[row * ps + wc] : 0u;
+          } else {  // (a column block: the mask's column may lie outside it -- from the arena, L2)
+            const bool in = row < d && wc < stride;
+            const unsigned v = gm[in ? (size_t)row * stride + wc : 0];
+            mw[jj][ii] = in ? v : 0u;
+          }
         }
       }
       if (__ballot((mw[0][0] | mw[0][1] | mw[1][0] | mw[1][1]) != 0u) == 0ull) continue;  // no pair (i, j) in this block
       mma_v16f acc[2][2];
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[jj][ii][r] = 0.f;
       const int xi = (IB * 64 + l31) * ps + h - c0, xj = (JB * 64 + l31) * ps + h - c0, hop = 32 * ps;
-      for (int ks = ks0; ks < kb1; ++ks) {
+      {  // the first column step takes a ZERO C operand (an inline constant of the MFMA) instead of 64 registers cleared per block
+        const mma_v16f zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const int ks = ks0;
+        const unsigned wi0 = S.bits[xi + 2 * ks], wi1 = S.bits[xi + 2 * ks + hop], wj0 = S.bits[xj + 2 * ks], wj1 = S.bits[xj + 2 * ks + hop];
+        const mma_v8i fi0 = mma_expand_b(wi0), fi1 = mma_expand_b(wi1), fj0 = mma_expand_a(wj0), fj1 = mma_expand_a(wj1);
+        acc[0][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fj0, fi0, zero, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        acc[0][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fj0, fi1, zero, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        acc[1][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fj1, fi0, zero, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        acc[1][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fj1, fi1, zero, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+      }
+      for (int ks = ks0 + 1; ks < kb1; ++ks) {
         const unsigned wi0 = S.bits[xi + 2 * ks], wi1 = S.bits[xi + 2 * ks + hop], wj0 = S.bits[xj + 2 * ks], wj1 = S.bits[xj + 2 * ks + hop];
         const mma_v8i fi0 = mma_expand_b(wi0), fi1 = mma_expand_b(wi1), fj0 = mma_expand_a(wj0), fj1 = mma_expand_a(wj1);
         // unit scales (E8M0 127); formats: 4 = FP4 (E2M1) for both operands
