@@ -170,10 +170,20 @@ hipError_t launch_cbuild(const CBuildParams &p, int stage, int grid_blocks, hipS
 // The matrices of a narrow chunk's vertices are contiguous in the arena (vertex order): one coalesced copy into LDS, then one thread
 // per row i:  sum_{j in M_i} popc(M_i & M_j)  (clique4_warp_edge.cuh:22-27 on bit rows) -- with a topological numbering M_j has no bit
 // at or below j, so the words below j / 32 are skipped.
+// Round 6: the kernel was one dependent chain per chunk -- dequeue atomic -> chunk record -> matrix offsets -> matrix words -> barrier ->
+// count (waves waiting 0.78 of their cycles, every unit below 0.4: profiles/r05/clique4_rmat22ef28_pmc_summary.txt).  Now a workgroup takes
+// kSmallGrab chunks per atomic, eight threads fetch their records and offsets side by side, and the words of chunk k + 1 are requested (into
+// registers, then the OTHER of two LDS buffers) before chunk k is counted.
+constexpr int kSmallGrab = 8;
+struct SmallInfo {
+  int ub, nvl, eb, nel, nwords, pad_;
+  unsigned long long b0;
+};
 struct alignas(16) SmallLds {
-  unsigned bits[kBitWords];
-  int rpl[kMaxChunkVerts + 1];
-  int boff[kMaxChunkVerts + 1];  // LDS word offset of every vertex' matrix
+  unsigned bits[2][kBitWords];
+  int rpl[2][kMaxChunkVerts + 1];
+  int boff[2][kMaxChunkVerts + 1];  // LDS word offset of every vertex' matrix
+  SmallInfo info[kSmallGrab];
   unsigned queue_pos;
   int pad_[3];
 };
@@ -182,44 +192,91 @@ __global__ __launch_bounds__(kWavesPerBlock *GM_WAVE, 8) void clique_small_kerne
   __shared__ SmallLds S;
   const int tid = threadIdx.x, lane = tid & (GM_WAVE - 1);
   constexpr int NT = kWavesPerBlock * GM_WAVE;
+  constexpr int kWordsPerThread = (kBitWords + NT - 1) / NT, kVertsPerThread = (kMaxChunkVerts + 1 + NT - 1) / NT;
   unsigned long long tot = 0;
   for (;;) {
-    if (tid == 0) S.queue_pos = atomicAdd(p.queue, 1u);
+    if (tid == 0) S.queue_pos = atomicAdd(p.queue, (unsigned)kSmallGrab);
     __syncthreads();
-    const unsigned q = S.queue_pos;
-    if (q >= (unsigned)p.count) break;
-    const size_t pos = (size_t)p.first + (size_t)q * (size_t)p.step;
-    const ChunkRec r = p.chunks[p.order ? (size_t)p.order[pos] : pos];
-    const int ub = r.u_begin, nvl = r.u_end - r.u_begin, eb = r.e_begin, nel = r.e_end - r.e_begin;
-    const unsigned long long b0 = p.base[ub];
-    const int nwords = (int)(p.base[ub + nvl] - b0);  // <= kBitWords: the chunk table was cut for that
-    if (nwords == 0) { __syncthreads(); continue; }
-    for (int i = tid; i <= nvl; i += NT) {
-      S.rpl[i] = p.rp[ub + i];
-      S.boff[i] = (int)(p.base[ub + i] - b0);
+    const unsigned q0 = S.queue_pos;
+    if (q0 >= (unsigned)p.count) break;
+    const int nq = (int)min((unsigned)kSmallGrab, (unsigned)p.count - q0);
+    if (tid < nq) {  // the records and offsets of the batch's chunks, side by side
+      const size_t pos = (size_t)p.first + (size_t)(q0 + (unsigned)tid) * (size_t)p.step;
+      const ChunkRec r = p.chunks[p.order ? (size_t)p.order[pos] : pos];
+      SmallInfo x;
+      x.ub = r.u_begin;
+      x.nvl = r.u_end - r.u_begin;
+      x.eb = r.e_begin;
+      x.nel = r.e_end - r.e_begin;
+      x.b0 = p.base[x.ub];
+      x.nwords = (int)(p.base[x.ub + x.nvl] - x.b0);  // <= kBitWords: the chunk table was cut for that
+      x.pad_ = 0;
+      S.info[tid] = x;
     }
-    for (int i = tid; i < nwords; i += NT) S.bits[i] = p.mat[b0 + (unsigned long long)i];
     __syncthreads();
-    unsigned c = 0;
-    for (int le = tid; le < nel; le += NT) {
-      const int lo = hs_local_row(S.rpl, nvl, eb + le);
-      const int d = S.rpl[lo + 1] - S.rpl[lo];
-      if (S.boff[lo + 1] == S.boff[lo]) continue;  // d < kCbMinDeg: no matrix
-      const int s = (d + 31) >> 5, i = eb + le - S.rpl[lo];
-      const unsigned *M = S.bits + S.boff[lo];
-      const unsigned *Mi = M + i * s;
-      for (int w = 0; w < s; ++w) {
-        unsigned x = Mi[w];
-        while (x) {
-          const int bit = __ffs((int)x) - 1;
-          x &= x - 1;
-          const unsigned *Mj = M + (w * 32 + bit) * s;
-          for (int w2 = p.topo ? w : 0; w2 < s; ++w2) c += (unsigned)__popc(Mi[w2] & Mj[w2]);  // (topological: M_j has no bit below word w)
+    // registers of the chunk being fetched
+    unsigned wv[kWordsPerThread];
+    int rv[kVertsPerThread];
+    unsigned long long bv[kVertsPerThread];
+    auto fetch = [&](const int k) {  // (no waiting here: the values are used by stash)
+      const SmallInfo x = S.info[k];
+#pragma unroll
+      for (int j = 0; j < kVertsPerThread; ++j) {
+        const int i = min(tid + j * NT, x.nvl);
+        rv[j] = p.rp[x.ub + i];
+        bv[j] = p.base[x.ub + i];
+      }
+      if (x.nwords > 0) {  // (workgroup-uniform; a chunk without a matrix has nothing to read -- and may sit at the arena's very end)
+#pragma unroll
+        for (int j = 0; j < kWordsPerThread; ++j) wv[j] = p.mat[x.b0 + (unsigned long long)min(tid + j * NT, x.nwords - 1)];
+      }
+    };
+    auto stash = [&](const int k) {
+      const SmallInfo x = S.info[k];
+      const int b = k & 1;
+#pragma unroll
+      for (int j = 0; j < kVertsPerThread; ++j) {
+        const int i = tid + j * NT;
+        if (i <= x.nvl) {
+          S.rpl[b][i] = rv[j];
+          S.boff[b][i] = (int)(bv[j] - x.b0);
         }
       }
+#pragma unroll
+      for (int j = 0; j < kWordsPerThread; ++j)
+        if (tid + j * NT < x.nwords) S.bits[b][tid + j * NT] = wv[j];
+    };
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    unsigned c = 0;
+    for (int k = 0; k < nq; ++k) {
+      if (k + 1 < nq) fetch(k + 1);  // (wave-uniform) in flight while chunk k is counted
+      const SmallInfo x = S.info[k];
+      const int b = k & 1;
+      if (x.nwords > 0) {
+        for (int le = tid; le < x.nel; le += NT) {
+          const int lo = hs_local_row(S.rpl[b], x.nvl, x.eb + le);
+          const int d = S.rpl[b][lo + 1] - S.rpl[b][lo];
+          if (S.boff[b][lo + 1] == S.boff[b][lo]) continue;  // d < kCbMinDeg: no matrix
+          const int s = (d + 31) >> 5, i = x.eb + le - S.rpl[b][lo];
+          const unsigned *M = S.bits[b] + S.boff[b][lo];
+          const unsigned *Mi = M + i * s;
+          for (int w = 0; w < s; ++w) {
+            unsigned xw = Mi[w];
+            while (xw) {
+              const int bit = __ffs((int)xw) - 1;
+              xw &= xw - 1;
+              const unsigned *Mj = M + (w * 32 + bit) * s;
+              for (int w2 = p.topo ? w : 0; w2 < s; ++w2) c += (unsigned)__popc(Mi[w2] & Mj[w2]);  // (topological: M_j has no bit below word w)
+            }
+          }
+        }
+      }
+      if (k + 1 < nq) stash(k + 1);  // into the other buffer: nobody reads it (its last readers passed the barrier below an iteration ago)
+      __syncthreads();
     }
     tot += (unsigned long long)c;
-    __syncthreads();
   }
   const unsigned long long s0 = wave_sum_u64(tot);
   if (lane == 0 && s0) atomicAdd(&p.counters[0], s0);
