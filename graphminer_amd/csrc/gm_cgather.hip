@@ -206,6 +206,9 @@ __global__ __launch_bounds__(kCgWaves *GM_WAVE) void cgather_kernel(const CGathe
 #ifndef CGB_HEAD
 #define CGB_HEAD 5
 #endif
+#ifndef CGB_PAIR_MAX
+#define CGB_PAIR_MAX 0
+#endif
 constexpr int kCgbWaves = CGB_WAVES;
 struct alignas(16) CGatherBLds {
   unsigned img[kCgbWords];
@@ -341,7 +344,16 @@ __device__ __forceinline__ void cgb_rows(const unsigned *img, const int rb4v, co
     if (++g >= gend) break;
   }
 #else
-  (void)wb;
+  if constexpr (N <= CGB_PAIR_MAX) {  // two rows per trip: their LDS reads go out together and the loop's scalar bookkeeping is halved
+    for (; g + 1 < gend; g += 2) {
+      cgb_read<N>(img, readlane(rb4v, g & (GM_WAVE - 1)), wo, wa);
+      cgb_read<N>(img, readlane(rb4v, (g + 1) & (GM_WAVE - 1)), wo, wb);
+      row(wa);
+      row(wb);
+    }
+  } else {
+    (void)wb;
+  }
   for (; g < gend; ++g) {
     cgb_read<N>(img, readlane(rb4v, g & (GM_WAVE - 1)), wo, wa);
     row(wa);
