@@ -1343,8 +1343,9 @@ def main():
         traffic, traffic_src = {}, "off"
         if a.traffic == "auto":
             # N > 1: ONE rocprofv3 pass pair of rank 0's share on rank 0's GPU (the other ranks wait in the closing barrier)
+            # (the issue-side passes only at N = 1: a property of the kernels, and at N > 1 the other ranks wait in the closing barrier meanwhile)
             got, traffic_src = measure_traffic(a, [x["workload"] for x in recs], share=(0, world) if world > 1 else (a.share_rank, max(a.share_world, 1)),
-                                               device=r.local_rank)
+                                               device=r.local_rank, issue=(world == 1))
             traffic = got or {}
         if (a.traffic == "file" or (a.traffic == "auto" and not traffic)) and os.path.exists(os.path.join(ROOT, "profiles", "traffic.json")):
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))

@@ -80,21 +80,26 @@ __global__ __launch_bounds__(WAVES *GM_WAVE) void clique_mma_kernel(const Clique
   const int l31 = lane & 31, h = lane >> 5;
   const bool topo = p.topo != 0;
   unsigned long long tot = 0;
+  // (round 6: the dequeue of the NEXT entry is issued before the current one is worked on, and an entry's {d+, matrix offset} is one record
+  // in queue order -- the chain atomic -> slot -> vertex -> row bounds / offset -> matrix words was five dependent round trips per vertex)
+  if (tid == 0) S.queue_pos = atomicAdd(p.queue, 1u);
+  __syncthreads();
   for (;;) {
-    if (tid == 0) S.queue_pos = atomicAdd(p.queue, 1u);
-    __syncthreads();
     const unsigned q = S.queue_pos;
     // column blocks: a queue entry is ONE block of a vertex (entry = slot * 8 + block) -- independent sums, and a rank's share of the
     // few widest vertices balances block by block
     constexpr int kBlkShift = BLOCKS ? 3 : 0;
     if (q >= ((unsigned)p.count << kBlkShift)) break;
-    const int slot = p.slots[q >> kBlkShift];
-    const int u = p.verts[slot];
-    const int d = p.rp[u + 1] - p.rp[u], stride = (d + 31) >> 5;
-    const unsigned *__restrict__ gm = p.mat + p.base[slot];
+    __syncthreads();  // (everybody has read the queue word)
+    unsigned qn = 0u;
+    if (tid == 0) qn = atomicAdd(p.queue, 1u);  // in flight while this entry is counted; published at the bottom
+    const int4 qr = p.qrec[q >> kBlkShift];
+    const int d = qr.x, stride = (d + 31) >> 5;
+    const unsigned *__restrict__ gm = p.mat + (((unsigned long long)(unsigned)qr.z << 32) | (unsigned long long)(unsigned)qr.y);
     const int cw = BLOCKS ? clique_mma_block_words(d, WORDS) : ((stride + 1) & ~1);
     const int c0 = BLOCKS ? (int)(q & 7u) * cw : 0;
     if (c0 >= stride) {  // (workgroup-uniform: this vertex has fewer blocks)
+      if (tid == 0) S.queue_pos = qn;
       __syncthreads();
       continue;
     }
@@ -194,6 +199,7 @@ __global__ __launch_bounds__(WAVES *GM_WAVE) void clique_mma_kernel(const Clique
       }
     }
     tot += (unsigned long long)c;
+    if (tid == 0) S.queue_pos = qn;
     __syncthreads();  // the block is rewritten by the next queue entry
   }
   const unsigned long long s0 = wave_sum_u64(tot);

@@ -245,6 +245,7 @@ struct CliquePlan {
   int *d_verts = nullptr;
   unsigned long long *d_slot_base = nullptr;  // slot -> word offset of its matrix inside its round's arena
   int *d_mcls_slots = nullptr;
+  int4 *d_mcls_rec = nullptr;        // per entry of d_mcls_slots: {d+, word offset of the matrix (low, high), 0} (gm_cmma.hip)
   int core_base = -1;                // >= 0: the rows of the wide vertices' matrices whose first endpoint is >= core_base are gathered from the
                                      // core bitmap of the graph (gm_cgather.hip); the task lists of the streamed build leave them out
   std::vector<CliqueRound> rounds;

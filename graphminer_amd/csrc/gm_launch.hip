@@ -675,6 +675,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
         c.base = plan->d_slot_base;
         c.mat = g->d_wide_mat;
         c.slots = plan->d_mcls_slots + rd.mcls_begin[cls];
+        c.qrec = plan->d_mcls_rec + rd.mcls_begin[cls];
         c.count = (int)(rd.mcls_begin[cls + 1] - rd.mcls_begin[cls]);
         c.queue = g->d_wide_queue + qword++;
         c.counters = g->d_counters;

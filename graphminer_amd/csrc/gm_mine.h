@@ -309,6 +309,7 @@ struct CliqueCountParams {
   const unsigned long long *base;   // slot -> word offset of the vertex's matrix in `mat`
   const unsigned *mat;              // matrix arena
   const int *slots;                 // the slots of this launch (one count class), heaviest first
+  const int4 *qrec;                 // ... and, in the same order, {d+, matrix offset low, high, -}: ONE load behind the dequeue instead of slot -> vertex -> row bounds + offset
   int count;
   unsigned *queue;                  // dequeue head (zeroed before launch; its own word)
   unsigned long long *counters;     // [0] += 4-cliques

@@ -2063,10 +2063,19 @@ int clique_wide_min_words() {
   return v;
 }
 
+__global__ __launch_bounds__(256) void mcls_rec_kernel(int n, const int *__restrict__ slots, const int *__restrict__ verts, const int *__restrict__ rp,
+                                                       const unsigned long long *__restrict__ slot_base, int4 *__restrict__ rec) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int slot = slots[k], u = verts[slot];
+  const unsigned long long b = slot_base[slot];
+  rec[k] = make_int4(rp[u + 1] - rp[u], (int)(unsigned)b, (int)(unsigned)(b >> 32), 0);
+}
 static void free_clique_plan(CliquePlan &pl) {
   if (pl.d_verts) (void)hipFree(pl.d_verts);
   if (pl.d_slot_base) (void)hipFree(pl.d_slot_base);
   if (pl.d_mcls_slots) (void)hipFree(pl.d_mcls_slots);
+  if (pl.d_mcls_rec) (void)hipFree(pl.d_mcls_rec);
   for (auto &rd : pl.rounds) {
     if (rd.d_base) (void)hipFree(rd.d_base);
     if (rd.d_tasks) (void)hipFree(rd.d_tasks);
@@ -2077,7 +2086,7 @@ static void free_clique_plan(CliquePlan &pl) {
     free_table(rd.host_tab);
   }
   pl.rounds.clear();
-  pl.d_verts = nullptr; pl.d_slot_base = nullptr; pl.d_mcls_slots = nullptr;
+  pl.d_verts = nullptr; pl.d_slot_base = nullptr; pl.d_mcls_slots = nullptr; pl.d_mcls_rec = nullptr;
 }
 void free_clique_plans(gm_graph *g) {
   for (auto &pl : g->clique_plans) free_clique_plan(pl);
@@ -2333,6 +2342,11 @@ int get_clique_plan(gm_graph *g, int rank, int world, int policy, int target, un
       if (rc2) { free_clique_plan(pl); return rc2; }
     }
     need_words = std::max(need_words, pl.rounds[r].words);
+  }
+  if (!mcls_slots.empty()) {  // (the slot offsets are known now: the records the count kernels read behind their dequeue)
+    HIP_TRY(dev_malloc(&pl.d_mcls_rec, sizeof(int4) * mcls_slots.size()));
+    hipLaunchKernelGGL(mcls_rec_kernel, blocks((long long)mcls_slots.size()), dim3(256), 0, 0, (int)mcls_slots.size(), pl.d_mcls_slots, pl.d_verts, g->d_rp,
+                       pl.d_slot_base, pl.d_mcls_rec);
   }
   setup_trace("clique: rounds built");
   const size_t need = (size_t)need_words * 4;
