@@ -34,9 +34,13 @@ struct alignas(16) CBuildLds {
   int trpl[kMaxChunkVerts + 1];    // row offsets of the chunk's task lists
   unsigned rows[WAVES][kCbRowBuf];
   HsWave<STAGE> w[WAVES];                 // (while the set is built: the fill counters of its buckets)
+  // the chunk being worked on and the NEXT one (round 6): queue position, record, start and number of its tasks -- fetched by thread 0 while the
+  // other waves stream the current chunk's batches; the chain dequeue -> order -> record -> task bounds was four dependent round trips per chunk
+  ChunkRec grec[2];
+  unsigned gq[2];
+  int gtb[2], gnt[2];
   int next_batch;
-  unsigned queue_pos;
-  int pad_;
+  int pad_[3];
 };
 
 template <int STAGE, int WAVES>
@@ -55,21 +59,38 @@ void cbuild_kernel(const CBuildParams p) {
   unsigned *__restrict__ mat = p.mat;
   HsWave<STAGE> &L = B.w[wave];
   unsigned *rb = B.rows[wave];
-  for (;;) {
-    if (tid == 0) B.queue_pos = atomicAdd(p.queue, 1u);
-    __syncthreads();
-    const unsigned q = B.queue_pos;
+  auto fetch = [&](const int slot) {  // thread 0: dequeue + the chunk's record and task bounds into slot `slot`
+    const unsigned qq = atomicAdd(p.queue, 1u);
+    B.gq[slot] = qq;
+    if (qq < (unsigned)p.count) {
+      const ChunkRec rr = p.chunks[p.order ? p.order[qq] : (int)qq];
+      const int t0 = trp[rr.u_begin];
+      B.grec[slot] = rr;
+      B.gtb[slot] = t0;
+      B.gnt[slot] = trp[rr.u_end] - t0;
+    }
+  };
+  if (tid == 0) fetch(0);
+  __syncthreads();
+  for (int it = 0;; ++it) {
+    const int cur = it & 1;
+    const unsigned q = B.gq[cur];
     if (q >= (unsigned)p.count) break;
-    const ChunkRec r = p.chunks[p.order ? p.order[q] : (int)q];
+    const ChunkRec r = B.grec[cur];
     const int ub = r.u_begin, nvl = r.u_end - r.u_begin;
     const int eb = r.e_begin, nel = r.e_end - r.e_begin;
-    const int tb = trp[ub], ntask = trp[ub + nvl] - tb;
-    if (ntask == 0) { __syncthreads(); continue; }  // (these vertices host nothing for this rank: nothing to stage)
+    const int tb = B.gtb[cur], ntask = B.gnt[cur];
+    if (ntask == 0) {  // (workgroup-uniform: these vertices host nothing for this rank -- nothing to stage)
+      if (tid == 0) fetch(cur ^ 1);
+      __syncthreads();
+      continue;
+    }
     // ---- workgroup: the chunk's DAG rows into the set -------------------------------------------------------------------
     for (int i = tid; i <= nvl; i += nthreads) B.trpl[i] = trp[ub + i];
     if (tid == 0) B.next_batch = 0;
     const bool fallback = hs_build<STAGE, nthreads>(B.set, reinterpret_cast<unsigned *>(&B.w[0]), rp, col, ub, nvl, eb, nel,
                                                      (p.flags & (1 << 22)) != 0, tid);  // (ends with a barrier)
+    if (tid == 0) fetch(cur ^ 1);  // (its wave joins the batches when the three loads are back; the others have started)
     // ---- waves: batches of 64 tasks, sub-batches of as many rows as the wave's row buffer holds -----------------------------
     // (a chunk with few tasks -- the share of one rank of eight holds ~125 per chunk -- takes smaller batches, so that all waves
     // get some: with 64 two waves of every workgroup idled, the build of a 1/8 share ran at 0.68 of its ideal)
