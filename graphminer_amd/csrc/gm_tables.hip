@@ -1957,7 +1957,10 @@ __global__ __launch_bounds__(256) void cgb_item_place_kernel(long long n, const 
   if (k >= n) return;
   if (flag[k]) items[pos[k]] = make_int2((int)k, (int)keys[k]);
 }
-constexpr unsigned long long kCgbItemCost = 1ull << 20;  // probes (+ overheads) of a work item: ~80 us of one workgroup
+#ifndef GM_CGB_ITEM_COST
+#define GM_CGB_ITEM_COST (1ull << 20)
+#endif
+constexpr unsigned long long kCgbItemCost = GM_CGB_ITEM_COST;  // probes (+ overheads) of a work item: ~80 us of one workgroup
 static int build_gather_index(gm_graph *g, CliquePlan &pl, CliqueRound &rd, ScanTemp &tmp) {
   const int nslots = (int)(rd.w1 - rd.w0);
   if (nslots <= 0 || pl.core_base < 0 || g->cg_tri_state != 1 || rd.words >= (1ull << 32)) return GM_OK;  // (no index: the row-major gather)
