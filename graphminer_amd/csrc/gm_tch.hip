@@ -45,13 +45,22 @@ struct alignas(16) TchWave {
   unsigned bits[BITWIN / 32 + 8];  // list-start marks of the flattened positions, one bit each (+ the over-read of the last group)
 };
 
+// waves of a workgroup: four on the 1024-bucket table; GM_TCH_WAVES_BIG on the 2048-bucket one (the hosts with rows of 1025 .. 2048 entries)
+#ifndef GM_TCH_WAVES_BIG
+#define GM_TCH_WAVES_BIG 4
+#endif
+#ifndef GM_TCH_MIN_WG_BIG
+#define GM_TCH_MIN_WG_BIG 4
+#endif
+template <int STAGE>
+constexpr int tch_waves() { return STAGE <= 1024 ? kWavesPerBlock : GM_TCH_WAVES_BIG; }
 template <int STAGE>
 struct alignas(16) TchLds {
   uint4 table[STAGE];              // buckets of four ids
   int rpl[kMaxChunkVerts + 1];     // row offsets of the chunk's DAG rows (global entry indices)
   int trpl[kMaxChunkVerts + 1];    // row offsets of its task lists
   static constexpr int kBitWindow = STAGE <= 1024 ? 8192 : 4096;
-  TchWave<kBitWindow> w[kWavesPerBlock];  // (while the table is built: packed 16-bit fill counters of the buckets)
+  TchWave<kBitWindow> w[tch_waves<STAGE>()];  // (while the table is built: packed 16-bit fill counters of the buckets)
   int ovf_key[kTchOvfCap];
   int ovf_salt[kTchOvfCap];
   int n_ovf;
@@ -299,13 +308,14 @@ __device__ __forceinline__ unsigned tch_pass(TchLds<STAGE> &B, TchWave<TchLds<ST
 #define GM_TCH_MIN_WG 6
 #endif
 template <int STAGE>
-__global__ __launch_bounds__((kWavesPerBlock * GM_WAVE), (STAGE <= 1024 ? GM_TCH_MIN_WG : 4))
+__global__ __launch_bounds__((tch_waves<STAGE>() * GM_WAVE), (STAGE <= 1024 ? GM_TCH_MIN_WG : GM_TCH_MIN_WG_BIG))
 void tch_kernel(const MineParams p) {
   __shared__ TchLds<STAGE> B;
   using H = TchHash<STAGE>;
   const int lane = threadIdx.x & (GM_WAVE - 1);
   const int wave = threadIdx.x >> 6;
-  const int tid = threadIdx.x, nthreads = kWavesPerBlock * GM_WAVE;
+  constexpr int nthreads = tch_waves<STAGE>() * GM_WAVE;
+  const int tid = threadIdx.x;
   const int *__restrict__ rp = p.g.rp;
   const int *__restrict__ col = p.g.col;
   const int *__restrict__ trp = p.g.trp;
@@ -491,15 +501,18 @@ void tch_kernel(const MineParams p) {
 }
 
 // 1024 buckets (16 KB of LDS + 7.6 KB: six workgroups per CU) or 2048 (32 KB: four) -- the longest DAG row must fit
-int tch_per_cu(int stage) { return stage <= 1024 ? 6 : 4; }
+int tch_per_cu(int stage) {
+  if (stage <= 1024) return 6;
+  return (int)std::max<size_t>(1, std::min<size_t>(163840 / sizeof(TchLds<kTctStageMax>), 2048 / (tch_waves<kTctStageMax>() * GM_WAVE)));
+}
 hipError_t launch_tch(const MineParams &p, int stage, int grid_blocks, hipStream_t stream) {
   static_assert(sizeof(TchLds<1024>) * 6 <= 163840, "six workgroups per CU");
-  static_assert(sizeof(TchLds<kTctStageMax>) * 4 <= 163840, "four workgroups per CU");
-  static_assert(sizeof(TchWave<4096>) * kWavesPerBlock >= (size_t)kTctStageMax * 2, "fill counters alias the wave scratch");
+  static_assert(sizeof(TchLds<kTctStageMax>) <= 163840, "one workgroup per CU at least");
+  static_assert(sizeof(TchWave<4096>) * tch_waves<kTctStageMax>() >= (size_t)kTctStageMax * 2, "fill counters alias the wave scratch");
   if (p.g.trp == nullptr || p.g.tdesc == nullptr) return hipErrorInvalidValue;
-  const dim3 grid((unsigned)grid_blocks), block(kWavesPerBlock * GM_WAVE);
-  if (stage <= 1024) hipLaunchKernelGGL((tch_kernel<1024>), grid, block, 0, stream, p);
-  else hipLaunchKernelGGL((tch_kernel<kTctStageMax>), grid, block, 0, stream, p);
+  const dim3 grid((unsigned)grid_blocks);
+  if (stage <= 1024) hipLaunchKernelGGL((tch_kernel<1024>), grid, dim3(kWavesPerBlock * GM_WAVE), 0, stream, p);
+  else hipLaunchKernelGGL((tch_kernel<kTctStageMax>), grid, dim3(tch_waves<kTctStageMax>() * GM_WAVE), 0, stream, p);
   return hipGetLastError();
 }
 
