@@ -1,6 +1,7 @@
 // gm_graph.hip -- the device graph handle behind include/graphminer_amd.h: upload / adopt (GraphGPU::init, include/graph_gpu.h:69-122),
 // Graph::orientation and Graph::sort_neighbors on the GPU (src/common/graph.cc:233-279,138-146), degree renumbering, download.
 #include "gm_host.h"
+#include <unordered_map>
 #include "gm_scan.h"
 #include "gm_setops.h"
 using namespace gm;
@@ -52,15 +53,74 @@ struct BigBlock { void *p; size_t bytes; int device; };
 std::mutex g_big_mu;
 std::vector<BigBlock> g_big_blocks;
 constexpr size_t kBigCacheBudget = (size_t)16 << 30;  // per device
-constexpr size_t kBigCacheBlocks = 64;                // per device
+constexpr size_t kBigCacheBlocks = 512;               // per device (temporaries AND the persistent arrays of freed handles)
 bool big_cache_on() { return gm_opt("GM_NO_TEMP_POOL") == nullptr; }  // (read at every call: tests switch it inside one process)
+// Blocks of >= kBigCacheMinBytes that dev_malloc handed out (persistent arrays of a handle: key stream, task lists, matrices, tables): their
+// sizes, so that dev_free can put them into the same per-device cache instead of giving them back to the driver -- a FRESH handle on a device
+// that still has a live one then builds everything without a single hipMalloc / hipFree (round 6: both cost 0.01 - 0.2 ms on a good day and tens
+// of ms per GB in windows of seconds, profiles/r05/alloc_jitter.txt; the driver's round-6 mid run saw first calls of 57 / 82 / 267 / 399 ms for
+// 9 / 16 / 41 / 69).  The cache is emptied when the LAST handle of the device is freed, and whenever an allocation meets an out-of-memory error.
+std::unordered_map<void *, size_t> g_dev_sizes;  // (under g_big_mu)
+int g_live_handles[64] = {0};                    // (under g_big_mu) handles alive per device
+bool cache_take(int dev, size_t bytes, size_t max_bytes, void **p, size_t *got) {  // (caller holds g_big_mu) the smallest cached block in [bytes, max_bytes]
+  size_t best = g_big_blocks.size();
+  for (size_t i = 0; i < g_big_blocks.size(); ++i) {
+    const BigBlock &b = g_big_blocks[i];
+    if (b.device == dev && b.bytes >= bytes && b.bytes <= max_bytes && (best == g_big_blocks.size() || b.bytes < g_big_blocks[best].bytes)) best = i;
+  }
+  if (best == g_big_blocks.size()) return false;
+  *p = g_big_blocks[best].p;
+  *got = g_big_blocks[best].bytes;
+  g_big_blocks.erase(g_big_blocks.begin() + (long)best);
+  return true;
+}
 }  // namespace
+void dev_handle_born(int device) {
+  std::lock_guard<std::mutex> lk(g_big_mu);
+  if (device >= 0 && device < 64) ++g_live_handles[device];
+}
+bool dev_handle_died(int device) {  // true: it was the device's last one
+  std::lock_guard<std::mutex> lk(g_big_mu);
+  if (device < 0 || device >= 64) return true;
+  return --g_live_handles[device] <= 0;
+}
 hipError_t dev_malloc_bytes(void **p, size_t bytes) {
-  const hipError_t e = hipMalloc(p, bytes);
-  if (e != hipErrorOutOfMemory) return e;
-  (void)hipGetLastError();  // no room: the cached temporaries of this device go back to the driver, then once more
-  big_cache_trim();
-  return hipMalloc(p, bytes);
+  const bool cached = bytes >= kBigCacheMinBytes && big_cache_on();
+  int dev = 0;
+  if (cached) {
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_big_mu);
+    size_t got = 0;
+    if (cache_take(dev, bytes, bytes + bytes / 4, p, &got)) {  // (a persistent array: a block at most a quarter larger than asked for)
+      g_dev_sizes[*p] = got;
+      return hipSuccess;  // (big_cache_put synchronised the device before the block went in)
+    }
+  }
+  hipError_t e = hipMalloc(p, bytes);
+  if (e == hipErrorOutOfMemory) {
+    (void)hipGetLastError();  // no room: the cached blocks of this device go back to the driver, then once more
+    big_cache_trim();
+    e = hipMalloc(p, bytes);
+  }
+  if (e == hipSuccess && cached) {
+    std::lock_guard<std::mutex> lk(g_big_mu);
+    g_dev_sizes[*p] = bytes;
+  }
+  return e;
+}
+void dev_free(void *p) {
+  if (!p) return;
+  size_t bytes = 0;
+  {
+    std::lock_guard<std::mutex> lk(g_big_mu);
+    auto it = g_dev_sizes.find(p);
+    if (it != g_dev_sizes.end()) {
+      bytes = it->second;
+      g_dev_sizes.erase(it);
+    }
+  }
+  if (bytes) big_cache_put(p, bytes);  // (synchronises the device; beyond the cache's budget: hipFree)
+  else (void)hipFree(p);
 }
 hipError_t big_cache_get(void **p, size_t bytes, size_t *block_bytes) {
   *block_bytes = 0;
@@ -68,28 +128,16 @@ hipError_t big_cache_get(void **p, size_t bytes, size_t *block_bytes) {
   if (on) {
     int dev = 0;
     (void)hipGetDevice(&dev);
-    void *hit = nullptr;
-    size_t hit_bytes = 0;
-    {
-      std::lock_guard<std::mutex> lk(g_big_mu);
-      size_t best = g_big_blocks.size();
-      for (size_t i = 0; i < g_big_blocks.size(); ++i) {  // the smallest block that holds the request without wasting more than 3 / 4 of itself
-        const BigBlock &b = g_big_blocks[i];
-        if (b.device == dev && b.bytes >= bytes && b.bytes / 4 <= bytes && (best == g_big_blocks.size() || b.bytes < g_big_blocks[best].bytes)) best = i;
-      }
-      if (best != g_big_blocks.size()) {
-        hit = g_big_blocks[best].p;
-        hit_bytes = g_big_blocks[best].bytes;
-        g_big_blocks.erase(g_big_blocks.begin() + (long)best);
-      }
-    }
-    if (hit) {
-      *p = hit;
-      *block_bytes = hit_bytes;
-      return hipSuccess;  // (big_cache_put synchronised the device before the block went in)
-    }
+    std::lock_guard<std::mutex> lk(g_big_mu);
+    // (a temporary: the smallest block that holds the request without wasting more than 3 / 4 of itself)
+    if (cache_take(dev, bytes, bytes * 4, p, block_bytes)) return hipSuccess;  // (big_cache_put synchronised the device before the block went in)
   }
-  const hipError_t e = dev_malloc_bytes(p, bytes);
+  hipError_t e = hipMalloc(p, bytes);
+  if (e == hipErrorOutOfMemory) {
+    (void)hipGetLastError();
+    big_cache_trim();
+    e = hipMalloc(p, bytes);
+  }
   if (e == hipSuccess && on) *block_bytes = bytes;  // (0: a plain allocation, freed by hipFree)
   return e;
 }
@@ -189,64 +237,70 @@ extern "C" void gm_graph_free(gm_graph *g) {
   (void)hipSetDevice(g->device);
   free_tables(g);
   for (auto &b : g->bitmap_sets) {
-    if (b.d_bitmaps) (void)hipFree(b.d_bitmaps);
-    if (b.d_row_slot) (void)hipFree(b.d_row_slot);
+    if (b.d_bitmaps) dev_free(b.d_bitmaps);
+    if (b.d_row_slot) dev_free(b.d_row_slot);
   }
-  if (g->d_rp) (void)hipFree(g->d_rp);
-  if (g->d_rp64) (void)hipFree(g->d_rp64);
-  if (g->own_col && g->d_col) (void)hipFree(g->d_col);
-  if (g->d_edesc) (void)hipFree(g->d_edesc);
-  if (g->d_symdeg) (void)hipFree(g->d_symdeg);
-  if (g->d_trp) (void)hipFree(g->d_trp);
-  if (g->d_tdesc) (void)hipFree(g->d_tdesc);
-  if (g->d_tedge) (void)hipFree(g->d_tedge);
+  if (g->d_rp) dev_free(g->d_rp);
+  if (g->d_rp64) dev_free(g->d_rp64);
+  if (g->own_col && g->d_col) dev_free(g->d_col);
+  if (g->d_edesc) dev_free(g->d_edesc);
+  if (g->d_symdeg) dev_free(g->d_symdeg);
+  if (g->d_trp) dev_free(g->d_trp);
+  if (g->d_tdesc) dev_free(g->d_tdesc);
+  if (g->d_tedge) dev_free(g->d_tedge);
   for (void *q : {(void *)g->d_emoff, (void *)g->d_tmoff, (void *)g->d_smask, (void *)g->d_sup_far_rows})
-    if (q) (void)hipFree(q);
-  if (g->d_long_rows) (void)hipFree(g->d_long_rows);
-  if (g->d_long_prefix) (void)hipFree(g->d_long_prefix);
-  if (g->d_colk) (void)hipFree(g->d_colk);
-  if (g->d_tdesck) (void)hipFree(g->d_tdesck);
-  if (g->d_kst) (void)hipFree(g->d_kst);
+    if (q) dev_free(q);
+  if (g->d_long_rows) dev_free(g->d_long_rows);
+  if (g->d_long_prefix) dev_free(g->d_long_prefix);
+  if (g->d_colk) dev_free(g->d_colk);
+  if (g->d_tdesck) dev_free(g->d_tdesck);
+  if (g->d_kst) dev_free(g->d_kst);
   for (void *q : {(void *)g->d_kst_et, (void *)g->d_tedgel, (void *)g->d_kst2, (void *)g->d_tdescl2})
-    if (q) (void)hipFree(q);
-  if (g->d_kst_rp) (void)hipFree(g->d_kst_rp);
-  if (g->d_trpl) (void)hipFree(g->d_trpl);
-  if (g->d_tdescl) (void)hipFree(g->d_tdescl);
-  if (g->d_sup) (void)hipFree(g->d_sup);
+    if (q) dev_free(q);
+  if (g->d_kst_rp) dev_free(g->d_kst_rp);
+  if (g->d_trpl) dev_free(g->d_trpl);
+  if (g->d_tdescl) dev_free(g->d_tdescl);
+  if (g->d_sup) dev_free(g->d_sup);
   free_clique_plans(g);
-  if (g->d_wide_mat) (void)hipFree(g->d_wide_mat);
-  if (g->d_wide_sorted) (void)hipFree(g->d_wide_sorted);
-  if (g->d_wide_queue) (void)hipFree(g->d_wide_queue);
+  if (g->d_wide_mat) dev_free(g->d_wide_mat);
+  if (g->d_wide_sorted) dev_free(g->d_wide_sorted);
+  if (g->d_wide_queue) dev_free(g->d_wide_queue);
   for (auto &st_ : g->aux_stream) if (st_) (void)hipStreamDestroy(st_);
   for (auto &ev_ : g->aux_done) if (ev_) (void)hipEventDestroy(ev_);
-  if (g->pool.base) (void)hipFree(g->pool.base);
-  if (g->d_counters) (void)hipFree(g->d_counters);
-  if (g->d_scratch) (void)hipFree(g->d_scratch);
-  if (g->d_core) (void)hipFree(g->d_core);
+  if (g->pool.base) dev_free(g->pool.base);
+  if (g->d_counters) dev_free(g->d_counters);
+  if (g->d_scratch) dev_free(g->d_scratch);
+  if (g->d_core) dev_free(g->d_core);
   for (void *q : {(void *)g->d_cg_tri, (void *)g->d_cg_rowbase, (void *)g->d_cg_bid, (void *)g->d_cg_blk})
-    if (q) (void)hipFree(q);
-  if (g->d_csym) (void)hipFree(g->d_csym);
-  if (g->d_cfirst) (void)hipFree(g->d_cfirst);
-  if (g->d_idx0) (void)hipFree(g->d_idx0);
-  if (g->d_wblock_prefix) (void)hipFree(g->d_wblock_prefix);
-  if (g->d_house_prefix) (void)hipFree(g->d_house_prefix);
-  if (g->d_pent_touched) (void)hipFree(g->d_pent_touched);
-  if (g->d_house_t) (void)hipFree(g->d_house_t);
-  if (g->d_house_tlt) (void)hipFree(g->d_house_tlt);
-  if (g->d_house_tasks) (void)hipFree(g->d_house_tasks);
-  if (g->d_house_acc) (void)hipFree(g->d_house_acc);
-  if (g->d_house_touched) (void)hipFree(g->d_house_touched);
-  if (g->d_rect_tasks) (void)hipFree(g->d_rect_tasks);
-  if (g->d_rect_acc) (void)hipFree(g->d_rect_acc);
+    if (q) dev_free(q);
+  if (g->d_csym) dev_free(g->d_csym);
+  if (g->d_cfirst) dev_free(g->d_cfirst);
+  if (g->d_idx0) dev_free(g->d_idx0);
+  if (g->d_wblock_prefix) dev_free(g->d_wblock_prefix);
+  if (g->d_house_prefix) dev_free(g->d_house_prefix);
+  if (g->d_pent_touched) dev_free(g->d_pent_touched);
+  if (g->d_house_t) dev_free(g->d_house_t);
+  if (g->d_house_tlt) dev_free(g->d_house_tlt);
+  if (g->d_house_tasks) dev_free(g->d_house_tasks);
+  if (g->d_house_acc) dev_free(g->d_house_acc);
+  if (g->d_house_touched) dev_free(g->d_house_touched);
+  if (g->d_rect_tasks) dev_free(g->d_rect_tasks);
+  if (g->d_rect_acc) dev_free(g->d_rect_acc);
   for (auto &pr : g->ev)
     for (auto &e : pr)
       if (e) (void)hipEventDestroy(e);
-  const bool root = g->pool_owner == nullptr;
+  const bool last = g->counted && dev_handle_died(g->device);
   delete g;
-  if (root) big_cache_trim();  // the large temporaries kept for reuse go back to the driver with the handle (not inside a timed call)
+  // the blocks kept for reuse -- large temporaries, and the persistent arrays of freed handles (dev_free) -- go back to the driver with the
+  // device's LAST handle (not inside a timed call); while another handle lives they serve the next one
+  if (last) big_cache_trim();
 }
 
 int finish_handle(gm_graph *g) {
+  if (!g->counted) {
+    g->counted = true;
+    dev_handle_born(g->device);
+  }
   static std::once_flag warm;  // once per process: load every kernel module now, not inside the first (timed) table build or launch
   std::call_once(warm, [] {
     gm_touch_mine();
@@ -707,7 +761,7 @@ static int orient_impl(const gm_graph *sym, const OffT *rp_in, gm_graph **out) {
   // the topological renumbering of this DAG sorts by -- get_relabeled mode 2)
   int *sdeg = nullptr;
   HIP_TRY(dev_malloc(&sdeg, sizeof(int) * (size_t)std::max(nv, 1)));
-  struct SdegGuard { int *&p; ~SdegGuard() { if (p) (void)hipFree(p); } } sdeg_guard{sdeg};
+  struct SdegGuard { int *&p; ~SdegGuard() { if (p) dev_free(p); } } sdeg_guard{sdeg};
   if (nv > 0) hipLaunchKernelGGL((symdeg_kernel<OffT>), dim3(vb), dim3(256), 0, 0, nv, rp_in, sdeg);
   // segment table of the long rows (device): counts -> exclusive scan -> fill
   DevBuf<int> nseg_of, seg_first, deg, segcnt;

@@ -70,6 +70,9 @@ constexpr size_t kBigCacheMinBytes = (size_t)4 << 20;
 // temporaries of this device go back to the driver and the request is made once more -- the cache may park up to its budget of memory
 // that nothing else can reach, and a setup path must not fail (or quietly drop an optimisation) while it does.
 hipError_t dev_malloc_bytes(void **p, size_t bytes);
+void dev_free(void *p);           // the counterpart: a block of >= kBigCacheMinBytes goes to the device's cache, anything else to hipFree
+void dev_handle_born(int device);  // (gm_graph.hip: the cache lives as long as the device has a handle)
+bool dev_handle_died(int device);
 template <class T>
 inline hipError_t dev_malloc(T **p, size_t bytes) { return dev_malloc_bytes(reinterpret_cast<void **>(p), bytes); }
 
@@ -86,7 +89,7 @@ struct DevBuf {  // RAII device array; pooled when a PoolScope is open and the p
   void drop() {
     if (p && !pooled) {
       if (block_bytes) big_cache_put(p, block_bytes);
-      else (void)hipFree(p);
+      else dev_free(p);
     }
     p = nullptr;
     pooled = false;
@@ -393,6 +396,7 @@ struct gm_graph {
   hipStream_t aux_stream[3] = {nullptr, nullptr, nullptr};  // class kernels that cannot fill the chip run beside the others (run_pattern)
   hipEvent_t aux_done[3] = {nullptr, nullptr, nullptr};
   TempPool pool;  // temporaries of the setup paths (PoolScope)
+  bool counted = false;            // finish_handle has registered the handle with its device (dev_handle_born)
   gm_graph *pool_owner = nullptr;  // a derived handle (renumbered copy, cached orientation) borrows its owner's pool: the owner outlives it,
                                    // and one caller works on a handle family at a time -- a pool of its own is ~0.8 ms of hipMalloc
   gm_setup_times setup = {0, 0, 0, 0, 0};  // accumulated pre-processing time of this handle (gm_graph_setup_times)

@@ -56,7 +56,7 @@ static int giant_task_edges(gm_graph *g, unsigned long long *out) {
     if (e == hipSuccess && g->nv > 0)
       hipLaunchKernelGGL(giant_edges_kernel, dim3((unsigned)std::min<long long>(((long long)g->nv + 255) / 256, 2048)), dim3(256), 0, 0, g->nv, g->d_rp, d_s);
     if (e == hipSuccess) e = hipMemcpy(&s, d_s, 8, hipMemcpyDeviceToHost);
-    (void)hipFree(d_s);
+    dev_free(d_s);
     if (e != hipSuccess) return hip_fail(e, "giant_edges_kernel", __FILE__, __LINE__);
     g->giant_edges = s;
   }
@@ -507,7 +507,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
     }
     const size_t need = (size_t)slot_words * sizeof(unsigned) * (size_t)grid;
     if (need > g->scratch_bytes) {
-      if (g->d_scratch) (void)hipFree(g->d_scratch);
+      if (g->d_scratch) dev_free(g->d_scratch);
       g->d_scratch = nullptr;
       g->scratch_bytes = 0;
       HIP_TRY(dev_malloc(&g->d_scratch, need));
@@ -540,7 +540,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
     if (tab_cls[3] && tab_cls[3]->n > 0) {
       const size_t need = (size_t)giant_scratch_words(g->max_deg) * sizeof(unsigned) * (size_t)g->cu_count * (size_t)giant_per_cu();
       if (need > g->scratch_bytes) {
-        if (g->d_scratch) (void)hipFree(g->d_scratch);
+        if (g->d_scratch) dev_free(g->d_scratch);
         g->d_scratch = nullptr;
         g->scratch_bytes = 0;
         HIP_TRY(dev_malloc(&g->d_scratch, need));
@@ -869,7 +869,7 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
     HIP_TRY(hipStreamSynchronize(stream));
     std::vector<unsigned long long> ticks(tab->n);
     HIP_TRY(hipMemcpy(ticks.data(), d_ticks, sizeof(unsigned long long) * tab->n, hipMemcpyDeviceToHost));
-    (void)hipFree(d_ticks);
+    dev_free(d_ticks);
     std::vector<ChunkRec> recs(tab->n);
     HIP_TRY(hipMemcpy(recs.data(), tab->d, sizeof(ChunkRec) * tab->n, hipMemcpyDeviceToHost));
     if (int rcv = table_host_views(g, tab)) return rcv;
@@ -985,7 +985,7 @@ int ensure_mean_sq_deg(gm_graph *self) {
     if (e == hipSuccess && self->nv > 0)
       hipLaunchKernelGGL(sum_sq_deg_kernel, dim3((unsigned)std::min<long long>(((long long)self->nv + 255) / 256, 2048)), dim3(256), 0, 0, self->nv, self->d_rp, d_s);
     if (e == hipSuccess) e = hipMemcpy(&s2, d_s, 8, hipMemcpyDeviceToHost);
-    (void)hipFree(d_s);
+    dev_free(d_s);
     if (e != hipSuccess) return hip_fail(e, "sum_sq_deg_kernel", __FILE__, __LINE__);
     self->mean_sq_deg = self->ne > 0 ? (double)s2 / (double)self->ne : 0.0;
   }
@@ -1135,7 +1135,7 @@ static int run_rect_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h_
     std::vector<unsigned long long> work(std::max<size_t>(nv, 1));
     hipError_t e = nv ? launch_rect_work(gv, g->d_idx0, d_work, 0) : hipSuccess;
     if (e == hipSuccess) e = hipMemcpy(work.data(), d_work, sizeof(unsigned long long) * nv, hipMemcpyDeviceToHost);
-    (void)hipFree(d_work);
+    dev_free(d_work);
     if (e != hipSuccess) return hip_fail(e, "rect_work_kernel", __FILE__, __LINE__);
     std::vector<int> vs;
     vs.reserve(nv);
@@ -1180,7 +1180,7 @@ static int run_rect_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h_
   grid = std::max<long long>(1, std::min<long long>(grid, count));
   const size_t need = (size_t)per_wg * (size_t)grid;
   if (need > g->rect_acc_bytes) {
-    if (g->d_rect_acc) (void)hipFree(g->d_rect_acc);
+    if (g->d_rect_acc) dev_free(g->d_rect_acc);
     g->d_rect_acc = nullptr;
     g->rect_acc_bytes = 0;
     HIP_TRY(dev_malloc(&g->d_rect_acc, need));
@@ -1189,7 +1189,7 @@ static int run_rect_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h_
   }
   p.acc = g->d_rect_acc;
   if (need > g->pent_touched_bytes) {  // touched-vertex lists: same shape as the maps (one int list of up to nv entries per wave)
-    if (g->d_pent_touched) (void)hipFree(g->d_pent_touched);
+    if (g->d_pent_touched) dev_free(g->d_pent_touched);
     g->d_pent_touched = nullptr;
     g->pent_touched_bytes = 0;
     HIP_TRY(dev_malloc(&g->d_pent_touched, need));
@@ -1269,7 +1269,7 @@ static int run_house_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h
     std::vector<unsigned long long> work(std::max<size_t>(nv, 1));
     hipError_t e = nv ? launch_house_work(gv, d_work, 0) : hipSuccess;
     if (e == hipSuccess) e = hipMemcpy(work.data(), d_work, sizeof(unsigned long long) * nv, hipMemcpyDeviceToHost);
-    (void)hipFree(d_work);
+    dev_free(d_work);
     if (e != hipSuccess) return hip_fail(e, "house_work_kernel", __FILE__, __LINE__);
     std::vector<int> vs;
     vs.reserve(nv);
@@ -1314,12 +1314,12 @@ static int run_house_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h
   grid = std::max<long long>(1, std::min<long long>(grid, count));
   const size_t need = (size_t)per_wg * (size_t)grid;
   if (need > g->house_acc_bytes) {
-    if (g->d_house_acc) (void)hipFree(g->d_house_acc);
+    if (g->d_house_acc) dev_free(g->d_house_acc);
     g->d_house_acc = nullptr;
     g->house_acc_bytes = 0;
     HIP_TRY(dev_malloc(&g->d_house_acc, need));
     HIP_TRY(hipMemset(g->d_house_acc, 0, need));  // every launch leaves the maps zeroed again
-    if (g->d_house_touched) (void)hipFree(g->d_house_touched);
+    if (g->d_house_touched) dev_free(g->d_house_touched);
     g->d_house_touched = nullptr;
     HIP_TRY(dev_malloc(&g->d_house_touched, need / 2));  // one int list per map
     g->house_acc_bytes = need;
@@ -1353,7 +1353,7 @@ static int run_house_flat(const gm_graph *cg, const gm_launch *la_in, uint64_t *
     std::vector<unsigned> nblk(std::max<size_t>(ne, 1));
     hipError_t e = ne ? launch_house_blocks(gv, d_nblk, 0) : hipSuccess;
     if (e == hipSuccess) e = hipMemcpy(nblk.data(), d_nblk, sizeof(unsigned) * ne, hipMemcpyDeviceToHost);
-    (void)hipFree(d_nblk);
+    dev_free(d_nblk);
     if (e != hipSuccess) return hip_fail(e, "house block table", __FILE__, __LINE__);
     std::vector<unsigned long long> pre(ne + 1);
     unsigned long long acc = 0;
@@ -1413,7 +1413,7 @@ static int run_sgl_nested(int pat, const gm_graph *cg, const gm_launch *la_in, u
   if (pat == SGL_HOUSE || pat == SGL_DIAMOND) {  // per-wave list for the materialised S = N(v0) ^ N(v1)
     const size_t need = (size_t)grid * 4 * (size_t)p.max_deg * sizeof(int);
     if (need > g->scratch_bytes) {
-      if (g->d_scratch) (void)hipFree(g->d_scratch);
+      if (g->d_scratch) dev_free(g->d_scratch);
       g->d_scratch = nullptr;
       g->scratch_bytes = 0;
       HIP_TRY(dev_malloc(&g->d_scratch, need));

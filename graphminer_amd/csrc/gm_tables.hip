@@ -6,16 +6,16 @@
 using namespace gm;
 
 static void free_table(ChunkTable &t) {
-  if (t.d) (void)hipFree(t.d);
-  if (t.d_slot) (void)hipFree(t.d_slot);
-  if (t.d_row_slot && t.own_bitmaps) (void)hipFree(t.d_row_slot);
-  for (int i = 0; i < 2; ++i) if (t.d_order[i]) (void)hipFree(t.d_order[i]);
-  if (t.d_bitmaps && t.own_bitmaps) (void)hipFree(t.d_bitmaps);
-  if (t.d_edges) (void)hipFree(t.d_edges);
-  if (t.d_firstv) (void)hipFree(t.d_firstv);
-  if (t.d_cost) (void)hipFree(t.d_cost);
+  if (t.d) dev_free(t.d);
+  if (t.d_slot) dev_free(t.d_slot);
+  if (t.d_row_slot && t.own_bitmaps) dev_free(t.d_row_slot);
+  for (int i = 0; i < 2; ++i) if (t.d_order[i]) dev_free(t.d_order[i]);
+  if (t.d_bitmaps && t.own_bitmaps) dev_free(t.d_bitmaps);
+  if (t.d_edges) dev_free(t.d_edges);
+  if (t.d_firstv) dev_free(t.d_firstv);
+  if (t.d_cost) dev_free(t.d_cost);
   for (auto &sh : t.shares)
-    if (sh.d) (void)hipFree(sh.d);
+    if (sh.d) dev_free(sh.d);
   t.shares.clear();
   t.d_edges = t.d_firstv = nullptr; t.d_cost = nullptr;
   t.d = nullptr; t.d_slot = nullptr; t.d_row_slot = nullptr; t.d_order[0] = t.d_order[1] = nullptr; t.d_bitmaps = nullptr;
@@ -376,7 +376,7 @@ static int build_table_device(gm_graph *g, ChunkTable &t, bool sym_table, double
   int n = 0;
   HIP_TRY(hipMemcpy(&n, off.p + n0, sizeof(int), hipMemcpyDeviceToHost));
   setup_trace("table: walk emit, cost, parts");
-  (void)hipFree(t.d);
+  dev_free(t.d);
   t.d = nullptr;
   HIP_TRY(dev_malloc(&t.d, sizeof(ChunkRec) * (size_t)n));
   setup_trace("table: free + alloc of the records");
@@ -593,7 +593,7 @@ int get_share_order(gm_graph *g, ChunkTable *t, int world, int rank, int policy,
     HIP_TRY(dev_malloc(&sh.d, sizeof(int) * (size_t)std::max(cnt, 1)));
     hipLaunchKernelGGL(share_emit_kernel, grid, block, 0, 0, n, order, flag.p, off.p, t->d_edges, sh.d, esum.p);
     if (hipMemcpy(&sh.edges, esum.p, sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) {
-      (void)hipFree(sh.d);
+      dev_free(sh.d);
       return hip_fail(hipGetLastError(), "share order", __FILE__, __LINE__);
     }
     sh.n = cnt;
@@ -655,8 +655,8 @@ int get_table(gm_graph *g, int target, bool allow_split, int bit_words, unsigned
                          sym_table ? 1 : 0, kStageCapWide);
       e = hipMemcpy(cost.data(), d_cost, sizeof(unsigned long long) * recs.size(), hipMemcpyDeviceToHost);
     }
-    if (d_tmp) (void)hipFree(d_tmp);
-    if (d_cost) (void)hipFree(d_cost);
+    if (d_tmp) dev_free(d_tmp);
+    if (d_cost) dev_free(d_cost);
     if (e != hipSuccess) return hip_fail(e, "chunk_cost_kernel", __FILE__, __LINE__);
   }
   if ((allow_split || sym_table) && part_cap != 0) {  // (clique chunks are never cut: their second phase needs the whole bit-matrix; part_cap 0: never)
@@ -768,7 +768,7 @@ int get_table(gm_graph *g, int target, bool allow_split, int bit_words, unsigned
       HIP_TRY(hipMemcpy(d_rows, rows.data(), sizeof(int) * nb, hipMemcpyHostToDevice));
       hipLaunchKernelGGL(bitmap_build_kernel, dim3((unsigned)nb), dim3(256), 0, 0, g->d_rp, g->d_col, d_rows, t.d_bitmaps, words);
       hipError_t e = hipDeviceSynchronize();
-      (void)hipFree(d_rows);
+      dev_free(d_rows);
       if (e != hipSuccess) return hip_fail(e, "bitmap_build_kernel", __FILE__, __LINE__);
       t.n_bitmaps = nb;
       t.bitmap_words = words;
@@ -841,7 +841,7 @@ static void build_inline_copies(gm_graph *g, ScanTemp &tmp) {
   auto fail = [&]() {
     (void)hipGetLastError();
     for (void *p : {(void *)off, (void *)colk, (void *)tdk})
-      if (p) (void)hipFree(p);
+      if (p) dev_free(p);
   };
   if (dev_malloc(&off, 8 * (size_t)(nt + 1)) != hipSuccess) return fail();
   const long long blocks = std::min<long long>((nt + 256) / 256, (long long)g->cu_count * 32);
@@ -861,7 +861,7 @@ static void build_inline_copies(gm_graph *g, ScanTemp &tmp) {
   const long long cblocks = std::min<long long>((nt * 8 + 255) / 256, (long long)g->cu_count * 64);
   hipLaunchKernelGGL(inl_copy_kernel, dim3((unsigned)cblocks), dim3(256), 0, 0, nt, g->d_tdesc, off, lmax, nt, colk, tdk);
   if (hipDeviceSynchronize() != hipSuccess) return fail();
-  (void)hipFree(off);
+  dev_free(off);
   g->d_colk = colk;
   g->d_tdesck = tdk;
   g->n_inline_keys = total;
@@ -1193,7 +1193,7 @@ int ensure_keystream(gm_graph *g, bool edges, bool *built, bool allow_core) {
   KstEdges ed{nullptr, nullptr};
   auto fail = [&](hipError_t e, const char *what) {
     for (void *q : {second ? nullptr : (void *)krp, second ? nullptr : (void *)trpl, (void *)kst, (void *)tdl, (void *)ed.kst_et, (void *)ed.tedgel})
-      if (q) (void)hipFree(q);
+      if (q) dev_free(q);
     return hip_fail(e, what, __FILE__, __LINE__);
   };
   hipError_t e = hipSuccess;
@@ -1213,8 +1213,8 @@ int ensure_keystream(gm_graph *g, bool edges, bool *built, bool allow_core) {
     if (total < key_limit) break;
     lmax >>= 1;
     if (lmax < 4) {
-      (void)hipFree(krp);
-      (void)hipFree(trpl);
+      dev_free(krp);
+      dev_free(trpl);
       g->kst_state = 2;
       return GM_OK;
     }
@@ -1318,9 +1318,9 @@ int ensure_tasklists(gm_graph *g, bool /*with_edges*/) {
     e = hipDeviceSynchronize();
   }
   if (e != hipSuccess) {
-    (void)hipFree(trp);
-    if (td) (void)hipFree(td);
-    if (tedge) (void)hipFree(tedge);
+    dev_free(trp);
+    if (td) dev_free(td);
+    if (tedge) dev_free(tedge);
     return hip_fail(e, "task lists", __FILE__, __LINE__);
   }
   if (tl_skip < g->nv) {
@@ -1398,8 +1398,8 @@ int ensure_sup_corner(gm_graph *g) {
   if (e == hipSuccess) e = launch_core_sym_fill(g->nv, g->tl_skip_from, words, (long long)e0, g->ne, g->d_rp, g->d_col, bits, first_pos, g->cu_count, 0);
   if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e != hipSuccess) {
-    (void)hipFree(bits);
-    if (first_pos) (void)hipFree(first_pos);
+    dev_free(bits);
+    if (first_pos) dev_free(first_pos);
     return hip_fail(e, "symmetric corner", __FILE__, __LINE__);
   }
   g->d_cfirst = first_pos;
@@ -1479,7 +1479,7 @@ int ensure_sup_masks(gm_graph *g) {
   }
   if (e != hipSuccess) {  // (an optimisation that did not fit: the atomics stay)
     for (void *q : {(void *)emoff, (void *)tmoff, (void *)arena, (void *)far_rows})
-      if (q) (void)hipFree(q);
+      if (q) dev_free(q);
     (void)hipGetLastError();
     g->smask_state = 2;
     g->setup.table_ms += timer.ms();
@@ -1537,7 +1537,7 @@ int ensure_edesc(gm_graph *g) {
   hipLaunchKernelGGL(edesc_kernel, dim3((unsigned)blocks), dim3(256), 0, 0, g->ne, g->d_rp, g->d_col, d);
   hipError_t e = hipDeviceSynchronize();
   setup_trace("edge descriptors");
-  if (e != hipSuccess) { (void)hipFree(d); return hip_fail(e, "edesc_kernel", __FILE__, __LINE__); }
+  if (e != hipSuccess) { dev_free(d); return hip_fail(e, "edesc_kernel", __FILE__, __LINE__); }
   g->d_edesc = d;
   g->setup.table_ms += timer.ms();
   return GM_OK;
@@ -1846,7 +1846,7 @@ int ensure_core_tri(gm_graph *g) {
   }
   if (e != hipSuccess) {  // (no room: the row-major gather does the work)
     for (void *q : {(void *)tri, (void *)d_bid, (void *)d_rowbase, (void *)d_blk})
-      if (q) (void)hipFree(q);
+      if (q) dev_free(q);
     (void)hipGetLastError();
     g->cg_tri_state = 2;
     return GM_OK;
@@ -1992,7 +1992,7 @@ static int build_gather_index(gm_graph *g, CliquePlan &pl, CliqueRound &rd, Scan
   hipLaunchKernelGGL(cgb_table_fill_kernel, wgrid, dim3(256), 0, 0, (int)rd.w0, nslots, pl.d_verts, g->d_rp, g->d_col, pl.core_base, poff.p, tab);
   struct TabGuard {  // (the table belongs to the round once the index is complete)
     unsigned *p;
-    ~TabGuard() { if (p) (void)hipFree(p); }
+    ~TabGuard() { if (p) dev_free(p); }
   } tab_guard{tab};
   DevBuf<unsigned> keys, keys_s, idx, idx_s;
   DevBuf<uint4> recs;
@@ -2045,8 +2045,8 @@ static int build_gather_index(gm_graph *g, CliquePlan &pl, CliqueRound &rd, Scan
     e = hipDeviceSynchronize();
   }
   if (e != hipSuccess) {
-    (void)hipFree(units);
-    if (items) (void)hipFree(items);
+    dev_free(units);
+    if (items) dev_free(items);
     return hip_fail(e, "gather index", __FILE__, __LINE__);
   }
   rd.d_gunits = units;
@@ -2075,17 +2075,17 @@ __global__ __launch_bounds__(256) void mcls_rec_kernel(int n, const int *__restr
   rec[k] = make_int4(rp[u + 1] - rp[u], (int)(unsigned)b, (int)(unsigned)(b >> 32), 0);
 }
 static void free_clique_plan(CliquePlan &pl) {
-  if (pl.d_verts) (void)hipFree(pl.d_verts);
-  if (pl.d_slot_base) (void)hipFree(pl.d_slot_base);
-  if (pl.d_mcls_slots) (void)hipFree(pl.d_mcls_slots);
-  if (pl.d_mcls_rec) (void)hipFree(pl.d_mcls_rec);
+  if (pl.d_verts) dev_free(pl.d_verts);
+  if (pl.d_slot_base) dev_free(pl.d_slot_base);
+  if (pl.d_mcls_slots) dev_free(pl.d_mcls_slots);
+  if (pl.d_mcls_rec) dev_free(pl.d_mcls_rec);
   for (auto &rd : pl.rounds) {
-    if (rd.d_base) (void)hipFree(rd.d_base);
-    if (rd.d_tasks) (void)hipFree(rd.d_tasks);
-    if (rd.d_trp) (void)hipFree(rd.d_trp);
-    if (rd.d_gunits) (void)hipFree(rd.d_gunits);
-    if (rd.d_gtab) (void)hipFree(rd.d_gtab);
-    if (rd.d_gitems) (void)hipFree(rd.d_gitems);
+    if (rd.d_base) dev_free(rd.d_base);
+    if (rd.d_tasks) dev_free(rd.d_tasks);
+    if (rd.d_trp) dev_free(rd.d_trp);
+    if (rd.d_gunits) dev_free(rd.d_gunits);
+    if (rd.d_gtab) dev_free(rd.d_gtab);
+    if (rd.d_gitems) dev_free(rd.d_gitems);
     free_table(rd.host_tab);
   }
   pl.rounds.clear();
@@ -2354,7 +2354,7 @@ int get_clique_plan(gm_graph *g, int rank, int world, int policy, int target, un
   setup_trace("clique: rounds built");
   const size_t need = (size_t)need_words * 4;
   if (need > g->wide_mat_bytes) {
-    if (g->d_wide_mat) (void)hipFree(g->d_wide_mat);
+    if (g->d_wide_mat) dev_free(g->d_wide_mat);
     g->d_wide_mat = nullptr;
     g->wide_mat_bytes = 0;
     HIP_TRY(dev_malloc(&g->d_wide_mat, std::max<size_t>(need, 16)));

@@ -199,7 +199,7 @@ extern "C" int gm_selftest(int device, int *n_fail) {
   hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, 0, d);
   int h[512];
   hipError_t e = hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
-  (void)hipFree(d);
+  dev_free(d);
   if (e != hipSuccess) return hip_fail(e, "selftest", __FILE__, __LINE__);
   int bad = 0, acc = 0, mx = 0, rk = 0;
   for (int l = 0; l < 64; ++l) {

@@ -290,7 +290,40 @@ def test_own_algorithm_bytes_equal_a_brute_force_count():
     assert own_d["parts"]["triangles"] == tri
     own = dp[(dp >= bench.kernel_constants()["cb_min_deg"]) & (dp <= bench.kernel_constants()["cb_max_deg"])].astype(np.int64)
     arena = int((own * ((own + 31) // 32)).sum())
-    assert bench.own_bytes_device("clique4", bg)["bytes"] == 4 * int(kc) + 16 * tasks + 4 * nd + 16 * (nv + 1) + 8 * arena + 4 * gathered
+    # round 6: the rows gathered from the hub core go through the BLOCKED gather (csrc/gm_cgather.hip): (vertex, block of core rows) units in
+    # block order, each reading a 16-byte record, 4 B per row and its 16-bit column table from its first row's tile pair on; work items of
+    # ~2^20 probes, one 64 KB block image each -- restated here from the block geometry of tests/test_corner_blocks.py
+    from test_corner_blocks import geometry
+
+    core_h = nv - core_base
+    _words, bid, _rowbase, _blk, _total = geometry(core_h, core_base & 31)
+    wide_v = [u for u in range(nv) if dp[u] * ((dp[u] + 31) // 32) > K["wide_min_words"] and dp[u] <= K["cb_max_deg"]]
+    wide_v.sort(key=lambda u: (-int(dp[u]), u))  # the plan's slot order: longest rows first, stable
+    units = []  # (block, slot, first row index, rows, d)
+    for slot, u in enumerate(wide_v):
+        srow = np.sort(rank[dci[drp[u]:drp[u + 1]]])
+        dd = len(srow)
+        i = int(np.searchsorted(srow, core_base))
+        while i < dd:
+            b0 = bid[srow[i] - core_base]
+            j = i
+            while j < dd and bid[srow[j] - core_base] == b0:
+                j += 1
+            units.append((int(b0), slot, i, j - i, dd))
+            i = j
+    units.sort(key=lambda t: (t[0], t[1], t[2]))
+    unit_bytes = sum(16 + 4 * r + 256 * max(((dd + 63) // 64 + 1) // 2 - ((i0 + 1) >> 7), 0) for _b, _s, i0, r, dd in units)
+    items, cum, prev = 0, 0, None
+    for b0, _s, i0, r, dd in units:
+        cost = r * (dd - 1 - i0) - r * (r - 1) // 2 + 64 * r + 256
+        key = (b0, cum >> 20)
+        items += key != prev
+        prev = key
+        cum += cost
+    own_c = bench.own_bytes_device("clique4", bg)
+    assert own_c["parts"]["blocked_gather"] == {"units": len(units), "unit_bytes": unit_bytes, "items": items, "blocks": len(_blk)}
+    assert own_c["parts"]["core_words_gathered_x4_row_major"] == 4 * gathered  # (the row-major gather of rounds 4 - 5, kept for comparison)
+    assert own_c["bytes"] == 4 * int(kc) + 16 * tasks + 4 * nd + 16 * (nv + 1) + 8 * arena + unit_bytes + 65536 * items
     bg.free()
 
 
