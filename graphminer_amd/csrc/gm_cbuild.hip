@@ -89,7 +89,7 @@ void cbuild_kernel(const CBuildParams p) {
     for (int i = tid; i <= nvl; i += nthreads) B.trpl[i] = trp[ub + i];
     if (tid == 0) B.next_batch = 0;
     const bool fallback = hs_build<STAGE, nthreads>(B.set, reinterpret_cast<unsigned *>(&B.w[0]), rp, col, ub, nvl, eb, nel,
-                                                     (p.flags & (1 << 22)) != 0, tid);  // (ends with a barrier)
+                                                     (p.flags & (1 << 22)) != 0, tid, B.trpl);  // (ends with a barrier; only the rows that host a task)
     if (tid == 0) fetch(cur ^ 1);  // (its wave joins the batches when the three loads are back; the others have started)
     // ---- waves: batches of 64 tasks, sub-batches of as many rows as the wave's row buffer holds -----------------------------
     // (a chunk with few tasks -- the share of one rank of eight holds ~125 per chunk -- takes smaller batches, so that all waves

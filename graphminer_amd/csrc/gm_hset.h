@@ -63,9 +63,12 @@ __device__ __forceinline__ int hs_local_row(const int *rpl, const int nvl, const
 // Two passes over the entries, which stay in registers in between: (1) every entry takes a number in its bucket; (2) when the bucket's
 // total is known, numbers 0..3 (0..2 if the bucket overflowed: its last slot holds the marker) go to the table, the rest to the surplus
 // list.  (An entry at one of the two positions the table cannot hold counts as five and writes the marker itself.)
+// task_rows (optional, LDS: nvl + 1 offsets): only the rows i with task_rows[i + 1] > task_rows[i] are staged -- nobody looks a key up in
+// a row that hosts no task (round 6: a rank of eight finds ~70 tasks in a chunk of 2048 entries and staged all of them, in every chunk).
 template <int STAGE, int NT>
 __device__ __forceinline__ bool hs_build(HsTable<STAGE> &S, unsigned *fill32, const int *__restrict__ rp, const int *__restrict__ col,
-                                         const int ub, const int nvl, const int eb, const int nel, const bool force_fallback, const int tid) {
+                                         const int ub, const int nvl, const int eb, const int nel, const bool force_fallback, const int tid,
+                                         const int *task_rows = nullptr) {
   using H = HsHash<STAGE>;
   for (int i = tid; i <= nvl; i += NT) S.rpl[i] = rp[ub + i];
   {
@@ -92,9 +95,10 @@ __device__ __forceinline__ bool hs_build(HsTable<STAGE> &S, unsigned *fill32, co
 #pragma unroll
     for (int j = 0; j < kU; ++j) {
       const int i = i0 + j * NT;
-      pk[it][j] = 0u;
+      pk[it][j] = 0xffffffffu;  // (not staged)
       if (i < nel) {
         const int lo = hs_local_row(S.rpl, nvl, eb + i);
+        if (task_rows != nullptr && task_rows[lo + 1] == task_rows[lo]) continue;  // the row hosts nothing
         const unsigned b = H::bucket(H::hash(xv[it][j]), H::salt(lo)) >> 4;
         const unsigned shift = (b & 1u) * 16u;
         const unsigned num = (atomicAdd(&fill32[b >> 1], ((unsigned)i < H::kPosLimit ? 1u : 5u) << shift) >> shift) & 0xffffu;
@@ -108,7 +112,7 @@ __device__ __forceinline__ bool hs_build(HsTable<STAGE> &S, unsigned *fill32, co
 #pragma unroll
     for (int j = 0; j < kU; ++j) {
       const int i = it * kU * NT + j * NT + tid;
-      if (i < nel) {
+      if (i < nel && pk[it][j] != 0xffffffffu) {
         const unsigned lo = pk[it][j] & 255u, num = pk[it][j] >> 8;
         const unsigned s = H::salt((int)lo), h = H::hash(xv[it][j]);
         const unsigned b = H::bucket(h, s) >> 4;
