@@ -1613,6 +1613,27 @@ extern "C" int gm_sgl(const gm_graph *sym, const char *pattern, const gm_launch 
     self->ring_alias = (run_on != sym) ? const_cast<gm_graph *>(run_on) : nullptr;
     return rc;
   }
+  // The other 4-vertex patterns of src/sgl/omp_base.cc:21-31 (round 6) need no enumeration of their own: with tri = |N(u) ^ N(v)|,
+  // su = d(u) - tri - 1, sv = d(v) - tri - 1 per undirected edge -- the four per-edge sums of the formula 4-motif (PAT_MOTIF4E,
+  // src/motif/cpu_kernels/automine_formula.h:33-41: raw0 = sum su (su - 1) + sv (sv - 1), raw1 = sum su sv, raw2 = sum tri (su + sv),
+  // raw3 = sum tri (tri - 1)) --
+  //   tailedtriangle (tailedtriangle.h:1-12) = sum_v t(v) (d(v) - 2) = 1/2 sum_e tri (d(u) + d(v) - 4)         = raw2 / 2 + raw3
+  //   4path          (4path.h:1-14)          = sum_e (d(u) - 1)(d(v) - 1) - 3 T  (T = 1/3 sum_e tri)            = raw1 + raw2 + raw3
+  //   3star          (3star.h:1-13)          = sum_v C(d(v), 3) = 1/6 sum_e [(d(u)-1)(d(u)-2) + (d(v)-1)(d(v)-2)] = (raw0 + 2 raw2 + 2 raw3) / 6
+  // (the reference's symmetry breaking makes each of them the plain edge-induced count; checked against sgl_omp_base on the seven golden
+  // graphs).  One GPU: the divisions need the sums of the whole graph.
+  const bool is_tt = strcmp(pattern, "tailedtriangle") == 0, is_p4 = strcmp(pattern, "4path") == 0, is_s3 = strcmp(pattern, "3star") == 0;
+  if (is_tt || is_p4 || is_s3) {
+    if (!sym) return GM_ERR_INVALID;
+    if (int rc0 = reject_big(sym)) return rc0;
+    if (la && (la->world > 1 || la->d_counts)) return GM_ERR_UNSUPPORTED;  // (a rank's partial sums cannot be halved / divided by six on their own)
+    uint64_t raw[4] = {0, 0, 0, 0};
+    const int rc = run_pattern(PAT_MOTIF4E, sym, la, 4, raw, 4, st, FIN_RAW4, 0);
+    if (rc) return rc;
+    const_cast<gm_graph *>(sym)->ring_alias = nullptr;
+    if (total) *total = is_tt ? raw[2] / 2 + raw[3] : is_p4 ? raw[1] + raw[2] + raw[3] : (raw[0] + 2 * raw[2] + 2 * raw[3]) / 6;
+    return GM_OK;
+  }
   if (total) *total = 0;  // "Not implemented", total_num = 0 (src/sgl/omp_base.cc:51-53)
   return GM_ERR_UNSUPPORTED;
 }

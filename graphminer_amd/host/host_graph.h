@@ -83,6 +83,9 @@ class Pattern {
   bool is_rectangle() const { return name_ == "rectangle"; }
   bool is_house() const { return name_ == "house"; }
   bool is_pentagon() const { return name_ == "pentagon"; }
+  bool is_tailedtriangle() const { return name_ == "tailedtriangle"; }  // include/pattern.hh:64-66
+  bool is_4path() const { return name_ == "4path"; }
+  bool is_3star() const { return name_ == "3star"; }
   const std::string &get_name() const { return name_; }
 
  private:

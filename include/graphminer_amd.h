@@ -182,13 +182,15 @@ int gm_tc(const gm_graph *dag, const gm_launch *launch, uint64_t *total, gm_stat
  * cores (csrc/gm_ctc.hip: sum_{i<j, M_ij} popc(M_i & M_j) over the H x H corner of the adjacency matrix -- the loop of omp_base.cc:15-21 on
  * bit rows) and the streamed kernel takes every other edge.  After a first gm_tc: info[0] = H (0: no such corner on this handle),
  * info[1] = DAG entries inside the corner, info[2] = 64 x 64 blocks of the product, info[3] = vertices of the core bitmap.
- * GM_TC_CORE_H in the environment (read when the handle's key stream is built): 0 = off, any other value = that H. */
+ * gm_dev_option("GM_TC_CORE_H", ..) (read when the handle's key stream is built): 0 = off, any other value = that H. */
 int gm_tc_core_info(const gm_graph *dag, int64_t info[4]);
 
 /* SglSolver: edge-induced subgraph listing on the SYMMETRIC graph, pattern by NAME
  * (include/pattern.hh:62-78). Implemented: "diamond" (src/sgl/cpu_kernels/diamond.h:1-14,
  * src/sgl/gpu_kernels/diamond_count.cuh:3-21), "rectangle" (rectangle.h:1-11), "house" (house.h:1-16),
- * "pentagon" (pentagon.h:2-17). Others -> GM_ERR_UNSUPPORTED, *total = 0.
+ * "pentagon" (pentagon.h:2-17), and -- one GPU, from the per-edge sums of the formula 4-motif, no enumeration of their own --
+ * "tailedtriangle" (tailedtriangle.h:1-12), "4path" (4path.h:1-14), "3star" (3star.h:1-13).  Others (the 5- and 6-vertex patterns of
+ * src/sgl/omp_base.cc:33-49 beyond house / pentagon) -> GM_ERR_UNSUPPORTED, *total = 0.
  * diamond = sum over the edges of C(|N(v0) ^ N(v1)|, 2). One GPU: |N(v0) ^ N(v1)| of every edge -- its triangles -- from ONE pass over
  * the triangles of the oriented copy (edge supports, gm_sup.hip; the copy is built and cached on first use; also for a graph of
  * >= 2^31 entries); world > 1, a DAG row beyond 2048 entries, or tune[6] & 0x10000000: one intersection of the two symmetric lists per

@@ -403,6 +403,64 @@ uint64_t gmo_rectangle(const gmo_graph *g) {
   return counter;
 }
 
+/* ---- the other 4-vertex SgL patterns of src/sgl/omp_base.cc:21-31 (round 6).  The loop nests are the reference's; where its innermost
+ * loop only counts (`counter += 1` under a filter) the count of the qualifying entries is taken at once -- same number, and a restatement
+ * that finishes on R-MAT-14 ---------------------------------------------------------------------------------------------------------- */
+uint64_t gmo_3star(const gmo_graph *g) {
+  /* src/sgl/cpu_kernels/3star.h:1-13: v1 > v2 > v3, all in N(v0) */
+  uint64_t counter = 0;
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : counter)
+  for (gmo_vid v0 = 0; v0 < g->nv; v0++) {
+    gmo_vid d0 = deg_of(g, v0);
+    for (gmo_vid i = 0; i < d0; i++)      /* v1 = y0[i] */
+      for (gmo_vid j = 0; j < i; j++)     /* v2 = y0[j] < v1 (rows ascending: the `break` at v2 >= v1) */
+        counter += (uint64_t)j;           /* the v3 in N(v0) below v2: y0[0 .. j) */
+  }
+  return counter;
+}
+
+uint64_t gmo_4path(const gmo_graph *g) {
+  /* src/sgl/cpu_kernels/4path.h:1-14: v0 - v1 - v2 - v3, v2 != v0, v3 < v0 (break), v3 != v1 */
+  uint64_t counter = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : counter)
+  for (gmo_vid v0 = 0; v0 < g->nv; v0++) {
+    const gmo_vid *y0 = row_of(g, v0);
+    gmo_vid d0 = deg_of(g, v0);
+    for (gmo_vid i = 0; i < d0; i++) {
+      gmo_vid v1 = y0[i];
+      const gmo_vid *y1 = row_of(g, v1);
+      gmo_vid d1 = deg_of(g, v1);
+      for (gmo_vid j = 0; j < d1; j++) {
+        gmo_vid v2 = y1[j];
+        if (v2 == v0) continue;
+        const gmo_vid *y2 = row_of(g, v2);
+        gmo_vid d2 = deg_of(g, v2);
+        /* the v3 in N(v2) with v3 < v0 and v3 != v1: the entries below v0, minus one when v1 is among them (v1 is in N(v2)) */
+        gmo_vid below = gmo_bounded(y2, d2, v0); /* (VertexSet::bounded: the entries below v0) */
+        counter += (uint64_t)below - (uint64_t)(v1 < v0 ? 1 : 0);
+      }
+    }
+  }
+  return counter;
+}
+
+uint64_t gmo_tailedtriangle(const gmo_graph *g) {
+  /* src/sgl/cpu_kernels/tailedtriangle.h:1-12: v2 in N(v0) ^ N(v1), v2 < v1; v3 in N(v0), v3 != v1, v3 != v2 */
+  uint64_t counter = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : counter)
+  for (gmo_vid v0 = 0; v0 < g->nv; v0++) {
+    const gmo_vid *y0 = row_of(g, v0);
+    gmo_vid d0 = deg_of(g, v0);
+    for (gmo_vid i = 0; i < d0; i++) {
+      gmo_vid v1 = y0[i];
+      /* |intersection_set(N(v0), N(v1), v1)| members v2, each with the d0 - 2 entries of N(v0) that are neither v1 nor v2 */
+      uint64_t n = gmo_intersect_num_upper(y0, d0, row_of(g, v1), deg_of(g, v1), v1);
+      counter += n * (uint64_t)(d0 - 2);
+    }
+  }
+  return counter;
+}
+
 uint64_t gmo_house(const gmo_graph *g) {
   /* src/sgl/cpu_kernels/house.h:1-16 */
   uint64_t counter = 0;

@@ -76,6 +76,9 @@ uint64_t gmo_clique_sample(const gmo_graph *dag, int k, gmo_vid stride, gmo_vid 
 void gmo_motif3_sample(const gmo_graph *sym, gmo_vid stride, gmo_vid offset, uint64_t out[2], uint64_t *tasks);
 uint64_t gmo_rectangle(const gmo_graph *sym);
 uint64_t gmo_house(const gmo_graph *sym);
+uint64_t gmo_3star(const gmo_graph *sym);          /* src/sgl/cpu_kernels/3star.h */
+uint64_t gmo_4path(const gmo_graph *sym);          /* src/sgl/cpu_kernels/4path.h */
+uint64_t gmo_tailedtriangle(const gmo_graph *sym); /* src/sgl/cpu_kernels/tailedtriangle.h */
 uint64_t gmo_pentagon(const gmo_graph *sym);
 /* k in {3,4,5}: the reference's automine loops; k in 6..8: same DFS written recursively. */
 uint64_t gmo_clique(const gmo_graph *dag, int k);

@@ -87,7 +87,7 @@ def counts_for(prefix, heavy=True, have=None):
         return counts_for_update(prefix, heavy, have)
     r = {}
     r["tc"] = last_int(run("tc_omp_base", prefix), r"total_num_triangles = (\d+)")
-    pats = ["diamond", "rectangle"] + (["house", "pentagon"] if heavy else [])  # (heavy == "sgl" is truthy)
+    pats = ["diamond", "rectangle", "tailedtriangle", "4path", "3star"] + (["house", "pentagon"] if heavy else [])  # (heavy == "sgl" is truthy)
     heavy = heavy is True
     for p in pats:
         r[p] = last_int(run("sgl_omp_base", prefix, p), r"total_num = (\d+)")
@@ -116,6 +116,9 @@ def counts_for_update(prefix, heavy, have):
     for k in (6, 7, 8):
         r.put(f"clique{k}", lambda: last_int(run("clique_omp_recursive", prefix, k), rf"num_{k}-cliques = (\d+)"))
     r.put("motif4", lambda: [int(x) for x in re.findall(r"pattern \d+: (\d+)", run("motif_omp_formula", prefix, 4))])
+    # round 6: the other 4-vertex SgL patterns of src/sgl/omp_base.cc:21-31 (tailedtriangle.h, 4path.h, 3star.h)
+    for pat in ("tailedtriangle", "4path", "3star"):
+        r.put(pat, lambda pat=pat: last_int(run("sgl_omp_base", prefix, pat), r"total_num = (\d+)"))
     return dict(r)
 
 

@@ -32,7 +32,7 @@ def lib():
         L = C.CDLL(LIB)
         G = C.POINTER(gmo_graph)
         P = C.c_void_p
-        for name in ("gmo_tc", "gmo_diamond", "gmo_rectangle", "gmo_house", "gmo_pentagon",
+        for name in ("gmo_tc", "gmo_diamond", "gmo_rectangle", "gmo_house", "gmo_pentagon", "gmo_3star", "gmo_4path", "gmo_tailedtriangle",
                      "gmo_alg_bytes_tc", "gmo_alg_bytes_diamond", "gmo_alg_bytes_clique4", "gmo_alg_bytes_motif3"):
             getattr(L, name).restype = C.c_uint64
             getattr(L, name).argtypes = [G]
@@ -156,6 +156,9 @@ def num_threads():
 def diamond(sym): return int(lib().gmo_diamond(sym.ref()))
 def rectangle(sym): return int(lib().gmo_rectangle(sym.ref()))
 def house(sym): return int(lib().gmo_house(sym.ref()))
+def star3(sym): return int(lib().gmo_3star(sym.ref()))
+def path4(sym): return int(lib().gmo_4path(sym.ref()))
+def tailedtriangle(sym): return int(lib().gmo_tailedtriangle(sym.ref()))
 def pentagon(sym): return int(lib().gmo_pentagon(sym.ref()))
 def clique(dag, k): return int(lib().gmo_clique(dag.ref(), k))
 

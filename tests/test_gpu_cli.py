@@ -32,7 +32,7 @@ def test_cli_result_lines(name):
     assert out[-1] == f"total_num_triangles = {e['tc']}"
     out = run("sgl_gpu_base", prefix, "diamond")
     assert "Pattern: diamond" in out and out[-1] == f"total_num = {e['diamond']}"
-    for pat in ("rectangle", "house", "pentagon"):
+    for pat in ("rectangle", "house", "pentagon", "tailedtriangle", "4path", "3star"):
         assert run("sgl_gpu_base", prefix, pat)[-1] == f"total_num = {e[pat]}"
     out = run("sgl_gpu_base", prefix, "foo")
     assert out[-2:] == ["Not implemented", "total_num = 0"]  # src/sgl/omp_base.cc:51-53

@@ -33,7 +33,7 @@ def test_reference_mains_with_hip_solvers(name):
     prefix = os.path.join(ROOT, "tests", "fixtures", name, "graph")
     hip, omp = run("tc_hip_base", prefix), run("tc_omp_base", prefix)
     assert hip[-1] == omp[-1] == f"total_num_triangles = {e['tc']}"
-    for pat in ("diamond", "rectangle", "house", "pentagon"):
+    for pat in ("diamond", "rectangle", "house", "pentagon", "tailedtriangle", "4path", "3star"):
         hip, omp = run("sgl_hip_base", prefix, pat), run("sgl_omp_base", prefix, pat)
         assert hip[-1] == omp[-1] == f"total_num = {e[pat]}"
     for k in (4, 5):

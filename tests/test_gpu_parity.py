@@ -129,6 +129,29 @@ def test_diamond_matches_reference(gg):
     assert SglSolver(sym, "diamond", tune=[64, 1, 0, 0, 0, 0]) == GOLDEN[name]["diamond"]
 
 
+@pytest.mark.parametrize("pattern", ["tailedtriangle", "4path", "3star"])
+def test_sgl_four_vertex_patterns_from_the_per_edge_sums(gg, pattern):
+    """tailedtriangle.h / 4path.h / 3star.h (src/sgl/omp_base.cc:21-31): the HIP path takes them from the four per-edge sums of the formula
+    4-motif (one |N(u) ^ N(v)| per edge, csrc/gm_launch.hip gm_sgl); goldens from sgl_omp_base, the oracle restates the loop nests"""
+    name, g, sym, _ = gg
+    e = GOLDEN[name]
+    if pattern not in e:
+        pytest.skip("no golden")
+    total, st = SglSolver(sym, pattern, return_stats=True)
+    assert total == e[pattern] and st.kernel_ms > 0
+    assert SglSolver(sym, pattern, tune=[0, 0, 0, 0, 0, 0, 0x80000]) == e[pattern]  # every row through the general kernel
+    assert SglSolver(sym, pattern) == e[pattern]
+    if e["ne"] < 100000:
+        osym = O.OGraph(g.row_ptr, g.col_idx)
+        assert total == {"tailedtriangle": O.tailedtriangle, "4path": O.path4, "3star": O.star3}[pattern](osym)
+    # a rank's partial sums cannot be halved / divided by six on their own: refused, like the reference has no multi-GPU SgL
+    lib = _lib.load()
+    la = _lib.gm_launch()
+    la.world, la.rank = 2, 0
+    tot = C.c_uint64(7)
+    assert lib.gm_sgl(sym.handle, pattern.encode(), C.byref(la), C.byref(tot), None) == _lib.GM_ERR_UNSUPPORTED
+
+
 @pytest.mark.parametrize("pattern", ["rectangle", "house", "pentagon"])
 def test_sgl_nested_patterns_match_reference(gg, pattern):
     """rectangle.h / house.h / pentagon.h loop nests on the wave64 primitives; goldens from sgl_omp_base"""

@@ -42,6 +42,21 @@ def test_diamond_rectangle(graphs):
     assert O.rectangle(sym) == GOLDEN[name]["rectangle"]
 
 
+def test_tailedtriangle_4path_3star(graphs):
+    """the other 4-vertex SgL patterns (src/sgl/cpu_kernels/tailedtriangle.h, 4path.h, 3star.h): oracle = sgl_omp_base on every golden graph,
+    = the closed forms the HIP path uses (sums of the per-edge quantities of the formula 4-motif, csrc/gm_launch.hip gm_sgl)"""
+    name, g, sym, _ = graphs
+    e = GOLDEN[name]
+    if "3star" not in e:
+        pytest.skip("no golden")
+    assert (O.star3(sym), O.path4(sym), O.tailedtriangle(sym)) == (e["3star"], e["4path"], e["tailedtriangle"])
+    if "motif4" in e:  # the identities with the vertex-induced 4-motif counts [3-star, 4-path, tailed triangle, 4-cycle, diamond, 4-clique]
+        m = e["motif4"]
+        assert e["3star"] == m[0] + m[2] + 2 * m[4] + 4 * m[5]
+        assert e["tailedtriangle"] == m[2] + 4 * m[4] + 12 * m[5]
+        assert e["4path"] == m[1] + 2 * m[2] + 4 * m[3] + 6 * m[4] + 12 * m[5]
+
+
 def test_house_pentagon(graphs):
     name, _, sym, _ = graphs
     e = GOLDEN[name]
@@ -86,6 +101,7 @@ def test_readme_known_answers_small():
     # src/triangle/README.md:53, src/sgl/README.md:53, src/clique/README.md:53, src/motif/README.md:52
     c = GOLDEN["citeseer"]
     assert (c["tc"], c["diamond"], c["rectangle"], c["house"], c["pentagon"]) == (1166, 3730, 6059, 55359, 28394)
+    assert (c["tailedtriangle"], c["4path"], c["3star"]) == (34760, 185589, 250950)  # sgl_omp_base on citeseer
     assert c["motif4"] == [222630, 111153, 22900, 3094, 2200, 255]
 
 
