@@ -92,6 +92,8 @@ SYMBOLS = [
     ("gm_motif", C.c_int, [_P, C.c_int, C.POINTER(gm_launch), C.POINTER(C.c_uint64), C.c_int, C.POINTER(gm_stats)]),
     ("gm_motif4_partial", C.c_int, [_P, C.POINTER(gm_launch), C.POINTER(C.c_uint64), C.POINTER(gm_stats)]),
     ("gm_motif4_finish", C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("gm_sgl4_partial", C.c_int, [_P, C.POINTER(gm_launch), C.POINTER(C.c_uint64), C.POINTER(gm_stats)]),
+    ("gm_sgl4_finish", C.c_int, [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("gm_motif_formula", C.c_int, [_P, C.c_int, C.POINTER(gm_launch), C.POINTER(C.c_uint64), C.c_int, C.POINTER(gm_stats)]),
     ("gm_setop_batch", C.c_int, [C.c_int, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     ("gm_rmat_keys", C.c_int, [C.c_int, C.c_int64, C.c_uint64, _P, _P]),

@@ -11,7 +11,7 @@
 
 namespace gm {
 
-#define GM_IS_CLIQUE(P) ((P) == PAT_CLIQUE4 || (P) == PAT_CLIQUEK)
+#define GM_IS_CLIQUE(P) ((P) == PAT_CLIQUE4 || (P) == PAT_CLIQUEK || (P) == PAT_CLIQUEK_DEEP)
 #define GM_IS_PEREDGE(P) ((P) == PAT_DIAMOND || (P) == PAT_MOTIF4E || (P) == PAT_DAGSTATS)  // need |N(v0) ^ N(v1)| per task edge
 
 // Workgroup classes of the mining kernel. CLS 0 is the general one (4 waves, 21-32 KB of LDS, 5-7 workgroups per CU).
@@ -187,6 +187,18 @@ __device__ __forceinline__ unsigned long long clique4_count_tiled(unsigned *__re
 // (the nested intersect levels of clique5..8_warp_edge.cuh / automine_5clique, automine_omp.h:138-157).
 constexpr int kSmallWords = 8;  // LDS-resident matrices have rows of <= 256 columns
 
+// Levels up to kCliqueInlineM (k <= 8, the range of the reference's GPU solver: src/clique/gpu_base.cu:59-71) are inlined into one
+// another; a deeper level (k = 9..12, counted by the reference's generic clique_omp_recursive / edge_warp_iterative.cuh:2-75) is a real
+// function, compiled once and called by every k above it -- inlined all the way the four extra cases took the build from 4 to 16
+// minutes (every level carries a copy of all the levels below it, for every k).  The called levels see generic pointers (flat loads).
+constexpr int kCliqueInlineM = 6;
+struct SmallSet { unsigned w[kSmallWords]; };
+template <int M>
+__device__ __noinline__ unsigned long long clique_small_outlined(SmallSet S, const unsigned *bits, int row0, int stride);
+template <int M>
+__device__ __forceinline__ unsigned long long clique_small_call(const unsigned (&S)[kSmallWords], const unsigned *__restrict__ bits,
+                                                                const int row0, const int stride);
+
 template <int M>
 struct CliqueSmall {  // one lane per row, the candidate set lives in 8 registers
   static __device__ __forceinline__ unsigned long long run(const unsigned (&S)[kSmallWords], const unsigned *__restrict__ bits,
@@ -202,7 +214,7 @@ struct CliqueSmall {  // one lane per row, the candidate set lives in 8 register
         unsigned T[kSmallWords];
 #pragma unroll
         for (int w2 = 0; w2 < kSmallWords; ++w2) T[w2] = (w2 < stride) ? (S[w2] & Mj[w2]) : 0u;
-        c += CliqueSmall<M - 1>::run(T, bits, row0, stride);
+        c += clique_small_call<M - 1>(T, bits, row0, stride);
       }
     }
     return c;
@@ -217,6 +229,23 @@ struct CliqueSmall<1> {
     return c;
   }
 };
+
+template <int M>
+__device__ __noinline__ unsigned long long clique_small_outlined(SmallSet S, const unsigned *bits, int row0, int stride) {
+  return CliqueSmall<M>::run(S.w, bits, row0, stride);
+}
+template <int M>
+__device__ __forceinline__ unsigned long long clique_small_call(const unsigned (&S)[kSmallWords], const unsigned *__restrict__ bits,
+                                                                const int row0, const int stride) {
+  if constexpr (M > kCliqueInlineM) {
+    SmallSet s;
+#pragma unroll
+    for (int w = 0; w < kSmallWords; ++w) s.w[w] = S[w];
+    return clique_small_outlined<M>(s, bits, row0, stride);
+  } else {
+    return CliqueSmall<M>::run(S, bits, row0, stride);
+  }
+}
 
 template <int M>
 __device__ __forceinline__ unsigned long long cliquek_count_small(const int *__restrict__ rpl, const unsigned *__restrict__ bits,
@@ -234,10 +263,15 @@ __device__ __forceinline__ unsigned long long cliquek_count_small(const int *__r
     unsigned S[kSmallWords];
 #pragma unroll
     for (int w = 0; w < kSmallWords; ++w) S[w] = (w < stride) ? bits[(size_t)le * stride + w] : 0u;
-    c += CliqueSmall<M>::run(S, bits, row0, stride);
+    c += clique_small_call<M>(S, bits, row0, stride);
   }
   return c;
 }
+
+template <int M>
+__device__ __noinline__ unsigned long long clique_wide_outlined(unsigned S, const unsigned *bits, int lane, int stride);
+template <int M>
+__device__ __forceinline__ unsigned long long clique_wide_call(const unsigned S, const unsigned *__restrict__ bits, const int lane, const int stride);
 
 template <int M>
 struct CliqueWide {  // one wave per row, lane w holds word w of the candidate set (stride <= 64)
@@ -267,7 +301,7 @@ struct CliqueWide {  // one wave per row, lane w holds word w of the candidate s
         for (int u = 0; u < 4; ++u) mj[u] = bits[(size_t)j[u] * stride + lw];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-          if (u < n) c += CliqueWide<M - 1>::run(S & mj[u], bits, lane, stride);
+          if (u < n) c += clique_wide_call<M - 1>(S & mj[u], bits, lane, stride);
       }
     }
     return c;
@@ -279,6 +313,16 @@ struct CliqueWide<1> {
     return (unsigned long long)__popc(S);  // per-lane partial; summed over the wave at kernel end
   }
 };
+
+template <int M>
+__device__ __noinline__ unsigned long long clique_wide_outlined(unsigned S, const unsigned *bits, int lane, int stride) {
+  return CliqueWide<M>::run(S, bits, lane, stride);
+}
+template <int M>
+__device__ __forceinline__ unsigned long long clique_wide_call(const unsigned S, const unsigned *__restrict__ bits, const int lane, const int stride) {
+  if constexpr (M > kCliqueInlineM) return clique_wide_outlined<M>(S, bits, lane, stride);
+  else return CliqueWide<M>::run(S, bits, lane, stride);
+}
 
 // k >= 5 on a big vertex, through INDUCED SUB-MATRICES: every deeper level of row i only ever looks at the rows and
 // columns in M_i, so the workgroup compacts that |M_i| x |M_i| sub-matrix into LDS once (row j = M_j restricted to the
@@ -316,7 +360,13 @@ __device__ __forceinline__ unsigned long long cliquek_count_sub(unsigned *__rest
                                                                 unsigned short *__restrict__ plist, const unsigned *__restrict__ gbits,
                                                                 unsigned *__restrict__ sub_arena, const size_t arena_step,
                                                                 const int tid, const int lane, const int wave, const int nel,
-                                                                const int stride, const bool force_anywidth = false) {
+                                                                const int stride, const bool force_anywidth = false);
+template <int M>
+__device__ __forceinline__ unsigned long long cliquek_count_sub_body(unsigned *__restrict__ sub, int *__restrict__ lds_scratch,
+                                                                unsigned short *__restrict__ plist, const unsigned *__restrict__ gbits,
+                                                                unsigned *__restrict__ sub_arena, const size_t arena_step,
+                                                                const int tid, const int lane, const int wave, const int nel,
+                                                                const int stride, const bool force_anywidth) {
   static_assert(kBitWords >= 256 * kSmallWords, "the sub-matrix of 256 rows must fit the bit-matrix LDS");
   static_assert(sizeof(WaveLds) * kWavesPerBlock >= 2 * 32 * kSubMaxStride, "the position list (one entry per column) lives in the idle pass scratch");
   static_assert(kStageCapClique >= kWavesPerBlock * kSubMaxStride, "one row buffer per wave in the idle stage");
@@ -381,7 +431,7 @@ __device__ __forceinline__ unsigned long long cliquek_count_sub(unsigned *__rest
         unsigned S[kSmallWords];
 #pragma unroll
         for (int w = 0; w < kSmallWords; ++w) S[w] = sub[p * kSmallWords + w];
-        c += CliqueSmall<M - 1>::run(S, sub, 0, kSmallWords);
+        c += clique_small_call<M - 1>(S, sub, 0, kSmallWords);
       }
     } else {
       __threadfence();
@@ -402,6 +452,24 @@ __device__ __forceinline__ unsigned long long cliquek_count_sub(unsigned *__rest
   return c;
 }
 
+template <int M>
+__device__ __noinline__ unsigned long long cliquek_count_sub_outlined(unsigned *sub, int *lds_scratch, unsigned short *plist, const unsigned *gbits,
+                                                                      unsigned *sub_arena, size_t arena_step, int tid, int lane, int wave,
+                                                                      int nel, int stride, bool force_anywidth) {
+  return cliquek_count_sub_body<M>(sub, lds_scratch, plist, gbits, sub_arena, arena_step, tid, lane, wave, nel, stride, force_anywidth);
+}
+template <int M>
+__device__ __forceinline__ unsigned long long cliquek_count_sub(unsigned *__restrict__ sub, int *__restrict__ lds_scratch,
+                                                                unsigned short *__restrict__ plist, const unsigned *__restrict__ gbits,
+                                                                unsigned *__restrict__ sub_arena, const size_t arena_step,
+                                                                const int tid, const int lane, const int wave, const int nel,
+                                                                const int stride, const bool force_anywidth) {
+  if constexpr (M > kCliqueInlineM)
+    return cliquek_count_sub_outlined<M>(sub, lds_scratch, plist, gbits, sub_arena, arena_step, tid, lane, wave, nel, stride, force_anywidth);
+  else
+    return cliquek_count_sub_body<M>(sub, lds_scratch, plist, gbits, sub_arena, arena_step, tid, lane, wave, nel, stride, force_anywidth);
+}
+
 // The same induced-sub-matrix recursion for rows of ANY width (more than kSubMaxStride words: beyond 4096 columns). Nothing of the
 // row is held in registers or LDS: the set-bit positions of M_i go to a list in the workgroup's global scratch (plist_g, one list per
 // recursion level, plist_step entries apart), the compacted rows are gathered bit by bit from the arena. Slow and exact -- the
@@ -409,6 +477,11 @@ __device__ __forceinline__ unsigned long long cliquek_count_sub(unsigned *__rest
 // round 2 refused such rows; only the top rows of a DAG that was not oriented by degree ever get here.
 template <int M>
 __device__ __forceinline__ unsigned long long cliquek_count_sub_any(unsigned *__restrict__ sub, int *__restrict__ lds_m, int *__restrict__ plist_g,
+                                                                    const size_t plist_step, const unsigned *__restrict__ gbits,
+                                                                    unsigned *__restrict__ sub_arena, const size_t arena_step, const int tid,
+                                                                    const int lane, const int wave, const int nel, const int stride);
+template <int M>
+__device__ __forceinline__ unsigned long long cliquek_count_sub_any_body(unsigned *__restrict__ sub, int *__restrict__ lds_m, int *__restrict__ plist_g,
                                                                     const size_t plist_step, const unsigned *__restrict__ gbits,
                                                                     unsigned *__restrict__ sub_arena, const size_t arena_step, const int tid,
                                                                     const int lane, const int wave, const int nel, const int stride) {
@@ -458,7 +531,7 @@ __device__ __forceinline__ unsigned long long cliquek_count_sub_any(unsigned *__
         unsigned S[kSmallWords];
 #pragma unroll
         for (int w = 0; w < kSmallWords; ++w) S[w] = sub[p * kSmallWords + w];
-        c += CliqueSmall<M - 1>::run(S, sub, 0, kSmallWords);
+        c += clique_small_call<M - 1>(S, sub, 0, kSmallWords);
       }
     } else {
       __threadfence();
@@ -480,12 +553,29 @@ __device__ __forceinline__ unsigned long long cliquek_count_sub_any(unsigned *__
 }
 
 template <int M>
+__device__ __noinline__ unsigned long long cliquek_count_sub_any_outlined(unsigned *sub, int *lds_m, int *plist_g, size_t plist_step, const unsigned *gbits,
+                                                                          unsigned *sub_arena, size_t arena_step, int tid, int lane, int wave, int nel,
+                                                                          int stride) {
+  return cliquek_count_sub_any_body<M>(sub, lds_m, plist_g, plist_step, gbits, sub_arena, arena_step, tid, lane, wave, nel, stride);
+}
+template <int M>
+__device__ __forceinline__ unsigned long long cliquek_count_sub_any(unsigned *__restrict__ sub, int *__restrict__ lds_m, int *__restrict__ plist_g,
+                                                                    const size_t plist_step, const unsigned *__restrict__ gbits,
+                                                                    unsigned *__restrict__ sub_arena, const size_t arena_step, const int tid,
+                                                                    const int lane, const int wave, const int nel, const int stride) {
+  if constexpr (M > kCliqueInlineM)
+    return cliquek_count_sub_any_outlined<M>(sub, lds_m, plist_g, plist_step, gbits, sub_arena, arena_step, tid, lane, wave, nel, stride);
+  else
+    return cliquek_count_sub_any_body<M>(sub, lds_m, plist_g, plist_step, gbits, sub_arena, arena_step, tid, lane, wave, nel, stride);
+}
+
+template <int M>
 __device__ __forceinline__ unsigned long long cliquek_count_wide(const unsigned *__restrict__ bits, const int lane, const int wave,
                                                                  const int nel, const int stride) {
   unsigned long long c = 0;
   for (int i = wave; i < nel; i += kWavesPerBlock) {
     const unsigned mi = (lane < stride) ? bits[(size_t)i * stride + lane] : 0u;
-    c += CliqueWide<M>::run(mi, bits, lane, stride);
+    c += clique_wide_call<M>(mi, bits, lane, stride);
   }
   return c;
 }
@@ -825,9 +915,9 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT,
         else if (bits_lds) acc.c0 += clique4_count(B.rpl, B.bits, tid, nthreads, eb, nel, nvl, stride);
         else acc.c0 += clique4_count(B.rpl, gbits, tid, nthreads, eb, nel, nvl, stride);
         break;
-#define GM_CLIQUE_CASE(K)                                                                                   \
+#define GM_CLIQUE_CASE(K, INSTANCE)                                                                                   \
       case K:                                                                                                \
-        if (PAT != PAT_CLIQUEK) break;                                                                       \
+        if (PAT != INSTANCE) break;                                                                          \
         if (wide2 && !((p.flags & 64) && wide))                                                               \
           acc.c0 += cliquek_count_sub<K - 2>(B.bits, B.stage, reinterpret_cast<unsigned short *>(&B.w[0]), gbits,       \
                                              gbits + p.scratch_region, p.scratch_region, tid, lane,   \
@@ -839,10 +929,17 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT,
                                                  (size_t)p.scratch_plist, gbits, gbits + p.scratch_region, p.scratch_region, tid, lane, wave, nel, stride); \
         else acc.c1 += 1; /* (cannot happen: a matrix beyond LDS is a one-row chunk) */                        \
         break;
-      GM_CLIQUE_CASE(5)
-      GM_CLIQUE_CASE(6)
-      GM_CLIQUE_CASE(7)
-      GM_CLIQUE_CASE(8)
+      GM_CLIQUE_CASE(5, PAT_CLIQUEK)
+      GM_CLIQUE_CASE(6, PAT_CLIQUEK)
+      GM_CLIQUE_CASE(7, PAT_CLIQUEK)
+      GM_CLIQUE_CASE(8, PAT_CLIQUEK)
+      // beyond the reference's GPU dispatch (src/clique/gpu_base.cu:59-71 stops at 8; its clique_omp_recursive and
+      // edge_warp_iterative.cuh:2-75 are generic in k, src/clique/README.md:59 lists k = 9): an instance of its own, so that the called
+      // levels (kCliqueInlineM) and their stack stay out of the kernel that counts k <= 8
+      GM_CLIQUE_CASE(9, PAT_CLIQUEK_DEEP)
+      GM_CLIQUE_CASE(10, PAT_CLIQUEK_DEEP)
+      GM_CLIQUE_CASE(11, PAT_CLIQUEK_DEEP)
+      GM_CLIQUE_CASE(12, PAT_CLIQUEK_DEEP)
 #undef GM_CLIQUE_CASE
       default: break;
     }
@@ -857,7 +954,7 @@ __device__ __forceinline__ void process_chunk(const MineParams &p, BlockLds<PAT,
 // give up at 74 VGPRs = 6 waves per SIMD once the edge descriptors were added; asking for 7 makes it fit the 72 of 7 waves)
 // The symmetric-graph patterns (31.5 KB of LDS: 5 workgroups per CU) get 5 for the same reason: 96 VGPRs, not 97.
 template <int PAT, int CLS = 0>
-__global__ __launch_bounds__((MineCfg<PAT, CLS>::waves * GM_WAVE), (CLS == 2 ? 1 : CLS == 1 ? 2 : PAT == PAT_CLIQUEK ? 4 : (PAT == PAT_TC ? GM_TC_WAVES : 5)))
+__global__ __launch_bounds__((MineCfg<PAT, CLS>::waves * GM_WAVE), (CLS == 2 ? 1 : CLS == 1 ? 2 : (PAT == PAT_CLIQUEK || PAT == PAT_CLIQUEK_DEEP) ? 4 : (PAT == PAT_TC ? GM_TC_WAVES : 5)))
 void mine_kernel(const MineParams p) {
   __shared__ BlockLds<PAT, CLS> B;
   const int lane = threadIdx.x & (GM_WAVE - 1);

@@ -1559,6 +1559,29 @@ extern "C" int gm_diamond_support_finish(const gm_graph *sym, const gm_launch *l
   return GM_OK;
 }
 
+static int sgl4_kind(const char *pattern) {  // 1 tailedtriangle, 2 4path, 3 3star, 0 none of them
+  if (!pattern) return 0;
+  return strcmp(pattern, "tailedtriangle") == 0 ? 1 : strcmp(pattern, "4path") == 0 ? 2 : strcmp(pattern, "3star") == 0 ? 3 : 0;
+}
+
+// A rank's share of the four per-edge sums behind tailedtriangle / 4path / 3star (see gm_sgl): plain sums over its tasks, so the shares
+// add up; with la->d_counts they are left in that device buffer, ordered on la->stream (raw may be NULL then).
+extern "C" int gm_sgl4_partial(const gm_graph *sym, const gm_launch *la, uint64_t raw[4], gm_stats *st) {
+  if (!sym || (!raw && !(la && la->d_counts))) return GM_ERR_INVALID;
+  if (int rc0 = reject_big(sym)) return rc0;
+  const int rc = run_pattern(PAT_MOTIF4E, sym, la, 4, raw, 4, st, FIN_RAW4, 0);
+  if (rc) return rc;
+  const_cast<gm_graph *>(sym)->ring_alias = nullptr;
+  return GM_OK;
+}
+
+extern "C" int gm_sgl4_finish(const char *pattern, const uint64_t raw[4], uint64_t *total) {
+  const int kind = sgl4_kind(pattern);
+  if (!kind || !raw || !total) return GM_ERR_INVALID;
+  *total = kind == 1 ? raw[2] / 2 + raw[3] : kind == 2 ? raw[1] + raw[2] + raw[3] : (raw[0] + 2 * raw[2] + 2 * raw[3]) / 6;
+  return GM_OK;
+}
+
 extern "C" int gm_sgl(const gm_graph *sym, const char *pattern, const gm_launch *la, uint64_t *total, gm_stats *st) {
   if (!pattern) return GM_ERR_INVALID;
   if (strcmp(pattern, "diamond") == 0) {
@@ -1621,18 +1644,12 @@ extern "C" int gm_sgl(const gm_graph *sym, const char *pattern, const gm_launch 
   //   4path          (4path.h:1-14)          = sum_e (d(u) - 1)(d(v) - 1) - 3 T  (T = 1/3 sum_e tri)            = raw1 + raw2 + raw3
   //   3star          (3star.h:1-13)          = sum_v C(d(v), 3) = 1/6 sum_e [(d(u)-1)(d(u)-2) + (d(v)-1)(d(v)-2)] = (raw0 + 2 raw2 + 2 raw3) / 6
   // (the reference's symmetry breaking makes each of them the plain edge-induced count; checked against sgl_omp_base on the seven golden
-  // graphs).  One GPU: the divisions need the sums of the whole graph.
-  const bool is_tt = strcmp(pattern, "tailedtriangle") == 0, is_p4 = strcmp(pattern, "4path") == 0, is_s3 = strcmp(pattern, "3star") == 0;
-  if (is_tt || is_p4 || is_s3) {
-    if (!sym) return GM_ERR_INVALID;
-    if (int rc0 = reject_big(sym)) return rc0;
-    if (la && (la->world > 1 || la->d_counts)) return GM_ERR_UNSUPPORTED;  // (a rank's partial sums cannot be halved / divided by six on their own)
+  // graphs).  The divisions need the sums of the whole graph: a rank's share goes through gm_sgl4_partial.
+  if (sgl4_kind(pattern)) {
+    if (la && (la->world > 1 || la->d_counts)) return GM_ERR_UNSUPPORTED;  // several ranks: gm_sgl4_partial + all-reduce + gm_sgl4_finish
     uint64_t raw[4] = {0, 0, 0, 0};
-    const int rc = run_pattern(PAT_MOTIF4E, sym, la, 4, raw, 4, st, FIN_RAW4, 0);
-    if (rc) return rc;
-    const_cast<gm_graph *>(sym)->ring_alias = nullptr;
-    if (total) *total = is_tt ? raw[2] / 2 + raw[3] : is_p4 ? raw[1] + raw[2] + raw[3] : (raw[0] + 2 * raw[2] + 2 * raw[3]) / 6;
-    return GM_OK;
+    const int rc = gm_sgl4_partial(sym, la, raw, st);
+    return rc ? rc : gm_sgl4_finish(pattern, raw, total);
   }
   if (total) *total = 0;  // "Not implemented", total_num = 0 (src/sgl/omp_base.cc:51-53)
   return GM_ERR_UNSUPPORTED;
@@ -1640,7 +1657,7 @@ extern "C" int gm_sgl(const gm_graph *sym, const char *pattern, const gm_launch 
 
 extern "C" int gm_clique(const gm_graph *dag, int k, const gm_launch *la, uint64_t *total, gm_stats *st) {
   if (k == 3) return run_tc(dag, la, total, 1, st);
-  if (k < 3 || k > 8) {
+  if (k < 3 || k > GM_MAX_CLIQUE_K) {
     if (total) *total = 0;
     return GM_ERR_INVALID;
   }

@@ -123,11 +123,12 @@ constexpr unsigned kNoMask = 0xffffffffu;
 constexpr int kSupMaskMinTail = GM_SUP_MASK_MIN_TAIL;
 constexpr int kSupMaskSpare = 3;  // spare 64-bit words behind the mask of a long list (tile groups of at most kSupMaskSpare + 1 tiles)
 
-enum Pattern : int { PAT_TC = 0, PAT_DIAMOND = 1, PAT_MOTIF3 = 2, PAT_CLIQUE4 = 3, PAT_CLIQUEK = 4 /* k = 5..8 */,
+enum Pattern : int { PAT_TC = 0, PAT_DIAMOND = 1, PAT_MOTIF3 = 2, PAT_CLIQUE4 = 3, PAT_CLIQUEK = 4 /* k = 5..12 */,
                      PAT_MOTIF4E = 5 /* per-edge sums of the 4-motif formula */,
                      PAT_DAGSTATS = 6 /* tooling: sum n, sum n^2, sum_{matches} d+(w) for the 4-clique algorithmic bytes */,
                      PAT_SUPPORT = 7 /* edge supports from the DAG's triangles + sum C(t, 2): the diamond count (gm_sup.hip) */,
-                     PAT_SUPPORT_PART = 8 /* ... a rank's share of the supports only, into the caller's buffer (gm_diamond_support_partial) */ };
+                     PAT_SUPPORT_PART = 8 /* ... a rank's share of the supports only, into the caller's buffer (gm_diamond_support_partial) */,
+                     PAT_CLIQUEK_DEEP = 9 /* kernel side only: the instance of the mining kernel PAT_CLIQUEK launches for k = 9..12 (gm_chunk.h) */ };
 
 // Symmetric-graph patterns stage up to 3072 entries: on skewed graphs thousands of rows have 1-3 K neighbours; with a
 // 1024-entry stage they are SPLIT rows whose keys are bisected in HBM, otherwise ordinary staged chunks behind
@@ -169,7 +170,7 @@ __host__ __device__ inline bool sym_hosts(int a, int b, int u, int v, int stage_
 constexpr int kStageCapClique = 1024;
 constexpr int stage_cap_of(int pat) {
   return (pat == PAT_DIAMOND || pat == PAT_MOTIF3 || pat == PAT_MOTIF4E) ? kStageCapWide
-         : (pat == PAT_CLIQUE4 || pat == PAT_CLIQUEK) ? kStageCapClique : kStageCap;
+         : (pat == PAT_CLIQUE4 || pat == PAT_CLIQUEK || pat == PAT_CLIQUEK_DEEP) ? kStageCapClique : kStageCap;
 }
 
 struct MineParams {

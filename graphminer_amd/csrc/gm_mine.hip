@@ -768,7 +768,10 @@ hipError_t launch_mine(Pattern pat, const MineParams &p, int grid_blocks, hipStr
     case PAT_DAGSTATS: hipLaunchKernelGGL(mine_kernel<PAT_DAGSTATS>, grid, block, 0, stream, p); break;
     case PAT_MOTIF3: hipLaunchKernelGGL(mine_kernel<PAT_MOTIF3>, grid, block, 0, stream, p); break;
     case PAT_CLIQUE4: hipLaunchKernelGGL(mine_kernel<PAT_CLIQUE4>, grid, block, 0, stream, p); break;
-    case PAT_CLIQUEK: hipLaunchKernelGGL(mine_kernel<PAT_CLIQUEK>, grid, block, 0, stream, p); break;
+    case PAT_CLIQUEK:
+      if (p.k > 8) hipLaunchKernelGGL(mine_kernel<PAT_CLIQUEK_DEEP>, grid, block, 0, stream, p);
+      else hipLaunchKernelGGL(mine_kernel<PAT_CLIQUEK>, grid, block, 0, stream, p);
+      break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -127,10 +127,19 @@ bool opt_set(const char *name) { return gm_dev_option_get(name) != nullptr; }
   } while (0)
 
 
+bool sgl4(const Job &j) {
+  return j.kind == Job::SGL && j.pattern &&
+         (!std::strcmp(j.pattern, "tailedtriangle") || !std::strcmp(j.pattern, "4path") || !std::strcmp(j.pattern, "3star"));
+}
+
 int call(const Job &j, gm_graph *g, const gm_launch *la, uint64_t *out, gm_stats *st) {
   switch (j.kind) {
     case Job::TC: return gm_tc(g, la, out, st);
-    case Job::SGL: return gm_sgl(g, j.pattern, la, out, st);
+    case Job::SGL:
+      // tailedtriangle / 4path / 3star on several GPUs: the four raw per-edge sums stay on the device, the all-reduce adds them,
+      // run_multi applies gm_sgl4_finish (the halving / division by six needs the whole graph's sums)
+      if (sgl4(j) && la && la->d_counts && !out) return gm_sgl4_partial(g, la, out, st);
+      return gm_sgl(g, j.pattern, la, out, st);
     case Job::CLIQUE: return gm_clique(g, j.k, la, out, st);
     case Job::MOTIF:
       // 4-motif on several GPUs: every rank leaves its six RAW sums on the device (gm_motif4_partial), the all-reduce adds
@@ -262,7 +271,7 @@ bool run_multi(const gm_csr &g, const Job &j, int n, int chunk, uint64_t *out) {
       // (every rank gets the same verdict on "unsupported" / invalid -- it depends on the pattern, not on the share -- so either all
       // ranks join the all-reduce or none does)
       if (rcs[i] != GM_OK) return;
-      NCCL_OK(ncclAllReduce(d_cnt[i], d_cnt[i], size_t(j.ncounts), ncclUint64, ncclSum, comms[i], streams[i]));
+      NCCL_OK(ncclAllReduce(d_cnt[i], d_cnt[i], sgl4(j) ? size_t(4) : size_t(j.ncounts), ncclUint64, ncclSum, comms[i], streams[i]));
       HIP_OK(hipStreamSynchronize(streams[i]));
     });
     for (int i = 0; i < n; ++i) {
@@ -290,6 +299,12 @@ bool run_multi(const gm_csr &g, const Job &j, int n, int chunk, uint64_t *out) {
     }
     std::cout << "runtime [" << j.name << "] = " << t.Seconds() << " sec\n";
     HIP_OK(hipSetDevice(0));
+    if (sgl4(j)) {  // reduced raw sums -> the pattern's count
+      uint64_t raw[4];
+      HIP_OK(hipMemcpy(raw, d_cnt[0], sizeof raw, hipMemcpyDeviceToHost));
+      int rc = gm_sgl4_finish(j.pattern, raw, out);
+      if (rc) die(rc, "gm_sgl4_finish");
+    } else
     HIP_OK(hipMemcpy(out, d_cnt[0], sizeof(uint64_t) * size_t(j.ncounts), hipMemcpyDeviceToHost));
     if (j.kind == Job::MOTIF && j.k == 4) {  // reduced raw sums -> the six vertex-induced counts
       uint64_t raw[6];

@@ -38,7 +38,7 @@ void SglSolver(Graph &g, Pattern &p, uint64_t &total, int n_devices, int chunk_s
 }
 
 void CliqueSolver(Graph &g, int k, uint64_t &total, int n_gpu, int chunk_size) {
-  if (k < 3 || k > 8) {
+  if (k < 3 || k > GM_MAX_CLIQUE_K) {  // (the reference's solvers stop at 8: automine_omp.h:179-182, gpu_base.cu:59-71; its generic ones do not)
     std::cout << "Not implemented yet\n";  // src/clique/cpu_kernels/automine_omp.h:179-182
     std::exit(0);
   }

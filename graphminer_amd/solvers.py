@@ -99,6 +99,22 @@ def MotifSolver(g: DeviceGraph, k: int, *, rank=0, world=1, chunk=0, return_stat
     return (res, _stats(st)) if return_stats else res
 
 
+# ---- tailedtriangle / 4path / 3star on several ranks (include/graphminer_amd.h: gm_sgl4_*) ------------------------------------------------
+def sgl4_partial(g: DeviceGraph, *, rank=0, world=1, chunk=0, return_stats=False, **kw):
+    """this rank's share of the four per-edge sums the three patterns are closed forms of; sum the ranks' lists, then sgl4_finish"""
+    la, st, raw = _launch(rank, world, chunk, **kw), gm_stats(), (C.c_uint64 * 4)()
+    _lib.check(_lib.load().gm_sgl4_partial(g.handle, C.byref(la), None if la.d_counts else raw, C.byref(st)), "gm_sgl4_partial")
+    res = [int(x) for x in raw]
+    return (res, _stats(st)) if return_stats else res
+
+
+def sgl4_finish(pattern: str, raw) -> int:
+    """summed (mod 2**64) raw sums of every rank -> the count of `pattern`"""
+    total = C.c_uint64(0)
+    _lib.check(_lib.load().gm_sgl4_finish(pattern.encode(), (C.c_uint64 * 4)(*[int(x) & (2**64 - 1) for x in raw]), C.byref(total)), "gm_sgl4_finish")
+    return int(total.value)
+
+
 # ---- diamond on several ranks with the one-GPU algorithm (include/graphminer_amd.h: gm_diamond_support_*) ------------------------------
 def diamond_support_size(g: DeviceGraph, world: int = 1) -> int:
     """uint32 entries of a rank's support array: |E+| of the oriented copy, padded so that every rank's reduce-scatter slice is equal"""

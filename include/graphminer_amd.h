@@ -188,7 +188,7 @@ int gm_tc_core_info(const gm_graph *dag, int64_t info[4]);
 /* SglSolver: edge-induced subgraph listing on the SYMMETRIC graph, pattern by NAME
  * (include/pattern.hh:62-78). Implemented: "diamond" (src/sgl/cpu_kernels/diamond.h:1-14,
  * src/sgl/gpu_kernels/diamond_count.cuh:3-21), "rectangle" (rectangle.h:1-11), "house" (house.h:1-16),
- * "pentagon" (pentagon.h:2-17), and -- one GPU, from the per-edge sums of the formula 4-motif, no enumeration of their own --
+ * "pentagon" (pentagon.h:2-17), and -- one rank (several: gm_sgl4_partial), from the per-edge sums of the formula 4-motif, no enumeration of their own --
  * "tailedtriangle" (tailedtriangle.h:1-12), "4path" (4path.h:1-14), "3star" (3star.h:1-13).  Others (the 5- and 6-vertex patterns of
  * src/sgl/omp_base.cc:33-49 beyond house / pentagon) -> GM_ERR_UNSUPPORTED, *total = 0.
  * diamond = sum over the edges of C(|N(v0) ^ N(v1)|, 2). One GPU: |N(v0) ^ N(v1)| of every edge -- its triangles -- from ONE pass over
@@ -196,6 +196,13 @@ int gm_tc_core_info(const gm_graph *dag, int64_t info[4]);
  * >= 2^31 entries); world > 1, a DAG row beyond 2048 entries, or tune[6] & 0x10000000: one intersection of the two symmetric lists per
  * edge (gm_hrow.hip, gm_chunk.h). Same count. */
 int gm_sgl(const gm_graph *sym, const char *pattern, const gm_launch *launch, uint64_t *total, gm_stats *stats);
+
+/* tailedtriangle / 4path / 3star on SEVERAL ranks (the reference's sgl has no multi-GPU binary for them; same contract as
+ * gm_motif4_partial): every rank calls gm_sgl4_partial for its share of the four per-edge sums (plain sums over its tasks; with
+ * launch->d_counts they are left in that device buffer without synchronising and raw may be NULL), the ranks all-reduce raw[0..3],
+ * then gm_sgl4_finish(pattern, raw, &total) applies the pattern's closed form.  gm_sgl itself refuses world > 1 for these three. */
+int gm_sgl4_partial(const gm_graph *sym, const gm_launch *launch, uint64_t raw[4], gm_stats *stats);
+int gm_sgl4_finish(const char *pattern, const uint64_t raw[4], uint64_t *total);
 
 /* Diamond on SEVERAL ranks with the one-GPU algorithm (one shared pass over the triangles of the oriented copy; the reference has no
  * multi-GPU diamond: src/sgl/multigpu.cu:117 is commented out).  Per step, on every rank:
@@ -223,8 +230,10 @@ int gm_diamond_support_partial(const gm_graph *sym, const gm_launch *launch, uin
 int gm_diamond_support_finish(const gm_graph *sym, const gm_launch *launch, const uint32_t *d_support, int64_t count, uint64_t *total,
                               gm_stats *stats);
 
-/* CliqueSolver on the DAG, 3 <= k <= 8 (src/clique/cpu_kernels/automine_omp.h:67-83,138-157;
- * src/clique/gpu_kernels/clique4_warp_edge.cuh:3-31 ... clique8), any out-degree. k = 4: the first DFS level is re-hosted (every
+#define GM_MAX_CLIQUE_K 12
+/* CliqueSolver on the DAG, 3 <= k <= GM_MAX_CLIQUE_K (src/clique/cpu_kernels/automine_omp.h:67-83,138-157;
+ * src/clique/gpu_kernels/clique4_warp_edge.cuh:3-31 ... clique8; k = 9..12: the same levels once more, as the reference's generic
+ * clique_omp_recursive / edge_warp_iterative.cuh:2-75 count them -- its gpu_base.cu:59-71 stops at 8), any out-degree. k = 4: the first DFS level is re-hosted (every
  * edge at the endpoint with the longer out-list, gm_cbuild.hip), rows of up to 2048 entries keep their adjacency bit-matrix in an
  * arena in HBM, longer rows one per workgroup. k >= 5: the deeper levels run on induced sub-matrices; rows of up to 4096 entries sweep
  * them with two words per lane, longer rows out of the workgroup's global scratch (slow, exact; the degree-ordered DAG of com-Orkut has

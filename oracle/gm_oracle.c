@@ -573,13 +573,13 @@ static uint64_t clique_vertex(const gmo_graph *g, int k, gmo_vid v0, gmo_vid *bu
 
 static uint64_t clique_strided(const gmo_graph *g, int k, gmo_vid vb, gmo_vid ve, gmo_vid stride, uint64_t *tasks) {
   uint64_t counter = 0, t = 0;
-  if (k < 3 || k > 8) return 0;
+  if (k < 3 || k > 12) return 0;
   if (stride < 1) stride = 1;
   gmo_vid md = g->max_degree > 0 ? g->max_degree : 1;
   gmo_vid n = ve > vb ? (ve - vb + stride - 1) / stride : 0;
 #pragma omp parallel reduction(+ : counter, t)
   {
-    gmo_vid *buf = (gmo_vid *)malloc(sizeof(gmo_vid) * (size_t)md * 8);
+    gmo_vid *buf = (gmo_vid *)malloc(sizeof(gmo_vid) * (size_t)md * 12);
 #pragma omp for schedule(dynamic, 1)
     for (gmo_vid i = 0; i < n; i++) {
       gmo_vid v0 = vb + i * stride;

@@ -116,6 +116,11 @@ def counts_for_update(prefix, heavy, have):
     for k in (6, 7, 8):
         r.put(f"clique{k}", lambda: last_int(run("clique_omp_recursive", prefix, k), rf"num_{k}-cliques = (\d+)"))
     r.put("motif4", lambda: [int(x) for x in re.findall(r"pattern \d+: (\d+)", run("motif_omp_formula", prefix, 4))])
+    # round 6: k = 9..12 from the reference's generic solver (clique_omp_recursive; its automine / GPU solvers stop at 8), on the graphs
+    # where it takes seconds
+    if Graph(prefix).E() < 100000:
+        for k in (9, 10, 11, 12):
+            r.put(f"clique{k}", lambda k=k: last_int(run("clique_omp_recursive", prefix, k), rf"num_{k}-cliques = (\d+)"))
     # round 6: the other 4-vertex SgL patterns of src/sgl/omp_base.cc:21-31 (tailedtriangle.h, 4path.h, 3star.h)
     for pat in ("tailedtriangle", "4path", "3star"):
         r.put(pat, lambda pat=pat: last_int(run("sgl_omp_base", prefix, pat), r"total_num = (\d+)"))

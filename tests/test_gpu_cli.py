@@ -90,8 +90,8 @@ def test_clique_k5_on_a_row_beyond_4096_and_loud_failures(tmp_path):
     r = subprocess.run([os.path.join(BIN, "clique_gpu_base"), str(tmp_path / "graph"), "5"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-500:]
     assert r.stdout.strip().splitlines()[-1] == f"num_5-cliques = {want}"
-    r = subprocess.run([os.path.join(BIN, "clique_gpu_base"), str(tmp_path / "graph"), "9"], capture_output=True, text=True, timeout=300)
-    assert "Not implemented yet" in r.stdout and "num_9-cliques" not in r.stdout
+    r = subprocess.run([os.path.join(BIN, "clique_gpu_base"), str(tmp_path / "graph"), "13"], capture_output=True, text=True, timeout=300)
+    assert "Not implemented yet" in r.stdout and "num_13-cliques" not in r.stdout
 
 
 def test_cli_usage_exits_1():
@@ -109,6 +109,8 @@ def test_rccl_path_on_one_gpu():
     out = run("motif_multigpu", prefix, 3, 1, dev=dev)
     assert out[-2:] == [f"pattern 0: {e['motif3'][0]}", f"pattern 1: {e['motif3'][1]}"]
     assert run("sgl_multigpu", prefix, "diamond", 1, dev=dev)[-1] == f"total_num = {e['diamond']}"
+    for pat in ("tailedtriangle", "4path", "3star"):  # four raw per-edge sums all-reduced, then the closed form (gm_sgl4_partial / _finish)
+        assert run("sgl_multigpu", prefix, pat, 1, dev=dev)[-1] == f"total_num = {e[pat]}"
     # the environment is NOT a switch: the same variable there changes nothing (one device -> the one-GPU path, no broadcast line)
     r = subprocess.run([os.path.join(BIN, "tc_multigpu"), prefix, "1"], capture_output=True, text=True, timeout=300,
                        env=dict(os.environ, GM_FORCE_RCCL_PATH="1"))

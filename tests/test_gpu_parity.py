@@ -150,6 +150,15 @@ def test_sgl_four_vertex_patterns_from_the_per_edge_sums(gg, pattern):
     la.world, la.rank = 2, 0
     tot = C.c_uint64(7)
     assert lib.gm_sgl(sym.handle, pattern.encode(), C.byref(la), C.byref(tot), None) == _lib.GM_ERR_UNSUPPORTED
+    # ... so several ranks add up their raw sums (gm_sgl4_partial) and finish once
+    from graphminer_amd.solvers import sgl4_finish, sgl4_partial
+
+    for world in (2, 5):
+        raw = [0, 0, 0, 0]
+        for r in range(world):
+            raw = [x + y for x, y in zip(raw, sgl4_partial(sym, rank=r, world=world))]
+        assert sgl4_finish(pattern, raw) == e[pattern]
+    assert lib.gm_sgl4_finish(b"diamond", (C.c_uint64 * 4)(), C.byref(tot)) == _lib.GM_ERR_INVALID
 
 
 @pytest.mark.parametrize("pattern", ["rectangle", "house", "pentagon"])
@@ -211,10 +220,10 @@ def test_clique4_matches_reference(gg):
     assert CliqueSolver(dag, 4, tune=[0, 0, 0, 0, 0, 0, 0x800000]) == GOLDEN[name]["clique4"]  # the build's hashed set on its fallback lookup
 
 
-@pytest.mark.parametrize("k", [5, 6, 7, 8])
+@pytest.mark.parametrize("k", [5, 6, 7, 8, 9, 10, 11, 12])
 def test_clique_k_matches_reference(gg, k):
-    """k = 5 (automine_5clique, automine_omp.h:138-157) and k = 6, 7, 8 (goldens from clique_omp_recursive) on the
-    same bit-matrix: C_1(S)=|S|, C_m(S)=sum_{j in S} C_{m-1}(S & M_j)."""
+    """k = 5 (automine_5clique, automine_omp.h:138-157) and k = 6 .. 12 (goldens from clique_omp_recursive; the reference's GPU solver stops
+    at 8, src/clique/gpu_base.cu:59-71) on the same bit-matrix: C_1(S)=|S|, C_m(S)=sum_{j in S} C_{m-1}(S & M_j)."""
     name, _, _, dag = gg
     e = GOLDEN[name]
     if f"clique{k}" not in e:
@@ -326,6 +335,11 @@ def test_complete_graph_closed_forms(dev, n):
     assert CliqueSolver(d, 4) == math.comb(n, 4)
     for k in ((5, 6, 7, 8) if n <= 65 else (5, 6)):
         assert CliqueSolver(d, k) == math.comb(n, k)
+    if n == 5:
+        assert [CliqueSolver(d, k) for k in (9, 12)] == [0, 0]
+        k20 = _complete_graph(20).to_device(dev).orient()
+        assert [CliqueSolver(k20, k) for k in (9, 10, 11, 12)] == [math.comb(20, k) for k in (9, 10, 11, 12)]
+        assert CliqueSolver(_complete_graph(28).to_device(dev).orient(), 12) == math.comb(28, 12)
     assert SglSolver(s, "diamond") == math.comb(n, 2) * math.comb(n - 2, 2)
     assert MotifSolverE(s, 3) == [0, math.comb(n, 3)]
 
@@ -402,6 +416,36 @@ def test_deeper_cliques_on_a_row_wider_than_2048(dev):
         assert want > 0
         assert CliqueSolver(d2g, k) == want, k
     assert sum(CliqueSolver(d2g, 5, rank=r, world=3) for r in range(3)) == O.clique(odag2, 5)
+
+
+def _hub_over_a_random_graph(W, p, seed, planted=0):
+    """vertex 0 with W neighbours w_j, every w_j with W - 1 private leaves (0 -> w_j in the degree-ordered DAG: a row of W entries), a random
+    graph of density p on the w_j and a planted clique on the first `planted` of them"""
+    rng = np.random.default_rng(seed)
+    a, b = np.triu_indices(W, 1)
+    keep = (rng.random(a.size) < p) | (b < planted)
+    s = np.concatenate([np.zeros(W, dtype=np.uint64), np.repeat(np.arange(1, W + 1, dtype=np.uint64), W - 1), (a[keep] + 1).astype(np.uint64)])
+    d = np.concatenate([np.arange(1, W + 1, dtype=np.uint64), np.arange(W + 1, W + 1 + W * (W - 1), dtype=np.uint64), (b[keep] + 1).astype(np.uint64)])
+    return csr_from_pairs(int(W + 1 + W * (W - 1)), s, d)
+
+
+@pytest.mark.parametrize("W,p,planted", [(600, 0.35, 0), (2100, 0.12, 12), (4200, 0.04, 12)])
+def test_cliques_of_nine_to_twelve_on_wide_rows(dev, W, p, planted):
+    """k = 9..12 (the reference counts them with its generic clique_omp_recursive / edge_warp_iterative.cuh:2-75; gpu_base.cu:59-71 stops at 8)
+    where the deeper levels are CALLED, not inlined (gm_chunk.h kCliqueInlineM): a DAG row of 600 entries (sub-matrices in LDS / the second
+    arena slot), of 2100 (two words per lane) and of 4200 (everything from the workgroup's global scratch), against the oracle's DFS"""
+    g = _hub_over_a_random_graph(W, p, 23, planted)
+    odag = O.orient(O.OGraph(g.row_ptr, g.col_idx))
+    assert int(np.diff(odag.row_ptr).max()) == W
+    dg = g.to_device(dev).orient()
+    got = {}
+    for k in (9, 10, 11, 12):
+        want = O.clique(odag, k)
+        got[k] = want
+        assert CliqueSolver(dg, k) == want, k
+    assert got[9] > 0 and (planted == 0 or got[12] > 0)
+    assert sum(CliqueSolver(dg, 9, rank=r, world=3) for r in range(3)) == got[9]
+    assert CliqueSolver(dg, 9, tune=[0, 0, 0, 0, 0, 0, 0x20]) == got[9]  # the per-sub-tree walk (A/B)
 
 
 def test_deeper_cliques_sub_matrix_path_rmat14(dev):

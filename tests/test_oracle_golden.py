@@ -66,7 +66,7 @@ def test_house_pentagon(graphs):
     assert O.pentagon(sym) == e["pentagon"]
 
 
-@pytest.mark.parametrize("k", [4, 5, 6, 7, 8])
+@pytest.mark.parametrize("k", [4, 5, 6, 7, 8, 9, 10, 11, 12])  # (9..12: goldens from the generic clique_omp_recursive)
 def test_clique(graphs, k):
     name, _, _, dag = graphs
     e = GOLDEN[name]
