@@ -75,11 +75,11 @@ KERNELS = {
     "clique4": ["cgather_kernel", "cgatherb_kernel", "cbuild_kernel", "clique_mma_kernel", "clique_small_kernel", "mine_kernel<3,"],
     "clique5": ["mine_kernel<4,"],
     "motif3f": ["tch_kernel", "mine_kernel<0,", "core_tc_"],
-    "rectangle": ["rect_acc_kernel"],
+    "rectangle": ["rect_acc_kernel", "rect_lds_kernel"],
     "house": ["house_acc_kernel"],
     "pentagon": ["pent_acc_kernel"],
     # (gm_motif, k = 4: per-edge sums of the symmetric graph + rectangle by wedge accumulation + 4-clique of the oriented copy)
-    "motif4": ["mine_kernel<5,", "hrow_kernel<5,", "giant_kernel<5,", "rect_acc_kernel", "mine_kernel<3,", "cbuild_kernel", "cgather_kernel", "clique_mma_kernel",
+    "motif4": ["mine_kernel<5,", "hrow_kernel<5,", "giant_kernel<5,", "rect_acc_kernel", "rect_lds_kernel", "mine_kernel<3,", "cbuild_kernel", "cgather_kernel", "clique_mma_kernel",
                "clique_small_kernel", "cgatherb_kernel", "tch_kernel", "core_tc_"],
 }
 CORNER_KERNEL = "core_tc_"  # (the MFMA kernels of gm_ctc.hip: reported beside the whole-launch HBM roofline against the FP4 peak)

@@ -343,6 +343,15 @@ struct gm_graph {
   unsigned long long n_wblocks = 0;
   int4 *d_rect_tasks = nullptr;          // rectangle by wedge accumulation: task list, counter maps
   unsigned long long n_rect_tasks = 0;
+  // rectangle with the heavy centres' counter maps in LDS (round 6, gm_mine.hip rect_lds_kernel): row bounds per range boundary, the
+  // (centre, range) tasks, and rect_acc_kernel's list with the centres that keep only their ends below `rect_cut` first
+  int *d_rect_bnd = nullptr;
+  int2 *d_rect_lds_tasks = nullptr;
+  int4 *d_rect_cut_tasks = nullptr;
+  unsigned long long n_rect_lds_tasks = 0, n_rect_cut_tasks = 0, n_rect_cut = 0;
+  int rect_cut = 0;
+  gm::RectLdsRanges rect_ranges;
+  bool rect_lds_ready = false;
   unsigned *d_rect_acc = nullptr;
   size_t rect_acc_bytes = 0;
   unsigned *d_house_t = nullptr;         // house by wedge accumulation: per-entry tables, task list, 64-bit maps

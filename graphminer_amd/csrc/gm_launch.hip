@@ -1127,7 +1127,8 @@ static int run_rect_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h_
   gv.col = g->d_col;
   rc = ensure_idx0(g, gv);
   if (rc) return rc;
-  if (!g->d_rect_tasks) {  // once per graph: 2-path estimate per centre (device), task list (host): heavy first, then light by 4
+  const bool lds_maps = !pentagon && !(la->tune[6] & 0x20000);
+  if (!g->d_rect_tasks && !lds_maps) {  // once per graph: 2-path estimate per centre (device), task list (host): heavy first, then light by 4
     OtherSetupScope scope(g);
     const size_t nv = (size_t)g->nv;
     unsigned long long *d_work = nullptr;
@@ -1158,13 +1159,137 @@ static int run_rect_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h_
     HIP_TRY(dev_malloc(&g->d_rect_tasks, sizeof(int4) * std::max<size_t>(tasks.size(), 1)));
     if (!tasks.empty()) HIP_TRY(hipMemcpy(g->d_rect_tasks, tasks.data(), sizeof(int4) * tasks.size(), hipMemcpyHostToDevice));
   }
+  // rectangle: the 2-path ends in the last kRectLdsRanges * kRectLdsRange ids of the centres with >= GM_RECT_LDS_MIN 2-paths are counted in
+  // LDS maps (rect_lds_kernel); tune[6] & 0x20000: every end in the global maps, round 5's form.  Once per graph: the row bounds, the
+  // (centre, range) tasks -- every centre's own top range first, the centres heaviest first -- and rect_acc_kernel's list again with
+  // those centres (now only their ends below the cut) in front.
+  if (lds_maps && !g->rect_lds_ready) {
+    OtherSetupScope scope(g);
+    const size_t nv = (size_t)g->nv;
+    unsigned long long lds_min = 4096;
+    if (const char *e = gm_opt("GM_RECT_LDS_MIN")) lds_min = std::strtoull(e, nullptr, 10);
+    // the ranges, from the last ids down (the hubs of a graph numbered ascending in degree): a range's counters are as wide as the largest
+    // degree among its vertices needs -- whatever the numbering (tune[6] & 512 runs on the graph as given)
+    RectLdsRanges &rr = g->rect_ranges;
+    memset(&rr, 0, sizeof rr);
+    {
+      const int nblk = (int)((nv + kRectLdsWords - 1) / kRectLdsWords);
+      std::vector<int> bmax((size_t)std::max(nblk, 1), 0);
+      if (nv) {
+        int *d_bmax = nullptr;
+        HIP_TRY(dev_malloc(&d_bmax, sizeof(int) * (size_t)nblk));
+        hipError_t e0 = hipMemset(d_bmax, 0, sizeof(int) * (size_t)nblk);
+        if (e0 == hipSuccess) e0 = launch_rect_blockmax(gv, d_bmax, 0);
+        if (e0 == hipSuccess) e0 = hipMemcpy(bmax.data(), d_bmax, sizeof(int) * (size_t)nblk, hipMemcpyDeviceToHost);
+        dev_free(d_bmax);
+        if (e0 != hipSuccess) return hip_fail(e0, "rect_blockmax_kernel", __FILE__, __LINE__);
+      }
+      auto max_deg_of_blocks = [&](int b0, int nb) {  // blocks b0 .. b0 + nb - 1 (counted from the top), those that exist
+        int m = 0;
+        for (int b = b0; b < std::min(b0 + nb, nblk); ++b) m = std::max(m, bmax[(size_t)b]);
+        return m;
+      };
+      int blk = 0;
+      int top[kRectLdsRanges + 1], lbs[kRectLdsRanges], n = 0;
+      long long hi = (long long)g->nv;
+      top[0] = (int)hi;
+      int max_ranges = kRectLdsRanges;
+      if (const char *e = gm_opt("GM_RECT_LDS_RANGES")) max_ranges = std::max(1, std::min(kRectLdsRanges, std::atoi(e)));
+      while (hi > 0 && n < max_ranges) {
+        const int lb = max_deg_of_blocks(blk, 4) < 256 ? 3 : max_deg_of_blocks(blk, 2) < 65536 ? 4 : 5;
+        const long long width = (long long)kRectLdsWords << (5 - lb);
+        blk += 1 << (5 - lb);
+        hi = std::max<long long>(0, hi - width);
+        lbs[n] = lb;
+        top[++n] = (int)hi;
+      }
+      rr.n = n;
+      for (int k = 0; k <= n; ++k) rr.rb[k] = top[n - k];
+      for (int k = 0; k < n; ++k) rr.lb[k] = lbs[n - 1 - k];
+    }
+    g->rect_cut = rr.rb[0];
+    HIP_TRY(dev_malloc(&g->d_rect_bnd, sizeof(int) * (size_t)(rr.n + 1) * std::max<size_t>(nv, 1)));
+    unsigned long long *d_work = nullptr;
+    HIP_TRY(dev_malloc(&d_work, sizeof(unsigned long long) * 2 * std::max<size_t>(nv, 1)));
+    std::vector<unsigned long long> work(std::max<size_t>(nv, 1)), wcut(std::max<size_t>(nv, 1));
+    hipError_t e = hipSuccess;
+    if (nv) {
+      e = launch_rect_bounds(gv, rr, g->d_rect_bnd, 0);
+      if (e == hipSuccess) e = launch_rect_work_cut(gv, g->d_idx0, g->d_rect_bnd, rr.n + 1, d_work, 0);  // (both estimates: [0, nv) all ends, [nv, 2 nv) the ends below the cut)
+      if (e == hipSuccess) e = hipMemcpy(work.data(), d_work, sizeof(unsigned long long) * nv, hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpy(wcut.data(), d_work + nv, sizeof(unsigned long long) * nv, hipMemcpyDeviceToHost);
+    }
+    dev_free(d_work);
+    if (e != hipSuccess) return hip_fail(e, "rect_bounds_kernel", __FILE__, __LINE__);
+    std::vector<int> lds, rest;
+    for (size_t v = 0; v < nv; ++v) {
+      if (work[v] == 0) continue;
+      if (work[v] >= lds_min && (long long)v > (long long)g->rect_cut) lds.push_back((int)v);
+      else rest.push_back((int)v);
+    }
+    auto by = [](const std::vector<unsigned long long> &w) { return [&w](int a, int b) { return w[(size_t)a] > w[(size_t)b]; }; };
+    std::stable_sort(lds.begin(), lds.end(), by(work));
+    std::stable_sort(rest.begin(), rest.end(), by(work));
+    std::vector<int2> lt;
+    auto range_of = [&](int w) {  // the range that holds id w >= cut
+      int k = 0;
+      while (k + 1 < rr.n && rr.rb[k + 1] <= w) ++k;
+      return k;
+    };
+    // a centre with more neighbours below it than rect_lds_kernel has threads: a task per range, every centre's own top range first; the
+    // others: one task for all their ranges
+    std::vector<int> idx0h(std::max<size_t>(nv, 1));
+    if (nv) HIP_TRY(hipMemcpy(idx0h.data(), g->d_idx0, sizeof(int) * nv, hipMemcpyDeviceToHost));
+    const int per_wg = kRectLdsWaves * GM_WAVE;
+    for (int j = 0; j < rr.n; ++j)
+      for (int v : lds) {
+        if (idx0h[(size_t)v] <= per_wg) continue;
+        const int k = range_of(v - 1) - j;
+        if (k >= 0) lt.push_back(make_int2(v, k));
+      }
+    for (int v : lds)
+      if (idx0h[(size_t)v] <= per_wg) lt.push_back(make_int2(v, -1));
+    const unsigned long long heavy = 1ull << 15;  // 2-paths above which a centre gets a whole workgroup of rect_acc_kernel
+    std::vector<int4> tasks;
+    auto emit = [&](const std::vector<int> &vs, const std::vector<unsigned long long> &w) {
+      size_t i = 0;
+      for (; i < vs.size() && w[(size_t)vs[i]] >= heavy; ++i) tasks.push_back(make_int4(vs[i], -2, -2, -2));
+      for (; i < vs.size(); i += 4) {
+        int4 t = make_int4(vs[i], -1, -1, -1);
+        if (i + 1 < vs.size()) t.y = vs[i + 1];
+        if (i + 2 < vs.size()) t.z = vs[i + 2];
+        if (i + 3 < vs.size()) t.w = vs[i + 3];
+        tasks.push_back(t);
+      }
+    };
+    std::vector<int> ldscut;  // the LDS centres that have ends below the cut (none when the ranges cover the whole graph)
+    for (int v : lds)
+      if (wcut[(size_t)v] > 0) ldscut.push_back(v);
+    std::stable_sort(ldscut.begin(), ldscut.end(), by(wcut));
+    emit(ldscut, wcut);
+    g->n_rect_cut = tasks.size();
+    emit(rest, work);
+    g->n_rect_cut_tasks = tasks.size();
+    g->n_rect_lds_tasks = lt.size();
+    HIP_TRY(dev_malloc(&g->d_rect_cut_tasks, sizeof(int4) * std::max<size_t>(tasks.size(), 1)));
+    if (!tasks.empty()) HIP_TRY(hipMemcpy(g->d_rect_cut_tasks, tasks.data(), sizeof(int4) * tasks.size(), hipMemcpyHostToDevice));
+    HIP_TRY(dev_malloc(&g->d_rect_lds_tasks, sizeof(int2) * std::max<size_t>(lt.size(), 1)));
+    if (!lt.empty()) HIP_TRY(hipMemcpy(g->d_rect_lds_tasks, lt.data(), sizeof(int2) * lt.size(), hipMemcpyHostToDevice));
+    g->rect_lds_ready = true;
+  }
   RectAccParams p;
   memset(&p, 0, sizeof p);
   p.g = gv;
   p.idx0 = g->d_idx0;
-  p.tasks = g->d_rect_tasks;
+  p.tasks = lds_maps ? g->d_rect_cut_tasks : g->d_rect_tasks;
+  if (lds_maps) {
+    p.n_cut = g->n_rect_cut;
+    p.cut = g->rect_cut;
+    p.bnd0 = g->d_rect_bnd;
+    p.bnd_stride = g->rect_ranges.n + 1;
+  }
   int64_t first = 0, step = 1, count = 0;
-  gm_partition((int64_t)g->n_rect_tasks, ctx.rank, ctx.world, la->policy, &first, &step, &count);
+  gm_partition((int64_t)(lds_maps ? g->n_rect_cut_tasks : g->n_rect_tasks), ctx.rank, ctx.world, la->policy, &first, &step, &count);
   p.first = (unsigned long long)first;
   p.step = (unsigned long long)step;
   p.count = (unsigned long long)count;
@@ -1219,10 +1344,28 @@ static int run_rect_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h_
     fill_stats(st, (uint64_t)(g->ne / 2 / ctx.world), (uint64_t)count, (int)grid, 256);
     return end_launch(ctx, FIN_HALF_SIGNED, 0, h_out, 1, st);
   }
+  RectLdsParams lp;
+  memset(&lp, 0, sizeof lp);
+  int64_t lcount = 0;
+  if (lds_maps) {
+    lp.g = gv;
+    lp.idx0 = g->d_idx0;
+    lp.tasks = g->d_rect_lds_tasks;
+    int64_t lfirst = 0, lstep = 1;
+    gm_partition((int64_t)g->n_rect_lds_tasks, ctx.rank, ctx.world, la->policy, &lfirst, &lstep, &lcount);
+    lp.first = (unsigned long long)lfirst;
+    lp.step = (unsigned long long)lstep;
+    lp.count = (unsigned long long)lcount;
+    lp.bnd = g->d_rect_bnd;
+    lp.r = g->rect_ranges;
+    lp.queue = g->d_counters + 5;  // (its own dequeue word inside the zeroed 64-byte block)
+    lp.counters = g->d_counters;
+  }
   rc = start_timer(ctx);
   if (rc) return rc;
+  if (lcount > 0) HIP_TRY(launch_rect_lds(lp, (int)std::min<long long>((long long)g->cu_count, (long long)lcount), ctx.stream));
   if (count > 0) HIP_TRY(launch_rect_acc(p, (int)grid, ctx.stream));
-  fill_stats(st, (uint64_t)(g->ne / 2 / ctx.world), (uint64_t)count, (int)grid, 256);
+  fill_stats(st, (uint64_t)(g->ne / 2 / ctx.world), (uint64_t)(count + lcount), (int)grid, 256);
   return end_launch(ctx, FIN_COPY, 0, h_out, 1, st);
 }
 

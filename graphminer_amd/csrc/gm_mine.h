@@ -9,7 +9,7 @@
 // else's main must not change what it runs on an ambient variable).  What tests need to reach a path on a small graph, and the documented
 // fallbacks, are named options set through the C ABI -- gm_dev_option(name, value), include/graphminer_amd.h -- and read with gm_opt():
 //   GM_DIAMOND_PER_EDGE, GM_SUP_STREAM / GM_SUP_NO_MASKS / GM_SUP_MASK_MIN (edge supports), GM_TC_CORE_H / GM_SUP_CORE_H (hub corner),
-//   GM_BIG_NE, GM_KST_MAX_KEYS, GM_TOPO_MIN_ROW, GM_WIDE_ARENA_MB, GM_TCT_SPLIT_ALWAYS (limits lowered for tests), GM_ORIENT_TWO_GATHERS,
+//   GM_BIG_NE, GM_KST_MAX_KEYS, GM_TOPO_MIN_ROW, GM_WIDE_ARENA_MB, GM_TCT_SPLIT_ALWAYS, GM_RECT_LDS_MIN / GM_RECT_LDS_RANGES (limits lowered for tests), GM_ORIENT_TWO_GATHERS,
 //   GM_RELABEL_GLOBAL_SORT (the previous setup paths, compared in tests), GM_NO_TEMP_POOL, and the n-GPU runner's GM_FORCE_RCCL_PATH /
 //   GM_DIAMOND_SUPPORTS_MAX_WORLD (host/multi.cc).  Only GM_SETUP_TRACE (setup steps on stderr: diagnostics, no algorithm) is an
 //   environment variable.  In -DGM_DEVEL builds (make DEVEL=1) an option that is not set falls back to the environment, and the
@@ -242,8 +242,41 @@ struct RectAccParams {
   unsigned long long acc_stride;
   unsigned long long *queue;
   unsigned long long *counters;
+  // round 6: the first n_cut tasks are centres whose 2-path ends at or above `cut` are counted out of LDS maps (rect_lds_kernel):
+  // they walk the ends below cut only (bnd0[x] = where the entries >= cut of row x begin).  n_cut = 0: every end, as before.
+  unsigned long long n_cut;
+  int cut;
+  const int *bnd0;  // bnd0[x * bnd_stride]
+  int bnd_stride;
 };
 hipError_t launch_rect_acc(const RectAccParams &p, int grid_blocks, hipStream_t stream);
+
+// rectangle, the counter maps of the heavy centres in LDS (gm_mine.hip rect_lds_kernel): the ids [cut, nv) of a graph numbered ascending in
+// degree are cut into ranges, a task is (centre v0, range k): one workgroup walks the 2-paths v0 - x - w with w in the range and counts them
+// in a dense map in LDS.  A counter never exceeds d(w), and the degrees fall quickly below the hubs: a range whose largest degree is below
+// 2^8 / 2^16 packs four / two counters into a word (128 K / 64 K ids per range instead of 32 K), so that sixteen ranges reach far down.
+constexpr int kRectLdsWords = 32768;  // 128 KB of counters
+constexpr int kRectLdsRanges = 16;    // at most
+constexpr int kRectLdsWaves = 16;
+struct RectLdsRanges {
+  int n;                          // ranges in use
+  int rb[kRectLdsRanges + 1];     // range k = ids [rb[k], rb[k + 1]), ascending; rb[0] = cut, rb[n] = nv
+  int lb[kRectLdsRanges];         // log2 of the counter width of range k: 5, 4 or 3
+};
+struct RectLdsParams {
+  GraphView g;
+  const int *idx0;
+  const int2 *tasks;  // {v0, k}: range k of centre v0; {v0, -1}: every range of a centre with at most kRectLdsWaves * 64 neighbours below it
+  unsigned long long first, step, count;
+  const int *bnd;  // nv x (n + 1): bnd[x * (n + 1) + k] = index into col[] of the first entry >= rb[k] of row x
+  RectLdsRanges r;
+  unsigned long long *queue;
+  unsigned long long *counters;
+};
+hipError_t launch_rect_lds(const RectLdsParams &p, int grid_blocks, hipStream_t stream);
+hipError_t launch_rect_bounds(const GraphView &g, const RectLdsRanges &r, int *bnd, hipStream_t stream);
+hipError_t launch_rect_blockmax(const GraphView &g, int *blockmax, hipStream_t stream);  // blockmax[b] (zeroed) = largest degree among the ids [nv - (b + 1) W, nv - b W), W = kRectLdsWords
+hipError_t launch_rect_work_cut(const GraphView &g, const int *idx0, const int *bnd0, int bnd_stride, unsigned long long *work, hipStream_t stream);
 hipError_t launch_rect_work(const GraphView &g, const int *idx0, unsigned long long *work, hipStream_t stream);
 
 // house by wedge accumulation (gm_mine.hip): per-entry triangle tables + one 2-path walk per centre with a 64-bit

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void rect_work_kernel(GraphView g, const int *
 __global__ __launch_bounds__(256) void rect_acc_kernel(const RectAccParams p) {
   __shared__ WaveLds W[kWavesPerBlock];
   __shared__ int4 s_task;
-  __shared__ int s_next, s_ntouched;
+  __shared__ int s_next, s_ntouched, s_cut;
   __shared__ int s_wtouched[kWavesPerBlock];
   const int *__restrict__ rp = p.g.rp;
   const int *__restrict__ col = p.g.col;
@@ -155,6 +155,7 @@ __global__ __launch_bounds__(256) void rect_acc_kernel(const RectAccParams p) {
     if (threadIdx.x == 0) {
       const unsigned long long q = atomicAdd(p.queue, 1ull);
       s_task = (q < p.count) ? p.tasks[p.first + q * p.step] : make_int4(-3, -3, -3, -3);
+      s_cut = (q < p.count && p.first + q * p.step < p.n_cut) ? 1 : 0;
       s_next = 0;
       s_ntouched = 0;
     }
@@ -162,6 +163,7 @@ __global__ __launch_bounds__(256) void rect_acc_kernel(const RectAccParams p) {
     __syncthreads();
     const int4 t = s_task;
     if (t.x == -3) break;
+    const bool use_cut = s_cut != 0;  // (the ends at or above p.cut of this task's centres belong to rect_lds_kernel)
     const bool heavy = t.y == -2;
     const int v0 = heavy ? t.x : (wave == 0 ? t.x : wave == 1 ? t.y : wave == 2 ? t.z : t.w);
     unsigned *acc = p.acc + (heavy ? slot_wg : slot_own) * p.acc_stride;
@@ -189,7 +191,8 @@ __global__ __launch_bounds__(256) void rect_acc_kernel(const RectAccParams p) {
             if (i < nitems) {
               const int x = col[r0 + i];
               kb = rp[x];
-              llen = lower_bound(col + kb, rp[x + 1] - kb, v0);  // {w in N(x) : w < v0}
+              if (use_cut && p.cut <= v0) llen = p.bnd0[(size_t)x * (size_t)p.bnd_stride] - kb;  // {w in N(x) : w < cut}
+              else llen = lower_bound(col + kb, rp[x + 1] - kb, v0);  // {w in N(x) : w < v0}
             }
             // (measured: issuing the four returning atomics of a tile group back to back is ~5 % SLOWER than one at a
             // time -- the map updates are bound by the L2 atomic units, not by latency)
@@ -231,6 +234,313 @@ __global__ __launch_bounds__(256) void rect_acc_kernel(const RectAccParams p) {
   }
   const unsigned long long s0 = wave_sum_u64(cnt);
   if (lane == 0 && s0) atomicAdd(&p.counters[0], s0);
+}
+
+// ---- rectangle: the counter maps of the heavy centres in LDS (round 6) -----------------------------------------------------------------
+// rect_acc_kernel's maps are vertex-indexed arrays in global memory, one per wave, and every 2-path is a returning atomic that goes to L2
+// and beyond (R-MAT-20 ef 16: 5.6 G 2-paths, 42 bytes of traffic each, 344 ms -- 0.09 of the HBM rate, bound by the atomic units).  On a
+// graph numbered ascending in degree the ends w of the 2-paths are the hubs: 61 % lie in the last 32 K ids, 96 % in the last 256 K.  So
+// the id space [cut, nv) is cut into ranges (32 K ids of 32-bit counters at the hubs; 64 K / 128 K ids of 16- / 8-bit counters packed into
+// words where no vertex of the range has a degree of 2^16 / 2^8 -- a counter c(w) never exceeds d(w)) and a workgroup takes (centre v0, range k): it walks the neighbours x of v0
+// below v0, the entries of row x inside the range come from a table of row bounds (bnd: one binary search per (x, range boundary), once per
+// graph), every 2-path is ONE non-returning LDS atomic into a dense map, and sum C(c, 2) is taken when the map is read back and cleared.
+// The ends below cut stay with rect_acc_kernel (RectAccParams::cut).  Same count: rectangle.h:1-11 as restated above rect_work_kernel.
+#ifndef GM_RECT_LDS_TILES
+#define GM_RECT_LDS_TILES 8
+#endif
+constexpr int kRectLdsTiles = GM_RECT_LDS_TILES;  // tiles of 64 keys requested together by a wave of rect_lds_kernel
+struct alignas(16) WaveLdsFlat {  // what flat_pass<SEARCH_NONE> uses of the per-wave scratch
+  int4 desc[GM_WAVE];
+  unsigned char marks[kMarkWindow];
+};
+// every key of the lists (kb, llen) of the 64 lanes, flattened into tiles of 64 -- flat_pass<SEARCH_NONE> with the NEXT group of TG tiles
+// requested before the current one is handed to f(in[], key[]): the walk of rect_lds_kernel is one global load per key followed by one
+// LDS atomic, and with four loads per lane in flight and nothing behind them a 16-wave workgroup moved 1.2 G keys/s per CU (17.2 ms for the
+// 5.6 G 2-paths of R-MAT-20 ef 16), the latency of the loads, not the LDS.
+template <int TG, class LT, class F>
+__device__ __forceinline__ void flat_walk(LT &L, const int *__restrict__ col, const int lane, const int llen, const int kb, F f) {
+  static_assert(kMarkWindow % (GM_WAVE * TG) == 0, "a window of owner marks is a whole number of tile groups");
+  const int incl = wave_incl_scan_add(llen);
+  const int total = readlane(incl, GM_WAVE - 1);
+  if (total == 0) return;  // wave-uniform
+  const int off = incl - llen;
+  L.desc[lane] = make_int4(kb, off, 0, 0);
+  unsigned *m32 = reinterpret_cast<unsigned *>(L.marks);
+  int carry = 0;
+  int key[TG];
+  bool in[TG], have = false;
+  for (int wb = 0; wb < total; wb += kMarkWindow) {
+    const int wn = min(kMarkWindow, total - wb);
+    const int nwords = ((wn + GM_WAVE * TG - 1) / (GM_WAVE * TG)) * (GM_WAVE * TG / 4);
+    for (int i = lane; i < nwords; i += GM_WAVE) m32[i] = 0u;
+    wave_sync();
+    if (llen > 0 && off >= wb && off < wb + kMarkWindow) L.marks[off - wb] = (unsigned char)(lane + 1);
+    wave_sync();
+    for (int t = 0; t < wn; t += GM_WAVE * TG) {
+      int own[TG], nkey[TG];
+      bool nin[TG];
+#pragma unroll
+      for (int q = 0; q < TG; ++q) own[q] = (int)L.marks[t + q * GM_WAVE + lane];
+#pragma unroll
+      for (int q = 0; q < TG; ++q) {
+        own[q] = max(wave_incl_scan_max(own[q]), carry);
+        carry = readlane(own[q], GM_WAVE - 1);
+      }
+#pragma unroll
+      for (int q = 0; q < TG; ++q) {
+        const int pp = wb + t + q * GM_WAVE + lane;
+        nin[q] = pp < total;
+        const int4 d = L.desc[nin[q] ? own[q] - 1 : 0];
+        nkey[q] = col[nin[q] ? d.x + (pp - d.y) : 0];  // unconditional load (select on the index)
+      }
+      if (have) f(in, key);  // (the previous group, while this one's keys are on their way)
+#pragma unroll
+      for (int q = 0; q < TG; ++q) {
+        key[q] = nkey[q];
+        in[q] = nin[q];
+      }
+      have = true;
+    }
+    wave_sync();
+  }
+  if (have) f(in, key);
+}
+
+struct alignas(16) RectLds {
+  unsigned map[kRectLdsWords];
+  WaveLdsFlat w[kRectLdsWaves];
+  int2 task;
+  int next;
+  unsigned any[2];  // (by task parity: the flag of the next task is cleared while this one's map is read back)
+};
+
+__global__ __launch_bounds__(256) void rect_bounds_kernel(GraphView g, RectLdsRanges rr, int *__restrict__ bnd) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= g.nv) return;
+  const int r = g.rp[x], d = g.rp[x + 1] - r;
+  int at = 0;
+  for (int k = 0; k <= rr.n; ++k) {
+    at += (rr.rb[k] >= g.nv) ? d - at : lower_bound(g.col + r + at, d - at, rr.rb[k]);
+    bnd[(size_t)x * (size_t)(rr.n + 1) + (size_t)k] = r + at;
+  }
+}
+
+// largest degree per block of kRectLdsWords ids, counted from the LAST id down (the ranges are whole blocks)
+__global__ __launch_bounds__(256) void rect_blockmax_kernel(GraphView g, int *__restrict__ blockmax) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int xc = min(x, g.nv - 1);
+  const int b = (g.nv - 1 - xc) / kRectLdsWords, d = x < g.nv ? g.rp[xc + 1] - g.rp[xc] : 0;
+  // (a wave's 64 ids share a block except where one ends: one atomic per wave there, same-address atomics are served one after the other)
+  const int b0 = readfirst(b);
+  const bool same = __ballot(b != b0) == 0ull;
+  const int m = wave_max_nonneg(d);
+  if (same) {
+    if ((threadIdx.x & 63) == 0) atomicMax(&blockmax[b0], m);
+  } else {
+    atomicMax(&blockmax[b], d);
+  }
+}
+
+// 2-paths of centre v whose end lies below cut (the part rect_acc_kernel keeps for a centre whose other ends go to the LDS maps)
+__global__ __launch_bounds__(256) void rect_work_cut_kernel(GraphView g, const int *__restrict__ idx0, const int *__restrict__ bnd0, int bnd_stride,
+                                                            unsigned long long *__restrict__ work) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= g.nv) return;
+  unsigned long long w = 0, wc = 0;
+  const int r0 = g.rp[v];
+  for (int i = 0; i < idx0[v]; ++i) {
+    const int x = g.col[r0 + i];
+    w += (unsigned long long)(g.rp[x + 1] - g.rp[x]) + 1ull;  // (as rect_work_kernel)
+    wc += (unsigned long long)(bnd0[(size_t)x * (size_t)bnd_stride] - g.rp[x]);
+  }
+  work[v] = w;
+  work[(size_t)g.nv + (size_t)v] = wc;
+}
+
+#ifndef GM_RECT_LDS_LONG
+#define GM_RECT_LDS_LONG 64
+#endif
+constexpr int kRectLdsLong = GM_RECT_LDS_LONG;  // keys of a row inside the range from which the wave takes the row on its own
+
+__global__ __launch_bounds__(kRectLdsWaves *GM_WAVE) void rect_lds_kernel(const RectLdsParams p) {
+  __shared__ RectLds S;
+  const int *__restrict__ rp = p.g.rp;
+  const int *__restrict__ col = p.g.col;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tid = threadIdx.x;
+  constexpr int nthreads = kRectLdsWaves * GM_WAVE;
+  WaveLdsFlat &L = S.w[wave];
+  for (int i = tid; i < kRectLdsWords; i += nthreads) S.map[i] = 0u;
+  unsigned long long cnt = 0;
+  const int bs = p.r.n + 1;  // bounds per row
+  auto fetch = [&]() {
+    const unsigned long long q = atomicAdd(p.queue, 1ull);
+    return (q < p.count) ? p.tasks[p.first + q * p.step] : make_int2(-3, -3);
+  };
+  if (tid == 0) {
+    S.task = fetch();
+    S.next = 0;
+    S.any[0] = S.any[1] = 0u;
+  }
+  __syncthreads();
+  int ph = 0;  // ranges this workgroup has walked (the parity of the "any key" flag)
+  // the keys (kb, llen) of this wave's 64 rows into the map of range k; keys >= vlim are left out
+  // RTN: the atomic returns the counter and the old value is summed on the spot (0 + 1 + .. + (c - 1) = C(c, 2), as rect_acc_kernel does):
+  // the map is then cleared blindly instead of read back -- for the centres whose ranges hold few keys (measured: reading 128 KB of counters
+  // back after every one of the 190 K (centre, range) walks was 4.2 of the kernel's 12.5 ms)
+  auto walk = [&](const int kb, int llen, const int k, const int vlim, const bool RTN) {
+    const int lo = p.r.rb[k], lb = p.r.lb[k], sh = 5 - lb;  // counters of 2^lb bits, 2^sh of them in a word
+    const unsigned fm = (1u << sh) - 1u;
+    const unsigned cm = lb == 5 ? 0xffffffffu : (1u << (1 << lb)) - 1u;
+    auto add = [&](const int key) {
+      const unsigned off = (unsigned)(key - lo);
+      const unsigned fs = (off & fm) << lb;
+      if (key < vlim) {
+        if (RTN) cnt += (unsigned long long)((atomicAdd(&S.map[off >> sh], 1u << fs) >> fs) & cm);
+        else atomicAdd(&S.map[off >> sh], 1u << fs);  // (result unused: ds_add_u32; a field never carries: c(w) <= d(w) < 2^(2^lb))
+      }
+    };
+    // a row with kRectLdsLong keys or more inside the range (a hub centre's neighbours in the hubs' range): the lanes stride it, no flattening
+    unsigned long long lm = __ballot(llen >= kRectLdsLong);
+    while (lm) {  // wave-uniform
+      const int l = __ffsll((long long)lm) - 1;
+      lm &= lm - 1ull;
+      const int base = readlane(kb, l), len = readlane(llen, l);
+      for (int j0 = 0; j0 < len; j0 += 4 * GM_WAVE) {
+        int key[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) key[q] = col[base + min(j0 + q * GM_WAVE + lane, len - 1)];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (j0 + q * GM_WAVE + lane < len) add(key[q]);
+      }
+    }
+    if (llen >= kRectLdsLong) llen = 0;
+    auto inc = [&](const bool *in, const int *key) {
+#pragma unroll
+      for (int q = 0; q < kRectLdsTiles; ++q)
+        if (in[q]) add(key[q]);
+    };
+#if !defined(GM_RECT_ABL) || GM_RECT_ABL != 1
+    flat_walk<kRectLdsTiles>(L, col, lane, llen, kb, inc);
+#endif
+  };
+  // every wave is done with range k of centre v0: sum C(c, 2) over the map, cleared for the next range.  `nt`: the task to publish (the
+  // last thread holds it), null = keep the current one
+  auto finish = [&](const unsigned any, const int k, const int v0, const int2 *nt, const bool RTN) {
+    if (__ballot(any != 0u) != 0ull && lane == 0) S.any[ph & 1] = 1u;
+    __syncthreads();
+    if (tid == nthreads - 1) {
+      if (nt) S.task = *nt;
+      S.next = 0;
+      S.any[(ph + 1) & 1] = 0u;
+    }
+#if defined(GM_RECT_ABL) && GM_RECT_ABL == 2
+    if (false) {
+#else
+    if (S.any[ph & 1]) {  // (workgroup-uniform)
+#endif
+      const int lo = p.r.rb[k], lb = p.r.lb[k], sh = 5 - lb;
+      const unsigned fm = (1u << sh) - 1u;
+      const int words = (min(p.r.rb[k + 1], v0) - lo + (int)fm) >> sh;
+      const unsigned cm = lb == 5 ? 0xffffffffu : (1u << (1 << lb)) - 1u;
+      uint4 *m4 = reinterpret_cast<uint4 *>(S.map);
+      if (RTN) {
+        for (int i = tid; i < ((words + 3) >> 2); i += nthreads) m4[i] = make_uint4(0u, 0u, 0u, 0u);
+      } else
+      for (int i = tid; i < ((words + 3) >> 2); i += nthreads) {  // (the words behind the last one of the range stay zero)
+        const uint4 v4 = m4[i];
+        if ((v4.x | v4.y | v4.z | v4.w) == 0u) continue;
+        m4[i] = make_uint4(0u, 0u, 0u, 0u);
+        const unsigned vv[4] = {v4.x, v4.y, v4.z, v4.w};
+        if (lb == 5) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) cnt += (unsigned long long)vv[u] * (unsigned long long)(vv[u] - (vv[u] ? 1u : 0u)) / 2ull;
+        } else {  // packed counters are below 2^16: 32-bit arithmetic, the sum of a word's fields too
+          unsigned s32 = 0u;
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            for (unsigned f = 0; f <= fm; ++f) {
+              const unsigned c = (vv[u] >> (f << lb)) & cm;
+              s32 += (c * (c - (c ? 1u : 0u))) >> 1;
+            }
+          cnt += (unsigned long long)s32;
+        }
+      }
+    }
+    __syncthreads();
+    ++ph;
+  };
+  for (;;) {
+    const int2 t = S.task;
+    if (t.x == -3) break;
+    // the NEXT task is dequeued now and published after this one's first walk: a task used to begin with the round trip of the dequeue, its
+    // record, the neighbours of its centre and their bounds, one after the other, with the whole CU waiting (one workgroup fits its LDS)
+    int2 nt = make_int2(-3, -3);
+    if (tid == nthreads - 1) nt = fetch();
+    const int v0 = t.x;
+    const int r0 = rp[v0], nitems = p.idx0[v0];
+    if (t.y >= 0) {  // ---- ONE range of a centre with more neighbours than the workgroup has threads: batches of 64 rows, dealt to the waves
+      const int k = t.y;
+      const bool clip = p.r.rb[k + 1] > v0;  // the range holds v0: rows are cut at v0, not at the next boundary
+      unsigned any = 0u;
+      for (;;) {
+        int bi = 0;
+        if (lane == 0) bi = atomicAdd(&S.next, 1);
+        bi = readfirst(bi);
+        if (bi * GM_WAVE >= nitems) break;
+        const int i = bi * GM_WAVE + lane;
+        int llen = 0, kb = 0;
+        if (i < nitems) {
+          const int x = col[r0 + i];
+          const int *__restrict__ bx = p.bnd + (size_t)x * (size_t)bs + (size_t)k;
+          kb = bx[0];
+          const int ke = bx[1];
+          llen = clip ? lower_bound(col + kb, ke - kb, v0) : ke - kb;
+        }
+        any |= (unsigned)llen;
+        walk(kb, llen, k, 0x7fffffff, false);
+      }
+      finish(any, k, v0, &nt, false);
+    } else {  // ---- EVERY range of a centre with at most one neighbour per thread, from its own range down: a thread keeps its row, the end of
+              // one range is the start of the one above it, and the next start is requested while this range is walked
+      int ktop = 0;
+      while (ktop + 1 < p.r.n && p.r.rb[ktop + 1] < v0) ++ktop;  // the range that holds v0 - 1
+      // (row = lane * waves + wave: a centre with 200 neighbours gives every wave a dozen rows, not four waves 64 each and twelve none --
+      // the keys of a wave's rows are flattened over its lanes anyway)
+      const int row = lane * kRectLdsWaves + wave;
+      const bool valid = row < nitems;
+      const int x = valid ? col[r0 + row] : 0;
+      const int *__restrict__ bx = p.bnd + (size_t)x * (size_t)bs;
+      int kb = valid ? bx[ktop] : 0, ke = valid ? bx[ktop + 1] : 0;  // (the top range is walked to its end: the keys >= v0 are dropped by value)
+      for (int k = ktop; k >= 0; --k) {
+        const int nkb = (valid && k > 0) ? bx[k - 1] : 0;
+        const int llen = ke - kb;
+        walk(kb, llen, k, k == ktop ? v0 : 0x7fffffff, true);
+        finish((unsigned)llen, k, v0, k == ktop ? &nt : nullptr, true);
+        ke = kb;
+        kb = nkb;
+      }
+    }
+  }
+  const unsigned long long s0 = wave_sum_u64(cnt);
+  if (lane == 0 && s0) atomicAdd(&p.counters[0], s0);
+}
+
+hipError_t launch_rect_lds(const RectLdsParams &p, int grid_blocks, hipStream_t stream) {
+  hipLaunchKernelGGL(rect_lds_kernel, dim3((unsigned)grid_blocks), dim3(kRectLdsWaves * GM_WAVE), 0, stream, p);
+  return hipGetLastError();
+}
+hipError_t launch_rect_bounds(const GraphView &g, const RectLdsRanges &r, int *bnd, hipStream_t stream) {
+  hipLaunchKernelGGL(rect_bounds_kernel, dim3((unsigned)((g.nv + 255) / 256)), dim3(256), 0, stream, g, r, bnd);
+  return hipGetLastError();
+}
+hipError_t launch_rect_blockmax(const GraphView &g, int *blockmax, hipStream_t stream) {
+  hipLaunchKernelGGL(rect_blockmax_kernel, dim3((unsigned)((g.nv + 255) / 256)), dim3(256), 0, stream, g, blockmax);
+  return hipGetLastError();
+}
+hipError_t launch_rect_work_cut(const GraphView &g, const int *idx0, const int *bnd0, int bnd_stride, unsigned long long *work, hipStream_t stream) {
+  hipLaunchKernelGGL(rect_work_cut_kernel, dim3((unsigned)((g.nv + 255) / 256)), dim3(256), 0, stream, g, idx0, bnd0, bnd_stride, work);
+  return hipGetLastError();
 }
 
 hipError_t launch_rect_work(const GraphView &g, const int *idx0, unsigned long long *work, hipStream_t stream) {

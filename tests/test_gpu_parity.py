@@ -192,6 +192,49 @@ def test_sgl_nested_patterns_match_reference(gg, pattern):
         assert SglSolver(sym, pattern) == e[pattern]  # (the maps are left zeroed by every launch)
 
 
+@pytest.mark.parametrize("name", GRAPH_NAMES)
+def test_rectangle_counter_maps_in_lds(dev, name, devopt):
+    """rectangle.h:1-11 by wedge accumulation with the heavy centres' counter maps in LDS (gm_mine.hip rect_lds_kernel: (centre, id range)
+    tasks, row bounds per range boundary): GM_RECT_LDS_MIN=1 sends EVERY centre there on the golden graphs; goldens from sgl_omp_base"""
+    e = GOLDEN[name]
+    if "rectangle" not in e:
+        pytest.skip("no golden")
+    g = load_graph(name)
+    devopt("GM_RECT_LDS_MIN", "1")
+    with g.to_device(dev) as sym:
+        total, st = SglSolver(sym, "rectangle", return_stats=True)
+        assert total == e["rectangle"] and st.kernel_ms > 0
+        assert SglSolver(sym, "rectangle") == e["rectangle"]  # (the maps are left zeroed by every task)
+        assert sum(SglSolver(sym, "rectangle", rank=r, world=3) for r in range(3)) == e["rectangle"]
+        assert SglSolver(sym, "rectangle", tune=[0, 0, 0, 0, 0, 0, 0x20000]) == e["rectangle"]  # every end in the global maps (round 5)
+        if "motif4" in e:
+            assert MotifSolver(sym, 4) == e["motif4"]
+    devopt("GM_RECT_LDS_MIN", None)
+    with g.to_device(dev) as sym:  # the default threshold
+        assert SglSolver(sym, "rectangle") == e["rectangle"]
+
+
+def test_rectangle_lds_maps_beside_the_global_ones(dev, devopt):
+    """a graph of more vertices than the LDS ranges cover (GM_RECT_LDS_RANGES=2: the hubs' 32 K ids and one range of packed counters below
+    them): the ends below the cut stay in the global maps, the ranges above it hold every centre's own id somewhere (rows cut at v0) -- the
+    two forms of the kernel and the flattened wedge form agree"""
+    g = rmat_csr_numpy(19, 4, 3)
+    devopt("GM_RECT_LDS_MIN", "1")
+    devopt("GM_RECT_LDS_RANGES", "2")
+    with g.to_device(dev) as sym:
+        a = SglSolver(sym, "rectangle")
+        b = SglSolver(sym, "rectangle", tune=[0, 0, 0, 0, 0, 0, 0x20000])
+        c = SglSolver(sym, "rectangle", tune=[0, 0, 0, 0, 0, 0, 2048])
+        assert a == b == c and a > 0
+        assert sum(SglSolver(sym, "rectangle", rank=r, world=4, policy=1) for r in range(4)) == a
+    devopt("GM_RECT_LDS_RANGES", None)
+    with g.to_device(dev) as sym:  # every id in a range: 32-bit counters at the hubs, packed ones below
+        assert SglSolver(sym, "rectangle") == a
+    devopt("GM_RECT_LDS_MIN", None)
+    with g.to_device(dev) as sym:
+        assert SglSolver(sym, "rectangle") == a
+
+
 def test_house_hub_row_longer_than_lds_bitmap():
     """a hub with 17,000 neighbours (> the 16,384-bit LDS S-bitmap) plus a sparse random graph: the flattened kernel's
     long-row path against the wave-per-edge loop nest (house.h order) on the same graph"""
