@@ -76,7 +76,7 @@ KERNELS = {
     "clique5": ["mine_kernel<4,"],
     "motif3f": ["tch_kernel", "mine_kernel<0,", "core_tc_"],
     "rectangle": ["rect_acc_kernel", "rect_lds_kernel"],
-    "house": ["house_acc_kernel"],
+    "house": ["house_acc_kernel", "house_lds_kernel"],
     "pentagon": ["pent_acc_kernel"],
     # (gm_motif, k = 4: per-edge sums of the symmetric graph + rectangle by wedge accumulation + 4-clique of the oriented copy)
     "motif4": ["mine_kernel<5,", "hrow_kernel<5,", "giant_kernel<5,", "rect_acc_kernel", "rect_lds_kernel", "mine_kernel<3,", "cbuild_kernel", "cgather_kernel", "clique_mma_kernel",

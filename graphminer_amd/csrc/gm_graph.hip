@@ -284,6 +284,9 @@ extern "C" void gm_graph_free(gm_graph *g) {
   if (g->d_house_tasks) dev_free(g->d_house_tasks);
   if (g->d_house_acc) dev_free(g->d_house_acc);
   if (g->d_house_touched) dev_free(g->d_house_touched);
+  if (g->d_house_bnd) dev_free(g->d_house_bnd);
+  if (g->d_house_lds_tasks) dev_free(g->d_house_lds_tasks);
+  if (g->d_house_cut_tasks) dev_free(g->d_house_cut_tasks);
   if (g->d_rect_tasks) dev_free(g->d_rect_tasks);
   if (g->d_rect_bnd) dev_free(g->d_rect_bnd);
   if (g->d_rect_lds_tasks) dev_free(g->d_rect_lds_tasks);

@@ -361,6 +361,13 @@ struct gm_graph {
   unsigned long long *d_house_acc = nullptr;
   size_t house_acc_bytes = 0;
   int *d_house_touched = nullptr;
+  // house with the heavy centres' maps in LDS (round 6, gm_mine.hip house_lds_kernel): as for the rectangle
+  int *d_house_bnd = nullptr;
+  int2 *d_house_lds_tasks = nullptr;
+  int4 *d_house_cut_tasks = nullptr;
+  unsigned long long n_house_lds_tasks = 0, n_house_cut_tasks = 0, n_house_cut = 0;
+  gm::HouseLdsRanges house_ranges;
+  bool house_lds_ready = false;
   int *d_pent_touched = nullptr;         // pentagon by wedge accumulation: touched-vertex lists (same shape as d_rect_acc)
   size_t pent_touched_bytes = 0;
   unsigned long long *d_house_prefix = nullptr;  // house: per-entry task-block prefix

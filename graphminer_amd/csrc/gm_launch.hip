@@ -1163,6 +1163,7 @@ static int run_rect_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h_
   // LDS maps (rect_lds_kernel); tune[6] & 0x20000: every end in the global maps, round 5's form.  Once per graph: the row bounds, the
   // (centre, range) tasks -- every centre's own top range first, the centres heaviest first -- and rect_acc_kernel's list again with
   // those centres (now only their ends below the cut) in front.
+  setup_trace("rect: idx0 / old tasks");
   if (lds_maps && !g->rect_lds_ready) {
     OtherSetupScope scope(g);
     const size_t nv = (size_t)g->nv;
@@ -1207,6 +1208,7 @@ static int run_rect_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h_
       for (int k = 0; k <= n; ++k) rr.rb[k] = top[n - k];
       for (int k = 0; k < n; ++k) rr.lb[k] = lbs[n - 1 - k];
     }
+    setup_trace("rect: ranges");
     g->rect_cut = rr.rb[0];
     HIP_TRY(dev_malloc(&g->d_rect_bnd, sizeof(int) * (size_t)(rr.n + 1) * std::max<size_t>(nv, 1)));
     unsigned long long *d_work = nullptr;
@@ -1221,6 +1223,7 @@ static int run_rect_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h_
     }
     dev_free(d_work);
     if (e != hipSuccess) return hip_fail(e, "rect_bounds_kernel", __FILE__, __LINE__);
+    setup_trace("rect: bounds + work estimates");
     std::vector<int> lds, rest;
     for (size_t v = 0; v < nv; ++v) {
       if (work[v] == 0) continue;
@@ -1276,6 +1279,7 @@ static int run_rect_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h_
     HIP_TRY(dev_malloc(&g->d_rect_lds_tasks, sizeof(int2) * std::max<size_t>(lt.size(), 1)));
     if (!lt.empty()) HIP_TRY(hipMemcpy(g->d_rect_lds_tasks, lt.data(), sizeof(int2) * lt.size(), hipMemcpyHostToDevice));
     g->rect_lds_ready = true;
+    setup_trace("rect: task lists");
   }
   RectAccParams p;
   memset(&p, 0, sizeof p);
@@ -1301,7 +1305,11 @@ static int run_rect_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h_
   size_t free_b = 0, total_b = 0;
   (void)hipMemGetInfo(&free_b, &total_b);
   const unsigned long long budget = std::min<unsigned long long>(32ull << 30, (unsigned long long)free_b / 4 + (unsigned long long)g->rect_acc_bytes);  // (maps + touched lists)
-  long long grid = std::min<long long>((long long)g->cu_count * 8, (long long)std::max<unsigned long long>(1, budget / std::max<unsigned long long>(per_wg, 1)));
+  // (with the heavy centres in LDS what is left for the global maps is light: 1 / 2 / 4 / 8 workgroups per CU measured 11.15 / 10.95 /
+  // 11.1 / 11.0 ms for the rectangle of R-MAT-20 -- two, so that a first call does not allocate 2 x 32 GB of maps and lists)
+  int acc_wgs_per_cu = lds_maps ? 2 : 8;
+  if (const char *e = gm_sweep_env("GM_RECT_ACC_WGS")) acc_wgs_per_cu = std::max(1, std::atoi(e));
+  long long grid = std::min<long long>((long long)g->cu_count * acc_wgs_per_cu, (long long)std::max<unsigned long long>(1, budget / std::max<unsigned long long>(per_wg, 1)));
   grid = std::max<long long>(1, std::min<long long>(grid, count));
   const size_t need = (size_t)per_wg * (size_t)grid;
   if (need > g->rect_acc_bytes) {
@@ -1321,6 +1329,7 @@ static int run_rect_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h_
     g->pent_touched_bytes = need;
   }
   p.touched = g->d_pent_touched;
+  setup_trace("rect: global maps");
   if (pentagon) {
     rc = ensure_edge_tables(g, gv);
     if (rc) return rc;
@@ -1364,7 +1373,9 @@ static int run_rect_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h_
   rc = start_timer(ctx);
   if (rc) return rc;
   if (lcount > 0) HIP_TRY(launch_rect_lds(lp, (int)std::min<long long>((long long)g->cu_count, (long long)lcount), ctx.stream));
+  setup_trace("rect: lds kernel enqueued");
   if (count > 0) HIP_TRY(launch_rect_acc(p, (int)grid, ctx.stream));
+  setup_trace("rect: acc kernel enqueued");
   fill_stats(st, (uint64_t)(g->ne / 2 / ctx.world), (uint64_t)(count + lcount), (int)grid, 256);
   return end_launch(ctx, FIN_COPY, 0, h_out, 1, st);
 }
@@ -1404,7 +1415,84 @@ static int run_house_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h
   gv.col = g->d_col;
   rc = ensure_edge_tables(g, gv);
   if (rc) return rc;
-  if (!g->d_house_tasks) {  // once per graph
+  // the maps of the centres with >= GM_RECT_LDS_MIN 2-paths in LDS, range by range (house_lds_kernel); tune[6] & 0x20000: every end in the
+  // global maps, round 5's form.  Once per graph: ranges of kHouseLdsIds ids from the last id down, the row bounds, the tasks.
+  const bool lds_maps = !(la->tune[6] & 0x20000);
+  if (lds_maps && !g->house_lds_ready) {
+    OtherSetupScope scope(g);
+    const size_t nv = (size_t)g->nv;
+    unsigned long long lds_min = 4096;
+    if (const char *e = gm_opt("GM_RECT_LDS_MIN")) lds_min = std::strtoull(e, nullptr, 10);
+    int max_ranges = kHouseLdsRanges;
+    if (const char *e = gm_opt("GM_RECT_LDS_RANGES")) max_ranges = std::max(1, std::min(kHouseLdsRanges, std::atoi(e)));
+    HouseLdsRanges &rr = g->house_ranges;
+    memset(&rr, 0, sizeof rr);
+    rr.n = (int)std::min<long long>(max_ranges, ((long long)g->nv + kHouseLdsIds - 1) / kHouseLdsIds);
+    for (int k = 0; k <= rr.n; ++k) rr.rb[k] = (int)std::max<long long>(0, (long long)g->nv - (long long)(rr.n - k) * kHouseLdsIds);
+    const int cut = rr.rb[0];
+    HIP_TRY(dev_malloc(&g->d_house_bnd, sizeof(int) * (size_t)(rr.n + 1) * std::max<size_t>(nv, 1)));
+    unsigned long long *d_work = nullptr;
+    HIP_TRY(dev_malloc(&d_work, sizeof(unsigned long long) * 2 * std::max<size_t>(nv, 1)));
+    std::vector<unsigned long long> work(std::max<size_t>(nv, 1)), wcut(std::max<size_t>(nv, 1));
+    std::vector<int> rph(nv + 1, 0);
+    hipError_t e = hipSuccess;
+    if (nv) {
+      e = launch_house_bounds(gv, rr, g->d_house_bnd, 0);
+      if (e == hipSuccess) e = launch_house_work_cut(gv, g->d_house_bnd, rr.n + 1, d_work, 0);
+      if (e == hipSuccess) e = hipMemcpy(work.data(), d_work, sizeof(unsigned long long) * nv, hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpy(wcut.data(), d_work + nv, sizeof(unsigned long long) * nv, hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpy(rph.data(), g->d_rp, sizeof(int) * (nv + 1), hipMemcpyDeviceToHost);
+    }
+    dev_free(d_work);
+    if (e != hipSuccess) return hip_fail(e, "house_bounds_kernel", __FILE__, __LINE__);
+    std::vector<int> lds, rest;
+    for (size_t v = 0; v < nv; ++v) {
+      if (work[v] == 0) continue;
+      if (rr.n > 0 && work[v] >= lds_min) lds.push_back((int)v);
+      else rest.push_back((int)v);
+    }
+    auto by = [](const std::vector<unsigned long long> &w) { return [&w](int a, int b) { return w[(size_t)a] > w[(size_t)b]; }; };
+    std::stable_sort(lds.begin(), lds.end(), by(work));
+    std::stable_sort(rest.begin(), rest.end(), by(work));
+    const int per_wg = kRectLdsWaves * GM_WAVE;
+    auto deg = [&](int v) { return rph[(size_t)v + 1] - rph[(size_t)v]; };
+    std::vector<int2> lt;
+    for (int k = rr.n - 1; k >= 0; --k)  // (the hubs' ranges first: they hold most ends)
+      for (int v : lds)
+        if (deg(v) > per_wg) lt.push_back(make_int2(v, k));
+    for (int v : lds)
+      if (deg(v) <= per_wg) lt.push_back(make_int2(v, -1));
+    const unsigned long long heavy = 1ull << 15;
+    std::vector<int4> tasks;
+    auto emit = [&](const std::vector<int> &vs, const std::vector<unsigned long long> &w) {
+      size_t i = 0;
+      for (; i < vs.size() && w[(size_t)vs[i]] >= heavy; ++i) tasks.push_back(make_int4(vs[i], -2, -2, -2));
+      for (; i < vs.size(); i += 4) {
+        int4 t4 = make_int4(vs[i], -1, -1, -1);
+        if (i + 1 < vs.size()) t4.y = vs[i + 1];
+        if (i + 2 < vs.size()) t4.z = vs[i + 2];
+        if (i + 3 < vs.size()) t4.w = vs[i + 3];
+        tasks.push_back(t4);
+      }
+    };
+    // (every LDS centre stays in house_acc_kernel's list: its phase 0 -- the table terms and the intersections -- is done there, and of its
+    // 2-paths the ends below the cut; ordered by that remainder, the intersections taken as its degree)
+    std::vector<unsigned long long> wrem(std::max<size_t>(nv, 1), 0);
+    for (int v : lds) wrem[(size_t)v] = wcut[(size_t)v] + (unsigned long long)deg(v);
+    std::stable_sort(lds.begin(), lds.end(), by(wrem));
+    emit(lds, wrem);
+    g->n_house_cut = tasks.size();
+    emit(rest, work);
+    g->n_house_cut_tasks = tasks.size();
+    g->n_house_lds_tasks = lt.size();
+    (void)cut;
+    HIP_TRY(dev_malloc(&g->d_house_cut_tasks, sizeof(int4) * std::max<size_t>(tasks.size(), 1)));
+    if (!tasks.empty()) HIP_TRY(hipMemcpy(g->d_house_cut_tasks, tasks.data(), sizeof(int4) * tasks.size(), hipMemcpyHostToDevice));
+    HIP_TRY(dev_malloc(&g->d_house_lds_tasks, sizeof(int2) * std::max<size_t>(lt.size(), 1)));
+    if (!lt.empty()) HIP_TRY(hipMemcpy(g->d_house_lds_tasks, lt.data(), sizeof(int2) * lt.size(), hipMemcpyHostToDevice));
+    g->house_lds_ready = true;
+  }
+  if (!g->d_house_tasks && !lds_maps) {  // once per graph
     OtherSetupScope scope(g);
     const size_t nv = (size_t)g->nv;
     unsigned long long *d_work = nullptr;
@@ -1440,9 +1528,15 @@ static int run_house_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h
   p.g = gv;
   p.t = g->d_house_t;
   p.tlt = g->d_house_tlt;
-  p.tasks = g->d_house_tasks;
+  p.tasks = lds_maps ? g->d_house_cut_tasks : g->d_house_tasks;
+  if (lds_maps) {
+    p.n_cut = g->n_house_cut;
+    p.cut = g->house_ranges.rb[0];
+    p.bnd0 = g->d_house_bnd;
+    p.bnd_stride = g->house_ranges.n + 1;
+  }
   int64_t first = 0, step = 1, count = 0;
-  gm_partition((int64_t)g->n_house_tasks, ctx.rank, ctx.world, la->policy, &first, &step, &count);
+  gm_partition((int64_t)(lds_maps ? g->n_house_cut_tasks : g->n_house_tasks), ctx.rank, ctx.world, la->policy, &first, &step, &count);
   p.first = (unsigned long long)first;
   p.step = (unsigned long long)step;
   p.count = (unsigned long long)count;
@@ -1453,7 +1547,7 @@ static int run_house_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h
   size_t free_b = 0, total_b = 0;
   (void)hipMemGetInfo(&free_b, &total_b);
   const unsigned long long budget = std::min<unsigned long long>(32ull << 30, (unsigned long long)free_b / 3 + (unsigned long long)g->house_acc_bytes);  // (maps + touched lists)
-  long long grid = std::min<long long>((long long)g->cu_count * 8, (long long)std::max<unsigned long long>(1, budget / std::max<unsigned long long>(per_wg, 1)));
+  long long grid = std::min<long long>((long long)g->cu_count * (lds_maps ? 4 : 8), (long long)std::max<unsigned long long>(1, budget / std::max<unsigned long long>(per_wg, 1)));
   grid = std::max<long long>(1, std::min<long long>(grid, count));
   const size_t need = (size_t)per_wg * (size_t)grid;
   if (need > g->house_acc_bytes) {
@@ -1469,10 +1563,28 @@ static int run_house_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h
   }
   p.acc = g->d_house_acc;
   p.touched = g->d_house_touched;
+  HouseLdsParams lp;
+  memset(&lp, 0, sizeof lp);
+  int64_t lcount = 0;
+  if (lds_maps) {
+    lp.g = gv;
+    lp.t = g->d_house_t;
+    lp.tasks = g->d_house_lds_tasks;
+    int64_t lfirst = 0, lstep = 1;
+    gm_partition((int64_t)g->n_house_lds_tasks, ctx.rank, ctx.world, la->policy, &lfirst, &lstep, &lcount);
+    lp.first = (unsigned long long)lfirst;
+    lp.step = (unsigned long long)lstep;
+    lp.count = (unsigned long long)lcount;
+    lp.bnd = g->d_house_bnd;
+    lp.r = g->house_ranges;
+    lp.queue = g->d_counters + 5;  // (its own dequeue word inside the zeroed 64-byte block)
+    lp.counters = g->d_counters;
+  }
   rc = start_timer(ctx);
   if (rc) return rc;
+  if (lcount > 0) HIP_TRY(launch_house_lds(lp, (int)std::min<long long>((long long)g->cu_count, (long long)lcount), ctx.stream));
   if (count > 0) HIP_TRY(launch_house_acc(p, (int)grid, ctx.stream));
-  fill_stats(st, (uint64_t)(g->ne / 2 / ctx.world), (uint64_t)count, (int)grid, 256);
+  fill_stats(st, (uint64_t)(g->ne / 2 / ctx.world), (uint64_t)(count + lcount), (int)grid, 256);
   return end_launch(ctx, FIN_COPY, 0, h_out, 1, st);
 }
 

@@ -292,7 +292,34 @@ struct HouseAccParams {
   unsigned long long acc_stride;
   unsigned long long *queue;
   unsigned long long *counters;
+  // round 6: the first n_cut tasks are centres whose 2-path ends at or above `cut` are summed out of LDS maps (house_lds_kernel): phase 1
+  // walks their ends below cut only (bnd0[x * bnd_stride] = where the entries >= cut of row x begin).  n_cut = 0: every end, as before.
+  unsigned long long n_cut;
+  int cut;
+  const int *bnd0;
+  int bnd_stride;
 };
+// house, the (count | weighted sum) maps of the heavy centres in LDS (gm_mine.hip house_lds_kernel): ranges of kHouseLdsIds ids with one 64-bit
+// word each -- the same packing as the global maps -- from the last id down; tasks as for the rectangle (RectLdsParams)
+constexpr int kHouseLdsIds = 16384;  // 128 KB of 64-bit counters
+constexpr int kHouseLdsRanges = 64;  // at most: the last 1 M ids
+struct HouseLdsRanges {
+  int n;
+  int rb[kHouseLdsRanges + 1];  // range k = ids [rb[k], rb[k + 1]), ascending; rb[0] = cut, rb[n] = nv
+};
+struct HouseLdsParams {
+  GraphView g;
+  const unsigned *t;
+  const int2 *tasks;  // {v0, k}: range k of centre v0; {v0, -1}: every range of a centre with at most kRectLdsWaves * 64 neighbours
+  unsigned long long first, step, count;
+  const int *bnd;  // nv x (n + 1)
+  HouseLdsRanges r;
+  unsigned long long *queue;
+  unsigned long long *counters;
+};
+hipError_t launch_house_lds(const HouseLdsParams &p, int grid_blocks, hipStream_t stream);
+hipError_t launch_house_bounds(const GraphView &g, const HouseLdsRanges &r, int *bnd, hipStream_t stream);
+hipError_t launch_house_work_cut(const GraphView &g, const int *bnd0, int bnd_stride, unsigned long long *work, hipStream_t stream);
 hipError_t launch_edge_tab(const GraphView &g, unsigned *t, unsigned *tlt, unsigned long long *queue, int grid_blocks, hipStream_t stream);
 hipError_t launch_house_acc(const HouseAccParams &p, int grid_blocks, hipStream_t stream);
 hipError_t launch_house_work(const GraphView &g, unsigned long long *work, hipStream_t stream);

@@ -636,15 +636,13 @@ __global__ __launch_bounds__(256) void house_work_kernel(GraphView g, unsigned l
 
 __global__ __launch_bounds__(256) void house_acc_kernel(const HouseAccParams p) {
   __shared__ WaveLds W[kWavesPerBlock];
-  __shared__ int AUX[kWavesPerBlock][GM_WAVE];
   __shared__ int4 s_task;
-  __shared__ int s_next, s_ntouched;
+  __shared__ int s_next, s_ntouched, s_cut;
   __shared__ int s_wtouched[kWavesPerBlock];
   const int *__restrict__ rp = p.g.rp;
   const int *__restrict__ col = p.g.col;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   WaveLds &L = W[wave];
-  int *aux = AUX[wave];
   unsigned long long *acc_own = p.acc + ((size_t)blockIdx.x * kWavesPerBlock + wave) * p.acc_stride;
   unsigned long long *acc_wg = p.acc + ((size_t)blockIdx.x * kWavesPerBlock) * p.acc_stride;
   unsigned long long res = 0;  // A - B - C - D of this lane, modulo 2^64 (per centre the total is a count, >= 0)
@@ -652,6 +650,7 @@ __global__ __launch_bounds__(256) void house_acc_kernel(const HouseAccParams p) 
     if (threadIdx.x == 0) {
       const unsigned long long q = atomicAdd(p.queue, 1ull);
       s_task = (q < p.count) ? p.tasks[p.first + q * p.step] : make_int4(-3, -3, -3, -3);
+      s_cut = (q < p.count && p.first + q * p.step < p.n_cut) ? 1 : 0;
       s_next = 0;
       s_ntouched = 0;
     }
@@ -659,6 +658,7 @@ __global__ __launch_bounds__(256) void house_acc_kernel(const HouseAccParams p) 
     __syncthreads();
     const int4 tk = s_task;
     if (tk.x == -3) break;
+    const bool use_cut = s_cut != 0;  // (the ends at or above p.cut of this task's centres belong to house_lds_kernel)
     const bool heavy = tk.y == -2;
     const int v0 = heavy ? tk.x : (wave == 0 ? tk.x : wave == 1 ? tk.y : wave == 2 ? tk.z : tk.w);
     unsigned long long *acc = heavy ? acc_wg : acc_own;
@@ -694,24 +694,19 @@ __global__ __launch_bounds__(256) void house_acc_kernel(const HouseAccParams p) 
             if (valid) res -= (unsigned long long)p.tlt[r0 + i] * (unsigned long long)(te - 1u + (te == 0u ? 1u : 0u));  // C (t = 0 => tlt = 0)
             if (sb) res -= (unsigned long long)te * (unsigned long long)(d1 - 1);                                         // B
             if (sb) res += (unsigned long long)te;                                                                        // the "- 1" of D
-            int llen = 0, kb = 0, sbase = 0, sl = 0;
+            // D = sum over the common neighbours w of v0, v1 of t(v1, w).  Round 6: no intersection -- summed over the graph a triangle a < b < c
+            // is met as (v0, v1; w) = (b, a; c), (c, a; b), (c, b; a) and adds t(a, c) + 2 t(a, b), so an edge p < q collects its own t once per
+            // common neighbour between p and q and twice per common neighbour above q, and both numbers are in the tables: below q =
+            // tlt(q -> p), below p = tlt(p -> q).  (Until round 6 this was one bisected intersection per edge: 0.3 s of the house on R-MAT-20.)
             if (sb && te > 0u) {
-              if (d1 <= d0) { llen = d1; kb = r1; sbase = r0; sl = d0 | (1 << 30); }  // keys from N(v1): flag 1, kidx = position in N(v1)
-              else { llen = d0; kb = r0; sbase = r1; sl = d1; }                       // keys from N(v0): pos = position in N(v1)
+              const unsigned tl = p.tlt[r0 + i];                                        // common neighbours below v0
+              const unsigned tl_rev = p.tlt[r1 + lower_bound(col + r1, d1, v0)];     // ... below v1 (the entry v1 -> v0)
+              res -= (unsigned long long)te * (2ull * (unsigned long long)(te - tl) + (unsigned long long)(tl - tl_rev));  // D
             }
-            aux[lane] = r1;
-            wave_sync();
-            unsigned long long dsum = 0;
-            auto act = [&](bool f, int owner, int kidx, int pos, int flag, int) {
-              if (f) dsum += (unsigned long long)p.t[aux[owner] + (flag ? kidx : pos)];  // t(v1, w)
-            };
-            flat_pass<SEARCH_HBM>(L, nullptr, col, nullptr, lane, llen, kb, sbase, sl, act);
-            res -= dsum;  // D
-            wave_sync();
           } else {
             L.cnt[lane] = (valid && v1 < v0) ? te : 0u;  // delta of this entry's 2-paths
             wave_sync();
-            const int llen = valid ? d1 : 0;
+            const int llen = !valid ? 0 : use_cut ? p.bnd0[(size_t)v1 * (size_t)p.bnd_stride] - r1 : d1;
             if (phase == 1) {
               auto inc = [&](const bool *in, const int *key, const int *own) {
 #pragma unroll
@@ -753,6 +748,298 @@ __global__ __launch_bounds__(256) void house_acc_kernel(const HouseAccParams p) 
   }
   const unsigned long long s0 = wave_sum_u64(res);
   if (lane == 0 && s0) atomicAdd(&p.counters[0], s0);
+}
+
+// ---- house: the (count | weighted sum) maps of the heavy centres in LDS (round 6) --------------------------------------------------------
+// house_acc_kernel's phase 1 is the rectangle's walk with a 64-bit word per end w -- n(w) 2-paths in the low 24 bits, S(w) = the sum of their
+// rows' weights above -- and A(v0) = sum_w n(w) S(w) (the running form there: a 2-path of weight d adds d * n_old + S_old + d).  It walks
+// EVERY 2-path of every centre (sum_x d(x)^2: 70 G on R-MAT-20 ef 16, 3.6 s at the rate of the L2 atomics), so the scheme of rect_lds_kernel
+// pays even more: ranges of 16 K ids (one 64-bit LDS word each) from the last id down, (centre, range) tasks for the centres with more
+// neighbours than a workgroup has threads, one task for all ranges of the others; what lies below the ranges stays with house_acc_kernel.
+struct alignas(16) HouseLds {
+  unsigned long long map[kHouseLdsIds];
+  WaveLdsFlat w[kRectLdsWaves];
+  unsigned delta[kRectLdsWaves][GM_WAVE];  // weight of the row a lane holds
+  int2 task;
+  int next;
+  unsigned any[2];
+};
+
+__global__ __launch_bounds__(256) void house_bounds_kernel(GraphView g, HouseLdsRanges rr, int *__restrict__ bnd) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= g.nv) return;
+  const int r = g.rp[x], d = g.rp[x + 1] - r;
+  int at = 0;
+  for (int k = 0; k <= rr.n; ++k) {
+    at += (rr.rb[k] >= g.nv) ? d - at : lower_bound(g.col + r + at, d - at, rr.rb[k]);
+    bnd[(size_t)x * (size_t)(rr.n + 1) + (size_t)k] = r + at;
+  }
+}
+
+// per centre: [0, nv) every 2-path (house_work_kernel), [nv, 2 nv) those whose end lies below the cut
+__global__ __launch_bounds__(256) void house_work_cut_kernel(GraphView g, const int *__restrict__ bnd0, int bnd_stride, unsigned long long *__restrict__ work) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= g.nv) return;
+  unsigned long long w = 0, wc = 0;
+  for (int i = g.rp[v]; i < g.rp[v + 1]; ++i) {
+    const int x = g.col[i];
+    w += (unsigned long long)(g.rp[x + 1] - g.rp[x]) + 1ull;
+    wc += (unsigned long long)(bnd0[(size_t)x * (size_t)bnd_stride] - g.rp[x]);
+  }
+  work[v] = w;
+  work[(size_t)g.nv + (size_t)v] = wc;
+}
+
+// flat_walk with the owner of every key handed to f(in[], key[], own[] /* lane + 1 */)
+template <int TG, class LT, class F>
+__device__ __forceinline__ void flat_walk_own(LT &L, const int *__restrict__ col, const int lane, const int llen, const int kb, F f) {
+  static_assert(kMarkWindow % (GM_WAVE * TG) == 0, "a window of owner marks is a whole number of tile groups");
+  const int incl = wave_incl_scan_add(llen);
+  const int total = readlane(incl, GM_WAVE - 1);
+  if (total == 0) return;  // wave-uniform
+  const int off = incl - llen;
+  L.desc[lane] = make_int4(kb, off, 0, 0);
+  unsigned *m32 = reinterpret_cast<unsigned *>(L.marks);
+  int carry = 0;
+  int key[TG], kown[TG];
+  bool in[TG], have = false;
+  for (int wb = 0; wb < total; wb += kMarkWindow) {
+    const int wn = min(kMarkWindow, total - wb);
+    const int nwords = ((wn + GM_WAVE * TG - 1) / (GM_WAVE * TG)) * (GM_WAVE * TG / 4);
+    for (int i = lane; i < nwords; i += GM_WAVE) m32[i] = 0u;
+    wave_sync();
+    if (llen > 0 && off >= wb && off < wb + kMarkWindow) L.marks[off - wb] = (unsigned char)(lane + 1);
+    wave_sync();
+    for (int t = 0; t < wn; t += GM_WAVE * TG) {
+      int own[TG], nkey[TG];
+      bool nin[TG];
+#pragma unroll
+      for (int q = 0; q < TG; ++q) own[q] = (int)L.marks[t + q * GM_WAVE + lane];
+#pragma unroll
+      for (int q = 0; q < TG; ++q) {
+        own[q] = max(wave_incl_scan_max(own[q]), carry);
+        carry = readlane(own[q], GM_WAVE - 1);
+      }
+#pragma unroll
+      for (int q = 0; q < TG; ++q) {
+        const int pp = wb + t + q * GM_WAVE + lane;
+        nin[q] = pp < total;
+        const int4 d = L.desc[nin[q] ? own[q] - 1 : 0];
+        nkey[q] = col[nin[q] ? d.x + (pp - d.y) : 0];
+      }
+      if (have) f(in, key, kown);
+#pragma unroll
+      for (int q = 0; q < TG; ++q) {
+        key[q] = nkey[q];
+        in[q] = nin[q];
+        kown[q] = nin[q] ? own[q] : 1;
+      }
+      have = true;
+    }
+    wave_sync();
+  }
+  if (have) f(in, key, kown);
+}
+
+__global__ __launch_bounds__(kRectLdsWaves *GM_WAVE) void house_lds_kernel(const HouseLdsParams p) {
+  __shared__ HouseLds S;
+  const int *__restrict__ rp = p.g.rp;
+  const int *__restrict__ col = p.g.col;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tid = threadIdx.x;
+  constexpr int nthreads = kRectLdsWaves * GM_WAVE;
+  WaveLdsFlat &L = S.w[wave];
+  unsigned *dl = S.delta[wave];
+  for (int i = tid; i < kHouseLdsIds; i += nthreads) S.map[i] = 0ull;
+  unsigned long long res = 0;  // modulo 2^64, like house_acc_kernel's
+  const int bs = p.r.n + 1;
+  auto fetch = [&]() {
+    const unsigned long long q = atomicAdd(p.queue, 1ull);
+    return (q < p.count) ? p.tasks[p.first + q * p.step] : make_int2(-3, -3);
+  };
+  if (tid == 0) {
+    S.task = fetch();
+    S.next = 0;
+    S.any[0] = S.any[1] = 0u;
+  }
+  __syncthreads();
+  int ph = 0;
+  // the keys (kb, llen) of this wave's 64 rows -- weights in dl[] -- into the map of range k; the centre itself is no end
+  auto walk = [&](const int kb, int llen, const int k, const int v0, const bool RTN) {
+    const int lo = p.r.rb[k];
+    auto add = [&](const int key, const unsigned long long d) {
+      if (key == v0) return;
+      const unsigned long long inc = (d << 24) | 1ull;
+      if (RTN) {
+        const unsigned long long old = atomicAdd(&S.map[key - lo], inc);
+        res += d * (old & 0xffffffull) + (old >> 24) + d;
+      } else {
+        atomicAdd(&S.map[key - lo], inc);
+      }
+    };
+    unsigned long long lm = __ballot(llen >= kRectLdsLong);
+    while (lm) {  // wave-uniform: a long row, the lanes stride it
+      const int l = __ffsll((long long)lm) - 1;
+      lm &= lm - 1ull;
+      const int base = readlane(kb, l), len = readlane(llen, l);
+      const unsigned long long d = (unsigned long long)dl[l];
+      for (int j0 = 0; j0 < len; j0 += 4 * GM_WAVE) {
+        int key[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) key[q] = col[base + min(j0 + q * GM_WAVE + lane, len - 1)];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (j0 + q * GM_WAVE + lane < len) add(key[q], d);
+      }
+    }
+    if (llen >= kRectLdsLong) llen = 0;
+    auto inc = [&](const bool *in, const int *key, const int *own) {
+#pragma unroll
+      for (int q = 0; q < kRectLdsTiles; ++q)
+        if (in[q]) add(key[q], (unsigned long long)dl[own[q] - 1]);
+    };
+    flat_walk_own<kRectLdsTiles>(L, col, lane, llen, kb, inc);
+  };
+  auto finish = [&](const unsigned any, const int k, const int2 *nt, const bool RTN) {
+    if (__ballot(any != 0u) != 0ull && lane == 0) S.any[ph & 1] = 1u;
+    __syncthreads();
+    if (tid == nthreads - 1) {
+      if (nt) S.task = *nt;
+      S.next = 0;
+      S.any[(ph + 1) & 1] = 0u;
+    }
+    if (S.any[ph & 1]) {  // (workgroup-uniform)
+      const int ids = p.r.rb[k + 1] - p.r.rb[k];
+      if (RTN) {
+        for (int i = tid; i < ids; i += nthreads) S.map[i] = 0ull;
+      } else {
+        for (int i = tid; i < ids; i += nthreads) {
+          const unsigned long long v = S.map[i];
+          if (v) {
+            S.map[i] = 0ull;
+            res += (v & 0xffffffull) * (v >> 24);  // n(w) S(w)
+          }
+        }
+      }
+    }
+    __syncthreads();
+    ++ph;
+  };
+  for (;;) {
+    const int2 t = S.task;
+    if (t.x == -3) break;
+    int2 nt = make_int2(-3, -3);
+    if (tid == nthreads - 1) nt = fetch();
+    const int v0 = t.x;
+    const int r0 = rp[v0], nitems = rp[v0 + 1] - r0;
+    if (t.y >= 0) {  // one range of a centre with many neighbours
+      const int k = t.y;
+      unsigned any = 0u;
+      for (;;) {
+        int bi = 0;
+        if (lane == 0) bi = atomicAdd(&S.next, 1);
+        bi = readfirst(bi);
+        if (bi * GM_WAVE >= nitems) break;
+        const int i = bi * GM_WAVE + lane;
+        int llen = 0, kb = 0;
+        unsigned d = 0u;
+        if (i < nitems) {
+          const int x = col[r0 + i];
+          const int *__restrict__ bx = p.bnd + (size_t)x * (size_t)bs + (size_t)k;
+          kb = bx[0];
+          llen = bx[1] - kb;
+          d = x < v0 ? p.t[r0 + i] : 0u;
+        }
+        wave_sync();  // (the previous batch's walk is done with dl[])
+        dl[lane] = d;
+        wave_sync();
+        any |= (unsigned)llen;
+        walk(kb, llen, k, v0, false);
+      }
+      finish(any, k, &nt, false);
+    } else {  // every range of a centre with at most one neighbour per thread, from the last range down.  Such a centre has at most 1024
+              // neighbours, so n(w) <= 1024 and S(w) <= 1024 * 1023 fit 11 + 21 bits: 32-bit counters, TWO ranges of ids per walk
+      const int row = lane * kRectLdsWaves + wave;
+      const bool valid = row < nitems;
+      const int x = valid ? col[r0 + row] : 0;
+      const int *__restrict__ bx = p.bnd + (size_t)x * (size_t)bs;
+      dl[lane] = (valid && x < v0) ? p.t[r0 + row] : 0u;
+      wave_sync();
+      unsigned *map32 = reinterpret_cast<unsigned *>(S.map);
+      int k1 = p.r.n;  // ranges [k0, k1) per walk
+      int ke = valid ? bx[k1] : 0;
+      int kb = valid ? bx[max(k1 - 2, 0)] : 0;
+      bool first = true;
+      while (k1 > 0) {
+        const int k0 = max(k1 - 2, 0);
+        const int nkb = (valid && k0 > 0) ? bx[max(k0 - 2, 0)] : 0;
+        int llen = ke - kb;
+        const int lo = p.r.rb[k0];
+        auto add = [&](const int key, const unsigned d) {
+          if (key == v0) return;
+          const unsigned old = atomicAdd(&map32[key - lo], (d << 11) | 1u);
+          res += (unsigned long long)(d * (old & 0x7ffu) + (old >> 11) + d);
+        };
+        const unsigned any = (unsigned)llen;
+        unsigned long long lm = __ballot(llen >= kRectLdsLong);
+        while (lm) {  // wave-uniform: a long row, the lanes stride it
+          const int l = __ffsll((long long)lm) - 1;
+          lm &= lm - 1ull;
+          const int base = readlane(kb, l), len = readlane(llen, l);
+          const unsigned d = dl[l];
+          for (int j0 = 0; j0 < len; j0 += 4 * GM_WAVE) {
+            int key[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) key[q] = col[base + min(j0 + q * GM_WAVE + lane, len - 1)];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (j0 + q * GM_WAVE + lane < len) add(key[q], d);
+          }
+        }
+        if (llen >= kRectLdsLong) llen = 0;
+        auto inc = [&](const bool *in, const int *key, const int *own) {
+#pragma unroll
+          for (int q = 0; q < kRectLdsTiles; ++q)
+            if (in[q]) add(key[q], dl[own[q] - 1]);
+        };
+        flat_walk_own<kRectLdsTiles>(L, col, lane, llen, kb, inc);
+        // (finish, for two ranges of 32-bit counters)
+        if (__ballot(any != 0u) != 0ull && lane == 0) S.any[ph & 1] = 1u;
+        __syncthreads();
+        if (tid == nthreads - 1) {
+          if (first) S.task = nt;
+          S.next = 0;
+          S.any[(ph + 1) & 1] = 0u;
+        }
+        if (S.any[ph & 1]) {
+          uint4 *m4 = reinterpret_cast<uint4 *>(S.map);
+          const int ids = p.r.rb[k1] - lo;
+          for (int i = tid; i < ((ids + 3) >> 2); i += nthreads) m4[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        __syncthreads();
+        ++ph;
+        first = false;
+        ke = kb;
+        kb = nkb;
+        k1 = k0;
+      }
+      wave_sync();
+    }
+  }
+  const unsigned long long s0 = wave_sum_u64(res);
+  if (lane == 0 && s0) atomicAdd(&p.counters[0], s0);
+}
+
+hipError_t launch_house_lds(const HouseLdsParams &p, int grid_blocks, hipStream_t stream) {
+  hipLaunchKernelGGL(house_lds_kernel, dim3((unsigned)grid_blocks), dim3(kRectLdsWaves * GM_WAVE), 0, stream, p);
+  return hipGetLastError();
+}
+hipError_t launch_house_bounds(const GraphView &g, const HouseLdsRanges &r, int *bnd, hipStream_t stream) {
+  hipLaunchKernelGGL(house_bounds_kernel, dim3((unsigned)((g.nv + 255) / 256)), dim3(256), 0, stream, g, r, bnd);
+  return hipGetLastError();
+}
+hipError_t launch_house_work_cut(const GraphView &g, const int *bnd0, int bnd_stride, unsigned long long *work, hipStream_t stream) {
+  hipLaunchKernelGGL(house_work_cut_kernel, dim3((unsigned)((g.nv + 255) / 256)), dim3(256), 0, stream, g, bnd0, bnd_stride, work);
+  return hipGetLastError();
 }
 
 hipError_t launch_edge_tab(const GraphView &g, unsigned *t, unsigned *tlt, unsigned long long *queue, int grid_blocks, hipStream_t stream) {

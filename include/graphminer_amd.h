@@ -120,6 +120,7 @@ typedef struct gm_launch {
                          0x10000000 diamond / 3-motif by one intersection of the two symmetric lists per edge (the reference's loop
                          nests; default: from the triangles of the oriented copy), 0x4000000 TC by the chunked mining kernel (default: the shorter list
                          of every edge against a hashed set, gm_tch.hip),
+                         0x20000 rectangle / house with every counter map in global memory,
                          0x800000 hashed sets on their global-memory fallback lookup, 0x40000 4-clique in the mining kernel alone,
                          0x40000000 edge supports (diamond) with one atomic per streamed edge instead of the match masks (gm_sup.hip);
                          0x80000 / 0x100000 / 0x400000 / 0x1000000 / 0x2000000: variants of the per-edge class kernels (gm_launch.hip).
@@ -191,6 +192,10 @@ int gm_tc_core_info(const gm_graph *dag, int64_t info[4]);
  * "pentagon" (pentagon.h:2-17), and -- one rank (several: gm_sgl4_partial), from the per-edge sums of the formula 4-motif, no enumeration of their own --
  * "tailedtriangle" (tailedtriangle.h:1-12), "4path" (4path.h:1-14), "3star" (3star.h:1-13).  Others (the 5- and 6-vertex patterns of
  * src/sgl/omp_base.cc:33-49 beyond house / pentagon) -> GM_ERR_UNSUPPORTED, *total = 0.
+ * With world > 1 a rank's house / pentagon value is a partial MODULO 2^64 (a centre's positive and negative terms may be tasks of different
+ * ranks): add the ranks' values as uint64 (an all-reduce does), do not compare a single rank's value with anything.
+ * rectangle / house keep the counter maps of their heavy centres in LDS (gm_mine.hip rect_lds_kernel / house_lds_kernel; tune[6] & 0x20000:
+ * in global memory, round 5's form).
  * diamond = sum over the edges of C(|N(v0) ^ N(v1)|, 2). One GPU: |N(v0) ^ N(v1)| of every edge -- its triangles -- from ONE pass over
  * the triangles of the oriented copy (edge supports, gm_sup.hip; the copy is built and cached on first use; also for a graph of
  * >= 2^31 entries); world > 1, a DAG row beyond 2048 entries, or tune[6] & 0x10000000: one intersection of the two symmetric lists per

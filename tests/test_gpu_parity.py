@@ -235,6 +235,30 @@ def test_rectangle_lds_maps_beside_the_global_ones(dev, devopt):
         assert SglSolver(sym, "rectangle") == a
 
 
+@pytest.mark.parametrize("name", GRAPH_NAMES)
+def test_house_maps_in_lds(dev, name, devopt):
+    """house.h:1-16 by wedge accumulation with the heavy centres' (count | weighted sum) maps in LDS (gm_mine.hip house_lds_kernel);
+    GM_RECT_LDS_MIN=1 sends every centre there; goldens from sgl_omp_base"""
+    e = GOLDEN[name]
+    if "house" not in e:
+        pytest.skip("no golden")
+    g = load_graph(name)
+    devopt("GM_RECT_LDS_MIN", "1")
+    with g.to_device(dev) as sym:
+        total, st = SglSolver(sym, "house", return_stats=True)
+        assert total == e["house"] and st.kernel_ms > 0
+        assert SglSolver(sym, "house") == e["house"]  # (the maps are left zeroed)
+        assert sum(SglSolver(sym, "house", rank=r, world=3) for r in range(3)) % 2**64 == e["house"]
+        assert SglSolver(sym, "house", tune=[0, 0, 0, 0, 0, 0, 0x20000]) == e["house"]  # every end in the global maps (round 5)
+    devopt("GM_RECT_LDS_RANGES", "1")  # one range of 16 K ids in LDS, the ends below it in the global maps
+    with g.to_device(dev) as sym:
+        assert SglSolver(sym, "house") == e["house"]
+    devopt("GM_RECT_LDS_RANGES", None)
+    devopt("GM_RECT_LDS_MIN", None)
+    with g.to_device(dev) as sym:  # the default threshold
+        assert SglSolver(sym, "house") == e["house"]
+
+
 def test_house_hub_row_longer_than_lds_bitmap():
     """a hub with 17,000 neighbours (> the 16,384-bit LDS S-bitmap) plus a sparse random graph: the flattened kernel's
     long-row path against the wave-per-edge loop nest (house.h order) on the same graph"""
@@ -252,7 +276,8 @@ def test_house_hub_row_longer_than_lds_bitmap():
         assert flat == SglSolver(sym, "house", tune=[0, 0, 0, 0, 0, 0, 1024])
         assert flat == SglSolver(sym, "house", tune=[0, 0, 0, 0, 0, 0, 0x800])
         assert flat == SglSolver(sym, "house", tune=[0, 0, 0, 0, 0, 0, 0x8000])
-        assert flat == sum(SglSolver(sym, "house", rank=r, world=3) for r in range(3))
+        # (a rank's partial is exact modulo 2^64: a centre's positive term -- its maps, in LDS -- and its negative ones may be tasks of different ranks)
+        assert flat == sum(SglSolver(sym, "house", rank=r, world=3) for r in range(3)) % 2**64
 
 
 def test_clique4_matches_reference(gg):
