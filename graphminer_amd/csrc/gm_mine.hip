@@ -756,10 +756,13 @@ __global__ __launch_bounds__(256) void house_acc_kernel(const HouseAccParams p) 
 // EVERY 2-path of every centre (sum_x d(x)^2: 70 G on R-MAT-20 ef 16, 3.6 s at the rate of the L2 atomics), so the scheme of rect_lds_kernel
 // pays even more: ranges of 16 K ids (one 64-bit LDS word each) from the last id down, (centre, range) tasks for the centres with more
 // neighbours than a workgroup has threads, one task for all ranges of the others; what lies below the ranges stays with house_acc_kernel.
+constexpr int kHouseLongQ = 192, kHouseLongWg = 1024;  // queue entries; keys from which a row is shared out
 struct alignas(16) HouseLds {
   unsigned long long map[kHouseLdsIds];
   WaveLdsFlat w[kRectLdsWaves];
   unsigned delta[kRectLdsWaves][GM_WAVE];  // weight of the row a lane holds
+  int4 lq[kHouseLongQ];                    // one-task centres: the rows with many keys in the current ranges {start, keys, weight}, walked by ALL waves
+  int nlong;
   int2 task;
   int next;
   unsigned any[2];
@@ -859,6 +862,7 @@ __global__ __launch_bounds__(kRectLdsWaves *GM_WAVE) void house_lds_kernel(const
   if (tid == 0) {
     S.task = fetch();
     S.next = 0;
+    S.nlong = 0;
     S.any[0] = S.any[1] = 0u;
   }
   __syncthreads();
@@ -980,6 +984,37 @@ __global__ __launch_bounds__(kRectLdsWaves *GM_WAVE) void house_lds_kernel(const
           res += (unsigned long long)(d * (old & 0x7ffu) + (old >> 11) + d);
         };
         const unsigned any = (unsigned)llen;
+        // A centre beside a hub has the hub's row among its few: 10^5 keys that ONE wave would walk while fifteen wait.  Rows with
+        // kHouseLongWg keys or more inside these ranges go to a queue and every wave takes every 16th slice of 256 keys of each.
+        {
+          const unsigned long long wm = __ballot(llen >= kHouseLongWg);
+          if (wm != 0ull) {  // wave-uniform
+            int slot0 = 0;
+            if (lane == 0) slot0 = atomicAdd(&S.nlong, (int)__popcll(wm));
+            slot0 = readfirst(slot0);
+            if (llen >= kHouseLongWg) {
+              const int slot = slot0 + rank_below(wm);
+              if (slot < kHouseLongQ) {
+                S.lq[slot] = make_int4(kb, llen, (int)dl[lane], 0);
+                llen = 0;
+              }
+            }
+          }
+        }
+        __syncthreads();
+        const int nl = min(S.nlong, kHouseLongQ);
+        for (int e = 0; e < nl; ++e) {
+          const int4 le = S.lq[e];
+          const unsigned d = (unsigned)le.z;
+          for (int j0 = wave * 4 * GM_WAVE; j0 < le.y; j0 += kRectLdsWaves * 4 * GM_WAVE) {
+            int key[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) key[q] = col[le.x + min(j0 + q * GM_WAVE + lane, le.y - 1)];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (j0 + q * GM_WAVE + lane < le.y) add(key[q], d);
+          }
+        }
         unsigned long long lm = __ballot(llen >= kRectLdsLong);
         while (lm) {  // wave-uniform: a long row, the lanes stride it
           const int l = __ffsll((long long)lm) - 1;
@@ -1008,6 +1043,7 @@ __global__ __launch_bounds__(kRectLdsWaves *GM_WAVE) void house_lds_kernel(const
         if (tid == nthreads - 1) {
           if (first) S.task = nt;
           S.next = 0;
+          S.nlong = 0;  // (every wave has read the queue: the next walk appends after the barrier below)
           S.any[(ph + 1) & 1] = 0u;
         }
         if (S.any[ph & 1]) {
