@@ -297,8 +297,8 @@ def test_clique_k_matches_reference(gg, k):
     if f"clique{k}" not in e:
         pytest.skip("no golden for this k")
     assert CliqueSolver(dag, k) == e[f"clique{k}"]
-    if e[f"clique{k}"] > 10**11:
-        return  # (R-MAT-14, k = 8: 133 G cliques, 25 s per run -- the variants below are covered by the smaller graphs)
+    if e[f"clique{k}"] > 10**11 or k >= 11:
+        return  # (R-MAT-14, k = 8: 133 G cliques, 25 s per run; k = 11, 12 on R-MAT-10: 9 s per run -- the variants below are covered by the smaller graphs / k)
     assert CliqueSolver(dag, k, tune=[64, 1, 0, 0, 0, 1]) == e[f"clique{k}"]
     assert sum(CliqueSolver(dag, k, rank=r, world=3) for r in range(3)) == e[f"clique{k}"]
 
@@ -497,7 +497,7 @@ def _hub_over_a_random_graph(W, p, seed, planted=0):
     return csr_from_pairs(int(W + 1 + W * (W - 1)), s, d)
 
 
-@pytest.mark.parametrize("W,p,planted", [(600, 0.35, 0), (2100, 0.12, 12), (4200, 0.04, 12)])
+@pytest.mark.parametrize("W,p,planted", [(600, 0.3, 0), (2100, 0.12, 12), (4200, 0.04, 12)])
 def test_cliques_of_nine_to_twelve_on_wide_rows(dev, W, p, planted):
     """k = 9..12 (the reference counts them with its generic clique_omp_recursive / edge_warp_iterative.cuh:2-75; gpu_base.cu:59-71 stops at 8)
     where the deeper levels are CALLED, not inlined (gm_chunk.h kCliqueInlineM): a DAG row of 600 entries (sub-matrices in LDS / the second
@@ -511,7 +511,7 @@ def test_cliques_of_nine_to_twelve_on_wide_rows(dev, W, p, planted):
         want = O.clique(odag, k)
         got[k] = want
         assert CliqueSolver(dg, k) == want, k
-    assert got[9] > 0 and (planted == 0 or got[12] > 0)
+    assert got[9] > 0 and got[10] > 0 and (planted == 0 or got[12] > 0)
     assert sum(CliqueSolver(dg, 9, rank=r, world=3) for r in range(3)) == got[9]
     assert CliqueSolver(dg, 9, tune=[0, 0, 0, 0, 0, 0, 0x20]) == got[9]  # the per-sub-tree walk (A/B)
 
