@@ -1372,7 +1372,9 @@ static int run_rect_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h_
   }
   rc = start_timer(ctx);
   if (rc) return rc;
-  if (lcount > 0) HIP_TRY(launch_rect_lds(lp, (int)std::min<long long>((long long)g->cu_count, (long long)lcount), ctx.stream));
+  // (workgroups per CU: what its LDS -- the map + 1.5 KB of scratch per wave -- lets run together)
+  const int lds_wgs = std::max(1, (int)((160 * 1024) / (kRectLdsWords * 4 + kRectLdsWaves * 1536 + 1024)));
+  if (lcount > 0) HIP_TRY(launch_rect_lds(lp, (int)std::min<long long>((long long)g->cu_count * lds_wgs, (long long)lcount), ctx.stream));
   setup_trace("rect: lds kernel enqueued");
   if (count > 0) HIP_TRY(launch_rect_acc(p, (int)grid, ctx.stream));
   setup_trace("rect: acc kernel enqueued");
@@ -1427,9 +1429,12 @@ static int run_house_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h
     if (const char *e = gm_opt("GM_RECT_LDS_RANGES")) max_ranges = std::max(1, std::min(kHouseLdsRanges, std::atoi(e)));
     HouseLdsRanges &rr = g->house_ranges;
     memset(&rr, 0, sizeof rr);
-    rr.n = (int)std::min<long long>(max_ranges, ((long long)g->nv + kHouseLdsIds - 1) / kHouseLdsIds);
-    for (int k = 0; k <= rr.n; ++k) rr.rb[k] = (int)std::max<long long>(0, (long long)g->nv - (long long)(rr.n - k) * kHouseLdsIds);
-    const int cut = rr.rb[0];
+    // (the row-bound table has n + 1 entries per vertex: at most 4 GB of it)
+    const long long by_memory = std::max<long long>(1, (4ll << 30) / (4ll * (long long)std::max<size_t>(nv, 1)) - 1);
+    rr.n = (int)std::min<long long>(std::min<long long>(max_ranges, by_memory), ((long long)g->nv + kHouseLdsIds - 1) / kHouseLdsIds);
+    rr.nv = g->nv;
+    rr.cut = (int)std::max<long long>(0, (long long)g->nv - (long long)rr.n * kHouseLdsIds);
+    const int cut = rr.cut;
     HIP_TRY(dev_malloc(&g->d_house_bnd, sizeof(int) * (size_t)(rr.n + 1) * std::max<size_t>(nv, 1)));
     unsigned long long *d_work = nullptr;
     HIP_TRY(dev_malloc(&d_work, sizeof(unsigned long long) * 2 * std::max<size_t>(nv, 1)));
@@ -1531,7 +1536,7 @@ static int run_house_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h
   p.tasks = lds_maps ? g->d_house_cut_tasks : g->d_house_tasks;
   if (lds_maps) {
     p.n_cut = g->n_house_cut;
-    p.cut = g->house_ranges.rb[0];
+    p.cut = g->house_ranges.cut;
     p.bnd0 = g->d_house_bnd;
     p.bnd_stride = g->house_ranges.n + 1;
   }

@@ -255,8 +255,11 @@ hipError_t launch_rect_acc(const RectAccParams &p, int grid_blocks, hipStream_t 
 // degree are cut into ranges, a task is (centre v0, range k): one workgroup walks the 2-paths v0 - x - w with w in the range and counts them
 // in a dense map in LDS.  A counter never exceeds d(w), and the degrees fall quickly below the hubs: a range whose largest degree is below
 // 2^8 / 2^16 packs four / two counters into a word (128 K / 64 K ids per range instead of 32 K), so that sixteen ranges reach far down.
-constexpr int kRectLdsWords = 32768;  // 128 KB of counters
-constexpr int kRectLdsRanges = 16;    // at most
+#ifndef GM_RECT_LDS_WORDS
+#define GM_RECT_LDS_WORDS 32768
+#endif
+constexpr int kRectLdsWords = GM_RECT_LDS_WORDS;  // 128 KB of counters
+constexpr int kRectLdsRanges = 32;    // at most
 constexpr int kRectLdsWaves = 16;
 struct RectLdsRanges {
   int n;                          // ranges in use
@@ -302,10 +305,13 @@ struct HouseAccParams {
 // house, the (count | weighted sum) maps of the heavy centres in LDS (gm_mine.hip house_lds_kernel): ranges of kHouseLdsIds ids with one 64-bit
 // word each -- the same packing as the global maps -- from the last id down; tasks as for the rectangle (RectLdsParams)
 constexpr int kHouseLdsIds = 16384;  // 128 KB of 64-bit counters
-constexpr int kHouseLdsRanges = 64;  // at most: the last 1 M ids
+constexpr int kHouseLdsRanges = 256;  // at most: the last 4 M ids (and a row-bound table of at most 4 GB: gm_launch.hip)
 struct HouseLdsRanges {
-  int n;
-  int rb[kHouseLdsRanges + 1];  // range k = ids [rb[k], rb[k + 1]), ascending; rb[0] = cut, rb[n] = nv
+  int n, cut, nv;  // range k = ids [rb(k), rb(k + 1)), ascending; rb(0) = cut, rb(n) = nv
+  __host__ __device__ int rb(int k) const {
+    const long long b = (long long)cut + (long long)k * kHouseLdsIds;
+    return k >= n ? nv : (int)(b < (long long)nv ? b : (long long)nv);
+  }
 };
 struct HouseLdsParams {
   GraphView g;

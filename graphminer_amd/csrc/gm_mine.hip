@@ -774,7 +774,7 @@ __global__ __launch_bounds__(256) void house_bounds_kernel(GraphView g, HouseLds
   const int r = g.rp[x], d = g.rp[x + 1] - r;
   int at = 0;
   for (int k = 0; k <= rr.n; ++k) {
-    at += (rr.rb[k] >= g.nv) ? d - at : lower_bound(g.col + r + at, d - at, rr.rb[k]);
+    at += (rr.rb(k) >= g.nv) ? d - at : lower_bound(g.col + r + at, d - at, rr.rb(k));
     bnd[(size_t)x * (size_t)(rr.n + 1) + (size_t)k] = r + at;
   }
 }
@@ -869,7 +869,7 @@ __global__ __launch_bounds__(kRectLdsWaves *GM_WAVE) void house_lds_kernel(const
   int ph = 0;
   // the keys (kb, llen) of this wave's 64 rows -- weights in dl[] -- into the map of range k; the centre itself is no end
   auto walk = [&](const int kb, int llen, const int k, const int v0, const bool RTN) {
-    const int lo = p.r.rb[k];
+    const int lo = p.r.rb(k);
     auto add = [&](const int key, const unsigned long long d) {
       if (key == v0) return;
       const unsigned long long inc = (d << 24) | 1ull;
@@ -912,7 +912,7 @@ __global__ __launch_bounds__(kRectLdsWaves *GM_WAVE) void house_lds_kernel(const
       S.any[(ph + 1) & 1] = 0u;
     }
     if (S.any[ph & 1]) {  // (workgroup-uniform)
-      const int ids = p.r.rb[k + 1] - p.r.rb[k];
+      const int ids = p.r.rb(k + 1) - p.r.rb(k);
       if (RTN) {
         for (int i = tid; i < ids; i += nthreads) S.map[i] = 0ull;
       } else {
@@ -977,7 +977,7 @@ __global__ __launch_bounds__(kRectLdsWaves *GM_WAVE) void house_lds_kernel(const
         const int k0 = max(k1 - 2, 0);
         const int nkb = (valid && k0 > 0) ? bx[max(k0 - 2, 0)] : 0;
         int llen = ke - kb;
-        const int lo = p.r.rb[k0];
+        const int lo = p.r.rb(k0);
         auto add = [&](const int key, const unsigned d) {
           if (key == v0) return;
           const unsigned old = atomicAdd(&map32[key - lo], (d << 11) | 1u);
@@ -1048,7 +1048,7 @@ __global__ __launch_bounds__(kRectLdsWaves *GM_WAVE) void house_lds_kernel(const
         }
         if (S.any[ph & 1]) {
           uint4 *m4 = reinterpret_cast<uint4 *>(S.map);
-          const int ids = p.r.rb[k1] - lo;
+          const int ids = p.r.rb(k1) - lo;
           for (int i = tid; i < ((ids + 3) >> 2); i += nthreads) m4[i] = make_uint4(0u, 0u, 0u, 0u);
         }
         __syncthreads();
