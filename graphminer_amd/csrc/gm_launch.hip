@@ -1434,7 +1434,6 @@ static int run_house_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h
     rr.n = (int)std::min<long long>(std::min<long long>(max_ranges, by_memory), ((long long)g->nv + kHouseLdsIds - 1) / kHouseLdsIds);
     rr.nv = g->nv;
     rr.cut = (int)std::max<long long>(0, (long long)g->nv - (long long)rr.n * kHouseLdsIds);
-    const int cut = rr.cut;
     HIP_TRY(dev_malloc(&g->d_house_bnd, sizeof(int) * (size_t)(rr.n + 1) * std::max<size_t>(nv, 1)));
     unsigned long long *d_work = nullptr;
     HIP_TRY(dev_malloc(&d_work, sizeof(unsigned long long) * 2 * std::max<size_t>(nv, 1)));
@@ -1490,7 +1489,6 @@ static int run_house_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h
     emit(rest, work);
     g->n_house_cut_tasks = tasks.size();
     g->n_house_lds_tasks = lt.size();
-    (void)cut;
     HIP_TRY(dev_malloc(&g->d_house_cut_tasks, sizeof(int4) * std::max<size_t>(tasks.size(), 1)));
     if (!tasks.empty()) HIP_TRY(hipMemcpy(g->d_house_cut_tasks, tasks.data(), sizeof(int4) * tasks.size(), hipMemcpyHostToDevice));
     HIP_TRY(dev_malloc(&g->d_house_lds_tasks, sizeof(int2) * std::max<size_t>(lt.size(), 1)));
