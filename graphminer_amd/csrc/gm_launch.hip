@@ -1449,10 +1449,22 @@ static int run_house_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h
     }
     dev_free(d_work);
     if (e != hipSuccess) return hip_fail(e, "house_bounds_kernel", __FILE__, __LINE__);
+    // A centre with at most one neighbour per thread is ONE task that walks every range -- two per walk -- at ~2.5 us of a CU per walk
+    // whatever it finds there, against ~12 ns per 2-path in the global maps (both measured on R-MAT-20): it pays from ~200 2-paths per
+    // walk on.  (On a LiveJournal-sized power-law graph -- 4.8 M vertices, 111 walks -- the fixed 4096 made the house 1.27 x SLOWER than
+    // the global maps.)  A developer option that sets the threshold is taken as given.
+    const bool lds_min_given = gm_opt("GM_RECT_LDS_MIN") != nullptr;
+    unsigned long long per_walk = 200;
+    if (const char *e = gm_sweep_env("GM_HOUSE_WALK_MIN")) per_walk = std::strtoull(e, nullptr, 10);
+    const unsigned long long one_task_min = std::max<unsigned long long>(lds_min, per_walk * (unsigned long long)((rr.n + 1) / 2));
+    auto lds_min_of = [&](int v) {
+      const int d = rph[(size_t)v + 1] - rph[(size_t)v];
+      return (lds_min_given || d > kRectLdsWaves * GM_WAVE) ? lds_min : one_task_min;
+    };
     std::vector<int> lds, rest;
     for (size_t v = 0; v < nv; ++v) {
       if (work[v] == 0) continue;
-      if (rr.n > 0 && work[v] >= lds_min) lds.push_back((int)v);
+      if (rr.n > 0 && work[v] >= lds_min_of((int)v)) lds.push_back((int)v);
       else rest.push_back((int)v);
     }
     auto by = [](const std::vector<unsigned long long> &w) { return [&w](int a, int b) { return w[(size_t)a] > w[(size_t)b]; }; };
