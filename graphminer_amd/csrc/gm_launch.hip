@@ -1456,10 +1456,11 @@ static int run_house_acc(const gm_graph *cg, const gm_launch *la_in, uint64_t *h
     const bool lds_min_given = gm_opt("GM_RECT_LDS_MIN") != nullptr;
     unsigned long long per_walk = 200;
     if (const char *e = gm_sweep_env("GM_HOUSE_WALK_MIN")) per_walk = std::strtoull(e, nullptr, 10);
-    const unsigned long long one_task_min = std::max<unsigned long long>(lds_min, per_walk * (unsigned long long)((rr.n + 1) / 2));
     auto lds_min_of = [&](int v) {
       const int d = rph[(size_t)v + 1] - rph[(size_t)v];
-      return (lds_min_given || d > kRectLdsWaves * GM_WAVE) ? lds_min : one_task_min;
+      if (lds_min_given || d > kRectLdsWaves * GM_WAVE) return lds_min;
+      const int per = d <= 32 ? 4 : 2;  // ranges per walk (house_lds_kernel: 16-bit counters up to 32 neighbours)
+      return std::max<unsigned long long>(lds_min, per_walk * (unsigned long long)((rr.n + per - 1) / per));
     };
     std::vector<int> lds, rest;
     for (size_t v = 0; v < nv; ++v) {

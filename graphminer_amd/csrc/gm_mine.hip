@@ -968,20 +968,28 @@ __global__ __launch_bounds__(kRectLdsWaves *GM_WAVE) void house_lds_kernel(const
       const int *__restrict__ bx = p.bnd + (size_t)x * (size_t)bs;
       dl[lane] = (valid && x < v0) ? p.t[r0 + row] : 0u;
       wave_sync();
+      // (at most 32 neighbours: n <= 32 and S <= 32 * 31 fit 6 + 10 bits -- 16-bit counters, two to a word, FOUR ranges per walk: most
+      // one-task centres are low-degree vertices beside a hub, and what a walk costs them is its ~2.5 us, not its keys)
       unsigned *map32 = reinterpret_cast<unsigned *>(S.map);
+      const bool fw16 = nitems <= 32;
+      const int rw = fw16 ? 4 : 2;                // ranges per walk
+      const unsigned nb = fw16 ? 6u : 11u;        // bits of n in a counter
+      const unsigned nm = (1u << nb) - 1u, fm = fw16 ? 0xffffu : 0xffffffffu;
       int k1 = p.r.n;  // ranges [k0, k1) per walk
       int ke = valid ? bx[k1] : 0;
-      int kb = valid ? bx[max(k1 - 2, 0)] : 0;
+      int kb = valid ? bx[max(k1 - rw, 0)] : 0;
       bool first = true;
       while (k1 > 0) {
-        const int k0 = max(k1 - 2, 0);
-        const int nkb = (valid && k0 > 0) ? bx[max(k0 - 2, 0)] : 0;
+        const int k0 = max(k1 - rw, 0);
+        const int nkb = (valid && k0 > 0) ? bx[max(k0 - rw, 0)] : 0;
         int llen = ke - kb;
         const int lo = p.r.rb(k0);
         auto add = [&](const int key, const unsigned d) {
           if (key == v0) return;
-          const unsigned old = atomicAdd(&map32[key - lo], (d << 11) | 1u);
-          res += (unsigned long long)(d * (old & 0x7ffu) + (old >> 11) + d);
+          const unsigned off = (unsigned)(key - lo);
+          const unsigned sh = fw16 ? (off & 1u) << 4 : 0u;
+          const unsigned f = (atomicAdd(&map32[fw16 ? off >> 1 : off], ((d << nb) | 1u) << sh) >> sh) & fm;
+          res += (unsigned long long)(d * (f & nm) + (f >> nb) + d);
         };
         const unsigned any = (unsigned)llen;
         // A centre beside a hub has the hub's row among its few: 10^5 keys that ONE wave would walk while fifteen wait.  Rows with
@@ -1049,7 +1057,8 @@ __global__ __launch_bounds__(kRectLdsWaves *GM_WAVE) void house_lds_kernel(const
         if (S.any[ph & 1]) {
           uint4 *m4 = reinterpret_cast<uint4 *>(S.map);
           const int ids = p.r.rb(k1) - lo;
-          for (int i = tid; i < ((ids + 3) >> 2); i += nthreads) m4[i] = make_uint4(0u, 0u, 0u, 0u);
+          const int words = fw16 ? (ids + 1) >> 1 : ids;
+          for (int i = tid; i < ((words + 3) >> 2); i += nthreads) m4[i] = make_uint4(0u, 0u, 0u, 0u);
         }
         __syncthreads();
         ++ph;
