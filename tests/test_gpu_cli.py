@@ -109,6 +109,8 @@ def test_rccl_path_on_one_gpu():
     out = run("motif_multigpu", prefix, 3, 1, dev=dev)
     assert out[-2:] == [f"pattern 0: {e['motif3'][0]}", f"pattern 1: {e['motif3'][1]}"]
     assert run("sgl_multigpu", prefix, "diamond", 1, dev=dev)[-1] == f"total_num = {e['diamond']}"
+    for pat in ("rectangle", "house", "pentagon"):  # (two kernels each add into the device counter the all-reduce takes)
+        assert run("sgl_multigpu", prefix, pat, 1, dev=dev)[-1] == f"total_num = {e[pat]}"
     for pat in ("tailedtriangle", "4path", "3star"):  # four raw per-edge sums all-reduced, then the closed form (gm_sgl4_partial / _finish)
         assert run("sgl_multigpu", prefix, pat, 1, dev=dev)[-1] == f"total_num = {e[pat]}"
     # the environment is NOT a switch: the same variable there changes nothing (one device -> the one-GPU path, no broadcast line)
