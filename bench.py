@@ -103,6 +103,7 @@ def parse():
     ap.add_argument("--data-dir", default=os.environ.get("GM_DATA_DIR", ""), help="directory with livej/graph.* and com-orkut/graph.* (real datasets)")
     ap.add_argument("--uniform", default="", help="NV,M: uniform random graph instead of R-MAT (LiveJournal-size flat-degree stand-in)")
     ap.add_argument("--powerlaw", default="", help="NV,M,MAXDEG: Chung-Lu power-law graph (LiveJournal: 4847571,43000000,20000)")
+    ap.add_argument("--community", default="", help="NV,M: planted communities + power-law background with LiveJournal's triangle density (4847571,43000000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-standins", action="store_true", help="skip the extra LiveJournal-size stand-in graphs of the default run")
     ap.add_argument("--no-ref-baseline", action="store_true", help="skip the timed runs of the oracle/_ref reference binaries")
@@ -165,7 +166,7 @@ def build_graph(a, local_rank, scale, ef, graph_prefix=""):
     import torch
 
     from graphminer_amd import DeviceGraph, Graph
-    from graphminer_amd.rmat import powerlaw_csr_device, rmat_csr_device, uniform_csr_device
+    from graphminer_amd.rmat import community_csr_device, powerlaw_csr_device, rmat_csr_device, uniform_csr_device
 
     t = time.perf_counter()
     if graph_prefix:
@@ -175,6 +176,10 @@ def build_graph(a, local_rank, scale, ef, graph_prefix=""):
         ci = torch.from_numpy(h.col_idx).to(dev)
         sym = DeviceGraph.from_device_ptrs(h.V(), h.E(), rp.data_ptr(), ci.data_ptr(), local_rank, keepalive=(rp, ci))
         name = f"file:{graph_prefix}"
+    elif getattr(a, "community", ""):
+        cnv, cm = (int(x) for x in a.community.split(","))
+        sym, rp, ci = community_csr_device(cnv, cm, 64, 0.6, 20000, a.seed, local_rank)
+        name = f"community_nv{cnv}_m{cm}_c64_p0.6_seed{a.seed}"
     elif a.powerlaw:
         pnv, pm, pmax = (int(x) for x in a.powerlaw.split(","))
         sym, rp, ci = powerlaw_csr_device(pnv, pm, pmax, 2.5, a.seed, local_rank)
@@ -768,7 +773,7 @@ def measure_traffic(a, workloads, share=(0, 1), device=0, issue=True):
                     cmd += [flag, str(val)]
             if share[1] > 1:
                 cmd += ["--share-rank", str(share[0]), "--share-world", str(share[1]), "--policy", str(a.policy)]
-            for flag, val in (("--graph", a.graph), ("--data-dir", a.data_dir), ("--uniform", a.uniform), ("--powerlaw", a.powerlaw), ("--tune", a.tune)):
+            for flag, val in (("--graph", a.graph), ("--data-dir", a.data_dir), ("--uniform", a.uniform), ("--powerlaw", a.powerlaw), ("--community", getattr(a, "community", "")), ("--tune", a.tune)):
                 if val:
                     cmd += [flag, val]
             env = dict(os.environ, TMPDIR="/tmp")
@@ -1306,7 +1311,7 @@ def main():
     self_launch(a)
     r = Runner(a)
     world, rank = r.world, r.rank
-    single = bool(a.workload or a.graph or a.uniform or a.powerlaw)
+    single = bool(a.workload or a.graph or a.uniform or a.powerlaw or a.community)
     if single:
         todo = [(0, a.workload or "tc", WORKLOADS[a.workload or "tc"][3], None)]
     else:
@@ -1449,6 +1454,7 @@ def main():
             "dtype": "int32 (vertex ids, offsets; uint64 counts)",
             "data": "file" if head["graph"].startswith("file:") else ("synthetic uniform random graph (torch RNG)" if a.uniform else
                                                                      "synthetic Chung-Lu power-law graph (torch RNG)" if a.powerlaw else
+                                                                     "synthetic planted communities + power-law background (torch RNG)" if a.community else
                                                                      "synthetic R-MAT (0.57,0.19,0.19,0.05), SplitMix64 counter stream"),
             "config": {"workload": f"{head['workload']}: {WORKLOADS[head['workload']][3]}", "graph": head["graph"], "nv": head["nv"],
                        "ne_sym": head["ne_sym"], "tasks": head["tasks"], "max_degree": head["max_degree"],

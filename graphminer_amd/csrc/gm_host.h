@@ -334,6 +334,7 @@ struct gm_graph {
   int sorted_state = 0;              // 0 unknown, 1 every row strictly ascending, 2 not (graph_rows_sorted): the solvers refuse such a handle
   int topo_state = 0;                // 0 unknown, 1 every edge goes to a larger id, 2 not (graph_is_topological)
   unsigned long long giant_edges = ~0ull;  // sum of the rows beyond kStageCapBig entries (~0: not computed yet)
+  double tri_per_edge = -1.0;        // triangles per entry of this DAG, estimated from a sample (-1: not yet; the edge supports' stream switch)
   double mean_sq_deg = -1.0;         // sum_v d(v)^2 / ne: the mean length of the row an entry sits in (-1: not computed yet; topo_view)
   bool topo_relabel_failed = false;  // the (degree, id) numbering is not topological for this DAG: it runs as given
   const gm_graph *ring_alias = nullptr;
@@ -556,6 +557,7 @@ int sup_mask_min_tail(const gm_graph *g);  // (gm_tables.hip) kSupMaskMinTail or
 int ensure_sup_corner(gm_graph *g);  // (gm_tables.hip) d_csym / d_cfirst of a handle whose task lists leave a hub corner out
 int ensure_sup_masks(gm_graph *g);  // (gm_tables.hip) d_emoff / d_tmoff / d_smask of a topologically numbered DAG with task lists; GM_OK also when not applicable
 int ensure_mean_sq_deg(gm_graph *g);
+int ensure_tri_per_edge(gm_graph *g);  // (gm_launch.hip) |N+(u) ^ N+(v)| averaged over a sample of the DAG's entries
 unsigned long long task_part_cap(gm_graph *g, int world);
 int clique_wide_min_words();
 int get_clique_plan(gm_graph *g, int rank, int world, int policy, int target, unsigned long long part_cap, CliquePlan **out);

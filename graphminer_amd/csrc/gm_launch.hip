@@ -233,11 +233,15 @@ int run_pattern(Pattern pat, const gm_graph *cg, const gm_launch *la, int k, uin
     // The edge supports take the stream only where matches are RARE: a match of a streamed key costs them two gathers (the entries beside
     // the stream) and two global atomics, where a task of the lists costs one atomic per match and one per task.  Flat / power-law LJ-size
     // 1.06 / 1.55 -> 0.70 / 1.32 ms, but R-MAT-22 8.50 -> 10.95 and R-MAT-24 102 -> 115: the switch is the one that decides the renumbering
-    // (sum d+^2 / |E+| below kTopoMinMeanRow: short lists, few triangles per edge).  GM_SUP_STREAM=0 / 1 forces it.
+    // (sum d+^2 / |E+| below kSupStreamMaxMeanRow: short lists) -- and few triangles per edge, which short lists do not imply: on a graph
+    // with LiveJournal's size AND triangle density (planted communities, 6.7 triangles per DAG entry; round 6) the stream's two atomics per
+    // match made the diamond 13.4 ms where the task lists take 2.8.  The density is estimated from a sample of the entries
+    // (ensure_tri_per_edge): the stream below 0.5 triangles per entry (power law: 0.1, flat: 0).  GM_SUP_STREAM=0 / 1 forces it.
     bool sup_stream = false;
     if (support && !(la->tune[6] & 0x20000000)) {
       if (const char *e = gm_opt("GM_SUP_STREAM")) sup_stream = atoi(e) != 0;
-      else sup_stream = ensure_mean_sq_deg(g) == GM_OK && g->mean_sq_deg < (double)kTopoMinMeanRow;
+      else sup_stream = ensure_mean_sq_deg(g) == GM_OK && g->mean_sq_deg < (double)kSupStreamMaxMeanRow && ensure_tri_per_edge(g) == GM_OK &&
+                        g->tri_per_edge < 0.5;
     }
     if ((sup_stream || !support) && !(la->tune[6] & 0x20000000)) {
       const int rc_k = ensure_keystream(g, support, &use_kst, !support && !tct_long);  // (the triangle count: the hub corner may stay out, gm_ctc.hip)
@@ -964,6 +968,7 @@ extern "C" int gm_corner_times(const gm_graph *g, int n, double *ms_out, int *n_
 // R-MAT-22 6.45 / 6.26 / 5.28, LiveJournal-size flat degrees (5.5 keys per task) 0.88 / 0.85 / 0.86, power law with LiveJournal's
 // maximum degree (5.5 keys per task) 1.14 / 1.88 / 1.59. The switch is the mean length of the row a DAG entry sits in, sum d+^2 / |E+|
 // (R-MAT-22: 157, R-MAT-22 ef 28: 322, R-MAT-24: 367; the power-law graph: 11.6, flat: 10.5): >= kTopoMinMeanRow -> renumbered. GM_TOPO_MIN_ROW overrides (0: always).
+// Round 6: kTopoMinMeanRow = 0 -- with the kernels of rounds 4 - 5 the renumbered copy wins on those two graphs as well (gm_mine.h).
 __global__ __launch_bounds__(256) void sum_sq_deg_kernel(int nv, const int *__restrict__ rp, unsigned long long *__restrict__ out) {
   const long long stride = (long long)gridDim.x * blockDim.x;
   unsigned long long s = 0;
@@ -988,6 +993,53 @@ int ensure_mean_sq_deg(gm_graph *self) {
     dev_free(d_s);
     if (e != hipSuccess) return hip_fail(e, "sum_sq_deg_kernel", __FILE__, __LINE__);
     self->mean_sq_deg = self->ne > 0 ? (double)s2 / (double)self->ne : 0.0;
+  }
+  return GM_OK;
+}
+
+// Triangles per DAG entry, ESTIMATED: every stride-th entry (u -> v), |N+(u) ^ N+(v)| by a merge of the two sorted rows (at most 512 steps:
+// the estimate is asked for on short-row graphs), averaged.  The edge supports choose between the key stream and the task lists by it.
+__global__ __launch_bounds__(256) void tri_sample_kernel(int nv, long long ne, const int *__restrict__ rp, const int *__restrict__ col, long long stride,
+                                                         int nsamples, unsigned long long *__restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long c = 0;
+  if (i < nsamples) {
+    const long long e = (long long)i * stride;
+    if (e < ne) {
+      int lo = 0, hi = nv - 1;  // the row of entry e
+      while (lo < hi) {
+        const int mid = (int)(((long long)lo + hi + 1) >> 1);
+        if ((long long)rp[mid] <= e) lo = mid; else hi = mid - 1;
+      }
+      const int v = col[e];
+      int a = rp[lo], ae = rp[lo + 1], b = rp[v], be = rp[v + 1];
+      for (int step = 0; step < 512 && a < ae && b < be; ++step) {
+        const int x = col[a], y = col[b];
+        c += x == y ? 1ull : 0ull;
+        a += x <= y ? 1 : 0;
+        b += y <= x ? 1 : 0;
+      }
+    }
+  }
+  c = gm::wave_sum_u64(c);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
+int ensure_tri_per_edge(gm_graph *self) {
+  if (self->tri_per_edge < 0) {
+    HIP_TRY(hipSetDevice(self->device));
+    const int nsamples = (int)std::min<long long>(1 << 16, std::max<long long>(self->ne, 1));
+    const long long stride = std::max<long long>(1, self->ne / nsamples);
+    unsigned long long *d_s = nullptr, s = 0;
+    HIP_TRY(dev_malloc(&d_s, 8));
+    hipError_t e = hipMemset(d_s, 0, 8);
+    if (e == hipSuccess && self->ne > 0)
+      hipLaunchKernelGGL(tri_sample_kernel, dim3((unsigned)((nsamples + 255) / 256)), dim3(256), 0, 0, self->nv, (long long)self->ne, self->d_rp, self->d_col, stride,
+                         nsamples, d_s);
+    if (e == hipSuccess) e = hipMemcpy(&s, d_s, 8, hipMemcpyDeviceToHost);
+    dev_free(d_s);
+    if (e != hipSuccess) return hip_fail(e, "tri_sample_kernel", __FILE__, __LINE__);
+    self->tri_per_edge = (double)s / (double)nsamples;
   }
   return GM_OK;
 }

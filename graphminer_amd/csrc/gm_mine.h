@@ -543,7 +543,10 @@ constexpr int kWideMinWordsDefault = kBitWords;  // k-clique: a matrix of more w
 // k-clique: vertices of the dense hub core (gm_cgather.hip), GM_CORE_H overrides.  32 K = 128 MB of bitmap; 4-clique on R-MAT-22 ef 28 at
 // 4 K .. 128 K: 32.6 / 30.6 / 29.0 / 27.8 (32 K) / 29.1 / 30.7 ms -- the gathers are bound by the lines they pull through L2
 constexpr int kCoreHDefault = 32768;
-constexpr int kTopoMinMeanRow = 64;     // DAG patterns run on the topologically renumbered copy from this mean row length (sum d+^2 / |E+|) on
+constexpr int kSupStreamMaxMeanRow = 64;  // the edge supports read the key stream below this mean row length (and below 0.5 triangles per entry: gm_launch.hip)
+constexpr int kTopoMinMeanRow = 0;        // DAG patterns run on the topologically renumbered copy from this mean row length (sum d+^2 / |E+|) on: always
+                                          // (64 until round 6; with the hub corner and the key stream of rounds 4 - 5 the renumbered copy wins on the short-row
+                                          // graphs too: TC flat 0.396 -> 0.364 ms, power law 0.674 -> 0.490, communities 0.682 -> 0.618)
 
 // host-side launchers (gm_mine.hip)
 hipError_t launch_mine(Pattern pat, const MineParams &p, int grid_blocks, hipStream_t stream);

@@ -192,3 +192,48 @@ def powerlaw_csr_device(nv: int, m: int, max_deg: int = 20000, gamma: float = 2.
         torch.cuda.synchronize(dev)
     g = DeviceGraph.from_device_ptrs(nv, int(col.numel()), row_ptr.data_ptr(), col.data_ptr(), device, keepalive=(row_ptr, col))
     return g, row_ptr, col
+
+
+def community_csr_device(nv: int, m: int, csize: int = 64, p_in: float = 0.6, max_deg: int = 20000, seed: int = 1, device: int = 0):
+    """A stand-in with LiveJournal's TRIANGLE DENSITY: the flat and the power-law stand-ins have LiveJournal's |V| and |E|
+    but 4 M / 30 M triangles where LiveJournal has 286 M (src/triangle/README.md:58: 6.7 per oriented edge).  Planted communities -- cliques
+    of `csize` vertices thinned to density `p_in` (64, 0.6: ~1210 edges and ~9000 triangles each) -- take as many vertices as 90 % of the m
+    edges need; the other 10 % are a Chung-Lu power-law background over ALL vertices (hubs up to max_deg scaled by that share), ids randomly
+    permuted.  nv = 4,847,571, m = 43,000,000 gives ~2.0 M community vertices and ~290 M triangles.  Measurements only (torch RNG)."""
+    import torch
+
+    dev = torch.device("cuda", device)
+    per_c = csize * (csize - 1) // 2
+    m_in = int(m * 0.9)
+    ncomm = min(int(m_in / (per_c * p_in)), nv // csize)
+    with torch.cuda.device(dev):
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(seed)
+        iu = torch.triu_indices(csize, csize, 1, device=dev)
+        base = (torch.arange(ncomm, device=dev, dtype=torch.int64) * csize).repeat_interleave(per_c)
+        a_ = iu[0].repeat(ncomm) + base
+        b_ = iu[1].repeat(ncomm) + base
+        keep = torch.rand(a_.numel(), device=dev, generator=gen) < p_in
+        a_, b_ = a_[keep], b_[keep]
+        del base, keep
+        perm = torch.randperm(nv, device=dev, generator=gen)
+        s1, d1 = perm[a_], perm[b_]
+        del a_, b_
+    # background: the power-law generator's pairs over all vertices
+    m_bg = max(m - int(s1.numel()), 0)
+    gbg, rp_bg, ci_bg = powerlaw_csr_device(nv, max(m_bg, 1), max(int(max_deg), 2), 2.5, seed + 1, device)
+    with torch.cuda.device(dev):
+        src_bg = torch.repeat_interleave(torch.arange(nv, device=dev, dtype=torch.int64), (rp_bg[1:] - rp_bg[:-1]))
+        k_bg = (src_bg << 32) | ci_bg.to(torch.int64)
+        gbg.free()
+        del rp_bg, ci_bg, src_bg
+        keys = torch.unique(torch.cat([(s1 << 32) | d1, (d1 << 32) | s1, k_bg]))
+        del s1, d1, k_bg
+        src = keys >> 32
+        col = (keys & 0xFFFFFFFF).to(torch.int32).contiguous()
+        row_ptr = torch.zeros(nv + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(torch.bincount(src, minlength=nv), 0, out=row_ptr[1:])
+        del keys, src
+        torch.cuda.synchronize(dev)
+    g = DeviceGraph.from_device_ptrs(nv, int(col.numel()), row_ptr.data_ptr(), col.data_ptr(), device, keepalive=(row_ptr, col))
+    return g, row_ptr, col
