@@ -1293,8 +1293,9 @@ def compact_line(out, detail_path):
         line["configs"] = cfgs
         line["all_counts_match_cpu"] = out.get("all_counts_match_cpu")
     if out.get("livejournal_standins"):  # LiveJournal-sized graphs of the two other shapes (ids 2a / 2b: TC, 3a / 3b: diamond)
-        tags = {("tc", "uniform"): "2a", ("tc", "powerlaw"): "2b", ("diamond", "uniform"): "3a", ("diamond", "powerlaw"): "3b"}
-        line["standins"] = [{"id": tags.get((x["workload"], x["graph"].split("_")[0]), "?"), "kernel_ms": x["kernel_ms_avg"], "value": x["value"], "count": x["count"],
+        tags = {("tc", "uniform"): "2a", ("tc", "powerlaw"): "2b", ("tc", "community"): "2c", ("diamond", "uniform"): "3a", ("diamond", "powerlaw"): "3b",
+                ("diamond", "community"): "3c"}  # (2c / 3c: LiveJournal's triangle density; Medges/s = 43 / kernel_ms: left out for the 4 KB)
+        line["standins"] = [{"id": tags.get((x["workload"], x["graph"].split("_")[0]), "?"), "kernel_ms": x["kernel_ms_avg"], "count": x["count"],
                              **({"traffic_frac": x["traffic_frac"]} if x.get("traffic_frac") is not None else {"own_frac": x.get("frac")})} for x in out["livejournal_standins"]]
     if isinstance(out.get("tc_rmat24"), dict) and "roofline" in out["tc_rmat24"]:
         t = out["tc_rmat24"]
@@ -1468,9 +1469,10 @@ def main():
             # 115 k) two more graphs with LiveJournal's |V| and |E| bracket its shape: a flat-degree one (mean oriented list 9,
             # the short-list regime) and a Chung-Lu power-law one with LiveJournal's published maximum degree (20 k).
             extra = []
-            for kind, spec in (("uniform", "4847571,43000000"), ("powerlaw", "4847571,43000000,20000")):
+            # ... and a third with LiveJournal's TRIANGLE DENSITY (planted communities: 288 M triangles; the other two have 0 / 4 M)
+            for kind, spec in (("uniform", "4847571,43000000"), ("powerlaw", "4847571,43000000,20000"), ("community", "4847571,43000000")):
                 a2 = argparse.Namespace(**vars(a))
-                a2.uniform, a2.powerlaw = (spec, "") if kind == "uniform" else ("", spec)
+                a2.uniform, a2.powerlaw, a2.community = (spec if kind == "uniform" else ""), (spec if kind == "powerlaw" else ""), (spec if kind == "community" else "")
                 bg2 = build_graph(a2, r.local_rank, 0, 0)
                 tr2 = {}
                 if a.traffic == "auto":  # counter traffic of the LiveJournal-sized graphs too (two more passes per graph, the triangle count only)
