@@ -118,7 +118,7 @@ constexpr int kLongList = GM_LONG_LIST;
 constexpr unsigned kNoMask = 0xffffffffu;
 // edge supports: an in-edge task whose tail has at least this many keys reports its streamed edges as a match mask (gm_sup.hip)
 #ifndef GM_SUP_MASK_MIN_TAIL
-#define GM_SUP_MASK_MIN_TAIL 8
+#define GM_SUP_MASK_MIN_TAIL 2
 #endif
 constexpr int kSupMaskMinTail = GM_SUP_MASK_MIN_TAIL;
 constexpr int kSupMaskSpare = 3;  // spare 64-bit words behind the mask of a long list (tile groups of at most kSupMaskSpare + 1 tiles)
